@@ -1,0 +1,414 @@
+/*
+ * llkv_hip.h — C ABI of the MI355X-native execution path for LLKV.
+ *
+ * This is the drop-in boundary: the entry points a Rust `extern "C"` shim inside
+ * `llkv-executor` would bind in place of the CPU scan → filter → (join) → aggregate
+ * pipeline.  Plain pointers and sizes only; no C++/torch types cross it.
+ *
+ * Each declaration cites the reference interface (relative to the reference tree)
+ * whose behaviour it replaces.  Error behaviour follows `llkv-result/src/error.rs`:
+ * every call returns a status code, the message is fetched with
+ * `llkv_hip_last_error()` (thread-local), nothing unwinds across the boundary.
+ */
+#ifndef LLKV_HIP_H
+#define LLKV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLKV_HIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------- */
+/* Status codes — llkv-result/src/error.rs (InvalidArgumentError / Internal / */
+/* NotFound); UNSUPPORTED tells the caller to keep its own CPU route.         */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_status {
+  LLKV_OK = 0,
+  LLKV_INVALID_ARGUMENT = 1, /* Error::InvalidArgumentError (user visible)    */
+  LLKV_INTERNAL = 2,         /* Error::Internal                               */
+  LLKV_NOT_FOUND = 3,        /* Error::NotFound (scan of a missing column)    */
+  LLKV_UNSUPPORTED = 4,      /* plan shape not on the GPU path: fall back     */
+  LLKV_NO_DEVICE = 5,        /* no usable HIP device / extension not built    */
+  LLKV_PREDICATE_BUILD = 6   /* Error::PredicateBuild — literal cannot be cast
+                                to the column's native type
+                                (llkv-table/src/table.rs:1236)                 */
+} llkv_status;
+
+/* Column storage types the path accepts.  Mapping from SQL types:
+ * llkv-sql/src/lib.rs:25-28 (INT→Int64, DOUBLE→Float64, DATE→Date32,
+ * CHAR/VARCHAR→Utf8).  Filterable set: llkv-table/src/table.rs:1156-1168.    */
+typedef enum llkv_dtype {
+  LLKV_DT_NULL = 0,
+  LLKV_DT_INT64 = 1,
+  LLKV_DT_FLOAT64 = 2,
+  LLKV_DT_INT32 = 3,
+  LLKV_DT_DATE32 = 4,   /* i32 days since 1970-01-01                         */
+  LLKV_DT_UINT64 = 5,
+  LLKV_DT_UINT32 = 6,
+  LLKV_DT_FLOAT32 = 7,
+  LLKV_DT_UTF8 = 8,     /* staged as 1-byte dictionary codes in HBM          */
+  LLKV_DT_BOOLEAN = 9
+} llkv_dtype;
+
+/* ------------------------------------------------------------------------- */
+/* Literals — llkv-types/src/literal.rs (`Literal`), cast rules :364-520.     */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_literal_tag {
+  LLKV_LIT_NULL = 0,
+  LLKV_LIT_INT128 = 1,     /* lo/hi two's complement                         */
+  LLKV_LIT_FLOAT64 = 2,
+  LLKV_LIT_DECIMAL128 = 3, /* raw value in lo/hi, `scale`                    */
+  LLKV_LIT_BOOLEAN = 4,    /* lo = 0/1                                       */
+  LLKV_LIT_STRING = 5,     /* str (NUL terminated, borrowed)                 */
+  LLKV_LIT_DATE32 = 6      /* lo = days                                      */
+} llkv_literal_tag;
+
+typedef struct llkv_literal {
+  int32_t tag;   /* llkv_literal_tag */
+  int32_t scale; /* Decimal128 scale */
+  uint64_t lo;
+  int64_t hi;
+  double f64;
+  const char *str;
+} llkv_literal;
+
+/* ------------------------------------------------------------------------- */
+/* Leaf filters — llkv-expr `Filter{field_id, Operator}`, owned form           */
+/* llkv-compute/src/program.rs:80-112; typed evaluation                       */
+/* llkv-expr/src/typed_predicate.rs:75-146,253-312.                           */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_operator_kind {
+  LLKV_OP_EQUALS = 1,
+  LLKV_OP_RANGE = 2,
+  LLKV_OP_GT = 3,
+  LLKV_OP_GE = 4,
+  LLKV_OP_LT = 5,
+  LLKV_OP_LE = 6,
+  LLKV_OP_IN = 7,
+  LLKV_OP_IS_NULL = 8,
+  LLKV_OP_IS_NOT_NULL = 9
+} llkv_operator_kind;
+
+typedef enum llkv_bound_kind {
+  LLKV_BOUND_UNBOUNDED = 0,
+  LLKV_BOUND_INCLUDED = 1,
+  LLKV_BOUND_EXCLUDED = 2
+} llkv_bound_kind;
+
+typedef struct llkv_filter {
+  uint32_t field_id;
+  int32_t op;           /* llkv_operator_kind                                */
+  llkv_literal value;   /* EQUALS / GT / GE / LT / LE                        */
+  int32_t lower_kind;   /* RANGE: llkv_bound_kind                            */
+  llkv_literal lower;
+  int32_t upper_kind;
+  llkv_literal upper;
+  const llkv_literal *in_list; /* IN                                         */
+  uint32_t in_len;
+} llkv_filter;
+
+/* Predicate program — `EvalOp` stack program, llkv-compute/src/program.rs:48-78,
+ * interpreted by llkv-scan/src/predicate.rs:32-193.  `n_ops == 0` means the
+ * conjunction of all filters (`Expr::all_of`); no filters and no ops = TRUE.  */
+typedef enum llkv_eval_opcode {
+  LLKV_EVAL_PUSH_PREDICATE = 1, /* arg = index into filters[]                 */
+  LLKV_EVAL_PUSH_LITERAL = 2,   /* arg = 0/1                                  */
+  LLKV_EVAL_AND = 3,            /* arg = child_count                          */
+  LLKV_EVAL_OR = 4,             /* arg = child_count                          */
+  LLKV_EVAL_NOT = 5
+} llkv_eval_opcode;
+
+typedef struct llkv_eval_op {
+  int32_t op;
+  uint32_t arg;
+} llkv_eval_op;
+
+/* ------------------------------------------------------------------------- */
+/* Scalar expressions in postfix form — the token program of                  */
+/* llkv-compute/src/fast_numeric.rs:19-37 (`Token::{Column,Literal,Binary}`).  */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_token_kind {
+  LLKV_TOK_COLUMN = 1,
+  LLKV_TOK_LITERAL = 2,
+  LLKV_TOK_BINARY = 3
+} llkv_token_kind;
+
+typedef enum llkv_binary_op {
+  LLKV_BIN_ADD = 1,
+  LLKV_BIN_SUB = 2,
+  LLKV_BIN_MUL = 3,
+  LLKV_BIN_DIV = 4,
+  LLKV_BIN_MOD = 5
+} llkv_binary_op;
+
+typedef struct llkv_expr_token {
+  int32_t kind;  /* llkv_token_kind                                         */
+  int32_t binop; /* llkv_binary_op for LLKV_TOK_BINARY                       */
+  uint32_t field_id;
+  llkv_literal literal;
+} llkv_expr_token;
+
+/* ------------------------------------------------------------------------- */
+/* Aggregates — `AggregateSpec{alias,kind}` llkv-aggregate/src/lib.rs:25-69;  */
+/* the argument is a bare column or a computed projection                     */
+/* (llkv-executor/src/lib.rs:470-501).                                        */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_aggregate_kind {
+  LLKV_AGG_COUNT_STAR = 1,
+  LLKV_AGG_COUNT = 2,
+  LLKV_AGG_SUM = 3,
+  LLKV_AGG_TOTAL = 4,
+  LLKV_AGG_AVG = 5,
+  LLKV_AGG_MIN = 6,
+  LLKV_AGG_MAX = 7,
+  LLKV_AGG_COUNT_NULLS = 8
+} llkv_aggregate_kind;
+
+typedef struct llkv_aggregate_spec {
+  int32_t kind;     /* llkv_aggregate_kind                                   */
+  int32_t distinct; /* must be 0 on this path (DISTINCT = UNSUPPORTED)       */
+  const llkv_expr_token *expr; /* NULL for COUNT(*)                          */
+  uint32_t expr_len;
+  const char *alias;
+} llkv_aggregate_spec;
+
+/* One finalized aggregate cell = the 1-element Arrow array returned by
+ * `AggregateAccumulator::finalize` llkv-aggregate/src/lib.rs:1488-1939.      */
+typedef struct llkv_value {
+  int32_t dtype;   /* LLKV_DT_INT64 / LLKV_DT_FLOAT64 / LLKV_DT_UTF8        */
+  int32_t is_null;
+  int64_t i64;
+  double f64;
+  const char *str; /* group keys of Utf8 type; owned by the result object    */
+} llkv_value;
+
+/* ------------------------------------------------------------------------- */
+/* Device / context                                                           */
+/* ------------------------------------------------------------------------- */
+/* Bind the calling process to one GPU (one process per GPU). */
+llkv_status llkv_hip_init(int32_t device_ordinal);
+void llkv_hip_shutdown(void);
+int32_t llkv_hip_device_count(void);
+uint32_t llkv_hip_abi_version(void);
+/* Thread-local message of the last failing call on this thread. */
+const char *llkv_hip_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Tables — the HBM-resident image of a `Table`'s column chunks.               */
+/* Replaces the chunk walk of `ColumnStore` (llkv-column-map/src/store/        */
+/* scan/unsorted.rs:40-67); chunks are the sharding unit (131 072 rows per     */
+/* 8-byte column, llkv-column-map/src/store/constants.rs:22).                  */
+/* ------------------------------------------------------------------------- */
+typedef struct llkv_hip_table llkv_hip_table;
+
+/* `global_chunk_rows[n_global_chunks]` describes the whole table; this rank
+ * stages only the chunks of its shard (see llkv_hip_table_local_chunks).
+ * world == 1 stages everything.  world must divide 8 for results that are
+ * bit-identical across GPU counts.                                           */
+llkv_status llkv_hip_table_create(uint16_t table_id, const uint64_t *global_chunk_rows,
+                                  uint32_t n_global_chunks, uint32_t rank, uint32_t world,
+                                  llkv_hip_table **out);
+void llkv_hip_table_free(llkv_hip_table *table);
+/* Chunk range [first, first+count) of the global table this rank owns. */
+llkv_status llkv_hip_table_local_chunks(const llkv_hip_table *table, uint32_t *first,
+                                        uint32_t *count);
+uint64_t llkv_hip_table_total_rows(const llkv_hip_table *table); /* global   */
+uint64_t llkv_hip_table_local_rows(const llkv_hip_table *table);
+
+/* Stage the value buffers of one fixed-width column: `chunk_values[i]` points at
+ * the Arrow values buffer of local chunk i (host memory, `local chunk rows[i]`
+ * elements).  Copies go pinned-host → HBM with hipMemcpyAsync.                */
+llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,
+                                         const void *const *chunk_values, uint32_t n_chunks);
+/* Utf8 column given as Arrow offsets(i32)+data per chunk; staged as 1-byte
+ * dictionary codes (≤ 256 distinct values, else LLKV_UNSUPPORTED).           */
+llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t field_id,
+                                              const int32_t *const *chunk_offsets,
+                                              const uint8_t *const *chunk_data,
+                                              uint32_t n_chunks);
+/* Adopt a buffer that already lives in HBM (all local chunks back to back). */
+llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id,
+                                               int32_t dtype, const void *device_values);
+
+/* ------------------------------------------------------------------------- */
+/* Prepared queries: plan lowering + kernel selection happen once, launches   */
+/* are asynchronous on a caller-supplied HIP stream.                          */
+/* ------------------------------------------------------------------------- */
+typedef struct llkv_hip_query llkv_hip_query;
+
+/* Ungrouped aggregates with optional WHERE — replaces
+ * `execute_aggregates` llkv-executor/src/lib.rs:5357-5682 and
+ * `compute_aggregate_values` :6087-6665 (scan + accumulate + finalize).      */
+llkv_status llkv_hip_query_prepare_aggregate(const llkv_hip_table *table,
+                                             const llkv_filter *filters, uint32_t n_filters,
+                                             const llkv_eval_op *ops, uint32_t n_ops,
+                                             const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                                             llkv_hip_query **out);
+/* GROUP BY + aggregates — replaces `execute_group_by_single_table`
+ * llkv-executor/src/lib.rs:4405-4542 and `execute_group_by_with_aggregates`
+ * :5028-5355.  Groups come back in first-appearance order unless
+ * `order_by_keys` (ascending lexsort over the keys, :13762-13868).           */
+llkv_status llkv_hip_query_prepare_groupby(const llkv_hip_table *table,
+                                           const llkv_filter *filters, uint32_t n_filters,
+                                           const llkv_eval_op *ops, uint32_t n_ops,
+                                           const uint32_t *key_fields, uint32_t n_keys,
+                                           const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                                           int32_t order_by_keys, llkv_hip_query **out);
+void llkv_hip_query_free(llkv_hip_query *query);
+
+/* Enqueue the kernels of one execution on `hip_stream` (a hipStream_t, NULL =
+ * the library's own stream).  On return the per-shard partial state is being
+ * written to the exchange buffer.                                            */
+llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream);
+/* Device buffer of `len` int64 lanes holding this rank's partial aggregate
+ * state, zero where another rank owns the lane.  With world > 1 the caller
+ * all-reduces it (ncclSum over ncclInt64 — exact for every lane type because
+ * exactly one rank contributes non-zero bits per lane) before finish.        */
+llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_ptr,
+                                           uint64_t *len_i64);
+/* Copy the (combined) state to the host, fold it in canonical order and
+ * finalize.  Blocks until done.                                              */
+llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream);
+
+/* Results of the last finish(). Aggregate queries have exactly one group.    */
+uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query);
+uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query);
+uint32_t llkv_hip_query_num_aggregates(const llkv_hip_query *query);
+llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group, uint32_t key,
+                                     llkv_value *out);
+llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, uint32_t agg,
+                                 llkv_value *out);
+/* Status a finalize step produced for one aggregate (e.g. "integer overflow"
+ * is LLKV_INVALID_ARGUMENT, llkv-aggregate/src/lib.rs:816-829).              */
+
+/* Measurement hooks (bench only): HIP-event time of the dominant kernel,
+ * summed over launches since the last reset, and the launch count.           */
+llkv_status llkv_hip_query_set_profiling(llkv_hip_query *query, int32_t enabled);
+llkv_status llkv_hip_query_kernel_time(llkv_hip_query *query, double *total_ms,
+                                       uint64_t *launches, const char **kernel_name);
+/* Algorithmic bytes one launch reads on this rank (value buffers, once). */
+uint64_t llkv_hip_query_algorithmic_bytes(const llkv_hip_query *query);
+/* Name of the compiled kernel variant chosen for this plan. */
+const char *llkv_hip_query_kernel_signature(const llkv_hip_query *query);
+
+/* One-shot conveniences (prepare + launch + finish + copy out + free). */
+llkv_status llkv_hip_aggregate(const llkv_hip_table *table, const llkv_filter *filters,
+                               uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                               const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                               llkv_value *out_values);
+
+/* ------------------------------------------------------------------------- */
+/* Streaming scan — `StorageTable::scan_stream`                               */
+/* llkv-executor/src/types/storage.rs:20-50 → `execute_scan`                   */
+/* llkv-scan/src/execute.rs:47-295: filter → selection vector → 65 536-row     */
+/* windows → gathered projections → on_batch, ascending row-id order, never an */
+/* empty batch.                                                               */
+/* ------------------------------------------------------------------------- */
+typedef struct llkv_projection {
+  int32_t computed;            /* 0 = ScanProjection::Column, 1 = ::Computed  */
+  uint32_t field_id;           /* column projection                           */
+  const llkv_expr_token *expr; /* computed projection (postfix)               */
+  uint32_t expr_len;
+  const char *alias;
+} llkv_projection;
+
+typedef struct llkv_scan_options {
+  int32_t include_nulls;   /* ScanStreamOptions.include_nulls                 */
+  int32_t include_row_ids; /* ScanStreamOptions.include_row_ids               */
+} llkv_scan_options;
+
+typedef struct llkv_column_view {
+  int32_t dtype;
+  const void *values;      /* host memory, valid during the callback only     */
+  const uint8_t *validity; /* Arrow validity bitmap or NULL (all valid)       */
+  const char *const *dictionary; /* Utf8: code → string, else NULL            */
+} llkv_column_view;
+
+typedef struct llkv_batch_view {
+  uint64_t num_rows;
+  uint32_t num_columns;
+  const llkv_column_view *columns;
+  const uint64_t *row_ids; /* NULL unless include_row_ids                     */
+} llkv_batch_view;
+
+typedef void (*llkv_on_batch)(const llkv_batch_view *batch, void *user);
+
+llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_projection *projections,
+                                 uint32_t n_projections, const llkv_filter *filters,
+                                 uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                                 const llkv_scan_options *options, llkv_on_batch on_batch,
+                                 void *user);
+/* `StorageTable::filter_row_ids` (storage.rs:34-37): matching row ids, ascending.
+ * `*out_row_ids` is malloc'd; release with llkv_hip_free.                    */
+llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filter *filters,
+                                    uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                                    uint64_t **out_row_ids, uint64_t *out_len);
+void llkv_hip_free(void *ptr);
+
+/* ------------------------------------------------------------------------- */
+/* Hash join — `TableJoinExt::join_stream` llkv-join/src/lib.rs:240-282,        */
+/* integer fast path llkv-join/src/hash_join.rs:955-1417.  Build = right,      */
+/* probe = left; output = matching (left row, right row) index pairs in probe  */
+/* order × build insertion order, in batches of ≤ batch_size pairs.           */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_join_type {
+  LLKV_JOIN_INNER = 0,
+  LLKV_JOIN_LEFT = 1,
+  LLKV_JOIN_RIGHT = 2, /* unimplemented in the reference (hash_join.rs:328-332) */
+  LLKV_JOIN_FULL = 3,  /* idem                                                 */
+  LLKV_JOIN_SEMI = 4,
+  LLKV_JOIN_ANTI = 5
+} llkv_join_type;
+
+typedef struct llkv_join_key {
+  uint32_t left_field;
+  uint32_t right_field;
+  int32_t null_equals_null;
+} llkv_join_key;
+
+typedef struct llkv_join_options {
+  int32_t join_type;   /* llkv_join_type                                      */
+  uint64_t batch_size; /* JoinOptions.batch_size (default 8192); 0 = error    */
+} llkv_join_options;
+
+/* Index-pair batch: right_rows[i] == UINT64_MAX marks a NULL-padded right side
+ * (LEFT join).  SEMI/ANTI deliver left rows only (right_rows == NULL).       */
+typedef void (*llkv_on_join_batch)(const uint64_t *left_rows, const uint64_t *right_rows,
+                                   uint64_t n_pairs, void *user);
+
+llkv_status llkv_hip_join_stream(const llkv_hip_table *left, const llkv_hip_table *right,
+                                 const llkv_join_key *keys, uint32_t n_keys,
+                                 const llkv_join_options *options, llkv_on_join_batch on_batch,
+                                 void *user);
+
+/* ------------------------------------------------------------------------- */
+/* Plan inspection (host only, no device needed): lowers a plan exactly as the */
+/* prepare calls do and returns the kernel plan type.  Used by the build to    */
+/* pre-compile the benchmark plans and by tests of the typing rules.           */
+/* ------------------------------------------------------------------------- */
+typedef struct llkv_column_desc {
+  uint32_t field_id;
+  int32_t dtype;
+  uint64_t rows;      /* global table rows                                   */
+  int32_t has_stats;  /* integer min/max known                               */
+  int64_t min_i, max_i;
+  uint32_t dict_size; /* LLKV_DT_UTF8                                        */
+  const char *const *dictionary;
+} llkv_column_desc;
+
+llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols,
+                            const llkv_filter *filters, uint32_t n_filters,
+                            const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields,
+                            uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                            int32_t grouped, char *type_string_out, uint64_t type_string_cap,
+                            uint32_t *lanes_out, uint64_t *bytes_per_row_out);
+const char *llkv_plan_last_error(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* LLKV_HIP_H */

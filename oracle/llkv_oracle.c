@@ -1,0 +1,1426 @@
+/*
+ * llkv_oracle.c — CPU restatement of the reference's hot path (see llkv_oracle.h).
+ * TEST INFRASTRUCTURE ONLY.  Sequential, same pass structure as the reference:
+ * one pass per leaf predicate → row-id sets → set algebra → 65 536-row windows →
+ * gather → one temporary per arithmetic operator → strictly sequential accumulate.
+ *
+ * Every function names the reference file:line it follows (paths relative to the
+ * reference tree).  Third-party arithmetic restated from its published semantics:
+ * arrow-rs 57.1.0 `numeric::{add,sub,mul,rem}` (checked for integers, IEEE-754 for
+ * floats), Rust `partial_cmp`/`checked_add`/`as` casts, compiler-rt `powi`.
+ */
+#define _GNU_SOURCE
+#include "llkv_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+#define ROW_STREAM_CHUNK_SIZE 65536u /* llkv-scan/src/execute.rs:31 */
+
+/* ------------------------------------------------------------------ errors */
+static __thread char g_err[512];
+
+const char *orc_last_error(void) { return g_err; }
+
+static int32_t fail(int32_t code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+void orc_free(void *p) { free(p); }
+
+static void *xmalloc(size_t n) {
+  void *p = malloc(n ? n : 1);
+  if (!p) abort();
+  return p;
+}
+static void *xcalloc(size_t n, size_t m) {
+  void *p = calloc(n ? n : 1, m ? m : 1);
+  if (!p) abort();
+  return p;
+}
+static void *xrealloc(void *q, size_t n) {
+  void *p = realloc(q, n ? n : 1);
+  if (!p) abort();
+  return p;
+}
+
+/* ------------------------------------------------------------- id vectors */
+typedef struct idvec {
+  uint64_t *v;
+  uint64_t n, cap;
+} idvec;
+
+static void idv_push(idvec *a, uint64_t x) {
+  if (a->n == a->cap) {
+    a->cap = a->cap ? a->cap * 2 : 1024;
+    a->v = xrealloc(a->v, a->cap * sizeof(uint64_t));
+  }
+  a->v[a->n++] = x;
+}
+static void idv_free(idvec *a) {
+  free(a->v);
+  a->v = NULL;
+  a->n = a->cap = 0;
+}
+static idvec idv_all(uint64_t rows) {
+  idvec r = {xmalloc(rows * sizeof(uint64_t)), rows, rows};
+  for (uint64_t i = 0; i < rows; ++i) r.v[i] = i;
+  return r;
+}
+/* Roaring `&`, `|`, `-` on sorted id lists (llkv-scan/src/predicate.rs:109-183). */
+static idvec idv_and(const idvec *a, const idvec *b) {
+  idvec r = {0};
+  uint64_t i = 0, j = 0;
+  while (i < a->n && j < b->n) {
+    if (a->v[i] < b->v[j]) ++i;
+    else if (a->v[i] > b->v[j]) ++j;
+    else { idv_push(&r, a->v[i]); ++i; ++j; }
+  }
+  return r;
+}
+static idvec idv_or(const idvec *a, const idvec *b) {
+  idvec r = {0};
+  uint64_t i = 0, j = 0;
+  while (i < a->n || j < b->n) {
+    if (j >= b->n || (i < a->n && a->v[i] < b->v[j])) idv_push(&r, a->v[i++]);
+    else if (i >= a->n || a->v[i] > b->v[j]) idv_push(&r, b->v[j++]);
+    else { idv_push(&r, a->v[i]); ++i; ++j; }
+  }
+  return r;
+}
+static idvec idv_sub(const idvec *a, const idvec *b) {
+  idvec r = {0};
+  uint64_t i = 0, j = 0;
+  while (i < a->n) {
+    while (j < b->n && b->v[j] < a->v[i]) ++j;
+    if (j >= b->n || b->v[j] != a->v[i]) idv_push(&r, a->v[i]);
+    ++i;
+  }
+  return r;
+}
+
+/* ------------------------------------------------------------ column access */
+static const orc_column *find_col(const orc_table *t, uint32_t field_id) {
+  for (uint32_t i = 0; i < t->n_cols; ++i)
+    if (t->cols[i].field_id == field_id) return &t->cols[i];
+  return NULL;
+}
+static inline int col_valid(const orc_column *c, uint64_t row) {
+  return !c->validity || ((c->validity[row >> 3] >> (row & 7)) & 1);
+}
+static const char *dtype_name(int32_t dt) {
+  switch (dt) {
+  case LLKV_DT_INT64: return "Int64";
+  case LLKV_DT_FLOAT64: return "Float64";
+  case LLKV_DT_INT32: return "Int32";
+  case LLKV_DT_DATE32: return "Date32";
+  case LLKV_DT_UINT64: return "UInt64";
+  case LLKV_DT_UINT32: return "UInt32";
+  case LLKV_DT_FLOAT32: return "Float32";
+  case LLKV_DT_UTF8: return "Utf8";
+  case LLKV_DT_BOOLEAN: return "Boolean";
+  default: return "Null";
+  }
+}
+
+/* ----------------------------------------------------------- literal casts */
+/* llkv-types/src/literal.rs:364-520 (`FromLiteral`). */
+static i128 lit_i128(const llkv_literal *l) { return (i128)(((u128)(uint64_t)l->hi << 64) | (u128)l->lo); }
+
+static const char *lit_kind(const llkv_literal *l) {
+  switch (l->tag) {
+  case LLKV_LIT_FLOAT64: return "float";
+  case LLKV_LIT_BOOLEAN: return "boolean";
+  case LLKV_LIT_STRING: return "string";
+  case LLKV_LIT_DATE32: return "date";
+  case LLKV_LIT_DECIMAL128: return "decimal";
+  case LLKV_LIT_NULL: return "null";
+  default: return "integer";
+  }
+}
+
+/* compiler-rt __powidf2: what Rust's f64::powi lowers to. */
+static double powi_f64(double a, int b) {
+  const int recip = b < 0;
+  double r = 1;
+  for (;;) {
+    if (b & 1) r *= a;
+    b /= 2;
+    if (b == 0) break;
+    a *= a;
+  }
+  return recip ? 1 / r : r;
+}
+
+/* integer targets: literal.rs:368-420 */
+static int32_t lit_to_int(const llkv_literal *l, i128 lo, i128 hi, const char *target, i128 *out) {
+  i128 v;
+  if (l->tag == LLKV_LIT_INT128) v = lit_i128(l);
+  else if (l->tag == LLKV_LIT_DECIMAL128 && l->scale == 0) v = lit_i128(l);
+  else
+    return fail(LLKV_PREDICATE_BUILD, "literal cast error: expected integer, got %s", lit_kind(l));
+  if (v < lo || v > hi)
+    return fail(LLKV_PREDICATE_BUILD, "literal cast error: value out of range for %s", target);
+  *out = v;
+  return LLKV_OK;
+}
+/* f64: literal.rs:487-520; decimal → f64 llkv-types/src/decimal.rs:102-108 */
+static int32_t lit_to_f64(const llkv_literal *l, double *out) {
+  switch (l->tag) {
+  case LLKV_LIT_FLOAT64: *out = l->f64; return LLKV_OK;
+  case LLKV_LIT_INT128: *out = (double)lit_i128(l); return LLKV_OK;
+  case LLKV_LIT_DECIMAL128: {
+    i128 raw = lit_i128(l);
+    *out = raw == 0 ? 0.0 : (double)raw / powi_f64(10.0, l->scale);
+    return LLKV_OK;
+  }
+  default:
+    return fail(LLKV_PREDICATE_BUILD, "literal cast error: expected float, got %s", lit_kind(l));
+  }
+}
+/* f32: literal.rs:433-485 */
+static int32_t lit_to_f32(const llkv_literal *l, float *out) {
+  double v;
+  int32_t rc = lit_to_f64(l, &v);
+  if (rc) return rc;
+  float c = (float)v;
+  if (!isfinite(c)) return fail(LLKV_PREDICATE_BUILD, "literal cast error: float out of range for f32");
+  *out = c;
+  return LLKV_OK;
+}
+
+/* -------------------------------------------------------- typed predicates */
+/* llkv-expr/src/typed_predicate.rs:41-147 (`Predicate<V>::matches`), :253-312. */
+enum { VC_I64, VC_U64, VC_F64, VC_F32, VC_STR };
+typedef union nat {
+  int64_t i;
+  uint64_t u;
+  double d;
+  float f;
+  const char *s;
+} nat;
+
+typedef struct tpred {
+  int kind; /* llkv_operator_kind, or 0 = Predicate::All */
+  int vclass;
+  nat a;
+  int lower_kind, upper_kind;
+  nat lo, hi;
+  nat *in;
+  uint32_t n_in;
+} tpred;
+
+static int vclass_of(int32_t dtype) {
+  switch (dtype) {
+  case LLKV_DT_INT64: case LLKV_DT_INT32: case LLKV_DT_DATE32: return VC_I64;
+  case LLKV_DT_UINT64: case LLKV_DT_UINT32: return VC_U64;
+  case LLKV_DT_FLOAT64: return VC_F64;
+  case LLKV_DT_FLOAT32: return VC_F32;
+  case LLKV_DT_UTF8: return VC_STR;
+  default: return -1;
+  }
+}
+
+static int32_t cast_native(const llkv_literal *l, int32_t dtype, nat *out) {
+  i128 v;
+  int32_t rc;
+  switch (dtype) {
+  case LLKV_DT_INT64:
+    rc = lit_to_int(l, INT64_MIN, INT64_MAX, "i64", &v); if (rc) return rc; out->i = (int64_t)v; return LLKV_OK;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: /* Date32 filters as i32: table.rs:1160-1167 */
+    rc = lit_to_int(l, INT32_MIN, INT32_MAX, "i32", &v); if (rc) return rc; out->i = (int64_t)v; return LLKV_OK;
+  case LLKV_DT_UINT64:
+    rc = lit_to_int(l, 0, (i128)UINT64_MAX, "u64", &v); if (rc) return rc; out->u = (uint64_t)v; return LLKV_OK;
+  case LLKV_DT_UINT32:
+    rc = lit_to_int(l, 0, UINT32_MAX, "u32", &v); if (rc) return rc; out->u = (uint64_t)v; return LLKV_OK;
+  case LLKV_DT_FLOAT64: return lit_to_f64(l, &out->d);
+  case LLKV_DT_FLOAT32: return lit_to_f32(l, &out->f);
+  case LLKV_DT_UTF8:
+    if (l->tag != LLKV_LIT_STRING)
+      return fail(LLKV_PREDICATE_BUILD, "literal cast error: expected string, got %s", lit_kind(l));
+    out->s = l->str;
+    return LLKV_OK;
+  default:
+    return fail(LLKV_INTERNAL, "Filtering on type %s is not supported", dtype_name(dtype));
+  }
+}
+
+static int32_t build_predicate(const llkv_filter *f, int32_t dtype, tpred *p) {
+  memset(p, 0, sizeof *p);
+  p->vclass = vclass_of(dtype);
+  if (p->vclass < 0) return fail(LLKV_INTERNAL, "Filtering on type %s is not supported", dtype_name(dtype));
+  p->kind = f->op;
+  int32_t rc;
+  switch (f->op) {
+  case LLKV_OP_EQUALS: case LLKV_OP_GT: case LLKV_OP_GE: case LLKV_OP_LT: case LLKV_OP_LE:
+    return cast_native(&f->value, dtype, &p->a);
+  case LLKV_OP_RANGE:
+    p->lower_kind = f->lower_kind;
+    p->upper_kind = f->upper_kind;
+    if (f->lower_kind != LLKV_BOUND_UNBOUNDED && (rc = cast_native(&f->lower, dtype, &p->lo))) return rc;
+    if (f->upper_kind != LLKV_BOUND_UNBOUNDED && (rc = cast_native(&f->upper, dtype, &p->hi))) return rc;
+    if (f->lower_kind == LLKV_BOUND_UNBOUNDED && f->upper_kind == LLKV_BOUND_UNBOUNDED) p->kind = 0;
+    return LLKV_OK;
+  case LLKV_OP_IN:
+    p->in = xmalloc(sizeof(nat) * (f->in_len ? f->in_len : 1));
+    p->n_in = f->in_len;
+    for (uint32_t i = 0; i < f->in_len; ++i)
+      if ((rc = cast_native(&f->in_list[i], dtype, &p->in[i]))) { free(p->in); p->in = NULL; return rc; }
+    return LLKV_OK;
+  default:
+    return fail(LLKV_PREDICATE_BUILD, "unsupported operator for typed predicate: operator lacks typed literal support");
+  }
+}
+
+/* Rust partial_cmp: -1 / 0 / 1, or 2 for "None" (NaN involved). */
+static inline int pcmp(int vclass, nat v, nat t) {
+  switch (vclass) {
+  case VC_I64: return v.i < t.i ? -1 : v.i > t.i;
+  case VC_U64: return v.u < t.u ? -1 : v.u > t.u;
+  case VC_F64: return v.d < t.d ? -1 : v.d > t.d ? 1 : v.d == t.d ? 0 : 2;
+  case VC_F32: return v.f < t.f ? -1 : v.f > t.f ? 1 : v.f == t.f ? 0 : 2;
+  default: { int c = strcmp(v.s, t.s); return c < 0 ? -1 : c > 0; }
+  }
+}
+static inline int peq(int vclass, nat v, nat t) {
+  switch (vclass) {
+  case VC_I64: return v.i == t.i;
+  case VC_U64: return v.u == t.u;
+  case VC_F64: return v.d == t.d;
+  case VC_F32: return v.f == t.f;
+  default: return strcmp(v.s, t.s) == 0;
+  }
+}
+static int pred_matches(const tpred *p, nat v) {
+  int c;
+  switch (p->kind) {
+  case 0: return 1;
+  case LLKV_OP_EQUALS: return peq(p->vclass, v, p->a);
+  case LLKV_OP_GT: return pcmp(p->vclass, v, p->a) == 1;
+  case LLKV_OP_GE: c = pcmp(p->vclass, v, p->a); return c == 1 || c == 0;
+  case LLKV_OP_LT: return pcmp(p->vclass, v, p->a) == -1;
+  case LLKV_OP_LE: c = pcmp(p->vclass, v, p->a); return c == -1 || c == 0;
+  case LLKV_OP_RANGE:
+    if (p->lower_kind == LLKV_BOUND_INCLUDED) { c = pcmp(p->vclass, v, p->lo); if (!(c == 1 || c == 0)) return 0; }
+    else if (p->lower_kind == LLKV_BOUND_EXCLUDED) { if (pcmp(p->vclass, v, p->lo) != 1) return 0; }
+    if (p->upper_kind == LLKV_BOUND_INCLUDED) { c = pcmp(p->vclass, v, p->hi); if (!(c == -1 || c == 0)) return 0; }
+    else if (p->upper_kind == LLKV_BOUND_EXCLUDED) { if (pcmp(p->vclass, v, p->hi) != -1) return 0; }
+    return 1;
+  case LLKV_OP_IN:
+    for (uint32_t i = 0; i < p->n_in; ++i) if (peq(p->vclass, v, p->in[i])) return 1;
+    return 0;
+  default: return 0;
+  }
+}
+
+/* value of (col,row) in the predicate's value class; Utf8 values are copied to a
+ * scratch buffer because Arrow strings are not NUL-terminated. */
+static nat col_nat(const orc_column *c, uint64_t row, char **scratch, size_t *scratch_cap) {
+  nat v;
+  memset(&v, 0, sizeof v);
+  switch (c->dtype) {
+  case LLKV_DT_INT64: v.i = ((const int64_t *)c->values)[row]; break;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: v.i = ((const int32_t *)c->values)[row]; break;
+  case LLKV_DT_UINT64: v.u = ((const uint64_t *)c->values)[row]; break;
+  case LLKV_DT_UINT32: v.u = ((const uint32_t *)c->values)[row]; break;
+  case LLKV_DT_FLOAT64: v.d = ((const double *)c->values)[row]; break;
+  case LLKV_DT_FLOAT32: v.f = ((const float *)c->values)[row]; break;
+  case LLKV_DT_UTF8: {
+    size_t len = (size_t)(c->offsets[row + 1] - c->offsets[row]);
+    if (len + 1 > *scratch_cap) { *scratch_cap = len + 64; *scratch = xrealloc(*scratch, *scratch_cap); }
+    memcpy(*scratch, c->data + c->offsets[row], len);
+    (*scratch)[len] = 0;
+    v.s = *scratch;
+    break;
+  }
+  default: break;
+  }
+  return v;
+}
+
+/* Rows where `field` is present (llkv-table/src/table.rs:1202-1223). */
+static int32_t field_nonnull_rows(const orc_table *t, uint32_t field_id, idvec *out) {
+  const orc_column *c = find_col(t, field_id);
+  if (!c) return fail(LLKV_NOT_FOUND, "field %u not found", field_id);
+  idvec r = {0};
+  for (uint64_t i = 0; i < t->rows; ++i) if (col_valid(c, i)) idv_push(&r, i);
+  *out = r;
+  return LLKV_OK;
+}
+
+/* Leaf filter: llkv-table/src/table.rs:1117-1171,1225-1247; hot loop
+ * llkv-column-map/src/store/scan/filter.rs:937-955 (sequential, push row id). */
+static int32_t filter_leaf(const orc_table *t, const llkv_filter *f, idvec *out) {
+  const orc_column *c = find_col(t, f->field_id);
+  if (!c) return fail(LLKV_NOT_FOUND, "field %u not found", f->field_id);
+  if (f->op == LLKV_OP_IS_NOT_NULL) return field_nonnull_rows(t, f->field_id, out);
+  if (f->op == LLKV_OP_IS_NULL) {
+    idvec all = idv_all(t->rows), nn;
+    int32_t rc = field_nonnull_rows(t, f->field_id, &nn);
+    if (rc) { idv_free(&all); return rc; }
+    *out = idv_sub(&all, &nn);
+    idv_free(&all); idv_free(&nn);
+    return LLKV_OK;
+  }
+  if (f->op == LLKV_OP_RANGE && f->lower_kind == LLKV_BOUND_UNBOUNDED && f->upper_kind == LLKV_BOUND_UNBOUNDED) {
+    *out = idv_all(t->rows); /* table.rs:1146-1153: every table row, NULLs included */
+    return LLKV_OK;
+  }
+  tpred p;
+  int32_t rc = build_predicate(f, c->dtype, &p);
+  if (rc) return rc;
+  idvec r = {0};
+  char *scratch = NULL;
+  size_t cap = 0;
+  for (uint64_t i = 0; i < t->rows; ++i) {
+    if (!col_valid(c, i)) continue; /* None => false, table.rs:1241-1244 */
+    if (pred_matches(&p, col_nat(c, i, &scratch, &cap))) idv_push(&r, i);
+  }
+  free(scratch);
+  free(p.in);
+  *out = r;
+  return LLKV_OK;
+}
+
+/* Predicate VM: llkv-scan/src/predicate.rs:32-193.  Each stack entry carries the
+ * matching rows and the domain (rows where the sub-expression is determined),
+ * which is what the reference's separate DomainProgram computes
+ * (llkv-compute/src/program.rs:447-520; predicate.rs:665-777): Pred → non-null
+ * rows of the field, And → intersect, Or → union, Literal → all rows. */
+typedef struct vm_entry { idvec rows, dom; } vm_entry;
+
+int32_t orc_filter_row_ids(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
+                           const llkv_eval_op *ops, uint32_t n_ops, uint64_t **out_ids, uint64_t *out_len) {
+  llkv_eval_op *synth = NULL;
+  if (n_ops == 0) { /* Expr::all_of(filters) */
+    if (n_filters == 0) {
+      idvec all = idv_all(t->rows);
+      *out_ids = all.v; *out_len = all.n;
+      return LLKV_OK;
+    }
+    synth = xmalloc(sizeof(llkv_eval_op) * (n_filters + 1));
+    for (uint32_t i = 0; i < n_filters; ++i) { synth[i].op = LLKV_EVAL_PUSH_PREDICATE; synth[i].arg = i; }
+    n_ops = n_filters;
+    if (n_filters > 1) { synth[n_ops].op = LLKV_EVAL_AND; synth[n_ops].arg = n_filters; ++n_ops; }
+    ops = synth;
+  }
+  vm_entry *stack = xcalloc(n_ops + 1, sizeof(vm_entry));
+  uint32_t sp = 0;
+  int32_t rc = LLKV_OK;
+  for (uint32_t k = 0; k < n_ops && rc == LLKV_OK; ++k) {
+    const llkv_eval_op *op = &ops[k];
+    switch (op->op) {
+    case LLKV_EVAL_PUSH_PREDICATE: {
+      if (op->arg >= n_filters) { rc = fail(LLKV_INTERNAL, "predicate index out of range"); break; }
+      vm_entry e = {{0}, {0}};
+      rc = filter_leaf(t, &filters[op->arg], &e.rows);
+      if (rc == LLKV_OK) rc = field_nonnull_rows(t, filters[op->arg].field_id, &e.dom);
+      if (rc == LLKV_OK) stack[sp++] = e; else { idv_free(&e.rows); idv_free(&e.dom); }
+      break;
+    }
+    case LLKV_EVAL_PUSH_LITERAL: {
+      vm_entry e = {{0}, {0}};
+      if (op->arg) e.rows = idv_all(t->rows);
+      e.dom = idv_all(t->rows);
+      stack[sp++] = e;
+      break;
+    }
+    case LLKV_EVAL_AND: case LLKV_EVAL_OR: {
+      if (op->arg == 0 || op->arg > sp) { rc = fail(LLKV_INTERNAL, "predicate stack underflow"); break; }
+      vm_entry acc = stack[sp - op->arg];
+      for (uint32_t c = 1; c < op->arg; ++c) {
+        vm_entry nx = stack[sp - op->arg + c];
+        idvec r = op->op == LLKV_EVAL_AND ? idv_and(&acc.rows, &nx.rows) : idv_or(&acc.rows, &nx.rows);
+        idvec d = op->op == LLKV_EVAL_AND ? idv_and(&acc.dom, &nx.dom) : idv_or(&acc.dom, &nx.dom);
+        idv_free(&acc.rows); idv_free(&acc.dom); idv_free(&nx.rows); idv_free(&nx.dom);
+        acc.rows = r; acc.dom = d;
+      }
+      sp -= op->arg;
+      stack[sp++] = acc;
+      break;
+    }
+    case LLKV_EVAL_NOT: { /* predicate.rs:167-186: domain(child) − rows(child) */
+      if (sp == 0) { rc = fail(LLKV_INTERNAL, "predicate stack underflow"); break; }
+      vm_entry *e = &stack[sp - 1];
+      idvec r = idv_sub(&e->dom, &e->rows);
+      idv_free(&e->rows);
+      e->rows = r;
+      break;
+    }
+    default: rc = fail(LLKV_INTERNAL, "unknown predicate opcode %d", op->op);
+    }
+  }
+  if (rc == LLKV_OK && sp != 1) rc = fail(LLKV_INTERNAL, "predicate program left %u entries", sp);
+  if (rc == LLKV_OK) {
+    *out_ids = stack[0].rows.v;
+    *out_len = stack[0].rows.n;
+    stack[0].rows.v = NULL;
+  }
+  for (uint32_t i = 0; i < sp; ++i) { idv_free(&stack[i].rows); idv_free(&stack[i].dom); }
+  free(stack);
+  free(synth);
+  return rc;
+}
+
+/* ------------------------------------------------------ computed projections */
+/* Arrays as they flow through the scan: i64 / f64 only after the cast step (other
+ * integer widths are widened on gather: get_common_type keeps "widest",
+ * llkv-compute/src/kernels.rs:179-242). */
+typedef struct arr {
+  int32_t dtype; /* LLKV_DT_INT64 or LLKV_DT_FLOAT64, or pass-through dtype for plain columns */
+  uint64_t n;
+  void *values;
+  uint8_t *valid;
+  char **strings;
+} arr;
+
+static void arr_free(arr *a) {
+  free(a->values);
+  free(a->valid);
+  if (a->strings) { for (uint64_t i = 0; i < a->n; ++i) free(a->strings[i]); free(a->strings); }
+  memset(a, 0, sizeof *a);
+}
+
+static size_t dtype_width(int32_t dt) {
+  switch (dt) {
+  case LLKV_DT_INT64: case LLKV_DT_UINT64: case LLKV_DT_FLOAT64: return 8;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: case LLKV_DT_UINT32: case LLKV_DT_FLOAT32: return 4;
+  case LLKV_DT_BOOLEAN: return 1;
+  default: return 0;
+  }
+}
+
+/* Gather one column for a window of row ids: llkv-column-map/src/store/projection.rs
+ * :929-1352, gather.rs:764-884 — out[i] = value_of(row_ids[i]), absent → NULL. */
+static arr gather_column(const orc_column *c, const uint64_t *ids, uint64_t n) {
+  arr a;
+  memset(&a, 0, sizeof a);
+  a.dtype = c->dtype;
+  a.n = n;
+  a.valid = xmalloc(n);
+  if (c->dtype == LLKV_DT_UTF8) {
+    a.strings = xcalloc(n, sizeof(char *));
+    for (uint64_t i = 0; i < n; ++i) {
+      a.valid[i] = (uint8_t)col_valid(c, ids[i]);
+      size_t len = a.valid[i] ? (size_t)(c->offsets[ids[i] + 1] - c->offsets[ids[i]]) : 0;
+      a.strings[i] = xmalloc(len + 1);
+      if (len) memcpy(a.strings[i], c->data + c->offsets[ids[i]], len);
+      a.strings[i][len] = 0;
+    }
+    return a;
+  }
+  size_t w = dtype_width(c->dtype);
+  a.values = xmalloc(n * w);
+  for (uint64_t i = 0; i < n; ++i) {
+    a.valid[i] = (uint8_t)col_valid(c, ids[i]);
+    memcpy((char *)a.values + i * w, (const char *)c->values + ids[i] * w, w);
+  }
+  return a;
+}
+
+static int is_int_dtype(int32_t dt) {
+  return dt == LLKV_DT_INT64 || dt == LLKV_DT_INT32 || dt == LLKV_DT_UINT32;
+}
+/* get_common_type restricted to the numeric types on this path
+ * (llkv-compute/src/kernels.rs:179-242): any float → Float64; signed ints → widest;
+ * Int32/UInt32 with Int64 → Int64; a 64-bit unsigned side with a signed side → Float64. */
+static int32_t common_type(int32_t a, int32_t b) {
+  if (a == b) return a;
+  if (a == LLKV_DT_FLOAT64 || b == LLKV_DT_FLOAT64 || a == LLKV_DT_FLOAT32 || b == LLKV_DT_FLOAT32) return LLKV_DT_FLOAT64;
+  if (a == LLKV_DT_UINT64 || b == LLKV_DT_UINT64) return LLKV_DT_FLOAT64;
+  if (is_int_dtype(a) && is_int_dtype(b)) return LLKV_DT_INT64;
+  return LLKV_DT_NULL;
+}
+
+/* Result type of a postfix token program (fast_numeric.rs:249-298, PlanBuilder::visit).
+ * Returns LLKV_DT_NULL when the program is not numeric. */
+static int32_t infer_expr_type(const orc_table *t, const llkv_expr_token *e, uint32_t n, int *has_div, int32_t *rc_out) {
+  int32_t st[64];
+  uint32_t sp = 0;
+  *has_div = 0;
+  *rc_out = LLKV_OK;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (sp >= 63) { *rc_out = fail(LLKV_INTERNAL, "expression too deep"); return LLKV_DT_NULL; }
+    switch (e[i].kind) {
+    case LLKV_TOK_COLUMN: {
+      const orc_column *c = find_col(t, e[i].field_id);
+      if (!c) { *rc_out = fail(LLKV_NOT_FOUND, "field %u not found", e[i].field_id); return LLKV_DT_NULL; }
+      st[sp++] = c->dtype;
+      break;
+    }
+    case LLKV_TOK_LITERAL:
+      /* fast_numeric.rs:300-309: Int128 / Decimal(raw) → Int, Float64 → Float */
+      if (e[i].literal.tag == LLKV_LIT_FLOAT64) st[sp++] = LLKV_DT_FLOAT64;
+      else if (e[i].literal.tag == LLKV_LIT_INT128 || e[i].literal.tag == LLKV_LIT_DECIMAL128 || e[i].literal.tag == LLKV_LIT_NULL) st[sp++] = LLKV_DT_INT64;
+      else { *rc_out = fail(LLKV_UNSUPPORTED, "non-numeric literal in computed projection"); return LLKV_DT_NULL; }
+      break;
+    case LLKV_TOK_BINARY: {
+      if (sp < 2) { *rc_out = fail(LLKV_INTERNAL, "fast path stack underflow"); return LLKV_DT_NULL; }
+      if (e[i].binop == LLKV_BIN_DIV) *has_div = 1;
+      int32_t r = common_type(st[sp - 2], st[sp - 1]);
+      if (r == LLKV_DT_NULL || r == LLKV_DT_DATE32 || r == LLKV_DT_UTF8) { *rc_out = fail(LLKV_UNSUPPORTED, "unsupported operand types %s, %s", dtype_name(st[sp - 2]), dtype_name(st[sp - 1])); return LLKV_DT_NULL; }
+      if (r == LLKV_DT_INT32 || r == LLKV_DT_UINT32) r = r; /* same-type narrow ints stay narrow */
+      sp -= 2;
+      st[sp++] = r;
+      break;
+    }
+    default: *rc_out = fail(LLKV_INTERNAL, "bad token"); return LLKV_DT_NULL;
+    }
+  }
+  if (sp != 1) { *rc_out = fail(LLKV_INTERNAL, "fast path evaluation missing result"); return LLKV_DT_NULL; }
+  return st[0];
+}
+
+/* arrow `cast` of a numeric column to the program's target type (fast_numeric.rs:80-87). */
+static arr cast_to(const arr *src, int32_t target) {
+  arr a;
+  memset(&a, 0, sizeof a);
+  a.dtype = target;
+  a.n = src->n;
+  a.valid = xmalloc(src->n);
+  memcpy(a.valid, src->valid, src->n);
+  a.values = xmalloc(src->n * 8);
+  for (uint64_t i = 0; i < src->n; ++i) {
+    double d = 0;
+    int64_t v = 0;
+    switch (src->dtype) {
+    case LLKV_DT_INT64: v = ((int64_t *)src->values)[i]; d = (double)v; break;
+    case LLKV_DT_INT32: v = ((int32_t *)src->values)[i]; d = (double)v; break;
+    case LLKV_DT_UINT32: v = ((uint32_t *)src->values)[i]; d = (double)v; break;
+    case LLKV_DT_UINT64: d = (double)((uint64_t *)src->values)[i]; v = (int64_t)((uint64_t *)src->values)[i]; break;
+    case LLKV_DT_FLOAT64: d = ((double *)src->values)[i]; v = (int64_t)d; break;
+    case LLKV_DT_FLOAT32: d = ((float *)src->values)[i]; v = (int64_t)d; break;
+    default: break;
+    }
+    if (target == LLKV_DT_FLOAT64) ((double *)a.values)[i] = d; else ((int64_t *)a.values)[i] = v;
+  }
+  return a;
+}
+
+/* One arrow-arith kernel call = one temporary array (fast_numeric.rs:312-356):
+ * integers checked (overflow → error), floats IEEE; NULL in → NULL out.
+ * `Divide` never reaches here on the fast path (:273-275); the generic path's
+ * x/0 → NULL rule (kernels.rs:121-135) is applied for DIV and MOD. */
+static int32_t binary_kernel(const arr *l, const arr *r, int32_t op, arr *out) {
+  arr a;
+  memset(&a, 0, sizeof a);
+  a.dtype = l->dtype;
+  a.n = l->n;
+  a.valid = xmalloc(l->n);
+  a.values = xmalloc(l->n * 8);
+  for (uint64_t i = 0; i < l->n; ++i) {
+    a.valid[i] = l->valid[i] && r->valid[i];
+    if (!a.valid[i]) { ((int64_t *)a.values)[i] = 0; continue; }
+    if (l->dtype == LLKV_DT_FLOAT64) {
+      double x = ((double *)l->values)[i], y = ((double *)r->values)[i], z = 0;
+      switch (op) {
+      case LLKV_BIN_ADD: z = x + y; break;
+      case LLKV_BIN_SUB: z = x - y; break;
+      case LLKV_BIN_MUL: z = x * y; break;
+      case LLKV_BIN_DIV: if (y == 0.0) { a.valid[i] = 0; } else z = x / y; break;
+      case LLKV_BIN_MOD: if (y == 0.0) { a.valid[i] = 0; } else z = fmod(x, y); break;
+      }
+      ((double *)a.values)[i] = z;
+    } else {
+      int64_t x = ((int64_t *)l->values)[i], y = ((int64_t *)r->values)[i], z = 0;
+      int ovf = 0;
+      switch (op) {
+      case LLKV_BIN_ADD: ovf = __builtin_add_overflow(x, y, &z); break;
+      case LLKV_BIN_SUB: ovf = __builtin_sub_overflow(x, y, &z); break;
+      case LLKV_BIN_MUL: ovf = __builtin_mul_overflow(x, y, &z); break;
+      case LLKV_BIN_DIV: if (y == 0) a.valid[i] = 0; else if (x == INT64_MIN && y == -1) ovf = 1; else z = x / y; break;
+      case LLKV_BIN_MOD: if (y == 0) a.valid[i] = 0; else if (y == -1) z = 0; else z = x % y; break;
+      }
+      if (ovf) { arr_free(&a); return fail(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened on: %lld %s %lld", (long long)x, op == LLKV_BIN_ADD ? "+" : op == LLKV_BIN_SUB ? "-" : op == LLKV_BIN_MUL ? "*" : "/", (long long)y); }
+      ((int64_t *)a.values)[i] = z;
+    }
+  }
+  *out = a;
+  return LLKV_OK;
+}
+
+/* Evaluate a computed projection over gathered columns:
+ * llkv-compute/src/eval.rs:555-614 → NumericFastPath::execute fast_numeric.rs:69-121.
+ * Every column is cast to the final type first, every literal broadcast in the
+ * final type, then one kernel (one temporary) per operator. */
+typedef struct gathered {
+  uint32_t field_id;
+  arr a;
+} gathered;
+
+static const arr *find_gathered(const gathered *g, uint32_t n, uint32_t field_id) {
+  for (uint32_t i = 0; i < n; ++i) if (g[i].field_id == field_id) return &g[i].a;
+  return NULL;
+}
+
+static int32_t eval_program(const orc_table *t, const llkv_expr_token *e, uint32_t n_tok,
+                            const gathered *g, uint32_t n_g, uint64_t len, arr *out) {
+  int has_div, rc;
+  int32_t target = infer_expr_type(t, e, n_tok, &has_div, &rc);
+  if (rc) return rc;
+  if (target != LLKV_DT_FLOAT64) target = target == LLKV_DT_NULL ? LLKV_DT_NULL : LLKV_DT_INT64;
+  if (target == LLKV_DT_NULL) return fail(LLKV_UNSUPPORTED, "non-numeric computed projection");
+  arr st[64];
+  uint32_t sp = 0;
+  rc = LLKV_OK;
+  for (uint32_t i = 0; i < n_tok && rc == LLKV_OK; ++i) {
+    switch (e[i].kind) {
+    case LLKV_TOK_COLUMN: {
+      const arr *src = find_gathered(g, n_g, e[i].field_id);
+      if (!src) { rc = fail(LLKV_INTERNAL, "missing numeric array for fast path"); break; }
+      st[sp++] = cast_to(src, target);
+      break;
+    }
+    case LLKV_TOK_LITERAL: { /* make_literal_array fast_numeric.rs:123-240 */
+      arr a;
+      memset(&a, 0, sizeof a);
+      a.dtype = target; a.n = len; a.valid = xmalloc(len); a.values = xmalloc(len * 8);
+      const llkv_literal *l = &e[i].literal;
+      int isnull = l->tag == LLKV_LIT_NULL;
+      for (uint64_t k = 0; k < len; ++k) {
+        a.valid[k] = !isnull;
+        if (target == LLKV_DT_FLOAT64) ((double *)a.values)[k] = isnull ? 0 : l->tag == LLKV_LIT_FLOAT64 ? l->f64 : (double)lit_i128(l);
+        else ((int64_t *)a.values)[k] = isnull ? 0 : l->tag == LLKV_LIT_FLOAT64 ? (int64_t)l->f64 : (int64_t)lit_i128(l);
+      }
+      st[sp++] = a;
+      break;
+    }
+    case LLKV_TOK_BINARY: {
+      arr r = st[--sp], l = st[--sp], z;
+      rc = binary_kernel(&l, &r, e[i].binop, &z);
+      arr_free(&l); arr_free(&r);
+      if (rc == LLKV_OK) st[sp++] = z;
+      break;
+    }
+    }
+  }
+  if (rc != LLKV_OK) { for (uint32_t i = 0; i < sp; ++i) arr_free(&st[i]); return rc; }
+  *out = st[0];
+  return LLKV_OK;
+}
+
+/* ----------------------------------------------------------------- scan */
+static int is_simple_column(const llkv_expr_token *e, uint32_t n) { return n == 1 && e[0].kind == LLKV_TOK_COLUMN; }
+
+typedef struct proj_plan {
+  int computed;
+  uint32_t field_id;
+  const llkv_expr_token *expr;
+  uint32_t expr_len;
+} proj_plan;
+
+typedef void (*window_cb)(const arr *cols, uint32_t n_cols, const uint64_t *row_ids, uint64_t n, void *user, int32_t *rc);
+
+/* execute_scan llkv-scan/src/execute.rs:47-295; window materialisation
+ * row_stream.rs:369-438,451-623. */
+static int32_t scan_core(const orc_table *t, const proj_plan *projs, uint32_t n_projs,
+                         const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                         uint32_t n_ops, int include_nulls, window_cb cb, void *user) {
+  /* unique fields to gather (direct columns + expression inputs) */
+  uint32_t fields[128], n_fields = 0;
+  for (uint32_t p = 0; p < n_projs; ++p) {
+    uint32_t cnt = projs[p].computed ? projs[p].expr_len : 1;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      uint32_t fid;
+      if (projs[p].computed) { if (projs[p].expr[k].kind != LLKV_TOK_COLUMN) continue; fid = projs[p].expr[k].field_id; }
+      else fid = projs[p].field_id;
+      uint32_t j = 0;
+      while (j < n_fields && fields[j] != fid) ++j;
+      if (j == n_fields) { if (n_fields == 128) return fail(LLKV_INTERNAL, "too many fields"); fields[n_fields++] = fid; }
+    }
+  }
+  for (uint32_t j = 0; j < n_fields; ++j)
+    if (!find_col(t, fields[j])) return fail(LLKV_NOT_FOUND, "field %u not found", fields[j]);
+
+  uint64_t *ids = NULL, n_ids = 0;
+  int32_t rc = orc_filter_row_ids(t, filters, n_filters, ops, n_ops, &ids, &n_ids); /* execute.rs:219 */
+  if (rc) return rc;
+
+  /* all matching row ids are materialised, then cut into 65 536-row windows
+   * (row_stream.rs:243-254,289-299) */
+  for (uint64_t w0 = 0; w0 < n_ids && rc == LLKV_OK; w0 += ROW_STREAM_CHUNK_SIZE) {
+    uint64_t wn = n_ids - w0 < ROW_STREAM_CHUNK_SIZE ? n_ids - w0 : ROW_STREAM_CHUNK_SIZE;
+    uint64_t *wids = xmalloc(wn * sizeof(uint64_t));
+    uint64_t kept = 0;
+    /* GatherNullPolicy::DropNulls — drop rows whose gathered fields are ALL NULL
+     * (store/projection.rs:40-48,1326-1330) */
+    for (uint64_t i = 0; i < wn; ++i) {
+      uint64_t rid = ids[w0 + i];
+      int keep = include_nulls || n_fields == 0;
+      for (uint32_t j = 0; j < n_fields && !keep; ++j) keep = col_valid(find_col(t, fields[j]), rid);
+      if (keep) wids[kept++] = rid;
+    }
+    if (kept == 0) { free(wids); continue; } /* empty batches are not emitted, execute.rs:289-291 */
+    gathered *g = xcalloc(n_fields ? n_fields : 1, sizeof(gathered));
+    for (uint32_t j = 0; j < n_fields; ++j) { g[j].field_id = fields[j]; g[j].a = gather_column(find_col(t, fields[j]), wids, kept); }
+    arr *outs = xcalloc(n_projs ? n_projs : 1, sizeof(arr));
+    uint8_t *owned = xcalloc(n_projs ? n_projs : 1, 1);
+    for (uint32_t p = 0; p < n_projs && rc == LLKV_OK; ++p) {
+      if (!projs[p].computed) outs[p] = *find_gathered(g, n_fields, projs[p].field_id);
+      else { rc = eval_program(t, projs[p].expr, projs[p].expr_len, g, n_fields, kept, &outs[p]); owned[p] = rc == LLKV_OK; }
+    }
+    if (rc == LLKV_OK) cb(outs, n_projs, wids, kept, user, &rc);
+    for (uint32_t p = 0; p < n_projs; ++p) if (owned[p]) arr_free(&outs[p]);
+    for (uint32_t j = 0; j < n_fields; ++j) arr_free(&g[j].a);
+    free(outs); free(owned); free(g); free(wids);
+  }
+  free(ids);
+  return rc;
+}
+
+typedef struct stream_ctx {
+  orc_on_batch cb;
+  void *user;
+  int include_row_ids;
+} stream_ctx;
+
+static void stream_window(const arr *cols, uint32_t n_cols, const uint64_t *row_ids, uint64_t n, void *user, int32_t *rc) {
+  (void)rc;
+  stream_ctx *s = user;
+  orc_batch_column *bc = xcalloc(n_cols ? n_cols : 1, sizeof *bc);
+  for (uint32_t i = 0; i < n_cols; ++i) {
+    bc[i].dtype = cols[i].dtype;
+    bc[i].values = cols[i].values;
+    bc[i].valid = cols[i].valid;
+    bc[i].strings = (const char *const *)cols[i].strings;
+  }
+  orc_batch b = {n, n_cols, bc, s->include_row_ids ? row_ids : NULL};
+  s->cb(&b, s->user);
+  free(bc);
+}
+
+int32_t orc_scan_stream(const orc_table *t, const llkv_projection *projections, uint32_t n_projections,
+                        const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                        uint32_t n_ops, const llkv_scan_options *options, orc_on_batch on_batch, void *user) {
+  if (n_projections == 0) return fail(LLKV_INVALID_ARGUMENT, "scan requires at least one projection");
+  proj_plan *pp = xcalloc(n_projections, sizeof *pp);
+  for (uint32_t i = 0; i < n_projections; ++i) {
+    pp[i].computed = projections[i].computed;
+    pp[i].field_id = projections[i].field_id;
+    pp[i].expr = projections[i].expr;
+    pp[i].expr_len = projections[i].expr_len;
+  }
+  stream_ctx s = {on_batch, user, options ? options->include_row_ids : 0};
+  int32_t rc = scan_core(t, pp, n_projections, filters, n_filters, ops, n_ops, options ? options->include_nulls : 0, stream_window, &s);
+  free(pp);
+  return rc;
+}
+
+/* ------------------------------------------------------------ accumulators */
+/* llkv-aggregate/src/lib.rs: state :95-249, update :759-1477, finalize :1488-1939. */
+enum {
+  ACC_COUNT_STAR, ACC_COUNT_COLUMN, ACC_SUM_I64, ACC_SUM_F64, ACC_TOTAL_I64, ACC_TOTAL_F64,
+  ACC_AVG_I64, ACC_AVG_F64, ACC_MIN_I64, ACC_MIN_F64, ACC_MAX_I64, ACC_MAX_F64, ACC_COUNT_NULLS
+};
+typedef struct acc {
+  int kind;
+  int64_t i;      /* count / i64 sum / min / max */
+  double f;       /* f64 sum / min / max */
+  int64_t count;  /* avg count, count_nulls total rows */
+  int has;        /* has_values / saw_value / Some(..) */
+} acc;
+
+/* array_value_to_numeric :400-449 */
+static int32_t value_to_numeric(const arr *a, uint64_t i, double *out) {
+  switch (a->dtype) {
+  case LLKV_DT_INT64: *out = (double)((int64_t *)a->values)[i]; return LLKV_OK;
+  case LLKV_DT_FLOAT64: *out = ((double *)a->values)[i]; return LLKV_OK;
+  case LLKV_DT_UTF8: { /* SQLite behaviour: parse, non-numeric → 0.0 */
+    const char *s = a->strings[i];
+    while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r') ++s;
+    char *end;
+    double v = strtod(s, &end);
+    while (*end == ' ' || *end == '\t' || *end == '\n' || *end == '\r') ++end;
+    *out = (end == s || *end) ? 0.0 : v;
+    return LLKV_OK;
+  }
+  case LLKV_DT_BOOLEAN: *out = ((uint8_t *)a->values)[i] ? 1.0 : 0.0; return LLKV_OK;
+  default: return fail(LLKV_INVALID_ARGUMENT, "Numeric coercion not supported for column type %s", dtype_name(a->dtype));
+  }
+}
+
+/* kind selection: new_with_projection_index :463-748 after validate_aggregate_type
+ * (llkv-executor/src/lib.rs:5946-5988). */
+static int32_t acc_new(int32_t agg_kind, int32_t input_dtype, acc *out) {
+  memset(out, 0, sizeof *out);
+  if (agg_kind == LLKV_AGG_COUNT_STAR) { out->kind = ACC_COUNT_STAR; return LLKV_OK; }
+  if (agg_kind == LLKV_AGG_COUNT) { out->kind = ACC_COUNT_COLUMN; return LLKV_OK; }
+  if (agg_kind == LLKV_AGG_COUNT_NULLS) { out->kind = ACC_COUNT_NULLS; return LLKV_OK; }
+  const char *fn = agg_kind == LLKV_AGG_SUM ? "SUM" : agg_kind == LLKV_AGG_TOTAL ? "TOTAL" : agg_kind == LLKV_AGG_AVG ? "AVG" : agg_kind == LLKV_AGG_MIN ? "MIN" : "MAX";
+  int32_t dt;
+  switch (input_dtype) {
+  case LLKV_DT_INT64: case LLKV_DT_FLOAT64: dt = input_dtype; break;
+  case LLKV_DT_UTF8: case LLKV_DT_BOOLEAN: case LLKV_DT_DATE32: case LLKV_DT_NULL: dt = LLKV_DT_FLOAT64; break;
+  default: return fail(LLKV_INVALID_ARGUMENT, "%s aggregate not supported for column type %s", fn, dtype_name(input_dtype));
+  }
+  int is_i = dt == LLKV_DT_INT64;
+  switch (agg_kind) {
+  case LLKV_AGG_SUM: out->kind = is_i ? ACC_SUM_I64 : ACC_SUM_F64; break;
+  case LLKV_AGG_TOTAL: out->kind = is_i ? ACC_TOTAL_I64 : ACC_TOTAL_F64; break;
+  case LLKV_AGG_AVG: out->kind = is_i ? ACC_AVG_I64 : ACC_AVG_F64; break;
+  case LLKV_AGG_MIN: out->kind = is_i ? ACC_MIN_I64 : ACC_MIN_F64; break;
+  case LLKV_AGG_MAX: out->kind = is_i ? ACC_MAX_I64 : ACC_MAX_F64; break;
+  default: return fail(LLKV_UNSUPPORTED, "aggregate kind %d", agg_kind);
+  }
+  return LLKV_OK;
+}
+
+/* update(&RecordBatch) :759-1477 — strictly sequential, arrival order. */
+static int32_t acc_update(acc *a, const arr *col, uint64_t num_rows) {
+  switch (a->kind) {
+  case ACC_COUNT_STAR:
+    if (__builtin_add_overflow(a->i, (int64_t)num_rows, &a->i)) return fail(LLKV_INVALID_ARGUMENT, "COUNT result exceeds i64 range");
+    return LLKV_OK;
+  case ACC_COUNT_COLUMN: {
+    if (col->dtype == LLKV_DT_NULL) return LLKV_OK;
+    int64_t nn = 0;
+    for (uint64_t i = 0; i < col->n; ++i) nn += col->valid[i];
+    if (__builtin_add_overflow(a->i, nn, &a->i)) return fail(LLKV_INVALID_ARGUMENT, "COUNT result exceeds i64 range");
+    return LLKV_OK;
+  }
+  case ACC_COUNT_NULLS:
+    for (uint64_t i = 0; i < col->n; ++i) a->i += col->valid[i];
+    a->count += (int64_t)col->n;
+    return LLKV_OK;
+  case ACC_SUM_I64: case ACC_AVG_I64: case ACC_TOTAL_I64: case ACC_MIN_I64: case ACC_MAX_I64:
+    if (col->dtype == LLKV_DT_NULL) return LLKV_OK;
+    if (col->dtype != LLKV_DT_INT64) {
+      const char *fn = a->kind == ACC_SUM_I64 ? "SUM" : a->kind == ACC_AVG_I64 ? "AVG" : a->kind == ACC_TOTAL_I64 ? "TOTAL" : a->kind == ACC_MIN_I64 ? "MIN" : "MAX";
+      return fail(LLKV_INVALID_ARGUMENT, "%s aggregate expected an INT column in execution", fn);
+    }
+    for (uint64_t i = 0; i < col->n; ++i) {
+      if (!col->valid[i]) continue;
+      int64_t v = ((int64_t *)col->values)[i];
+      switch (a->kind) {
+      case ACC_SUM_I64: /* :801-830 checked_add */
+        a->has = 1;
+        if (__builtin_add_overflow(a->i, v, &a->i)) return fail(LLKV_INVALID_ARGUMENT, "integer overflow");
+        break;
+      case ACC_AVG_I64: /* :1114-1144 */
+        if (__builtin_add_overflow(a->i, v, &a->i)) return fail(LLKV_INVALID_ARGUMENT, "AVG aggregate sum exceeds i64 range");
+        a->count += 1;
+        break;
+      case ACC_TOTAL_I64: a->f += (double)v; break; /* :968-988 */
+      case ACC_MIN_I64: a->i = a->has ? (v < a->i ? v : a->i) : v; a->has = 1; break;
+      case ACC_MAX_I64: a->i = a->has ? (v > a->i ? v : a->i) : v; a->has = 1; break;
+      }
+    }
+    return LLKV_OK;
+  default: /* Float64 accumulators with numeric coercion */
+    if (col->dtype == LLKV_DT_NULL) return LLKV_OK;
+    for (uint64_t i = 0; i < col->n; ++i) {
+      if (!col->valid[i]) continue;
+      double v = 0;
+      int32_t rc = value_to_numeric(col, i, &v);
+      if (rc) return rc;
+      switch (a->kind) {
+      case ACC_SUM_F64: a->f += v; a->has = 1; break;      /* :870-888 */
+      case ACC_TOTAL_F64: a->f += v; break;                /* :1015-1034 */
+      case ACC_AVG_F64: a->f += v; a->count += 1; break;   /* :1177-1199 */
+      case ACC_MIN_F64: /* :1309-1331 partial_cmp strictly Less */
+        if (!a->has) { a->f = v; a->has = 1; } else if (v < a->f) a->f = v;
+        break;
+      case ACC_MAX_F64: /* :1377-1399 */
+        if (!a->has) { a->f = v; a->has = 1; } else if (v > a->f) a->f = v;
+        break;
+      }
+    }
+    return LLKV_OK;
+  }
+}
+
+/* finalize :1488-1939 */
+static void acc_finalize(const acc *a, llkv_value *out) {
+  memset(out, 0, sizeof *out);
+  switch (a->kind) {
+  case ACC_COUNT_STAR: case ACC_COUNT_COLUMN: out->dtype = LLKV_DT_INT64; out->i64 = a->i; break;
+  case ACC_COUNT_NULLS: out->dtype = LLKV_DT_INT64; out->i64 = a->count - a->i; break;
+  case ACC_SUM_I64: out->dtype = LLKV_DT_INT64; out->is_null = !a->has; out->i64 = a->has ? a->i : 0; break;
+  case ACC_SUM_F64: out->dtype = LLKV_DT_FLOAT64; out->is_null = !a->has; out->f64 = a->has ? a->f : 0; break;
+  case ACC_TOTAL_I64: case ACC_TOTAL_F64: out->dtype = LLKV_DT_FLOAT64; out->f64 = a->f; break;
+  case ACC_AVG_I64: out->dtype = LLKV_DT_FLOAT64; out->is_null = a->count <= 0; if (a->count > 0) out->f64 = (double)a->i / (double)a->count; break;
+  case ACC_AVG_F64: out->dtype = LLKV_DT_FLOAT64; out->is_null = a->count <= 0; if (a->count > 0) out->f64 = a->f / (double)a->count; break;
+  case ACC_MIN_I64: case ACC_MAX_I64: out->dtype = LLKV_DT_INT64; out->is_null = !a->has; out->i64 = a->has ? a->i : 0; break;
+  case ACC_MIN_F64: case ACC_MAX_F64: out->dtype = LLKV_DT_FLOAT64; out->is_null = !a->has; out->f64 = a->has ? a->f : 0; break;
+  }
+}
+
+/* -------------------------------------------------- ungrouped aggregates */
+typedef struct agg_ctx {
+  acc *accs;
+  const int32_t *proj_of_agg; /* -1 for COUNT(*) */
+  uint32_t n_aggs;
+} agg_ctx;
+
+static void agg_window(const arr *cols, uint32_t n_cols, const uint64_t *row_ids, uint64_t n, void *user, int32_t *rc) {
+  (void)row_ids; (void)n_cols;
+  agg_ctx *c = user;
+  /* for state in states { state.update(&batch) } llkv-executor/src/lib.rs:5633-5643 */
+  for (uint32_t i = 0; i < c->n_aggs && *rc == LLKV_OK; ++i) {
+    arr dummy;
+    memset(&dummy, 0, sizeof dummy);
+    const arr *col = c->proj_of_agg[i] >= 0 ? &cols[c->proj_of_agg[i]] : &dummy;
+    *rc = acc_update(&c->accs[i], col, n);
+  }
+}
+
+/* execute_aggregates llkv-executor/src/lib.rs:5357-5682 (bare columns) and
+ * compute_aggregate_values :6087-6665 (aggregate arguments that are expressions
+ * become computed scan projections, ensure_computed_projection :470-501).
+ * Scan options: include_nulls = true (:5569-5576). */
+int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
+                      const llkv_eval_op *ops, uint32_t n_ops, const llkv_aggregate_spec *aggs,
+                      uint32_t n_aggs, llkv_value *out_values) {
+  if (n_aggs == 0) return fail(LLKV_INVALID_ARGUMENT, "aggregate query requires at least one aggregate expression");
+  acc *accs = xcalloc(n_aggs, sizeof(acc));
+  int32_t *proj_of = xcalloc(n_aggs, sizeof(int32_t));
+  proj_plan *projs = xcalloc(n_aggs + 1, sizeof(proj_plan));
+  uint32_t n_projs = 0;
+  int32_t rc = LLKV_OK;
+  for (uint32_t i = 0; i < n_aggs && rc == LLKV_OK; ++i) {
+    if (aggs[i].distinct) { rc = fail(LLKV_UNSUPPORTED, "DISTINCT aggregates are out of scope"); break; }
+    if (aggs[i].kind == LLKV_AGG_COUNT_STAR) { proj_of[i] = -1; rc = acc_new(aggs[i].kind, LLKV_DT_NULL, &accs[i]); continue; }
+    int has_div;
+    int32_t dt = infer_expr_type(t, aggs[i].expr, aggs[i].expr_len, &has_div, &rc);
+    if (rc) break;
+    if (!is_simple_column(aggs[i].expr, aggs[i].expr_len) && dt != LLKV_DT_FLOAT64) dt = LLKV_DT_INT64;
+    rc = acc_new(aggs[i].kind, dt, &accs[i]);
+    if (rc) break;
+    proj_of[i] = (int32_t)n_projs;
+    projs[n_projs].computed = !is_simple_column(aggs[i].expr, aggs[i].expr_len);
+    projs[n_projs].field_id = aggs[i].expr[0].field_id;
+    projs[n_projs].expr = aggs[i].expr;
+    projs[n_projs].expr_len = aggs[i].expr_len;
+    ++n_projs;
+  }
+  if (rc == LLKV_OK) {
+    if (n_projs == 0) { /* COUNT(*) only: the scan still needs a column to drive row ids */
+      uint64_t *ids = NULL, n_ids = 0;
+      rc = orc_filter_row_ids(t, filters, n_filters, ops, n_ops, &ids, &n_ids);
+      if (rc == LLKV_OK) for (uint32_t i = 0; i < n_aggs && rc == LLKV_OK; ++i) { arr d; memset(&d, 0, sizeof d); rc = acc_update(&accs[i], &d, n_ids); }
+      free(ids);
+    } else {
+      agg_ctx c = {accs, proj_of, n_aggs};
+      rc = scan_core(t, projs, n_projs, filters, n_filters, ops, n_ops, /*include_nulls=*/1, agg_window, &c);
+      if (rc == LLKV_NOT_FOUND) rc = LLKV_OK; /* NotFound = empty table, :5646-5650 */
+    }
+  }
+  if (rc == LLKV_OK) for (uint32_t i = 0; i < n_aggs; ++i) acc_finalize(&accs[i], &out_values[i]);
+  free(accs); free(proj_of); free(projs);
+  return rc;
+}
+
+/* ------------------------------------------------------------- GROUP BY */
+/* PlanValue (llkv-plan/src/plans.rs:1038-1061) restricted to this path. */
+enum { PV_NULL, PV_INT, PV_FLOAT, PV_STR };
+typedef struct pval { int tag; int64_t i; double f; const char *s; } pval;
+
+static pval pv_from_arr(const arr *a, uint64_t i) {
+  pval v = {PV_NULL, 0, 0, NULL};
+  if (!a->valid[i]) return v;
+  switch (a->dtype) {
+  case LLKV_DT_INT64: v.tag = PV_INT; v.i = ((int64_t *)a->values)[i]; break;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: v.tag = PV_INT; v.i = ((int32_t *)a->values)[i]; break;
+  case LLKV_DT_UINT32: v.tag = PV_INT; v.i = ((uint32_t *)a->values)[i]; break;
+  case LLKV_DT_UINT64: v.tag = PV_INT; v.i = (int64_t)((uint64_t *)a->values)[i]; break;
+  case LLKV_DT_FLOAT64: v.tag = PV_FLOAT; v.f = ((double *)a->values)[i]; break;
+  case LLKV_DT_FLOAT32: v.tag = PV_FLOAT; v.f = ((float *)a->values)[i]; break;
+  case LLKV_DT_UTF8: v.tag = PV_STR; v.s = a->strings[i]; break;
+  default: break;
+  }
+  return v;
+}
+
+/* Rust `f64 as i64`: saturating, NaN → 0. */
+static int64_t f64_as_i64(double x) {
+  if (x != x) return 0;
+  if (x >= 9223372036854775808.0) return INT64_MAX;
+  if (x <= -9223372036854775808.0) return INT64_MIN;
+  return (int64_t)x;
+}
+
+/* evaluate_expr_with_plan_value_aggregates_and_row, Binary arm:
+ * llkv-executor/src/lib.rs:7193-7389.  Int∘Int for + - * is computed in f64 and cast
+ * back to i64 (:7338-7389); Int/Int truncates, i64::MIN / -1 → Float (:7213-7227);
+ * x/0, x%0 → NULL; NULL propagates. */
+static int32_t pv_binary(pval l, pval r, int32_t op, pval *out) {
+  pval z = {PV_NULL, 0, 0, NULL};
+  if (l.tag == PV_NULL || r.tag == PV_NULL) { *out = z; return LLKV_OK; }
+  if (l.tag == PV_STR || r.tag == PV_STR) return fail(LLKV_INVALID_ARGUMENT, "Non-numeric value in binary operation");
+  if (op == LLKV_BIN_DIV && l.tag == PV_INT && r.tag == PV_INT) {
+    if (r.i == 0) { *out = z; return LLKV_OK; }
+    if (l.i == INT64_MIN && r.i == -1) { z.tag = PV_FLOAT; z.f = (double)l.i / (double)r.i; *out = z; return LLKV_OK; }
+    z.tag = PV_INT; z.i = l.i / r.i; *out = z; return LLKV_OK;
+  }
+  int lf = l.tag == PV_FLOAT, rf = r.tag == PV_FLOAT;
+  double a = lf ? l.f : (double)l.i, b = rf ? r.f : (double)r.i, res = 0;
+  switch (op) {
+  case LLKV_BIN_ADD: res = a + b; break;
+  case LLKV_BIN_SUB: res = a - b; break;
+  case LLKV_BIN_MUL: res = a * b; break;
+  case LLKV_BIN_DIV: if (b == 0.0) { *out = z; return LLKV_OK; } res = a / b; break;
+  case LLKV_BIN_MOD: if (b == 0.0) { *out = z; return LLKV_OK; } res = fmod(a, b); break;
+  default: return fail(LLKV_INTERNAL, "bad binary op");
+  }
+  if (op == LLKV_BIN_DIV || lf || rf) { z.tag = PV_FLOAT; z.f = res; }
+  else { z.tag = PV_INT; z.i = f64_as_i64(res); }
+  *out = z;
+  return LLKV_OK;
+}
+
+static int32_t pv_eval(const llkv_expr_token *e, uint32_t n, const gathered *g, uint32_t n_g, uint64_t row, pval *out) {
+  pval st[64];
+  uint32_t sp = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    switch (e[i].kind) {
+    case LLKV_TOK_COLUMN: {
+      const arr *a = find_gathered(g, n_g, e[i].field_id);
+      if (!a) return fail(LLKV_INVALID_ARGUMENT, "column not found for aggregate");
+      st[sp++] = pv_from_arr(a, row);
+      break;
+    }
+    case LLKV_TOK_LITERAL: {
+      pval v = {PV_NULL, 0, 0, NULL};
+      const llkv_literal *l = &e[i].literal;
+      if (l->tag == LLKV_LIT_INT128) { v.tag = PV_INT; v.i = (int64_t)lit_i128(l); }
+      else if (l->tag == LLKV_LIT_FLOAT64) { v.tag = PV_FLOAT; v.f = l->f64; }
+      else if (l->tag != LLKV_LIT_NULL) return fail(LLKV_UNSUPPORTED, "literal kind in aggregate expression");
+      st[sp++] = v;
+      break;
+    }
+    case LLKV_TOK_BINARY: {
+      pval r = st[--sp], l = st[--sp], z;
+      int32_t rc = pv_binary(l, r, e[i].binop, &z);
+      if (rc) return rc;
+      st[sp++] = z;
+      break;
+    }
+    }
+  }
+  *out = st[0];
+  return LLKV_OK;
+}
+
+/* GroupKeyValue llkv-executor/src/lib.rs:99-106; group_key_value :9362-9456:
+ * every integer width and Date32 collapse to Int, Utf8 → owned String, NULL is its
+ * own key; Float keys are rejected. */
+typedef struct gkey { int tag; int64_t i; char *s; } gkey; /* tag: PV_NULL / PV_INT / PV_STR */
+
+struct orc_groups {
+  uint32_t n_groups, n_keys, n_aggs;
+  gkey *keys;        /* [n_groups][n_keys] */
+  llkv_value *vals;  /* [n_groups][n_aggs] */
+};
+
+uint32_t orc_groups_len(const orc_groups *g) { return g->n_groups; }
+int32_t orc_groups_key(const orc_groups *g, uint32_t group, uint32_t key, llkv_value *out) {
+  if (group >= g->n_groups || key >= g->n_keys) return fail(LLKV_INVALID_ARGUMENT, "index out of range");
+  const gkey *k = &g->keys[(size_t)group * g->n_keys + key];
+  memset(out, 0, sizeof *out);
+  out->is_null = k->tag == PV_NULL;
+  out->dtype = k->tag == PV_STR ? LLKV_DT_UTF8 : LLKV_DT_INT64;
+  out->i64 = k->i;
+  out->str = k->s;
+  return LLKV_OK;
+}
+int32_t orc_groups_value(const orc_groups *g, uint32_t group, uint32_t agg, llkv_value *out) {
+  if (group >= g->n_groups || agg >= g->n_aggs) return fail(LLKV_INVALID_ARGUMENT, "index out of range");
+  *out = g->vals[(size_t)group * g->n_aggs + agg];
+  return LLKV_OK;
+}
+void orc_groups_free(orc_groups *g) {
+  if (!g) return;
+  for (size_t i = 0; i < (size_t)g->n_groups * g->n_keys; ++i) free(g->keys[i].s);
+  free(g->keys); free(g->vals); free(g);
+}
+
+static int gkey_eq(const gkey *a, const gkey *b, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    if (a[i].tag != b[i].tag) return 0;
+    if (a[i].tag == PV_INT && a[i].i != b[i].i) return 0;
+    if (a[i].tag == PV_STR && strcmp(a[i].s, b[i].s)) return 0;
+  }
+  return 1;
+}
+static uint64_t gkey_hash(const gkey *a, uint32_t n) {
+  uint64_t h = 0xcbf29ce484222325ULL;
+  for (uint32_t i = 0; i < n; ++i) {
+    h = (h ^ (uint64_t)a[i].tag) * 0x100000001b3ULL;
+    if (a[i].tag == PV_INT) h = (h ^ (uint64_t)a[i].i) * 0x100000001b3ULL;
+    else if (a[i].tag == PV_STR) for (const char *p = a[i].s; *p; ++p) h = (h ^ (uint8_t)*p) * 0x100000001b3ULL;
+  }
+  return h;
+}
+/* lexsort ascending, NULLs first (arrow SortOptions default of the reference's
+ * ORDER BY ASC, llkv-executor/src/lib.rs:13762-13868) */
+static int gkey_cmp(const gkey *a, const gkey *b, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    if (a[i].tag == PV_NULL || b[i].tag == PV_NULL) { if (a[i].tag != b[i].tag) return a[i].tag == PV_NULL ? -1 : 1; continue; }
+    if (a[i].tag == PV_INT) { if (a[i].i != b[i].i) return a[i].i < b[i].i ? -1 : 1; }
+    else { int c = strcmp(a[i].s, b[i].s); if (c) return c; }
+  }
+  return 0;
+}
+
+typedef struct gb_rows {
+  gathered *cols; /* every needed field, all filtered rows materialised (:4512-4524) */
+  uint32_t n_cols;
+  uint64_t n, cap;
+} gb_rows;
+
+static void gb_window(const arr *cols, uint32_t n_cols, const uint64_t *row_ids, uint64_t n, void *user, int32_t *rc) {
+  (void)row_ids; (void)rc;
+  gb_rows *m = user;
+  if (m->n + n > m->cap) {
+    m->cap = (m->n + n) * 2;
+    for (uint32_t j = 0; j < n_cols; ++j) {
+      arr *a = &m->cols[j].a;
+      size_t w = dtype_width(a->dtype);
+      if (w) a->values = xrealloc(a->values, m->cap * w);
+      a->valid = xrealloc(a->valid, m->cap);
+      if (a->dtype == LLKV_DT_UTF8) a->strings = xrealloc(a->strings, m->cap * sizeof(char *));
+    }
+  }
+  for (uint32_t j = 0; j < n_cols; ++j) {
+    arr *a = &m->cols[j].a;
+    size_t w = dtype_width(a->dtype);
+    if (w) memcpy((char *)a->values + m->n * w, cols[j].values, n * w);
+    memcpy(a->valid + m->n, cols[j].valid, n);
+    if (a->dtype == LLKV_DT_UTF8) for (uint64_t i = 0; i < n; ++i) a->strings[m->n + i] = strdup(cols[j].strings[i]);
+    a->n = m->n + n;
+  }
+  m->n += n;
+}
+
+int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
+                    const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
+                    const llkv_aggregate_spec *aggs, uint32_t n_aggs, int32_t order_by_keys, orc_groups **out) {
+  if (n_keys == 0) return fail(LLKV_INVALID_ARGUMENT, "GROUP BY requires at least one key");
+  /* fields to materialise: keys + aggregate inputs (the reference materialises every
+   * table column, :4454; the unused ones do not influence the result) */
+  uint32_t fields[128], n_fields = 0;
+#define ADD_FIELD(fid) do { uint32_t _j = 0; while (_j < n_fields && fields[_j] != (fid)) ++_j; if (_j == n_fields) fields[n_fields++] = (fid); } while (0)
+  for (uint32_t k = 0; k < n_keys; ++k) ADD_FIELD(key_fields[k]);
+  for (uint32_t a = 0; a < n_aggs; ++a) for (uint32_t k = 0; k < aggs[a].expr_len; ++k) if (aggs[a].expr[k].kind == LLKV_TOK_COLUMN) ADD_FIELD(aggs[a].expr[k].field_id);
+#undef ADD_FIELD
+  proj_plan *projs = xcalloc(n_fields, sizeof *projs);
+  gb_rows m = {xcalloc(n_fields, sizeof(gathered)), n_fields, 0, 0};
+  for (uint32_t j = 0; j < n_fields; ++j) {
+    const orc_column *c = find_col(t, fields[j]);
+    if (!c) { free(projs); free(m.cols); return fail(LLKV_INVALID_ARGUMENT, "column %u not found in GROUP BY input", fields[j]); }
+    projs[j].field_id = fields[j];
+    m.cols[j].field_id = fields[j];
+    m.cols[j].a.dtype = c->dtype;
+  }
+  int32_t rc = scan_core(t, projs, n_fields, filters, n_filters, ops, n_ops, /*include_nulls=*/1, gb_window, &m);
+  free(projs);
+
+  /* pass 1: per-row key → group index in first-appearance order (:5065-5089) */
+  uint32_t n_groups = 0, cap_groups = 16;
+  gkey *gkeys = xcalloc((size_t)cap_groups * n_keys, sizeof(gkey));
+  uint32_t *group_of_row = xmalloc((m.n ? m.n : 1) * sizeof(uint32_t));
+  uint64_t tab_cap = 1024;
+  int64_t *tab = xmalloc(tab_cap * sizeof(int64_t));
+  memset(tab, 0xff, tab_cap * sizeof(int64_t));
+  gkey *cur = xcalloc(n_keys, sizeof(gkey));
+  for (uint64_t r = 0; r < m.n && rc == LLKV_OK; ++r) {
+    for (uint32_t k = 0; k < n_keys; ++k) {
+      const arr *a = find_gathered(m.cols, n_fields, key_fields[k]);
+      pval v = pv_from_arr(a, r);
+      if (v.tag == PV_FLOAT) { rc = fail(LLKV_INVALID_ARGUMENT, "GROUP BY does not support column type %s", dtype_name(a->dtype)); break; }
+      cur[k].tag = v.tag; cur[k].i = v.i; cur[k].s = (char *)v.s;
+    }
+    if (rc) break;
+    uint64_t h = gkey_hash(cur, n_keys) & (tab_cap - 1);
+    for (;;) {
+      if (tab[h] < 0) {
+        if (n_groups == cap_groups) { cap_groups *= 2; gkeys = xrealloc(gkeys, (size_t)cap_groups * n_keys * sizeof(gkey)); }
+        for (uint32_t k = 0; k < n_keys; ++k) { gkey *d = &gkeys[(size_t)n_groups * n_keys + k]; *d = cur[k]; if (d->tag == PV_STR) d->s = strdup(cur[k].s); }
+        tab[h] = n_groups;
+        group_of_row[r] = n_groups++;
+        if ((uint64_t)n_groups * 2 > tab_cap) { /* rehash */
+          tab_cap *= 4; tab = xrealloc(tab, tab_cap * sizeof(int64_t)); memset(tab, 0xff, tab_cap * sizeof(int64_t));
+          for (uint32_t g = 0; g < n_groups; ++g) { uint64_t hh = gkey_hash(&gkeys[(size_t)g * n_keys], n_keys) & (tab_cap - 1); while (tab[hh] >= 0) hh = (hh + 1) & (tab_cap - 1); tab[hh] = g; }
+        }
+        break;
+      }
+      if (gkey_eq(&gkeys[(size_t)tab[h] * n_keys], cur, n_keys)) { group_of_row[r] = (uint32_t)tab[h]; break; }
+      h = (h + 1) & (tab_cap - 1);
+    }
+  }
+  free(cur); free(tab);
+
+  /* pass 2: per group, rows in scan order; per aggregate a fresh AggregateState fed
+   * either the bare column or the per-row PlanValue results (:5101-5252) */
+  llkv_value *vals = xcalloc((size_t)(n_groups ? n_groups : 1) * (n_aggs ? n_aggs : 1), sizeof(llkv_value));
+  if (rc == LLKV_OK) {
+    /* bucket rows by group, preserving order */
+    uint64_t *start = xcalloc((size_t)n_groups + 1, sizeof(uint64_t));
+    for (uint64_t r = 0; r < m.n; ++r) start[group_of_row[r] + 1]++;
+    for (uint32_t g = 0; g < n_groups; ++g) start[g + 1] += start[g];
+    uint64_t *fill = xmalloc(((size_t)n_groups + 1) * sizeof(uint64_t));
+    memcpy(fill, start, ((size_t)n_groups + 1) * sizeof(uint64_t));
+    uint64_t *order = xmalloc((m.n ? m.n : 1) * sizeof(uint64_t));
+    for (uint64_t r = 0; r < m.n; ++r) order[fill[group_of_row[r]]++] = r;
+    for (uint32_t g = 0; g < n_groups && rc == LLKV_OK; ++g) {
+      uint64_t gn = start[g + 1] - start[g];
+      const uint64_t *rows = order + start[g];
+      for (uint32_t a = 0; a < n_aggs && rc == LLKV_OK; ++a) {
+        acc st;
+        arr col;
+        memset(&col, 0, sizeof col);
+        if (aggs[a].distinct) { rc = fail(LLKV_UNSUPPORTED, "DISTINCT aggregates are out of scope"); break; }
+        if (aggs[a].kind == LLKV_AGG_COUNT_STAR) {
+          rc = acc_new(aggs[a].kind, LLKV_DT_NULL, &st);
+          if (rc == LLKV_OK) rc = acc_update(&st, &col, gn);
+        } else if (is_simple_column(aggs[a].expr, aggs[a].expr_len)) {
+          const arr *src = find_gathered(m.cols, n_fields, aggs[a].expr[0].field_id);
+          rc = acc_new(aggs[a].kind, src->dtype, &st);
+          if (rc) break;
+          /* arrow `take` of the group's rows (:5131-5146) */
+          col.dtype = src->dtype; col.n = gn; col.valid = xmalloc(gn ? gn : 1);
+          size_t w = dtype_width(src->dtype);
+          col.values = xmalloc((gn ? gn : 1) * (w ? w : 1));
+          if (src->dtype == LLKV_DT_UTF8) col.strings = xcalloc(gn ? gn : 1, sizeof(char *));
+          for (uint64_t i = 0; i < gn; ++i) {
+            col.valid[i] = src->valid[rows[i]];
+            if (w) memcpy((char *)col.values + i * w, (char *)src->values + rows[i] * w, w);
+            if (col.strings) col.strings[i] = strdup(src->strings[rows[i]]);
+          }
+          rc = acc_update(&st, &col, gn);
+          arr_free(&col);
+        } else {
+          /* row-by-row PlanValue interpreter (:5186-5199), temp column typed from the
+           * first non-NULL value (plan_values_to_arrow_array :298-406) */
+          pval *pv = xmalloc((gn ? gn : 1) * sizeof(pval));
+          int first = PV_NULL;
+          for (uint64_t i = 0; i < gn && rc == LLKV_OK; ++i) {
+            rc = pv_eval(aggs[a].expr, aggs[a].expr_len, m.cols, n_fields, rows[i], &pv[i]);
+            if (first == PV_NULL && rc == LLKV_OK) first = pv[i].tag;
+          }
+          if (rc == LLKV_OK) {
+            col.n = gn; col.valid = xmalloc(gn ? gn : 1); col.values = xmalloc((gn ? gn : 1) * 8);
+            col.dtype = first == PV_FLOAT ? LLKV_DT_FLOAT64 : first == PV_INT ? LLKV_DT_INT64 : LLKV_DT_NULL;
+            for (uint64_t i = 0; i < gn && rc == LLKV_OK; ++i) {
+              col.valid[i] = pv[i].tag != PV_NULL;
+              if (col.dtype == LLKV_DT_FLOAT64) ((double *)col.values)[i] = pv[i].tag == PV_FLOAT ? pv[i].f : (double)pv[i].i;
+              else if (pv[i].tag == PV_FLOAT) rc = fail(LLKV_INVALID_ARGUMENT, "expected INTEGER plan value, found Float");
+              else ((int64_t *)col.values)[i] = pv[i].i;
+            }
+            if (col.dtype == LLKV_DT_NULL) { col.dtype = LLKV_DT_INT64; } /* new_null_array(Int64) */
+            if (rc == LLKV_OK) rc = acc_new(aggs[a].kind, col.dtype, &st);
+            if (rc == LLKV_OK) rc = acc_update(&st, &col, gn);
+            arr_free(&col);
+          }
+          free(pv);
+        }
+        if (rc == LLKV_OK) acc_finalize(&st, &vals[(size_t)g * n_aggs + a]);
+      }
+    }
+    free(start); free(fill); free(order);
+  }
+  free(group_of_row);
+  for (uint32_t j = 0; j < n_fields; ++j) arr_free(&m.cols[j].a);
+  free(m.cols);
+  if (rc != LLKV_OK) { for (size_t i = 0; i < (size_t)n_groups * n_keys; ++i) free(gkeys[i].s); free(gkeys); free(vals); return rc; }
+
+  orc_groups *res = xcalloc(1, sizeof *res);
+  res->n_groups = n_groups; res->n_keys = n_keys; res->n_aggs = n_aggs;
+  res->keys = gkeys; res->vals = vals;
+  if (order_by_keys && n_groups > 1) { /* insertion sort: stable, tiny result */
+    for (uint32_t i = 1; i < n_groups; ++i)
+      for (uint32_t j = i; j > 0 && gkey_cmp(&gkeys[(size_t)(j - 1) * n_keys], &gkeys[(size_t)j * n_keys], n_keys) > 0; --j) {
+        for (uint32_t k = 0; k < n_keys; ++k) { gkey tmp = gkeys[(size_t)(j - 1) * n_keys + k]; gkeys[(size_t)(j - 1) * n_keys + k] = gkeys[(size_t)j * n_keys + k]; gkeys[(size_t)j * n_keys + k] = tmp; }
+        for (uint32_t a = 0; a < n_aggs; ++a) { llkv_value tmp = vals[(size_t)(j - 1) * n_aggs + a]; vals[(size_t)(j - 1) * n_aggs + a] = vals[(size_t)j * n_aggs + a]; vals[(size_t)j * n_aggs + a] = tmp; }
+      }
+  }
+  *out = res;
+  return LLKV_OK;
+}
+
+/* --------------------------------------------------------------- hash join */
+/* Integer fast path llkv-join/src/hash_join.rs:955-1417: build on the right table
+ * (:209-215) — FxHashMap<key, Vec<RowRef>> in scan order (:1080-1137); probe the
+ * left in scan order (:1141-1214); NULL keys never match unless null_equals_null,
+ * which uses the sentinel i64::MIN (:1116-1123,1429,1441); batches of ≥ batch_size
+ * pairs are flushed after finishing a probe row (:1181-1193). */
+typedef struct jt_entry { int64_t key; uint64_t head, tail; int used; } jt_entry;
+
+static int32_t join_key_value(const orc_column *c, uint64_t row, int null_eq, int64_t *out) {
+  if (!col_valid(c, row)) { if (!null_eq) return 0; *out = INT64_MIN; return 1; }
+  switch (c->dtype) {
+  case LLKV_DT_INT64: *out = ((const int64_t *)c->values)[row]; return 1;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: *out = ((const int32_t *)c->values)[row]; return 1;
+  case LLKV_DT_UINT32: *out = ((const uint32_t *)c->values)[row]; return 1;
+  case LLKV_DT_UINT64: *out = (int64_t)((const uint64_t *)c->values)[row]; return 1;
+  default: return 0;
+  }
+}
+
+int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_join_key *keys,
+                      uint32_t n_keys, const llkv_join_options *options, orc_on_join_batch on_batch, void *user) {
+  uint64_t batch_size = options ? options->batch_size : 8192;
+  int jt = options ? options->join_type : LLKV_JOIN_INNER;
+  if (batch_size == 0) return fail(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero"); /* llkv-join/src/lib.rs:284-310 */
+  if (jt == LLKV_JOIN_RIGHT || jt == LLKV_JOIN_FULL) return fail(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented"); /* hash_join.rs:328-332 */
+  if (n_keys != 1) return fail(LLKV_UNSUPPORTED, "only single-key integer joins are restated (n_keys=%u)", n_keys);
+  const orc_column *lc = find_col(left, keys[0].left_field), *rc_ = find_col(right, keys[0].right_field);
+  if (!lc || !rc_) return fail(LLKV_NOT_FOUND, "join key field not found");
+  if (vclass_of(lc->dtype) > VC_U64 || vclass_of(rc_->dtype) > VC_U64 || vclass_of(lc->dtype) < 0 || vclass_of(rc_->dtype) < 0)
+    return fail(LLKV_UNSUPPORTED, "non-integer join key");
+  int null_eq = keys[0].null_equals_null;
+
+  /* build: open addressing on key, chained row lists in insertion order */
+  uint64_t cap = 16;
+  while (cap < right->rows * 2 + 16) cap <<= 1;
+  jt_entry *tab = xcalloc(cap, sizeof(jt_entry));
+  uint64_t *next = xmalloc((right->rows ? right->rows : 1) * sizeof(uint64_t));
+  for (uint64_t r = 0; r < right->rows; ++r) {
+    int64_t k;
+    next[r] = UINT64_MAX;
+    if (!join_key_value(rc_, r, null_eq, &k)) continue;
+    uint64_t h = ((uint64_t)k * 0x9E3779B97F4A7C15ULL) & (cap - 1);
+    while (tab[h].used && tab[h].key != k) h = (h + 1) & (cap - 1);
+    if (!tab[h].used) { tab[h].used = 1; tab[h].key = k; tab[h].head = tab[h].tail = r; }
+    else { next[tab[h].tail] = r; tab[h].tail = r; }
+  }
+  /* probe */
+  uint64_t *pl = xmalloc((batch_size + right->rows + 1) * sizeof(uint64_t));
+  uint64_t *pr = xmalloc((batch_size + right->rows + 1) * sizeof(uint64_t));
+  uint64_t np = 0;
+  for (uint64_t l = 0; l < left->rows; ++l) {
+    int64_t k;
+    int have = join_key_value(lc, l, null_eq, &k), matched = 0;
+    uint64_t h = 0;
+    if (have) {
+      h = ((uint64_t)k * 0x9E3779B97F4A7C15ULL) & (cap - 1);
+      while (tab[h].used && tab[h].key != k) h = (h + 1) & (cap - 1);
+      matched = tab[h].used;
+    }
+    switch (jt) {
+    case LLKV_JOIN_INNER:
+      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) { pl[np] = l; pr[np] = r; ++np; }
+      break;
+    case LLKV_JOIN_LEFT: /* :1468-1497 unmatched left rows padded with NULLs */
+      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) { pl[np] = l; pr[np] = r; ++np; }
+      else { pl[np] = l; pr[np] = UINT64_MAX; ++np; }
+      break;
+    case LLKV_JOIN_SEMI: if (matched) { pl[np] = l; pr[np] = 0; ++np; } break;
+    case LLKV_JOIN_ANTI: if (!matched) { pl[np] = l; pr[np] = 0; ++np; } break;
+    }
+    if (np >= batch_size) { on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user); np = 0; }
+  }
+  if (np) on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user);
+  free(pl); free(pr); free(next); free(tab);
+  return LLKV_OK;
+}

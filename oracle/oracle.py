@@ -1,0 +1,234 @@
+"""ctypes binding of the CPU oracle (oracle/libllkv_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+abi = importlib.import_module("rust-llkv_amd.abi")
+
+LIB_PATH = os.path.join(_HERE, "libllkv_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+class COrcColumn(C.Structure):
+    _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("values", C.c_void_p), ("validity", C.c_void_p),
+                ("offsets", C.c_void_p), ("data", C.c_void_p)]
+
+
+class COrcTable(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("n_cols", C.c_uint32), ("cols", C.POINTER(COrcColumn))]
+
+
+class COrcBatchColumn(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("values", C.c_void_p), ("valid", C.POINTER(C.c_uint8)),
+                ("strings", C.POINTER(C.c_char_p))]
+
+
+class COrcBatch(C.Structure):
+    _fields_ = [("num_rows", C.c_uint64), ("num_columns", C.c_uint32), ("columns", C.POINTER(COrcBatchColumn)),
+                ("row_ids", C.POINTER(C.c_uint64))]
+
+
+ORC_ON_BATCH = C.CFUNCTYPE(None, C.POINTER(COrcBatch), C.c_void_p)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_free.restype = None
+        L.orc_groups_len.restype = C.c_uint32
+        L.orc_groups_len.argtypes = [C.c_void_p]
+        L.orc_groups_free.argtypes = [C.c_void_p]
+        L.orc_groups_free.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise abi.LlkvError(rc, lib().orc_last_error().decode(errors="replace"))
+
+
+class OracleTable:
+    """In-memory table for the oracle: {field_id: (dtype, values, validity?)}.
+
+    ``values`` for Utf8 is a list of Python strings (None = NULL) or a uint8 array of 1-byte
+    strings; for fixed width a numpy array, with ``None`` entries allowed via ``mask``."""
+
+    def __init__(self, rows: int):
+        self.rows = rows
+        self._cols: List[COrcColumn] = []
+        self._keep: list = []
+
+    def add(self, field_id: int, dtype: int, values, valid: Optional[Sequence[bool]] = None):
+        c = COrcColumn()
+        c.field_id, c.dtype = field_id, dtype
+        if dtype == abi.DT_UTF8:
+            if isinstance(values, np.ndarray) and values.dtype == np.uint8:
+                data = np.ascontiguousarray(values)
+                offsets = np.arange(len(values) + 1, dtype=np.int32)
+            else:
+                enc = [(s or "").encode() for s in values]
+                if valid is None and any(s is None for s in values):
+                    valid = [s is not None for s in values]
+                offsets = np.zeros(len(enc) + 1, dtype=np.int32)
+                np.cumsum([len(e) for e in enc], out=offsets[1:])
+                data = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+            self._keep += [data, offsets]
+            c.offsets, c.data = offsets.ctypes.data, data.ctypes.data
+            assert len(offsets) == self.rows + 1
+        else:
+            arr = np.ascontiguousarray(values, dtype=np.dtype(abi.NUMPY_OF_DTYPE[dtype]))
+            assert len(arr) == self.rows, (len(arr), self.rows)
+            self._keep.append(arr)
+            c.values = arr.ctypes.data
+        if valid is not None:
+            bits = np.packbits(np.asarray(valid, dtype=bool), bitorder="little")
+            self._keep.append(bits)
+            c.validity = bits.ctypes.data
+        self._cols.append(c)
+        return self
+
+    def c(self) -> COrcTable:
+        arr = (COrcColumn * max(1, len(self._cols)))(*self._cols)
+        self._keep.append(arr)
+        t = COrcTable()
+        t.rows, t.n_cols, t.cols = self.rows, len(self._cols), arr
+        return t
+
+
+def filter_row_ids(table: OracleTable, predicate) -> np.ndarray:
+    p = abi.CPlan(predicate)
+    t = table.c()
+    out, n = C.POINTER(C.c_uint64)(), C.c_uint64()
+    check(lib().orc_filter_row_ids(C.byref(t), p.filters, p.n_filters, p.ops, p.n_ops, C.byref(out), C.byref(n)))
+    res = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+    lib().orc_free(out)
+    return res
+
+
+def aggregate(table: OracleTable, predicate, aggs) -> List[abi.Value]:
+    p = abi.CPlan(predicate, aggs)
+    t = table.c()
+    out = (abi.CValue * max(1, len(aggs)))()
+    check(lib().orc_aggregate(C.byref(t), p.filters, p.n_filters, p.ops, p.n_ops, p.aggs, p.n_aggs, out))
+    return [abi.Value.from_c(out[i]) for i in range(len(aggs))]
+
+
+def aggregate_parallel(table: OracleTable, filters, aggs, threads: int) -> List[abi.Value]:
+    p = abi.CPlan(list(filters), aggs)
+    t = table.c()
+    out = (abi.CValue * max(1, len(aggs)))()
+    check(lib().orc_aggregate_parallel(C.byref(t), p.filters, p.n_filters, p.aggs, p.n_aggs, out, C.c_int32(threads)))
+    return [abi.Value.from_c(out[i]) for i in range(len(aggs))]
+
+
+class GroupRow:
+    def __init__(self, keys, values):
+        self.keys, self.values = keys, values
+
+    def __repr__(self):
+        return f"GroupRow(keys={[k.value for k in self.keys]}, values={[v.value for v in self.values]})"
+
+
+def groupby(table: OracleTable, predicate, keys: Sequence[int], aggs, order_by_keys: bool = False) -> List[GroupRow]:
+    p = abi.CPlan(predicate, aggs, keys)
+    t = table.c()
+    g = C.c_void_p()
+    check(lib().orc_groupby(C.byref(t), p.filters, p.n_filters, p.ops, p.n_ops, p.keys, p.n_keys, p.aggs, p.n_aggs,
+                            C.c_int32(int(order_by_keys)), C.byref(g)))
+    rows = []
+    v = abi.CValue()
+    try:
+        for i in range(lib().orc_groups_len(g)):
+            ks, vs = [], []
+            for k in range(len(keys)):
+                check(lib().orc_groups_key(g, i, k, C.byref(v)))
+                ks.append(abi.Value.from_c(v))
+            for a in range(len(aggs)):
+                check(lib().orc_groups_value(g, i, a, C.byref(v)))
+                vs.append(abi.Value.from_c(v))
+            rows.append(GroupRow(ks, vs))
+    finally:
+        lib().orc_groups_free(g)
+    return rows
+
+
+def scan_stream(table: OracleTable, projections, predicate, include_nulls=False, include_row_ids=False):
+    """Returns the list of batches; each batch = (columns, row_ids) with columns as lists of
+    Python values (None = NULL).  ``projections``: field ids or ScalarExpr."""
+    keep: list = []
+    projs = (abi.CProjection * max(1, len(projections)))()
+    for i, pr in enumerate(projections):
+        if isinstance(pr, int):
+            projs[i].computed, projs[i].field_id = 0, pr
+        else:
+            arr = pr.to_c(keep)
+            projs[i].computed, projs[i].expr, projs[i].expr_len = 1, arr, len(pr.tokens)
+    p = abi.CPlan(predicate)
+    t = table.c()
+    opts = abi.CScanOptions(int(include_nulls), int(include_row_ids))
+    batches = []
+
+    def on_batch(bp, _user):
+        b = bp.contents
+        cols = []
+        for ci in range(b.num_columns):
+            c = b.columns[ci]
+            n = b.num_rows
+            valid = [bool(c.valid[i]) for i in range(n)]
+            if c.dtype == abi.DT_UTF8:
+                vals = [c.strings[i].decode() if valid[i] else None for i in range(n)]
+            else:
+                npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
+                raw = np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt)
+                vals = [raw[i].item() if valid[i] else None for i in range(n)]
+            cols.append(vals)
+        rids = [b.row_ids[i] for i in range(b.num_rows)] if b.row_ids else None
+        batches.append((cols, rids))
+
+    cb = ORC_ON_BATCH(on_batch)
+    check(lib().orc_scan_stream(C.byref(t), projs, C.c_uint32(len(projections)), p.filters, p.n_filters, p.ops, p.n_ops,
+                                C.byref(opts), cb, None))
+    return batches
+
+
+def hash_join(left: OracleTable, right: OracleTable, keys, join_type=abi.JOIN_INNER, batch_size=8192):
+    ck = (abi.CJoinKey * max(1, len(keys)))()
+    for i, k in enumerate(keys):
+        ck[i].left_field, ck[i].right_field = k[0], k[1]
+        ck[i].null_equals_null = int(k[2]) if len(k) > 2 else 0
+    opts = abi.CJoinOptions(join_type, batch_size)
+    lt, rt = left.c(), right.c()
+    batches = []
+
+    def on_batch(pl, pr, n, _u):
+        l = [pl[i] for i in range(n)]
+        r = [pr[i] for i in range(n)] if pr else None
+        batches.append((l, r))
+
+    cb = abi.ON_JOIN_BATCH(on_batch)
+    check(lib().orc_hash_join(C.byref(lt), C.byref(rt), ck, C.c_uint32(len(keys)), C.byref(opts), cb, None))
+    return batches

@@ -1,0 +1,34 @@
+// catalog.hpp — ahead-of-time compiled instantiations of fused_scan_kernel, keyed by the
+// plan type string produced by lower_plan() (plan.hpp).  Plans outside the catalog are
+// compiled at run time from the same header (jit.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace llkv {
+
+struct ScanParams;
+struct FoldParams;
+
+using ScanLauncher = hipError_t (*)(const ScanParams &p, hipStream_t stream);
+
+struct CatalogEntry {
+  const char *type_string;
+  ScanLauncher launch;
+  int lanes;
+  int unroll;
+};
+
+const CatalogEntry *catalog_find(const char *type_string);
+int catalog_size();
+const CatalogEntry *catalog_at(int i);
+
+hipError_t launch_fold_octants(const FoldParams &f, hipStream_t stream);
+
+// Column statistics (min/max of an integer column already resident in HBM).
+hipError_t launch_minmax_i64(const int64_t *values, uint64_t n, int64_t *d_minmax /*[2]*/, hipStream_t stream);
+hipError_t launch_minmax_i32(const int32_t *values, uint64_t n, int64_t *d_minmax /*[2]*/, hipStream_t stream);
+
+} // namespace llkv

@@ -1,0 +1,739 @@
+// engine.cpp — host side of the MI355X execution path behind include/llkv_hip.h:
+// device context, HBM-resident table images (chunk → tile → octant layout), prepared
+// queries (plan lowering → kernel selection → launch → canonical fold → finalize).
+//
+// The host logic mirrors the reference's operator interfaces:
+//   StorageTable::scan_stream / filter_row_ids   llkv-executor/src/types/storage.rs:20-50
+//   execute_aggregates / compute_aggregate_values llkv-executor/src/lib.rs:5357-5682,6087-6665
+//   execute_group_by_with_aggregates              llkv-executor/src/lib.rs:5028-5355
+//   AggregateAccumulator::finalize                llkv-aggregate/src/lib.rs:1488-1939
+// There is no CPU fallback in here: without a HIP device every data-path call fails
+// with LLKV_NO_DEVICE.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace llkv {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return set_error(_e == hipErrorNoDevice || _e == hipErrorInvalidDevice ? LLKV_NO_DEVICE : LLKV_INTERNAL, \
+                       std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+  } while (0)
+
+Context g_ctx;
+
+int ensure_device() {
+  if (g_ctx.ready) return LLKV_OK;
+  return set_error(LLKV_NO_DEVICE, "llkv_hip_init() has not bound a HIP device (no GPU path without one)");
+}
+
+static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------
+// Table image
+// ---------------------------------------------------------------------------------
+Table::~Table() {
+  for (auto &kv : cols) if (kv.second.owned && kv.second.d_values) (void)hipFree(kv.second.d_values);
+  for (auto &kv : tilesets) if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+}
+
+// Canonical octant bounds over the global chunk list and the shard of this rank
+// (DESIGN.md "Sharding").  Pure host logic: also exercised by the CPU tests.
+void compute_layout(Table &t) {
+  const uint32_t C = (uint32_t)t.global_chunk_rows.size();
+  for (int j = 0; j <= kOctantsHost; ++j) t.octant_chunk_begin[j] = (uint32_t)((uint64_t)j * C / kOctantsHost);
+  t.owned_mask = 0;
+  for (int o = 0; o < kOctantsHost; ++o)
+    if ((uint32_t)((uint64_t)o * t.world / kOctantsHost) == t.rank) t.owned_mask |= 1u << o;
+  int first_o = -1, last_o = -1;
+  for (int o = 0; o < kOctantsHost; ++o) if ((t.owned_mask >> o) & 1u) { if (first_o < 0) first_o = o; last_o = o; }
+  t.first_chunk = first_o < 0 ? 0 : t.octant_chunk_begin[first_o];
+  t.n_local_chunks = first_o < 0 ? 0 : t.octant_chunk_begin[last_o + 1] - t.first_chunk;
+  t.total_rows = 0;
+  t.local_logical_start = 0;
+  for (uint32_t c = 0; c < C; ++c) {
+    if (c == t.first_chunk) t.local_logical_start = t.total_rows;
+    t.total_rows += t.global_chunk_rows[c];
+  }
+  t.local_rows = 0;
+  t.chunk_dev_off.assign(t.n_local_chunks + 1, 0);
+  for (uint32_t c = 0; c < t.n_local_chunks; ++c) {
+    const uint64_t rows = t.global_chunk_rows[t.first_chunk + c];
+    t.local_rows += rows;
+    // every chunk starts on a 16-row boundary of the device image so that 16-byte loads of
+    // 8-byte columns and 2-byte loads of code columns stay aligned for ragged chunks
+    t.chunk_dev_off[c + 1] = round_up(t.chunk_dev_off[c] + rows, 16);
+  }
+  t.dev_rows = t.chunk_dev_off[t.n_local_chunks];
+}
+
+uint32_t octant_of_chunk(const Table &t, uint32_t global_chunk) {
+  for (int o = 0; o < kOctantsHost; ++o)
+    if (global_chunk >= t.octant_chunk_begin[o] && global_chunk < t.octant_chunk_begin[o + 1]) return (uint32_t)o;
+  return kOctantsHost - 1;
+}
+
+void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> &tiles, uint32_t (&octant_tile_begin)[kOctantsHost + 1]) {
+  tiles.clear();
+  uint64_t logical = t.local_logical_start;
+  std::vector<uint32_t> per_octant(kOctantsHost, 0);
+  for (uint32_t c = 0; c < t.n_local_chunks; ++c) {
+    const uint64_t rows = t.global_chunk_rows[t.first_chunk + c];
+    const uint32_t o = octant_of_chunk(t, t.first_chunk + c);
+    for (uint64_t r = 0; r < rows; r += tile_rows) {
+      TileDesc d;
+      d.dev_row = t.chunk_dev_off[c] + r;
+      d.logical_row = logical + r;
+      d.rows = (uint32_t)std::min<uint64_t>(tile_rows, rows - r);
+      d.octant = o;
+      tiles.push_back(d);
+      per_octant[o]++;
+    }
+    logical += rows;
+  }
+  octant_tile_begin[0] = 0;
+  for (int o = 0; o < kOctantsHost; ++o) octant_tile_begin[o + 1] = octant_tile_begin[o] + per_octant[o];
+}
+
+static int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
+  Table &t = const_cast<Table &>(tc);
+  std::lock_guard<std::mutex> lk(t.mu);
+  auto it = t.tilesets.find(tile_rows);
+  if (it != t.tilesets.end()) { *out = &it->second; return LLKV_OK; }
+  TileSet ts;
+  std::vector<TileDesc> tiles;
+  build_tiles_host(t, tile_rows, tiles, ts.octant_tile_begin);
+  ts.n_tiles = (uint32_t)tiles.size();
+  ts.tile_rows = tile_rows;
+  if (ts.n_tiles) {
+    HIP_TRY(hipMalloc((void **)&ts.d_tiles, tiles.size() * sizeof(TileDesc)));
+    HIP_TRY(hipMemcpy(ts.d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  }
+  auto ins = t.tilesets.emplace(tile_rows, ts);
+  *out = &ins.first->second;
+  return LLKV_OK;
+}
+
+static const uint64_t kSlackRows = 8192; // readable rows past the image end (unrolled tail steps)
+
+static int alloc_column(Table &t, uint32_t width, void **d_out) {
+  const uint64_t bytes = (t.dev_rows + kSlackRows) * width;
+  HIP_TRY(hipMalloc(d_out, bytes));
+  HIP_TRY(hipMemsetAsync(*d_out, 0, bytes, g_ctx.stream));
+  return LLKV_OK;
+}
+
+// pinned double buffer → hipMemcpyAsync (north_star: "pinned and hipMemcpyAsync'd into HBM")
+struct Stager {
+  static constexpr size_t kBuf = 8u << 20;
+  void *pinned[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  int cur = 0;
+  int init() {
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipHostMalloc(&pinned[i], kBuf, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    return LLKV_OK;
+  }
+  ~Stager() {
+    for (int i = 0; i < 2; ++i) {
+      if (pinned[i]) (void)hipHostFree(pinned[i]);
+      if (done[i]) (void)hipEventDestroy(done[i]);
+    }
+  }
+  int push(void *d_dst, const void *h_src, size_t bytes) {
+    size_t off = 0;
+    while (off < bytes) {
+      const size_t n = std::min(kBuf, bytes - off);
+      HIP_TRY(hipEventSynchronize(done[cur]));
+      std::memcpy(pinned[cur], (const char *)h_src + off, n);
+      HIP_TRY(hipMemcpyAsync((char *)d_dst + off, pinned[cur], n, hipMemcpyHostToDevice, g_ctx.stream));
+      HIP_TRY(hipEventRecord(done[cur], g_ctx.stream));
+      cur ^= 1;
+      off += n;
+    }
+    return LLKV_OK;
+  }
+};
+
+static int column_stats_device(Table &t, DeviceColumn &c) {
+  if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32) return LLKV_OK;
+  if (t.dev_rows == 0) return LLKV_OK;
+  int64_t init[2] = {INT64_MAX, INT64_MIN}, *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, sizeof init));
+  HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, g_ctx.stream));
+  // padding rows between ragged chunks are zero: they can only widen the range (safe side)
+  if (c.info.dtype == LLKV_DT_INT64) HIP_TRY(launch_minmax_i64((const int64_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
+  else HIP_TRY(launch_minmax_i32((const int32_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
+  int64_t mm[2];
+  HIP_TRY(hipMemcpyAsync(mm, d, sizeof mm, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  (void)hipFree(d);
+  c.info.has_stats = true;
+  c.info.min_i = mm[0];
+  c.info.max_i = mm[1];
+  return LLKV_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Query
+// ---------------------------------------------------------------------------------
+Query::~Query() {
+  if (d_tile_partials) (void)hipFree(d_tile_partials);
+  if (d_exchange) (void)hipFree(d_exchange);
+  if (d_lane_ops) (void)hipFree(d_lane_ops);
+  if (h_exchange) (void)hipHostFree(h_exchange);
+  for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+}
+
+static uint32_t pick_tile_rows(const LoweredPlan &p) {
+  if (const char *e = std::getenv("LLKV_HIP_TILE_ROWS")) {
+    long v = std::atol(e);
+    if (v >= 512 && v % 512 == 0) return (uint32_t)v;
+  }
+  // small states amortise their block reduction quickly; wide (grouped) states want longer
+  // tiles.  Depends on the plan only, never on the GPU count (bit-reproducibility).
+  return p.lanes <= 8 ? 8192u : 32768u;
+}
+
+int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                  uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs,
+                  uint32_t n_aggs, bool grouped, bool order_by_keys, Query **out) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (!table) return set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
+    auto it = table->cols.find(fid);
+    return it == table->cols.end() ? nullptr : &it->second.info;
+  };
+  std::unique_ptr<Query> q(new Query());
+  q->table = table;
+  q->order_by_keys = order_by_keys;
+  q->n_user_aggs = n_aggs;
+  std::string err;
+  rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, &q->plan, &err);
+  if (rc) return set_error(rc, err);
+  const LoweredPlan &p = q->plan;
+
+  if (!p.always_false) {
+    q->entry = catalog_find(p.type_string.c_str());
+    if (!q->entry) {
+      rc = jit_compile(p.type_string, &q->jit, &err);
+      if (rc) return set_error(rc, err);
+    }
+  }
+  const TileSet *ts = nullptr;
+  if ((rc = get_tileset(*table, pick_tile_rows(p), &ts))) return rc;
+  q->tiles = ts;
+
+  std::memset(&q->params, 0, sizeof q->params);
+  for (size_t s = 0; s < p.slot_fields.size(); ++s) q->params.col[s] = table->cols.at(p.slot_fields[s]).d_values;
+  for (size_t i = 0; i < p.lit_i.size(); ++i) q->params.lit_i[i] = p.lit_i[i];
+  for (size_t i = 0; i < p.lit_f.size(); ++i) q->params.lit_f[i] = p.lit_f[i];
+  for (size_t i = 0; i < p.key_strides.size(); ++i) q->params.key_stride[i] = p.key_strides[i];
+  q->params.tiles = ts->d_tiles;
+  q->params.n_tiles = ts->n_tiles;
+
+  const size_t lanes = (size_t)p.lanes;
+  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, std::max<size_t>(1, lanes * ts->n_tiles) * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void **)&q->d_exchange, kOctantsHost * lanes * sizeof(uint64_t)));
+  HIP_TRY(hipMemsetAsync(q->d_exchange, 0, kOctantsHost * lanes * sizeof(uint64_t), g_ctx.stream));
+  HIP_TRY(hipMalloc((void **)&q->d_lane_ops, lanes));
+  HIP_TRY(hipMemcpyAsync(q->d_lane_ops, p.lane_ops.data(), lanes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipHostMalloc((void **)&q->h_exchange, kOctantsHost * lanes * sizeof(uint64_t), hipHostMallocDefault));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  q->params.tile_partials = q->d_tile_partials;
+
+  std::memset(&q->fold, 0, sizeof q->fold);
+  q->fold.tile_partials = q->d_tile_partials;
+  q->fold.exchange = q->d_exchange;
+  q->fold.lane_ops = q->d_lane_ops;
+  for (int o = 0; o <= kOctantsHost; ++o) q->fold.octant_tile_begin[o] = ts->octant_tile_begin[o];
+  q->fold.n_tiles = ts->n_tiles;
+  q->fold.lanes = (uint32_t)lanes;
+  q->fold.owned_mask = table->owned_mask;
+  *out = q.release();
+  return LLKV_OK;
+}
+
+int Query::launch(hipStream_t stream) {
+  if (!stream) stream = g_ctx.stream;
+  const bool run_main = !plan.always_false && tiles->n_tiles > 0;
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  if (profiling && run_main) {
+    if (events_used == events.size()) {
+      HIP_TRY(hipEventCreate(&ev.first));
+      HIP_TRY(hipEventCreate(&ev.second));
+      events.push_back(ev);
+    }
+    ev = events[events_used++];
+    HIP_TRY(hipEventRecord(ev.first, stream));
+  }
+  if (run_main) {
+    if (entry) HIP_TRY(entry->launch(params, stream));
+    else {
+      int rc = jit_launch(jit, params, stream);
+      if (rc) return rc;
+    }
+    if (ev.second) HIP_TRY(hipEventRecord(ev.second, stream));
+  }
+  FoldParams f = fold;
+  if (!run_main) f.n_tiles = 0, std::fill(std::begin(f.octant_tile_begin), std::end(f.octant_tile_begin), 0u);
+  HIP_TRY(launch_fold_octants(f, stream));
+  launches++;
+  return LLKV_OK;
+}
+
+static inline uint64_t host_identity(int op) { return op == 2 ? 0x7FFFFFFFFFFFFFFFull : op == 3 ? 0x8000000000000000ull : 0ull; }
+static inline uint64_t host_combine(int op, uint64_t a, uint64_t b) {
+  switch (op) {
+  case 0: { double x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8); double z = x + y; uint64_t r; std::memcpy(&r, &z, 8); return r; }
+  case 1: return a + b;
+  case 2: return (int64_t)b < (int64_t)a ? b : a;
+  case 3: return (int64_t)b > (int64_t)a ? b : a;
+  default: return b > a ? b : a;
+  }
+}
+
+// Fold the 8 octant partials in octant order (same association for every GPU count).
+void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state) {
+  for (uint32_t l = 0; l < lanes; ++l) {
+    uint64_t v = host_identity(lane_ops[l]);
+    for (int o = 0; o < kOctantsHost; ++o) v = host_combine(lane_ops[l], v, exchange[(size_t)o * lanes + l]);
+    state[l] = v;
+  }
+}
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+static double key_to_f64(int64_t key) {
+  int64_t b = key < 0 ? (key ^ 0x7FFFFFFFFFFFFFFFll) : key;
+  double d;
+  std::memcpy(&d, &b, 8);
+  return d;
+}
+
+// Finalize one aggregate of one group: AggregateAccumulator::finalize
+// llkv-aggregate/src/lib.rs:1488-1939 on the folded lane state.
+int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base, llkv_value *out, std::string *err) {
+  std::memset(out, 0, sizeof *out);
+  const int64_t rows = (int64_t)g[0];
+  const uint64_t *l = a.lane >= 0 ? g + base + a.lane : nullptr;
+  auto as_f64 = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
+  auto exact_sum = [&](int64_t *sum, const char *overflow_msg) -> int {
+    const i128 total = ((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0];
+    if (total > (i128)INT64_MAX || total < (i128)INT64_MIN) { *err = overflow_msg; return LLKV_INVALID_ARGUMENT; }
+    if ((u128)l[2] * (u128)(uint64_t)rows > (u128)INT64_MAX) {
+      // the reference's checked_add chain is order dependent: a prefix may overflow although
+      // the total fits.  Not decidable from the order-free state → caller's CPU route decides.
+      *err = "possible intermediate i64 overflow in SUM: order-dependent check is not on the GPU path";
+      return LLKV_UNSUPPORTED;
+    }
+    *sum = (int64_t)total;
+    return LLKV_OK;
+  };
+  switch (a.fin) {
+  case AggFinal::CountRows: out->dtype = LLKV_DT_INT64; out->i64 = rows; return LLKV_OK;
+  case AggFinal::CountNullsZero: out->dtype = LLKV_DT_INT64; out->i64 = 0; return LLKV_OK;
+  case AggFinal::SumI64Fast: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
+  case AggFinal::SumI64: {
+    out->dtype = LLKV_DT_INT64;
+    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    return exact_sum(&out->i64, "integer overflow");
+  }
+  case AggFinal::SumF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; out->f64 = rows ? as_f64(l[0]) : 0.0; return LLKV_OK;
+  case AggFinal::TotalF64: out->dtype = LLKV_DT_FLOAT64; out->f64 = as_f64(l[0]); return LLKV_OK;
+  case AggFinal::AvgI64Fast: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = (double)(int64_t)l[0] / (double)rows; return LLKV_OK;
+  case AggFinal::AvgI64: {
+    out->dtype = LLKV_DT_FLOAT64;
+    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    int64_t s;
+    int rc = exact_sum(&s, "AVG aggregate sum exceeds i64 range");
+    if (rc) return rc;
+    out->f64 = (double)s / (double)rows;
+    return LLKV_OK;
+  }
+  case AggFinal::AvgF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = as_f64(l[0]) / (double)rows; return LLKV_OK;
+  case AggFinal::MinI64: case AggFinal::MaxI64: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
+  case AggFinal::MinF64: case AggFinal::MaxF64: {
+    out->dtype = LLKV_DT_FLOAT64;
+    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    if (l[2] & 1u) { out->f64 = std::nan(""); return LLKV_OK; } // a leading NaN sticks (:1319-1330)
+    const uint64_t none = a.fin == AggFinal::MinF64 ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
+    if (l[0] == none) { out->f64 = std::nan(""); return LLKV_OK; } // unreachable: first row is not NaN
+    double v = key_to_f64((int64_t)l[0]);
+    if (v == 0.0 && l[1] != 0x7FFFFFFFFFFFFFFFull && (l[1] & 1u)) v = -0.0; // ±0 ties keep the earlier row
+    out->f64 = v;
+    return LLKV_OK;
+  }
+  }
+  return LLKV_INTERNAL;
+}
+
+int Query::finish_from_exchange(const uint64_t *exchange) {
+  const LoweredPlan &p = plan;
+  std::vector<uint64_t> state(p.lanes);
+  fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
+  groups.clear();
+  if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic overflowed on a selected row
+    return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  const int base = p.grouped ? 2 : 1;
+  for (uint32_t g = 0; g < p.ng; ++g) {
+    const uint64_t *gl = &state[(size_t)g * p.k];
+    if (p.grouped && gl[0] == 0) continue; // group never appeared
+    GroupResult gr;
+    gr.first_row = p.grouped ? gl[1] : 0;
+    if (p.grouped)
+      for (size_t k = 0; k < p.key_fields.size(); ++k) {
+        const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
+        const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
+        gr.keys.push_back(code < dict.size() ? dict[code] : std::string());
+      }
+    gr.values.resize(p.aggs.size());
+    for (size_t a = 0; a < p.aggs.size(); ++a) {
+      std::string err;
+      int rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err);
+      if (rc) return set_error(rc, err);
+    }
+    groups.push_back(std::move(gr));
+  }
+  if (p.grouped) {
+    // first-appearance order (llkv-executor/src/lib.rs:5065-5089), then ORDER BY keys ASC
+    std::sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
+    if (order_by_keys) std::stable_sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.keys < b.keys; });
+  }
+  return LLKV_OK;
+}
+
+int Query::finish(hipStream_t stream) {
+  if (!stream) stream = g_ctx.stream;
+  const size_t bytes = kOctantsHost * (size_t)plan.lanes * sizeof(uint64_t);
+  HIP_TRY(hipMemcpyAsync(h_exchange, d_exchange, bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return finish_from_exchange(h_exchange);
+}
+
+} // namespace llkv
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+using namespace llkv;
+
+extern "C" {
+
+const char *llkv_hip_last_error(void) { return g_last_error.c_str(); }
+uint32_t llkv_hip_abi_version(void) { return LLKV_HIP_ABI_VERSION; }
+
+int32_t llkv_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+llkv_status llkv_hip_init(int32_t device_ordinal) {
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  if (g_ctx.ready) {
+    if (g_ctx.device == device_ordinal) return LLKV_OK;
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "already bound to another device (one process per GPU)");
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return (llkv_status)set_error(LLKV_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device_ordinal < 0 || device_ordinal >= n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "device ordinal out of range");
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return (llkv_status)set_error(LLKV_NO_DEVICE, hipGetErrorString(e));
+  if ((e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, hipGetErrorString(e));
+  g_ctx.device = device_ordinal;
+  g_ctx.ready = true;
+  return LLKV_OK;
+}
+
+void llkv_hip_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  if (!g_ctx.ready) return;
+  jit_shutdown();
+  (void)hipStreamDestroy(g_ctx.stream);
+  g_ctx.stream = nullptr;
+  g_ctx.ready = false;
+}
+
+void llkv_hip_free(void *ptr) { std::free(ptr); }
+
+// ---- tables -------------------------------------------------------------------------
+llkv_status llkv_hip_table_create(uint16_t table_id, const uint64_t *global_chunk_rows, uint32_t n_global_chunks,
+                                  uint32_t rank, uint32_t world, llkv_hip_table **out) {
+  if (!out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "out is NULL");
+  if (world == 0 || world > (uint32_t)kOctantsHost || rank >= world)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "world must be 1..8 and rank < world");
+  if (n_global_chunks && !global_chunk_rows) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk rows is NULL");
+  auto *t = new Table();
+  t->table_id = table_id;
+  t->rank = rank;
+  t->world = world;
+  t->global_chunk_rows.assign(global_chunk_rows, global_chunk_rows + n_global_chunks);
+  compute_layout(*t);
+  *out = reinterpret_cast<llkv_hip_table *>(t);
+  return LLKV_OK;
+}
+
+void llkv_hip_table_free(llkv_hip_table *table) { delete reinterpret_cast<Table *>(table); }
+
+llkv_status llkv_hip_table_local_chunks(const llkv_hip_table *table, uint32_t *first, uint32_t *count) {
+  if (!table) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto *t = reinterpret_cast<const Table *>(table);
+  if (first) *first = t->first_chunk;
+  if (count) *count = t->n_local_chunks;
+  return LLKV_OK;
+}
+uint64_t llkv_hip_table_total_rows(const llkv_hip_table *table) { return table ? reinterpret_cast<const Table *>(table)->total_rows : 0; }
+uint64_t llkv_hip_table_local_rows(const llkv_hip_table *table) { return table ? reinterpret_cast<const Table *>(table)->local_rows : 0; }
+
+static int check_new_column(Table *t, uint32_t field_id, uint32_t n_chunks) {
+  if (!t) return set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  if (t->cols.count(field_id)) return set_error(LLKV_INVALID_ARGUMENT, "field " + std::to_string(field_id) + " already staged");
+  if (n_chunks != t->n_local_chunks)
+    return set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(t->n_local_chunks) + " local chunks, got " + std::to_string(n_chunks));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,
+                                         const void *const *chunk_values, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, n_chunks);
+  if (rc) return (llkv_status)rc;
+  const uint32_t w = dtype_width(dtype);
+  if (w == 0 || dtype == LLKV_DT_UTF8) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, std::string("append_column: unsupported dtype ") + dtype_name(dtype));
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = dtype;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  if ((rc = alloc_column(*t, w, &c.d_values))) return (llkv_status)rc;
+  Stager st;
+  if ((rc = st.init())) return (llkv_status)rc;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    if (rows && !chunk_values[i]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
+    if ((rc = st.push((char *)c.d_values + t->chunk_dev_off[i] * w, chunk_values[i], rows * w))) return (llkv_status)rc;
+  }
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t field_id,
+                                              const int32_t *const *chunk_offsets, const uint8_t *const *chunk_data,
+                                              uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, n_chunks);
+  if (rc) return (llkv_status)rc;
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = LLKV_DT_UTF8;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  // dictionary-encode on the host at staging (SURVEY.md §7 "Utf8 group keys"): 1 B/row in HBM
+  std::vector<uint8_t> codes(t->dev_rows + 16, 0);
+  std::map<std::string, uint8_t> dict;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    const int32_t *off = chunk_offsets[i];
+    const uint8_t *data = chunk_data[i];
+    uint8_t *dst = codes.data() + t->chunk_dev_off[i];
+    // fast path for 1-byte strings (TPC-H flags)
+    int16_t lut[256];
+    std::fill(std::begin(lut), std::end(lut), (int16_t)-1);
+    for (uint64_t r = 0; r < rows; ++r) {
+      const int32_t len = off[r + 1] - off[r];
+      if (len == 1) {
+        const uint8_t ch = data[off[r]];
+        if (lut[ch] < 0) {
+          std::string s(1, (char)ch);
+          auto it = dict.find(s);
+          if (it == dict.end()) {
+            if (dict.size() >= 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+            it = dict.emplace(s, (uint8_t)dict.size()).first;
+            c.info.dictionary.push_back(s);
+          }
+          lut[ch] = it->second;
+        }
+        dst[r] = (uint8_t)lut[ch];
+      } else {
+        std::string s((const char *)data + off[r], (size_t)len);
+        auto it = dict.find(s);
+        if (it == dict.end()) {
+          if (dict.size() >= 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+          it = dict.emplace(s, (uint8_t)dict.size()).first;
+          c.info.dictionary.push_back(s);
+        }
+        dst[r] = it->second;
+      }
+    }
+  }
+  if ((rc = alloc_column(*t, 1, &c.d_values))) return (llkv_status)rc;
+  Stager st;
+  if ((rc = st.init())) return (llkv_status)rc;
+  if ((rc = st.push(c.d_values, codes.data(), t->dev_rows))) return (llkv_status)rc;
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,
+                                               const void *device_values) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, t ? t->n_local_chunks : 0);
+  if (rc) return (llkv_status)rc;
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  const uint32_t w = dtype_width(dtype);
+  if (w == 0 || dtype == LLKV_DT_UTF8) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "adopt_device_column: unsupported dtype");
+  if (t->dev_rows != t->local_rows)
+    return (llkv_status)set_error(LLKV_UNSUPPORTED, "adopting device buffers needs chunk row counts that are multiples of 16");
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = dtype;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  // the adopted buffer has no slack past its end; keep an owned image with slack instead
+  if ((rc = alloc_column(*t, w, &c.d_values))) return (llkv_status)rc;
+  if (hipMemcpyAsync(c.d_values, device_values, t->dev_rows * w, hipMemcpyDeviceToDevice, g_ctx.stream) != hipSuccess ||
+      hipStreamSynchronize(g_ctx.stream) != hipSuccess)
+    return (llkv_status)set_error(LLKV_INTERNAL, "device copy failed");
+  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+// ---- queries ------------------------------------------------------------------------
+llkv_status llkv_hip_query_prepare_aggregate(const llkv_hip_table *table, const llkv_filter *filters, uint32_t n_filters,
+                                             const llkv_eval_op *ops, uint32_t n_ops, const llkv_aggregate_spec *aggs,
+                                             uint32_t n_aggs, llkv_hip_query **out) {
+  if (!out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "out is NULL");
+  Query *q = nullptr;
+  int rc = prepare_query(reinterpret_cast<const Table *>(table), filters, n_filters, ops, n_ops, nullptr, 0, aggs, n_aggs, false, false, &q);
+  if (rc) return (llkv_status)rc;
+  *out = reinterpret_cast<llkv_hip_query *>(q);
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_prepare_groupby(const llkv_hip_table *table, const llkv_filter *filters, uint32_t n_filters,
+                                           const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields,
+                                           uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                                           int32_t order_by_keys, llkv_hip_query **out) {
+  if (!out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "out is NULL");
+  Query *q = nullptr;
+  int rc = prepare_query(reinterpret_cast<const Table *>(table), filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, true, order_by_keys != 0, &q);
+  if (rc) return (llkv_status)rc;
+  *out = reinterpret_cast<llkv_hip_query *>(q);
+  return LLKV_OK;
+}
+
+void llkv_hip_query_free(llkv_hip_query *query) { delete reinterpret_cast<Query *>(query); }
+
+llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  return (llkv_status) reinterpret_cast<Query *>(query)->launch((hipStream_t)hip_stream);
+}
+
+llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_ptr, uint64_t *len_i64) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  Query *q = reinterpret_cast<Query *>(query);
+  if (device_ptr) *device_ptr = q->d_exchange;
+  if (len_i64) *len_i64 = (uint64_t)kOctantsHost * (uint64_t)q->plan.lanes;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  return (llkv_status) reinterpret_cast<Query *>(query)->finish((hipStream_t)hip_stream);
+}
+
+uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->groups.size() : 0; }
+uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->plan.key_fields.size() : 0; }
+uint32_t llkv_hip_query_num_aggregates(const llkv_hip_query *query) { return query ? reinterpret_cast<const Query *>(query)->n_user_aggs : 0; }
+
+llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group, uint32_t key, llkv_value *out) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  if (!q || !out || group >= q->groups.size() || key >= q->groups[group].keys.size())
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/key index out of range");
+  std::memset(out, 0, sizeof *out);
+  out->dtype = LLKV_DT_UTF8;
+  out->str = q->groups[group].keys[key].c_str();
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, uint32_t agg, llkv_value *out) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  if (!q || !out || group >= q->groups.size() || agg >= q->groups[group].values.size())
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/aggregate index out of range");
+  *out = q->groups[group].values[agg];
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_set_profiling(llkv_hip_query *query, int32_t enabled) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  Query *q = reinterpret_cast<Query *>(query);
+  q->profiling = enabled != 0;
+  q->events_used = 0;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_kernel_time(llkv_hip_query *query, double *total_ms, uint64_t *launches, const char **kernel_name) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  Query *q = reinterpret_cast<Query *>(query);
+  double sum = 0;
+  for (size_t i = 0; i < q->events_used; ++i) {
+    float ms = 0;
+    if (hipEventSynchronize(q->events[i].second) != hipSuccess || hipEventElapsedTime(&ms, q->events[i].first, q->events[i].second) != hipSuccess)
+      return (llkv_status)set_error(LLKV_INTERNAL, "event timing failed");
+    sum += ms;
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = q->events_used;
+  if (kernel_name) *kernel_name = "fused_scan_kernel";
+  q->events_used = 0;
+  return LLKV_OK;
+}
+
+uint64_t llkv_hip_query_algorithmic_bytes(const llkv_hip_query *query) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  return q ? q->plan.bytes_per_row * q->table->local_rows : 0;
+}
+
+const char *llkv_hip_query_kernel_signature(const llkv_hip_query *query) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  return q ? q->plan.type_string.c_str() : "";
+}
+
+llkv_status llkv_hip_aggregate(const llkv_hip_table *table, const llkv_filter *filters, uint32_t n_filters,
+                               const llkv_eval_op *ops, uint32_t n_ops, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                               llkv_value *out_values) {
+  llkv_hip_query *q = nullptr;
+  llkv_status rc = llkv_hip_query_prepare_aggregate(table, filters, n_filters, ops, n_ops, aggs, n_aggs, &q);
+  if (rc) return rc;
+  rc = llkv_hip_query_launch(q, nullptr);
+  if (!rc) rc = llkv_hip_query_finish(q, nullptr);
+  if (!rc) for (uint32_t i = 0; i < n_aggs; ++i) llkv_hip_query_value(q, 0, i, &out_values[i]);
+  llkv_hip_query_free(q);
+  return rc;
+}
+
+} // extern "C"

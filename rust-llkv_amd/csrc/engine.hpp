@@ -1,0 +1,116 @@
+// engine.hpp — internal host-side types of libllkv_hip (see engine.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "catalog.hpp"
+#include "llkv_hip.h"
+#include "plan.hpp"
+#include "scan_params.h"
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace llkv {
+
+constexpr int kOctantsHost = kOctants;
+
+extern thread_local std::string g_last_error;
+int set_error(int code, const std::string &msg);
+
+struct Context {
+  std::mutex mu;
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+};
+extern Context g_ctx;
+int ensure_device();
+
+struct DeviceColumn {
+  ColumnInfo info;
+  void *d_values = nullptr;
+  bool owned = false;
+};
+
+struct TileSet {
+  TileDesc *d_tiles = nullptr;
+  uint32_t n_tiles = 0;
+  uint32_t tile_rows = 0;
+  uint32_t octant_tile_begin[kOctantsHost + 1] = {0};
+};
+
+struct Table {
+  uint16_t table_id = 0;
+  uint32_t rank = 0, world = 1;
+  std::vector<uint64_t> global_chunk_rows;
+  uint32_t octant_chunk_begin[kOctantsHost + 1] = {0};
+  uint32_t owned_mask = 0xff;
+  uint32_t first_chunk = 0, n_local_chunks = 0;
+  uint64_t total_rows = 0, local_rows = 0, local_logical_start = 0;
+  std::vector<uint64_t> chunk_dev_off; // local chunk → first row in the device image (+ end)
+  uint64_t dev_rows = 0;
+  std::map<uint32_t, DeviceColumn> cols;
+  std::map<uint32_t, TileSet> tilesets;
+  std::mutex mu;
+  ~Table();
+};
+
+void compute_layout(Table &t);
+uint32_t octant_of_chunk(const Table &t, uint32_t global_chunk);
+void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> &tiles,
+                      uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
+
+// run-time compiled plan (jit.cpp)
+struct JitKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+};
+int jit_compile(const std::string &type_string, JitKernel *out, std::string *err);
+int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream);
+void jit_shutdown();
+
+struct GroupResult {
+  uint64_t first_row = 0;
+  std::vector<std::string> keys;
+  std::vector<llkv_value> values;
+};
+
+struct Query {
+  const Table *table = nullptr;
+  LoweredPlan plan;
+  const CatalogEntry *entry = nullptr;
+  JitKernel jit;
+  const TileSet *tiles = nullptr;
+  ScanParams params;
+  FoldParams fold;
+  uint64_t *d_tile_partials = nullptr;
+  uint64_t *d_exchange = nullptr;
+  uint8_t *d_lane_ops = nullptr;
+  uint64_t *h_exchange = nullptr; // pinned
+  bool order_by_keys = false;
+  uint32_t n_user_aggs = 0;
+  std::vector<GroupResult> groups;
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  uint64_t launches = 0;
+
+  int launch(hipStream_t stream);
+  int finish(hipStream_t stream);
+  int finish_from_exchange(const uint64_t *exchange);
+  ~Query();
+};
+
+int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                  uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs,
+                  uint32_t n_aggs, bool grouped, bool order_by_keys, Query **out);
+
+void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state);
+int finalize_value(const AggOut &a, const uint64_t *group_lanes, int base, llkv_value *out, std::string *err);
+
+} // namespace llkv

@@ -1,0 +1,516 @@
+// fused_scan.hip.h — device-side building blocks of the fused
+// scan → predicate → (dense group id) → aggregate kernel for gfx950 (CDNA4).
+//
+// One kernel replaces the reference's five CPU passes (SURVEY.md §2 K1–K6):
+//   leaf filters      llkv-column-map/src/store/scan/filter.rs:937-955
+//   bitmap AND/OR/NOT llkv-scan/src/predicate.rs:87-186
+//   gather            llkv-column-map/src/store/projection.rs:929-1352
+//   computed exprs    llkv-compute/src/fast_numeric.rs:69-121,312-356
+//   accumulate        llkv-aggregate/src/lib.rs:759-1477
+//   GROUP BY          llkv-executor/src/lib.rs:5028-5355
+// Nothing but the per-tile partial state is ever written back to HBM.
+//
+// Shape of the work (HBM-bound, no MFMA — there is no contraction here):
+//   * a block owns one tile (a run of rows inside one chunk); a thread owns two
+//     consecutive rows per step, so every 8-byte column is read with one 16-byte
+//     load per lane (1 KiB contiguous per wave instruction), 4-byte columns with 8-byte
+//     loads, 1-byte dictionary codes with 2-byte loads;
+//   * predicates, expressions and per-group accumulators live in registers; a plan is
+//     a C++ type, so the row body is straight-line code;
+//   * partial state is a vector of independent 64-bit lanes, each with one of five
+//     combine ops, reduced in a fixed order (thread → LDS transpose → 16-lane
+//     butterfly → tile partial), which makes f64 sums bit-reproducible and independent
+//     of the GPU count (DESIGN.md "Determinism").
+//
+// The header is self-contained device code (usable from hiprtc).
+#pragma once
+
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#endif
+
+#include "scan_params.h"
+
+namespace llkv {
+
+__device__ __forceinline__ uint64_t lane_identity(int op) {
+  switch (op) {
+  case OP_MIN_I64: return 0x7FFFFFFFFFFFFFFFull;
+  case OP_MAX_I64: return 0x8000000000000000ull;
+  default: return 0ull; // +0.0, 0, 0
+  }
+}
+
+// Branch-free: `op` is a compile-time constant in the row loop (the selects fold away) and
+// a per-16-lane-group value in the reduction phases (no divergent branches there).
+__device__ __forceinline__ uint64_t lane_combine(int op, uint64_t a, uint64_t b) {
+  const uint64_t fadd = (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+  const uint64_t iadd = a + b;
+  const bool lt = (int64_t)b < (int64_t)a;
+  const uint64_t imin = lt ? b : a;
+  const uint64_t imax = (int64_t)b > (int64_t)a ? b : a;
+  const uint64_t umax = b > a ? b : a;
+  return op == OP_ADD_F64 ? fadd : op == OP_ADD_I64 ? iadd : op == OP_MIN_I64 ? imin : op == OP_MAX_I64 ? imax : umax;
+}
+
+template <int OP> __device__ __forceinline__ uint64_t lane_combine_s(uint64_t a, uint64_t b) {
+  if constexpr (OP == OP_ADD_F64) return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+  else if constexpr (OP == OP_ADD_I64) return a + b;
+  else if constexpr (OP == OP_MIN_I64) return (int64_t)b < (int64_t)a ? b : a;
+  else if constexpr (OP == OP_MAX_I64) return (int64_t)b > (int64_t)a ? b : a;
+  else return b > a ? b : a;
+}
+
+template <int OP> constexpr uint64_t lane_identity_s() {
+  return OP == OP_MIN_I64 ? 0x7FFFFFFFFFFFFFFFull : OP == OP_MAX_I64 ? 0x8000000000000000ull : 0ull;
+}
+
+// --------------------------------------------------------------------------
+// Storage types of staged columns
+// --------------------------------------------------------------------------
+struct I32 { using T = int32_t; static constexpr int W = 4; static constexpr bool is_float = false; };
+struct U32 { using T = uint32_t; static constexpr int W = 4; static constexpr bool is_float = false; };
+struct F32 { using T = float; static constexpr int W = 4; static constexpr bool is_float = true; };
+struct I64 { using T = int64_t; static constexpr int W = 8; static constexpr bool is_float = false; };
+struct U64 { using T = uint64_t; static constexpr int W = 8; static constexpr bool is_float = false; };
+struct F64 { using T = double; static constexpr int W = 8; static constexpr bool is_float = true; };
+struct U8 { using T = uint8_t; static constexpr int W = 1; static constexpr bool is_float = false; };
+
+template <class... Ts> struct Cols { static constexpr int N = sizeof...(Ts); };
+
+template <int I, class L> struct ColAt;
+template <int I, class T0, class... Ts> struct ColAt<I, Cols<T0, Ts...>> { using type = typename ColAt<I - 1, Cols<Ts...>>::type; };
+template <class T0, class... Ts> struct ColAt<0, Cols<T0, Ts...>> { using type = T0; };
+
+// Two consecutive rows of every column, as raw dwords (registers once unrolled).
+struct Loaded {
+  uint32_t w[kMaxCols][4];
+};
+
+template <class Ty> __device__ __forceinline__ void load_pair(const void *base, uint64_t row, uint32_t (&w)[4]) {
+  if constexpr (Ty::W == 8) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(static_cast<const char *>(base) + row * 8);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  } else if constexpr (Ty::W == 4) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(static_cast<const char *>(base) + row * 4);
+    w[0] = v.x; w[1] = v.y;
+  } else {
+    w[0] = *reinterpret_cast<const uint16_t *>(static_cast<const char *>(base) + row);
+  }
+}
+
+template <class CL, int I = 0> __device__ __forceinline__ void load_all(const ScanParams &p, uint64_t row, Loaded &ld) {
+  if constexpr (I < CL::N) {
+    load_pair<typename ColAt<I, CL>::type>(p.col[I], row, ld.w[I]);
+    load_all<CL, I + 1>(p, row, ld);
+  }
+}
+
+// Per-row evaluation context.
+struct Ctx {
+  const ScanParams &p;
+  const Loaded &ld;
+  uint32_t err; // sticky: checked integer arithmetic overflowed on a selected row
+  uint64_t row; // logical row id of the row being evaluated
+
+  template <class Ty> __device__ __forceinline__ typename Ty::T get(int s, int j) const {
+    if constexpr (Ty::W == 8) {
+      const uint64_t bits = ((uint64_t)ld.w[s][2 * j + 1] << 32) | ld.w[s][2 * j];
+      if constexpr (Ty::is_float) return __longlong_as_double((long long)bits);
+      else return (typename Ty::T)bits;
+    } else if constexpr (Ty::W == 4) {
+      if constexpr (Ty::is_float) return __uint_as_float(ld.w[s][j]);
+      else return (typename Ty::T)ld.w[s][j];
+    } else {
+      return (uint8_t)((ld.w[s][0] >> (8 * j)) & 0xffu);
+    }
+  }
+};
+
+// --------------------------------------------------------------------------
+// Scalar expressions (llkv-compute/src/fast_numeric.rs token programs, lowered to
+// a type).  The host lowering inserts the casts the reference performs: every column
+// is cast to the program's final type first (fast_numeric.rs:80-87).
+// --------------------------------------------------------------------------
+template <int S, class Ty> struct Col {
+  using Type = Ty;
+  static __device__ __forceinline__ typename Ty::T eval(Ctx &c, int j) { return c.get<Ty>(S, j); }
+};
+template <int K> struct LitI {
+  using Type = I64;
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int) { return c.p.lit_i[K]; }
+};
+template <int K> struct LitU {
+  using Type = U64;
+  static __device__ __forceinline__ uint64_t eval(Ctx &c, int) { return (uint64_t)c.p.lit_i[K]; }
+};
+template <int K> struct LitF {
+  using Type = F64;
+  static __device__ __forceinline__ double eval(Ctx &c, int) { return c.p.lit_f[K]; }
+};
+template <class E> struct ToF64 { // arrow cast int → f64 / f32 → f64
+  using Type = F64;
+  static __device__ __forceinline__ double eval(Ctx &c, int j) { return (double)E::eval(c, j); }
+};
+template <class E> struct ToI64 { // widening of the narrow integer types
+  using Type = I64;
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int j) { return (int64_t)E::eval(c, j); }
+};
+
+// Rust `f64 as i64`: saturating, NaN → 0 (llkv-executor/src/lib.rs:7385-7389).
+__device__ __forceinline__ int64_t f64_as_i64_sat(double x) {
+  if (x != x) return 0;
+  if (x >= 9223372036854775808.0) return 0x7FFFFFFFFFFFFFFFll;
+  if (x <= -9223372036854775808.0) return (int64_t)0x8000000000000000ull;
+  return (int64_t)x;
+}
+
+enum BinKind : int { B_ADD = 1, B_SUB = 2, B_MUL = 3 };
+
+// arrow-arith numeric::{add,sub,mul}: IEEE for floats, checked for integers
+// (overflow is an error: fast_numeric.rs:328-334 → Error::Internal).
+template <int OP, class L, class R> struct Bin {
+  using Type = typename L::Type;
+  static __device__ __forceinline__ typename Type::T eval(Ctx &c, int j) {
+    const auto a = L::eval(c, j);
+    const auto b = R::eval(c, j);
+    if constexpr (Type::is_float) {
+      if constexpr (OP == B_ADD) return a + b;
+      else if constexpr (OP == B_SUB) return a - b;
+      else return a * b;
+    } else {
+      int64_t z;
+      bool o;
+      if constexpr (OP == B_ADD) o = __builtin_add_overflow((int64_t)a, (int64_t)b, &z);
+      else if constexpr (OP == B_SUB) o = __builtin_sub_overflow((int64_t)a, (int64_t)b, &z);
+      else o = __builtin_mul_overflow((int64_t)a, (int64_t)b, &z);
+      c.err |= o ? 1u : 0u;
+      return z;
+    }
+  }
+};
+template <class L, class R> using Add = Bin<B_ADD, L, R>;
+template <class L, class R> using Sub = Bin<B_SUB, L, R>;
+template <class L, class R> using Mul = Bin<B_MUL, L, R>;
+
+// GROUP BY aggregate arguments go through the PlanValue interpreter, where Int∘Int for
+// + - * is computed in f64 and cast back (llkv-executor/src/lib.rs:7338-7389).
+template <int OP, class L, class R> struct BinViaF64 {
+  using Type = I64;
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int j) {
+    const double a = (double)L::eval(c, j), b = (double)R::eval(c, j);
+    if constexpr (OP == B_ADD) return f64_as_i64_sat(a + b);
+    else if constexpr (OP == B_SUB) return f64_as_i64_sat(a - b);
+    else return f64_as_i64_sat(a * b);
+  }
+};
+
+// --------------------------------------------------------------------------
+// Predicates (llkv-expr/src/typed_predicate.rs:75-146).  Native comparison operators
+// give Rust's partial_cmp behaviour: a NaN never matches an ordering or equality test.
+// Bound kinds: 0 unbounded, 1 included, 2 excluded.
+// --------------------------------------------------------------------------
+struct Nil {}; // unbounded side of a Range
+struct True {
+  static __device__ __forceinline__ bool eval(Ctx &, int) { return true; }
+};
+struct False {
+  static __device__ __forceinline__ bool eval(Ctx &, int) { return false; }
+};
+template <class E, int LK, class LO, int UK, class HI> struct Range {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    const auto v = E::eval(c, j);
+    bool ok = true;
+    // `&`, not `&&`: the row body must stay straight-line (no exec-mask branches)
+    if constexpr (LK == 1) ok = ok & (v >= LO::eval(c, j));
+    if constexpr (LK == 2) ok = ok & (v > LO::eval(c, j));
+    if constexpr (UK == 1) ok = ok & (v <= HI::eval(c, j));
+    if constexpr (UK == 2) ok = ok & (v < HI::eval(c, j));
+    return ok;
+  }
+};
+template <class E, class V> struct Eq {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return E::eval(c, j) == V::eval(c, j); }
+};
+template <class E, class... Vs> struct In {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    const auto v = E::eval(c, j);
+    return (bool)((int)(v == Vs::eval(c, j)) | ...);
+  }
+};
+template <class... Ps> struct And {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return (bool)((int)Ps::eval(c, j) & ...); }
+};
+template <class... Ps> struct Or {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return (bool)((int)Ps::eval(c, j) | ...); }
+};
+template <class P> struct Not { // domain = all rows on this path (no NULLs staged)
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return !P::eval(c, j); }
+};
+
+// --------------------------------------------------------------------------
+// Dense group ids from 1-byte dictionary codes (Utf8 keys staged as codes) or small
+// integers.  gid = Σ code_i · stride_i  <  NG.
+// --------------------------------------------------------------------------
+template <int S> struct KeyCode {
+  static __device__ __forceinline__ uint32_t code(Ctx &c, int j) { return c.get<U8>(S, j); }
+};
+template <int NG_, class... Ks> struct Keys {
+  static constexpr int NG = NG_;
+  static constexpr int NK = sizeof...(Ks);
+  template <int I, class K0, class... Kr> static __device__ __forceinline__ uint32_t acc(Ctx &c, int j) {
+    uint32_t g = K0::code(c, j) * c.p.key_stride[I];
+    if constexpr (sizeof...(Kr) > 0) g += acc<I + 1, Kr...>(c, j);
+    return g;
+  }
+  static __device__ __forceinline__ uint32_t gid(Ctx &c, int j) {
+    if constexpr (NK == 0) return 0u;
+    else return acc<0, Ks...>(c, j);
+  }
+};
+
+// --------------------------------------------------------------------------
+// Aggregate lane groups (llkv-aggregate/src/lib.rs:759-1477 state machines, restated as
+// order-independent lane updates; finalize happens on the host).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ int64_t f64_order_key(double v) { // total order, -0 canonicalised to +0
+  int64_t b = __double_as_longlong(v == 0.0 ? 0.0 : v);
+  return b < 0 ? (b ^ 0x7FFFFFFFFFFFFFFFll) : b;
+}
+
+template <class E> struct SumF64 { // SumFloat64 :870-888, AvgFloat64 :1177-1199, Total* :968-1034
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_F64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)__double_as_longlong((double)E::eval(c, j)); }
+};
+template <class E> struct SumI64 { // SumInt64 :801-830, AvgInt64 :1114-1144 — exact 96-bit split sum + max|v|
+  static constexpr int N = 3;
+  static constexpr int op(int k) { return k == 2 ? OP_MAX_U64 : OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    const int64_t v = (int64_t)E::eval(c, j);
+    o[0] = (uint64_t)(uint32_t)v;       // low 32 bits, unsigned
+    o[1] = (uint64_t)(v >> 32);         // high part, signed
+    o[2] = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+  }
+};
+// Same sum when the column statistics gathered at staging prove rows·max|v| < 2^63
+// (no prefix of the reference's checked_add chain can overflow): one wrapping lane.
+template <class E> struct SumI64Fast {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)(int64_t)E::eval(c, j); }
+};
+template <class E> struct MinI64 { // :1285-1308
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_MIN_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)(int64_t)E::eval(c, j); }
+};
+template <class E> struct MaxI64 { // :1354-1376
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_MAX_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)(int64_t)E::eval(c, j); }
+};
+// MinFloat64 :1309-1331 / MaxFloat64 :1377-1399 — sequential partial_cmp fold: a NaN never
+// replaces, a leading NaN sticks, ±0 ties keep the earlier row.  Lanes: best key over
+// non-NaN values, first zero (row<<1|sign), first selected row (row<<1|isnan).
+template <class E, bool IS_MAX> struct ExtF64 {
+  static constexpr int N = 3;
+  static constexpr int op(int k) { return k == 0 ? (IS_MAX ? OP_MAX_I64 : OP_MIN_I64) : OP_MIN_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    const double v = (double)E::eval(c, j);
+    const bool nan = v != v;
+    o[0] = nan ? lane_identity_s<IS_MAX ? OP_MAX_I64 : OP_MIN_I64>() : (uint64_t)f64_order_key(v);
+    o[1] = (v == 0.0) ? ((c.row << 1) | (uint64_t)((uint64_t)__double_as_longlong(v) >> 63)) : 0x7FFFFFFFFFFFFFFFull;
+    o[2] = (c.row << 1) | (nan ? 1u : 0u);
+  }
+};
+template <class E> using MinF64 = ExtF64<E, false>;
+template <class E> using MaxF64 = ExtF64<E, true>;
+
+template <class... As> struct Aggs {
+  static constexpr int N = (0 + ... + As::N);
+};
+
+// Plan = Cols × Pred × Keys × Aggs × unroll.  Lane layout per group:
+//   [0] rows (ADD_I64)   [1] first row id (MIN_I64, grouped plans only)   [..] aggregate lanes
+template <class CL, class PR, class KS, class AG, int U_ = 2> struct Plan {
+  using ColList = CL;
+  using Pred = PR;
+  using KeyT = KS;
+  using AggT = AG;
+  static constexpr int U = U_;
+  static constexpr int NG = KS::NG;
+  static constexpr bool grouped = KS::NK > 0;
+  static constexpr int BASE = grouped ? 2 : 1;
+  static constexpr int K = BASE + AG::N;
+  static constexpr int LANES = NG * K + 1; // + error lane (MAX_U64)
+};
+
+template <class AG> struct AggOps;
+template <class... As> struct AggOps<Aggs<As...>> {
+  template <class A0, class... Ar> static constexpr int at(int k) {
+    if (k < A0::N) return A0::op(k);
+    if constexpr (sizeof...(Ar) > 0) return at<Ar...>(k - A0::N);
+    else return OP_ADD_I64;
+  }
+  static constexpr int op(int k) {
+    if constexpr (sizeof...(As) == 0) return OP_ADD_I64;
+    else return at<As...>(k);
+  }
+  template <class A0, class... Ar> static __device__ __forceinline__ void contrib_all(Ctx &c, int j, uint64_t *o) {
+    A0::contrib(c, j, o);
+    if constexpr (sizeof...(Ar) > 0) contrib_all<Ar...>(c, j, o + A0::N);
+  }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    if constexpr (sizeof...(As) > 0) contrib_all<As...>(c, j, o);
+  }
+};
+
+template <class P> constexpr int plan_lane_op(int lane) {
+  if (lane == P::NG * P::K) return OP_MAX_U64; // error lane
+  const int k = lane % P::K;
+  if (k == 0) return OP_ADD_I64;
+  if (P::grouped && k == 1) return OP_MIN_I64;
+  return AggOps<typename P::AggT>::op(k - P::BASE);
+}
+
+template <class P> struct LaneOpTable {
+  int v[P::LANES];
+  constexpr LaneOpTable() : v{} {
+    for (int i = 0; i < P::LANES; ++i) v[i] = plan_lane_op<P>(i);
+  }
+};
+
+// --------------------------------------------------------------------------
+// The kernel
+// --------------------------------------------------------------------------
+constexpr int kRedBatch = 16;                 // lanes transposed through LDS per round
+constexpr int kRedRow = kBlock + kBlock / 16; // 16-element segments padded to 17
+
+template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {
+  constexpr int NG = P::NG, K = P::K, U = P::U, LANES = P::LANES;
+  constexpr LaneOpTable<P> ops{};
+  __shared__ uint64_t red[LANES < kRedBatch ? LANES : kRedBatch][kRedRow];
+
+  uint64_t acc[NG][K];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[g][k] = lane_identity(ops.v[g * K + k]);
+  uint32_t err = 0;
+
+  const TileDesc td = p.tiles[blockIdx.x];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
+
+  for (uint32_t s = 0; s < nsteps; s += U) {
+    Loaded ld[U];
+    // issue every load of the unrolled group before the first use (column buffers carry
+    // slack past the last tile, so the tail steps may read — and discard — past td.rows)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t row0 = (uint64_t)(s + u) * kStepRows + (uint64_t)tid * kRowsPerThread;
+      load_all<typename P::ColList>(p, td.dev_row + row0, ld[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t row0 = (s + u) * kStepRows + tid * kRowsPerThread;
+#pragma unroll
+      for (int j = 0; j < kRowsPerThread; ++j) {
+        Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
+        const bool in_tile = (row0 + j) < td.rows;
+        const bool pass = in_tile & P::Pred::eval(c, j);
+        const uint32_t gid = P::KeyT::gid(c, j);
+        uint64_t contrib[K];
+        contrib[0] = 1;
+        if constexpr (P::grouped) contrib[1] = c.row;
+        AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
+        err |= pass ? c.err : 0u;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool sel = pass & (NG == 1 || gid == (uint32_t)g);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int op = ops.v[g * K + k];
+            const uint64_t x = sel ? contrib[k] : lane_identity(op);
+            acc[g][k] = lane_combine(op, acc[g][k], x);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- block reduction: LDS transpose in rounds of kRedBatch lanes, fixed order ----
+  const uint32_t slot = tid + (tid >> 4); // padded position of this thread's element
+  const uint32_t ri = tid >> 4;           // lane of the round this thread reduces
+  const uint32_t rq = tid & 15;           // 16-element segment it reduces
+#pragma unroll
+  for (int base = 0; base < LANES; base += kRedBatch) {
+#pragma unroll
+    for (int i = 0; i < kRedBatch; ++i) {
+      const int lane = base + i;
+      if (lane < LANES) {
+        uint64_t v;
+        if (lane == NG * K) v = err;
+        else v = acc[lane / K][lane % K];
+        red[i][slot] = v;
+      }
+    }
+    __syncthreads();
+    const int lane = base + (int)ri;
+    if (lane < LANES) {
+      const int op = ops.v[lane];
+      const uint32_t seg = rq * 17;
+      uint64_t v = red[ri][seg];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) v = lane_combine(op, v, red[ri][seg + e]);
+      // butterfly over the 16 segment owners (lanes of one 16-lane row of the wave)
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 16);
+        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 16);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        // fixed operand order (lower segment first) keeps f64 adds reproducible
+        v = (rq & off) ? lane_combine(op, o, v) : lane_combine(op, v, o);
+      }
+      if (rq == 0) p.tile_partials[(uint64_t)lane * p.n_tiles + blockIdx.x] = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <class P> __global__ __launch_bounds__(kBlock) void fused_scan_kernel(const ScanParams p) { fused_scan_body<P>(p); }
+
+// --------------------------------------------------------------------------
+// Fold tile partials into the canonical octant partials (exchange buffer).
+// grid = (kOctants, ceil(lanes / 4)); one wave per (octant, lane).  Octants this rank
+// does not own are written as zero so that an integer-sum all-reduce of the buffer
+// concatenates the ranks' states bit-exactly.
+// --------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void fold_octants_kernel(const FoldParams f) {
+  const uint32_t o = blockIdx.x;
+  const uint32_t lane = blockIdx.y * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t l = threadIdx.x & 63;
+  if (lane >= f.lanes) return;
+  if (!((f.owned_mask >> o) & 1u)) {
+    if (l == 0) f.exchange[(uint64_t)o * f.lanes + lane] = 0;
+    return;
+  }
+  const int op = f.lane_ops[lane];
+  const uint32_t t0 = f.octant_tile_begin[o], t1 = f.octant_tile_begin[o + 1];
+  const uint64_t *src = f.tile_partials + (uint64_t)lane * f.n_tiles;
+  uint64_t v = lane_identity(op);
+  for (uint32_t t = t0 + l; t < t1; t += 64) v = lane_combine(op, v, src[t]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+    const uint64_t ov = ((uint64_t)hi << 32) | lo;
+    v = (l & off) ? lane_combine(op, ov, v) : lane_combine(op, v, ov);
+  }
+  if (l == 0) f.exchange[(uint64_t)o * f.lanes + lane] = v;
+}
+
+} // namespace llkv

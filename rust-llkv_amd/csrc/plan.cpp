@@ -1,0 +1,573 @@
+// plan.cpp — see plan.hpp.
+#include "plan.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace llkv {
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+static constexpr int kMaxColsHost = 8;
+static constexpr int kMaxLitsHost = 12;
+static constexpr int kMaxKeysHost = 4;
+static constexpr uint32_t kMaxDenseGroups = 8;
+
+const char *dtype_name(int32_t dt) {
+  switch (dt) {
+  case LLKV_DT_INT64: return "Int64";
+  case LLKV_DT_FLOAT64: return "Float64";
+  case LLKV_DT_INT32: return "Int32";
+  case LLKV_DT_DATE32: return "Date32";
+  case LLKV_DT_UINT64: return "UInt64";
+  case LLKV_DT_UINT32: return "UInt32";
+  case LLKV_DT_FLOAT32: return "Float32";
+  case LLKV_DT_UTF8: return "Utf8";
+  case LLKV_DT_BOOLEAN: return "Boolean";
+  default: return "Null";
+  }
+}
+
+const char *dtype_tag(int32_t dt) {
+  switch (dt) {
+  case LLKV_DT_INT64: return "I64";
+  case LLKV_DT_FLOAT64: return "F64";
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: return "I32";
+  case LLKV_DT_UINT64: return "U64";
+  case LLKV_DT_UINT32: return "U32";
+  case LLKV_DT_FLOAT32: return "F32";
+  case LLKV_DT_UTF8: case LLKV_DT_BOOLEAN: return "U8";
+  default: return "?";
+  }
+}
+
+uint32_t dtype_width(int32_t dt) {
+  switch (dt) {
+  case LLKV_DT_INT64: case LLKV_DT_FLOAT64: case LLKV_DT_UINT64: return 8;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: case LLKV_DT_UINT32: case LLKV_DT_FLOAT32: return 4;
+  case LLKV_DT_UTF8: case LLKV_DT_BOOLEAN: return 1;
+  default: return 0;
+  }
+}
+
+static i128 lit_i128(const llkv_literal &l) { return (i128)(((u128)(uint64_t)l.hi << 64) | (u128)l.lo); }
+
+static const char *lit_kind(const llkv_literal &l) {
+  switch (l.tag) {
+  case LLKV_LIT_FLOAT64: return "float";
+  case LLKV_LIT_BOOLEAN: return "boolean";
+  case LLKV_LIT_STRING: return "string";
+  case LLKV_LIT_DATE32: return "date";
+  case LLKV_LIT_DECIMAL128: return "decimal";
+  case LLKV_LIT_NULL: return "null";
+  default: return "integer";
+  }
+}
+
+// compiler-rt __powidf2 — what Rust's f64::powi lowers to (llkv-types/src/decimal.rs:102-108)
+static double powi_f64(double a, int b) {
+  const bool recip = b < 0;
+  double r = 1;
+  for (;;) {
+    if (b & 1) r *= a;
+    b /= 2;
+    if (b == 0) break;
+    a *= a;
+  }
+  return recip ? 1 / r : r;
+}
+
+static int set_err(std::string *err, int code, const std::string &msg) {
+  if (err) *err = msg;
+  return code;
+}
+
+// llkv-types/src/literal.rs:364-520
+int cast_literal_for_column(const llkv_literal &lit, int32_t dtype, NativeLit *out, std::string *err) {
+  auto int_cast = [&](i128 lo, i128 hi, const char *target) -> int {
+    i128 v;
+    if (lit.tag == LLKV_LIT_INT128) v = lit_i128(lit);
+    else if (lit.tag == LLKV_LIT_DECIMAL128 && lit.scale == 0) v = lit_i128(lit);
+    else return set_err(err, LLKV_PREDICATE_BUILD, std::string("literal cast error: expected integer, got ") + lit_kind(lit));
+    if (v < lo || v > hi) return set_err(err, LLKV_PREDICATE_BUILD, std::string("literal cast error: value out of range for ") + target);
+    out->i = (int64_t)v;
+    return LLKV_OK;
+  };
+  auto f64_cast = [&](double *dst) -> int {
+    switch (lit.tag) {
+    case LLKV_LIT_FLOAT64: *dst = lit.f64; return LLKV_OK;
+    case LLKV_LIT_INT128: *dst = (double)lit_i128(lit); return LLKV_OK;
+    case LLKV_LIT_DECIMAL128: {
+      i128 raw = lit_i128(lit);
+      *dst = raw == 0 ? 0.0 : (double)raw / powi_f64(10.0, lit.scale);
+      return LLKV_OK;
+    }
+    default: return set_err(err, LLKV_PREDICATE_BUILD, std::string("literal cast error: expected float, got ") + lit_kind(lit));
+    }
+  };
+  *out = NativeLit{};
+  switch (dtype) {
+  case LLKV_DT_INT64: return int_cast((i128)INT64_MIN, (i128)INT64_MAX, "i64");
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: return int_cast(INT32_MIN, INT32_MAX, "i32"); // Date32 filters as i32
+  case LLKV_DT_UINT32: return int_cast(0, UINT32_MAX, "u32");
+  case LLKV_DT_UINT64: {
+    out->is_unsigned = true;
+    i128 v;
+    if (lit.tag == LLKV_LIT_INT128 || (lit.tag == LLKV_LIT_DECIMAL128 && lit.scale == 0)) v = lit_i128(lit);
+    else return set_err(err, LLKV_PREDICATE_BUILD, std::string("literal cast error: expected integer, got ") + lit_kind(lit));
+    if (v < 0 || v > (i128)UINT64_MAX) return set_err(err, LLKV_PREDICATE_BUILD, "literal cast error: value out of range for u64");
+    out->i = (int64_t)(uint64_t)v;
+    return LLKV_OK;
+  }
+  case LLKV_DT_FLOAT64: out->is_float = true; return f64_cast(&out->f);
+  case LLKV_DT_FLOAT32: {
+    out->is_float = true;
+    double v;
+    int rc = f64_cast(&v);
+    if (rc) return rc;
+    float c = (float)v;
+    if (!std::isfinite(c)) return set_err(err, LLKV_PREDICATE_BUILD, "literal cast error: float out of range for f32");
+    out->f = (double)c;
+    return LLKV_OK;
+  }
+  default:
+    return set_err(err, LLKV_INTERNAL, std::string("Filtering on type ") + dtype_name(dtype) + " is not supported");
+  }
+}
+
+namespace {
+
+struct Lowering {
+  const ColumnResolver &resolve;
+  LoweredPlan &p;
+  std::string *err;
+  bool grouped;
+
+  int fail(int code, const std::string &m) { return set_err(err, code, m); }
+
+  int slot_of(uint32_t field, const ColumnInfo **ci_out, int *slot) {
+    const ColumnInfo *ci = resolve(field);
+    if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(field) + " not found");
+    *ci_out = ci;
+    for (size_t i = 0; i < p.slot_fields.size(); ++i)
+      if (p.slot_fields[i] == field) { *slot = (int)i; return LLKV_OK; }
+    if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 8 columns");
+    p.slot_fields.push_back(field);
+    p.slot_dtypes.push_back(ci->dtype);
+    *slot = (int)p.slot_fields.size() - 1;
+    return LLKV_OK;
+  }
+  std::string col_node(int slot, int32_t dtype) { return "Col<" + std::to_string(slot) + "," + dtype_tag(dtype) + ">"; }
+
+  int lit_i(int64_t v, std::string *node, const char *kind = "LitI") {
+    if ((int)p.lit_i.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many integer literals");
+    p.lit_i.push_back(v);
+    *node = std::string(kind) + "<" + std::to_string(p.lit_i.size() - 1) + ">";
+    return LLKV_OK;
+  }
+  int lit_f(double v, std::string *node) {
+    if ((int)p.lit_f.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many float literals");
+    p.lit_f.push_back(v);
+    *node = "LitF<" + std::to_string(p.lit_f.size() - 1) + ">";
+    return LLKV_OK;
+  }
+
+  int native_node(const llkv_literal &l, int32_t dtype, std::string *node) {
+    NativeLit n;
+    int rc = cast_literal_for_column(l, dtype, &n, err);
+    if (rc) return rc;
+    if (n.is_float) return lit_f(n.f, node);
+    return lit_i(n.i, node, n.is_unsigned ? "LitU" : "LitI");
+  }
+
+  // One leaf filter → predicate node (llkv-table/src/table.rs:1117-1171).
+  int leaf(const llkv_filter &f, std::string *out) {
+    const ColumnInfo *ci = resolve(f.field_id);
+    if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(f.field_id) + " not found");
+    if (f.op == LLKV_OP_IS_NOT_NULL) { *out = "True"; return LLKV_OK; }  // NULL-free staged columns
+    if (f.op == LLKV_OP_IS_NULL) { *out = "False"; return LLKV_OK; }
+    if (f.op == LLKV_OP_RANGE && f.lower_kind == LLKV_BOUND_UNBOUNDED && f.upper_kind == LLKV_BOUND_UNBOUNDED) { *out = "True"; return LLKV_OK; }
+    int slot;
+    int rc;
+    if (ci->dtype == LLKV_DT_UTF8) { // dictionary codes: equality only
+      auto code_of = [&](const llkv_literal &l, int *code) -> int {
+        if (l.tag != LLKV_LIT_STRING || !l.str) return fail(LLKV_PREDICATE_BUILD, std::string("literal cast error: expected string, got ") + lit_kind(l));
+        *code = -1;
+        for (size_t i = 0; i < ci->dictionary.size(); ++i) if (ci->dictionary[i] == l.str) *code = (int)i;
+        return LLKV_OK;
+      };
+      if (f.op == LLKV_OP_EQUALS) {
+        int code;
+        if ((rc = code_of(f.value, &code))) return rc;
+        if (code < 0) { *out = "False"; return LLKV_OK; }
+        if ((rc = slot_of(f.field_id, &ci, &slot))) return rc;
+        std::string lit;
+        if ((rc = lit_i(code, &lit))) return rc;
+        *out = "Eq<" + col_node(slot, ci->dtype) + "," + lit + ">";
+        return LLKV_OK;
+      }
+      if (f.op == LLKV_OP_IN) {
+        std::string lits;
+        for (uint32_t i = 0; i < f.in_len; ++i) {
+          int code;
+          if ((rc = code_of(f.in_list[i], &code))) return rc;
+          if (code < 0) continue;
+          std::string lit;
+          if ((rc = lit_i(code, &lit))) return rc;
+          lits += "," + lit;
+        }
+        if (lits.empty()) { *out = "False"; return LLKV_OK; }
+        if ((rc = slot_of(f.field_id, &ci, &slot))) return rc;
+        *out = "In<" + col_node(slot, ci->dtype) + lits + ">";
+        return LLKV_OK;
+      }
+      return fail(LLKV_UNSUPPORTED, "ordering predicates on dictionary-coded Utf8 columns");
+    }
+    if (dtype_width(ci->dtype) == 0 || ci->dtype == LLKV_DT_BOOLEAN)
+      return fail(LLKV_INTERNAL, std::string("Filtering on type ") + dtype_name(ci->dtype) + " is not supported");
+    // cast every literal first: cast errors surface even when the column needs no slot yet
+    std::string a, lo, hi;
+    switch (f.op) {
+    case LLKV_OP_EQUALS: case LLKV_OP_GT: case LLKV_OP_GE: case LLKV_OP_LT: case LLKV_OP_LE:
+      if ((rc = native_node(f.value, ci->dtype, &a))) return rc;
+      break;
+    case LLKV_OP_RANGE:
+      if (f.lower_kind != LLKV_BOUND_UNBOUNDED && (rc = native_node(f.lower, ci->dtype, &lo))) return rc;
+      if (f.upper_kind != LLKV_BOUND_UNBOUNDED && (rc = native_node(f.upper, ci->dtype, &hi))) return rc;
+      break;
+    case LLKV_OP_IN:
+      for (uint32_t i = 0; i < f.in_len; ++i) {
+        std::string n;
+        if ((rc = native_node(f.in_list[i], ci->dtype, &n))) return rc;
+        a += "," + n;
+      }
+      break;
+    default:
+      return fail(LLKV_PREDICATE_BUILD, "unsupported operator for typed predicate: operator lacks typed literal support");
+    }
+    if ((rc = slot_of(f.field_id, &ci, &slot))) return rc;
+    const std::string col = col_node(slot, ci->dtype);
+    switch (f.op) {
+    case LLKV_OP_EQUALS: *out = "Eq<" + col + "," + a + ">"; break;
+    case LLKV_OP_GT: *out = "Range<" + col + ",2," + a + ",0,Nil>"; break;
+    case LLKV_OP_GE: *out = "Range<" + col + ",1," + a + ",0,Nil>"; break;
+    case LLKV_OP_LT: *out = "Range<" + col + ",0,Nil,2," + a + ">"; break;
+    case LLKV_OP_LE: *out = "Range<" + col + ",0,Nil,1," + a + ">"; break;
+    case LLKV_OP_RANGE:
+      *out = "Range<" + col + "," + std::to_string(f.lower_kind) + "," + (lo.empty() ? "Nil" : lo) + "," +
+             std::to_string(f.upper_kind) + "," + (hi.empty() ? "Nil" : hi) + ">";
+      break;
+    case LLKV_OP_IN:
+      *out = a.empty() ? std::string("False") : "In<" + col + a + ">";
+      break;
+    }
+    return LLKV_OK;
+  }
+
+  // Predicate program (llkv-compute/src/program.rs:48-78) → nested node.
+  int predicate(const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops, std::string *out) {
+    int rc;
+    if (n_ops == 0) {
+      if (n_filters == 0) { *out = "True"; return LLKV_OK; }
+      std::string s = "And<";
+      for (uint32_t i = 0; i < n_filters; ++i) {
+        std::string l;
+        if ((rc = leaf(filters[i], &l))) return rc;
+        s += (i ? "," : "") + l;
+      }
+      *out = s + ">";
+      return LLKV_OK;
+    }
+    std::vector<std::string> st;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+      switch (ops[k].op) {
+      case LLKV_EVAL_PUSH_PREDICATE: {
+        if (ops[k].arg >= n_filters) return fail(LLKV_INTERNAL, "predicate index out of range");
+        std::string l;
+        if ((rc = leaf(filters[ops[k].arg], &l))) return rc;
+        st.push_back(l);
+        break;
+      }
+      case LLKV_EVAL_PUSH_LITERAL: st.push_back(ops[k].arg ? "True" : "False"); break;
+      case LLKV_EVAL_AND: case LLKV_EVAL_OR: {
+        if (ops[k].arg == 0 || ops[k].arg > st.size()) return fail(LLKV_INTERNAL, "predicate stack underflow");
+        std::string s = ops[k].op == LLKV_EVAL_AND ? "And<" : "Or<";
+        size_t b = st.size() - ops[k].arg;
+        for (size_t i = b; i < st.size(); ++i) s += (i > b ? "," : "") + st[i];
+        st.resize(b);
+        st.push_back(s + ">");
+        break;
+      }
+      case LLKV_EVAL_NOT:
+        if (st.empty()) return fail(LLKV_INTERNAL, "predicate stack underflow");
+        st.back() = "Not<" + st.back() + ">";
+        break;
+      default: return fail(LLKV_INTERNAL, "unknown predicate opcode");
+      }
+    }
+    if (st.size() != 1) return fail(LLKV_INTERNAL, "predicate program left " + std::to_string(st.size()) + " entries");
+    *out = st[0];
+    return LLKV_OK;
+  }
+
+  static bool is_int_class(int32_t dt) { return dt == LLKV_DT_INT64 || dt == LLKV_DT_INT32 || dt == LLKV_DT_UINT32; }
+  static bool is_float_class(int32_t dt) { return dt == LLKV_DT_FLOAT64 || dt == LLKV_DT_FLOAT32; }
+
+  // Computed projection, fast numeric path: final type first, then every column cast to
+  // it and every literal broadcast in it (llkv-compute/src/fast_numeric.rs:69-121).
+  int expr_fast(const llkv_expr_token *e, uint32_t n, std::string *node, bool *is_f64) {
+    bool any_float = false;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind == LLKV_TOK_COLUMN) {
+        const ColumnInfo *ci = resolve(e[i].field_id);
+        if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(e[i].field_id) + " not found");
+        if (is_float_class(ci->dtype)) any_float = true;
+        else if (!is_int_class(ci->dtype)) return fail(LLKV_UNSUPPORTED, std::string("computed projection over ") + dtype_name(ci->dtype));
+      } else if (e[i].kind == LLKV_TOK_LITERAL) {
+        if (e[i].literal.tag == LLKV_LIT_FLOAT64) any_float = true;
+        else if (e[i].literal.tag != LLKV_LIT_INT128) return fail(LLKV_UNSUPPORTED, "non-numeric literal in computed projection");
+      } else if (e[i].kind == LLKV_TOK_BINARY) {
+        if (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "division in computed projections (NULL on zero) is not on the GPU path");
+      }
+    }
+    std::vector<std::string> st;
+    int rc;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind == LLKV_TOK_COLUMN) {
+        const ColumnInfo *ci;
+        int slot;
+        if ((rc = slot_of(e[i].field_id, &ci, &slot))) return rc;
+        std::string c = col_node(slot, ci->dtype);
+        if (any_float) { if (ci->dtype != LLKV_DT_FLOAT64) c = "ToF64<" + c + ">"; }
+        else if (ci->dtype != LLKV_DT_INT64) c = "ToI64<" + c + ">";
+        st.push_back(c);
+      } else if (e[i].kind == LLKV_TOK_LITERAL) {
+        std::string l;
+        const llkv_literal &lit = e[i].literal;
+        if (any_float) rc = lit_f(lit.tag == LLKV_LIT_FLOAT64 ? lit.f64 : (double)lit_i128(lit), &l);
+        else rc = lit_i((int64_t)lit_i128(lit), &l);
+        if (rc) return rc;
+        st.push_back(l);
+      } else {
+        if (st.size() < 2) return fail(LLKV_INTERNAL, "fast path stack underflow");
+        std::string r = st.back(); st.pop_back();
+        std::string l = st.back(); st.pop_back();
+        const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : 3;
+        st.push_back("Bin<" + std::to_string(op) + "," + l + "," + r + ">");
+      }
+    }
+    if (st.size() != 1) return fail(LLKV_INTERNAL, "fast path evaluation missing result");
+    *node = st[0];
+    *is_f64 = any_float;
+    return LLKV_OK;
+  }
+
+  // GROUP BY aggregate argument, PlanValue semantics (llkv-executor/src/lib.rs:7193-7389).
+  int expr_planvalue(const llkv_expr_token *e, uint32_t n, std::string *node, bool *is_f64) {
+    struct V { std::string s; bool f; };
+    std::vector<V> st;
+    int rc;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind == LLKV_TOK_COLUMN) {
+        const ColumnInfo *ci;
+        int slot;
+        if ((rc = slot_of(e[i].field_id, &ci, &slot))) return rc;
+        std::string c = col_node(slot, ci->dtype);
+        if (ci->dtype == LLKV_DT_FLOAT64) st.push_back({c, true});
+        else if (ci->dtype == LLKV_DT_FLOAT32) st.push_back({"ToF64<" + c + ">", true});
+        else if (ci->dtype == LLKV_DT_INT64) st.push_back({c, false});
+        else if (is_int_class(ci->dtype)) st.push_back({"ToI64<" + c + ">", false});
+        else return fail(LLKV_UNSUPPORTED, std::string("aggregate expression over ") + dtype_name(ci->dtype));
+      } else if (e[i].kind == LLKV_TOK_LITERAL) {
+        std::string l;
+        const llkv_literal &lit = e[i].literal;
+        if (lit.tag == LLKV_LIT_FLOAT64) { if ((rc = lit_f(lit.f64, &l))) return rc; st.push_back({l, true}); }
+        else if (lit.tag == LLKV_LIT_INT128) { if ((rc = lit_i((int64_t)lit_i128(lit), &l))) return rc; st.push_back({l, false}); }
+        else return fail(LLKV_UNSUPPORTED, "literal kind in aggregate expression");
+      } else {
+        if (st.size() < 2) return fail(LLKV_INTERNAL, "expression stack underflow");
+        V r = st.back(); st.pop_back();
+        V l = st.back(); st.pop_back();
+        if (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "division in aggregate expressions (NULL on zero) is not on the GPU path");
+        const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : 3;
+        if (!l.f && !r.f) st.push_back({"BinViaF64<" + std::to_string(op) + "," + l.s + "," + r.s + ">", false});
+        else {
+          const std::string a = l.f ? l.s : "ToF64<" + l.s + ">", b = r.f ? r.s : "ToF64<" + r.s + ">";
+          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + ">", true});
+        }
+      }
+    }
+    if (st.size() != 1) return fail(LLKV_INTERNAL, "expression evaluation missing result");
+    *node = st[0].s;
+    *is_f64 = st[0].f;
+    return LLKV_OK;
+  }
+};
+
+} // namespace
+
+int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
+               const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  LoweredPlan &p = *out;
+  Lowering L{resolve, p, err, grouped};
+  p.grouped = grouped;
+  int rc;
+  if (n_aggs == 0 && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate query requires at least one aggregate expression");
+  if (grouped && n_keys == 0) return L.fail(LLKV_INVALID_ARGUMENT, "GROUP BY requires at least one key");
+
+  std::string pred;
+  if ((rc = L.predicate(filters, n_filters, ops, n_ops, &pred))) return rc;
+  p.always_false = pred == "False";
+
+  // keys
+  std::string keys = "Keys<";
+  if (grouped) {
+    if (n_keys > (uint32_t)kMaxKeysHost) return L.fail(LLKV_UNSUPPORTED, "more than 4 GROUP BY keys");
+    uint64_t ng = 1;
+    std::string nodes;
+    for (uint32_t k = 0; k < n_keys; ++k) {
+      const ColumnInfo *ci;
+      int slot;
+      const ColumnInfo *probe = resolve(key_fields[k]);
+      if (!probe) return L.fail(LLKV_INVALID_ARGUMENT, "column '" + std::to_string(key_fields[k]) + "' not found in GROUP BY input");
+      if (probe->dtype == LLKV_DT_FLOAT64 || probe->dtype == LLKV_DT_FLOAT32)
+        return L.fail(LLKV_INVALID_ARGUMENT, std::string("GROUP BY does not support column type ") + dtype_name(probe->dtype));
+      if (probe->dtype != LLKV_DT_UTF8) return L.fail(LLKV_UNSUPPORTED, "dense GROUP BY needs dictionary-coded keys (integer keys take the hash path)");
+      if ((rc = L.slot_of(key_fields[k], &ci, &slot))) return rc;
+      uint32_t card = (uint32_t)(ci->dictionary.empty() ? 1 : ci->dictionary.size());
+      p.key_fields.push_back(key_fields[k]);
+      p.key_slots.push_back((uint32_t)slot);
+      p.key_cards.push_back(card);
+      ng *= card;
+      nodes += ",KeyCode<" + std::to_string(slot) + ">";
+    }
+    if (ng > kMaxDenseGroups) return L.fail(LLKV_UNSUPPORTED, "more than 8 dense groups (" + std::to_string(ng) + ")");
+    p.ng = (uint32_t)ng;
+    p.key_strides.assign(n_keys, 1);
+    for (int k = (int)n_keys - 2; k >= 0; --k) p.key_strides[k] = p.key_strides[k + 1] * p.key_cards[k + 1];
+    keys += std::to_string(p.ng) + nodes + ">";
+  } else {
+    p.ng = 1;
+    keys += "1>";
+  }
+
+  // aggregates → deduplicated lane groups
+  const int base = grouped ? 2 : 1;
+  std::vector<std::string> groups; // lane-group node strings
+  std::vector<int> group_lane;     // first lane (relative to base) of each lane group
+  std::vector<std::vector<uint8_t>> group_ops;
+  int next_lane = 0;
+  auto add_group = [&](const std::string &node, std::vector<uint8_t> lane_ops) -> int {
+    for (size_t i = 0; i < groups.size(); ++i) if (groups[i] == node) return group_lane[i];
+    groups.push_back(node);
+    group_lane.push_back(next_lane);
+    group_ops.push_back(lane_ops);
+    next_lane += (int)lane_ops.size();
+    return group_lane.back();
+  };
+  enum { ADD_F64 = 0, ADD_I64 = 1, MIN_I64 = 2, MAX_I64 = 3, MAX_U64 = 4 };
+
+  for (uint32_t a = 0; a < n_aggs; ++a) {
+    const llkv_aggregate_spec &s = aggs[a];
+    if (s.distinct) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates are not on the GPU path");
+    AggOut o{AggFinal::CountRows, -1};
+    if (s.kind == LLKV_AGG_COUNT_STAR) { p.aggs.push_back(o); continue; }
+    if (!s.expr || s.expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
+    const bool simple = s.expr_len == 1 && s.expr[0].kind == LLKV_TOK_COLUMN;
+    std::string node;
+    bool is_f64 = false;
+    const ColumnInfo *simple_ci = nullptr;
+    if (simple) {
+      simple_ci = resolve(s.expr[0].field_id);
+      if (!simple_ci) return L.fail(LLKV_INVALID_ARGUMENT, "unknown column '" + std::to_string(s.expr[0].field_id) + "' in aggregate");
+    }
+    if (s.kind == LLKV_AGG_COUNT || s.kind == LLKV_AGG_COUNT_NULLS) {
+      // NULL-free staged columns: COUNT(x) = rows, COUNT_NULLS(x) = 0; the argument still has to resolve
+      for (uint32_t i = 0; i < s.expr_len; ++i)
+        if (s.expr[i].kind == LLKV_TOK_COLUMN && !resolve(s.expr[i].field_id)) return L.fail(LLKV_NOT_FOUND, "field not found");
+      o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
+      p.aggs.push_back(o);
+      continue;
+    }
+    const char *fn = s.kind == LLKV_AGG_SUM ? "SUM" : s.kind == LLKV_AGG_TOTAL ? "TOTAL" : s.kind == LLKV_AGG_AVG ? "AVG" : s.kind == LLKV_AGG_MIN ? "MIN" : "MAX";
+    if (simple) {
+      // validate_aggregate_type llkv-executor/src/lib.rs:5946-5988
+      const int32_t dt = simple_ci->dtype;
+      if (dt == LLKV_DT_UTF8 || dt == LLKV_DT_BOOLEAN || dt == LLKV_DT_DATE32)
+        return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over " + dtype_name(dt) + " (SQLite-style numeric coercion) is not on the GPU path");
+      if (dt != LLKV_DT_INT64 && dt != LLKV_DT_FLOAT64)
+        return L.fail(LLKV_INVALID_ARGUMENT, std::string(fn) + " aggregate not supported for column type " + dtype_name(dt));
+      const ColumnInfo *ci;
+      int slot;
+      if ((rc = L.slot_of(s.expr[0].field_id, &ci, &slot))) return rc;
+      node = L.col_node(slot, dt);
+      is_f64 = dt == LLKV_DT_FLOAT64;
+    } else {
+      rc = grouped ? L.expr_planvalue(s.expr, s.expr_len, &node, &is_f64) : L.expr_fast(s.expr, s.expr_len, &node, &is_f64);
+      if (rc) return rc;
+    }
+    // statistics that exclude i64 overflow of any prefix sum: rows · max|v| ≤ i64::MAX
+    bool fast_i64 = false;
+    if (!is_f64 && simple && simple_ci->has_stats) {
+      auto mag = [](int64_t v) -> u128 { return v < 0 ? (u128)(-(i128)v) : (u128)v; };
+      u128 m = mag(simple_ci->min_i) > mag(simple_ci->max_i) ? mag(simple_ci->min_i) : mag(simple_ci->max_i);
+      fast_i64 = m * (u128)simple_ci->rows <= (u128)INT64_MAX;
+    }
+    switch (s.kind) {
+    case LLKV_AGG_SUM:
+      if (is_f64) { o.fin = AggFinal::SumF64; o.lane = add_group("SumF64<" + node + ">", {ADD_F64}); }
+      else if (fast_i64) { o.fin = AggFinal::SumI64Fast; o.lane = add_group("SumI64Fast<" + node + ">", {ADD_I64}); }
+      else { o.fin = AggFinal::SumI64; o.lane = add_group("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
+      break;
+    case LLKV_AGG_TOTAL:
+      o.fin = AggFinal::TotalF64;
+      o.lane = add_group(is_f64 ? "SumF64<" + node + ">" : "SumF64<ToF64<" + node + ">>", {ADD_F64});
+      break;
+    case LLKV_AGG_AVG:
+      if (is_f64) { o.fin = AggFinal::AvgF64; o.lane = add_group("SumF64<" + node + ">", {ADD_F64}); }
+      else if (fast_i64) { o.fin = AggFinal::AvgI64Fast; o.lane = add_group("SumI64Fast<" + node + ">", {ADD_I64}); }
+      else { o.fin = AggFinal::AvgI64; o.lane = add_group("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
+      break;
+    case LLKV_AGG_MIN:
+      if (is_f64) { o.fin = AggFinal::MinF64; o.lane = add_group("MinF64<" + node + ">", {MIN_I64, MIN_I64, MIN_I64}); }
+      else { o.fin = AggFinal::MinI64; o.lane = add_group("MinI64<" + node + ">", {MIN_I64}); }
+      break;
+    case LLKV_AGG_MAX:
+      if (is_f64) { o.fin = AggFinal::MaxF64; o.lane = add_group("MaxF64<" + node + ">", {MAX_I64, MIN_I64, MIN_I64}); }
+      else { o.fin = AggFinal::MaxI64; o.lane = add_group("MaxI64<" + node + ">", {MAX_I64}); }
+      break;
+    default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
+    }
+    p.aggs.push_back(o);
+  }
+
+  p.k = base + next_lane;
+  p.lanes = (int)p.ng * p.k + 1;
+  p.lane_ops.clear();
+  for (uint32_t g = 0; g < p.ng; ++g) {
+    p.lane_ops.push_back(ADD_I64);
+    if (grouped) p.lane_ops.push_back(MIN_I64);
+    for (auto &go : group_ops) for (uint8_t op : go) p.lane_ops.push_back(op);
+  }
+  p.lane_ops.push_back(MAX_U64);
+  p.unroll = p.lanes <= 8 ? 4 : 2;
+
+  std::string cols = "Cols<";
+  p.bytes_per_row = 0;
+  for (size_t i = 0; i < p.slot_dtypes.size(); ++i) {
+    cols += (i ? "," : "") + std::string(dtype_tag(p.slot_dtypes[i]));
+    p.bytes_per_row += dtype_width(p.slot_dtypes[i]);
+  }
+  cols += ">";
+  std::string ag = "Aggs<";
+  for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
+  ag += ">";
+  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + ">";
+  return LLKV_OK;
+}
+
+} // namespace llkv

@@ -1,0 +1,91 @@
+// plan.hpp — host-side lowering of the reference's plan vocabulary (filters, predicate
+// program, postfix expressions, aggregate specs; see include/llkv_hip.h) to a kernel plan:
+// a C++ type string naming an instantiation of fused_scan_kernel<Plan<...>>, the literal
+// banks, the column slots and the lane layout the host needs to finalize.
+//
+// The lowering restates, on the host, the typing decisions of the reference:
+//   literal → native casts            llkv-types/src/literal.rs:364-520
+//   leaf predicate typing             llkv-expr/src/typed_predicate.rs:253-312
+//   computed projection typing        llkv-compute/src/kernels.rs:179-242, fast_numeric.rs:69-121
+//   aggregate admission / accumulators llkv-executor/src/lib.rs:5946-5988, llkv-aggregate/src/lib.rs:463-748
+//   GROUP BY argument semantics       llkv-executor/src/lib.rs:7193-7389
+#pragma once
+
+#include "llkv_hip.h"
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace llkv {
+
+struct ColumnInfo {
+  uint32_t field_id = 0;
+  int32_t dtype = LLKV_DT_NULL;
+  uint64_t rows = 0;                    // global row count of the table
+  bool has_stats = false;               // integer min/max known (staging statistics)
+  int64_t min_i = 0, max_i = 0;
+  std::vector<std::string> dictionary;  // LLKV_DT_UTF8: code → string
+};
+
+using ColumnResolver = std::function<const ColumnInfo *(uint32_t field_id)>;
+
+enum class AggFinal : int {
+  CountRows,   // COUNT(*) / COUNT(col) on a NULL-free column
+  SumI64,      // 3 lanes: lo32, hi32, max|v|
+  SumI64Fast,  // 1 wrapping lane, overflow excluded by statistics
+  SumF64,      // 1 lane
+  TotalF64,    // SumF64 lane, never NULL
+  AvgI64,      // SumI64 lanes + rows
+  AvgI64Fast,
+  AvgF64,
+  MinI64, MaxI64,
+  MinF64, MaxF64,
+  CountNullsZero // COUNT_NULLS on a NULL-free column = 0
+};
+
+struct AggOut {
+  AggFinal fin;
+  int lane = -1; // first lane of its lane group, relative to the group's lane block
+};
+
+struct LoweredPlan {
+  std::string type_string;            // "Plan<Cols<...>,<pred>,Keys<...>,Aggs<...>,U>"
+  std::vector<uint32_t> slot_fields;  // slot → field id
+  std::vector<int32_t> slot_dtypes;   // slot → llkv_dtype (UTF8 = 1-byte codes)
+  std::vector<int64_t> lit_i;
+  std::vector<double> lit_f;
+  std::vector<uint32_t> key_fields, key_slots, key_strides, key_cards;
+  uint32_t ng = 1;
+  bool grouped = false;
+  int k = 1;      // lanes per group
+  int lanes = 2;  // ng * k + 1
+  int unroll = 2;
+  std::vector<uint8_t> lane_ops; // size lanes
+  std::vector<AggOut> aggs;      // one per requested aggregate
+  uint64_t bytes_per_row = 0;    // algorithmic bytes (value buffers, once)
+  bool always_false = false;     // predicate folded to FALSE on the host
+};
+
+// Lowers a plan.  `grouped` selects the GROUP BY argument semantics (PlanValue
+// interpreter) instead of the computed-projection fast path.  Returns an llkv_status;
+// on failure `err` holds the message.
+int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
+               const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, LoweredPlan *out,
+               std::string *err);
+
+// Typed literal cast used by leaf predicates (shared with the selection path).
+struct NativeLit {
+  bool is_float = false, is_unsigned = false;
+  int64_t i = 0;
+  double f = 0;
+};
+int cast_literal_for_column(const llkv_literal &lit, int32_t dtype, NativeLit *out, std::string *err);
+
+const char *dtype_name(int32_t dtype);
+const char *dtype_tag(int32_t dtype); // "I64", "F64", ...
+uint32_t dtype_width(int32_t dtype);
+
+} // namespace llkv

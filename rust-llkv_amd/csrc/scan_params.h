@@ -1,0 +1,60 @@
+// scan_params.h — plain-old-data shared by host and device code of the fused scan path
+// (kernel arguments, tile descriptors, lane algebra constants).  No device code here.
+#pragma once
+
+#ifndef __HIPCC_RTC__
+#include <stdint.h>
+#else
+// hiprtc has no <stdint.h>; same widths as the host definitions
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned short uint16_t;
+typedef short int16_t;
+typedef unsigned char uint8_t;
+#endif
+
+namespace llkv {
+
+// Lane algebra: every partial state is a vector of independent 64-bit lanes.
+enum LaneOp : int { OP_ADD_F64 = 0, OP_ADD_I64 = 1, OP_MIN_I64 = 2, OP_MAX_I64 = 3, OP_MAX_U64 = 4 };
+
+constexpr int kBlock = 256;
+constexpr int kRowsPerThread = 2;
+constexpr int kStepRows = kBlock * kRowsPerThread; // 512 rows per block step
+constexpr int kMaxCols = 8;
+constexpr int kMaxLits = 12;
+constexpr int kMaxKeys = 4;
+constexpr int kOctants = 8; // canonical partition of the chunk list
+
+struct TileDesc {
+  uint64_t dev_row;     // first row of the tile in the device column image
+  uint64_t logical_row; // row id of that row (dense ids)
+  uint32_t rows;
+  uint32_t octant;
+};
+
+struct ScanParams {
+  const void *col[kMaxCols];
+  const TileDesc *tiles;
+  uint64_t *tile_partials; // [lanes][n_tiles]
+  int64_t lit_i[kMaxLits];
+  double lit_f[kMaxLits];
+  uint32_t key_stride[kMaxKeys];
+  uint32_t n_tiles;
+  uint32_t pad_;
+};
+
+// Arguments of fold_octants_kernel.
+struct FoldParams {
+  const uint64_t *tile_partials; // [lanes][n_tiles]
+  uint64_t *exchange;            // [kOctants][lanes]
+  const uint8_t *lane_ops;       // [lanes]
+  uint32_t octant_tile_begin[kOctants + 1];
+  uint32_t n_tiles;
+  uint32_t lanes;
+  uint32_t owned_mask;
+};
+
+} // namespace llkv

@@ -1,0 +1,289 @@
+"""Harness-side binding of libllkv_hip.so (include/llkv_hip.h) — the same calls a Rust
+``extern "C"`` shim inside llkv-executor would make.
+
+There is deliberately no CPU fallback: if the HIP library is missing or no device can be
+bound, every data-path call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import abi
+from .abi import (AggregateSpec, CPlan, CValue, Expr, Filter, LlkvError, Value)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllkv_hip.so")
+
+_lib = None
+
+
+def lib():
+    """Loads the C-ABI library.  torch (if importable) is imported first so both share one
+    HIP runtime (same SONAME libamdhip64.so.7) and streams / device pointers interoperate."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing — the HIP extension is not built "
+                           "(run __graft_entry__.build()); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.llkv_hip_last_error.restype = C.c_char_p
+    L.llkv_hip_abi_version.restype = C.c_uint32
+    L.llkv_hip_table_total_rows.restype = C.c_uint64
+    L.llkv_hip_table_total_rows.argtypes = [C.c_void_p]
+    L.llkv_hip_table_local_rows.restype = C.c_uint64
+    L.llkv_hip_table_local_rows.argtypes = [C.c_void_p]
+    L.llkv_hip_table_free.argtypes = [C.c_void_p]
+    L.llkv_hip_table_free.restype = None
+    L.llkv_hip_query_free.argtypes = [C.c_void_p]
+    L.llkv_hip_query_free.restype = None
+    L.llkv_hip_query_algorithmic_bytes.restype = C.c_uint64
+    L.llkv_hip_query_algorithmic_bytes.argtypes = [C.c_void_p]
+    L.llkv_hip_query_kernel_signature.restype = C.c_char_p
+    L.llkv_hip_query_kernel_signature.argtypes = [C.c_void_p]
+    for name in ("llkv_hip_query_num_groups", "llkv_hip_query_num_keys", "llkv_hip_query_num_aggregates"):
+        getattr(L, name).restype = C.c_uint32
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.llkv_hip_free.argtypes = [C.c_void_p]
+    L.llkv_hip_free.restype = None
+    L.llkv_plan_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise LlkvError(rc, lib().llkv_hip_last_error().decode(errors="replace"))
+
+
+_bound_device: Optional[int] = None
+
+
+def init(device: int = 0):
+    """llkv_hip_init: bind this process to one GPU (one process per GPU)."""
+    global _bound_device
+    check(lib().llkv_hip_init(C.c_int32(device)))
+    _bound_device = device
+
+
+def device_count() -> int:
+    return int(lib().llkv_hip_device_count())
+
+
+def shutdown():
+    global _bound_device
+    lib().llkv_hip_shutdown()
+    _bound_device = None
+
+
+class HipTable:
+    """HBM image of a table's column chunks (the `Table` the executor scans)."""
+
+    def __init__(self, table_id: int, chunk_rows: Sequence[int], rank: int = 0, world: int = 1):
+        self._h = C.c_void_p()
+        self.chunk_rows = [int(r) for r in chunk_rows]
+        arr = (C.c_uint64 * max(1, len(self.chunk_rows)))(*self.chunk_rows)
+        check(lib().llkv_hip_table_create(C.c_uint16(table_id), arr, C.c_uint32(len(self.chunk_rows)), C.c_uint32(rank),
+                                          C.c_uint32(world), C.byref(self._h)))
+        first, count = C.c_uint32(), C.c_uint32()
+        check(lib().llkv_hip_table_local_chunks(self._h, C.byref(first), C.byref(count)))
+        self.first_chunk, self.n_local_chunks = first.value, count.value
+        self.rank, self.world = rank, world
+        self._keep: list = []
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def total_rows(self) -> int:
+        return int(lib().llkv_hip_table_total_rows(self._h))
+
+    @property
+    def local_rows(self) -> int:
+        return int(lib().llkv_hip_table_local_rows(self._h))
+
+    @property
+    def local_chunk_rows(self) -> List[int]:
+        return self.chunk_rows[self.first_chunk:self.first_chunk + self.n_local_chunks]
+
+    def _split(self, values: np.ndarray) -> List[np.ndarray]:
+        """Splits a contiguous local array into the local chunks (zero-copy views)."""
+        out, off = [], 0
+        for r in self.local_chunk_rows:
+            out.append(values[off:off + r])
+            off += r
+        if off != len(values):
+            raise ValueError(f"column has {len(values)} rows, local chunks hold {off}")
+        return out
+
+    def append_column(self, field_id: int, dtype: int, values: Union[np.ndarray, Sequence[np.ndarray]]):
+        """Stage one fixed-width column (local rows only): pinned host → hipMemcpyAsync → HBM."""
+        chunks = self._split(values) if isinstance(values, np.ndarray) else list(values)
+        want = np.dtype(abi.NUMPY_OF_DTYPE[dtype])
+        chunks = [np.ascontiguousarray(c, dtype=want) for c in chunks]
+        ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
+        check(lib().llkv_hip_table_append_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), ptrs, C.c_uint32(len(chunks))))
+
+    def append_utf8_column(self, field_id: int, strings: Union[np.ndarray, Sequence]):
+        """Stage a Utf8 column.  ``strings`` is either a uint8 array of 1-byte strings (Arrow
+        offsets are then 0..n) or a sequence of Python strings."""
+        chunks_off, chunks_data = [], []
+        if isinstance(strings, np.ndarray) and strings.dtype == np.uint8:
+            for c in self._split(strings):
+                chunks_off.append(np.arange(len(c) + 1, dtype=np.int32))
+                chunks_data.append(np.ascontiguousarray(c))
+        else:
+            off = 0
+            strings = list(strings)
+            for r in self.local_chunk_rows:
+                enc = [s.encode() for s in strings[off:off + r]]
+                off += r
+                lens = np.fromiter((len(e) for e in enc), dtype=np.int64, count=len(enc))
+                offsets = np.zeros(len(enc) + 1, dtype=np.int32)
+                np.cumsum(lens, out=offsets[1:])
+                chunks_off.append(offsets)
+                chunks_data.append(np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy())
+        poff = (C.c_void_p * max(1, len(chunks_off)))(*[c.ctypes.data for c in chunks_off])
+        pdat = (C.c_void_p * max(1, len(chunks_data)))(*[c.ctypes.data for c in chunks_data])
+        check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off))))
+
+    def adopt_device_column(self, field_id: int, dtype: int, device_ptr: int):
+        check(lib().llkv_hip_table_adopt_device_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), C.c_void_p(device_ptr)))
+
+    def close(self):
+        if self._h:
+            lib().llkv_hip_table_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupRow:
+    def __init__(self, keys: List[Value], values: List[Value]):
+        self.keys, self.values = keys, values
+
+    def __repr__(self):
+        return f"GroupRow(keys={[k.value for k in self.keys]}, values={[v.value for v in self.values]})"
+
+
+class PreparedQuery:
+    """A lowered plan bound to a table: launch() enqueues the kernels, finish() returns rows."""
+
+    def __init__(self, table: HipTable, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (),
+                 order_by_keys: bool = False):
+        self._plan = CPlan(predicate, aggs, keys)
+        self._h = C.c_void_p()
+        self.table = table
+        self.n_aggs = len(aggs)
+        p = self._plan
+        if keys:
+            check(lib().llkv_hip_query_prepare_groupby(table.handle, p.filters, p.n_filters, p.ops, p.n_ops, p.keys, p.n_keys,
+                                                       p.aggs, p.n_aggs, C.c_int32(int(order_by_keys)), C.byref(self._h)))
+        else:
+            check(lib().llkv_hip_query_prepare_aggregate(table.handle, p.filters, p.n_filters, p.ops, p.n_ops, p.aggs, p.n_aggs,
+                                                         C.byref(self._h)))
+
+    @property
+    def kernel_signature(self) -> str:
+        return lib().llkv_hip_query_kernel_signature(self._h).decode()
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(lib().llkv_hip_query_algorithmic_bytes(self._h))
+
+    def launch(self, stream: int = 0):
+        check(lib().llkv_hip_query_launch(self._h, C.c_void_p(stream)))
+
+    def exchange_buffer(self):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(lib().llkv_hip_query_exchange_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def finish(self, stream: int = 0) -> List[GroupRow]:
+        check(lib().llkv_hip_query_finish(self._h, C.c_void_p(stream)))
+        return self.rows()
+
+    def rows(self) -> List[GroupRow]:
+        L = lib()
+        out = []
+        ng, nk, na = L.llkv_hip_query_num_groups(self._h), L.llkv_hip_query_num_keys(self._h), L.llkv_hip_query_num_aggregates(self._h)
+        v = CValue()
+        for g in range(ng):
+            keys, vals = [], []
+            for k in range(nk):
+                check(L.llkv_hip_query_group_key(self._h, g, k, C.byref(v)))
+                keys.append(Value.from_c(v))
+            for a in range(na):
+                check(L.llkv_hip_query_value(self._h, g, a, C.byref(v)))
+                vals.append(Value.from_c(v))
+            out.append(GroupRow(keys, vals))
+        return out
+
+    def run(self, stream: int = 0) -> List[GroupRow]:
+        self.launch(stream)
+        return self.finish(stream)
+
+    def set_profiling(self, enabled: bool):
+        check(lib().llkv_hip_query_set_profiling(self._h, C.c_int32(int(enabled))))
+
+    def kernel_time(self):
+        ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
+        check(lib().llkv_hip_query_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(name)))
+        return ms.value, n.value, (name.value or b"").decode()
+
+    def close(self):
+        if self._h:
+            lib().llkv_hip_query_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def aggregate(table: HipTable, predicate, aggs: Sequence[AggregateSpec]) -> List[Value]:
+    """execute_aggregates / compute_aggregate_values (llkv-executor/src/lib.rs:5357,6087)."""
+    q = PreparedQuery(table, predicate, aggs)
+    try:
+        return q.run()[0].values
+    finally:
+        q.close()
+
+
+def groupby(table: HipTable, predicate, keys: Sequence[int], aggs: Sequence[AggregateSpec], order_by_keys: bool = False) -> List[GroupRow]:
+    """execute_group_by_single_table (llkv-executor/src/lib.rs:4405)."""
+    q = PreparedQuery(table, predicate, aggs, keys, order_by_keys)
+    try:
+        return q.run()
+    finally:
+        q.close()
+
+
+def lower_plan(column_descs, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (), grouped: bool = False,
+               plan_lib=None):
+    """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError."""
+    L = plan_lib or lib()
+    L.llkv_plan_last_error.restype = C.c_char_p
+    p = CPlan(predicate, aggs, keys)
+    buf = C.create_string_buffer(16384)
+    lanes, bpr = C.c_uint32(), C.c_uint64()
+    rc = L.llkv_plan_lower(column_descs, C.c_uint32(len(column_descs)), p.filters, p.n_filters, p.ops, p.n_ops, p.keys, p.n_keys,
+                           p.aggs, p.n_aggs, C.c_int32(int(grouped)), buf, C.c_uint64(len(buf)), C.byref(lanes), C.byref(bpr))
+    if rc != 0:
+        raise LlkvError(rc, L.llkv_plan_last_error().decode(errors="replace"))
+    return buf.value.decode(), lanes.value, bpr.value
