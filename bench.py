@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — rows/sec + achieved HBM GB/s of the MI355X hot path on TPC-H Q1/Q6.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one execution of the query over the HBM-resident lineitem columns of this rank's
+shard: fused scan kernel → octant fold → (N>1: one RCCL all-reduce of the partial aggregate
+state) → host finalize.  Default workload: TPC-H Q1 at SF10 (BASELINE.json configs[2]); every
+rank holds an SF10 shard (weak scaling: the table is SF(10·N), chunk-sharded), --scaling strong
+shards one SF10 table across the ranks instead (configs[3]).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="q1_sf10", help="q1_sf10 | q6_sf10 | q6_sf1 | q1_sf1 | c1_sf0.01 ...")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the workload timed on the CPU oracle (0 = auto)")
+    ap.add_argument("--also", default="q6_sf10,q6_sf1", help="extra workloads measured (N=1 only) and reported under 'also'")
+    return ap.parse_args()
+
+
+def stage(rt, tpch, abi, query, total_rows, scale, rank, world, row_begin_global=0):
+    """Generate this rank's shard on the host and stage the needed columns into HBM."""
+    chunks = tpch.chunk_rows(total_rows)
+    table = rt.HipTable(1, chunks, rank, world)
+    first_row = sum(chunks[:table.first_chunk])
+    data = tpch.gen_lineitem(table.local_rows, scale, query.columns, row_begin=row_begin_global + first_row)
+    for name in query.columns:
+        fid, dt = tpch.LINEITEM_SCHEMA[name]
+        if dt == abi.DT_UTF8:
+            table.append_utf8_column(fid, data[name])
+        else:
+            table.append_column(fid, dt, data[name])
+    return table, data
+
+
+def run_steps(q, steps, dist, stream_ptr, ex_tensor):
+    for _ in range(steps):
+        q.launch(stream_ptr)
+        if ex_tensor is not None:
+            dist.all_reduce(ex_tensor)  # ncclSum over int64 lanes: exact concatenation of shard states
+        rows = q.finish(stream_ptr)
+    return rows
+
+
+def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmup):
+    qname, sf = name.split("_")
+    query = tpch.QUERIES[qname]()
+    rows_sf = tpch.LINEITEM_ROWS[sf]
+    scale = tpch.SCALE[sf]
+    if scaling == "weak":
+        total_rows, gen_scale = rows_sf * world, scale * world
+    else:
+        total_rows, gen_scale = rows_sf, scale
+    if scaling == "weak" and world > 1:
+        # every rank holds one SF-sized shard of a (SF·world) table: ragged chunk list, shard r = block r
+        chunks = []
+        for _ in range(world):
+            chunks += tpch.chunk_rows(rows_sf)
+        table = rt.HipTable(1, chunks, rank, world)
+        first_row = sum(chunks[:table.first_chunk])
+        data = tpch.gen_lineitem(table.local_rows, gen_scale, query.columns, row_begin=first_row)
+        for cname in query.columns:
+            fid, dt = tpch.LINEITEM_SCHEMA[cname]
+            (table.append_utf8_column(fid, data[cname]) if dt == abi.DT_UTF8 else table.append_column(fid, dt, data[cname]))
+    else:
+        table, data = stage(rt, tpch, abi, query, total_rows, gen_scale, rank, world)
+    del data
+
+    q = rt.PreparedQuery(table, query.predicate, query.aggs, query.keys, query.order_by_keys)
+    # a dedicated non-default stream shared by the library's kernels and torch's collective,
+    # so launch → all-reduce → copy-out are ordered without host synchronisation
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    stream_ptr = stream.cuda_stream
+    ex_tensor = None
+    if world > 1:
+        # zero-copy int64 view of the library's exchange buffer for torch.distributed (RCCL)
+        ptr, n = q.exchange_buffer()
+        ex_tensor = _tensor_from_ptr(torch, ptr, n)
+
+    run_steps(q, warmup, dist, stream_ptr, ex_tensor)
+    q.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows = run_steps(q, steps, dist, stream_ptr, ex_tensor)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms, launches, kname = q.kernel_time()
+    q.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {
+        "name": name, "query": query, "table": table, "prepared": q, "rows_result": rows,
+        "seconds": dt, "total_rows": total_rows, "local_rows": table.local_rows,
+        "kernel_ms_avg": kern_ms / max(1, launches), "kernel_launches": launches, "kernel_name": kname,
+        "alg_bytes_local": q.algorithmic_bytes, "signature": q.kernel_signature,
+    }
+    return res
+
+
+def _tensor_from_ptr(torch, ptr, n_i64):
+    """int64 CUDA tensor aliasing a raw device pointer (exchange buffer), via __cuda_array_interface__."""
+
+    class _Raw:
+        pass
+
+    raw = _Raw()
+    raw.__cuda_array_interface__ = {"shape": (int(n_i64),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(raw, device="cuda")
+
+
+def cpu_baseline(tpch, abi, query, sf, sample_rows):
+    """The oracle ("port") timed on this box's host cores on a bounded sample of the workload."""
+    from oracle import oracle as orc
+
+    rows = min(sample_rows, tpch.LINEITEM_ROWS[sf])
+    data = tpch.gen_lineitem(rows, tpch.SCALE[sf], query.columns)
+    t = orc.OracleTable(rows)
+    for name in query.columns:
+        fid, dt = tpch.LINEITEM_SCHEMA[name]
+        t.add(fid, dt, data[name])
+    t0 = time.perf_counter()
+    if query.grouped:
+        orc.groupby(t, query.predicate, query.keys, query.aggs, query.order_by_keys)
+    else:
+        orc.aggregate(t, query.predicate, query.aggs)
+    dt = time.perf_counter() - t0
+    out = {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"first {rows} lineitem rows of {query.name}_{sf}, reference-faithful sequential oracle, {dt:.2f} s"}
+    if not query.grouped:
+        threads = os.cpu_count() or 1
+        prows = min(tpch.LINEITEM_ROWS[sf], max(rows, 20_000_000))
+        if prows != rows:
+            data = tpch.gen_lineitem(prows, tpch.SCALE[sf], query.columns)
+            t = orc.OracleTable(prows)
+            for name in query.columns:
+                fid, dtp = tpch.LINEITEM_SCHEMA[name]
+                t.add(fid, dtp, data[name])
+        t0 = time.perf_counter()
+        orc.aggregate_parallel(t, query.predicate, query.aggs, threads)
+        pdt = time.perf_counter() - t0
+        out["parallel"] = {"value": prows / pdt, "unit": "rows/s", "cores": threads,
+                           "sample": f"{prows} rows, chunk-parallel fused oracle, {pdt:.3f} s"}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    import torch.distributed as dist
+
+    abi = importlib.import_module("rust-llkv_amd.abi")
+    rt = importlib.import_module("rust-llkv_amd.runtime")
+    tpch = importlib.import_module("rust-llkv_amd.tpch")
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    rt.init(local_rank)
+
+    main_res = measure(rt, tpch, abi, torch, dist, args.workload, rank, world, args.scaling, args.steps, args.warmup)
+    rows_total = main_res["total_rows"]
+    value = rows_total * args.steps / main_res["seconds"]
+    kern_s = main_res["kernel_ms_avg"] / 1e3
+    achieved = main_res["alg_bytes_local"] / kern_s / 1e9 if kern_s > 0 else 0.0
+    qname, sf = args.workload.split("_")
+    out = {
+        "metric": "rows/sec + HBM GB/s, TPC-H Q1/Q6 SF10 at 1/2/4/8 MI355X",
+        "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main_res["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"TPC-H {qname.upper()} {sf.upper()} lineitem per GPU ({main_res['local_rows']} rows/GPU, "
+                        f"{rows_total} rows total), columns resident in HBM, {main_res['query'].bytes_per_row} B/row algorithmic",
+            "sharding": "by chunk (131072 rows) into 8 canonical octants; RCCL all-reduce of partial aggregate state" if world > 1 else "single GPU",
+            "kernel": main_res["signature"],
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": main_res["kernel_name"], "kernel_ms": main_res["kernel_ms_avg"],
+            "algorithmic_bytes_per_launch": main_res["alg_bytes_local"],
+        },
+        "hbm_gbs_end_to_end": main_res["query"].bytes_per_row * value / 1e9,
+    }
+
+    if rank == 0 and world == 1:
+        also = {}
+        # free the main workload's HBM image before staging the next one
+        main_q = main_res.pop("prepared"); main_q.close()
+        main_res.pop("table").close()
+        for name in [w for w in args.also.split(",") if w and w != args.workload]:
+            r = measure(rt, tpch, abi, torch, dist, name, 0, 1, "weak", args.steps, args.warmup)
+            ks = r["kernel_ms_avg"] / 1e3
+            also[name] = {"rows_per_s": r["total_rows"] * args.steps / r["seconds"], "ms_per_step": r["seconds"] / args.steps * 1e3,
+                          "kernel_ms": r["kernel_ms_avg"], "achieved_gbs": r["alg_bytes_local"] / ks / 1e9 if ks else 0.0,
+                          "frac": (r["alg_bytes_local"] / ks / 1e9 / HBM_PEAK_GBS) if ks else 0.0}
+            r["prepared"].close(); r["table"].close()
+        out["also"] = also
+        if not args.no_cpu_baseline:
+            sample = args.cpu_sample_rows or (3_000_000 if main_res["query"].grouped else 6_000_000)
+            out["cpu_baseline"] = cpu_baseline(tpch, abi, main_res["query"], sf, sample)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
