@@ -274,6 +274,11 @@ llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_
  * finalize.  Blocks until done.                                              */
 llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream);
 
+/* Same, from an exchange image the caller already holds on the host (for hosts
+ * that run the collective themselves; `len_i64` must match exchange_buffer). */
+llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_t *exchange,
+                                            uint64_t len_i64);
+
 /* Results of the last finish(). Aggregate queries have exactly one group.    */
 uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query);
 uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query);
@@ -384,6 +389,24 @@ llkv_status llkv_hip_join_stream(const llkv_hip_table *left, const llkv_hip_tabl
                                  const llkv_join_key *keys, uint32_t n_keys,
                                  const llkv_join_options *options, llkv_on_join_batch on_batch,
                                  void *user);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU combine, host pieces (no device needed).  The chunk list is cut    */
+/* into 8 canonical octants (boundaries floor(j·C/8)); rank r of `world` owns   */
+/* octants [r·8/world, (r+1)·8/world).  Partial aggregate state is exchanged    */
+/* per octant and folded in octant order, so 1/2/4/8-GPU runs agree bit for bit.*/
+/* ------------------------------------------------------------------------- */
+#define LLKV_HIP_OCTANTS 8
+llkv_status llkv_hip_shard_layout(uint32_t n_chunks, uint32_t world,
+                                  uint32_t *octant_chunk_begin /* [9] */,
+                                  uint32_t *octant_owner /* [8] */);
+/* Lane combine ops of a prepared query (one byte per lane: 0 add f64, 1 add i64,
+ * 2 min i64, 3 max i64, 4 max u64). `ops_out` may be NULL to query the count.  */
+llkv_status llkv_hip_query_lane_ops(const llkv_hip_query *query, uint8_t *ops_out, uint32_t *lanes);
+/* Canonical fold of an exchange buffer [8][lanes] → state[lanes] (what finish()
+ * does after the copy-out).                                                    */
+llkv_status llkv_hip_fold_exchange(const uint64_t *exchange, const uint8_t *lane_ops,
+                                   uint32_t lanes, uint64_t *state_out);
 
 /* ------------------------------------------------------------------------- */
 /* Plan inspection (host only, no device needed): lowers a plan exactly as the */

@@ -666,6 +666,13 @@ llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream) {
   return (llkv_status) reinterpret_cast<Query *>(query)->finish((hipStream_t)hip_stream);
 }
 
+llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_t *exchange, uint64_t len_i64) {
+  if (!query || !exchange) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  Query *q = reinterpret_cast<Query *>(query);
+  if (len_i64 != (uint64_t)kOctantsHost * (uint64_t)q->plan.lanes) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "exchange length mismatch");
+  return (llkv_status)q->finish_from_exchange(exchange);
+}
+
 uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->groups.size() : 0; }
 uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->plan.key_fields.size() : 0; }
 uint32_t llkv_hip_query_num_aggregates(const llkv_hip_query *query) { return query ? reinterpret_cast<const Query *>(query)->n_user_aggs : 0; }
@@ -721,6 +728,27 @@ uint64_t llkv_hip_query_algorithmic_bytes(const llkv_hip_query *query) {
 const char *llkv_hip_query_kernel_signature(const llkv_hip_query *query) {
   const Query *q = reinterpret_cast<const Query *>(query);
   return q ? q->plan.type_string.c_str() : "";
+}
+
+llkv_status llkv_hip_shard_layout(uint32_t n_chunks, uint32_t world, uint32_t *octant_chunk_begin, uint32_t *octant_owner) {
+  if (world == 0 || world > (uint32_t)kOctantsHost) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "world must be 1..8");
+  for (int j = 0; j <= kOctantsHost; ++j) if (octant_chunk_begin) octant_chunk_begin[j] = (uint32_t)((uint64_t)j * n_chunks / kOctantsHost);
+  for (int o = 0; o < kOctantsHost; ++o) if (octant_owner) octant_owner[o] = (uint32_t)((uint64_t)o * world / kOctantsHost);
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_lane_ops(const llkv_hip_query *query, uint8_t *ops_out, uint32_t *lanes) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  if (!q) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  if (lanes) *lanes = (uint32_t)q->plan.lanes;
+  if (ops_out) std::memcpy(ops_out, q->plan.lane_ops.data(), q->plan.lane_ops.size());
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_fold_exchange(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state_out) {
+  if (!exchange || !lane_ops || !state_out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  fold_exchange_host(exchange, lane_ops, lanes, state_out);
+  return LLKV_OK;
 }
 
 llkv_status llkv_hip_aggregate(const llkv_hip_table *table, const llkv_filter *filters, uint32_t n_filters,

@@ -216,6 +216,31 @@ class PreparedQuery:
         check(lib().llkv_hip_query_finish(self._h, C.c_void_p(stream)))
         return self.rows()
 
+    def read_exchange(self, stream: int = 0) -> np.ndarray:
+        """Copy of this rank's exchange image [8][lanes] (uint64 lanes) — test / host-collective helper."""
+        import torch
+        ptr, n = self.exchange_buffer()
+        torch.cuda.synchronize()
+
+        class _Raw:
+            pass
+
+        raw = _Raw()
+        raw.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(raw, device="cuda").cpu().numpy().view(np.uint64).reshape(8, -1).copy()
+
+    def finish_from_host(self, exchange: np.ndarray) -> List[GroupRow]:
+        ex = np.ascontiguousarray(exchange, dtype=np.uint64).reshape(-1)
+        check(lib().llkv_hip_query_finish_from_host(self._h, ex.ctypes.data_as(C.c_void_p), C.c_uint64(ex.size)))
+        return self.rows()
+
+    def lane_ops(self) -> List[int]:
+        n = C.c_uint32()
+        check(lib().llkv_hip_query_lane_ops(self._h, None, C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        check(lib().llkv_hip_query_lane_ops(self._h, buf, C.byref(n)))
+        return list(buf)
+
     def rows(self) -> List[GroupRow]:
         L = lib()
         out = []

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 (gloo): the multi-GPU combine — shard ownership, the integer-SUM all-reduce of the
+zero-padded exchange buffer, the canonical host fold — gives bit-identical results to a single rank.
+The per-octant partial states are produced by the same numpy routine on every rank (on GPUs they come
+from the fused kernel + octant fold; the exchange + fold code under test is the product's)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, mod
+
+LANE_OPS = [1, 0, 0, 2, 3, 4]  # rows (add i64), two f64 sums, min i64, max i64, error flag (max u64)
+
+
+def octant_partials(lo, hi, x, y):
+    """Emulated per-octant state over rows [lo, hi): what K_main + K_fold leave in one exchange row."""
+    out = np.zeros(len(LANE_OPS), dtype=np.uint64)
+    xs, ys = x[lo:hi], y[lo:hi]
+    out[0] = np.uint64(hi - lo)
+    out[1] = np.float64(xs.sum()).view(np.uint64)
+    out[2] = np.float64((xs * ys).sum()).view(np.uint64)  # negative sums: bit patterns with the top bit set
+    out[3] = np.int64(ys.min() if hi > lo else np.iinfo(np.int64).max).view(np.uint64)
+    out[4] = np.int64(ys.max() if hi > lo else np.iinfo(np.int64).min).view(np.uint64)
+    out[5] = 0
+    return out
+
+
+def make_data(n):
+    rng = np.random.default_rng(7)
+    return rng.normal(size=n) * 1e6 - 3e5, rng.integers(-10**12, 10**12, size=n)
+
+
+def exchange_for_rank(dist_mod, lib, rank, world, chunk_rows, x, y):
+    begin, owner = dist_mod.shard_layout(lib, len(chunk_rows), world)
+    row_of_chunk = np.concatenate([[0], np.cumsum(chunk_rows)])
+    ex = np.zeros((8, len(LANE_OPS)), dtype=np.uint64)
+    for o in range(8):
+        if owner[o] == rank:
+            ex[o] = octant_partials(int(row_of_chunk[begin[o]]), int(row_of_chunk[begin[o + 1]]), x, y)
+    return ex
+
+
+def _worker(rank, world, port, chunk_rows, n, out_path):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = mod("runtime").lib()
+    dmod = mod("dist")
+    x, y = make_data(n)
+    ex = exchange_for_rank(dmod, lib, rank, world, chunk_rows, x, y)
+    t = torch.from_numpy(ex.view(np.int64).reshape(-1).copy())
+    dmod.all_reduce_exchange(dist, t)  # the query's single collective
+    state = dmod.fold_exchange(lib, t.numpy().view(np.uint64).reshape(8, -1), LANE_OPS)
+    if rank == 0:
+        np.save(out_path, state)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_rank_combine_is_bit_identical_to_one_rank(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    chunk_rows = [1000] * 37 + [123]  # ragged last chunk, octants of unequal size
+    n = sum(chunk_rows)
+    out = str(tmp_path / "state.npy")
+    mp.spawn(_worker, args=(world, _free_port(), chunk_rows, n, out), nprocs=world, join=True)
+    got = np.load(out)
+
+    lib = mod("runtime").lib()
+    dmod = mod("dist")
+    x, y = make_data(n)
+    want = dmod.fold_exchange(lib, exchange_for_rank(dmod, lib, 0, 1, chunk_rows, x, y), LANE_OPS)
+    assert got.tobytes() == want.tobytes()  # bit-exact, f64 lanes included
+    assert int(want[0]) == n
+    assert want[3].view(np.int64) == y.min() and want[4].view(np.int64) == y.max()
+    # and the fold really is "octants in order": a plain left-to-right sum of the 8 octant sums
+    ex = exchange_for_rank(dmod, lib, 0, 1, chunk_rows, x, y)
+    acc = 0.0
+    for o in range(8):
+        acc += float(ex[o, 1:2].view(np.float64)[0])
+    assert np.float64(acc).view(np.uint64) == want[1]

@@ -1,0 +1,252 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, with the CPU oracle.
+Bit-exact for counts / integer sums / min / max / group keys; f64 sums and averages within 1e-9 relative
+(the reference sums strictly left to right, llkv-aggregate/src/lib.rs:881-887; its own TPC-H tolerance is
+1e-9, llkv-tpch/src/qualification.rs:39)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import DTYPES, build_aggs, build_filter, fval, golden, oracle_table, same_value
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+AGGS = golden("aggregates.json")
+
+
+def stage_both(rt, orc, abi, columns, chunk_rows):
+    """columns: [(field_id, dtype, numpy array | list[str])] → (HipTable, OracleTable)."""
+    n = sum(chunk_rows)
+    ht = rt.HipTable(1, chunk_rows)
+    ot = orc.OracleTable(n)
+    for fid, dt, vals in columns:
+        ot.add(fid, dt, vals)
+        if dt == abi.DT_UTF8:
+            ht.append_utf8_column(fid, vals)
+        else:
+            ht.append_column(fid, dt, vals)
+    return ht, ot
+
+
+def assert_values(got, want, ctx=""):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype, (ctx, g, w)
+        if w.value is None or isinstance(w.value, int):
+            assert g.value == w.value, (ctx, g, w)
+        else:
+            assert same_value(g.value, w.value, REL), (ctx, g, w)
+
+
+def lineitem(tpch, abi, rows, scale, cols=None):
+    d = tpch.gen_lineitem(rows, scale, cols)
+    return d, [(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], d[c]) for c in d]
+
+
+@pytest.mark.parametrize("sf,chunk", [("sf0.01", 8192), ("sf0.01", 131072), ("sf1", 131072)])
+def test_tpch_queries_match_oracle(rt, orc, abi, tpch, sf, chunk):
+    """configs[0..2] shapes: C1, Q6, Q1 on synthetic lineitem, ragged last chunk."""
+    n = tpch.LINEITEM_ROWS[sf]
+    d, cols = lineitem(tpch, abi, n, tpch.SCALE[sf])
+    ht, ot = stage_both(rt, orc, abi, cols, tpch.chunk_rows(n, chunk))
+    for name in ("c1", "q6"):
+        q = tpch.QUERIES[name]()
+        assert_values(rt.aggregate(ht, q.predicate, q.aggs), orc.aggregate(ot, q.predicate, q.aggs), name)
+    q = tpch.q1()
+    got = rt.groupby(ht, q.predicate, q.keys, q.aggs, True)
+    want = orc.groupby(ot, q.predicate, q.keys, q.aggs, True)
+    assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want]
+    for g, w in zip(got, want):
+        assert_values(g.values, w.values, "q1")
+    # without ORDER BY: first-appearance order (llkv-executor/src/lib.rs:5065-5089)
+    got = rt.groupby(ht, q.predicate, q.keys, q.aggs, False)
+    want = orc.groupby(ot, q.predicate, q.keys, q.aggs, False)
+    assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want]
+
+
+@pytest.mark.parametrize("case", [c for c in AGGS["cases"]], ids=lambda c: c["name"])
+def test_reference_aggregate_known_answers(rt, abi, case):
+    """The reference's own known answers (tests/golden/aggregates.json) through the GPU path (run-time
+    specialised kernels)."""
+    n = len(case["columns"][0]["values"])
+    ht = rt.HipTable(1, [n])
+    for c in case["columns"]:
+        dt = DTYPES[c["dtype"]]
+        ht.append_column(c["field_id"], dt, np.array([fval(v) for v in c["values"]], dtype=abi.NUMPY_OF_DTYPE[dt]))
+    pred = [build_filter(abi, case["filter"])] if "filter" in case else None
+    aggs = build_aggs(abi, case["aggs"])
+    if "expect_error" in case:
+        with pytest.raises(abi.LlkvError) as e:
+            rt.aggregate(ht, pred, aggs)
+        assert e.value.kind == case["expect_error"], e.value
+        return
+    got = rt.aggregate(ht, pred, aggs)
+    for g, w in zip(got, case["expect"]):
+        assert same_value(g.value, w), (g, w)
+
+
+def random_columns(rng, n):
+    i64 = rng.integers(-10**9, 10**9, size=n).astype(np.int64)
+    f64 = rng.normal(size=n) * 1e3
+    f64[rng.random(n) < 0.01] = np.nan
+    f64[rng.random(n) < 0.01] = -0.0
+    i32 = rng.integers(-1000, 1000, size=n).astype(np.int32)
+    big = rng.integers(-2**62, 2**62, size=n).astype(np.int64)
+    flags = rng.integers(0, 3, size=n)
+    s = np.array([ord("x"), ord("y"), ord("z")], dtype=np.uint8)[flags]
+    return i64, f64, i32, big, s
+
+
+@pytest.mark.parametrize("chunks", [[1], [15, 16, 17], [512, 513, 1], [8192, 100, 8192, 7], [1000] * 37 + [123]])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_plans_match_oracle(rt, orc, abi, chunks, seed):
+    """Ragged chunk lists (tile tails, 16-row alignment padding), general predicate programs (And/Or/Not),
+    every aggregate kind, NaN / -0.0 / large integers."""
+    rng = np.random.default_rng(seed * 1000 + len(chunks))
+    n = sum(chunks)
+    i64, f64, i32, big, s = random_columns(rng, n)
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64), (2, abi.DT_FLOAT64, f64), (3, abi.DT_INT32, i32), (4, abi.DT_INT64, big),
+                                       (5, abi.DT_UTF8, s)], chunks)
+    F, O, B, E, A, col = abi.Filter, abi.Operator, abi.Bound, abi.Expr, abi.AggregateSpec, abi.col
+    preds = [
+        None,
+        [F(1, O.LessThan(0))],
+        [F(3, O.Range(B.Included(-500), B.Excluded(250))), F(2, O.GreaterThan(-100.5))],
+        E.any_of([F(1, O.GreaterThanOrEquals(5 * 10**8)), E.all_of([F(3, O.In([1, 2, 3, 5, 8])), F(2, O.LessThanOrEquals(0))])]),
+        E.not_(E.all_of([F(2, O.GreaterThan(0.0)), F(1, O.LessThan(10**8))])),  # NaN rows: NOT(x > 0) is true
+        [F(1, O.Equals(123456789012))],  # matches nothing
+        [F(5, O.Equals("y"))],
+    ]
+    aggs = [A.count_star(), A.sum(1), A.sum(2), A.avg(1), A.avg(2), A.min(1), A.max(1), A.min(2), A.max(2), A.total(1), A.total(2),
+            A.count(2), A.sum(col(2) * (1 - col(2))), A.sum(col(1) + col(3)), A.sum(col(1) * 3 - 7), A.min(col(2) * 2.0), A.sum(4)]
+    for p in preds:
+        try:
+            want = orc.aggregate(ot, p, aggs)
+        except abi.LlkvError as e:
+            with pytest.raises(abi.LlkvError) as g:
+                rt.aggregate(ht, p, aggs)
+            assert g.value.kind in (e.kind, "Unsupported"), (g.value, e)
+            continue
+        assert_values(rt.aggregate(ht, p, aggs), want, str(p))
+    # grouped: dictionary key, PlanValue argument semantics (Int∘Int through f64)
+    gaggs = [A.count_star(), A.sum(1), A.sum(col(1) * col(3)), A.avg(2), A.sum(col(2) * (1 - col(3))), A.max(1)]
+    for p in (None, [F(3, O.GreaterThan(0))]):
+        got, want = rt.groupby(ht, p, [5], gaggs, True), orc.groupby(ot, p, [5], gaggs, True)
+        assert [r.keys[0].value for r in got] == [r.keys[0].value for r in want]
+        for g, w in zip(got, want):
+            assert_values(g.values, w.values, "grouped")
+
+
+def test_empty_table_and_no_matches(rt, abi):
+    A = abi.AggregateSpec
+    ht = rt.HipTable(1, [])
+    ht.append_column(1, abi.DT_INT64, [])
+    ht.append_column(2, abi.DT_FLOAT64, [])
+    got = rt.aggregate(ht, None, [A.count_star(), A.sum(1), A.sum(2), A.total(2), A.avg(1), A.min(2)])
+    assert [g.value for g in got] == [0, None, None, 0.0, None, None]
+    ht = rt.HipTable(1, [5])
+    ht.append_column(1, abi.DT_INT64, np.arange(5, dtype=np.int64))
+    ht.append_utf8_column(2, ["a", "b", "a", "c", "b"])
+    assert rt.groupby(ht, [abi.Filter(1, abi.Operator.GreaterThan(100))], [2], [A.count_star()]) == []
+    rows = rt.groupby(ht, None, [2], [A.count_star(), A.sum(1)])
+    assert [(r.keys[0].value, r.values[0].value, r.values[1].value) for r in rows] == [("a", 2, 2), ("b", 2, 5), ("c", 1, 3)]
+
+
+def test_integer_overflow_semantics(rt, abi):
+    """SUM(Int64) overflow is an error like the reference's checked_add (llkv-aggregate/src/lib.rs:816-829);
+    a total that fits but whose prefixes may not is handed back (UNSUPPORTED) instead of guessed."""
+    A = abi.AggregateSpec
+    big = 2**62
+    ht = rt.HipTable(1, [4])
+    ht.append_column(1, abi.DT_INT64, np.array([big, big, big, big], dtype=np.int64))
+    with pytest.raises(abi.LlkvError) as e:
+        rt.aggregate(ht, None, [A.sum(1)])
+    assert e.value.kind == "InvalidArgumentError" and "integer overflow" in e.value.message
+    ht = rt.HipTable(1, [4])
+    ht.append_column(1, abi.DT_INT64, np.array([big, big, -big, -big], dtype=np.int64))
+    with pytest.raises(abi.LlkvError) as e:
+        rt.aggregate(ht, None, [A.sum(1)])
+    assert e.value.kind == "Unsupported"
+    # checked multiply in a computed projection (arrow numeric::mul, fast_numeric.rs:328-334)
+    ht2 = rt.HipTable(1, [1])
+    ht2.append_column(1, abi.DT_INT64, np.array([2**40], dtype=np.int64))
+    with pytest.raises(abi.LlkvError) as e:
+        rt.aggregate(ht2, None, [A.sum(abi.col(1) * 2**30)])
+    assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+
+
+def test_results_are_bit_reproducible_and_gpu_count_invariant(rt, abi, tpch):
+    """Same bits run to run, and the same bits whether the table is one shard or two shards whose exchange
+    images are summed as integers (what the RCCL all-reduce does) — on ONE device."""
+    n = 1_000_003
+    chunks = tpch.chunk_rows(n, 32768)
+    d = tpch.gen_lineitem(n, 1.0)
+    q = tpch.q1()
+
+    def stage(rank, world):
+        ht = rt.HipTable(1, chunks, rank, world)
+        lo = sum(chunks[:ht.first_chunk])
+        for c in q.columns:
+            fid, dt = tpch.LINEITEM_SCHEMA[c]
+            part = d[c][lo:lo + ht.local_rows]
+            ht.append_utf8_column(fid, part) if dt == abi.DT_UTF8 else ht.append_column(fid, dt, part)
+        return ht
+
+    one = stage(0, 1)
+    pq = rt.PreparedQuery(one, q.predicate, q.aggs, q.keys, True)
+    r1 = pq.run()
+    ex1 = pq.read_exchange()
+    r1b = pq.run()
+    assert np.array_equal(ex1, pq.read_exchange())
+    flat = lambda rows: [(tuple(k.value for k in r.keys), tuple(np.float64(v.value).tobytes() if isinstance(v.value, float) else v.value for v in r.values)) for r in rows]
+    assert flat(r1) == flat(r1b)
+    for world in (2, 4, 8):
+        total = np.zeros_like(ex1).view(np.int64)
+        last = None
+        for rank in range(world):
+            pr = rt.PreparedQuery(stage(rank, world), q.predicate, q.aggs, q.keys, True)
+            pr.launch()
+            ex = pr.read_exchange()
+            owned = [o for o in range(8) if o * world // 8 == rank]
+            assert not ex[[o for o in range(8) if o not in owned]].any(), "non-owned octants must be zero"
+            total += ex.view(np.int64)
+            last = pr
+        assert np.array_equal(total.view(np.uint64), ex1), f"world={world}"
+        assert flat(last.finish_from_host(total.view(np.uint64))) == flat(r1)
+
+
+@pytest.mark.parametrize("name", ["q6", "q1"])
+def test_full_size_properties_sf10(rt, abi, tpch, name):
+    """BASELINE.json sizes (SF10, 59 986 052 rows): size-independent checks — integer lanes exact against
+    numpy, f64 sums within 1e-9 of a pairwise numpy sum, keys sorted, idempotent."""
+    n = tpch.LINEITEM_ROWS["sf10"]
+    q = tpch.QUERIES[name]()
+    d = tpch.gen_lineitem(n, 10.0, q.columns)
+    ht = rt.HipTable(1, tpch.chunk_rows(n))
+    for c in q.columns:
+        fid, dt = tpch.LINEITEM_SCHEMA[c]
+        ht.append_utf8_column(fid, d[c]) if dt == abi.DT_UTF8 else ht.append_column(fid, dt, d[c])
+    pq = rt.PreparedQuery(ht, q.predicate, q.aggs, q.keys, q.order_by_keys)
+    rows = pq.run()
+    again = pq.run()
+    assert [[v.value for v in r.values] for r in rows] == [[v.value for v in r.values] for r in again]
+    if name == "q6":
+        m = (d["l_shipdate"] >= 8766) & (d["l_shipdate"] < 9131) & (d["l_discount"] >= 0.05) & (d["l_discount"] <= 0.07) & (d["l_quantity"] < 24)
+        want = float((d["l_extendedprice"][m] * d["l_discount"][m]).sum())
+        assert abs(rows[0].values[0].value - want) <= REL * want
+    else:
+        keys = [tuple(k.value for k in r.keys) for r in rows]
+        assert keys == sorted(keys) and len(keys) == 4
+        sel = d["l_shipdate"] <= 10471
+        assert sum(r.values[7].value for r in rows) == int(sel.sum())
+        for r in rows:
+            g = sel & (d["l_returnflag"] == ord(r.keys[0].value)) & (d["l_linestatus"] == ord(r.keys[1].value))
+            assert r.values[0].value == int(d["l_quantity"][g].sum())  # exact
+            assert r.values[7].value == int(g.sum())
+            p, disc, tax = d["l_extendedprice"][g], d["l_discount"][g], d["l_tax"][g]
+            assert abs(r.values[1].value - p.sum()) <= REL * p.sum()
+            assert abs(r.values[2].value - (p * (1 - disc)).sum()) <= REL * p.sum()
+            assert abs(r.values[3].value - (p * (1 - disc) * (1 + tax)).sum()) <= REL * p.sum()
+            assert abs(r.values[4].value - d["l_quantity"][g].sum() / g.sum()) <= 1e-12 * 50
+            assert abs(r.values[6].value - disc.sum() / g.sum()) <= REL

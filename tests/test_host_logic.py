@@ -1,0 +1,160 @@
+"""CPU: host logic of the product — C-ABI surface, plan lowering (typing rules of the reference),
+shard layout.  No compute calls: there is no GPU here and no CPU fallback in the product."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, mod
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return mod("runtime").lib()
+
+
+def declared_functions(header):
+    with open(os.path.join(ROOT, "include", header)) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(llkv_(?:hip|plan|tpch)_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_functions("llkv_hip.h")
+    assert len(names) > 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"libllkv_hip.so does not export: {missing}"
+    assert lib.llkv_hip_abi_version() == 1
+
+
+def test_generator_library_exports_every_declared_symbol(tpch):
+    g = tpch.gen_lib()
+    missing = [n for n in declared_functions("llkv_tpch_gen.h") if not hasattr(g, n)]
+    assert not missing
+
+
+def test_data_path_fails_loudly_without_a_device(lib, abi):
+    """No silent CPU path: without a bound device prepare/launch return NO_DEVICE."""
+    rt = mod("runtime")
+    if rt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(abi.LlkvError) as e:
+        rt.init(0)
+    assert e.value.kind == "NoDevice"
+    t = rt.HipTable(1, [4])
+    with pytest.raises(abi.LlkvError) as e:
+        t.append_column(1, abi.DT_INT64, np.arange(4, dtype=np.int64))
+    assert e.value.kind == "NoDevice"
+
+
+def test_generator_is_row_addressable(tpch):
+    """Any shard can be generated independently: rows [a,b) equal the slice of rows [0,b)."""
+    full = tpch.gen_lineitem(5000, 0.01)
+    part = tpch.gen_lineitem(1234, 0.01, row_begin=3000)
+    for k in full:
+        assert np.array_equal(full[k][3000:4234], part[k]), k
+    assert set(np.unique(full["l_returnflag"])) <= {ord("A"), ord("N"), ord("R")}
+    assert full["l_quantity"].min() >= 1 and full["l_quantity"].max() <= 50
+    assert np.all(np.diff(full["l_orderkey"]) >= 0)
+    # discount / tax equal their literal casts (k / 100.0)
+    assert set(np.unique(full["l_discount"])) <= {k / 100.0 for k in range(11)}
+
+
+def test_lowering_of_benchmark_plans_hits_the_aot_catalog(lib, abi, tpch):
+    rt = mod("runtime")
+    keep = []
+    descs = tpch.lineitem_column_descs(tpch.LINEITEM_ROWS["sf10"], keep)
+    inc = open(os.path.join(ROOT, "rust-llkv_amd", "csrc", "catalog_entries.inc")).read()
+    for name, mk in tpch.QUERIES.items():
+        q = mk()
+        ts, lanes, bpr = rt.lower_plan(descs, q.predicate, q.aggs, q.keys, q.grouped)
+        assert bpr == q.bytes_per_row  # 16 / 28 / 38 B per row
+        assert f'"{ts}"' in inc, f"{name} is not pre-compiled"
+    ts, lanes, _ = rt.lower_plan(descs, tpch.q1().predicate, tpch.q1().aggs, tpch.q1().keys, True)
+    assert "Keys<6,KeyCode<1>,KeyCode<2>>" in ts and lanes == 6 * 7 + 1
+
+
+def _desc(abi, cols):
+    arr = (abi.CColumnDesc * len(cols))()
+    for i, (fid, dt) in enumerate(cols):
+        arr[i].field_id, arr[i].dtype, arr[i].rows = fid, dt, 1000
+    return arr
+
+
+def test_literal_cast_rules(lib, abi):
+    """llkv-types/src/literal.rs:364-520: integer columns accept only integer (or scale-0 decimal)
+    literals; Date32 filters as i32 and rejects a Date32 literal; f64 accepts ints and decimals."""
+    rt = mod("runtime")
+    d = _desc(abi, [(1, abi.DT_INT64), (2, abi.DT_FLOAT64), (3, abi.DT_DATE32), (4, abi.DT_INT32)])
+    F, O, A, L = abi.Filter, abi.Operator, abi.AggregateSpec, abi.Literal
+    cnt = [A.count_star()]
+    for bad in (F(1, O.LessThan(24.5)), F(3, O.GreaterThanOrEquals(L.date32(8766))), F(1, O.Equals("x")),
+                F(4, O.LessThan(2**40)), F(1, O.LessThan(L.decimal(245, 1)))):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.lower_plan(d, [bad], cnt)
+        assert e.value.kind == "PredicateBuild", bad
+    ts, _, _ = rt.lower_plan(d, [F(1, O.LessThan(L.decimal(24, 0))), F(2, O.GreaterThanOrEquals(L.decimal(5, 2))), F(2, O.LessThan(3))], cnt)
+    assert ts.startswith("Plan<Cols<I64,F64>,And<Range<Col<0,I64>,0,Nil,2,LitI<0>>,Range<Col<1,F64>,1,LitF<0>,0,Nil>,Range<Col<1,F64>,0,Nil,2,LitF<1>>>")
+    with pytest.raises(abi.LlkvError) as e:
+        rt.lower_plan(d, [F(9, O.LessThan(1))], cnt)
+    assert e.value.kind == "NotFound"
+
+
+def test_expression_typing_rules(lib, abi):
+    """Fast path: everything is cast to the final type first (fast_numeric.rs:69-121); GROUP BY arguments use
+    the PlanValue rules where Int∘Int goes through f64 (llkv-executor/src/lib.rs:7338-7389)."""
+    rt = mod("runtime")
+    d = (abi.CColumnDesc * 3)()
+    d[0].field_id, d[0].dtype, d[0].rows = 1, abi.DT_INT64, 10
+    d[1].field_id, d[1].dtype, d[1].rows = 2, abi.DT_FLOAT64, 10
+    names = (C.c_char_p * 2)(b"x", b"y")
+    d[2].field_id, d[2].dtype, d[2].rows, d[2].dict_size, d[2].dictionary = 3, abi.DT_UTF8, 10, 2, names
+    A, col = abi.AggregateSpec, abi.col
+    ts, _, _ = rt.lower_plan(d, None, [A.sum((col(1) + col(1)) * col(2))])
+    assert "SumF64<Bin<3,Bin<1,ToF64<Col<0,I64>>,ToF64<Col<0,I64>>>,Col<1,F64>>>" in ts  # the i64 add happens in f64
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * 2)])
+    assert "SumI64<Bin<3,Col<0,I64>,LitI<0>>>" in ts  # checked i64, exact 96-bit split accumulator
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * 2), A.sum(col(1) * (1 - col(2)))], keys=[3], grouped=True)
+    assert "BinViaF64<3,Col<1,I64>,LitI<0>>" in ts and "Bin<3,ToF64<Col<1,I64>>,Bin<2,ToF64<LitI<1>>,Col<2,F64>>>" in ts
+    with pytest.raises(abi.LlkvError) as e:
+        rt.lower_plan(d, None, [A.sum(col(1) / col(2))])
+    assert e.value.kind == "Unsupported"  # x/0 → NULL needs the CPU route for now
+    d32 = _desc(abi, [(1, abi.DT_INT32)])
+    with pytest.raises(abi.LlkvError) as e:
+        rt.lower_plan(d32, None, [A.sum(1)])
+    assert e.value.kind == "InvalidArgumentError" and "not supported for column type Int32" in e.value.message
+
+
+def test_int_sum_uses_statistics_to_exclude_overflow(lib, abi):
+    rt = mod("runtime")
+    d = (abi.CColumnDesc * 1)()
+    d[0].field_id, d[0].dtype, d[0].rows, d[0].has_stats, d[0].min_i, d[0].max_i = 1, abi.DT_INT64, 60_000_000, 1, 1, 50
+    ts, _, _ = rt.lower_plan(d, None, [abi.AggregateSpec.sum(1)])
+    assert "SumI64Fast<Col<0,I64>>" in ts
+    d[0].max_i = 2**62
+    ts, _, _ = rt.lower_plan(d, None, [abi.AggregateSpec.sum(1)])
+    assert "SumI64<Col<0,I64>>" in ts
+
+
+@pytest.mark.parametrize("n_chunks", [0, 1, 7, 8, 458, 916, 3664])
+def test_shard_layout_partitions_chunks(lib, n_chunks):
+    """Every chunk belongs to exactly one octant and one rank; shards are contiguous; world 1/2/4/8 shard
+    boundaries are octant boundaries (so partial states never straddle ranks)."""
+    dist = mod("dist")
+    begin1, _ = dist.shard_layout(lib, n_chunks, 1)
+    assert begin1[0] == 0 and begin1[8] == n_chunks and all(b <= c for b, c in zip(begin1, begin1[1:]))
+    rt = mod("runtime")
+    for world in (1, 2, 4, 8):
+        begin, owner = dist.shard_layout(lib, n_chunks, world)
+        assert begin == begin1
+        covered = []
+        for rank in range(world):
+            t = rt.HipTable(1, [100] * n_chunks, rank, world)
+            octs = [o for o in range(8) if owner[o] == rank]
+            assert octs == list(range(rank * 8 // world, (rank + 1) * 8 // world))
+            assert t.first_chunk == begin[octs[0]] and t.n_local_chunks == begin[octs[-1] + 1] - begin[octs[0]]
+            covered += list(range(t.first_chunk, t.first_chunk + t.n_local_chunks))
+            assert t.total_rows == 100 * n_chunks and t.local_rows == 100 * t.n_local_chunks
+        assert covered == list(range(n_chunks))
