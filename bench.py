@@ -39,8 +39,9 @@ def parse():
     return ap.parse_args()
 
 
-def stage(rt, tpch, abi, query, total_rows, scale, rank, world, row_begin_global=0):
+def stage(rt, tpch, abi, dist, query, total_rows, scale, rank, world, row_begin_global=0):
     """Generate this rank's shard on the host and stage the needed columns into HBM."""
+    dmod = importlib.import_module("rust-llkv_amd.dist")
     chunks = tpch.chunk_rows(total_rows)
     table = rt.HipTable(1, chunks, rank, world)
     first_row = sum(chunks[:table.first_chunk])
@@ -48,7 +49,7 @@ def stage(rt, tpch, abi, query, total_rows, scale, rank, world, row_begin_global
     for name in query.columns:
         fid, dt = tpch.LINEITEM_SCHEMA[name]
         if dt == abi.DT_UTF8:
-            table.append_utf8_column(fid, data[name])
+            table.append_utf8_column(fid, data[name], dmod.table_wide_dictionary(dist, data[name], world))
         else:
             table.append_column(fid, dt, data[name])
     return table, data
@@ -80,11 +81,15 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
         table = rt.HipTable(1, chunks, rank, world)
         first_row = sum(chunks[:table.first_chunk])
         data = tpch.gen_lineitem(table.local_rows, gen_scale, query.columns, row_begin=first_row)
+        dmod = importlib.import_module("rust-llkv_amd.dist")
         for cname in query.columns:
             fid, dt = tpch.LINEITEM_SCHEMA[cname]
-            (table.append_utf8_column(fid, data[cname]) if dt == abi.DT_UTF8 else table.append_column(fid, dt, data[cname]))
+            if dt == abi.DT_UTF8:
+                table.append_utf8_column(fid, data[cname], dmod.table_wide_dictionary(dist, data[cname], world))
+            else:
+                table.append_column(fid, dt, data[cname])
     else:
-        table, data = stage(rt, tpch, abi, query, total_rows, gen_scale, rank, world)
+        table, data = stage(rt, tpch, abi, dist, query, total_rows, gen_scale, rank, world)
     del data
 
     q = rt.PreparedQuery(table, query.predicate, query.aggs, query.keys, query.order_by_keys)

@@ -225,11 +225,16 @@ uint64_t llkv_hip_table_local_rows(const llkv_hip_table *table);
 llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,
                                          const void *const *chunk_values, uint32_t n_chunks);
 /* Utf8 column given as Arrow offsets(i32)+data per chunk; staged as 1-byte
- * dictionary codes (≤ 256 distinct values, else LLKV_UNSUPPORTED).           */
+ * dictionary codes (≤ 256 distinct values, else LLKV_UNSUPPORTED).
+ * `dictionary` (dict_size strings) fixes the code of every value; it is REQUIRED
+ * when the table is sharded (world > 1) so that all ranks agree on the codes —
+ * e.g. the sorted union of the shards' distinct values.  With world == 1 it may
+ * be NULL: codes are then assigned in first-appearance order.                  */
 llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t field_id,
                                               const int32_t *const *chunk_offsets,
                                               const uint8_t *const *chunk_data,
-                                              uint32_t n_chunks);
+                                              uint32_t n_chunks,
+                                              const char *const *dictionary, uint32_t dict_size);
 /* Adopt a buffer that already lives in HBM (all local chunks back to back). */
 llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id,
                                                int32_t dtype, const void *device_values);

@@ -540,10 +540,13 @@ llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_i
 
 llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t field_id,
                                               const int32_t *const *chunk_offsets, const uint8_t *const *chunk_data,
-                                              uint32_t n_chunks) {
+                                              uint32_t n_chunks, const char *const *dictionary, uint32_t dict_size) {
   Table *t = reinterpret_cast<Table *>(table);
   int rc = check_new_column(t, field_id, n_chunks);
   if (rc) return (llkv_status)rc;
+  if (!dictionary && t->world > 1)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "sharded Utf8 columns need a table-wide dictionary (ranks must agree on the codes)");
+  if (dict_size > 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
   if ((rc = ensure_device())) return (llkv_status)rc;
   DeviceColumn c;
   c.info.field_id = field_id;
@@ -553,38 +556,42 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
   // dictionary-encode on the host at staging (SURVEY.md §7 "Utf8 group keys"): 1 B/row in HBM
   std::vector<uint8_t> codes(t->dev_rows + 16, 0);
   std::map<std::string, uint8_t> dict;
+  const bool fixed = dictionary != nullptr;
+  for (uint32_t d = 0; d < dict_size && fixed; ++d) {
+    std::string s = dictionary[d] ? dictionary[d] : "";
+    if (!dict.emplace(s, (uint8_t)d).second) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "duplicate dictionary entry '" + s + "'");
+    c.info.dictionary.push_back(s);
+  }
+  auto code_of = [&](const std::string &s, uint8_t *out) -> int {
+    auto it = dict.find(s);
+    if (it == dict.end()) {
+      if (fixed) return set_error(LLKV_INVALID_ARGUMENT, "value '" + s + "' is not in the supplied dictionary");
+      if (dict.size() >= 256) return set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+      it = dict.emplace(s, (uint8_t)dict.size()).first;
+      c.info.dictionary.push_back(s);
+    }
+    *out = it->second;
+    return LLKV_OK;
+  };
   for (uint32_t i = 0; i < n_chunks; ++i) {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
     const int32_t *off = chunk_offsets[i];
     const uint8_t *data = chunk_data[i];
     uint8_t *dst = codes.data() + t->chunk_dev_off[i];
-    // fast path for 1-byte strings (TPC-H flags)
-    int16_t lut[256];
+    int16_t lut[256]; // fast path for 1-byte strings (TPC-H flags)
     std::fill(std::begin(lut), std::end(lut), (int16_t)-1);
     for (uint64_t r = 0; r < rows; ++r) {
       const int32_t len = off[r + 1] - off[r];
       if (len == 1) {
         const uint8_t ch = data[off[r]];
         if (lut[ch] < 0) {
-          std::string s(1, (char)ch);
-          auto it = dict.find(s);
-          if (it == dict.end()) {
-            if (dict.size() >= 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
-            it = dict.emplace(s, (uint8_t)dict.size()).first;
-            c.info.dictionary.push_back(s);
-          }
-          lut[ch] = it->second;
+          uint8_t code;
+          if ((rc = code_of(std::string(1, (char)ch), &code))) return (llkv_status)rc;
+          lut[ch] = code;
         }
         dst[r] = (uint8_t)lut[ch];
       } else {
-        std::string s((const char *)data + off[r], (size_t)len);
-        auto it = dict.find(s);
-        if (it == dict.end()) {
-          if (dict.size() >= 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
-          it = dict.emplace(s, (uint8_t)dict.size()).first;
-          c.info.dictionary.push_back(s);
-        }
-        dst[r] = it->second;
+        if ((rc = code_of(std::string((const char *)data + off[r], (size_t)len), &dst[r]))) return (llkv_status)rc;
       }
     }
   }

@@ -44,3 +44,17 @@ def fold_exchange(lib, exchange: np.ndarray, lane_ops: Sequence[int]) -> np.ndar
     if rc != 0:
         raise ValueError(lib.llkv_hip_last_error().decode())
     return out
+
+
+def table_wide_dictionary(dist, local_values, world: int) -> List[str]:
+    """Sorted union of the shards' distinct Utf8 values (staging-time agreement on dictionary codes).
+    ``local_values``: uint8 array of 1-byte strings or a sequence of str."""
+    if isinstance(local_values, np.ndarray) and local_values.dtype == np.uint8:
+        local = sorted({chr(int(v)) for v in np.unique(local_values)})
+    else:
+        local = sorted(set(local_values))
+    if world <= 1:
+        return local
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    return sorted(set().union(*gathered))

@@ -133,9 +133,10 @@ class HipTable:
         ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
         check(lib().llkv_hip_table_append_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), ptrs, C.c_uint32(len(chunks))))
 
-    def append_utf8_column(self, field_id: int, strings: Union[np.ndarray, Sequence]):
+    def append_utf8_column(self, field_id: int, strings: Union[np.ndarray, Sequence], dictionary: Optional[Sequence[str]] = None):
         """Stage a Utf8 column.  ``strings`` is either a uint8 array of 1-byte strings (Arrow
-        offsets are then 0..n) or a sequence of Python strings."""
+        offsets are then 0..n) or a sequence of Python strings.  ``dictionary`` fixes the codes
+        (required for sharded tables: every rank must pass the same table-wide dictionary)."""
         chunks_off, chunks_data = [], []
         if isinstance(strings, np.ndarray) and strings.dtype == np.uint8:
             for c in self._split(strings):
@@ -154,7 +155,12 @@ class HipTable:
                 chunks_data.append(np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy())
         poff = (C.c_void_p * max(1, len(chunks_off)))(*[c.ctypes.data for c in chunks_off])
         pdat = (C.c_void_p * max(1, len(chunks_data)))(*[c.ctypes.data for c in chunks_data])
-        check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off))))
+        if dictionary is None:
+            dptr, dn = None, 0
+        else:
+            enc = [d.encode() for d in dictionary]
+            dptr, dn = (C.c_char_p * max(1, len(enc)))(*enc), len(enc)
+        check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off)), dptr, C.c_uint32(dn)))
 
     def adopt_device_column(self, field_id: int, dtype: int, device_ptr: int):
         check(lib().llkv_hip_table_adopt_device_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), C.c_void_p(device_ptr)))
