@@ -225,7 +225,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->order_by_keys = order_by_keys;
   q->n_user_aggs = n_aggs;
   std::string err;
-  rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, &q->plan, &err);
+  rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, /*track_first=*/!order_by_keys, &q->plan, &err);
   if (rc) return set_error(rc, err);
   const LoweredPlan &p = q->plan;
 
@@ -392,12 +392,12 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
   groups.clear();
   if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic overflowed on a selected row
     return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
-  const int base = p.grouped ? 2 : 1;
+  const int base = p.track_first ? 2 : 1;
   for (uint32_t g = 0; g < p.ng; ++g) {
     const uint64_t *gl = &state[(size_t)g * p.k];
     if (p.grouped && gl[0] == 0) continue; // group never appeared
     GroupResult gr;
-    gr.first_row = p.grouped ? gl[1] : 0;
+    gr.first_row = p.track_first ? gl[1] : 0;
     if (p.grouped)
       for (size_t k = 0; k < p.key_fields.size(); ++k) {
         const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
@@ -414,7 +414,7 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
   }
   if (p.grouped) {
     // first-appearance order (llkv-executor/src/lib.rs:5065-5089), then ORDER BY keys ASC
-    std::sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
+    if (p.track_first) std::sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
     if (order_by_keys) std::stable_sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.keys < b.keys; });
   }
   return LLKV_OK;

@@ -256,8 +256,11 @@ template <class P> struct Not { // domain = all rows on this path (no NULLs stag
 template <int S> struct KeyCode {
   static __device__ __forceinline__ uint32_t code(Ctx &c, int j) { return c.get<U8>(S, j); }
 };
-template <int NG_, class... Ks> struct Keys {
+// FIRST = 1 keeps the row id of each group's first row (first-appearance output order,
+// llkv-executor/src/lib.rs:5065-5089); with ORDER BY on the keys it is not needed.
+template <int NG_, int FIRST_, class... Ks> struct Keys {
   static constexpr int NG = NG_;
+  static constexpr int FIRST = FIRST_;
   static constexpr int NK = sizeof...(Ks);
   template <int I, class K0, class... Kr> static __device__ __forceinline__ uint32_t acc(Ctx &c, int j) {
     uint32_t g = K0::code(c, j) * c.p.key_stride[I];
@@ -332,17 +335,22 @@ template <class... As> struct Aggs {
   static constexpr int N = (0 + ... + As::N);
 };
 
-// Plan = Cols × Pred × Keys × Aggs × unroll.  Lane layout per group:
-//   [0] rows (ADD_I64)   [1] first row id (MIN_I64, grouped plans only)   [..] aggregate lanes
-template <class CL, class PR, class KS, class AG, int U_ = 2> struct Plan {
+// Plan = Cols × Pred × Keys × Aggs × unroll × accumulator placement.  Lane layout per group:
+//   [0] rows (ADD_I64)   [1] first row id (MIN_I64, only with Keys<.., FIRST=1, ..>)   [..] aggregate lanes
+// ACC = 0: accumulators in registers, masked per group (ungrouped plans, NG = 1);
+// ACC = 1: accumulators in per-thread private LDS slots updated with DS atomics
+//          (ds_add_f64 / ds_add_u64 / ds_min_i64 / ...), indexed by the row's own group id.
+template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0> struct Plan {
   using ColList = CL;
   using Pred = PR;
   using KeyT = KS;
   using AggT = AG;
   static constexpr int U = U_;
+  static constexpr int ACC = ACC_;
   static constexpr int NG = KS::NG;
   static constexpr bool grouped = KS::NK > 0;
-  static constexpr int BASE = grouped ? 2 : 1;
+  static constexpr bool first = KS::FIRST != 0;
+  static constexpr int BASE = first ? 2 : 1;
   static constexpr int K = BASE + AG::N;
   static constexpr int LANES = NG * K + 1; // + error lane (MAX_U64)
 };
@@ -371,7 +379,7 @@ template <class P> constexpr int plan_lane_op(int lane) {
   if (lane == P::NG * P::K) return OP_MAX_U64; // error lane
   const int k = lane % P::K;
   if (k == 0) return OP_ADD_I64;
-  if (P::grouped && k == 1) return OP_MIN_I64;
+  if (P::first && k == 1) return OP_MIN_I64;
   return AggOps<typename P::AggT>::op(k - P::BASE);
 }
 
@@ -388,7 +396,7 @@ template <class P> struct LaneOpTable {
 constexpr int kRedBatch = 16;                 // lanes transposed through LDS per round
 constexpr int kRedRow = kBlock + kBlock / 16; // 16-element segments padded to 17
 
-template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {
+template <class P> __device__ __forceinline__ void fused_scan_body_reg(const ScanParams &p) {
   constexpr int NG = P::NG, K = P::K, U = P::U, LANES = P::LANES;
   constexpr LaneOpTable<P> ops{};
   __shared__ uint64_t red[LANES < kRedBatch ? LANES : kRedBatch][kRedRow];
@@ -424,7 +432,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body(const ScanPar
         const uint32_t gid = P::KeyT::gid(c, j);
         uint64_t contrib[K];
         contrib[0] = 1;
-        if constexpr (P::grouped) contrib[1] = c.row;
+        if constexpr (P::first) contrib[1] = c.row;
         AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
         err |= pass ? c.err : 0u;
 #pragma unroll
@@ -478,6 +486,101 @@ template <class P> __device__ __forceinline__ void fused_scan_body(const ScanPar
     }
     __syncthreads();
   }
+}
+
+
+// ---- grouped plans: accumulators in per-thread private LDS slots -------------------
+// acc[slot][tid], slot = gid * K + k.  Every thread only ever touches its own column, so the DS
+// read-modify-write instructions are uncontended, execute in program order and the result is
+// deterministic; a row updates K slots of ITS group — no per-group masking, no accumulator VGPRs.
+template <int OP> __device__ __forceinline__ void lds_accumulate(uint64_t *slot, uint64_t x) {
+  if constexpr (OP == OP_ADD_F64)
+    (void)__hip_atomic_fetch_add(reinterpret_cast<double *>(slot), __longlong_as_double((long long)x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else if constexpr (OP == OP_ADD_I64)
+    (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(slot), (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else if constexpr (OP == OP_MIN_I64)
+    (void)__hip_atomic_fetch_min(reinterpret_cast<long long *>(slot), (long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else if constexpr (OP == OP_MAX_I64)
+    (void)__hip_atomic_fetch_max(reinterpret_cast<long long *>(slot), (long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot), (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class P, int K0 = 0> __device__ __forceinline__ void lds_accumulate_row(uint64_t *group_base, const uint64_t *contrib) {
+  if constexpr (K0 < P::K) {
+    lds_accumulate<plan_lane_op<P>(K0)>(group_base + K0 * kBlock, contrib[K0]);
+    lds_accumulate_row<P, K0 + 1>(group_base, contrib);
+  }
+}
+
+template <class P> __device__ __forceinline__ void fused_scan_body_lds(const ScanParams &p) {
+  constexpr int NG = P::NG, K = P::K, U = P::U, LANES = P::LANES;
+  constexpr LaneOpTable<P> ops{};
+  __shared__ uint64_t acc[LANES][kBlock]; // last row: error flags
+
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
+  uint32_t err = 0;
+
+  const TileDesc td = p.tiles[blockIdx.x];
+  const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
+
+  for (uint32_t s = 0; s < nsteps; s += U) {
+    Loaded ld[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t row0 = (uint64_t)(s + u) * kStepRows + (uint64_t)tid * kRowsPerThread;
+      load_all<typename P::ColList>(p, td.dev_row + row0, ld[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t row0 = (s + u) * kStepRows + tid * kRowsPerThread;
+#pragma unroll
+      for (int j = 0; j < kRowsPerThread; ++j) {
+        Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
+        const bool in_tile = (row0 + j) < td.rows;
+        const bool pass = in_tile & P::Pred::eval(c, j);
+        uint32_t gid = P::KeyT::gid(c, j);
+        gid = gid < (uint32_t)NG ? gid : 0u; // rows past the tile end carry arbitrary codes
+        uint64_t contrib[K];
+        contrib[0] = 1;
+        if constexpr (P::first) contrib[1] = c.row;
+        AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
+        err |= pass ? c.err : 0u;
+        if (pass) lds_accumulate_row<P>(&acc[gid * K][tid], contrib);
+      }
+    }
+  }
+  acc[NG * K][tid] = err;
+  __syncthreads(); // drains the DS queue of every wave (lgkmcnt(0)) before the cross-thread reads
+
+  // ---- block reduction straight out of the accumulator image, fixed order ----
+  const uint32_t ri = tid >> 4, rq = tid & 15;
+#pragma unroll 1
+  for (int base = 0; base < LANES; base += kRedBatch) {
+    const int lane = base + (int)ri;
+    if (lane < LANES) {
+      const int op = ops.v[lane];
+      const uint64_t *seg = &acc[lane][rq * 16];
+      uint64_t v = seg[0];
+#pragma unroll
+      for (int e = 1; e < 16; ++e) v = lane_combine(op, v, seg[e]);
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off, 16);
+        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 16);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = (rq & off) ? lane_combine(op, o, v) : lane_combine(op, v, o);
+      }
+      if (rq == 0) p.tile_partials[(uint64_t)lane * p.n_tiles + blockIdx.x] = v;
+    }
+  }
+}
+
+template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {
+  if constexpr (P::ACC == 1) fused_scan_body_lds<P>(p);
+  else fused_scan_body_reg<P>(p);
 }
 
 template <class P> __global__ __launch_bounds__(kBlock) void fused_scan_kernel(const ScanParams p) { fused_scan_body<P>(p); }

@@ -410,7 +410,7 @@ struct Lowering {
 
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
-               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, LoweredPlan *out, std::string *err) {
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err) {
   *out = LoweredPlan{};
   LoweredPlan &p = *out;
   Lowering L{resolve, p, err, grouped};
@@ -449,14 +449,14 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     p.ng = (uint32_t)ng;
     p.key_strides.assign(n_keys, 1);
     for (int k = (int)n_keys - 2; k >= 0; --k) p.key_strides[k] = p.key_strides[k + 1] * p.key_cards[k + 1];
-    keys += std::to_string(p.ng) + nodes + ">";
+    keys += std::to_string(p.ng) + "," + (track_first ? "1" : "0") + nodes + ">";
   } else {
     p.ng = 1;
-    keys += "1>";
+    keys += "1,0>";
   }
 
   // aggregates → deduplicated lane groups
-  const int base = grouped ? 2 : 1;
+  const int base = (grouped && track_first) ? 2 : 1;
   std::vector<std::string> groups; // lane-group node strings
   std::vector<int> group_lane;     // first lane (relative to base) of each lane group
   std::vector<std::vector<uint8_t>> group_ops;
@@ -550,11 +550,17 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   p.lane_ops.clear();
   for (uint32_t g = 0; g < p.ng; ++g) {
     p.lane_ops.push_back(ADD_I64);
-    if (grouped) p.lane_ops.push_back(MIN_I64);
+    if (grouped && track_first) p.lane_ops.push_back(MIN_I64);
     for (auto &go : group_ops) for (uint8_t op : go) p.lane_ops.push_back(op);
   }
   p.lane_ops.push_back(MAX_U64);
-  p.unroll = p.lanes <= 8 ? 4 : 2;
+  // accumulator placement: grouped plans keep their state in per-thread LDS slots (DS atomics
+  // indexed by the row's group id); ungrouped plans keep it in registers
+  p.acc_lds = grouped && p.ng > 1;
+  p.track_first = grouped && track_first;
+  if (p.acc_lds && (size_t)p.lanes * 2048 > 160u * 1024)
+    return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
+  p.unroll = (p.acc_lds || p.lanes <= 8) ? 4 : 2;
 
   std::string cols = "Cols<";
   p.bytes_per_row = 0;
@@ -566,7 +572,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   std::string ag = "Aggs<";
   for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
   ag += ">";
-  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + ">";
+  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_lds ? "1" : "0") + ">";
   return LLKV_OK;
 }
 

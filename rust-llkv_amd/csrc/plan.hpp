@@ -59,6 +59,8 @@ struct LoweredPlan {
   std::vector<uint32_t> key_fields, key_slots, key_strides, key_cards;
   uint32_t ng = 1;
   bool grouped = false;
+  bool track_first = false; // lane [1] = first row id of the group (first-appearance order)
+  bool acc_lds = false;     // accumulators in per-thread LDS slots (grouped plans)
   int k = 1;      // lanes per group
   int lanes = 2;  // ng * k + 1
   int unroll = 2;
@@ -69,12 +71,13 @@ struct LoweredPlan {
 };
 
 // Lowers a plan.  `grouped` selects the GROUP BY argument semantics (PlanValue
-// interpreter) instead of the computed-projection fast path.  Returns an llkv_status;
+// interpreter) instead of the computed-projection fast path; `track_first` keeps each
+// group's first row id (needed unless the output is ordered by the keys).  Returns an llkv_status;
 // on failure `err` holds the message.
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
-               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, LoweredPlan *out,
-               std::string *err);
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first,
+               LoweredPlan *out, std::string *err);
 
 // Typed literal cast used by leaf predicates (shared with the selection path).
 struct NativeLit {

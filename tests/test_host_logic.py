@@ -69,11 +69,13 @@ def test_lowering_of_benchmark_plans_hits_the_aot_catalog(lib, abi, tpch):
     inc = open(os.path.join(ROOT, "rust-llkv_amd", "csrc", "catalog_entries.inc")).read()
     for name, mk in tpch.QUERIES.items():
         q = mk()
-        ts, lanes, bpr = rt.lower_plan(descs, q.predicate, q.aggs, q.keys, q.grouped)
+        ts, lanes, bpr = rt.lower_plan(descs, q.predicate, q.aggs, q.keys, q.grouped, order_by_keys=q.order_by_keys)
         assert bpr == q.bytes_per_row  # 16 / 28 / 38 B per row
         assert f'"{ts}"' in inc, f"{name} is not pre-compiled"
+    ts, lanes, _ = rt.lower_plan(descs, tpch.q1().predicate, tpch.q1().aggs, tpch.q1().keys, True, order_by_keys=True)
+    assert "Keys<6,0,KeyCode<1>,KeyCode<2>>" in ts and lanes == 6 * 6 + 1 and ts.endswith(",4,1>")  # LDS accumulators
     ts, lanes, _ = rt.lower_plan(descs, tpch.q1().predicate, tpch.q1().aggs, tpch.q1().keys, True)
-    assert "Keys<6,KeyCode<1>,KeyCode<2>>" in ts and lanes == 6 * 7 + 1
+    assert "Keys<6,1,KeyCode<1>,KeyCode<2>>" in ts and lanes == 6 * 7 + 1  # first-appearance order needs the first-row lane
 
 
 def _desc(abi, cols):
