@@ -55,12 +55,24 @@ def stage(rt, tpch, abi, dist, query, total_rows, scale, rank, world, row_begin_
     return table, data
 
 
-def run_steps(q, steps, dist, stream_ptr, ex_tensor):
-    for _ in range(steps):
+DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i while the GPU runs i+1..)
+
+
+def run_steps(q, steps, dist, stream_ptr, ex_tensors):
+    """K complete executions; every result is folded and finalized on the host inside the timed region."""
+    rows, outstanding = None, 0
+    for i in range(steps):
         q.launch(stream_ptr)
-        if ex_tensor is not None:
-            dist.all_reduce(ex_tensor)  # ncclSum over int64 lanes: exact concatenation of shard states
-        rows = q.finish(stream_ptr)
+        if ex_tensors is not None:
+            dist.all_reduce(ex_tensors[i % DEPTH])  # ncclSum over int64 lanes: exact concatenation of shard states
+        q.submit(stream_ptr)
+        outstanding += 1
+        if outstanding == DEPTH:
+            rows = q.collect()
+            outstanding -= 1
+    while outstanding:
+        rows = q.collect()
+        outstanding -= 1
     return rows
 
 
@@ -98,11 +110,12 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     stream_ptr = stream.cuda_stream
+    q.set_depth(DEPTH)
     ex_tensor = None
     if world > 1:
-        # zero-copy int64 view of the library's exchange buffer for torch.distributed (RCCL)
+        # zero-copy int64 views of the library's exchange ring for torch.distributed (RCCL)
         ptr, n = q.exchange_buffer()
-        ex_tensor = _tensor_from_ptr(torch, ptr, n)
+        ex_tensor = [_tensor_from_ptr(torch, ptr + slot * n * 8, n) for slot in range(DEPTH)]
 
     run_steps(q, warmup, dist, stream_ptr, ex_tensor)
     q.set_profiling(True)

@@ -279,6 +279,16 @@ llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_
  * finalize.  Blocks until done.                                              */
 llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream);
 
+/* Pipelined form (several executions of one prepared query in flight, e.g. many
+ * concurrent sessions): set_depth(D) allows D launches before the oldest must be
+ * collected.  Per execution: launch → [caller's all-reduce of exchange_buffer] →
+ * submit (enqueue the copy-out) … later collect (wait + fold + finalize the
+ * OLDEST submitted execution; results readable until the next collect).
+ * finish() = submit + collect everything outstanding.                         */
+llkv_status llkv_hip_query_set_depth(llkv_hip_query *query, uint32_t depth);
+llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream);
+llkv_status llkv_hip_query_collect(llkv_hip_query *query);
+
 /* Same, from an exchange image the caller already holds on the host (for hosts
  * that run the collective themselves; `len_i64` must match exchange_buffer). */
 llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_t *exchange,

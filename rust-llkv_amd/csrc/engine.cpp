@@ -198,6 +198,7 @@ Query::~Query() {
   if (d_lane_ops) (void)hipFree(d_lane_ops);
   if (h_exchange) (void)hipHostFree(h_exchange);
   for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto &e : copied) if (e) (void)hipEventDestroy(e);
 }
 
 static uint32_t pick_tile_rows(const LoweredPlan &p) {
@@ -250,11 +251,13 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
 
   const size_t lanes = (size_t)p.lanes;
   HIP_TRY(hipMalloc((void **)&q->d_tile_partials, std::max<size_t>(1, lanes * ts->n_tiles) * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc((void **)&q->d_exchange, kOctantsHost * lanes * sizeof(uint64_t)));
-  HIP_TRY(hipMemsetAsync(q->d_exchange, 0, kOctantsHost * lanes * sizeof(uint64_t), g_ctx.stream));
+  const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
+  HIP_TRY(hipMalloc((void **)&q->d_exchange, ring_bytes));
+  HIP_TRY(hipMemsetAsync(q->d_exchange, 0, ring_bytes, g_ctx.stream));
+  for (auto &e : q->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipMalloc((void **)&q->d_lane_ops, lanes));
   HIP_TRY(hipMemcpyAsync(q->d_lane_ops, p.lane_ops.data(), lanes, hipMemcpyHostToDevice, g_ctx.stream));
-  HIP_TRY(hipHostMalloc((void **)&q->h_exchange, kOctantsHost * lanes * sizeof(uint64_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&q->h_exchange, ring_bytes, hipHostMallocDefault));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   q->params.tile_partials = q->d_tile_partials;
 
@@ -272,6 +275,8 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
 
 int Query::launch(hipStream_t stream) {
   if (!stream) stream = g_ctx.stream;
+  if (n_launched - n_collected >= depth)
+    return set_error(LLKV_INVALID_ARGUMENT, "query pipeline is full: collect a finished execution first (depth " + std::to_string(depth) + ")");
   const bool run_main = !plan.always_false && tiles->n_tiles > 0;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (profiling && run_main) {
@@ -292,9 +297,11 @@ int Query::launch(hipStream_t stream) {
     if (ev.second) HIP_TRY(hipEventRecord(ev.second, stream));
   }
   FoldParams f = fold;
+  f.exchange = d_exchange + (n_launched % depth) * exchange_len();
   if (!run_main) f.n_tiles = 0, std::fill(std::begin(f.octant_tile_begin), std::end(f.octant_tile_begin), 0u);
   HIP_TRY(launch_fold_octants(f, stream));
   launches++;
+  n_launched++;
   return LLKV_OK;
 }
 
@@ -420,12 +427,36 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
   return LLKV_OK;
 }
 
-int Query::finish(hipStream_t stream) {
+// Enqueue the copy-out of the oldest launched-but-not-submitted execution (after the caller's
+// collective, if any, on the same stream).
+int Query::submit(hipStream_t stream) {
   if (!stream) stream = g_ctx.stream;
-  const size_t bytes = kOctantsHost * (size_t)plan.lanes * sizeof(uint64_t);
-  HIP_TRY(hipMemcpyAsync(h_exchange, d_exchange, bytes, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  return finish_from_exchange(h_exchange);
+  if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "submit without a launched execution");
+  const uint32_t slot = (uint32_t)(n_submitted % depth);
+  const size_t bytes = exchange_len() * sizeof(uint64_t);
+  HIP_TRY(hipMemcpyAsync(h_exchange + slot * exchange_len(), d_exchange + slot * exchange_len(), bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(copied[slot], stream));
+  n_submitted++;
+  return LLKV_OK;
+}
+
+// Wait for the oldest submitted execution, fold and finalize it.
+int Query::collect() {
+  if (n_collected >= n_submitted) return set_error(LLKV_INVALID_ARGUMENT, "collect without a submitted execution");
+  const uint32_t slot = (uint32_t)(n_collected % depth);
+  HIP_TRY(hipEventSynchronize(copied[slot]));
+  n_collected++;
+  return finish_from_exchange(h_exchange + slot * exchange_len());
+}
+
+int Query::finish(hipStream_t stream) {
+  while (n_submitted < n_launched) {
+    int rc = submit(stream);
+    if (rc) return rc;
+  }
+  int rc = LLKV_OK;
+  while (n_collected < n_submitted && rc == LLKV_OK) rc = collect();
+  return rc;
 }
 
 } // namespace llkv
@@ -663,7 +694,9 @@ llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream) {
 llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_ptr, uint64_t *len_i64) {
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   Query *q = reinterpret_cast<Query *>(query);
-  if (device_ptr) *device_ptr = q->d_exchange;
+  // image of the most recently launched execution
+  const uint64_t last = q->n_launched ? q->n_launched - 1 : 0;
+  if (device_ptr) *device_ptr = q->d_exchange + (last % q->depth) * q->exchange_len();
   if (len_i64) *len_i64 = (uint64_t)kOctantsHost * (uint64_t)q->plan.lanes;
   return LLKV_OK;
 }
@@ -678,6 +711,26 @@ llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_
   Query *q = reinterpret_cast<Query *>(query);
   if (len_i64 != (uint64_t)kOctantsHost * (uint64_t)q->plan.lanes) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "exchange length mismatch");
   return (llkv_status)q->finish_from_exchange(exchange);
+}
+
+llkv_status llkv_hip_query_set_depth(llkv_hip_query *query, uint32_t depth) {
+  Query *q = reinterpret_cast<Query *>(query);
+  if (!q) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  if (depth == 0 || depth > Query::kMaxDepth) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "depth must be 1..8");
+  if (q->n_launched != q->n_collected) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "executions in flight");
+  q->depth = depth;
+  q->n_launched = q->n_submitted = q->n_collected = 0;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  return (llkv_status) reinterpret_cast<Query *>(query)->submit((hipStream_t)hip_stream);
+}
+
+llkv_status llkv_hip_query_collect(llkv_hip_query *query) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  return (llkv_status) reinterpret_cast<Query *>(query)->collect();
 }
 
 uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->groups.size() : 0; }

@@ -89,9 +89,15 @@ struct Query {
   ScanParams params;
   FoldParams fold;
   uint64_t *d_tile_partials = nullptr;
-  uint64_t *d_exchange = nullptr;
+  // ring of exchange images so that up to `depth` executions are in flight: the host
+  // finalizes execution i while the GPU already runs i+1
+  static constexpr uint32_t kMaxDepth = 8;
+  uint32_t depth = 1;
+  uint64_t n_launched = 0, n_submitted = 0, n_collected = 0;
+  hipEvent_t copied[kMaxDepth] = {nullptr};
+  uint64_t *d_exchange = nullptr; // [kMaxDepth][kOctants][lanes]
   uint8_t *d_lane_ops = nullptr;
-  uint64_t *h_exchange = nullptr; // pinned
+  uint64_t *h_exchange = nullptr; // pinned, same shape
   bool order_by_keys = false;
   uint32_t n_user_aggs = 0;
   std::vector<GroupResult> groups;
@@ -100,7 +106,10 @@ struct Query {
   size_t events_used = 0;
   uint64_t launches = 0;
 
+  size_t exchange_len() const { return (size_t)kOctants * (size_t)plan.lanes; }
   int launch(hipStream_t stream);
+  int submit(hipStream_t stream);
+  int collect();
   int finish(hipStream_t stream);
   int finish_from_exchange(const uint64_t *exchange);
   ~Query();

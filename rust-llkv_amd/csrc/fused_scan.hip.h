@@ -605,7 +605,15 @@ __global__ __launch_bounds__(kBlock) void fold_octants_kernel(const FoldParams f
   const uint32_t t0 = f.octant_tile_begin[o], t1 = f.octant_tile_begin[o + 1];
   const uint64_t *src = f.tile_partials + (uint64_t)lane * f.n_tiles;
   uint64_t v = lane_identity(op);
-  for (uint32_t t = t0 + l; t < t1; t += 64) v = lane_combine(op, v, src[t]);
+  uint32_t t = t0 + l;
+  for (; t + 448 < t1; t += 512) { // 8 independent loads in flight, combined in the same order as the tail loop
+    uint64_t a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = src[t + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v = lane_combine(op, v, a[i]);
+  }
+  for (; t < t1; t += 64) v = lane_combine(op, v, src[t]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);

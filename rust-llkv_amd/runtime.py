@@ -218,6 +218,16 @@ class PreparedQuery:
         check(lib().llkv_hip_query_exchange_buffer(self._h, C.byref(ptr), C.byref(n)))
         return ptr.value, n.value
 
+    def set_depth(self, depth: int):
+        check(lib().llkv_hip_query_set_depth(self._h, C.c_uint32(depth)))
+
+    def submit(self, stream: int = 0):
+        check(lib().llkv_hip_query_submit(self._h, C.c_void_p(stream)))
+
+    def collect(self) -> List[GroupRow]:
+        check(lib().llkv_hip_query_collect(self._h))
+        return self.rows()
+
     def finish(self, stream: int = 0) -> List[GroupRow]:
         check(lib().llkv_hip_query_finish(self._h, C.c_void_p(stream)))
         return self.rows()
