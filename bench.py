@@ -143,6 +143,22 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     return res
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_traffic.json: 2·FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md §HBM).  Counters cannot be collected from inside this process."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            if workload in doc:
+                return doc[workload]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def _tensor_from_ptr(torch, ptr, n_i64):
     """int64 CUDA tensor aliasing a raw device pointer (exchange buffer), via __cuda_array_interface__."""
 
@@ -229,7 +245,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": main_res["kernel_name"], "kernel_ms": main_res["kernel_ms_avg"],
+            "traffic": (pmc_traffic(args.workload)[0] if world == 1 else None), "traffic_source": pmc_traffic(args.workload)[1],
+            "kernel": main_res["kernel_name"], "kernel_ms": main_res["kernel_ms_avg"],
             "algorithmic_bytes_per_launch": main_res["alg_bytes_local"],
         },
         "hbm_gbs_end_to_end": main_res["query"].bytes_per_row * value / 1e9,
