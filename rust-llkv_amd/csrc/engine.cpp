@@ -108,7 +108,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
   for (int o = 0; o < kOctantsHost; ++o) octant_tile_begin[o + 1] = octant_tile_begin[o] + per_octant[o];
 }
 
-static int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
+int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
   Table &t = const_cast<Table &>(tc);
   std::lock_guard<std::mutex> lk(t.mu);
   auto it = t.tilesets.find(tile_rows);
@@ -233,7 +233,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   if (!p.always_false) {
     q->entry = catalog_find(p.type_string.c_str());
     if (!q->entry) {
-      rc = jit_compile(p.type_string, &q->jit, &err);
+      rc = jit_compile(JitKind::Scan, p.type_string, &q->jit, &err);
       if (rc) return set_error(rc, err);
     }
   }

@@ -66,12 +66,15 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2 };
 struct JitKernel {
   hipModule_t module = nullptr;
-  hipFunction_t fn = nullptr;
+  hipFunction_t fn = nullptr;  // scan / select-count / project
+  hipFunction_t fn2 = nullptr; // select-write
 };
-int jit_compile(const std::string &type_string, JitKernel *out, std::string *err);
+int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, std::string *err);
 int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream);
+int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t bytes, hipStream_t stream);
 void jit_shutdown();
 
 struct GroupResult {
@@ -118,6 +121,19 @@ struct Query {
 int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                   uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs,
                   uint32_t n_aggs, bool grouped, bool order_by_keys, Query **out);
+
+int get_tileset(const Table &t, uint32_t tile_rows, const TileSet **out);
+
+// Selection vector of a predicate over a table image (stream.cpp): ascending logical row ids
+// and the matching device row indices.
+struct Selection {
+  uint64_t n = 0;
+  uint64_t *d_ids = nullptr;
+  uint64_t *d_dev = nullptr;
+  ~Selection();
+};
+int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                  uint32_t n_ops, Selection *sel);
 
 void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state);
 int finalize_value(const AggOut &a, const uint64_t *group_lanes, int base, llkv_value *out, std::string *err);

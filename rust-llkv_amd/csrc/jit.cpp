@@ -1,34 +1,61 @@
-// jit.cpp — run-time specialisation of the fused scan kernel for plans outside the AOT
-// catalog.  The kernel source is the same hand-written header the catalog is built from
-// (embedded at build time as kFusedScanSource); hiprtc instantiates it for one plan type
-// for gfx950, the code object is cached per plan type string for the process lifetime.
+// jit.cpp — run-time specialisation of the hand-written kernel templates for plans outside
+// the AOT catalog.  The kernel source is the same header set the catalog is built from
+// (embedded at build time as kFusedScanSource); hiprtc instantiates it for ONE plan type for
+// gfx950.  Code objects are cached per (kind, plan type) in memory and on disk.
 #include "engine.hpp"
 
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <unordered_map>
 
 namespace llkv {
 
-#include "fused_scan_source.inc" // generated: const char *const kFusedScanSource
+#include "fused_scan_source.inc" // generated: static const char *const kFusedScanSource
 
 namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
-} // namespace
 
-int jit_compile(const std::string &type_string, JitKernel *out, std::string *err) {
-  std::lock_guard<std::mutex> lk(g_jit_mu);
-  auto it = g_jit_cache.find(type_string);
-  if (it != g_jit_cache.end()) { *out = it->second; return LLKV_OK; }
+const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : "project"; }
 
-  std::string src = kFusedScanSource;
-  src += "\nusing namespace llkv;\nextern \"C\" __global__ __launch_bounds__(256) void llkv_jit_scan(const ScanParams p) {\n"
-         "  fused_scan_body<" + type_string + ">(p);\n}\n";
+std::string wrapper_source(JitKind kind, const std::string &ts) {
+  std::string s = "\nusing namespace llkv;\n";
+  switch (kind) {
+  case JitKind::Scan:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { fused_scan_body<" + ts + ">(p); }\n";
+    break;
+  case JitKind::Select:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { select_body<" + ts + ", false>(p); }\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_b(const ScanParams p) { select_body<" + ts + ", true>(p); }\n";
+    break;
+  case JitKind::Project:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ProjParams p) { project_body<" + ts + ">(p); }\n";
+    break;
+  }
+  return s;
+}
+
+uint64_t fnv1a(const std::string &s) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (unsigned char c : s) h = (h ^ c) * 0x100000001b3ull;
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char *e = std::getenv("LLKV_HIP_CACHE_DIR")) return e;
+  if (const char *h = std::getenv("HOME")) return std::string(h) + "/.cache/llkv_hip";
+  return "/tmp/llkv_hip_cache";
+}
+
+int compile_to_code(const std::string &src, std::vector<char> *code, std::string *err) {
   hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "llkv_jit_scan.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+  if (hiprtcCreateProgram(&prog, src.c_str(), "llkv_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     *err = "hiprtcCreateProgram failed";
     return LLKV_INTERNAL;
   }
@@ -40,32 +67,66 @@ int jit_compile(const std::string &type_string, JitKernel *out, std::string *err
     std::string log(n, '\0');
     if (n) hiprtcGetProgramLog(prog, &log[0]);
     hiprtcDestroyProgram(&prog);
-    *err = "hiprtc compile failed for " + type_string + ":\n" + log;
+    *err = "hiprtc compile failed:\n" + log;
     return LLKV_INTERNAL;
   }
   size_t code_size = 0;
   hiprtcGetCodeSize(prog, &code_size);
-  std::vector<char> code(code_size);
-  hiprtcGetCode(prog, code.data());
+  code->resize(code_size);
+  hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
+  return LLKV_OK;
+}
+} // namespace
 
+int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, std::string *err) {
+  std::lock_guard<std::mutex> lk(g_jit_mu);
+  const std::string key = std::string(kind_name(kind)) + "|" + type_string;
+  auto it = g_jit_cache.find(key);
+  if (it != g_jit_cache.end()) { *out = it->second; return LLKV_OK; }
+
+  const std::string src = std::string(kFusedScanSource) + wrapper_source(kind, type_string);
+  char hex[32];
+  std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src));
+  const std::string dir = cache_dir(), path = dir + "/" + hex + ".hsaco";
+  std::vector<char> code;
+  {
+    std::ifstream f(path, std::ios::binary);
+    if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  }
+  if (code.empty()) {
+    int rc = compile_to_code(src, &code, err);
+    if (rc) { *err = "plan " + type_string + ": " + *err; return rc; }
+    ::mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); std::rename(tmp.c_str(), path.c_str()); }
+  }
   JitKernel k;
   hipError_t e = hipModuleLoadData(&k.module, code.data());
   if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_scan");
+  e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_a");
   if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  g_jit_cache.emplace(type_string, k);
+  if (kind == JitKind::Select) {
+    e = hipModuleGetFunction(&k.fn2, k.module, "llkv_jit_b");
+    if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
+  }
+  g_jit_cache.emplace(key, k);
   *out = k;
   return LLKV_OK;
 }
 
-int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream) {
-  if (p.n_tiles == 0) return LLKV_OK;
-  ScanParams copy = p;
-  void *args[] = {&copy};
-  hipError_t e = hipModuleLaunchKernel(k.fn, p.n_tiles, 1, 1, kBlock, 1, 1, 0, stream, args, nullptr);
+int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t /*bytes*/, hipStream_t stream) {
+  if (grid == 0) return LLKV_OK;
+  void *args[] = {params};
+  hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, kBlock, 1, 1, 0, stream, args, nullptr);
   if (e != hipSuccess) return set_error(LLKV_INTERNAL, std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e));
   return LLKV_OK;
+}
+
+int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream) {
+  ScanParams copy = p;
+  return jit_launch_raw(k.fn, p.n_tiles, &copy, sizeof copy, stream);
 }
 
 void jit_shutdown() {
@@ -74,26 +135,23 @@ void jit_shutdown() {
   g_jit_cache.clear();
 }
 
-// Exposed for the CPU build check: compiles a plan for gfx950 without touching a device.
+// Build check (no device needed): compiles one plan of the given kind for gfx950.
+// kind: 0 scan, 1 select, 2 project.
 extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out, uint64_t log_cap) {
-  std::string src = kFusedScanSource;
-  src += std::string("\nusing namespace llkv;\nextern \"C\" __global__ __launch_bounds__(256) void llkv_jit_scan(const ScanParams p) {\n"
-                     "  fused_scan_body<") + type_string + ">(p);\n}\n";
-  hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "llkv_jit_scan.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return LLKV_INTERNAL;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-  hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
-  size_t n = 0;
-  hiprtcGetProgramLogSize(prog, &n);
+  int kind = 0;
+  std::string ts = type_string;
+  if (ts.rfind("SelPlan<", 0) == 0) kind = 1;
+  else if (ts.rfind("ProjPlan<", 0) == 0) kind = 2;
+  const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
+  std::vector<char> code;
+  std::string err;
+  int rc = compile_to_code(src, &code, &err);
   if (log_out && log_cap) {
-    std::string log(n, '\0');
-    if (n) hiprtcGetProgramLog(prog, &log[0]);
-    size_t m = std::min<size_t>(log.size(), log_cap - 1);
-    std::memcpy(log_out, log.data(), m);
+    size_t m = std::min<size_t>(err.size(), log_cap - 1);
+    std::memcpy(log_out, err.data(), m);
     log_out[m] = 0;
   }
-  hiprtcDestroyProgram(&prog);
-  return r == HIPRTC_SUCCESS ? LLKV_OK : LLKV_INTERNAL;
+  return rc;
 }
 
 } // namespace llkv

@@ -318,19 +318,27 @@ struct Lowering {
   // Computed projection, fast numeric path: final type first, then every column cast to
   // it and every literal broadcast in it (llkv-compute/src/fast_numeric.rs:69-121).
   int expr_fast(const llkv_expr_token *e, uint32_t n, std::string *node, bool *is_f64) {
-    bool any_float = false;
+    bool any_float = false, any_u64 = false, any_other = false;
     for (uint32_t i = 0; i < n; ++i) {
       if (e[i].kind == LLKV_TOK_COLUMN) {
         const ColumnInfo *ci = resolve(e[i].field_id);
         if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(e[i].field_id) + " not found");
+        if (ci->dtype == LLKV_DT_UINT64) { any_u64 = true; continue; }
+        any_other = true;
         if (is_float_class(ci->dtype)) any_float = true;
         else if (!is_int_class(ci->dtype)) return fail(LLKV_UNSUPPORTED, std::string("computed projection over ") + dtype_name(ci->dtype));
       } else if (e[i].kind == LLKV_TOK_LITERAL) {
+        any_other = true;
         if (e[i].literal.tag == LLKV_LIT_FLOAT64) any_float = true;
         else if (e[i].literal.tag != LLKV_LIT_INT128) return fail(LLKV_UNSUPPORTED, "non-numeric literal in computed projection");
       } else if (e[i].kind == LLKV_TOK_BINARY) {
         if (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "division in computed projections (NULL on zero) is not on the GPU path");
       }
+    }
+    // get_common_type (llkv-compute/src/kernels.rs:179-242): a 64-bit unsigned side with a signed side → Float64
+    if (any_u64) {
+      if (n > 1 && !any_other) return fail(LLKV_UNSUPPORTED, "UInt64-only arithmetic");
+      if (n > 1) any_float = true;
     }
     std::vector<std::string> st;
     int rc;
@@ -341,7 +349,7 @@ struct Lowering {
         if ((rc = slot_of(e[i].field_id, &ci, &slot))) return rc;
         std::string c = col_node(slot, ci->dtype);
         if (any_float) { if (ci->dtype != LLKV_DT_FLOAT64) c = "ToF64<" + c + ">"; }
-        else if (ci->dtype != LLKV_DT_INT64) c = "ToI64<" + c + ">";
+        else if (ci->dtype != LLKV_DT_INT64 && ci->dtype != LLKV_DT_UINT64) c = "ToI64<" + c + ">";
         st.push_back(c);
       } else if (e[i].kind == LLKV_TOK_LITERAL) {
         std::string l;
@@ -573,6 +581,71 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
   ag += ">";
   p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_lds ? "1" : "0") + ">";
+  return LLKV_OK;
+}
+
+static std::string cols_string(const LoweredPlan &p, uint64_t *bytes) {
+  std::string cols = "Cols<";
+  uint64_t b = 0;
+  for (size_t i = 0; i < p.slot_dtypes.size(); ++i) {
+    cols += (i ? "," : "") + std::string(dtype_tag(p.slot_dtypes[i]));
+    b += dtype_width(p.slot_dtypes[i]);
+  }
+  if (bytes) *bytes = b;
+  return cols + ">";
+}
+
+int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
+                    const llkv_eval_op *ops, uint32_t n_ops, LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  Lowering L{resolve, *out, err, false};
+  std::string pred;
+  int rc = L.predicate(filters, n_filters, ops, n_ops, &pred);
+  if (rc) return rc;
+  out->always_false = pred == "False";
+  out->always_true = pred == "True";
+  out->type_string = "SelPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + ">";
+  return LLKV_OK;
+}
+
+int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,
+                     LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  Lowering L{resolve, *out, err, false};
+  if (n_projections == 0) return L.fail(LLKV_INVALID_ARGUMENT, "scan requires at least one projection");
+  if (n_projections > 8) return L.fail(LLKV_UNSUPPORTED, "more than 8 projections");
+  std::string outs = "Outs<";
+  int rc;
+  for (uint32_t i = 0; i < n_projections; ++i) {
+    const llkv_projection &pr = projections[i];
+    std::string node;
+    if (!pr.computed) {
+      const ColumnInfo *ci;
+      int slot;
+      if ((rc = L.slot_of(pr.field_id, &ci, &slot))) return rc;
+      if (dtype_width(ci->dtype) == 0) return L.fail(LLKV_UNSUPPORTED, std::string("projection of ") + dtype_name(ci->dtype));
+      node = L.col_node(slot, ci->dtype);
+      out->out_dtypes.push_back(ci->dtype);
+      out->out_fields.push_back((int32_t)pr.field_id);
+    } else {
+      bool is_f64 = false;
+      if (!pr.expr || pr.expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "computed projection without expression");
+      if (pr.expr_len == 1 && pr.expr[0].kind == LLKV_TOK_COLUMN) { // bare column written as an expression
+        const ColumnInfo *ci;
+        int slot;
+        if ((rc = L.slot_of(pr.expr[0].field_id, &ci, &slot))) return rc;
+        node = L.col_node(slot, ci->dtype);
+        out->out_dtypes.push_back(ci->dtype);
+        out->out_fields.push_back((int32_t)pr.expr[0].field_id);
+      } else {
+        if ((rc = L.expr_fast(pr.expr, pr.expr_len, &node, &is_f64))) return rc;
+        out->out_dtypes.push_back(is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64);
+        out->out_fields.push_back(-1);
+      }
+    }
+    outs += (i ? "," : "") + node;
+  }
+  out->type_string = "ProjPlan<" + cols_string(*out, &out->bytes_per_row) + "," + outs + ">>";
   return LLKV_OK;
 }
 

@@ -68,6 +68,9 @@ struct LoweredPlan {
   std::vector<AggOut> aggs;      // one per requested aggregate
   uint64_t bytes_per_row = 0;    // algorithmic bytes (value buffers, once)
   bool always_false = false;     // predicate folded to FALSE on the host
+  bool always_true = false;      // selection plans: predicate folded to TRUE
+  std::vector<int32_t> out_dtypes; // projection plans: storage dtype of each output
+  std::vector<int32_t> out_fields; // projection plans: source field of a passthrough column, else -1
 };
 
 // Lowers a plan.  `grouped` selects the GROUP BY argument semantics (PlanValue
@@ -78,6 +81,14 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
                const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first,
                LoweredPlan *out, std::string *err);
+
+// Predicate only → "SelPlan<Cols<…>,pred>" (selection-vector kernels, select.hip.h).
+int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
+                    const llkv_eval_op *ops, uint32_t n_ops, LoweredPlan *out, std::string *err);
+// Scan projections (ScanProjection::{Column,Computed}, llkv-scan/src/lib.rs:59-65) →
+// "ProjPlan<Cols<…>,Outs<…>>" (window gather + computed expressions).
+int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,
+                     LoweredPlan *out, std::string *err);
 
 // Typed literal cast used by leaf predicates (shared with the selection path).
 struct NativeLit {

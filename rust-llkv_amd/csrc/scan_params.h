@@ -43,6 +43,22 @@ struct ScanParams {
   double lit_f[kMaxLits];
   uint32_t key_stride[kMaxKeys];
   uint32_t n_tiles;
+  uint32_t sub_rows;          // selection kernels: rows per wave sub-tile (tile_rows / 4)
+  const uint64_t *aux_in;     // selection: exclusive offsets per (tile, wave)
+  uint64_t *aux_out;          // selection: logical row ids out
+  uint64_t *aux_out2;         // selection: device row indices out
+};
+
+constexpr int kMaxOuts = 8;
+// Arguments of project_kernel (gather + computed projections over a window of selected rows).
+struct ProjParams {
+  const void *col[kMaxCols];
+  const uint64_t *dev_rows; // window of device row indices
+  void *out[kMaxOuts];
+  uint32_t *error_flag;
+  int64_t lit_i[kMaxLits];
+  double lit_f[kMaxLits];
+  uint32_t n;
   uint32_t pad_;
 };
 

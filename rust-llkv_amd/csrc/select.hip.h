@@ -1,0 +1,126 @@
+// select.hip.h — selection-vector materialisation and window projection for the
+// non-aggregate consumers of the scan (StorageTable::scan_stream / filter_row_ids):
+//   predicate → row ids      replaces llkv-column-map/src/store/scan/filter.rs:937-955 + the
+//                            Roaring set algebra of llkv-scan/src/predicate.rs:87-186
+//   gather + computed exprs  replaces llkv-column-map/src/store/projection.rs:929-1352 and
+//                            llkv-compute/src/fast_numeric.rs:69-121 for one 65 536-row window
+// Same predicate / expression types as the fused scan (fused_scan.hip.h); wave ballot +
+// popcount prefix give every selected row its output slot, tiles and waves are ordered, so the
+// ids come out ascending without a sort.
+#pragma once
+
+#include "fused_scan.hip.h"
+
+namespace llkv {
+
+template <class CL, class PR> struct SelPlan {
+  using ColList = CL;
+  using Pred = PR;
+};
+
+// Each wave owns a contiguous quarter of the tile; a lane owns two consecutive rows per step.
+template <class P, bool WRITE> __device__ __forceinline__ void select_body(const ScanParams &p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t sub0 = wave * p.sub_rows;
+  const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
+  const uint64_t slot = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
+  uint64_t base = WRITE ? p.aux_in[slot] : 0;
+  uint64_t count = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t r = sub0; r < sub1; r += 128) {
+    Loaded ld;
+    const uint32_t row0 = r + lane * 2;
+    load_all<typename P::ColList>(p, td.dev_row + row0, ld);
+    bool f[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
+      f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+    }
+    const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
+    if constexpr (WRITE) {
+      const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
+      if (f[0]) { p.aux_out[pre] = td.logical_row + row0; p.aux_out2[pre] = td.dev_row + row0; }
+      if (f[1]) { p.aux_out[pre + (f[0] ? 1 : 0)] = td.logical_row + row0 + 1; p.aux_out2[pre + (f[0] ? 1 : 0)] = td.dev_row + row0 + 1; }
+      base += __popcll(b0) + __popcll(b1);
+    } else {
+      count += __popcll(b0) + __popcll(b1);
+    }
+  }
+  if constexpr (!WRITE) {
+    if (lane == 0) p.tile_partials[slot] = count;
+  }
+}
+
+// Exclusive scan of the per-(tile, wave) counts; one block, fixed order.  out[n] = total.
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint64_t *in, uint64_t *out, uint32_t n) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+  uint64_t s = 0;
+  for (uint32_t i = b; i < e; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis–Steele inclusive scan
+    const uint64_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = t ? part[t - 1] : 0;
+  for (uint32_t i = b; i < e; ++i) { out[i] = run; run += in[i]; }
+  if (t == 1023) out[n] = part[1023];
+}
+
+// ---- window projection ---------------------------------------------------------------
+template <class... Es> struct Outs { static constexpr int N = sizeof...(Es); };
+template <class CL, class OT> struct ProjPlan {
+  using ColList = CL;
+  using OutT = OT;
+};
+
+template <class Ty> __device__ __forceinline__ void load_one(const void *base, uint64_t row, uint32_t (&w)[4]) {
+  if constexpr (Ty::W == 8) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(static_cast<const char *>(base) + row * 8);
+    w[0] = v.x; w[1] = v.y;
+  } else if constexpr (Ty::W == 4) {
+    w[0] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(base) + row * 4);
+  } else {
+    w[0] = *reinterpret_cast<const uint8_t *>(static_cast<const char *>(base) + row);
+  }
+}
+template <class CL, int I = 0> __device__ __forceinline__ void gather_all(const ProjParams &p, uint64_t row, Loaded &ld) {
+  if constexpr (I < CL::N) {
+    load_one<typename ColAt<I, CL>::type>(p.col[I], row, ld.w[I]);
+    gather_all<CL, I + 1>(p, row, ld);
+  }
+}
+template <int I, class E0, class... Er> __device__ __forceinline__ void store_outs(const ProjParams &p, Ctx &c, uint32_t i) {
+  using T = typename E0::Type::T;
+  reinterpret_cast<T *>(p.out[I])[i] = E0::eval(c, 0);
+  if constexpr (sizeof...(Er) > 0) store_outs<I + 1, Er...>(p, c, i);
+}
+template <class OT> struct StoreOuts;
+template <class... Es> struct StoreOuts<Outs<Es...>> {
+  static __device__ __forceinline__ void run(const ProjParams &p, Ctx &c, uint32_t i) { store_outs<0, Es...>(p, c, i); }
+};
+
+// out_k[i] = E_k(row ids[i]): one selected row per thread; outputs are written coalesced.
+template <class P> __device__ __forceinline__ void project_body(const ProjParams &pp) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= pp.n) return;
+  // the expression types read literals through a ScanParams-shaped context
+  ScanParams sp;
+#pragma unroll
+  for (int k = 0; k < kMaxLits; ++k) { sp.lit_i[k] = pp.lit_i[k]; sp.lit_f[k] = pp.lit_f[k]; }
+  Loaded ld;
+  const uint64_t row = pp.dev_rows[i];
+  gather_all<typename P::ColList>(pp, row, ld);
+  Ctx c{sp, ld, 0u, row};
+  StoreOuts<typename P::OutT>::run(pp, c, i);
+  if (c.err) atomicOr(pp.error_flag, 1u);
+}
+
+} // namespace llkv

@@ -1,19 +1,210 @@
-// stream.cpp — StorageTable::scan_stream / filter_row_ids and TableJoinExt::join_stream
-// entry points (selection-vector materialisation, gather, hash join).
+// stream.cpp — StorageTable::scan_stream / filter_row_ids
+// (llkv-executor/src/types/storage.rs:20-50 → execute_scan llkv-scan/src/execute.rs:47-295):
+// predicate → selection vector (ballot + popcount prefix, ascending row ids) → 65 536-row
+// windows (execute.rs:31) → gather + computed projections on the device → pinned host
+// window → on_batch on the calling thread, in row-id order, never an empty batch.
 #include "engine.hpp"
+
+#include <cstring>
+#include <memory>
+
+namespace llkv {
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return set_error(LLKV_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+static constexpr uint32_t kRowStreamChunk = 65536; // ROW_STREAM_CHUNK_SIZE, llkv-scan/src/execute.rs:31
+static constexpr uint32_t kSelectTileRows = 8192;
+
+struct DeviceBuf {
+  void *p = nullptr;
+  ~DeviceBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return LLKV_OK; }
+};
+struct PinnedBuf {
+  void *p = nullptr;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  int alloc(size_t bytes) { HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault)); return LLKV_OK; }
+};
+
+int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                  uint32_t n_ops, Selection *sel) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (!t) return set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
+    auto it = t->cols.find(fid);
+    return it == t->cols.end() ? nullptr : &it->second.info;
+  };
+  LoweredPlan plan;
+  std::string err;
+  if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, &plan, &err))) return set_error(rc, err);
+  sel->n = 0;
+  if (plan.always_false || t->local_rows == 0) return LLKV_OK;
+  const TileSet *ts = nullptr;
+  if ((rc = get_tileset(*t, kSelectTileRows, &ts))) return rc;
+  JitKernel k;
+  if ((rc = jit_compile(JitKind::Select, plan.type_string, &k, &err))) return set_error(rc, err);
+
+  hipStream_t stream = g_ctx.stream;
+  const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
+  DeviceBuf counts, offsets;
+  if ((rc = counts.alloc((size_t)n_slots * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
+  ScanParams p;
+  std::memset(&p, 0, sizeof p);
+  for (size_t s = 0; s < plan.slot_fields.size(); ++s) p.col[s] = t->cols.at(plan.slot_fields[s]).d_values;
+  for (size_t i = 0; i < plan.lit_i.size(); ++i) p.lit_i[i] = plan.lit_i[i];
+  for (size_t i = 0; i < plan.lit_f.size(); ++i) p.lit_f[i] = plan.lit_f[i];
+  p.tiles = ts->d_tiles;
+  p.n_tiles = ts->n_tiles;
+  p.sub_rows = kSelectTileRows / (kBlock / 64);
+  p.tile_partials = (uint64_t *)counts.p;
+  if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &p, sizeof p, stream))) return rc;
+  HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, stream));
+  uint64_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  sel->n = total;
+  if (total == 0) return LLKV_OK;
+  HIP_TRY(hipMalloc((void **)&sel->d_ids, total * 8));
+  HIP_TRY(hipMalloc((void **)&sel->d_dev, total * 8));
+  p.aux_in = (const uint64_t *)offsets.p;
+  p.aux_out = sel->d_ids;
+  p.aux_out2 = sel->d_dev;
+  if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
+  HIP_TRY(hipStreamSynchronize(stream));
+  return LLKV_OK;
+}
+
+Selection::~Selection() {
+  if (d_ids) (void)hipFree(d_ids);
+  if (d_dev) (void)hipFree(d_dev);
+}
+
+} // namespace llkv
 
 using namespace llkv;
 
 extern "C" {
 
-llkv_status llkv_hip_scan_stream(const llkv_hip_table *, const llkv_projection *, uint32_t, const llkv_filter *, uint32_t,
-                                 const llkv_eval_op *, uint32_t, const llkv_scan_options *, llkv_on_batch, void *) {
-  return (llkv_status)set_error(LLKV_UNSUPPORTED, "scan_stream: selection-vector path not built yet");
+llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filter *filters, uint32_t n_filters,
+                                    const llkv_eval_op *ops, uint32_t n_ops, uint64_t **out_row_ids, uint64_t *out_len) {
+  if (!out_row_ids || !out_len) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL output");
+  Selection sel;
+  int rc = run_selection(reinterpret_cast<const Table *>(table), filters, n_filters, ops, n_ops, &sel);
+  if (rc) return (llkv_status)rc;
+  uint64_t *ids = (uint64_t *)std::malloc(sel.n ? sel.n * 8 : 8);
+  if (!ids) return (llkv_status)set_error(LLKV_INTERNAL, "out of memory");
+  if (sel.n && hipMemcpy(ids, sel.d_ids, sel.n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    std::free(ids);
+    return (llkv_status)set_error(LLKV_INTERNAL, "copy of row ids failed");
+  }
+  *out_row_ids = ids;
+  *out_len = sel.n;
+  return LLKV_OK;
 }
 
-llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *, const llkv_filter *, uint32_t, const llkv_eval_op *, uint32_t,
-                                    uint64_t **, uint64_t *) {
-  return (llkv_status)set_error(LLKV_UNSUPPORTED, "filter_row_ids: selection-vector path not built yet");
+llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_projection *projections, uint32_t n_projections,
+                                 const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                                 const llkv_scan_options *options, llkv_on_batch on_batch, void *user) {
+  const Table *t = reinterpret_cast<const Table *>(table);
+  int rc = ensure_device();
+  if (rc) return (llkv_status)rc;
+  if (!t || !on_batch) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
+    auto it = t->cols.find(fid);
+    return it == t->cols.end() ? nullptr : &it->second.info;
+  };
+  // projections are validated before any row is touched (execute_scan builds the output schema first,
+  // llkv-scan/src/execute.rs:66-186)
+  LoweredPlan proj;
+  std::string err;
+  if ((rc = lower_projection(resolve, projections, n_projections, &proj, &err))) return (llkv_status)set_error(rc, err);
+  Selection sel;
+  if ((rc = run_selection(t, filters, n_filters, ops, n_ops, &sel))) return (llkv_status)rc;
+  if (sel.n == 0) return LLKV_OK; // a filter that matches nothing yields no batch
+  JitKernel k;
+  if ((rc = jit_compile(JitKind::Project, proj.type_string, &k, &err))) return (llkv_status)set_error(rc, err);
+
+  hipStream_t stream = g_ctx.stream;
+  const uint32_t n_out = (uint32_t)proj.out_dtypes.size();
+  const bool with_ids = options && options->include_row_ids;
+  // two window buffers: while the host consumes window w, the device fills w + 1
+  struct Win {
+    DeviceBuf d[kMaxOuts];
+    PinnedBuf h[kMaxOuts], h_ids;
+    hipEvent_t done = nullptr;
+    uint32_t n = 0;
+    ~Win() { if (done) (void)hipEventDestroy(done); }
+  } win[2];
+  DeviceBuf d_err;
+  if ((rc = d_err.alloc(4))) return (llkv_status)rc;
+  if (hipMemsetAsync(d_err.p, 0, 4, stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "memset failed");
+  for (auto &w : win) {
+    for (uint32_t o = 0; o < n_out; ++o) {
+      const size_t bytes = (size_t)kRowStreamChunk * dtype_width(proj.out_dtypes[o]);
+      if ((rc = w.d[o].alloc(bytes)) || (rc = w.h[o].alloc(bytes))) return (llkv_status)rc;
+    }
+    if (with_ids && (rc = w.h_ids.alloc((size_t)kRowStreamChunk * 8))) return (llkv_status)rc;
+    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "event create failed");
+  }
+  ProjParams pp;
+  std::memset(&pp, 0, sizeof pp);
+  for (size_t s = 0; s < proj.slot_fields.size(); ++s) pp.col[s] = t->cols.at(proj.slot_fields[s]).d_values;
+  for (size_t i = 0; i < proj.lit_i.size(); ++i) pp.lit_i[i] = proj.lit_i[i];
+  for (size_t i = 0; i < proj.lit_f.size(); ++i) pp.lit_f[i] = proj.lit_f[i];
+  pp.error_flag = (uint32_t *)d_err.p;
+
+  auto enqueue = [&](uint64_t w0, Win &w) -> int {
+    w.n = (uint32_t)std::min<uint64_t>(kRowStreamChunk, sel.n - w0);
+    ProjParams q = pp;
+    q.dev_rows = sel.d_dev + w0;
+    q.n = w.n;
+    for (uint32_t o = 0; o < n_out; ++o) q.out[o] = w.d[o].p;
+    int r = jit_launch_raw(k.fn, (w.n + kBlock - 1) / kBlock, &q, sizeof q, stream);
+    if (r) return r;
+    for (uint32_t o = 0; o < n_out; ++o)
+      HIP_TRY(hipMemcpyAsync(w.h[o].p, w.d[o].p, (size_t)w.n * dtype_width(proj.out_dtypes[o]), hipMemcpyDeviceToHost, stream));
+    if (with_ids) HIP_TRY(hipMemcpyAsync(w.h_ids.p, sel.d_ids + w0, (size_t)w.n * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(w.done, stream));
+    return LLKV_OK;
+  };
+
+  // dictionaries of passthrough Utf8 columns
+  std::vector<std::vector<const char *>> dicts(n_out);
+  for (uint32_t o = 0; o < n_out; ++o)
+    if (proj.out_dtypes[o] == LLKV_DT_UTF8 && proj.out_fields[o] >= 0)
+      for (auto &s : t->cols.at((uint32_t)proj.out_fields[o]).info.dictionary) dicts[o].push_back(s.c_str());
+
+  int cur = 0;
+  if ((rc = enqueue(0, win[0]))) return (llkv_status)rc;
+  for (uint64_t w0 = 0; w0 < sel.n; w0 += kRowStreamChunk) {
+    const uint64_t next = w0 + kRowStreamChunk;
+    if (next < sel.n && (rc = enqueue(next, win[cur ^ 1]))) return (llkv_status)rc;
+    Win &w = win[cur];
+    if (hipEventSynchronize(w.done) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "window copy failed");
+    llkv_column_view cols[kMaxOuts];
+    for (uint32_t o = 0; o < n_out; ++o) {
+      cols[o].dtype = proj.out_dtypes[o];
+      cols[o].values = w.h[o].p;
+      cols[o].validity = nullptr; // staged columns carry no NULLs
+      cols[o].dictionary = dicts[o].empty() ? nullptr : dicts[o].data();
+    }
+    llkv_batch_view b;
+    b.num_rows = w.n;
+    b.num_columns = n_out;
+    b.columns = cols;
+    b.row_ids = with_ids ? (const uint64_t *)w.h_ids.p : nullptr;
+    on_batch(&b, user); // calling thread, ascending row-id order
+    cur ^= 1;
+  }
+  uint32_t errflag = 0;
+  if (hipMemcpy(&errflag, d_err.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "copy failed");
+  if (errflag) return (llkv_status)set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  return LLKV_OK;
 }
 
 llkv_status llkv_hip_join_stream(const llkv_hip_table *, const llkv_hip_table *, const llkv_join_key *, uint32_t,

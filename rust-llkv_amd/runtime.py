@@ -315,6 +315,52 @@ def groupby(table: HipTable, predicate, keys: Sequence[int], aggs: Sequence[Aggr
         q.close()
 
 
+def filter_row_ids(table: HipTable, predicate) -> np.ndarray:
+    """StorageTable::filter_row_ids (llkv-executor/src/types/storage.rs:34-37): ascending row ids."""
+    p = CPlan(predicate)
+    out, n = C.POINTER(C.c_uint64)(), C.c_uint64()
+    check(lib().llkv_hip_filter_row_ids(table.handle, p.filters, p.n_filters, p.ops, p.n_ops, C.byref(out), C.byref(n)))
+    res = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+    lib().llkv_hip_free(out)
+    return res
+
+
+def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False):
+    """StorageTable::scan_stream: returns the list of batches [(columns, row_ids)], each column a list of
+    Python values.  ``projections``: field ids (ScanProjection::Column) or ScalarExpr (::Computed)."""
+    keep: list = []
+    projs = (abi.CProjection * max(1, len(projections)))()
+    for i, pr in enumerate(projections):
+        if isinstance(pr, int):
+            projs[i].computed, projs[i].field_id = 0, pr
+        else:
+            arr = pr.to_c(keep)
+            projs[i].computed, projs[i].expr, projs[i].expr_len = 1, arr, len(pr.tokens)
+    p = CPlan(predicate)
+    opts = abi.CScanOptions(int(include_nulls), int(include_row_ids))
+    batches = []
+
+    def on_batch(bp, _user):
+        b = bp.contents
+        n = int(b.num_rows)
+        cols = []
+        for ci in range(b.num_columns):
+            c = b.columns[ci]
+            if c.dtype == abi.DT_UTF8:
+                codes = np.frombuffer(C.string_at(c.values, n), dtype=np.uint8)
+                cols.append([c.dictionary[int(k)].decode() for k in codes])
+            else:
+                npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
+                cols.append(np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt).tolist())
+        rids = np.frombuffer(C.string_at(b.row_ids, n * 8), dtype=np.uint64).tolist() if b.row_ids else None
+        batches.append((cols, rids))
+
+    cb = abi.ON_BATCH(on_batch)
+    check(lib().llkv_hip_scan_stream(table.handle, projs, C.c_uint32(len(projections)), p.filters, p.n_filters, p.ops, p.n_ops,
+                                     C.byref(opts), cb, None))
+    return batches
+
+
 def lower_plan(column_descs, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (), grouped: bool = False,
                plan_lib=None, order_by_keys: bool = False):
     """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError."""

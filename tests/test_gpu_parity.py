@@ -253,3 +253,52 @@ def test_full_size_properties_sf10(rt, abi, tpch, name):
             assert abs(r.values[3].value - (p * (1 - disc) * (1 + tax)).sum()) <= REL * p.sum()
             assert abs(r.values[4].value - d["l_quantity"][g].sum() / g.sum()) <= 1e-12 * 50
             assert abs(r.values[6].value - disc.sum() / g.sum()) <= REL
+
+
+TABLE = golden("table_scan.json")
+
+
+@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] == "base"], ids=lambda c: c["name"])
+def test_reference_table_scan_known_answers(rt, abi, case):
+    """The reference's filtered-scan / And / Or / Not / computed-projection tests (tests/golden/table_scan.json)
+    through llkv_hip_scan_stream.  (The include-nulls cases need NULL cells, which are not staged on the GPU.)"""
+    from conftest import build_predicate, build_expr
+    tdef = TABLE["tables"]["base"]
+    ht = rt.HipTable(1, [tdef["rows"]])
+    for c in tdef["columns"]:
+        dt = DTYPES[c["dtype"]]
+        ht.append_column(c["field_id"], dt, np.array(c["values"], dtype=abi.NUMPY_OF_DTYPE[dt]))
+    projections = [p if isinstance(p, int) else build_expr(abi, p) for p in case["project"]]
+    batches = rt.scan_stream(ht, projections, build_predicate(abi, case["predicate"]))
+    cols = [[] for _ in projections]
+    for bcols, _ in batches:
+        assert len(bcols[0]) > 0
+        for i, c in enumerate(bcols):
+            cols[i].extend(c)
+    assert cols == case["expect"]
+
+
+@pytest.mark.parametrize("chunks", [[7], [15, 16, 17], [8192, 100, 8192, 7], [131072, 131072, 50000]])
+def test_scan_stream_and_row_ids_match_oracle(rt, orc, abi, chunks):
+    """Selection vectors: ascending ids, 65 536-row windows, gather of every storage type, computed projections."""
+    rng = np.random.default_rng(len(chunks))
+    n = sum(chunks)
+    i64, f64, i32, big, s = random_columns(rng, n)
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64), (2, abi.DT_FLOAT64, f64), (3, abi.DT_INT32, i32), (5, abi.DT_UTF8, s)], chunks)
+    F, O, B, E, col = abi.Filter, abi.Operator, abi.Bound, abi.Expr, abi.col
+    preds = [None, [F(1, O.LessThan(0))], E.any_of([F(3, O.In([1, 2, 3])), E.not_(F(2, O.GreaterThan(-500.0)))]), [F(1, O.Equals(2**40))]]
+    for p in preds:
+        want_ids = orc.filter_row_ids(ot, p)
+        got_ids = rt.filter_row_ids(ht, p)
+        assert np.array_equal(got_ids, want_ids)
+        projs = [1, 2, 3, 5, col(2) * 2.0 + col(1), col(1) + col(3)]
+        got = rt.scan_stream(ht, projs, p, include_row_ids=True)
+        want = orc.scan_stream(ot, projs, p, include_nulls=True, include_row_ids=True)
+        assert [len(b[1]) for b in got] == [len(b[1]) for b in want]
+        assert all(len(b[1]) <= 65536 and len(b[1]) > 0 for b in got)
+        for (gc, gr), (wc, wr) in zip(got, want):
+            assert gr == wr
+            for a, b in zip(gc, wc):
+                assert len(a) == len(b)
+                for x, y in zip(a, b):
+                    assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (x, y)
