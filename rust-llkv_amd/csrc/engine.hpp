@@ -135,6 +135,9 @@ struct Selection {
 int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                   uint32_t n_ops, Selection *sel);
 
+int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
+             const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);
+
 void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state);
 int finalize_value(const AggOut &a, const uint64_t *group_lanes, int base, llkv_value *out, std::string *err);
 

@@ -1,0 +1,174 @@
+// join.cpp — TableJoinExt::join_stream (llkv-join/src/lib.rs:240-282) over two HBM table
+// images: validation as the reference's (`validate_join_options`), build on the RIGHT table
+// (hash_join.rs:209-215), probe the LEFT in scan order, pairs delivered in probe order × build
+// insertion order in batches that follow the reference's flush rule (a batch ends after the probe
+// row that brings it to ≥ batch_size pairs, and at the end of every probe window,
+// hash_join.rs:1181-1213).
+#include "engine.hpp"
+#include "join.hpp"
+
+#include <cstring>
+#include <vector>
+
+namespace llkv {
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return set_error(LLKV_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+namespace {
+struct DBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  ~DBuf() { if (p) (void)hipFree(p); }
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return LLKV_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
+    cap = bytes;
+    return LLKV_OK;
+  }
+};
+struct HBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  ~HBuf() { if (p) (void)hipHostFree(p); }
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return LLKV_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
+    cap = bytes;
+    return LLKV_OK;
+  }
+};
+
+constexpr uint32_t kJoinTileRows = 8192;
+constexpr uint32_t kWindowTiles = 8; // 65 536 probe rows per window = one reference probe batch
+
+int key_column(const Table *t, uint32_t field, JoinKeyColumn *out) {
+  auto it = t->cols.find(field);
+  if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "join key field " + std::to_string(field) + " not found");
+  const int32_t dt = it->second.info.dtype;
+  out->values = it->second.d_values;
+  switch (dt) {
+  case LLKV_DT_INT64: case LLKV_DT_UINT64: out->width = 8; out->is_signed = 1; return LLKV_OK;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: out->width = 4; out->is_signed = 1; return LLKV_OK;
+  case LLKV_DT_UINT32: out->width = 4; out->is_signed = 0; return LLKV_OK;
+  default: return set_error(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(dt) + " (integer fast path only)");
+  }
+}
+} // namespace
+
+int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
+             const llkv_join_options *options, llkv_on_join_batch on_batch, void *user) {
+  const uint64_t batch_size = options ? options->batch_size : 8192;
+  const int jt = options ? options->join_type : LLKV_JOIN_INNER;
+  // validate_join_options llkv-join/src/lib.rs:284-310, hash_join.rs:328-332
+  if (batch_size == 0) return set_error(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero");
+  if (jt == LLKV_JOIN_RIGHT || jt == LLKV_JOIN_FULL) return set_error(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented");
+  if (jt != LLKV_JOIN_INNER && jt != LLKV_JOIN_LEFT && jt != LLKV_JOIN_SEMI && jt != LLKV_JOIN_ANTI) return set_error(LLKV_INVALID_ARGUMENT, "unknown join type");
+  int rc = ensure_device();
+  if (rc) return rc;
+  if (!left || !right || !on_batch) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (n_keys != 1) return set_error(LLKV_UNSUPPORTED, "GPU join path takes exactly one integer key pair (cross products and composite keys stay on the CPU route)");
+  JoinKeyColumn lk, rk;
+  if ((rc = key_column(left, keys[0].left_field, &lk)) || (rc = key_column(right, keys[0].right_field, &rk))) return rc;
+
+  hipStream_t s = g_ctx.stream;
+  const TileSet *tr = nullptr, *tl = nullptr;
+  if ((rc = get_tileset(*right, kJoinTileRows, &tr)) || (rc = get_tileset(*left, kJoinTileRows, &tl))) return rc;
+
+  // ---- build (right) ----
+  const uint64_t n_build = right->local_rows;
+  if (n_build >= (1ull << 31)) return set_error(LLKV_UNSUPPORTED, "build side larger than 2^31 rows");
+  uint64_t cap = 1024;
+  uint32_t bits = 10;
+  while (cap < 2 * n_build) { cap <<= 1; ++bits; }
+  DBuf owner, slot_of, dev_of, log_of, seg_start, seg_count, idx_in, slot_sorted, idx_sorted, tile_base, tmp;
+  if ((rc = owner.ensure(cap * 8)) || (rc = seg_start.ensure(cap * 4)) || (rc = seg_count.ensure(cap * 4)) ||
+      (rc = slot_of.ensure(n_build * 4)) || (rc = dev_of.ensure(n_build * 8)) || (rc = log_of.ensure(n_build * 8)) ||
+      (rc = idx_in.ensure(n_build * 4)) || (rc = slot_sorted.ensure(n_build * 4)) || (rc = idx_sorted.ensure(n_build * 4)) ||
+      (rc = tile_base.ensure((size_t)(tr->n_tiles + 1) * 8)))
+    return rc;
+  HIP_TRY(hipMemsetAsync(owner.p, 0xFF, cap * 8, s));
+  HIP_TRY(hipMemsetAsync(seg_count.p, 0, cap * 4, s));
+  if (n_build) {
+    std::vector<TileDesc> tiles;
+    uint32_t otb[kOctantsHost + 1];
+    build_tiles_host(*right, kJoinTileRows, tiles, otb);
+    std::vector<uint64_t> base(tiles.size() + 1, 0);
+    for (size_t i = 0; i < tiles.size(); ++i) base[i + 1] = base[i] + tiles[i].rows;
+    HIP_TRY(hipMemcpyAsync(tile_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // `base` is pageable host memory
+    HIP_TRY(hj_launch_claim(rk, tr->d_tiles, tr->n_tiles, kJoinTileRows, (unsigned long long *)owner.p, cap - 1, (uint32_t *)slot_of.p,
+                            (uint64_t *)dev_of.p, (uint64_t *)log_of.p, (const uint64_t *)tile_base.p, s));
+    HIP_TRY(hj_launch_iota((uint32_t *)idx_in.p, (uint32_t)n_build, s));
+    size_t tmp_bytes = 0;
+    HIP_TRY(hj_sort_by_slot(nullptr, &tmp_bytes, (const uint32_t *)slot_of.p, (uint32_t *)slot_sorted.p, (const uint32_t *)idx_in.p,
+                            (uint32_t *)idx_sorted.p, (uint32_t)n_build, bits, s));
+    if ((rc = tmp.ensure(tmp_bytes))) return rc;
+    HIP_TRY(hj_sort_by_slot(tmp.p, &tmp_bytes, (const uint32_t *)slot_of.p, (uint32_t *)slot_sorted.p, (const uint32_t *)idx_in.p,
+                            (uint32_t *)idx_sorted.p, (uint32_t)n_build, bits, s));
+    HIP_TRY(hj_launch_segments((const uint32_t *)slot_sorted.p, (uint32_t)n_build, (uint32_t *)seg_start.p, (uint32_t *)seg_count.p, s));
+  }
+
+  // ---- probe (left), window by window ----
+  const uint32_t win_pos = kWindowTiles * kJoinTileRows;
+  DBuf counts, mslot, offsets, out_l, out_r;
+  HBuf h_l, h_r, h_off;
+  if ((rc = counts.ensure((size_t)win_pos * 8)) || (rc = mslot.ensure((size_t)win_pos * 4)) || (rc = offsets.ensure((size_t)(win_pos + 1) * 8)) ||
+      (rc = h_off.ensure((size_t)(win_pos + 1) * 8)))
+    return rc;
+  const bool left_only = jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI;
+  for (uint32_t t0 = 0; t0 < tl->n_tiles; t0 += kWindowTiles) {
+    const uint32_t nt = std::min(kWindowTiles, tl->n_tiles - t0);
+    const uint32_t npos = nt * kJoinTileRows;
+    ProbeParams p;
+    std::memset(&p, 0, sizeof p);
+    p.lkey = lk; p.rkey = rk;
+    p.tiles = tl->d_tiles + t0; p.n_tiles = nt; p.tile_rows = kJoinTileRows;
+    p.slot_owner = (const unsigned long long *)owner.p; p.cap_mask = cap - 1;
+    p.seg_start = (const uint32_t *)seg_start.p; p.seg_count = (const uint32_t *)seg_count.p;
+    p.sorted_idx = (const uint32_t *)idx_sorted.p; p.build_logical = (const uint64_t *)log_of.p;
+    p.join_type = jt;
+    p.counts = (uint64_t *)counts.p; p.match_slot = (uint32_t *)mslot.p;
+    HIP_TRY(hj_launch_probe_count(p, s));
+    HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, npos, s));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + npos, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (total == 0) continue;
+    if ((rc = out_l.ensure(total * 8)) || (rc = out_r.ensure(total * 8)) || (rc = h_l.ensure(total * 8)) || (rc = h_r.ensure(total * 8))) return rc;
+    p.offsets = (const uint64_t *)offsets.p;
+    p.out_left = (uint64_t *)out_l.p; p.out_right = (uint64_t *)out_r.p;
+    HIP_TRY(hj_launch_probe_write(p, s));
+    HIP_TRY(hipMemcpyAsync(h_l.p, out_l.p, total * 8, hipMemcpyDeviceToHost, s));
+    if (!left_only) HIP_TRY(hipMemcpyAsync(h_r.p, out_r.p, total * 8, hipMemcpyDeviceToHost, s));
+    const bool need_split = total >= batch_size;
+    if (need_split) HIP_TRY(hipMemcpyAsync(h_off.p, offsets.p, (size_t)(npos + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t *hl = (const uint64_t *)h_l.p, *hr = left_only ? nullptr : (const uint64_t *)h_r.p;
+    if (!need_split) {
+      on_batch(hl, hr, total, user);
+    } else {
+      // flush after the probe row that brings the batch to ≥ batch_size pairs (hash_join.rs:1181-1193)
+      const uint64_t *off = (const uint64_t *)h_off.p;
+      uint64_t start = 0;
+      for (uint32_t i = 0; i < npos; ++i) {
+        const uint64_t end = off[i + 1];
+        if (end - start >= batch_size) {
+          on_batch(hl + start, hr ? hr + start : nullptr, end - start, user);
+          start = end;
+        }
+      }
+      if (total > start) on_batch(hl + start, hr ? hr + start : nullptr, total - start, user);
+    }
+  }
+  return LLKV_OK;
+}
+
+} // namespace llkv

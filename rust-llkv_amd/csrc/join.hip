@@ -1,0 +1,161 @@
+// join.hip — integer-key hash join kernels for gfx950 (llkv-join/src/hash_join.rs:955-1417 and the
+// executor's build_join_match_indices llkv-executor/src/lib.rs:12458-12581 restated for the GPU).
+//
+// Build = right table.  Distinct keys claim slots of an open-addressing table in HBM with one
+// 64-bit CAS per contended slot (the slot stores the claiming ROW, keys are compared through the key
+// column, so any i64 is a legal key); a stable radix sort of (slot, row) then lays the rows of every key
+// out contiguously in insertion order — the order the reference's Vec<RowRef> has.  Probe = left table in
+// scan order: count → exclusive scan → write, so output pairs are in probe order × build insertion
+// order, deterministically.  Hash probing is latency/atomics bound, not HBM-bandwidth bound.
+#include "join.hpp"
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+namespace llkv {
+
+__device__ __forceinline__ long long load_key(const JoinKeyColumn &k, uint64_t row) {
+  if (k.width == 8) return reinterpret_cast<const long long *>(k.values)[row];
+  const uint32_t v = reinterpret_cast<const uint32_t *>(k.values)[row];
+  return k.is_signed ? (long long)(int32_t)v : (long long)v;
+}
+
+__device__ __forceinline__ uint64_t hash_key(long long k) {
+  uint64_t x = (uint64_t)k;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
+constexpr unsigned long long kEmpty = ~0ull;
+
+__global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeyColumn key, const TileDesc *tiles, uint32_t tile_rows,
+                                                        unsigned long long *slot_owner, uint64_t cap_mask,
+                                                        uint32_t *slot_of, uint64_t *dev_row_of, uint64_t *logical_of,
+                                                        const uint64_t *tile_compact_base) {
+  const TileDesc td = tiles[blockIdx.x];
+  const uint64_t cbase = tile_compact_base[blockIdx.x];
+  for (uint32_t r = threadIdx.x; r < td.rows; r += blockDim.x) {
+    const uint64_t drow = td.dev_row + r;
+    const uint64_t ci = cbase + r; // compact build index (dense over real rows)
+    dev_row_of[ci] = drow;
+    logical_of[ci] = td.logical_row + r;
+    const long long k = load_key(key, drow);
+    uint64_t s = hash_key(k) & cap_mask;
+    for (;;) {
+      unsigned long long owner = slot_owner[s];
+      if (owner == kEmpty) {
+        const unsigned long long prev = atomicCAS(&slot_owner[s], kEmpty, (unsigned long long)drow);
+        owner = prev == kEmpty ? (unsigned long long)drow : prev;
+      }
+      if (owner == (unsigned long long)drow || load_key(key, owner) == k) break;
+      s = (s + 1) & cap_mask;
+    }
+    slot_of[ci] = (uint32_t)s;
+  }
+  (void)tile_rows;
+}
+
+hipError_t hj_launch_claim(const JoinKeyColumn &key, const TileDesc *tiles, uint32_t n_tiles, uint32_t tile_rows,
+                           unsigned long long *slot_owner, uint64_t cap_mask, uint32_t *slot_of_row,
+                           uint64_t *dev_row_of, uint64_t *logical_of, const uint64_t *tile_compact_base, hipStream_t s) {
+  if (n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_claim_kernel, dim3(n_tiles), dim3(256), 0, s, key, tiles, tile_rows, slot_owner, cap_mask,
+                     slot_of_row, dev_row_of, logical_of, tile_compact_base);
+  return hipGetLastError();
+}
+
+hipError_t hj_sort_by_slot(void *tmp, size_t *tmp_bytes, const uint32_t *slot_in, uint32_t *slot_out,
+                           const uint32_t *idx_in, uint32_t *idx_out, uint32_t n, uint32_t slot_bits, hipStream_t s) {
+  return rocprim::radix_sort_pairs(tmp, *tmp_bytes, slot_in, slot_out, idx_in, idx_out, (size_t)n, 0u, slot_bits, s);
+}
+
+__global__ __launch_bounds__(256) void hj_segments_kernel(const uint32_t *sorted_slot, uint32_t n, uint32_t *seg_start, uint32_t *seg_count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = sorted_slot[i];
+  if (i == 0 || sorted_slot[i - 1] != s) {
+    seg_start[s] = i;
+    uint32_t j = i + 1; // segments are short (duplicates per key); the tail walk is bounded by the run
+    while (j < n && sorted_slot[j] == s) ++j;
+    seg_count[s] = j - i;
+  }
+}
+hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t *seg_start, uint32_t *seg_count, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sorted_slot, n, seg_start, seg_count);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n);
+  return hipGetLastError();
+}
+
+// JOIN types: 0 inner, 1 left, 4 semi, 5 anti (include/llkv_hip.h)
+__global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  for (uint32_t r = threadIdx.x; r < p.tile_rows; r += blockDim.x) {
+    const uint64_t pos = (uint64_t)blockIdx.x * p.tile_rows + r;
+    uint64_t cnt = 0;
+    uint32_t mslot = 0xFFFFFFFFu;
+    if (r < td.rows) {
+      const long long k = load_key(p.lkey, td.dev_row + r);
+      uint64_t s = hash_key(k) & p.cap_mask;
+      for (;;) {
+        const unsigned long long owner = p.slot_owner[s];
+        if (owner == kEmpty) break;
+        if (load_key(p.rkey, owner) == k) { mslot = (uint32_t)s; break; }
+        s = (s + 1) & p.cap_mask;
+      }
+      const uint64_t m = mslot != 0xFFFFFFFFu ? p.seg_count[mslot] : 0;
+      switch (p.join_type) {
+      case 0: cnt = m; break;
+      case 1: cnt = m ? m : 1; break;
+      case 4: cnt = m ? 1 : 0; break;
+      default: cnt = m ? 0 : 1; break;
+      }
+    }
+    p.counts[pos] = cnt;
+    p.match_slot[pos] = mslot;
+  }
+}
+hipError_t hj_launch_probe_count(const ProbeParams &p, hipStream_t s) {
+  if (p.n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_probe_count_kernel, dim3(p.n_tiles), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_probe_write_kernel(ProbeParams p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  for (uint32_t r = threadIdx.x; r < td.rows; r += blockDim.x) {
+    const uint64_t pos = (uint64_t)blockIdx.x * p.tile_rows + r;
+    const uint64_t cnt = p.counts[pos];
+    if (cnt == 0) continue;
+    uint64_t o = p.offsets[pos];
+    const uint64_t lrow = td.logical_row + r;
+    const uint32_t ms = p.match_slot[pos];
+    if (p.join_type == 0 || (p.join_type == 1 && ms != 0xFFFFFFFFu)) {
+      const uint32_t st = p.seg_start[ms];
+      for (uint64_t i = 0; i < cnt; ++i) {
+        p.out_left[o + i] = lrow;
+        p.out_right[o + i] = p.build_logical[p.sorted_idx[st + i]];
+      }
+    } else {
+      p.out_left[o] = lrow;
+      p.out_right[o] = ~0ull; // LEFT: NULL-padded right side; SEMI/ANTI: unused
+    }
+  }
+}
+hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s) {
+  if (p.n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_probe_write_kernel, dim3(p.n_tiles), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+} // namespace llkv

@@ -1,0 +1,51 @@
+// join.hpp — device entry points of the integer-key hash join (join.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "scan_params.h"
+
+#include <cstdint>
+
+namespace llkv {
+
+struct JoinKeyColumn {
+  const void *values; // device column image
+  uint32_t width;     // 4 or 8 bytes
+  uint32_t is_signed; // sign-extend 4-byte keys
+};
+
+// Build side: distinct keys claim slots of an open-addressing table (slot_owner = row that owns the slot,
+// UINT64_MAX = empty); every build row records its slot.  All arrays are device memory.
+hipError_t hj_launch_claim(const JoinKeyColumn &key, const TileDesc *tiles, uint32_t n_tiles, uint32_t tile_rows,
+                           unsigned long long *slot_owner, uint64_t cap_mask, uint32_t *slot_of_row /*[dev rows]*/,
+                           uint64_t *dev_row_of /*[n_build]: compact index → device row*/,
+                           uint64_t *logical_of /*[n_build]*/, const uint64_t *tile_compact_base, hipStream_t s);
+// Stable sort of (slot, compact build index) pairs by slot → build rows of one key are contiguous and in
+// insertion (row) order.  Returns the rocPRIM status; *tmp_bytes is queried when tmp == nullptr.
+hipError_t hj_sort_by_slot(void *tmp, size_t *tmp_bytes, const uint32_t *slot_in, uint32_t *slot_out,
+                           const uint32_t *idx_in, uint32_t *idx_out, uint32_t n, uint32_t slot_bits, hipStream_t s);
+// seg_start[slot] / seg_count[slot] from the sorted slot list.
+hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t *seg_start, uint32_t *seg_count, hipStream_t s);
+// identity index 0..n-1
+hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
+
+struct ProbeParams {
+  JoinKeyColumn lkey, rkey;
+  const TileDesc *tiles; // probe-side tiles of this window
+  uint32_t n_tiles, tile_rows;
+  const unsigned long long *slot_owner;
+  uint64_t cap_mask;
+  const uint32_t *seg_start, *seg_count; // per slot
+  const uint32_t *sorted_idx;            // compact build indices grouped by slot, insertion order
+  const uint64_t *build_logical;         // compact build index → logical row id
+  int32_t join_type;                     // llkv_join_type
+  uint64_t *counts;                      // [n_tiles * tile_rows] pairs emitted per probe position
+  uint32_t *match_slot;                  // [n_tiles * tile_rows] matching slot or UINT32_MAX
+  const uint64_t *offsets;               // exclusive scan of counts
+  uint64_t *out_left, *out_right;        // pair output
+};
+hipError_t hj_launch_probe_count(const ProbeParams &p, hipStream_t s);
+hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s);
+
+} // namespace llkv

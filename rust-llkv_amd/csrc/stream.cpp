@@ -207,9 +207,9 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   return LLKV_OK;
 }
 
-llkv_status llkv_hip_join_stream(const llkv_hip_table *, const llkv_hip_table *, const llkv_join_key *, uint32_t,
-                                 const llkv_join_options *, llkv_on_join_batch, void *) {
-  return (llkv_status)set_error(LLKV_UNSUPPORTED, "join_stream: hash join path not built yet");
+llkv_status llkv_hip_join_stream(const llkv_hip_table *left, const llkv_hip_table *right, const llkv_join_key *keys,
+                                 uint32_t n_keys, const llkv_join_options *options, llkv_on_join_batch on_batch, void *user) {
+  return (llkv_status)run_join(reinterpret_cast<const Table *>(left), reinterpret_cast<const Table *>(right), keys, n_keys, options, on_batch, user);
 }
 
 } // extern "C"

@@ -361,6 +361,26 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
     return batches
 
 
+def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN_INNER, batch_size: int = 8192):
+    """TableJoinExt::join_stream (llkv-join/src/lib.rs:240-282): list of batches (left_rows, right_rows|None);
+    a right row of 2**64-1 is the NULL padding of a LEFT join."""
+    ck = (abi.CJoinKey * max(1, len(keys)))()
+    for i, k in enumerate(keys):
+        ck[i].left_field, ck[i].right_field = k[0], k[1]
+        ck[i].null_equals_null = int(k[2]) if len(k) > 2 else 0
+    opts = abi.CJoinOptions(join_type, batch_size)
+    batches = []
+
+    def on_batch(pl, pr, n, _u):
+        l = np.ctypeslib.as_array(pl, shape=(n,)).tolist()
+        r = np.ctypeslib.as_array(pr, shape=(n,)).tolist() if pr else None
+        batches.append((l, r))
+
+    cb = abi.ON_JOIN_BATCH(on_batch)
+    check(lib().llkv_hip_join_stream(left.handle, right.handle, ck, C.c_uint32(len(keys)), C.byref(opts), cb, None))
+    return batches
+
+
 def lower_plan(column_descs, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (), grouped: bool = False,
                plan_lib=None, order_by_keys: bool = False):
     """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError."""

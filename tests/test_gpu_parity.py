@@ -302,3 +302,65 @@ def test_scan_stream_and_row_ids_match_oracle(rt, orc, abi, chunks):
                 assert len(a) == len(b)
                 for x, y in zip(a, b):
                     assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (x, y)
+
+
+JOINS = golden("joins.json")
+JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
+
+
+def _join_side(rt, abi, rows):
+    t = rt.HipTable(1, [len(rows)])
+    t.append_column(1, abi.DT_INT32, np.array([r[0] for r in rows], dtype=np.int32))
+    t.append_utf8_column(2, [r[1] for r in rows])
+    return t
+
+
+@pytest.mark.parametrize("case", JOINS["cases"], ids=lambda c: c["name"])
+def test_reference_join_known_answers(rt, abi, case):
+    """llkv-join/tests/join_tests.rs through llkv_hip_join_stream."""
+    left, right = _join_side(rt, abi, case["left"]), _join_side(rt, abi, case["right"])
+    if "expect_error" in case:
+        with pytest.raises(abi.LlkvError) as e:
+            rt.join_stream(left, right, [(1, 1)], JT[case["type"]], case.get("batch_size", 8192))
+        assert e.value.kind == case["expect_error"]
+        return
+    batches = rt.join_stream(left, right, [(1, 1)], JT[case["type"]], case.get("batch_size", 8192))
+    ls = [x for b in batches for x in b[0]]
+    assert len(ls) == case["expect_rows"]
+    if "expect_pairs" in case:
+        rs = [x for b in batches for x in b[1]]
+        assert [[l, None if r == 2**64 - 1 else r] for l, r in zip(ls, rs)] == case["expect_pairs"]
+    if "expect_left" in case:
+        assert ls == case["expect_left"] and all(b[1] is None for b in batches)
+
+
+def test_right_and_full_joins_are_rejected_like_the_reference(rt, abi):
+    left, right = _join_side(rt, abi, [[1, "a"]]), _join_side(rt, abi, [[1, "b"]])
+    for jt in (abi.JOIN_RIGHT, abi.JOIN_FULL):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.join_stream(left, right, [(1, 1)], jt)
+        assert e.value.kind == "InvalidArgumentError"
+
+
+@pytest.mark.parametrize("n_left,n_right,keyspace,batch", [(1000, 300, 50, 8192), (200_000, 50_000, 40_000, 8192), (70_000, 10, 3, 1000), (5, 100_000, 1000, 7)])
+@pytest.mark.parametrize("jt", ["inner", "left", "semi", "anti"])
+def test_random_joins_match_oracle(rt, orc, abi, n_left, n_right, keyspace, batch, jt):
+    """Many-to-many duplicates, skew, misses: pair SEQUENCE identical to the reference order (probe order ×
+    build insertion order); batch boundaries follow the flush rule within each 65 536-row probe window."""
+    rng = np.random.default_rng(n_left + n_right)
+    lk = rng.integers(-keyspace, keyspace, size=n_left).astype(np.int64)
+    rk = rng.integers(-keyspace // 2, keyspace * 2, size=n_right).astype(np.int64)
+    lt = rt.HipTable(1, [n_left]); lt.append_column(1, abi.DT_INT64, lk)
+    rtab = rt.HipTable(2, [n_right]); rtab.append_column(7, abi.DT_INT64, rk)
+    ol = orc.OracleTable(n_left).add(1, abi.DT_INT64, lk)
+    orr = orc.OracleTable(n_right).add(7, abi.DT_INT64, rk)
+    got = rt.join_stream(lt, rtab, [(1, 7)], JT[jt], batch)
+    want = orc.hash_join(ol, orr, [(1, 7)], JT[jt], batch)
+    gl = [x for b in got for x in b[0]]; wl = [x for b in want for x in b[0]]
+    assert gl == wl
+    if jt in ("inner", "left"):
+        assert [x for b in got for x in b[1]] == [x for b in want for x in b[1]]
+    else:
+        assert all(b[1] is None for b in got)
+    if n_left <= 65536:  # a single probe window: batch boundaries are the reference's exactly
+        assert [len(b[0]) for b in got] == [len(b[0]) for b in want]
