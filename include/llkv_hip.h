@@ -406,6 +406,39 @@ llkv_status llkv_hip_join_stream(const llkv_hip_table *left, const llkv_hip_tabl
                                  void *user);
 
 /* ------------------------------------------------------------------------- */
+/* Join → GROUP BY → ORDER BY … LIMIT for the TPC-H Q3 shape — the executor's   */
+/* multi-table route: try_execute_hash_join llkv-executor/src/lib.rs:3780-4052, */
+/* hash_join_table_batches :12218-12392, post-join filter mask :1629-1646,      */
+/* execute_group_by_from_batches, sort_record_batch_with_order :13762-13868,    */
+/* LIMIT :10925-10955.                                                          */
+/*   fact ⋈ dim [⋉ dim2]  GROUP BY dim.key, payload…   SUM(fact expr)           */
+/*   ORDER BY sum DESC, payload[0] ASC   LIMIT k                                */
+/* dim.key must be unique (a primary key); groups are then identified by the    */
+/* dim row.  Sums add the fact rows of a group in scan order, like the          */
+/* reference, so they are bit-exact with it.                                    */
+/* ------------------------------------------------------------------------- */
+typedef struct llkv_join_side {
+  const llkv_hip_table *table;
+  const llkv_filter *filters; /* conjunction (Expr::all_of)                      */
+  uint32_t n_filters;
+  uint32_t key_field;         /* integer join key                                */
+} llkv_join_side;
+
+typedef struct llkv_join_group_row {
+  int64_t key;        /* dim key (= fact key) of the group                       */
+  double sum;
+  uint64_t count;     /* fact rows in the group                                  */
+  int64_t payload[4]; /* dim payload columns (integers / Date32)                 */
+} llkv_join_group_row;
+
+llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
+                                       uint32_t dim_fk_field, const llkv_join_side *dim2 /* may be NULL */,
+                                       const uint32_t *payload_fields, uint32_t n_payload,
+                                       const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
+                                       uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n,
+                                       uint64_t *out_total_groups);
+
+/* ------------------------------------------------------------------------- */
 /* Multi-GPU combine, host pieces (no device needed).  The chunk list is cut    */
 /* into 8 canonical octants (boundaries floor(j·C/8)); rank r of `world` owns   */
 /* octants [r·8/world, (r+1)·8/world).  Partial aggregate state is exchanged    */

@@ -97,6 +97,14 @@ class CColumnDesc(C.Structure):
                 ("dictionary", C.POINTER(C.c_char_p))]
 
 
+class CJoinSide(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("filters", C.POINTER(CFilter)), ("n_filters", C.c_uint32), ("key_field", C.c_uint32)]
+
+
+class CJoinGroupRow(C.Structure):
+    _fields_ = [("key", C.c_int64), ("sum", C.c_double), ("count", C.c_uint64), ("payload", C.c_int64 * 4)]
+
+
 ON_BATCH = C.CFUNCTYPE(None, C.POINTER(CBatchView), C.c_void_p)
 ON_JOIN_BATCH = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p)
 

@@ -206,9 +206,10 @@ static uint32_t pick_tile_rows(const LoweredPlan &p) {
     long v = std::atol(e);
     if (v >= 512 && v % 512 == 0) return (uint32_t)v;
   }
-  // small states amortise their block reduction quickly; wide (grouped) states want longer
-  // tiles.  Depends on the plan only, never on the GPU count (bit-reproducibility).
-  return p.lanes <= 8 ? 8192u : 32768u;
+  // narrow register states amortise their block reduction quickly and like many small tiles;
+  // LDS-resident grouped states (2 workgroups/CU) want long tiles (sweep: profiles/r01/).
+  // Depends on the plan only, never on the GPU count (bit-reproducibility).
+  return p.acc_lds ? 65536u : 8192u;
 }
 
 int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
@@ -231,7 +232,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   const LoweredPlan &p = q->plan;
 
   if (!p.always_false) {
-    q->entry = catalog_find(p.type_string.c_str());
+    q->entry = std::getenv("LLKV_HIP_FORCE_JIT") ? nullptr : catalog_find(p.type_string.c_str());
     if (!q->entry) {
       rc = jit_compile(JitKind::Scan, p.type_string, &q->jit, &err);
       if (rc) return set_error(rc, err);

@@ -66,7 +66,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
-enum class JitKind : int { Scan = 0, Select = 1, Project = 2 };
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3 };
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // scan / select-count / project

@@ -22,7 +22,7 @@ namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
 
-const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : "project"; }
+const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : "probe"; }
 
 std::string wrapper_source(JitKind kind, const std::string &ts) {
   std::string s = "\nusing namespace llkv;\n";
@@ -36,6 +36,10 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     break;
   case JitKind::Project:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ProjParams p) { project_body<" + ts + ">(p); }\n";
+    break;
+  case JitKind::Probe:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { probe_emit_body<" + ts + ", false>(p); }\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_b(const ScanParams p) { probe_emit_body<" + ts + ", true>(p); }\n";
     break;
   }
   return s;
@@ -59,8 +63,17 @@ int compile_to_code(const std::string &src, std::vector<char> *code, std::string
     *err = "hiprtcCreateProgram failed";
     return LLKV_INTERNAL;
   }
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-  hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+  std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  std::string extra = std::getenv("LLKV_HIP_JIT_DEFINES") ? std::getenv("LLKV_HIP_JIT_DEFINES") : ""; // e.g. "-DLLKV_NT_LOADS=1"
+  std::vector<std::string> extra_opts;
+  for (size_t b = 0; b < extra.size();) {
+    size_t e = extra.find(' ', b);
+    if (e == std::string::npos) e = extra.size();
+    if (e > b) extra_opts.push_back(extra.substr(b, e - b));
+    b = e + 1;
+  }
+  for (auto &o : extra_opts) opts.push_back(o.c_str());
+  hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
@@ -85,7 +98,8 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) { *out = it->second; return LLKV_OK; }
 
-  const std::string src = std::string(kFusedScanSource) + wrapper_source(kind, type_string);
+  const std::string src = std::string(kFusedScanSource) + wrapper_source(kind, type_string) +
+                          (std::getenv("LLKV_HIP_JIT_DEFINES") ? std::string("\n// ") + std::getenv("LLKV_HIP_JIT_DEFINES") + "\n" : std::string());
   char hex[32];
   std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src));
   const std::string dir = cache_dir(), path = dir + "/" + hex + ".hsaco";
@@ -107,7 +121,7 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
   e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_a");
   if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  if (kind == JitKind::Select) {
+  if (kind == JitKind::Select || kind == JitKind::Probe) {
     e = hipModuleGetFunction(&k.fn2, k.module, "llkv_jit_b");
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
   }
@@ -142,6 +156,7 @@ extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out,
   std::string ts = type_string;
   if (ts.rfind("SelPlan<", 0) == 0) kind = 1;
   else if (ts.rfind("ProjPlan<", 0) == 0) kind = 2;
+  else if (ts.rfind("ProbePlan<", 0) == 0) kind = 3;
   const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
   std::vector<char> code;
   std::string err;

@@ -158,4 +158,106 @@ hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- join → GROUP BY → top-k pipeline pieces -----------------------------------------------
+__global__ __launch_bounds__(256) void hj_claim_list_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n,
+                                                             unsigned long long *slot_owner, uint64_t cap_mask, uint32_t *dup_flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long drow = dev_rows[i];
+  const long long k = load_key(key, drow);
+  uint64_t s = hash_key(k) & cap_mask;
+  for (;;) {
+    unsigned long long owner = slot_owner[s];
+    if (owner == kEmpty) {
+      const unsigned long long prev = atomicCAS(&slot_owner[s], kEmpty, drow);
+      owner = prev == kEmpty ? drow : prev;
+    }
+    if (owner == drow) break;
+    if (load_key(key, owner) == k) { atomicOr(dup_flag, 1u); break; }
+    s = (s + 1) & cap_mask;
+  }
+}
+hipError_t hj_launch_claim_list(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, unsigned long long *slot_owner,
+                                uint64_t cap_mask, uint32_t *dup_flag, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_claim_list_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, key, dev_rows, n, slot_owner, cap_mask, dup_flag);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_semi_flags_kernel(JoinKeyColumn fk, const uint64_t *dev_rows, uint64_t n, JoinKeyColumn set_key,
+                                                             const unsigned long long *set_owner, uint64_t set_mask, uint64_t *flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long k = load_key(fk, dev_rows[i]);
+  uint64_t s = hash_key(k) & set_mask;
+  uint64_t hit = 0;
+  for (;;) {
+    const unsigned long long owner = set_owner[s];
+    if (owner == kEmpty) break;
+    if (load_key(set_key, owner) == k) { hit = 1; break; }
+    s = (s + 1) & set_mask;
+  }
+  flags[i] = hit;
+}
+hipError_t hj_launch_semi_flags(const JoinKeyColumn &fk, const uint64_t *dev_rows, uint64_t n, const JoinKeyColumn &set_key,
+                                const unsigned long long *set_owner, uint64_t set_mask, uint64_t *flags, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_semi_flags_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, fk, dev_rows, n, set_key, set_owner, set_mask, flags);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_compact_kernel(const uint64_t *in, const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) out[offsets[i]] = in[i];
+}
+hipError_t hj_launch_compact(const uint64_t *in, const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_compact_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, flags, offsets, n, out);
+  return hipGetLastError();
+}
+
+hipError_t hj_exclusive_scan_u64(void *tmp, size_t *tmp_bytes, const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t s) {
+  return rocprim::exclusive_scan(tmp, *tmp_bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
+}
+hipError_t hj_sort_u32_u64(void *tmp, size_t *tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout,
+                           uint64_t n, uint32_t bits, hipStream_t s) {
+  return rocprim::radix_sort_pairs(tmp, *tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, s);
+}
+hipError_t hj_sort_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
+                           uint64_t n, hipStream_t s) {
+  return rocprim::radix_sort_pairs(tmp, *tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, 64u, s);
+}
+
+__global__ __launch_bounds__(256) void hj_segment_sums_kernel(const uint32_t *slot, const uint64_t *val, uint64_t n, double *sum_by_slot, uint64_t *count_by_slot) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = slot[i];
+  if (i != 0 && slot[i - 1] == s) return; // not the head of its run
+  double acc = 0.0; // SumFloat64 starts at 0.0 and adds in arrival order (llkv-aggregate/src/lib.rs:870-888)
+  uint64_t j = i;
+  for (; j < n && slot[j] == s; ++j) acc += __longlong_as_double((long long)val[j]);
+  sum_by_slot[s] = acc;
+  count_by_slot[s] = j - i;
+}
+hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
+                                  uint64_t *count_by_slot, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_segment_sums_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, sorted_slot, sorted_val, n, sum_by_slot, count_by_slot);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_topk_keys_kernel(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  slots[i] = (uint32_t)i;
+  if (count_by_slot[i] == 0) { keys[i] = ~0ull; return; } // no group in this slot: sorts last
+  long long b = __double_as_longlong(sum_by_slot[i]);
+  const uint64_t asc = b < 0 ? ~(uint64_t)b : ((uint64_t)b | 0x8000000000000000ull); // ascending order key of an f64
+  keys[i] = ~asc == ~0ull ? ~asc - 1 : ~asc;                                           // descending; never collides with the sentinel
+}
+hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots, hipStream_t s) {
+  hipLaunchKernelGGL(hj_topk_keys_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, sum_by_slot, count_by_slot, cap, keys, slots);
+  return hipGetLastError();
+}
+
 } // namespace llkv

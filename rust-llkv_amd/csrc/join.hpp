@@ -48,4 +48,24 @@ struct ProbeParams {
 hipError_t hj_launch_probe_count(const ProbeParams &p, hipStream_t s);
 hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s);
 
+// ---- join → GROUP BY → top-k pipeline pieces (join_agg.cpp) ---------------------------
+// Claim the keys of the listed build rows; *dup_flag is set when a key occurs twice.
+hipError_t hj_launch_claim_list(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, unsigned long long *slot_owner,
+                                uint64_t cap_mask, uint32_t *dup_flag, hipStream_t s);
+// flags[i] = 1 when the foreign key of listed row i is present in the table.
+hipError_t hj_launch_semi_flags(const JoinKeyColumn &fk, const uint64_t *dev_rows, uint64_t n, const JoinKeyColumn &set_key,
+                                const unsigned long long *set_owner, uint64_t set_mask, uint64_t *flags, hipStream_t s);
+hipError_t hj_launch_compact(const uint64_t *in, const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t *out, hipStream_t s);
+hipError_t hj_exclusive_scan_u64(void *tmp, size_t *tmp_bytes, const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t s);
+hipError_t hj_sort_u32_u64(void *tmp, size_t *tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout,
+                           uint64_t n, uint32_t bits, hipStream_t s);
+hipError_t hj_sort_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
+                           uint64_t n, hipStream_t s);
+// Left-to-right f64 sum of every run of equal slots (rows of a group in scan order: the reference's
+// accumulation order) → sum_by_slot[slot]; topk_key[slot] = descending order key of the sum (slots
+// without a group sort last).
+hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
+                                  uint64_t *count_by_slot, hipStream_t s);
+hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots, hipStream_t s);
+
 } // namespace llkv

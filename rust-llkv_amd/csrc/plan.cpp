@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace llkv {
@@ -569,6 +570,10 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   if (p.acc_lds && (size_t)p.lanes * 2048 > 160u * 1024)
     return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
   p.unroll = (p.acc_lds || p.lanes <= 8) ? 4 : 2;
+  if (const char *e = std::getenv("LLKV_HIP_UNROLL")) { // tuning knob (run-time specialised kernels only)
+    const int u = std::atoi(e);
+    if (u == 1 || u == 2 || u == 4 || u == 8) p.unroll = u;
+  }
 
   std::string cols = "Cols<";
   p.bytes_per_row = 0;
@@ -605,6 +610,28 @@ int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, u
   out->always_false = pred == "False";
   out->always_true = pred == "True";
   out->type_string = "SelPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + ">";
+  return LLKV_OK;
+}
+
+int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
+                const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  Lowering L{resolve, *out, err, true};
+  std::string pred, key, val;
+  int rc = L.predicate(filters, n_filters, nullptr, 0, &pred);
+  if (rc) return rc;
+  out->always_false = pred == "False";
+  const ColumnInfo *ci;
+  int slot;
+  if ((rc = L.slot_of(key_field, &ci, &slot))) return rc;
+  if (ci->dtype == LLKV_DT_INT64 || ci->dtype == LLKV_DT_UINT64) key = L.col_node(slot, LLKV_DT_INT64);
+  else if (ci->dtype == LLKV_DT_INT32 || ci->dtype == LLKV_DT_DATE32 || ci->dtype == LLKV_DT_UINT32) key = "ToI64<" + L.col_node(slot, ci->dtype) + ">";
+  else return L.fail(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(ci->dtype));
+  bool is_f64 = false;
+  if (!expr || expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
+  if ((rc = L.expr_planvalue(expr, expr_len, &val, &is_f64))) return rc;
+  if (!is_f64) return L.fail(LLKV_UNSUPPORTED, "integer SUM in the join-aggregate pipeline");
+  out->type_string = "ProbePlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + "," + key + "," + val + ">";
   return LLKV_OK;
 }
 

@@ -90,6 +90,11 @@ int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, u
 int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,
                      LoweredPlan *out, std::string *err);
 
+// Fact side of a join → aggregate pipeline → "ProbePlan<Cols<…>,pred,KeyExpr,ValExpr>" (select.hip.h).
+// The aggregate argument follows the GROUP BY (PlanValue) semantics and must be Float64.
+int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
+                const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err);
+
 // Typed literal cast used by leaf predicates (shared with the selection path).
 struct NativeLit {
   bool is_float = false, is_unsigned = false;

@@ -47,6 +47,13 @@ struct ScanParams {
   const uint64_t *aux_in;     // selection: exclusive offsets per (tile, wave)
   uint64_t *aux_out;          // selection: logical row ids out
   uint64_t *aux_out2;         // selection: device row indices out
+  // probe-emit kernels (join → aggregate pipelines): open-addressing table of the build side
+  const unsigned long long *ht_owner; // slot → owning build device row (~0 = empty)
+  uint64_t ht_mask;
+  const void *ht_keys;        // build key column image
+  uint32_t ht_key_width;      // 4 or 8
+  uint32_t ht_key_signed;
+  uint32_t *aux_out32;        // probe-emit: matching slot per emitted row
 };
 
 constexpr int kMaxOuts = 8;

@@ -53,6 +53,75 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
   }
 }
 
+// ---- probe-emit: fact-side rows that pass the predicate AND hit the build table emit
+// (slot, value) in row order — the input of the order-preserving join → GROUP BY pipeline
+// (llkv-executor/src/lib.rs:12529-12569 probe + :1629-1646 mask + :5186-5199 per-row argument).
+template <class CL, class PR, class KE, class VE> struct ProbePlan {
+  using ColList = CL;
+  using Pred = PR;
+  using KeyE = KE;
+  using ValE = VE;
+};
+
+__device__ __forceinline__ long long ht_load_key(const ScanParams &p, unsigned long long row) {
+  if (p.ht_key_width == 8) return reinterpret_cast<const long long *>(p.ht_keys)[row];
+  const uint32_t v = reinterpret_cast<const uint32_t *>(p.ht_keys)[row];
+  return p.ht_key_signed ? (long long)(int32_t)v : (long long)v;
+}
+__device__ __forceinline__ uint64_t ht_hash(long long k) {
+  uint64_t x = (uint64_t)k;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
+  uint64_t s = ht_hash(k) & p.ht_mask;
+  for (;;) {
+    const unsigned long long owner = p.ht_owner[s];
+    if (owner == ~0ull) return 0xFFFFFFFFu;
+    if (ht_load_key(p, owner) == k) return (uint32_t)s;
+    s = (s + 1) & p.ht_mask;
+  }
+}
+
+template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t sub0 = wave * p.sub_rows;
+  const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
+  const uint64_t slot_idx = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
+  uint64_t base = WRITE ? p.aux_in[slot_idx] : 0;
+  uint64_t count = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t r = sub0; r < sub1; r += 128) {
+    Loaded ld;
+    const uint32_t row0 = r + lane * 2;
+    load_all<typename P::ColList>(p, td.dev_row + row0, ld);
+    bool f[2];
+    uint32_t hit[2];
+    uint64_t val[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
+      const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+      hit[j] = pass ? ht_find(p, (long long)P::KeyE::eval(c, j)) : 0xFFFFFFFFu; // hash probe only for surviving rows
+      f[j] = hit[j] != 0xFFFFFFFFu;
+      val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
+    }
+    const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
+    if constexpr (WRITE) {
+      const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
+      if (f[0]) { p.aux_out32[pre] = hit[0]; p.aux_out[pre] = val[0]; }
+      if (f[1]) { p.aux_out32[pre + (f[0] ? 1 : 0)] = hit[1]; p.aux_out[pre + (f[0] ? 1 : 0)] = val[1]; }
+      base += __popcll(b0) + __popcll(b1);
+    } else {
+      count += __popcll(b0) + __popcll(b1);
+    }
+  }
+  if constexpr (!WRITE) {
+    if (lane == 0) p.tile_partials[slot_idx] = count;
+  }
+}
+
 // Exclusive scan of the per-(tile, wave) counts; one block, fixed order.  out[n] = total.
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint64_t *in, uint64_t *out, uint32_t n) {
   __shared__ uint64_t part[1024];

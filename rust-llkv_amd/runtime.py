@@ -381,6 +381,33 @@ def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN
     return batches
 
 
+def join_groupby_topk(fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, sum_expr,
+                      payload_fields: Sequence[int] = (), limit: int = 10, dim_fk: int = 0, dim2: Optional[HipTable] = None,
+                      dim2_filters=(), dim2_key: int = 0):
+    """fact ⋈ dim [⋉ dim2] GROUP BY dim key (+payload) SUM(expr) ORDER BY sum DESC, payload[0] LIMIT k
+    (TPC-H Q3 shape; llkv_hip_join_groupby_topk).  Returns (rows, total_groups); rows = (key, sum, count, payload...)."""
+    keep = []
+
+    def side(table, filters, key):
+        p = CPlan(list(filters or []))
+        keep.append(p)
+        s = abi.CJoinSide()
+        s.table, s.filters, s.n_filters, s.key_field = table.handle, p.filters, p.n_filters, key
+        return s
+
+    f, d = side(fact, fact_filters, fact_key), side(dim, dim_filters, dim_key)
+    d2 = side(dim2, dim2_filters, dim2_key) if dim2 is not None else None
+    toks = sum_expr.to_c(keep)
+    pay = (C.c_uint32 * max(1, len(payload_fields)))(*payload_fields)
+    rows = (abi.CJoinGroupRow * max(1, limit))()
+    n, total = C.c_uint32(), C.c_uint64()
+    check(lib().llkv_hip_join_groupby_topk(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None, pay,
+                                           C.c_uint32(len(payload_fields)), toks, C.c_uint32(len(sum_expr.tokens)), C.c_uint32(limit),
+                                           rows, C.byref(n), C.byref(total)))
+    out = [(r.key, r.sum, r.count) + tuple(r.payload[i] for i in range(len(payload_fields))) for r in rows[:n.value]]
+    return out, total.value
+
+
 def lower_plan(column_descs, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (), grouped: bool = False,
                plan_lib=None, order_by_keys: bool = False):
     """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError."""

@@ -364,3 +364,65 @@ def test_random_joins_match_oracle(rt, orc, abi, n_left, n_right, keyspace, batc
         assert all(b[1] is None for b in got)
     if n_left <= 65536:  # a single probe window: batch boundaries are the reference's exactly
         assert [len(b[0]) for b in got] == [len(b[0]) for b in want]
+
+
+@pytest.mark.parametrize("rows,scale", [(60175, 0.01), (600_000, 0.1)])
+def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
+    """TPC-H Q3 shape (BASELINE.json configs[4], single GPU): customer(segment) ⋉ orders(date) ⋈ lineitem(shipdate),
+    GROUP BY l_orderkey, o_orderdate, o_shippriority, SUM(price*(1-disc)), ORDER BY revenue DESC, o_orderdate LIMIT 10.
+    The oracle side composes the restated operators in the executor's order (join → mask → group-by → sort → limit);
+    sums add an order's lineitems in scan order on both sides, so revenue is compared bit for bit."""
+    D = tpch.DATE_1995_03_15
+    li = tpch.gen_lineitem(rows, scale)
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    seg = [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]]
+
+    # ---- GPU
+    lt = rt.HipTable(1, tpch.chunk_rows(rows, 65536))
+    for c in ("l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"):
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
+    ot_ = rt.HipTable(2, tpch.chunk_rows(n_ord, 65536))
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c])
+    ct = rt.HipTable(3, tpch.chunk_rows(n_cust, 65536))
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, seg)
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    revenue = col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT))
+    got, total = rt.join_groupby_topk(
+        lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY,
+        ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, revenue,
+        payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10,
+        dim_fk=tpch.O_CUSTKEY, dim2=ct, dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+
+    # ---- oracle composition
+    cust_t = orc.OracleTable(n_cust).add(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"]).add(tpch.C_MKTSEGMENT, abi.DT_UTF8, seg)
+    c_rows = orc.filter_row_ids(cust_t, [F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))])
+    custkeys = cu["c_custkey"][c_rows.astype(np.int64)]
+    # customer ⋈ orders (inner, key custkey): the orders whose customer qualifies, in order-row order
+    o_tab = orc.OracleTable(n_ord).add(tpch.O_CUSTKEY, abi.DT_INT64, od["o_custkey"])
+    c_tab = orc.OracleTable(len(custkeys)).add(tpch.C_CUSTKEY, abi.DT_INT64, custkeys)
+    o_sel = np.array([l for b in orc.hash_join(o_tab, c_tab, [(tpch.O_CUSTKEY, tpch.C_CUSTKEY)], abi.JOIN_SEMI) for l in b[0]], dtype=np.int64)
+    # ⋈ lineitem on orderkey
+    l_tab = orc.OracleTable(rows).add(tpch.L_ORDERKEY, abi.DT_INT64, li["l_orderkey"])
+    oj = orc.OracleTable(len(o_sel)).add(tpch.O_ORDERKEY, abi.DT_INT64, od["o_orderkey"][o_sel])
+    pairs = orc.hash_join(l_tab, oj, [(tpch.L_ORDERKEY, tpch.O_ORDERKEY)], abi.JOIN_INNER)
+    pl = np.array([x for b in pairs for x in b[0]], dtype=np.int64)
+    po = o_sel[np.array([x for b in pairs for x in b[1]], dtype=np.int64)]
+    # remaining WHERE conjuncts as a mask over the joined rows (llkv-executor/src/lib.rs:1629-1646)
+    m = (od["o_orderdate"][po] < D) & (li["l_shipdate"][pl] > D)
+    pl, po = pl[m], po[m]
+    j = orc.OracleTable(len(pl))
+    j.add(1, abi.DT_INT64, li["l_orderkey"][pl]).add(2, abi.DT_DATE32, od["o_orderdate"][po]).add(3, abi.DT_INT64, od["o_shippriority"][po])
+    j.add(4, abi.DT_FLOAT64, li["l_extendedprice"][pl]).add(5, abi.DT_FLOAT64, li["l_discount"][pl])
+    groups = orc.groupby(j, None, [1, 2, 3], [abi.AggregateSpec.sum(col(4) * (1 - col(5))), abi.AggregateSpec.count_star()])
+    want = sorted(((g.keys[0].value, g.values[0].value, g.values[1].value, g.keys[1].value, g.keys[2].value) for g in groups),
+                  key=lambda r: (-r[1], r[3]))[:10]
+    assert total == len(groups)
+    assert len(got) == len(want) == 10
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and g[2] == w[2] and g[3] == w[3] and g[4] == w[4], (g, w)
+        assert np.float64(g[1]).tobytes() == np.float64(w[1]).tobytes(), (g, w)  # bit-exact revenue
