@@ -90,7 +90,14 @@ typedef enum llkv_operator_kind {
   LLKV_OP_LE = 6,
   LLKV_OP_IN = 7,
   LLKV_OP_IS_NULL = 8,
-  LLKV_OP_IS_NOT_NULL = 9
+  LLKV_OP_IS_NOT_NULL = 9,
+  /* MVCC visibility as a leaf: the row filter every SqlEngine SELECT applies after the
+   * predicate (MvccRowIdFilter llkv-transaction/src/helpers.rs:259-312, rule RowVersion::is_visible_for
+   * llkv-transaction/src/mvcc.rs:283-333).  field_id = the `created_by` column (UInt64),
+   * value.lo = field id of the `deleted_by` column, lower.lo = snapshot.txn_id,
+   * upper.lo = snapshot.snapshot_id, in_list = txn ids whose status is NOT Committed
+   * (Active / Aborted; ≤ 4 on the GPU path).                                              */
+  LLKV_OP_MVCC_VISIBLE = 10
 } llkv_operator_kind;
 
 typedef enum llkv_bound_kind {
@@ -235,6 +242,42 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
                                               const uint8_t *const *chunk_data,
                                               uint32_t n_chunks,
                                               const char *const *dictionary, uint32_t dict_size);
+/* --- llkv-column-map chunk format ------------------------- */
+/* `ARR0` blob header, llkv-column-map/src/serialization.rs:41-140: 24 bytes
+ * (magic, layout, type code, len, extra_a, extra_b) then the payload; no null
+ * bitmaps exist on disk.                                                      */
+typedef struct llkv_arr0_desc {
+  int32_t layout;        /* 0 Primitive, 1 FslFloat32, 2 Varlen, 3 Struct       */
+  int32_t type_code;     /* PrimType, serialization.rs:146-166                  */
+  int32_t dtype;         /* llkv_dtype, or -1 when the path does not take it    */
+  int32_t reserved;
+  uint64_t len;          /* element count                                       */
+  uint64_t payload_offset; /* = 24                                              */
+  uint64_t values_offset;  /* Primitive: = payload; Varlen: after the offsets   */
+  uint64_t values_len;
+  uint64_t offsets_len;    /* Varlen only                                       */
+} llkv_arr0_desc;
+llkv_status llkv_hip_arr0_describe(const uint8_t *blob, uint64_t blob_len, llkv_arr0_desc *out);
+
+/* Row-id shadow chunk metadata (ChunkMetadata, store/descriptor.rs:19-84) and the
+ * density test of `dense_row_runs` (store/scan/filter.rs:1510-1582): every chunk
+ * spans exactly row_count ids and chunks follow one another.  The GPU path takes
+ * dense tables only; `*is_dense == 0` means "stay on the CPU route".           */
+typedef struct llkv_chunk_meta {
+  uint64_t row_count;
+  uint64_t min_val_u64;
+  uint64_t max_val_u64;
+} llkv_chunk_meta;
+llkv_status llkv_hip_dense_row_runs(const llkv_chunk_meta *rowid_chunks, uint32_t n_chunks,
+                                    int32_t *is_dense, uint64_t *first_row_id);
+
+/* Stage one column straight from its ARR0 chunk blobs (the pager blobs the
+ * reference deserializes zero-copy, serialization.rs:438-488).                 */
+llkv_status llkv_hip_table_append_arr0_column(llkv_hip_table *table, uint32_t field_id,
+                                              const uint8_t *const *chunk_blobs,
+                                              const uint64_t *chunk_blob_lens, uint32_t n_chunks,
+                                              const char *const *dictionary, uint32_t dict_size);
+
 /* Adopt a buffer that already lives in HBM (all local chunks back to back). */
 llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id,
                                                int32_t dtype, const void *device_values);

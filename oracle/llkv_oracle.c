@@ -358,11 +358,47 @@ static int32_t field_nonnull_rows(const orc_table *t, uint32_t field_id, idvec *
   return LLKV_OK;
 }
 
+/* MVCC row filter as a leaf: RowVersion::is_visible_for llkv-transaction/src/mvcc.rs:283-333 applied row by
+ * row as filter_row_ids_for_snapshot does (llkv-transaction/src/helpers.rs:205-244).  TxnIdManager::status
+ * (mvcc.rs:157-171): TXN_ID_NONE → None, TXN_ID_AUTO_COMMIT → Committed, listed ids → not committed,
+ * anything else → Committed. */
+static int32_t mvcc_visible_rows(const orc_table *t, const llkv_filter *f, idvec *out) {
+  const orc_column *cc = find_col(t, f->field_id), *dc = find_col(t, (uint32_t)f->value.lo);
+  if (!cc || !dc) return fail(LLKV_NOT_FOUND, "MVCC column not found");
+  if (cc->dtype != LLKV_DT_UINT64 || dc->dtype != LLKV_DT_UINT64) return fail(LLKV_INVALID_ARGUMENT, "MVCC columns must be UInt64");
+  const uint64_t txn = f->lower.lo, snap = f->upper.lo, NONE = UINT64_MAX, AUTO = 1;
+  idvec r = {0};
+  for (uint64_t i = 0; i < t->rows; ++i) {
+    const uint64_t created = ((const uint64_t *)cc->values)[i], deleted = ((const uint64_t *)dc->values)[i];
+    int visible;
+#define COMMITTED(id, res) do { res = (id) != NONE; if ((id) != AUTO) for (uint32_t k = 0; k < f->in_len; ++k) if (f->in_list[k].lo == (id)) res = 0; } while (0)
+    if (created == txn && txn != AUTO) visible = deleted != txn;
+    else {
+      int c_ok;
+      COMMITTED(created, c_ok);
+      if (!c_ok) visible = 0;
+      else if (created > snap) visible = 0;
+      else if (deleted == NONE) visible = 1;
+      else if (deleted == txn && txn != AUTO) visible = 0;
+      else {
+        int d_ok;
+        COMMITTED(deleted, d_ok);
+        visible = !d_ok ? 1 : deleted > snap;
+      }
+    }
+#undef COMMITTED
+    if (visible) idv_push(&r, i);
+  }
+  *out = r;
+  return LLKV_OK;
+}
+
 /* Leaf filter: llkv-table/src/table.rs:1117-1171,1225-1247; hot loop
  * llkv-column-map/src/store/scan/filter.rs:937-955 (sequential, push row id). */
 static int32_t filter_leaf(const orc_table *t, const llkv_filter *f, idvec *out) {
   const orc_column *c = find_col(t, f->field_id);
   if (!c) return fail(LLKV_NOT_FOUND, "field %u not found", f->field_id);
+  if (f->op == LLKV_OP_MVCC_VISIBLE) return mvcc_visible_rows(t, f, out);
   if (f->op == LLKV_OP_IS_NOT_NULL) return field_nonnull_rows(t, f->field_id, out);
   if (f->op == LLKV_OP_IS_NULL) {
     idvec all = idv_all(t->rows), nn;

@@ -25,7 +25,7 @@ NUMPY_OF_DTYPE = {DT_INT64: "int64", DT_FLOAT64: "float64", DT_INT32: "int32", D
                   DT_UINT64: "uint64", DT_UINT32: "uint32", DT_FLOAT32: "float32", DT_BOOLEAN: "uint8"}
 
 LIT_NULL, LIT_INT128, LIT_FLOAT64, LIT_DECIMAL128, LIT_BOOLEAN, LIT_STRING, LIT_DATE32 = range(7)
-OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL = range(1, 10)
+OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE = range(1, 11)
 BOUND_UNBOUNDED, BOUND_INCLUDED, BOUND_EXCLUDED = range(3)
 EVAL_PUSH_PREDICATE, EVAL_PUSH_LITERAL, EVAL_AND, EVAL_OR, EVAL_NOT = range(1, 6)
 TOK_COLUMN, TOK_LITERAL, TOK_BINARY = range(1, 4)
@@ -103,6 +103,15 @@ class CJoinSide(C.Structure):
 
 class CJoinGroupRow(C.Structure):
     _fields_ = [("key", C.c_int64), ("sum", C.c_double), ("count", C.c_uint64), ("payload", C.c_int64 * 4)]
+
+
+class CArr0Desc(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("type_code", C.c_int32), ("dtype", C.c_int32), ("reserved", C.c_int32), ("len", C.c_uint64),
+                ("payload_offset", C.c_uint64), ("values_offset", C.c_uint64), ("values_len", C.c_uint64), ("offsets_len", C.c_uint64)]
+
+
+class CChunkMeta(C.Structure):
+    _fields_ = [("row_count", C.c_uint64), ("min_val_u64", C.c_uint64), ("max_val_u64", C.c_uint64)]
 
 
 ON_BATCH = C.CFUNCTYPE(None, C.POINTER(CBatchView), C.c_void_p)
@@ -235,6 +244,12 @@ class Operator:
     @staticmethod
     def In(values: Sequence):
         return Operator(OP_IN, values=tuple(Literal.of(v) for v in values))
+
+    @staticmethod
+    def MvccVisible(deleted_by_field: int, txn_id: int, snapshot_id: int, uncommitted: Sequence[int] = ()):
+        """MvccRowIdFilter as a leaf on the `created_by` column (llkv-transaction/src/helpers.rs:259-312)."""
+        return Operator(OP_MVCC_VISIBLE, Literal.of(deleted_by_field), Bound(BOUND_INCLUDED, txn_id), Bound(BOUND_INCLUDED, snapshot_id),
+                        tuple(Literal.of(u) for u in uncommitted))
 
     IsNull: ClassVar["Operator"]
     IsNotNull: ClassVar["Operator"]
@@ -465,14 +480,14 @@ class CPlan:
             cf.field_id, cf.op = f.field_id, f.op.kind
             if f.op.value is not None:
                 cf.value = f.op.value.to_c(self.keep)
-            if f.op.kind == OP_RANGE:
+            if f.op.kind in (OP_RANGE, OP_MVCC_VISIBLE):
                 cf.lower_kind = f.op.lower.kind
                 if f.op.lower.value is not None:
                     cf.lower = f.op.lower.value.to_c(self.keep)
                 cf.upper_kind = f.op.upper.kind
                 if f.op.upper.value is not None:
                     cf.upper = f.op.upper.value.to_c(self.keep)
-            if f.op.kind == OP_IN:
+            if f.op.kind in (OP_IN, OP_MVCC_VISIBLE):
                 lst = (CLiteral * max(1, len(f.op.values)))()
                 for j, v in enumerate(f.op.values):
                     lst[j] = v.to_c(self.keep)

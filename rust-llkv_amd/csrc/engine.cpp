@@ -209,7 +209,7 @@ static uint32_t pick_tile_rows(const LoweredPlan &p) {
   // narrow register states amortise their block reduction quickly and like many small tiles;
   // LDS-resident grouped states (2 workgroups/CU) want long tiles (sweep: profiles/r01/).
   // Depends on the plan only, never on the GPU count (bit-reproducibility).
-  return p.acc_lds ? 65536u : 8192u;
+  return p.acc_lds ? 65536u : 4096u;
 }
 
 int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,

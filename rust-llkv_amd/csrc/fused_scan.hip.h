@@ -255,6 +255,23 @@ template <class E, class... Vs> struct In {
     return (bool)((int)(v == Vs::eval(c, j)) | ...);
   }
 };
+// MVCC visibility of a row version (llkv-transaction/src/mvcc.rs:283-333), fused into the scan instead of
+// the reference's per-row gather of `_created_by` / `_deleted_by` (helpers.rs:205-244).  UN… = txn ids whose
+// status is not Committed; TXN_ID_NONE = u64::MAX has status None; TXN_ID_AUTO_COMMIT = 1 is never "current".
+template <class C, class D, class TXN, class SNAP, class... UN> struct Mvcc {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    const uint64_t created = (uint64_t)C::eval(c, j), deleted = (uint64_t)D::eval(c, j);
+    const uint64_t txn = (uint64_t)TXN::eval(c, j), snap = (uint64_t)SNAP::eval(c, j);
+    const uint64_t none = ~0ull;
+    const bool cur = txn != 1ull;
+    const bool c_uncommitted = (created == none) | (bool)((int)0 | ... | (int)(created == (uint64_t)UN::eval(c, j)));
+    const bool d_uncommitted = (bool)((int)0 | ... | (int)(deleted == (uint64_t)UN::eval(c, j)));
+    const bool own = (created == txn) & cur;
+    const bool other = !c_uncommitted & (created <= snap) &
+                       ((deleted == none) | (!((deleted == txn) & cur) & (d_uncommitted | (deleted > snap))));
+    return own ? (deleted != txn) : other;
+  }
+};
 template <class... Ps> struct And {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return (bool)((int)Ps::eval(c, j) & ...); }
 };

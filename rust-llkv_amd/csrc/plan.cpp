@@ -12,7 +12,7 @@ typedef __int128 i128;
 typedef unsigned __int128 u128;
 
 static constexpr int kMaxColsHost = 8;
-static constexpr int kMaxLitsHost = 12;
+static constexpr int kMaxLitsHost = 16;
 static constexpr int kMaxKeysHost = 4;
 static constexpr uint32_t kMaxDenseGroups = 8;
 
@@ -187,6 +187,24 @@ struct Lowering {
   int leaf(const llkv_filter &f, std::string *out) {
     const ColumnInfo *ci = resolve(f.field_id);
     if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(f.field_id) + " not found");
+    if (f.op == LLKV_OP_MVCC_VISIBLE) { // MvccRowIdFilter as a leaf
+      const ColumnInfo *cd = resolve((uint32_t)f.value.lo);
+      if (!cd) return fail(LLKV_NOT_FOUND, "deleted_by field " + std::to_string((uint32_t)f.value.lo) + " not found");
+      if (ci->dtype != LLKV_DT_UINT64 || cd->dtype != LLKV_DT_UINT64) return fail(LLKV_INVALID_ARGUMENT, "MVCC columns must be UInt64");
+      if (f.in_len > 4) return fail(LLKV_UNSUPPORTED, "more than 4 non-committed transactions in the snapshot");
+      int sc, sd, rc2;
+      const ColumnInfo *tmp;
+      if ((rc2 = slot_of(f.field_id, &tmp, &sc)) || (rc2 = slot_of((uint32_t)f.value.lo, &tmp, &sd))) return rc2;
+      std::string txn, snap, un;
+      if ((rc2 = lit_i((int64_t)f.lower.lo, &txn, "LitU")) || (rc2 = lit_i((int64_t)f.upper.lo, &snap, "LitU"))) return rc2;
+      for (uint32_t i = 0; i < f.in_len; ++i) {
+        std::string u;
+        if ((rc2 = lit_i((int64_t)f.in_list[i].lo, &u, "LitU"))) return rc2;
+        un += "," + u;
+      }
+      *out = "Mvcc<" + col_node(sc, LLKV_DT_UINT64) + "," + col_node(sd, LLKV_DT_UINT64) + "," + txn + "," + snap + un + ">";
+      return LLKV_OK;
+    }
     if (f.op == LLKV_OP_IS_NOT_NULL) { *out = "True"; return LLKV_OK; }  // NULL-free staged columns
     if (f.op == LLKV_OP_IS_NULL) { *out = "False"; return LLKV_OK; }
     if (f.op == LLKV_OP_RANGE && f.lower_kind == LLKV_BOUND_UNBOUNDED && f.upper_kind == LLKV_BOUND_UNBOUNDED) { *out = "True"; return LLKV_OK; }

@@ -24,7 +24,7 @@ constexpr int kBlock = 256;
 constexpr int kRowsPerThread = 2;
 constexpr int kStepRows = kBlock * kRowsPerThread; // 512 rows per block step
 constexpr int kMaxCols = 8;
-constexpr int kMaxLits = 12;
+constexpr int kMaxLits = 16;
 constexpr int kMaxKeys = 4;
 constexpr int kOctants = 8; // canonical partition of the chunk list
 

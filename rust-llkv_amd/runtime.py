@@ -162,6 +162,18 @@ class HipTable:
             dptr, dn = (C.c_char_p * max(1, len(enc)))(*enc), len(enc)
         check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off)), dptr, C.c_uint32(dn)))
 
+    def append_arr0_column(self, field_id: int, blobs: Sequence[bytes], dictionary: Optional[Sequence[str]] = None):
+        """Stage a column from its llkv-column-map `ARR0` chunk blobs (one per local chunk)."""
+        bufs = [np.frombuffer(b, dtype=np.uint8) for b in blobs]
+        ptrs = (C.c_void_p * max(1, len(bufs)))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_uint64 * max(1, len(bufs)))(*[len(b) for b in bufs])
+        if dictionary is None:
+            dptr, dn = None, 0
+        else:
+            enc = [d.encode() for d in dictionary]
+            dptr, dn = (C.c_char_p * max(1, len(enc)))(*enc), len(enc)
+        check(lib().llkv_hip_table_append_arr0_column(self._h, C.c_uint32(field_id), ptrs, lens, C.c_uint32(len(bufs)), dptr, C.c_uint32(dn)))
+
     def adopt_device_column(self, field_id: int, dtype: int, device_ptr: int):
         check(lib().llkv_hip_table_adopt_device_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), C.c_void_p(device_ptr)))
 
@@ -313,6 +325,41 @@ def groupby(table: HipTable, predicate, keys: Sequence[int], aggs: Sequence[Aggr
         return q.run()
     finally:
         q.close()
+
+
+PRIM_TYPE_CODES = {abi.DT_UINT64: 1, abi.DT_INT32: 2, abi.DT_UINT32: 3, abi.DT_FLOAT32: 4, abi.DT_INT64: 6, abi.DT_FLOAT64: 11,
+                   abi.DT_UTF8: 12, abi.DT_DATE32: 16}
+
+
+def arr0_serialize(dtype: int, values) -> bytes:
+    """Writer of the `ARR0` chunk blob for the types on this path (layout documented in
+    llkv-column-map/src/serialization.rs:41-140) — harness / test helper."""
+    import struct
+    if dtype == abi.DT_UTF8:
+        enc = [s.encode() for s in values]
+        offsets = np.zeros(len(enc) + 1, dtype=np.int32)
+        np.cumsum([len(e) for e in enc], out=offsets[1:])
+        data = b"".join(enc)
+        return b"ARR0" + bytes([2, 12, 0, 0]) + struct.pack("<QII", len(enc), offsets.nbytes, len(data)) + offsets.tobytes() + data
+    arr = np.ascontiguousarray(values, dtype=np.dtype(abi.NUMPY_OF_DTYPE[dtype]))
+    return b"ARR0" + bytes([0, PRIM_TYPE_CODES[dtype], 0, 0]) + struct.pack("<QII", len(arr), arr.nbytes, 0) + arr.tobytes()
+
+
+def arr0_describe(blob: bytes):
+    d = abi.CArr0Desc()
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    check(lib().llkv_hip_arr0_describe(buf.ctypes.data_as(C.c_void_p), C.c_uint64(len(blob)), C.byref(d)))
+    return d
+
+
+def dense_row_runs(chunks: Sequence) -> tuple:
+    """dense_row_runs (llkv-column-map/src/store/scan/filter.rs:1510-1582) over (row_count, min, max) triples."""
+    arr = (abi.CChunkMeta * max(1, len(chunks)))()
+    for i, (n, lo, hi) in enumerate(chunks):
+        arr[i].row_count, arr[i].min_val_u64, arr[i].max_val_u64 = n, lo, hi
+    dense, first = C.c_int32(), C.c_uint64()
+    check(lib().llkv_hip_dense_row_runs(arr, C.c_uint32(len(chunks)), C.byref(dense), C.byref(first)))
+    return bool(dense.value), first.value
 
 
 def filter_row_ids(table: HipTable, predicate) -> np.ndarray:

@@ -426,3 +426,44 @@ def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
     for g, w in zip(got, want):
         assert g[0] == w[0] and g[2] == w[2] and g[3] == w[3] and g[4] == w[4], (g, w)
         assert np.float64(g[1]).tobytes() == np.float64(w[1]).tobytes(), (g, w)  # bit-exact revenue
+
+
+def test_table_staged_from_arr0_chunk_blobs(rt, orc, abi, tpch):
+    """§8f-1: ingest llkv-column-map chunk blobs (`ARR0`) instead of raw buffers; results identical."""
+    n = 20_000
+    chunks = tpch.chunk_rows(n, 8192)
+    d = tpch.gen_lineitem(n, 0.01)
+    q = tpch.q1()
+    ht = rt.HipTable(1, chunks)
+    ot = orc.OracleTable(n)
+    for c in q.columns:
+        fid, dt = tpch.LINEITEM_SCHEMA[c]
+        ot.add(fid, dt, d[c])
+        blobs, off = [], 0
+        for r in chunks:
+            part = d[c][off:off + r]
+            blobs.append(rt.arr0_serialize(dt, [chr(int(v)) for v in part] if dt == abi.DT_UTF8 else part))
+            off += r
+        ht.append_arr0_column(fid, blobs)
+    got, want = rt.groupby(ht, q.predicate, q.keys, q.aggs, True), orc.groupby(ot, q.predicate, q.keys, q.aggs, True)
+    assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want]
+    for g, w in zip(got, want):
+        assert_values(g.values, w.values, "arr0")
+
+
+def test_mvcc_visibility_fused_into_the_scan(rt, orc, abi):
+    """§8f-2: the MVCC row filter as a predicate leaf, ANDed with the user predicate inside the kernels
+    (aggregate, selection) — against the oracle's row-by-row restatement of is_visible_for."""
+    rng = np.random.default_rng(11)
+    n = 50_000
+    NONE = 2**64 - 1
+    created = rng.choice(np.array([1, 2, 3, 4, 5, 6, 7, 9, NONE], dtype=np.uint64), size=n)
+    deleted = rng.choice(np.array([NONE, NONE, NONE, 1, 3, 4, 5, 6, 7, 8], dtype=np.uint64), size=n)
+    val = rng.integers(0, 1000, size=n).astype(np.int64)
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_UINT64, created), (2, abi.DT_UINT64, deleted), (3, abi.DT_INT64, val)], [8192] * 6 + [848])
+    F, O, E, A = abi.Filter, abi.Operator, abi.Expr, abi.AggregateSpec
+    for txn, snap, un in ((7, 5, [4]), (1, 6, [4, 9]), (9, 9, []), (2, 0, [3, 4, 5, 6])):
+        vis = F(1, O.MvccVisible(2, txn_id=txn, snapshot_id=snap, uncommitted=un))
+        assert np.array_equal(rt.filter_row_ids(ht, [vis]), orc.filter_row_ids(ot, [vis]))
+        pred = E.all_of([F(3, O.LessThan(500)), vis])
+        assert_values(rt.aggregate(ht, pred, [A.count_star(), A.sum(3), A.max(3)]), orc.aggregate(ot, pred, [A.count_star(), A.sum(3), A.max(3)]), "mvcc")

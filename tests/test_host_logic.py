@@ -160,3 +160,33 @@ def test_shard_layout_partitions_chunks(lib, n_chunks):
             covered += list(range(t.first_chunk, t.first_chunk + t.n_local_chunks))
             assert t.total_rows == 100 * n_chunks and t.local_rows == 100 * t.n_local_chunks
         assert covered == list(range(n_chunks))
+
+
+def test_arr0_chunk_reader(lib, abi):
+    """`ARR0` header (llkv-column-map/src/serialization.rs:41-140): magic, layout, PrimType code, len, extra_a/b."""
+    rt = mod("runtime")
+    blob = rt.arr0_serialize(abi.DT_INT64, np.arange(5, dtype=np.int64))
+    d = rt.arr0_describe(blob)
+    assert (d.layout, d.type_code, d.dtype, d.len, d.payload_offset, d.values_len) == (0, 6, abi.DT_INT64, 5, 24, 40)
+    d = rt.arr0_describe(rt.arr0_serialize(abi.DT_DATE32, np.arange(3, dtype=np.int32)))
+    assert (d.type_code, d.dtype, d.values_len) == (16, abi.DT_DATE32, 12)
+    d = rt.arr0_describe(rt.arr0_serialize(abi.DT_UTF8, ["ab", "", "cde"]))
+    assert (d.layout, d.type_code, d.dtype, d.len, d.offsets_len, d.values_len, d.values_offset) == (2, 12, abi.DT_UTF8, 3, 16, 5, 40)
+    for bad in (b"ARR1" + blob[4:], blob[:20], blob + b"x"):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.arr0_describe(bad)
+        assert e.value.kind == "Internal"
+    d = rt.arr0_describe(b"ARR0" + bytes([0, 18, 15, 2]) + (2).to_bytes(8, "little") + (32).to_bytes(4, "little") + bytes(4) + bytes(32))
+    assert d.dtype == -1  # Decimal128 is not on this path (it cannot even be leaf-filtered, llkv-table/src/table.rs:1160-1167)
+
+
+def test_dense_row_runs(lib):
+    """store/scan/filter.rs:1510-1582: chunks must each span exactly row_count ids and follow one another."""
+    rt = mod("runtime")
+    assert rt.dense_row_runs([(131072, 0, 131071), (131072, 131072, 262143), (7, 262144, 262150)]) == (True, 0)
+    assert rt.dense_row_runs([(4, 1, 4)]) == (True, 1)
+    assert rt.dense_row_runs([]) == (True, 0)
+    assert rt.dense_row_runs([(4, 1, 5)])[0] is False          # a hole inside a chunk
+    assert rt.dense_row_runs([(4, 0, 3), (4, 5, 8)])[0] is False  # a gap between chunks
+    assert rt.dense_row_runs([(4, 0, 3), (0, 0, 0), (2, 4, 5)])[0] is True  # empty chunks are skipped
+    assert rt.dense_row_runs([(4, 3, 0)])[0] is False

@@ -134,3 +134,31 @@ def test_q6_against_numpy(orc, abi, tpch):
         assert r.values[0].value == int(d["l_quantity"][sel].sum())
         assert r.values[7].value == int(sel.sum())
         assert abs(r.values[1].value - d["l_extendedprice"][sel].sum()) <= 1e-9 * r.values[1].value
+
+
+def test_mvcc_visibility_rules(orc, abi):
+    """RowVersion::is_visible_for (llkv-transaction/src/mvcc.rs:283-333) case by case:
+    (created_by, deleted_by) under snapshot {txn_id 7, snapshot_id 5}, txn 4 Active (not committed)."""
+    NONE = 2**64 - 1
+    rows = [
+        (1, NONE),   # auto-commit creator, never deleted                     → visible
+        (3, NONE),   # committed creator ≤ snapshot                           → visible
+        (6, NONE),   # creator committed AFTER the snapshot (6 > 5)           → invisible
+        (4, NONE),   # creator not committed                                  → invisible
+        (7, NONE),   # created by the current transaction                     → visible
+        (7, 7),      # created and deleted by the current transaction         → invisible
+        (3, 7),      # deleted by the current transaction                     → invisible
+        (3, 4),      # deleter not committed                                  → still visible
+        (3, 5),      # deleter committed, ≤ snapshot                          → invisible
+        (3, 6),      # deleter committed after the snapshot                   → visible
+        (NONE, NONE),  # creator status None                                  → invisible
+        (1, 1),      # deleted by an auto-commit statement (1 ≤ 5)            → invisible
+    ]
+    t = orc.OracleTable(len(rows))
+    t.add(1, abi.DT_UINT64, np.array([r[0] for r in rows], dtype=np.uint64)).add(2, abi.DT_UINT64, np.array([r[1] for r in rows], dtype=np.uint64))
+    F, O = abi.Filter, abi.Operator
+    got = orc.filter_row_ids(t, [F(1, O.MvccVisible(2, txn_id=7, snapshot_id=5, uncommitted=[4]))])
+    assert got.tolist() == [0, 1, 4, 7, 9]
+    # auto-commit snapshot (txn_id = 1) is never "the current transaction" (mvcc.rs:296)
+    got = orc.filter_row_ids(t, [F(1, O.MvccVisible(2, txn_id=1, snapshot_id=9, uncommitted=[4]))])
+    assert got.tolist() == [0, 1, 2, 4, 7]
