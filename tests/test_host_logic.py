@@ -190,3 +190,28 @@ def test_dense_row_runs(lib):
     assert rt.dense_row_runs([(4, 0, 3), (4, 5, 8)])[0] is False  # a gap between chunks
     assert rt.dense_row_runs([(4, 0, 3), (0, 0, 0), (2, 4, 5)])[0] is True  # empty chunks are skipped
     assert rt.dense_row_runs([(4, 3, 0)])[0] is False
+
+
+def test_qualification_value_parsing_and_tolerance():
+    """llkv-tpch/src/qualification.rs:947-993 (its in-file tests) restated."""
+    from decimal import Decimal
+    q = mod("qualify")
+    assert q.parse_expected_value("NULL", "integer") == ("null", None)
+    assert q.parse_expected_value("hello", "string") == ("string", "hello")
+    assert q.parse_expected_value("42", "integer") == ("int", 42)
+    assert q.parse_expected_value("12.50", "decimal") == ("decimal", Decimal("12.5"))
+    tag, v = q.parse_expected_value("0.125", "float")
+    assert tag == "float" and abs(v - 0.125) < 1e-9
+    dec, flt = ("decimal", Decimal("1.2345")), ("float", 1.2345)
+    assert q.values_equal(dec, flt, "float") and q.values_equal(flt, dec, "float")
+    assert q.values_equal(("float", 1.0), ("float", 1.0 + 5e-10), "float")
+    assert not q.values_equal(("float", 1.0), ("float", 1.0 + 2e-9), "float")  # absolute tolerance 1e-9
+    assert not q.values_equal(("int", 1), ("float", 1.0), "integer")
+    d = q.diff_rows([[("int", 1)]], [[("int", 2)]], ["integer"])
+    assert len(d.missing) == 1 and len(d.extra) == 1
+    d = q.diff_rows([[("int", 1)], [("int", 2)]], [[("int", 2)], [("int", 1)]], ["integer"])  # order-insensitive
+    assert d.ok
+    with pytest.raises(ValueError):
+        q.kind_from_token("xyz")
+    rows = q.parse_answer_set("l_returnflag|cnt\nA |  3\n\nN|NULL\n", ["string", "integer"])
+    assert rows == [[("string", "A"), ("int", 3)], [("string", "N"), ("null", None)]]
