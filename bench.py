@@ -112,7 +112,7 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     stream_ptr = stream.cuda_stream
     q.set_depth(DEPTH)
     ex_tensor = None
-    if world > 1:
+    if world > 1 or os.environ.get("LLKV_BENCH_FORCE_COLLECTIVE"):  # the env knob rehearses the collective path on one GPU
         # zero-copy int64 views of the library's exchange ring for torch.distributed (RCCL)
         ptr, n = q.exchange_buffer()
         ex_tensor = [_tensor_from_ptr(torch, ptr + slot * n * 8, n) for slot in range(DEPTH)]
@@ -221,8 +221,9 @@ def main():
     tpch = importlib.import_module("rust-llkv_amd.tpch")
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("LLKV_BENCH_FORCE_COLLECTIVE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     rt.init(local_rank)
 
@@ -270,7 +271,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tpch, abi, main_res["query"], sf, sample)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -54,19 +54,30 @@ def parse_expected_value(text: str, kind: str):
         raise ValueError(f"unable to parse float '{text}': {e}")
 
 
-def engine_value(v, kind: str):
-    """An engine result cell → qualification value: ints stay ints, floats are floats (sum columns of
-    Float64 engines arrive as floats and meet Decimal expectations through the mixed rule)."""
+def date32_to_string(days: int) -> str:
+    """date32_to_string (qualification.rs:598-603)."""
+    import datetime
+    return (datetime.date(1970, 1, 1) + datetime.timedelta(days=int(days))).isoformat()
+
+
+def engine_value(v, kind: str, is_date: bool = False):
+    """extract_value (qualification.rs:342-353): the engine cell is read ACCORDING TO THE EXPECTED KIND —
+    string kind formats (dates as YYYY-MM-DD, integers as text), integer kind → int, decimal kind → exact
+    Decimal (Int64 exactly, Float64 through Decimal::from_f64), float kind → f64."""
     if v is None:
         return ("null", None)
-    if isinstance(v, str):
-        return ("string", v)
-    if isinstance(v, bool):
+    if kind == "string":
+        if is_date:
+            return ("string", date32_to_string(v))
+        return ("string", v if isinstance(v, str) else str(v))
+    if kind == "integer":
         return ("int", int(v))
-    if isinstance(v, int):
-        return ("int", v)
-    if isinstance(v, Decimal):
-        return ("decimal", v.normalize())
+    if kind == "decimal":
+        if isinstance(v, Decimal):
+            return ("decimal", v.normalize())
+        if isinstance(v, int):
+            return ("decimal", Decimal(v).normalize())
+        return ("decimal", Decimal(repr(float(v))).normalize())
     return ("float", float(v))
 
 
