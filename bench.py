@@ -58,14 +58,19 @@ def stage(rt, tpch, abi, dist, query, total_rows, scale, rank, world, row_begin_
 DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i while the GPU runs i+1..)
 
 
-def run_steps(q, steps, dist, stream_ptr, ex_tensors):
-    """K complete executions; every result is folded and finalized on the host inside the timed region."""
+def run_steps(q, steps, dist, stream_ptr, ex_tensors, torch=None, comm=None):
+    """K complete executions; every result is folded and finalized on the host inside the timed region.
+    The scan runs on the compute stream; fold → [RCCL all-reduce] → copy-out run beside the next scan."""
     rows, outstanding = None, 0
     for i in range(steps):
         q.launch(stream_ptr)
         if ex_tensors is not None:
-            dist.all_reduce(ex_tensors[i % DEPTH])  # ncclSum over int64 lanes: exact concatenation of shard states
-        q.submit(stream_ptr)
+            q.wait_folded(comm.cuda_stream)
+            with torch.cuda.stream(comm):
+                dist.all_reduce(ex_tensors[i % DEPTH])  # ncclSum over int64 lanes: exact concatenation of shard states
+            q.submit(comm.cuda_stream)
+        else:
+            q.submit(0)
         outstanding += 1
         if outstanding == DEPTH:
             rows = q.collect()
@@ -117,13 +122,14 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
         ptr, n = q.exchange_buffer()
         ex_tensor = [_tensor_from_ptr(torch, ptr + slot * n * 8, n) for slot in range(DEPTH)]
 
-    run_steps(q, warmup, dist, stream_ptr, ex_tensor)
+    comm = torch.cuda.Stream() if ex_tensor is not None else None
+    run_steps(q, warmup, dist, stream_ptr, ex_tensor, torch, comm)
     q.set_profiling(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows = run_steps(q, steps, dist, stream_ptr, ex_tensor)
+    rows = run_steps(q, steps, dist, stream_ptr, ex_tensor, torch, comm)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

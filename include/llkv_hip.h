@@ -308,9 +308,8 @@ llkv_status llkv_hip_query_prepare_groupby(const llkv_hip_table *table,
                                            int32_t order_by_keys, llkv_hip_query **out);
 void llkv_hip_query_free(llkv_hip_query *query);
 
-/* Enqueue the kernels of one execution on `hip_stream` (a hipStream_t, NULL =
- * the library's own stream).  On return the per-shard partial state is being
- * written to the exchange buffer.                                            */
+/* Enqueue one execution: the fused scan on `hip_stream` (a hipStream_t, NULL =
+ * the library's own stream), the octant fold on the query's side stream.     */
 llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream);
 /* Device buffer of `len` int64 lanes holding this rank's partial aggregate
  * state, zero where another rank owns the lane.  With world > 1 the caller
@@ -329,6 +328,11 @@ llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream);
  * OLDEST submitted execution; results readable until the next collect).
  * finish() = submit + collect everything outstanding.                         */
 llkv_status llkv_hip_query_set_depth(llkv_hip_query *query, uint32_t depth);
+/* The octant fold runs on a side stream of the query.  wait_folded makes `hip_stream`
+ * wait for the exchange image of the latest launch (call it before an all-reduce issued
+ * on a communication stream); submit(hip_stream) orders the copy-out after the fold and
+ * after prior work on `hip_stream` (NULL = the side stream itself, single-GPU case).   */
+llkv_status llkv_hip_query_wait_folded(llkv_hip_query *query, void *hip_stream);
 llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream);
 llkv_status llkv_hip_query_collect(llkv_hip_query *query);
 

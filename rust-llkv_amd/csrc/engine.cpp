@@ -199,6 +199,10 @@ Query::~Query() {
   if (h_exchange) (void)hipHostFree(h_exchange);
   for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto &e : copied) if (e) (void)hipEventDestroy(e);
+  for (auto &e : ev_main) if (e) (void)hipEventDestroy(e);
+  for (auto &e : ev_fold) if (e) (void)hipEventDestroy(e);
+  for (auto &e : ev_pfree) if (e) (void)hipEventDestroy(e);
+  if (side) (void)hipStreamDestroy(side);
 }
 
 static uint32_t pick_tile_rows(const LoweredPlan &p) {
@@ -251,7 +255,16 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->params.n_tiles = ts->n_tiles;
 
   const size_t lanes = (size_t)p.lanes;
-  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, std::max<size_t>(1, lanes * ts->n_tiles) * sizeof(uint64_t)));
+  q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles);
+  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, 2 * q->partials_len * sizeof(uint64_t)));
+  {
+    int lo = 0, hi = 0; // the side stream gets the highest priority: its tiny kernels slip in as scan blocks retire
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&q->side, hipStreamNonBlocking, hi));
+  }
+  for (auto &e : q->ev_main) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : q->ev_fold) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : q->ev_pfree) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
   HIP_TRY(hipMalloc((void **)&q->d_exchange, ring_bytes));
   HIP_TRY(hipMemsetAsync(q->d_exchange, 0, ring_bytes, g_ctx.stream));
@@ -274,12 +287,17 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   return LLKV_OK;
 }
 
+// One execution: the fused scan on the caller's stream, the octant fold on the query's side stream
+// (ordered by events), so that the fold / collective / copy-out of execution i overlap the scan of i+1.
 int Query::launch(hipStream_t stream) {
   if (!stream) stream = g_ctx.stream;
   if (n_launched - n_collected >= depth)
     return set_error(LLKV_INVALID_ARGUMENT, "query pipeline is full: collect a finished execution first (depth " + std::to_string(depth) + ")");
+  const uint32_t slot = (uint32_t)(n_launched % depth);
+  const uint32_t pb = (uint32_t)(n_launched & 1);
   const bool run_main = !plan.always_false && tiles->n_tiles > 0;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  if (n_launched >= 2) HIP_TRY(hipStreamWaitEvent(stream, ev_pfree[pb], 0)); // the fold two executions back released this image
   if (profiling && run_main) {
     if (events_used == events.size()) {
       HIP_TRY(hipEventCreate(&ev.first));
@@ -290,19 +308,35 @@ int Query::launch(hipStream_t stream) {
     HIP_TRY(hipEventRecord(ev.first, stream));
   }
   if (run_main) {
-    if (entry) HIP_TRY(entry->launch(params, stream));
+    ScanParams p = params;
+    p.tile_partials = d_tile_partials + pb * partials_len;
+    if (entry) HIP_TRY(entry->launch(p, stream));
     else {
-      int rc = jit_launch(jit, params, stream);
+      int rc = jit_launch(jit, p, stream);
       if (rc) return rc;
     }
     if (ev.second) HIP_TRY(hipEventRecord(ev.second, stream));
   }
+  HIP_TRY(hipEventRecord(ev_main[slot], stream));
+  HIP_TRY(hipStreamWaitEvent(side, ev_main[slot], 0));
   FoldParams f = fold;
-  f.exchange = d_exchange + (n_launched % depth) * exchange_len();
+  f.tile_partials = d_tile_partials + pb * partials_len;
+  f.exchange = d_exchange + slot * exchange_len();
   if (!run_main) f.n_tiles = 0, std::fill(std::begin(f.octant_tile_begin), std::end(f.octant_tile_begin), 0u);
-  HIP_TRY(launch_fold_octants(f, stream));
+  HIP_TRY(launch_fold_octants(f, side));
+  HIP_TRY(hipEventRecord(ev_fold[slot], side));
+  HIP_TRY(hipEventRecord(ev_pfree[pb], side));
   launches++;
   n_launched++;
+  return LLKV_OK;
+}
+
+// Make `stream` wait until the exchange image of the most recent launch is complete (for a caller
+// that runs the all-reduce on its own communication stream).
+int Query::wait_folded(hipStream_t stream) {
+  if (n_launched == 0) return set_error(LLKV_INVALID_ARGUMENT, "no execution launched");
+  if (!stream) stream = g_ctx.stream;
+  HIP_TRY(hipStreamWaitEvent(stream, ev_fold[(n_launched - 1) % depth], 0));
   return LLKV_OK;
 }
 
@@ -431,9 +465,10 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
 // Enqueue the copy-out of the oldest launched-but-not-submitted execution (after the caller's
 // collective, if any, on the same stream).
 int Query::submit(hipStream_t stream) {
-  if (!stream) stream = g_ctx.stream;
   if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "submit without a launched execution");
   const uint32_t slot = (uint32_t)(n_submitted % depth);
+  if (!stream) stream = side; // already ordered after the fold
+  else HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
   const size_t bytes = exchange_len() * sizeof(uint64_t);
   HIP_TRY(hipMemcpyAsync(h_exchange + slot * exchange_len(), d_exchange + slot * exchange_len(), bytes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipEventRecord(copied[slot], stream));
@@ -722,6 +757,11 @@ llkv_status llkv_hip_query_set_depth(llkv_hip_query *query, uint32_t depth) {
   q->depth = depth;
   q->n_launched = q->n_submitted = q->n_collected = 0;
   return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_wait_folded(llkv_hip_query *query, void *hip_stream) {
+  if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
+  return (llkv_status) reinterpret_cast<Query *>(query)->wait_folded((hipStream_t)hip_stream);
 }
 
 llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream) {

@@ -91,13 +91,17 @@ struct Query {
   const TileSet *tiles = nullptr;
   ScanParams params;
   FoldParams fold;
-  uint64_t *d_tile_partials = nullptr;
   // ring of exchange images so that up to `depth` executions are in flight: the host
   // finalizes execution i while the GPU already runs i+1
   static constexpr uint32_t kMaxDepth = 8;
   uint32_t depth = 1;
   uint64_t n_launched = 0, n_submitted = 0, n_collected = 0;
   hipEvent_t copied[kMaxDepth] = {nullptr};
+  // two tile-partial images: the fold of execution i (side stream) overlaps the scan of i+1
+  uint64_t *d_tile_partials = nullptr; // [2][lanes][n_tiles]
+  size_t partials_len = 0;             // lanes * n_tiles
+  hipStream_t side = nullptr;          // fold + copy-out run here, off the scan's critical path
+  hipEvent_t ev_main[kMaxDepth] = {nullptr}, ev_fold[kMaxDepth] = {nullptr}, ev_pfree[2] = {nullptr, nullptr};
   uint64_t *d_exchange = nullptr; // [kMaxDepth][kOctants][lanes]
   uint8_t *d_lane_ops = nullptr;
   uint64_t *h_exchange = nullptr; // pinned, same shape
@@ -111,6 +115,7 @@ struct Query {
 
   size_t exchange_len() const { return (size_t)kOctants * (size_t)plan.lanes; }
   int launch(hipStream_t stream);
+  int wait_folded(hipStream_t stream);
   int submit(hipStream_t stream);
   int collect();
   int finish(hipStream_t stream);

@@ -233,6 +233,9 @@ class PreparedQuery:
     def set_depth(self, depth: int):
         check(lib().llkv_hip_query_set_depth(self._h, C.c_uint32(depth)))
 
+    def wait_folded(self, stream: int):
+        check(lib().llkv_hip_query_wait_folded(self._h, C.c_void_p(stream)))
+
     def submit(self, stream: int = 0):
         check(lib().llkv_hip_query_submit(self._h, C.c_void_p(stream)))
 
