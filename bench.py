@@ -60,7 +60,8 @@ DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i w
 
 def run_steps(q, steps, dist, stream_ptr, ex_tensors, torch=None, comm=None):
     """K complete executions; every result is folded and finalized on the host inside the timed region.
-    The scan runs on the compute stream; fold → [RCCL all-reduce] → copy-out run beside the next scan."""
+    One kernel per execution on the compute stream; with several ranks the RCCL all-reduce of the exchange
+    image and its copy-out run on a communication stream beside the next scan."""
     rows, outstanding = None, 0
     for i in range(steps):
         q.launch(stream_ptr)

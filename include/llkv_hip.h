@@ -336,6 +336,10 @@ llkv_status llkv_hip_query_wait_folded(llkv_hip_query *query, void *hip_stream);
 llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream);
 llkv_status llkv_hip_query_collect(llkv_hip_query *query);
 
+/* Blocking copy of the latest launch's exchange image (len_i64 lanes) to host memory —
+ * for hosts that run the collective themselves, and for tests.                        */
+llkv_status llkv_hip_query_read_exchange(llkv_hip_query *query, uint64_t *out, uint64_t len_i64);
+
 /* Same, from an exchange image the caller already holds on the host (for hosts
  * that run the collective themselves; `len_i64` must match exchange_buffer). */
 llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_t *exchange,

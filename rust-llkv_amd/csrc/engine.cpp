@@ -194,15 +194,13 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
 // ---------------------------------------------------------------------------------
 Query::~Query() {
   if (d_tile_partials) (void)hipFree(d_tile_partials);
-  if (d_exchange) (void)hipFree(d_exchange);
-  if (d_lane_ops) (void)hipFree(d_lane_ops);
+  if (d_exchange && !host_mapped) (void)hipFree(d_exchange);
+  if (d_octant_counter) (void)hipFree(d_octant_counter);
+  if (d_empty_image) (void)hipFree(d_empty_image);
   if (h_exchange) (void)hipHostFree(h_exchange);
   for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto &e : copied) if (e) (void)hipEventDestroy(e);
-  for (auto &e : ev_main) if (e) (void)hipEventDestroy(e);
   for (auto &e : ev_fold) if (e) (void)hipEventDestroy(e);
-  for (auto &e : ev_pfree) if (e) (void)hipEventDestroy(e);
-  if (side) (void)hipStreamDestroy(side);
 }
 
 static uint32_t pick_tile_rows(const LoweredPlan &p) {
@@ -255,77 +253,70 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->params.n_tiles = ts->n_tiles;
 
   const size_t lanes = (size_t)p.lanes;
-  q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles);
-  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, 2 * q->partials_len * sizeof(uint64_t)));
-  {
-    int lo = 0, hi = 0; // the side stream gets the highest priority: its tiny kernels slip in as scan blocks retire
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&q->side, hipStreamNonBlocking, hi));
-  }
-  for (auto &e : q->ev_main) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, std::max<size_t>(1, lanes * ts->n_tiles) * sizeof(uint64_t)));
   for (auto &e : q->ev_fold) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto &e : q->ev_pfree) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
-  HIP_TRY(hipMalloc((void **)&q->d_exchange, ring_bytes));
-  HIP_TRY(hipMemsetAsync(q->d_exchange, 0, ring_bytes, g_ctx.stream));
   for (auto &e : q->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_TRY(hipMalloc((void **)&q->d_lane_ops, lanes));
-  HIP_TRY(hipMemcpyAsync(q->d_lane_ops, p.lane_ops.data(), lanes, hipMemcpyHostToDevice, g_ctx.stream));
+  const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
   HIP_TRY(hipHostMalloc((void **)&q->h_exchange, ring_bytes, hipHostMallocDefault));
+  std::memset(q->h_exchange, 0, ring_bytes);
+  q->host_mapped = table->world == 1; // nobody else reads the image: let the kernel write it to the host directly
+  if (q->host_mapped) q->d_exchange = q->h_exchange;
+  else {
+    HIP_TRY(hipMalloc((void **)&q->d_exchange, ring_bytes));
+    HIP_TRY(hipMemsetAsync(q->d_exchange, 0, ring_bytes, g_ctx.stream));
+  }
+  HIP_TRY(hipMalloc((void **)&q->d_octant_counter, kOctantsHost * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(q->d_octant_counter, 0, kOctantsHost * sizeof(uint32_t), g_ctx.stream));
+  { // image of an execution that launches no workgroup: identities for owned octants, zero for the others
+    std::vector<uint64_t> img(kOctantsHost * lanes, 0);
+    for (int o = 0; o < kOctantsHost; ++o)
+      if ((table->owned_mask >> o) & 1u)
+        for (size_t l = 0; l < lanes; ++l) img[o * lanes + l] = p.lane_ops[l] == 2 ? 0x7FFFFFFFFFFFFFFFull : p.lane_ops[l] == 3 ? 0x8000000000000000ull : 0ull;
+    HIP_TRY(hipMalloc((void **)&q->d_empty_image, img.size() * 8));
+    HIP_TRY(hipMemcpy(q->d_empty_image, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   q->params.tile_partials = q->d_tile_partials;
-
-  std::memset(&q->fold, 0, sizeof q->fold);
-  q->fold.tile_partials = q->d_tile_partials;
-  q->fold.exchange = q->d_exchange;
-  q->fold.lane_ops = q->d_lane_ops;
-  for (int o = 0; o <= kOctantsHost; ++o) q->fold.octant_tile_begin[o] = ts->octant_tile_begin[o];
-  q->fold.n_tiles = ts->n_tiles;
-  q->fold.lanes = (uint32_t)lanes;
-  q->fold.owned_mask = table->owned_mask;
+  q->params.octant_counter = q->d_octant_counter;
+  for (int o = 0; o <= kOctantsHost; ++o) q->params.octant_tile_begin[o] = ts->octant_tile_begin[o];
+  q->params.owned_mask = table->owned_mask;
   *out = q.release();
   return LLKV_OK;
 }
 
-// One execution: the fused scan on the caller's stream, the octant fold on the query's side stream
-// (ordered by events), so that the fold / collective / copy-out of execution i overlap the scan of i+1.
+// One execution = ONE kernel: the fused scan, whose last workgroup per octant folds the octant's tile
+// partials into the exchange image of this slot (device memory, or pinned host memory when single-rank).
 int Query::launch(hipStream_t stream) {
   if (!stream) stream = g_ctx.stream;
   if (n_launched - n_collected >= depth)
     return set_error(LLKV_INVALID_ARGUMENT, "query pipeline is full: collect a finished execution first (depth " + std::to_string(depth) + ")");
   const uint32_t slot = (uint32_t)(n_launched % depth);
-  const uint32_t pb = (uint32_t)(n_launched & 1);
   const bool run_main = !plan.always_false && tiles->n_tiles > 0;
-  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-  if (n_launched >= 2) HIP_TRY(hipStreamWaitEvent(stream, ev_pfree[pb], 0)); // the fold two executions back released this image
-  if (profiling && run_main) {
-    if (events_used == events.size()) {
-      HIP_TRY(hipEventCreate(&ev.first));
-      HIP_TRY(hipEventCreate(&ev.second));
-      events.push_back(ev);
-    }
-    ev = events[events_used++];
-    HIP_TRY(hipEventRecord(ev.first, stream));
-  }
+  uint64_t *image = d_exchange + slot * exchange_len();
   if (run_main) {
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (profiling) {
+      if (events_used == events.size()) {
+        HIP_TRY(hipEventCreate(&ev.first));
+        HIP_TRY(hipEventCreate(&ev.second));
+        events.push_back(ev);
+      }
+      ev = events[events_used++];
+      HIP_TRY(hipEventRecord(ev.first, stream));
+    }
     ScanParams p = params;
-    p.tile_partials = d_tile_partials + pb * partials_len;
+    p.exchange = image;
     if (entry) HIP_TRY(entry->launch(p, stream));
     else {
       int rc = jit_launch(jit, p, stream);
       if (rc) return rc;
     }
     if (ev.second) HIP_TRY(hipEventRecord(ev.second, stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(image, d_empty_image, exchange_len() * sizeof(uint64_t), hipMemcpyDefault, stream));
   }
-  HIP_TRY(hipEventRecord(ev_main[slot], stream));
-  HIP_TRY(hipStreamWaitEvent(side, ev_main[slot], 0));
-  FoldParams f = fold;
-  f.tile_partials = d_tile_partials + pb * partials_len;
-  f.exchange = d_exchange + slot * exchange_len();
-  if (!run_main) f.n_tiles = 0, std::fill(std::begin(f.octant_tile_begin), std::end(f.octant_tile_begin), 0u);
-  HIP_TRY(launch_fold_octants(f, side));
-  HIP_TRY(hipEventRecord(ev_fold[slot], side));
-  HIP_TRY(hipEventRecord(ev_pfree[pb], side));
+  HIP_TRY(hipEventRecord(ev_fold[slot], stream));
+  slot_stream[slot] = stream;
   launches++;
   n_launched++;
   return LLKV_OK;
@@ -336,142 +327,23 @@ int Query::launch(hipStream_t stream) {
 int Query::wait_folded(hipStream_t stream) {
   if (n_launched == 0) return set_error(LLKV_INVALID_ARGUMENT, "no execution launched");
   if (!stream) stream = g_ctx.stream;
-  HIP_TRY(hipStreamWaitEvent(stream, ev_fold[(n_launched - 1) % depth], 0));
-  return LLKV_OK;
-}
-
-static inline uint64_t host_identity(int op) { return op == 2 ? 0x7FFFFFFFFFFFFFFFull : op == 3 ? 0x8000000000000000ull : 0ull; }
-static inline uint64_t host_combine(int op, uint64_t a, uint64_t b) {
-  switch (op) {
-  case 0: { double x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8); double z = x + y; uint64_t r; std::memcpy(&r, &z, 8); return r; }
-  case 1: return a + b;
-  case 2: return (int64_t)b < (int64_t)a ? b : a;
-  case 3: return (int64_t)b > (int64_t)a ? b : a;
-  default: return b > a ? b : a;
-  }
-}
-
-// Fold the 8 octant partials in octant order (same association for every GPU count).
-void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state) {
-  for (uint32_t l = 0; l < lanes; ++l) {
-    uint64_t v = host_identity(lane_ops[l]);
-    for (int o = 0; o < kOctantsHost; ++o) v = host_combine(lane_ops[l], v, exchange[(size_t)o * lanes + l]);
-    state[l] = v;
-  }
-}
-
-typedef __int128 i128;
-typedef unsigned __int128 u128;
-
-static double key_to_f64(int64_t key) {
-  int64_t b = key < 0 ? (key ^ 0x7FFFFFFFFFFFFFFFll) : key;
-  double d;
-  std::memcpy(&d, &b, 8);
-  return d;
-}
-
-// Finalize one aggregate of one group: AggregateAccumulator::finalize
-// llkv-aggregate/src/lib.rs:1488-1939 on the folded lane state.
-int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base, llkv_value *out, std::string *err) {
-  std::memset(out, 0, sizeof *out);
-  const int64_t rows = (int64_t)g[0];
-  const uint64_t *l = a.lane >= 0 ? g + base + a.lane : nullptr;
-  auto as_f64 = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
-  auto exact_sum = [&](int64_t *sum, const char *overflow_msg) -> int {
-    const i128 total = ((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0];
-    if (total > (i128)INT64_MAX || total < (i128)INT64_MIN) { *err = overflow_msg; return LLKV_INVALID_ARGUMENT; }
-    if ((u128)l[2] * (u128)(uint64_t)rows > (u128)INT64_MAX) {
-      // the reference's checked_add chain is order dependent: a prefix may overflow although
-      // the total fits.  Not decidable from the order-free state → caller's CPU route decides.
-      *err = "possible intermediate i64 overflow in SUM: order-dependent check is not on the GPU path";
-      return LLKV_UNSUPPORTED;
-    }
-    *sum = (int64_t)total;
-    return LLKV_OK;
-  };
-  switch (a.fin) {
-  case AggFinal::CountRows: out->dtype = LLKV_DT_INT64; out->i64 = rows; return LLKV_OK;
-  case AggFinal::CountNullsZero: out->dtype = LLKV_DT_INT64; out->i64 = 0; return LLKV_OK;
-  case AggFinal::SumI64Fast: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
-  case AggFinal::SumI64: {
-    out->dtype = LLKV_DT_INT64;
-    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
-    return exact_sum(&out->i64, "integer overflow");
-  }
-  case AggFinal::SumF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; out->f64 = rows ? as_f64(l[0]) : 0.0; return LLKV_OK;
-  case AggFinal::TotalF64: out->dtype = LLKV_DT_FLOAT64; out->f64 = as_f64(l[0]); return LLKV_OK;
-  case AggFinal::AvgI64Fast: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = (double)(int64_t)l[0] / (double)rows; return LLKV_OK;
-  case AggFinal::AvgI64: {
-    out->dtype = LLKV_DT_FLOAT64;
-    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
-    int64_t s;
-    int rc = exact_sum(&s, "AVG aggregate sum exceeds i64 range");
-    if (rc) return rc;
-    out->f64 = (double)s / (double)rows;
-    return LLKV_OK;
-  }
-  case AggFinal::AvgF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = as_f64(l[0]) / (double)rows; return LLKV_OK;
-  case AggFinal::MinI64: case AggFinal::MaxI64: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
-  case AggFinal::MinF64: case AggFinal::MaxF64: {
-    out->dtype = LLKV_DT_FLOAT64;
-    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
-    if (l[2] & 1u) { out->f64 = std::nan(""); return LLKV_OK; } // a leading NaN sticks (:1319-1330)
-    const uint64_t none = a.fin == AggFinal::MinF64 ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
-    if (l[0] == none) { out->f64 = std::nan(""); return LLKV_OK; } // unreachable: first row is not NaN
-    double v = key_to_f64((int64_t)l[0]);
-    if (v == 0.0 && l[1] != 0x7FFFFFFFFFFFFFFFull && (l[1] & 1u)) v = -0.0; // ±0 ties keep the earlier row
-    out->f64 = v;
-    return LLKV_OK;
-  }
-  }
-  return LLKV_INTERNAL;
-}
-
-int Query::finish_from_exchange(const uint64_t *exchange) {
-  const LoweredPlan &p = plan;
-  std::vector<uint64_t> state(p.lanes);
-  fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
-  groups.clear();
-  if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic overflowed on a selected row
-    return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
-  const int base = p.track_first ? 2 : 1;
-  for (uint32_t g = 0; g < p.ng; ++g) {
-    const uint64_t *gl = &state[(size_t)g * p.k];
-    if (p.grouped && gl[0] == 0) continue; // group never appeared
-    GroupResult gr;
-    gr.first_row = p.track_first ? gl[1] : 0;
-    if (p.grouped)
-      for (size_t k = 0; k < p.key_fields.size(); ++k) {
-        const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
-        const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
-        gr.keys.push_back(code < dict.size() ? dict[code] : std::string());
-      }
-    gr.values.resize(p.aggs.size());
-    for (size_t a = 0; a < p.aggs.size(); ++a) {
-      std::string err;
-      int rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err);
-      if (rc) return set_error(rc, err);
-    }
-    groups.push_back(std::move(gr));
-  }
-  if (p.grouped) {
-    // first-appearance order (llkv-executor/src/lib.rs:5065-5089), then ORDER BY keys ASC
-    if (p.track_first) std::sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
-    if (order_by_keys) std::stable_sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.keys < b.keys; });
-  }
+  const uint32_t slot = (uint32_t)((n_launched - 1) % depth);
+  if (stream != slot_stream[slot]) HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
   return LLKV_OK;
 }
 
 // Enqueue the copy-out of the oldest launched-but-not-submitted execution (after the caller's
-// collective, if any, on the same stream).
+// collective, if any, on `stream`).  Single-rank images already live in host memory.
 int Query::submit(hipStream_t stream) {
   if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "submit without a launched execution");
   const uint32_t slot = (uint32_t)(n_submitted % depth);
-  if (!stream) stream = side; // already ordered after the fold
-  else HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
-  const size_t bytes = exchange_len() * sizeof(uint64_t);
-  HIP_TRY(hipMemcpyAsync(h_exchange + slot * exchange_len(), d_exchange + slot * exchange_len(), bytes, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipEventRecord(copied[slot], stream));
+  if (!host_mapped) {
+    if (!stream) stream = slot_stream[slot];
+    else if (stream != slot_stream[slot]) HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
+    const size_t bytes = exchange_len() * sizeof(uint64_t);
+    HIP_TRY(hipMemcpyAsync(h_exchange + slot * exchange_len(), d_exchange + slot * exchange_len(), bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(copied[slot], stream));
+  }
   n_submitted++;
   return LLKV_OK;
 }
@@ -480,7 +352,7 @@ int Query::submit(hipStream_t stream) {
 int Query::collect() {
   if (n_collected >= n_submitted) return set_error(LLKV_INVALID_ARGUMENT, "collect without a submitted execution");
   const uint32_t slot = (uint32_t)(n_collected % depth);
-  HIP_TRY(hipEventSynchronize(copied[slot]));
+  HIP_TRY(hipEventSynchronize(host_mapped ? ev_fold[slot] : copied[slot]));
   n_collected++;
   return finish_from_exchange(h_exchange + slot * exchange_len());
 }
@@ -740,6 +612,18 @@ llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_
 llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream) {
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   return (llkv_status) reinterpret_cast<Query *>(query)->finish((hipStream_t)hip_stream);
+}
+
+llkv_status llkv_hip_query_read_exchange(llkv_hip_query *query, uint64_t *out, uint64_t len_i64) {
+  Query *q = reinterpret_cast<Query *>(query);
+  if (!q || !out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (q->n_launched == 0) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "no execution launched");
+  if (len_i64 != q->exchange_len()) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "exchange length mismatch");
+  const uint32_t slot = (uint32_t)((q->n_launched - 1) % q->depth);
+  if (hipEventSynchronize(q->ev_fold[slot]) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "event wait failed");
+  if (hipMemcpy(out, q->d_exchange + slot * q->exchange_len(), len_i64 * 8, hipMemcpyDefault) != hipSuccess)
+    return (llkv_status)set_error(LLKV_INTERNAL, "exchange copy failed");
+  return LLKV_OK;
 }
 
 llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_t *exchange, uint64_t len_i64) {

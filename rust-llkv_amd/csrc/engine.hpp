@@ -90,20 +90,19 @@ struct Query {
   JitKernel jit;
   const TileSet *tiles = nullptr;
   ScanParams params;
-  FoldParams fold;
   // ring of exchange images so that up to `depth` executions are in flight: the host
   // finalizes execution i while the GPU already runs i+1
   static constexpr uint32_t kMaxDepth = 8;
   uint32_t depth = 1;
   uint64_t n_launched = 0, n_submitted = 0, n_collected = 0;
   hipEvent_t copied[kMaxDepth] = {nullptr};
-  // two tile-partial images: the fold of execution i (side stream) overlaps the scan of i+1
-  uint64_t *d_tile_partials = nullptr; // [2][lanes][n_tiles]
-  size_t partials_len = 0;             // lanes * n_tiles
-  hipStream_t side = nullptr;          // fold + copy-out run here, off the scan's critical path
-  hipEvent_t ev_main[kMaxDepth] = {nullptr}, ev_fold[kMaxDepth] = {nullptr}, ev_pfree[2] = {nullptr, nullptr};
+  uint64_t *d_tile_partials = nullptr; // [lanes][n_tiles]
+  uint32_t *d_octant_counter = nullptr; // [kOctants] arrival tickets of the in-kernel fold
+  uint64_t *d_empty_image = nullptr;    // exchange image of an execution without tiles
+  hipEvent_t ev_fold[kMaxDepth] = {nullptr}; // exchange image of the slot complete
+  hipStream_t slot_stream[kMaxDepth] = {nullptr};
+  bool host_mapped = false;            // single rank: the kernel writes the image straight into pinned host memory
   uint64_t *d_exchange = nullptr; // [kMaxDepth][kOctants][lanes]
-  uint8_t *d_lane_ops = nullptr;
   uint64_t *h_exchange = nullptr; // pinned, same shape
   bool order_by_keys = false;
   uint32_t n_user_aggs = 0;

@@ -54,6 +54,11 @@ struct ScanParams {
   uint32_t ht_key_width;      // 4 or 8
   uint32_t ht_key_signed;
   uint32_t *aux_out32;        // probe-emit: matching slot per emitted row
+  // in-kernel octant fold (fused scan): the last workgroup of an octant to finish folds its tiles
+  uint64_t *exchange;         // [kOctants][lanes] image of this execution (device or host-mapped memory)
+  uint32_t *octant_counter;   // [kOctants] arrival tickets, zero between launches
+  uint32_t octant_tile_begin[kOctants + 1];
+  uint32_t owned_mask;        // octants of this rank; rows of the others are written as zero
 };
 
 constexpr int kMaxOuts = 8;
@@ -69,15 +74,5 @@ struct ProjParams {
   uint32_t pad_;
 };
 
-// Arguments of fold_octants_kernel.
-struct FoldParams {
-  const uint64_t *tile_partials; // [lanes][n_tiles]
-  uint64_t *exchange;            // [kOctants][lanes]
-  const uint8_t *lane_ops;       // [lanes]
-  uint32_t octant_tile_begin[kOctants + 1];
-  uint32_t n_tiles;
-  uint32_t lanes;
-  uint32_t owned_mask;
-};
 
 } // namespace llkv

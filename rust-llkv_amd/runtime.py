@@ -249,16 +249,10 @@ class PreparedQuery:
 
     def read_exchange(self, stream: int = 0) -> np.ndarray:
         """Copy of this rank's exchange image [8][lanes] (uint64 lanes) — test / host-collective helper."""
-        import torch
-        ptr, n = self.exchange_buffer()
-        torch.cuda.synchronize()
-
-        class _Raw:
-            pass
-
-        raw = _Raw()
-        raw.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(raw, device="cuda").cpu().numpy().view(np.uint64).reshape(8, -1).copy()
+        _, n = self.exchange_buffer()
+        out = np.zeros(int(n), dtype=np.uint64)
+        check(lib().llkv_hip_query_read_exchange(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint64(n)))
+        return out.reshape(8, -1)
 
     def finish_from_host(self, exchange: np.ndarray) -> List[GroupRow]:
         ex = np.ascontiguousarray(exchange, dtype=np.uint64).reshape(-1)
