@@ -322,6 +322,128 @@ int Query::launch(hipStream_t stream) {
   return LLKV_OK;
 }
 
+static inline uint64_t host_identity(int op) { return op == 2 ? 0x7FFFFFFFFFFFFFFFull : op == 3 ? 0x8000000000000000ull : 0ull; }
+static inline uint64_t host_combine(int op, uint64_t a, uint64_t b) {
+  switch (op) {
+  case 0: { double x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8); double z = x + y; uint64_t r; std::memcpy(&r, &z, 8); return r; }
+  case 1: return a + b;
+  case 2: return (int64_t)b < (int64_t)a ? b : a;
+  case 3: return (int64_t)b > (int64_t)a ? b : a;
+  default: return b > a ? b : a;
+  }
+}
+
+// Fold the 8 octant partials in octant order (same association for every GPU count).
+void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state) {
+  for (uint32_t l = 0; l < lanes; ++l) {
+    uint64_t v = host_identity(lane_ops[l]);
+    for (int o = 0; o < kOctantsHost; ++o) v = host_combine(lane_ops[l], v, exchange[(size_t)o * lanes + l]);
+    state[l] = v;
+  }
+}
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+static double key_to_f64(int64_t key) {
+  int64_t b = key < 0 ? (key ^ 0x7FFFFFFFFFFFFFFFll) : key;
+  double d;
+  std::memcpy(&d, &b, 8);
+  return d;
+}
+
+// Finalize one aggregate of one group: AggregateAccumulator::finalize
+// llkv-aggregate/src/lib.rs:1488-1939 on the folded lane state.
+int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base, llkv_value *out, std::string *err) {
+  std::memset(out, 0, sizeof *out);
+  const int64_t rows = (int64_t)g[0];
+  const uint64_t *l = a.lane >= 0 ? g + base + a.lane : nullptr;
+  auto as_f64 = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
+  auto exact_sum = [&](int64_t *sum, const char *overflow_msg) -> int {
+    const i128 total = ((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0];
+    if (total > (i128)INT64_MAX || total < (i128)INT64_MIN) { *err = overflow_msg; return LLKV_INVALID_ARGUMENT; }
+    if ((u128)l[2] * (u128)(uint64_t)rows > (u128)INT64_MAX) {
+      // the reference's checked_add chain is order dependent: a prefix may overflow although
+      // the total fits.  Not decidable from the order-free state → caller's CPU route decides.
+      *err = "possible intermediate i64 overflow in SUM: order-dependent check is not on the GPU path";
+      return LLKV_UNSUPPORTED;
+    }
+    *sum = (int64_t)total;
+    return LLKV_OK;
+  };
+  switch (a.fin) {
+  case AggFinal::CountRows: out->dtype = LLKV_DT_INT64; out->i64 = rows; return LLKV_OK;
+  case AggFinal::CountNullsZero: out->dtype = LLKV_DT_INT64; out->i64 = 0; return LLKV_OK;
+  case AggFinal::SumI64Fast: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
+  case AggFinal::SumI64: {
+    out->dtype = LLKV_DT_INT64;
+    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    return exact_sum(&out->i64, "integer overflow");
+  }
+  case AggFinal::SumF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; out->f64 = rows ? as_f64(l[0]) : 0.0; return LLKV_OK;
+  case AggFinal::TotalF64: out->dtype = LLKV_DT_FLOAT64; out->f64 = as_f64(l[0]); return LLKV_OK;
+  case AggFinal::AvgI64Fast: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = (double)(int64_t)l[0] / (double)rows; return LLKV_OK;
+  case AggFinal::AvgI64: {
+    out->dtype = LLKV_DT_FLOAT64;
+    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    int64_t s;
+    int rc = exact_sum(&s, "AVG aggregate sum exceeds i64 range");
+    if (rc) return rc;
+    out->f64 = (double)s / (double)rows;
+    return LLKV_OK;
+  }
+  case AggFinal::AvgF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = as_f64(l[0]) / (double)rows; return LLKV_OK;
+  case AggFinal::MinI64: case AggFinal::MaxI64: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
+  case AggFinal::MinF64: case AggFinal::MaxF64: {
+    out->dtype = LLKV_DT_FLOAT64;
+    if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    if (l[2] & 1u) { out->f64 = std::nan(""); return LLKV_OK; } // a leading NaN sticks (:1319-1330)
+    const uint64_t none = a.fin == AggFinal::MinF64 ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
+    if (l[0] == none) { out->f64 = std::nan(""); return LLKV_OK; } // unreachable: first row is not NaN
+    double v = key_to_f64((int64_t)l[0]);
+    if (v == 0.0 && l[1] != 0x7FFFFFFFFFFFFFFFull && (l[1] & 1u)) v = -0.0; // ±0 ties keep the earlier row
+    out->f64 = v;
+    return LLKV_OK;
+  }
+  }
+  return LLKV_INTERNAL;
+}
+
+int Query::finish_from_exchange(const uint64_t *exchange) {
+  const LoweredPlan &p = plan;
+  std::vector<uint64_t> state(p.lanes);
+  fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
+  groups.clear();
+  if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic overflowed on a selected row
+    return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  const int base = p.track_first ? 2 : 1;
+  for (uint32_t g = 0; g < p.ng; ++g) {
+    const uint64_t *gl = &state[(size_t)g * p.k];
+    if (p.grouped && gl[0] == 0) continue; // group never appeared
+    GroupResult gr;
+    gr.first_row = p.track_first ? gl[1] : 0;
+    if (p.grouped)
+      for (size_t k = 0; k < p.key_fields.size(); ++k) {
+        const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
+        const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
+        gr.keys.push_back(code < dict.size() ? dict[code] : std::string());
+      }
+    gr.values.resize(p.aggs.size());
+    for (size_t a = 0; a < p.aggs.size(); ++a) {
+      std::string err;
+      int rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err);
+      if (rc) return set_error(rc, err);
+    }
+    groups.push_back(std::move(gr));
+  }
+  if (p.grouped) {
+    // first-appearance order (llkv-executor/src/lib.rs:5065-5089), then ORDER BY keys ASC
+    if (p.track_first) std::sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
+    if (order_by_keys) std::stable_sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.keys < b.keys; });
+  }
+  return LLKV_OK;
+}
+
 // Make `stream` wait until the exchange image of the most recent launch is complete (for a caller
 // that runs the all-reduce on its own communication stream).
 int Query::wait_folded(hipStream_t stream) {
