@@ -60,25 +60,32 @@ DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i w
 
 def run_steps(q, steps, dist, stream_ptr, ex_tensors, torch=None, comm=None):
     """K complete executions; every result is folded and finalized on the host inside the timed region.
-    One kernel per execution on the compute stream; with several ranks the RCCL all-reduce of the exchange
-    image and its copy-out run on a communication stream beside the next scan."""
-    rows, outstanding = None, 0
-    for i in range(steps):
-        q.launch(stream_ptr)
+    Steady state = one kernel per execution on the compute stream (the scan of execution i folds the tile
+    partials of i-1); with several ranks the RCCL all-reduce of an execution's exchange image and its
+    copy-out run on a communication stream, one execution behind, beside the next scan."""
+    rows, launched, submitted, collected = None, 0, 0, 0
+
+    def exchange(slot):
         if ex_tensors is not None:
             q.wait_folded(comm.cuda_stream)
             with torch.cuda.stream(comm):
-                dist.all_reduce(ex_tensors[i % DEPTH])  # ncclSum over int64 lanes: exact concatenation of shard states
+                dist.all_reduce(ex_tensors[slot])  # ncclSum over int64 lanes: exact concatenation of shard states
             q.submit(comm.cuda_stream)
         else:
             q.submit(0)
-        outstanding += 1
-        if outstanding == DEPTH:
-            rows = q.collect()
-            outstanding -= 1
-    while outstanding:
-        rows = q.collect()
-        outstanding -= 1
+
+    for i in range(steps):
+        if launched - collected == DEPTH:
+            if submitted == collected:
+                exchange(submitted % DEPTH); submitted += 1
+            rows = q.collect(); collected += 1
+        q.launch(stream_ptr); launched += 1
+        if launched - submitted >= 2:  # the image of the previous execution completed with this launch
+            exchange(submitted % DEPTH); submitted += 1
+    while collected < launched:
+        if submitted == collected:
+            exchange(submitted % DEPTH); submitted += 1
+        rows = q.collect(); collected += 1
     return rows
 
 

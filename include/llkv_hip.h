@@ -308,11 +308,13 @@ llkv_status llkv_hip_query_prepare_groupby(const llkv_hip_table *table,
                                            int32_t order_by_keys, llkv_hip_query **out);
 void llkv_hip_query_free(llkv_hip_query *query);
 
-/* Enqueue one execution: the fused scan on `hip_stream` (a hipStream_t, NULL =
- * the library's own stream), the octant fold on the query's side stream.     */
+/* Enqueue one execution on `hip_stream` (a hipStream_t, NULL = the library's
+ * own stream).                                                               */
 llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream);
 /* Device buffer of `len` int64 lanes holding this rank's partial aggregate
- * state, zero where another rank owns the lane.  With world > 1 the caller
+ * state of the oldest execution awaiting submission (slot s of the ring lives
+ * at base + s·len, executions use slots round-robin), zero where another rank
+ * owns the lane.  With world > 1 the caller
  * all-reduces it (ncclSum over ncclInt64 — exact for every lane type because
  * exactly one rank contributes non-zero bits per lane) before finish.        */
 llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_ptr,
@@ -328,10 +330,13 @@ llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream);
  * OLDEST submitted execution; results readable until the next collect).
  * finish() = submit + collect everything outstanding.                         */
 llkv_status llkv_hip_query_set_depth(llkv_hip_query *query, uint32_t depth);
-/* The octant fold runs on a side stream of the query.  wait_folded makes `hip_stream`
- * wait for the exchange image of the latest launch (call it before an all-reduce issued
- * on a communication stream); submit(hip_stream) orders the copy-out after the fold and
- * after prior work on `hip_stream` (NULL = the side stream itself, single-GPU case).   */
+/* In steady state an execution is ONE kernel launch: the scan of execution i also folds
+ * the tile partials of execution i-1 (its first workgroups), so the exchange image of an
+ * execution completes with the NEXT launch — or with a small standalone fold when its
+ * result is requested first.  wait_folded makes `hip_stream` wait for the image of the
+ * oldest execution not yet submitted (call it before an all-reduce issued on a
+ * communication stream); submit(hip_stream) orders that execution's copy-out after
+ * prior work on `hip_stream` (NULL = the stream it was launched on).                   */
 llkv_status llkv_hip_query_wait_folded(llkv_hip_query *query, void *hip_stream);
 llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream);
 llkv_status llkv_hip_query_collect(llkv_hip_query *query);

@@ -29,6 +29,12 @@ int catalog_size() { return (int)(sizeof(kCatalog) / sizeof(kCatalog[0])) - 1; }
 const CatalogEntry *catalog_at(int i) { return i >= 0 && i < catalog_size() ? &kCatalog[i] : nullptr; }
 
 
+hipError_t launch_fold_octants(const FoldParams &f, hipStream_t stream) {
+  const uint32_t waves = kBlock / 64;
+  hipLaunchKernelGGL(fold_octants_kernel, dim3(kOctants, (f.lanes + waves - 1) / waves), dim3(kBlock), 0, stream, f);
+  return hipGetLastError();
+}
+
 hipError_t launch_exclusive_scan(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t stream) {
   hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, in, out, n);
   return hipGetLastError();

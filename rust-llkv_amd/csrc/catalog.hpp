@@ -10,6 +10,7 @@
 namespace llkv {
 
 struct ScanParams;
+struct FoldParams;
 
 using ScanLauncher = hipError_t (*)(const ScanParams &p, hipStream_t stream);
 
@@ -23,6 +24,8 @@ struct CatalogEntry {
 const CatalogEntry *catalog_find(const char *type_string);
 int catalog_size();
 const CatalogEntry *catalog_at(int i);
+
+hipError_t launch_fold_octants(const FoldParams &f, hipStream_t stream);
 
 // Exclusive scan of n uint64 counts (out has n + 1 entries, out[n] = total); one block.
 hipError_t launch_exclusive_scan(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t stream);

@@ -195,7 +195,7 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
 Query::~Query() {
   if (d_tile_partials) (void)hipFree(d_tile_partials);
   if (d_exchange && !host_mapped) (void)hipFree(d_exchange);
-  if (d_octant_counter) (void)hipFree(d_octant_counter);
+  if (d_lane_ops) (void)hipFree(d_lane_ops);
   if (d_empty_image) (void)hipFree(d_empty_image);
   if (h_exchange) (void)hipHostFree(h_exchange);
   for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -253,7 +253,10 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->params.n_tiles = ts->n_tiles;
 
   const size_t lanes = (size_t)p.lanes;
-  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, std::max<size_t>(1, lanes * ts->n_tiles) * sizeof(uint64_t)));
+  q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles);
+  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, 2 * q->partials_len * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void **)&q->d_lane_ops, lanes));
+  HIP_TRY(hipMemcpyAsync(q->d_lane_ops, p.lane_ops.data(), lanes, hipMemcpyHostToDevice, g_ctx.stream));
   for (auto &e : q->ev_fold) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : q->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
@@ -265,8 +268,6 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     HIP_TRY(hipMalloc((void **)&q->d_exchange, ring_bytes));
     HIP_TRY(hipMemsetAsync(q->d_exchange, 0, ring_bytes, g_ctx.stream));
   }
-  HIP_TRY(hipMalloc((void **)&q->d_octant_counter, kOctantsHost * sizeof(uint32_t)));
-  HIP_TRY(hipMemsetAsync(q->d_octant_counter, 0, kOctantsHost * sizeof(uint32_t), g_ctx.stream));
   { // image of an execution that launches no workgroup: identities for owned octants, zero for the others
     std::vector<uint64_t> img(kOctantsHost * lanes, 0);
     for (int o = 0; o < kOctantsHost; ++o)
@@ -277,22 +278,44 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   q->params.tile_partials = q->d_tile_partials;
-  q->params.octant_counter = q->d_octant_counter;
   for (int o = 0; o <= kOctantsHost; ++o) q->params.octant_tile_begin[o] = ts->octant_tile_begin[o];
   q->params.owned_mask = table->owned_mask;
+  std::memset(&q->fold, 0, sizeof q->fold);
+  q->fold.lane_ops = q->d_lane_ops;
+  for (int o = 0; o <= kOctantsHost; ++o) q->fold.octant_tile_begin[o] = ts->octant_tile_begin[o];
+  q->fold.n_tiles = ts->n_tiles;
+  q->fold.lanes = (uint32_t)lanes;
+  q->fold.owned_mask = table->owned_mask;
   *out = q.release();
   return LLKV_OK;
 }
 
-// One execution = ONE kernel: the fused scan, whose last workgroup per octant folds the octant's tile
-// partials into the exchange image of this slot (device memory, or pinned host memory when single-rank).
+// One execution = ONE kernel launch in steady state: the fused scan of execution i, whose first workgroups
+// also fold the tile partials of execution i-1 into that execution's exchange image (two partial images).
+// Whatever is still unfolded when its result is asked for is flushed by the standalone fold kernel.
+int Query::flush_pending() {
+  if (!pending) return LLKV_OK;
+  FoldParams f = fold;
+  f.tile_partials = d_tile_partials + pending_pb * partials_len;
+  f.exchange = d_exchange + pending_slot * exchange_len();
+  HIP_TRY(launch_fold_octants(f, pending_stream));
+  HIP_TRY(hipEventRecord(ev_fold[pending_slot], pending_stream));
+  pending = false;
+  return LLKV_OK;
+}
+
 int Query::launch(hipStream_t stream) {
   if (!stream) stream = g_ctx.stream;
   if (n_launched - n_collected >= depth)
     return set_error(LLKV_INVALID_ARGUMENT, "query pipeline is full: collect a finished execution first (depth " + std::to_string(depth) + ")");
   const uint32_t slot = (uint32_t)(n_launched % depth);
+  const uint32_t pb = (uint32_t)(n_launched & 1);
   const bool run_main = !plan.always_false && tiles->n_tiles > 0;
   uint64_t *image = d_exchange + slot * exchange_len();
+  const uint32_t fold_blocks = (uint32_t)kOctantsHost * (uint32_t)((plan.lanes + kBlock / 64 - 1) / (kBlock / 64));
+  bool piggy = false;
+  int rc;
+  if (pending && !(run_main && tiles->n_tiles >= fold_blocks && stream == pending_stream) && (rc = flush_pending())) return rc;
   if (run_main) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (profiling) {
@@ -305,17 +328,24 @@ int Query::launch(hipStream_t stream) {
       HIP_TRY(hipEventRecord(ev.first, stream));
     }
     ScanParams p = params;
-    p.exchange = image;
-    if (entry) HIP_TRY(entry->launch(p, stream));
-    else {
-      int rc = jit_launch(jit, p, stream);
-      if (rc) return rc;
+    p.tile_partials = d_tile_partials + pb * partials_len;
+    if (pending) {
+      p.prev_partials = d_tile_partials + pending_pb * partials_len;
+      p.prev_exchange = d_exchange + pending_slot * exchange_len();
+      piggy = true;
     }
+    if (entry) HIP_TRY(entry->launch(p, stream));
+    else if ((rc = jit_launch(jit, p, stream))) return rc;
     if (ev.second) HIP_TRY(hipEventRecord(ev.second, stream));
+    if (piggy) HIP_TRY(hipEventRecord(ev_fold[pending_slot], stream));
+    pending = true;
+    pending_slot = slot;
+    pending_pb = pb;
+    pending_stream = stream;
   } else {
     HIP_TRY(hipMemcpyAsync(image, d_empty_image, exchange_len() * sizeof(uint64_t), hipMemcpyDefault, stream));
+    HIP_TRY(hipEventRecord(ev_fold[slot], stream));
   }
-  HIP_TRY(hipEventRecord(ev_fold[slot], stream));
   slot_stream[slot] = stream;
   launches++;
   n_launched++;
@@ -444,12 +474,14 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
   return LLKV_OK;
 }
 
-// Make `stream` wait until the exchange image of the most recent launch is complete (for a caller
-// that runs the all-reduce on its own communication stream).
+// Make `stream` wait until the exchange image of the OLDEST not-yet-submitted execution is complete (for a
+// caller that runs the all-reduce on a communication stream before submit).
 int Query::wait_folded(hipStream_t stream) {
-  if (n_launched == 0) return set_error(LLKV_INVALID_ARGUMENT, "no execution launched");
+  if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "no launched execution awaits submission");
   if (!stream) stream = g_ctx.stream;
-  const uint32_t slot = (uint32_t)((n_launched - 1) % depth);
+  const uint32_t slot = (uint32_t)(n_submitted % depth);
+  int rc;
+  if (pending && pending_slot == slot && (rc = flush_pending())) return rc;
   if (stream != slot_stream[slot]) HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
   return LLKV_OK;
 }
@@ -460,6 +492,8 @@ int Query::submit(hipStream_t stream) {
   if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "submit without a launched execution");
   const uint32_t slot = (uint32_t)(n_submitted % depth);
   if (!host_mapped) {
+    int rc;
+    if (pending && pending_slot == slot && (rc = flush_pending())) return rc;
     if (!stream) stream = slot_stream[slot];
     else if (stream != slot_stream[slot]) HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
     const size_t bytes = exchange_len() * sizeof(uint64_t);
@@ -474,6 +508,8 @@ int Query::submit(hipStream_t stream) {
 int Query::collect() {
   if (n_collected >= n_submitted) return set_error(LLKV_INVALID_ARGUMENT, "collect without a submitted execution");
   const uint32_t slot = (uint32_t)(n_collected % depth);
+  int rc;
+  if (pending && pending_slot == slot && (rc = flush_pending())) return rc; // nothing was launched behind it
   HIP_TRY(hipEventSynchronize(host_mapped ? ev_fold[slot] : copied[slot]));
   n_collected++;
   return finish_from_exchange(h_exchange + slot * exchange_len());
@@ -724,9 +760,10 @@ llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream) {
 llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_ptr, uint64_t *len_i64) {
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   Query *q = reinterpret_cast<Query *>(query);
-  // image of the most recently launched execution
-  const uint64_t last = q->n_launched ? q->n_launched - 1 : 0;
-  if (device_ptr) *device_ptr = q->d_exchange + (last % q->depth) * q->exchange_len();
+  // image of the oldest execution awaiting submission (slot 0 before the first launch); consecutive
+  // executions use consecutive slots of one ring: slot s lives at base + s * len
+  const uint64_t cur = q->n_submitted < q->n_launched ? q->n_submitted : (q->n_launched ? q->n_launched - 1 : 0);
+  if (device_ptr) *device_ptr = q->d_exchange + (cur % q->depth) * q->exchange_len();
   if (len_i64) *len_i64 = (uint64_t)kOctantsHost * (uint64_t)q->plan.lanes;
   return LLKV_OK;
 }
@@ -742,6 +779,7 @@ llkv_status llkv_hip_query_read_exchange(llkv_hip_query *query, uint64_t *out, u
   if (q->n_launched == 0) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "no execution launched");
   if (len_i64 != q->exchange_len()) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "exchange length mismatch");
   const uint32_t slot = (uint32_t)((q->n_launched - 1) % q->depth);
+  if (q->pending && q->pending_slot == slot && q->flush_pending()) return LLKV_INTERNAL;
   if (hipEventSynchronize(q->ev_fold[slot]) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "event wait failed");
   if (hipMemcpy(out, q->d_exchange + slot * q->exchange_len(), len_i64 * 8, hipMemcpyDefault) != hipSuccess)
     return (llkv_status)set_error(LLKV_INTERNAL, "exchange copy failed");

@@ -96,8 +96,14 @@ struct Query {
   uint32_t depth = 1;
   uint64_t n_launched = 0, n_submitted = 0, n_collected = 0;
   hipEvent_t copied[kMaxDepth] = {nullptr};
-  uint64_t *d_tile_partials = nullptr; // [lanes][n_tiles]
-  uint32_t *d_octant_counter = nullptr; // [kOctants] arrival tickets of the in-kernel fold
+  // two tile-partial images: execution i+1 scans into one while its first workgroups fold the other
+  uint64_t *d_tile_partials = nullptr; // [2][lanes][n_tiles]
+  size_t partials_len = 0;
+  uint8_t *d_lane_ops = nullptr;       // standalone fold kernel
+  FoldParams fold;
+  bool pending = false;                // the latest scan's tile partials are not folded yet
+  uint32_t pending_slot = 0, pending_pb = 0;
+  hipStream_t pending_stream = nullptr;
   uint64_t *d_empty_image = nullptr;    // exchange image of an execution without tiles
   hipEvent_t ev_fold[kMaxDepth] = {nullptr}; // exchange image of the slot complete
   hipStream_t slot_stream[kMaxDepth] = {nullptr};
@@ -114,6 +120,7 @@ struct Query {
 
   size_t exchange_len() const { return (size_t)kOctants * (size_t)plan.lanes; }
   int launch(hipStream_t stream);
+  int flush_pending();
   int wait_folded(hipStream_t stream);
   int submit(hipStream_t stream);
   int collect();

@@ -424,68 +424,54 @@ template <class P> struct LaneOpTable {
 };
 
 // --------------------------------------------------------------------------
-// In-kernel octant fold.  Every workgroup publishes its tile partial write-through (sc1), drains,
-// and takes a ticket on its octant; the workgroup whose ticket is last folds the octant's tiles in
-// tile order (same association as a sequential loop) into the exchange image.  Hand-off form:
-// MI355X_MICROARCH.md "Valid forms", row 1 (sc1 stores → every storing wave's vmcnt(0) → workgroup
-// barrier → ONE lane's agent-scope atomic add; the last adder's workgroup loads sc1 after a barrier).
-// Workgroup 0 also writes the rows nobody folds: zero for octants of other ranks (so an integer
-// all-reduce concatenates the ranks' images), the lane identities for owned octants without tiles.
+// Octant fold: tile partials → exchange image [kOctants][lanes], one wave per (octant, lane), tiles
+// combined in tile order (8 loads in flight, same association as a sequential loop).  Rows of octants
+// this rank does not own are written as zero so that an integer-sum all-reduce of the image
+// concatenates the ranks' states bit-exactly; an owned octant without tiles yields the lane identity.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ void publish_partial(const ScanParams &p, int lane, uint64_t v) {
-  __hip_atomic_store(p.tile_partials + (uint64_t)lane * p.n_tiles + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void fold_one_lane(const uint64_t *tile_partials, uint64_t *exchange, const uint32_t *octant_tile_begin,
+                                              uint32_t owned_mask, uint32_t n_tiles, uint32_t lanes, uint32_t o, uint32_t lane, int op) {
+  const uint32_t l = threadIdx.x & 63;
+  if (!((owned_mask >> o) & 1u)) {
+    if (l == 0) exchange[(uint64_t)o * lanes + lane] = 0;
+    return;
+  }
+  const uint32_t t0 = octant_tile_begin[o], t1 = octant_tile_begin[o + 1];
+  const uint64_t *src = tile_partials + (uint64_t)lane * n_tiles;
+  uint64_t v = lane_identity(op);
+  uint32_t t = t0 + l;
+  for (; t + 448 < t1; t += 512) {
+    uint64_t a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = src[t + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v = lane_combine(op, v, a[i]);
+  }
+  for (; t < t1; t += 64) v = lane_combine(op, v, src[t]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+    const uint64_t ov = ((uint64_t)hi << 32) | lo;
+    v = (l & off) ? lane_combine(op, ov, v) : lane_combine(op, v, ov);
+  }
+  if (l == 0) exchange[(uint64_t)o * lanes + lane] = v;
 }
 
-template <class P> __device__ __forceinline__ void fold_octant_if_last(const ScanParams &p, uint32_t octant) {
-  constexpr int LANES = P::LANES;
+// Piggy-back form: workgroups [0, kOctants · ceil(LANES/4)) of a scan launch fold the PREVIOUS execution.
+template <class P> constexpr uint32_t piggyback_blocks() { return (uint32_t)kOctants * (uint32_t)((P::LANES + kBlock / 64 - 1) / (kBlock / 64)); }
+
+template <class P> __device__ __forceinline__ void piggyback_fold(const ScanParams &p) {
+  if (p.prev_partials == nullptr || blockIdx.x >= piggyback_blocks<P>()) return;
   constexpr LaneOpTable<P> ops{};
-  __shared__ uint32_t s_last;
-  const uint32_t tid = threadIdx.x;
-  if (blockIdx.x == 0) {
-    for (uint32_t i = tid; i < (uint32_t)(kOctants * LANES); i += kBlock) {
-      const uint32_t o = i / LANES, l = i % LANES;
-      const bool owned = (p.owned_mask >> o) & 1u;
-      const bool empty = p.octant_tile_begin[o + 1] == p.octant_tile_begin[o];
-      if (!owned) __hip_atomic_store(p.exchange + i, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (empty) __hip_atomic_store(p.exchange + i, lane_identity(ops.v[l]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t n_in_octant = p.octant_tile_begin[octant + 1] - p.octant_tile_begin[octant];
-    const uint32_t prev = __hip_atomic_fetch_add(p.octant_counter + octant, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t last = prev + 1u == n_in_octant ? 1u : 0u;
-    if (last) __hip_atomic_store(p.octant_counter + octant, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const uint32_t wave = tid >> 6, l = tid & 63;
-  const uint32_t t0 = p.octant_tile_begin[octant], t1 = p.octant_tile_begin[octant + 1];
-  for (int lane = (int)wave; lane < LANES; lane += kBlock / 64) {
-    const int op = ops.v[lane];
-    const uint64_t *src = p.tile_partials + (uint64_t)lane * p.n_tiles;
-    uint64_t v = lane_identity(op);
-    uint32_t t = t0 + l;
-    for (; t + 448 < t1; t += 512) { // 8 loads in flight, combined in tile order
-      uint64_t a[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = __hip_atomic_load(src + t + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v = lane_combine(op, v, a[i]);
-    }
-    for (; t < t1; t += 64) v = lane_combine(op, v, __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
-      const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
-      const uint64_t ov = ((uint64_t)hi << 32) | lo;
-      v = (l & off) ? lane_combine(op, ov, v) : lane_combine(op, v, ov);
-    }
-    if (l == 0) __hip_atomic_store(p.exchange + (uint64_t)octant * LANES + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const uint32_t o = blockIdx.x % kOctants;
+  const uint32_t lane = (blockIdx.x / kOctants) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (lane < (uint32_t)P::LANES)
+    fold_one_lane(p.prev_partials, p.prev_exchange, p.octant_tile_begin, p.owned_mask, p.n_tiles, (uint32_t)P::LANES, o, lane, ops.v[lane]);
+}
+
+__device__ __forceinline__ void publish_partial(const ScanParams &p, int lane, uint64_t v) {
+  p.tile_partials[(uint64_t)lane * p.n_tiles + blockIdx.x] = v;
 }
 
 // --------------------------------------------------------------------------
@@ -509,6 +495,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
   const TileDesc td = p.tiles[blockIdx.x];
   const uint32_t tid = threadIdx.x;
   const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
+  piggyback_fold<P>(p);
 
   for (uint32_t s = 0; s < nsteps; s += U) {
     Loaded ld[U];
@@ -584,7 +571,6 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
     }
     __syncthreads();
   }
-  fold_octant_if_last<P>(p, td.octant);
 }
 
 
@@ -624,6 +610,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
 
   const TileDesc td = p.tiles[blockIdx.x];
   const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
+  piggyback_fold<P>(p);
 
   for (uint32_t s = 0; s < nsteps; s += U) {
     Loaded ld[U];
@@ -675,7 +662,6 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
       if (rq == 0) publish_partial(p, lane, v);
     }
   }
-  fold_octant_if_last<P>(p, td.octant);
 }
 
 template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {
@@ -684,5 +670,12 @@ template <class P> __device__ __forceinline__ void fused_scan_body(const ScanPar
 }
 
 template <class P> __global__ __launch_bounds__(kBlock) void fused_scan_kernel(const ScanParams p) { fused_scan_body<P>(p); }
+
+// Standalone fold (flush of the last execution, and of tables with fewer tiles than fold workgroups).
+// grid = (kOctants, ceil(lanes / 4)).
+__global__ __launch_bounds__(kBlock) void fold_octants_kernel(const FoldParams f) {
+  const uint32_t lane = blockIdx.y * (kBlock / 64) + (threadIdx.x >> 6);
+  if (lane < f.lanes) fold_one_lane(f.tile_partials, f.exchange, f.octant_tile_begin, f.owned_mask, f.n_tiles, f.lanes, blockIdx.x, lane, f.lane_ops[lane]);
+}
 
 } // namespace llkv

@@ -54,11 +54,13 @@ struct ScanParams {
   uint32_t ht_key_width;      // 4 or 8
   uint32_t ht_key_signed;
   uint32_t *aux_out32;        // probe-emit: matching slot per emitted row
-  // in-kernel octant fold (fused scan): the last workgroup of an octant to finish folds its tiles
-  uint64_t *exchange;         // [kOctants][lanes] image of this execution (device or host-mapped memory)
-  uint32_t *octant_counter;   // [kOctants] arrival tickets, zero between launches
+  // piggy-back fold: the first workgroups of this launch fold the tile partials the PREVIOUS launch of
+  // the query left behind (visible through the kernel boundary — no atomics, no fences) while the rest of
+  // the grid already streams; the standalone fold_octants_kernel flushes the last execution.
+  const uint64_t *prev_partials; // [lanes][n_tiles] of the previous execution, or nullptr
+  uint64_t *prev_exchange;       // [kOctants][lanes] image to fold it into
   uint32_t octant_tile_begin[kOctants + 1];
-  uint32_t owned_mask;        // octants of this rank; rows of the others are written as zero
+  uint32_t owned_mask;           // octants of this rank; rows of the others are written as zero
 };
 
 constexpr int kMaxOuts = 8;
@@ -74,5 +76,16 @@ struct ProjParams {
   uint32_t pad_;
 };
 
+
+// Arguments of the standalone fold_octants_kernel.
+struct FoldParams {
+  const uint64_t *tile_partials; // [lanes][n_tiles]
+  uint64_t *exchange;            // [kOctants][lanes]
+  const uint8_t *lane_ops;       // [lanes]
+  uint32_t octant_tile_begin[kOctants + 1];
+  uint32_t n_tiles;
+  uint32_t lanes;
+  uint32_t owned_mask;
+};
 
 } // namespace llkv
