@@ -55,6 +55,7 @@ def stage(rt, tpch, abi, dist, query, total_rows, scale, rank, world, row_begin_
     return table, data
 
 
+PROFILE_EVERY = 4
 DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i while the GPU runs i+1..)
 
 
@@ -132,7 +133,7 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
 
     comm = torch.cuda.Stream() if ex_tensor is not None else None
     run_steps(q, warmup, dist, stream_ptr, ex_tensor, torch, comm)
-    q.set_profiling(True)
+    q.set_profiling(PROFILE_EVERY)  # HIP events around every 4th scan kernel of the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -363,6 +363,8 @@ llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, ui
 
 /* Measurement hooks (bench only): HIP-event time of the dominant kernel,
  * summed over launches since the last reset, and the launch count.           */
+/* enabled: 0 off, 1 every launch, n > 1 every n-th launch (fewer event packets
+ * between back-to-back kernels).                                               */
 llkv_status llkv_hip_query_set_profiling(llkv_hip_query *query, int32_t enabled);
 llkv_status llkv_hip_query_kernel_time(llkv_hip_query *query, double *total_ms,
                                        uint64_t *launches, const char **kernel_name);

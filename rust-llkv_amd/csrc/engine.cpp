@@ -318,7 +318,8 @@ int Query::launch(hipStream_t stream) {
   if (pending && !(run_main && tiles->n_tiles >= fold_blocks && stream == pending_stream) && (rc = flush_pending())) return rc;
   if (run_main) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    if (profiling) {
+    // event pairs bracket every `profile_every`-th scan: each record is a packet between back-to-back kernels
+    if (profiling && (launches % profile_every) == 0) {
       if (events_used == events.size()) {
         HIP_TRY(hipEventCreate(&ev.first));
         HIP_TRY(hipEventCreate(&ev.second));
@@ -844,6 +845,7 @@ llkv_status llkv_hip_query_set_profiling(llkv_hip_query *query, int32_t enabled)
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   Query *q = reinterpret_cast<Query *>(query);
   q->profiling = enabled != 0;
+  q->profile_every = enabled > 1 ? (uint32_t)enabled : 1u;
   q->events_used = 0;
   return LLKV_OK;
 }

@@ -114,6 +114,7 @@ struct Query {
   uint32_t n_user_aggs = 0;
   std::vector<GroupResult> groups;
   bool profiling = false;
+  uint32_t profile_every = 1; // bracket every n-th scan with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   uint64_t launches = 0;

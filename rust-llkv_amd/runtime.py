@@ -286,7 +286,8 @@ class PreparedQuery:
         self.launch(stream)
         return self.finish(stream)
 
-    def set_profiling(self, enabled: bool):
+    def set_profiling(self, enabled):
+        """False/0 off, True/1 every launch, n > 1: HIP events around every n-th scan."""
         check(lib().llkv_hip_query_set_profiling(self._h, C.c_int32(int(enabled))))
 
     def kernel_time(self):
