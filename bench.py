@@ -282,7 +282,7 @@ def main():
             r["prepared"].close(); r["table"].close()
         out["also"] = also
         if not args.no_cpu_baseline:
-            sample = args.cpu_sample_rows or (3_000_000 if main_res["query"].grouped else 6_000_000)
+            sample = args.cpu_sample_rows or (40_000_000 if main_res["query"].grouped else 60_000_000)  # ≈10–20 s of CPU work
             out["cpu_baseline"] = cpu_baseline(tpch, abi, main_res["query"], sf, sample)
     if rank == 0:
         print(json.dumps(out))
