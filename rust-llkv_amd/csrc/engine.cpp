@@ -456,8 +456,15 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
     if (p.grouped)
       for (size_t k = 0; k < p.key_fields.size(); ++k) {
         const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
-        const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
-        gr.keys.push_back(code < dict.size() ? dict[code] : std::string());
+        GroupKey gk;
+        if (p.key_is_int[k]) {
+          gk.is_int = true;
+          gk.i = p.key_bases[k] + (int64_t)code;
+        } else {
+          const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
+          gk.s = code < dict.size() ? dict[code] : std::string();
+        }
+        gr.keys.push_back(std::move(gk));
       }
     gr.values.resize(p.aggs.size());
     for (size_t a = 0; a < p.aggs.size(); ++a) {
@@ -828,8 +835,9 @@ llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group
   if (!q || !out || group >= q->groups.size() || key >= q->groups[group].keys.size())
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/key index out of range");
   std::memset(out, 0, sizeof *out);
-  out->dtype = LLKV_DT_UTF8;
-  out->str = q->groups[group].keys[key].c_str();
+  const GroupKey &gk = q->groups[group].keys[key];
+  if (gk.is_int) { out->dtype = LLKV_DT_INT64; out->i64 = gk.i; }
+  else { out->dtype = LLKV_DT_UTF8; out->str = gk.s.c_str(); }
   return LLKV_OK;
 }
 

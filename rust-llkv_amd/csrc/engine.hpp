@@ -77,9 +77,16 @@ int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream);
 int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t bytes, hipStream_t stream);
 void jit_shutdown();
 
+struct GroupKey { // GroupKeyValue: String or Int (llkv-executor/src/lib.rs:99-106)
+  bool is_int = false;
+  int64_t i = 0;
+  std::string s;
+  bool operator<(const GroupKey &o) const { return is_int ? i < o.i : s < o.s; }
+  bool operator==(const GroupKey &o) const { return is_int ? i == o.i : s == o.s; }
+};
 struct GroupResult {
   uint64_t first_row = 0;
-  std::vector<std::string> keys;
+  std::vector<GroupKey> keys;
   std::vector<llkv_value> values;
 };
 

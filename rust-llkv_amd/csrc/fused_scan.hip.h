@@ -289,6 +289,10 @@ template <class P> struct Not { // domain = all rows on this path (no NULLs stag
 template <int S> struct KeyCode {
   static __device__ __forceinline__ uint32_t code(Ctx &c, int j) { return c.get<U8>(S, j); }
 };
+// Integer key with a small statistics-bounded range: code = value − column minimum.
+template <int S, class Ty, class Base> struct KeyInt {
+  static __device__ __forceinline__ uint32_t code(Ctx &c, int j) { return (uint32_t)((int64_t)c.get<Ty>(S, j) - (int64_t)Base::eval(c, j)); }
+};
 // FIRST = 1 keeps the row id of each group's first row (first-appearance output order,
 // llkv-executor/src/lib.rs:5065-5089); with ORDER BY on the keys it is not needed.
 template <int NG_, int FIRST_, class... Ks> struct Keys {

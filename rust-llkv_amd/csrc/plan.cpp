@@ -14,7 +14,7 @@ typedef unsigned __int128 u128;
 static constexpr int kMaxColsHost = 8;
 static constexpr int kMaxLitsHost = 16;
 static constexpr int kMaxKeysHost = 4;
-static constexpr uint32_t kMaxDenseGroups = 8;
+static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
 
 const char *dtype_name(int32_t dt) {
   switch (dt) {
@@ -463,16 +463,35 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       if (!probe) return L.fail(LLKV_INVALID_ARGUMENT, "column '" + std::to_string(key_fields[k]) + "' not found in GROUP BY input");
       if (probe->dtype == LLKV_DT_FLOAT64 || probe->dtype == LLKV_DT_FLOAT32)
         return L.fail(LLKV_INVALID_ARGUMENT, std::string("GROUP BY does not support column type ") + dtype_name(probe->dtype));
-      if (probe->dtype != LLKV_DT_UTF8) return L.fail(LLKV_UNSUPPORTED, "dense GROUP BY needs dictionary-coded keys (integer keys take the hash path)");
+      // GroupKeyValue (llkv-executor/src/lib.rs:99-106, 9362-9456): Utf8 → String, every integer width and
+      // Date32 → Int.  Dense ids come from the dictionary code, or from value − column minimum for
+      // integer columns whose staging statistics bound the range.
+      const bool int_key = probe->dtype == LLKV_DT_INT64 || probe->dtype == LLKV_DT_INT32 || probe->dtype == LLKV_DT_DATE32;
+      if (probe->dtype != LLKV_DT_UTF8 && !int_key) return L.fail(LLKV_UNSUPPORTED, std::string("dense GROUP BY over ") + dtype_name(probe->dtype));
+      if (int_key) {
+        if (!probe->has_stats) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key without column statistics (hash path)");
+        const unsigned __int128 range = (unsigned __int128)((__int128)probe->max_i - (__int128)probe->min_i) + 1;
+        if (range > 256) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key spans more than 256 values (hash path)");
+      }
       if ((rc = L.slot_of(key_fields[k], &ci, &slot))) return rc;
-      uint32_t card = (uint32_t)(ci->dictionary.empty() ? 1 : ci->dictionary.size());
+      uint32_t card;
+      if (int_key) {
+        card = (uint32_t)((__int128)ci->max_i - (__int128)ci->min_i + 1);
+        std::string base;
+        if ((rc = L.lit_i(ci->min_i, &base))) return rc;
+        nodes += ",KeyInt<" + std::to_string(slot) + "," + dtype_tag(ci->dtype) + "," + base + ">";
+      } else {
+        card = (uint32_t)(ci->dictionary.empty() ? 1 : ci->dictionary.size());
+        nodes += ",KeyCode<" + std::to_string(slot) + ">";
+      }
       p.key_fields.push_back(key_fields[k]);
       p.key_slots.push_back((uint32_t)slot);
       p.key_cards.push_back(card);
+      p.key_bases.push_back(int_key ? ci->min_i : 0);
+      p.key_is_int.push_back(int_key ? 1 : 0);
       ng *= card;
-      nodes += ",KeyCode<" + std::to_string(slot) + ">";
     }
-    if (ng > kMaxDenseGroups) return L.fail(LLKV_UNSUPPORTED, "more than 8 dense groups (" + std::to_string(ng) + ")");
+    if (ng > kMaxDenseGroups) return L.fail(LLKV_UNSUPPORTED, "more than 64 dense groups (" + std::to_string(ng) + ")");
     p.ng = (uint32_t)ng;
     p.key_strides.assign(n_keys, 1);
     for (int k = (int)n_keys - 2; k >= 0; --k) p.key_strides[k] = p.key_strides[k + 1] * p.key_cards[k + 1];

@@ -494,3 +494,26 @@ def test_q1_qualifies_against_an_oracle_answer_set(rt, orc, abi, tpch):
     diff, elapsed = qual.qualify(run, "\n".join(lines), qual.Q1_TOKENS)
     assert diff.ok, (diff.missing, diff.extra)
     assert elapsed > 0
+
+
+def test_integer_and_multi_key_group_by(rt, orc, abi, tpch):
+    """GroupKeyValue::Int keys (every integer width and Date32 collapse to Int, llkv-executor/src/lib.rs:9362-9456)
+    through dense ids from the staging statistics; up to 64 dense groups in the LDS accumulator image."""
+    n = 100_000
+    d = tpch.gen_lineitem(n, 0.02)
+    rng = np.random.default_rng(5)
+    day = (9000 + rng.integers(0, 9, size=n)).astype(np.int32)
+    cols = [(4, abi.DT_INT64, d["l_linenumber"]), (9, abi.DT_UTF8, d["l_returnflag"]), (5, abi.DT_INT64, d["l_quantity"]),
+            (6, abi.DT_FLOAT64, d["l_extendedprice"]), (20, abi.DT_DATE32, day)]
+    ht, ot = stage_both(rt, orc, abi, cols, tpch.chunk_rows(n, 8192))
+    A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+    aggs = [A.count_star(), A.sum(5), A.avg(6), A.min(5), A.max(6)]
+    for keys, pred in (([4], None), ([4, 9], [F(5, O.LessThan(30))]), ([20], None), ([9, 20], [F(6, O.GreaterThan(20000.0))])):
+        for ordered in (True, False):
+            got, want = rt.groupby(ht, pred, keys, aggs, ordered), orc.groupby(ot, pred, keys, aggs, ordered)
+            assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (keys, ordered)
+            for g, w in zip(got, want):
+                assert_values(g.values, w.values, str(keys))
+    with pytest.raises(abi.LlkvError) as e:  # l_quantity × l_linenumber × day = 50·7·9 groups: hash path, not built
+        rt.groupby(ht, None, [5, 4, 20], [A.count_star()])
+    assert e.value.kind == "Unsupported"
