@@ -10,6 +10,7 @@
 // There is no CPU fallback in here: without a HIP device every data-path call fails
 // with LLKV_NO_DEVICE.
 #include "engine.hpp"
+#include "join.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -232,6 +233,15 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, /*track_first=*/!order_by_keys, &q->plan, &err);
   if (rc) return set_error(rc, err);
   const LoweredPlan &p = q->plan;
+  if (!grouped) {
+    q->exact_plans.resize(n_aggs);
+    for (uint32_t a = 0; a < n_aggs; ++a)
+      if (p.aggs[a].fin == AggFinal::SumI64 || p.aggs[a].fin == AggFinal::AvgI64) {
+        std::string ignore;
+        if (lower_emit(resolve, filters, n_filters, ops, n_ops, aggs[a].expr, aggs[a].expr_len, &q->exact_plans[a], &ignore) != LLKV_OK)
+          q->exact_plans[a] = LoweredPlan{};
+      }
+  }
 
   if (!p.always_false) {
     q->entry = std::getenv("LLKV_HIP_FORCE_JIT") ? nullptr : catalog_find(p.type_string.c_str());
@@ -385,7 +395,7 @@ static double key_to_f64(int64_t key) {
 
 // Finalize one aggregate of one group: AggregateAccumulator::finalize
 // llkv-aggregate/src/lib.rs:1488-1939 on the folded lane state.
-int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base, llkv_value *out, std::string *err) {
+int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base, llkv_value *out, std::string *err, bool prefixes_checked) {
   std::memset(out, 0, sizeof *out);
   const int64_t rows = (int64_t)g[0];
   const uint64_t *l = a.lane >= 0 ? g + base + a.lane : nullptr;
@@ -393,7 +403,7 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   auto exact_sum = [&](int64_t *sum, const char *overflow_msg) -> int {
     const i128 total = ((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0];
     if (total > (i128)INT64_MAX || total < (i128)INT64_MIN) { *err = overflow_msg; return LLKV_INVALID_ARGUMENT; }
-    if ((u128)l[2] * (u128)(uint64_t)rows > (u128)INT64_MAX) {
+    if (!prefixes_checked && (u128)l[2] * (u128)(uint64_t)rows > (u128)INT64_MAX) {
       // the reference's checked_add chain is order dependent: a prefix may overflow although
       // the total fits.  Not decidable from the order-free state → caller's CPU route decides.
       *err = "possible intermediate i64 overflow in SUM: order-dependent check is not on the GPU path";
@@ -440,6 +450,57 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   return LLKV_INTERNAL;
 }
 
+// Exact replay of the reference's sequential checked_add chain (llkv-aggregate/src/lib.rs:801-830) for one
+// aggregate: selected argument values in row order → 128-bit inclusive scan → any prefix outside i64?
+int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
+  if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "possible intermediate i64 overflow in SUM: the order-dependent check needs the whole table on one rank");
+  const LoweredPlan &ep = exact_plans[agg];
+  hipStream_t s = g_ctx.stream;
+  *overflow = false;
+  if (ep.always_false || table->local_rows == 0) return LLKV_OK;
+  JitKernel k;
+  std::string err;
+  int rc = jit_compile(JitKind::Emit, ep.type_string, &k, &err);
+  if (rc) return set_error(rc, err);
+  const TileSet *ts = nullptr;
+  if ((rc = get_tileset(*table, 8192, &ts))) return rc;
+  const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
+  struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } counts, offsets, vals, prefix, flag, tmp;
+  HIP_TRY(hipMalloc(&counts.p, (size_t)n_slots * 8));
+  HIP_TRY(hipMalloc(&offsets.p, (size_t)(n_slots + 1) * 8));
+  ScanParams sp;
+  std::memset(&sp, 0, sizeof sp);
+  for (size_t i = 0; i < ep.slot_fields.size(); ++i) sp.col[i] = table->cols.at(ep.slot_fields[i]).d_values;
+  for (size_t i = 0; i < ep.lit_i.size(); ++i) sp.lit_i[i] = ep.lit_i[i];
+  for (size_t i = 0; i < ep.lit_f.size(); ++i) sp.lit_f[i] = ep.lit_f[i];
+  sp.tiles = ts->d_tiles;
+  sp.n_tiles = ts->n_tiles;
+  sp.sub_rows = 8192 / (kBlock / 64);
+  sp.tile_partials = (uint64_t *)counts.p;
+  if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &sp, sizeof sp, s))) return rc;
+  HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, s));
+  uint64_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n == 0) return LLKV_OK;
+  HIP_TRY(hipMalloc(&vals.p, n * 8));
+  HIP_TRY(hipMalloc(&prefix.p, n * 16));
+  HIP_TRY(hipMalloc(&flag.p, 4));
+  HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
+  sp.aux_in = (const uint64_t *)offsets.p;
+  sp.aux_out = (uint64_t *)vals.p;
+  if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &sp, sizeof sp, s))) return rc;
+  size_t tb = 0;
+  HIP_TRY(hj_prefix_overflow(nullptr, &tb, (const int64_t *)vals.p, n, prefix.p, (uint32_t *)flag.p, s));
+  HIP_TRY(hipMalloc(&tmp.p, tb ? tb : 8));
+  HIP_TRY(hj_prefix_overflow(tmp.p, &tb, (const int64_t *)vals.p, n, prefix.p, (uint32_t *)flag.p, s));
+  uint32_t f = 0;
+  HIP_TRY(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *overflow = f != 0;
+  return LLKV_OK;
+}
+
 int Query::finish_from_exchange(const uint64_t *exchange) {
   const LoweredPlan &p = plan;
   std::vector<uint64_t> state(p.lanes);
@@ -469,7 +530,15 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
     gr.values.resize(p.aggs.size());
     for (size_t a = 0; a < p.aggs.size(); ++a) {
       std::string err;
-      int rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err);
+      int rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err, false);
+      if (rc == LLKV_UNSUPPORTED && !p.grouped && a < exact_plans.size() && !exact_plans[a].type_string.empty()) {
+        // the order-free state cannot tell whether a PREFIX of the reference's checked_add chain overflows:
+        // decide it exactly from the selected values in row order
+        bool overflow = false;
+        if ((rc = exact_prefix_overflow(a, &overflow))) return rc;
+        if (overflow) return set_error(LLKV_INVALID_ARGUMENT, p.aggs[a].fin == AggFinal::AvgI64 ? "AVG aggregate sum exceeds i64 range" : "integer overflow");
+        rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err, true);
+      }
       if (rc) return set_error(rc, err);
     }
     groups.push_back(std::move(gr));

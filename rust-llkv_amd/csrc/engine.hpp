@@ -66,7 +66,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
-enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3 };
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4 };
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // scan / select-count / project
@@ -120,6 +120,10 @@ struct Query {
   bool order_by_keys = false;
   uint32_t n_user_aggs = 0;
   std::vector<GroupResult> groups;
+  // ungrouped SUM/AVG(Int64) without overflow-excluding statistics: plan that emits the argument values of
+  // the selected rows in row order, for the exact prefix-overflow check (index = aggregate, empty = n/a)
+  std::vector<LoweredPlan> exact_plans;
+  int exact_prefix_overflow(size_t agg, bool *overflow);
   bool profiling = false;
   uint32_t profile_every = 1; // bracket every n-th scan with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -158,6 +162,6 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);
 
 void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state);
-int finalize_value(const AggOut &a, const uint64_t *group_lanes, int base, llkv_value *out, std::string *err);
+int finalize_value(const AggOut &a, const uint64_t *group_lanes, int base, llkv_value *out, std::string *err, bool prefixes_checked);
 
 } // namespace llkv

@@ -22,7 +22,7 @@ namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
 
-const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : "probe"; }
+const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : "emit"; }
 
 std::string wrapper_source(JitKind kind, const std::string &ts) {
   std::string s = "\nusing namespace llkv;\n";
@@ -36,6 +36,10 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     break;
   case JitKind::Project:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ProjParams p) { project_body<" + ts + ">(p); }\n";
+    break;
+  case JitKind::Emit:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { emit_body<" + ts + ", false>(p); }\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_b(const ScanParams p) { emit_body<" + ts + ", true>(p); }\n";
     break;
   case JitKind::Probe:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { probe_emit_body<" + ts + ", false>(p); }\n";
@@ -121,7 +125,7 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
   e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_a");
   if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  if (kind == JitKind::Select || kind == JitKind::Probe) {
+  if (kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit) {
     e = hipModuleGetFunction(&k.fn2, k.module, "llkv_jit_b");
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
   }
@@ -157,6 +161,7 @@ extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out,
   if (ts.rfind("SelPlan<", 0) == 0) kind = 1;
   else if (ts.rfind("ProjPlan<", 0) == 0) kind = 2;
   else if (ts.rfind("ProbePlan<", 0) == 0) kind = 3;
+  else if (ts.rfind("EmitPlan<", 0) == 0) kind = 4;
   const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
   std::vector<char> code;
   std::string err;

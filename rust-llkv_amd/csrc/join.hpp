@@ -68,4 +68,8 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
                                   uint64_t *count_by_slot, hipStream_t s);
 hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots, hipStream_t s);
 
+// Does any prefix of vals[0..n) (summed left to right, exactly) leave the i64 range?  *d_flag |= 1 if so.
+// `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.
+hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s);
+
 } // namespace llkv

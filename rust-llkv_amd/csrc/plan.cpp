@@ -650,6 +650,29 @@ int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, u
   return LLKV_OK;
 }
 
+int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+               uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  Lowering L{resolve, *out, err, false};
+  std::string pred, val;
+  int rc = L.predicate(filters, n_filters, ops, n_ops, &pred);
+  if (rc) return rc;
+  out->always_false = pred == "False";
+  bool is_f64 = false;
+  if (expr_len == 1 && expr[0].kind == LLKV_TOK_COLUMN) {
+    const ColumnInfo *ci;
+    int slot;
+    if ((rc = L.slot_of(expr[0].field_id, &ci, &slot))) return rc;
+    if (ci->dtype != LLKV_DT_INT64) return L.fail(LLKV_UNSUPPORTED, "exact sum check over a non-Int64 column");
+    val = L.col_node(slot, ci->dtype);
+  } else {
+    if ((rc = L.expr_fast(expr, expr_len, &val, &is_f64))) return rc;
+    if (is_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
+  }
+  out->type_string = "EmitPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + "," + val + ">";
+  return LLKV_OK;
+}
+
 int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
                 const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err) {
   *out = LoweredPlan{};

@@ -97,6 +97,10 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
 int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
                 const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err);
 
+// Selected argument values in row order → "EmitPlan<Cols<…>,pred,ValExpr>" (exact SUM(Int64) overflow check).
+int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+               uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err);
+
 // Typed literal cast used by leaf predicates (shared with the selection path).
 struct NativeLit {
   bool is_float = false, is_unsigned = false;

@@ -122,6 +122,51 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
   }
 }
 
+// ---- value-emit: the argument values of the rows that pass the predicate, in row order.  Used by the
+// exact, order-dependent overflow check of SUM(Int64) (the reference's checked_add chain,
+// llkv-aggregate/src/lib.rs:801-830) when column statistics cannot exclude a prefix overflow.
+template <class CL, class PR, class VE> struct EmitPlan {
+  using ColList = CL;
+  using Pred = PR;
+  using ValE = VE;
+};
+
+template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const ScanParams &p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t sub0 = wave * p.sub_rows;
+  const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
+  const uint64_t slot_idx = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
+  uint64_t base = WRITE ? p.aux_in[slot_idx] : 0;
+  uint64_t count = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t r = sub0; r < sub1; r += 128) {
+    Loaded ld;
+    const uint32_t row0 = r + lane * 2;
+    load_all<typename P::ColList>(p, td.dev_row + row0, ld);
+    bool f[2];
+    uint64_t val[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
+      f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+      val[j] = (uint64_t)(int64_t)P::ValE::eval(c, j);
+    }
+    const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
+    if constexpr (WRITE) {
+      const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
+      if (f[0]) p.aux_out[pre] = val[0];
+      if (f[1]) p.aux_out[pre + (f[0] ? 1 : 0)] = val[1];
+      base += __popcll(b0) + __popcll(b1);
+    } else {
+      count += __popcll(b0) + __popcll(b1);
+    }
+  }
+  if constexpr (!WRITE) {
+    if (lane == 0) p.tile_partials[slot_idx] = count;
+  }
+}
+
 // Exclusive scan of the per-(tile, wave) counts; one block, fixed order.  out[n] = total.
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint64_t *in, uint64_t *out, uint32_t n) {
   __shared__ uint64_t part[1024];

@@ -162,3 +162,15 @@ def test_mvcc_visibility_rules(orc, abi):
     # auto-commit snapshot (txn_id = 1) is never "the current transaction" (mvcc.rs:296)
     got = orc.filter_row_ids(t, [F(1, O.MvccVisible(2, txn_id=1, snapshot_id=9, uncommitted=[4]))])
     assert got.tolist() == [0, 1, 2, 4, 7]
+
+
+def test_sum_int64_overflow_is_order_dependent(orc, abi):
+    """checked_add chain (llkv-aggregate/src/lib.rs:816-829): a prefix that overflows is an error even when the total fits."""
+    A = abi.AggregateSpec
+    big = 2**62
+    t = orc.OracleTable(4).add(1, abi.DT_INT64, np.array([big, big, -big, -big], dtype=np.int64))
+    with pytest.raises(abi.LlkvError) as e:
+        orc.aggregate(t, None, [A.sum(1)])
+    assert e.value.kind == "InvalidArgumentError"
+    t = orc.OracleTable(4).add(1, abi.DT_INT64, np.array([big, -big, big, -big], dtype=np.int64))
+    assert orc.aggregate(t, None, [A.sum(1)])[0].value == 0
