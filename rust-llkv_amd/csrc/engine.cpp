@@ -44,6 +44,61 @@ int ensure_device() {
 static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------------
+// Scratch allocator
+// ---------------------------------------------------------------------------------
+namespace {
+std::mutex g_scratch_mu;
+std::multimap<size_t, void *> g_scratch_free;   // capacity → block
+std::map<void *, size_t> g_scratch_cap;          // live + cached blocks → capacity
+size_t g_scratch_cached = 0;
+constexpr size_t kScratchCacheLimit = 16ull << 30;
+} // namespace
+
+void *scratch_alloc(size_t bytes) {
+  size_t cap = 4096;
+  while (cap < bytes) cap <<= 1; // power-of-two classes: a freed block fits every later request of its class
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto it = g_scratch_free.find(cap);
+    if (it != g_scratch_free.end()) {
+      void *p = it->second;
+      g_scratch_free.erase(it);
+      g_scratch_cached -= cap;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    scratch_release_all(); // give cached blocks back and retry once
+    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  g_scratch_cap[p] = cap;
+  return p;
+}
+
+void scratch_free(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  auto it = g_scratch_cap.find(p);
+  if (it == g_scratch_cap.end()) return;
+  if (g_scratch_cached + it->second > kScratchCacheLimit) {
+    (void)hipFree(p);
+    g_scratch_cap.erase(it);
+    return;
+  }
+  g_scratch_free.emplace(it->second, p);
+  g_scratch_cached += it->second;
+}
+
+void scratch_release_all() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  for (auto &kv : g_scratch_free) { (void)hipFree(kv.second); g_scratch_cap.erase(kv.second); }
+  g_scratch_free.clear();
+  g_scratch_cached = 0;
+}
+
+// ---------------------------------------------------------------------------------
 // Table image
 // ---------------------------------------------------------------------------------
 Table::~Table() {
@@ -641,6 +696,7 @@ void llkv_hip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_ctx.mu);
   if (!g_ctx.ready) return;
   jit_shutdown();
+  scratch_release_all();
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;

@@ -147,6 +147,22 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
 
 int get_tileset(const Table &t, uint32_t tile_rows, const TileSet **out);
 
+// Caching device scratch allocator (hipMalloc/hipFree cost ~100 µs each; operator pipelines allocate dozens of
+// temporaries per call).  Blocks are reused by capacity; everything is released at llkv_hip_shutdown.
+void *scratch_alloc(size_t bytes);
+void scratch_free(void *p);
+void scratch_release_all();
+struct Scratch { // RAII temporary
+  void *p = nullptr;
+  ~Scratch() { if (p) scratch_free(p); }
+  int alloc(size_t bytes) {
+    if (p) scratch_free(p);
+    p = scratch_alloc(bytes);
+    return p ? LLKV_OK : set_error(LLKV_INTERNAL, "device scratch allocation of " + std::to_string(bytes) + " bytes failed");
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 // Selection vector of a predicate over a table image (stream.cpp): ascending logical row ids
 // and the matching device row indices.
 struct Selection {

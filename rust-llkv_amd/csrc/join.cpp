@@ -22,12 +22,12 @@ namespace {
 struct DBuf {
   void *p = nullptr;
   size_t cap = 0;
-  ~DBuf() { if (p) (void)hipFree(p); }
+  ~DBuf() { scratch_free(p); }
   int ensure(size_t bytes) {
-    if (bytes <= cap) return LLKV_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    HIP_TRY(hipMalloc(&p, bytes ? bytes : 8));
+    if (bytes <= cap && p) return LLKV_OK;
+    scratch_free(p);
+    p = scratch_alloc(bytes ? bytes : 8);
+    if (!p) return set_error(LLKV_INTERNAL, "device scratch allocation failed");
     cap = bytes;
     return LLKV_OK;
   }

@@ -246,52 +246,45 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void hj_topk_keys_kernel(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots) {
+__global__ __launch_bounds__(256) void hj_topk_keys_kernel(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys,
+                                                            uint32_t *slots, unsigned long long *n_groups) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool has = i < cap && count_by_slot[i] != 0;
+  const unsigned long long b = __ballot(has);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_groups, (unsigned long long)__popcll(b));
   if (i >= cap) return;
   slots[i] = (uint32_t)i;
-  if (count_by_slot[i] == 0) { keys[i] = ~0ull; return; } // no group in this slot: sorts last
-  long long b = __double_as_longlong(sum_by_slot[i]);
-  const uint64_t asc = b < 0 ? ~(uint64_t)b : ((uint64_t)b | 0x8000000000000000ull); // ascending order key of an f64
-  keys[i] = ~asc == ~0ull ? ~asc - 1 : ~asc;                                           // descending; never collides with the sentinel
+  if (!has) { keys[i] = ~0ull; return; } // no group in this slot: sorts last
+  long long bits = __double_as_longlong(sum_by_slot[i]);
+  const uint64_t asc = bits < 0 ? ~(uint64_t)bits : ((uint64_t)bits | 0x8000000000000000ull); // ascending order key of an f64
+  keys[i] = ~asc == ~0ull ? ~asc - 1 : ~asc;                                                   // descending; never the sentinel
 }
-hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots, hipStream_t s) {
-  hipLaunchKernelGGL(hj_topk_keys_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, sum_by_slot, count_by_slot, cap, keys, slots);
+hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots,
+                               unsigned long long *n_groups, hipStream_t s) {
+  hipLaunchKernelGGL(hj_topk_keys_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, sum_by_slot, count_by_slot, cap, keys, slots, n_groups);
   return hipGetLastError();
 }
 
-// ---- exact, order-dependent SUM(Int64) overflow check -------------------------------------------
-struct I128 {
-  uint64_t lo;
-  int64_t hi;
-};
-struct I128Add {
-  __host__ __device__ I128 operator()(const I128 &a, const I128 &b) const {
-    I128 r;
-    r.lo = a.lo + b.lo;
-    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1 : 0);
-    return r;
-  }
-};
-__global__ __launch_bounds__(256) void widen_i64_kernel(const int64_t *v, uint64_t n, I128 *out) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { out[i].lo = (uint64_t)v[i]; out[i].hi = v[i] < 0 ? -1 : 0; }
-}
-__global__ __launch_bounds__(256) void prefix_range_kernel(const I128 *p, uint64_t n, uint32_t *flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(128) void hj_gather_candidates_kernel(const uint64_t *sorted_keys, const uint32_t *sorted_slots, uint32_t n,
+                                                                   const unsigned long long *slot_owner, const double *sum_by_slot,
+                                                                   const uint64_t *count_by_slot, CandidateCols cols, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // in i64 range ⇔ hi is the sign extension of lo
-  const bool ok = p[i].hi == ((int64_t)p[i].lo < 0 ? -1 : 0);
-  if (!ok) atomicOr(flag, 1u);
+  uint64_t *o = out + (uint64_t)i * 8;
+  o[0] = sorted_keys[i];
+  if (sorted_keys[i] == ~0ull) { for (int k = 1; k < 8; ++k) o[k] = 0; return; }
+  const uint32_t slot = sorted_slots[i];
+  const unsigned long long owner = slot_owner[slot];
+  o[1] = (uint64_t)load_key(cols.key, owner);
+  o[2] = (uint64_t)__double_as_longlong(sum_by_slot[slot]);
+  o[3] = count_by_slot[slot];
+  for (uint32_t k = 0; k < 4; ++k) o[4 + k] = k < cols.n_payload ? (uint64_t)load_key(cols.payload[k], owner) : 0;
 }
-hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s) {
-  I128 *pre = reinterpret_cast<I128 *>(d_prefix);
-  if (tmp == nullptr) return rocprim::inclusive_scan(nullptr, *tmp_bytes, pre, pre, (size_t)n, I128Add(), s);
+hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_slots, uint32_t n, const unsigned long long *slot_owner,
+                                       const double *sum_by_slot, const uint64_t *count_by_slot, CandidateCols cols, uint64_t *out, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(widen_i64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, vals, n, pre);
-  hipError_t e = rocprim::inclusive_scan(tmp, *tmp_bytes, pre, pre, (size_t)n, I128Add(), s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(prefix_range_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pre, n, d_flag);
+  hipLaunchKernelGGL(hj_gather_candidates_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sorted_keys, sorted_slots, n, slot_owner, sum_by_slot,
+                     count_by_slot, cols, out);
   return hipGetLastError();
 }
 

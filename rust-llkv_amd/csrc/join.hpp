@@ -66,7 +66,16 @@ hipError_t hj_sort_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *kin, ui
 // without a group sort last).
 hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
                                   uint64_t *count_by_slot, hipStream_t s);
-hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots, hipStream_t s);
+hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots,
+                               unsigned long long *n_groups /* += groups */, hipStream_t s);
+// One record per candidate slot: {sort key, dim key, sum bits, count, payload[4]} (8 × 8 bytes).
+struct CandidateCols {
+  JoinKeyColumn key;
+  JoinKeyColumn payload[4];
+  uint32_t n_payload;
+};
+hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_slots, uint32_t n, const unsigned long long *slot_owner,
+                                       const double *sum_by_slot, const uint64_t *count_by_slot, CandidateCols cols, uint64_t *out /*[n][8]*/, hipStream_t s);
 
 // Does any prefix of vals[0..n) (summed left to right, exactly) leave the i64 range?  *d_flag |= 1 if so.
 // `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.

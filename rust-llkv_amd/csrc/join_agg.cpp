@@ -19,11 +19,7 @@ namespace llkv {
   } while (0)
 
 namespace {
-struct DB {
-  void *p = nullptr;
-  ~DB() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return LLKV_OK; }
-};
+using DB = Scratch;
 
 int int_key_column(const Table *t, uint32_t field, JoinKeyColumn *out) {
   auto it = t->cols.find(field);
@@ -150,8 +146,8 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
   {
     DB tmp;
     size_t tb = 0;
-    // offsets[n_slots] is not produced by rocprim's exclusive scan: scan n_slots + 1 entries (last count = 0)
-    HIP_TRY(hipMemsetAsync((uint64_t *)counts.p + 0, 0, 0, s));
+    // offsets[n_slots] (the total) is not produced by an exclusive scan of n_slots entries: scan n_slots + 1
+    // entries whose last count is 0
     DB counts1;
     if ((rc = counts1.alloc((size_t)(n_slots + 1) * 8))) return rc;
     HIP_TRY(hipMemsetAsync(counts1.p, 0, (size_t)(n_slots + 1) * 8, s));
@@ -181,70 +177,60 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
     HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_slot.p, (uint32_t *)s_slot.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
-  DB sums, cnts, tk_keys, tk_slots, tk_keys_s, tk_slots_s;
+  DB sums, cnts, tk_keys, tk_slots, tk_keys_s, tk_slots_s, n_groups_d;
   if ((rc = sums.alloc(ht.cap * 8)) || (rc = cnts.alloc(ht.cap * 8)) || (rc = tk_keys.alloc(ht.cap * 8)) || (rc = tk_slots.alloc(ht.cap * 4)) ||
-      (rc = tk_keys_s.alloc(ht.cap * 8)) || (rc = tk_slots_s.alloc(ht.cap * 4)))
+      (rc = tk_keys_s.alloc(ht.cap * 8)) || (rc = tk_slots_s.alloc(ht.cap * 4)) || (rc = n_groups_d.alloc(8)))
     return rc;
   HIP_TRY(hipMemsetAsync(cnts.p, 0, ht.cap * 8, s));
+  HIP_TRY(hipMemsetAsync(n_groups_d.p, 0, 8, s));
   HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_slot.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
-  HIP_TRY(hj_launch_topk_keys((const double *)sums.p, (const uint64_t *)cnts.p, ht.cap, (uint64_t *)tk_keys.p, (uint32_t *)tk_slots.p, s));
+  HIP_TRY(hj_launch_topk_keys((const double *)sums.p, (const uint64_t *)cnts.p, ht.cap, (uint64_t *)tk_keys.p, (uint32_t *)tk_slots.p,
+                              (unsigned long long *)n_groups_d.p, s));
   {
     DB tmp;
     size_t tb = 0;
     HIP_TRY(hj_sort_u64_u32(nullptr, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_slots.p, (uint32_t *)tk_slots_s.p, ht.cap, s));
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_slots.p, (uint32_t *)tk_slots_s.p, ht.cap, s));
-    HIP_TRY(hipStreamSynchronize(s));
   }
-  // ---- candidates → host: the first (limit + slack) groups by descending sum -------------------
-  const uint64_t want = std::min<uint64_t>(ht.cap, (uint64_t)limit + 64);
-  std::vector<uint64_t> hk(want);
-  std::vector<uint32_t> hs(want);
-  HIP_TRY(hipMemcpy(hk.data(), tk_keys_s.p, want * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(hs.data(), tk_slots_s.p, want * 4, hipMemcpyDeviceToHost));
-  uint64_t n_cand = 0;
-  while (n_cand < want && hk[n_cand] != ~0ull) ++n_cand;
-  if (n_cand == want && want < ht.cap && n_cand > limit && hk[limit - 1] == hk[want - 1])
+  // ---- candidates → host: the first (limit + slack) groups by descending sum, gathered in ONE kernel + ONE copy ----
+  const uint32_t want = (uint32_t)std::min<uint64_t>(ht.cap, (uint64_t)limit + 64);
+  CandidateCols cc;
+  std::memset(&cc, 0, sizeof cc);
+  cc.key = kd;
+  cc.n_payload = n_payload;
+  for (uint32_t i = 0; i < n_payload; ++i) if ((rc = int_key_column(td, payload_fields[i], &cc.payload[i]))) return rc;
+  DB cand_d;
+  if ((rc = cand_d.alloc((size_t)want * 64 + 8))) return rc;
+  HIP_TRY(hj_launch_gather_candidates((const uint64_t *)tk_keys_s.p, (const uint32_t *)tk_slots_s.p, want, (const unsigned long long *)ht.owner.p,
+                                      (const double *)sums.p, (const uint64_t *)cnts.p, cc, (uint64_t *)cand_d.p, s));
+  std::vector<uint64_t> hc((size_t)want * 8);
+  uint64_t n_groups = 0;
+  HIP_TRY(hipMemcpyAsync(hc.data(), cand_d.p, (size_t)want * 64, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&n_groups, n_groups_d.p, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  uint32_t n_cand = 0;
+  while (n_cand < want && hc[(size_t)n_cand * 8] != ~0ull) ++n_cand;
+  if (n_cand == want && (uint64_t)want < ht.cap && n_cand > limit && limit > 0 && hc[(size_t)(limit - 1) * 8] == hc[(size_t)(want - 1) * 8])
     return set_error(LLKV_UNSUPPORTED, "more than 64 groups tie on the LIMIT boundary");
-  std::vector<JoinKeyColumn> pay(n_payload);
-  for (uint32_t i = 0; i < n_payload; ++i) if ((rc = int_key_column(td, payload_fields[i], &pay[i]))) return rc;
-  auto fetch = [&](const JoinKeyColumn &c, uint64_t drow, int64_t *out) -> int {
-    if (c.width == 8) { HIP_TRY(hipMemcpy(out, (const char *)c.values + drow * 8, 8, hipMemcpyDeviceToHost)); return LLKV_OK; }
-    uint32_t v = 0;
-    HIP_TRY(hipMemcpy(&v, (const char *)c.values + drow * 4, 4, hipMemcpyDeviceToHost));
-    *out = c.is_signed ? (int64_t)(int32_t)v : (int64_t)v;
-    return LLKV_OK;
-  };
   std::vector<llkv_join_group_row> cand(n_cand);
-  for (uint64_t i = 0; i < n_cand; ++i) {
+  for (uint32_t i = 0; i < n_cand; ++i) {
+    const uint64_t *c = &hc[(size_t)i * 8];
     llkv_join_group_row &g = cand[i];
-    std::memset(&g, 0, sizeof g);
-    uint64_t owner = 0;
-    HIP_TRY(hipMemcpy(&owner, (const uint64_t *)ht.owner.p + hs[i], 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&g.sum, (const double *)sums.p + hs[i], 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&g.count, (const uint64_t *)cnts.p + hs[i], 8, hipMemcpyDeviceToHost));
-    if ((rc = fetch(kd, owner, &g.key))) return rc;
-    for (uint32_t j = 0; j < n_payload; ++j) if ((rc = fetch(pay[j], owner, &g.payload[j]))) return rc;
+    g.key = (int64_t)c[1];
+    std::memcpy(&g.sum, &c[2], 8);
+    g.count = c[3];
+    for (int k = 0; k < 4; ++k) g.payload[k] = (int64_t)c[4 + k];
   }
   // ORDER BY sum DESC, payload[0] ASC (arrow lexsort, llkv-executor/src/lib.rs:13847-13864); LIMIT
   std::stable_sort(cand.begin(), cand.end(), [&](const llkv_join_group_row &a, const llkv_join_group_row &b) {
     if (a.sum != b.sum) return a.sum > b.sum;
     return n_payload ? a.payload[0] < b.payload[0] : false;
   });
-  const uint32_t n = (uint32_t)std::min<uint64_t>(limit, n_cand);
+  const uint32_t n = std::min<uint32_t>(limit, n_cand);
   for (uint32_t i = 0; i < n; ++i) out_rows[i] = cand[i];
   *out_n = n;
-  if (out_total_groups) { // number of groups = slots with a non-sentinel key
-    // binary search for the first sentinel in the sorted keys
-    uint64_t lo = 0, hi = ht.cap;
-    while (lo < hi) {
-      const uint64_t mid = (lo + hi) / 2;
-      uint64_t v = 0;
-      HIP_TRY(hipMemcpy(&v, (const uint64_t *)tk_keys_s.p + mid, 8, hipMemcpyDeviceToHost));
-      if (v == ~0ull) hi = mid; else lo = mid + 1;
-    }
-    *out_total_groups = lo;
-  }
+  if (out_total_groups) *out_total_groups = n_groups;
   return LLKV_OK;
 }
 

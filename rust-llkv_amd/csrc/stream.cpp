@@ -19,11 +19,7 @@ namespace llkv {
 static constexpr uint32_t kRowStreamChunk = 65536; // ROW_STREAM_CHUNK_SIZE, llkv-scan/src/execute.rs:31
 static constexpr uint32_t kSelectTileRows = 8192;
 
-struct DeviceBuf {
-  void *p = nullptr;
-  ~DeviceBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return LLKV_OK; }
-};
+using DeviceBuf = Scratch;
 struct PinnedBuf {
   void *p = nullptr;
   ~PinnedBuf() { if (p) (void)hipHostFree(p); }
@@ -69,8 +65,9 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
   HIP_TRY(hipStreamSynchronize(stream));
   sel->n = total;
   if (total == 0) return LLKV_OK;
-  HIP_TRY(hipMalloc((void **)&sel->d_ids, total * 8));
-  HIP_TRY(hipMalloc((void **)&sel->d_dev, total * 8));
+  sel->d_ids = (uint64_t *)scratch_alloc(total * 8);
+  sel->d_dev = (uint64_t *)scratch_alloc(total * 8);
+  if (!sel->d_ids || !sel->d_dev) return set_error(LLKV_INTERNAL, "device scratch allocation failed");
   p.aux_in = (const uint64_t *)offsets.p;
   p.aux_out = sel->d_ids;
   p.aux_out2 = sel->d_dev;
@@ -80,8 +77,8 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
 }
 
 Selection::~Selection() {
-  if (d_ids) (void)hipFree(d_ids);
-  if (d_dev) (void)hipFree(d_dev);
+  scratch_free(d_ids);
+  scratch_free(d_dev);
 }
 
 } // namespace llkv
