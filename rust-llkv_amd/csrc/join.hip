@@ -288,4 +288,39 @@ hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32
   return hipGetLastError();
 }
 
+// ---- exact, order-dependent SUM(Int64) overflow check -------------------------------------------
+struct I128 {
+  uint64_t lo;
+  int64_t hi;
+};
+struct I128Add {
+  __host__ __device__ I128 operator()(const I128 &a, const I128 &b) const {
+    I128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1 : 0);
+    return r;
+  }
+};
+__global__ __launch_bounds__(256) void widen_i64_kernel(const int64_t *v, uint64_t n, I128 *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { out[i].lo = (uint64_t)v[i]; out[i].hi = v[i] < 0 ? -1 : 0; }
+}
+__global__ __launch_bounds__(256) void prefix_range_kernel(const I128 *p, uint64_t n, uint32_t *flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // in i64 range ⇔ hi is the sign extension of lo
+  const bool ok = p[i].hi == ((int64_t)p[i].lo < 0 ? -1 : 0);
+  if (!ok) atomicOr(flag, 1u);
+}
+hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s) {
+  I128 *pre = reinterpret_cast<I128 *>(d_prefix);
+  if (tmp == nullptr) return rocprim::inclusive_scan(nullptr, *tmp_bytes, pre, pre, (size_t)n, I128Add(), s);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(widen_i64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, vals, n, pre);
+  hipError_t e = rocprim::inclusive_scan(tmp, *tmp_bytes, pre, pre, (size_t)n, I128Add(), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(prefix_range_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pre, n, d_flag);
+  return hipGetLastError();
+}
+
 } // namespace llkv
