@@ -97,8 +97,23 @@ typedef enum llkv_operator_kind {
    * value.lo = field id of the `deleted_by` column, lower.lo = snapshot.txn_id,
    * upper.lo = snapshot.snapshot_id, in_list = txn ids whose status is NOT Committed
    * (Active / Aborted; ≤ 4 on the GPU path).                                              */
-  LLKV_OP_MVCC_VISIBLE = 10
+  LLKV_OP_MVCC_VISIBLE = 10,
+  /* Expr::Compare { left, op, right } over scalar expressions (the expr-vs-expr route,
+   * evaluate_compare_rows llkv-scan/src/predicate.rs:562-663 → compute_compare
+   * llkv-compute/src/kernels.rs:269-297): both sides are coerced to their common type and
+   * compared with arrow's `cmp` kernels — for floats that is IEEE totalOrder (NaN above
+   * everything, -0.0 below +0.0), unlike the leaf predicates' partial_cmp.  Uses cmp_*.   */
+  LLKV_OP_COMPARE = 11
 } llkv_operator_kind;
+
+typedef enum llkv_compare_op { /* llkv_expr::CompareOp */
+  LLKV_CMP_EQ = 1,
+  LLKV_CMP_NOT_EQ = 2,
+  LLKV_CMP_LT = 3,
+  LLKV_CMP_LT_EQ = 4,
+  LLKV_CMP_GT = 5,
+  LLKV_CMP_GT_EQ = 6
+} llkv_compare_op;
 
 typedef enum llkv_bound_kind {
   LLKV_BOUND_UNBOUNDED = 0,
@@ -116,6 +131,11 @@ typedef struct llkv_filter {
   llkv_literal upper;
   const llkv_literal *in_list; /* IN                                         */
   uint32_t in_len;
+  int32_t cmp_op;              /* LLKV_OP_COMPARE: llkv_compare_op              */
+  const struct llkv_expr_token *cmp_left;
+  uint32_t cmp_left_len;
+  const struct llkv_expr_token *cmp_right;
+  uint32_t cmp_right_len;
 } llkv_filter;
 
 /* Predicate program — `EvalOp` stack program, llkv-compute/src/program.rs:48-78,

@@ -428,6 +428,8 @@ static int32_t filter_leaf(const orc_table *t, const llkv_filter *f, idvec *out)
   return LLKV_OK;
 }
 
+static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom);
+
 /* Predicate VM: llkv-scan/src/predicate.rs:32-193.  Each stack entry carries the
  * matching rows and the domain (rows where the sub-expression is determined),
  * which is what the reference's separate DomainProgram computes
@@ -459,8 +461,11 @@ int32_t orc_filter_row_ids(const orc_table *t, const llkv_filter *filters, uint3
     case LLKV_EVAL_PUSH_PREDICATE: {
       if (op->arg >= n_filters) { rc = fail(LLKV_INTERNAL, "predicate index out of range"); break; }
       vm_entry e = {{0}, {0}};
-      rc = filter_leaf(t, &filters[op->arg], &e.rows);
-      if (rc == LLKV_OK) rc = field_nonnull_rows(t, filters[op->arg].field_id, &e.dom);
+      if (filters[op->arg].op == LLKV_OP_COMPARE) rc = compare_rows(t, &filters[op->arg], &e.rows, &e.dom);
+      else {
+        rc = filter_leaf(t, &filters[op->arg], &e.rows);
+        if (rc == LLKV_OK) rc = field_nonnull_rows(t, filters[op->arg].field_id, &e.dom);
+      }
       if (rc == LLKV_OK) stack[sp++] = e; else { idv_free(&e.rows); idv_free(&e.dom); }
       break;
     }
@@ -605,7 +610,10 @@ static int32_t infer_expr_type(const orc_table *t, const llkv_expr_token *e, uin
       if (e[i].binop == LLKV_BIN_DIV) *has_div = 1;
       int32_t r = common_type(st[sp - 2], st[sp - 1]);
       if (r == LLKV_DT_NULL || r == LLKV_DT_DATE32 || r == LLKV_DT_UTF8) { *rc_out = fail(LLKV_UNSUPPORTED, "unsupported operand types %s, %s", dtype_name(st[sp - 2]), dtype_name(st[sp - 1])); return LLKV_DT_NULL; }
-      if (r == LLKV_DT_INT32 || r == LLKV_DT_UINT32) r = r; /* same-type narrow ints stay narrow */
+      /* Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference — checked i32 arithmetic and an
+       * Int32 result; literal ⊕ literal is folded in i128 first (eval.rs:761-791).  Neither is restated. */
+      if (r == LLKV_DT_INT32 || r == LLKV_DT_UINT32) { *rc_out = fail(LLKV_UNSUPPORTED, "32-bit-only integer arithmetic"); return LLKV_DT_NULL; }
+      if (i >= 2 && e[i - 1].kind == LLKV_TOK_LITERAL && e[i - 2].kind == LLKV_TOK_LITERAL) { *rc_out = fail(LLKV_UNSUPPORTED, "constant sub-expression"); return LLKV_DT_NULL; }
       sp -= 2;
       st[sp++] = r;
       break;
@@ -742,6 +750,161 @@ static int32_t eval_program(const orc_table *t, const llkv_expr_token *e, uint32
   }
   if (rc != LLKV_OK) { for (uint32_t i = 0; i < sp; ++i) arr_free(&st[i]); return rc; }
   *out = st[0];
+  return LLKV_OK;
+}
+
+/* ------------------------------------------------------------ Expr::Compare */
+/* collect_row_ids_for_compare llkv-scan/src/predicate.rs:333-396 and its domain twin :779-818:
+ *  - column ⋈ non-NULL literal (not <>) is rewritten to a leaf filter (simple_compare_filter :970-1010);
+ *  - otherwise both sides are evaluated over the rows where every referenced field is present
+ *    (evaluate_compare_rows :562-663), coerced to get_common_type of their result types and compared with
+ *    arrow-ord's cmp kernels (compute_compare llkv-compute/src/kernels.rs:269-297) — integers natively,
+ *    floats by IEEE totalOrder; a row is "determined" when both sides are non-NULL. */
+static int64_t total_order_key(double v) {
+  int64_t b;
+  memcpy(&b, &v, 8);
+  return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+}
+
+/* One side over `n` row ids; the array keeps the side's own arrow type. */
+static int32_t compare_side(const orc_table *t, const llkv_expr_token *e, uint32_t n_tok, const gathered *g, uint32_t n_g,
+                            const uint64_t *ids, uint64_t n, arr *out) {
+  for (uint32_t i = 0; i < n_tok; ++i)
+    if (e[i].kind == LLKV_TOK_LITERAL && e[i].literal.tag == LLKV_LIT_NULL) return fail(LLKV_UNSUPPORTED, "NULL literal in a comparison");
+  if (n_tok == 1 && e[0].kind == LLKV_TOK_COLUMN) { /* VectorizedExpr::Array: the column as gathered */
+    const orc_column *c = find_col(t, e[0].field_id);
+    if (!c) return fail(LLKV_NOT_FOUND, "field %u not found", e[0].field_id);
+    if (dtype_width(c->dtype) == 0 || c->dtype == LLKV_DT_BOOLEAN || c->dtype == LLKV_DT_DATE32) return fail(LLKV_UNSUPPORTED, "comparison over %s", dtype_name(c->dtype));
+    *out = gather_column(c, ids, n);
+    return LLKV_OK;
+  }
+  if (n_tok == 1 && e[0].kind == LLKV_TOK_LITERAL) {
+    const llkv_literal *l = &e[0].literal;
+    arr a;
+    memset(&a, 0, sizeof a);
+    a.n = n; a.valid = xmalloc(n ? n : 1); a.values = xmalloc((n ? n : 1) * 8);
+    memset(a.valid, 1, n);
+    if (l->tag == LLKV_LIT_FLOAT64) { a.dtype = LLKV_DT_FLOAT64; for (uint64_t k = 0; k < n; ++k) ((double *)a.values)[k] = l->f64; }
+    else if (l->tag == LLKV_LIT_INT128) {
+      __int128 v = lit_i128(l);
+      if (v < (__int128)INT64_MIN || v > (__int128)INT64_MAX) { arr_free(&a); return fail(LLKV_UNSUPPORTED, "integer literal beyond Int64 in a comparison"); }
+      a.dtype = LLKV_DT_INT64;
+      for (uint64_t k = 0; k < n; ++k) ((int64_t *)a.values)[k] = (int64_t)v;
+    } else { arr_free(&a); return fail(LLKV_UNSUPPORTED, "non-numeric literal in a comparison"); }
+    *out = a;
+    return LLKV_OK;
+  }
+  return eval_program(t, e, n_tok, g, n_g, n, out);
+}
+
+static int is_unsigned_dtype(int32_t dt) { return dt == LLKV_DT_UINT32 || dt == LLKV_DT_UINT64; }
+static int is_64bit_dtype(int32_t dt) { return dt == LLKV_DT_INT64 || dt == LLKV_DT_UINT64; }
+
+static int rel_i(int32_t op, int64_t a, int64_t b) {
+  switch (op) { case LLKV_CMP_EQ: return a == b; case LLKV_CMP_NOT_EQ: return a != b; case LLKV_CMP_LT: return a < b;
+                case LLKV_CMP_LT_EQ: return a <= b; case LLKV_CMP_GT: return a > b; default: return a >= b; }
+}
+static int rel_u(int32_t op, uint64_t a, uint64_t b) {
+  switch (op) { case LLKV_CMP_EQ: return a == b; case LLKV_CMP_NOT_EQ: return a != b; case LLKV_CMP_LT: return a < b;
+                case LLKV_CMP_LT_EQ: return a <= b; case LLKV_CMP_GT: return a > b; default: return a >= b; }
+}
+static double side_as_f64(const arr *a, uint64_t i) { /* arrow cast → Float64 */
+  switch (a->dtype) {
+  case LLKV_DT_FLOAT64: return ((double *)a->values)[i];
+  case LLKV_DT_FLOAT32: return (double)((float *)a->values)[i];
+  case LLKV_DT_INT64: return (double)((int64_t *)a->values)[i];
+  case LLKV_DT_UINT64: return (double)((uint64_t *)a->values)[i];
+  case LLKV_DT_INT32: return (double)((int32_t *)a->values)[i];
+  default: return (double)((uint32_t *)a->values)[i];
+  }
+}
+static int64_t side_as_i64(const arr *a, uint64_t i) {
+  switch (a->dtype) {
+  case LLKV_DT_INT64: return ((int64_t *)a->values)[i];
+  case LLKV_DT_UINT64: return (int64_t)((uint64_t *)a->values)[i];
+  case LLKV_DT_INT32: return ((int32_t *)a->values)[i];
+  default: return (int64_t)((uint32_t *)a->values)[i];
+  }
+}
+
+static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom) {
+  if (f->cmp_op < LLKV_CMP_EQ || f->cmp_op > LLKV_CMP_GT_EQ) return fail(LLKV_INVALID_ARGUMENT, "unknown compare operator");
+  if (!f->cmp_left || !f->cmp_right || !f->cmp_left_len || !f->cmp_right_len) return fail(LLKV_INVALID_ARGUMENT, "compare needs two expressions");
+  const llkv_expr_token *l = f->cmp_left, *r = f->cmp_right;
+  const int l_col = f->cmp_left_len == 1 && l[0].kind == LLKV_TOK_COLUMN, r_col = f->cmp_right_len == 1 && r[0].kind == LLKV_TOK_COLUMN;
+  const int l_lit = f->cmp_left_len == 1 && l[0].kind == LLKV_TOK_LITERAL, r_lit = f->cmp_right_len == 1 && r[0].kind == LLKV_TOK_LITERAL;
+  if (f->cmp_op != LLKV_CMP_NOT_EQ && ((l_col && r_lit) || (l_lit && r_col))) {
+    const llkv_literal *lit = l_col ? &r[0].literal : &l[0].literal;
+    if (lit->tag != LLKV_LIT_NULL) {
+      llkv_filter leaf;
+      memset(&leaf, 0, sizeof leaf);
+      leaf.field_id = l_col ? l[0].field_id : r[0].field_id;
+      int32_t op = f->cmp_op;
+      if (!l_col) op = op == LLKV_CMP_LT ? LLKV_CMP_GT : op == LLKV_CMP_LT_EQ ? LLKV_CMP_GT_EQ : op == LLKV_CMP_GT ? LLKV_CMP_LT : op == LLKV_CMP_GT_EQ ? LLKV_CMP_LT_EQ : op;
+      leaf.op = op == LLKV_CMP_EQ ? LLKV_OP_EQUALS : op == LLKV_CMP_LT ? LLKV_OP_LT : op == LLKV_CMP_LT_EQ ? LLKV_OP_LE : op == LLKV_CMP_GT ? LLKV_OP_GT : LLKV_OP_GE;
+      leaf.value = *lit;
+      int32_t rc = filter_leaf(t, &leaf, rows);
+      if (rc == LLKV_OK) rc = field_nonnull_rows(t, leaf.field_id, dom);
+      return rc;
+    }
+  }
+  /* referenced fields, ascending (ordered_fields) */
+  uint32_t fields[64], n_fields = 0;
+  for (int side = 0; side < 2; ++side) {
+    const llkv_expr_token *e = side ? r : l;
+    const uint32_t n = side ? f->cmp_right_len : f->cmp_left_len;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind != LLKV_TOK_COLUMN) continue;
+      uint32_t j = 0;
+      while (j < n_fields && fields[j] != e[i].field_id) ++j;
+      if (j == n_fields) { if (n_fields == 64) return fail(LLKV_INTERNAL, "too many fields"); fields[n_fields++] = e[i].field_id; }
+    }
+  }
+  if (n_fields == 0) return fail(LLKV_UNSUPPORTED, "constant comparison");
+  idvec d = {0};
+  for (uint32_t j = 0; j < n_fields; ++j) {
+    idvec nn;
+    int32_t rc = field_nonnull_rows(t, fields[j], &nn);
+    if (rc) { idv_free(&d); return rc; }
+    if (j == 0) d = nn;
+    else { idvec x = idv_and(&d, &nn); idv_free(&d); idv_free(&nn); d = x; }
+  }
+  idvec matched = {0}, determined = {0};
+  int32_t rc = LLKV_OK;
+  /* 4096-row chunks of the domain (CHUNK_SIZE), each gathered and evaluated on its own */
+  for (uint64_t c0 = 0; c0 < d.n && rc == LLKV_OK; c0 += 4096) {
+    const uint64_t n = d.n - c0 < 4096 ? d.n - c0 : 4096;
+    gathered g[64];
+    for (uint32_t j = 0; j < n_fields; ++j) { g[j].field_id = fields[j]; g[j].a = gather_column(find_col(t, fields[j]), d.v + c0, n); }
+    arr la, ra;
+    memset(&la, 0, sizeof la); memset(&ra, 0, sizeof ra);
+    rc = compare_side(t, l, f->cmp_left_len, g, n_fields, d.v + c0, n, &la);
+    if (rc == LLKV_OK) rc = compare_side(t, r, f->cmp_right_len, g, n_fields, d.v + c0, n, &ra);
+    if (rc == LLKV_OK) {
+      /* get_common_type (kernels.rs:179-242) */
+      const int lf = la.dtype == LLKV_DT_FLOAT64 || la.dtype == LLKV_DT_FLOAT32, rf = ra.dtype == LLKV_DT_FLOAT64 || ra.dtype == LLKV_DT_FLOAT32;
+      int mode; /* 0 = Float64, 1 = signed, 2 = unsigned */
+      if (lf || rf) mode = 0;
+      else if (is_unsigned_dtype(la.dtype) && is_unsigned_dtype(ra.dtype)) mode = 2;
+      else if (is_unsigned_dtype(la.dtype) != is_unsigned_dtype(ra.dtype)) mode = (is_64bit_dtype(la.dtype) || is_64bit_dtype(ra.dtype)) ? 0 : 1;
+      else mode = 1;
+      for (uint64_t i = 0; i < n; ++i) {
+        if (!la.valid[i] || !ra.valid[i]) continue; /* NULL compare → NULL: neither matched nor determined */
+        idv_push(&determined, d.v[c0 + i]);
+        int m;
+        if (mode == 0) m = rel_i(f->cmp_op, total_order_key(side_as_f64(&la, i)), total_order_key(side_as_f64(&ra, i)));
+        else if (mode == 1) m = rel_i(f->cmp_op, side_as_i64(&la, i), side_as_i64(&ra, i));
+        else m = rel_u(f->cmp_op, (uint64_t)side_as_i64(&la, i), (uint64_t)side_as_i64(&ra, i));
+        if (m) idv_push(&matched, d.v[c0 + i]);
+      }
+    }
+    arr_free(&la); arr_free(&ra);
+    for (uint32_t j = 0; j < n_fields; ++j) arr_free(&g[j].a);
+  }
+  idv_free(&d);
+  if (rc) { idv_free(&matched); idv_free(&determined); return rc; }
+  *rows = matched;
+  *dom = determined;
   return LLKV_OK;
 }
 

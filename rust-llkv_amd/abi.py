@@ -25,7 +25,8 @@ NUMPY_OF_DTYPE = {DT_INT64: "int64", DT_FLOAT64: "float64", DT_INT32: "int32", D
                   DT_UINT64: "uint64", DT_UINT32: "uint32", DT_FLOAT32: "float32", DT_BOOLEAN: "uint8"}
 
 LIT_NULL, LIT_INT128, LIT_FLOAT64, LIT_DECIMAL128, LIT_BOOLEAN, LIT_STRING, LIT_DATE32 = range(7)
-OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE = range(1, 11)
+OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE, OP_COMPARE = range(1, 12)
+CMP_EQ, CMP_NOT_EQ, CMP_LT, CMP_LT_EQ, CMP_GT, CMP_GT_EQ = range(1, 7)
 BOUND_UNBOUNDED, BOUND_INCLUDED, BOUND_EXCLUDED = range(3)
 EVAL_PUSH_PREDICATE, EVAL_PUSH_LITERAL, EVAL_AND, EVAL_OR, EVAL_NOT = range(1, 6)
 TOK_COLUMN, TOK_LITERAL, TOK_BINARY = range(1, 4)
@@ -40,18 +41,20 @@ class CLiteral(C.Structure):
                 ("f64", C.c_double), ("str", C.c_char_p)]
 
 
+class CExprToken(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("binop", C.c_int32), ("field_id", C.c_uint32), ("literal", CLiteral)]
+
+
 class CFilter(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("op", C.c_int32), ("value", CLiteral),
                 ("lower_kind", C.c_int32), ("lower", CLiteral), ("upper_kind", C.c_int32),
-                ("upper", CLiteral), ("in_list", C.POINTER(CLiteral)), ("in_len", C.c_uint32)]
+                ("upper", CLiteral), ("in_list", C.POINTER(CLiteral)), ("in_len", C.c_uint32),
+                ("cmp_op", C.c_int32), ("cmp_left", C.POINTER(CExprToken)), ("cmp_left_len", C.c_uint32),
+                ("cmp_right", C.POINTER(CExprToken)), ("cmp_right_len", C.c_uint32)]
 
 
 class CEvalOp(C.Structure):
     _fields_ = [("op", C.c_int32), ("arg", C.c_uint32)]
-
-
-class CExprToken(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("binop", C.c_int32), ("field_id", C.c_uint32), ("literal", CLiteral)]
 
 
 class CAggregateSpec(C.Structure):
@@ -216,6 +219,7 @@ class Operator:
     lower: Optional[Bound] = None
     upper: Optional[Bound] = None
     values: Tuple[Literal, ...] = ()
+    cmp: Optional[tuple] = None  # (left ScalarExpr, CMP_*, right ScalarExpr)
 
     @staticmethod
     def Equals(v):
@@ -291,6 +295,11 @@ class Expr:
     @staticmethod
     def literal(v: bool) -> "Expr":
         return Expr("lit", value=v)
+
+    @staticmethod
+    def compare(left, op: int, right) -> "Expr":
+        """Expr::Compare { left, op, right } over scalar expressions (CMP_EQ … CMP_GT_EQ)."""
+        return Expr.pred(Filter(0, Operator(OP_COMPARE, cmp=(_scalar(left), op, _scalar(right)))))
 
     @staticmethod
     def true() -> "Expr":
@@ -487,6 +496,10 @@ class CPlan:
                 cf.upper_kind = f.op.upper.kind
                 if f.op.upper.value is not None:
                     cf.upper = f.op.upper.value.to_c(self.keep)
+            if f.op.kind == OP_COMPARE:
+                l, op, r = f.op.cmp
+                la, ra = l.to_c(self.keep), r.to_c(self.keep)
+                cf.cmp_op, cf.cmp_left, cf.cmp_left_len, cf.cmp_right, cf.cmp_right_len = op, la, len(l.tokens), ra, len(r.tokens)
             if f.op.kind in (OP_IN, OP_MVCC_VISIBLE):
                 lst = (CLiteral * max(1, len(f.op.values)))()
                 for j, v in enumerate(f.op.values):

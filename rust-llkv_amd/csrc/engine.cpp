@@ -537,6 +537,7 @@ int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
   uint64_t n = 0;
   HIP_TRY(hipMemcpyAsync(&n, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (n >= kPredErrorBit) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison");
   if (n == 0) return LLKV_OK;
   HIP_TRY(hipMalloc(&vals.p, n * 8));
   HIP_TRY(hipMalloc(&prefix.p, n * 16));

@@ -129,6 +129,7 @@ struct Ctx {
   const Loaded &ld;
   uint32_t err; // sticky: checked integer arithmetic overflowed on a selected row
   uint64_t row; // logical row id of the row being evaluated
+  uint32_t perr; // sticky: ... inside the predicate (Expr::Compare sides), which is evaluated on EVERY row
 
   template <class Ty> __device__ __forceinline__ typename Ty::T get(int s, int j) const {
     if constexpr (Ty::W == 8) {
@@ -253,6 +254,33 @@ template <class E, class... Vs> struct In {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) {
     const auto v = E::eval(c, j);
     return (bool)((int)(v == Vs::eval(c, j)) | ...);
+  }
+};
+// Expr::Compare over two scalar expressions of one common type (llkv-compute/src/kernels.rs:269-297).
+// arrow-ord `cmp::{eq,neq,lt,lt_eq,gt,gt_eq}`: integers natively, floats by IEEE totalOrder.
+// OP: 1 eq, 2 neq, 3 lt, 4 lteq, 5 gt, 6 gteq.
+__device__ __forceinline__ int64_t f64_total_order_key(double v) {
+  const int64_t b = __double_as_longlong(v);
+  return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+}
+template <int OP, class L, class R> struct Cmp {
+  template <class T> static __device__ __forceinline__ bool rel(T a, T b) {
+    if constexpr (OP == 1) return a == b; else if constexpr (OP == 2) return a != b; else if constexpr (OP == 3) return a < b;
+    else if constexpr (OP == 4) return a <= b; else if constexpr (OP == 5) return a > b; else return a >= b;
+  }
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    // both sides are evaluated over the whole domain, so their arithmetic errors count on rows the rest of
+    // the predicate rejects too (evaluate_compare_rows runs before the row sets are intersected)
+    const uint32_t outer = c.err;
+    c.err = 0;
+    const auto a = L::eval(c, j);
+    const auto b = R::eval(c, j);
+    c.perr |= c.err;
+    c.err = outer;
+    if constexpr (L::Type::is_float) return rel<int64_t>(f64_total_order_key((double)a), f64_total_order_key((double)b));
+    else if constexpr (sizeof(typename L::Type::T) == 8 && !(((typename L::Type::T)-1) < 0)) return rel<uint64_t>((uint64_t)a, (uint64_t)b); // UInt64 common type
+    else if constexpr (sizeof(typename R::Type::T) == 8 && !(((typename R::Type::T)-1) < 0)) return rel<uint64_t>((uint64_t)a, (uint64_t)b);
+    else return rel<int64_t>((int64_t)a, (int64_t)b);
   }
 };
 // MVCC visibility of a row version (llkv-transaction/src/mvcc.rs:283-333), fused into the scan instead of
@@ -523,7 +551,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
         contrib[0] = 1;
         if constexpr (P::first) contrib[1] = c.row;
         AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
-        err |= pass ? c.err : 0u;
+        err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const bool sel = pass & (NG == 1 || gid == (uint32_t)g);
@@ -637,7 +665,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
         contrib[0] = 1;
         if constexpr (P::first) contrib[1] = c.row;
         AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
-        err |= pass ? c.err : 0u;
+        err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
         if (pass) lds_accumulate_row<P>(&acc[gid * K][tid], contrib);
       }
     }

@@ -159,6 +159,7 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
   }
   uint64_t n_pairs = 0;
   HIP_TRY(hipMemcpy(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost));
+  if (n_pairs >= kPredErrorBit) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison");
   if (n_pairs == 0) return LLKV_OK;
   DB e_slot, e_val, s_slot, s_val;
   if ((rc = e_slot.alloc(n_pairs * 4)) || (rc = e_val.alloc(n_pairs * 8)) || (rc = s_slot.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;

@@ -185,6 +185,7 @@ struct Lowering {
 
   // One leaf filter → predicate node (llkv-table/src/table.rs:1117-1171).
   int leaf(const llkv_filter &f, std::string *out) {
+    if (f.op == LLKV_OP_COMPARE) return compare_leaf(f, out);
     const ColumnInfo *ci = resolve(f.field_id);
     if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(f.field_id) + " not found");
     if (f.op == LLKV_OP_MVCC_VISIBLE) { // MvccRowIdFilter as a leaf
@@ -331,6 +332,87 @@ struct Lowering {
     return LLKV_OK;
   }
 
+  // ---- Expr::Compare (collect_row_ids_for_compare, llkv-scan/src/predicate.rs:333-396) ----
+  // Arrow type class of one side: a bare column keeps its own type, an integer literal is Int64
+  // (literal_type, llkv-compute/src/eval.rs:167-185), a computed side has the fast path's result type.
+  enum class Side { S32, U32, S64, U64, F };
+  int expr_side(const llkv_expr_token *e, uint32_t n, std::string *node, Side *cls) {
+    for (uint32_t i = 0; i < n; ++i)
+      if (e[i].kind == LLKV_TOK_LITERAL && e[i].literal.tag == LLKV_LIT_NULL) return fail(LLKV_UNSUPPORTED, "NULL literal in a comparison");
+    if (n == 1 && e[0].kind == LLKV_TOK_COLUMN) {
+      const ColumnInfo *ci;
+      int slot, rc;
+      if ((rc = slot_of(e[0].field_id, &ci, &slot))) return rc;
+      const std::string c = col_node(slot, ci->dtype);
+      switch (ci->dtype) {
+      case LLKV_DT_FLOAT64: *node = c; *cls = Side::F; break;
+      case LLKV_DT_FLOAT32: *node = "ToF64<" + c + ">"; *cls = Side::F; break; // totalOrder survives the exact widening
+      case LLKV_DT_INT64: *node = c; *cls = Side::S64; break;
+      case LLKV_DT_UINT64: *node = c; *cls = Side::U64; break;
+      case LLKV_DT_INT32: *node = "ToI64<" + c + ">"; *cls = Side::S32; break;
+      case LLKV_DT_UINT32: *node = "ToI64<" + c + ">"; *cls = Side::U32; break;
+      default: return fail(LLKV_UNSUPPORTED, std::string("comparison over ") + dtype_name(ci->dtype));
+      }
+      return LLKV_OK;
+    }
+    if (n == 1 && e[0].kind == LLKV_TOK_LITERAL) {
+      const llkv_literal &lit = e[0].literal;
+      if (lit.tag == LLKV_LIT_FLOAT64) { *cls = Side::F; return lit_f(lit.f64, node); }
+      if (lit.tag != LLKV_LIT_INT128) return fail(LLKV_UNSUPPORTED, "non-numeric literal in a comparison");
+      const __int128 v = lit_i128(lit);
+      if (v < (__int128)INT64_MIN || v > (__int128)INT64_MAX) return fail(LLKV_UNSUPPORTED, "integer literal beyond Int64 in a comparison");
+      *cls = Side::S64;
+      return lit_i((int64_t)v, node);
+    }
+    bool is_f64 = false;
+    const int rc = expr_fast(e, n, node, &is_f64);
+    *cls = is_f64 ? Side::F : Side::S64;
+    return rc;
+  }
+
+  int compare_leaf(const llkv_filter &f, std::string *out) {
+    if (f.cmp_op < LLKV_CMP_EQ || f.cmp_op > LLKV_CMP_GT_EQ) return fail(LLKV_INVALID_ARGUMENT, "unknown compare operator");
+    if (!f.cmp_left || !f.cmp_right || !f.cmp_left_len || !f.cmp_right_len) return fail(LLKV_INVALID_ARGUMENT, "compare needs two expressions");
+    const llkv_expr_token *l = f.cmp_left, *r = f.cmp_right;
+    // simple_compare_filter (predicate.rs:970-1010): column ⋈ non-NULL literal (not <>) is a leaf filter
+    // with the leaf's typed-literal semantics; literal ⋈ column flips the operator.
+    const bool l_col = f.cmp_left_len == 1 && l[0].kind == LLKV_TOK_COLUMN, r_col = f.cmp_right_len == 1 && r[0].kind == LLKV_TOK_COLUMN;
+    const bool l_lit = f.cmp_left_len == 1 && l[0].kind == LLKV_TOK_LITERAL, r_lit = f.cmp_right_len == 1 && r[0].kind == LLKV_TOK_LITERAL;
+    if (f.cmp_op != LLKV_CMP_NOT_EQ && ((l_col && r_lit) || (l_lit && r_col))) {
+      const llkv_literal &lit = l_col ? r[0].literal : l[0].literal;
+      if (lit.tag != LLKV_LIT_NULL) {
+        static const int32_t direct[7] = {0, LLKV_OP_EQUALS, 0, LLKV_OP_LT, LLKV_OP_LE, LLKV_OP_GT, LLKV_OP_GE};
+        static const int32_t flipped[7] = {0, LLKV_OP_EQUALS, 0, LLKV_OP_GT, LLKV_OP_GE, LLKV_OP_LT, LLKV_OP_LE};
+        llkv_filter leaf_f{};
+        leaf_f.field_id = l_col ? l[0].field_id : r[0].field_id;
+        leaf_f.op = l_col ? direct[f.cmp_op] : flipped[f.cmp_op];
+        leaf_f.value = lit;
+        return leaf(leaf_f, out);
+      }
+    }
+    bool any_col = false;
+    for (uint32_t i = 0; i < f.cmp_left_len; ++i) any_col |= l[i].kind == LLKV_TOK_COLUMN;
+    for (uint32_t i = 0; i < f.cmp_right_len; ++i) any_col |= r[i].kind == LLKV_TOK_COLUMN;
+    if (!any_col) return fail(LLKV_UNSUPPORTED, "constant comparison");
+    std::string ln, rn;
+    Side lc, rc_;
+    int rc;
+    if ((rc = expr_side(l, f.cmp_left_len, &ln, &lc)) || (rc = expr_side(r, f.cmp_right_len, &rn, &rc_))) return rc;
+    // get_common_type (llkv-compute/src/kernels.rs:179-242) of the two sides
+    const auto is_unsigned = [](Side s) { return s == Side::U32 || s == Side::U64; };
+    const auto is_64 = [](Side s) { return s == Side::S64 || s == Side::U64; };
+    bool as_float = lc == Side::F || rc_ == Side::F;
+    if (!as_float && is_unsigned(lc) != is_unsigned(rc_) && (is_64(lc) || is_64(rc_))) as_float = true; // signed ⋈ unsigned, 64 bits wide → Float64
+    if (as_float) {
+      if (lc != Side::F) ln = "ToF64<" + ln + ">";
+      if (rc_ != Side::F) rn = "ToF64<" + rn + ">";
+    }
+    // otherwise both signed (Int32/Int64 → i64 compare), both unsigned (→ u64 compare; a widened UInt32
+    // is a non-negative i64, which C++ converts to u64 unchanged) or 32-bit mixed (→ Int64)
+    *out = "Cmp<" + std::to_string(f.cmp_op) + "," + ln + "," + rn + ">";
+    return LLKV_OK;
+  }
+
   static bool is_int_class(int32_t dt) { return dt == LLKV_DT_INT64 || dt == LLKV_DT_INT32 || dt == LLKV_DT_UINT32; }
   static bool is_float_class(int32_t dt) { return dt == LLKV_DT_FLOAT64 || dt == LLKV_DT_FLOAT32; }
 
@@ -354,6 +436,18 @@ struct Lowering {
         if (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "division in computed projections (NULL on zero) is not on the GPU path");
       }
     }
+    // Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference (checked i32 arithmetic, Int32 result)
+    if (n > 1 && !any_float && !any_u64) {
+      bool all_i32 = true, all_u32 = true;
+      for (uint32_t i = 0; i < n; ++i) {
+        if (e[i].kind == LLKV_TOK_LITERAL) all_i32 = all_u32 = false;
+        else if (e[i].kind == LLKV_TOK_COLUMN) { const int32_t dt = resolve(e[i].field_id)->dtype; all_i32 &= dt == LLKV_DT_INT32; all_u32 &= dt == LLKV_DT_UINT32; }
+      }
+      if (all_i32 || all_u32) return fail(LLKV_UNSUPPORTED, "32-bit-only integer arithmetic");
+    }
+    // ScalarEvaluator::simplify folds literal ⊕ literal in i128 first (eval.rs:761-791)
+    for (uint32_t i = 2; i < n; ++i)
+      if (e[i].kind == LLKV_TOK_BINARY && e[i - 1].kind == LLKV_TOK_LITERAL && e[i - 2].kind == LLKV_TOK_LITERAL) return fail(LLKV_UNSUPPORTED, "constant sub-expression");
     // get_common_type (llkv-compute/src/kernels.rs:179-242): a 64-bit unsigned side with a signed side → Float64
     if (any_u64) {
       if (n > 1 && !any_other) return fail(LLKV_UNSUPPORTED, "UInt64-only arithmetic");

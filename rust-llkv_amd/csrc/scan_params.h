@@ -35,6 +35,11 @@ struct TileDesc {
   uint32_t octant;
 };
 
+// Selection-style kernels (select / probe-emit / value-emit) report a checked-arithmetic error inside the
+// predicate (Expr::Compare over computed sides) by adding this to the (tile, wave) count of the counting
+// pass; real counts stay far below it, so `total >= kPredErrorBit` on the host means "error".
+constexpr uint64_t kPredErrorBit = 1ull << 40;
+
 struct ScanParams {
   const void *col[kMaxCols];
   const TileDesc *tiles;

@@ -27,6 +27,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
   const uint64_t slot = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
   uint64_t base = WRITE ? p.aux_in[slot] : 0;
   uint64_t count = 0;
+  uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   for (uint32_t r = sub0; r < sub1; r += 128) {
     Loaded ld;
@@ -37,6 +38,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
     for (int j = 0; j < 2; ++j) {
       Ctx c{p, ld, 0u, td.logical_row + row0 + j};
       f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+      perr |= ((row0 + j) < sub1) ? c.perr : 0u;
     }
     const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
     if constexpr (WRITE) {
@@ -49,7 +51,8 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
     }
   }
   if constexpr (!WRITE) {
-    if (lane == 0) p.tile_partials[slot] = count;
+    const bool any_err = __ballot(perr != 0) != 0;
+    if (lane == 0) p.tile_partials[slot] = count + (any_err ? kPredErrorBit : 0);
   }
 }
 
@@ -91,6 +94,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
   const uint64_t slot_idx = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
   uint64_t base = WRITE ? p.aux_in[slot_idx] : 0;
   uint64_t count = 0;
+  uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   for (uint32_t r = sub0; r < sub1; r += 128) {
     Loaded ld;
@@ -103,6 +107,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
     for (int j = 0; j < 2; ++j) {
       Ctx c{p, ld, 0u, td.logical_row + row0 + j};
       const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+      perr |= ((row0 + j) < sub1) ? c.perr : 0u;
       hit[j] = pass ? ht_find(p, (long long)P::KeyE::eval(c, j)) : 0xFFFFFFFFu; // hash probe only for surviving rows
       f[j] = hit[j] != 0xFFFFFFFFu;
       val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
@@ -118,7 +123,8 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
     }
   }
   if constexpr (!WRITE) {
-    if (lane == 0) p.tile_partials[slot_idx] = count;
+    const bool any_err = __ballot(perr != 0) != 0;
+    if (lane == 0) p.tile_partials[slot_idx] = count + (any_err ? kPredErrorBit : 0);
   }
 }
 
@@ -139,6 +145,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const S
   const uint64_t slot_idx = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
   uint64_t base = WRITE ? p.aux_in[slot_idx] : 0;
   uint64_t count = 0;
+  uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   for (uint32_t r = sub0; r < sub1; r += 128) {
     Loaded ld;
@@ -150,6 +157,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const S
     for (int j = 0; j < 2; ++j) {
       Ctx c{p, ld, 0u, td.logical_row + row0 + j};
       f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+      perr |= ((row0 + j) < sub1) ? c.perr : 0u;
       val[j] = (uint64_t)(int64_t)P::ValE::eval(c, j);
     }
     const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
@@ -163,7 +171,8 @@ template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const S
     }
   }
   if constexpr (!WRITE) {
-    if (lane == 0) p.tile_partials[slot_idx] = count;
+    const bool any_err = __ballot(perr != 0) != 0;
+    if (lane == 0) p.tile_partials[slot_idx] = count + (any_err ? kPredErrorBit : 0);
   }
 }
 

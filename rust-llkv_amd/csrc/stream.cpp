@@ -63,6 +63,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
   uint64_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  if (total >= kPredErrorBit) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison");
   sel->n = total;
   if (total == 0) return LLKV_OK;
   sel->d_ids = (uint64_t *)scratch_alloc(total * 8);

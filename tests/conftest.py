@@ -75,6 +75,10 @@ def build_predicate(abi, spec):
         return abi.Expr.any_of([build_predicate(abi, s) for s in spec["or"]])
     if "not" in spec:
         return abi.Expr.not_(build_predicate(abi, spec["not"]))
+    if "compare" in spec:
+        c = spec["compare"]
+        op = {"eq": abi.CMP_EQ, "ne": abi.CMP_NOT_EQ, "lt": abi.CMP_LT, "le": abi.CMP_LT_EQ, "gt": abi.CMP_GT, "ge": abi.CMP_GT_EQ}[c["op"]]
+        return abi.Expr.compare(build_expr(abi, c["left"]), op, build_expr(abi, c["right"]))
     raise ValueError(spec)
 
 

@@ -320,6 +320,70 @@ def test_scan_stream_and_row_ids_match_oracle(rt, orc, abi, chunks):
                     assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (x, y)
 
 
+@pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])
+def test_expression_compares_match_oracle(rt, orc, abi, chunks):
+    """Expr::Compare fused into the scan (Cmp node): every common-type class of get_common_type, totalOrder on
+    floats, column ⋈ literal through the leaf route, NOT over the determined rows, inside AND / OR, feeding
+    row ids, aggregates and GROUP BY."""
+    rng = np.random.default_rng(sum(chunks))
+    n = sum(chunks)
+    i64 = rng.integers(-50, 50, size=n).astype(np.int64)
+    f64 = rng.integers(-50, 50, size=n).astype(np.float64)
+    f64[rng.random(n) < 0.05] = np.nan
+    f64[rng.random(n) < 0.05] = -0.0
+    f64[rng.random(n) < 0.05] = 0.0
+    f64b = f64.copy()
+    rng.shuffle(f64b)
+    i32 = rng.integers(-50, 50, size=n).astype(np.int32)
+    u64 = rng.integers(0, 60, size=n).astype(np.uint64)
+    u64[rng.random(n) < 0.05] = 2**64 - 1
+    u64[rng.random(n) < 0.05] = 2**53 + 1
+    u32 = rng.integers(0, 60, size=n).astype(np.uint32)
+    wide = rng.integers(2**53 - 2, 2**53 + 3, size=n).astype(np.int64)
+    keys = np.array([ord("a"), ord("b"), ord("c")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64), (2, abi.DT_FLOAT64, f64), (3, abi.DT_INT32, i32), (4, abi.DT_UINT64, u64),
+                                       (5, abi.DT_UINT32, u32), (6, abi.DT_FLOAT64, f64b), (7, abi.DT_INT64, wide), (8, abi.DT_UTF8, keys)], chunks)
+    E, col, A, F, O = abi.Expr, abi.col, abi.AggregateSpec, abi.Filter, abi.Operator
+    ops = [abi.CMP_EQ, abi.CMP_NOT_EQ, abi.CMP_LT, abi.CMP_LT_EQ, abi.CMP_GT, abi.CMP_GT_EQ]
+    sides = [(col(2), col(6)),            # Float64 totalOrder: NaN, ±0.0
+             (col(1), col(3)),            # Int64 ⋈ Int32
+             (col(3), col(5)),            # Int32 ⋈ UInt32 → Int64
+             (col(4), col(5)),            # UInt64 ⋈ UInt32 → UInt64
+             (col(7), col(4)),            # Int64 ⋈ UInt64 → Float64 (2^53 ± 1 collide)
+             (col(5), col(1)),            # UInt32 ⋈ Int64 → Float64
+             (col(4) + col(3), 40),       # the reference's own shape
+             (col(1) * 2 - col(3), col(2)),
+             (col(1), col(2) * 0.5),
+             (col(2), 0.0), (0.0, col(2)), (col(3), 7), (7, col(5))]  # column ⋈ literal: leaf route unless <>
+    for l, r in sides:
+        for op in ops:
+            e = E.compare(l, op, r)
+            want = orc.filter_row_ids(ot, e)
+            assert np.array_equal(rt.filter_row_ids(ht, e), want), (l.tokens if hasattr(l, "tokens") else l, op)
+            ne = E.not_(e)
+            assert np.array_equal(rt.filter_row_ids(ht, ne), orc.filter_row_ids(ot, ne))
+    mixed = E.any_of([E.all_of([E.compare(col(1) + col(3), abi.CMP_GT, col(2)), F(3, O.LessThan(10))]), E.not_(E.compare(col(4), abi.CMP_LT_EQ, col(5)))])
+    aggs = [A.count_star(), A.sum(1), A.min(1), A.max(2), A.sum(col(1) * col(3))]
+    assert_values(rt.aggregate(ht, mixed, aggs), orc.aggregate(ot, mixed, aggs), "compare/aggregate")
+    got, want = rt.groupby(ht, mixed, [8], [A.count_star(), A.sum(1)], True), orc.groupby(ot, mixed, [8], [A.count_star(), A.sum(1)], True)
+    assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want]
+    for g, w in zip(got, want):
+        assert_values(g.values, w.values, "compare/groupby")
+    batches_g = rt.scan_stream(ht, [1, col(1) + col(3)], mixed, include_row_ids=True)
+    batches_o = orc.scan_stream(ot, [1, col(1) + col(3)], mixed, include_nulls=True, include_row_ids=True)
+    assert [b[1] for b in batches_g] == [b[1] for b in batches_o] and [b[0] for b in batches_g] == [b[0] for b in batches_o]
+    # checked arithmetic inside a compare side fails the scan even when another conjunct rejects the row
+    boom = E.all_of([E.compare(col(7) * 2**12, abi.CMP_GT, col(1)), F(3, O.Equals(10**6))])
+    for run in (lambda: rt.filter_row_ids(ht, boom), lambda: rt.aggregate(ht, boom, [A.count_star()]),
+                lambda: rt.groupby(ht, boom, [8], [A.count_star()], True), lambda: rt.scan_stream(ht, [1], boom)):
+        with pytest.raises(abi.LlkvError) as e:
+            run()
+        assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+    with pytest.raises(abi.LlkvError) as e:
+        orc.filter_row_ids(ot, boom)
+    assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 

@@ -129,6 +129,37 @@ def test_expression_typing_rules(lib, abi):
     assert e.value.kind == "InvalidArgumentError" and "not supported for column type Int32" in e.value.message
 
 
+def test_compare_lowering_follows_the_common_type_rules(lib, abi):
+    """Expr::Compare (llkv-scan/src/predicate.rs:333-396): column ⋈ literal is the leaf filter; anything else
+    is evaluated per side and coerced with get_common_type (llkv-compute/src/kernels.rs:179-242)."""
+    rt = mod("runtime")
+    d = _desc(abi, [(1, abi.DT_INT64), (2, abi.DT_FLOAT64), (3, abi.DT_INT32), (4, abi.DT_UINT64), (5, abi.DT_UINT32)])
+    E, col, cnt = abi.Expr, abi.col, [abi.AggregateSpec.count_star()]
+    F, O = abi.Filter, abi.Operator
+    # simple_compare_filter: same plan as the leaf predicate, literal ⋈ column flips the operator
+    leaf, _, _ = rt.lower_plan(d, E.pred(F(3, O.GreaterThan(7))), cnt)
+    assert rt.lower_plan(d, E.compare(col(3), abi.CMP_GT, 7), cnt)[0] == leaf
+    assert rt.lower_plan(d, E.compare(7, abi.CMP_LT, col(3)), cnt)[0] == leaf
+    # <> is never a leaf: Int32 column vs Int64 literal → Int64 compare
+    ts, _, _ = rt.lower_plan(d, E.compare(col(3), abi.CMP_NOT_EQ, 7), cnt)
+    assert "Cmp<2,ToI64<Col<0,I32>>,LitI<0>>" in ts
+    # the reference's own case: UInt64 + Int32 is Float64, so the Int64 literal is compared as Float64
+    ts, _, _ = rt.lower_plan(d, E.compare(col(4) + col(3), abi.CMP_GT, 220), cnt)
+    assert "Cmp<5,Bin<1,ToF64<Col<0,U64>>,ToF64<Col<1,I32>>>,ToF64<LitI<0>>>" in ts
+    # signed ⋈ unsigned: 64 bits wide → Float64, 32 bits → Int64; unsigned ⋈ unsigned stays unsigned
+    assert "Cmp<3,ToF64<Col<0,I64>>,ToF64<Col<1,U64>>>" in rt.lower_plan(d, E.compare(col(1), abi.CMP_LT, col(4)), cnt)[0]
+    assert "Cmp<3,ToF64<ToI64<Col<0,U32>>>,ToF64<Col<1,I64>>>" in rt.lower_plan(d, E.compare(col(5), abi.CMP_LT, col(1)), cnt)[0]
+    assert "Cmp<3,ToI64<Col<0,I32>>,ToI64<Col<1,U32>>>" in rt.lower_plan(d, E.compare(col(3), abi.CMP_LT, col(5)), cnt)[0]
+    assert "Cmp<6,Col<0,U64>,ToI64<Col<1,U32>>>" in rt.lower_plan(d, E.compare(col(4), abi.CMP_GT_EQ, col(5)), cnt)[0]
+    assert "Cmp<1,Bin<3,Col<0,I64>,LitI<0>>,ToI64<Col<1,I32>>>" in rt.lower_plan(d, E.compare(col(1) * 3, abi.CMP_EQ, col(3)), cnt)[0]
+    for bad in (E.compare(abi.ScalarExpr.literal(1) + 2, abi.CMP_LT, 4),  # constant compare
+                E.compare(col(3) + col(3), abi.CMP_LT, col(1)),             # Int32-only arithmetic stays Int32
+                E.compare(col(1), abi.CMP_NOT_EQ, abi.ScalarExpr.literal(abi.Literal.of(None)))):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.lower_plan(d, bad, cnt)
+        assert e.value.kind == "Unsupported"
+
+
 def test_int_sum_uses_statistics_to_exclude_overflow(lib, abi):
     rt = mod("runtime")
     d = (abi.CColumnDesc * 1)()

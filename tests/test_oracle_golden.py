@@ -174,3 +174,31 @@ def test_sum_int64_overflow_is_order_dependent(orc, abi):
     assert e.value.kind == "InvalidArgumentError"
     t = orc.OracleTable(4).add(1, abi.DT_INT64, np.array([big, -big, big, -big], dtype=np.int64))
     assert orc.aggregate(t, None, [A.sum(1)])[0].value == 0
+
+
+def test_compare_uses_total_order_and_common_types(orc, abi):
+    """Expr::Compare → arrow-ord cmp kernels (llkv-compute/src/kernels.rs:269-297): floats by IEEE totalOrder
+    (NaN above +inf, -0.0 below +0.0), unlike the leaf predicate's partial_cmp; NOT is taken over the rows
+    where both sides are determined (llkv-scan/src/predicate.rs:779-818)."""
+    E, col = abi.Expr, abi.col
+    t = orc.OracleTable(6)
+    t.add(1, abi.DT_FLOAT64, np.array([1.0, float("nan"), -0.0, 0.0, float("inf"), -1.0]))
+    t.add(2, abi.DT_FLOAT64, np.array([0.0, float("inf"), 0.0, -0.0, float("nan"), -1.0]))
+    t.add(3, abi.DT_INT64, np.array([2**53 + 1, -1, 0, 5, 7, -1], dtype=np.int64))
+    t.add(4, abi.DT_UINT64, np.array([2**53, 2**64 - 1, 0, 5, 6, 1], dtype=np.uint64))
+    ids = lambda e: list(orc.filter_row_ids(t, e))
+    assert ids(E.compare(col(1), abi.CMP_GT, col(2))) == [0, 1, 3]      # NaN > inf, 0.0 > -0.0
+    assert ids(E.compare(col(1), abi.CMP_EQ, col(2))) == [5]            # -0.0 ≠ 0.0 under totalOrder
+    assert ids(E.not_(E.compare(col(1), abi.CMP_GT, col(2)))) == [2, 4, 5]
+    # the leaf route (column ⋈ literal) keeps partial_cmp: NaN matches nothing, -0.0 == 0.0
+    assert ids(E.compare(col(1), abi.CMP_GT, 0.5)) == [0, 4]
+    assert ids(E.compare(col(1), abi.CMP_EQ, 0.0)) == [2, 3]
+    # but <> is evaluated row-wise with totalOrder: only +0.0 equals the literal
+    assert ids(E.compare(col(1), abi.CMP_NOT_EQ, 0.0)) == [0, 1, 2, 4, 5]
+    # Int64 ⋈ UInt64 → Float64: 2^53 + 1 rounds onto 2^53, -1 < 2^64
+    assert ids(E.compare(col(3), abi.CMP_EQ, col(4))) == [0, 2, 3]
+    assert ids(E.compare(col(3), abi.CMP_LT, col(4))) == [1, 5]
+    # checked arithmetic on a side is an error for the whole scan, whatever the other conjuncts select
+    with pytest.raises(abi.LlkvError) as e:
+        ids(E.all_of([E.compare(col(3) * 2**12, abi.CMP_GT, col(3)), abi.Filter(3, abi.Operator.Equals(5))]))
+    assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
