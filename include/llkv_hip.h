@@ -302,6 +302,18 @@ llkv_status llkv_hip_table_append_arr0_column(llkv_hip_table *table, uint32_t fi
 llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id,
                                                int32_t dtype, const void *device_values);
 
+/* NULL cells of an already staged column.  In the reference a NULL cell is a row
+ * id that is absent from the column's row-id shadow chunks (llkv-table/src/
+ * table.rs:1202-1223; gather turns it into an Arrow NULL, llkv-column-map/src/
+ * store/projection.rs:929-1352); the binding passes that as one Arrow validity
+ * bitmap per local chunk (LSB first, bit = 1 → present; a NULL pointer = the chunk
+ * has no NULL cell).  The mask is kept as 1 B/row in HBM next to the values and
+ * is read only by plans that touch the column; the values under NULL cells are
+ * never observed.  A column without NULL cells stays on the NULL-free fast path. */
+llkv_status llkv_hip_table_set_column_validity(llkv_hip_table *table, uint32_t field_id,
+                                               const uint8_t *const *chunk_validity,
+                                               uint32_t n_chunks);
+
 /* ------------------------------------------------------------------------- */
 /* Prepared queries: plan lowering + kernel selection happen once, launches   */
 /* are asynchronous on a caller-supplied HIP stream.                          */
@@ -547,6 +559,7 @@ typedef struct llkv_column_desc {
   int64_t min_i, max_i;
   uint32_t dict_size; /* LLKV_DT_UTF8                                        */
   const char *const *dictionary;
+  int32_t nullable;   /* the column has NULL cells                           */
 } llkv_column_desc;
 
 /* `grouped`: 0 = ungrouped aggregates, 1 = GROUP BY (groups in first-appearance

@@ -97,7 +97,7 @@ class CJoinOptions(C.Structure):
 class CColumnDesc(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("rows", C.c_uint64), ("has_stats", C.c_int32),
                 ("min_i", C.c_int64), ("max_i", C.c_int64), ("dict_size", C.c_uint32),
-                ("dictionary", C.POINTER(C.c_char_p))]
+                ("dictionary", C.POINTER(C.c_char_p)), ("nullable", C.c_int32)]
 
 
 class CJoinSide(C.Structure):

@@ -102,7 +102,10 @@ void scratch_release_all() {
 // Table image
 // ---------------------------------------------------------------------------------
 Table::~Table() {
-  for (auto &kv : cols) if (kv.second.owned && kv.second.d_values) (void)hipFree(kv.second.d_values);
+  for (auto &kv : cols) {
+    if (kv.second.owned && kv.second.d_values) (void)hipFree(kv.second.d_values);
+    if (kv.second.d_valid) (void)hipFree(kv.second.d_valid);
+  }
   for (auto &kv : tilesets) if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
 }
 
@@ -310,7 +313,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->tiles = ts;
 
   std::memset(&q->params, 0, sizeof q->params);
-  for (size_t s = 0; s < p.slot_fields.size(); ++s) q->params.col[s] = table->cols.at(p.slot_fields[s]).d_values;
+  for (size_t s = 0; s < p.slot_fields.size(); ++s) q->params.col[s] = slot_buffer(table->cols, p, s);
   for (size_t i = 0; i < p.lit_i.size(); ++i) q->params.lit_i[i] = p.lit_i[i];
   for (size_t i = 0; i < p.lit_f.size(); ++i) q->params.lit_f[i] = p.lit_f[i];
   for (size_t i = 0; i < p.key_strides.size(); ++i) q->params.key_stride[i] = p.key_strides[i];
@@ -452,7 +455,8 @@ static double key_to_f64(int64_t key) {
 // llkv-aggregate/src/lib.rs:1488-1939 on the folded lane state.
 int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base, llkv_value *out, std::string *err, bool prefixes_checked) {
   std::memset(out, 0, sizeof *out);
-  const int64_t rows = (int64_t)g[0];
+  // rows the accumulator saw: the group's rows, or the non-NULL argument rows when the argument has NULL cells
+  const int64_t rows = a.count_lane >= 0 ? (int64_t)g[base + a.count_lane] : (int64_t)g[0];
   const uint64_t *l = a.lane >= 0 ? g + base + a.lane : nullptr;
   auto as_f64 = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
   auto exact_sum = [&](int64_t *sum, const char *overflow_msg) -> int {
@@ -467,9 +471,16 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
     *sum = (int64_t)total;
     return LLKV_OK;
   };
+  if (a.typed_by_first_value && rows == 0 && (a.fin == AggFinal::SumF64 || a.fin == AggFinal::MinF64 || a.fin == AggFinal::MaxF64)) {
+    out->dtype = LLKV_DT_INT64; // an all-NULL temp column is an Int64 column: SUM / MIN / MAX come back as Int64 NULLs
+    out->is_null = 1;
+    return LLKV_OK;
+  }
   switch (a.fin) {
   case AggFinal::CountRows: out->dtype = LLKV_DT_INT64; out->i64 = rows; return LLKV_OK;
   case AggFinal::CountNullsZero: out->dtype = LLKV_DT_INT64; out->i64 = 0; return LLKV_OK;
+  case AggFinal::CountValid: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)l[0]; return LLKV_OK;
+  case AggFinal::CountNulls: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)g[0] - (int64_t)l[0]; return LLKV_OK;
   case AggFinal::SumI64Fast: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
   case AggFinal::SumI64: {
     out->dtype = LLKV_DT_INT64;
@@ -525,7 +536,7 @@ int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
   HIP_TRY(hipMalloc(&offsets.p, (size_t)(n_slots + 1) * 8));
   ScanParams sp;
   std::memset(&sp, 0, sizeof sp);
-  for (size_t i = 0; i < ep.slot_fields.size(); ++i) sp.col[i] = table->cols.at(ep.slot_fields[i]).d_values;
+  for (size_t i = 0; i < ep.slot_fields.size(); ++i) sp.col[i] = slot_buffer(table->cols, ep, i);
   for (size_t i = 0; i < ep.lit_i.size(); ++i) sp.lit_i[i] = ep.lit_i[i];
   for (size_t i = 0; i < ep.lit_f.size(); ++i) sp.lit_f[i] = ep.lit_f[i];
   sp.tiles = ts->d_tiles;
@@ -832,6 +843,51 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
   if ((rc = st.push(c.d_values, codes.data(), t->dev_rows))) return (llkv_status)rc;
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
   t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_set_column_validity(llkv_hip_table *table, uint32_t field_id,
+                                               const uint8_t *const *chunk_validity, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  if (n_chunks != t->n_local_chunks)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(t->n_local_chunks) + " local chunks, got " + std::to_string(n_chunks));
+  if (!chunk_validity) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk validity array is NULL");
+  int rc = ensure_device();
+  if (rc) return (llkv_status)rc;
+  DeviceColumn &c = it->second;
+  // Arrow bitmaps → 1 B/row in the device row layout (rows of padding between chunks stay 0; tiles never
+  // select them)
+  std::vector<uint8_t> mask(t->dev_rows + 16, 0);
+  uint64_t nulls = 0;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    uint8_t *dst = mask.data() + t->chunk_dev_off[i];
+    const uint8_t *bits = chunk_validity[i];
+    if (!bits) { std::memset(dst, 1, rows); continue; }
+    for (uint64_t r = 0; r < rows; ++r) {
+      const uint8_t v = (bits[r >> 3] >> (r & 7)) & 1u;
+      dst[r] = v;
+      nulls += !v;
+    }
+  }
+  if (c.d_valid) { (void)hipFree(c.d_valid); c.d_valid = nullptr; }
+  c.info.nullable = false;
+  // whether a column "has NULL cells" must not depend on the shard: with world > 1 any supplied bitmap makes
+  // the column nullable on every rank (plans must agree across ranks)
+  bool any_bitmap = false;
+  for (uint32_t i = 0; i < n_chunks; ++i) any_bitmap |= chunk_validity[i] != nullptr;
+  if (nulls == 0 && !(t->world > 1 && any_bitmap)) return LLKV_OK;
+  void *d = nullptr;
+  if ((rc = alloc_column(*t, 1, &d))) return (llkv_status)rc;
+  Stager st;
+  if ((rc = st.init())) { (void)hipFree(d); return (llkv_status)rc; }
+  if ((rc = st.push(d, mask.data(), t->dev_rows))) { (void)hipFree(d); return (llkv_status)rc; }
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) { (void)hipFree(d); return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed"); }
+  c.d_valid = (uint8_t *)d;
+  c.info.nullable = true;
   return LLKV_OK;
 }
 

@@ -34,8 +34,15 @@ int ensure_device();
 struct DeviceColumn {
   ColumnInfo info;
   void *d_values = nullptr;
+  uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
   bool owned = false;
 };
+
+// Device buffer read by slot `s` of a lowered plan: the field's values, or its validity mask.
+inline const void *slot_buffer(const std::map<uint32_t, DeviceColumn> &cols, const LoweredPlan &p, size_t s) {
+  const DeviceColumn &c = cols.at(p.slot_fields[s]);
+  return (s < p.slot_is_valid.size() && p.slot_is_valid[s]) ? (const void *)c.d_valid : (const void *)c.d_values;
+}
 
 struct TileSet {
   TileDesc *d_tiles = nullptr;
@@ -172,7 +179,7 @@ struct Selection {
   ~Selection();
 };
 int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
-                  uint32_t n_ops, Selection *sel);
+                  uint32_t n_ops, Selection *sel, const uint32_t *drop_null_fields = nullptr, uint32_t n_drop_null_fields = 0);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

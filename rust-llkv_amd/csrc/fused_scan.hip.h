@@ -263,7 +263,12 @@ __device__ __forceinline__ int64_t f64_total_order_key(double v) {
   const int64_t b = __double_as_longlong(v);
   return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
 }
-template <int OP, class L, class R> struct Cmp {
+struct AlwaysValid {
+  static __device__ __forceinline__ bool eval(Ctx &, int) { return true; }
+};
+// V: rows where every field of the two sides is present — the compare's domain; elsewhere nothing is
+// evaluated (no match, no arithmetic error).
+template <int OP, class L, class R, class V = AlwaysValid> struct Cmp {
   template <class T> static __device__ __forceinline__ bool rel(T a, T b) {
     if constexpr (OP == 1) return a == b; else if constexpr (OP == 2) return a != b; else if constexpr (OP == 3) return a < b;
     else if constexpr (OP == 4) return a <= b; else if constexpr (OP == 5) return a > b; else return a >= b;
@@ -275,12 +280,15 @@ template <int OP, class L, class R> struct Cmp {
     c.err = 0;
     const auto a = L::eval(c, j);
     const auto b = R::eval(c, j);
-    c.perr |= c.err;
+    const bool v = V::eval(c, j);
+    c.perr |= v ? c.err : 0u;
     c.err = outer;
-    if constexpr (L::Type::is_float) return rel<int64_t>(f64_total_order_key((double)a), f64_total_order_key((double)b));
-    else if constexpr (sizeof(typename L::Type::T) == 8 && !(((typename L::Type::T)-1) < 0)) return rel<uint64_t>((uint64_t)a, (uint64_t)b); // UInt64 common type
-    else if constexpr (sizeof(typename R::Type::T) == 8 && !(((typename R::Type::T)-1) < 0)) return rel<uint64_t>((uint64_t)a, (uint64_t)b);
-    else return rel<int64_t>((int64_t)a, (int64_t)b);
+    bool m;
+    if constexpr (L::Type::is_float) m = rel<int64_t>(f64_total_order_key((double)a), f64_total_order_key((double)b));
+    else if constexpr (sizeof(typename L::Type::T) == 8 && !(((typename L::Type::T)-1) < 0)) m = rel<uint64_t>((uint64_t)a, (uint64_t)b); // UInt64 common type
+    else if constexpr (sizeof(typename R::Type::T) == 8 && !(((typename R::Type::T)-1) < 0)) m = rel<uint64_t>((uint64_t)a, (uint64_t)b);
+    else m = rel<int64_t>((int64_t)a, (int64_t)b);
+    return v & m;
   }
 };
 // MVCC visibility of a row version (llkv-transaction/src/mvcc.rs:283-333), fused into the scan instead of
@@ -306,8 +314,14 @@ template <class... Ps> struct And {
 template <class... Ps> struct Or {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return (bool)((int)Ps::eval(c, j) | ...); }
 };
-template <class P> struct Not { // domain = all rows on this path (no NULLs staged)
+// Complement within all rows; the host lowering intersects it with the child's domain when some column of
+// the child has NULL cells (llkv-scan/src/predicate.rs:167-186).
+template <class P> struct Not {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return !P::eval(c, j); }
+};
+// The field of validity slot S is present in this row (1 B/row mask staged beside the values).
+template <int S> struct Valid {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return c.get<U8>(S, j) != 0; }
 };
 
 // --------------------------------------------------------------------------
@@ -395,6 +409,29 @@ template <class E, bool IS_MAX> struct ExtF64 {
 };
 template <class E> using MinF64 = ExtF64<E, false>;
 template <class E> using MaxF64 = ExtF64<E, true>;
+
+// COUNT(x) / COUNT_NULLS(x) over an argument with NULL cells: the rows where it is present (:769-786,1422-1445).
+template <class V> struct CountIf {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = V::eval(c, j) ? 1u : 0u; }
+};
+// Any accumulator over an argument with NULL cells: a NULL row contributes every lane's identity (accumulators
+// skip NULLs, and arrow's checked kernels do not evaluate NULL slots), and one more lane counts the non-NULL
+// rows — the AVG denominator and the "no rows → NULL" test of finalize.
+template <class V, class A> struct IfValid {
+  static constexpr int N = A::N + 1;
+  static constexpr int op(int k) { return k < A::N ? A::op(k) : OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    const uint32_t outer = c.err;
+    A::contrib(c, j, o);
+    const bool v = V::eval(c, j);
+    c.err = v ? c.err : outer;
+#pragma unroll
+    for (int k = 0; k < A::N; ++k) o[k] = v ? o[k] : lane_identity(A::op(k));
+    o[A::N] = v ? 1u : 0u;
+  }
+};
 
 template <class... As> struct Aggs {
   static constexpr int N = (0 + ... + As::N);

@@ -53,6 +53,7 @@ int key_column(const Table *t, uint32_t field, JoinKeyColumn *out) {
   auto it = t->cols.find(field);
   if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "join key field " + std::to_string(field) + " not found");
   const int32_t dt = it->second.info.dtype;
+  if (it->second.info.nullable) return set_error(LLKV_UNSUPPORTED, "join key column with NULL cells");
   out->values = it->second.d_values;
   switch (dt) {
   case LLKV_DT_INT64: case LLKV_DT_UINT64: out->width = 8; out->is_signed = 1; return LLKV_OK;

@@ -24,6 +24,7 @@ using DB = Scratch;
 int int_key_column(const Table *t, uint32_t field, JoinKeyColumn *out) {
   auto it = t->cols.find(field);
   if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "field " + std::to_string(field) + " not found");
+  if (it->second.info.nullable) return set_error(LLKV_UNSUPPORTED, "key column with NULL cells in the join-aggregate pipeline");
   out->values = it->second.d_values;
   switch (it->second.info.dtype) {
   case LLKV_DT_INT64: case LLKV_DT_UINT64: out->width = 8; out->is_signed = 1; return LLKV_OK;
@@ -130,7 +131,7 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
   if ((rc = counts.alloc((size_t)n_slots * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
   ScanParams p;
   std::memset(&p, 0, sizeof p);
-  for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = tf->cols.at(plan.slot_fields[i]).d_values;
+  for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = slot_buffer(tf->cols, plan, i);
   for (size_t i = 0; i < plan.lit_i.size(); ++i) p.lit_i[i] = plan.lit_i[i];
   for (size_t i = 0; i < plan.lit_f.size(); ++i) p.lit_f[i] = plan.lit_f[i];
   p.tiles = ts->d_tiles;

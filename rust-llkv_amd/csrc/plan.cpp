@@ -1,6 +1,7 @@
 // plan.cpp — see plan.hpp.
 #include "plan.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,7 +12,7 @@ namespace llkv {
 typedef __int128 i128;
 typedef unsigned __int128 u128;
 
-static constexpr int kMaxColsHost = 8;
+static constexpr int kMaxColsHost = 16;
 static constexpr int kMaxLitsHost = 16;
 static constexpr int kMaxKeysHost = 4;
 static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
@@ -153,11 +154,50 @@ struct Lowering {
     if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(field) + " not found");
     *ci_out = ci;
     for (size_t i = 0; i < p.slot_fields.size(); ++i)
-      if (p.slot_fields[i] == field) { *slot = (int)i; return LLKV_OK; }
-    if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 8 columns");
+      if (p.slot_fields[i] == field && !p.slot_is_valid[i]) { *slot = (int)i; return LLKV_OK; }
+    if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 16 column buffers");
     p.slot_fields.push_back(field);
     p.slot_dtypes.push_back(ci->dtype);
+    p.slot_is_valid.push_back(0);
     *slot = (int)p.slot_fields.size() - 1;
+    return LLKV_OK;
+  }
+  // Validity of a field as a predicate node: "" when the column has no NULL cell, else `Valid<slot>` over the
+  // field's 1 B/row validity mask (a NULL cell is a row id absent from the column, llkv-table/src/table.rs:1202-1223).
+  int valid_of_field(uint32_t field, std::string *v) {
+    v->clear();
+    const ColumnInfo *ci = resolve(field);
+    if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(field) + " not found");
+    if (!ci->nullable) return LLKV_OK;
+    int slot = -1;
+    for (size_t i = 0; i < p.slot_fields.size(); ++i)
+      if (p.slot_fields[i] == field && p.slot_is_valid[i]) slot = (int)i;
+    if (slot < 0) {
+      if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 16 column buffers");
+      p.slot_fields.push_back(field);
+      p.slot_dtypes.push_back(LLKV_DT_UTF8); // 1-byte cells
+      p.slot_is_valid.push_back(1);
+      slot = (int)p.slot_fields.size() - 1;
+    }
+    *v = "Valid<" + std::to_string(slot) + ">";
+    return LLKV_OK;
+  }
+  static std::string all_of(const std::vector<std::string> &vs) { // conjunction of validity nodes; "" = always valid
+    if (vs.empty()) return "";
+    if (vs.size() == 1) return vs[0];
+    std::string s = "And<";
+    for (size_t i = 0; i < vs.size(); ++i) s += (i ? "," : "") + vs[i];
+    return s + ">";
+  }
+  // NULL propagates through arithmetic: an expression is valid where all of its columns are.
+  int valid_of_expr(const llkv_expr_token *e, uint32_t n, std::vector<std::string> *vs) {
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind != LLKV_TOK_COLUMN) continue;
+      std::string v;
+      int rc = valid_of_field(e[i].field_id, &v);
+      if (rc) return rc;
+      if (!v.empty() && std::find(vs->begin(), vs->end(), v) == vs->end()) vs->push_back(v);
+    }
     return LLKV_OK;
   }
   std::string col_node(int slot, int32_t dtype) { return "Col<" + std::to_string(slot) + "," + dtype_tag(dtype) + ">"; }
@@ -183,9 +223,26 @@ struct Lowering {
     return lit_i(n.i, node, n.is_unsigned ? "LitU" : "LitI");
   }
 
-  // One leaf filter → predicate node (llkv-table/src/table.rs:1117-1171).
-  int leaf(const llkv_filter &f, std::string *out) {
-    if (f.op == LLKV_OP_COMPARE) return compare_leaf(f, out);
+  // One leaf → (matching rows, domain).  The domain is where the leaf is determined — the rows where the
+  // field is present (DomainOp::PushFieldAll, llkv-compute/src/program.rs:466, llkv-scan/src/predicate.rs:665-777);
+  // "True" = every row.  A NULL cell never matches (table.rs:1241-1244).
+  int leaf(const llkv_filter &f, std::string *rows, std::string *dom) {
+    if (f.op == LLKV_OP_COMPARE) return compare_leaf(f, rows, dom);
+    std::string v, x;
+    int rc = valid_of_field(f.field_id, &v);
+    if (rc) return rc;
+    *dom = v.empty() ? "True" : v;
+    if (f.op == LLKV_OP_IS_NOT_NULL) { *rows = *dom; return LLKV_OK; } // row-universe algebra, table.rs:1128-1143
+    if (f.op == LLKV_OP_IS_NULL) { *rows = v.empty() ? "False" : "Not<" + v + ">"; return LLKV_OK; }
+    if ((rc = leaf_values(f, &x))) return rc;
+    const bool all_rows = f.op == LLKV_OP_RANGE && f.lower_kind == LLKV_BOUND_UNBOUNDED && f.upper_kind == LLKV_BOUND_UNBOUNDED; // NULLs included, table.rs:1146-1153
+    if (v.empty() || all_rows || x == "False") *rows = x;
+    else *rows = x == "True" ? v : "And<" + v + "," + x + ">";
+    return LLKV_OK;
+  }
+
+  // The value test of a leaf filter, NULL cells aside (llkv-table/src/table.rs:1117-1171).
+  int leaf_values(const llkv_filter &f, std::string *out) {
     const ColumnInfo *ci = resolve(f.field_id);
     if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(f.field_id) + " not found");
     if (f.op == LLKV_OP_MVCC_VISIBLE) { // MvccRowIdFilter as a leaf
@@ -206,8 +263,6 @@ struct Lowering {
       *out = "Mvcc<" + col_node(sc, LLKV_DT_UINT64) + "," + col_node(sd, LLKV_DT_UINT64) + "," + txn + "," + snap + un + ">";
       return LLKV_OK;
     }
-    if (f.op == LLKV_OP_IS_NOT_NULL) { *out = "True"; return LLKV_OK; }  // NULL-free staged columns
-    if (f.op == LLKV_OP_IS_NULL) { *out = "False"; return LLKV_OK; }
     if (f.op == LLKV_OP_RANGE && f.lower_kind == LLKV_BOUND_UNBOUNDED && f.upper_kind == LLKV_BOUND_UNBOUNDED) { *out = "True"; return LLKV_OK; }
     int slot;
     int rc;
@@ -286,49 +341,67 @@ struct Lowering {
     return LLKV_OK;
   }
 
-  // Predicate program (llkv-compute/src/program.rs:48-78) → nested node.
+  // Predicate program (llkv-compute/src/program.rs:48-78) → nested node.  Every stack entry carries the rows
+  // it matches and its domain, as the reference's DomainProgram does (program.rs:447-520): And → intersect,
+  // Or → union, Not → domain(child) − rows(child) with the domain unchanged (predicate.rs:167-186).
+  struct PredEntry { std::string rows, dom; };
+  static std::string nary(const char *op, const std::vector<std::string> &xs) {
+    std::string s = std::string(op) + "<";
+    for (size_t i = 0; i < xs.size(); ++i) s += (i ? "," : "") + xs[i];
+    return s + ">";
+  }
   int predicate(const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops, std::string *out) {
     int rc;
     if (n_ops == 0) {
       if (n_filters == 0) { *out = "True"; return LLKV_OK; }
-      std::string s = "And<";
+      std::vector<std::string> ls;
       for (uint32_t i = 0; i < n_filters; ++i) {
-        std::string l;
-        if ((rc = leaf(filters[i], &l))) return rc;
-        s += (i ? "," : "") + l;
+        std::string l, d;
+        if ((rc = leaf(filters[i], &l, &d))) return rc;
+        ls.push_back(l);
       }
-      *out = s + ">";
+      *out = nary("And", ls);
       return LLKV_OK;
     }
-    std::vector<std::string> st;
+    std::vector<PredEntry> st;
     for (uint32_t k = 0; k < n_ops; ++k) {
       switch (ops[k].op) {
       case LLKV_EVAL_PUSH_PREDICATE: {
         if (ops[k].arg >= n_filters) return fail(LLKV_INTERNAL, "predicate index out of range");
-        std::string l;
-        if ((rc = leaf(filters[ops[k].arg], &l))) return rc;
-        st.push_back(l);
+        PredEntry e;
+        if ((rc = leaf(filters[ops[k].arg], &e.rows, &e.dom))) return rc;
+        st.push_back(e);
         break;
       }
-      case LLKV_EVAL_PUSH_LITERAL: st.push_back(ops[k].arg ? "True" : "False"); break;
+      case LLKV_EVAL_PUSH_LITERAL: st.push_back({ops[k].arg ? "True" : "False", "True"}); break;
       case LLKV_EVAL_AND: case LLKV_EVAL_OR: {
         if (ops[k].arg == 0 || ops[k].arg > st.size()) return fail(LLKV_INTERNAL, "predicate stack underflow");
-        std::string s = ops[k].op == LLKV_EVAL_AND ? "And<" : "Or<";
-        size_t b = st.size() - ops[k].arg;
-        for (size_t i = b; i < st.size(); ++i) s += (i > b ? "," : "") + st[i];
+        const bool is_and = ops[k].op == LLKV_EVAL_AND;
+        const size_t b = st.size() - ops[k].arg;
+        std::vector<std::string> rows, doms;
+        bool dom_all = false;
+        for (size_t i = b; i < st.size(); ++i) {
+          rows.push_back(st[i].rows);
+          if (st[i].dom == "True") dom_all = true; // neutral for the intersection, absorbing for the union
+          else if (std::find(doms.begin(), doms.end(), st[i].dom) == doms.end()) doms.push_back(st[i].dom);
+        }
+        PredEntry e;
+        e.rows = nary(is_and ? "And" : "Or", rows);
+        if (is_and) e.dom = doms.empty() ? "True" : doms.size() == 1 ? doms[0] : nary("And", doms);
+        else e.dom = (dom_all || doms.empty()) ? "True" : doms.size() == 1 ? doms[0] : nary("Or", doms);
         st.resize(b);
-        st.push_back(s + ">");
+        st.push_back(e);
         break;
       }
       case LLKV_EVAL_NOT:
         if (st.empty()) return fail(LLKV_INTERNAL, "predicate stack underflow");
-        st.back() = "Not<" + st.back() + ">";
+        st.back().rows = st.back().dom == "True" ? "Not<" + st.back().rows + ">" : "And<" + st.back().dom + ",Not<" + st.back().rows + ">>";
         break;
       default: return fail(LLKV_INTERNAL, "unknown predicate opcode");
       }
     }
     if (st.size() != 1) return fail(LLKV_INTERNAL, "predicate program left " + std::to_string(st.size()) + " entries");
-    *out = st[0];
+    *out = st[0].rows;
     return LLKV_OK;
   }
 
@@ -370,7 +443,7 @@ struct Lowering {
     return rc;
   }
 
-  int compare_leaf(const llkv_filter &f, std::string *out) {
+  int compare_leaf(const llkv_filter &f, std::string *out, std::string *dom) {
     if (f.cmp_op < LLKV_CMP_EQ || f.cmp_op > LLKV_CMP_GT_EQ) return fail(LLKV_INVALID_ARGUMENT, "unknown compare operator");
     if (!f.cmp_left || !f.cmp_right || !f.cmp_left_len || !f.cmp_right_len) return fail(LLKV_INVALID_ARGUMENT, "compare needs two expressions");
     const llkv_expr_token *l = f.cmp_left, *r = f.cmp_right;
@@ -387,7 +460,7 @@ struct Lowering {
         leaf_f.field_id = l_col ? l[0].field_id : r[0].field_id;
         leaf_f.op = l_col ? direct[f.cmp_op] : flipped[f.cmp_op];
         leaf_f.value = lit;
-        return leaf(leaf_f, out);
+        return leaf(leaf_f, out, dom);
       }
     }
     bool any_col = false;
@@ -409,7 +482,12 @@ struct Lowering {
     }
     // otherwise both signed (Int32/Int64 → i64 compare), both unsigned (→ u64 compare; a widened UInt32
     // is a non-negative i64, which C++ converts to u64 unchanged) or 32-bit mixed (→ Int64)
-    *out = "Cmp<" + std::to_string(f.cmp_op) + "," + ln + "," + rn + ">";
+    // rows where every referenced field is present = where both sides are determined (predicate.rs:366-388,635-638)
+    std::vector<std::string> vs;
+    if ((rc = valid_of_expr(l, f.cmp_left_len, &vs)) || (rc = valid_of_expr(r, f.cmp_right_len, &vs))) return rc;
+    const std::string v = all_of(vs);
+    *dom = v.empty() ? "True" : v;
+    *out = "Cmp<" + std::to_string(f.cmp_op) + "," + ln + "," + rn + (v.empty() ? "" : "," + v) + ">";
     return LLKV_OK;
   }
 
@@ -562,6 +640,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       // integer columns whose staging statistics bound the range.
       const bool int_key = probe->dtype == LLKV_DT_INT64 || probe->dtype == LLKV_DT_INT32 || probe->dtype == LLKV_DT_DATE32;
       if (probe->dtype != LLKV_DT_UTF8 && !int_key) return L.fail(LLKV_UNSUPPORTED, std::string("dense GROUP BY over ") + dtype_name(probe->dtype));
+      if (probe->nullable) return L.fail(LLKV_UNSUPPORTED, "GROUP BY key with NULL cells (NULL is its own group)");
       if (int_key) {
         if (!probe->has_stats) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key without column statistics (hash path)");
         const unsigned __int128 range = (unsigned __int128)((__int128)probe->max_i - (__int128)probe->min_i) + 1;
@@ -625,11 +704,18 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       simple_ci = resolve(s.expr[0].field_id);
       if (!simple_ci) return L.fail(LLKV_INVALID_ARGUMENT, "unknown column '" + std::to_string(s.expr[0].field_id) + "' in aggregate");
     }
+    // rows where the argument is non-NULL (NULL propagates through arithmetic; accumulators skip NULLs,
+    // llkv-aggregate/src/lib.rs:769-786,801-830)
+    std::vector<std::string> vs;
+    if ((rc = L.valid_of_expr(s.expr, s.expr_len, &vs))) return rc;
+    const std::string valid = Lowering::all_of(vs);
     if (s.kind == LLKV_AGG_COUNT || s.kind == LLKV_AGG_COUNT_NULLS) {
-      // NULL-free staged columns: COUNT(x) = rows, COUNT_NULLS(x) = 0; the argument still has to resolve
-      for (uint32_t i = 0; i < s.expr_len; ++i)
-        if (s.expr[i].kind == LLKV_TOK_COLUMN && !resolve(s.expr[i].field_id)) return L.fail(LLKV_NOT_FOUND, "field not found");
-      o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
+      // NULL-free argument: COUNT(x) = rows, COUNT_NULLS(x) = 0
+      if (valid.empty()) o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
+      else {
+        o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountValid : AggFinal::CountNulls;
+        o.lane = add_group("CountIf<" + valid + ">", {ADD_I64});
+      }
       p.aggs.push_back(o);
       continue;
     }
@@ -649,6 +735,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     } else {
       rc = grouped ? L.expr_planvalue(s.expr, s.expr_len, &node, &is_f64) : L.expr_fast(s.expr, s.expr_len, &node, &is_f64);
       if (rc) return rc;
+      o.typed_by_first_value = grouped;
     }
     // statistics that exclude i64 overflow of any prefix sum: rows · max|v| ≤ i64::MAX
     bool fast_i64 = false;
@@ -657,28 +744,36 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       u128 m = mag(simple_ci->min_i) > mag(simple_ci->max_i) ? mag(simple_ci->min_i) : mag(simple_ci->max_i);
       fast_i64 = m * (u128)simple_ci->rows <= (u128)INT64_MAX;
     }
+    // NULL argument rows contribute each lane's identity; one more lane counts the non-NULL rows
+    auto add_agg = [&](const std::string &inner, std::vector<uint8_t> lane_ops) {
+      if (valid.empty()) { o.lane = add_group(inner, lane_ops); return; }
+      const int n_inner = (int)lane_ops.size();
+      lane_ops.push_back(ADD_I64);
+      o.lane = add_group("IfValid<" + valid + "," + inner + ">", lane_ops);
+      o.count_lane = o.lane + n_inner;
+    };
     switch (s.kind) {
     case LLKV_AGG_SUM:
-      if (is_f64) { o.fin = AggFinal::SumF64; o.lane = add_group("SumF64<" + node + ">", {ADD_F64}); }
-      else if (fast_i64) { o.fin = AggFinal::SumI64Fast; o.lane = add_group("SumI64Fast<" + node + ">", {ADD_I64}); }
-      else { o.fin = AggFinal::SumI64; o.lane = add_group("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
+      if (is_f64) { o.fin = AggFinal::SumF64; add_agg("SumF64<" + node + ">", {ADD_F64}); }
+      else if (fast_i64) { o.fin = AggFinal::SumI64Fast; add_agg("SumI64Fast<" + node + ">", {ADD_I64}); }
+      else { o.fin = AggFinal::SumI64; add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
       break;
     case LLKV_AGG_TOTAL:
       o.fin = AggFinal::TotalF64;
-      o.lane = add_group(is_f64 ? "SumF64<" + node + ">" : "SumF64<ToF64<" + node + ">>", {ADD_F64});
+      add_agg(is_f64 ? "SumF64<" + node + ">" : "SumF64<ToF64<" + node + ">>", {ADD_F64});
       break;
     case LLKV_AGG_AVG:
-      if (is_f64) { o.fin = AggFinal::AvgF64; o.lane = add_group("SumF64<" + node + ">", {ADD_F64}); }
-      else if (fast_i64) { o.fin = AggFinal::AvgI64Fast; o.lane = add_group("SumI64Fast<" + node + ">", {ADD_I64}); }
-      else { o.fin = AggFinal::AvgI64; o.lane = add_group("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
+      if (is_f64) { o.fin = AggFinal::AvgF64; add_agg("SumF64<" + node + ">", {ADD_F64}); }
+      else if (fast_i64) { o.fin = AggFinal::AvgI64Fast; add_agg("SumI64Fast<" + node + ">", {ADD_I64}); }
+      else { o.fin = AggFinal::AvgI64; add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
       break;
     case LLKV_AGG_MIN:
-      if (is_f64) { o.fin = AggFinal::MinF64; o.lane = add_group("MinF64<" + node + ">", {MIN_I64, MIN_I64, MIN_I64}); }
-      else { o.fin = AggFinal::MinI64; o.lane = add_group("MinI64<" + node + ">", {MIN_I64}); }
+      if (is_f64) { o.fin = AggFinal::MinF64; add_agg("MinF64<" + node + ">", {MIN_I64, MIN_I64, MIN_I64}); }
+      else { o.fin = AggFinal::MinI64; add_agg("MinI64<" + node + ">", {MIN_I64}); }
       break;
     case LLKV_AGG_MAX:
-      if (is_f64) { o.fin = AggFinal::MaxF64; o.lane = add_group("MaxF64<" + node + ">", {MAX_I64, MIN_I64, MIN_I64}); }
-      else { o.fin = AggFinal::MaxI64; o.lane = add_group("MaxI64<" + node + ">", {MAX_I64}); }
+      if (is_f64) { o.fin = AggFinal::MaxF64; add_agg("MaxF64<" + node + ">", {MAX_I64, MIN_I64, MIN_I64}); }
+      else { o.fin = AggFinal::MaxI64; add_agg("MaxI64<" + node + ">", {MAX_I64}); }
       break;
     default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
     }
@@ -732,12 +827,29 @@ static std::string cols_string(const LoweredPlan &p, uint64_t *bytes) {
 }
 
 int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
-                    const llkv_eval_op *ops, uint32_t n_ops, LoweredPlan *out, std::string *err) {
+                    const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *drop_null_fields, uint32_t n_drop_null_fields,
+                    LoweredPlan *out, std::string *err) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, false};
   std::string pred;
   int rc = L.predicate(filters, n_filters, ops, n_ops, &pred);
   if (rc) return rc;
+  // GatherNullPolicy::DropNulls (llkv-column-map/src/store/projection.rs:40-48,1326-1330): a row is dropped when
+  // every gathered field is NULL — possible only if all of them have NULL cells
+  if (n_drop_null_fields) {
+    std::vector<std::string> vs;
+    bool some_never_null = false;
+    for (uint32_t i = 0; i < n_drop_null_fields; ++i) {
+      std::string v;
+      if ((rc = L.valid_of_field(drop_null_fields[i], &v))) return rc;
+      if (v.empty()) some_never_null = true;
+      else if (std::find(vs.begin(), vs.end(), v) == vs.end()) vs.push_back(v);
+    }
+    if (!some_never_null && pred != "False") {
+      const std::string any = vs.size() == 1 ? vs[0] : Lowering::nary("Or", vs);
+      pred = pred == "True" ? any : "And<" + pred + "," + any + ">";
+    }
+  }
   out->always_false = pred == "False";
   out->always_true = pred == "True";
   out->type_string = "SelPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + ">";
@@ -763,6 +875,12 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     if ((rc = L.expr_fast(expr, expr_len, &val, &is_f64))) return rc;
     if (is_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
   }
+  { // NULL argument rows are not part of the accumulator's chain
+    std::vector<std::string> vs;
+    if ((rc = L.valid_of_expr(expr, expr_len, &vs))) return rc;
+    const std::string v = Lowering::all_of(vs);
+    if (!v.empty() && pred != "False") pred = pred == "True" ? v : "And<" + pred + "," + v + ">";
+  }
   out->type_string = "EmitPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + "," + val + ">";
   return LLKV_OK;
 }
@@ -778,6 +896,10 @@ int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint3
   const ColumnInfo *ci;
   int slot;
   if ((rc = L.slot_of(key_field, &ci, &slot))) return rc;
+  if (ci->nullable) return L.fail(LLKV_UNSUPPORTED, "NULL join keys in the join-aggregate pipeline");
+  for (uint32_t i = 0; i < expr_len; ++i)
+    if (expr && expr[i].kind == LLKV_TOK_COLUMN && resolve(expr[i].field_id) && resolve(expr[i].field_id)->nullable)
+      return L.fail(LLKV_UNSUPPORTED, "NULL aggregate arguments in the join-aggregate pipeline");
   if (ci->dtype == LLKV_DT_INT64 || ci->dtype == LLKV_DT_UINT64) key = L.col_node(slot, LLKV_DT_INT64);
   else if (ci->dtype == LLKV_DT_INT32 || ci->dtype == LLKV_DT_DATE32 || ci->dtype == LLKV_DT_UINT32) key = "ToI64<" + L.col_node(slot, ci->dtype) + ">";
   else return L.fail(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(ci->dtype));
@@ -808,6 +930,10 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
       node = L.col_node(slot, ci->dtype);
       out->out_dtypes.push_back(ci->dtype);
       out->out_fields.push_back((int32_t)pr.field_id);
+      std::string v;
+      if ((rc = L.valid_of_field(pr.field_id, &v))) return rc;
+      if (!v.empty()) node = "OutV<" + node + "," + v + ">";
+      out->out_nullable.push_back(!v.empty());
     } else {
       bool is_f64 = false;
       if (!pr.expr || pr.expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "computed projection without expression");
@@ -823,6 +949,11 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
         out->out_dtypes.push_back(is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64);
         out->out_fields.push_back(-1);
       }
+      std::vector<std::string> vs;
+      if ((rc = L.valid_of_expr(pr.expr, pr.expr_len, &vs))) return rc;
+      const std::string v = Lowering::all_of(vs);
+      if (!v.empty()) node = "OutV<" + node + "," + v + ">";
+      out->out_nullable.push_back(!v.empty());
     }
     outs += (i ? "," : "") + node;
   }

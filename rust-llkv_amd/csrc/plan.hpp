@@ -27,6 +27,7 @@ struct ColumnInfo {
   bool has_stats = false;               // integer min/max known (staging statistics)
   int64_t min_i = 0, max_i = 0;
   std::vector<std::string> dictionary;  // LLKV_DT_UTF8: code → string
+  bool nullable = false;                // some cell is NULL (row id absent from the column): a 1 B/row validity mask is staged
 };
 
 using ColumnResolver = std::function<const ColumnInfo *(uint32_t field_id)>;
@@ -42,18 +43,24 @@ enum class AggFinal : int {
   AvgF64,
   MinI64, MaxI64,
   MinF64, MaxF64,
-  CountNullsZero // COUNT_NULLS on a NULL-free column = 0
+  CountNullsZero, // COUNT_NULLS on a NULL-free column = 0
+  CountValid,     // COUNT(x), x nullable: the valid-row lane
+  CountNulls      // COUNT_NULLS(x), x nullable: rows − valid rows
 };
 
 struct AggOut {
   AggFinal fin;
   int lane = -1; // first lane of its lane group, relative to the group's lane block
+  bool typed_by_first_value = false; // GROUP BY computed argument: the group's temp column takes the type of its first
+                                     // non-NULL value, Int64 when there is none (llkv-executor/src/lib.rs:298-406)
+  int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
 };
 
 struct LoweredPlan {
   std::string type_string;            // "Plan<Cols<...>,<pred>,Keys<...>,Aggs<...>,U>"
   std::vector<uint32_t> slot_fields;  // slot → field id
   std::vector<int32_t> slot_dtypes;   // slot → llkv_dtype (UTF8 = 1-byte codes)
+  std::vector<uint8_t> slot_is_valid; // slot reads the field's validity mask (1 B/row) instead of its values
   std::vector<int64_t> lit_i;
   std::vector<double> lit_f;
   std::vector<uint32_t> key_fields, key_slots, key_strides, key_cards;
@@ -73,6 +80,7 @@ struct LoweredPlan {
   bool always_true = false;      // selection plans: predicate folded to TRUE
   std::vector<int32_t> out_dtypes; // projection plans: storage dtype of each output
   std::vector<int32_t> out_fields; // projection plans: source field of a passthrough column, else -1
+  std::vector<uint8_t> out_nullable; // projection plans: the output carries a validity bitmap
 };
 
 // Lowers a plan.  `grouped` selects the GROUP BY argument semantics (PlanValue
@@ -85,8 +93,10 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
                LoweredPlan *out, std::string *err);
 
 // Predicate only → "SelPlan<Cols<…>,pred>" (selection-vector kernels, select.hip.h).
+// `drop_null_fields`: GatherNullPolicy::DropNulls — rows whose listed fields are ALL NULL are not selected.
 int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
-                    const llkv_eval_op *ops, uint32_t n_ops, LoweredPlan *out, std::string *err);
+                    const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *drop_null_fields, uint32_t n_drop_null_fields,
+                    LoweredPlan *out, std::string *err);
 // Scan projections (ScanProjection::{Column,Computed}, llkv-scan/src/lib.rs:59-65) →
 // "ProjPlan<Cols<…>,Outs<…>>" (window gather + computed expressions).
 int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,

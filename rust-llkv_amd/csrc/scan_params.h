@@ -23,7 +23,7 @@ enum LaneOp : int { OP_ADD_F64 = 0, OP_ADD_I64 = 1, OP_MIN_I64 = 2, OP_MAX_I64 =
 constexpr int kBlock = 256;
 constexpr int kRowsPerThread = 2;
 constexpr int kStepRows = kBlock * kRowsPerThread; // 512 rows per block step
-constexpr int kMaxCols = 8;
+constexpr int kMaxCols = 16; // value slots + validity-mask slots of one plan
 constexpr int kMaxLits = 16;
 constexpr int kMaxKeys = 4;
 constexpr int kOctants = 8; // canonical partition of the chunk list
@@ -74,6 +74,7 @@ struct ProjParams {
   const void *col[kMaxCols];
   const uint64_t *dev_rows; // window of device row indices
   void *out[kMaxOuts];
+  uint64_t *out_valid[kMaxOuts]; // Arrow validity bitmap of a nullable output (64 rows per word), else nullptr
   uint32_t *error_flag;
   int64_t lit_i[kMaxLits];
   double lit_f[kMaxLits];

@@ -220,9 +220,30 @@ template <class CL, int I = 0> __device__ __forceinline__ void gather_all(const 
     gather_all<CL, I + 1>(p, row, ld);
   }
 }
+// Output with NULLs: the value (arithmetic errors under a NULL do not count — arrow skips NULL slots) and one
+// validity bit per row, packed per wave with a ballot into the Arrow bitmap of the window (bit k of word w =
+// row 64·w + k; lane order = row order).
+template <class E, class V> struct OutV {
+  using Type = typename E::Type;
+  using ValidT = V;
+  static __device__ __forceinline__ typename E::Type::T eval(Ctx &c, int j) {
+    const uint32_t outer = c.err;
+    const auto x = E::eval(c, j);
+    c.err = V::eval(c, j) ? c.err : outer;
+    return x;
+  }
+};
+template <class E> struct out_valid_of { using type = void; };
+template <class E, class V> struct out_valid_of<OutV<E, V>> { using type = V; };
+
 template <int I, class E0, class... Er> __device__ __forceinline__ void store_outs(const ProjParams &p, Ctx &c, uint32_t i) {
   using T = typename E0::Type::T;
   reinterpret_cast<T *>(p.out[I])[i] = E0::eval(c, 0);
+  using VT = typename out_valid_of<E0>::type;
+  if constexpr (!__is_same(VT, void)) {
+    const uint64_t bits = __ballot(VT::eval(c, 0));
+    if ((threadIdx.x & 63) == 0) p.out_valid[I][i >> 6] = bits;
+  }
   if constexpr (sizeof...(Er) > 0) store_outs<I + 1, Er...>(p, c, i);
 }
 template <class OT> struct StoreOuts;

@@ -27,7 +27,7 @@ struct PinnedBuf {
 };
 
 int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
-                  uint32_t n_ops, Selection *sel) {
+                  uint32_t n_ops, Selection *sel, const uint32_t *drop_null_fields, uint32_t n_drop_null_fields) {
   int rc = ensure_device();
   if (rc) return rc;
   if (!t) return set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
@@ -37,7 +37,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
   };
   LoweredPlan plan;
   std::string err;
-  if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, &plan, &err))) return set_error(rc, err);
+  if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, drop_null_fields, n_drop_null_fields, &plan, &err))) return set_error(rc, err);
   sel->n = 0;
   if (plan.always_false || t->local_rows == 0) return LLKV_OK;
   const TileSet *ts = nullptr;
@@ -51,7 +51,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
   if ((rc = counts.alloc((size_t)n_slots * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
   ScanParams p;
   std::memset(&p, 0, sizeof p);
-  for (size_t s = 0; s < plan.slot_fields.size(); ++s) p.col[s] = t->cols.at(plan.slot_fields[s]).d_values;
+  for (size_t s = 0; s < plan.slot_fields.size(); ++s) p.col[s] = slot_buffer(t->cols, plan, s);
   for (size_t i = 0; i < plan.lit_i.size(); ++i) p.lit_i[i] = plan.lit_i[i];
   for (size_t i = 0; i < plan.lit_f.size(); ++i) p.lit_f[i] = plan.lit_f[i];
   p.tiles = ts->d_tiles;
@@ -122,7 +122,17 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   std::string err;
   if ((rc = lower_projection(resolve, projections, n_projections, &proj, &err))) return (llkv_status)set_error(rc, err);
   Selection sel;
-  if ((rc = run_selection(t, filters, n_filters, ops, n_ops, &sel))) return (llkv_status)rc;
+  // include_nulls = false → GatherNullPolicy::DropNulls over the gathered fields (projected columns and the
+  // inputs of computed projections; llkv-scan/src/row_stream.rs:451-623)
+  std::vector<uint32_t> gathered;
+  if (!(options && options->include_nulls)) {
+    for (uint32_t i = 0; i < n_projections; ++i) {
+      if (!projections[i].computed) gathered.push_back(projections[i].field_id);
+      else for (uint32_t k = 0; k < projections[i].expr_len; ++k)
+        if (projections[i].expr[k].kind == LLKV_TOK_COLUMN) gathered.push_back(projections[i].expr[k].field_id);
+    }
+  }
+  if ((rc = run_selection(t, filters, n_filters, ops, n_ops, &sel, gathered.data(), (uint32_t)gathered.size()))) return (llkv_status)rc;
   if (sel.n == 0) return LLKV_OK; // a filter that matches nothing yields no batch
   JitKernel k;
   if ((rc = jit_compile(JitKind::Project, proj.type_string, &k, &err))) return (llkv_status)set_error(rc, err);
@@ -132,8 +142,8 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   const bool with_ids = options && options->include_row_ids;
   // two window buffers: while the host consumes window w, the device fills w + 1
   struct Win {
-    DeviceBuf d[kMaxOuts];
-    PinnedBuf h[kMaxOuts], h_ids;
+    DeviceBuf d[kMaxOuts], d_valid[kMaxOuts];
+    PinnedBuf h[kMaxOuts], h_valid[kMaxOuts], h_ids;
     hipEvent_t done = nullptr;
     uint32_t n = 0;
     ~Win() { if (done) (void)hipEventDestroy(done); }
@@ -145,13 +155,14 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     for (uint32_t o = 0; o < n_out; ++o) {
       const size_t bytes = (size_t)kRowStreamChunk * dtype_width(proj.out_dtypes[o]);
       if ((rc = w.d[o].alloc(bytes)) || (rc = w.h[o].alloc(bytes))) return (llkv_status)rc;
+      if (proj.out_nullable[o] && ((rc = w.d_valid[o].alloc(kRowStreamChunk / 8)) || (rc = w.h_valid[o].alloc(kRowStreamChunk / 8)))) return (llkv_status)rc;
     }
     if (with_ids && (rc = w.h_ids.alloc((size_t)kRowStreamChunk * 8))) return (llkv_status)rc;
     if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "event create failed");
   }
   ProjParams pp;
   std::memset(&pp, 0, sizeof pp);
-  for (size_t s = 0; s < proj.slot_fields.size(); ++s) pp.col[s] = t->cols.at(proj.slot_fields[s]).d_values;
+  for (size_t s = 0; s < proj.slot_fields.size(); ++s) pp.col[s] = slot_buffer(t->cols, proj, s);
   for (size_t i = 0; i < proj.lit_i.size(); ++i) pp.lit_i[i] = proj.lit_i[i];
   for (size_t i = 0; i < proj.lit_f.size(); ++i) pp.lit_f[i] = proj.lit_f[i];
   pp.error_flag = (uint32_t *)d_err.p;
@@ -161,11 +172,14 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     ProjParams q = pp;
     q.dev_rows = sel.d_dev + w0;
     q.n = w.n;
-    for (uint32_t o = 0; o < n_out; ++o) q.out[o] = w.d[o].p;
+    for (uint32_t o = 0; o < n_out; ++o) { q.out[o] = w.d[o].p; q.out_valid[o] = (uint64_t *)w.d_valid[o].p; }
     int r = jit_launch_raw(k.fn, (w.n + kBlock - 1) / kBlock, &q, sizeof q, stream);
     if (r) return r;
     for (uint32_t o = 0; o < n_out; ++o)
+    {
       HIP_TRY(hipMemcpyAsync(w.h[o].p, w.d[o].p, (size_t)w.n * dtype_width(proj.out_dtypes[o]), hipMemcpyDeviceToHost, stream));
+      if (proj.out_nullable[o]) HIP_TRY(hipMemcpyAsync(w.h_valid[o].p, w.d_valid[o].p, (size_t)((w.n + 63) / 64) * 8, hipMemcpyDeviceToHost, stream));
+    }
     if (with_ids) HIP_TRY(hipMemcpyAsync(w.h_ids.p, sel.d_ids + w0, (size_t)w.n * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(w.done, stream));
     return LLKV_OK;
@@ -188,7 +202,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     for (uint32_t o = 0; o < n_out; ++o) {
       cols[o].dtype = proj.out_dtypes[o];
       cols[o].values = w.h[o].p;
-      cols[o].validity = nullptr; // staged columns carry no NULLs
+      cols[o].validity = proj.out_nullable[o] ? (const uint8_t *)w.h_valid[o].p : nullptr;
       cols[o].dictionary = dicts[o].empty() ? nullptr : dicts[o].data();
     }
     llkv_batch_view b;

@@ -16,7 +16,7 @@ from . import abi
 from .abi import (AggregateSpec, CPlan, CValue, Expr, Filter, LlkvError, Value)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllkv_hip.so")
+LIB_PATH = os.environ.get("LLKV_HIP_LIB") or os.path.join(_HERE, "libllkv_hip.so")  # override: A/B builds of the same ABI
 
 _lib = None
 
@@ -125,15 +125,25 @@ class HipTable:
             raise ValueError(f"column has {len(values)} rows, local chunks hold {off}")
         return out
 
-    def append_column(self, field_id: int, dtype: int, values: Union[np.ndarray, Sequence[np.ndarray]]):
-        """Stage one fixed-width column (local rows only): pinned host → hipMemcpyAsync → HBM."""
+    def append_column(self, field_id: int, dtype: int, values: Union[np.ndarray, Sequence[np.ndarray]], valid=None):
+        """Stage one fixed-width column (local rows only): pinned host → hipMemcpyAsync → HBM.
+        ``valid``: optional boolean array (local rows), False = NULL cell."""
         chunks = self._split(values) if isinstance(values, np.ndarray) else list(values)
         want = np.dtype(abi.NUMPY_OF_DTYPE[dtype])
         chunks = [np.ascontiguousarray(c, dtype=want) for c in chunks]
         ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
         check(lib().llkv_hip_table_append_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), ptrs, C.c_uint32(len(chunks))))
+        if valid is not None:
+            self.set_column_validity(field_id, valid)
 
-    def append_utf8_column(self, field_id: int, strings: Union[np.ndarray, Sequence], dictionary: Optional[Sequence[str]] = None):
+    def set_column_validity(self, field_id: int, valid):
+        """NULL cells of a staged column as one Arrow validity bitmap per local chunk (LSB first)."""
+        valid = np.asarray(valid, dtype=bool)
+        bitmaps = [np.packbits(c, bitorder="little") if len(c) else np.zeros(1, dtype=np.uint8) for c in self._split(valid)]
+        ptrs = (C.c_void_p * max(1, len(bitmaps)))(*[b.ctypes.data for b in bitmaps])
+        check(lib().llkv_hip_table_set_column_validity(self._h, C.c_uint32(field_id), ptrs, C.c_uint32(len(bitmaps))))
+
+    def append_utf8_column(self, field_id: int, strings: Union[np.ndarray, Sequence], dictionary: Optional[Sequence[str]] = None, valid=None):
         """Stage a Utf8 column.  ``strings`` is either a uint8 array of 1-byte strings (Arrow
         offsets are then 0..n) or a sequence of Python strings.  ``dictionary`` fixes the codes
         (required for sharded tables: every rank must pass the same table-wide dictionary)."""
@@ -145,6 +155,9 @@ class HipTable:
         else:
             off = 0
             strings = list(strings)
+            if valid is None and any(x is None for x in strings):
+                valid = [x is not None for x in strings]
+            strings = ["" if x is None else x for x in strings]
             for r in self.local_chunk_rows:
                 enc = [s.encode() for s in strings[off:off + r]]
                 off += r
@@ -161,6 +174,8 @@ class HipTable:
             enc = [d.encode() for d in dictionary]
             dptr, dn = (C.c_char_p * max(1, len(enc)))(*enc), len(enc)
         check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off)), dptr, C.c_uint32(dn)))
+        if valid is not None:
+            self.set_column_validity(field_id, valid)
 
     def append_arr0_column(self, field_id: int, blobs: Sequence[bytes], dictionary: Optional[Sequence[str]] = None):
         """Stage a column from its llkv-column-map `ARR0` chunk blobs (one per local chunk)."""
@@ -393,10 +408,14 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
             c = b.columns[ci]
             if c.dtype == abi.DT_UTF8:
                 codes = np.frombuffer(C.string_at(c.values, n), dtype=np.uint8)
-                cols.append([c.dictionary[int(k)].decode() for k in codes])
+                vals = [c.dictionary[int(k)].decode() for k in codes]
             else:
                 npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
-                cols.append(np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt).tolist())
+                vals = np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt).tolist()
+            if c.validity:  # Arrow validity bitmap → None for NULL cells
+                bits = np.unpackbits(np.frombuffer(C.string_at(c.validity, (n + 7) // 8), dtype=np.uint8), bitorder="little")[:n]
+                vals = [v if ok else None for v, ok in zip(vals, bits)]
+            cols.append(vals)
         rids = np.frombuffer(C.string_at(b.row_ids, n * 8), dtype=np.uint64).tolist() if b.row_ids else None
         batches.append((cols, rids))
 

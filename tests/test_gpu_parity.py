@@ -16,16 +16,22 @@ AGGS = golden("aggregates.json")
 
 
 def stage_both(rt, orc, abi, columns, chunk_rows):
-    """columns: [(field_id, dtype, numpy array | list[str])] → (HipTable, OracleTable)."""
+    """columns: [(field_id, dtype, numpy array | list[str][, valid mask])] → (HipTable, OracleTable)."""
     n = sum(chunk_rows)
     ht = rt.HipTable(1, chunk_rows)
     ot = orc.OracleTable(n)
-    for fid, dt, vals in columns:
-        ot.add(fid, dt, vals)
+    for col in columns:
+        fid, dt, vals = col[:3]
+        valid = col[3] if len(col) > 3 else None
         if dt == abi.DT_UTF8:
-            ht.append_utf8_column(fid, vals)
+            if valid is None:
+                ot.add(fid, dt, vals)
+            else:
+                ot.add(fid, dt, [v if ok else None for v, ok in zip(vals, valid)])
+            ht.append_utf8_column(fid, vals, valid=valid)
         else:
-            ht.append_column(fid, dt, vals)
+            ot.add(fid, dt, vals, None if valid is None else list(valid))
+            ht.append_column(fid, dt, vals, valid=valid)
     return ht, ot
 
 
@@ -382,6 +388,100 @@ def test_expression_compares_match_oracle(rt, orc, abi, chunks):
     with pytest.raises(abi.LlkvError) as e:
         orc.filter_row_ids(ot, boom)
     assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+
+
+@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] == "with_nulls"], ids=lambda c: c["name"])
+def test_reference_include_nulls_known_answers(rt, abi, case):
+    """test_scan_stream_include_nulls_toggle (table.rs:2357-2486) through llkv_hip_scan_stream: a NULL cell is
+    staged as a validity bit, DropNulls drops the rows whose projected columns are all NULL."""
+    from conftest import build_predicate
+    tdef = TABLE["tables"]["with_nulls"]
+    ht = rt.HipTable(1, [tdef["rows"]])
+    for c in tdef["columns"]:
+        dt = DTYPES[c["dtype"]]
+        valid = [v is not None for v in c["values"]]
+        ht.append_column(c["field_id"], dt, np.array([0 if v is None else v for v in c["values"]], dtype=abi.NUMPY_OF_DTYPE[dt]),
+                         valid=None if all(valid) else valid)
+    batches = rt.scan_stream(ht, case["project"], build_predicate(abi, case["predicate"]), include_nulls=case.get("include_nulls", False))
+    cols = [[] for _ in case["project"]]
+    for bcols, _ in batches:
+        for i, c in enumerate(bcols):
+            cols[i].extend(c)
+    assert cols == case["expect"]
+
+
+@pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5], [65536, 70000]])
+def test_null_cells_match_oracle(rt, orc, abi, chunks):
+    """NULL cells (validity masks in HBM): three-valued predicates with domain-relative NOT, IS [NOT] NULL,
+    compares, NULL-skipping accumulators with their own row counts, GROUP BY arguments, DropNulls / IncludeNulls
+    scans with validity bitmaps on the way out."""
+    rng = np.random.default_rng(7 + len(chunks))
+    n = sum(chunks)
+    i64 = rng.integers(-100, 100, size=n).astype(np.int64)
+    f64 = rng.integers(-100, 100, size=n).astype(np.float64) / 4
+    f64[rng.random(n) < 0.02] = np.nan
+    i32 = rng.integers(-100, 100, size=n).astype(np.int32)
+    dense = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+    keys = np.array([ord("a"), ord("b"), ord("c")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    tags = [("x", "y", "zz")[k] for k in rng.integers(0, 3, size=n)]
+    v1, v2, v3, v6 = rng.random(n) > 0.2, rng.random(n) > 0.1, rng.random(n) > 0.5, rng.random(n) > 0.3
+    v1[:3] = False  # leading NULLs: "first row" of MIN/MAX must be the first non-NULL one
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64, v1), (2, abi.DT_FLOAT64, f64, v2), (3, abi.DT_INT32, i32, v3),
+                                       (4, abi.DT_INT64, dense), (5, abi.DT_UTF8, keys), (6, abi.DT_UTF8, tags, v6)], chunks)
+    E, F, O, B, A, col = abi.Expr, abi.Filter, abi.Operator, abi.Bound, abi.AggregateSpec, abi.col
+    preds = [None,
+             [F(1, O.LessThan(10))],
+             E.pred(F(1, O.IsNull)), E.pred(F(2, O.IsNotNull)), E.not_(F(1, O.IsNull)), E.not_(F(6, O.IsNotNull)),
+             E.not_(F(1, O.LessThan(10))),
+             E.not_(E.all_of([F(1, O.LessThan(10)), F(2, O.GreaterThan(-3.0))])),
+             E.not_(E.any_of([F(1, O.LessThan(10)), F(3, O.In([1, 2, 3, 4, 5]))])),
+             E.not_(E.any_of([F(1, O.LessThan(10)), F(4, O.GreaterThan(0))])),
+             E.any_of([E.all_of([F(1, O.GreaterThanOrEquals(0)), E.not_(F(2, O.Range(B.Included(-5.0), B.Excluded(5.0))))]), E.pred(F(3, O.IsNull))]),
+             E.pred(F(1, O.Range(B.Unbounded, B.Unbounded))), E.not_(F(1, O.Range(B.Unbounded, B.Unbounded))),
+             E.compare(col(1), abi.CMP_GT, col(2)), E.not_(E.compare(col(1) + col(3), abi.CMP_LT_EQ, col(4))),
+             E.all_of([E.compare(col(2), abi.CMP_NOT_EQ, 0.0), E.pred(F(6, O.Equals("zz")))]),
+             E.not_(E.not_(F(2, O.GreaterThan(0.0))))]
+    aggs = [A.count_star(), A.count(1), A.count_nulls(2), A.sum(1), A.avg(1), A.min(1), A.max(1), A.min(2), A.max(2), A.total(2), A.avg(2),
+            A.sum(col(1) * col(2)), A.sum(col(1) * 3 - col(3)), A.sum(4), A.count(col(1) + col(3)), A.count(6)]
+    gaggs = [A.count_star(), A.count(1), A.sum(1), A.avg(2), A.min(1), A.max(2), A.sum(col(1) * col(2)), A.sum(4)]
+    for i, p in enumerate(preds):
+        want = orc.filter_row_ids(ot, p)
+        assert np.array_equal(rt.filter_row_ids(ht, p), want), i
+        assert_values(rt.aggregate(ht, p, aggs), orc.aggregate(ot, p, aggs), f"pred {i}")
+        got, exp = rt.groupby(ht, p, [5], gaggs, True), orc.groupby(ot, p, [5], gaggs, True)
+        assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp]
+        for g, w in zip(got, exp):
+            assert_values(g.values, w.values, f"groupby pred {i}")
+    if n < 20000:
+        for p in (preds[0], preds[1], preds[10]):
+            for projs in ([1], [1, 2], [2, col(1) * 2 + col(3)], [6], [6, 3], [4, 1]):
+                for inc in (False, True):
+                    got = rt.scan_stream(ht, projs, p, include_nulls=inc, include_row_ids=True)
+                    want = orc.scan_stream(ot, projs, p, include_nulls=inc, include_row_ids=True)
+                    assert [b[1] for b in got] == [b[1] for b in want], (projs, inc)
+                    for (gc, _), (wc, _) in zip(got, want):
+                        for a, b in zip(gc, wc):
+                            assert len(a) == len(b)
+                            assert all((x == y) or (isinstance(x, float) and isinstance(y, float) and math.isnan(x) and math.isnan(y)) for x, y in zip(a, b)), (projs, inc)
+    # an arithmetic overflow under a NULL is not an error (arrow's checked kernels skip NULL slots) …
+    big = np.full(n, 2**62, dtype=np.int64)
+    ok = np.zeros(n, dtype=bool)
+    ht2, ot2 = stage_both(rt, orc, abi, [(1, abi.DT_INT64, big, ok), (2, abi.DT_INT64, np.ones(n, dtype=np.int64))], chunks)
+    for t, m in ((ht2, rt), (ot2, orc)):
+        r = m.aggregate(t, E.not_(E.compare(col(1) * 4, abi.CMP_GT, col(2))), [A.sum(col(1) * 4), A.count_star(), A.count(1)])
+        assert [x.value for x in r] == [None, 0, 0]
+        r = m.aggregate(t, None, [A.sum(col(1) * 4), A.count_star(), A.count(1)])
+        assert [x.value for x in r] == [None, n, 0]
+    # … but it is one as soon as a single such cell is present
+    ok[n // 2] = True
+    ht3, ot3 = stage_both(rt, orc, abi, [(1, abi.DT_INT64, big, ok), (2, abi.DT_INT64, np.ones(n, dtype=np.int64))], chunks)
+    for t, m in ((ht3, rt), (ot3, orc)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.aggregate(t, None, [A.sum(col(1) * 4)])
+        assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+        with pytest.raises(abi.LlkvError) as e:
+            m.filter_row_ids(t, E.compare(col(1) * 4, abi.CMP_GT, col(2)))
+        assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
 
 
 JOINS = golden("joins.json")

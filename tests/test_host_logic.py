@@ -80,8 +80,9 @@ def test_lowering_of_benchmark_plans_hits_the_aot_catalog(lib, abi, tpch):
 
 def _desc(abi, cols):
     arr = (abi.CColumnDesc * len(cols))()
-    for i, (fid, dt) in enumerate(cols):
-        arr[i].field_id, arr[i].dtype, arr[i].rows = fid, dt, 1000
+    for i, col in enumerate(cols):
+        arr[i].field_id, arr[i].dtype, arr[i].rows = col[0], col[1], 1000
+        arr[i].nullable = int(len(col) > 2 and col[2])
     return arr
 
 
@@ -158,6 +159,40 @@ def test_compare_lowering_follows_the_common_type_rules(lib, abi):
         with pytest.raises(abi.LlkvError) as e:
             rt.lower_plan(d, bad, cnt)
         assert e.value.kind == "Unsupported"
+
+
+def test_null_cells_lower_to_validity_masks_and_domains(lib, abi):
+    """A NULL cell never matches a leaf (table.rs:1241-1244); NOT is taken inside the child's domain
+    (predicate.rs:167-186, program.rs:447-520); accumulators skip NULL arguments and count what they saw."""
+    rt = mod("runtime")
+    d = _desc(abi, [(1, abi.DT_INT64, True), (2, abi.DT_FLOAT64, True), (3, abi.DT_INT64)])
+    E, F, O, A, col = abi.Expr, abi.Filter, abi.Operator, abi.AggregateSpec, abi.col
+    cnt = [A.count_star()]
+    ts = rt.lower_plan(d, E.pred(F(1, O.LessThan(5))), cnt)[0]
+    assert "Cols<U8,I64>,And<Valid<0>,Range<Col<1,I64>,0,Nil,2,LitI<0>>>" in ts
+    # NOT: domain = rows where the field is present; a NULL-free column keeps the plain complement
+    assert "And<Valid<0>,Not<And<Valid<0>,Range<" in rt.lower_plan(d, E.not_(F(1, O.LessThan(5))), cnt)[0]
+    assert ",Not<Range<Col<0,I64>" in rt.lower_plan(d, E.not_(F(3, O.LessThan(5))), cnt)[0]
+    # Or → union of the domains, And → intersection; a NULL-free child makes the union every row
+    ts = rt.lower_plan(d, E.not_(E.any_of([F(1, O.LessThan(5)), F(2, O.GreaterThan(1.0))])), cnt)[0]
+    assert "And<Or<Valid<0>,Valid<2>>,Not<Or<" in ts
+    ts = rt.lower_plan(d, E.not_(E.any_of([F(1, O.LessThan(5)), F(3, O.GreaterThan(1))])), cnt)[0]
+    assert ",Not<Or<And<Valid<0>,Range<" in ts and "And<Or<" not in ts
+    ts = rt.lower_plan(d, E.not_(E.all_of([F(1, O.LessThan(5)), F(2, O.GreaterThan(1.0))])), cnt)[0]
+    assert "And<And<Valid<0>,Valid<2>>,Not<And<" in ts
+    # IS NULL / IS NOT NULL are row-universe algebra on the mask; unbounded ranges keep NULL rows
+    assert ",Not<Valid<0>>," in rt.lower_plan(d, E.pred(F(1, O.IsNull)), cnt)[0]
+    assert ",Valid<0>,Keys" in rt.lower_plan(d, E.pred(F(1, O.IsNotNull)), cnt)[0]
+    assert ",True,Keys" in rt.lower_plan(d, E.pred(F(1, O.Range(abi.Bound.Unbounded, abi.Bound.Unbounded))), cnt)[0]
+    # compares are determined where every referenced field is present
+    assert "Cols<I64,F64,U8,U8>,Cmp<5,ToF64<Col<0,I64>>,Col<1,F64>,And<Valid<2>,Valid<3>>>" in rt.lower_plan(d, E.compare(col(1), abi.CMP_GT, col(2)), cnt)[0]
+    # aggregates
+    ts, lanes, _ = rt.lower_plan(d, None, [A.count(1), A.count_nulls(1), A.sum(1), A.avg(2), A.sum(col(1) * col(2)), A.sum(3)])
+    assert "CountIf<Valid<0>>" in ts and "IfValid<Valid<0>,SumI64<Col<1,I64>>>" in ts and "IfValid<Valid<2>,SumF64<Col<3,F64>>>" in ts
+    assert "IfValid<And<Valid<0>,Valid<2>>,SumF64<Bin<3,ToF64<Col<1,I64>>,Col<3,F64>>>>" in ts and ",SumI64<Col<4,I64>>>" in ts
+    with pytest.raises(abi.LlkvError) as e:
+        rt.lower_plan(d, None, cnt, keys=[1], grouped=True)
+    assert e.value.kind == "Unsupported"
 
 
 def test_int_sum_uses_statistics_to_exclude_overflow(lib, abi):
