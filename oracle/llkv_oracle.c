@@ -1556,7 +1556,11 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
 typedef struct jt_entry { int64_t key; uint64_t head, tail; int used; } jt_entry;
 
 static int32_t join_key_value(const orc_column *c, uint64_t row, int null_eq, int64_t *out) {
-  if (!col_valid(c, row)) { if (!null_eq) return 0; *out = INT64_MIN; return 1; }
+  if (!col_valid(c, row)) { /* per-type sentinels of the fast paths, hash_join.rs:1429-1465 */
+    if (!null_eq) return 0;
+    *out = c->dtype == LLKV_DT_INT64 ? INT64_MIN : c->dtype == LLKV_DT_UINT64 ? (int64_t)UINT64_MAX : c->dtype == LLKV_DT_UINT32 ? (int64_t)UINT32_MAX : (int64_t)INT32_MIN;
+    return 1;
+  }
   switch (c->dtype) {
   case LLKV_DT_INT64: *out = ((const int64_t *)c->values)[row]; return 1;
   case LLKV_DT_INT32: case LLKV_DT_DATE32: *out = ((const int32_t *)c->values)[row]; return 1;
@@ -1577,6 +1581,8 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
   if (!lc || !rc_) return fail(LLKV_NOT_FOUND, "join key field not found");
   if (vclass_of(lc->dtype) > VC_U64 || vclass_of(rc_->dtype) > VC_U64 || vclass_of(lc->dtype) < 0 || vclass_of(rc_->dtype) < 0)
     return fail(LLKV_UNSUPPORTED, "non-integer join key");
+  /* fast path only for identical key types (hash_join.rs:174-198); the generic typed-key path is not restated */
+  if (lc->dtype != rc_->dtype) return fail(LLKV_UNSUPPORTED, "join keys of different types");
   int null_eq = keys[0].null_equals_null;
 
   /* build: open addressing on key, chained row lists in insertion order */

@@ -49,16 +49,21 @@ struct HBuf {
 constexpr uint32_t kJoinTileRows = 8192;
 constexpr uint32_t kWindowTiles = 8; // 65 536 probe rows per window = one reference probe batch
 
-int key_column(const Table *t, uint32_t field, JoinKeyColumn *out) {
+int key_column(const Table *t, uint32_t field, bool null_equals_null, JoinKeyColumn *out, int32_t *dtype) {
   auto it = t->cols.find(field);
   if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "join key field " + std::to_string(field) + " not found");
   const int32_t dt = it->second.info.dtype;
-  if (it->second.info.nullable) return set_error(LLKV_UNSUPPORTED, "join key column with NULL cells");
+  *dtype = dt;
   out->values = it->second.d_values;
+  out->valid = it->second.info.nullable ? it->second.d_valid : nullptr;
+  out->null_equals_null = null_equals_null ? 1u : 0u;
+  if (out->valid && null_equals_null && dt == LLKV_DT_DATE32)
+    return set_error(LLKV_UNSUPPORTED, "null_equals_null over Date32 keys (generic path: NULL = NULL without a sentinel)");
   switch (dt) {
-  case LLKV_DT_INT64: case LLKV_DT_UINT64: out->width = 8; out->is_signed = 1; return LLKV_OK;
-  case LLKV_DT_INT32: case LLKV_DT_DATE32: out->width = 4; out->is_signed = 1; return LLKV_OK;
-  case LLKV_DT_UINT32: out->width = 4; out->is_signed = 0; return LLKV_OK;
+  case LLKV_DT_INT64: out->width = 8; out->is_signed = 1; out->null_sentinel = INT64_MIN; return LLKV_OK;
+  case LLKV_DT_UINT64: out->width = 8; out->is_signed = 1; out->null_sentinel = (long long)UINT64_MAX; return LLKV_OK;
+  case LLKV_DT_INT32: case LLKV_DT_DATE32: out->width = 4; out->is_signed = 1; out->null_sentinel = INT32_MIN; return LLKV_OK;
+  case LLKV_DT_UINT32: out->width = 4; out->is_signed = 0; out->null_sentinel = (long long)UINT32_MAX; return LLKV_OK;
   default: return set_error(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(dt) + " (integer fast path only)");
   }
 }
@@ -77,7 +82,12 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   if (!left || !right || !on_batch) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
   if (n_keys != 1) return set_error(LLKV_UNSUPPORTED, "GPU join path takes exactly one integer key pair (cross products and composite keys stay on the CPU route)");
   JoinKeyColumn lk, rk;
-  if ((rc = key_column(left, keys[0].left_field, &lk)) || (rc = key_column(right, keys[0].right_field, &rk))) return rc;
+  int32_t ldt, rdt;
+  const bool null_eq = keys[0].null_equals_null != 0;
+  if ((rc = key_column(left, keys[0].left_field, null_eq, &lk, &ldt)) || (rc = key_column(right, keys[0].right_field, null_eq, &rk, &rdt))) return rc;
+  // the integer fast path needs identical key types (hash_join.rs:174-198); mixed types take the generic
+  // typed-key path, where values of different types never compare equal
+  if (ldt != rdt) return set_error(LLKV_UNSUPPORTED, std::string("join keys of different types (") + dtype_name(ldt) + ", " + dtype_name(rdt) + ")");
 
   hipStream_t s = g_ctx.stream;
   const TileSet *tr = nullptr, *tl = nullptr;
@@ -90,13 +100,13 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   uint32_t bits = 10;
   while (cap < 2 * n_build) { cap <<= 1; ++bits; }
   DBuf owner, slot_of, dev_of, log_of, seg_start, seg_count, idx_in, slot_sorted, idx_sorted, tile_base, tmp;
-  if ((rc = owner.ensure(cap * 8)) || (rc = seg_start.ensure(cap * 4)) || (rc = seg_count.ensure(cap * 4)) ||
+  if ((rc = owner.ensure(cap * 8)) || (rc = seg_start.ensure((cap + 1) * 4)) || (rc = seg_count.ensure((cap + 1) * 4)) ||
       (rc = slot_of.ensure(n_build * 4)) || (rc = dev_of.ensure(n_build * 8)) || (rc = log_of.ensure(n_build * 8)) ||
       (rc = idx_in.ensure(n_build * 4)) || (rc = slot_sorted.ensure(n_build * 4)) || (rc = idx_sorted.ensure(n_build * 4)) ||
       (rc = tile_base.ensure((size_t)(tr->n_tiles + 1) * 8)))
     return rc;
   HIP_TRY(hipMemsetAsync(owner.p, 0xFF, cap * 8, s));
-  HIP_TRY(hipMemsetAsync(seg_count.p, 0, cap * 4, s));
+  HIP_TRY(hipMemsetAsync(seg_count.p, 0, (cap + 1) * 4, s)); // + the slot that parks NULL build keys
   if (n_build) {
     std::vector<TileDesc> tiles;
     uint32_t otb[kOctantsHost + 1];
@@ -110,10 +120,10 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     HIP_TRY(hj_launch_iota((uint32_t *)idx_in.p, (uint32_t)n_build, s));
     size_t tmp_bytes = 0;
     HIP_TRY(hj_sort_by_slot(nullptr, &tmp_bytes, (const uint32_t *)slot_of.p, (uint32_t *)slot_sorted.p, (const uint32_t *)idx_in.p,
-                            (uint32_t *)idx_sorted.p, (uint32_t)n_build, bits, s));
+                            (uint32_t *)idx_sorted.p, (uint32_t)n_build, bits + 1, s));
     if ((rc = tmp.ensure(tmp_bytes))) return rc;
     HIP_TRY(hj_sort_by_slot(tmp.p, &tmp_bytes, (const uint32_t *)slot_of.p, (uint32_t *)slot_sorted.p, (const uint32_t *)idx_in.p,
-                            (uint32_t *)idx_sorted.p, (uint32_t)n_build, bits, s));
+                            (uint32_t *)idx_sorted.p, (uint32_t)n_build, bits + 1, s));
     HIP_TRY(hj_launch_segments((const uint32_t *)slot_sorted.p, (uint32_t)n_build, (uint32_t *)seg_start.p, (uint32_t *)seg_count.p, s));
   }
 

@@ -21,6 +21,16 @@ __device__ __forceinline__ long long load_key(const JoinKeyColumn &k, uint64_t r
   return k.is_signed ? (long long)(int32_t)v : (long long)v;
 }
 
+// Key of `row`; false when it is a NULL that matches nothing.
+__device__ __forceinline__ bool load_key_nullable(const JoinKeyColumn &k, uint64_t row, long long *out) {
+  if (k.valid && !k.valid[row]) {
+    *out = k.null_sentinel;
+    return k.null_equals_null != 0;
+  }
+  *out = load_key(k, row);
+  return true;
+}
+
 __device__ __forceinline__ uint64_t hash_key(long long k) {
   uint64_t x = (uint64_t)k;
   x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
@@ -40,7 +50,11 @@ __global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeyColumn key, const 
     const uint64_t ci = cbase + r; // compact build index (dense over real rows)
     dev_row_of[ci] = drow;
     logical_of[ci] = td.logical_row + r;
-    const long long k = load_key(key, drow);
+    long long k;
+    if (!load_key_nullable(key, drow, &k)) { // a NULL build key is parked in the extra slot no probe reaches
+      slot_of[ci] = (uint32_t)(cap_mask + 1);
+      continue;
+    }
     uint64_t s = hash_key(k) & cap_mask;
     for (;;) {
       unsigned long long owner = slot_owner[s];
@@ -48,7 +62,8 @@ __global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeyColumn key, const 
         const unsigned long long prev = atomicCAS(&slot_owner[s], kEmpty, (unsigned long long)drow);
         owner = prev == kEmpty ? (unsigned long long)drow : prev;
       }
-      if (owner == (unsigned long long)drow || load_key(key, owner) == k) break;
+      long long ko;
+      if (owner == (unsigned long long)drow || (load_key_nullable(key, owner, &ko), ko == k)) break;
       s = (s + 1) & cap_mask;
     }
     slot_of[ci] = (uint32_t)s;
@@ -105,13 +120,17 @@ __global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
     uint64_t cnt = 0;
     uint32_t mslot = 0xFFFFFFFFu;
     if (r < td.rows) {
-      const long long k = load_key(p.lkey, td.dev_row + r);
-      uint64_t s = hash_key(k) & p.cap_mask;
-      for (;;) {
-        const unsigned long long owner = p.slot_owner[s];
-        if (owner == kEmpty) break;
-        if (load_key(p.rkey, owner) == k) { mslot = (uint32_t)s; break; }
-        s = (s + 1) & p.cap_mask;
+      long long k;
+      if (load_key_nullable(p.lkey, td.dev_row + r, &k)) {
+        uint64_t s = hash_key(k) & p.cap_mask;
+        for (;;) {
+          const unsigned long long owner = p.slot_owner[s];
+          if (owner == kEmpty) break;
+          long long ko;
+          load_key_nullable(p.rkey, owner, &ko); // owners are never non-matching NULLs
+          if (ko == k) { mslot = (uint32_t)s; break; }
+          s = (s + 1) & p.cap_mask;
+        }
       }
       const uint64_t m = mslot != 0xFFFFFFFFu ? p.seg_count[mslot] : 0;
       switch (p.join_type) {

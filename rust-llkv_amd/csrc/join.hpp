@@ -13,6 +13,12 @@ struct JoinKeyColumn {
   const void *values; // device column image
   uint32_t width;     // 4 or 8 bytes
   uint32_t is_signed; // sign-extend 4-byte keys
+  // NULL cells: a NULL key matches nothing (llkv-join/src/hash_join.rs:1116-1123,1172-1177) unless the join
+  // key says null_equals_null, in which case the reference substitutes a per-type sentinel — and a real key of
+  // that value then joins with the NULLs (:1429-1465); restated as is.
+  const uint8_t *valid = nullptr; // 1 B/row validity mask or nullptr (no NULL cells)
+  uint32_t null_equals_null = 0;
+  long long null_sentinel = 0;
 };
 
 // Build side: distinct keys claim slots of an open-addressing table (slot_owner = row that owns the slot,

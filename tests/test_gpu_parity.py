@@ -546,6 +546,40 @@ def test_random_joins_match_oracle(rt, orc, abi, n_left, n_right, keyspace, batc
         assert [len(b[0]) for b in got] == [len(b[0]) for b in want]
 
 
+@pytest.mark.parametrize("dt", ["DT_INT64", "DT_INT32", "DT_UINT32", "DT_UINT64"])
+@pytest.mark.parametrize("null_eq", [False, True])
+def test_joins_with_null_keys_match_oracle(rt, orc, abi, dt, null_eq):
+    """A NULL key matches nothing (hash_join.rs:1116-1123,1172-1177); with null_equals_null the reference
+    substitutes a per-type sentinel, so a real key of that value joins with the NULLs (:1429-1465)."""
+    dtype = getattr(abi, dt)
+    npdt = np.dtype(abi.NUMPY_OF_DTYPE[dtype])
+    sentinel = {abi.DT_INT64: -2**63, abi.DT_INT32: -2**31, abi.DT_UINT32: 2**32 - 1, abi.DT_UINT64: 2**64 - 1}[dtype]
+    rng = np.random.default_rng(5)
+    n_left, n_right = 9000, 3000
+    lk = rng.integers(0, 400, size=n_left).astype(npdt)
+    rk = rng.integers(100, 600, size=n_right).astype(npdt)
+    lk[rng.random(n_left) < 0.01] = sentinel
+    rk[rng.random(n_right) < 0.01] = sentinel
+    lv, rv = rng.random(n_left) > 0.1, rng.random(n_right) > 0.1
+    lt = rt.HipTable(1, [4096, n_left - 4096]); lt.append_column(1, dtype, lk, valid=lv)
+    rtab = rt.HipTable(2, [n_right]); rtab.append_column(7, dtype, rk, valid=rv)
+    ol = orc.OracleTable(n_left).add(1, dtype, lk, list(lv))
+    orr = orc.OracleTable(n_right).add(7, dtype, rk, list(rv))
+    for jt in ("inner", "left", "semi", "anti"):
+        got = rt.join_stream(lt, rtab, [(1, 7, null_eq)], JT[jt], 8192)
+        want = orc.hash_join(ol, orr, [(1, 7, null_eq)], JT[jt], 8192)
+        assert [x for b in got for x in b[0]] == [x for b in want for x in b[0]], jt
+        if jt in ("inner", "left"):
+            assert [x for b in got for x in b[1]] == [x for b in want for x in b[1]], jt
+        assert [len(b[0]) for b in got] == [len(b[0]) for b in want]
+    # key types must agree (the integer fast path; hash_join.rs:174-198)
+    if dtype != abi.DT_INT64:
+        other = rt.HipTable(3, [4]); other.append_column(9, abi.DT_INT64, np.arange(4, dtype=np.int64))
+        with pytest.raises(abi.LlkvError) as e:
+            rt.join_stream(lt, other, [(1, 9)], JT["inner"], 8192)
+        assert e.value.kind == "Unsupported"
+
+
 @pytest.mark.parametrize("rows,scale", [(60175, 0.01), (600_000, 0.1)])
 def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
     """TPC-H Q3 shape (BASELINE.json configs[4], single GPU): customer(segment) ⋉ orders(date) ⋈ lineitem(shipdate),
