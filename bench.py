@@ -52,6 +52,8 @@ def stage(rt, tpch, abi, dist, query, total_rows, scale, rank, world, row_begin_
             table.append_utf8_column(fid, data[name], dmod.table_wide_dictionary(dist, data[name], world))
         else:
             table.append_column(fid, dt, data[name])
+    dmod.share_column_stats(dist, table, [tpch.LINEITEM_SCHEMA[n][0] for n in query.columns if tpch.LINEITEM_SCHEMA[n][1] != abi.DT_UTF8 and
+                                          table.local_column_stats(tpch.LINEITEM_SCHEMA[n][0]) is not None], world)
     return table, data
 
 
@@ -114,6 +116,8 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
                 table.append_utf8_column(fid, data[cname], dmod.table_wide_dictionary(dist, data[cname], world))
             else:
                 table.append_column(fid, dt, data[cname])
+        dmod.share_column_stats(dist, table, [tpch.LINEITEM_SCHEMA[n][0] for n in query.columns if tpch.LINEITEM_SCHEMA[n][1] != abi.DT_UTF8 and
+                                              table.local_column_stats(tpch.LINEITEM_SCHEMA[n][0]) is not None], world)
     else:
         table, data = stage(rt, tpch, abi, dist, query, total_rows, gen_scale, rank, world)
     del data

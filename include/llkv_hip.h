@@ -51,7 +51,8 @@ typedef enum llkv_dtype {
   LLKV_DT_UINT32 = 6,
   LLKV_DT_FLOAT32 = 7,
   LLKV_DT_UTF8 = 8,     /* staged as 1-byte dictionary codes in HBM          */
-  LLKV_DT_BOOLEAN = 9
+  LLKV_DT_BOOLEAN = 9,
+  LLKV_DT_DECIMAL128 = 10 /* i128 raw value, little endian, with the column's (precision, scale) */
 } llkv_dtype;
 
 /* ------------------------------------------------------------------------- */
@@ -206,11 +207,13 @@ typedef struct llkv_aggregate_spec {
 /* One finalized aggregate cell = the 1-element Arrow array returned by
  * `AggregateAccumulator::finalize` llkv-aggregate/src/lib.rs:1488-1939.      */
 typedef struct llkv_value {
-  int32_t dtype;   /* LLKV_DT_INT64 / LLKV_DT_FLOAT64 / LLKV_DT_UTF8        */
+  int32_t dtype;   /* LLKV_DT_INT64 / LLKV_DT_FLOAT64 / LLKV_DT_UTF8 / LLKV_DT_DECIMAL128 */
   int32_t is_null;
-  int64_t i64;
+  int64_t i64;     /* Decimal128: low 64 bits of the raw value                */
   double f64;
   const char *str; /* group keys of Utf8 type; owned by the result object    */
+  int64_t i64_hi;  /* Decimal128: high 64 bits of the raw value              */
+  int32_t precision, scale; /* Decimal128(precision, scale)                  */
 } llkv_value;
 
 /* ------------------------------------------------------------------------- */
@@ -301,6 +304,30 @@ llkv_status llkv_hip_table_append_arr0_column(llkv_hip_table *table, uint32_t fi
 /* Adopt a buffer that already lives in HBM (all local chunks back to back). */
 llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id,
                                                int32_t dtype, const void *device_values);
+
+/* Decimal128(precision, scale) column: 16-byte little-endian i128 raw values per row
+ * (arrow Decimal128Array).  The reference cannot filter such a column at the leaf
+ * (llkv-table/src/table.rs:1160-1167) but aggregates it exactly (i128 checked sums,
+ * llkv-aggregate/src/lib.rs:925-967,1236-1284,1720-1804).  When every value of the
+ * column fits 64 bits (DECIMAL(15,2) money columns always do) the HBM image is
+ * narrowed to 8 B/row at staging — half the traffic, and a sum of < 2^63 rows can
+ * no longer leave i128, so the order-dependent overflow check disappears; wider
+ * values return LLKV_UNSUPPORTED.                                               */
+llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint32_t field_id,
+                                                    int32_t precision, int32_t scale,
+                                                    const void *const *chunk_values,
+                                                    uint32_t n_chunks);
+
+/* Integer column statistics (the analogue of ChunkMetadata.min/max_val_u64, llkv-column-map/src/store/
+ * descriptor.rs:19-84).  Plans use them (exact SUM without overflow tracking, dense integer GROUP BY), so every
+ * rank of a sharded table must see the SAME, table-wide values: a single-rank table gets them from a reduction
+ * at staging; with world > 1 the local values are only readable here, and the binding installs the table-wide
+ * ones (the descriptor holds every chunk's min/max; or an all-reduce of the local values) before preparing
+ * queries.  Without them the plans fall back to the statistics-free forms.                                   */
+llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint32_t field_id,
+                                              int32_t *has_stats, int64_t *min_value, int64_t *max_value);
+llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t field_id,
+                                            int64_t min_value, int64_t max_value);
 
 /* NULL cells of an already staged column.  In the reference a NULL cell is a row
  * id that is absent from the column's row-id shadow chunks (llkv-table/src/
@@ -436,6 +463,7 @@ typedef struct llkv_column_view {
   const void *values;      /* host memory, valid during the callback only     */
   const uint8_t *validity; /* Arrow validity bitmap or NULL (all valid)       */
   const char *const *dictionary; /* Utf8: code → string, else NULL            */
+  int32_t precision, scale;      /* Decimal128: 16-byte little-endian values  */
 } llkv_column_view;
 
 typedef struct llkv_batch_view {
@@ -560,6 +588,7 @@ typedef struct llkv_column_desc {
   uint32_t dict_size; /* LLKV_DT_UTF8                                        */
   const char *const *dictionary;
   int32_t nullable;   /* the column has NULL cells                           */
+  int32_t precision, scale; /* LLKV_DT_DECIMAL128                            */
 } llkv_column_desc;
 
 /* `grouped`: 0 = ungrouped aggregates, 1 = GROUP BY (groups in first-appearance

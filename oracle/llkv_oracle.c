@@ -129,6 +129,7 @@ static const char *dtype_name(int32_t dt) {
   case LLKV_DT_FLOAT32: return "Float32";
   case LLKV_DT_UTF8: return "Utf8";
   case LLKV_DT_BOOLEAN: return "Boolean";
+  case LLKV_DT_DECIMAL128: return "Decimal128";
   default: return "Null";
   }
 }
@@ -412,6 +413,8 @@ static int32_t filter_leaf(const orc_table *t, const llkv_filter *f, idvec *out)
     *out = idv_all(t->rows); /* table.rs:1146-1153: every table row, NULLs included */
     return LLKV_OK;
   }
+  if (c->dtype == LLKV_DT_DECIMAL128) /* llkv-table/src/table.rs:1160-1167 (the DataType's Debug form) */
+    return fail(LLKV_INTERNAL, "Filtering on type Decimal128(%d, %d) is not supported", c->precision, c->scale);
   tpred p;
   int32_t rc = build_predicate(f, c->dtype, &p);
   if (rc) return rc;
@@ -523,6 +526,7 @@ typedef struct arr {
   void *values;
   uint8_t *valid;
   char **strings;
+  int32_t precision, scale; /* LLKV_DT_DECIMAL128 */
 } arr;
 
 static void arr_free(arr *a) {
@@ -537,6 +541,7 @@ static size_t dtype_width(int32_t dt) {
   case LLKV_DT_INT64: case LLKV_DT_UINT64: case LLKV_DT_FLOAT64: return 8;
   case LLKV_DT_INT32: case LLKV_DT_DATE32: case LLKV_DT_UINT32: case LLKV_DT_FLOAT32: return 4;
   case LLKV_DT_BOOLEAN: return 1;
+  case LLKV_DT_DECIMAL128: return 16;
   default: return 0;
   }
 }
@@ -547,6 +552,7 @@ static arr gather_column(const orc_column *c, const uint64_t *ids, uint64_t n) {
   arr a;
   memset(&a, 0, sizeof a);
   a.dtype = c->dtype;
+  a.precision = c->precision; a.scale = c->scale;
   a.n = n;
   a.valid = xmalloc(n);
   if (c->dtype == LLKV_DT_UTF8) {
@@ -992,6 +998,7 @@ static void stream_window(const arr *cols, uint32_t n_cols, const uint64_t *row_
     bc[i].values = cols[i].values;
     bc[i].valid = cols[i].valid;
     bc[i].strings = (const char *const *)cols[i].strings;
+    bc[i].precision = cols[i].precision; bc[i].scale = cols[i].scale;
   }
   orc_batch b = {n, n_cols, bc, s->include_row_ids ? row_ids : NULL};
   s->cb(&b, s->user);
@@ -1019,7 +1026,8 @@ int32_t orc_scan_stream(const orc_table *t, const llkv_projection *projections, 
 /* llkv-aggregate/src/lib.rs: state :95-249, update :759-1477, finalize :1488-1939. */
 enum {
   ACC_COUNT_STAR, ACC_COUNT_COLUMN, ACC_SUM_I64, ACC_SUM_F64, ACC_TOTAL_I64, ACC_TOTAL_F64,
-  ACC_AVG_I64, ACC_AVG_F64, ACC_MIN_I64, ACC_MIN_F64, ACC_MAX_I64, ACC_MAX_F64, ACC_COUNT_NULLS
+  ACC_AVG_I64, ACC_AVG_F64, ACC_MIN_I64, ACC_MIN_F64, ACC_MAX_I64, ACC_MAX_F64, ACC_COUNT_NULLS,
+  ACC_SUM_DEC, ACC_TOTAL_DEC, ACC_AVG_DEC, ACC_MIN_DEC, ACC_MAX_DEC /* Decimal128: i128 state, :925-967,1071-1088,1236-1259,1332-1352,1400-1420 */
 };
 typedef struct acc {
   int kind;
@@ -1027,6 +1035,8 @@ typedef struct acc {
   double f;       /* f64 sum / min / max */
   int64_t count;  /* avg count, count_nulls total rows */
   int has;        /* has_values / saw_value / Some(..) */
+  __int128 d;     /* Decimal128 sum / min / max */
+  int32_t precision, scale;
 } acc;
 
 /* array_value_to_numeric :400-449 */
@@ -1057,6 +1067,10 @@ static int32_t acc_new(int32_t agg_kind, int32_t input_dtype, acc *out) {
   if (agg_kind == LLKV_AGG_COUNT_NULLS) { out->kind = ACC_COUNT_NULLS; return LLKV_OK; }
   const char *fn = agg_kind == LLKV_AGG_SUM ? "SUM" : agg_kind == LLKV_AGG_TOTAL ? "TOTAL" : agg_kind == LLKV_AGG_AVG ? "AVG" : agg_kind == LLKV_AGG_MIN ? "MIN" : "MAX";
   int32_t dt;
+  if (input_dtype == LLKV_DT_DECIMAL128) { /* (precision, scale) are filled in by the caller */
+    out->kind = agg_kind == LLKV_AGG_SUM ? ACC_SUM_DEC : agg_kind == LLKV_AGG_TOTAL ? ACC_TOTAL_DEC : agg_kind == LLKV_AGG_AVG ? ACC_AVG_DEC : agg_kind == LLKV_AGG_MIN ? ACC_MIN_DEC : ACC_MAX_DEC;
+    return LLKV_OK;
+  }
   switch (input_dtype) {
   case LLKV_DT_INT64: case LLKV_DT_FLOAT64: dt = input_dtype; break;
   case LLKV_DT_UTF8: case LLKV_DT_BOOLEAN: case LLKV_DT_DATE32: case LLKV_DT_NULL: dt = LLKV_DT_FLOAT64; break;
@@ -1115,6 +1129,26 @@ static int32_t acc_update(acc *a, const arr *col, uint64_t num_rows) {
       }
     }
     return LLKV_OK;
+  case ACC_SUM_DEC: case ACC_TOTAL_DEC: case ACC_AVG_DEC: case ACC_MIN_DEC: case ACC_MAX_DEC:
+    if (col->dtype != LLKV_DT_DECIMAL128) return fail(LLKV_INVALID_ARGUMENT, "Expected Decimal128 array");
+    a->precision = col->precision; a->scale = col->scale;
+    for (uint64_t i = 0; i < col->n; ++i) {
+      if (!col->valid[i]) continue;
+      __int128 v;
+      memcpy(&v, (const char *)col->values + i * 16, 16);
+      switch (a->kind) {
+      case ACC_SUM_DEC: case ACC_AVG_DEC:
+        if (__builtin_add_overflow(a->d, v, &a->d)) return fail(LLKV_INVALID_ARGUMENT, "Decimal128 sum overflow");
+        if (a->kind == ACC_AVG_DEC) a->count += 1;
+        break;
+      case ACC_TOTAL_DEC:
+        if (__builtin_add_overflow(a->d, v, &a->d)) return fail(LLKV_INVALID_ARGUMENT, "Decimal128 total overflow");
+        break;
+      case ACC_MIN_DEC: a->d = a->has ? (v < a->d ? v : a->d) : v; a->has = 1; break;
+      case ACC_MAX_DEC: a->d = a->has ? (v > a->d ? v : a->d) : v; a->has = 1; break;
+      }
+    }
+    return LLKV_OK;
   default: /* Float64 accumulators with numeric coercion */
     if (col->dtype == LLKV_DT_NULL) return LLKV_OK;
     for (uint64_t i = 0; i < col->n; ++i) {
@@ -1151,6 +1185,22 @@ static void acc_finalize(const acc *a, llkv_value *out) {
   case ACC_AVG_F64: out->dtype = LLKV_DT_FLOAT64; out->is_null = a->count <= 0; if (a->count > 0) out->f64 = a->f / (double)a->count; break;
   case ACC_MIN_I64: case ACC_MAX_I64: out->dtype = LLKV_DT_INT64; out->is_null = !a->has; out->i64 = a->has ? a->i : 0; break;
   case ACC_MIN_F64: case ACC_MAX_F64: out->dtype = LLKV_DT_FLOAT64; out->is_null = !a->has; out->f64 = a->has ? a->f : 0; break;
+  case ACC_SUM_DEC: case ACC_TOTAL_DEC: case ACC_AVG_DEC: case ACC_MIN_DEC: case ACC_MAX_DEC: {
+    __int128 v = a->d;
+    out->dtype = LLKV_DT_DECIMAL128; out->precision = a->precision; out->scale = a->scale;
+    if (a->kind == ACC_AVG_DEC) { /* :1720-1760 sum / count, rounded half away from zero */
+      if (a->count > 0) {
+        const __int128 n = a->count, rem = a->d % n;
+        v = a->d / n;
+        if ((rem < 0 ? -rem : rem) * 2 >= n) v += (a->d > 0) ? 1 : -1; /* sum.signum() vs count.signum() (> 0) */
+      } else out->is_null = 1;
+    } else if (a->kind == ACC_MIN_DEC || a->kind == ACC_MAX_DEC) out->is_null = !a->has;
+    /* SUM / TOTAL: `vec![sum]` — 0, never NULL, even without rows (:1567-1582,1640-1655) */
+    if (out->is_null) v = 0;
+    out->i64 = (int64_t)(uint64_t)v;
+    out->i64_hi = (int64_t)(v >> 64);
+    break;
+  }
   }
 }
 
@@ -1195,6 +1245,10 @@ int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n
     if (!is_simple_column(aggs[i].expr, aggs[i].expr_len) && dt != LLKV_DT_FLOAT64) dt = LLKV_DT_INT64;
     rc = acc_new(aggs[i].kind, dt, &accs[i]);
     if (rc) break;
+    if (dt == LLKV_DT_DECIMAL128) { /* the spec's DataType::Decimal128(precision, scale) */
+      const orc_column *dc = find_col(t, aggs[i].expr[0].field_id);
+      accs[i].precision = dc->precision; accs[i].scale = dc->scale;
+    }
     proj_of[i] = (int32_t)n_projs;
     projs[n_projs].computed = !is_simple_column(aggs[i].expr, aggs[i].expr_len);
     projs[n_projs].field_id = aggs[i].expr[0].field_id;
@@ -1419,7 +1473,7 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
     if (!c) { free(projs); free(m.cols); return fail(LLKV_INVALID_ARGUMENT, "column %u not found in GROUP BY input", fields[j]); }
     projs[j].field_id = fields[j];
     m.cols[j].field_id = fields[j];
-    m.cols[j].a.dtype = c->dtype;
+    m.cols[j].a.dtype = c->dtype; m.cols[j].a.precision = c->precision; m.cols[j].a.scale = c->scale;
   }
   int32_t rc = scan_core(t, projs, n_fields, filters, n_filters, ops, n_ops, /*include_nulls=*/1, gb_window, &m);
   free(projs);
@@ -1436,7 +1490,7 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
     for (uint32_t k = 0; k < n_keys; ++k) {
       const arr *a = find_gathered(m.cols, n_fields, key_fields[k]);
       pval v = pv_from_arr(a, r);
-      if (v.tag == PV_FLOAT) { rc = fail(LLKV_INVALID_ARGUMENT, "GROUP BY does not support column type %s", dtype_name(a->dtype)); break; }
+      if (v.tag == PV_FLOAT || a->dtype == LLKV_DT_DECIMAL128) { rc = fail(LLKV_INVALID_ARGUMENT, "GROUP BY does not support column type %s", dtype_name(a->dtype)); break; }
       cur[k].tag = v.tag; cur[k].i = v.i; cur[k].s = (char *)v.s;
     }
     if (rc) break;
@@ -1486,8 +1540,9 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
           const arr *src = find_gathered(m.cols, n_fields, aggs[a].expr[0].field_id);
           rc = acc_new(aggs[a].kind, src->dtype, &st);
           if (rc) break;
+          st.precision = src->precision; st.scale = src->scale;
           /* arrow `take` of the group's rows (:5131-5146) */
-          col.dtype = src->dtype; col.n = gn; col.valid = xmalloc(gn ? gn : 1);
+          col.dtype = src->dtype; col.precision = src->precision; col.scale = src->scale; col.n = gn; col.valid = xmalloc(gn ? gn : 1);
           size_t w = dtype_width(src->dtype);
           col.values = xmalloc((gn ? gn : 1) * (w ? w : 1));
           if (src->dtype == LLKV_DT_UTF8) col.strings = xcalloc(gn ? gn : 1, sizeof(char *));

@@ -31,6 +31,7 @@ typedef struct orc_column {
   const uint8_t *validity;
   const int32_t *offsets;  /* LLKV_DT_UTF8: Arrow offsets (rows+1)                */
   const uint8_t *data;     /* LLKV_DT_UTF8: Arrow data                            */
+  int32_t precision, scale; /* LLKV_DT_DECIMAL128: values are 16-byte little-endian i128 */
 } orc_column;
 
 typedef struct orc_table {
@@ -53,6 +54,7 @@ typedef struct orc_batch_column {
   const void *values;      /* i64 / f64 / i32 / u64 / f32 / u32 values; Utf8: NULL */
   const uint8_t *valid;    /* one byte per row, 1 = valid                          */
   const char *const *strings; /* Utf8: per-row NUL-terminated copies              */
+  int32_t precision, scale;   /* Decimal128 (16-byte values)                       */
 } orc_batch_column;
 
 typedef struct orc_batch {

@@ -27,7 +27,7 @@ def build():
 
 class COrcColumn(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("values", C.c_void_p), ("validity", C.c_void_p),
-                ("offsets", C.c_void_p), ("data", C.c_void_p)]
+                ("offsets", C.c_void_p), ("data", C.c_void_p), ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 class COrcTable(C.Structure):
@@ -36,7 +36,7 @@ class COrcTable(C.Structure):
 
 class COrcBatchColumn(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("values", C.c_void_p), ("valid", C.POINTER(C.c_uint8)),
-                ("strings", C.POINTER(C.c_char_p))]
+                ("strings", C.POINTER(C.c_char_p)), ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 class COrcBatch(C.Structure):
@@ -82,10 +82,15 @@ class OracleTable:
         self._cols: List[COrcColumn] = []
         self._keep: list = []
 
-    def add(self, field_id: int, dtype: int, values, valid: Optional[Sequence[bool]] = None):
+    def add(self, field_id: int, dtype: int, values, valid: Optional[Sequence[bool]] = None, precision: int = 0, scale: int = 0):
         c = COrcColumn()
         c.field_id, c.dtype = field_id, dtype
-        if dtype == abi.DT_UTF8:
+        if dtype == abi.DT_DECIMAL128:  # Python ints → 16-byte little-endian raw values
+            arr = abi.i128_buffer(values)
+            assert len(arr) == self.rows
+            self._keep.append(arr)
+            c.values, c.precision, c.scale = arr.ctypes.data, precision, scale
+        elif dtype == abi.DT_UTF8:
             if isinstance(values, np.ndarray) and values.dtype == np.uint8:
                 data = np.ascontiguousarray(values)
                 offsets = np.arange(len(values) + 1, dtype=np.int32)
@@ -199,7 +204,10 @@ def scan_stream(table: OracleTable, projections, predicate, include_nulls=False,
             c = b.columns[ci]
             n = b.num_rows
             valid = [bool(c.valid[i]) for i in range(n)]
-            if c.dtype == abi.DT_UTF8:
+            if c.dtype == abi.DT_DECIMAL128:
+                raw = np.frombuffer(C.string_at(c.values, n * 16), dtype=np.uint64).reshape(n, 2)
+                vals = [abi.i128_from_words(int(raw[i, 0]), int(np.int64(raw[i, 1]))) if valid[i] else None for i in range(n)]
+            elif c.dtype == abi.DT_UTF8:
                 vals = [c.strings[i].decode() if valid[i] else None for i in range(n)]
             else:
                 npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])

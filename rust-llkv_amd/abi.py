@@ -18,11 +18,28 @@ STATUS_NAMES = {
     5: "NoDevice", 6: "PredicateBuild",
 }
 
-DT_NULL, DT_INT64, DT_FLOAT64, DT_INT32, DT_DATE32, DT_UINT64, DT_UINT32, DT_FLOAT32, DT_UTF8, DT_BOOLEAN = range(10)
+DT_NULL, DT_INT64, DT_FLOAT64, DT_INT32, DT_DATE32, DT_UINT64, DT_UINT32, DT_FLOAT32, DT_UTF8, DT_BOOLEAN, DT_DECIMAL128 = range(11)
 DT_NAMES = {0: "Null", 1: "Int64", 2: "Float64", 3: "Int32", 4: "Date32", 5: "UInt64", 6: "UInt32",
-            7: "Float32", 8: "Utf8", 9: "Boolean"}
+            7: "Float32", 8: "Utf8", 9: "Boolean", 10: "Decimal128"}
 NUMPY_OF_DTYPE = {DT_INT64: "int64", DT_FLOAT64: "float64", DT_INT32: "int32", DT_DATE32: "int32",
                   DT_UINT64: "uint64", DT_UINT32: "uint32", DT_FLOAT32: "float32", DT_BOOLEAN: "uint8"}
+
+
+
+def i128_buffer(values) -> "np.ndarray":
+    """Python ints → arrow Decimal128 raw buffer: (n, 2) uint64, little endian (lo, hi)."""
+    import numpy as np
+    out = np.empty((len(values), 2), dtype=np.uint64)
+    for i, v in enumerate(values):
+        u = int(v) & ((1 << 128) - 1)
+        out[i, 0], out[i, 1] = u & 0xFFFFFFFFFFFFFFFF, u >> 64
+    return out
+
+
+def i128_from_words(lo: int, hi: int) -> int:
+    """(low u64 bits, high i64) → Python int."""
+    return (int(hi) << 64) | (int(lo) & 0xFFFFFFFFFFFFFFFF)
+
 
 LIT_NULL, LIT_INT128, LIT_FLOAT64, LIT_DECIMAL128, LIT_BOOLEAN, LIT_STRING, LIT_DATE32 = range(7)
 OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE, OP_COMPARE = range(1, 12)
@@ -64,7 +81,7 @@ class CAggregateSpec(C.Structure):
 
 class CValue(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("is_null", C.c_int32), ("i64", C.c_int64), ("f64", C.c_double),
-                ("str", C.c_char_p)]
+                ("str", C.c_char_p), ("i64_hi", C.c_int64), ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 class CProjection(C.Structure):
@@ -78,7 +95,7 @@ class CScanOptions(C.Structure):
 
 class CColumnView(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("values", C.c_void_p), ("validity", C.POINTER(C.c_uint8)),
-                ("dictionary", C.POINTER(C.c_char_p))]
+                ("dictionary", C.POINTER(C.c_char_p)), ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 class CBatchView(C.Structure):
@@ -97,7 +114,8 @@ class CJoinOptions(C.Structure):
 class CColumnDesc(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("rows", C.c_uint64), ("has_stats", C.c_int32),
                 ("min_i", C.c_int64), ("max_i", C.c_int64), ("dict_size", C.c_uint32),
-                ("dictionary", C.POINTER(C.c_char_p)), ("nullable", C.c_int32)]
+                ("dictionary", C.POINTER(C.c_char_p)), ("nullable", C.c_int32),
+                ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 class CJoinSide(C.Structure):
@@ -457,9 +475,13 @@ class Value:
     dtype: int
     is_null: bool
     value: object
+    precision: int = 0  # Decimal128(precision, scale); value = raw i128
+    scale: int = 0
 
     @staticmethod
     def from_c(c: CValue) -> "Value":
+        if c.dtype == DT_DECIMAL128:
+            return Value(c.dtype, bool(c.is_null), None if c.is_null else i128_from_words(c.i64, c.i64_hi), c.precision, c.scale)
         if c.is_null:
             return Value(c.dtype, True, None)
         if c.dtype == DT_FLOAT64:

@@ -230,21 +230,26 @@ struct Stager {
 };
 
 static int column_stats_device(Table &t, DeviceColumn &c) {
-  if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32) return LLKV_OK;
+  if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
   if (t.dev_rows == 0) return LLKV_OK;
   int64_t init[2] = {INT64_MAX, INT64_MIN}, *d = nullptr;
   HIP_TRY(hipMalloc((void **)&d, sizeof init));
   HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, g_ctx.stream));
   // padding rows between ragged chunks are zero: they can only widen the range (safe side)
-  if (c.info.dtype == LLKV_DT_INT64) HIP_TRY(launch_minmax_i64((const int64_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
+  if (c.info.dtype == LLKV_DT_INT64 || c.info.dtype == LLKV_DT_DECIMAL128) HIP_TRY(launch_minmax_i64((const int64_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
   else HIP_TRY(launch_minmax_i32((const int32_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
   int64_t mm[2];
   HIP_TRY(hipMemcpyAsync(mm, d, sizeof mm, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   (void)hipFree(d);
-  c.info.has_stats = true;
-  c.info.min_i = mm[0];
-  c.info.max_i = mm[1];
+  c.has_local_stats = true;
+  c.local_min = mm[0];
+  c.local_max = mm[1];
+  if (t.world == 1) { // plans must not depend on the shard: sharded tables get table-wide statistics from the binding
+    c.info.has_stats = true;
+    c.info.min_i = mm[0];
+    c.info.max_i = mm[1];
+  }
   return LLKV_OK;
 }
 
@@ -474,6 +479,30 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   if (a.typed_by_first_value && rows == 0 && (a.fin == AggFinal::SumF64 || a.fin == AggFinal::MinF64 || a.fin == AggFinal::MaxF64)) {
     out->dtype = LLKV_DT_INT64; // an all-NULL temp column is an Int64 column: SUM / MIN / MAX come back as Int64 NULLs
     out->is_null = 1;
+    return LLKV_OK;
+  }
+  if (a.fin == AggFinal::SumDec || a.fin == AggFinal::TotalDec || a.fin == AggFinal::AvgDec || a.fin == AggFinal::MinDec || a.fin == AggFinal::MaxDec) {
+    // Decimal128 finalize (llkv-aggregate/src/lib.rs:1567-1582,1640-1655,1720-1760): the 64-bit values cannot
+    // carry a sum of < 2^63 rows out of i128, so "Decimal128 sum overflow" is unreachable on this path
+    out->dtype = LLKV_DT_DECIMAL128;
+    out->precision = a.precision;
+    out->scale = a.scale;
+    i128 v = 0;
+    if (a.fin == AggFinal::MinDec || a.fin == AggFinal::MaxDec) {
+      out->is_null = rows == 0;
+      v = rows ? (i128)(int64_t)l[0] : 0;
+    } else {
+      const i128 sum = a.fast_sum ? (i128)(int64_t)l[0] : (((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0]);
+      if (a.fin == AggFinal::AvgDec) {
+        if (rows > 0) { // sum / count, rounded half away from zero
+          const i128 n = rows, rem = sum % n;
+          v = sum / n;
+          if ((rem < 0 ? -rem : rem) * 2 >= n) v += sum > 0 ? 1 : -1;
+        } else out->is_null = 1;
+      } else v = sum; // SUM / TOTAL: `vec![sum]` — 0, not NULL, without rows
+    }
+    out->i64 = (int64_t)(uint64_t)v;
+    out->i64_hi = (int64_t)(v >> 64);
     return LLKV_OK;
   }
   switch (a.fin) {
@@ -842,6 +871,77 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
   if ((rc = st.init())) return (llkv_status)rc;
   if ((rc = st.push(c.d_values, codes.data(), t->dev_rows))) return (llkv_status)rc;
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint32_t field_id, int32_t *has_stats,
+                                              int64_t *min_value, int64_t *max_value) {
+  const Table *t = reinterpret_cast<const Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  if (has_stats) *has_stats = it->second.has_local_stats ? 1 : 0;
+  if (min_value) *min_value = it->second.local_min;
+  if (max_value) *max_value = it->second.local_max;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t field_id, int64_t min_value, int64_t max_value) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  DeviceColumn &c = it->second;
+  if (min_value > max_value) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "min exceeds max");
+  // a bound that does not cover this rank's rows would make "provably no overflow" and dense group ids wrong
+  // (the local reduction also sees the zeroed padding rows between ragged chunks, so a local bound of 0 on a
+  // padded image proves nothing)
+  const bool padded = t->dev_rows != t->local_rows;
+  const bool lo_ok = min_value <= c.local_min || (padded && c.local_min == 0), hi_ok = max_value >= c.local_max || (padded && c.local_max == 0);
+  if (c.has_local_stats && t->local_rows && !(lo_ok && hi_ok))
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "column statistics do not cover the staged values");
+  c.info.has_stats = true;
+  c.info.min_i = min_value;
+  c.info.max_i = max_value;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint32_t field_id, int32_t precision, int32_t scale,
+                                                    const void *const *chunk_values, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, n_chunks);
+  if (rc) return (llkv_status)rc;
+  if (precision < 1 || precision > 38 || scale > precision || scale < -128)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "invalid Decimal128 precision/scale");
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  // narrow the 16-byte raw values to the 8 B/row device image; a value that needs more than 64 bits keeps the
+  // column on the caller's CPU route
+  std::vector<int64_t> narrow(t->dev_rows + 16, 0);
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    if (rows && !chunk_values[i]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
+    const int64_t *src = static_cast<const int64_t *>(chunk_values[i]); // (lo, hi) pairs, little endian
+    int64_t *dst = narrow.data() + t->chunk_dev_off[i];
+    for (uint64_t r = 0; r < rows; ++r) {
+      const int64_t lo = src[2 * r], hi = src[2 * r + 1];
+      if (hi != (lo >> 63)) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id));
+      dst[r] = lo;
+    }
+  }
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = LLKV_DT_DECIMAL128;
+  c.info.precision = precision;
+  c.info.scale = scale;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  if ((rc = alloc_column(*t, 8, &c.d_values))) return (llkv_status)rc;
+  Stager st;
+  if ((rc = st.init())) return (llkv_status)rc;
+  if ((rc = st.push(c.d_values, narrow.data(), t->dev_rows * 8))) return (llkv_status)rc;
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
   t->cols.emplace(field_id, std::move(c));
   return LLKV_OK;
 }

@@ -34,6 +34,8 @@ int ensure_device();
 struct DeviceColumn {
   ColumnInfo info;
   void *d_values = nullptr;
+  bool has_local_stats = false; // min / max of this rank's rows (info.has_stats / min_i / max_i are table-wide)
+  int64_t local_min = 0, local_max = 0;
   uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
   bool owned = false;
 };

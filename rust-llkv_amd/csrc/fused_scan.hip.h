@@ -75,6 +75,7 @@ struct F32 { using T = float; static constexpr int W = 4; static constexpr bool 
 struct I64 { using T = int64_t; static constexpr int W = 8; static constexpr bool is_float = false; };
 struct U64 { using T = uint64_t; static constexpr int W = 8; static constexpr bool is_float = false; };
 struct F64 { using T = double; static constexpr int W = 8; static constexpr bool is_float = true; };
+struct I128 { using T = __int128; static constexpr int W = 16; static constexpr bool is_float = false; }; // outputs only
 struct U8 { using T = uint8_t; static constexpr int W = 1; static constexpr bool is_float = false; };
 
 template <class... Ts> struct Cols { static constexpr int N = sizeof...(Ts); };
@@ -169,6 +170,10 @@ template <int K> struct LitF {
 template <class E> struct ToF64 { // arrow cast int → f64 / f32 → f64
   using Type = F64;
   static __device__ __forceinline__ double eval(Ctx &c, int j) { return (double)E::eval(c, j); }
+};
+template <class E> struct Widen128 { // Decimal128 column staged as i64 → arrow's 16-byte raw value on the way out
+  using Type = I128;
+  static __device__ __forceinline__ __int128 eval(Ctx &c, int j) { return (__int128)(int64_t)E::eval(c, j); }
 };
 template <class E> struct ToI64 { // widening of the narrow integer types
   using Type = I64;

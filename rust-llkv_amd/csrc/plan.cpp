@@ -28,13 +28,14 @@ const char *dtype_name(int32_t dt) {
   case LLKV_DT_FLOAT32: return "Float32";
   case LLKV_DT_UTF8: return "Utf8";
   case LLKV_DT_BOOLEAN: return "Boolean";
+  case LLKV_DT_DECIMAL128: return "Decimal128";
   default: return "Null";
   }
 }
 
 const char *dtype_tag(int32_t dt) {
   switch (dt) {
-  case LLKV_DT_INT64: return "I64";
+  case LLKV_DT_INT64: case LLKV_DT_DECIMAL128: return "I64"; // decimals are staged narrowed to 64 bits
   case LLKV_DT_FLOAT64: return "F64";
   case LLKV_DT_INT32: case LLKV_DT_DATE32: return "I32";
   case LLKV_DT_UINT64: return "U64";
@@ -47,12 +48,14 @@ const char *dtype_tag(int32_t dt) {
 
 uint32_t dtype_width(int32_t dt) {
   switch (dt) {
-  case LLKV_DT_INT64: case LLKV_DT_FLOAT64: case LLKV_DT_UINT64: return 8;
+  case LLKV_DT_INT64: case LLKV_DT_FLOAT64: case LLKV_DT_UINT64: case LLKV_DT_DECIMAL128: return 8;
   case LLKV_DT_INT32: case LLKV_DT_DATE32: case LLKV_DT_UINT32: case LLKV_DT_FLOAT32: return 4;
   case LLKV_DT_UTF8: case LLKV_DT_BOOLEAN: return 1;
   default: return 0;
   }
 }
+
+uint32_t dtype_out_width(int32_t dt) { return dt == LLKV_DT_DECIMAL128 ? 16 : dtype_width(dt); }
 
 static i128 lit_i128(const llkv_literal &l) { return (i128)(((u128)(uint64_t)l.hi << 64) | (u128)l.lo); }
 
@@ -300,6 +303,8 @@ struct Lowering {
       }
       return fail(LLKV_UNSUPPORTED, "ordering predicates on dictionary-coded Utf8 columns");
     }
+    if (ci->dtype == LLKV_DT_DECIMAL128) // llkv-table/src/table.rs:1160-1167
+      return fail(LLKV_INTERNAL, "Filtering on type Decimal128(" + std::to_string(ci->precision) + ", " + std::to_string(ci->scale) + ") is not supported");
     if (dtype_width(ci->dtype) == 0 || ci->dtype == LLKV_DT_BOOLEAN)
       return fail(LLKV_INTERNAL, std::string("Filtering on type ") + dtype_name(ci->dtype) + " is not supported");
     // cast every literal first: cast errors surface even when the column needs no slot yet
@@ -633,7 +638,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       int slot;
       const ColumnInfo *probe = resolve(key_fields[k]);
       if (!probe) return L.fail(LLKV_INVALID_ARGUMENT, "column '" + std::to_string(key_fields[k]) + "' not found in GROUP BY input");
-      if (probe->dtype == LLKV_DT_FLOAT64 || probe->dtype == LLKV_DT_FLOAT32)
+      if (probe->dtype == LLKV_DT_FLOAT64 || probe->dtype == LLKV_DT_FLOAT32 || probe->dtype == LLKV_DT_DECIMAL128)
         return L.fail(LLKV_INVALID_ARGUMENT, std::string("GROUP BY does not support column type ") + dtype_name(probe->dtype));
       // GroupKeyValue (llkv-executor/src/lib.rs:99-106, 9362-9456): Utf8 → String, every integer width and
       // Date32 → Int.  Dense ids come from the dictionary code, or from value − column minimum for
@@ -725,7 +730,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       const int32_t dt = simple_ci->dtype;
       if (dt == LLKV_DT_UTF8 || dt == LLKV_DT_BOOLEAN || dt == LLKV_DT_DATE32)
         return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over " + dtype_name(dt) + " (SQLite-style numeric coercion) is not on the GPU path");
-      if (dt != LLKV_DT_INT64 && dt != LLKV_DT_FLOAT64)
+      if (dt != LLKV_DT_INT64 && dt != LLKV_DT_FLOAT64 && dt != LLKV_DT_DECIMAL128)
         return L.fail(LLKV_INVALID_ARGUMENT, std::string(fn) + " aggregate not supported for column type " + dtype_name(dt));
       const ColumnInfo *ci;
       int slot;
@@ -752,6 +757,24 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       o.lane = add_group("IfValid<" + valid + "," + inner + ">", lane_ops);
       o.count_lane = o.lane + n_inner;
     };
+    if (simple && simple_ci->dtype == LLKV_DT_DECIMAL128) {
+      // Decimal128 accumulators (llkv-aggregate/src/lib.rs:925-967,1071-1088,1236-1259,1332-1352,1400-1420) over the
+      // 64-bit image: the same exact lanes as Int64, finalized in i128 with the column's (precision, scale)
+      o.precision = simple_ci->precision; o.scale = simple_ci->scale;
+      o.fast_sum = fast_i64;
+      switch (s.kind) {
+      case LLKV_AGG_SUM: case LLKV_AGG_TOTAL: case LLKV_AGG_AVG:
+        o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumDec : s.kind == LLKV_AGG_TOTAL ? AggFinal::TotalDec : AggFinal::AvgDec;
+        if (fast_i64) add_agg("SumI64Fast<" + node + ">", {ADD_I64});
+        else add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64});
+        break;
+      case LLKV_AGG_MIN: o.fin = AggFinal::MinDec; add_agg("MinI64<" + node + ">", {MIN_I64}); break;
+      case LLKV_AGG_MAX: o.fin = AggFinal::MaxDec; add_agg("MaxI64<" + node + ">", {MAX_I64}); break;
+      default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
+      }
+      p.aggs.push_back(o);
+      continue;
+    }
     switch (s.kind) {
     case LLKV_AGG_SUM:
       if (is_f64) { o.fin = AggFinal::SumF64; add_agg("SumF64<" + node + ">", {ADD_F64}); }
@@ -928,6 +951,7 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
       if ((rc = L.slot_of(pr.field_id, &ci, &slot))) return rc;
       if (dtype_width(ci->dtype) == 0) return L.fail(LLKV_UNSUPPORTED, std::string("projection of ") + dtype_name(ci->dtype));
       node = L.col_node(slot, ci->dtype);
+      if (ci->dtype == LLKV_DT_DECIMAL128) node = "Widen128<" + node + ">"; // back to arrow's 16-byte raw values
       out->out_dtypes.push_back(ci->dtype);
       out->out_fields.push_back((int32_t)pr.field_id);
       std::string v;
@@ -942,6 +966,7 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
         int slot;
         if ((rc = L.slot_of(pr.expr[0].field_id, &ci, &slot))) return rc;
         node = L.col_node(slot, ci->dtype);
+        if (ci->dtype == LLKV_DT_DECIMAL128) node = "Widen128<" + node + ">";
         out->out_dtypes.push_back(ci->dtype);
         out->out_fields.push_back((int32_t)pr.expr[0].field_id);
       } else {

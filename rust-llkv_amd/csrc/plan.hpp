@@ -27,6 +27,7 @@ struct ColumnInfo {
   bool has_stats = false;               // integer min/max known (staging statistics)
   int64_t min_i = 0, max_i = 0;
   std::vector<std::string> dictionary;  // LLKV_DT_UTF8: code → string
+  int32_t precision = 0, scale = 0;     // LLKV_DT_DECIMAL128 (device image: the raw values narrowed to i64)
   bool nullable = false;                // some cell is NULL (row id absent from the column): a 1 B/row validity mask is staged
 };
 
@@ -44,6 +45,7 @@ enum class AggFinal : int {
   MinI64, MaxI64,
   MinF64, MaxF64,
   CountNullsZero, // COUNT_NULLS on a NULL-free column = 0
+  SumDec, TotalDec, AvgDec, MinDec, MaxDec, // Decimal128 column narrowed to i64: SumI64 / SumI64Fast / MinI64 / MaxI64 lanes
   CountValid,     // COUNT(x), x nullable: the valid-row lane
   CountNulls      // COUNT_NULLS(x), x nullable: rows − valid rows
 };
@@ -53,6 +55,8 @@ struct AggOut {
   int lane = -1; // first lane of its lane group, relative to the group's lane block
   bool typed_by_first_value = false; // GROUP BY computed argument: the group's temp column takes the type of its first
                                      // non-NULL value, Int64 when there is none (llkv-executor/src/lib.rs:298-406)
+  bool fast_sum = false;        // decimal sums: one wrapping lane (statistics exclude i64 overflow) instead of the 96-bit split
+  int32_t precision = 0, scale = 0; // Decimal128 results
   int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
 };
 
@@ -121,6 +125,7 @@ int cast_literal_for_column(const llkv_literal &lit, int32_t dtype, NativeLit *o
 
 const char *dtype_name(int32_t dtype);
 const char *dtype_tag(int32_t dtype); // "I64", "F64", ...
-uint32_t dtype_width(int32_t dtype);
+uint32_t dtype_width(int32_t dtype);     // bytes per row of the device image
+uint32_t dtype_out_width(int32_t dtype); // bytes per row handed to the caller (Decimal128: 16)
 
 } // namespace llkv

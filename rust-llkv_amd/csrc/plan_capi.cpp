@@ -27,6 +27,8 @@ llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols, const
     infos[i].min_i = cols[i].min_i;
     infos[i].max_i = cols[i].max_i;
     infos[i].nullable = cols[i].nullable != 0;
+    infos[i].precision = cols[i].precision;
+    infos[i].scale = cols[i].scale;
     for (uint32_t d = 0; d < cols[i].dict_size; ++d)
       infos[i].dictionary.push_back(cols[i].dictionary && cols[i].dictionary[d] ? cols[i].dictionary[d] : "");
   }

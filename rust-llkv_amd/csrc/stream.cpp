@@ -153,7 +153,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   if (hipMemsetAsync(d_err.p, 0, 4, stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "memset failed");
   for (auto &w : win) {
     for (uint32_t o = 0; o < n_out; ++o) {
-      const size_t bytes = (size_t)kRowStreamChunk * dtype_width(proj.out_dtypes[o]);
+      const size_t bytes = (size_t)kRowStreamChunk * dtype_out_width(proj.out_dtypes[o]);
       if ((rc = w.d[o].alloc(bytes)) || (rc = w.h[o].alloc(bytes))) return (llkv_status)rc;
       if (proj.out_nullable[o] && ((rc = w.d_valid[o].alloc(kRowStreamChunk / 8)) || (rc = w.h_valid[o].alloc(kRowStreamChunk / 8)))) return (llkv_status)rc;
     }
@@ -177,7 +177,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     if (r) return r;
     for (uint32_t o = 0; o < n_out; ++o)
     {
-      HIP_TRY(hipMemcpyAsync(w.h[o].p, w.d[o].p, (size_t)w.n * dtype_width(proj.out_dtypes[o]), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(w.h[o].p, w.d[o].p, (size_t)w.n * dtype_out_width(proj.out_dtypes[o]), hipMemcpyDeviceToHost, stream));
       if (proj.out_nullable[o]) HIP_TRY(hipMemcpyAsync(w.h_valid[o].p, w.d_valid[o].p, (size_t)((w.n + 63) / 64) * 8, hipMemcpyDeviceToHost, stream));
     }
     if (with_ids) HIP_TRY(hipMemcpyAsync(w.h_ids.p, sel.d_ids + w0, (size_t)w.n * 8, hipMemcpyDeviceToHost, stream));
@@ -204,6 +204,12 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
       cols[o].values = w.h[o].p;
       cols[o].validity = proj.out_nullable[o] ? (const uint8_t *)w.h_valid[o].p : nullptr;
       cols[o].dictionary = dicts[o].empty() ? nullptr : dicts[o].data();
+      cols[o].precision = cols[o].scale = 0;
+      if (proj.out_dtypes[o] == LLKV_DT_DECIMAL128 && proj.out_fields[o] >= 0) {
+        const ColumnInfo &ci = t->cols.at((uint32_t)proj.out_fields[o]).info;
+        cols[o].precision = ci.precision;
+        cols[o].scale = ci.scale;
+      }
     }
     llkv_batch_view b;
     b.num_rows = w.n;

@@ -58,3 +58,19 @@ def table_wide_dictionary(dist, local_values, world: int) -> List[str]:
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     return sorted(set().union(*gathered))
+
+
+def share_column_stats(dist, table, field_ids, world: int) -> None:
+    """Table-wide integer statistics for a sharded table: every rank must lower the same plan, so the
+    statistics plans rely on (overflow-free SUM, dense integer GROUP BY) are the all-gathered min / max of
+    the shards' values — what the reference's column descriptor holds for all chunks
+    (llkv-column-map/src/store/descriptor.rs:19-84)."""
+    if world <= 1:
+        return
+    local = {int(f): table.local_column_stats(int(f)) for f in field_ids}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    for f in local:
+        pairs = [g[f] for g in gathered if g.get(f) is not None]
+        if len(pairs) == world:  # a rank without rows reports its (empty) range too; all must have statistics
+            table.set_column_stats(f, min(p[0] for p in pairs), max(p[1] for p in pairs))

@@ -136,6 +136,26 @@ class HipTable:
         if valid is not None:
             self.set_column_validity(field_id, valid)
 
+    def append_decimal128_column(self, field_id: int, precision: int, scale: int, values, valid=None):
+        """Stage a Decimal128(precision, scale) column from Python ints (raw values) or an (n, 2) uint64 buffer."""
+        buf = values if isinstance(values, np.ndarray) and values.ndim == 2 else abi.i128_buffer(values)
+        chunks = [np.ascontiguousarray(c) for c in self._split(buf)]
+        ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
+        check(lib().llkv_hip_table_append_decimal128_column(self._h, C.c_uint32(field_id), C.c_int32(precision), C.c_int32(scale),
+                                                            ptrs, C.c_uint32(len(chunks))))
+        if valid is not None:
+            self.set_column_validity(field_id, valid)
+
+    def local_column_stats(self, field_id: int):
+        """(min, max) of this rank's rows of an integer column, or None."""
+        has, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+        check(lib().llkv_hip_table_local_column_stats(self._h, C.c_uint32(field_id), C.byref(has), C.byref(lo), C.byref(hi)))
+        return (lo.value, hi.value) if has.value else None
+
+    def set_column_stats(self, field_id: int, lo: int, hi: int):
+        """Installs the table-wide (min, max) of an integer column (sharded tables; see dist.share_column_stats)."""
+        check(lib().llkv_hip_table_set_column_stats(self._h, C.c_uint32(field_id), C.c_int64(lo), C.c_int64(hi)))
+
     def set_column_validity(self, field_id: int, valid):
         """NULL cells of a staged column as one Arrow validity bitmap per local chunk (LSB first)."""
         valid = np.asarray(valid, dtype=bool)
@@ -406,7 +426,10 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
         cols = []
         for ci in range(b.num_columns):
             c = b.columns[ci]
-            if c.dtype == abi.DT_UTF8:
+            if c.dtype == abi.DT_DECIMAL128:
+                raw = np.frombuffer(C.string_at(c.values, n * 16), dtype=np.uint64).reshape(n, 2)
+                vals = [abi.i128_from_words(int(lo), int(np.int64(hi))) for lo, hi in raw]
+            elif c.dtype == abi.DT_UTF8:
                 codes = np.frombuffer(C.string_at(c.values, n), dtype=np.uint8)
                 vals = [c.dictionary[int(k)].decode() for k in codes]
             else:

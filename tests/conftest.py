@@ -52,7 +52,7 @@ def golden(name: str):
         return json.load(f)
 
 
-DTYPES = {"Int64": 1, "Float64": 2, "Int32": 3, "Date32": 4, "UInt64": 5, "UInt32": 6, "Float32": 7, "Utf8": 8}
+DTYPES = {"Int64": 1, "Float64": 2, "Int32": 3, "Date32": 4, "UInt64": 5, "UInt32": 6, "Float32": 7, "Utf8": 8, "Decimal128": 10}
 
 
 def fval(v):
@@ -128,7 +128,9 @@ def oracle_table(orc, abi, columns, rows=None):
         if any(v is None for v in vals):
             valid = [v is not None for v in vals]
             vals = [0 if v is None else v for v in vals]
-        if dt == abi.DT_UTF8:
+        if dt == abi.DT_DECIMAL128:
+            t.add(c["field_id"], dt, vals, valid, precision=c["precision"], scale=c["scale"])
+        elif dt == abi.DT_UTF8:
             t.add(c["field_id"], dt, [None if (valid and not valid[i]) else vals[i] for i in range(len(vals))])
         else:
             t.add(c["field_id"], dt, np.array(vals, dtype=abi.NUMPY_OF_DTYPE[dt]), valid)

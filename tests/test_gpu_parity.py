@@ -79,7 +79,10 @@ def test_reference_aggregate_known_answers(rt, abi, case):
     ht = rt.HipTable(1, [n])
     for c in case["columns"]:
         dt = DTYPES[c["dtype"]]
-        ht.append_column(c["field_id"], dt, np.array([fval(v) for v in c["values"]], dtype=abi.NUMPY_OF_DTYPE[dt]))
+        if dt == abi.DT_DECIMAL128:
+            ht.append_decimal128_column(c["field_id"], c["precision"], c["scale"], c["values"])
+        else:
+            ht.append_column(c["field_id"], dt, np.array([fval(v) for v in c["values"]], dtype=abi.NUMPY_OF_DTYPE[dt]))
     pred = [build_filter(abi, case["filter"])] if "filter" in case else None
     aggs = build_aggs(abi, case["aggs"])
     if "expect_error" in case:
@@ -216,6 +219,13 @@ def test_results_are_bit_reproducible_and_gpu_count_invariant(rt, abi, tpch):
                 ht.append_utf8_column(fid, part, sorted({chr(int(v)) for v in np.unique(d[c])}))
             else:
                 ht.append_column(fid, dt, part)
+                # every rank must lower the same plan: table-wide statistics, as the binding installs them from
+                # the column descriptor (dist.share_column_stats); a bound that misses staged values is refused
+                if world > 1 and ht.local_column_stats(fid) is not None:
+                    if ht.local_rows:
+                        with pytest.raises(abi.LlkvError):
+                            ht.set_column_stats(fid, int(part.min()) - 2, int(part.max()) - 1)
+                    ht.set_column_stats(fid, int(d[c].min()), int(d[c].max()))
         return ht
 
     one = stage(0, 1)
@@ -482,6 +492,55 @@ def test_null_cells_match_oracle(rt, orc, abi, chunks):
         with pytest.raises(abi.LlkvError) as e:
             m.filter_row_ids(t, E.compare(col(1) * 4, abi.CMP_GT, col(2)))
         assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+
+
+@pytest.mark.parametrize("chunks", [[5], [4096, 4097, 3], [65536, 40000]])
+def test_decimal128_accumulators_match_oracle(rt, orc, abi, chunks):
+    """Decimal128 columns (staged narrowed to 64 bits): exact SUM / TOTAL / AVG (half away from zero) / MIN /
+    MAX / COUNT with and without NULL cells, filters on other columns, GROUP BY, projection back to 16-byte
+    values; the reference's refusal to filter a Decimal128 column; wide values stay on the CPU route."""
+    rng = np.random.default_rng(len(chunks))
+    n = sum(chunks)
+    money = [int(v) for v in rng.integers(-10**13, 10**13, size=n)]          # DECIMAL(15,2)
+    big = [int(v) for v in rng.integers(-2**62, 2**62, size=n)]               # sums leave i64, stay far inside i128
+    flag = rng.integers(0, 4, size=n).astype(np.int64)
+    keys = np.array([ord("a"), ord("b"), ord("c")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    valid = rng.random(n) > 0.2
+    ht = rt.HipTable(1, chunks)
+    ht.append_decimal128_column(1, 15, 2, money)
+    ht.append_decimal128_column(2, 38, 4, big, valid=valid)
+    ht.append_column(3, abi.DT_INT64, flag)
+    ht.append_utf8_column(4, keys)
+    ot = orc.OracleTable(n)
+    ot.add(1, abi.DT_DECIMAL128, money, precision=15, scale=2)
+    ot.add(2, abi.DT_DECIMAL128, big, list(valid), precision=38, scale=4)
+    ot.add(3, abi.DT_INT64, flag).add(4, abi.DT_UTF8, keys)
+    A, F, O, E = abi.AggregateSpec, abi.Filter, abi.Operator, abi.Expr
+    aggs = [A.sum(1), A.avg(1), A.min(1), A.max(1), A.total(1), A.count(1), A.sum(2), A.avg(2), A.min(2), A.max(2), A.total(2), A.count(2), A.count_nulls(2), A.count_star()]
+    for pred in (None, [F(3, O.Equals(1))], [F(3, O.GreaterThan(7))], E.not_(F(3, O.In([0, 2])))):
+        got, want = rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs)
+        assert got == want, pred  # dataclass equality: dtype, NULL-ness, raw i128, precision and scale
+        g, w = rt.groupby(ht, pred, [4], aggs, True), orc.groupby(ot, pred, [4], aggs, True)
+        assert [[k.value for k in r.keys] for r in g] == [[k.value for k in r.keys] for r in w]
+        for a, b in zip(g, w):
+            for i, (x, y) in enumerate(zip(a.values, b.values)):
+                assert x == y, (pred, a.keys[0].value, i, x, y)
+    if n < 20000:
+        for inc in (False, True):
+            got = rt.scan_stream(ht, [2, 1, 3], [F(3, O.LessThan(2))], include_nulls=inc, include_row_ids=True)
+            want = orc.scan_stream(ot, [2, 1, 3], [F(3, O.LessThan(2))], include_nulls=inc, include_row_ids=True)
+            assert got == want
+    for m, t in ((rt, ht), (orc, ot)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.aggregate(t, [F(1, O.LessThan(5))], [A.count_star()])
+        assert e.value.kind == "Internal" and e.value.message.endswith("Filtering on type Decimal128(15, 2) is not supported")
+        with pytest.raises(abi.LlkvError) as e:
+            m.groupby(t, None, [1], [A.count_star()], True)
+        assert e.value.kind == "InvalidArgumentError"
+    wide = rt.HipTable(2, [2])
+    with pytest.raises(abi.LlkvError) as e:
+        wide.append_decimal128_column(1, 38, 0, [1, 10**30])
+    assert e.value.kind == "Unsupported"
 
 
 JOINS = golden("joins.json")
