@@ -547,6 +547,8 @@ typedef struct llkv_join_group_row {
   double sum;
   uint64_t count;     /* fact rows in the group                                  */
   int64_t payload[4]; /* dim payload columns (integers / Date32)                 */
+  uint64_t group_index; /* position of the dim row among the qualifying dim rows (row order): the final
+                         * tie-break of the ordering, identical on every rank                            */
 } llkv_join_group_row;
 
 llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
@@ -555,6 +557,40 @@ llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_jo
                                        const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
                                        uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n,
                                        uint64_t *out_total_groups);
+
+/* The same pipeline for a fact table sharded over ranks (one process per GPU):
+ * the dimension tables are staged whole (world = 1) on every rank, the fact table by chunk.
+ *   1. prepare            local build, probe, per-group sums and row counts (group = qualifying dim row)
+ *   2. counts_buffer      int64[len] in HBM: the binding all-reduces it (SUM) in place — the one sizeable
+ *                         collective (8 B per qualifying dim row)
+ *   3. straddlers         this rank's raw (group, value) pairs, in row order, of the groups whose rows are
+ *                         spread over several ranks; the binding all-gathers them (few for a fact table
+ *                         clustered by the key) and concatenates in rank order
+ *   4. fold_straddlers    host only: exact left-to-right sums of those groups in global row order
+ *   5. candidates         the top `limit` groups this rank reports (held alone, or straddlers held first)
+ *   6. merge              host only: ORDER BY / LIMIT over the all-gathered candidates
+ * Results are bit-identical to the single-GPU call for every rank count.                              */
+typedef struct llkv_hip_join_agg llkv_hip_join_agg;
+llkv_status llkv_hip_join_agg_prepare(const llkv_join_side *fact, const llkv_join_side *dim,
+                                      uint32_t dim_fk_field, const llkv_join_side *dim2 /* may be NULL */,
+                                      const uint32_t *payload_fields, uint32_t n_payload,
+                                      const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
+                                      llkv_hip_join_agg **out);
+void llkv_hip_join_agg_free(llkv_hip_join_agg *h);
+llkv_status llkv_hip_join_agg_counts_buffer(llkv_hip_join_agg *h, void **device_ptr, uint64_t *len_i64);
+llkv_status llkv_hip_join_agg_straddlers(llkv_hip_join_agg *h, const uint32_t **groups,
+                                         const double **values, uint64_t *n);
+llkv_status llkv_hip_join_agg_fold_straddlers(const uint32_t *groups, const double *values,
+                                              const uint64_t *rank_offsets /* [world + 1] */, uint32_t world,
+                                              uint32_t *out_groups, double *out_sums, uint64_t *out_counts,
+                                              uint32_t *out_first_rank, uint64_t *n_out /* capacity in, count out */);
+llkv_status llkv_hip_join_agg_candidates(llkv_hip_join_agg *h, const uint32_t *folded_groups,
+                                         const double *folded_sums, const uint64_t *folded_counts,
+                                         const uint32_t *folded_first_rank, uint64_t n_folded, uint32_t rank,
+                                         uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n,
+                                         uint64_t *out_groups /* groups this rank reports */);
+llkv_status llkv_hip_join_agg_merge(const llkv_join_group_row *rows, uint32_t n, uint32_t n_payload,
+                                    uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n);
 
 /* ------------------------------------------------------------------------- */
 /* Multi-GPU combine, host pieces (no device needed).  The chunk list is cut    */

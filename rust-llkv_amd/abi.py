@@ -123,7 +123,8 @@ class CJoinSide(C.Structure):
 
 
 class CJoinGroupRow(C.Structure):
-    _fields_ = [("key", C.c_int64), ("sum", C.c_double), ("count", C.c_uint64), ("payload", C.c_int64 * 4)]
+    _fields_ = [("key", C.c_int64), ("sum", C.c_double), ("count", C.c_uint64), ("payload", C.c_int64 * 4),
+                ("group_index", C.c_uint64)]
 
 
 class CArr0Desc(C.Structure):

@@ -307,6 +307,108 @@ hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32
   return hipGetLastError();
 }
 
+// ---- deterministic group ids + the pieces of the sharded join → GROUP BY pipeline ------------------
+__global__ __launch_bounds__(256) void hj_slot_groups_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n,
+                                                              const unsigned long long *slot_owner, uint64_t cap_mask, uint32_t *slot_group) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long drow = dev_rows[i];
+  const long long k = load_key(key, drow);
+  uint64_t s = hash_key(k) & cap_mask;
+  for (;;) { // the key is in the table (unique keys: its owner is this very row)
+    const unsigned long long owner = slot_owner[s];
+    if (owner == drow || owner == kEmpty) break;
+    s = (s + 1) & cap_mask;
+  }
+  slot_group[s] = (uint32_t)i;
+}
+hipError_t hj_launch_slot_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, const unsigned long long *slot_owner,
+                                 uint64_t cap_mask, uint32_t *slot_group, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_slot_groups_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, key, dev_rows, n, slot_owner, cap_mask, slot_group);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_map_u32_kernel(uint32_t *inout, uint64_t n, const uint32_t *table) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inout[i] = table[inout[i]];
+}
+hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_map_u32_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, inout, n, table);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_straddler_flags_kernel(const uint32_t *group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
+                                                                  uint64_t *flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = local_cnt[group[i]] != (uint64_t)global_cnt[group[i]] ? 1u : 0u;
+}
+hipError_t hj_launch_straddler_flags(const uint32_t *sorted_group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
+                                     uint64_t *flags, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_straddler_flags_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, sorted_group, n, local_cnt, global_cnt, flags);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_compact_pairs_kernel(const uint32_t *group, const uint64_t *val, const uint64_t *flags, const uint64_t *offsets,
+                                                                uint64_t n, uint32_t *out_group, uint64_t *out_val) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) { out_group[offsets[i]] = group[i]; out_val[offsets[i]] = val[i]; }
+}
+hipError_t hj_launch_compact_pairs(const uint32_t *group, const uint64_t *val, const uint64_t *flags, const uint64_t *offsets, uint64_t n,
+                                   uint32_t *out_group, uint64_t *out_val, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_compact_pairs_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, group, val, flags, offsets, n, out_group, out_val);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_report_counts_kernel(const uint64_t *local_cnt, const int64_t *global_cnt, uint64_t n, uint64_t *report) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) report[i] = local_cnt[i] == (uint64_t)global_cnt[i] ? local_cnt[i] : 0;
+}
+hipError_t hj_launch_report_counts(const uint64_t *local_cnt, const int64_t *global_cnt, uint64_t n, uint64_t *report, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_report_counts_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, local_cnt, global_cnt, n, report);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_patch_groups_kernel(const uint32_t *groups, const double *sums, const uint64_t *counts, uint64_t n,
+                                                               double *sum_by_group, uint64_t *report) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { sum_by_group[groups[i]] = sums[i]; report[groups[i]] = counts[i]; }
+}
+hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, const uint64_t *counts, uint64_t n, double *sum_by_group,
+                                  uint64_t *report, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_patch_groups_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, groups, sums, counts, n, sum_by_group, report);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(128) void hj_gather_group_candidates_kernel(const uint64_t *sorted_keys, const uint32_t *sorted_groups, uint32_t n,
+                                                                         const uint64_t *dim_rows, const double *sum_by_group,
+                                                                         const uint64_t *count_by_group, CandidateCols cols, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t *o = out + (uint64_t)i * 8;
+  o[0] = sorted_keys[i];
+  if (sorted_keys[i] == ~0ull) { for (int k = 1; k < 8; ++k) o[k] = 0; return; }
+  const uint32_t g = sorted_groups[i];
+  const uint64_t owner = dim_rows[g];
+  o[1] = (uint64_t)load_key(cols.key, owner);
+  o[2] = (uint64_t)__double_as_longlong(sum_by_group[g]);
+  o[3] = count_by_group[g];
+  for (uint32_t k = 0; k < 4; ++k) o[4 + k] = k < cols.n_payload ? (uint64_t)load_key(cols.payload[k], owner) : 0;
+}
+hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
+                                             const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols, uint64_t *out,
+                                             hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_gather_group_candidates_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sorted_keys, sorted_groups, n, dim_rows,
+                     sum_by_group, count_by_group, cols, out);
+  return hipGetLastError();
+}
+
 // ---- exact, order-dependent SUM(Int64) overflow check -------------------------------------------
 struct I128 {
   uint64_t lo;

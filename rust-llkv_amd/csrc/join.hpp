@@ -83,6 +83,25 @@ struct CandidateCols {
 hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_slots, uint32_t n, const unsigned long long *slot_owner,
                                        const double *sum_by_slot, const uint64_t *count_by_slot, CandidateCols cols, uint64_t *out /*[n][8]*/, hipStream_t s);
 
+// ---- group ids that do not depend on hash-table timing (sharded fact tables exchange per-group state) ------
+// slot_group[slot] = i for the i-th listed dim row (the list is in row order, identical on every rank).
+hipError_t hj_launch_slot_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, const unsigned long long *slot_owner,
+                                 uint64_t cap_mask, uint32_t *slot_group, hipStream_t s);
+hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table, hipStream_t s);
+// flags[i] = 1 when the group of sorted pair i has rows on another rank too (local count ≠ global count).
+hipError_t hj_launch_straddler_flags(const uint32_t *sorted_group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
+                                     uint64_t *flags, hipStream_t s);
+hipError_t hj_launch_compact_pairs(const uint32_t *group, const uint64_t *val, const uint64_t *flags, const uint64_t *offsets, uint64_t n,
+                                   uint32_t *out_group, uint64_t *out_val, hipStream_t s);
+// report[g] = rows of group g when this rank alone holds it, else 0 (straddlers are patched in afterwards).
+hipError_t hj_launch_report_counts(const uint64_t *local_cnt, const int64_t *global_cnt, uint64_t n, uint64_t *report, hipStream_t s);
+hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, const uint64_t *counts, uint64_t n, double *sum_by_group,
+                                  uint64_t *report, hipStream_t s);
+// gather_candidates for group ids: owner row = dim_rows[group].
+hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
+                                             const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,
+                                             uint64_t *out /*[n][8]*/, hipStream_t s);
+
 // Does any prefix of vals[0..n) (summed left to right, exactly) leave the i64 range?  *d_flag |= 1 if so.
 // `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.
 hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s);

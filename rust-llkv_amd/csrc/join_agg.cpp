@@ -1,13 +1,25 @@
-// join_agg.cpp — llkv_hip_join_groupby_topk: the TPC-H Q3 shape on the GPU (see include/llkv_hip.h).
+// join_agg.cpp — the TPC-H Q3 shape on the GPU (include/llkv_hip.h: llkv_hip_join_groupby_topk and the phased
+// llkv_hip_join_agg_* form for a fact table sharded over ranks).
 //   dim2 (customer) filter → key set            select + claim
 //   dim  (orders)   filter ⋉ dim2 → hash table  select + semi flags + scan/compact + claim
-//   fact (lineitem) filter ⋈ dim → (slot, value) pairs in scan order   probe-emit (count/scan/write)
-//   stable sort by slot → per-group left-to-right f64 sums (the reference's order) → top-k
+//   fact (lineitem) filter ⋈ dim → (group, value) pairs in scan order   probe-emit (count/scan/write)
+//   stable sort by group → per-group left-to-right f64 sums (the reference's order) → top-k
+// Group id = position of the dim row in the qualifying-dim-row list (row order): the same on every rank that
+// holds the replicated dimension tables, unlike hash-table slots, whose assignment depends on CAS timing.
+//
+// Sharded fact table: dims replicated, fact rows sharded by chunk.  A group whose rows all
+// live on one rank is summed there exactly.  A group that straddles ranks must be summed in global row order
+// to stay bit-exact with the reference's sequential `value += v`: ranks all-reduce the per-group row counts
+// (int64, the one sizeable collective), find the straddlers (local count ≠ global count), all-gather only
+// their raw (group, value) pairs — a handful for a fact table clustered by the key, as lineitem is — and fold
+// them in rank order, i.e. global row order.  Each rank then reports the candidates of the groups it alone
+// holds plus the straddlers it holds first; the union is merged on the host.
 #include "engine.hpp"
 #include "join.hpp"
 
 #include <algorithm>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 namespace llkv {
@@ -54,20 +66,62 @@ struct HashSet {
     return LLKV_OK;
   }
 };
+
+int scan_exclusive(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t s) {
+  DB tmp;
+  size_t tb = 0;
+  HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, in, out, n, s));
+  int rc = tmp.alloc(tb ? tb : 8);
+  if (rc) return rc;
+  HIP_TRY(hj_exclusive_scan_u64(tmp.p, &tb, in, out, n, s));
+  HIP_TRY(hipStreamSynchronize(s)); // tmp is released on return
+  return LLKV_OK;
+}
+
+// ORDER BY sum DESC, payload[0] ASC (arrow lexsort, llkv-executor/src/lib.rs:13847-13864); ties beyond that
+// are left in an unspecified order by the reference — here: dim row order, so every rank count agrees.
+bool row_before(const llkv_join_group_row &a, const llkv_join_group_row &b, uint32_t n_payload) {
+  if (a.sum != b.sum) return a.sum > b.sum;
+  if (n_payload && a.payload[0] != b.payload[0]) return a.payload[0] < b.payload[0];
+  return a.group_index < b.group_index;
+}
 } // namespace
 
-int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
-                          const uint32_t *payload_fields, uint32_t n_payload, const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
-                          uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_total_groups) {
+struct JoinAgg {
+  const Table *tf = nullptr, *td = nullptr;
+  uint32_t n_payload = 0;
+  CandidateCols cc{};
+  Selection seld;                    // qualifying dim rows before the dim2 semi join
+  DB kept;                           // … and after it
+  const uint64_t *d_dim_rows = nullptr;
+  uint64_t n_dim = 0;                // groups = qualifying dim rows, in row order
+  DB sums, cnts, gcnts, report;      // per group: local f64 sum, local rows, exchanged rows (int64), rows this rank reports
+  DB s_group, s_val;                 // local (group, value) pairs sorted by group, row order within a group
+  uint64_t n_pairs = 0;
+  std::vector<uint32_t> st_groups;   // straddler pairs of this rank (host)
+  std::vector<double> st_vals;
+  bool have_straddlers = false;
+
+  int prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
+              const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len);
+  int straddlers();
+  int candidates(const uint32_t *f_groups, const double *f_sums, const uint64_t *f_counts, const uint32_t *f_first_rank, uint64_t n_folded,
+                 uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups);
+};
+
+int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
+                     const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len) {
   int rc = ensure_device();
   if (rc) return rc;
-  if (!fact || !dim || !fact->table || !dim->table || !out_rows || !out_n) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
-  if (n_payload > 4) return set_error(LLKV_UNSUPPORTED, "more than 4 payload columns");
-  const Table *tf = reinterpret_cast<const Table *>(fact->table), *td = reinterpret_cast<const Table *>(dim->table);
+  if (!fact || !dim || !fact->table || !dim->table) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (n_payload_ > 4) return set_error(LLKV_UNSUPPORTED, "more than 4 payload columns");
+  tf = reinterpret_cast<const Table *>(fact->table);
+  td = reinterpret_cast<const Table *>(dim->table);
   const Table *t2 = dim2 ? reinterpret_cast<const Table *>(dim2->table) : nullptr;
+  if (td->world != 1 || (t2 && t2->world != 1))
+    return set_error(LLKV_INVALID_ARGUMENT, "dimension tables are replicated: stage them whole (world = 1) on every rank; only the fact table is sharded");
+  n_payload = n_payload_;
   hipStream_t s = g_ctx.stream;
-  *out_n = 0;
-  if (out_total_groups) *out_total_groups = 0;
 
   // ---- dim2 key set -------------------------------------------------------------------
   HashSet set2;
@@ -80,19 +134,14 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
     if ((rc = set2.build(k2, sel2.d_dev, sel2.n, &dup, s))) return rc;
   }
   // ---- dim rows: filter [⋉ dim2] ------------------------------------------------------
-  Selection seld;
   if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) return rc;
-  DB kept; // device rows of the qualifying dim rows
-  uint64_t n_dim = seld.n;
-  const uint64_t *d_dim_rows = seld.d_dev;
+  n_dim = seld.n;
+  d_dim_rows = seld.d_dev;
   if (t2 && seld.n) {
-    DB flags, offs, tmp;
+    DB flags, offs;
     if ((rc = flags.alloc(seld.n * 8)) || (rc = offs.alloc((seld.n + 1) * 8))) return rc;
     HIP_TRY(hj_launch_semi_flags(fk, seld.d_dev, seld.n, k2, (const unsigned long long *)set2.owner.p, set2.cap - 1, (uint64_t *)flags.p, s));
-    size_t tb = 0;
-    HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, (const uint64_t *)flags.p, (uint64_t *)offs.p, seld.n, s));
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(hj_exclusive_scan_u64(tmp.p, &tb, (const uint64_t *)flags.p, (uint64_t *)offs.p, seld.n, s));
+    if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, seld.n, s))) return rc;
     uint64_t last_off = 0, last_flag = 0;
     HIP_TRY(hipMemcpyAsync(&last_off, (uint64_t *)offs.p + seld.n - 1, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&last_flag, (uint64_t *)flags.p + seld.n - 1, 8, hipMemcpyDeviceToHost, s));
@@ -103,15 +152,27 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
     HIP_TRY(hipStreamSynchronize(s));
     d_dim_rows = (const uint64_t *)kept.p;
   }
+  if (n_dim >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "dimension too large");
   if (n_dim == 0) return LLKV_OK;
-  // ---- dim hash table -------------------------------------------------------------------
+  if ((rc = sums.alloc(n_dim * 8)) || (rc = cnts.alloc(n_dim * 8)) || (rc = gcnts.alloc(n_dim * 8)) || (rc = report.alloc(n_dim * 8))) return rc;
+  HIP_TRY(hipMemsetAsync(sums.p, 0, n_dim * 8, s));
+  HIP_TRY(hipMemsetAsync(cnts.p, 0, n_dim * 8, s));
+  HIP_TRY(hipMemsetAsync(gcnts.p, 0, n_dim * 8, s));
+
+  // ---- dim hash table, slot → group id -----------------------------------------------------
   JoinKeyColumn kd{};
   if ((rc = int_key_column(td, dim->key_field, &kd))) return rc;
+  std::memset(&cc, 0, sizeof cc);
+  cc.key = kd;
+  cc.n_payload = n_payload;
+  for (uint32_t i = 0; i < n_payload; ++i) if ((rc = int_key_column(td, payload_fields[i], &cc.payload[i]))) return rc;
   HashSet ht;
   bool dup = false;
   if ((rc = ht.build(kd, d_dim_rows, n_dim, &dup, s))) return rc;
   if (dup) return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row");
-  if (ht.cap >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "dimension too large");
+  DB slot_group;
+  if ((rc = slot_group.alloc(ht.cap * 4))) return rc;
+  HIP_TRY(hj_launch_slot_groups(kd, d_dim_rows, n_dim, (const unsigned long long *)ht.owner.p, ht.cap - 1, (uint32_t *)slot_group.p, s));
 
   // ---- fact probe-emit -------------------------------------------------------------------
   auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
@@ -121,14 +182,15 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
   LoweredPlan plan;
   std::string err;
   if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err))) return set_error(rc, err);
-  if (plan.always_false || tf->local_rows == 0) return LLKV_OK;
+  if (plan.always_false || tf->local_rows == 0) { HIP_TRY(hipStreamSynchronize(s)); return LLKV_OK; }
   JitKernel k;
   if ((rc = jit_compile(JitKind::Probe, plan.type_string, &k, &err))) return set_error(rc, err);
   const TileSet *ts = nullptr;
   if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
   const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
   DB counts, offsets;
-  if ((rc = counts.alloc((size_t)n_slots * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
+  if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
+  HIP_TRY(hipMemsetAsync(counts.p, 0, (size_t)(n_slots + 1) * 8, s)); // the extra trailing 0 makes offsets[n_slots] the total
   ScanParams p;
   std::memset(&p, 0, sizeof p);
   for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = slot_buffer(tf->cols, plan, i);
@@ -144,76 +206,121 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
   p.ht_key_width = kd.width;
   p.ht_key_signed = kd.is_signed;
   if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &p, sizeof p, s))) return rc;
-  {
-    DB tmp;
-    size_t tb = 0;
-    // offsets[n_slots] (the total) is not produced by an exclusive scan of n_slots entries: scan n_slots + 1
-    // entries whose last count is 0
-    DB counts1;
-    if ((rc = counts1.alloc((size_t)(n_slots + 1) * 8))) return rc;
-    HIP_TRY(hipMemsetAsync(counts1.p, 0, (size_t)(n_slots + 1) * 8, s));
-    HIP_TRY(hipMemcpyAsync(counts1.p, counts.p, (size_t)n_slots * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, (const uint64_t *)counts1.p, (uint64_t *)offsets.p, n_slots + 1, s));
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(hj_exclusive_scan_u64(tmp.p, &tb, (const uint64_t *)counts1.p, (uint64_t *)offsets.p, n_slots + 1, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
-  uint64_t n_pairs = 0;
+  if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, s))) return rc;
   HIP_TRY(hipMemcpy(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost));
-  if (n_pairs >= kPredErrorBit) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison");
+  if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
-  DB e_slot, e_val, s_slot, s_val;
-  if ((rc = e_slot.alloc(n_pairs * 4)) || (rc = e_val.alloc(n_pairs * 8)) || (rc = s_slot.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;
+  DB e_group, e_val;
+  if ((rc = e_group.alloc(n_pairs * 4)) || (rc = e_val.alloc(n_pairs * 8)) || (rc = s_group.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;
   p.aux_in = (const uint64_t *)offsets.p;
-  p.aux_out32 = (uint32_t *)e_slot.p;
+  p.aux_out32 = (uint32_t *)e_group.p;
   p.aux_out = (uint64_t *)e_val.p;
   if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
-  // ---- stable sort by slot, per-group sums in scan order ---------------------------------------
+  HIP_TRY(hj_launch_map_u32((uint32_t *)e_group.p, n_pairs, (const uint32_t *)slot_group.p, s)); // slot → group id
+  // ---- stable sort by group, per-group sums in scan order ---------------------------------------
   uint32_t bits = 1;
-  while ((1ull << bits) < ht.cap) ++bits;
+  while ((1ull << bits) < n_dim) ++bits;
   {
     DB tmp;
     size_t tb = 0;
-    HIP_TRY(hj_sort_u32_u64(nullptr, &tb, (const uint32_t *)e_slot.p, (uint32_t *)s_slot.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
+    HIP_TRY(hj_sort_u32_u64(nullptr, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
     if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_slot.p, (uint32_t *)s_slot.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
+    HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
-  DB sums, cnts, tk_keys, tk_slots, tk_keys_s, tk_slots_s, n_groups_d;
-  if ((rc = sums.alloc(ht.cap * 8)) || (rc = cnts.alloc(ht.cap * 8)) || (rc = tk_keys.alloc(ht.cap * 8)) || (rc = tk_slots.alloc(ht.cap * 4)) ||
-      (rc = tk_keys_s.alloc(ht.cap * 8)) || (rc = tk_slots_s.alloc(ht.cap * 4)) || (rc = n_groups_d.alloc(8)))
+  HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
+  HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
+  HIP_TRY(hipStreamSynchronize(s));
+  return LLKV_OK;
+}
+
+// After the all-reduce of gcnts: this rank's raw pairs of the groups that other ranks hold rows of too.
+int JoinAgg::straddlers() {
+  st_groups.clear();
+  st_vals.clear();
+  have_straddlers = true;
+  if (n_pairs == 0 || n_dim == 0) return LLKV_OK;
+  hipStream_t s = g_ctx.stream;
+  DB flags, offs;
+  int rc;
+  if ((rc = flags.alloc((n_pairs + 1) * 8)) || (rc = offs.alloc((n_pairs + 1) * 8))) return rc;
+  HIP_TRY(hipMemsetAsync(flags.p, 0, (n_pairs + 1) * 8, s));
+  HIP_TRY(hj_launch_straddler_flags((const uint32_t *)s_group.p, n_pairs, (const uint64_t *)cnts.p, (const int64_t *)gcnts.p, (uint64_t *)flags.p, s));
+  if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, n_pairs + 1, s))) return rc;
+  uint64_t n = 0;
+  HIP_TRY(hipMemcpy(&n, (uint64_t *)offs.p + n_pairs, 8, hipMemcpyDeviceToHost));
+  if (n == 0) return LLKV_OK;
+  if (n > (64ull << 20)) return set_error(LLKV_UNSUPPORTED, "fact rows of groups that straddle ranks exceed 64 Mi: the fact table is not clustered by the join key");
+  DB og, ov;
+  if ((rc = og.alloc(n * 4)) || (rc = ov.alloc(n * 8))) return rc;
+  HIP_TRY(hj_launch_compact_pairs((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, (const uint64_t *)flags.p, (const uint64_t *)offs.p, n_pairs,
+                                  (uint32_t *)og.p, (uint64_t *)ov.p, s));
+  st_groups.resize(n);
+  st_vals.resize(n);
+  HIP_TRY(hipMemcpyAsync(st_groups.data(), og.p, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(st_vals.data(), ov.p, n * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return LLKV_OK;
+}
+
+int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const uint64_t *f_counts, const uint32_t *f_first_rank, uint64_t n_folded,
+                        uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups) {
+  *out_n = 0;
+  if (out_groups) *out_groups = 0;
+  if (n_dim == 0) return LLKV_OK;
+  hipStream_t s = g_ctx.stream;
+  int rc;
+  // groups this rank reports: the ones it alone holds …
+  HIP_TRY(hj_launch_report_counts((const uint64_t *)cnts.p, (const int64_t *)gcnts.p, n_dim, (uint64_t *)report.p, s));
+  // … plus the straddlers it holds first, with their exact sums and global counts
+  std::vector<uint32_t> mg;
+  std::vector<double> ms;
+  std::vector<uint64_t> mc;
+  for (uint64_t i = 0; i < n_folded; ++i) {
+    if (f_groups[i] >= n_dim) return set_error(LLKV_INVALID_ARGUMENT, "folded straddler group out of range");
+    if (f_first_rank[i] != rank) continue;
+    mg.push_back(f_groups[i]); ms.push_back(f_sums[i]); mc.push_back(f_counts[i]);
+  }
+  DB dg, dsum, dcnt;
+  if (!mg.empty()) {
+    if ((rc = dg.alloc(mg.size() * 4)) || (rc = dsum.alloc(mg.size() * 8)) || (rc = dcnt.alloc(mg.size() * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(dg.p, mg.data(), mg.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dsum.p, ms.data(), ms.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dcnt.p, mc.data(), mc.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hj_launch_patch_groups((const uint32_t *)dg.p, (const double *)dsum.p, (const uint64_t *)dcnt.p, mg.size(), (double *)sums.p, (uint64_t *)report.p, s));
+    HIP_TRY(hipStreamSynchronize(s)); // the host vectors are pageable
+  }
+  DB tk_keys, tk_groups, tk_keys_s, tk_groups_s, n_groups_d;
+  if ((rc = tk_keys.alloc(n_dim * 8)) || (rc = tk_groups.alloc(n_dim * 4)) || (rc = tk_keys_s.alloc(n_dim * 8)) || (rc = tk_groups_s.alloc(n_dim * 4)) ||
+      (rc = n_groups_d.alloc(8)))
     return rc;
-  HIP_TRY(hipMemsetAsync(cnts.p, 0, ht.cap * 8, s));
   HIP_TRY(hipMemsetAsync(n_groups_d.p, 0, 8, s));
-  HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_slot.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
-  HIP_TRY(hj_launch_topk_keys((const double *)sums.p, (const uint64_t *)cnts.p, ht.cap, (uint64_t *)tk_keys.p, (uint32_t *)tk_slots.p,
+  HIP_TRY(hj_launch_topk_keys((const double *)sums.p, (const uint64_t *)report.p, n_dim, (uint64_t *)tk_keys.p, (uint32_t *)tk_groups.p,
                               (unsigned long long *)n_groups_d.p, s));
   {
     DB tmp;
     size_t tb = 0;
-    HIP_TRY(hj_sort_u64_u32(nullptr, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_slots.p, (uint32_t *)tk_slots_s.p, ht.cap, s));
+    HIP_TRY(hj_sort_u64_u32(nullptr, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
     if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_slots.p, (uint32_t *)tk_slots_s.p, ht.cap, s));
+    HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
+    HIP_TRY(hipStreamSynchronize(s));
   }
   // ---- candidates → host: the first (limit + slack) groups by descending sum, gathered in ONE kernel + ONE copy ----
-  const uint32_t want = (uint32_t)std::min<uint64_t>(ht.cap, (uint64_t)limit + 64);
-  CandidateCols cc;
-  std::memset(&cc, 0, sizeof cc);
-  cc.key = kd;
-  cc.n_payload = n_payload;
-  for (uint32_t i = 0; i < n_payload; ++i) if ((rc = int_key_column(td, payload_fields[i], &cc.payload[i]))) return rc;
+  const uint32_t want = (uint32_t)std::min<uint64_t>(n_dim, (uint64_t)limit + 64);
   DB cand_d;
   if ((rc = cand_d.alloc((size_t)want * 64 + 8))) return rc;
-  HIP_TRY(hj_launch_gather_candidates((const uint64_t *)tk_keys_s.p, (const uint32_t *)tk_slots_s.p, want, (const unsigned long long *)ht.owner.p,
-                                      (const double *)sums.p, (const uint64_t *)cnts.p, cc, (uint64_t *)cand_d.p, s));
+  HIP_TRY(hj_launch_gather_group_candidates((const uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups_s.p, want, d_dim_rows, (const double *)sums.p,
+                                            (const uint64_t *)report.p, cc, (uint64_t *)cand_d.p, s));
   std::vector<uint64_t> hc((size_t)want * 8);
+  std::vector<uint32_t> hg(want);
   uint64_t n_groups = 0;
   HIP_TRY(hipMemcpyAsync(hc.data(), cand_d.p, (size_t)want * 64, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hg.data(), tk_groups_s.p, (size_t)want * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(&n_groups, n_groups_d.p, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   uint32_t n_cand = 0;
   while (n_cand < want && hc[(size_t)n_cand * 8] != ~0ull) ++n_cand;
-  if (n_cand == want && (uint64_t)want < ht.cap && n_cand > limit && limit > 0 && hc[(size_t)(limit - 1) * 8] == hc[(size_t)(want - 1) * 8])
+  if (n_cand == want && (uint64_t)want < n_dim && n_cand > limit && limit > 0 && hc[(size_t)(limit - 1) * 8] == hc[(size_t)(want - 1) * 8])
     return set_error(LLKV_UNSUPPORTED, "more than 64 groups tie on the LIMIT boundary");
   std::vector<llkv_join_group_row> cand(n_cand);
   for (uint32_t i = 0; i < n_cand; ++i) {
@@ -223,25 +330,119 @@ int run_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim,
     std::memcpy(&g.sum, &c[2], 8);
     g.count = c[3];
     for (int k = 0; k < 4; ++k) g.payload[k] = (int64_t)c[4 + k];
+    g.group_index = hg[i];
   }
-  // ORDER BY sum DESC, payload[0] ASC (arrow lexsort, llkv-executor/src/lib.rs:13847-13864); LIMIT
-  std::stable_sort(cand.begin(), cand.end(), [&](const llkv_join_group_row &a, const llkv_join_group_row &b) {
-    if (a.sum != b.sum) return a.sum > b.sum;
-    return n_payload ? a.payload[0] < b.payload[0] : false;
-  });
+  const uint32_t np = n_payload;
+  std::sort(cand.begin(), cand.end(), [np](const llkv_join_group_row &a, const llkv_join_group_row &b) { return row_before(a, b, np); });
   const uint32_t n = std::min<uint32_t>(limit, n_cand);
   for (uint32_t i = 0; i < n; ++i) out_rows[i] = cand[i];
   *out_n = n;
-  if (out_total_groups) *out_total_groups = n_groups;
+  if (out_groups) *out_groups = n_groups;
   return LLKV_OK;
 }
 
 } // namespace llkv
 
-extern "C" llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field,
-                                                  const llkv_join_side *dim2, const uint32_t *payload_fields, uint32_t n_payload,
-                                                  const llkv_expr_token *sum_expr, uint32_t sum_expr_len, uint32_t limit,
-                                                  llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_total_groups) {
-  return (llkv_status)llkv::run_join_groupby_topk(fact, dim, dim_fk_field, dim2, payload_fields, n_payload, sum_expr, sum_expr_len, limit,
-                                                  out_rows, out_n, out_total_groups);
+using namespace llkv;
+
+extern "C" {
+
+llkv_status llkv_hip_join_agg_prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
+                                      const uint32_t *payload_fields, uint32_t n_payload, const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
+                                      llkv_hip_join_agg **out) {
+  if (!out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "out is NULL");
+  auto *j = new JoinAgg();
+  const int rc = j->prepare(fact, dim, dim_fk_field, dim2, payload_fields, n_payload, sum_expr, sum_expr_len);
+  if (rc) { delete j; return (llkv_status)rc; }
+  *out = reinterpret_cast<llkv_hip_join_agg *>(j);
+  return LLKV_OK;
 }
+
+void llkv_hip_join_agg_free(llkv_hip_join_agg *h) { delete reinterpret_cast<JoinAgg *>(h); }
+
+llkv_status llkv_hip_join_agg_counts_buffer(llkv_hip_join_agg *h, void **device_ptr, uint64_t *len_i64) {
+  auto *j = reinterpret_cast<JoinAgg *>(h);
+  if (!j || !device_ptr || !len_i64) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  *device_ptr = j->gcnts.p;
+  *len_i64 = j->n_dim;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_join_agg_straddlers(llkv_hip_join_agg *h, const uint32_t **groups, const double **values, uint64_t *n) {
+  auto *j = reinterpret_cast<JoinAgg *>(h);
+  if (!j || !groups || !values || !n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  const int rc = j->straddlers();
+  if (rc) return (llkv_status)rc;
+  *groups = j->st_groups.data();
+  *values = j->st_vals.data();
+  *n = j->st_groups.size();
+  return LLKV_OK;
+}
+
+// Host only: fold the straddler pairs of all ranks, concatenated in rank order (= global row order within
+// each group), into exact per-group sums: SumFloat64 starts at 0.0 and adds in arrival order
+// (llkv-aggregate/src/lib.rs:870-888).  Outputs are in order of first appearance; *n_out: capacity in, count out.
+llkv_status llkv_hip_join_agg_fold_straddlers(const uint32_t *groups, const double *values, const uint64_t *rank_offsets, uint32_t world,
+                                              uint32_t *out_groups, double *out_sums, uint64_t *out_counts, uint32_t *out_first_rank,
+                                              uint64_t *n_out) {
+  if (!rank_offsets || !n_out || world == 0) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  const uint64_t cap = *n_out;
+  std::unordered_map<uint32_t, uint64_t> index;
+  uint64_t n = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    if (rank_offsets[r + 1] < rank_offsets[r]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "rank offsets must ascend");
+    for (uint64_t i = rank_offsets[r]; i < rank_offsets[r + 1]; ++i) {
+      auto it = index.find(groups[i]);
+      if (it == index.end()) {
+        if (n == cap) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "output capacity too small");
+        it = index.emplace(groups[i], n).first;
+        out_groups[n] = groups[i];
+        out_sums[n] = 0.0;
+        out_counts[n] = 0;
+        out_first_rank[n] = r;
+        ++n;
+      }
+      out_sums[it->second] += values[i];
+      out_counts[it->second] += 1;
+    }
+  }
+  *n_out = n;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_join_agg_candidates(llkv_hip_join_agg *h, const uint32_t *folded_groups, const double *folded_sums,
+                                         const uint64_t *folded_counts, const uint32_t *folded_first_rank, uint64_t n_folded, uint32_t rank,
+                                         uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups) {
+  auto *j = reinterpret_cast<JoinAgg *>(h);
+  if (!j || !out_rows || !out_n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (n_folded && (!folded_groups || !folded_sums || !folded_counts || !folded_first_rank)) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL folded arrays");
+  return (llkv_status)j->candidates(folded_groups, folded_sums, folded_counts, folded_first_rank, n_folded, rank, limit, out_rows, out_n, out_groups);
+}
+
+// Host only: ORDER BY sum DESC, payload[0] ASC, LIMIT over the ranks' candidates.
+llkv_status llkv_hip_join_agg_merge(const llkv_join_group_row *rows, uint32_t n, uint32_t n_payload, uint32_t limit,
+                                    llkv_join_group_row *out_rows, uint32_t *out_n) {
+  if ((n && !rows) || !out_rows || !out_n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  std::vector<llkv_join_group_row> v(rows, rows + n);
+  std::sort(v.begin(), v.end(), [n_payload](const llkv_join_group_row &a, const llkv_join_group_row &b) { return row_before(a, b, n_payload); });
+  const uint32_t m = std::min<uint32_t>(limit, n);
+  for (uint32_t i = 0; i < m; ++i) out_rows[i] = v[i];
+  *out_n = m;
+  return LLKV_OK;
+}
+
+// Single-rank form: prepare → (nothing to exchange) → candidates.
+llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field,
+                                       const llkv_join_side *dim2, const uint32_t *payload_fields, uint32_t n_payload,
+                                       const llkv_expr_token *sum_expr, uint32_t sum_expr_len, uint32_t limit,
+                                       llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_total_groups) {
+  if (!out_rows || !out_n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (fact && fact->table && reinterpret_cast<const Table *>(fact->table)->world != 1)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "a sharded fact table needs the phased llkv_hip_join_agg_* calls (counts all-reduce, straddler exchange)");
+  JoinAgg j;
+  int rc = j.prepare(fact, dim, dim_fk_field, dim2, payload_fields, n_payload, sum_expr, sum_expr_len);
+  if (rc) return (llkv_status)rc;
+  return (llkv_status)j.candidates(nullptr, nullptr, nullptr, nullptr, 0, 0, limit, out_rows, out_n, out_total_groups);
+}
+
+} // extern "C"

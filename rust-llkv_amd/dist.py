@@ -74,3 +74,27 @@ def share_column_stats(dist, table, field_ids, world: int) -> None:
         pairs = [g[f] for g in gathered if g.get(f) is not None]
         if len(pairs) == world:  # a rank without rows reports its (empty) range too; all must have statistics
             table.set_column_stats(f, min(p[0] for p in pairs), max(p[1] for p in pairs))
+
+
+def join_groupby_topk(dist, rt, join_agg, rank: int, world: int, limit: int, all_reduce_counts):
+    """Drives the collectives of the sharded join → GROUP BY → top-k pipeline (runtime.JoinAgg; dims replicated,
+    fact sharded).  ``all_reduce_counts(ptr, n)`` sums the int64 device buffer across ranks in place (RCCL through
+    torch on the GPU box; the tests substitute their own).  Returns (rows, total_groups), identical on every rank."""
+    ptr, n = join_agg.counts_buffer()
+    if world > 1 and n:
+        all_reduce_counts(ptr, n)
+    g, v = join_agg.straddlers()
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (g, v))
+    else:
+        gathered = [(g, v)]
+    folded = rt.fold_straddlers([x[0] for x in gathered], [x[1] for x in gathered])
+    rows, reported = join_agg.candidates(folded, rank, limit)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (rows, reported))
+    else:
+        parts = [(rows, reported)]
+    merged = rt.merge_join_rows([r for p in parts for r in p[0]], join_agg.n_payload, limit)
+    return merged, sum(p[1] for p in parts)

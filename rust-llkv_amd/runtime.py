@@ -495,6 +495,95 @@ def join_groupby_topk(fact: HipTable, fact_filters, fact_key: int, dim: HipTable
     return out, total.value
 
 
+class JoinAgg:
+    """The join → GROUP BY → top-k pipeline in phases, for a fact table sharded over ranks
+    (llkv_hip_join_agg_*; dist.join_groupby_topk drives the collectives between the phases)."""
+
+    def __init__(self, fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, sum_expr,
+                 payload_fields: Sequence[int] = (), dim_fk: int = 0, dim2: Optional[HipTable] = None, dim2_filters=(), dim2_key: int = 0):
+        keep = []
+
+        def side(table, filters, key):
+            p = CPlan(list(filters or []))
+            keep.append(p)
+            s = abi.CJoinSide()
+            s.table, s.filters, s.n_filters, s.key_field = table.handle, p.filters, p.n_filters, key
+            return s
+
+        f, d = side(fact, fact_filters, fact_key), side(dim, dim_filters, dim_key)
+        d2 = side(dim2, dim2_filters, dim2_key) if dim2 is not None else None
+        toks = sum_expr.to_c(keep)
+        pay = (C.c_uint32 * max(1, len(payload_fields)))(*payload_fields)
+        self.n_payload = len(payload_fields)
+        self._h = C.c_void_p()
+        check(lib().llkv_hip_join_agg_prepare(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None, pay,
+                                              C.c_uint32(len(payload_fields)), toks, C.c_uint32(len(sum_expr.tokens)), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().llkv_hip_join_agg_free(self._h)
+            self._h = None
+
+    def counts_buffer(self):
+        """(device pointer, length) of the int64 per-group row counts to all-reduce (SUM) in place."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        check(lib().llkv_hip_join_agg_counts_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value or 0, n.value
+
+    def straddlers(self):
+        """This rank's (groups uint32, values float64) pairs of the groups other ranks hold rows of too."""
+        g, v, n = C.POINTER(C.c_uint32)(), C.POINTER(C.c_double)(), C.c_uint64()
+        check(lib().llkv_hip_join_agg_straddlers(self._h, C.byref(g), C.byref(v), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.float64)
+        return np.ctypeslib.as_array(g, shape=(n.value,)).copy(), np.ctypeslib.as_array(v, shape=(n.value,)).copy()
+
+    def candidates(self, folded, rank: int, limit: int):
+        """folded = fold_straddlers(...) → (rows of this rank's report as CJoinGroupRow list, groups reported)."""
+        fg, fs, fc, fr = folded
+        rows = (abi.CJoinGroupRow * max(1, limit))()
+        n, total = C.c_uint32(), C.c_uint64()
+        ptr = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if len(a) else None
+        check(lib().llkv_hip_join_agg_candidates(self._h, ptr(fg, C.c_uint32), ptr(fs, C.c_double), ptr(fc, C.c_uint64), ptr(fr, C.c_uint32),
+                                                 C.c_uint64(len(fg)), C.c_uint32(rank), C.c_uint32(limit), rows, C.byref(n), C.byref(total)))
+        return [join_row_tuple(r) for r in rows[:n.value]], total.value
+
+
+def join_row_tuple(r):
+    """CJoinGroupRow → (key, sum, count, payload[4], group_index): a picklable form for all_gather_object."""
+    return (int(r.key), float(r.sum), int(r.count), tuple(int(r.payload[i]) for i in range(4)), int(r.group_index))
+
+
+def fold_straddlers(groups_by_rank, values_by_rank):
+    """Host only (llkv_hip_join_agg_fold_straddlers): exact sums of the straddling groups in global row order."""
+    world = len(groups_by_rank)
+    groups = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.uint32) for g in groups_by_rank]) if world else np.zeros(0, np.uint32))
+    values = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in values_by_rank]) if world else np.zeros(0, np.float64))
+    offs = np.zeros(world + 1, dtype=np.uint64)
+    np.cumsum([len(g) for g in groups_by_rank], out=offs[1:])
+    cap = max(1, len(groups))
+    og, os_, oc, of = np.zeros(cap, np.uint32), np.zeros(cap, np.float64), np.zeros(cap, np.uint64), np.zeros(cap, np.uint32)
+    n = C.c_uint64(cap)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    check(lib().llkv_hip_join_agg_fold_straddlers(p(groups, C.c_uint32), p(values, C.c_double), p(offs, C.c_uint64), C.c_uint32(world),
+                                                  p(og, C.c_uint32), p(os_, C.c_double), p(oc, C.c_uint64), p(of, C.c_uint32), C.byref(n)))
+    k = n.value
+    return og[:k].copy(), os_[:k].copy(), oc[:k].copy(), of[:k].copy()
+
+
+def merge_join_rows(rows, n_payload: int, limit: int):
+    """Host only (llkv_hip_join_agg_merge): ORDER BY sum DESC, payload[0] ASC, dim row order; LIMIT."""
+    arr = (abi.CJoinGroupRow * max(1, len(rows)))()
+    for i, t in enumerate(rows):
+        arr[i].key, arr[i].sum, arr[i].count, arr[i].group_index = t[0], t[1], t[2], t[4]
+        for k in range(4):
+            arr[i].payload[k] = t[3][k]
+    out = (abi.CJoinGroupRow * max(1, limit))()
+    n = C.c_uint32()
+    check(lib().llkv_hip_join_agg_merge(arr, C.c_uint32(len(rows)), C.c_uint32(n_payload), C.c_uint32(limit), out, C.byref(n)))
+    return [(r.key, r.sum, r.count) + tuple(r.payload[i] for i in range(n_payload)) for r in out[:n.value]]
+
+
 def lower_plan(column_descs, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (), grouped: bool = False,
                plan_lib=None, order_by_keys: bool = False):
     """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError."""

@@ -92,3 +92,86 @@ def test_two_rank_combine_is_bit_identical_to_one_rank(tmp_path, world):
     for o in range(8):
         acc += float(ex[o, 1:2].view(np.float64)[0])
     assert np.float64(acc).view(np.uint64) == want[1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Sharded join → GROUP BY → top-k: the product's collective driver (dist.join_groupby_topk)
+# and host pieces (fold_straddlers, merge) on two gloo ranks.  The device phases (probe, per-group sums) are
+# stood in by numpy with the same contract: per-group row counts, straddler pairs in row order, candidates.
+# ---------------------------------------------------------------------------------------------------
+class _HostJoinAgg:
+    def __init__(self, groups, values, n_groups, payload):
+        self.groups, self.values, self.n_payload, self.payload = groups, values, 1, payload
+        self.local = np.bincount(groups, minlength=n_groups).astype(np.int64)
+        self.counts = self.local.copy()
+
+    def counts_buffer(self):
+        return self.counts, len(self.counts)
+
+    def straddlers(self):
+        m = (self.local != self.counts)[self.groups]
+        return self.groups[m].astype(np.uint32), self.values[m]
+
+    def candidates(self, folded, rank, limit):
+        sums, cnt = {}, {}
+        for g, v in zip(self.groups, self.values):  # left-to-right f64 adds from 0.0, row order
+            if self.local[g] == self.counts[g]:
+                sums[g] = sums.get(g, 0.0) + float(v)
+                cnt[g] = cnt.get(g, 0) + 1
+        for g, s, c, r in zip(*folded):
+            if r == rank:
+                sums[int(g)], cnt[int(g)] = float(s), int(c)
+        rows = sorted(((10_000 + g, s, cnt[g], (int(self.payload[g]), 0, 0, 0), g) for g, s in sums.items()), key=lambda t: (-t[1], t[3][0], t[4]))
+        return rows[:limit], len(rows)
+
+
+def _join_data(n_rows, n_groups, clustered):
+    rng = np.random.default_rng(11)
+    groups = np.sort(rng.integers(0, n_groups, size=n_rows)) if clustered else rng.integers(0, n_groups, size=n_rows)
+    values = rng.normal(size=n_rows) * 1e5
+    payload = rng.integers(0, 50, size=n_groups)
+    return groups.astype(np.int64), values, payload
+
+
+def _join_worker(rank, world, port, n_rows, n_groups, clustered, out_path):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rt, dmod = mod("runtime"), mod("dist")
+    rt.lib()
+    groups, values, payload = _join_data(n_rows, n_groups, clustered)
+    lo, hi = rank * n_rows // world, (rank + 1) * n_rows // world
+    ja = _HostJoinAgg(groups[lo:hi], values[lo:hi], n_groups, payload)
+
+    def all_reduce_counts(buf, n):
+        dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
+
+    rows, total = dmod.join_groupby_topk(dist, rt, ja, rank, world, 10, all_reduce_counts)
+    if rank == 1:  # every rank holds the same answer; check a non-zero one
+        np.save(out_path, np.array([(r[0], np.float64(r[1]).view(np.uint64), r[2], r[3]) for r in rows] + [(total, 0, 0, 0)], dtype=np.uint64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("clustered", [True, False])
+def test_two_rank_join_groupby_topk_is_bit_identical_to_one_rank(tmp_path, clustered):
+    import torch.multiprocessing as mp
+
+    n_rows, n_groups = 20_000, 700
+    out = str(tmp_path / "rows.npy")
+    mp.spawn(_join_worker, args=(2, _free_port(), n_rows, n_groups, clustered, out), nprocs=2, join=True)
+    got = np.load(out)
+    groups, values, payload = _join_data(n_rows, n_groups, clustered)
+    sums, cnt = np.zeros(n_groups), np.zeros(n_groups, dtype=np.int64)
+    for g, v in zip(groups, values):  # the reference's order: one sequential fold over the whole table
+        sums[g] = sums[g] + v if cnt[g] else 0.0 + v
+        cnt[g] += 1
+    present = [g for g in range(n_groups) if cnt[g]]
+    want = sorted(present, key=lambda g: (-sums[g], payload[g], g))[:10]
+    assert int(got[-1, 0]) == len(present)
+    assert [int(r[0]) for r in got[:-1]] == [10_000 + g for g in want]
+    assert [int(r[1]) for r in got[:-1]] == [int(np.float64(sums[g]).view(np.uint64)) for g in want]  # bit-exact f64 sums
+    assert [int(r[2]) for r in got[:-1]] == [int(cnt[g]) for g in want]

@@ -701,6 +701,86 @@ def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
         assert np.float64(g[1]).tobytes() == np.float64(w[1]).tobytes(), (g, w)  # bit-exact revenue
 
 
+def _device_i64(ptr, n):
+    """int64 torch tensor aliasing a raw device pointer (what the RCCL all-reduce is given on the GPU box)."""
+    import torch
+
+    class Raw:
+        pass
+    raw = Raw()
+    raw.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(raw, device="cuda")
+
+
+@pytest.mark.parametrize("clustered", [True, False])
+def test_q3_sharded_fact_table_is_rank_count_invariant(rt, abi, tpch, clustered):
+    """dimension tables replicated, lineitem sharded by chunk over 2 / 4 / 8 ranks (emulated on
+    one device: the collectives are done by hand).  Orders whose lineitems straddle a shard boundary are summed
+    from their raw values in global row order, so keys, counts, group totals and the revenue BITS equal the
+    single-GPU answer for every rank count — also when the fact table is NOT clustered by the key and nearly
+    every group straddles."""
+    D = tpch.DATE_1995_03_15
+    rows, scale = 60175, 0.01
+    li = tpch.gen_lineitem(rows, scale)
+    if not clustered:
+        perm = np.random.default_rng(3).permutation(rows)
+        li = {k: v[perm] for k, v in li.items()}
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    seg = [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]]
+    ot_ = rt.HipTable(2, tpch.chunk_rows(n_ord, 65536))
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c])
+    ct = rt.HipTable(3, tpch.chunk_rows(n_cust, 65536))
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, seg)
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    revenue = col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT))
+    chunks = tpch.chunk_rows(rows, 1000)  # 61 chunks: ragged shards, many boundaries inside orders
+
+    def fact(rank, world):
+        t = rt.HipTable(1, chunks, rank, world)
+        lo = sum(chunks[:t.first_chunk])
+        for c in ("l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"):
+            t.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c][lo:lo + t.local_rows])
+        return t
+
+    args = lambda t: dict(fact=t, fact_filters=[F(tpch.L_SHIPDATE, O.GreaterThan(D))], fact_key=tpch.L_ORDERKEY, dim=ot_,
+                          dim_filters=[F(tpch.O_ORDERDATE, O.LessThan(D))], dim_key=tpch.O_ORDERKEY, sum_expr=revenue,
+                          payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                          dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    whole = fact(0, 1)
+    want, want_total = rt.join_groupby_topk(limit=10, **args(whole))
+    assert len(want) == 10 and want_total > 100
+    bits = lambda rws: [(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in rws]
+    for world in (2, 4, 8):
+        shards = [fact(r, world) for r in range(world)]
+        with pytest.raises(abi.LlkvError):  # the one-call form refuses a shard: its answer would be partial
+            rt.join_groupby_topk(limit=10, **args(shards[0]))
+        joins = [rt.JoinAgg(**args(t)) for t in shards]
+        bufs = [j.counts_buffer() for j in joins]
+        assert len({n for _, n in bufs}) == 1  # same groups on every rank: the qualifying dim rows
+        tensors = [_device_i64(p, n) for p, n in bufs]
+        total = sum(t.clone() for t in tensors)  # ncclAllReduce(SUM) by hand
+        for t in tensors:
+            t.copy_(total)
+        import torch
+        torch.cuda.synchronize()
+        strad = [j.straddlers() for j in joins]
+        n_strad_pairs = sum(len(g) for g, _ in strad)
+        if clustered:
+            assert n_strad_pairs <= world * 7  # ≤ one order per shard boundary, ≤ 7 lines each
+        else:
+            assert n_strad_pairs > 100
+        folded = rt.fold_straddlers([g for g, _ in strad], [v for _, v in strad])
+        parts = [j.candidates(folded, r, 10) for r, j in enumerate(joins)]
+        got = rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)
+        assert bits(got) == bits(want), world
+        assert sum(n for _, n in parts) == want_total
+
+
 def test_table_staged_from_arr0_chunk_blobs(rt, orc, abi, tpch):
     """§8f-1: ingest llkv-column-map chunk blobs (`ARR0`) instead of raw buffers; results identical."""
     n = 20_000
