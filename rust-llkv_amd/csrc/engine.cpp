@@ -614,7 +614,10 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
       for (size_t k = 0; k < p.key_fields.size(); ++k) {
         const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
         GroupKey gk;
-        if (p.key_is_int[k]) {
+        if (p.key_nullable[k] && code == p.key_cards[k] - 1) {
+          gk.is_null = true;
+          gk.is_int = p.key_is_int[k] != 0;
+        } else if (p.key_is_int[k]) {
           gk.is_int = true;
           gk.i = p.key_bases[k] + (int64_t)code;
         } else {
@@ -1120,6 +1123,7 @@ llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group
   const GroupKey &gk = q->groups[group].keys[key];
   if (gk.is_int) { out->dtype = LLKV_DT_INT64; out->i64 = gk.i; }
   else { out->dtype = LLKV_DT_UTF8; out->str = gk.s.c_str(); }
+  out->is_null = gk.is_null ? 1 : 0;
   return LLKV_OK;
 }
 

@@ -88,10 +88,12 @@ void jit_shutdown();
 
 struct GroupKey { // GroupKeyValue: String or Int (llkv-executor/src/lib.rs:99-106)
   bool is_int = false;
+  bool is_null = false; // GroupKeyValue::Null
   int64_t i = 0;
   std::string s;
-  bool operator<(const GroupKey &o) const { return is_int ? i < o.i : s < o.s; }
-  bool operator==(const GroupKey &o) const { return is_int ? i == o.i : s == o.s; }
+  // ORDER BY key ASC with NULLS FIRST (the caller re-sorts the handful of groups for any other order)
+  bool operator<(const GroupKey &o) const { return (is_null || o.is_null) ? (is_null && !o.is_null) : (is_int ? i < o.i : s < o.s); }
+  bool operator==(const GroupKey &o) const { return (is_null || o.is_null) ? (is_null == o.is_null) : (is_int ? i == o.i : s == o.s); }
 };
 struct GroupResult {
   uint64_t first_row = 0;

@@ -340,6 +340,10 @@ template <int S> struct KeyCode {
 template <int S, class Ty, class Base> struct KeyInt {
   static __device__ __forceinline__ uint32_t code(Ctx &c, int j) { return (uint32_t)((int64_t)c.get<Ty>(S, j) - (int64_t)Base::eval(c, j)); }
 };
+// Key column with NULL cells: NULL is its own group, coded right after the non-NULL codes.
+template <class V, class K, int NULL_CODE> struct KeyOrNull {
+  static __device__ __forceinline__ uint32_t code(Ctx &c, int j) { return V::eval(c, j) ? K::code(c, j) : (uint32_t)NULL_CODE; }
+};
 // FIRST = 1 keeps the row id of each group's first row (first-appearance output order,
 // llkv-executor/src/lib.rs:5065-5089); with ORDER BY on the keys it is not needed.
 template <int NG_, int FIRST_, class... Ks> struct Keys {

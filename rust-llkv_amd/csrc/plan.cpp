@@ -645,7 +645,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       // integer columns whose staging statistics bound the range.
       const bool int_key = probe->dtype == LLKV_DT_INT64 || probe->dtype == LLKV_DT_INT32 || probe->dtype == LLKV_DT_DATE32;
       if (probe->dtype != LLKV_DT_UTF8 && !int_key) return L.fail(LLKV_UNSUPPORTED, std::string("dense GROUP BY over ") + dtype_name(probe->dtype));
-      if (probe->nullable) return L.fail(LLKV_UNSUPPORTED, "GROUP BY key with NULL cells (NULL is its own group)");
+
       if (int_key) {
         if (!probe->has_stats) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key without column statistics (hash path)");
         const unsigned __int128 range = (unsigned __int128)((__int128)probe->max_i - (__int128)probe->min_i) + 1;
@@ -653,15 +653,22 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       }
       if ((rc = L.slot_of(key_fields[k], &ci, &slot))) return rc;
       uint32_t card;
+      std::string node;
       if (int_key) {
         card = (uint32_t)((__int128)ci->max_i - (__int128)ci->min_i + 1);
         std::string base;
         if ((rc = L.lit_i(ci->min_i, &base))) return rc;
-        nodes += ",KeyInt<" + std::to_string(slot) + "," + dtype_tag(ci->dtype) + "," + base + ">";
+        node = "KeyInt<" + std::to_string(slot) + "," + dtype_tag(ci->dtype) + "," + base + ">";
       } else {
         card = (uint32_t)(ci->dictionary.empty() ? 1 : ci->dictionary.size());
-        nodes += ",KeyCode<" + std::to_string(slot) + ">";
+        node = "KeyCode<" + std::to_string(slot) + ">";
       }
+      // GroupKeyValue::Null is a group of its own (llkv-executor/src/lib.rs:99-106,9362-9456): one more code
+      std::string kv;
+      if ((rc = L.valid_of_field(key_fields[k], &kv))) return rc;
+      if (!kv.empty()) { node = "KeyOrNull<" + kv + "," + node + "," + std::to_string(card) + ">"; card += 1; }
+      p.key_nullable.push_back(kv.empty() ? 0 : 1);
+      nodes += "," + node;
       p.key_fields.push_back(key_fields[k]);
       p.key_slots.push_back((uint32_t)slot);
       p.key_cards.push_back(card);

@@ -70,6 +70,7 @@ struct LoweredPlan {
   std::vector<uint32_t> key_fields, key_slots, key_strides, key_cards;
   std::vector<int64_t> key_bases;   // integer keys: code = value - base (column minimum); unused for Utf8
   std::vector<uint8_t> key_is_int;
+  std::vector<uint8_t> key_nullable; // the key column has NULL cells: code == cardinality − 1 is the NULL group
   uint32_t ng = 1;
   bool grouped = false;
   bool track_first = false; // lane [1] = first row id of the group (first-appearance order)

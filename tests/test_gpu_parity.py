@@ -437,7 +437,8 @@ def test_null_cells_match_oracle(rt, orc, abi, chunks):
     v1, v2, v3, v6 = rng.random(n) > 0.2, rng.random(n) > 0.1, rng.random(n) > 0.5, rng.random(n) > 0.3
     v1[:3] = False  # leading NULLs: "first row" of MIN/MAX must be the first non-NULL one
     ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64, v1), (2, abi.DT_FLOAT64, f64, v2), (3, abi.DT_INT32, i32, v3),
-                                       (4, abi.DT_INT64, dense), (5, abi.DT_UTF8, keys), (6, abi.DT_UTF8, tags, v6)], chunks)
+                                       (4, abi.DT_INT64, dense), (5, abi.DT_UTF8, keys), (6, abi.DT_UTF8, tags, v6),
+                                       (7, abi.DT_DATE32, (i32 % 5).astype(np.int32) - 2, v3)], chunks)
     E, F, O, B, A, col = abi.Expr, abi.Filter, abi.Operator, abi.Bound, abi.AggregateSpec, abi.col
     preds = [None,
              [F(1, O.LessThan(10))],
@@ -462,6 +463,15 @@ def test_null_cells_match_oracle(rt, orc, abi, chunks):
         assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp]
         for g, w in zip(got, exp):
             assert_values(g.values, w.values, f"groupby pred {i}")
+    # NULL is a group of its own: Utf8 and integer keys with NULL cells, alone and combined
+    for keyset in ([6], [7], [6, 5], [7, 6]):
+        for order in (True, False):
+            ga = gaggs[:4] if len(keyset) == 1 else gaggs[:2]  # the dense LDS image holds ≤ 79 lanes
+            got, exp = rt.groupby(ht, preds[1], keyset, ga, order), orc.groupby(ot, preds[1], keyset, ga, order)
+            assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp], (keyset, order)
+            assert any(k.value is None for r in got for k in r.keys)
+            for g, w in zip(got, exp):
+                assert_values(g.values, w.values, f"null keys {keyset}")
     if n < 20000:
         for p in (preds[0], preds[1], preds[10]):
             for projs in ([1], [1, 2], [2, col(1) * 2 + col(3)], [6], [6, 3], [4, 1]):

@@ -190,9 +190,11 @@ def test_null_cells_lower_to_validity_masks_and_domains(lib, abi):
     ts, lanes, _ = rt.lower_plan(d, None, [A.count(1), A.count_nulls(1), A.sum(1), A.avg(2), A.sum(col(1) * col(2)), A.sum(3)])
     assert "CountIf<Valid<0>>" in ts and "IfValid<Valid<0>,SumI64<Col<1,I64>>>" in ts and "IfValid<Valid<2>,SumF64<Col<3,F64>>>" in ts
     assert "IfValid<And<Valid<0>,Valid<2>>,SumF64<Bin<3,ToF64<Col<1,I64>>,Col<3,F64>>>>" in ts and ",SumI64<Col<4,I64>>>" in ts
-    with pytest.raises(abi.LlkvError) as e:
-        rt.lower_plan(d, None, cnt, keys=[1], grouped=True)
-    assert e.value.kind == "Unsupported"
+    # a key column with NULL cells: NULL is one more group (GroupKeyValue::Null)
+    dk = _desc(abi, [(1, abi.DT_INT64, True), (2, abi.DT_FLOAT64, True)])
+    dk[0].has_stats, dk[0].min_i, dk[0].max_i = 1, 10, 13
+    ts, lanes, _ = rt.lower_plan(dk, None, [A.count_star(), A.sum(2)], keys=[1], grouped=True)
+    assert "Keys<5,1,KeyOrNull<Valid<1>,KeyInt<0,I64,LitI<0>>,4>>" in ts and lanes == 5 * 4 + 1  # rows, first row, sum, non-NULL count
 
 
 def test_int_sum_uses_statistics_to_exclude_overflow(lib, abi):
