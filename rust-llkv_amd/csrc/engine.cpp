@@ -257,6 +257,7 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
 // Query
 // ---------------------------------------------------------------------------------
 Query::~Query() {
+  if (sorted) sorted_groupby_free(sorted);
   if (d_tile_partials) (void)hipFree(d_tile_partials);
   if (d_exchange && !host_mapped) (void)hipFree(d_exchange);
   if (d_lane_ops) (void)hipFree(d_lane_ops);
@@ -292,8 +293,18 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->table = table;
   q->order_by_keys = order_by_keys;
   q->n_user_aggs = n_aggs;
+  q->n_user_keys = grouped ? n_keys : 0;
   std::string err;
   rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, /*track_first=*/!order_by_keys, &q->plan, &err);
+  if (rc == LLKV_UNSUPPORTED && grouped) {
+    // too many groups / too wide a state / sparse or unbounded integer keys for the dense kernel: sort-based route
+    const std::string dense_err = err;
+    if (sorted_groupby_prepare(table, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, order_by_keys, &q->sorted) == LLKV_OK) {
+      *out = q.release();
+      return LLKV_OK;
+    }
+    return set_error(rc, dense_err + "; sort-based route: " + g_last_error);
+  }
   if (rc) return set_error(rc, err);
   const LoweredPlan &p = q->plan;
   if (!grouped) {
@@ -378,6 +389,13 @@ int Query::flush_pending() {
 }
 
 int Query::launch(hipStream_t stream) {
+  if (sorted) { // the sort-based route runs to completion here; submit / collect only hand the result over
+    if (n_launched != n_collected) return set_error(LLKV_INVALID_ARGUMENT, "a sort-based GROUP BY keeps one execution in flight");
+    const int rc = sorted_groupby_run(sorted, &groups);
+    if (rc) return rc;
+    n_launched++;
+    return LLKV_OK;
+  }
   if (!stream) stream = g_ctx.stream;
   if (n_launched - n_collected >= depth)
     return set_error(LLKV_INVALID_ARGUMENT, "query pipeline is full: collect a finished execution first (depth " + std::to_string(depth) + ")");
@@ -508,6 +526,7 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   switch (a.fin) {
   case AggFinal::CountRows: out->dtype = LLKV_DT_INT64; out->i64 = rows; return LLKV_OK;
   case AggFinal::CountNullsZero: out->dtype = LLKV_DT_INT64; out->i64 = 0; return LLKV_OK;
+  case AggFinal::SumDec: case AggFinal::TotalDec: case AggFinal::AvgDec: case AggFinal::MinDec: case AggFinal::MaxDec: break; // handled above
   case AggFinal::CountValid: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)l[0]; return LLKV_OK;
   case AggFinal::CountNulls: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)g[0] - (int64_t)l[0]; return LLKV_OK;
   case AggFinal::SumI64Fast: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
@@ -653,6 +672,7 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
 // Make `stream` wait until the exchange image of the OLDEST not-yet-submitted execution is complete (for a
 // caller that runs the all-reduce on a communication stream before submit).
 int Query::wait_folded(hipStream_t stream) {
+  if (sorted) return LLKV_OK;
   if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "no launched execution awaits submission");
   if (!stream) stream = g_ctx.stream;
   const uint32_t slot = (uint32_t)(n_submitted % depth);
@@ -666,6 +686,7 @@ int Query::wait_folded(hipStream_t stream) {
 // collective, if any, on `stream`).  Single-rank images already live in host memory.
 int Query::submit(hipStream_t stream) {
   if (n_submitted >= n_launched) return set_error(LLKV_INVALID_ARGUMENT, "submit without a launched execution");
+  if (sorted) { n_submitted++; return LLKV_OK; }
   const uint32_t slot = (uint32_t)(n_submitted % depth);
   if (!host_mapped) {
     int rc;
@@ -683,6 +704,7 @@ int Query::submit(hipStream_t stream) {
 // Wait for the oldest submitted execution, fold and finalize it.
 int Query::collect() {
   if (n_collected >= n_submitted) return set_error(LLKV_INVALID_ARGUMENT, "collect without a submitted execution");
+  if (sorted) { n_collected++; return LLKV_OK; }
   const uint32_t slot = (uint32_t)(n_collected % depth);
   int rc;
   if (pending && pending_slot == slot && (rc = flush_pending())) return rc; // nothing was launched behind it
@@ -1053,6 +1075,7 @@ llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream) {
 llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_ptr, uint64_t *len_i64) {
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   Query *q = reinterpret_cast<Query *>(query);
+  if (q->sorted) return (llkv_status)set_error(LLKV_UNSUPPORTED, "a sort-based GROUP BY has no exchange image (single rank only)");
   // image of the oldest execution awaiting submission (slot 0 before the first launch); consecutive
   // executions use consecutive slots of one ring: slot s lives at base + s * len
   const uint64_t cur = q->n_submitted < q->n_launched ? q->n_submitted : (q->n_launched ? q->n_launched - 1 : 0);
@@ -1112,7 +1135,7 @@ llkv_status llkv_hip_query_collect(llkv_hip_query *query) {
 }
 
 uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->groups.size() : 0; }
-uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->plan.key_fields.size() : 0; }
+uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->n_user_keys : 0; }
 uint32_t llkv_hip_query_num_aggregates(const llkv_hip_query *query) { return query ? reinterpret_cast<const Query *>(query)->n_user_aggs : 0; }
 
 llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group, uint32_t key, llkv_value *out) {

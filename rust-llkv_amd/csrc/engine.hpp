@@ -75,7 +75,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
-enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4 };
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5 };
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // scan / select-count / project
@@ -101,8 +101,17 @@ struct GroupResult {
   std::vector<llkv_value> values;
 };
 
+// Sort-based GROUP BY (group_sort.cpp): any number of groups, any state width.
+struct SortedGroupBy;
+int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                           const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
+                           bool order_by_keys, SortedGroupBy **out);
+int sorted_groupby_run(SortedGroupBy *s, std::vector<GroupResult> *groups);
+void sorted_groupby_free(SortedGroupBy *s);
+
 struct Query {
   const Table *table = nullptr;
+  SortedGroupBy *sorted = nullptr; // set when the dense GROUP BY kernel cannot hold the groups: executions run synchronously in launch()
   LoweredPlan plan;
   const CatalogEntry *entry = nullptr;
   JitKernel jit;
@@ -129,7 +138,7 @@ struct Query {
   uint64_t *d_exchange = nullptr; // [kMaxDepth][kOctants][lanes]
   uint64_t *h_exchange = nullptr; // pinned, same shape
   bool order_by_keys = false;
-  uint32_t n_user_aggs = 0;
+  uint32_t n_user_aggs = 0, n_user_keys = 0;
   std::vector<GroupResult> groups;
   // ungrouped SUM/AVG(Int64) without overflow-excluding statistics: plan that emits the argument values of
   // the selected rows in row order, for the exact prefix-overflow check (index = aggregate, empty = n/a)
@@ -184,6 +193,7 @@ struct Selection {
 };
 int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                   uint32_t n_ops, Selection *sel, const uint32_t *drop_null_fields = nullptr, uint32_t n_drop_null_fields = 0);
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

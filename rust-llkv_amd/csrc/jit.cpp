@@ -22,7 +22,7 @@ namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
 
-const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : "emit"; }
+const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : k == JitKind::Reduce ? "reduce" : "emit"; }
 
 std::string wrapper_source(JitKind kind, const std::string &ts) {
   std::string s = "\nusing namespace llkv;\n";
@@ -36,6 +36,9 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     break;
   case JitKind::Project:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ProjParams p) { project_body<" + ts + ">(p); }\n";
+    break;
+  case JitKind::Reduce:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ReduceParams p) { group_reduce_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Emit:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { emit_body<" + ts + ", false>(p); }\n";
@@ -162,6 +165,7 @@ extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out,
   else if (ts.rfind("ProjPlan<", 0) == 0) kind = 2;
   else if (ts.rfind("ProbePlan<", 0) == 0) kind = 3;
   else if (ts.rfind("EmitPlan<", 0) == 0) kind = 4;
+  else if (ts.rfind("ReducePlan<", 0) == 0) kind = 5;
   const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
   std::vector<char> code;
   std::string err;

@@ -409,6 +409,89 @@ hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const 
   return hipGetLastError();
 }
 
+// ---- sort-based GROUP BY: generic key handling -------------------------------------------------------
+__device__ __forceinline__ bool key_cell(const JoinKeyColumn &k, uint64_t row, long long *out) {
+  if (k.valid && !k.valid[row]) { *out = 0; return false; }
+  if (k.width == 8) *out = reinterpret_cast<const long long *>(k.values)[row];
+  else if (k.width == 4) {
+    const uint32_t v = reinterpret_cast<const uint32_t *>(k.values)[row];
+    *out = k.is_signed ? (long long)(int32_t)v : (long long)v;
+  } else *out = (long long)reinterpret_cast<const uint8_t *>(k.values)[row];
+  return true;
+}
+__global__ __launch_bounds__(256) void hj_gather_sort_keys_kernel(JoinKeyColumn col, long long base, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  long long v;
+  const bool ok = key_cell(col, dev_rows[perm[i]], &v);
+  keys[i] = ok ? (uint64_t)v - (uint64_t)base : 0ull;
+}
+hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_gather_sort_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, base, dev_rows, perm, n, keys);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_gather_valid_kernel(JoinKeyColumn col, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint32_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = col.valid[dev_rows[perm[i]]] ? 1u : 0u;
+}
+hipError_t hj_launch_gather_valid(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint32_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_gather_valid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, dev_rows, perm, n, out);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_group_boundaries_kernel(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool diff = i == 0;
+  if (!diff) {
+    const uint64_t a = dev_rows[perm[i]], b = dev_rows[perm[i - 1]];
+    for (uint32_t k = 0; k < ks.n; ++k) {
+      long long va, vb;
+      const bool oa = key_cell(ks.k[k], a, &va), ob = key_cell(ks.k[k], b, &vb);
+      diff |= (oa != ob) | (oa & (va != vb));
+    }
+  }
+  flags[i] = diff ? 1u : 0u;
+}
+hipError_t hj_launch_group_boundaries(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *flags, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_group_boundaries_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, ks, dev_rows, perm, n, flags);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_segment_starts_kernel(const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t n_groups, uint64_t *seg_start) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) seg_start[offsets[i]] = i;
+  if (i == 0) seg_start[n_groups] = n;
+}
+hipError_t hj_launch_segment_starts(const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t n_groups, uint64_t *seg_start, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_segment_starts_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, flags, offsets, n, n_groups, seg_start);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_group_keys_kernel(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start,
+                                                             uint64_t n_groups, int64_t *out_vals, uint8_t *out_valid) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint64_t row = dev_rows[perm[seg_start[g]]];
+  for (uint32_t k = 0; k < ks.n; ++k) {
+    long long v;
+    const bool ok = key_cell(ks.k[k], row, &v);
+    out_vals[(uint64_t)k * n_groups + g] = v;
+    out_valid[(uint64_t)k * n_groups + g] = ok ? 1 : 0;
+  }
+}
+hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups,
+                                int64_t *out_vals, uint8_t *out_valid, hipStream_t s) {
+  if (n_groups == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_group_keys_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, s, ks, dev_rows, perm, seg_start, n_groups, out_vals, out_valid);
+  return hipGetLastError();
+}
+hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
+                                uint64_t n, uint32_t end_bit, hipStream_t s) {
+  return rocprim::radix_sort_pairs(tmp, *tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, end_bit, s);
+}
+
 // ---- exact, order-dependent SUM(Int64) overflow check -------------------------------------------
 struct I128 {
   uint64_t lo;

@@ -102,6 +102,26 @@ hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const 
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,
                                              uint64_t *out /*[n][8]*/, hipStream_t s);
 
+// ---- sort-based GROUP BY (group_sort.cpp): generic key handling -------------------------------------------
+// keys[i] = value − base (as u64) of column `col` at selected row perm[i]: order preserving when base is the
+// column minimum (statistics) or the type minimum (i64::MIN ⇔ flipping the sign bit); NULL cell → 0, told
+// apart by the validity pass.
+hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys, hipStream_t s);
+hipError_t hj_launch_gather_valid(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint32_t *out, hipStream_t s);
+struct GroupKeySet {
+  JoinKeyColumn k[4];
+  uint32_t n;
+};
+// flags[i] = 1 when sorted position i starts a new group (i == 0 or some key differs from position i − 1).
+hipError_t hj_launch_group_boundaries(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *flags, hipStream_t s);
+// seg_start[offsets[i]] = i for every flagged i; seg_start[n_groups] = n.
+hipError_t hj_launch_segment_starts(const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t n_groups, uint64_t *seg_start, hipStream_t s);
+// Raw key cells of each group's first sorted row: out_vals[k][g] (sign-extended to i64), out_valid[k][g].
+hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups,
+                                int64_t *out_vals /*[n_keys][n_groups]*/, uint8_t *out_valid /*[n_keys][n_groups]*/, hipStream_t s);
+hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
+                                uint64_t n, uint32_t end_bit, hipStream_t s);
+
 // Does any prefix of vals[0..n) (summed left to right, exactly) leave the i64 range?  *d_flag |= 1 if so.
 // `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.
 hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s);

@@ -612,86 +612,12 @@ struct Lowering {
 
 } // namespace
 
-int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
-               const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
-               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err) {
-  *out = LoweredPlan{};
-  LoweredPlan &p = *out;
-  Lowering L{resolve, p, err, grouped};
-  p.grouped = grouped;
+// Aggregate list → deduplicated lane groups (node strings + lane ops) and one AggOut per aggregate.
+static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped,
+                            std::vector<std::string> &groups, std::vector<std::vector<uint8_t>> &group_ops, int &next_lane) {
+  LoweredPlan &p = L.p;
   int rc;
-  if (n_aggs == 0 && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate query requires at least one aggregate expression");
-  if (grouped && n_keys == 0) return L.fail(LLKV_INVALID_ARGUMENT, "GROUP BY requires at least one key");
-
-  std::string pred;
-  if ((rc = L.predicate(filters, n_filters, ops, n_ops, &pred))) return rc;
-  p.always_false = pred == "False";
-
-  // keys
-  std::string keys = "Keys<";
-  if (grouped) {
-    if (n_keys > (uint32_t)kMaxKeysHost) return L.fail(LLKV_UNSUPPORTED, "more than 4 GROUP BY keys");
-    uint64_t ng = 1;
-    std::string nodes;
-    for (uint32_t k = 0; k < n_keys; ++k) {
-      const ColumnInfo *ci;
-      int slot;
-      const ColumnInfo *probe = resolve(key_fields[k]);
-      if (!probe) return L.fail(LLKV_INVALID_ARGUMENT, "column '" + std::to_string(key_fields[k]) + "' not found in GROUP BY input");
-      if (probe->dtype == LLKV_DT_FLOAT64 || probe->dtype == LLKV_DT_FLOAT32 || probe->dtype == LLKV_DT_DECIMAL128)
-        return L.fail(LLKV_INVALID_ARGUMENT, std::string("GROUP BY does not support column type ") + dtype_name(probe->dtype));
-      // GroupKeyValue (llkv-executor/src/lib.rs:99-106, 9362-9456): Utf8 → String, every integer width and
-      // Date32 → Int.  Dense ids come from the dictionary code, or from value − column minimum for
-      // integer columns whose staging statistics bound the range.
-      const bool int_key = probe->dtype == LLKV_DT_INT64 || probe->dtype == LLKV_DT_INT32 || probe->dtype == LLKV_DT_DATE32;
-      if (probe->dtype != LLKV_DT_UTF8 && !int_key) return L.fail(LLKV_UNSUPPORTED, std::string("dense GROUP BY over ") + dtype_name(probe->dtype));
-
-      if (int_key) {
-        if (!probe->has_stats) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key without column statistics (hash path)");
-        const unsigned __int128 range = (unsigned __int128)((__int128)probe->max_i - (__int128)probe->min_i) + 1;
-        if (range > 256) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key spans more than 256 values (hash path)");
-      }
-      if ((rc = L.slot_of(key_fields[k], &ci, &slot))) return rc;
-      uint32_t card;
-      std::string node;
-      if (int_key) {
-        card = (uint32_t)((__int128)ci->max_i - (__int128)ci->min_i + 1);
-        std::string base;
-        if ((rc = L.lit_i(ci->min_i, &base))) return rc;
-        node = "KeyInt<" + std::to_string(slot) + "," + dtype_tag(ci->dtype) + "," + base + ">";
-      } else {
-        card = (uint32_t)(ci->dictionary.empty() ? 1 : ci->dictionary.size());
-        node = "KeyCode<" + std::to_string(slot) + ">";
-      }
-      // GroupKeyValue::Null is a group of its own (llkv-executor/src/lib.rs:99-106,9362-9456): one more code
-      std::string kv;
-      if ((rc = L.valid_of_field(key_fields[k], &kv))) return rc;
-      if (!kv.empty()) { node = "KeyOrNull<" + kv + "," + node + "," + std::to_string(card) + ">"; card += 1; }
-      p.key_nullable.push_back(kv.empty() ? 0 : 1);
-      nodes += "," + node;
-      p.key_fields.push_back(key_fields[k]);
-      p.key_slots.push_back((uint32_t)slot);
-      p.key_cards.push_back(card);
-      p.key_bases.push_back(int_key ? ci->min_i : 0);
-      p.key_is_int.push_back(int_key ? 1 : 0);
-      ng *= card;
-    }
-    if (ng > kMaxDenseGroups) return L.fail(LLKV_UNSUPPORTED, "more than 64 dense groups (" + std::to_string(ng) + ")");
-    p.ng = (uint32_t)ng;
-    p.key_strides.assign(n_keys, 1);
-    for (int k = (int)n_keys - 2; k >= 0; --k) p.key_strides[k] = p.key_strides[k + 1] * p.key_cards[k + 1];
-    keys += std::to_string(p.ng) + "," + (track_first ? "1" : "0") + nodes + ">";
-  } else {
-    p.ng = 1;
-    keys += "1,0>";
-  }
-
-  // aggregates → deduplicated lane groups
-  const int base = (grouped && track_first) ? 2 : 1;
-  std::vector<std::string> groups; // lane-group node strings
   std::vector<int> group_lane;     // first lane (relative to base) of each lane group
-  std::vector<std::vector<uint8_t>> group_ops;
-  int next_lane = 0;
   auto add_group = [&](const std::string &node, std::vector<uint8_t> lane_ops) -> int {
     for (size_t i = 0; i < groups.size(); ++i) if (groups[i] == node) return group_lane[i];
     groups.push_back(node);
@@ -810,6 +736,91 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     p.aggs.push_back(o);
   }
 
+  return LLKV_OK;
+}
+
+int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
+               const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  LoweredPlan &p = *out;
+  Lowering L{resolve, p, err, grouped};
+  p.grouped = grouped;
+  int rc;
+  if (n_aggs == 0 && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate query requires at least one aggregate expression");
+  if (grouped && n_keys == 0) return L.fail(LLKV_INVALID_ARGUMENT, "GROUP BY requires at least one key");
+
+  std::string pred;
+  if ((rc = L.predicate(filters, n_filters, ops, n_ops, &pred))) return rc;
+  p.always_false = pred == "False";
+
+  // keys
+  std::string keys = "Keys<";
+  if (grouped) {
+    if (n_keys > (uint32_t)kMaxKeysHost) return L.fail(LLKV_UNSUPPORTED, "more than 4 GROUP BY keys");
+    uint64_t ng = 1;
+    std::string nodes;
+    for (uint32_t k = 0; k < n_keys; ++k) {
+      const ColumnInfo *ci;
+      int slot;
+      const ColumnInfo *probe = resolve(key_fields[k]);
+      if (!probe) return L.fail(LLKV_INVALID_ARGUMENT, "column '" + std::to_string(key_fields[k]) + "' not found in GROUP BY input");
+      if (probe->dtype == LLKV_DT_FLOAT64 || probe->dtype == LLKV_DT_FLOAT32 || probe->dtype == LLKV_DT_DECIMAL128)
+        return L.fail(LLKV_INVALID_ARGUMENT, std::string("GROUP BY does not support column type ") + dtype_name(probe->dtype));
+      // GroupKeyValue (llkv-executor/src/lib.rs:99-106, 9362-9456): Utf8 → String, every integer width and
+      // Date32 → Int.  Dense ids come from the dictionary code, or from value − column minimum for
+      // integer columns whose staging statistics bound the range.
+      const bool int_key = probe->dtype == LLKV_DT_INT64 || probe->dtype == LLKV_DT_INT32 || probe->dtype == LLKV_DT_DATE32;
+      if (probe->dtype != LLKV_DT_UTF8 && !int_key) return L.fail(LLKV_UNSUPPORTED, std::string("dense GROUP BY over ") + dtype_name(probe->dtype));
+
+      if (int_key) {
+        if (!probe->has_stats) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key without column statistics (hash path)");
+        const unsigned __int128 range = (unsigned __int128)((__int128)probe->max_i - (__int128)probe->min_i) + 1;
+        if (range > 256) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key spans more than 256 values (hash path)");
+      }
+      if ((rc = L.slot_of(key_fields[k], &ci, &slot))) return rc;
+      uint32_t card;
+      std::string node;
+      if (int_key) {
+        card = (uint32_t)((__int128)ci->max_i - (__int128)ci->min_i + 1);
+        std::string base;
+        if ((rc = L.lit_i(ci->min_i, &base))) return rc;
+        node = "KeyInt<" + std::to_string(slot) + "," + dtype_tag(ci->dtype) + "," + base + ">";
+      } else {
+        card = (uint32_t)(ci->dictionary.empty() ? 1 : ci->dictionary.size());
+        node = "KeyCode<" + std::to_string(slot) + ">";
+      }
+      // GroupKeyValue::Null is a group of its own (llkv-executor/src/lib.rs:99-106,9362-9456): one more code
+      std::string kv;
+      if ((rc = L.valid_of_field(key_fields[k], &kv))) return rc;
+      if (!kv.empty()) { node = "KeyOrNull<" + kv + "," + node + "," + std::to_string(card) + ">"; card += 1; }
+      p.key_nullable.push_back(kv.empty() ? 0 : 1);
+      nodes += "," + node;
+      p.key_fields.push_back(key_fields[k]);
+      p.key_slots.push_back((uint32_t)slot);
+      p.key_cards.push_back(card);
+      p.key_bases.push_back(int_key ? ci->min_i : 0);
+      p.key_is_int.push_back(int_key ? 1 : 0);
+      ng *= card;
+    }
+    if (ng > kMaxDenseGroups) return L.fail(LLKV_UNSUPPORTED, "more than 64 dense groups (" + std::to_string(ng) + ")");
+    p.ng = (uint32_t)ng;
+    p.key_strides.assign(n_keys, 1);
+    for (int k = (int)n_keys - 2; k >= 0; --k) p.key_strides[k] = p.key_strides[k + 1] * p.key_cards[k + 1];
+    keys += std::to_string(p.ng) + "," + (track_first ? "1" : "0") + nodes + ">";
+  } else {
+    p.ng = 1;
+    keys += "1,0>";
+  }
+
+  // aggregates → deduplicated lane groups
+  const int base = (grouped && track_first) ? 2 : 1;
+  std::vector<std::string> groups; // lane-group node strings
+  std::vector<std::vector<uint8_t>> group_ops;
+  int next_lane = 0;
+  if ((rc = lower_aggregates(L, resolve, aggs, n_aggs, grouped, groups, group_ops, next_lane))) return rc;
+  enum { ADD_F64 = 0, ADD_I64 = 1, MIN_I64 = 2, MAX_I64 = 3, MAX_U64 = 4 };
+
   p.k = base + next_lane;
   p.lanes = (int)p.ng * p.k + 1;
   p.lane_ops.clear();
@@ -854,6 +865,27 @@ static std::string cols_string(const LoweredPlan &p, uint64_t *bytes) {
   }
   if (bytes) *bytes = b;
   return cols + ">";
+}
+
+int lower_reduce(const ColumnResolver &resolve, const llkv_aggregate_spec *aggs, uint32_t n_aggs, LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  LoweredPlan &p = *out;
+  Lowering L{resolve, p, err, true};
+  p.grouped = true;
+  p.track_first = true;
+  std::vector<std::string> groups;
+  std::vector<std::vector<uint8_t>> group_ops;
+  int next_lane = 0, rc;
+  if ((rc = lower_aggregates(L, resolve, aggs, n_aggs, true, groups, group_ops, next_lane))) return rc;
+  p.ng = 1;
+  p.k = 2 + next_lane;
+  p.lanes = p.k;
+  p.lane_ops = {1 /*ADD_I64 rows*/, 2 /*MIN_I64 first row*/};
+  for (auto &go : group_ops) for (uint8_t op : go) p.lane_ops.push_back(op);
+  std::string ag = "Aggs<";
+  for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
+  p.type_string = "ReducePlan<" + cols_string(p, &p.bytes_per_row) + "," + ag + ">>";
+  return LLKV_OK;
 }
 
 int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,

@@ -116,6 +116,11 @@ int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint3
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err);
 
+// Aggregates of a sort-based GROUP BY (any number of groups, any state width): "ReducePlan<Cols<…>,Aggs<…>>",
+// one wave per group over the group's rows (select.hip.h: group_reduce_body).  Lane layout per group:
+// [rows][first row id][aggregate lanes…]; GROUP BY (PlanValue) argument semantics.
+int lower_reduce(const ColumnResolver &resolve, const llkv_aggregate_spec *aggs, uint32_t n_aggs, LoweredPlan *out, std::string *err);
+
 // Typed literal cast used by leaf predicates (shared with the selection path).
 struct NativeLit {
   bool is_float = false, is_unsigned = false;

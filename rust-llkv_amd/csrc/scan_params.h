@@ -83,6 +83,21 @@ struct ProjParams {
 };
 
 
+// Arguments of the group-reduce kernel of the sort-based GROUP BY: one wave per group over the group's segment
+// of the sorted selection.
+struct ReduceParams {
+  const void *col[kMaxCols];
+  const uint32_t *perm;      // sorted position → index into the selection arrays
+  const uint64_t *dev_rows;  // selection: device row index
+  const uint64_t *row_ids;   // selection: logical row id
+  const uint64_t *seg_start; // [n_groups + 1] segment bounds in sorted positions
+  uint64_t *out;             // [n_groups][K] lanes: rows, first row id, aggregate lanes
+  uint32_t *error_flag;
+  int64_t lit_i[kMaxLits];
+  double lit_f[kMaxLits];
+  uint64_t n_groups;
+};
+
 // Arguments of the standalone fold_octants_kernel.
 struct FoldParams {
   const uint64_t *tile_partials; // [lanes][n_tiles]

@@ -214,12 +214,13 @@ template <class Ty> __device__ __forceinline__ void load_one(const void *base, u
     w[0] = *reinterpret_cast<const uint8_t *>(static_cast<const char *>(base) + row);
   }
 }
-template <class CL, int I = 0> __device__ __forceinline__ void gather_all(const ProjParams &p, uint64_t row, Loaded &ld) {
+template <class CL, int I = 0> __device__ __forceinline__ void gather_cols(const void *const *col, uint64_t row, Loaded &ld) {
   if constexpr (I < CL::N) {
-    load_one<typename ColAt<I, CL>::type>(p.col[I], row, ld.w[I]);
-    gather_all<CL, I + 1>(p, row, ld);
+    load_one<typename ColAt<I, CL>::type>(col[I], row, ld.w[I]);
+    gather_cols<CL, I + 1>(col, row, ld);
   }
 }
+template <class CL> __device__ __forceinline__ void gather_all(const ProjParams &p, uint64_t row, Loaded &ld) { gather_cols<CL>(p.col, row, ld); }
 // Output with NULLs: the value (arithmetic errors under a NULL do not count — arrow skips NULL slots) and one
 // validity bit per row, packed per wave with a ballot into the Arrow bitmap of the window (bit k of word w =
 // row 64·w + k; lane order = row order).
@@ -265,6 +266,59 @@ template <class P> __device__ __forceinline__ void project_body(const ProjParams
   Ctx c{sp, ld, 0u, row};
   StoreOuts<typename P::OutT>::run(pp, c, i);
   if (c.err) atomicOr(pp.error_flag, 1u);
+}
+
+// ---- sort-based GROUP BY: per-group reduction -------------------------------------------------------
+// Rows of a group are contiguous in the sorted selection (stable sort: row order inside a group).  One wave
+// per group: lane l takes the group's elements l, l + 64, … (row order within a lane), then the 64 partial
+// states are combined by a fixed butterfly — deterministic, exact for integer lanes, a fixed association for
+// f64 sums.  Lanes: [0] rows, [1] first row id, then the aggregates' lanes (same layout and host finalize as
+// the dense GROUP BY kernel).
+template <class CL, class AG> struct ReducePlan {
+  using ColList = CL;
+  using AggT = AG;
+  static constexpr int K = 2 + AG::N;
+};
+template <class P> constexpr int reduce_lane_op(int k) { return k == 0 ? OP_ADD_I64 : k == 1 ? OP_MIN_I64 : AggOps<typename P::AggT>::op(k - 2); }
+
+template <class P> __device__ __forceinline__ void group_reduce_body(const ReduceParams &rp) {
+  constexpr int K = P::K;
+  const uint64_t g = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (g >= rp.n_groups) return;
+  ScanParams sp; // the expression types read literals through a ScanParams-shaped context
+#pragma unroll
+  for (int k = 0; k < kMaxLits; ++k) { sp.lit_i[k] = rp.lit_i[k]; sp.lit_f[k] = rp.lit_f[k]; }
+  uint64_t acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = lane_identity(reduce_lane_op<P>(k));
+  uint32_t err = 0;
+  const uint64_t b = rp.seg_start[g], e = rp.seg_start[g + 1];
+  for (uint64_t i = b + lane; i < e; i += 64) {
+    const uint32_t s = rp.perm[i];
+    Loaded ld;
+    gather_cols<typename P::ColList>(rp.col, rp.dev_rows[s], ld);
+    Ctx c{sp, ld, 0u, rp.row_ids[s]};
+    uint64_t contrib[K];
+    contrib[0] = 1;
+    contrib[1] = c.row;
+    AggOps<typename P::AggT>::contrib(c, 0, contrib + 2);
+    err |= c.err;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = lane_combine(reduce_lane_op<P>(k), acc[k], contrib[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    uint64_t v = acc[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { // partner order is fixed: (l, l^1), then pairs of pairs, …
+      const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+      // combine(lower lane's value, upper lane's value): every lane of a pair computes the same result
+      v = (lane & o) ? lane_combine(reduce_lane_op<P>(k), other, v) : lane_combine(reduce_lane_op<P>(k), v, other);
+    }
+    if (lane == 0) rp.out[g * K + k] = v;
+  }
+  if (__ballot(err != 0) && lane == 0) atomicOr(rp.error_flag, 1u);
 }
 
 } // namespace llkv

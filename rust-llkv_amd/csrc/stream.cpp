@@ -38,6 +38,15 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
   LoweredPlan plan;
   std::string err;
   if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, drop_null_fields, n_drop_null_fields, &plan, &err))) return set_error(rc, err);
+  return run_selection_lowered(t, plan, sel);
+}
+
+// The selection kernels of an already lowered predicate (prepared statements keep the plan).
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel) {
+  int rc;
+  std::string err;
+  scratch_free(sel->d_ids); sel->d_ids = nullptr;
+  scratch_free(sel->d_dev); sel->d_dev = nullptr;
   sel->n = 0;
   if (plan.always_false || t->local_rows == 0) return LLKV_OK;
   const TileSet *ts = nullptr;

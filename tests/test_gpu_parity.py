@@ -553,6 +553,52 @@ def test_decimal128_accumulators_match_oracle(rt, orc, abi, chunks):
     assert e.value.kind == "Unsupported"
 
 
+@pytest.mark.parametrize("chunks", [[13], [4096, 4097, 5], [65536, 70000, 65536]])
+def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks):
+    """GROUP BY shapes the dense LDS kernel cannot hold — thousands of groups, sparse or unbounded integer keys,
+    several keys, wide aggregate states — go through the sort-based route: same groups, same first-appearance /
+    key order, exact integer results, f64 sums within 1e-9."""
+    rng = np.random.default_rng(3 + len(chunks))
+    n = sum(chunks)
+    k_sparse = (rng.integers(0, 3000, size=n) * 1_000_003 - 10**9).astype(np.int64)   # ≤ 3000 groups, huge range
+    k_date = rng.integers(8000, 8400, size=n).astype(np.int32)                          # 400 groups: range > 256
+    k_u32 = rng.integers(0, 7, size=n).astype(np.uint32)
+    k_tag = [("x", "y", "zz", "")[k] for k in rng.integers(0, 4, size=n)]
+    i64 = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    f64 = rng.integers(-4000, 4000, size=n).astype(np.float64) / 8
+    f64[rng.random(n) < 0.01] = np.nan
+    vk, va = rng.random(n) > 0.1, rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, k_sparse), (2, abi.DT_DATE32, k_date, vk), (3, abi.DT_UINT32, k_u32), (4, abi.DT_UTF8, k_tag, vk),
+                                       (5, abi.DT_INT64, i64, va), (6, abi.DT_FLOAT64, f64)], chunks)
+    A, F, O, E, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.Expr, abi.col
+    narrow = [A.count_star(), A.sum(5), A.max(6)]
+    wide = [A.count_star(), A.count(5), A.count_nulls(5), A.sum(5), A.avg(5), A.min(5), A.max(5), A.total(5), A.sum(6), A.avg(6), A.min(6), A.max(6),
+            A.sum(col(5) * col(6)), A.sum(col(5) * 3 - col(5)), A.total(6)]
+    cases = [([1], narrow), ([2], narrow), ([1, 3], narrow), ([2, 4], narrow), ([4, 2, 3], narrow), ([3], wide), ([4], wide), ([2, 3], wide)]
+    preds = [None, [F(5, O.GreaterThan(0))], E.not_(E.any_of([F(6, O.LessThan(0.0)), F(3, O.Equals(2))]))]
+    for keys, aggs in cases:
+        for pred in preds if len(chunks) < 3 else preds[:2]:
+            for order in (True, False):
+                got, exp = rt.groupby(ht, pred, keys, aggs, order), orc.groupby(ot, pred, keys, aggs, order)
+                assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp], (keys, order)
+                for g, w in zip(got, exp):
+                    assert_values(g.values, w.values, f"sorted group by {keys}")
+    # float and decimal keys are refused like the reference; no match → no groups
+    with pytest.raises(abi.LlkvError) as e:
+        rt.groupby(ht, None, [6, 1], narrow, True)
+    assert e.value.kind == "InvalidArgumentError"
+    assert rt.groupby(ht, [F(5, O.GreaterThan(10**6))], [1], wide, True) == []
+    # an Int64 sum that leaves the range fails the query on both sides (PlanValue arguments go through f64 first)
+    kinds = []
+    for m, t in ((rt, ht), (orc, ot)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.groupby(t, None, [3], [A.sum(col(1) * 2**40 * 2**20)] + wide, True)
+        kinds.append((e.value.kind, e.value.message))
+    # (when only a prefix of the chain can overflow the GPU route hands the query back instead of guessing)
+    assert kinds[1][0] == "InvalidArgumentError" and "integer overflow" in kinds[1][1]
+    assert kinds[0][0] in ("InvalidArgumentError", "Unsupported")
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 
@@ -876,13 +922,13 @@ def test_integer_and_multi_key_group_by(rt, orc, abi, tpch):
     for keys, pred, aggs in (([4], None, wide), ([4, 9], [F(5, O.LessThan(30))], narrow), ([20], None, wide),
                              ([9, 20], [F(6, O.GreaterThan(20000.0))], narrow[:1] + [A.sum(5)])):
         for ordered in (True, False):
-            if not ordered and len(keys) == 2 and keys == [9, 20]:
-                continue  # 27 groups × 3 lanes + first-row lane exceeds the image
             got, want = rt.groupby(ht, pred, keys, aggs, ordered), orc.groupby(ot, pred, keys, aggs, ordered)
             assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (keys, ordered)
             for g, w in zip(got, want):
                 assert_values(g.values, w.values, str(keys))
-    for keys, aggs in (([5, 4, 20], [A.count_star()]), ([4, 9], wide)):  # 50·7·9 groups / 21 groups × 7 lanes: hash path, not built
-        with pytest.raises(abi.LlkvError) as e:
-            rt.groupby(ht, None, keys, aggs)
-        assert e.value.kind == "Unsupported"
+    for keys, aggs in (([5, 4, 20], [A.count_star()]), ([4, 9], wide)):  # 50·7·9 groups / 21 groups × 7 lanes: the sort-based route
+        for ordered in (True, False):
+            got, want = rt.groupby(ht, None, keys, aggs, ordered), orc.groupby(ot, None, keys, aggs, ordered)
+            assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (keys, ordered)
+            for g, w in zip(got, want):
+                assert_values(g.values, w.values, str(keys))
