@@ -391,7 +391,7 @@ int Query::flush_pending() {
 int Query::launch(hipStream_t stream) {
   if (sorted) { // the sort-based route runs to completion here; submit / collect only hand the result over
     if (n_launched != n_collected) return set_error(LLKV_INVALID_ARGUMENT, "a sort-based GROUP BY keeps one execution in flight");
-    const int rc = sorted_groupby_run(sorted, &groups);
+    const int rc = sorted_groupby_run(sorted, &lazy);
     if (rc) return rc;
     n_launched++;
     return LLKV_OK;
@@ -1134,12 +1134,32 @@ llkv_status llkv_hip_query_collect(llkv_hip_query *query) {
   return (llkv_status) reinterpret_cast<Query *>(query)->collect();
 }
 
-uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->groups.size() : 0; }
+uint32_t llkv_hip_query_num_groups(const llkv_hip_query *query) {
+  if (!query) return 0;
+  const Query *q = reinterpret_cast<const Query *>(query);
+  return q->lazy.active ? (uint32_t)q->lazy.n : (uint32_t)q->groups.size();
+}
 uint32_t llkv_hip_query_num_keys(const llkv_hip_query *query) { return query ? (uint32_t) reinterpret_cast<const Query *>(query)->n_user_keys : 0; }
 uint32_t llkv_hip_query_num_aggregates(const llkv_hip_query *query) { return query ? reinterpret_cast<const Query *>(query)->n_user_aggs : 0; }
 
 llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group, uint32_t key, llkv_value *out) {
   const Query *q = reinterpret_cast<const Query *>(query);
+  if (q && out && q->lazy.active) { // sort-based route: decode the cell on request
+    const LazyGroups &lz = q->lazy;
+    if (group >= lz.n || key >= lz.n_keys) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/key index out of range");
+    std::memset(out, 0, sizeof *out);
+    const ColumnInfo *ci = lz.key_cols[key];
+    const int64_t v = lz.key_vals[(size_t)key * lz.n + group];
+    out->is_null = lz.key_valid[(size_t)key * lz.n + group] ? 0 : 1;
+    if (ci->dtype == LLKV_DT_UTF8) {
+      out->dtype = LLKV_DT_UTF8;
+      out->str = (!out->is_null && (uint64_t)v < ci->dictionary.size()) ? ci->dictionary[(size_t)v].c_str() : "";
+    } else {
+      out->dtype = LLKV_DT_INT64;
+      out->i64 = out->is_null ? 0 : v;
+    }
+    return LLKV_OK;
+  }
   if (!q || !out || group >= q->groups.size() || key >= q->groups[group].keys.size())
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/key index out of range");
   std::memset(out, 0, sizeof *out);
@@ -1152,6 +1172,13 @@ llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group
 
 llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, uint32_t agg, llkv_value *out) {
   const Query *q = reinterpret_cast<const Query *>(query);
+  if (q && out && q->lazy.active) {
+    const LazyGroups &lz = q->lazy;
+    if (group >= lz.n || agg >= lz.plan->aggs.size()) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/aggregate index out of range");
+    std::string err;
+    const int rc = finalize_value(lz.plan->aggs[agg], lz.lanes + (size_t)group * lz.k, 2, out, &err, false);
+    return rc ? (llkv_status)set_error(rc, err) : LLKV_OK;
+  }
   if (!q || !out || group >= q->groups.size() || agg >= q->groups[group].values.size())
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/aggregate index out of range");
   *out = q->groups[group].values[agg];

@@ -101,16 +101,31 @@ struct GroupResult {
   std::vector<llkv_value> values;
 };
 
+// Result of a sort-based GROUP BY, kept as the arrays the device produced (already in output order, pinned host
+// memory) and finalized cell by cell on request: millions of groups cost no per-group host objects.
+struct LazyGroups {
+  bool active = false;
+  uint64_t n = 0;
+  int k = 0;                       // lanes per group: rows, first row id, aggregate lanes
+  uint32_t n_keys = 0;
+  const uint64_t *lanes = nullptr; // [n][k]
+  const int64_t *key_vals = nullptr;   // [n_keys][n] raw key cells (dictionary code / integer)
+  const uint8_t *key_valid = nullptr;  // [n_keys][n]
+  const LoweredPlan *plan = nullptr;   // aggregate finalization
+  std::vector<const ColumnInfo *> key_cols;
+};
+
 // Sort-based GROUP BY (group_sort.cpp): any number of groups, any state width.
 struct SortedGroupBy;
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                            const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
                            bool order_by_keys, SortedGroupBy **out);
-int sorted_groupby_run(SortedGroupBy *s, std::vector<GroupResult> *groups);
+int sorted_groupby_run(SortedGroupBy *s, LazyGroups *out);
 void sorted_groupby_free(SortedGroupBy *s);
 
 struct Query {
   const Table *table = nullptr;
+  LazyGroups lazy;
   SortedGroupBy *sorted = nullptr; // set when the dense GROUP BY kernel cannot hold the groups: executions run synchronously in launch()
   LoweredPlan plan;
   const CatalogEntry *entry = nullptr;

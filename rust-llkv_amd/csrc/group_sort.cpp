@@ -13,6 +13,9 @@
 #include "join.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -33,10 +36,30 @@ struct SortedGroupBy {
   std::vector<uint32_t> key_fields;
   bool order_by_keys = false;
   JitKernel red_kernel;
-  int run(std::vector<GroupResult> *groups);
+  // result arrays of the latest execution, pinned host memory reused across executions
+  void *h_lanes = nullptr, *h_kv = nullptr, *h_kvalid = nullptr;
+  size_t cap_lanes = 0, cap_kv = 0, cap_kvalid = 0;
+  int run(LazyGroups *out);
+  ~SortedGroupBy() {
+    if (h_lanes) (void)hipHostFree(h_lanes);
+    if (h_kv) (void)hipHostFree(h_kv);
+    if (h_kvalid) (void)hipHostFree(h_kvalid);
+  }
 };
 
 void sorted_groupby_free(SortedGroupBy *s) { delete s; }
+
+namespace {
+int pinned_reserve(void **p, size_t *cap, size_t bytes) {
+  if (bytes <= *cap) return LLKV_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIP_TRY(hipHostMalloc(p, bytes + bytes / 4 + 64, hipHostMallocDefault));
+  *cap = bytes + bytes / 4 + 64;
+  return LLKV_OK;
+}
+} // namespace
 
 // Admission: GROUP BY shapes the dense kernel turned down for capacity reasons only.
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
@@ -96,19 +119,35 @@ int key_column_of(const Table *t, uint32_t field, JoinKeyColumn *kc, long long *
 }
 } // namespace
 
-int SortedGroupBy::run(std::vector<GroupResult> *groups) {
-  groups->clear();
+int SortedGroupBy::run(LazyGroups *out) {
+  *out = LazyGroups{};
+  out->active = true;
+  out->plan = &red_plan;
+  out->k = red_plan.k;
+  out->n_keys = (uint32_t)key_fields.size();
+  for (uint32_t f : key_fields) out->key_cols.push_back(&table->cols.at(f).info);
   hipStream_t s = g_ctx.stream;
   int rc;
+  // LLKV_HIP_TRACE=1: phase times on stderr (each mark synchronizes the stream)
+  const bool trace = std::getenv("LLKV_HIP_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[llkv group_sort] %-22s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   Selection sel;
   if ((rc = run_selection_lowered(table, sel_plan, &sel))) return rc;
   const uint64_t n = sel.n;
+  mark("selection");
   if (n == 0) return LLKV_OK;
   if (n >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "more than 2^32 selected rows in a sort-based GROUP BY");
   const uint32_t n_keys = (uint32_t)key_fields.size();
 
   // ---- sort the selection by the keys (LSD: last key first; every pass is stable) ------------------------
-  Scratch perm_a, perm_b, keys_a, keys_b, vkeys_a, vkeys_b, tmp;
+  Scratch perm_a, perm_b, keys_a, keys_b, vkeys_a, vkeys_b, tmp, rank_d;
   if ((rc = perm_a.alloc(n * 4)) || (rc = perm_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8))) return rc;
   HIP_TRY(hj_launch_iota(perm_a.as<uint32_t>(), (uint32_t)n, s));
   uint32_t *perm = perm_a.as<uint32_t>(), *perm_other = perm_b.as<uint32_t>();
@@ -119,7 +158,20 @@ int SortedGroupBy::run(std::vector<GroupResult> *groups) {
     long long base;
     uint32_t bits;
     if ((rc = key_column_of(table, key_fields[k], &ks.k[k], &base, &bits))) return rc;
-    HIP_TRY(hj_launch_gather_sort_keys(ks.k[k], base, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
+    const uint8_t *code_rank = nullptr;
+    const ColumnInfo &ci = table->cols.at(key_fields[k]).info;
+    if (order_by_keys && ci.dtype == LLKV_DT_UTF8) { // ORDER BY the key: codes sort as their strings do
+      std::vector<uint32_t> idx(ci.dictionary.size());
+      std::iota(idx.begin(), idx.end(), 0u);
+      std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ci.dictionary[a] < ci.dictionary[b]; });
+      uint8_t rank[256] = {0};
+      for (size_t r = 0; r < idx.size(); ++r) rank[idx[r]] = (uint8_t)r;
+      if ((rc = rank_d.alloc(256))) return rc;
+      HIP_TRY(hipMemcpyAsync(rank_d.p, rank, 256, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s)); // `rank` is a stack array
+      code_rank = rank_d.as<uint8_t>();
+    }
+    HIP_TRY(hj_launch_gather_sort_keys(ks.k[k], base, code_rank, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
     size_t tb = 0;
     HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, bits, s));
     if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
@@ -138,6 +190,7 @@ int SortedGroupBy::run(std::vector<GroupResult> *groups) {
     HIP_TRY(hipStreamSynchronize(s)); // tmp is reallocated by the next pass
   }
 
+  mark("key sorts");
   // ---- group boundaries → segment starts -----------------------------------------------------------------
   Scratch flags, offs, seg;
   if ((rc = flags.alloc((n + 1) * 8)) || (rc = offs.alloc((n + 1) * 8))) return rc;
@@ -154,8 +207,29 @@ int SortedGroupBy::run(std::vector<GroupResult> *groups) {
   HIP_TRY(hipStreamSynchronize(s));
   if ((rc = seg.alloc((n_groups + 1) * 8))) return rc;
   HIP_TRY(hj_launch_segment_starts(flags.as<uint64_t>(), offs.as<uint64_t>(), n, n_groups, seg.as<uint64_t>(), s));
+  mark("boundaries");
 
-  // ---- per-group reduction ---------------------------------------------------------------------------------
+  // ---- output order -----------------------------------------------------------------------------------------
+  // ORDER BY the keys: the segments already are in key order (NULLS FIRST).  Otherwise first appearance
+  // (llkv-executor/src/lib.rs:5065-5089): sort the segments by the row id of their first row.
+  Scratch first_d, first_s, ord_in, ord_out;
+  const uint32_t *order = nullptr;
+  if (!order_by_keys && n_groups > 1) {
+    if ((rc = first_d.alloc(n_groups * 8)) || (rc = first_s.alloc(n_groups * 8)) || (rc = ord_in.alloc(n_groups * 4)) || (rc = ord_out.alloc(n_groups * 4))) return rc;
+    HIP_TRY(hj_launch_first_rows(sel.d_ids, perm, seg.as<uint64_t>(), n_groups, first_d.as<uint64_t>(), s));
+    HIP_TRY(hj_launch_iota(ord_in.as<uint32_t>(), (uint32_t)n_groups, s));
+    uint32_t bits = 1;
+    while (bits < 64 && (table->total_rows >> bits) != 0) ++bits;
+    size_t tb = 0;
+    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_sort_u64_u32_bits(tmp.p, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
+    order = ord_out.as<uint32_t>();
+  }
+  mark("output order");
+
+  // ---- per-group reduction, written in output order ------------------------------------------------------------
   const LoweredPlan &rp = red_plan;
   const int K = rp.k;
   Scratch lanes_d, err_d, kv_d, kvalid_d;
@@ -171,54 +245,46 @@ int SortedGroupBy::run(std::vector<GroupResult> *groups) {
   p.dev_rows = sel.d_dev;
   p.row_ids = sel.d_ids;
   p.seg_start = seg.as<uint64_t>();
+  p.order = order;
   p.out = lanes_d.as<uint64_t>();
   p.error_flag = err_d.as<uint32_t>();
   p.n_groups = n_groups;
   const uint64_t waves_per_block = kBlock / 64;
   if ((rc = jit_launch_raw(red_kernel.fn, (uint32_t)((n_groups + waves_per_block - 1) / waves_per_block), &p, sizeof p, s))) return rc;
-  HIP_TRY(hj_launch_group_keys(ks, sel.d_dev, perm, seg.as<uint64_t>(), n_groups, kv_d.as<int64_t>(), kvalid_d.as<uint8_t>(), s));
+  HIP_TRY(hj_launch_group_keys(ks, sel.d_dev, perm, seg.as<uint64_t>(), order, n_groups, kv_d.as<int64_t>(), kvalid_d.as<uint8_t>(), s));
+  mark("group reduce");
 
-  std::vector<uint64_t> lanes(n_groups * (size_t)K);
-  std::vector<int64_t> kv(n_groups * n_keys);
-  std::vector<uint8_t> kvalid(n_groups * n_keys);
+  if ((rc = pinned_reserve(&h_lanes, &cap_lanes, n_groups * (size_t)K * 8)) || (rc = pinned_reserve(&h_kv, &cap_kv, n_groups * n_keys * 8)) ||
+      (rc = pinned_reserve(&h_kvalid, &cap_kvalid, n_groups * n_keys)))
+    return rc;
   uint32_t errflag = 0;
-  HIP_TRY(hipMemcpyAsync(lanes.data(), lanes_d.p, lanes.size() * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(kv.data(), kv_d.p, kv.size() * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(kvalid.data(), kvalid_d.p, kvalid.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_lanes, lanes_d.p, n_groups * (size_t)K * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_kv, kv_d.p, n_groups * n_keys * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_kvalid, kvalid_d.p, n_groups * n_keys, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(&errflag, err_d.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (errflag) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  mark("copy out");
 
-  // ---- host: keys, finalize, order ---------------------------------------------------------------------------
-  groups->resize(n_groups);
-  for (uint64_t g = 0; g < n_groups; ++g) {
-    GroupResult &gr = (*groups)[g];
-    const uint64_t *gl = &lanes[g * (size_t)K];
-    gr.first_row = gl[1];
-    gr.keys.resize(n_keys);
-    for (uint32_t k = 0; k < n_keys; ++k) {
-      const DeviceColumn &c = table->cols.at(key_fields[k]);
-      GroupKey &gk = gr.keys[k];
-      gk.is_int = c.info.dtype != LLKV_DT_UTF8;
-      gk.is_null = !kvalid[(size_t)k * n_groups + g];
-      if (gk.is_null) continue;
-      const int64_t v = kv[(size_t)k * n_groups + g];
-      if (gk.is_int) gk.i = v;
-      else gk.s = (uint64_t)v < c.info.dictionary.size() ? c.info.dictionary[(size_t)v] : std::string();
-    }
-    gr.values.resize(rp.aggs.size());
-    for (size_t a = 0; a < rp.aggs.size(); ++a) {
+  // ---- host: only the aggregates whose finalize can fail are visited now; cells are decoded on request ----------
+  const uint64_t *lanes = static_cast<const uint64_t *>(h_lanes);
+  for (size_t a = 0; a < rp.aggs.size(); ++a) {
+    if (rp.aggs[a].fin != AggFinal::SumI64 && rp.aggs[a].fin != AggFinal::AvgI64) continue;
+    for (uint64_t g = 0; g < n_groups; ++g) {
+      llkv_value v;
       std::string err;
       // a GROUP BY sum that may have overflowed in a prefix is handed back, as on the dense route
-      if ((rc = finalize_value(rp.aggs[a], gl, 2, &gr.values[a], &err, false))) return set_error(rc, err);
+      if ((rc = finalize_value(rp.aggs[a], lanes + g * (size_t)K, 2, &v, &err, false))) return set_error(rc, err);
     }
   }
-  // first-appearance order (llkv-executor/src/lib.rs:5065-5089), then ORDER BY keys ASC (NULLS FIRST)
-  std::sort(groups->begin(), groups->end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
-  if (order_by_keys) std::stable_sort(groups->begin(), groups->end(), [](const GroupResult &a, const GroupResult &b) { return a.keys < b.keys; });
+  out->n = n_groups;
+  out->lanes = lanes;
+  out->key_vals = static_cast<const int64_t *>(h_kv);
+  out->key_valid = static_cast<const uint8_t *>(h_kvalid);
+  mark("host checks");
   return LLKV_OK;
 }
 
-int sorted_groupby_run(SortedGroupBy *s, std::vector<GroupResult> *groups) { return s->run(groups); }
+int sorted_groupby_run(SortedGroupBy *s, LazyGroups *out) { return s->run(out); }
 
 } // namespace llkv

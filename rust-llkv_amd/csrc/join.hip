@@ -419,16 +419,18 @@ __device__ __forceinline__ bool key_cell(const JoinKeyColumn &k, uint64_t row, l
   } else *out = (long long)reinterpret_cast<const uint8_t *>(k.values)[row];
   return true;
 }
-__global__ __launch_bounds__(256) void hj_gather_sort_keys_kernel(JoinKeyColumn col, long long base, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys) {
+__global__ __launch_bounds__(256) void hj_gather_sort_keys_kernel(JoinKeyColumn col, long long base, const uint8_t *code_rank, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   long long v;
   const bool ok = key_cell(col, dev_rows[perm[i]], &v);
+  if (code_rank) v = code_rank[(uint8_t)v];
   keys[i] = ok ? (uint64_t)v - (uint64_t)base : 0ull;
 }
-hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys, hipStream_t s) {
+hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint8_t *code_rank, const uint64_t *dev_rows, const uint32_t *perm,
+                                      uint64_t n, uint64_t *keys, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_gather_sort_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, base, dev_rows, perm, n, keys);
+  hipLaunchKernelGGL(hj_gather_sort_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, base, code_rank, dev_rows, perm, n, keys);
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void hj_gather_valid_kernel(JoinKeyColumn col, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint32_t *out) {
@@ -469,11 +471,20 @@ hipError_t hj_launch_segment_starts(const uint64_t *flags, const uint64_t *offse
   hipLaunchKernelGGL(hj_segment_starts_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, flags, offsets, n, n_groups, seg_start);
   return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void hj_first_rows_kernel(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_groups) first_rows[g] = row_ids[perm[seg_start[g]]];
+}
+hipError_t hj_launch_first_rows(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows, hipStream_t s) {
+  if (n_groups == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_first_rows_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, s, row_ids, perm, seg_start, n_groups, first_rows);
+  return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void hj_group_keys_kernel(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start,
-                                                             uint64_t n_groups, int64_t *out_vals, uint8_t *out_valid) {
+                                                             const uint32_t *order, uint64_t n_groups, int64_t *out_vals, uint8_t *out_valid) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
-  const uint64_t row = dev_rows[perm[seg_start[g]]];
+  const uint64_t row = dev_rows[perm[seg_start[order ? order[g] : g]]];
   for (uint32_t k = 0; k < ks.n; ++k) {
     long long v;
     const bool ok = key_cell(ks.k[k], row, &v);
@@ -481,10 +492,10 @@ __global__ __launch_bounds__(256) void hj_group_keys_kernel(GroupKeySet ks, cons
     out_valid[(uint64_t)k * n_groups + g] = ok ? 1 : 0;
   }
 }
-hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups,
+hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, const uint32_t *order, uint64_t n_groups,
                                 int64_t *out_vals, uint8_t *out_valid, hipStream_t s) {
   if (n_groups == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_group_keys_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, s, ks, dev_rows, perm, seg_start, n_groups, out_vals, out_valid);
+  hipLaunchKernelGGL(hj_group_keys_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, s, ks, dev_rows, perm, seg_start, order, n_groups, out_vals, out_valid);
   return hipGetLastError();
 }
 hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,

@@ -106,7 +106,11 @@ hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const 
 // keys[i] = value − base (as u64) of column `col` at selected row perm[i]: order preserving when base is the
 // column minimum (statistics) or the type minimum (i64::MIN ⇔ flipping the sign bit); NULL cell → 0, told
 // apart by the validity pass.
-hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *keys, hipStream_t s);
+// `code_rank` (256 entries, or nullptr): dictionary code → rank of its string, so that code columns sort as strings.
+hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint8_t *code_rank, const uint64_t *dev_rows, const uint32_t *perm,
+                                      uint64_t n, uint64_t *keys, hipStream_t s);
+// first_rows[g] = logical row id of the first row of segment g (the stable sort keeps row order inside a group).
+hipError_t hj_launch_first_rows(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows, hipStream_t s);
 hipError_t hj_launch_gather_valid(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint32_t *out, hipStream_t s);
 struct GroupKeySet {
   JoinKeyColumn k[4];
@@ -117,7 +121,7 @@ hipError_t hj_launch_group_boundaries(GroupKeySet ks, const uint64_t *dev_rows, 
 // seg_start[offsets[i]] = i for every flagged i; seg_start[n_groups] = n.
 hipError_t hj_launch_segment_starts(const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t n_groups, uint64_t *seg_start, hipStream_t s);
 // Raw key cells of each group's first sorted row: out_vals[k][g] (sign-extended to i64), out_valid[k][g].
-hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups,
+hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, const uint32_t *order, uint64_t n_groups,
                                 int64_t *out_vals /*[n_keys][n_groups]*/, uint8_t *out_valid /*[n_keys][n_groups]*/, hipStream_t s);
 hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
                                 uint64_t n, uint32_t end_bit, hipStream_t s);

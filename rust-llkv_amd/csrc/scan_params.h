@@ -91,6 +91,7 @@ struct ReduceParams {
   const uint64_t *dev_rows;  // selection: device row index
   const uint64_t *row_ids;   // selection: logical row id
   const uint64_t *seg_start; // [n_groups + 1] segment bounds in sorted positions
+  const uint32_t *order;     // output position → segment (nullptr = identity): groups leave in their final order
   uint64_t *out;             // [n_groups][K] lanes: rows, first row id, aggregate lanes
   uint32_t *error_flag;
   int64_t lit_i[kMaxLits];

@@ -293,7 +293,8 @@ template <class P> __device__ __forceinline__ void group_reduce_body(const Reduc
 #pragma unroll
   for (int k = 0; k < K; ++k) acc[k] = lane_identity(reduce_lane_op<P>(k));
   uint32_t err = 0;
-  const uint64_t b = rp.seg_start[g], e = rp.seg_start[g + 1];
+  const uint64_t sg = rp.order ? rp.order[g] : g;
+  const uint64_t b = rp.seg_start[sg], e = rp.seg_start[sg + 1];
   for (uint64_t i = b + lane; i < e; i += 64) {
     const uint32_t s = rp.perm[i];
     Loaded ld;

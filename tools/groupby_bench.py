@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Sort-based GROUP BY at SF10 on one GPU: GROUP BY l_orderkey (≈15 M groups), l_partkey (2 M groups),
+l_shipdate (≈2500 groups) and the wide-state Q1 shape with every aggregate doubled — inputs resident in HBM."""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+abi = importlib.import_module("rust-llkv_amd.abi"); rt = importlib.import_module("rust-llkv_amd.runtime"); tpch = importlib.import_module("rust-llkv_amd.tpch")
+sf = sys.argv[1] if len(sys.argv) > 1 else "sf10"
+rt.init(0)
+rows, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
+cols = ["l_orderkey", "l_partkey", "l_shipdate", "l_quantity", "l_extendedprice", "l_discount", "l_returnflag", "l_linestatus"]
+li = tpch.gen_lineitem(rows, scale, cols)
+t = rt.HipTable(1, tpch.chunk_rows(rows))
+for c in cols:
+    fid, dt = tpch.LINEITEM_SCHEMA[c]
+    (t.append_utf8_column if dt == abi.DT_UTF8 else lambda f, v, d=dt: t.append_column(f, d, v))(fid, li[c])
+A, col = abi.AggregateSpec, abi.col
+S = tpch.LINEITEM_SCHEMA
+rev = col(S["l_extendedprice"][0]) * (1 - col(S["l_discount"][0]))
+narrow = [A.count_star(), A.sum(S["l_quantity"][0]), A.sum(rev)]
+wide = [A.count_star(), A.sum(S["l_quantity"][0]), A.avg(S["l_quantity"][0]), A.min(S["l_quantity"][0]), A.max(S["l_quantity"][0]), A.sum(S["l_extendedprice"][0]),
+        A.avg(S["l_extendedprice"][0]), A.min(S["l_extendedprice"][0]), A.max(S["l_extendedprice"][0]), A.sum(rev), A.avg(S["l_discount"][0]), A.total(S["l_discount"][0])]
+out = {}
+for name, keys, aggs in (("by_orderkey", [S["l_orderkey"][0]], narrow), ("by_partkey", [S["l_partkey"][0]], narrow), ("by_shipdate", [S["l_shipdate"][0]], narrow),
+                         ("q1_wide_state", [S["l_returnflag"][0], S["l_linestatus"][0]], wide)):
+    q = rt.PreparedQuery(t, None, aggs, keys, True)
+    ts = []
+    for i in range(3):
+        t0 = time.perf_counter(); q.launch(0); dt_launch = time.perf_counter() - t0  # device pipeline + host finalize of every group
+        ng = rt.lib().llkv_hip_query_num_groups(q._h)
+        check = rt.lib().llkv_hip_query_finish(q._h, None)
+        assert check == 0
+        ts.append(dt_launch)
+    out[name] = {"groups": int(ng), "seconds_best": min(ts), "rows_per_s": rows / min(ts)}
+print(json.dumps({"workload": f"groupby_{sf}", "rows": rows, **out}))
