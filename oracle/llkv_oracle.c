@@ -657,28 +657,30 @@ static arr cast_to(const arr *src, int32_t target) {
   return a;
 }
 
-/* One arrow-arith kernel call = one temporary array (fast_numeric.rs:312-356):
- * integers checked (overflow → error), floats IEEE; NULL in → NULL out.
- * `Divide` never reaches here on the fast path (:273-275); the generic path's
- * x/0 → NULL rule (kernels.rs:121-135) is applied for DIV and MOD. */
+/* One arrow-arith kernel call = one temporary array (fast_numeric.rs:312-356, kernels.rs:99-177):
+ * integers checked (overflow → error; `%` is mod_wrapping after a zero check → "Divide by zero"), floats IEEE (fmod for %); NULL in → NULL out,
+ * and a slot is only evaluated where both operands are valid.  Divide is never on the fast path (:273-275);
+ * on the generic path zeros of the divisor become NULLs first (kernels.rs:121-135), then arrow `div`
+ * (truncating, i64::MIN / -1 overflows). */
 static int32_t binary_kernel(const arr *l, const arr *r, int32_t op, arr *out) {
   arr a;
   memset(&a, 0, sizeof a);
   a.dtype = l->dtype;
   a.n = l->n;
-  a.valid = xmalloc(l->n);
-  a.values = xmalloc(l->n * 8);
+  a.valid = xmalloc(l->n ? l->n : 1);
+  a.values = xmalloc((l->n ? l->n : 1) * 8);
   for (uint64_t i = 0; i < l->n; ++i) {
     a.valid[i] = l->valid[i] && r->valid[i];
-    if (!a.valid[i]) { ((int64_t *)a.values)[i] = 0; continue; }
+    ((int64_t *)a.values)[i] = 0;
+    if (!a.valid[i]) continue;
     if (l->dtype == LLKV_DT_FLOAT64) {
       double x = ((double *)l->values)[i], y = ((double *)r->values)[i], z = 0;
       switch (op) {
       case LLKV_BIN_ADD: z = x + y; break;
       case LLKV_BIN_SUB: z = x - y; break;
       case LLKV_BIN_MUL: z = x * y; break;
-      case LLKV_BIN_DIV: if (y == 0.0) { a.valid[i] = 0; } else z = x / y; break;
-      case LLKV_BIN_MOD: if (y == 0.0) { a.valid[i] = 0; } else z = fmod(x, y); break;
+      case LLKV_BIN_DIV: if (y == 0.0) a.valid[i] = 0; else z = x / y; break; /* nullif(rhs == 0) */
+      case LLKV_BIN_MOD: z = fmod(x, y); break;
       }
       ((double *)a.values)[i] = z;
     } else {
@@ -689,9 +691,12 @@ static int32_t binary_kernel(const arr *l, const arr *r, int32_t op, arr *out) {
       case LLKV_BIN_SUB: ovf = __builtin_sub_overflow(x, y, &z); break;
       case LLKV_BIN_MUL: ovf = __builtin_mul_overflow(x, y, &z); break;
       case LLKV_BIN_DIV: if (y == 0) a.valid[i] = 0; else if (x == INT64_MIN && y == -1) ovf = 1; else z = x / y; break;
-      case LLKV_BIN_MOD: if (y == 0) a.valid[i] = 0; else if (y == -1) z = 0; else z = x % y; break;
+      case LLKV_BIN_MOD:
+        if (y == 0) { arr_free(&a); return fail(LLKV_INTERNAL, "Divide by zero"); }
+        z = y == -1 ? 0 : x % y; /* mod_wrapping: i64::MIN % -1 = 0 */
+        break;
       }
-      if (ovf) { arr_free(&a); return fail(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened on: %lld %s %lld", (long long)x, op == LLKV_BIN_ADD ? "+" : op == LLKV_BIN_SUB ? "-" : op == LLKV_BIN_MUL ? "*" : "/", (long long)y); }
+      if (ovf) { arr_free(&a); return fail(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened on: %lld %s %lld", (long long)x, op == LLKV_BIN_ADD ? "+" : op == LLKV_BIN_SUB ? "-" : op == LLKV_BIN_MUL ? "*" : op == LLKV_BIN_DIV ? "/" : "%", (long long)y); }
       ((int64_t *)a.values)[i] = z;
     }
   }
@@ -723,6 +728,50 @@ static int32_t eval_program(const orc_table *t, const llkv_expr_token *e, uint32
   arr st[64];
   uint32_t sp = 0;
   rc = LLKV_OK;
+  if (has_div) {
+    /* Generic route (try_evaluate_vectorized eval.rs:616-665 → compute_binary kernels.rs:99-177): every Binary
+     * node coerces its own operands to their common type.  Restated for Int64 / Float64 operands. */
+    for (uint32_t i = 0; i < n_tok && rc == LLKV_OK; ++i) {
+      switch (e[i].kind) {
+      case LLKV_TOK_COLUMN: {
+        const arr *src = find_gathered(g, n_g, e[i].field_id);
+        if (!src) { rc = fail(LLKV_INTERNAL, "missing column for field"); break; }
+        if (src->dtype != LLKV_DT_INT64 && src->dtype != LLKV_DT_FLOAT64) { rc = fail(LLKV_UNSUPPORTED, "division over %s operands", dtype_name(src->dtype)); break; }
+        st[sp++] = cast_to(src, src->dtype);
+        break;
+      }
+      case LLKV_TOK_LITERAL: {
+        const llkv_literal *l = &e[i].literal;
+        if (l->tag != LLKV_LIT_INT128 && l->tag != LLKV_LIT_FLOAT64) { rc = fail(LLKV_UNSUPPORTED, "literal kind in a computed projection"); break; }
+        arr a;
+        memset(&a, 0, sizeof a);
+        a.dtype = l->tag == LLKV_LIT_FLOAT64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64; a.n = len; a.valid = xmalloc(len ? len : 1); a.values = xmalloc((len ? len : 1) * 8);
+        for (uint64_t k = 0; k < len; ++k) {
+          a.valid[k] = 1;
+          if (a.dtype == LLKV_DT_FLOAT64) ((double *)a.values)[k] = l->f64; else ((int64_t *)a.values)[k] = (int64_t)lit_i128(l); /* `*i as i64` */
+        }
+        st[sp++] = a;
+        break;
+      }
+      case LLKV_TOK_BINARY: {
+        arr r = st[--sp], l = st[--sp], z;
+        if (l.dtype != r.dtype) { /* Int64 ⊕ Float64 → Float64 */
+          arr *ia = l.dtype == LLKV_DT_INT64 ? &l : &r;
+          arr c = cast_to(ia, LLKV_DT_FLOAT64);
+          arr_free(ia);
+          *ia = c;
+        }
+        rc = binary_kernel(&l, &r, e[i].binop, &z);
+        arr_free(&l); arr_free(&r);
+        if (rc == LLKV_OK) st[sp++] = z;
+        break;
+      }
+      }
+    }
+    if (rc != LLKV_OK) { for (uint32_t i = 0; i < sp; ++i) arr_free(&st[i]); return rc; }
+    *out = st[0];
+    return LLKV_OK;
+  }
   for (uint32_t i = 0; i < n_tok && rc == LLKV_OK; ++i) {
     switch (e[i].kind) {
     case LLKV_TOK_COLUMN: {

@@ -621,8 +621,8 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
   std::vector<uint64_t> state(p.lanes);
   fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
   groups.clear();
-  if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic overflowed on a selected row
-    return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic failed on a selected row
+    return set_error(LLKV_INTERNAL, arith_error_message(state[(size_t)p.ng * p.k]));
   const int base = p.track_first ? 2 : 1;
   for (uint32_t g = 0; g < p.ng; ++g) {
     const uint64_t *gl = &state[(size_t)g * p.k];

@@ -115,6 +115,12 @@ struct LazyGroups {
   std::vector<const ColumnInfo *> key_cols;
 };
 
+// Message of a device-side arithmetic error code (fused_scan.hip.h: kErrOverflow = 1, kErrDivZero = 2), as the
+// reference's arrow kernels word it (Error::Internal).
+inline const char *arith_error_message(uint64_t code) {
+  return (code & 2u) ? "Divide by zero" : "Arithmetic overflow: Overflow happened in a computed projection";
+}
+
 // Sort-based GROUP BY (group_sort.cpp): any number of groups, any state width.
 struct SortedGroupBy;
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,

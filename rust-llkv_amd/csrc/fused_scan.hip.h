@@ -151,33 +151,48 @@ struct Ctx {
 // a type).  The host lowering inserts the casts the reference performs: every column
 // is cast to the program's final type first (fast_numeric.rs:80-87).
 // --------------------------------------------------------------------------
+// Every expression node also answers `valid`: is the value non-NULL in this row?  NULL propagates through
+// arithmetic, a division by zero yields NULL (llkv-compute/src/kernels.rs:121-135), and arrow's checked kernels
+// evaluate a node only where its operands are valid — so a node raises its arithmetic error only there.
 template <int S, class Ty> struct Col {
   using Type = Ty;
   static __device__ __forceinline__ typename Ty::T eval(Ctx &c, int j) { return c.get<Ty>(S, j); }
+  static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
+};
+template <int S, class Ty, int SV> struct ColN { // column with NULL cells: validity mask in slot SV
+  using Type = Ty;
+  static __device__ __forceinline__ typename Ty::T eval(Ctx &c, int j) { return c.get<Ty>(S, j); }
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return c.get<U8>(SV, j) != 0; }
 };
 template <int K> struct LitI {
   using Type = I64;
   static __device__ __forceinline__ int64_t eval(Ctx &c, int) { return c.p.lit_i[K]; }
+  static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
 };
 template <int K> struct LitU {
   using Type = U64;
   static __device__ __forceinline__ uint64_t eval(Ctx &c, int) { return (uint64_t)c.p.lit_i[K]; }
+  static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
 };
 template <int K> struct LitF {
   using Type = F64;
   static __device__ __forceinline__ double eval(Ctx &c, int) { return c.p.lit_f[K]; }
+  static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
 };
 template <class E> struct ToF64 { // arrow cast int → f64 / f32 → f64
   using Type = F64;
   static __device__ __forceinline__ double eval(Ctx &c, int j) { return (double)E::eval(c, j); }
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return E::valid(c, j); }
 };
 template <class E> struct Widen128 { // Decimal128 column staged as i64 → arrow's 16-byte raw value on the way out
   using Type = I128;
   static __device__ __forceinline__ __int128 eval(Ctx &c, int j) { return (__int128)(int64_t)E::eval(c, j); }
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return E::valid(c, j); }
 };
 template <class E> struct ToI64 { // widening of the narrow integer types
   using Type = I64;
   static __device__ __forceinline__ int64_t eval(Ctx &c, int j) { return (int64_t)E::eval(c, j); }
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return E::valid(c, j); }
 };
 
 // Rust `f64 as i64`: saturating, NaN → 0 (llkv-executor/src/lib.rs:7385-7389).
@@ -188,26 +203,37 @@ __device__ __forceinline__ int64_t f64_as_i64_sat(double x) {
   return (int64_t)x;
 }
 
-enum BinKind : int { B_ADD = 1, B_SUB = 2, B_MUL = 3 };
+enum BinKind : int { B_ADD = 1, B_SUB = 2, B_MUL = 3, B_REM = 4 };
+// sticky error codes of Ctx::err / the error lane (combined with max): 1 = arithmetic overflow, 2 = division by zero
+constexpr uint32_t kErrOverflow = 1u, kErrDivZero = 2u;
 
-// arrow-arith numeric::{add,sub,mul}: IEEE for floats, checked for integers
-// (overflow is an error: fast_numeric.rs:328-334 → Error::Internal).
+// arrow-arith numeric::{add,sub,mul,rem}: IEEE for floats; integers checked (overflow is an error,
+// fast_numeric.rs:328-334 → Error::Internal) except `%`, which is a zero check ("Divide by zero") followed by
+// mod_wrapping; a node is evaluated only where both operands are valid.
 template <int OP, class L, class R> struct Bin {
   using Type = typename L::Type;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j); }
   static __device__ __forceinline__ typename Type::T eval(Ctx &c, int j) {
     const auto a = L::eval(c, j);
     const auto b = R::eval(c, j);
     if constexpr (Type::is_float) {
       if constexpr (OP == B_ADD) return a + b;
       else if constexpr (OP == B_SUB) return a - b;
-      else return a * b;
+      else if constexpr (OP == B_MUL) return a * b;
+      else return fmod(a, b);
+    } else if constexpr (OP == B_REM) {
+      const bool ok = valid(c, j);
+      const int64_t x = (int64_t)a, y = (int64_t)b;
+      const bool zero = y == 0; // arrow `rem`: zero check, then mod_wrapping (i64::MIN % -1 = 0)
+      c.err = max(c.err, (ok & zero) ? kErrDivZero : 0u);
+      return (zero | (y == -1)) ? 0 : x % y;
     } else {
       int64_t z;
       bool o;
       if constexpr (OP == B_ADD) o = __builtin_add_overflow((int64_t)a, (int64_t)b, &z);
       else if constexpr (OP == B_SUB) o = __builtin_sub_overflow((int64_t)a, (int64_t)b, &z);
       else o = __builtin_mul_overflow((int64_t)a, (int64_t)b, &z);
-      c.err |= o ? 1u : 0u;
+      c.err = max(c.err, (o & valid(c, j)) ? kErrOverflow : 0u);
       return z;
     }
   }
@@ -216,16 +242,54 @@ template <class L, class R> using Add = Bin<B_ADD, L, R>;
 template <class L, class R> using Sub = Bin<B_SUB, L, R>;
 template <class L, class R> using Mul = Bin<B_MUL, L, R>;
 
+// Divide on the generic (per-node typed) path, compute_binary llkv-compute/src/kernels.rs:99-177: zeros of
+// the divisor become NULLs first, then arrow `div` — truncating and checked for integers (i64::MIN / -1
+// overflows), IEEE for floats.  The operands arrive coerced to their common type.
+template <class L, class R> struct Div {
+  using Type = typename L::Type;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & (R::eval(c, j) != 0); }
+  static __device__ __forceinline__ typename Type::T eval(Ctx &c, int j) {
+    const auto a = L::eval(c, j);
+    const auto b = R::eval(c, j);
+    if constexpr (Type::is_float) return a / b;
+    else {
+      const int64_t x = (int64_t)a, y = (int64_t)b;
+      const bool ovf = (x == (int64_t)0x8000000000000000ull) & (y == -1);
+      c.err = max(c.err, (ovf & valid(c, j)) ? kErrOverflow : 0u);
+      return ((y == 0) | ovf) ? 0 : x / y;
+    }
+  }
+};
+
 // GROUP BY aggregate arguments go through the PlanValue interpreter, where Int∘Int for
-// + - * is computed in f64 and cast back (llkv-executor/src/lib.rs:7338-7389).
+// + - * % is computed in f64 and cast back (llkv-executor/src/lib.rs:7338-7389); x % 0 is NULL.
 template <int OP, class L, class R> struct BinViaF64 {
   using Type = I64;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) {
+    if constexpr (OP == B_REM) return L::valid(c, j) & R::valid(c, j) & ((double)R::eval(c, j) != 0.0);
+    else return L::valid(c, j) & R::valid(c, j);
+  }
   static __device__ __forceinline__ int64_t eval(Ctx &c, int j) {
     const double a = (double)L::eval(c, j), b = (double)R::eval(c, j);
     if constexpr (OP == B_ADD) return f64_as_i64_sat(a + b);
     else if constexpr (OP == B_SUB) return f64_as_i64_sat(a - b);
-    else return f64_as_i64_sat(a * b);
+    else if constexpr (OP == B_MUL) return f64_as_i64_sat(a * b);
+    else return f64_as_i64_sat(fmod(a, b));
   }
+};
+// PlanValue division / modulo with a Float operand: f64 arithmetic, NULL when the divisor is zero.
+template <int IS_MOD, class L, class R> struct DivPV {
+  using Type = F64;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & ((double)R::eval(c, j) != 0.0); }
+  static __device__ __forceinline__ double eval(Ctx &c, int j) {
+    const double a = (double)L::eval(c, j), b = (double)R::eval(c, j);
+    if constexpr (IS_MOD) return fmod(a, b);
+    else return a / b;
+  }
+};
+// Predicate form of an expression's validity.
+template <class E> struct VE {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return E::valid(c, j); }
 };
 
 // --------------------------------------------------------------------------
@@ -426,16 +490,14 @@ template <class V> struct CountIf {
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = V::eval(c, j) ? 1u : 0u; }
 };
 // Any accumulator over an argument with NULL cells: a NULL row contributes every lane's identity (accumulators
-// skip NULLs, and arrow's checked kernels do not evaluate NULL slots), and one more lane counts the non-NULL
+// skip NULLs), and one more lane counts the non-NULL
 // rows — the AVG denominator and the "no rows → NULL" test of finalize.
 template <class V, class A> struct IfValid {
   static constexpr int N = A::N + 1;
   static constexpr int op(int k) { return k < A::N ? A::op(k) : OP_ADD_I64; }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
-    const uint32_t outer = c.err;
     A::contrib(c, j, o);
     const bool v = V::eval(c, j);
-    c.err = v ? c.err : outer;
 #pragma unroll
     for (int k = 0; k < A::N; ++k) o[k] = v ? o[k] : lane_identity(A::op(k));
     o[A::N] = v ? 1u : 0u;

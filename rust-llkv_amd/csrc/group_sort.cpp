@@ -263,7 +263,7 @@ int SortedGroupBy::run(LazyGroups *out) {
   HIP_TRY(hipMemcpyAsync(h_kvalid, kvalid_d.p, n_groups * n_keys, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(&errflag, err_d.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (errflag) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  if (errflag) return set_error(LLKV_INTERNAL, arith_error_message(errflag));
   mark("copy out");
 
   // ---- host: only the aggregates whose finalize can fail are visited now; cells are decoded on request ----------

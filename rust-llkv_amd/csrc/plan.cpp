@@ -204,6 +204,34 @@ struct Lowering {
     return LLKV_OK;
   }
   std::string col_node(int slot, int32_t dtype) { return "Col<" + std::to_string(slot) + "," + dtype_tag(dtype) + ">"; }
+  // Column as an operand of an expression: carries its validity when it has NULL cells (NULL propagates, and
+  // a node raises arithmetic errors only where its operands are valid).
+  int expr_col_node(uint32_t field, const ColumnInfo **ci, std::string *node) {
+    int slot, rc;
+    if ((rc = slot_of(field, ci, &slot))) return rc;
+    std::string v;
+    if ((rc = valid_of_field(field, &v))) return rc;
+    if (v.empty()) *node = col_node(slot, (*ci)->dtype);
+    else *node = "ColN<" + std::to_string(slot) + "," + dtype_tag((*ci)->dtype) + "," + v.substr(6, v.size() - 7) + ">"; // "Valid<k>" → k
+    return LLKV_OK;
+  }
+  // Does the value of an expression depend on more than "all columns present"?  (NULL cells or divisions.)
+  static bool has_division(const llkv_expr_token *e, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) if (e[i].kind == LLKV_TOK_BINARY && (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD)) return true;
+    return false;
+  }
+  // Validity of a lowered expression node as a predicate: "" when it can never be NULL.
+  int valid_of_node(const llkv_expr_token *e, uint32_t n, const std::string &node, bool grouped_semantics, std::string *v) {
+    std::vector<std::string> vs;
+    int rc = valid_of_expr(e, n, &vs);
+    if (rc) return rc;
+    bool div = false;
+    for (uint32_t i = 0; i < n; ++i)
+      if (e[i].kind == LLKV_TOK_BINARY && (e[i].binop == LLKV_BIN_DIV || (grouped_semantics && e[i].binop == LLKV_BIN_MOD))) div = true; // x/0 (and PlanValue x%0) → NULL
+    if (n == 1 && e[0].kind == LLKV_TOK_COLUMN) { *v = all_of(vs); return LLKV_OK; }
+    *v = (vs.empty() && !div) ? std::string() : "VE<" + node + ">";
+    return LLKV_OK;
+  }
 
   int lit_i(int64_t v, std::string *node, const char *kind = "LitI") {
     if ((int)p.lit_i.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many integer literals");
@@ -490,6 +518,8 @@ struct Lowering {
     // rows where every referenced field is present = where both sides are determined (predicate.rs:366-388,635-638)
     std::vector<std::string> vs;
     if ((rc = valid_of_expr(l, f.cmp_left_len, &vs)) || (rc = valid_of_expr(r, f.cmp_right_len, &vs))) return rc;
+    if (has_division(l, f.cmp_left_len)) vs.push_back("VE<" + ln + ">");  // a NULL side (x / 0) leaves the row undetermined
+    if (has_division(r, f.cmp_right_len)) vs.push_back("VE<" + rn + ">");
     const std::string v = all_of(vs);
     *dom = v.empty() ? "True" : v;
     *out = "Cmp<" + std::to_string(f.cmp_op) + "," + ln + "," + rn + (v.empty() ? "" : "," + v) + ">";
@@ -516,7 +546,7 @@ struct Lowering {
         if (e[i].literal.tag == LLKV_LIT_FLOAT64) any_float = true;
         else if (e[i].literal.tag != LLKV_LIT_INT128) return fail(LLKV_UNSUPPORTED, "non-numeric literal in computed projection");
       } else if (e[i].kind == LLKV_TOK_BINARY) {
-        if (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "division in computed projections (NULL on zero) is not on the GPU path");
+        if (e[i].binop == LLKV_BIN_DIV) return expr_generic(e, n, node, is_f64); // Divide leaves the fast path (fast_numeric.rs:273-275)
       }
     }
     // Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference (checked i32 arithmetic, Int32 result)
@@ -541,9 +571,8 @@ struct Lowering {
     for (uint32_t i = 0; i < n; ++i) {
       if (e[i].kind == LLKV_TOK_COLUMN) {
         const ColumnInfo *ci;
-        int slot;
-        if ((rc = slot_of(e[i].field_id, &ci, &slot))) return rc;
-        std::string c = col_node(slot, ci->dtype);
+        std::string c;
+        if ((rc = expr_col_node(e[i].field_id, &ci, &c))) return rc;
         if (any_float) { if (ci->dtype != LLKV_DT_FLOAT64) c = "ToF64<" + c + ">"; }
         else if (ci->dtype != LLKV_DT_INT64 && ci->dtype != LLKV_DT_UINT64) c = "ToI64<" + c + ">";
         st.push_back(c);
@@ -558,13 +587,54 @@ struct Lowering {
         if (st.size() < 2) return fail(LLKV_INTERNAL, "fast path stack underflow");
         std::string r = st.back(); st.pop_back();
         std::string l = st.back(); st.pop_back();
-        const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : 3;
+        const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
         st.push_back("Bin<" + std::to_string(op) + "," + l + "," + r + ">");
       }
     }
     if (st.size() != 1) return fail(LLKV_INTERNAL, "fast path evaluation missing result");
     *node = st[0];
     *is_f64 = any_float;
+    return LLKV_OK;
+  }
+
+  // Expressions with a Divide take the generic route (try_evaluate_vectorized llkv-compute/src/eval.rs:616-665 →
+  // compute_binary kernels.rs:99-177): every Binary node coerces its own two operands to their common type
+  // (not the whole expression to one final type), integers stay checked, zeros of a divisor become NULLs.
+  // Restated for Int64 / Float64 operands; narrower or unsigned ones keep the query on the caller's route.
+  int expr_generic(const llkv_expr_token *e, uint32_t n, std::string *node, bool *is_f64) {
+    struct V { std::string s; bool f; };
+    std::vector<V> st;
+    int rc;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind == LLKV_TOK_COLUMN) {
+        const ColumnInfo *ci;
+        std::string c;
+        if ((rc = expr_col_node(e[i].field_id, &ci, &c))) return rc;
+        if (ci->dtype != LLKV_DT_INT64 && ci->dtype != LLKV_DT_FLOAT64)
+          return fail(LLKV_UNSUPPORTED, std::string("division over ") + dtype_name(ci->dtype) + " operands (per-node typing of narrow types)");
+        st.push_back({c, ci->dtype == LLKV_DT_FLOAT64});
+      } else if (e[i].kind == LLKV_TOK_LITERAL) {
+        std::string l;
+        const llkv_literal &lit = e[i].literal;
+        if (lit.tag == LLKV_LIT_FLOAT64) { if ((rc = lit_f(lit.f64, &l))) return rc; st.push_back({l, true}); }
+        else if (lit.tag == LLKV_LIT_INT128) { if ((rc = lit_i((int64_t)lit_i128(lit), &l))) return rc; st.push_back({l, false}); } // `*i as i64`
+        else return fail(LLKV_UNSUPPORTED, "literal kind in a computed projection");
+      } else {
+        if (st.size() < 2) return fail(LLKV_INTERNAL, "expression stack underflow");
+        V r = st.back(); st.pop_back();
+        V l = st.back(); st.pop_back();
+        const bool f = l.f || r.f; // get_common_type: Int64 ⊕ Float64 → Float64
+        const std::string a = (f && !l.f) ? "ToF64<" + l.s + ">" : l.s, b = (f && !r.f) ? "ToF64<" + r.s + ">" : r.s;
+        if (e[i].binop == LLKV_BIN_DIV) st.push_back({"Div<" + a + "," + b + ">", f});
+        else {
+          const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
+          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + ">", f});
+        }
+      }
+    }
+    if (st.size() != 1) return fail(LLKV_INTERNAL, "expression evaluation missing result");
+    *node = st[0].s;
+    *is_f64 = st[0].f;
     return LLKV_OK;
   }
 
@@ -576,9 +646,8 @@ struct Lowering {
     for (uint32_t i = 0; i < n; ++i) {
       if (e[i].kind == LLKV_TOK_COLUMN) {
         const ColumnInfo *ci;
-        int slot;
-        if ((rc = slot_of(e[i].field_id, &ci, &slot))) return rc;
-        std::string c = col_node(slot, ci->dtype);
+        std::string c;
+        if ((rc = expr_col_node(e[i].field_id, &ci, &c))) return rc;
         if (ci->dtype == LLKV_DT_FLOAT64) st.push_back({c, true});
         else if (ci->dtype == LLKV_DT_FLOAT32) st.push_back({"ToF64<" + c + ">", true});
         else if (ci->dtype == LLKV_DT_INT64) st.push_back({c, false});
@@ -594,8 +663,14 @@ struct Lowering {
         if (st.size() < 2) return fail(LLKV_INTERNAL, "expression stack underflow");
         V r = st.back(); st.pop_back();
         V l = st.back(); st.pop_back();
-        if (e[i].binop == LLKV_BIN_DIV || e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "division in aggregate expressions (NULL on zero) is not on the GPU path");
-        const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : 3;
+        if (e[i].binop == LLKV_BIN_DIV || (e[i].binop == LLKV_BIN_MOD && (l.f || r.f))) {
+          // Int / Int truncates but turns Float for i64::MIN / -1 (:7213-7227): the type of the group's temp column
+          // would depend on the data
+          if (!l.f && !r.f) return fail(LLKV_UNSUPPORTED, "integer division in GROUP BY aggregate arguments");
+          st.push_back({std::string("DivPV<") + (e[i].binop == LLKV_BIN_MOD ? "1" : "0") + "," + l.s + "," + r.s + ">", true});
+          continue;
+        }
+        const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
         if (!l.f && !r.f) st.push_back({"BinViaF64<" + std::to_string(op) + "," + l.s + "," + r.s + ">", false});
         else {
           const std::string a = l.f ? l.s : "ToF64<" + l.s + ">", b = r.f ? r.s : "ToF64<" + r.s + ">";
@@ -642,11 +717,18 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       simple_ci = resolve(s.expr[0].field_id);
       if (!simple_ci) return L.fail(LLKV_INVALID_ARGUMENT, "unknown column '" + std::to_string(s.expr[0].field_id) + "' in aggregate");
     }
-    // rows where the argument is non-NULL (NULL propagates through arithmetic; accumulators skip NULLs,
-    // llkv-aggregate/src/lib.rs:769-786,801-830)
-    std::vector<std::string> vs;
-    if ((rc = L.valid_of_expr(s.expr, s.expr_len, &vs))) return rc;
-    const std::string valid = Lowering::all_of(vs);
+    // rows where the argument is non-NULL (NULL propagates through arithmetic, x / 0 is NULL; accumulators
+    // skip NULLs, llkv-aggregate/src/lib.rs:769-786,801-830)
+    std::string valid;
+    if (simple) {
+      std::vector<std::string> vs;
+      if ((rc = L.valid_of_expr(s.expr, s.expr_len, &vs))) return rc;
+      valid = Lowering::all_of(vs);
+    } else {
+      rc = grouped ? L.expr_planvalue(s.expr, s.expr_len, &node, &is_f64) : L.expr_fast(s.expr, s.expr_len, &node, &is_f64);
+      if (rc) return rc;
+      if ((rc = L.valid_of_node(s.expr, s.expr_len, node, grouped, &valid))) return rc;
+    }
     if (s.kind == LLKV_AGG_COUNT || s.kind == LLKV_AGG_COUNT_NULLS) {
       // NULL-free argument: COUNT(x) = rows, COUNT_NULLS(x) = 0
       if (valid.empty()) o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
@@ -671,8 +753,6 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       node = L.col_node(slot, dt);
       is_f64 = dt == LLKV_DT_FLOAT64;
     } else {
-      rc = grouped ? L.expr_planvalue(s.expr, s.expr_len, &node, &is_f64) : L.expr_fast(s.expr, s.expr_len, &node, &is_f64);
-      if (rc) return rc;
       o.typed_by_first_value = grouped;
     }
     // statistics that exclude i64 overflow of any prefix sum: rows · max|v| ≤ i64::MAX
@@ -938,9 +1018,8 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     if (is_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
   }
   { // NULL argument rows are not part of the accumulator's chain
-    std::vector<std::string> vs;
-    if ((rc = L.valid_of_expr(expr, expr_len, &vs))) return rc;
-    const std::string v = Lowering::all_of(vs);
+    std::string v;
+    if ((rc = L.valid_of_node(expr, expr_len, val, false, &v))) return rc;
     if (!v.empty() && pred != "False") pred = pred == "True" ? v : "And<" + pred + "," + v + ">";
   }
   out->type_string = "EmitPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + "," + val + ">";
@@ -1013,9 +1092,8 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
         out->out_dtypes.push_back(is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64);
         out->out_fields.push_back(-1);
       }
-      std::vector<std::string> vs;
-      if ((rc = L.valid_of_expr(pr.expr, pr.expr_len, &vs))) return rc;
-      const std::string v = Lowering::all_of(vs);
+      std::string v;
+      if ((rc = L.valid_of_node(pr.expr, pr.expr_len, node, false, &v))) return rc;
       if (!v.empty()) node = "OutV<" + node + "," + v + ">";
       out->out_nullable.push_back(!v.empty());
     }

@@ -221,18 +221,13 @@ template <class CL, int I = 0> __device__ __forceinline__ void gather_cols(const
   }
 }
 template <class CL> __device__ __forceinline__ void gather_all(const ProjParams &p, uint64_t row, Loaded &ld) { gather_cols<CL>(p.col, row, ld); }
-// Output with NULLs: the value (arithmetic errors under a NULL do not count — arrow skips NULL slots) and one
+// Output with NULLs: the value and one
 // validity bit per row, packed per wave with a ballot into the Arrow bitmap of the window (bit k of word w =
 // row 64·w + k; lane order = row order).
 template <class E, class V> struct OutV {
   using Type = typename E::Type;
   using ValidT = V;
-  static __device__ __forceinline__ typename E::Type::T eval(Ctx &c, int j) {
-    const uint32_t outer = c.err;
-    const auto x = E::eval(c, j);
-    c.err = V::eval(c, j) ? c.err : outer;
-    return x;
-  }
+  static __device__ __forceinline__ typename E::Type::T eval(Ctx &c, int j) { return E::eval(c, j); }
 };
 template <class E> struct out_valid_of { using type = void; };
 template <class E, class V> struct out_valid_of<OutV<E, V>> { using type = V; };
@@ -265,7 +260,7 @@ template <class P> __device__ __forceinline__ void project_body(const ProjParams
   gather_all<typename P::ColList>(pp, row, ld);
   Ctx c{sp, ld, 0u, row};
   StoreOuts<typename P::OutT>::run(pp, c, i);
-  if (c.err) atomicOr(pp.error_flag, 1u);
+  if (c.err) atomicOr(pp.error_flag, c.err);
 }
 
 // ---- sort-based GROUP BY: per-group reduction -------------------------------------------------------
@@ -319,7 +314,7 @@ template <class P> __device__ __forceinline__ void group_reduce_body(const Reduc
     }
     if (lane == 0) rp.out[g * K + k] = v;
   }
-  if (__ballot(err != 0) && lane == 0) atomicOr(rp.error_flag, 1u);
+  if (err) atomicOr(rp.error_flag, err);
 }
 
 } // namespace llkv

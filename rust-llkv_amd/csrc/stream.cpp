@@ -230,7 +230,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   }
   uint32_t errflag = 0;
   if (hipMemcpy(&errflag, d_err.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "copy failed");
-  if (errflag) return (llkv_status)set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a computed projection");
+  if (errflag) return (llkv_status)set_error(LLKV_INTERNAL, arith_error_message(errflag));
   return LLKV_OK;
 }
 

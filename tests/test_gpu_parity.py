@@ -599,6 +599,70 @@ def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks):
     assert kinds[0][0] in ("InvalidArgumentError", "Unsupported")
 
 
+@pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])
+def test_division_and_modulo_match_oracle(rt, orc, abi, chunks):
+    """Divide leaves the fast numeric path: per-node typing, zeros of a divisor become NULLs, integer division
+    truncates (compute_binary, llkv-compute/src/kernels.rs:99-177); `%` is arrow `rem` (zero → "Divide by zero");
+    GROUP BY arguments follow the PlanValue rules (x / 0 and x % 0 → NULL).  Arithmetic errors are raised node by
+    node, only where that node's operands are valid."""
+    rng = np.random.default_rng(11 + len(chunks))
+    n = sum(chunks)
+    a = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    b = rng.integers(-3, 4, size=n).astype(np.int64)            # plenty of zeros
+    nz = np.where(b == 0, 5, b).astype(np.int64)                # never zero
+    f = rng.integers(-40, 40, size=n).astype(np.float64) / 4    # zeros, -0.0 below
+    f[rng.random(n) < 0.02] = -0.0
+    g = rng.integers(1, 9, size=n).astype(np.float64) / 2
+    keys = np.array([ord("p"), ord("q")], dtype=np.uint8)[rng.integers(0, 2, size=n)]
+    va = rng.random(n) > 0.15
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, a, va), (2, abi.DT_INT64, b), (3, abi.DT_INT64, nz), (4, abi.DT_FLOAT64, f),
+                                       (5, abi.DT_FLOAT64, g), (6, abi.DT_UTF8, keys)], chunks)
+    A, F, O, E, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.Expr, abi.col
+    aggs = [A.count_star(), A.sum(col(1) / col(2)), A.count(col(1) / col(2)), A.count_nulls(col(1) / col(2)), A.avg(col(1) / col(2)), A.sum(col(1) % col(3)),
+            A.sum((col(1) + col(3)) / col(4)), A.min(col(5) / col(4)), A.max((col(1) * 2) / (col(2) * col(3))), A.total(col(1) / 4.0), A.sum(col(4) % col(5)),
+            A.sum(col(1) / col(3) * col(2))]
+    for pred in (None, [F(3, O.GreaterThan(0))], E.compare(col(1) / col(2), abi.CMP_GT, col(3)), E.not_(E.compare(col(5) / col(4), abi.CMP_LT_EQ, 1.0))):
+        assert np.array_equal(rt.filter_row_ids(ht, pred), orc.filter_row_ids(ot, pred))
+        assert_values(rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs), "division")
+    gaggs = [A.count_star(), A.sum(col(4) / col(5)), A.count(col(5) / col(4)), A.sum(col(1) % col(2)), A.count(col(1) % col(2)), A.avg(col(1) / 8.0), A.sum(col(4) % col(5))]
+    got, want = rt.groupby(ht, None, [6], gaggs, True), orc.groupby(ot, None, [6], gaggs, True)
+    assert [r.keys[0].value for r in got] == [r.keys[0].value for r in want]
+    for x, y in zip(got, want):
+        assert_values(x.values, y.values, "division/groupby")
+    if n < 20000:
+        projs = [1, col(1) / col(2), col(5) / col(4), col(1) % col(3), (col(1) + 1) / col(3)]
+        for inc in (False, True):
+            got = rt.scan_stream(ht, projs, [F(3, O.LessThan(3))], include_nulls=inc, include_row_ids=True)
+            want = orc.scan_stream(ot, projs, [F(3, O.LessThan(3))], include_nulls=inc, include_row_ids=True)
+            assert [b[1] for b in got] == [b[1] for b in want]
+            for (gc, _), (wc, _) in zip(got, want):
+                for x, y in zip(gc, wc):
+                    assert all((p == q) or (isinstance(p, float) and isinstance(q, float) and math.isnan(p) and math.isnan(q)) for p, q in zip(x, y))
+    # errors: `% 0`; i64::MIN / -1; a node's error counts wherever ITS operands are valid, whatever else is NULL
+    for m, t in ((rt, ht), (orc, ot)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.aggregate(t, None, [A.sum(col(3) % col(2))])
+        assert e.value.kind == "Internal" and "Divide by zero" in e.value.message
+    with pytest.raises(abi.LlkvError) as e:  # Int / Int in a GROUP BY argument can turn Float (i64::MIN / -1): handed back
+        rt.groupby(ht, None, [6], [A.sum(col(1) / col(3))], True)
+    assert e.value.kind == "Unsupported"
+    mn = np.array([-2**63, 5, 7] + [1] * (n - 3), dtype=np.int64)
+    m1 = np.array([-1, 0, 2] + [1] * (n - 3), dtype=np.int64)
+    other = np.zeros(n, dtype=np.int64)
+    ov = np.ones(n, dtype=bool)
+    ov[0] = False
+    ht2, ot2 = stage_both(rt, orc, abi, [(1, abi.DT_INT64, mn), (2, abi.DT_INT64, m1), (3, abi.DT_INT64, other, ov)], chunks)
+    for m, t in ((rt, ht2), (orc, ot2)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.aggregate(t, None, [A.sum(col(1) / col(2))])
+        assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+        with pytest.raises(abi.LlkvError) as e:  # row 0: column 3 is NULL there, but the division node's operands are not
+            m.aggregate(t, None, [A.sum(col(1) / col(2) + col(3))])
+        assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+        r = m.aggregate(t, [F(2, O.GreaterThanOrEquals(0))], [A.sum(col(1) / col(2)), A.count(col(1) / col(2)), A.sum(col(1) % col(2) if False else col(1) / col(2) + col(3))])
+        assert [x.value for x in r] == [3 + (n - 3), n - 2, 3 + (n - 3)]
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 

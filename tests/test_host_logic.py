@@ -121,9 +121,16 @@ def test_expression_typing_rules(lib, abi):
     assert "SumI64<Bin<3,Col<0,I64>,LitI<0>>>" in ts  # checked i64, exact 96-bit split accumulator
     ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * 2), A.sum(col(1) * (1 - col(2)))], keys=[3], grouped=True)
     assert "BinViaF64<3,Col<1,I64>,LitI<0>>" in ts and "Bin<3,ToF64<Col<1,I64>>,Bin<2,ToF64<LitI<1>>,Col<2,F64>>>" in ts
+    # Divide leaves the fast path: every node is typed on its own operands, a zero divisor makes the row NULL
+    ts, _, _ = rt.lower_plan(d, None, [A.sum((col(1) + col(1)) / col(2)), A.sum(col(1) % 7)])
+    assert "IfValid<VE<Div<ToF64<Bin<1,Col<0,I64>,Col<0,I64>>>,Col<1,F64>>>,SumF64<Div<ToF64<Bin<1,Col<0,I64>,Col<0,I64>>>,Col<1,F64>>>>" in ts
+    assert "SumI64<Bin<4,Col<0,I64>,LitI<0>>>" in ts  # % stays on the fast path: checked, `% 0` is an error
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(2) / col(1)), A.sum(col(1) % 3)], keys=[3], grouped=True)
+    assert "IfValid<VE<DivPV<0,Col<1,F64>,Col<2,I64>>>,SumF64<DivPV<0,Col<1,F64>,Col<2,I64>>>>" in ts
+    assert "IfValid<VE<BinViaF64<4,Col<2,I64>,LitI<0>>>,SumI64<BinViaF64<4,Col<2,I64>,LitI<0>>>>" in ts  # PlanValue x % 0 → NULL
     with pytest.raises(abi.LlkvError) as e:
-        rt.lower_plan(d, None, [A.sum(col(1) / col(2))])
-    assert e.value.kind == "Unsupported"  # x/0 → NULL needs the CPU route for now
+        rt.lower_plan(d, None, [A.sum(col(1) / col(1))], keys=[3], grouped=True)
+    assert e.value.kind == "Unsupported"  # Int / Int in a GROUP BY argument turns Float for i64::MIN / -1
     d32 = _desc(abi, [(1, abi.DT_INT32)])
     with pytest.raises(abi.LlkvError) as e:
         rt.lower_plan(d32, None, [A.sum(1)])
@@ -189,7 +196,7 @@ def test_null_cells_lower_to_validity_masks_and_domains(lib, abi):
     # aggregates
     ts, lanes, _ = rt.lower_plan(d, None, [A.count(1), A.count_nulls(1), A.sum(1), A.avg(2), A.sum(col(1) * col(2)), A.sum(3)])
     assert "CountIf<Valid<0>>" in ts and "IfValid<Valid<0>,SumI64<Col<1,I64>>>" in ts and "IfValid<Valid<2>,SumF64<Col<3,F64>>>" in ts
-    assert "IfValid<And<Valid<0>,Valid<2>>,SumF64<Bin<3,ToF64<Col<1,I64>>,Col<3,F64>>>>" in ts and ",SumI64<Col<4,I64>>>" in ts
+    assert "IfValid<VE<Bin<3,ToF64<ColN<1,I64,0>>,ColN<3,F64,2>>>,SumF64<Bin<3,ToF64<ColN<1,I64,0>>,ColN<3,F64,2>>>>" in ts and ",SumI64<Col<4,I64>>>" in ts
     # a key column with NULL cells: NULL is one more group (GroupKeyValue::Null)
     dk = _desc(abi, [(1, abi.DT_INT64, True), (2, abi.DT_FLOAT64, True)])
     dk[0].has_stats, dk[0].min_i, dk[0].max_i = 1, 10, 13

@@ -101,13 +101,23 @@ def test_group_by_int_expression_goes_through_f64(orc, abi):
 
 
 def test_aggregate_expression_div_by_zero_is_null(orc, abi):
-    """x / 0 and x % 0 → NULL (llkv-executor/src/lib.rs:14020-14048, llkv-compute/src/kernels.rs:121-135)."""
-    t = orc.OracleTable(2)
-    t.add(1, abi.DT_INT64, np.array([10, 20], dtype=np.int64))
-    t.add(2, abi.DT_INT64, np.array([0, 5], dtype=np.int64))
-    A = abi.AggregateSpec
-    got = orc.aggregate(t, None, [A.sum(abi.col(1) / abi.col(2)), A.count(abi.col(1) % abi.col(2))])
-    assert got[0].value == 4 and got[1].value == 1
+    """Scan projections: x / 0 → NULL (zeros of the divisor are nullified first, llkv-compute/src/kernels.rs:121-135)
+    but x % 0 is arrow's `rem` → "Divide by zero" (:136-138, fast_numeric.rs:328-334).  GROUP BY arguments go through
+    the PlanValue interpreter, where both are NULL (llkv-executor/src/lib.rs:7193-7389, tests :14020-14048)."""
+    t = orc.OracleTable(3)
+    t.add(1, abi.DT_INT64, np.array([10, 20, 7], dtype=np.int64))
+    t.add(2, abi.DT_INT64, np.array([0, 5, 2], dtype=np.int64))
+    t.add(3, abi.DT_UTF8, ["g", "g", "g"])
+    A, col = abi.AggregateSpec, abi.col
+    got = orc.aggregate(t, None, [A.sum(col(1) / col(2)), A.count(col(1) / col(2)), A.sum(col(1) / 4.0)])
+    assert [g.value for g in got] == [7, 2, 9.25]  # 20/5 + 7/2 (truncating); 10/0 is NULL
+    with pytest.raises(abi.LlkvError) as e:
+        orc.aggregate(t, None, [A.count(col(1) % col(2))])
+    assert e.value.kind == "Internal" and "Divide by zero" in e.value.message
+    got = orc.aggregate(t, [abi.Filter(2, abi.Operator.GreaterThan(0))], [A.sum(col(1) % col(2))])
+    assert got[0].value == 1
+    rows = orc.groupby(t, None, [3], [A.count(col(1) % col(2)), A.sum(col(1) % col(2)), A.sum(col(1) / 4.0)])
+    assert [v.value for v in rows[0].values] == [2, 1, 9.25]
 
 
 def test_q6_against_numpy(orc, abi, tpch):
