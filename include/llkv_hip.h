@@ -104,7 +104,16 @@ typedef enum llkv_operator_kind {
    * llkv-compute/src/kernels.rs:269-297): both sides are coerced to their common type and
    * compared with arrow's `cmp` kernels — for floats that is IEEE totalOrder (NaN above
    * everything, -0.0 below +0.0), unlike the leaf predicates' partial_cmp.  Uses cmp_*.   */
-  LLKV_OP_COMPARE = 11
+  LLKV_OP_COMPARE = 11,
+  /* Expr::InList { expr, list, negated } (EvalOp::PushInList, evaluate_in_list_over_rows llkv-scan/src/
+   * predicate.rs:443-560): over the rows where every referenced field is present, the target (cmp_left) is
+   * coerced item by item to the common type with each list expression and compared with arrow `eq` (floats by
+   * totalOrder); the item results are OR-ed, `negated` inverts.  Uses cmp_left, list_*, negated.          */
+  LLKV_OP_IN_LIST = 12,
+  /* Expr::IsNull { expr, negated } over a scalar expression (EvalOp::PushIsNull, collect_row_ids_for_is_null
+   * predicate.rs:249-331): a bare column is the IS [NOT] NULL leaf; otherwise the rows — among those where at
+   * least one referenced field is present — whose value is (not) NULL.  Uses cmp_left, negated.            */
+  LLKV_OP_IS_NULL_EXPR = 13
 } llkv_operator_kind;
 
 typedef enum llkv_compare_op { /* llkv_expr::CompareOp */
@@ -137,6 +146,10 @@ typedef struct llkv_filter {
   uint32_t cmp_left_len;
   const struct llkv_expr_token *cmp_right;
   uint32_t cmp_right_len;
+  const struct llkv_expr_token *const *list_exprs; /* LLKV_OP_IN_LIST: the list's expressions */
+  const uint32_t *list_expr_lens;
+  uint32_t list_len;
+  int32_t negated;             /* LLKV_OP_IN_LIST / LLKV_OP_IS_NULL_EXPR                  */
 } llkv_filter;
 
 /* Predicate program — `EvalOp` stack program, llkv-compute/src/program.rs:48-78,

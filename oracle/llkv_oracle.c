@@ -432,6 +432,8 @@ static int32_t filter_leaf(const orc_table *t, const llkv_filter *f, idvec *out)
 }
 
 static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom);
+static int32_t in_list_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom);
+static int32_t is_null_expr_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom);
 
 /* Predicate VM: llkv-scan/src/predicate.rs:32-193.  Each stack entry carries the
  * matching rows and the domain (rows where the sub-expression is determined),
@@ -465,6 +467,8 @@ int32_t orc_filter_row_ids(const orc_table *t, const llkv_filter *filters, uint3
       if (op->arg >= n_filters) { rc = fail(LLKV_INTERNAL, "predicate index out of range"); break; }
       vm_entry e = {{0}, {0}};
       if (filters[op->arg].op == LLKV_OP_COMPARE) rc = compare_rows(t, &filters[op->arg], &e.rows, &e.dom);
+      else if (filters[op->arg].op == LLKV_OP_IN_LIST) rc = in_list_rows(t, &filters[op->arg], &e.rows, &e.dom);
+      else if (filters[op->arg].op == LLKV_OP_IS_NULL_EXPR) rc = is_null_expr_rows(t, &filters[op->arg], &e.rows, &e.dom);
       else {
         rc = filter_leaf(t, &filters[op->arg], &e.rows);
         if (rc == LLKV_OK) rc = field_nonnull_rows(t, filters[op->arg].field_id, &e.dom);
@@ -960,6 +964,144 @@ static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *row
   if (rc) { idv_free(&matched); idv_free(&determined); return rc; }
   *rows = matched;
   *dom = determined;
+  return LLKV_OK;
+}
+
+/* ------------------------------------------------- Expr::InList / Expr::IsNull */
+static void collect_expr_fields(const llkv_expr_token *e, uint32_t n, uint32_t *fields, uint32_t *n_fields) {
+  for (uint32_t i = 0; i < n; ++i) {
+    if (e[i].kind != LLKV_TOK_COLUMN) continue;
+    uint32_t j = 0;
+    while (j < *n_fields && fields[j] != e[i].field_id) ++j;
+    if (j == *n_fields && *n_fields < 64) fields[(*n_fields)++] = e[i].field_id;
+  }
+}
+
+static int dtype_mode(int32_t a, int32_t b) { /* 0 = Float64, 1 = signed, 2 = unsigned: get_common_type of two sides */
+  const int af = a == LLKV_DT_FLOAT64 || a == LLKV_DT_FLOAT32, bf = b == LLKV_DT_FLOAT64 || b == LLKV_DT_FLOAT32;
+  if (af || bf) return 0;
+  if (is_unsigned_dtype(a) && is_unsigned_dtype(b)) return 2;
+  if (is_unsigned_dtype(a) != is_unsigned_dtype(b)) return (is_64bit_dtype(a) || is_64bit_dtype(b)) ? 0 : 1;
+  return 1;
+}
+
+/* evaluate_in_list_over_rows llkv-scan/src/predicate.rs:443-560: rows where every referenced field is present;
+ * the target is re-coerced with every item (`target_array = new_target`), `eq` per item (floats by totalOrder),
+ * or_kleene over the items, `not` when negated; a NULL result is neither matched nor determined. */
+static int32_t in_list_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom) {
+  if (!f->cmp_left || !f->cmp_left_len) return fail(LLKV_INVALID_ARGUMENT, "IN list needs a target expression");
+  uint32_t fields[64], n_fields = 0;
+  collect_expr_fields(f->cmp_left, f->cmp_left_len, fields, &n_fields);
+  for (uint32_t k = 0; k < f->list_len; ++k) collect_expr_fields(f->list_exprs[k], f->list_expr_lens[k], fields, &n_fields);
+  if (n_fields == 0) return fail(LLKV_UNSUPPORTED, "constant IN list");
+  idvec d = {0};
+  for (uint32_t j = 0; j < n_fields; ++j) {
+    idvec nn;
+    int32_t rc = field_nonnull_rows(t, fields[j], &nn);
+    if (rc) { idv_free(&d); return rc; }
+    if (j == 0) d = nn;
+    else { idvec x = idv_and(&d, &nn); idv_free(&d); idv_free(&nn); d = x; }
+  }
+  idvec matched = {0}, determined = {0};
+  int32_t rc = LLKV_OK;
+  for (uint64_t c0 = 0; c0 < d.n && rc == LLKV_OK; c0 += 4096) {
+    const uint64_t n = d.n - c0 < 4096 ? d.n - c0 : 4096;
+    gathered g[64];
+    for (uint32_t j = 0; j < n_fields; ++j) { g[j].field_id = fields[j]; g[j].a = gather_column(find_col(t, fields[j]), d.v + c0, n); }
+    arr tgt;
+    memset(&tgt, 0, sizeof tgt);
+    rc = compare_side(t, f->cmp_left, f->cmp_left_len, g, n_fields, d.v + c0, n, &tgt);
+    int8_t *acc = xmalloc(n ? n : 1); /* Kleene: 0 false, 1 true, -1 NULL; starts as "no item yet" = false */
+    memset(acc, 0, n);
+    int have = 0;
+    for (uint32_t k = 0; k < f->list_len && rc == LLKV_OK; ++k) {
+      arr it;
+      memset(&it, 0, sizeof it);
+      rc = compare_side(t, f->list_exprs[k], f->list_expr_lens[k], g, n_fields, d.v + c0, n, &it);
+      if (rc) break;
+      const int mode = dtype_mode(tgt.dtype, it.dtype);
+      if (mode == 0 && tgt.dtype != LLKV_DT_FLOAT64) { /* the coerced target replaces the target */
+        arr c = cast_to(&tgt, LLKV_DT_FLOAT64);
+        arr_free(&tgt);
+        tgt = c;
+      }
+      for (uint64_t i = 0; i < n; ++i) {
+        int8_t eq;
+        if (!tgt.valid[i] || !it.valid[i]) eq = -1;
+        else if (mode == 0) eq = total_order_key(side_as_f64(&tgt, i)) == total_order_key(side_as_f64(&it, i));
+        else eq = side_as_i64(&tgt, i) == side_as_i64(&it, i);
+        if (!have) acc[i] = eq;
+        else acc[i] = (acc[i] == 1 || eq == 1) ? 1 : (acc[i] == -1 || eq == -1) ? -1 : 0; /* or_kleene */
+      }
+      have = 1;
+      arr_free(&it);
+    }
+    if (rc == LLKV_OK)
+      for (uint64_t i = 0; i < n; ++i) {
+        if (acc[i] < 0) continue;
+        const int v = f->negated ? !acc[i] : acc[i];
+        idv_push(&determined, d.v[c0 + i]);
+        if (v) idv_push(&matched, d.v[c0 + i]);
+      }
+    free(acc);
+    arr_free(&tgt);
+    for (uint32_t j = 0; j < n_fields; ++j) arr_free(&g[j].a);
+  }
+  idv_free(&d);
+  if (rc) { idv_free(&matched); idv_free(&determined); return rc; }
+  *rows = matched;
+  *dom = determined;
+  return LLKV_OK;
+}
+
+/* collect_row_ids_for_is_null llkv-scan/src/predicate.rs:249-331; domain: PushIsNullDomain :744-767. */
+static int32_t is_null_expr_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom) {
+  if (!f->cmp_left || !f->cmp_left_len) return fail(LLKV_INVALID_ARGUMENT, "IS NULL needs an expression");
+  if (f->cmp_left_len == 1 && f->cmp_left[0].kind == LLKV_TOK_COLUMN) {
+    llkv_filter leaf;
+    memset(&leaf, 0, sizeof leaf);
+    leaf.field_id = f->cmp_left[0].field_id;
+    leaf.op = f->negated ? LLKV_OP_IS_NOT_NULL : LLKV_OP_IS_NULL;
+    int32_t rc = filter_leaf(t, &leaf, rows);
+    if (rc == LLKV_OK) rc = field_nonnull_rows(t, leaf.field_id, dom);
+    return rc;
+  }
+  uint32_t fields[64], n_fields = 0;
+  collect_expr_fields(f->cmp_left, f->cmp_left_len, fields, &n_fields);
+  if (n_fields == 0) return fail(LLKV_UNSUPPORTED, "constant IS NULL");
+  idvec uni = {0}, inter = {0};
+  for (uint32_t j = 0; j < n_fields; ++j) {
+    idvec nn;
+    int32_t rc = field_nonnull_rows(t, fields[j], &nn);
+    if (rc) { idv_free(&uni); idv_free(&inter); return rc; }
+    if (j == 0) { uni = nn; inter = idv_and(&nn, &nn); }
+    else {
+      idvec u = idv_or(&uni, &nn), x = idv_and(&inter, &nn);
+      idv_free(&uni); idv_free(&inter); idv_free(&nn);
+      uni = u; inter = x;
+    }
+  }
+  idvec res = {0};
+  int32_t rc = LLKV_OK;
+  for (uint64_t c0 = 0; c0 < uni.n && rc == LLKV_OK; c0 += 4096) {
+    const uint64_t n = uni.n - c0 < 4096 ? uni.n - c0 : 4096;
+    gathered g[64];
+    for (uint32_t j = 0; j < n_fields; ++j) { g[j].field_id = fields[j]; g[j].a = gather_column(find_col(t, fields[j]), uni.v + c0, n); }
+    arr v;
+    memset(&v, 0, sizeof v);
+    rc = eval_program(t, f->cmp_left, f->cmp_left_len, g, n_fields, n, &v);
+    if (rc == LLKV_OK)
+      for (uint64_t i = 0; i < n; ++i) {
+        const int is_null = !v.valid[i];
+        if ((is_null && !f->negated) || (!is_null && f->negated)) idv_push(&res, uni.v[c0 + i]);
+      }
+    arr_free(&v);
+    for (uint32_t j = 0; j < n_fields; ++j) arr_free(&g[j].a);
+  }
+  idv_free(&uni);
+  if (rc) { idv_free(&res); idv_free(&inter); return rc; }
+  *rows = res;
+  *dom = inter;
   return LLKV_OK;
 }
 

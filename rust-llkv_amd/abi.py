@@ -42,7 +42,7 @@ def i128_from_words(lo: int, hi: int) -> int:
 
 
 LIT_NULL, LIT_INT128, LIT_FLOAT64, LIT_DECIMAL128, LIT_BOOLEAN, LIT_STRING, LIT_DATE32 = range(7)
-OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE, OP_COMPARE = range(1, 12)
+OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE, OP_COMPARE, OP_IN_LIST, OP_IS_NULL_EXPR = range(1, 14)
 CMP_EQ, CMP_NOT_EQ, CMP_LT, CMP_LT_EQ, CMP_GT, CMP_GT_EQ = range(1, 7)
 BOUND_UNBOUNDED, BOUND_INCLUDED, BOUND_EXCLUDED = range(3)
 EVAL_PUSH_PREDICATE, EVAL_PUSH_LITERAL, EVAL_AND, EVAL_OR, EVAL_NOT = range(1, 6)
@@ -67,7 +67,9 @@ class CFilter(C.Structure):
                 ("lower_kind", C.c_int32), ("lower", CLiteral), ("upper_kind", C.c_int32),
                 ("upper", CLiteral), ("in_list", C.POINTER(CLiteral)), ("in_len", C.c_uint32),
                 ("cmp_op", C.c_int32), ("cmp_left", C.POINTER(CExprToken)), ("cmp_left_len", C.c_uint32),
-                ("cmp_right", C.POINTER(CExprToken)), ("cmp_right_len", C.c_uint32)]
+                ("cmp_right", C.POINTER(CExprToken)), ("cmp_right_len", C.c_uint32),
+                ("list_exprs", C.POINTER(C.POINTER(CExprToken))), ("list_expr_lens", C.POINTER(C.c_uint32)), ("list_len", C.c_uint32),
+                ("negated", C.c_int32)]
 
 
 class CEvalOp(C.Structure):
@@ -239,6 +241,8 @@ class Operator:
     upper: Optional[Bound] = None
     values: Tuple[Literal, ...] = ()
     cmp: Optional[tuple] = None  # (left ScalarExpr, CMP_*, right ScalarExpr)
+    in_list: Optional[tuple] = None  # (target ScalarExpr, [item ScalarExpr], negated)
+    is_null_expr: Optional[tuple] = None  # (ScalarExpr, negated)
 
     @staticmethod
     def Equals(v):
@@ -319,6 +323,16 @@ class Expr:
     def compare(left, op: int, right) -> "Expr":
         """Expr::Compare { left, op, right } over scalar expressions (CMP_EQ … CMP_GT_EQ)."""
         return Expr.pred(Filter(0, Operator(OP_COMPARE, cmp=(_scalar(left), op, _scalar(right)))))
+
+    @staticmethod
+    def in_list(target, items, negated: bool = False) -> "Expr":
+        """Expr::InList { expr, list, negated } over scalar expressions."""
+        return Expr.pred(Filter(0, Operator(OP_IN_LIST, in_list=(_scalar(target), [_scalar(i) for i in items], bool(negated)))))
+
+    @staticmethod
+    def is_null(expr, negated: bool = False) -> "Expr":
+        """Expr::IsNull { expr, negated } over a scalar expression."""
+        return Expr.pred(Filter(0, Operator(OP_IS_NULL_EXPR, is_null_expr=(_scalar(expr), bool(negated)))))
 
     @staticmethod
     def true() -> "Expr":
@@ -523,6 +537,17 @@ class CPlan:
                 l, op, r = f.op.cmp
                 la, ra = l.to_c(self.keep), r.to_c(self.keep)
                 cf.cmp_op, cf.cmp_left, cf.cmp_left_len, cf.cmp_right, cf.cmp_right_len = op, la, len(l.tokens), ra, len(r.tokens)
+            if f.op.kind == OP_IN_LIST:
+                tgt, items, neg = f.op.in_list
+                arrs = [it.to_c(self.keep) for it in items]
+                ptrs = (C.POINTER(CExprToken) * max(1, len(arrs)))(*[C.cast(a, C.POINTER(CExprToken)) for a in arrs])
+                lens = (C.c_uint32 * max(1, len(arrs)))(*[len(it.tokens) for it in items])
+                self.keep += [ptrs, lens]
+                cf.cmp_left, cf.cmp_left_len = tgt.to_c(self.keep), len(tgt.tokens)
+                cf.list_exprs, cf.list_expr_lens, cf.list_len, cf.negated = ptrs, lens, len(arrs), int(neg)
+            if f.op.kind == OP_IS_NULL_EXPR:
+                ex, neg = f.op.is_null_expr
+                cf.cmp_left, cf.cmp_left_len, cf.negated = ex.to_c(self.keep), len(ex.tokens), int(neg)
             if f.op.kind in (OP_IN, OP_MVCC_VISIBLE):
                 lst = (CLiteral * max(1, len(f.op.values)))()
                 for j, v in enumerate(f.op.values):

@@ -259,6 +259,8 @@ struct Lowering {
   // "True" = every row.  A NULL cell never matches (table.rs:1241-1244).
   int leaf(const llkv_filter &f, std::string *rows, std::string *dom) {
     if (f.op == LLKV_OP_COMPARE) return compare_leaf(f, rows, dom);
+    if (f.op == LLKV_OP_IN_LIST) return in_list_leaf(f, rows, dom);
+    if (f.op == LLKV_OP_IS_NULL_EXPR) return is_null_expr_leaf(f, rows, dom);
     std::string v, x;
     int rc = valid_of_field(f.field_id, &v);
     if (rc) return rc;
@@ -474,6 +476,92 @@ struct Lowering {
     const int rc = expr_fast(e, n, node, &is_f64);
     *cls = is_f64 ? Side::F : Side::S64;
     return rc;
+  }
+
+  // get_common_type (llkv-compute/src/kernels.rs:179-242) over the side classes
+  static Side common_side(Side a, Side b) {
+    if (a == b) return a;
+    if (a == Side::F || b == Side::F) return Side::F;
+    const auto uns = [](Side s) { return s == Side::U32 || s == Side::U64; };
+    const auto wide = [](Side s) { return s == Side::S64 || s == Side::U64; };
+    if (uns(a) && uns(b)) return Side::U64;
+    if (!uns(a) && !uns(b)) return Side::S64;
+    return (wide(a) || wide(b)) ? Side::F : Side::S64; // signed ⋈ unsigned, 64 bits wide → Float64
+  }
+  // arrow `cast` of a side node to the common type (the integer classes share an i64 / u64 image already)
+  static std::string cast_side(const std::string &node, Side from, Side to) { return (to == Side::F && from != Side::F) ? "ToF64<" + node + ">" : node; }
+
+  // Expr::InList (evaluate_in_list_over_rows, llkv-scan/src/predicate.rs:443-560): the target is coerced item by
+  // item — its type can only widen along the list — and compared with `eq`; over rows where all fields are present
+  // nothing is NULL, so or_kleene / not are plain OR / NOT.
+  int in_list_leaf(const llkv_filter &f, std::string *out, std::string *dom) {
+    if (!f.cmp_left || !f.cmp_left_len) return fail(LLKV_INVALID_ARGUMENT, "IN list needs a target expression");
+    if (f.list_len && (!f.list_exprs || !f.list_expr_lens)) return fail(LLKV_INVALID_ARGUMENT, "IN list arrays are NULL");
+    bool any_col = false, div = has_division(f.cmp_left, f.cmp_left_len);
+    for (uint32_t i = 0; i < f.cmp_left_len; ++i) any_col |= f.cmp_left[i].kind == LLKV_TOK_COLUMN;
+    for (uint32_t k = 0; k < f.list_len; ++k) {
+      div |= has_division(f.list_exprs[k], f.list_expr_lens[k]);
+      for (uint32_t i = 0; i < f.list_expr_lens[k]; ++i) any_col |= f.list_exprs[k][i].kind == LLKV_TOK_COLUMN;
+    }
+    if (!any_col) return fail(LLKV_UNSUPPORTED, "constant IN list");
+    if (div) return fail(LLKV_UNSUPPORTED, "division inside an IN list (three-valued OR over NULL items)");
+    std::string tn;
+    Side tc;
+    int rc;
+    if ((rc = expr_side(f.cmp_left, f.cmp_left_len, &tn, &tc))) return rc;
+    std::vector<std::string> vs, eqs;
+    if ((rc = valid_of_expr(f.cmp_left, f.cmp_left_len, &vs))) return rc;
+    for (uint32_t k = 0; k < f.list_len; ++k) {
+      std::string in;
+      Side ic;
+      if ((rc = expr_side(f.list_exprs[k], f.list_expr_lens[k], &in, &ic)) || (rc = valid_of_expr(f.list_exprs[k], f.list_expr_lens[k], &vs))) return rc;
+      const Side t = common_side(tc, ic);
+      tn = cast_side(tn, tc, t); // the coerced target replaces the target (`target_array = new_target`)
+      tc = t;
+      eqs.push_back("Cmp<1," + cast_side(in, ic, t) + "," + tn + ">");
+    }
+    const std::string v = all_of(vs);
+    *dom = v.empty() ? "True" : v;
+    std::string hit = eqs.empty() ? "False" : eqs.size() == 1 ? eqs[0] : nary("Or", eqs);
+    if (f.negated) hit = hit == "False" ? "True" : "Not<" + hit + ">";
+    if (v.empty()) *out = hit;
+    else *out = hit == "True" ? v : hit == "False" ? "False" : "And<" + v + "," + hit + ">";
+    return LLKV_OK;
+  }
+
+  // Expr::IsNull over a scalar expression (collect_row_ids_for_is_null, predicate.rs:249-331).
+  int is_null_expr_leaf(const llkv_filter &f, std::string *out, std::string *dom) {
+    if (!f.cmp_left || !f.cmp_left_len) return fail(LLKV_INVALID_ARGUMENT, "IS NULL needs an expression");
+    if (f.cmp_left_len == 1 && f.cmp_left[0].kind == LLKV_TOK_COLUMN) { // bare column: the leaf filter
+      llkv_filter leaf_f{};
+      leaf_f.field_id = f.cmp_left[0].field_id;
+      leaf_f.op = f.negated ? LLKV_OP_IS_NOT_NULL : LLKV_OP_IS_NULL;
+      return leaf(leaf_f, out, dom);
+    }
+    std::vector<std::string> vs;
+    bool some_never_null = false, any_col = false;
+    int rc;
+    for (uint32_t i = 0; i < f.cmp_left_len; ++i) {
+      if (f.cmp_left[i].kind != LLKV_TOK_COLUMN) continue;
+      any_col = true;
+      std::string v;
+      if ((rc = valid_of_field(f.cmp_left[i].field_id, &v))) return rc;
+      if (v.empty()) some_never_null = true;
+      else if (std::find(vs.begin(), vs.end(), v) == vs.end()) vs.push_back(v);
+    }
+    if (!any_col) return fail(LLKV_UNSUPPORTED, "constant IS NULL");
+    std::string node;
+    bool is_f64 = false;
+    if ((rc = expr_fast(f.cmp_left, f.cmp_left_len, &node, &is_f64))) return rc;
+    std::string ve;
+    if ((rc = valid_of_node(f.cmp_left, f.cmp_left_len, node, false, &ve))) return rc;
+    // the scanned rows are those where AT LEAST ONE referenced field is present (:286-291)
+    const std::string uni = some_never_null ? "" : (vs.size() == 1 ? vs[0] : nary("Or", vs));
+    std::string hit = ve.empty() ? (f.negated ? "True" : "False") : (f.negated ? ve : "Not<" + ve + ">");
+    if (uni.empty() || hit == "False") *out = hit;
+    else *out = hit == "True" ? uni : "And<" + uni + "," + hit + ">";
+    *dom = vs.empty() ? "True" : all_of(vs); // PushIsNullDomain: rows where every field is present (:744-767)
+    return LLKV_OK;
   }
 
   int compare_leaf(const llkv_filter &f, std::string *out, std::string *dom) {

@@ -663,6 +663,31 @@ def test_division_and_modulo_match_oracle(rt, orc, abi, chunks):
         assert [x.value for x in r] == [3 + (n - 3), n - 2, 3 + (n - 3)]
 
 
+@pytest.mark.parametrize("chunks", [[10], [4096, 4097, 5], [65536, 70000]])
+def test_in_list_and_is_null_expressions_match_oracle(rt, orc, abi, chunks):
+    """EvalOp::PushInList / PushIsNull over scalar expressions, fused into the scan like every other predicate."""
+    rng = np.random.default_rng(21 + len(chunks))
+    n = sum(chunks)
+    a = rng.integers(-5, 6, size=n).astype(np.int64)
+    b = rng.integers(-5, 6, size=n).astype(np.int64)
+    f = rng.integers(-5, 6, size=n).astype(np.float64)
+    f[rng.random(n) < 0.05] = np.nan
+    f[rng.random(n) < 0.05] = -0.0
+    u = rng.integers(0, 6, size=n).astype(np.uint64)
+    va, vf = rng.random(n) > 0.2, rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, a, va), (2, abi.DT_INT64, b), (3, abi.DT_FLOAT64, f, vf), (4, abi.DT_UINT64, u)], chunks)
+    E, F, O, A, col = abi.Expr, abi.Filter, abi.Operator, abi.AggregateSpec, abi.col
+    preds = [E.in_list(col(1), [1, 2, 3]), E.in_list(col(1), [1, 2, 3], negated=True), E.not_(E.in_list(col(1), [col(2), 4])),
+             E.in_list(col(2) * 2, [col(1), col(3), 4]), E.in_list(col(3), [float("nan"), 0.0, col(2)]), E.in_list(col(4), [col(2), 3], negated=True),
+             E.in_list(col(2), [], negated=True), E.in_list(col(2), []),
+             E.is_null(col(1) + col(3)), E.is_null(col(1) + col(3), negated=True), E.not_(E.is_null(col(1) * col(2))), E.is_null(col(2) / (col(2) - 1)),
+             E.is_null(col(1) / col(2), negated=True), E.is_null(col(3)), E.any_of([E.is_null(col(1) - col(2)), E.all_of([E.in_list(col(2), [0, 1]), F(3, O.GreaterThan(0.0))])])]
+    aggs = [A.count_star(), A.sum(2), A.count(1)]
+    for i, p in enumerate(preds):
+        assert np.array_equal(rt.filter_row_ids(ht, p), orc.filter_row_ids(ot, p)), i
+        assert_values(rt.aggregate(ht, p, aggs), orc.aggregate(ot, p, aggs), f"pred {i}")
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 

@@ -204,6 +204,26 @@ def test_null_cells_lower_to_validity_masks_and_domains(lib, abi):
     assert "Keys<5,1,KeyOrNull<Valid<1>,KeyInt<0,I64,LitI<0>>,4>>" in ts and lanes == 5 * 4 + 1  # rows, first row, sum, non-NULL count
 
 
+def test_in_list_and_is_null_expression_lowering(lib, abi):
+    """Expr::InList / Expr::IsNull over scalar expressions (llkv-scan/src/predicate.rs:249-331,443-560)."""
+    rt = mod("runtime")
+    d = _desc(abi, [(1, abi.DT_INT64, True), (2, abi.DT_FLOAT64), (3, abi.DT_INT64)])
+    E, col, cnt = abi.Expr, abi.col, [abi.AggregateSpec.count_star()]
+    ts = rt.lower_plan(d, E.in_list(col(3), [1, col(2), 4]), cnt)[0]  # the Float64 item widens the target for the items after it
+    assert "Or<Cmp<1,LitI<0>,Col<0,I64>>,Cmp<1,Col<1,F64>,ToF64<Col<0,I64>>>,Cmp<1,ToF64<LitI<1>>,ToF64<Col<0,I64>>>>" in ts
+    ts = rt.lower_plan(d, E.in_list(col(1), [7], negated=True), cnt)[0]
+    assert "Cols<I64,U8>,And<Valid<1>,Not<Cmp<1,LitI<0>,Col<0,I64>>>>" in ts
+    assert rt.lower_plan(d, E.is_null(col(1)), cnt)[0] == rt.lower_plan(d, E.pred(abi.Filter(1, abi.Operator.IsNull)), cnt)[0]
+    ts = rt.lower_plan(d, E.is_null(col(1) + col(3)), cnt)[0]  # a never-NULL field makes every row part of the scan
+    assert ",Not<VE<Bin<1,ColN<1,I64,0>,Col<2,I64>>>>,Keys" in ts
+    ts = rt.lower_plan(d, E.is_null(col(3) / col(3), negated=True), cnt)[0]
+    assert ",VE<Div<Col<0,I64>,Col<0,I64>>>,Keys" in ts
+    for bad in (E.in_list(abi.ScalarExpr.literal(3), [1, 2]), E.in_list(col(3), [col(3) / 2]), E.is_null(abi.ScalarExpr.literal(1) + 2)):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.lower_plan(d, bad, cnt)
+        assert e.value.kind == "Unsupported"
+
+
 def test_int_sum_uses_statistics_to_exclude_overflow(lib, abi):
     rt = mod("runtime")
     d = (abi.CColumnDesc * 1)()

@@ -212,3 +212,25 @@ def test_compare_uses_total_order_and_common_types(orc, abi):
     with pytest.raises(abi.LlkvError) as e:
         ids(E.all_of([E.compare(col(3) * 2**12, abi.CMP_GT, col(3)), abi.Filter(3, abi.Operator.Equals(5))]))
     assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
+
+
+def test_in_list_and_is_null_over_expressions(orc, abi):
+    """Expr::InList (llkv-scan/src/predicate.rs:443-560) and Expr::IsNull over scalar expressions (:249-331):
+    domains, item-by-item coercion of the target, totalOrder equality, the union-of-fields quirk of IS NULL."""
+    E, col = abi.Expr, abi.col
+    t = orc.OracleTable(6)
+    t.add(1, abi.DT_INT64, np.array([1, 2, 3, 4, 5, 6], dtype=np.int64), [True, True, False, True, True, False])
+    t.add(2, abi.DT_FLOAT64, np.array([1.0, float("nan"), 3.0, -0.0, 5.5, 0.0]), [True, True, True, True, False, False])
+    ids = lambda e: list(orc.filter_row_ids(t, e))
+    assert ids(E.in_list(col(1), [1, 4, 9])) == [0, 3]
+    assert ids(E.in_list(col(1), [1, 4, 9], negated=True)) == [1, 4]          # NULL targets are outside the domain
+    assert ids(E.not_(E.in_list(col(1), [1, 4, 9]))) == [1, 4]
+    assert ids(E.in_list(col(1), [], negated=True)) == [0, 1, 3, 4]            # empty list: false, negated true
+    assert ids(E.in_list(col(1) + 0, [col(2), 4])) == [0, 3]                   # Int64 target coerced to Float64 by the first item
+    assert ids(E.in_list(col(2), [float("nan"), 0.0])) == [1]                  # NaN = NaN, -0.0 ≠ 0.0 (row 5 has NULLs)
+    # IS NULL over an expression: rows where at least one field is present and the value is NULL
+    assert ids(E.is_null(col(1) + col(2))) == [2, 4]                           # row 5 (both absent) is never scanned
+    assert ids(E.is_null(col(1) + col(2), negated=True)) == [0, 1, 3]
+    assert ids(E.not_(E.is_null(col(1) + col(2)))) == [0, 1, 3]                # NOT: within the rows where every field is present
+    assert ids(E.is_null(col(1))) == [2, 5] and ids(E.is_null(col(1), negated=True)) == [0, 1, 3, 4]  # bare column: the leaf
+    assert ids(E.is_null(col(2) / (col(1) - 1))) == [0, 2, 4]                  # x / 0 is NULL
