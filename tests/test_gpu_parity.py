@@ -784,6 +784,70 @@ def test_random_predicate_trees_match_oracle(rt, orc, abi, seed):
     assert checked >= 10
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_aggregate_lists_match_oracle(rt, orc, abi, seed):
+    """Seeded random aggregate lists over bare columns and random expressions (NULL cells, + - * / %), ungrouped
+    (fast / generic projection typing) and grouped (PlanValue typing; dense and sort-based routes)."""
+    rng = np.random.default_rng(500 + seed)
+    chunks = [4096, 4097, 777]
+    n = sum(chunks)
+    i1 = rng.integers(-50, 50, size=n).astype(np.int64)
+    i2 = rng.integers(-3, 4, size=n).astype(np.int64)
+    f3 = rng.integers(-40, 40, size=n).astype(np.float64) / 4
+    f3[rng.random(n) < 0.02] = np.nan
+    f4 = rng.integers(1, 9, size=n).astype(np.float64) / 2
+    key = np.array([ord("a"), ord("b"), ord("c")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    key2 = rng.integers(0, 700, size=n).astype(np.int64) * 1000  # sparse: the sort-based route
+    v1, v3 = rng.random(n) > 0.2, rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i1, v1), (2, abi.DT_INT64, i2), (3, abi.DT_FLOAT64, f3, v3), (4, abi.DT_FLOAT64, f4),
+                                       (5, abi.DT_UTF8, key), (6, abi.DT_INT64, key2)], chunks)
+    A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+
+    def expr(grouped):
+        e = col(int(rng.choice([1, 2, 3, 4])))
+        for _ in range(int(rng.integers(1, 4))):
+            other = col(int(rng.choice([1, 2, 3, 4]))) if rng.random() < 0.6 else (int(rng.integers(1, 5)) if rng.random() < 0.5 else float(rng.integers(1, 5)) / 2)
+            op = rng.choice(["+", "-", "*", "/", "%"], p=[0.3, 0.25, 0.25, 0.1, 0.1])
+            e = {"+": lambda a, b: a + b, "-": lambda a, b: a - b, "*": lambda a, b: a * b, "/": lambda a, b: a / b, "%": lambda a, b: a % b}[op](e, other)
+        return e
+
+    def agg_list(grouped):
+        out = [A.count_star()]
+        for _ in range(int(rng.integers(2, 6))):
+            arg = int(rng.choice([1, 3, 4])) if rng.random() < 0.4 else expr(grouped)
+            kind = rng.choice(["sum", "avg", "min", "max", "count", "total", "count_nulls"])
+            out.append(getattr(A, kind)(arg))
+        return out
+
+    checked = 0
+    for k in range(6):
+        pred = [None, [F(2, O.GreaterThanOrEquals(0))], [F(1, O.LessThan(20))]][k % 3]
+        for grouped, keys in ((False, None), (True, [5]), (True, [6])):
+            aggs = agg_list(grouped)
+            run_o = (lambda: orc.groupby(ot, pred, keys, aggs, True)) if grouped else (lambda: orc.aggregate(ot, pred, aggs))
+            run_g = (lambda: rt.groupby(ht, pred, keys, aggs, True)) if grouped else (lambda: rt.aggregate(ht, pred, aggs))
+            try:
+                want = run_o()
+            except abi.LlkvError as e:
+                with pytest.raises(abi.LlkvError) as g:
+                    run_g()
+                assert g.value.kind in (e.kind, "Unsupported"), (k, grouped, e, g.value)
+                continue
+            try:
+                got = run_g()
+            except abi.LlkvError as g:
+                assert g.kind == "Unsupported", (k, grouped, g)
+                continue
+            if grouped:
+                assert [[x.value for x in r.keys] for r in got] == [[x.value for x in r.keys] for r in want]
+                for a, b in zip(got, want):
+                    assert_values(a.values, b.values, f"seed {seed} case {k} grouped")
+            else:
+                assert_values(got, want, f"seed {seed} case {k}")
+            checked += 1
+    assert checked >= 8
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 
