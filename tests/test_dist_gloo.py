@@ -175,3 +175,42 @@ def test_two_rank_join_groupby_topk_is_bit_identical_to_one_rank(tmp_path, clust
     assert [int(r[0]) for r in got[:-1]] == [10_000 + g for g in want]
     assert [int(r[1]) for r in got[:-1]] == [int(np.float64(sums[g]).view(np.uint64)) for g in want]  # bit-exact f64 sums
     assert [int(r[2]) for r in got[:-1]] == [int(cnt[g]) for g in want]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Table-wide column statistics for sharded tables (dist.share_column_stats): every rank must install the same
+# (min, max), or the ranks would lower different plans.
+# ---------------------------------------------------------------------------------------------------
+class _StatsTable:
+    def __init__(self, local):
+        self.local, self.installed = local, {}
+
+    def local_column_stats(self, f):
+        return self.local.get(f)
+
+    def set_column_stats(self, f, lo, hi):
+        self.installed[f] = (lo, hi)
+
+
+def _stats_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dmod = mod("dist")
+    local = [{4: (1, 30), 10: (8035, 9000), 6: None}, {4: (5, 50), 10: (8900, 10471), 6: None}][rank]
+    t = _StatsTable(local)
+    dmod.share_column_stats(dist, t, [4, 10, 6], world)
+    np.save(out_path + f".{rank}.npy", np.array([t.installed.get(4, (0, 0)), t.installed.get(10, (0, 0)), t.installed.get(6, (-1, -1))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_install_identical_table_wide_statistics(tmp_path):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "stats")
+    mp.spawn(_stats_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    assert a.tolist() == b.tolist() == [[1, 50], [8035, 10471], [-1, -1]]  # a column without statistics stays without
