@@ -319,6 +319,17 @@ template <class E, int LK, class LO, int UK, class HI> struct Range {
 template <class E, class V> struct Eq {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return E::eval(c, j) == V::eval(c, j); }
 };
+// Any predicate over a dictionary-coded (≤ 256 entries) Utf8 column: the host evaluates it once per dictionary
+// string and hands over the 256-bit set of qualifying codes (ordering predicates compare strings as
+// Rust's `str::cmp`, llkv-expr/src/typed_predicate.rs:171-185).
+template <class E, class M0, class M1, class M2, class M3> struct InMask {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    const uint32_t code = (uint32_t)E::eval(c, j);
+    const uint32_t w = code >> 6;
+    const uint64_t m = w == 0 ? M0::eval(c, j) : w == 1 ? M1::eval(c, j) : w == 2 ? M2::eval(c, j) : M3::eval(c, j);
+    return (m >> (code & 63)) & 1u;
+  }
+};
 template <class E, class... Vs> struct In {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) {
     const auto v = E::eval(c, j);

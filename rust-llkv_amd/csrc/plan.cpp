@@ -331,7 +331,43 @@ struct Lowering {
         *out = "In<" + col_node(slot, ci->dtype) + lits + ">";
         return LLKV_OK;
       }
-      return fail(LLKV_UNSUPPORTED, "ordering predicates on dictionary-coded Utf8 columns");
+      // ordering predicates: evaluate once per dictionary string (str::cmp = byte order), ship the set of codes
+      auto lit_str = [&](const llkv_literal &l, std::string *out_s) -> int {
+        if (l.tag != LLKV_LIT_STRING || !l.str) return fail(LLKV_PREDICATE_BUILD, std::string("literal cast error: expected string, got ") + lit_kind(l));
+        *out_s = l.str;
+        return LLKV_OK;
+      };
+      std::string lo_s, hi_s;
+      int lo_k = LLKV_BOUND_UNBOUNDED, hi_k = LLKV_BOUND_UNBOUNDED;
+      switch (f.op) {
+      case LLKV_OP_GT: lo_k = LLKV_BOUND_EXCLUDED; if ((rc = lit_str(f.value, &lo_s))) return rc; break;
+      case LLKV_OP_GE: lo_k = LLKV_BOUND_INCLUDED; if ((rc = lit_str(f.value, &lo_s))) return rc; break;
+      case LLKV_OP_LT: hi_k = LLKV_BOUND_EXCLUDED; if ((rc = lit_str(f.value, &hi_s))) return rc; break;
+      case LLKV_OP_LE: hi_k = LLKV_BOUND_INCLUDED; if ((rc = lit_str(f.value, &hi_s))) return rc; break;
+      case LLKV_OP_RANGE:
+        lo_k = f.lower_kind; hi_k = f.upper_kind;
+        if (lo_k != LLKV_BOUND_UNBOUNDED && (rc = lit_str(f.lower, &lo_s))) return rc;
+        if (hi_k != LLKV_BOUND_UNBOUNDED && (rc = lit_str(f.upper, &hi_s))) return rc;
+        break;
+      default: return fail(LLKV_PREDICATE_BUILD, "unsupported operator for typed predicate: operator lacks string literal support");
+      }
+      uint64_t mask[4] = {0, 0, 0, 0};
+      bool any = false;
+      for (size_t i = 0; i < ci->dictionary.size() && i < 256; ++i) {
+        const std::string &v = ci->dictionary[i];
+        bool ok = true;
+        if (lo_k == LLKV_BOUND_INCLUDED) ok = ok && v.compare(lo_s) >= 0;
+        if (lo_k == LLKV_BOUND_EXCLUDED) ok = ok && v.compare(lo_s) > 0;
+        if (hi_k == LLKV_BOUND_INCLUDED) ok = ok && v.compare(hi_s) <= 0;
+        if (hi_k == LLKV_BOUND_EXCLUDED) ok = ok && v.compare(hi_s) < 0;
+        if (ok) { mask[i >> 6] |= 1ull << (i & 63); any = true; }
+      }
+      if (!any) { *out = "False"; return LLKV_OK; }
+      if ((rc = slot_of(f.field_id, &ci, &slot))) return rc;
+      std::string m[4];
+      for (int w = 0; w < 4; ++w) if ((rc = lit_i((int64_t)mask[w], &m[w], "LitU"))) return rc;
+      *out = "InMask<" + col_node(slot, ci->dtype) + "," + m[0] + "," + m[1] + "," + m[2] + "," + m[3] + ">";
+      return LLKV_OK;
     }
     if (ci->dtype == LLKV_DT_DECIMAL128) // llkv-table/src/table.rs:1160-1167
       return fail(LLKV_INTERNAL, "Filtering on type Decimal128(" + std::to_string(ci->precision) + ", " + std::to_string(ci->scale) + ") is not supported");

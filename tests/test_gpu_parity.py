@@ -451,7 +451,10 @@ def test_null_cells_match_oracle(rt, orc, abi, chunks):
              E.pred(F(1, O.Range(B.Unbounded, B.Unbounded))), E.not_(F(1, O.Range(B.Unbounded, B.Unbounded))),
              E.compare(col(1), abi.CMP_GT, col(2)), E.not_(E.compare(col(1) + col(3), abi.CMP_LT_EQ, col(4))),
              E.all_of([E.compare(col(2), abi.CMP_NOT_EQ, 0.0), E.pred(F(6, O.Equals("zz")))]),
-             E.not_(E.not_(F(2, O.GreaterThan(0.0))))]
+             E.not_(E.not_(F(2, O.GreaterThan(0.0)))),
+             # ordering predicates on a dictionary-coded Utf8 column: the set of qualifying codes (str::cmp order)
+             [F(6, O.GreaterThan("x"))], E.not_(F(6, O.Range(B.Included("y"), B.Unbounded))), [F(6, O.LessThanOrEquals("y")), F(5, O.GreaterThanOrEquals("b"))],
+             E.pred(F(6, O.Range(B.Excluded("x"), B.Excluded("zz")))), [F(6, O.LessThan("a"))]]
     aggs = [A.count_star(), A.count(1), A.count_nulls(2), A.sum(1), A.avg(1), A.min(1), A.max(1), A.min(2), A.max(2), A.total(2), A.avg(2),
             A.sum(col(1) * col(2)), A.sum(col(1) * 3 - col(3)), A.sum(4), A.count(col(1) + col(3)), A.count(6)]
     gaggs = [A.count_star(), A.count(1), A.sum(1), A.avg(2), A.min(1), A.max(2), A.sum(col(1) * col(2)), A.sum(4)]

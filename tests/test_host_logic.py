@@ -204,6 +204,23 @@ def test_null_cells_lower_to_validity_masks_and_domains(lib, abi):
     assert "Keys<5,1,KeyOrNull<Valid<1>,KeyInt<0,I64,LitI<0>>,4>>" in ts and lanes == 5 * 4 + 1  # rows, first row, sum, non-NULL count
 
 
+def test_utf8_ordering_predicates_become_code_sets(lib, abi):
+    """Utf8 columns are 1-byte dictionary codes in HBM: an ordering predicate is evaluated once per dictionary
+    string on the host (str::cmp, llkv-expr/src/typed_predicate.rs:171-185) and shipped as a 256-bit code set."""
+    rt = mod("runtime")
+    d = (abi.CColumnDesc * 1)()
+    names = (C.c_char_p * 4)(b"pear", b"apple", b"fig", b"zebra")  # codes in first-appearance order, not sorted
+    d[0].field_id, d[0].dtype, d[0].rows, d[0].dict_size, d[0].dictionary = 1, abi.DT_UTF8, 10, 4, names
+    F, O, B, cnt = abi.Filter, abi.Operator, abi.Bound, [abi.AggregateSpec.count_star()]
+    ts, _, _ = rt.lower_plan(d, [F(1, O.GreaterThan("fig"))], cnt)
+    assert "InMask<Col<0,U8>,LitU<0>,LitU<1>,LitU<2>,LitU<3>>" in ts
+    assert "And<False>" in rt.lower_plan(d, [F(1, O.LessThan("apple"))], cnt)[0]      # no dictionary string qualifies
+    assert "InMask<" in rt.lower_plan(d, [F(1, O.Range(B.Included("b"), B.Excluded("q")))], cnt)[0]
+    with pytest.raises(abi.LlkvError) as e:
+        rt.lower_plan(d, [F(1, O.LessThan(3))], cnt)
+    assert e.value.kind == "PredicateBuild"
+
+
 def test_in_list_and_is_null_expression_lowering(lib, abi):
     """Expr::InList / Expr::IsNull over scalar expressions (llkv-scan/src/predicate.rs:249-331,443-560)."""
     rt = mod("runtime")
