@@ -113,7 +113,13 @@ typedef enum llkv_operator_kind {
   /* Expr::IsNull { expr, negated } over a scalar expression (EvalOp::PushIsNull, collect_row_ids_for_is_null
    * predicate.rs:249-331): a bare column is the IS [NOT] NULL leaf; otherwise the rows — among those where at
    * least one referenced field is present — whose value is (not) NULL.  Uses cmp_left, negated.            */
-  LLKV_OP_IS_NULL_EXPR = 13
+  LLKV_OP_IS_NULL_EXPR = 13,
+  /* Operator::{StartsWith, EndsWith, Contains}{pattern, case_sensitive} over Utf8 columns (llkv-expr/src/
+   * typed_predicate.rs:186-210,439-458): `value` holds the pattern (String literal), `case_sensitive` the flag;
+   * case-insensitive = both sides through to_lowercase (ASCII strings on the GPU path).                  */
+  LLKV_OP_STARTS_WITH = 14,
+  LLKV_OP_ENDS_WITH = 15,
+  LLKV_OP_CONTAINS = 16
 } llkv_operator_kind;
 
 typedef enum llkv_compare_op { /* llkv_expr::CompareOp */
@@ -150,6 +156,7 @@ typedef struct llkv_filter {
   const uint32_t *list_expr_lens;
   uint32_t list_len;
   int32_t negated;             /* LLKV_OP_IN_LIST / LLKV_OP_IS_NULL_EXPR                  */
+  int32_t case_sensitive;      /* LLKV_OP_STARTS_WITH / ENDS_WITH / CONTAINS              */
 } llkv_filter;
 
 /* Predicate program — `EvalOp` stack program, llkv-compute/src/program.rs:48-78,

@@ -219,6 +219,7 @@ typedef struct tpred {
   nat lo, hi;
   nat *in;
   uint32_t n_in;
+  int case_sensitive; /* StartsWith / EndsWith / Contains */
 } tpred;
 
 static int vclass_of(int32_t dtype) {
@@ -278,9 +279,29 @@ static int32_t build_predicate(const llkv_filter *f, int32_t dtype, tpred *p) {
     for (uint32_t i = 0; i < f->in_len; ++i)
       if ((rc = cast_native(&f->in_list[i], dtype, &p->in[i]))) { free(p->in); p->in = NULL; return rc; }
     return LLKV_OK;
+  case LLKV_OP_STARTS_WITH: case LLKV_OP_ENDS_WITH: case LLKV_OP_CONTAINS: /* typed_predicate.rs:439-458: strings only */
+    if (p->vclass != VC_STR) return fail(LLKV_PREDICATE_BUILD, "unsupported operator for typed predicate: operator lacks typed literal support");
+    p->case_sensitive = f->case_sensitive;
+    return cast_native(&f->value, dtype, &p->a);
   default:
     return fail(LLKV_PREDICATE_BUILD, "unsupported operator for typed predicate: operator lacks typed literal support");
   }
+}
+
+/* String patterns, typed_predicate.rs:186-210: case-insensitive = both sides through to_lowercase (restated for
+ * ASCII; other bytes are left alone). */
+static int str_pattern(int kind, const char *v, const char *pat, int case_sensitive) {
+  size_t nv = strlen(v), np = strlen(pat);
+  if (np > nv) return 0;
+  char *a = xmalloc(nv + 1), *b = xmalloc(np + 1);
+  for (size_t i = 0; i <= nv; ++i) a[i] = (!case_sensitive && v[i] >= 'A' && v[i] <= 'Z') ? (char)(v[i] + 32) : v[i];
+  for (size_t i = 0; i <= np; ++i) b[i] = (!case_sensitive && pat[i] >= 'A' && pat[i] <= 'Z') ? (char)(pat[i] + 32) : pat[i];
+  int r;
+  if (kind == LLKV_OP_STARTS_WITH) r = memcmp(a, b, np) == 0;
+  else if (kind == LLKV_OP_ENDS_WITH) r = memcmp(a + nv - np, b, np) == 0;
+  else r = strstr(a, b) != NULL;
+  free(a); free(b);
+  return r;
 }
 
 /* Rust partial_cmp: -1 / 0 / 1, or 2 for "None" (NaN involved). */
@@ -320,6 +341,7 @@ static int pred_matches(const tpred *p, nat v) {
   case LLKV_OP_IN:
     for (uint32_t i = 0; i < p->n_in; ++i) if (peq(p->vclass, v, p->in[i])) return 1;
     return 0;
+  case LLKV_OP_STARTS_WITH: case LLKV_OP_ENDS_WITH: case LLKV_OP_CONTAINS: return str_pattern(p->kind, v.s, p->a.s, p->case_sensitive);
   default: return 0;
   }
 }

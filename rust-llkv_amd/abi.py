@@ -42,7 +42,7 @@ def i128_from_words(lo: int, hi: int) -> int:
 
 
 LIT_NULL, LIT_INT128, LIT_FLOAT64, LIT_DECIMAL128, LIT_BOOLEAN, LIT_STRING, LIT_DATE32 = range(7)
-OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE, OP_COMPARE, OP_IN_LIST, OP_IS_NULL_EXPR = range(1, 14)
+OP_EQUALS, OP_RANGE, OP_GT, OP_GE, OP_LT, OP_LE, OP_IN, OP_IS_NULL, OP_IS_NOT_NULL, OP_MVCC_VISIBLE, OP_COMPARE, OP_IN_LIST, OP_IS_NULL_EXPR, OP_STARTS_WITH, OP_ENDS_WITH, OP_CONTAINS = range(1, 17)
 CMP_EQ, CMP_NOT_EQ, CMP_LT, CMP_LT_EQ, CMP_GT, CMP_GT_EQ = range(1, 7)
 BOUND_UNBOUNDED, BOUND_INCLUDED, BOUND_EXCLUDED = range(3)
 EVAL_PUSH_PREDICATE, EVAL_PUSH_LITERAL, EVAL_AND, EVAL_OR, EVAL_NOT = range(1, 6)
@@ -69,7 +69,7 @@ class CFilter(C.Structure):
                 ("cmp_op", C.c_int32), ("cmp_left", C.POINTER(CExprToken)), ("cmp_left_len", C.c_uint32),
                 ("cmp_right", C.POINTER(CExprToken)), ("cmp_right_len", C.c_uint32),
                 ("list_exprs", C.POINTER(C.POINTER(CExprToken))), ("list_expr_lens", C.POINTER(C.c_uint32)), ("list_len", C.c_uint32),
-                ("negated", C.c_int32)]
+                ("negated", C.c_int32), ("case_sensitive", C.c_int32)]
 
 
 class CEvalOp(C.Structure):
@@ -243,6 +243,19 @@ class Operator:
     cmp: Optional[tuple] = None  # (left ScalarExpr, CMP_*, right ScalarExpr)
     in_list: Optional[tuple] = None  # (target ScalarExpr, [item ScalarExpr], negated)
     is_null_expr: Optional[tuple] = None  # (ScalarExpr, negated)
+    case_sensitive: bool = True  # StartsWith / EndsWith / Contains
+
+    @staticmethod
+    def StartsWith(pattern: str, case_sensitive: bool = True):
+        return Operator(OP_STARTS_WITH, value=Literal.of(pattern), case_sensitive=case_sensitive)
+
+    @staticmethod
+    def EndsWith(pattern: str, case_sensitive: bool = True):
+        return Operator(OP_ENDS_WITH, value=Literal.of(pattern), case_sensitive=case_sensitive)
+
+    @staticmethod
+    def Contains(pattern: str, case_sensitive: bool = True):
+        return Operator(OP_CONTAINS, value=Literal.of(pattern), case_sensitive=case_sensitive)
 
     @staticmethod
     def Equals(v):
@@ -537,6 +550,8 @@ class CPlan:
                 l, op, r = f.op.cmp
                 la, ra = l.to_c(self.keep), r.to_c(self.keep)
                 cf.cmp_op, cf.cmp_left, cf.cmp_left_len, cf.cmp_right, cf.cmp_right_len = op, la, len(l.tokens), ra, len(r.tokens)
+            if f.op.kind in (OP_STARTS_WITH, OP_ENDS_WITH, OP_CONTAINS):
+                cf.case_sensitive = int(f.op.case_sensitive)
             if f.op.kind == OP_IN_LIST:
                 tgt, items, neg = f.op.in_list
                 arrs = [it.to_c(self.keep) for it in items]

@@ -337,9 +337,20 @@ struct Lowering {
         *out_s = l.str;
         return LLKV_OK;
       };
-      std::string lo_s, hi_s;
+      std::string lo_s, hi_s, pat;
       int lo_k = LLKV_BOUND_UNBOUNDED, hi_k = LLKV_BOUND_UNBOUNDED;
-      switch (f.op) {
+      const bool pattern_op = f.op == LLKV_OP_STARTS_WITH || f.op == LLKV_OP_ENDS_WITH || f.op == LLKV_OP_CONTAINS;
+      auto ascii = [](const std::string &x) { for (unsigned char ch : x) if (ch >= 0x80) return false; return true; };
+      auto lower = [](std::string x) { for (char &ch : x) if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32); return x; };
+      if (pattern_op) { // Operator::{StartsWith, EndsWith, Contains} (typed_predicate.rs:186-210)
+        if ((rc = lit_str(f.value, &pat))) return rc;
+        if (!f.case_sensitive) {
+          if (!ascii(pat)) return fail(LLKV_UNSUPPORTED, "case-insensitive pattern with non-ASCII characters (Unicode to_lowercase)");
+          pat = lower(pat);
+        }
+      }
+      switch (pattern_op ? LLKV_OP_RANGE + 1000 : f.op) {
+      case LLKV_OP_RANGE + 1000: break;
       case LLKV_OP_GT: lo_k = LLKV_BOUND_EXCLUDED; if ((rc = lit_str(f.value, &lo_s))) return rc; break;
       case LLKV_OP_GE: lo_k = LLKV_BOUND_INCLUDED; if ((rc = lit_str(f.value, &lo_s))) return rc; break;
       case LLKV_OP_LT: hi_k = LLKV_BOUND_EXCLUDED; if ((rc = lit_str(f.value, &hi_s))) return rc; break;
@@ -356,6 +367,13 @@ struct Lowering {
       for (size_t i = 0; i < ci->dictionary.size() && i < 256; ++i) {
         const std::string &v = ci->dictionary[i];
         bool ok = true;
+        if (pattern_op) {
+          if (!f.case_sensitive && !ascii(v)) return fail(LLKV_UNSUPPORTED, "case-insensitive pattern over non-ASCII strings (Unicode to_lowercase)");
+          const std::string x = f.case_sensitive ? v : lower(v);
+          if (f.op == LLKV_OP_STARTS_WITH) ok = x.size() >= pat.size() && x.compare(0, pat.size(), pat) == 0;
+          else if (f.op == LLKV_OP_ENDS_WITH) ok = x.size() >= pat.size() && x.compare(x.size() - pat.size(), pat.size(), pat) == 0;
+          else ok = x.find(pat) != std::string::npos;
+        }
         if (lo_k == LLKV_BOUND_INCLUDED) ok = ok && v.compare(lo_s) >= 0;
         if (lo_k == LLKV_BOUND_EXCLUDED) ok = ok && v.compare(lo_s) > 0;
         if (hi_k == LLKV_BOUND_INCLUDED) ok = ok && v.compare(hi_s) <= 0;

@@ -95,6 +95,20 @@ def build_filter(abi, f):
     return abi.Filter(f["field"], ctor(f["value"]))
 
 
+def build_string_operator(abi, op):
+    """tests/golden/string_predicates.json operator → abi.Operator."""
+    O, B = abi.Operator, abi.Bound
+    k = op["kind"]
+    if k == "eq":
+        return O.Equals(op["value"])
+    if k == "in":
+        return O.In(op["values"])
+    if k == "range":
+        bound = lambda b: B.Unbounded if b is None else (B.Included(b[1]) if b[0] == "included" else B.Excluded(b[1]))
+        return O.Range(bound(op.get("lower")), bound(op.get("upper")))
+    return {"starts_with": O.StartsWith, "ends_with": O.EndsWith, "contains": O.Contains}[k](op["pattern"], op["case_sensitive"])
+
+
 def build_expr(abi, e):
     if "col" in e:
         return abi.ScalarExpr.column(e["col"])

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 if __name__ == "__main__":
-    for fn in ("table_scan.json", "joins.json", "aggregates.json"):
+    for fn in ("table_scan.json", "joins.json", "aggregates.json", "string_predicates.json"):
         with open(os.path.join(HERE, fn)) as f:
             doc = json.load(f)
         assert "source" in doc

@@ -454,7 +454,8 @@ def test_null_cells_match_oracle(rt, orc, abi, chunks):
              E.not_(E.not_(F(2, O.GreaterThan(0.0)))),
              # ordering predicates on a dictionary-coded Utf8 column: the set of qualifying codes (str::cmp order)
              [F(6, O.GreaterThan("x"))], E.not_(F(6, O.Range(B.Included("y"), B.Unbounded))), [F(6, O.LessThanOrEquals("y")), F(5, O.GreaterThanOrEquals("b"))],
-             E.pred(F(6, O.Range(B.Excluded("x"), B.Excluded("zz")))), [F(6, O.LessThan("a"))]]
+             E.pred(F(6, O.Range(B.Excluded("x"), B.Excluded("zz")))), [F(6, O.LessThan("a"))],
+             [F(6, O.StartsWith("z"))], E.not_(F(6, O.EndsWith("Z", False))), E.any_of([F(6, O.Contains("y")), F(5, O.Contains("B", False))])]
     aggs = [A.count_star(), A.count(1), A.count_nulls(2), A.sum(1), A.avg(1), A.min(1), A.max(1), A.min(2), A.max(2), A.total(2), A.avg(2),
             A.sum(col(1) * col(2)), A.sum(col(1) * 3 - col(3)), A.sum(4), A.count(col(1) + col(3)), A.count(6)]
     gaggs = [A.count_star(), A.count(1), A.sum(1), A.avg(2), A.min(1), A.max(2), A.sum(col(1) * col(2)), A.sum(4)]
@@ -849,6 +850,17 @@ def test_random_aggregate_lists_match_oracle(rt, orc, abi, seed):
                 assert_values(got, want, f"seed {seed} case {k}")
             checked += 1
     assert checked >= 8
+
+
+@pytest.mark.parametrize("case", golden("string_predicates.json")["cases"], ids=lambda c: c["name"])
+def test_reference_string_predicate_known_answers(rt, abi, case):
+    """typed_predicate.rs:538-600 through the GPU path: string predicates run on dictionary codes, the host having
+    evaluated the predicate once per dictionary string."""
+    from conftest import build_string_operator
+    ht = rt.HipTable(1, [len(case["values"])])
+    ht.append_utf8_column(1, case["values"])
+    ids = set(rt.filter_row_ids(ht, [abi.Filter(1, build_string_operator(abi, case["op"]))]).tolist())
+    assert [i in ids for i in range(len(case["values"]))] == case["expect"]
 
 
 JOINS = golden("joins.json")

@@ -3,11 +3,12 @@
 import numpy as np
 import pytest
 
-from conftest import build_aggs, build_filter, build_predicate, build_expr, golden, oracle_table, same_value, DTYPES
+from conftest import build_aggs, build_filter, build_predicate, build_expr, build_string_operator, golden, oracle_table, same_value, DTYPES
 
 TABLE = golden("table_scan.json")
 JOINS = golden("joins.json")
 AGGS = golden("aggregates.json")
+STRINGS = golden("string_predicates.json")
 
 
 @pytest.mark.parametrize("case", TABLE["cases"], ids=lambda c: c["name"])
@@ -234,3 +235,11 @@ def test_in_list_and_is_null_over_expressions(orc, abi):
     assert ids(E.not_(E.is_null(col(1) + col(2)))) == [0, 1, 3]                # NOT: within the rows where every field is present
     assert ids(E.is_null(col(1))) == [2, 5] and ids(E.is_null(col(1), negated=True)) == [0, 1, 3, 4]  # bare column: the leaf
     assert ids(E.is_null(col(2) / (col(1) - 1))) == [0, 2, 4]                  # x / 0 is NULL
+
+
+@pytest.mark.parametrize("case", STRINGS["cases"], ids=lambda c: c["name"])
+def test_string_predicate_cases(case, orc, abi):
+    """The reference's string predicate known answers (typed_predicate.rs:538-600) through the oracle's leaf filter."""
+    t = orc.OracleTable(len(case["values"])).add(1, abi.DT_UTF8, case["values"])
+    ids = set(orc.filter_row_ids(t, [abi.Filter(1, build_string_operator(abi, case["op"]))]).tolist())
+    assert [i in ids for i in range(len(case["values"]))] == case["expect"]
