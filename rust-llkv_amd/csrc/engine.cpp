@@ -37,8 +37,15 @@ int set_error(int code, const std::string &msg) {
 Context g_ctx;
 
 int ensure_device() {
-  if (g_ctx.ready) return LLKV_OK;
-  return set_error(LLKV_NO_DEVICE, "llkv_hip_init() has not bound a HIP device (no GPU path without one)");
+  if (!g_ctx.ready) return set_error(LLKV_NO_DEVICE, "llkv_hip_init() has not bound a HIP device (no GPU path without one)");
+  // the current HIP device is per host thread: a call arriving on another thread of the process (the traits
+  // are Send + Sync, llkv-executor/src/types/storage.rs:20-50) must land on the GPU this process is bound to
+  static thread_local int bound = -1;
+  if (bound != g_ctx.device) {
+    if (hipSetDevice(g_ctx.device) != hipSuccess) return set_error(LLKV_NO_DEVICE, "hipSetDevice failed on this thread");
+    bound = g_ctx.device;
+  }
+  return LLKV_OK;
 }
 
 static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
@@ -1068,6 +1075,7 @@ llkv_status llkv_hip_query_prepare_groupby(const llkv_hip_table *table, const ll
 void llkv_hip_query_free(llkv_hip_query *query) { delete reinterpret_cast<Query *>(query); }
 
 llkv_status llkv_hip_query_launch(llkv_hip_query *query, void *hip_stream) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   return (llkv_status) reinterpret_cast<Query *>(query)->launch((hipStream_t)hip_stream);
 }
@@ -1085,11 +1093,13 @@ llkv_status llkv_hip_query_exchange_buffer(llkv_hip_query *query, void **device_
 }
 
 llkv_status llkv_hip_query_finish(llkv_hip_query *query, void *hip_stream) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   return (llkv_status) reinterpret_cast<Query *>(query)->finish((hipStream_t)hip_stream);
 }
 
 llkv_status llkv_hip_query_read_exchange(llkv_hip_query *query, uint64_t *out, uint64_t len_i64) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   Query *q = reinterpret_cast<Query *>(query);
   if (!q || !out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
   if (q->n_launched == 0) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "no execution launched");
@@ -1103,6 +1113,7 @@ llkv_status llkv_hip_query_read_exchange(llkv_hip_query *query, uint64_t *out, u
 }
 
 llkv_status llkv_hip_query_finish_from_host(llkv_hip_query *query, const uint64_t *exchange, uint64_t len_i64) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   if (!query || !exchange) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
   Query *q = reinterpret_cast<Query *>(query);
   if (len_i64 != (uint64_t)kOctantsHost * (uint64_t)q->plan.lanes) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "exchange length mismatch");
@@ -1120,16 +1131,19 @@ llkv_status llkv_hip_query_set_depth(llkv_hip_query *query, uint32_t depth) {
 }
 
 llkv_status llkv_hip_query_wait_folded(llkv_hip_query *query, void *hip_stream) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   return (llkv_status) reinterpret_cast<Query *>(query)->wait_folded((hipStream_t)hip_stream);
 }
 
 llkv_status llkv_hip_query_submit(llkv_hip_query *query, void *hip_stream) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   return (llkv_status) reinterpret_cast<Query *>(query)->submit((hipStream_t)hip_stream);
 }
 
 llkv_status llkv_hip_query_collect(llkv_hip_query *query) {
+  if (int rc_dev = ensure_device()) return (llkv_status)rc_dev;
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   return (llkv_status) reinterpret_cast<Query *>(query)->collect();
 }

@@ -863,6 +863,53 @@ def test_reference_string_predicate_known_answers(rt, abi, case):
     assert [i in ids for i in range(len(case["values"]))] == case["expect"]
 
 
+def test_concurrent_callers_get_sequential_answers(rt, abi, tpch):
+    """The reference's storage traits are Send + Sync and queries arrive from several threads (SURVEY §8b
+    "Threading"): four host threads share one table image and run aggregates, GROUP BYs (dense and sort-based),
+    selections, scans and joins at the same time; every answer must equal the one computed alone."""
+    import threading
+    n = 300_000
+    d = tpch.gen_lineitem(n, 0.05)
+    ht = rt.HipTable(1, tpch.chunk_rows(n, 32768))
+    for c, (fid, dt) in tpch.LINEITEM_SCHEMA.items():
+        if dt == abi.DT_UTF8:
+            ht.append_utf8_column(fid, d[c])
+        else:
+            ht.append_column(fid, dt, d[c])
+    dim = rt.HipTable(2, [5000])
+    dim.append_column(1, abi.DT_INT64, np.arange(1, 5001, dtype=np.int64) * 7)
+    S, A, F, O, col = tpch.LINEITEM_SCHEMA, abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+    q1, q6 = tpch.q1(), tpch.q6()
+    flat = lambda rows: [(tuple(k.value for k in r.keys), tuple(np.float64(v.value).tobytes() if isinstance(v.value, float) else v.value for v in r.values)) for r in rows]
+    jobs = {
+        "q6": lambda: [np.float64(v.value).tobytes() for v in rt.aggregate(ht, q6.predicate, q6.aggs)],
+        "q1": lambda: flat(rt.groupby(ht, q1.predicate, q1.keys, q1.aggs, True)),
+        "by_partkey": lambda: flat(rt.groupby(ht, [F(S["l_quantity"][0], O.LessThan(10))], [S["l_partkey"][0]], [A.count_star(), A.sum(S["l_quantity"][0])], True))[:500],
+        "row_ids": lambda: rt.filter_row_ids(ht, [F(S["l_discount"][0], O.GreaterThan(0.08))]).tolist(),
+        "scan": lambda: [b[1][:50] for b in rt.scan_stream(ht, [S["l_orderkey"][0], col(S["l_extendedprice"][0]) * 2.0], [F(S["l_quantity"][0], O.Equals(7))], include_row_ids=True)],
+        "join": lambda: [x for b in rt.join_stream(ht, dim, [(S["l_partkey"][0], 1)], JT["semi"], 8192) for x in b[0]][:2000],
+    }
+    want = {k: f() for k, f in jobs.items()}
+    errors, names = [], list(jobs)
+
+    def worker(tid):
+        try:
+            for it in range(6):
+                name = names[(tid + it) % len(names)]
+                if jobs[name]() != want[name]:
+                    errors.append((tid, it, name, "mismatch"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, "exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a worker hung"
+    assert not errors, errors[:5]
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 
