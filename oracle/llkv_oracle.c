@@ -1250,6 +1250,12 @@ typedef struct acc {
   int has;        /* has_values / saw_value / Some(..) */
   __int128 d;     /* Decimal128 sum / min / max */
   int32_t precision, scale;
+  /* DISTINCT variants (:103-204): the `seen` set, kept as the arrival-ordered list of values (Int by value,
+   * Float by bit pattern :252-331); first appearances are folded in order at finalize */
+  int distinct, distinct_kind, distinct_f64;
+  uint64_t *seen;
+  uint64_t n_seen, cap_seen;
+  int32_t distinct_rc;
 } acc;
 
 /* array_value_to_numeric :400-449 */
@@ -1301,8 +1307,77 @@ static int32_t acc_new(int32_t agg_kind, int32_t input_dtype, acc *out) {
   return LLKV_OK;
 }
 
+static int32_t acc_new_distinct(int32_t agg_kind, int32_t input_dtype, acc *out) {
+  memset(out, 0, sizeof *out);
+  if (input_dtype != LLKV_DT_INT64 && input_dtype != LLKV_DT_FLOAT64) return fail(LLKV_UNSUPPORTED, "DISTINCT aggregate over %s", dtype_name(input_dtype));
+  if (agg_kind != LLKV_AGG_COUNT && agg_kind != LLKV_AGG_SUM && agg_kind != LLKV_AGG_TOTAL && agg_kind != LLKV_AGG_AVG)
+    return fail(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind %d", agg_kind);
+  out->distinct = 1;
+  out->distinct_kind = agg_kind;
+  out->distinct_f64 = input_dtype == LLKV_DT_FLOAT64;
+  return LLKV_OK;
+}
+
+typedef struct seen_ent { uint64_t v; uint64_t idx; } seen_ent;
+static int seen_cmp(const void *a, const void *b) {
+  const seen_ent *x = a, *y = b;
+  if (x->v != y->v) return x->v < y->v ? -1 : 1;
+  return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+static int idx_cmp(const void *a, const void *b) {
+  const seen_ent *x = a, *y = b;
+  return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+
+/* finalize of the DISTINCT accumulators: :1502-1510 (count), :1531-1543,1555-1565 (sum), :1619-1637 (total),
+ * :1684-1720 (avg).  Returns the error update() would have raised. */
+static int32_t acc_finalize_distinct(const acc *a, llkv_value *out) {
+  memset(out, 0, sizeof *out);
+  seen_ent *e = xmalloc((a->n_seen ? a->n_seen : 1) * sizeof *e);
+  for (uint64_t i = 0; i < a->n_seen; ++i) { e[i].v = a->seen[i]; e[i].idx = i; }
+  qsort(e, a->n_seen, sizeof *e, seen_cmp);
+  uint64_t m = 0;
+  for (uint64_t i = 0; i < a->n_seen; ++i) if (i == 0 || e[i].v != e[i - 1].v) e[m++] = e[i]; /* first appearance of each key */
+  qsort(e, m, sizeof *e, idx_cmp);
+  int32_t rc = LLKV_OK;
+  double fs = 0.0;
+  int64_t is = 0;
+  for (uint64_t i = 0; i < m && rc == LLKV_OK; ++i) {
+    if (a->distinct_f64) { double v; memcpy(&v, &e[i].v, 8); fs += v; }
+    else if (a->distinct_kind == LLKV_AGG_TOTAL) fs += (double)(int64_t)e[i].v;
+    else if (a->distinct_kind != LLKV_AGG_COUNT && __builtin_add_overflow(is, (int64_t)e[i].v, &is))
+      rc = fail(LLKV_INVALID_ARGUMENT, a->distinct_kind == LLKV_AGG_AVG ? "AVG(DISTINCT) aggregate sum exceeds i64 range" : "integer overflow");
+  }
+  free(e);
+  if (rc) return rc;
+  switch (a->distinct_kind) {
+  case LLKV_AGG_COUNT: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)m; break;
+  case LLKV_AGG_TOTAL: out->dtype = LLKV_DT_FLOAT64; out->f64 = fs; break;
+  case LLKV_AGG_SUM:
+    out->dtype = a->distinct_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64;
+    out->is_null = m == 0;
+    if (m) { if (a->distinct_f64) out->f64 = fs; else out->i64 = is; }
+    break;
+  default: /* AVG */
+    out->dtype = LLKV_DT_FLOAT64;
+    out->is_null = m == 0;
+    if (m) out->f64 = (a->distinct_f64 ? fs : (double)is) / (double)m;
+    break;
+  }
+  return LLKV_OK;
+}
+
 /* update(&RecordBatch) :759-1477 — strictly sequential, arrival order. */
 static int32_t acc_update(acc *a, const arr *col, uint64_t num_rows) {
+  if (a->distinct) {
+    if (col->dtype == LLKV_DT_NULL) return LLKV_OK;
+    for (uint64_t i = 0; i < col->n; ++i) {
+      if (!col->valid[i]) continue;
+      if (a->n_seen == a->cap_seen) { a->cap_seen = a->cap_seen ? a->cap_seen * 2 : 1024; a->seen = xrealloc(a->seen, a->cap_seen * 8); }
+      memcpy(&a->seen[a->n_seen++], (const char *)col->values + i * 8, 8);
+    }
+    return LLKV_OK;
+  }
   switch (a->kind) {
   case ACC_COUNT_STAR:
     if (__builtin_add_overflow(a->i, (int64_t)num_rows, &a->i)) return fail(LLKV_INVALID_ARGUMENT, "COUNT result exceeds i64 range");
@@ -1450,13 +1525,13 @@ int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n
   uint32_t n_projs = 0;
   int32_t rc = LLKV_OK;
   for (uint32_t i = 0; i < n_aggs && rc == LLKV_OK; ++i) {
-    if (aggs[i].distinct) { rc = fail(LLKV_UNSUPPORTED, "DISTINCT aggregates are out of scope"); break; }
     if (aggs[i].kind == LLKV_AGG_COUNT_STAR) { proj_of[i] = -1; rc = acc_new(aggs[i].kind, LLKV_DT_NULL, &accs[i]); continue; }
     int has_div;
     int32_t dt = infer_expr_type(t, aggs[i].expr, aggs[i].expr_len, &has_div, &rc);
     if (rc) break;
     if (!is_simple_column(aggs[i].expr, aggs[i].expr_len) && dt != LLKV_DT_FLOAT64) dt = LLKV_DT_INT64;
-    rc = acc_new(aggs[i].kind, dt, &accs[i]);
+    const int is_distinct = aggs[i].distinct && aggs[i].kind != LLKV_AGG_MIN && aggs[i].kind != LLKV_AGG_MAX; /* MIN / MAX have no DISTINCT form */
+    rc = is_distinct ? acc_new_distinct(aggs[i].kind, dt, &accs[i]) : acc_new(aggs[i].kind, dt, &accs[i]);
     if (rc) break;
     if (dt == LLKV_DT_DECIMAL128) { /* the spec's DataType::Decimal128(precision, scale) */
       const orc_column *dc = find_col(t, aggs[i].expr[0].field_id);
@@ -1481,7 +1556,11 @@ int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n
       if (rc == LLKV_NOT_FOUND) rc = LLKV_OK; /* NotFound = empty table, :5646-5650 */
     }
   }
-  if (rc == LLKV_OK) for (uint32_t i = 0; i < n_aggs; ++i) acc_finalize(&accs[i], &out_values[i]);
+  for (uint32_t i = 0; i < n_aggs && rc == LLKV_OK; ++i) {
+    if (accs[i].distinct) rc = acc_finalize_distinct(&accs[i], &out_values[i]);
+    else acc_finalize(&accs[i], &out_values[i]);
+  }
+  for (uint32_t i = 0; i < n_aggs; ++i) free(accs[i].seen);
   free(accs); free(proj_of); free(projs);
   return rc;
 }

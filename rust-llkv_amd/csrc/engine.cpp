@@ -302,6 +302,33 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->n_user_aggs = n_aggs;
   q->n_user_keys = grouped ? n_keys : 0;
   std::string err;
+  // ungrouped DISTINCT aggregates are evaluated by their own sort-based pipeline at finish; the fused scan
+  // carries a COUNT(*) in their place.  MIN / MAX ignore DISTINCT.
+  std::vector<llkv_aggregate_spec> subst;
+  if (!grouped) {
+    bool any = false;
+    for (uint32_t a = 0; a < n_aggs; ++a) any |= aggs[a].distinct != 0;
+    if (any) {
+      subst.assign(aggs, aggs + n_aggs);
+      q->distinct.resize(n_aggs);
+      for (uint32_t a = 0; a < n_aggs; ++a) {
+        if (!aggs[a].distinct) continue;
+        subst[a].distinct = 0;
+        const int kind = aggs[a].kind;
+        if (kind == LLKV_AGG_MIN || kind == LLKV_AGG_MAX || kind == LLKV_AGG_COUNT_STAR) continue;
+        if (kind != LLKV_AGG_COUNT && kind != LLKV_AGG_SUM && kind != LLKV_AGG_TOTAL && kind != LLKV_AGG_AVG)
+          return set_error(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind " + std::to_string(kind));
+        if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "DISTINCT aggregates on a sharded table");
+        if (!aggs[a].expr || !aggs[a].expr_len) return set_error(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
+        Query::DistinctAgg &da = q->distinct[a];
+        if ((rc = lower_emit(resolve, filters, n_filters, ops, n_ops, aggs[a].expr, aggs[a].expr_len, &da.plan, &err, /*allow_f64=*/true, &da.is_f64)))
+          return set_error(rc, err);
+        da.kind = kind;
+        subst[a].kind = LLKV_AGG_COUNT_STAR;
+      }
+      aggs = subst.data();
+    }
+  }
   rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, /*track_first=*/!order_by_keys, &q->plan, &err);
   if (rc == LLKV_UNSUPPORTED && grouped) {
     // too many groups / too wide a state / sparse or unbounded integer keys for the dense kernel: sort-based route
@@ -573,11 +600,10 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
 
 // Exact replay of the reference's sequential checked_add chain (llkv-aggregate/src/lib.rs:801-830) for one
 // aggregate: selected argument values in row order → 128-bit inclusive scan → any prefix outside i64?
-int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
-  if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "possible intermediate i64 overflow in SUM: the order-dependent check needs the whole table on one rank");
-  const LoweredPlan &ep = exact_plans[agg];
+// Argument values of the rows a predicate selects, in row order (EmitPlan: count / scan / write).
+int Query::emit_values(const LoweredPlan &ep, Scratch *vals, uint64_t *n_out) {
   hipStream_t s = g_ctx.stream;
-  *overflow = false;
+  *n_out = 0;
   if (ep.always_false || table->local_rows == 0) return LLKV_OK;
   JitKernel k;
   std::string err;
@@ -586,9 +612,8 @@ int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
   const TileSet *ts = nullptr;
   if ((rc = get_tileset(*table, 8192, &ts))) return rc;
   const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
-  struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } counts, offsets, vals, prefix, flag, tmp;
-  HIP_TRY(hipMalloc(&counts.p, (size_t)n_slots * 8));
-  HIP_TRY(hipMalloc(&offsets.p, (size_t)(n_slots + 1) * 8));
+  Scratch counts, offsets;
+  if ((rc = counts.alloc((size_t)n_slots * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
   ScanParams sp;
   std::memset(&sp, 0, sizeof sp);
   for (size_t i = 0; i < ep.slot_fields.size(); ++i) sp.col[i] = slot_buffer(table->cols, ep, i);
@@ -597,30 +622,139 @@ int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
   sp.tiles = ts->d_tiles;
   sp.n_tiles = ts->n_tiles;
   sp.sub_rows = 8192 / (kBlock / 64);
-  sp.tile_partials = (uint64_t *)counts.p;
+  sp.tile_partials = counts.as<uint64_t>();
   if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &sp, sizeof sp, s))) return rc;
-  HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, s));
+  HIP_TRY(launch_exclusive_scan(counts.as<uint64_t>(), offsets.as<uint64_t>(), n_slots, s));
   uint64_t n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&n, offsets.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (n >= kPredErrorBit) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison");
   if (n == 0) return LLKV_OK;
-  HIP_TRY(hipMalloc(&vals.p, n * 8));
-  HIP_TRY(hipMalloc(&prefix.p, n * 16));
-  HIP_TRY(hipMalloc(&flag.p, 4));
-  HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
-  sp.aux_in = (const uint64_t *)offsets.p;
-  sp.aux_out = (uint64_t *)vals.p;
+  if ((rc = vals->alloc(n * 8))) return rc;
+  sp.aux_in = offsets.as<uint64_t>();
+  sp.aux_out = vals->as<uint64_t>();
   if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &sp, sizeof sp, s))) return rc;
+  HIP_TRY(hipStreamSynchronize(s)); // counts / offsets are released on return
+  *n_out = n;
+  return LLKV_OK;
+}
+
+// Exact replay of the reference's sequential checked_add chain (llkv-aggregate/src/lib.rs:801-830) for one
+// aggregate: selected argument values in row order → 128-bit inclusive scan → any prefix outside i64?
+static int prefix_overflow_of(const int64_t *d_vals, uint64_t n, bool *overflow, __int128 *total) {
+  hipStream_t s = g_ctx.stream;
+  *overflow = false;
+  if (total) *total = 0;
+  if (n == 0) return LLKV_OK;
+  Scratch prefix, flag, tmp;
+  int rc;
+  if ((rc = prefix.alloc(n * 16)) || (rc = flag.alloc(4))) return rc;
+  HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
   size_t tb = 0;
-  HIP_TRY(hj_prefix_overflow(nullptr, &tb, (const int64_t *)vals.p, n, prefix.p, (uint32_t *)flag.p, s));
-  HIP_TRY(hipMalloc(&tmp.p, tb ? tb : 8));
-  HIP_TRY(hj_prefix_overflow(tmp.p, &tb, (const int64_t *)vals.p, n, prefix.p, (uint32_t *)flag.p, s));
+  HIP_TRY(hj_prefix_overflow(nullptr, &tb, d_vals, n, prefix.p, flag.as<uint32_t>(), s));
+  if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+  HIP_TRY(hj_prefix_overflow(tmp.p, &tb, d_vals, n, prefix.p, flag.as<uint32_t>(), s));
   uint32_t f = 0;
+  uint64_t last[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(last, static_cast<const char *>(prefix.p) + (n - 1) * 16, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   *overflow = f != 0;
+  if (total) *total = (__int128)(((unsigned __int128)last[1] << 64) | last[0]);
   return LLKV_OK;
+}
+
+int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
+  if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "possible intermediate i64 overflow in SUM: the order-dependent check needs the whole table on one rank");
+  Scratch vals;
+  uint64_t n = 0;
+  int rc = emit_values(exact_plans[agg], &vals, &n);
+  if (rc) return rc;
+  return prefix_overflow_of(vals.as<int64_t>(), n, overflow, nullptr);
+}
+
+// DISTINCT aggregates (llkv-aggregate/src/lib.rs: CountDistinctColumn :787-799, SumDistinct* :831-867,889-924,
+// TotalDistinct* :990-1066, AvgDistinct* :1145-1232; keys: Int by value, Float by bit pattern :252-331): the
+// accumulator adds a value the first time it sees it, so the sum runs over the distinct values in order of
+// FIRST APPEARANCE.  Selected values in row order → stable sort by value → run heads (= first appearances) →
+// back into row order → exact i64 prefix scan / ordered f64 sum.
+int Query::distinct_value(size_t agg, llkv_value *out) {
+  const DistinctAgg &da = distinct[agg];
+  std::memset(out, 0, sizeof *out);
+  hipStream_t s = g_ctx.stream;
+  Scratch vals;
+  uint64_t n = 0;
+  int rc = emit_values(da.plan, &vals, &n);
+  if (rc) return rc;
+  if (n >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "more than 2^32 selected rows in a DISTINCT aggregate");
+  uint64_t m = 0; // distinct values
+  Scratch dv;     // … in order of first appearance
+  if (n) {
+    Scratch pos, vals_s, pos_s, flags, offs, tmp, hv, hp, hp_s;
+    if ((rc = pos.alloc(n * 4)) || (rc = vals_s.alloc(n * 8)) || (rc = pos_s.alloc(n * 4)) || (rc = flags.alloc((n + 1) * 8)) || (rc = offs.alloc((n + 1) * 8))) return rc;
+    HIP_TRY(hj_launch_iota(pos.as<uint32_t>(), (uint32_t)n, s));
+    size_t tb = 0;
+    HIP_TRY(hj_sort_u64_u32(nullptr, &tb, vals.as<uint64_t>(), vals_s.as<uint64_t>(), pos.as<uint32_t>(), pos_s.as<uint32_t>(), n, s));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, vals.as<uint64_t>(), vals_s.as<uint64_t>(), pos.as<uint32_t>(), pos_s.as<uint32_t>(), n, s));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, (n + 1) * 8, s));
+    HIP_TRY(hj_launch_run_heads(vals_s.as<uint64_t>(), n, flags.as<uint64_t>(), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    tb = 0;
+    HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, flags.as<uint64_t>(), offs.as<uint64_t>(), n + 1, s));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_exclusive_scan_u64(tmp.p, &tb, flags.as<uint64_t>(), offs.as<uint64_t>(), n + 1, s));
+    HIP_TRY(hipMemcpyAsync(&m, offs.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = hv.alloc(m * 8)) || (rc = hp.alloc(m * 4)) || (rc = hp_s.alloc(m * 4)) || (rc = dv.alloc(m * 8))) return rc;
+    // heads: (position of the first appearance, value); the stable sort put the smallest position first in its run
+    HIP_TRY(hj_launch_compact_pairs(pos_s.as<uint32_t>(), vals_s.as<uint64_t>(), flags.as<uint64_t>(), offs.as<uint64_t>(), n, hp.as<uint32_t>(), hv.as<uint64_t>(), s));
+    uint32_t bits = 1;
+    while (bits < 32 && (n >> bits) != 0) ++bits;
+    tb = 0;
+    HIP_TRY(hj_sort_u32_u64(nullptr, &tb, hp.as<uint32_t>(), hp_s.as<uint32_t>(), hv.as<uint64_t>(), dv.as<uint64_t>(), m, bits, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, hp.as<uint32_t>(), hp_s.as<uint32_t>(), hv.as<uint64_t>(), dv.as<uint64_t>(), m, bits, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  auto f64_sum = [&](int as_int, double *sum) -> int {
+    *sum = 0.0;
+    if (m == 0) return LLKV_OK;
+    Scratch d;
+    int r = d.alloc(8);
+    if (r) return r;
+    HIP_TRY(hj_launch_sum_f64_ordered(dv.as<uint64_t>(), m, as_int, d.as<double>(), s));
+    HIP_TRY(hipMemcpyAsync(sum, d.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LLKV_OK;
+  };
+  switch (da.kind) {
+  case LLKV_AGG_COUNT: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)m; return LLKV_OK;
+  case LLKV_AGG_TOTAL: {
+    out->dtype = LLKV_DT_FLOAT64;
+    return f64_sum(da.is_f64 ? 0 : 1, &out->f64);
+  }
+  case LLKV_AGG_SUM: case LLKV_AGG_AVG: {
+    const bool avg = da.kind == LLKV_AGG_AVG;
+    out->dtype = (avg || da.is_f64) ? LLKV_DT_FLOAT64 : LLKV_DT_INT64;
+    if (m == 0) { out->is_null = 1; return LLKV_OK; }
+    if (da.is_f64) {
+      double sum;
+      if ((rc = f64_sum(0, &sum))) return rc;
+      out->f64 = avg ? sum / (double)m : sum;
+      return LLKV_OK;
+    }
+    bool overflow = false;
+    __int128 total = 0;
+    if ((rc = prefix_overflow_of(dv.as<int64_t>(), m, &overflow, &total))) return rc;
+    if (overflow) return set_error(LLKV_INVALID_ARGUMENT, avg ? "AVG(DISTINCT) aggregate sum exceeds i64 range" : "integer overflow");
+    if (avg) out->f64 = (double)(int64_t)total / (double)m;
+    else out->i64 = (int64_t)total;
+    return LLKV_OK;
+  }
+  default: return set_error(LLKV_INTERNAL, "not a DISTINCT aggregate");
+  }
 }
 
 int Query::finish_from_exchange(const uint64_t *exchange) {
@@ -666,6 +800,9 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
       }
       if (rc) return set_error(rc, err);
     }
+    if (!p.grouped)
+      for (size_t a = 0; a < distinct.size() && a < gr.values.size(); ++a)
+        if (distinct[a].kind >= 0) { int rc = distinct_value(a, &gr.values[a]); if (rc) return rc; }
     groups.push_back(std::move(gr));
   }
   if (p.grouped) {

@@ -115,6 +115,8 @@ struct LazyGroups {
   std::vector<const ColumnInfo *> key_cols;
 };
 
+struct Scratch;
+
 // Message of a device-side arithmetic error code (fused_scan.hip.h: kErrOverflow = 1, kErrDivZero = 2), as the
 // reference's arrow kernels word it (Error::Internal).
 inline const char *arith_error_message(uint64_t code) {
@@ -165,6 +167,12 @@ struct Query {
   // the selected rows in row order, for the exact prefix-overflow check (index = aggregate, empty = n/a)
   std::vector<LoweredPlan> exact_plans;
   int exact_prefix_overflow(size_t agg, bool *overflow);
+  // ungrouped DISTINCT aggregates (COUNT / SUM / TOTAL / AVG): a value-emission plan per aggregate, evaluated
+  // at finish by a sort-based pipeline (index = aggregate; kind < 0 = not a DISTINCT aggregate)
+  struct DistinctAgg { int kind = -1; bool is_f64 = false; LoweredPlan plan; };
+  std::vector<DistinctAgg> distinct;
+  int emit_values(const LoweredPlan &ep, Scratch *vals, uint64_t *n);
+  int distinct_value(size_t agg, llkv_value *out);
   bool profiling = false;
   uint32_t profile_every = 1; // bracket every n-th scan with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

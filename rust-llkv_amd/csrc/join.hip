@@ -503,6 +503,40 @@ hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *ki
   return rocprim::radix_sort_pairs(tmp, *tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, end_bit, s);
 }
 
+// ---- DISTINCT aggregates ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hj_run_heads_kernel(const uint64_t *sorted, uint64_t n, uint64_t *flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+}
+hipError_t hj_launch_run_heads(const uint64_t *sorted, uint64_t n, uint64_t *flags, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_run_heads_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, sorted, n, flags);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(64) void hj_sum_f64_ordered_kernel(const uint64_t *vals, uint64_t n, int as_int, double *out) {
+  const uint32_t lane = threadIdx.x;
+  auto at = [&](uint64_t i) { return as_int ? (double)(long long)vals[i] : __longlong_as_double((long long)vals[i]); };
+  if (n <= 65536) { // the reference's own order: 0.0, then += in arrival order
+    if (lane == 0) {
+      double acc = 0.0;
+      for (uint64_t i = 0; i < n; ++i) acc += at(i);
+      *out = acc;
+    }
+    return;
+  }
+  double acc = 0.0;
+  for (uint64_t i = lane; i < n; i += 64) acc += at(i);
+  for (int o = 1; o < 64; o <<= 1) {
+    const double other = __shfl_xor(acc, o);
+    acc = (lane & o) ? other + acc : acc + other;
+  }
+  if (lane == 0) *out = acc;
+}
+hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(hj_sum_f64_ordered_kernel, dim3(1), dim3(64), 0, s, vals, n, as_int, out);
+  return hipGetLastError();
+}
+
 // ---- exact, order-dependent SUM(Int64) overflow check -------------------------------------------
 struct I128 {
   uint64_t lo;

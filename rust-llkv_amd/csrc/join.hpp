@@ -126,6 +126,14 @@ hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const 
 hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout,
                                 uint64_t n, uint32_t end_bit, hipStream_t s);
 
+// ---- DISTINCT aggregates (engine.cpp: Query::distinct_value) ---------------------------------------------
+// flags[i] = 1 when sorted value i differs from sorted value i − 1 (the head of a run of equal keys).
+hipError_t hj_launch_run_heads(const uint64_t *sorted, uint64_t n, uint64_t *flags, hipStream_t s);
+// Left-to-right f64 sum of vals[0..n) (as_int: the values are i64, added as `v as f64`; else f64 bit images):
+// strictly sequential up to 65 536 values (bit-exact with the reference's `sum += v`), beyond that one wave in
+// lane-strided order with a fixed butterfly.  *out = the sum.
+hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, hipStream_t s);
+
 // Does any prefix of vals[0..n) (summed left to right, exactly) leave the i64 range?  *d_flag |= 1 if so.
 // `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.
 hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s);

@@ -1141,7 +1141,8 @@ int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, u
 }
 
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
-               uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err) {
+               uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err,
+               bool allow_f64, bool *is_f64_out) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, false};
   std::string pred, val;
@@ -1153,12 +1154,14 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     const ColumnInfo *ci;
     int slot;
     if ((rc = L.slot_of(expr[0].field_id, &ci, &slot))) return rc;
-    if (ci->dtype != LLKV_DT_INT64) return L.fail(LLKV_UNSUPPORTED, "exact sum check over a non-Int64 column");
+    if (ci->dtype != LLKV_DT_INT64 && !(allow_f64 && ci->dtype == LLKV_DT_FLOAT64)) return L.fail(LLKV_UNSUPPORTED, std::string("value emission over a ") + dtype_name(ci->dtype) + " column");
     val = L.col_node(slot, ci->dtype);
+    is_f64 = ci->dtype == LLKV_DT_FLOAT64;
   } else {
     if ((rc = L.expr_fast(expr, expr_len, &val, &is_f64))) return rc;
-    if (is_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
+    if (is_f64 && !allow_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
   }
+  if (is_f64_out) *is_f64_out = is_f64;
   { // NULL argument rows are not part of the accumulator's chain
     std::string v;
     if ((rc = L.valid_of_node(expr, expr_len, val, false, &v))) return rc;

@@ -158,7 +158,8 @@ template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const S
       Ctx c{p, ld, 0u, td.logical_row + row0 + j};
       f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
       perr |= ((row0 + j) < sub1) ? c.perr : 0u;
-      val[j] = (uint64_t)(int64_t)P::ValE::eval(c, j);
+      if constexpr (P::ValE::Type::is_float) val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j)); // f64: bit image
+      else val[j] = (uint64_t)(int64_t)P::ValE::eval(c, j);
     }
     const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
     if constexpr (WRITE) {

@@ -128,7 +128,9 @@ def build_aggs(abi, specs):
         if k == "count_star":
             out.append(A.count_star())
         else:
-            out.append(getattr(A, k)(build_expr(abi, s["expr"])))
+            spec = getattr(A, k)(build_expr(abi, s["expr"]))
+            spec.distinct = bool(s.get("distinct", False))
+            out.append(spec)
     return out
 
 

@@ -910,6 +910,49 @@ def test_concurrent_callers_get_sequential_answers(rt, abi, tpch):
     assert not errors, errors[:5]
 
 
+@pytest.mark.parametrize("chunks", [[7], [4096, 4097, 5], [65536, 70000]])
+def test_distinct_aggregates_match_oracle(rt, orc, abi, chunks):
+    """COUNT / SUM / TOTAL / AVG (DISTINCT x): the accumulators add a value the first time they see it
+    (llkv-aggregate/src/lib.rs:787-799,831-867,889-924), i.e. the distinct values in order of first appearance —
+    Int keys by value, Float keys by bit pattern (NaN payloads and -0.0 are their own keys)."""
+    rng = np.random.default_rng(31 + len(chunks))
+    n = sum(chunks)
+    few = rng.integers(-20, 20, size=n).astype(np.int64)
+    many = rng.integers(-10**6, 10**6, size=n).astype(np.int64)
+    f = rng.integers(-30, 30, size=n).astype(np.float64) / 4
+    f[rng.random(n) < 0.03] = np.nan
+    f[rng.random(n) < 0.03] = -0.0
+    sel = rng.integers(0, 5, size=n).astype(np.int64)
+    vf = rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, few), (2, abi.DT_INT64, many), (3, abi.DT_FLOAT64, f, vf), (4, abi.DT_INT64, sel)], chunks)
+    A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+
+    def D(kind, e):
+        s = getattr(A, kind)(e)
+        s.distinct = True
+        return s
+
+    aggs = [D("count", 1), D("sum", 1), D("avg", 1), D("total", 1), D("count", 2), D("sum", 2), D("count", 3), D("sum", 3), D("avg", 3), D("total", 3),
+            D("sum", col(1) * col(4)), D("count", col(3) * 2.0), D("min", 1), D("max", 3), A.sum(1), A.count_star()]
+    for pred in (None, [F(4, O.Equals(2))], [F(4, O.GreaterThan(9))]):
+        got, want = rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs)
+        assert_values(got, want, f"distinct {pred}")
+        for i in (0, 1, 4, 5, 6, 10, 11):  # counts and integer sums are exact
+            assert got[i].value == want[i].value
+    # checked i64 adds over the distinct values, in first-appearance order
+    big = np.array([2**62, 2**62, 5, 2**62 + 1] + [5] * (n - 4), dtype=np.int64)[:n] if n >= 4 else np.array([2**62] * n, dtype=np.int64)
+    ht2, ot2 = stage_both(rt, orc, abi, [(1, abi.DT_INT64, big)], chunks)
+    if n >= 4:
+        for m, t in ((rt, ht2), (orc, ot2)):
+            with pytest.raises(abi.LlkvError) as e:
+                m.aggregate(t, None, [D("sum", 1)])
+            assert e.value.kind == "InvalidArgumentError" and "integer overflow" in e.value.message
+            with pytest.raises(abi.LlkvError) as e:
+                m.aggregate(t, None, [D("avg", 1)])
+            assert e.value.kind == "InvalidArgumentError" and "AVG(DISTINCT) aggregate sum exceeds i64 range" in e.value.message
+            assert m.aggregate(t, None, [D("count", 1), D("total", 1)])[0].value == 3
+
+
 JOINS = golden("joins.json")
 JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
 
