@@ -1923,6 +1923,28 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
   int jt = options ? options->join_type : LLKV_JOIN_INNER;
   if (batch_size == 0) return fail(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero"); /* llkv-join/src/lib.rs:284-310 */
   if (jt == LLKV_JOIN_RIGHT || jt == LLKV_JOIN_FULL) return fail(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented"); /* hash_join.rs:328-332 */
+  if (n_keys == 0) { /* cross_product_stream hash_join.rs:1500-1599, cross_join_pair cartesian.rs:22-80 */
+    if (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) return fail(LLKV_INTERNAL, "cross join schema mismatch");
+    if (right->rows == 0 && jt == LLKV_JOIN_INNER) return LLKV_OK;
+    for (uint64_t l0 = 0; l0 < left->rows; l0 += ROW_STREAM_CHUNK_SIZE) {
+      uint64_t ln = left->rows - l0 < ROW_STREAM_CHUNK_SIZE ? left->rows - l0 : ROW_STREAM_CHUNK_SIZE;
+      if (right->rows == 0) {
+        uint64_t *l = xmalloc(ln * 8), *r = xmalloc(ln * 8);
+        for (uint64_t i = 0; i < ln; ++i) { l[i] = l0 + i; r[i] = UINT64_MAX; }
+        on_batch(l, r, ln, user);
+        free(l); free(r);
+        continue;
+      }
+      for (uint64_t r0 = 0; r0 < right->rows; r0 += ROW_STREAM_CHUNK_SIZE) {
+        uint64_t rn = right->rows - r0 < ROW_STREAM_CHUNK_SIZE ? right->rows - r0 : ROW_STREAM_CHUNK_SIZE, np = ln * rn, k = 0;
+        uint64_t *l = xmalloc(np * 8), *r = xmalloc(np * 8);
+        for (uint64_t i = 0; i < ln; ++i) for (uint64_t j = 0; j < rn; ++j) { l[k] = l0 + i; r[k++] = r0 + j; }
+        on_batch(l, r, np, user);
+        free(l); free(r);
+      }
+    }
+    return LLKV_OK;
+  }
   if (n_keys != 1) return fail(LLKV_UNSUPPORTED, "only single-key integer joins are restated (n_keys=%u)", n_keys);
   const orc_column *lc = find_col(left, keys[0].left_field), *rc_ = find_col(right, keys[0].right_field);
   if (!lc || !rc_) return fail(LLKV_NOT_FOUND, "join key field not found");

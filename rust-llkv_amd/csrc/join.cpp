@@ -80,7 +80,41 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   int rc = ensure_device();
   if (rc) return rc;
   if (!left || !right || !on_batch) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
-  if (n_keys != 1) return set_error(LLKV_UNSUPPORTED, "GPU join path takes exactly one integer key pair (cross products and composite keys stay on the CPU route)");
+  if (n_keys == 0) {
+    // Empty join keys = Cartesian product (cross_product_stream, llkv-join/src/hash_join.rs:1500-1599): every
+    // 65 536-row scan window of the left against every window of the right, left-major inside a pair of windows;
+    // LEFT with an empty right side pads; SEMI / ANTI trip the reference's schema check.
+    if (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) return set_error(LLKV_INTERNAL, "cross join schema mismatch: semi / anti joins deliver left columns only");
+    const uint64_t nl = left->local_rows, nr = right->local_rows;
+    if (left->world != 1 || right->world != 1) return set_error(LLKV_UNSUPPORTED, "cross product over sharded tables");
+    if (nr == 0 && jt == LLKV_JOIN_INNER) return LLKV_OK;
+    constexpr uint64_t kWin = 65536;
+    hipStream_t s = g_ctx.stream;
+    DBuf d_l, d_r;
+    HBuf h_l, h_r;
+    for (uint64_t l0 = 0; l0 < nl; l0 += kWin) {
+      const uint64_t ln = std::min(kWin, nl - l0);
+      if (nr == 0) { // LEFT: NULL-padded right side (synthesize_left_join_nulls)
+        if ((rc = h_l.ensure(ln * 8)) || (rc = h_r.ensure(ln * 8))) return rc;
+        uint64_t *hl = (uint64_t *)h_l.p, *hr = (uint64_t *)h_r.p;
+        for (uint64_t i = 0; i < ln; ++i) { hl[i] = left->local_logical_start + l0 + i; hr[i] = ~0ull; }
+        on_batch(hl, hr, ln, user);
+        continue;
+      }
+      for (uint64_t r0 = 0; r0 < nr; r0 += kWin) {
+        const uint64_t rn = std::min(kWin, nr - r0), np = ln * rn;
+        if (np > (1ull << 28)) return set_error(LLKV_UNSUPPORTED, "cross product batch of more than 2^28 pairs");
+        if ((rc = d_l.ensure(np * 8)) || (rc = d_r.ensure(np * 8)) || (rc = h_l.ensure(np * 8)) || (rc = h_r.ensure(np * 8))) return rc;
+        HIP_TRY(hj_launch_cross_pairs(l0, ln, r0, rn, (uint64_t *)d_l.p, (uint64_t *)d_r.p, s));
+        HIP_TRY(hipMemcpyAsync(h_l.p, d_l.p, np * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_r.p, d_r.p, np * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        on_batch((const uint64_t *)h_l.p, (const uint64_t *)h_r.p, np, user);
+      }
+    }
+    return LLKV_OK;
+  }
+  if (n_keys != 1) return set_error(LLKV_UNSUPPORTED, "GPU join path takes one integer key pair or none (composite keys stay on the CPU route)");
   JoinKeyColumn lk, rk;
   int32_t ldt, rdt;
   const bool null_eq = keys[0].null_equals_null != 0;

@@ -112,6 +112,19 @@ hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void hj_cross_pairs_kernel(uint64_t l0, uint64_t ln, uint64_t r0, uint64_t rn, uint64_t *out_left, uint64_t *out_right) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ln * rn) return;
+  out_left[i] = l0 + i / rn;
+  out_right[i] = r0 + i % rn;
+}
+hipError_t hj_launch_cross_pairs(uint64_t l0, uint64_t ln, uint64_t r0, uint64_t rn, uint64_t *out_left, uint64_t *out_right, hipStream_t s) {
+  const uint64_t n = ln * rn;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_cross_pairs_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, l0, ln, r0, rn, out_left, out_right);
+  return hipGetLastError();
+}
+
 // JOIN types: 0 inner, 1 left, 4 semi, 5 anti (include/llkv_hip.h)
 __global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
   const TileDesc td = p.tiles[blockIdx.x];

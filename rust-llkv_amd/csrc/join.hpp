@@ -36,6 +36,10 @@ hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t 
 // identity index 0..n-1
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
 
+// Cross product of two row windows, left-major (cross_join_pair llkv-join/src/cartesian.rs:22-80):
+// pair i = (l0 + i / rn, r0 + i % rn).
+hipError_t hj_launch_cross_pairs(uint64_t l0, uint64_t ln, uint64_t r0, uint64_t rn, uint64_t *out_left, uint64_t *out_right, hipStream_t s);
+
 struct ProbeParams {
   JoinKeyColumn lkey, rkey;
   const TileDesc *tiles; // probe-side tiles of this window

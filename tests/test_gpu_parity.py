@@ -970,10 +970,10 @@ def test_reference_join_known_answers(rt, abi, case):
     left, right = _join_side(rt, abi, case["left"]), _join_side(rt, abi, case["right"])
     if "expect_error" in case:
         with pytest.raises(abi.LlkvError) as e:
-            rt.join_stream(left, right, [(1, 1)], JT[case["type"]], case.get("batch_size", 8192))
+            rt.join_stream(left, right, [] if case.get("cross") else [(1, 1)], JT[case["type"]], case.get("batch_size", 8192))
         assert e.value.kind == case["expect_error"]
         return
-    batches = rt.join_stream(left, right, [(1, 1)], JT[case["type"]], case.get("batch_size", 8192))
+    batches = rt.join_stream(left, right, [] if case.get("cross") else [(1, 1)], JT[case["type"]], case.get("batch_size", 8192))
     ls = [x for b in batches for x in b[0]]
     assert len(ls) == case["expect_rows"]
     if "expect_pairs" in case:
@@ -981,6 +981,27 @@ def test_reference_join_known_answers(rt, abi, case):
         assert [[l, None if r == 2**64 - 1 else r] for l, r in zip(ls, rs)] == case["expect_pairs"]
     if "expect_left" in case:
         assert ls == case["expect_left"] and all(b[1] is None for b in batches)
+
+
+def test_cross_products_match_oracle(rt, orc, abi):
+    """Empty join keys = Cartesian product (llkv-join/src/hash_join.rs:1500-1599): window by window, left-major;
+    LEFT with an empty right side pads with NULLs; SEMI / ANTI fail the reference's schema check."""
+    nl, nr = 70_000, 300  # two left scan windows
+    lt = rt.HipTable(1, [nl]); lt.append_column(1, abi.DT_INT64, np.arange(nl, dtype=np.int64))
+    rtab = rt.HipTable(2, [nr]); rtab.append_column(7, abi.DT_INT64, np.arange(nr, dtype=np.int64))
+    empty = rt.HipTable(3, [0]); empty.append_column(7, abi.DT_INT64, np.zeros(0, dtype=np.int64))
+    ol, orr, oe = orc.OracleTable(nl).add(1, abi.DT_INT64, np.arange(nl, dtype=np.int64)), orc.OracleTable(nr).add(7, abi.DT_INT64, np.arange(nr, dtype=np.int64)), orc.OracleTable(0).add(7, abi.DT_INT64, np.zeros(0, dtype=np.int64))
+    got, want = rt.join_stream(lt, rtab, [], JT["inner"]), orc.hash_join(ol, orr, [], JT["inner"])
+    assert [len(b[0]) for b in got] == [len(b[0]) for b in want] == [65536 * nr, (nl - 65536) * nr]
+    for (gl, gr_), (wl, wr) in zip(got, want):
+        assert gl[:1000] == wl[:1000] and gr_[:1000] == wr[:1000] and gl[-1000:] == wl[-1000:] and gr_[-1000:] == wr[-1000:]
+    got, want = rt.join_stream(lt, empty, [], JT["left"]), orc.hash_join(ol, oe, [], JT["left"])
+    assert [(b[0][0], b[0][-1], b[1][0], len(b[0])) for b in got] == [(b[0][0], b[0][-1], b[1][0], len(b[0])) for b in want]
+    assert rt.join_stream(lt, empty, [], JT["inner"]) == []
+    for m, (a, b) in ((rt, (lt, rtab)), (orc, (ol, orr))):
+        with pytest.raises(abi.LlkvError) as e:
+            (m.join_stream if m is rt else m.hash_join)(a, b, [], JT["semi"])
+        assert e.value.kind == "Internal"
 
 
 def test_right_and_full_joins_are_rejected_like_the_reference(rt, abi):

@@ -45,10 +45,10 @@ def test_join_cases(case, orc, abi):
     jt = {"inner": abi.JOIN_INNER, "left": abi.JOIN_LEFT, "semi": abi.JOIN_SEMI, "anti": abi.JOIN_ANTI}[case["type"]]
     if "expect_error" in case:
         with pytest.raises(abi.LlkvError) as e:
-            orc.hash_join(left, right, [(1, 1)], jt, case.get("batch_size", 8192))
+            orc.hash_join(left, right, [] if case.get("cross") else [(1, 1)], jt, case.get("batch_size", 8192))
         assert e.value.kind == case["expect_error"]
         return
-    batches = orc.hash_join(left, right, [(1, 1)], jt, case.get("batch_size", 8192))
+    batches = orc.hash_join(left, right, [] if case.get("cross") else [(1, 1)], jt, case.get("batch_size", 8192))
     ls = [x for b in batches for x in b[0]]
     assert len(ls) == case["expect_rows"]
     if "expect_pairs" in case:
