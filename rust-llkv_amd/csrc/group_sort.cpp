@@ -195,7 +195,10 @@ int SortedGroupBy::run(LazyGroups *out) {
   Scratch flags, offs, seg;
   if ((rc = flags.alloc((n + 1) * 8)) || (rc = offs.alloc((n + 1) * 8))) return rc;
   HIP_TRY(hipMemsetAsync(flags.p, 0, (n + 1) * 8, s));
-  HIP_TRY(hj_launch_group_boundaries(ks, sel.d_dev, perm, n, flags.as<uint64_t>(), s));
+  // one NULL-free key: the sorted key images of the last pass are the keys — a streaming compare instead of two
+  // random gathers per position
+  if (n_keys == 1 && !ks.k[0].valid) HIP_TRY(hj_launch_run_heads(keys_b.as<uint64_t>(), n, flags.as<uint64_t>(), s));
+  else HIP_TRY(hj_launch_group_boundaries(ks, sel.d_dev, perm, n, flags.as<uint64_t>(), s));
   {
     size_t tb = 0;
     HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, flags.as<uint64_t>(), offs.as<uint64_t>(), n + 1, s));

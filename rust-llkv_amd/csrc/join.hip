@@ -280,20 +280,34 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
 
 __global__ __launch_bounds__(256) void hj_topk_keys_kernel(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys,
                                                             uint32_t *slots, unsigned long long *n_groups) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool has = i < cap && count_by_slot[i] != 0;
-  const unsigned long long b = __ballot(has);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_groups, (unsigned long long)__popcll(b));
-  if (i >= cap) return;
-  slots[i] = (uint32_t)i;
-  if (!has) { keys[i] = ~0ull; return; } // no group in this slot: sorts last
-  long long bits = __double_as_longlong(sum_by_slot[i]);
-  const uint64_t asc = bits < 0 ? ~(uint64_t)bits : ((uint64_t)bits | 0x8000000000000000ull); // ascending order key of an f64
-  keys[i] = ~asc == ~0ull ? ~asc - 1 : ~asc;                                                   // descending; never the sentinel
+  // 8 elements per thread, one atomic per workgroup: same-address atomics serialize at ~10 ns each, so a
+  // per-wave atomic over millions of slots costs more than the rest of the kernel
+  __shared__ uint32_t block_count;
+  if (threadIdx.x == 0) block_count = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  const uint64_t base = (uint64_t)blockIdx.x * (256 * 8);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint64_t i = base + (uint64_t)r * 256 + threadIdx.x;
+    if (i >= cap) continue;
+    const bool has = count_by_slot[i] != 0;
+    mine += has ? 1u : 0u;
+    slots[i] = (uint32_t)i;
+    if (!has) { keys[i] = ~0ull; continue; } // no group in this slot: sorts last
+    long long bits = __double_as_longlong(sum_by_slot[i]);
+    const uint64_t asc = bits < 0 ? ~(uint64_t)bits : ((uint64_t)bits | 0x8000000000000000ull); // ascending order key of an f64
+    keys[i] = ~asc == ~0ull ? ~asc - 1 : ~asc;                                                   // descending; never the sentinel
+  }
+  for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&block_count, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && block_count) atomicAdd(n_groups, (unsigned long long)block_count);
 }
 hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots,
                                unsigned long long *n_groups, hipStream_t s) {
-  hipLaunchKernelGGL(hj_topk_keys_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, sum_by_slot, count_by_slot, cap, keys, slots, n_groups);
+  if (cap == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_topk_keys_kernel, dim3((uint32_t)((cap + 2047) / 2048)), dim3(256), 0, s, sum_by_slot, count_by_slot, cap, keys, slots, n_groups);
   return hipGetLastError();
 }
 
@@ -398,26 +412,36 @@ hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, co
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(128) void hj_gather_group_candidates_kernel(const uint64_t *sorted_keys, const uint32_t *sorted_groups, uint32_t n,
+__global__ __launch_bounds__(256) void hj_high_halves_kernel(const uint64_t *keys, uint64_t n, uint32_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint32_t)(keys[i] >> 32);
+}
+hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_high_halves_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, keys, n, out);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(128) void hj_gather_group_candidates_kernel(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n,
                                                                          const uint64_t *dim_rows, const double *sum_by_group,
                                                                          const uint64_t *count_by_group, CandidateCols cols, uint64_t *out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t *o = out + (uint64_t)i * 8;
-  o[0] = sorted_keys[i];
-  if (sorted_keys[i] == ~0ull) { for (int k = 1; k < 8; ++k) o[k] = 0; return; }
   const uint32_t g = sorted_groups[i];
+  const uint64_t key = sorted_keys ? sorted_keys[i] : keys_by_group[g];
+  o[0] = key;
+  if (key == ~0ull) { for (int k = 1; k < 8; ++k) o[k] = 0; return; }
   const uint64_t owner = dim_rows[g];
   o[1] = (uint64_t)load_key(cols.key, owner);
   o[2] = (uint64_t)__double_as_longlong(sum_by_group[g]);
   o[3] = count_by_group[g];
   for (uint32_t k = 0; k < 4; ++k) o[4 + k] = k < cols.n_payload ? (uint64_t)load_key(cols.payload[k], owner) : 0;
 }
-hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
+hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols, uint64_t *out,
                                              hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_gather_group_candidates_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sorted_keys, sorted_groups, n, dim_rows,
+  hipLaunchKernelGGL(hj_gather_group_candidates_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sorted_keys, keys_by_group, sorted_groups, n, dim_rows,
                      sum_by_group, count_by_group, cols, out);
   return hipGetLastError();
 }

@@ -102,7 +102,9 @@ hipError_t hj_launch_report_counts(const uint64_t *local_cnt, const int64_t *glo
 hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, const uint64_t *counts, uint64_t n, double *sum_by_group,
                                   uint64_t *report, hipStream_t s);
 // gather_candidates for group ids: owner row = dim_rows[group].
-hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
+// (`sorted_keys` may be nullptr: the key of candidate i is then `keys_by_group[sorted_groups[i]]`.)
+hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s);
+hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,
                                              uint64_t *out /*[n][8]*/, hipStream_t s);
 

@@ -18,6 +18,7 @@
 #include "join.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -297,31 +298,50 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   HIP_TRY(hipMemsetAsync(n_groups_d.p, 0, 8, s));
   HIP_TRY(hj_launch_topk_keys((const double *)sums.p, (const uint64_t *)report.p, n_dim, (uint64_t *)tk_keys.p, (uint32_t *)tk_groups.p,
                               (unsigned long long *)n_groups_d.p, s));
-  {
-    DB tmp;
-    size_t tb = 0;
-    HIP_TRY(hj_sort_u64_u32(nullptr, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
-  // ---- candidates → host: the first (limit + slack) groups by descending sum, gathered in ONE kernel + ONE copy ----
+  // ---- candidates → host: the first (limit + slack) groups by descending sum ------------------------------------
+  // The top groups are decided by the high half of the order key almost always: sort on bits 32..63 first (half
+  // the radix passes) and fall back to all 64 bits only when the cut falls inside a run of equal high halves.
   const uint32_t want = (uint32_t)std::min<uint64_t>(n_dim, (uint64_t)limit + 64);
   DB cand_d;
   if ((rc = cand_d.alloc((size_t)want * 64 + 8))) return rc;
-  HIP_TRY(hj_launch_gather_group_candidates((const uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups_s.p, want, d_dim_rows, (const double *)sums.p,
-                                            (const uint64_t *)report.p, cc, (uint64_t *)cand_d.p, s));
   std::vector<uint64_t> hc((size_t)want * 8);
   std::vector<uint32_t> hg(want);
   uint64_t n_groups = 0;
-  HIP_TRY(hipMemcpyAsync(hc.data(), cand_d.p, (size_t)want * 64, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(hg.data(), tk_groups_s.p, (size_t)want * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&n_groups, n_groups_d.p, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
   uint32_t n_cand = 0;
-  while (n_cand < want && hc[(size_t)n_cand * 8] != ~0ull) ++n_cand;
-  if (n_cand == want && (uint64_t)want < n_dim && n_cand > limit && limit > 0 && hc[(size_t)(limit - 1) * 8] == hc[(size_t)(want - 1) * 8])
-    return set_error(LLKV_UNSUPPORTED, "more than 64 groups tie on the LIMIT boundary");
+  DB hi, hi_s;
+  if ((rc = hi.alloc(n_dim * 4)) || (rc = hi_s.alloc(n_dim * 4))) return rc;
+  for (int pass = std::getenv("LLKV_HIP_TOPK_FULL") ? 1 : 0; pass < 2; ++pass) {
+    DB tmp;
+    size_t tb = 0;
+    const uint32_t shift = pass == 0 ? 32 : 0;
+    if (pass == 0) { // 32-bit keys = high halves of the order keys, (u32, u32) pairs: 4 radix passes instead of 8
+      HIP_TRY(hj_launch_high_halves((const uint64_t *)tk_keys.p, n_dim, (uint32_t *)hi.p, s));
+      HIP_TRY(hj_sort_by_slot(nullptr, &tb, (const uint32_t *)hi.p, (uint32_t *)hi_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, (uint32_t)n_dim, 32, s));
+      if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+      HIP_TRY(hj_sort_by_slot(tmp.p, &tb, (const uint32_t *)hi.p, (uint32_t *)hi_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, (uint32_t)n_dim, 32, s));
+    } else {
+      HIP_TRY(hj_sort_u64_u32(nullptr, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
+      if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+      HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
+    }
+    HIP_TRY(hj_launch_gather_group_candidates(pass == 0 ? nullptr : (const uint64_t *)tk_keys_s.p, (const uint64_t *)tk_keys.p, (const uint32_t *)tk_groups_s.p, want,
+                                              d_dim_rows, (const double *)sums.p, (const uint64_t *)report.p, cc, (uint64_t *)cand_d.p, s));
+    HIP_TRY(hipMemcpyAsync(hc.data(), cand_d.p, (size_t)want * 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hg.data(), tk_groups_s.p, (size_t)want * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&n_groups, n_groups_d.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // candidates without a group (sentinel key) only trail the others on the full key; on the half key they may
+    // be interleaved with a group: then — or when the cut falls inside a run of equal compared bits — decide on
+    // the full key
+    uint32_t first_sentinel = 0;
+    while (first_sentinel < want && hc[(size_t)first_sentinel * 8] != ~0ull) ++first_sentinel;
+    n_cand = first_sentinel;
+    const bool cut_inside_tie = n_cand == want && (uint64_t)want < n_dim && limit > 0 && n_cand > limit &&
+                                (hc[(size_t)(limit - 1) * 8] >> shift) == (hc[(size_t)(want - 1) * 8] >> shift);
+    if (pass == 0 && (cut_inside_tie || n_cand < want)) continue;
+    if (cut_inside_tie) return set_error(LLKV_UNSUPPORTED, "more than 64 groups tie on the LIMIT boundary");
+    break;
+  }
   std::vector<llkv_join_group_row> cand(n_cand);
   for (uint32_t i = 0; i < n_cand; ++i) {
     const uint64_t *c = &hc[(size_t)i * 8];
