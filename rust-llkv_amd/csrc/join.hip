@@ -366,6 +366,23 @@ hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table,
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void hj_compact_stripes_kernel(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
+                                                                  uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val) {
+  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= n_slots) return;
+  const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
+  for (uint64_t i = threadIdx.x & 63; i < cnt; i += 64) {
+    out_group[dst + i] = slot_group[stripe_slot[src + i]];
+    out_val[dst + i] = stripe_val[src + i];
+  }
+}
+hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
+                                     uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s) {
+  if (n_slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_compact_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_slot, stripe_val, counts, offsets, n_slots, stripe, slot_group, out_group, out_val);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void hj_straddler_flags_kernel(const uint32_t *group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
                                                                   uint64_t *flags) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

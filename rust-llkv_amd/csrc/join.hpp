@@ -92,6 +92,10 @@ hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32
 hipError_t hj_launch_slot_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, const unsigned long long *slot_owner,
                                  uint64_t cap_mask, uint32_t *slot_group, hipStream_t s);
 hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table, hipStream_t s);
+// Compaction of the single-pass probe output: stripe `slot` holds counts[slot] pairs at slot·stripe; they move to
+// offsets[slot] with the hash slot translated to its group id.
+hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
+                                     uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s);
 // flags[i] = 1 when the group of sorted pair i has rows on another rank too (local count ≠ global count).
 hipError_t hj_launch_straddler_flags(const uint32_t *sorted_group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
                                      uint64_t *flags, hipStream_t s);

@@ -206,18 +206,23 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   p.ht_keys = kd.values;
   p.ht_key_width = kd.width;
   p.ht_key_signed = kd.is_signed;
-  if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &p, sizeof p, s))) return rc;
+  // single pass over the fact columns: every (tile, wave) writes its pairs into its own stripe and reports its
+  // count; only the emitted pairs (a few percent of the rows for Q3) are touched again by the compaction
+  const uint32_t stripe = p.sub_rows;
+  DB st_slot, st_val;
+  if ((rc = st_slot.alloc((size_t)n_slots * stripe * 4)) || (rc = st_val.alloc((size_t)n_slots * stripe * 8))) return rc;
+  p.aux_in = nullptr;
+  p.aux_out32 = (uint32_t *)st_slot.p;
+  p.aux_out = (uint64_t *)st_val.p;
+  if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
   if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, s))) return rc;
   HIP_TRY(hipMemcpy(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost));
   if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
   DB e_group, e_val;
   if ((rc = e_group.alloc(n_pairs * 4)) || (rc = e_val.alloc(n_pairs * 8)) || (rc = s_group.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;
-  p.aux_in = (const uint64_t *)offsets.p;
-  p.aux_out32 = (uint32_t *)e_group.p;
-  p.aux_out = (uint64_t *)e_val.p;
-  if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
-  HIP_TRY(hj_launch_map_u32((uint32_t *)e_group.p, n_pairs, (const uint32_t *)slot_group.p, s)); // slot → group id
+  HIP_TRY(hj_launch_compact_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p, n_slots, stripe,
+                                    (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
   // ---- stable sort by group, per-group sums in scan order ---------------------------------------
   uint32_t bits = 1;
   while ((1ull << bits) < n_dim) ++bits;

@@ -92,7 +92,12 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
   const uint32_t sub0 = wave * p.sub_rows;
   const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
   const uint64_t slot_idx = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
-  uint64_t base = WRITE ? p.aux_in[slot_idx] : 0;
+  // WRITE with aux_in == nullptr is the single-pass form: each (tile, wave) writes into its own sub_rows-sized
+  // stripe of the output and reports its count as well; a compaction of the (few) emitted pairs replaces the
+  // second scan of the fact columns
+  const bool strided = WRITE && p.aux_in == nullptr;
+  uint64_t base = WRITE ? (strided ? slot_idx * p.sub_rows : p.aux_in[slot_idx]) : 0;
+  const uint64_t base0 = base;
   uint64_t count = 0;
   uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -122,9 +127,9 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
       count += __popcll(b0) + __popcll(b1);
     }
   }
-  if constexpr (!WRITE) {
+  if (!WRITE || strided) {
     const bool any_err = __ballot(perr != 0) != 0;
-    if (lane == 0) p.tile_partials[slot_idx] = count + (any_err ? kPredErrorBit : 0);
+    if (lane == 0) p.tile_partials[slot_idx] = (WRITE ? base - base0 : count) + (any_err ? kPredErrorBit : 0);
   }
 }
 
