@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the workload timed on the CPU oracle (0 = auto)")
-    ap.add_argument("--also", default="q6_sf10,q6_sf1", help="extra workloads measured (N=1 only) and reported under 'also'")
+    ap.add_argument("--also", default="q6_sf10,q6_sf1,q3_sf10", help="extra workloads measured (N=1 only) and reported under 'also'")
     return ap.parse_args()
 
 
@@ -224,6 +224,49 @@ def cpu_baseline(tpch, abi, query, sf, sample_rows):
     return out
 
 
+def measure_q3(rt, tpch, abi, sf):
+    """BASELINE.json configs[4], single-GPU form: customer(segment) ⋉ orders(date) ⋈ lineitem(shipdate), GROUP BY the
+    order, SUM(price·(1−disc)), top 10 — wall time of llkv_hip_join_groupby_topk with every input resident in HBM
+    (hash probing is latency bound: GB/s are quoted against the algorithmic bytes of SURVEY.md §8d for reference)."""
+    rows, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
+    D = tpch.DATE_1995_03_15
+    li = tpch.gen_lineitem(rows, scale, ["l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"])
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    lt = rt.HipTable(1, tpch.chunk_rows(rows))
+    for c in li:
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
+    ot = rt.HipTable(2, tpch.chunk_rows(n_ord))
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot.append_column(fid, dt, od[c])
+    ct = rt.HipTable(3, tpch.chunk_rows(n_cust))
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]])
+    del li, od, cu
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    rev = col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT))
+
+    def run():
+        return rt.join_groupby_topk(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, rev,
+                                    payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10, dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                                    dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    run()
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        _, groups = run()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    alg = rows * 28 + n_ord * 28 + n_cust * 9
+    for t in (lt, ot, ct):
+        t.close()
+    return {"rows_per_s": rows / med, "ms_per_step": med * 1e3, "groups": int(groups), "achieved_gbs": alg / med / 1e9, "frac": alg / med / 1e9 / HBM_PEAK_GBS,
+            "note": "whole pipeline (2 selections, semi join, hash build, probe, sort, sums, top-k), host-timed median of 7"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,6 +321,9 @@ def main():
         main_q = main_res.pop("prepared"); main_q.close()
         main_res.pop("table").close()
         for name in [w for w in args.also.split(",") if w and w != args.workload]:
+            if name.startswith("q3_"):
+                also[name] = measure_q3(rt, tpch, abi, name.split("_")[1])
+                continue
             r = measure(rt, tpch, abi, torch, dist, name, 0, 1, "weak", args.steps, args.warmup)
             ks = r["kernel_ms_avg"] / 1e3
             also[name] = {"rows_per_s": r["total_rows"] * args.steps / r["seconds"], "ms_per_step": r["seconds"] / args.steps * 1e3,
