@@ -473,9 +473,24 @@ typedef struct llkv_projection {
   const char *alias;
 } llkv_projection;
 
+typedef enum llkv_order_transform { /* ScanOrderTransform llkv-scan/src/lib.rs:41-46 */
+  LLKV_ORDER_IDENTITY_INT64 = 0,
+  LLKV_ORDER_IDENTITY_INT32 = 1,
+  LLKV_ORDER_IDENTITY_UTF8 = 2,
+  LLKV_ORDER_CAST_UTF8_TO_INTEGER = 3
+} llkv_order_transform;
+
 typedef struct llkv_scan_options {
   int32_t include_nulls;   /* ScanStreamOptions.include_nulls                 */
   int32_t include_row_ids; /* ScanStreamOptions.include_row_ids               */
+  /* ScanStreamOptions.order (ScanOrderSpec, llkv-scan/src/lib.rs:48-55; sort_row_ids_with_order llkv-scan/src/
+   * ordering.rs:16-140): the selected rows are sorted by one column before they are cut into windows.  Rows
+   * with equal keys keep row-id order (arrow's sort leaves ties unspecified).                                  */
+  int32_t order_enabled;
+  uint32_t order_field;
+  int32_t order_descending;
+  int32_t order_nulls_first;
+  int32_t order_transform; /* llkv_order_transform                            */
 } llkv_scan_options;
 
 typedef struct llkv_column_view {

@@ -12,6 +12,7 @@
 #define _GNU_SOURCE
 #include "llkv_oracle.h"
 
+#include <errno.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1141,9 +1142,19 @@ typedef void (*window_cb)(const arr *cols, uint32_t n_cols, const uint64_t *row_
 
 /* execute_scan llkv-scan/src/execute.rs:47-295; window materialisation
  * row_stream.rs:369-438,451-623. */
+static int32_t order_row_ids(const orc_table *t, const llkv_scan_options *o, uint64_t *ids, uint64_t n);
+
+static int32_t scan_core_ordered(const orc_table *t, const proj_plan *projs, uint32_t n_projs,
+                                 const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                                 uint32_t n_ops, int include_nulls, const llkv_scan_options *order, window_cb cb, void *user);
 static int32_t scan_core(const orc_table *t, const proj_plan *projs, uint32_t n_projs,
                          const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                          uint32_t n_ops, int include_nulls, window_cb cb, void *user) {
+  return scan_core_ordered(t, projs, n_projs, filters, n_filters, ops, n_ops, include_nulls, NULL, cb, user);
+}
+static int32_t scan_core_ordered(const orc_table *t, const proj_plan *projs, uint32_t n_projs,
+                                 const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
+                                 uint32_t n_ops, int include_nulls, const llkv_scan_options *order, window_cb cb, void *user) {
   /* unique fields to gather (direct columns + expression inputs) */
   uint32_t fields[128], n_fields = 0;
   for (uint32_t p = 0; p < n_projs; ++p) {
@@ -1163,6 +1174,7 @@ static int32_t scan_core(const orc_table *t, const proj_plan *projs, uint32_t n_
   uint64_t *ids = NULL, n_ids = 0;
   int32_t rc = orc_filter_row_ids(t, filters, n_filters, ops, n_ops, &ids, &n_ids); /* execute.rs:219 */
   if (rc) return rc;
+  if (order && order->order_enabled && n_ids && (rc = order_row_ids(t, order, ids, n_ids))) { free(ids); return rc; } /* execute.rs:221-237 */
 
   /* all matching row ids are materialised, then cut into 65 536-row windows
    * (row_stream.rs:243-254,289-299) */
@@ -1230,9 +1242,66 @@ int32_t orc_scan_stream(const orc_table *t, const llkv_projection *projections, 
     pp[i].expr_len = projections[i].expr_len;
   }
   stream_ctx s = {on_batch, user, options ? options->include_row_ids : 0};
-  int32_t rc = scan_core(t, pp, n_projections, filters, n_filters, ops, n_ops, options ? options->include_nulls : 0, stream_window, &s);
+  int32_t rc = scan_core_ordered(t, pp, n_projections, filters, n_filters, ops, n_ops, options ? options->include_nulls : 0, options, stream_window, &s);
   free(pp);
   return rc;
+}
+
+/* sort_row_ids_with_order llkv-scan/src/ordering.rs:16-140: gather the ORDER BY column for the selected rows and
+ * arrow sort_to_indices {descending, nulls_first}; ties are left unspecified by arrow — kept in row-id order here. */
+typedef struct ord_ent { int is_null; int64_t i; const char *s; uint64_t id; uint64_t pos; } ord_ent;
+static int g_ord_desc, g_ord_nulls_first, g_ord_str;
+static int ord_cmp(const void *a, const void *b) {
+  const ord_ent *x = a, *y = b;
+  if (x->is_null != y->is_null) return (x->is_null ? -1 : 1) * (g_ord_nulls_first ? 1 : -1);
+  if (!x->is_null) {
+    int c = g_ord_str ? strcmp(x->s, y->s) : (x->i < y->i ? -1 : x->i > y->i);
+    if (c) return g_ord_desc ? -c : c;
+  }
+  return x->pos < y->pos ? -1 : x->pos > y->pos;
+}
+static int32_t order_row_ids(const orc_table *t, const llkv_scan_options *o, uint64_t *ids, uint64_t n) {
+  const orc_column *c = find_col(t, o->order_field);
+  if (!c) return fail(LLKV_NOT_FOUND, "ORDER BY field %u not found", o->order_field);
+  switch (o->order_transform) {
+  case LLKV_ORDER_IDENTITY_INT64: if (c->dtype != LLKV_DT_INT64) return fail(LLKV_INVALID_ARGUMENT, "ORDER BY expected INT64 column for IdentityInt64 transform"); break;
+  case LLKV_ORDER_IDENTITY_INT32: if (c->dtype != LLKV_DT_INT32) return fail(LLKV_INVALID_ARGUMENT, "ORDER BY expected INT32 column for IdentityInt32 transform"); break;
+  case LLKV_ORDER_IDENTITY_UTF8: if (c->dtype != LLKV_DT_UTF8) return fail(LLKV_INVALID_ARGUMENT, "ORDER BY expected UTF8 column for IdentityUtf8 transform"); break;
+  case LLKV_ORDER_CAST_UTF8_TO_INTEGER: if (c->dtype != LLKV_DT_UTF8) return fail(LLKV_INVALID_ARGUMENT, "ORDER BY CAST expects a UTF8 column"); break;
+  default: return fail(LLKV_INVALID_ARGUMENT, "unknown ORDER BY transform");
+  }
+  ord_ent *e = xmalloc(n * sizeof *e);
+  char **owned = xcalloc(n, sizeof(char *));
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t r = ids[k];
+    e[k].id = r; e[k].pos = k; e[k].i = 0; e[k].s = NULL;
+    e[k].is_null = !col_valid(c, r);
+    if (e[k].is_null) continue;
+    if (c->dtype == LLKV_DT_INT64) e[k].i = ((const int64_t *)c->values)[r];
+    else if (c->dtype == LLKV_DT_INT32) e[k].i = ((const int32_t *)c->values)[r];
+    else {
+      size_t len = (size_t)(c->offsets[r + 1] - c->offsets[r]);
+      owned[k] = xmalloc(len + 1);
+      memcpy(owned[k], c->data + c->offsets[r], len);
+      owned[k][len] = 0;
+      e[k].s = owned[k];
+      if (o->order_transform == LLKV_ORDER_CAST_UTF8_TO_INTEGER) { /* str::parse::<i64>, failures → NULL */
+        char *end;
+        errno = 0;
+        long long v = strtoll(owned[k], &end, 10);
+        int ok = len > 0 && *end == 0 && errno == 0 && !(owned[k][0] == ' ' || owned[k][0] == '\t');
+        if (ok) e[k].i = v; else e[k].is_null = 1;
+      }
+    }
+  }
+  g_ord_desc = o->order_descending != 0;
+  g_ord_nulls_first = o->order_nulls_first != 0;
+  g_ord_str = o->order_transform == LLKV_ORDER_IDENTITY_UTF8;
+  qsort(e, n, sizeof *e, ord_cmp);
+  for (uint64_t k = 0; k < n; ++k) ids[k] = e[k].id;
+  for (uint64_t k = 0; k < n; ++k) free(owned[k]);
+  free(owned); free(e);
+  return LLKV_OK;
 }
 
 /* ------------------------------------------------------------ accumulators */

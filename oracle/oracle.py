@@ -181,7 +181,7 @@ def groupby(table: OracleTable, predicate, keys: Sequence[int], aggs, order_by_k
     return rows
 
 
-def scan_stream(table: OracleTable, projections, predicate, include_nulls=False, include_row_ids=False):
+def scan_stream(table: OracleTable, projections, predicate, include_nulls=False, include_row_ids=False, order=None):
     """Returns the list of batches; each batch = (columns, row_ids) with columns as lists of
     Python values (None = NULL).  ``projections``: field ids or ScalarExpr."""
     keep: list = []
@@ -194,7 +194,7 @@ def scan_stream(table: OracleTable, projections, predicate, include_nulls=False,
             projs[i].computed, projs[i].expr, projs[i].expr_len = 1, arr, len(pr.tokens)
     p = abi.CPlan(predicate)
     t = table.c()
-    opts = abi.CScanOptions(int(include_nulls), int(include_row_ids))
+    opts = abi.scan_options(include_nulls, include_row_ids, order)
     batches = []
 
     def on_batch(bp, _user):

@@ -92,7 +92,19 @@ class CProjection(C.Structure):
 
 
 class CScanOptions(C.Structure):
-    _fields_ = [("include_nulls", C.c_int32), ("include_row_ids", C.c_int32)]
+    _fields_ = [("include_nulls", C.c_int32), ("include_row_ids", C.c_int32), ("order_enabled", C.c_int32), ("order_field", C.c_uint32),
+                ("order_descending", C.c_int32), ("order_nulls_first", C.c_int32), ("order_transform", C.c_int32)]
+
+
+ORDER_IDENTITY_INT64, ORDER_IDENTITY_INT32, ORDER_IDENTITY_UTF8, ORDER_CAST_UTF8_TO_INTEGER = range(4)
+
+
+def scan_options(include_nulls=False, include_row_ids=False, order=None) -> "CScanOptions":
+    """order = (field_id, descending, nulls_first, transform) or None (ScanOrderSpec)."""
+    o = CScanOptions(int(include_nulls), int(include_row_ids))
+    if order is not None:
+        o.order_enabled, o.order_field, o.order_descending, o.order_nulls_first, o.order_transform = 1, order[0], int(order[1]), int(order[2]), order[3]
+    return o
 
 
 class CColumnView(C.Structure):

@@ -591,6 +591,35 @@ hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_in
   return hipGetLastError();
 }
 
+// ---- ordered scans ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hj_gather_u64_kernel(const uint64_t *in, const uint32_t *perm, uint64_t n, uint64_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[perm[i]];
+}
+hipError_t hj_launch_gather_u64(const uint64_t *in, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_gather_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, perm, n, out);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_xor_u64_kernel(uint64_t *keys, uint64_t n, uint64_t mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] ^= mask;
+}
+hipError_t hj_launch_xor_u64(uint64_t *keys, uint64_t n, uint64_t mask, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_xor_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, keys, n, mask);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_xor_u32_kernel(uint32_t *keys, uint64_t n, uint32_t mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] ^= mask;
+}
+hipError_t hj_launch_xor_u32(uint32_t *keys, uint64_t n, uint32_t mask, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_xor_u32_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, keys, n, mask);
+  return hipGetLastError();
+}
+
 // ---- exact, order-dependent SUM(Int64) overflow check -------------------------------------------
 struct I128 {
   uint64_t lo;

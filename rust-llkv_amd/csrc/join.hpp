@@ -144,6 +144,11 @@ hipError_t hj_launch_run_heads(const uint64_t *sorted, uint64_t n, uint64_t *fla
 // lane-strided order with a fixed butterfly.  *out = the sum.
 hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, hipStream_t s);
 
+// ---- ordered scans (stream.cpp) -----------------------------------------------------------------------------
+hipError_t hj_launch_gather_u64(const uint64_t *in, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t s);
+hipError_t hj_launch_xor_u64(uint64_t *keys, uint64_t n, uint64_t mask, hipStream_t s);
+hipError_t hj_launch_xor_u32(uint32_t *keys, uint64_t n, uint32_t mask, hipStream_t s);
+
 // Does any prefix of vals[0..n) (summed left to right, exactly) leave the i64 range?  *d_flag |= 1 if so.
 // `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.
 hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s);

@@ -4,6 +4,7 @@
 // windows (execute.rs:31) → gather + computed projections on the device → pinned host
 // window → on_batch on the calling thread, in row-id order, never an empty batch.
 #include "engine.hpp"
+#include "join.hpp"
 
 #include <cstring>
 #include <memory>
@@ -86,6 +87,84 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
   return LLKV_OK;
 }
 
+// ScanStreamOptions.order: sort the selection by one column (sort_row_ids_with_order, llkv-scan/src/ordering.rs:16-140
+// → arrow sort_to_indices with {descending, nulls_first}); stable, so equal keys keep row-id order.
+static int sort_selection(const Table *t, const llkv_scan_options *o, Selection *sel) {
+  auto it = t->cols.find(o->order_field);
+  if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "ORDER BY field " + std::to_string(o->order_field) + " not found");
+  const DeviceColumn &c = it->second;
+  switch (o->order_transform) {
+  case LLKV_ORDER_IDENTITY_INT64: if (c.info.dtype != LLKV_DT_INT64) return set_error(LLKV_INVALID_ARGUMENT, "ORDER BY expected INT64 column for IdentityInt64 transform"); break;
+  case LLKV_ORDER_IDENTITY_INT32: if (c.info.dtype != LLKV_DT_INT32) return set_error(LLKV_INVALID_ARGUMENT, "ORDER BY expected INT32 column for IdentityInt32 transform"); break;
+  case LLKV_ORDER_IDENTITY_UTF8: if (c.info.dtype != LLKV_DT_UTF8) return set_error(LLKV_INVALID_ARGUMENT, "ORDER BY expected UTF8 column for IdentityUtf8 transform"); break;
+  case LLKV_ORDER_CAST_UTF8_TO_INTEGER:
+    if (c.info.dtype != LLKV_DT_UTF8) return set_error(LLKV_INVALID_ARGUMENT, "ORDER BY CAST expects a UTF8 column");
+    return set_error(LLKV_UNSUPPORTED, "ORDER BY CAST(utf8 AS INTEGER) is not on the GPU path");
+  default: return set_error(LLKV_INVALID_ARGUMENT, "unknown ORDER BY transform");
+  }
+  const uint64_t n = sel->n;
+  if (n < 2) return LLKV_OK;
+  if (n >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "more than 2^32 selected rows in an ordered scan");
+  hipStream_t s = g_ctx.stream;
+  JoinKeyColumn kc;
+  std::memset(&kc, 0, sizeof kc);
+  kc.values = c.d_values;
+  kc.valid = c.info.nullable ? c.d_valid : nullptr;
+  long long base = 0;
+  Scratch rank_d;
+  const uint8_t *code_rank = nullptr;
+  if (c.info.dtype == LLKV_DT_INT64) { kc.width = 8; kc.is_signed = 1; base = INT64_MIN; }
+  else if (c.info.dtype == LLKV_DT_INT32) { kc.width = 4; kc.is_signed = 1; base = INT32_MIN; }
+  else { // dictionary codes sort as their strings do (str::cmp)
+    kc.width = 1;
+    std::vector<uint32_t> idx(c.info.dictionary.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return c.info.dictionary[a] < c.info.dictionary[b]; });
+    uint8_t rank[256] = {0};
+    for (size_t r = 0; r < idx.size(); ++r) rank[idx[r]] = (uint8_t)r;
+    int rc = rank_d.alloc(256);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rank_d.p, rank, 256, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    code_rank = rank_d.as<uint8_t>();
+  }
+  Scratch perm_a, perm_b, keys_a, keys_b, tmp;
+  int rc;
+  if ((rc = perm_a.alloc(n * 4)) || (rc = perm_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8))) return rc;
+  HIP_TRY(hj_launch_iota(perm_a.as<uint32_t>(), (uint32_t)n, s));
+  uint32_t *perm = perm_a.as<uint32_t>(), *other = perm_b.as<uint32_t>();
+  HIP_TRY(hj_launch_gather_sort_keys(kc, base, code_rank, sel->d_dev, perm, n, keys_a.as<uint64_t>(), s));
+  if (o->order_descending) HIP_TRY(hj_launch_xor_u64(keys_a.as<uint64_t>(), n, ~0ull, s)); // descending = ascending on the complement, still stable
+  size_t tb = 0;
+  HIP_TRY(hj_sort_u64_u32(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, other, n, s));
+  if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+  HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, other, n, s));
+  std::swap(perm, other);
+  HIP_TRY(hipStreamSynchronize(s));
+  if (kc.valid) { // NULL cells: one more stable 1-bit pass puts them first or last
+    Scratch va, vb;
+    if ((rc = va.alloc(n * 4)) || (rc = vb.alloc(n * 4))) return rc;
+    HIP_TRY(hj_launch_gather_valid(kc, sel->d_dev, perm, n, va.as<uint32_t>(), s));
+    if (!o->order_nulls_first) HIP_TRY(hj_launch_xor_u32(va.as<uint32_t>(), n, 1u, s));
+    size_t vb_bytes = 0;
+    HIP_TRY(hj_sort_by_slot(nullptr, &vb_bytes, va.as<uint32_t>(), vb.as<uint32_t>(), perm, other, (uint32_t)n, 1, s));
+    if ((rc = tmp.alloc(vb_bytes ? vb_bytes : 8))) return rc;
+    HIP_TRY(hj_sort_by_slot(tmp.p, &vb_bytes, va.as<uint32_t>(), vb.as<uint32_t>(), perm, other, (uint32_t)n, 1, s));
+    std::swap(perm, other);
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  uint64_t *ids2 = (uint64_t *)scratch_alloc(n * 8), *dev2 = (uint64_t *)scratch_alloc(n * 8);
+  if (!ids2 || !dev2) { scratch_free(ids2); scratch_free(dev2); return set_error(LLKV_INTERNAL, "device scratch allocation failed"); }
+  HIP_TRY(hj_launch_gather_u64(sel->d_ids, perm, n, ids2, s));
+  HIP_TRY(hj_launch_gather_u64(sel->d_dev, perm, n, dev2, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  scratch_free(sel->d_ids);
+  scratch_free(sel->d_dev);
+  sel->d_ids = ids2;
+  sel->d_dev = dev2;
+  return LLKV_OK;
+}
+
 Selection::~Selection() {
   scratch_free(d_ids);
   scratch_free(d_dev);
@@ -143,6 +222,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   }
   if ((rc = run_selection(t, filters, n_filters, ops, n_ops, &sel, gathered.data(), (uint32_t)gathered.size()))) return (llkv_status)rc;
   if (sel.n == 0) return LLKV_OK; // a filter that matches nothing yields no batch
+  if (options && options->order_enabled && (rc = sort_selection(t, options, &sel))) return (llkv_status)rc;
   JitKernel k;
   if ((rc = jit_compile(JitKind::Project, proj.type_string, &k, &err))) return (llkv_status)set_error(rc, err);
 

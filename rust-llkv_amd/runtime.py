@@ -405,7 +405,7 @@ def filter_row_ids(table: HipTable, predicate) -> np.ndarray:
     return res
 
 
-def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False):
+def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False, order=None):
     """StorageTable::scan_stream: returns the list of batches [(columns, row_ids)], each column a list of
     Python values.  ``projections``: field ids (ScanProjection::Column) or ScalarExpr (::Computed)."""
     keep: list = []
@@ -417,7 +417,7 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
             arr = pr.to_c(keep)
             projs[i].computed, projs[i].expr, projs[i].expr_len = 1, arr, len(pr.tokens)
     p = CPlan(predicate)
-    opts = abi.CScanOptions(int(include_nulls), int(include_row_ids))
+    opts = abi.scan_options(include_nulls, include_row_ids, order)
     batches = []
 
     def on_batch(bp, _user):
