@@ -18,7 +18,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 abi = importlib.import_module("rust-llkv_amd.abi")
 
-LIB_PATH = os.path.join(_HERE, "libllkv_oracle.so")
+LIB_PATH = os.environ.get("LLKV_ORACLE_LIB") or os.path.join(_HERE, "libllkv_oracle.so")  # override: sanitizer builds
 
 
 def build():
