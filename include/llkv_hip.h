@@ -349,6 +349,12 @@ llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint3
 llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t field_id,
                                             int64_t min_value, int64_t max_value);
 
+/* Bytes moved host → HBM by the staging calls of this process so far, and the wall
+ * time those copies took (pinned ring fill + DMA; the host-side preparation of a
+ * column image — dictionary coding, bitmap expansion — is not in it).  Purely
+ * informational: staging happens once per resident column, outside every query.   */
+void llkv_hip_staging_stats(uint64_t *bytes, double *seconds);
+
 /* NULL cells of an already staged column.  In the reference a NULL cell is a row
  * id that is absent from the column's row-id shadow chunks (llkv-table/src/
  * table.rs:1202-1223; gather turns it into an Arrow NULL, llkv-column-map/src/

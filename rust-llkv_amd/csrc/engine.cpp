@@ -13,9 +13,12 @@
 #include "join.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace llkv {
 
@@ -202,39 +205,129 @@ static int alloc_column(Table &t, uint32_t width, void **d_out) {
   return LLKV_OK;
 }
 
-// pinned double buffer → hipMemcpyAsync (north_star: "pinned and hipMemcpyAsync'd into HBM")
-struct Stager {
-  static constexpr size_t kBuf = 8u << 20;
-  void *pinned[2] = {nullptr, nullptr};
-  hipEvent_t done[2] = {nullptr, nullptr};
-  int cur = 0;
+// Staging: host chunks → pinned ring → hipMemcpyAsync → HBM (north_star: "pinned and hipMemcpyAsync'd into HBM").
+// One lane = one copy stream + a small ring of pinned buffers + one host thread filling them, so the memcpy into
+// pinned memory (the slow half: one core moves ~10 GB/s) runs on several cores while the DMA engines drain the
+// other lanes.  The lanes live for the life of the device binding (pinning memory per column costs more than the
+// copy of a small column).
+struct StagePiece {
+  void *d_dst;
+  const void *h_src;
+  size_t bytes;
+};
+
+struct StagerPool {
+  static constexpr int kLanes = 6, kDepth = 2;
+  static constexpr size_t kBuf = 2u << 20;
+  struct Lane {
+    hipStream_t stream = nullptr;
+    void *pinned[kDepth] = {};
+    hipEvent_t done[kDepth] = {};
+    int cur = 0;
+  };
+  std::mutex mu; // one staging call at a time
+  Lane lanes[kLanes];
+  bool ready = false;
+  uint64_t staged_bytes = 0;
+  double staged_seconds = 0;
+
   int init() {
-    for (int i = 0; i < 2; ++i) {
-      HIP_TRY(hipHostMalloc(&pinned[i], kBuf, hipHostMallocDefault));
-      HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    if (ready) return LLKV_OK;
+    for (Lane &l : lanes) {
+      HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+      for (int i = 0; i < kDepth; ++i) {
+        HIP_TRY(hipHostMalloc(&l.pinned[i], kBuf, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&l.done[i], hipEventDisableTiming));
+      }
     }
+    ready = true;
     return LLKV_OK;
   }
-  ~Stager() {
-    for (int i = 0; i < 2; ++i) {
-      if (pinned[i]) (void)hipHostFree(pinned[i]);
-      if (done[i]) (void)hipEventDestroy(done[i]);
+  void release() {
+    for (Lane &l : lanes) {
+      for (int i = 0; i < kDepth; ++i) {
+        if (l.pinned[i]) (void)hipHostFree(l.pinned[i]);
+        if (l.done[i]) (void)hipEventDestroy(l.done[i]);
+        l.pinned[i] = nullptr;
+        l.done[i] = nullptr;
+      }
+      if (l.stream) (void)hipStreamDestroy(l.stream);
+      l.stream = nullptr;
     }
+    ready = false;
   }
-  int push(void *d_dst, const void *h_src, size_t bytes) {
-    size_t off = 0;
-    while (off < bytes) {
-      const size_t n = std::min(kBuf, bytes - off);
-      HIP_TRY(hipEventSynchronize(done[cur]));
-      std::memcpy(pinned[cur], (const char *)h_src + off, n);
-      HIP_TRY(hipMemcpyAsync((char *)d_dst + off, pinned[cur], n, hipMemcpyHostToDevice, g_ctx.stream));
-      HIP_TRY(hipEventRecord(done[cur], g_ctx.stream));
-      cur ^= 1;
-      off += n;
-    }
+  // copies every piece and returns when all of them are in HBM
+  int run(const std::vector<StagePiece> &pieces) {
+    std::lock_guard<std::mutex> lk(mu);
+    int rc = init();
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<StagePiece> seg;
+    size_t total = 0;
+    for (const StagePiece &p : pieces)
+      for (size_t off = 0; off < p.bytes; off += kBuf) {
+        seg.push_back({(char *)p.d_dst + off, (const char *)p.h_src + off, std::min(kBuf, p.bytes - off)});
+        total += seg.back().bytes;
+      }
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{LLKV_OK};
+    std::string message;
+    std::mutex message_mu;
+    auto work = [&](Lane &l) {
+      int r = ensure_device();
+      auto fail = [&](hipError_t e) {
+        std::lock_guard<std::mutex> g(message_mu);
+        if (failed.exchange(LLKV_INTERNAL) == LLKV_OK) message = std::string("staging copy failed: ") + hipGetErrorString(e);
+      };
+      if (r) { failed = r; std::lock_guard<std::mutex> g(message_mu); message = g_last_error; return; }
+      hipError_t e;
+      for (size_t i; failed == LLKV_OK && (i = next.fetch_add(1)) < seg.size();) {
+        if ((e = hipEventSynchronize(l.done[l.cur])) != hipSuccess) return fail(e);
+        std::memcpy(l.pinned[l.cur], seg[i].h_src, seg[i].bytes);
+        if ((e = hipMemcpyAsync(seg[i].d_dst, l.pinned[l.cur], seg[i].bytes, hipMemcpyHostToDevice, l.stream)) != hipSuccess) return fail(e);
+        if ((e = hipEventRecord(l.done[l.cur], l.stream)) != hipSuccess) return fail(e);
+        l.cur = (l.cur + 1) % kDepth;
+      }
+      if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
+    };
+    const int n_threads = (int)std::min<size_t>(kLanes, (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
+    std::vector<std::thread> threads;
+    for (int k = 1; k < n_threads; ++k) threads.emplace_back(work, std::ref(lanes[k]));
+    work(lanes[0]);
+    for (std::thread &t : threads) t.join();
+    staged_bytes += total;
+    staged_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failed != LLKV_OK) return set_error(failed, message);
     return LLKV_OK;
   }
 };
+static StagerPool g_stager;
+
+// host-side preparation of a column image (dictionary coding, bitmap expansion, Decimal128 narrowing) runs chunk
+// by chunk on a few threads; fn(chunk) returns a status, the first failure wins
+template <class Fn> static int for_each_chunk_parallel(uint32_t n_chunks, Fn &&fn) {
+  const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const unsigned n_threads = std::min<unsigned>(hw, std::max(1u, n_chunks / 4));
+  std::atomic<uint32_t> next{0};
+  std::atomic<int> failed{LLKV_OK};
+  std::string message;
+  std::mutex message_mu;
+  auto work = [&] {
+    for (uint32_t i; failed == LLKV_OK && (i = next.fetch_add(1)) < n_chunks;) {
+      const int rc = fn(i);
+      if (rc) {
+        std::lock_guard<std::mutex> g(message_mu);
+        if (failed.exchange(rc) == LLKV_OK) message = g_last_error;
+      }
+    }
+  };
+  std::vector<std::thread> threads;
+  for (unsigned k = 1; k < n_threads; ++k) threads.emplace_back(work);
+  work();
+  for (std::thread &t : threads) t.join();
+  if (failed != LLKV_OK) return set_error(failed, message);
+  return LLKV_OK;
+}
 
 static int column_stats_device(Table &t, DeviceColumn &c) {
   if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
@@ -907,6 +1000,7 @@ void llkv_hip_shutdown(void) {
   if (!g_ctx.ready) return;
   jit_shutdown();
   scratch_release_all();
+  g_stager.release();
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;
@@ -965,14 +1059,14 @@ llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_i
   c.info.rows = t->total_rows;
   c.owned = true;
   if ((rc = alloc_column(*t, w, &c.d_values))) return (llkv_status)rc;
-  Stager st;
-  if ((rc = st.init())) return (llkv_status)rc;
+  std::vector<StagePiece> pieces;
   for (uint32_t i = 0; i < n_chunks; ++i) {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
     if (rows && !chunk_values[i]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
-    if ((rc = st.push((char *)c.d_values + t->chunk_dev_off[i] * w, chunk_values[i], rows * w))) return (llkv_status)rc;
+    if (rows) pieces.push_back({(char *)c.d_values + t->chunk_dev_off[i] * w, chunk_values[i], rows * w});
   }
-  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed"); // the image is zeroed
+  if ((rc = g_stager.run(pieces))) return (llkv_status)rc;
   if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
   t->cols.emplace(field_id, std::move(c));
   return LLKV_OK;
@@ -1002,44 +1096,72 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
     if (!dict.emplace(s, (uint8_t)d).second) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "duplicate dictionary entry '" + s + "'");
     c.info.dictionary.push_back(s);
   }
-  auto code_of = [&](const std::string &s, uint8_t *out) -> int {
-    auto it = dict.find(s);
-    if (it == dict.end()) {
-      if (fixed) return set_error(LLKV_INVALID_ARGUMENT, "value '" + s + "' is not in the supplied dictionary");
-      if (dict.size() >= 256) return set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
-      it = dict.emplace(s, (uint8_t)dict.size()).first;
-      c.info.dictionary.push_back(s);
-    }
-    *out = it->second;
-    return LLKV_OK;
-  };
-  for (uint32_t i = 0; i < n_chunks; ++i) {
+  if (!fixed) {
+    // codes follow the order of first appearance: every chunk lists its distinct values in that order (in
+    // parallel), the lists are merged in chunk order
+    std::vector<std::vector<std::string>> seen(n_chunks);
+    rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
+      const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+      const int32_t *off = chunk_offsets[i];
+      const uint8_t *data = chunk_data[i];
+      bool one_byte[256] = {};
+      std::map<std::string, int> local;
+      for (uint64_t r = 0; r < rows; ++r) {
+        const int32_t len = off[r + 1] - off[r];
+        if (len == 1) {
+          const uint8_t ch = data[off[r]];
+          if (!one_byte[ch]) { one_byte[ch] = true; seen[i].emplace_back(1, (char)ch); }
+        } else {
+          std::string s((const char *)data + off[r], (size_t)len);
+          if (local.emplace(s, 0).second) seen[i].push_back(std::move(s));
+        }
+        if (seen[i].size() > 256) return set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+      }
+      return LLKV_OK;
+    });
+    if (rc) return (llkv_status)rc;
+    for (uint32_t i = 0; i < n_chunks; ++i)
+      for (std::string &s : seen[i])
+        if (!dict.count(s)) {
+          if (dict.size() >= 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+          dict.emplace(s, (uint8_t)dict.size());
+          c.info.dictionary.push_back(s);
+        }
+  }
+  rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
     const int32_t *off = chunk_offsets[i];
     const uint8_t *data = chunk_data[i];
     uint8_t *dst = codes.data() + t->chunk_dev_off[i];
     int16_t lut[256]; // fast path for 1-byte strings (TPC-H flags)
     std::fill(std::begin(lut), std::end(lut), (int16_t)-1);
+    auto code_of = [&](const std::string &s, uint8_t *out) -> int {
+      auto it = dict.find(s);
+      if (it == dict.end()) return set_error(LLKV_INVALID_ARGUMENT, "value '" + s + "' is not in the supplied dictionary");
+      *out = it->second;
+      return LLKV_OK;
+    };
     for (uint64_t r = 0; r < rows; ++r) {
       const int32_t len = off[r + 1] - off[r];
+      int e;
       if (len == 1) {
         const uint8_t ch = data[off[r]];
         if (lut[ch] < 0) {
           uint8_t code;
-          if ((rc = code_of(std::string(1, (char)ch), &code))) return (llkv_status)rc;
+          if ((e = code_of(std::string(1, (char)ch), &code))) return e;
           lut[ch] = code;
         }
         dst[r] = (uint8_t)lut[ch];
-      } else {
-        if ((rc = code_of(std::string((const char *)data + off[r], (size_t)len), &dst[r]))) return (llkv_status)rc;
+      } else if ((e = code_of(std::string((const char *)data + off[r], (size_t)len), &dst[r]))) {
+        return e;
       }
     }
-  }
+    return LLKV_OK;
+  });
+  if (rc) return (llkv_status)rc;
   if ((rc = alloc_column(*t, 1, &c.d_values))) return (llkv_status)rc;
-  Stager st;
-  if ((rc = st.init())) return (llkv_status)rc;
-  if ((rc = st.push(c.d_values, codes.data(), t->dev_rows))) return (llkv_status)rc;
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if ((rc = g_stager.run({{c.d_values, codes.data(), (size_t)t->dev_rows}}))) return (llkv_status)rc;
   t->cols.emplace(field_id, std::move(c));
   return LLKV_OK;
 }
@@ -1054,6 +1176,12 @@ llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint3
   if (min_value) *min_value = it->second.local_min;
   if (max_value) *max_value = it->second.local_max;
   return LLKV_OK;
+}
+
+void llkv_hip_staging_stats(uint64_t *bytes, double *seconds) {
+  std::lock_guard<std::mutex> lk(g_stager.mu);
+  if (bytes) *bytes = g_stager.staged_bytes;
+  if (seconds) *seconds = g_stager.staged_seconds;
 }
 
 llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t field_id, int64_t min_value, int64_t max_value) {
@@ -1087,17 +1215,19 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
   // narrow the 16-byte raw values to the 8 B/row device image; a value that needs more than 64 bits keeps the
   // column on the caller's CPU route
   std::vector<int64_t> narrow(t->dev_rows + 16, 0);
-  for (uint32_t i = 0; i < n_chunks; ++i) {
+  rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
-    if (rows && !chunk_values[i]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
+    if (rows && !chunk_values[i]) return set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
     const int64_t *src = static_cast<const int64_t *>(chunk_values[i]); // (lo, hi) pairs, little endian
     int64_t *dst = narrow.data() + t->chunk_dev_off[i];
     for (uint64_t r = 0; r < rows; ++r) {
       const int64_t lo = src[2 * r], hi = src[2 * r + 1];
-      if (hi != (lo >> 63)) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id));
+      if (hi != (lo >> 63)) return set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id));
       dst[r] = lo;
     }
-  }
+    return LLKV_OK;
+  });
+  if (rc) return (llkv_status)rc;
   DeviceColumn c;
   c.info.field_id = field_id;
   c.info.dtype = LLKV_DT_DECIMAL128;
@@ -1106,10 +1236,8 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
   c.info.rows = t->total_rows;
   c.owned = true;
   if ((rc = alloc_column(*t, 8, &c.d_values))) return (llkv_status)rc;
-  Stager st;
-  if ((rc = st.init())) return (llkv_status)rc;
-  if ((rc = st.push(c.d_values, narrow.data(), t->dev_rows * 8))) return (llkv_status)rc;
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if ((rc = g_stager.run({{c.d_values, narrow.data(), (size_t)t->dev_rows * 8}}))) return (llkv_status)rc;
   if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
   t->cols.emplace(field_id, std::move(c));
   return LLKV_OK;
@@ -1130,18 +1258,22 @@ llkv_status llkv_hip_table_set_column_validity(llkv_hip_table *table, uint32_t f
   // Arrow bitmaps → 1 B/row in the device row layout (rows of padding between chunks stay 0; tiles never
   // select them)
   std::vector<uint8_t> mask(t->dev_rows + 16, 0);
-  uint64_t nulls = 0;
-  for (uint32_t i = 0; i < n_chunks; ++i) {
+  std::atomic<uint64_t> nulls{0};
+  rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
     uint8_t *dst = mask.data() + t->chunk_dev_off[i];
     const uint8_t *bits = chunk_validity[i];
-    if (!bits) { std::memset(dst, 1, rows); continue; }
+    if (!bits) { std::memset(dst, 1, rows); return LLKV_OK; }
+    uint64_t n = 0;
     for (uint64_t r = 0; r < rows; ++r) {
       const uint8_t v = (bits[r >> 3] >> (r & 7)) & 1u;
       dst[r] = v;
-      nulls += !v;
+      n += !v;
     }
-  }
+    nulls += n;
+    return LLKV_OK;
+  });
+  if (rc) return (llkv_status)rc;
   if (c.d_valid) { (void)hipFree(c.d_valid); c.d_valid = nullptr; }
   c.info.nullable = false;
   // whether a column "has NULL cells" must not depend on the shard: with world > 1 any supplied bitmap makes
@@ -1151,10 +1283,8 @@ llkv_status llkv_hip_table_set_column_validity(llkv_hip_table *table, uint32_t f
   if (nulls == 0 && !(t->world > 1 && any_bitmap)) return LLKV_OK;
   void *d = nullptr;
   if ((rc = alloc_column(*t, 1, &d))) return (llkv_status)rc;
-  Stager st;
-  if ((rc = st.init())) { (void)hipFree(d); return (llkv_status)rc; }
-  if ((rc = st.push(d, mask.data(), t->dev_rows))) { (void)hipFree(d); return (llkv_status)rc; }
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) { (void)hipFree(d); return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed"); }
+  if ((rc = g_stager.run({{d, mask.data(), (size_t)t->dev_rows}}))) { (void)hipFree(d); return (llkv_status)rc; }
   c.d_valid = (uint8_t *)d;
   c.info.nullable = true;
   return LLKV_OK;

@@ -50,7 +50,9 @@ def table_wide_dictionary(dist, local_values, world: int) -> List[str]:
     """Sorted union of the shards' distinct Utf8 values (staging-time agreement on dictionary codes).
     ``local_values``: uint8 array of 1-byte strings or a sequence of str."""
     if isinstance(local_values, np.ndarray) and local_values.dtype == np.uint8:
-        local = sorted({chr(int(v)) for v in np.unique(local_values)})
+        seen = np.zeros(256, dtype=bool)
+        seen[local_values] = True  # one pass, no sort of the column
+        local = sorted(chr(int(v)) for v in np.flatnonzero(seen))
     else:
         local = sorted(set(local_values))
     if world <= 1:

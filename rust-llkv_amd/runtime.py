@@ -41,6 +41,7 @@ def lib():
     L.llkv_hip_table_total_rows.argtypes = [C.c_void_p]
     L.llkv_hip_table_local_rows.restype = C.c_uint64
     L.llkv_hip_table_local_rows.argtypes = [C.c_void_p]
+    L.llkv_hip_staging_stats.restype = None
     L.llkv_hip_table_free.argtypes = [C.c_void_p]
     L.llkv_hip_table_free.restype = None
     L.llkv_hip_query_free.argtypes = [C.c_void_p]
@@ -76,6 +77,13 @@ def init(device: int = 0):
 
 def device_count() -> int:
     return int(lib().llkv_hip_device_count())
+
+
+def staging_stats():
+    """(bytes, seconds) of the host → HBM copies this process has made so far."""
+    b, t = C.c_uint64(), C.c_double()
+    lib().llkv_hip_staging_stats(C.byref(b), C.byref(t))
+    return b.value, t.value
 
 
 def shutdown():
@@ -169,8 +177,9 @@ class HipTable:
         (required for sharded tables: every rank must pass the same table-wide dictionary)."""
         chunks_off, chunks_data = [], []
         if isinstance(strings, np.ndarray) and strings.dtype == np.uint8:
+            ramp = np.arange(max(self.local_chunk_rows, default=0) + 1, dtype=np.int32)  # offsets 0..n of any chunk
             for c in self._split(strings):
-                chunks_off.append(np.arange(len(c) + 1, dtype=np.int32))
+                chunks_off.append(ramp)
                 chunks_data.append(np.ascontiguousarray(c))
         else:
             off = 0
