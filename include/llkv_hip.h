@@ -529,10 +529,20 @@ llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filt
 void llkv_hip_free(void *ptr);
 
 /* ------------------------------------------------------------------------- */
-/* Hash join — `TableJoinExt::join_stream` llkv-join/src/lib.rs:240-282,        */
-/* integer fast path llkv-join/src/hash_join.rs:955-1417.  Build = right,      */
-/* probe = left; output = matching (left row, right row) index pairs in probe  */
-/* order × build insertion order, in batches of ≤ batch_size pairs.           */
+/* Hash join — `TableJoinExt::join_stream` llkv-join/src/lib.rs:240-282.        */
+/* Build = right, probe = left; output = matching (left row, right row) index  */
+/* pairs in probe order × build insertion order, in the reference's batches.   */
+/* · one key pair of one integer type (Int32/Int64/UInt32/UInt64) on both      */
+/*   sides: the integer fast path, hash_join.rs:955-1417 (null_equals_null =   */
+/*   per-type sentinel; a batch ends after the probe row that brings it to     */
+/*   ≥ batch_size pairs and at the end of every 65 536-row probe scan batch);  */
+/* · any other key list of 1..4 pairs: the generic typed-key path, :200-335,   */
+/*   :377-505 (all parts equal; NULL equals nothing or, under                  */
+/*   null_equals_null, the marker Utf8("<NULL>"); floats by bit pattern;       */
+/*   values of two different types never equal; a value of a type              */
+/*   extract_key_value does not list — Date32, Boolean, Decimal128 — takes the */
+/*   row out; the probe is cut into slices of batch_size rows first);          */
+/* · no key pair: the Cartesian product, :1500-1599.                           */
 /* ------------------------------------------------------------------------- */
 typedef enum llkv_join_type {
   LLKV_JOIN_INNER = 0,

@@ -1969,21 +1969,57 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
  * left in scan order (:1141-1214); NULL keys never match unless null_equals_null,
  * which uses the sentinel i64::MIN (:1116-1123,1429,1441); batches of ≥ batch_size
  * pairs are flushed after finishing a probe row (:1181-1193). */
-typedef struct jt_entry { int64_t key; uint64_t head, tail; int used; } jt_entry;
+typedef struct jt_entry { uint64_t head, tail; int used; } jt_entry;
 
-static int32_t join_key_value(const orc_column *c, uint64_t row, int null_eq, int64_t *out) {
-  if (!col_valid(c, row)) { /* per-type sentinels of the fast paths, hash_join.rs:1429-1465 */
-    if (!null_eq) return 0;
-    *out = c->dtype == LLKV_DT_INT64 ? INT64_MIN : c->dtype == LLKV_DT_UINT64 ? (int64_t)UINT64_MAX : c->dtype == LLKV_DT_UINT32 ? (int64_t)UINT32_MAX : (int64_t)INT32_MIN;
-    return 1;
+/* One part of a join key.  kind 0: no key (the row matches nothing); 1: a value of type `dtype` with the bit
+ * pattern `bits` (fast path: the i64 image, sentinels included); 2: a string.
+ * Generic path (hash_join.rs:62-148,377-505): NULL → KeyValue::Null (equal to nothing) or, under
+ * null_equals_null, Utf8("<NULL>"); floats by bit pattern; values of different types are never equal; types
+ * extract_key_value does not list (Date32, Boolean, Decimal128) fail the extraction → no key. */
+typedef struct jk_part { int kind; int32_t dtype; uint64_t bits; const char *str; uint32_t len; } jk_part;
+
+static jk_part join_key_part(const orc_column *c, uint64_t row, int null_eq, int fast) {
+  jk_part p = {0, c->dtype, 0, NULL, 0};
+  if (!col_valid(c, row)) {
+    if (!null_eq) return p;
+    if (fast) { /* per-type sentinels of the fast paths, hash_join.rs:1429-1465 */
+      p.kind = 1;
+      p.bits = c->dtype == LLKV_DT_INT64 ? (uint64_t)INT64_MIN : c->dtype == LLKV_DT_UINT64 ? UINT64_MAX : c->dtype == LLKV_DT_UINT32 ? (uint64_t)UINT32_MAX : (uint64_t)(int64_t)INT32_MIN;
+      return p;
+    }
+    p.kind = 2; p.dtype = LLKV_DT_UTF8; p.str = "<NULL>"; p.len = 6;
+    return p;
   }
   switch (c->dtype) {
-  case LLKV_DT_INT64: *out = ((const int64_t *)c->values)[row]; return 1;
-  case LLKV_DT_INT32: case LLKV_DT_DATE32: *out = ((const int32_t *)c->values)[row]; return 1;
-  case LLKV_DT_UINT32: *out = ((const uint32_t *)c->values)[row]; return 1;
-  case LLKV_DT_UINT64: *out = (int64_t)((const uint64_t *)c->values)[row]; return 1;
-  default: return 0;
+  case LLKV_DT_INT64: case LLKV_DT_UINT64: case LLKV_DT_FLOAT64: p.kind = 1; p.bits = ((const uint64_t *)c->values)[row]; return p;
+  case LLKV_DT_INT32: p.kind = 1; p.bits = (uint64_t)(int64_t)((const int32_t *)c->values)[row]; return p;
+  case LLKV_DT_UINT32: case LLKV_DT_FLOAT32: p.kind = 1; p.bits = ((const uint32_t *)c->values)[row]; return p;
+  case LLKV_DT_UTF8: p.kind = 2; p.str = (const char *)c->data + c->offsets[row]; p.len = (uint32_t)(c->offsets[row + 1] - c->offsets[row]); return p;
+  default: return p; /* "Unsupported join key type" → the row is skipped (`if let Ok(key)`) */
   }
+}
+
+static int join_row_hash(const orc_column *const *cols, const llkv_join_key *keys, uint32_t n_keys, int fast, uint64_t row, uint64_t *out) {
+  uint64_t h = 1469598103934665603ULL;
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    jk_part p = join_key_part(cols[i], row, keys[i].null_equals_null, fast);
+    if (p.kind == 0) return 0;
+    if (p.kind == 1) h = (h ^ p.bits) * 1099511628211ULL;
+    else for (uint32_t j = 0; j < p.len; ++j) h = (h ^ (uint8_t)p.str[j]) * 1099511628211ULL;
+    h ^= h >> 29;
+  }
+  *out = h;
+  return 1;
+}
+
+/* both rows have keys (join_row_hash succeeded) */
+static int join_rows_equal(const orc_column *const *ca, uint64_t ra, const orc_column *const *cb, uint64_t rb, const llkv_join_key *keys, uint32_t n_keys, int fast) {
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    jk_part a = join_key_part(ca[i], ra, keys[i].null_equals_null, fast), b = join_key_part(cb[i], rb, keys[i].null_equals_null, fast);
+    if (a.kind != b.kind || a.dtype != b.dtype) return 0;
+    if (a.kind == 1 ? a.bits != b.bits : (a.len != b.len || memcmp(a.str, b.str, a.len) != 0)) return 0;
+  }
+  return 1;
 }
 
 int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_join_key *keys,
@@ -2014,40 +2050,44 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
     }
     return LLKV_OK;
   }
-  if (n_keys != 1) return fail(LLKV_UNSUPPORTED, "only single-key integer joins are restated (n_keys=%u)", n_keys);
-  const orc_column *lc = find_col(left, keys[0].left_field), *rc_ = find_col(right, keys[0].right_field);
-  if (!lc || !rc_) return fail(LLKV_NOT_FOUND, "join key field not found");
-  if (vclass_of(lc->dtype) > VC_U64 || vclass_of(rc_->dtype) > VC_U64 || vclass_of(lc->dtype) < 0 || vclass_of(rc_->dtype) < 0)
-    return fail(LLKV_UNSUPPORTED, "non-integer join key");
-  /* fast path only for identical key types (hash_join.rs:174-198); the generic typed-key path is not restated */
-  if (lc->dtype != rc_->dtype) return fail(LLKV_UNSUPPORTED, "join keys of different types");
-  int null_eq = keys[0].null_equals_null;
+  if (n_keys > 4) return fail(LLKV_UNSUPPORTED, "more than four join key pairs (n_keys=%u)", n_keys);
+  const orc_column *lcs[4], *rcs[4];
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    lcs[i] = find_col(left, keys[i].left_field);
+    rcs[i] = find_col(right, keys[i].right_field);
+    if (!lcs[i] || !rcs[i]) return fail(LLKV_NOT_FOUND, "join key field not found");
+  }
+  /* integer fast path: one key, identical integer key types (hash_join.rs:171-200); everything else takes the
+   * generic typed-key path */
+  int fast = n_keys == 1 && lcs[0]->dtype == rcs[0]->dtype &&
+             (lcs[0]->dtype == LLKV_DT_INT32 || lcs[0]->dtype == LLKV_DT_INT64 || lcs[0]->dtype == LLKV_DT_UINT32 || lcs[0]->dtype == LLKV_DT_UINT64);
 
-  /* build: open addressing on key, chained row lists in insertion order */
+  /* build: open addressing on the key (first row with that key), chained row lists in insertion order */
   uint64_t cap = 16;
   while (cap < right->rows * 2 + 16) cap <<= 1;
   jt_entry *tab = xcalloc(cap, sizeof(jt_entry));
   uint64_t *next = xmalloc((right->rows ? right->rows : 1) * sizeof(uint64_t));
   for (uint64_t r = 0; r < right->rows; ++r) {
-    int64_t k;
     next[r] = UINT64_MAX;
-    if (!join_key_value(rc_, r, null_eq, &k)) continue;
-    uint64_t h = ((uint64_t)k * 0x9E3779B97F4A7C15ULL) & (cap - 1);
-    while (tab[h].used && tab[h].key != k) h = (h + 1) & (cap - 1);
-    if (!tab[h].used) { tab[h].used = 1; tab[h].key = k; tab[h].head = tab[h].tail = r; }
+    uint64_t hk;
+    if (!join_row_hash(rcs, keys, n_keys, fast, r, &hk)) continue;
+    uint64_t h = (hk * 0x9E3779B97F4A7C15ULL) & (cap - 1);
+    while (tab[h].used && !join_rows_equal(rcs, tab[h].head, rcs, r, keys, n_keys, fast)) h = (h + 1) & (cap - 1);
+    if (!tab[h].used) { tab[h].used = 1; tab[h].head = tab[h].tail = r; }
     else { next[tab[h].tail] = r; tab[h].tail = r; }
   }
-  /* probe */
+  /* probe: one scan batch of 65 536 left rows at a time (:1010-1070); the generic path cuts every scan batch
+   * into slices of batch_size rows first (:228-246); inside a batch / slice the pairs are flushed after the
+   * probe row that brings them to >= batch_size, and at its end (:1181-1213, :509-565) */
   uint64_t *pl = xmalloc((batch_size + right->rows + 1) * sizeof(uint64_t));
   uint64_t *pr = xmalloc((batch_size + right->rows + 1) * sizeof(uint64_t));
   uint64_t np = 0;
   for (uint64_t l = 0; l < left->rows; ++l) {
-    int64_t k;
-    int have = join_key_value(lc, l, null_eq, &k), matched = 0;
-    uint64_t h = 0;
-    if (have) {
-      h = ((uint64_t)k * 0x9E3779B97F4A7C15ULL) & (cap - 1);
-      while (tab[h].used && tab[h].key != k) h = (h + 1) & (cap - 1);
+    int matched = 0;
+    uint64_t h = 0, hk;
+    if (join_row_hash(lcs, keys, n_keys, fast, l, &hk)) {
+      h = (hk * 0x9E3779B97F4A7C15ULL) & (cap - 1);
+      while (tab[h].used && !join_rows_equal(rcs, tab[h].head, lcs, l, keys, n_keys, fast)) h = (h + 1) & (cap - 1);
       matched = tab[h].used;
     }
     switch (jt) {
@@ -2061,9 +2101,10 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
     case LLKV_JOIN_SEMI: if (matched) { pl[np] = l; pr[np] = 0; ++np; } break;
     case LLKV_JOIN_ANTI: if (!matched) { pl[np] = l; pr[np] = 0; ++np; } break;
     }
-    if (np >= batch_size) { on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user); np = 0; }
+    uint64_t in_win = l % ROW_STREAM_CHUNK_SIZE;
+    int boundary = in_win + 1 == ROW_STREAM_CHUNK_SIZE || l + 1 == left->rows || (!fast && (in_win + 1) % batch_size == 0);
+    if (np && (np >= batch_size || boundary)) { on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user); np = 0; }
   }
-  if (np) on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user);
   free(pl); free(pr); free(next); free(tab);
   return LLKV_OK;
 }

@@ -49,22 +49,29 @@ struct HBuf {
 constexpr uint32_t kJoinTileRows = 8192;
 constexpr uint32_t kWindowTiles = 8; // 65 536 probe rows per window = one reference probe batch
 
-int key_column(const Table *t, uint32_t field, bool null_equals_null, JoinKeyColumn *out, int32_t *dtype) {
+bool fast_key_type(int32_t dt) { return dt == LLKV_DT_INT32 || dt == LLKV_DT_INT64 || dt == LLKV_DT_UINT32 || dt == LLKV_DT_UINT64; }
+// the types extract_key_value (hash_join.rs:405-505) turns into a KeyValue; any other key type fails there
+bool generic_key_type(int32_t dt) { return fast_key_type(dt) || dt == LLKV_DT_FLOAT32 || dt == LLKV_DT_FLOAT64 || dt == LLKV_DT_UTF8; }
+
+int key_part(const Table *t, uint32_t field, const DeviceColumn **col, JoinKeyPart *out) {
   auto it = t->cols.find(field);
   if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "join key field " + std::to_string(field) + " not found");
-  const int32_t dt = it->second.info.dtype;
-  *dtype = dt;
-  out->values = it->second.d_values;
-  out->valid = it->second.info.nullable ? it->second.d_valid : nullptr;
-  out->null_equals_null = null_equals_null ? 1u : 0u;
-  if (out->valid && null_equals_null && dt == LLKV_DT_DATE32)
-    return set_error(LLKV_UNSUPPORTED, "null_equals_null over Date32 keys (generic path: NULL = NULL without a sentinel)");
+  const DeviceColumn &c = it->second;
+  *col = &c;
+  std::memset(out, 0, sizeof *out);
+  out->values = c.d_values;
+  out->valid = c.info.nullable ? c.d_valid : nullptr;
+  out->width = c.info.dtype == LLKV_DT_UTF8 ? 1u : dtype_width(c.info.dtype);
+  out->is_signed = c.info.dtype == LLKV_DT_INT32 ? 1u : 0u;
+  return LLKV_OK;
+}
+
+long long fast_null_sentinel(int32_t dt) { // hash_join.rs:1429-1465
   switch (dt) {
-  case LLKV_DT_INT64: out->width = 8; out->is_signed = 1; out->null_sentinel = INT64_MIN; return LLKV_OK;
-  case LLKV_DT_UINT64: out->width = 8; out->is_signed = 1; out->null_sentinel = (long long)UINT64_MAX; return LLKV_OK;
-  case LLKV_DT_INT32: case LLKV_DT_DATE32: out->width = 4; out->is_signed = 1; out->null_sentinel = INT32_MIN; return LLKV_OK;
-  case LLKV_DT_UINT32: out->width = 4; out->is_signed = 0; out->null_sentinel = (long long)UINT32_MAX; return LLKV_OK;
-  default: return set_error(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(dt) + " (integer fast path only)");
+  case LLKV_DT_INT64: return INT64_MIN;
+  case LLKV_DT_UINT64: return (long long)UINT64_MAX;
+  case LLKV_DT_INT32: return INT32_MIN;
+  default: return (long long)UINT32_MAX;
   }
 }
 } // namespace
@@ -114,14 +121,68 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     }
     return LLKV_OK;
   }
-  if (n_keys != 1) return set_error(LLKV_UNSUPPORTED, "GPU join path takes one integer key pair or none (composite keys stay on the CPU route)");
-  JoinKeyColumn lk, rk;
-  int32_t ldt, rdt;
-  const bool null_eq = keys[0].null_equals_null != 0;
-  if ((rc = key_column(left, keys[0].left_field, null_eq, &lk, &ldt)) || (rc = key_column(right, keys[0].right_field, null_eq, &rk, &rdt))) return rc;
-  // the integer fast path needs identical key types (hash_join.rs:174-198); mixed types take the generic
-  // typed-key path, where values of different types never compare equal
-  if (ldt != rdt) return set_error(LLKV_UNSUPPORTED, std::string("join keys of different types (") + dtype_name(ldt) + ", " + dtype_name(rdt) + ")");
+  if (n_keys > kMaxJoinKeys) return set_error(LLKV_UNSUPPORTED, "GPU join path takes at most " + std::to_string(kMaxJoinKeys) + " key pairs");
+  if (!keys) return set_error(LLKV_INVALID_ARGUMENT, "join keys is NULL");
+  JoinKeySet lk, rk;
+  std::memset(&lk, 0, sizeof lk);
+  std::memset(&rk, 0, sizeof rk);
+  lk.n = rk.n = n_keys;
+  const DeviceColumn *lc[kMaxJoinKeys], *rc_[kMaxJoinKeys];
+  for (uint32_t i = 0; i < n_keys; ++i)
+    if ((rc = key_part(left, keys[i].left_field, &lc[i], &lk.k[i])) || (rc = key_part(right, keys[i].right_field, &rc_[i], &rk.k[i]))) return rc;
+  // one key of one fast integer type on both sides → the integer fast path; anything else → the generic
+  // typed-key path (hash_join.rs:171-200), with its own NULL rule and its own batching
+  const bool fast = n_keys == 1 && lc[0]->info.dtype == rc_[0]->info.dtype && fast_key_type(lc[0]->info.dtype);
+  DBuf translate;
+  if (fast) {
+    for (JoinKeyPart *k : {&lk.k[0], &rk.k[0]}) {
+      k->null_equals_null = keys[0].null_equals_null != 0;
+      k->null_is_value = 1;
+      k->null_value = fast_null_sentinel(lc[0]->info.dtype);
+    }
+  } else {
+    std::vector<uint16_t> tables((size_t)n_keys * 256, 0xFFFFu);
+    bool any_table = false;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+      const int32_t ldt = lc[i]->info.dtype, rdt = rc_[i]->info.dtype;
+      JoinKeyPart &l = lk.k[i], &r = rk.k[i];
+      const bool null_eq = keys[i].null_equals_null != 0;
+      l.null_equals_null = r.null_equals_null = null_eq;
+      l.unusable = !generic_key_type(ldt);
+      r.unusable = !generic_key_type(rdt);
+      if (ldt != LLKV_DT_UTF8 && rdt != LLKV_DT_UTF8) {
+        l.values_never_match = r.values_never_match = ldt != rdt; // NULLs still meet through the `nulls` bit
+        continue;
+      }
+      // at least one Utf8 side: keys live in the build column's code space; the NULL marker is the string
+      // "<NULL>" (hash_join.rs:391-396) — the build dictionary's code for it, or 256 when it has none
+      const std::vector<std::string> none;
+      const std::vector<std::string> &rdict = rdt == LLKV_DT_UTF8 ? rc_[i]->info.dictionary : none;
+      long long null_code = 256;
+      for (size_t c = 0; c < rdict.size(); ++c)
+        if (rdict[c] == "<NULL>") null_code = (long long)c;
+      l.null_is_value = r.null_is_value = 1;
+      l.null_value = r.null_value = null_code;
+      if (rdt != LLKV_DT_UTF8) r.values_never_match = 1;
+      if (ldt != LLKV_DT_UTF8) { l.values_never_match = 1; continue; }
+      uint16_t *tab = tables.data() + (size_t)i * 256;
+      const std::vector<std::string> &ldict = lc[i]->info.dictionary;
+      for (size_t c = 0; c < ldict.size() && c < 256; ++c) {
+        for (size_t d = 0; d < rdict.size(); ++d)
+          if (rdict[d] == ldict[c]) tab[c] = (uint16_t)d;
+        if (tab[c] == 0xFFFFu && null_eq && ldict[c] == "<NULL>") tab[c] = (uint16_t)null_code;
+      }
+      any_table = true;
+      l.translate = reinterpret_cast<const uint16_t *>(1); // patched below
+    }
+    if (any_table) {
+      if ((rc = translate.ensure(tables.size() * 2))) return rc;
+      HIP_TRY(hipMemcpyAsync(translate.p, tables.data(), tables.size() * 2, hipMemcpyHostToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream)); // `tables` is pageable host memory
+      for (uint32_t i = 0; i < n_keys; ++i)
+        if (lk.k[i].translate) lk.k[i].translate = (const uint16_t *)translate.p + (size_t)i * 256;
+    }
+  }
 
   hipStream_t s = g_ctx.stream;
   const TileSet *tr = nullptr, *tl = nullptr;
@@ -169,6 +230,19 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
       (rc = h_off.ensure((size_t)(win_pos + 1) * 8)))
     return rc;
   const bool left_only = jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI;
+  // Batches.  The reference probes one scan batch (65 536 rows of the left table) at a time and flushes after the
+  // probe row that brings the pending pairs to ≥ batch_size, and at the end of the scan batch (fast path,
+  // hash_join.rs:1141-1213); the generic path first cuts every scan batch into slices of batch_size probe rows
+  // and applies the same rule inside each slice (:228-246,509-565).  Device windows are 8 tiles; when chunk sizes
+  // leave ragged tiles a reference batch can span two device windows, its head then waits in `pend_*`.
+  constexpr uint64_t kRefWindow = 65536;
+  std::vector<TileDesc> ltiles;
+  {
+    uint32_t otb[kOctantsHost + 1];
+    build_tiles_host(*left, kJoinTileRows, ltiles, otb);
+  }
+  const uint64_t left_end = left->local_logical_start + left->local_rows;
+  std::vector<uint64_t> pend_l, pend_r;
   for (uint32_t t0 = 0; t0 < tl->n_tiles; t0 += kWindowTiles) {
     const uint32_t nt = std::min(kWindowTiles, tl->n_tiles - t0);
     const uint32_t npos = nt * kJoinTileRows;
@@ -186,33 +260,59 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     uint64_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + npos, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (total == 0) continue;
-    if ((rc = out_l.ensure(total * 8)) || (rc = out_r.ensure(total * 8)) || (rc = h_l.ensure(total * 8)) || (rc = h_r.ensure(total * 8))) return rc;
-    p.offsets = (const uint64_t *)offsets.p;
-    p.out_left = (uint64_t *)out_l.p; p.out_right = (uint64_t *)out_r.p;
-    HIP_TRY(hj_launch_probe_write(p, s));
-    HIP_TRY(hipMemcpyAsync(h_l.p, out_l.p, total * 8, hipMemcpyDeviceToHost, s));
-    if (!left_only) HIP_TRY(hipMemcpyAsync(h_r.p, out_r.p, total * 8, hipMemcpyDeviceToHost, s));
-    const bool need_split = total >= batch_size;
-    if (need_split) HIP_TRY(hipMemcpyAsync(h_off.p, offsets.p, (size_t)(npos + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (total == 0 && pend_l.empty()) continue;
+    uint64_t wrows = 0;
+    for (uint32_t t = 0; t < nt; ++t) wrows += ltiles[t0 + t].rows;
+    const uint64_t first_logical = ltiles[t0].logical_row;
+    const bool whole_batch = pend_l.empty() && first_logical % kRefWindow == 0 &&
+                             (wrows == kRefWindow || first_logical + wrows == left_end) && (fast || batch_size >= wrows);
+    const bool walk = !(whole_batch && total < batch_size);
+    if (total) {
+      if ((rc = out_l.ensure(total * 8)) || (rc = out_r.ensure(total * 8)) || (rc = h_l.ensure(total * 8)) || (rc = h_r.ensure(total * 8))) return rc;
+      p.offsets = (const uint64_t *)offsets.p;
+      p.out_left = (uint64_t *)out_l.p; p.out_right = (uint64_t *)out_r.p;
+      HIP_TRY(hj_launch_probe_write(p, s));
+      HIP_TRY(hipMemcpyAsync(h_l.p, out_l.p, total * 8, hipMemcpyDeviceToHost, s));
+      if (!left_only) HIP_TRY(hipMemcpyAsync(h_r.p, out_r.p, total * 8, hipMemcpyDeviceToHost, s));
+    }
+    if (walk) HIP_TRY(hipMemcpyAsync(h_off.p, offsets.p, (size_t)(npos + 1) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint64_t *hl = (const uint64_t *)h_l.p, *hr = left_only ? nullptr : (const uint64_t *)h_r.p;
-    if (!need_split) {
+    if (!walk) {
       on_batch(hl, hr, total, user);
-    } else {
-      // flush after the probe row that brings the batch to ≥ batch_size pairs (hash_join.rs:1181-1193)
-      const uint64_t *off = (const uint64_t *)h_off.p;
-      uint64_t start = 0;
-      for (uint32_t i = 0; i < npos; ++i) {
-        const uint64_t end = off[i + 1];
-        if (end - start >= batch_size) {
-          on_batch(hl + start, hr ? hr + start : nullptr, end - start, user);
-          start = end;
-        }
+      continue;
+    }
+    const uint64_t *off = (const uint64_t *)h_off.p;
+    uint64_t start = 0;
+    auto deliver = [&](uint64_t end) {
+      if (pend_l.empty()) {
+        on_batch(hl + start, hr ? hr + start : nullptr, end - start, user);
+      } else {
+        pend_l.insert(pend_l.end(), hl + start, hl + end);
+        if (hr) pend_r.insert(pend_r.end(), hr + start, hr + end);
+        on_batch(pend_l.data(), hr ? pend_r.data() : nullptr, pend_l.size(), user);
+        pend_l.clear();
+        pend_r.clear();
       }
-      if (total > start) on_batch(hl + start, hr ? hr + start : nullptr, total - start, user);
+      start = end;
+    };
+    for (uint32_t t = 0; t < nt; ++t) {
+      const TileDesc &td = ltiles[t0 + t];
+      for (uint32_t r = 0; r < td.rows; ++r) {
+        const uint64_t logical = td.logical_row + r, in_win = logical % kRefWindow;
+        const uint64_t end = off[(uint64_t)t * kJoinTileRows + r + 1];
+        const uint64_t acc = pend_l.size() + (end - start);
+        if (acc == 0) continue;
+        const bool boundary = in_win + 1 == kRefWindow || logical + 1 == left_end || (!fast && (in_win + 1) % batch_size == 0);
+        if (acc >= batch_size || boundary) deliver(end);
+      }
+    }
+    if (total > start) { // the reference batch goes on in the next device window
+      pend_l.insert(pend_l.end(), hl + start, hl + total);
+      if (hr) pend_r.insert(pend_r.end(), hr + start, hr + total);
     }
   }
+  if (!pend_l.empty()) on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
   return LLKV_OK;
 }
 

@@ -21,16 +21,6 @@ __device__ __forceinline__ long long load_key(const JoinKeyColumn &k, uint64_t r
   return k.is_signed ? (long long)(int32_t)v : (long long)v;
 }
 
-// Key of `row`; false when it is a NULL that matches nothing.
-__device__ __forceinline__ bool load_key_nullable(const JoinKeyColumn &k, uint64_t row, long long *out) {
-  if (k.valid && !k.valid[row]) {
-    *out = k.null_sentinel;
-    return k.null_equals_null != 0;
-  }
-  *out = load_key(k, row);
-  return true;
-}
-
 __device__ __forceinline__ uint64_t hash_key(long long k) {
   uint64_t x = (uint64_t)k;
   x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
@@ -39,7 +29,57 @@ __device__ __forceinline__ uint64_t hash_key(long long k) {
 
 constexpr unsigned long long kEmpty = ~0ull;
 
-__global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeyColumn key, const TileDesc *tiles, uint32_t tile_rows,
+// Canonical key of `row` (see JoinKeyPart); false when the row has no key that could match.
+struct KeyTuple {
+  long long v[kMaxJoinKeys];
+  uint32_t nulls; // bit i: part i is a NULL that equals other NULLs
+};
+__device__ __forceinline__ bool load_tuple(const JoinKeySet &ks, uint64_t row, KeyTuple *out) {
+  out->nulls = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < kMaxJoinKeys; ++i) {
+    if (i >= ks.n) break;
+    const JoinKeyPart &k = ks.k[i];
+    if (k.valid && !k.valid[row]) { // the NULL test comes first: a NULL of an unlisted type still is the marker
+      if (!k.null_equals_null) return false;
+      if (k.null_is_value) { out->v[i] = k.null_value; }
+      else { out->v[i] = 0; out->nulls |= 1u << i; }
+      continue;
+    }
+    if (k.values_never_match || k.unusable) return false;
+    long long v;
+    if (k.width == 8) v = reinterpret_cast<const long long *>(k.values)[row];
+    else if (k.width == 4) {
+      const uint32_t w = reinterpret_cast<const uint32_t *>(k.values)[row];
+      v = k.is_signed ? (long long)(int32_t)w : (long long)w;
+    } else {
+      uint32_t code = reinterpret_cast<const uint8_t *>(k.values)[row];
+      if (k.translate) {
+        code = k.translate[code];
+        if (code == 0xFFFFu) return false;
+      }
+      v = (long long)code;
+    }
+    out->v[i] = v;
+  }
+  return true;
+}
+__device__ __forceinline__ bool same_tuple(const KeyTuple &a, const KeyTuple &b, uint32_t n) {
+  bool eq = a.nulls == b.nulls;
+#pragma unroll
+  for (uint32_t i = 0; i < kMaxJoinKeys; ++i)
+    if (i < n) eq &= a.v[i] == b.v[i];
+  return eq;
+}
+__device__ __forceinline__ uint64_t hash_tuple(const KeyTuple &t, uint32_t n) {
+  uint64_t h = hash_key(t.v[0]); // one key: the hash of the value itself
+#pragma unroll
+  for (uint32_t i = 1; i < kMaxJoinKeys; ++i)
+    if (i < n) h = hash_key((long long)(h * 0x9E3779B97F4A7C15ull + (uint64_t)t.v[i]));
+  return h ^ ((uint64_t)t.nulls * 0xD6E8FEB86659FD93ull);
+}
+
+__global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeySet key, const TileDesc *tiles, uint32_t tile_rows,
                                                         unsigned long long *slot_owner, uint64_t cap_mask,
                                                         uint32_t *slot_of, uint64_t *dev_row_of, uint64_t *logical_of,
                                                         const uint64_t *tile_compact_base) {
@@ -50,20 +90,22 @@ __global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeyColumn key, const 
     const uint64_t ci = cbase + r; // compact build index (dense over real rows)
     dev_row_of[ci] = drow;
     logical_of[ci] = td.logical_row + r;
-    long long k;
-    if (!load_key_nullable(key, drow, &k)) { // a NULL build key is parked in the extra slot no probe reaches
+    KeyTuple k;
+    if (!load_tuple(key, drow, &k)) { // a build row without a key is parked in the extra slot no probe reaches
       slot_of[ci] = (uint32_t)(cap_mask + 1);
       continue;
     }
-    uint64_t s = hash_key(k) & cap_mask;
+    uint64_t s = hash_tuple(k, key.n) & cap_mask;
     for (;;) {
       unsigned long long owner = slot_owner[s];
       if (owner == kEmpty) {
         const unsigned long long prev = atomicCAS(&slot_owner[s], kEmpty, (unsigned long long)drow);
         owner = prev == kEmpty ? (unsigned long long)drow : prev;
       }
-      long long ko;
-      if (owner == (unsigned long long)drow || (load_key_nullable(key, owner, &ko), ko == k)) break;
+      if (owner == (unsigned long long)drow) break;
+      KeyTuple ko;
+      load_tuple(key, owner, &ko); // owners always have keys
+      if (same_tuple(ko, k, key.n)) break;
       s = (s + 1) & cap_mask;
     }
     slot_of[ci] = (uint32_t)s;
@@ -71,7 +113,7 @@ __global__ __launch_bounds__(256) void hj_claim_kernel(JoinKeyColumn key, const 
   (void)tile_rows;
 }
 
-hipError_t hj_launch_claim(const JoinKeyColumn &key, const TileDesc *tiles, uint32_t n_tiles, uint32_t tile_rows,
+hipError_t hj_launch_claim(const JoinKeySet &key, const TileDesc *tiles, uint32_t n_tiles, uint32_t tile_rows,
                            unsigned long long *slot_owner, uint64_t cap_mask, uint32_t *slot_of_row,
                            uint64_t *dev_row_of, uint64_t *logical_of, const uint64_t *tile_compact_base, hipStream_t s) {
   if (n_tiles == 0) return hipSuccess;
@@ -133,15 +175,15 @@ __global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
     uint64_t cnt = 0;
     uint32_t mslot = 0xFFFFFFFFu;
     if (r < td.rows) {
-      long long k;
-      if (load_key_nullable(p.lkey, td.dev_row + r, &k)) {
-        uint64_t s = hash_key(k) & p.cap_mask;
+      KeyTuple k;
+      if (load_tuple(p.lkey, td.dev_row + r, &k)) {
+        uint64_t s = hash_tuple(k, p.lkey.n) & p.cap_mask;
         for (;;) {
           const unsigned long long owner = p.slot_owner[s];
           if (owner == kEmpty) break;
-          long long ko;
-          load_key_nullable(p.rkey, owner, &ko); // owners are never non-matching NULLs
-          if (ko == k) { mslot = (uint32_t)s; break; }
+          KeyTuple ko;
+          load_tuple(p.rkey, owner, &ko); // owners always have keys
+          if (same_tuple(ko, k, p.lkey.n)) { mslot = (uint32_t)s; break; }
           s = (s + 1) & p.cap_mask;
         }
       }

@@ -21,9 +21,40 @@ struct JoinKeyColumn {
   long long null_sentinel = 0;
 };
 
+// One column of a join key in the form both join routes share.  Every cell becomes a canonical (value, is_null)
+// pair or "no key" (the row then matches nothing):
+//  · integer fast path (one key, Int32/Int64/UInt32/UInt64 on both sides, hash_join.rs:174-198): a NULL under
+//    null_equals_null becomes the per-type sentinel VALUE (null_is_value), so a real key of that value joins the
+//    NULLs (:1429-1465);
+//  · generic typed-key path (any other key list, hash_join.rs:62-148,377-505): values are equal when their types
+//    and bits are (floats by bit pattern); values of two different types never are (`values_never_match`); a NULL
+//    is KeyValue::Null (equal to nothing) or, under null_equals_null, the marker Utf8("<NULL>") — equal to the
+//    other NULLs and to a real string "<NULL>"; key types extract_key_value does not list (Date32, Boolean,
+//    Decimal128) make the extraction fail, which drops the row from the build and leaves a probe row unmatched
+//    (`unusable`).
+// Utf8 columns are dictionary codes; `translate` maps the probe table's codes into the build table's code space
+// (0xFFFF: the string does not occur on the build side).
+struct JoinKeyPart {
+  const void *values;
+  const uint8_t *valid;      // 1 B/row validity mask or nullptr
+  const uint16_t *translate; // 256 entries (device) or nullptr
+  uint32_t width;            // 1, 4 or 8 bytes
+  uint32_t is_signed;
+  uint32_t null_equals_null;
+  uint32_t null_is_value;
+  long long null_value;
+  uint32_t values_never_match;
+  uint32_t unusable;
+};
+struct JoinKeySet {
+  JoinKeyPart k[4];
+  uint32_t n;
+};
+constexpr uint32_t kMaxJoinKeys = 4;
+
 // Build side: distinct keys claim slots of an open-addressing table (slot_owner = row that owns the slot,
 // UINT64_MAX = empty); every build row records its slot.  All arrays are device memory.
-hipError_t hj_launch_claim(const JoinKeyColumn &key, const TileDesc *tiles, uint32_t n_tiles, uint32_t tile_rows,
+hipError_t hj_launch_claim(const JoinKeySet &key, const TileDesc *tiles, uint32_t n_tiles, uint32_t tile_rows,
                            unsigned long long *slot_owner, uint64_t cap_mask, uint32_t *slot_of_row /*[dev rows]*/,
                            uint64_t *dev_row_of /*[n_build]: compact index → device row*/,
                            uint64_t *logical_of /*[n_build]*/, const uint64_t *tile_compact_base, hipStream_t s);
@@ -41,7 +72,7 @@ hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
 hipError_t hj_launch_cross_pairs(uint64_t l0, uint64_t ln, uint64_t r0, uint64_t rn, uint64_t *out_left, uint64_t *out_right, hipStream_t s);
 
 struct ProbeParams {
-  JoinKeyColumn lkey, rkey;
+  JoinKeySet lkey, rkey;
   const TileDesc *tiles; // probe-side tiles of this window
   uint32_t n_tiles, tile_rows;
   const unsigned long long *slot_owner;

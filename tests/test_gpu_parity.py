@@ -1060,8 +1060,7 @@ def test_random_joins_match_oracle(rt, orc, abi, n_left, n_right, keyspace, batc
         assert [x for b in got for x in b[1]] == [x for b in want for x in b[1]]
     else:
         assert all(b[1] is None for b in got)
-    if n_left <= 65536:  # a single probe window: batch boundaries are the reference's exactly
-        assert [len(b[0]) for b in got] == [len(b[0]) for b in want]
+    assert [len(b[0]) for b in got] == [len(b[0]) for b in want]  # flushes: ≥ batch_size pairs, and every 65 536 probe rows
 
 
 @pytest.mark.parametrize("dt", ["DT_INT64", "DT_INT32", "DT_UINT32", "DT_UINT64"])
@@ -1090,12 +1089,89 @@ def test_joins_with_null_keys_match_oracle(rt, orc, abi, dt, null_eq):
         if jt in ("inner", "left"):
             assert [x for b in got for x in b[1]] == [x for b in want for x in b[1]], jt
         assert [len(b[0]) for b in got] == [len(b[0]) for b in want]
-    # key types must agree (the integer fast path; hash_join.rs:174-198)
+    # two different key types leave the integer fast path (hash_join.rs:174-198): the generic path compares typed
+    # values, which are then never equal
     if dtype != abi.DT_INT64:
         other = rt.HipTable(3, [4]); other.append_column(9, abi.DT_INT64, np.arange(4, dtype=np.int64))
-        with pytest.raises(abi.LlkvError) as e:
-            rt.join_stream(lt, other, [(1, 9)], JT["inner"], 8192)
-        assert e.value.kind == "Unsupported"
+        assert rt.join_stream(lt, other, [(1, 9)], JT["inner"], 8192) == []
+
+
+def _keyed_tables(rt, orc, abi, cols_left, cols_right, chunks_left, n_right):
+    """cols: [(field, dtype, values, valid|None)] staged on both engines."""
+    lt, rtab = rt.HipTable(1, chunks_left), rt.HipTable(2, [n_right])
+    ol, orr = orc.OracleTable(sum(chunks_left)), orc.OracleTable(n_right)
+    for ht, ot, cols in ((lt, ol, cols_left), (rtab, orr, cols_right)):
+        for f, dt, vals, valid in cols:
+            if dt == abi.DT_UTF8:
+                ht.append_utf8_column(f, vals)
+                ot.add(f, dt, vals)
+            else:
+                ht.append_column(f, dt, vals, valid=valid)
+                ot.add(f, dt, vals, None if valid is None else list(valid))
+    return lt, rtab, ol, orr
+
+
+def _same_join(rt, orc, tables, keys, batch=8192, jts=("inner", "left", "semi", "anti")):
+    lt, rtab, ol, orr = tables
+    for jt in jts:
+        got, want = rt.join_stream(lt, rtab, keys, JT[jt], batch), orc.hash_join(ol, orr, keys, JT[jt], batch)
+        assert [x for b in got for x in b[0]] == [x for b in want for x in b[0]], (keys, jt)
+        if jt in ("inner", "left"):
+            assert [x for b in got for x in b[1]] == [x for b in want for x in b[1]], (keys, jt)
+        assert [len(b[0]) for b in got] == [len(b[0]) for b in want], (keys, jt, batch)
+    return got
+
+
+@pytest.mark.parametrize("null_eq", [(False, False), (True, False), (True, True)])
+def test_composite_key_joins_match_oracle(rt, orc, abi, null_eq):
+    """Key lists that are not one fast integer pair take the reference's generic typed-key path
+    (llkv-join/src/hash_join.rs:200-335,377-505): all parts equal, NULL handling per part, probe cut into slices
+    of batch_size rows.  Ragged chunks on the probe side: reference batches that span two device windows."""
+    rng = np.random.default_rng(77)
+    chunks, n_right = [30_000, 50_001, 7, 20_000], 40_000
+    n_left = sum(chunks)
+    la, lb = rng.integers(0, 300, size=n_left).astype(np.int64), rng.integers(0, 40, size=n_left).astype(np.int32)
+    ra, rb = rng.integers(0, 300, size=n_right).astype(np.int64), rng.integers(0, 40, size=n_right).astype(np.int32)
+    lva, lvb, rva, rvb = rng.random(n_left) > 0.05, rng.random(n_left) > 0.05, rng.random(n_right) > 0.05, rng.random(n_right) > 0.05
+    tabs = _keyed_tables(rt, orc, abi, [(1, abi.DT_INT64, la, lva), (2, abi.DT_INT32, lb, lvb)], [(7, abi.DT_INT64, ra, rva), (8, abi.DT_INT32, rb, rvb)], chunks, n_right)
+    keys = [(1, 7, null_eq[0]), (2, 8, null_eq[1])]
+    got = _same_join(rt, orc, tabs, keys, 8192)
+    assert sum(len(b[0]) for b in got) > 0
+    _same_join(rt, orc, tabs, keys, 1000, jts=("inner", "anti"))
+    _same_join(rt, orc, tabs, keys, 100_000, jts=("left",))
+    # the same columns through the single-key fast path keep its batching (no slices) on the ragged probe side
+    _same_join(rt, orc, tabs, [(1, 7, null_eq[0])], 5000, jts=("inner", "semi"))
+
+
+def test_generic_key_types_match_oracle(rt, orc, abi):
+    """Float64 keys by bit pattern, Utf8 keys through the two tables' dictionaries (with the "<NULL>" marker
+    string), mismatched types (never equal), Date32 (key extraction fails: the row matches nothing)."""
+    rng = np.random.default_rng(78)
+    n_left, n_right = 70_001, 5_000
+    words_l = ["a", "bb", "<NULL>", "ccc", "", None, "only-left"]
+    words_r = ["bb", "ccc", None, "", "only-right", "a"]
+    ls = [words_l[k] for k in rng.integers(0, len(words_l), size=n_left)]
+    rs = [words_r[k] for k in rng.integers(0, len(words_r), size=n_right)]
+    fl = rng.choice(np.array([0.0, -0.0, np.nan, 1.5, 2.5, -7.25]), size=n_left)
+    fr = rng.choice(np.array([0.0, np.nan, 1.5, 3.5, -7.25]), size=n_right)
+    il, ir = rng.integers(0, 50, size=n_left).astype(np.int32), rng.integers(0, 50, size=n_right).astype(np.int64)
+    dl, dr = rng.integers(0, 5, size=n_left).astype(np.int32), rng.integers(0, 5, size=n_right).astype(np.int32)
+    vl, vr = rng.random(n_left) > 0.1, rng.random(n_right) > 0.02
+    tabs = _keyed_tables(rt, orc, abi,
+                         [(1, abi.DT_UTF8, ls, None), (2, abi.DT_FLOAT64, fl, vl), (3, abi.DT_INT32, il, vl), (4, abi.DT_DATE32, dl, vl), (5, abi.DT_INT64, il.astype(np.int64), None)],
+                         [(1, abi.DT_UTF8, rs, None), (2, abi.DT_FLOAT64, fr, vr), (3, abi.DT_INT64, ir, vr), (4, abi.DT_DATE32, dr, vr), (5, abi.DT_INT64, ir, None)],
+                         [n_left], n_right)
+    for null_eq in (False, True):
+        _same_join(rt, orc, tabs, [(1, 1, null_eq)], 50_000, jts=("semi", "anti"))        # Utf8 ⋈ Utf8
+        _same_join(rt, orc, tabs, [(2, 2, null_eq)], 50_000, jts=("semi", "anti"))        # Float64 bits
+        _same_join(rt, orc, tabs, [(3, 3, null_eq)], 8192, jts=("inner", "left"))          # Int32 against Int64
+        _same_join(rt, orc, tabs, [(4, 4, null_eq)], 8192, jts=("inner", "anti"))          # Date32
+        _same_join(rt, orc, tabs, [(1, 3, null_eq)], 8192, jts=("inner",))                 # Utf8 against Int64 (only the marker meets NULLs)
+        _same_join(rt, orc, tabs, [(3, 1, null_eq)], 8192, jts=("semi", "anti"))           # Int32 against Utf8
+        _same_join(rt, orc, tabs, [(5, 5), (1, 1, null_eq)], 20_000, jts=("semi", "left"))  # Int64 + Utf8 composite
+    with pytest.raises(abi.LlkvError) as e:
+        rt.join_stream(tabs[0], tabs[1], [(5, 5)] * 5, JT["inner"])
+    assert e.value.kind == "Unsupported"
 
 
 @pytest.mark.parametrize("rows,scale", [(60175, 0.01), (600_000, 0.1)])

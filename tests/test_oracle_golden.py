@@ -60,6 +60,53 @@ def test_join_cases(case, orc, abi):
         assert all(b[1] is None for b in batches), "semi/anti joins deliver left columns only"
 
 
+def test_generic_join_key_rules(orc, abi):
+    """The generic typed-key path (llkv-join/src/hash_join.rs:62-148,377-505; any key list that is not one
+    fast integer pair), expectations derived by hand from its rules: all parts equal; NULL equals nothing, or —
+    under null_equals_null — the marker Utf8("<NULL>"), which also equals a real string "<NULL>"; values of two
+    different types never match; a VALUE of a type extract_key_value does not list (Date32) drops the row."""
+    def pairs(batches):
+        return [(l, None if r == 2**64 - 1 else r) for b in batches for l, r in zip(b[0], b[1])]
+
+    # two-part key (Int64, Int32): NULLs in either part
+    left = orc.OracleTable(5).add(1, abi.DT_INT64, np.array([1, 1, 0, 2, 1]), [True, True, False, True, True]) \
+                             .add(2, abi.DT_INT32, np.array([1, 2, 1, 0, 1], dtype=np.int32), [True, True, True, False, True])
+    right = orc.OracleTable(5).add(1, abi.DT_INT64, np.array([1, 1, 2, 0, 1]), [True, True, True, False, True]) \
+                              .add(2, abi.DT_INT32, np.array([1, 1, 0, 1, 2], dtype=np.int32), [True, True, False, True, True])
+    assert pairs(orc.hash_join(left, right, [(1, 1), (2, 2)], abi.JOIN_INNER)) == [(0, 0), (0, 1), (1, 4), (4, 0), (4, 1)]
+    # NULL = NULL on the first part only: (NULL,1) meets (NULL,1); (2,NULL) still matches nothing
+    assert pairs(orc.hash_join(left, right, [(1, 1, True), (2, 2)], abi.JOIN_INNER)) == [(0, 0), (0, 1), (1, 4), (2, 3), (4, 0), (4, 1)]
+    assert pairs(orc.hash_join(left, right, [(1, 1, True), (2, 2, True)], abi.JOIN_LEFT)) == [(0, 0), (0, 1), (1, 4), (2, 3), (3, 2), (4, 0), (4, 1)]
+    assert [x for b in orc.hash_join(left, right, [(1, 1), (2, 2)], abi.JOIN_ANTI) for x in b[0]] == [2, 3]
+    # Utf8 key: by string; the NULL marker is the string "<NULL>"
+    ls = orc.OracleTable(4).add(1, abi.DT_UTF8, ["a", None, "<NULL>", "b"])
+    rs = orc.OracleTable(4).add(1, abi.DT_UTF8, ["b", "<NULL>", None, "c"])
+    assert pairs(orc.hash_join(ls, rs, [(1, 1)], abi.JOIN_INNER)) == [(2, 1), (3, 0)]
+    assert pairs(orc.hash_join(ls, rs, [(1, 1, True)], abi.JOIN_INNER)) == [(1, 1), (1, 2), (2, 1), (2, 2), (3, 0)]
+    # Int32 against Int64: never equal — but NULLs meet under null_equals_null, and so does a string "<NULL>"
+    l32 = orc.OracleTable(3).add(1, abi.DT_INT32, np.array([7, 0, 8], dtype=np.int32), [True, False, True])
+    r64 = orc.OracleTable(3).add(1, abi.DT_INT64, np.array([7, 8, 0]), [True, True, False])
+    assert pairs(orc.hash_join(l32, r64, [(1, 1)], abi.JOIN_INNER)) == []
+    assert pairs(orc.hash_join(l32, r64, [(1, 1, True)], abi.JOIN_LEFT)) == [(0, None), (1, 2), (2, None)]
+    assert pairs(orc.hash_join(ls, r64, [(1, 1, True)], abi.JOIN_INNER)) == [(1, 2), (2, 2)]
+    # Date32 values fail the key extraction (row skipped); Float64 keys compare by bit pattern (0.0 != -0.0, NaN == NaN)
+    ld = orc.OracleTable(3).add(1, abi.DT_DATE32, np.array([10, 0, 11], dtype=np.int32), [True, False, True])
+    rd = orc.OracleTable(3).add(1, abi.DT_DATE32, np.array([10, 11, 0], dtype=np.int32), [True, True, False])
+    assert pairs(orc.hash_join(ld, rd, [(1, 1)], abi.JOIN_INNER)) == []
+    assert pairs(orc.hash_join(ld, rd, [(1, 1, True)], abi.JOIN_INNER)) == [(1, 2)]
+    lf = orc.OracleTable(4).add(1, abi.DT_FLOAT64, np.array([0.0, -0.0, np.nan, 1.5]))
+    rf = orc.OracleTable(4).add(1, abi.DT_FLOAT64, np.array([1.5, np.nan, 0.0, 1.5]))
+    assert pairs(orc.hash_join(lf, rf, [(1, 1)], abi.JOIN_INNER)) == [(0, 2), (2, 1), (3, 0), (3, 3)]
+    # batches: the generic path cuts the probe into slices of batch_size rows (hash_join.rs:228-246)
+    n = 10
+    lb = orc.OracleTable(n).add(1, abi.DT_FLOAT64, np.arange(n, dtype=np.float64))
+    rb = orc.OracleTable(n).add(1, abi.DT_FLOAT64, np.arange(n, dtype=np.float64) * 2)
+    assert [b[0] for b in orc.hash_join(lb, rb, [(1, 1)], abi.JOIN_INNER, 4)] == [[0, 2], [4, 6], [8]]
+    li = orc.OracleTable(n).add(1, abi.DT_INT64, np.arange(n))
+    ri = orc.OracleTable(n).add(1, abi.DT_INT64, np.arange(n) * 2)
+    assert [b[0] for b in orc.hash_join(li, ri, [(1, 1)], abi.JOIN_INNER, 4)] == [[0, 2, 4, 6], [8]]  # fast path: no slices
+
+
 @pytest.mark.parametrize("case", AGGS["cases"], ids=lambda c: c["name"])
 def test_aggregate_cases(case, orc, abi):
     t = oracle_table(orc, abi, case["columns"])
