@@ -222,7 +222,13 @@ struct Selection {
 };
 int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                   uint32_t n_ops, Selection *sel, const uint32_t *drop_null_fields = nullptr, uint32_t n_drop_null_fields = 0);
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel);
+// `key_set`: the bitmap an InKeySet conjunct of the plan tests (plan.hpp: lower_selection_in_set)
+struct KeySetView {
+  const uint64_t *bits;
+  int64_t kmin;
+  uint64_t span;
+};
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

@@ -388,6 +388,21 @@ template <class C, class D, class TXN, class SNAP, class... UN> struct Mvcc {
     return own ? (deleted != txn) : other;
   }
 };
+// Semi join against a statistics-bounded key set: bit (key − bm_min) of the launch's bitmap (ScanParams::bm_bits;
+// the dimension chains of join → aggregate pipelines, llkv-executor/src/lib.rs:3780-4052 restated as a filter of
+// the middle table).
+template <class E> struct InKeySet {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    const uint64_t d = (uint64_t)(long long)E::eval(c, j) - (uint64_t)c.p.bm_min; // key < min wraps to a huge value
+    if (d > c.p.bm_span) return false;
+    return (c.p.bm_bits[d >> 6] >> (d & 63)) & 1ull;
+  }
+};
+// A, and only for the rows that pass it, B (B gathers from a table: skipping it for the rows A rejects saves the
+// loads; And<> evaluates every conjunct branch-free)
+template <class A, class B> struct AndThen {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) { return A::eval(c, j) && B::eval(c, j); }
+};
 template <class... Ps> struct And {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return (bool)((int)Ps::eval(c, j) & ...); }
 };

@@ -313,6 +313,27 @@ __global__ __launch_bounds__(256) void hj_segment_sums_kernel(const uint32_t *sl
   sum_by_slot[s] = acc;
   count_by_slot[s] = j - i;
 }
+// The same over pairs that are NOT sorted: every run of equal groups is summed where it lies; *multi_run is set
+// when some group has a second run (count_by_group must start at zero), and the caller falls back to the sort.
+__global__ __launch_bounds__(256) void hj_run_sums_kernel(const uint32_t *group, const uint64_t *val, uint64_t n, double *sum_by_group,
+                                                           unsigned long long *count_by_group, uint32_t *multi_run) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = group[i];
+  if (i != 0 && group[i - 1] == g) return;
+  double acc = 0.0;
+  uint64_t j = i;
+  for (; j < n && group[j] == g; ++j) acc += __longlong_as_double((long long)val[j]);
+  if (atomicAdd(&count_by_group[g], (unsigned long long)(j - i)) != 0) atomicOr(multi_run, 1u);
+  sum_by_group[g] = acc;
+}
+hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64_t n, double *sum_by_group, uint64_t *count_by_group,
+                              uint32_t *multi_run, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_run_sums_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, group, val, n, sum_by_group,
+                     (unsigned long long *)count_by_group, multi_run);
+  return hipGetLastError();
+}
 hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
                                   uint64_t *count_by_slot, hipStream_t s) {
   if (n == 0) return hipSuccess;
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256) void hj_compact_stripes_kernel(const uint32_t 
   if (slot >= n_slots) return;
   const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
   for (uint64_t i = threadIdx.x & 63; i < cnt; i += 64) {
-    out_group[dst + i] = slot_group[stripe_slot[src + i]];
+    out_group[dst + i] = slot_group ? slot_group[stripe_slot[src + i]] : stripe_slot[src + i];
     out_val[dst + i] = stripe_val[src + i];
   }
 }
@@ -422,6 +443,47 @@ hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t
                                      uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s) {
   if (n_slots == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_compact_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_slot, stripe_val, counts, offsets, n_slots, stripe, slot_group, out_group, out_val);
+  return hipGetLastError();
+}
+
+// ---- direct-address form of the dim table (statistics-bounded key range) ------------------------------------
+__global__ __launch_bounds__(256) void hj_bitmap_build_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,
+                                                               unsigned long long *bits, uint32_t *dup_flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t d = (uint64_t)load_key(key, dev_rows ? dev_rows[i] : i) - (uint64_t)kmin;
+  const unsigned long long bit = 1ull << (d & 63);
+  if (atomicOr(&bits[d >> 6], bit) & bit) atomicOr(dup_flag, 1u);
+}
+hipError_t hj_launch_bitmap_build(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, unsigned long long *bits,
+                                  uint32_t *dup_flag, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_bitmap_build_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, key, dev_rows, n, kmin, bits, dup_flag);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hj_popc_words_kernel(const uint64_t *bits, uint64_t n_words, uint32_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_words) out[i] = (uint32_t)__popcll(bits[i]);
+}
+hipError_t hj_launch_popc_words(const uint64_t *bits, uint64_t n_words, uint32_t *out, hipStream_t s) {
+  if (n_words == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_popc_words_kernel, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, s, bits, n_words, out);
+  return hipGetLastError();
+}
+hipError_t hj_exclusive_scan_u32(void *tmp, size_t *tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s) {
+  return rocprim::exclusive_scan(tmp, *tmp_bytes, in, out, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), s);
+}
+__global__ __launch_bounds__(256) void hj_bitmap_groups_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,
+                                                                const uint64_t *bits, const uint32_t *prefix, uint32_t *group_of_rank) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t d = (uint64_t)load_key(key, dev_rows[i]) - (uint64_t)kmin;
+  group_of_rank[prefix[d >> 6] + __popcll(bits[d >> 6] & ((1ull << (d & 63)) - 1))] = (uint32_t)i;
+}
+hipError_t hj_launch_bitmap_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, const uint64_t *bits,
+                                   const uint32_t *prefix, uint32_t *group_of_rank, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_bitmap_groups_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, key, dev_rows, n, kmin, bits, prefix, group_of_rank);
   return hipGetLastError();
 }
 
@@ -480,6 +542,98 @@ hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out
   hipLaunchKernelGGL(hj_high_halves_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, keys, n, out);
   return hipGetLastError();
 }
+// ---- top-k by selection instead of a full sort -------------------------------------------------------
+// Every slice of the groups reports its best order key; the want-th best of those is a threshold T that at least
+// `want` groups reach (the slice winners themselves), so every group of the final top `want` has key ≤ T.  The few
+// groups with key ≤ T are the candidates; the host orders them exactly.  No same-address atomics anywhere (a
+// histogram of the keys serialises on its hot bins).
+__device__ __forceinline__ uint64_t desc_order_key(double v) {
+  const long long bits = __double_as_longlong(v);
+  const uint64_t asc = bits < 0 ? ~(uint64_t)bits : ((uint64_t)bits | 0x8000000000000000ull);
+  return ~asc;
+}
+// slice b = groups [b·per, (b+1)·per): best[b] = smallest descending key of its groups with rows (~0: none)
+__global__ __launch_bounds__(256) void hj_topk_slice_best_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t per, uint64_t *best,
+                                                                  unsigned long long *n_groups) {
+  __shared__ uint64_t wave_best[4];
+  __shared__ uint32_t wave_count[4];
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint64_t mine = ~0ull;
+  uint32_t have = 0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    if (counts[i] == 0) continue;
+    ++have;
+    const uint64_t k = desc_order_key(sums[i]);
+    mine = k < mine ? k : mine;
+  }
+  for (int o = 32; o; o >>= 1) {
+    const uint64_t other = __shfl_xor(mine, o);
+    mine = other < mine ? other : mine;
+    have += __shfl_xor(have, o);
+  }
+  if ((threadIdx.x & 63) == 0) { wave_best[threadIdx.x >> 6] = mine; wave_count[threadIdx.x >> 6] = have; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t b = wave_best[0];
+    uint32_t c = wave_count[0];
+    for (int w = 1; w < 4; ++w) { b = wave_best[w] < b ? wave_best[w] : b; c += wave_count[w]; }
+    best[blockIdx.x] = b;
+    if (c) atomicAdd(n_groups, (unsigned long long)c);
+  }
+}
+// one workgroup: *threshold = want-th smallest of best[0..n_slices) (n_slices ≤ 1024; ~0 when fewer slices have groups)
+__global__ __launch_bounds__(1024) void hj_topk_threshold_kernel(const uint64_t *best, uint32_t n_slices, uint32_t want, uint64_t *threshold) {
+  __shared__ uint64_t v[1024];
+  const uint32_t t = threadIdx.x;
+  v[t] = t < n_slices ? best[t] : ~0ull;
+  __syncthreads();
+  for (uint32_t k = 2; k <= 1024; k <<= 1)
+    for (uint32_t j = k >> 1; j; j >>= 1) { // bitonic sort, ascending
+      const uint32_t other = t ^ j;
+      if (other > t) {
+        const bool up = (t & k) == 0;
+        const uint64_t a = v[t], b = v[other];
+        if ((a > b) == up) { v[t] = b; v[other] = a; }
+      }
+      __syncthreads();
+    }
+  if (t == 0) *threshold = v[want - 1 < 1023 ? want - 1 : 1023];
+}
+__global__ __launch_bounds__(256) void hj_topk_collect_kernel(const double *sums, const uint64_t *counts, uint64_t n, const uint64_t *threshold, uint32_t cap,
+                                                               uint32_t *groups, uint32_t *counter) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || counts[i] == 0) return;
+  if (desc_order_key(sums[i]) > *threshold) return;
+  const uint32_t at = atomicAdd(counter, 1u);
+  if (at < cap) groups[at] = (uint32_t)i;
+}
+__global__ __launch_bounds__(128) void hj_gather_collected_kernel(const uint32_t *groups, const uint32_t *counter, uint32_t cap, const uint64_t *dim_rows,
+                                                                   const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap || i >= *counter) return;
+  uint64_t *o = out + (uint64_t)i * 8;
+  const uint32_t g = groups[i];
+  const uint64_t owner = dim_rows[g];
+  o[0] = g;
+  o[1] = (uint64_t)load_key(cols.key, owner);
+  o[2] = (uint64_t)__double_as_longlong(sum_by_group[g]);
+  o[3] = count_by_group[g];
+  for (uint32_t k = 0; k < 4; ++k) o[4 + k] = k < cols.n_payload ? (uint64_t)load_key(cols.payload[k], owner) : 0;
+}
+hipError_t hj_launch_topk_select(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
+                                 uint64_t *best /*[1024]*/, uint64_t *state /*[3] zeroed: threshold, candidates (u32), groups*/,
+                                 uint32_t *groups /*[cap]*/, uint64_t *out /*[cap][8]*/, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const uint64_t per = (n + 1023) / 1024; // as many slices as the threshold kernel sorts: the bound is tightest
+  const uint32_t n_slices = (uint32_t)((n + per - 1) / per);
+  if (want > 1024) want = 1024;
+  hipLaunchKernelGGL(hj_topk_slice_best_kernel, dim3(n_slices), dim3(256), 0, s, sums, counts, n, per, best, (unsigned long long *)(state + 2));
+  hipLaunchKernelGGL(hj_topk_threshold_kernel, dim3(1), dim3(1024), 0, s, best, n_slices, want, state);
+  hipLaunchKernelGGL(hj_topk_collect_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, sums, counts, n, state, cap, groups, (uint32_t *)(state + 1));
+  hipLaunchKernelGGL(hj_gather_collected_kernel, dim3((cap + 127) / 128), dim3(128), 0, s, groups, (const uint32_t *)(state + 1), cap, dim_rows, sums, counts, cols, out);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(128) void hj_gather_group_candidates_kernel(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n,
                                                                          const uint64_t *dim_rows, const double *sum_by_group,
                                                                          const uint64_t *count_by_group, CandidateCols cols, uint64_t *out) {

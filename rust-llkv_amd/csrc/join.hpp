@@ -107,6 +107,10 @@ hipError_t hj_sort_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *kin, ui
 // without a group sort last).
 hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
                                   uint64_t *count_by_slot, hipStream_t s);
+// The same over unsorted pairs: runs are summed where they lie; *multi_run is set when a group has two runs
+// (count_by_group must start at zero) — the caller then sorts.
+hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64_t n, double *sum_by_group, uint64_t *count_by_group,
+                              uint32_t *multi_run, hipStream_t s);
 hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots,
                                unsigned long long *n_groups /* += groups */, hipStream_t s);
 // One record per candidate slot: {sort key, dim key, sum bits, count, payload[4]} (8 × 8 bytes).
@@ -127,6 +131,16 @@ hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table,
 // offsets[slot] with the hash slot translated to its group id.
 hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
                                      uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s);
+// Direct-address form of a dim table whose key range is bounded by the column statistics: bit (key − kmin) set for
+// every listed row (*dup_flag when a key occurs twice; dev_rows == nullptr lists rows 0..n−1), per-word popcounts →
+// exclusive scan = rank of each word's first set bit, group_of_rank[rank(key of listed row i)] = i.
+// (`slot_group` of hj_launch_compact_stripes may then be nullptr: the stripes already hold group ids.)
+hipError_t hj_launch_bitmap_build(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, unsigned long long *bits,
+                                  uint32_t *dup_flag, hipStream_t s);
+hipError_t hj_launch_popc_words(const uint64_t *bits, uint64_t n_words, uint32_t *out, hipStream_t s);
+hipError_t hj_exclusive_scan_u32(void *tmp, size_t *tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s);
+hipError_t hj_launch_bitmap_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, const uint64_t *bits,
+                                   const uint32_t *prefix, uint32_t *group_of_rank, hipStream_t s);
 // flags[i] = 1 when the group of sorted pair i has rows on another rank too (local count ≠ global count).
 hipError_t hj_launch_straddler_flags(const uint32_t *sorted_group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
                                      uint64_t *flags, hipStream_t s);
@@ -138,6 +152,13 @@ hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, co
                                   uint64_t *report, hipStream_t s);
 // gather_candidates for group ids: owner row = dim_rows[group].
 // (`sorted_keys` may be nullptr: the key of candidate i is then `keys_by_group[sorted_groups[i]]`.)
+// Top-k by selection: the groups are cut into ≤ 1024 slices, each reports its best order key; the want-th best of
+// those bounds the final top `want` from below, and the groups that reach it (in no particular order, at most `cap`
+// of them; state[1] = how many qualified) come back as candidate records {group, dim key, sum bits, count,
+// payload[4]}.  state[2] += groups that have rows.
+hipError_t hj_launch_topk_select(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
+                                 uint64_t *best /*[1024]*/, uint64_t *state /*[3] zeroed: threshold, candidates (u32), groups*/,
+                                 uint32_t *groups /*[cap]*/, uint64_t *out /*[cap][8]*/, hipStream_t s);
 hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s);
 hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,

@@ -68,6 +68,46 @@ struct HashSet {
   }
 };
 
+// Direct-address form of a key set whose range the column statistics bound (join.hpp): bitmap + rank + group ids.
+constexpr uint64_t kMaxDirectSpan = 1ull << 30; // 128 MiB of bits + 64 MiB of word ranks at most
+struct DirectTable {
+  DB bits, prefix, group;
+  int64_t kmin = 0;
+  uint64_t span = 0;
+  static bool usable(const ColumnInfo &ci) {
+    return ci.has_stats && ci.max_i >= ci.min_i && (uint64_t)ci.max_i - (uint64_t)ci.min_i < kMaxDirectSpan;
+  }
+  // `with_groups`: also the rank → list index table (the group ids of the join-aggregate pipeline)
+  int build(const ColumnInfo &ci, const JoinKeyColumn &key, const uint64_t *d_rows, uint64_t n, bool with_groups, bool *dup, hipStream_t s) {
+    kmin = ci.min_i;
+    span = (uint64_t)ci.max_i - (uint64_t)ci.min_i;
+    const uint64_t n_words = span / 64 + 1;
+    int rc;
+    DB flag;
+    if ((rc = bits.alloc(n_words * 8)) || (rc = flag.alloc(4))) return rc;
+    HIP_TRY(hipMemsetAsync(bits.p, 0, n_words * 8, s));
+    HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
+    HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, (uint32_t *)flag.p, s));
+    uint32_t f = 0;
+    HIP_TRY(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, s));
+    if (with_groups) {
+      DB tmp;
+      size_t tb = 0;
+      if ((rc = prefix.alloc(n_words * 4)) || (rc = group.alloc((n ? n : 1) * 4))) return rc;
+      HIP_TRY(hj_launch_popc_words((const uint64_t *)bits.p, n_words, (uint32_t *)prefix.p, s));
+      HIP_TRY(hj_exclusive_scan_u32(nullptr, &tb, (const uint32_t *)prefix.p, (uint32_t *)prefix.p, n_words, s));
+      if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+      HIP_TRY(hj_exclusive_scan_u32(tmp.p, &tb, (const uint32_t *)prefix.p, (uint32_t *)prefix.p, n_words, s));
+      HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, (uint32_t *)group.p, s));
+      HIP_TRY(hipStreamSynchronize(s)); // tmp is released on return
+    } else {
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    *dup = f != 0;
+    return LLKV_OK;
+  }
+};
+
 int scan_exclusive(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t s) {
   DB tmp;
   size_t tb = 0;
@@ -96,7 +136,9 @@ struct JoinAgg {
   DB kept;                           // … and after it
   const uint64_t *d_dim_rows = nullptr;
   uint64_t n_dim = 0;                // groups = qualifying dim rows, in row order
-  DB sums, cnts, gcnts, report;      // per group: local f64 sum, local rows, exchanged rows (int64), rows this rank reports
+  struct View { void *p = nullptr; };
+  DB group_state;                    // one block, one memset:
+  View sums, cnts, gcnts, report;    // per group: local f64 sum, local rows, exchanged rows (int64), rows this rank reports
   DB s_group, s_val;                 // local (group, value) pairs sorted by group, row order within a group
   uint64_t n_pairs = 0;
   std::vector<uint32_t> st_groups;   // straddler pairs of this rank (host)
@@ -124,21 +166,42 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   n_payload = n_payload_;
   hipStream_t s = g_ctx.stream;
 
-  // ---- dim2 key set -------------------------------------------------------------------
+  // ---- dim rows: filter [⋉ dim2] ------------------------------------------------------
+  // dim2's key range bounded by its statistics → the semi join is one more conjunct of dim's selection (a bit
+  // test); otherwise: hash set of dim2's keys, flags over dim's selection, compaction
   HashSet set2;
+  DirectTable set2_bits;
   JoinKeyColumn k2{}, fk{};
+  bool fused_semi = false;
   if (t2) {
     Selection sel2;
     if ((rc = run_selection(t2, dim2->filters, dim2->n_filters, nullptr, 0, &sel2))) return rc;
     if ((rc = int_key_column(t2, dim2->key_field, &k2)) || (rc = int_key_column(td, dim_fk_field, &fk))) return rc;
+    const ColumnInfo &k2_info = t2->cols.find(dim2->key_field)->second.info;
     bool dup = false;
-    if ((rc = set2.build(k2, sel2.d_dev, sel2.n, &dup, s))) return rc;
+    fused_semi = DirectTable::usable(k2_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
+    if (fused_semi) {
+      if ((rc = set2_bits.build(k2_info, k2, sel2.d_dev, sel2.n, false, &dup, s))) return rc;
+    } else if ((rc = set2.build(k2, sel2.d_dev, sel2.n, &dup, s))) {
+      return rc;
+    }
   }
-  // ---- dim rows: filter [⋉ dim2] ------------------------------------------------------
-  if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) return rc;
+  if (fused_semi) {
+    auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
+      auto it = td->cols.find(fid);
+      return it == td->cols.end() ? nullptr : &it->second.info;
+    };
+    LoweredPlan sel_plan;
+    std::string err;
+    if ((rc = lower_selection_in_set(resolve_d, dim->filters, dim->n_filters, dim_fk_field, &sel_plan, &err))) return set_error(rc, err);
+    const KeySetView view{(const uint64_t *)set2_bits.bits.p, set2_bits.kmin, set2_bits.span};
+    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view))) return rc;
+  } else if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) {
+    return rc;
+  }
   n_dim = seld.n;
   d_dim_rows = seld.d_dev;
-  if (t2 && seld.n) {
+  if (t2 && !fused_semi && seld.n) {
     DB flags, offs;
     if ((rc = flags.alloc(seld.n * 8)) || (rc = offs.alloc((seld.n + 1) * 8))) return rc;
     HIP_TRY(hj_launch_semi_flags(fk, seld.d_dev, seld.n, k2, (const unsigned long long *)set2.owner.p, set2.cap - 1, (uint64_t *)flags.p, s));
@@ -155,10 +218,13 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   }
   if (n_dim >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "dimension too large");
   if (n_dim == 0) return LLKV_OK;
-  if ((rc = sums.alloc(n_dim * 8)) || (rc = cnts.alloc(n_dim * 8)) || (rc = gcnts.alloc(n_dim * 8)) || (rc = report.alloc(n_dim * 8))) return rc;
-  HIP_TRY(hipMemsetAsync(sums.p, 0, n_dim * 8, s));
-  HIP_TRY(hipMemsetAsync(cnts.p, 0, n_dim * 8, s));
-  HIP_TRY(hipMemsetAsync(gcnts.p, 0, n_dim * 8, s));
+  const size_t state_bytes = (n_dim * 8 + 4095) / 4096 * 4096; // whole pages: the memset is one fill kernel
+  if ((rc = group_state.alloc(4 * state_bytes))) return rc;
+  sums.p = group_state.p;
+  cnts.p = (char *)group_state.p + state_bytes;
+  gcnts.p = (char *)group_state.p + 2 * state_bytes;
+  report.p = (char *)group_state.p + 3 * state_bytes;
+  HIP_TRY(hipMemsetAsync(group_state.p, 0, 3 * state_bytes, s));
 
   // ---- dim hash table, slot → group id -----------------------------------------------------
   JoinKeyColumn kd{};
@@ -167,13 +233,24 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   cc.key = kd;
   cc.n_payload = n_payload;
   for (uint32_t i = 0; i < n_payload; ++i) if ((rc = int_key_column(td, payload_fields[i], &cc.payload[i]))) return rc;
+  // key range bounded by the column statistics → bitmap + rank (no hashing, and a clustered fact table probes it
+  // almost sequentially); otherwise the open-addressing table
+  const ColumnInfo &kd_info = td->cols.find(dim->key_field)->second.info;
+  const bool direct = DirectTable::usable(kd_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
   HashSet ht;
-  bool dup = false;
-  if ((rc = ht.build(kd, d_dim_rows, n_dim, &dup, s))) return rc;
-  if (dup) return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row");
+  DirectTable dt;
   DB slot_group;
-  if ((rc = slot_group.alloc(ht.cap * 4))) return rc;
-  HIP_TRY(hj_launch_slot_groups(kd, d_dim_rows, n_dim, (const unsigned long long *)ht.owner.p, ht.cap - 1, (uint32_t *)slot_group.p, s));
+  bool dup = false;
+  if (direct) {
+    if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, &dup, s))) return rc;
+  } else {
+    if ((rc = ht.build(kd, d_dim_rows, n_dim, &dup, s))) return rc;
+  }
+  if (dup) return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row");
+  if (!direct) {
+    if ((rc = slot_group.alloc(ht.cap * 4))) return rc;
+    HIP_TRY(hj_launch_slot_groups(kd, d_dim_rows, n_dim, (const unsigned long long *)ht.owner.p, ht.cap - 1, (uint32_t *)slot_group.p, s));
+  }
 
   // ---- fact probe-emit -------------------------------------------------------------------
   auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
@@ -201,11 +278,19 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   p.n_tiles = ts->n_tiles;
   p.sub_rows = 8192 / (kBlock / 64);
   p.tile_partials = (uint64_t *)counts.p;
-  p.ht_owner = (const unsigned long long *)ht.owner.p;
-  p.ht_mask = ht.cap - 1;
-  p.ht_keys = kd.values;
-  p.ht_key_width = kd.width;
-  p.ht_key_signed = kd.is_signed;
+  if (direct) {
+    p.bm_bits = (const uint64_t *)dt.bits.p;
+    p.bm_prefix = (const uint32_t *)dt.prefix.p;
+    p.bm_group = (const uint32_t *)dt.group.p;
+    p.bm_min = dt.kmin;
+    p.bm_span = dt.span;
+  } else {
+    p.ht_owner = (const unsigned long long *)ht.owner.p;
+    p.ht_mask = ht.cap - 1;
+    p.ht_keys = kd.values;
+    p.ht_key_width = kd.width;
+    p.ht_key_signed = kd.is_signed;
+  }
   // single pass over the fact columns: every (tile, wave) writes its pairs into its own stripe and reports its
   // count; only the emitted pairs (a few percent of the rows for Q3) are touched again by the compaction
   const uint32_t stripe = p.sub_rows;
@@ -222,19 +307,33 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   DB e_group, e_val;
   if ((rc = e_group.alloc(n_pairs * 4)) || (rc = e_val.alloc(n_pairs * 8)) || (rc = s_group.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;
   HIP_TRY(hj_launch_compact_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p, n_slots, stripe,
-                                    (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
-  // ---- stable sort by group, per-group sums in scan order ---------------------------------------
-  uint32_t bits = 1;
-  while ((1ull << bits) < n_dim) ++bits;
-  {
+                                    direct ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
+  // ---- per-group sums in scan order ------------------------------------------------------------
+  // The pairs are in row order.  A fact table clustered by the join key leaves every group as ONE run of them: sum
+  // the runs where they lie; only when some group turns out to have a second run, sort (stable) by group first.
+  DB multi;
+  if ((rc = multi.alloc(4))) return rc;
+  HIP_TRY(hipMemsetAsync(multi.p, 0, 4, s));
+  HIP_TRY(hj_launch_run_sums((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, (uint32_t *)multi.p, s));
+  uint32_t multi_run = 0;
+  HIP_TRY(hipMemcpyAsync(&multi_run, multi.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
+    std::swap(s_group.p, e_group.p); // a group's pairs are contiguous and in row order: all the later phases need
+    std::swap(s_val.p, e_val.p);
+  } else {
+    uint32_t bits = 1;
+    while ((1ull << bits) < n_dim) ++bits;
     DB tmp;
     size_t tb = 0;
+    HIP_TRY(hipMemsetAsync(sums.p, 0, n_dim * 8, s));
+    HIP_TRY(hipMemsetAsync(cnts.p, 0, n_dim * 8, s));
     HIP_TRY(hj_sort_u32_u64(nullptr, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
+    HIP_TRY(hipStreamSynchronize(s)); // tmp is released at the end of the block
   }
-  HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
   HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
   HIP_TRY(hipStreamSynchronize(s));
   return LLKV_OK;
@@ -295,6 +394,42 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     HIP_TRY(hipMemcpyAsync(dcnt.p, mc.data(), mc.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hj_launch_patch_groups((const uint32_t *)dg.p, (const double *)dsum.p, (const uint64_t *)dcnt.p, mg.size(), (double *)sums.p, (uint64_t *)report.p, s));
     HIP_TRY(hipStreamSynchronize(s)); // the host vectors are pageable
+  }
+  const uint32_t np = n_payload;
+  // ---- top-k by selection: the best keys of ≤ 1024 slices of the groups bound the LIMIT from below; the few groups
+  // that reach the bound go to the host, which orders them exactly (sum DESC, payload[0], dim row).  More than kCap
+  // of them (many equal sums) falls back to the sort below.
+  if (!std::getenv("LLKV_HIP_TOPK_SORT") && limit <= 1024) {
+    constexpr uint32_t kCap = 2048;
+    DB best, state, groups_d, recs;
+    if ((rc = best.alloc(1024 * 8)) || (rc = state.alloc(24)) || (rc = groups_d.alloc(kCap * 4)) || (rc = recs.alloc((size_t)kCap * 64))) return rc;
+    HIP_TRY(hipMemsetAsync(state.p, 0, 24, s));
+    HIP_TRY(hj_launch_topk_select((const double *)sums.p, (const uint64_t *)report.p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p,
+                                  (uint64_t *)state.p, (uint32_t *)groups_d.p, (uint64_t *)recs.p, s));
+    uint64_t head[3] = {0, 0, 0}; // threshold, candidates, groups
+    HIP_TRY(hipMemcpyAsync(head, state.p, 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t n_sel = (uint32_t)head[1];
+    if (n_sel <= kCap) {
+      std::vector<uint64_t> hrec((size_t)n_sel * 8);
+      if (n_sel) HIP_TRY(hipMemcpy(hrec.data(), recs.p, (size_t)n_sel * 64, hipMemcpyDeviceToHost));
+      std::vector<llkv_join_group_row> cand(n_sel);
+      for (uint32_t i = 0; i < n_sel; ++i) {
+        const uint64_t *c = &hrec[(size_t)i * 8];
+        llkv_join_group_row &g = cand[i];
+        g.group_index = (uint32_t)c[0];
+        g.key = (int64_t)c[1];
+        std::memcpy(&g.sum, &c[2], 8);
+        g.count = c[3];
+        for (int k = 0; k < 4; ++k) g.payload[k] = (int64_t)c[4 + k];
+      }
+      std::sort(cand.begin(), cand.end(), [np](const llkv_join_group_row &a, const llkv_join_group_row &b) { return row_before(a, b, np); });
+      const uint32_t n = std::min<uint32_t>(limit, n_sel);
+      for (uint32_t i = 0; i < n; ++i) out_rows[i] = cand[i];
+      *out_n = n;
+      if (out_groups) *out_groups = head[2];
+      return LLKV_OK;
+    }
   }
   DB tk_keys, tk_groups, tk_keys_s, tk_groups_s, n_groups_d;
   if ((rc = tk_keys.alloc(n_dim * 8)) || (rc = tk_groups.alloc(n_dim * 4)) || (rc = tk_keys_s.alloc(n_dim * 8)) || (rc = tk_groups_s.alloc(n_dim * 4)) ||
@@ -357,7 +492,6 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     for (int k = 0; k < 4; ++k) g.payload[k] = (int64_t)c[4 + k];
     g.group_index = hg[i];
   }
-  const uint32_t np = n_payload;
   std::sort(cand.begin(), cand.end(), [np](const llkv_join_group_row &a, const llkv_join_group_row &b) { return row_before(a, b, np); });
   const uint32_t n = std::min<uint32_t>(limit, n_cand);
   for (uint32_t i = 0; i < n; ++i) out_rows[i] = cand[i];

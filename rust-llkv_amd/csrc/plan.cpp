@@ -1140,6 +1140,27 @@ int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, u
   return LLKV_OK;
 }
 
+int lower_selection_in_set(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
+                           LoweredPlan *out, std::string *err) {
+  *out = LoweredPlan{};
+  Lowering L{resolve, *out, err, false};
+  std::string pred, key;
+  int rc = L.predicate(filters, n_filters, nullptr, 0, &pred);
+  if (rc) return rc;
+  const ColumnInfo *ci;
+  int slot;
+  if ((rc = L.slot_of(key_field, &ci, &slot))) return rc;
+  if (ci->nullable) return L.fail(LLKV_UNSUPPORTED, "NULL join keys in the join-aggregate pipeline");
+  if (ci->dtype == LLKV_DT_INT64 || ci->dtype == LLKV_DT_UINT64) key = L.col_node(slot, LLKV_DT_INT64);
+  else if (ci->dtype == LLKV_DT_INT32 || ci->dtype == LLKV_DT_DATE32 || ci->dtype == LLKV_DT_UINT32) key = "ToI64<" + L.col_node(slot, ci->dtype) + ">";
+  else return L.fail(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(ci->dtype));
+  out->always_false = pred == "False";
+  const std::string in_set = "InKeySet<" + key + ">";
+  if (!out->always_false) pred = pred == "True" ? in_set : "AndThen<" + pred + "," + in_set + ">";
+  out->type_string = "SelPlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + ">";
+  return LLKV_OK;
+}
+
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err,
                bool allow_f64, bool *is_f64_out) {

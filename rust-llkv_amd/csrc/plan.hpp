@@ -102,6 +102,10 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
 int lower_selection(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                     const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *drop_null_fields, uint32_t n_drop_null_fields,
                     LoweredPlan *out, std::string *err);
+// The same with one more conjunct: the integer column `key_field` (no NULL cells) must be in the key set the launch
+// binds (InKeySet, fused_scan.hip.h) → "SelPlan<Cols<…>,AndThen<pred,InKeySet<key>>>".
+int lower_selection_in_set(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
+                           LoweredPlan *out, std::string *err);
 // Scan projections (ScanProjection::{Column,Computed}, llkv-scan/src/lib.rs:59-65) →
 // "ProjPlan<Cols<…>,Outs<…>>" (window gather + computed expressions).
 int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,

@@ -66,6 +66,15 @@ struct ScanParams {
   uint64_t *prev_exchange;       // [kOctants][lanes] image to fold it into
   uint32_t octant_tile_begin[kOctants + 1];
   uint32_t owned_mask;           // octants of this rank; rows of the others are written as zero
+  // probe-emit over a statistics-bounded build key: direct addressing instead of hashing.  Bit (k − bm_min) of
+  // bm_bits says whether key k is on the build side; its rank among the set bits (bm_prefix = set bits before
+  // the word) indexes bm_group, the group id of that key.  A fact table clustered by the key walks these arrays
+  // almost sequentially.
+  const uint64_t *bm_bits;       // nullptr: hash table (ht_*)
+  const uint32_t *bm_prefix;
+  const uint32_t *bm_group;
+  int64_t bm_min;
+  uint64_t bm_span;              // max − min
 };
 
 constexpr int kMaxOuts = 8;

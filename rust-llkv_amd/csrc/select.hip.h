@@ -86,6 +86,15 @@ __device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
   }
 }
 
+// direct addressing: group id of key k, or 0xFFFFFFFF (see ScanParams::bm_bits)
+__device__ __forceinline__ uint32_t bm_find(const ScanParams &p, long long k) {
+  const uint64_t d = (uint64_t)k - (uint64_t)p.bm_min; // k < min wraps to a huge value
+  if (d > p.bm_span) return 0xFFFFFFFFu;
+  const uint64_t w = p.bm_bits[d >> 6], bit = 1ull << (d & 63);
+  if (!(w & bit)) return 0xFFFFFFFFu;
+  return p.bm_group[p.bm_prefix[d >> 6] + __popcll(w & (bit - 1))];
+}
+
 template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -113,7 +122,8 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
       Ctx c{p, ld, 0u, td.logical_row + row0 + j};
       const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
       perr |= ((row0 + j) < sub1) ? c.perr : 0u;
-      hit[j] = pass ? ht_find(p, (long long)P::KeyE::eval(c, j)) : 0xFFFFFFFFu; // hash probe only for surviving rows
+      // probe only for surviving rows (the branch on the table form is uniform over the grid)
+      hit[j] = !pass ? 0xFFFFFFFFu : p.bm_bits ? bm_find(p, (long long)P::KeyE::eval(c, j)) : ht_find(p, (long long)P::KeyE::eval(c, j));
       f[j] = hit[j] != 0xFFFFFFFFu;
       val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
     }

@@ -43,7 +43,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
 }
 
 // The selection kernels of an already lowered predicate (prepared statements keep the plan).
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel) {
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set) {
   int rc;
   std::string err;
   scratch_free(sel->d_ids); sel->d_ids = nullptr;
@@ -68,6 +68,11 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
   p.n_tiles = ts->n_tiles;
   p.sub_rows = kSelectTileRows / (kBlock / 64);
   p.tile_partials = (uint64_t *)counts.p;
+  if (key_set) {
+    p.bm_bits = key_set->bits;
+    p.bm_min = key_set->kmin;
+    p.bm_span = key_set->span;
+  }
   if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &p, sizeof p, stream))) return rc;
   HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, stream));
   uint64_t total = 0;

@@ -1236,6 +1236,33 @@ def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
         assert np.float64(g[1]).tobytes() == np.float64(w[1]).tobytes(), (g, w)  # bit-exact revenue
 
 
+@pytest.mark.parametrize("n_orders,limit", [(1500, 10), (40_000, 10), (40_000, 300)])
+def test_join_groupby_topk_with_tied_sums(rt, abi, n_orders, limit):
+    """Top-k by selection (slice winners → threshold → candidates → exact host order): thousands of groups share
+    a handful of sums, so the LIMIT cut falls inside runs of equal sums and equal dates; order = sum DESC,
+    payload[0] ASC, then dim row.  Expected values computed with numpy from the same inputs (sums of ≤ 3 small
+    integers-as-f64 are exact in any order)."""
+    rng = np.random.default_rng(n_orders + limit)
+    okey = np.arange(1, n_orders + 1, dtype=np.int64) * 3
+    odate = rng.integers(9000, 9004, size=n_orders).astype(np.int32)
+    lines = rng.integers(1, 4, size=n_orders)
+    lkey = np.repeat(okey, lines)
+    price = rng.choice(np.array([100.0, 200.0, 300.0]), size=len(lkey))
+    price[rng.random(len(lkey)) < 0.0005] = 1e6  # a few clear winners
+    orphan = rng.random(len(lkey)) < 0.05        # fact rows without an order
+    lkey = np.where(orphan, lkey + 1, lkey)
+    ot_ = rt.HipTable(2, [n_orders]); ot_.append_column(1, abi.DT_INT64, okey); ot_.append_column(2, abi.DT_DATE32, odate)
+    lt = rt.HipTable(1, [len(lkey)]); lt.append_column(7, abi.DT_INT64, lkey); lt.append_column(8, abi.DT_FLOAT64, price)
+    got, total = rt.join_groupby_topk(lt, [], 7, ot_, [abi.Filter(2, abi.Operator.LessThan(9003))], 1, abi.col(8) * 1.0, payload_fields=[2], limit=limit)
+    sums, counts = np.zeros(n_orders), np.zeros(n_orders, dtype=np.int64)
+    idx = (lkey // 3 - 1)[~orphan]
+    np.add.at(sums, idx, price[~orphan]); np.add.at(counts, idx, 1)
+    live = np.flatnonzero((counts > 0) & (odate < 9003))
+    order = sorted(live.tolist(), key=lambda i: (-sums[i], odate[i], i))[:limit]
+    assert total == len(live)
+    assert [(r[0], r[1], r[2], r[3]) for r in got] == [(int(okey[i]), float(sums[i]), int(counts[i]), int(odate[i])) for i in order]
+
+
 def _device_i64(ptr, n):
     """int64 torch tensor aliasing a raw device pointer (what the RCCL all-reduce is given on the GPU box)."""
     import torch
