@@ -228,7 +228,9 @@ struct KeySetView {
   int64_t kmin;
   uint64_t span;
 };
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr);
+// `single_pass`: evaluate the predicate once (striped output + compaction) instead of count pass + write pass —
+// pays when the predicate is expensive (table gathers) or few rows pass
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr, bool single_pass = false);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

@@ -446,6 +446,24 @@ hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t
   return hipGetLastError();
 }
 
+// the same for the two u64 streams of a single-pass selection (row ids, device rows)
+__global__ __launch_bounds__(256) void hj_compact_stripes2_kernel(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets,
+                                                                   uint32_t n_slots, uint32_t stripe, uint64_t *out_a, uint64_t *out_b) {
+  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= n_slots) return;
+  const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
+  for (uint64_t i = threadIdx.x & 63; i < cnt; i += 64) {
+    out_a[dst + i] = stripe_a[src + i];
+    out_b[dst + i] = stripe_b[src + i];
+  }
+}
+hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
+                                      uint32_t stripe, uint64_t *out_a, uint64_t *out_b, hipStream_t s) {
+  if (n_slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_compact_stripes2_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_a, stripe_b, counts, offsets, n_slots, stripe, out_a, out_b);
+  return hipGetLastError();
+}
+
 // ---- direct-address form of the dim table (statistics-bounded key range) ------------------------------------
 __global__ __launch_bounds__(256) void hj_bitmap_build_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,
                                                                unsigned long long *bits, uint32_t *dup_flag) {

@@ -71,27 +71,24 @@ struct HashSet {
 // Direct-address form of a key set whose range the column statistics bound (join.hpp): bitmap + rank + group ids.
 constexpr uint64_t kMaxDirectSpan = 1ull << 30; // 128 MiB of bits + 64 MiB of word ranks at most
 struct DirectTable {
-  DB bits, prefix, group;
+  DB bits, prefix, group, flag, tmp;
   int64_t kmin = 0;
   uint64_t span = 0;
   static bool usable(const ColumnInfo &ci) {
     return ci.has_stats && ci.max_i >= ci.min_i && (uint64_t)ci.max_i - (uint64_t)ci.min_i < kMaxDirectSpan;
   }
-  // `with_groups`: also the rank → list index table (the group ids of the join-aggregate pipeline)
-  int build(const ColumnInfo &ci, const JoinKeyColumn &key, const uint64_t *d_rows, uint64_t n, bool with_groups, bool *dup, hipStream_t s) {
+  // Launches only (no host synchronisation): `flag` (device, u32) is non-zero afterwards when a key occurred twice.
+  // `with_groups`: also the rank → list index table (the group ids of the join-aggregate pipeline).
+  int build(const ColumnInfo &ci, const JoinKeyColumn &key, const uint64_t *d_rows, uint64_t n, bool with_groups, hipStream_t s) {
     kmin = ci.min_i;
     span = (uint64_t)ci.max_i - (uint64_t)ci.min_i;
-    const uint64_t n_words = span / 64 + 1;
+    const uint64_t n_words = (span / 64 + 1 + 511) / 512 * 512; // whole pages: one fill kernel
     int rc;
-    DB flag;
     if ((rc = bits.alloc(n_words * 8)) || (rc = flag.alloc(4))) return rc;
     HIP_TRY(hipMemsetAsync(bits.p, 0, n_words * 8, s));
     HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
     HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, (uint32_t *)flag.p, s));
-    uint32_t f = 0;
-    HIP_TRY(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, s));
     if (with_groups) {
-      DB tmp;
       size_t tb = 0;
       if ((rc = prefix.alloc(n_words * 4)) || (rc = group.alloc((n ? n : 1) * 4))) return rc;
       HIP_TRY(hj_launch_popc_words((const uint64_t *)bits.p, n_words, (uint32_t *)prefix.p, s));
@@ -99,23 +96,18 @@ struct DirectTable {
       if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
       HIP_TRY(hj_exclusive_scan_u32(tmp.p, &tb, (const uint32_t *)prefix.p, (uint32_t *)prefix.p, n_words, s));
       HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, (uint32_t *)group.p, s));
-      HIP_TRY(hipStreamSynchronize(s)); // tmp is released on return
-    } else {
-      HIP_TRY(hipStreamSynchronize(s));
     }
-    *dup = f != 0;
     return LLKV_OK;
   }
 };
 
-int scan_exclusive(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t s) {
-  DB tmp;
+// `tmp` belongs to the caller and must outlive the scan on the stream (no host synchronisation here)
+int scan_exclusive(const uint64_t *in, uint64_t *out, uint64_t n, DB &tmp, hipStream_t s) {
   size_t tb = 0;
   HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, in, out, n, s));
   int rc = tmp.alloc(tb ? tb : 8);
   if (rc) return rc;
   HIP_TRY(hj_exclusive_scan_u64(tmp.p, &tb, in, out, n, s));
-  HIP_TRY(hipStreamSynchronize(s)); // tmp is released on return
   return LLKV_OK;
 }
 
@@ -180,8 +172,9 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     const ColumnInfo &k2_info = t2->cols.find(dim2->key_field)->second.info;
     bool dup = false;
     fused_semi = DirectTable::usable(k2_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
-    if (fused_semi) {
-      if ((rc = set2_bits.build(k2_info, k2, sel2.d_dev, sel2.n, false, &dup, s))) return rc;
+    if (fused_semi) { // a set: a key that occurs twice is no error
+      if ((rc = set2_bits.build(k2_info, k2, sel2.d_dev, sel2.n, false, s))) return rc;
+      HIP_TRY(hipStreamSynchronize(s)); // sel2 is released at the end of the block
     } else if ((rc = set2.build(k2, sel2.d_dev, sel2.n, &dup, s))) {
       return rc;
     }
@@ -195,17 +188,17 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     std::string err;
     if ((rc = lower_selection_in_set(resolve_d, dim->filters, dim->n_filters, dim_fk_field, &sel_plan, &err))) return set_error(rc, err);
     const KeySetView view{(const uint64_t *)set2_bits.bits.p, set2_bits.kmin, set2_bits.span};
-    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view))) return rc;
+    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, true))) return rc; // the bit test gathers: evaluate it once
   } else if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) {
     return rc;
   }
   n_dim = seld.n;
   d_dim_rows = seld.d_dev;
   if (t2 && !fused_semi && seld.n) {
-    DB flags, offs;
+    DB flags, offs, scan_tmp;
     if ((rc = flags.alloc(seld.n * 8)) || (rc = offs.alloc((seld.n + 1) * 8))) return rc;
     HIP_TRY(hj_launch_semi_flags(fk, seld.d_dev, seld.n, k2, (const unsigned long long *)set2.owner.p, set2.cap - 1, (uint64_t *)flags.p, s));
-    if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, seld.n, s))) return rc;
+    if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, seld.n, scan_tmp, s))) return rc;
     uint64_t last_off = 0, last_flag = 0;
     HIP_TRY(hipMemcpyAsync(&last_off, (uint64_t *)offs.p + seld.n - 1, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&last_flag, (uint64_t *)flags.p + seld.n - 1, 8, hipMemcpyDeviceToHost, s));
@@ -241,8 +234,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   DirectTable dt;
   DB slot_group;
   bool dup = false;
-  if (direct) {
-    if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, &dup, s))) return rc;
+  if (direct) { // launches only; the duplicate flag is read with the pair count below
+    if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, s))) return rc;
   } else {
     if ((rc = ht.build(kd, d_dim_rows, n_dim, &dup, s))) return rc;
   }
@@ -300,8 +293,13 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   p.aux_out32 = (uint32_t *)st_slot.p;
   p.aux_out = (uint64_t *)st_val.p;
   if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
-  if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, s))) return rc;
-  HIP_TRY(hipMemcpy(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost));
+  DB scan_tmp;
+  if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
+  uint32_t dup_keys = 0;
+  HIP_TRY(hipMemcpyAsync(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, s));
+  if (direct) HIP_TRY(hipMemcpyAsync(&dup_keys, dt.flag.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
   if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
   DB e_group, e_val;
@@ -317,10 +315,12 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   HIP_TRY(hj_launch_run_sums((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, (uint32_t *)multi.p, s));
   uint32_t multi_run = 0;
   HIP_TRY(hipMemcpyAsync(&multi_run, multi.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
   HIP_TRY(hipStreamSynchronize(s));
   if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
     std::swap(s_group.p, e_group.p); // a group's pairs are contiguous and in row order: all the later phases need
     std::swap(s_val.p, e_val.p);
+    return LLKV_OK;
   } else {
     uint32_t bits = 1;
     while ((1ull << bits) < n_dim) ++bits;
@@ -332,10 +332,9 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
     HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
+    HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s)); // tmp is released at the end of the block
   }
-  HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
-  HIP_TRY(hipStreamSynchronize(s));
   return LLKV_OK;
 }
 
@@ -351,7 +350,8 @@ int JoinAgg::straddlers() {
   if ((rc = flags.alloc((n_pairs + 1) * 8)) || (rc = offs.alloc((n_pairs + 1) * 8))) return rc;
   HIP_TRY(hipMemsetAsync(flags.p, 0, (n_pairs + 1) * 8, s));
   HIP_TRY(hj_launch_straddler_flags((const uint32_t *)s_group.p, n_pairs, (const uint64_t *)cnts.p, (const int64_t *)gcnts.p, (uint64_t *)flags.p, s));
-  if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, n_pairs + 1, s))) return rc;
+  DB scan_tmp;
+  if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, n_pairs + 1, scan_tmp, s))) return rc;
   uint64_t n = 0;
   HIP_TRY(hipMemcpy(&n, (uint64_t *)offs.p + n_pairs, 8, hipMemcpyDeviceToHost));
   if (n == 0) return LLKV_OK;
@@ -400,22 +400,23 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   // that reach the bound go to the host, which orders them exactly (sum DESC, payload[0], dim row).  More than kCap
   // of them (many equal sums) falls back to the sort below.
   if (!std::getenv("LLKV_HIP_TOPK_SORT") && limit <= 1024) {
-    constexpr uint32_t kCap = 2048;
-    DB best, state, groups_d, recs;
-    if ((rc = best.alloc(1024 * 8)) || (rc = state.alloc(24)) || (rc = groups_d.alloc(kCap * 4)) || (rc = recs.alloc((size_t)kCap * 64))) return rc;
-    HIP_TRY(hipMemsetAsync(state.p, 0, 24, s));
+    constexpr uint32_t kCap = 2048, kFirst = 256;
+    DB best, blk, groups_d; // blk = {threshold, candidates, groups, pad…}[8] then the candidate records
+    if ((rc = best.alloc(1024 * 8)) || (rc = blk.alloc(64 + (size_t)kCap * 64)) || (rc = groups_d.alloc(kCap * 4))) return rc;
+    uint64_t *state = (uint64_t *)blk.p, *recs = state + 8;
+    HIP_TRY(hipMemsetAsync(state, 0, 64, s));
     HIP_TRY(hj_launch_topk_select((const double *)sums.p, (const uint64_t *)report.p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p,
-                                  (uint64_t *)state.p, (uint32_t *)groups_d.p, (uint64_t *)recs.p, s));
-    uint64_t head[3] = {0, 0, 0}; // threshold, candidates, groups
-    HIP_TRY(hipMemcpyAsync(head, state.p, 24, hipMemcpyDeviceToHost, s));
+                                  state, (uint32_t *)groups_d.p, recs, s));
+    std::vector<uint64_t> hrec(8 + (size_t)kCap * 8); // one read-back: the head and the first records (all of them, usually)
+    HIP_TRY(hipMemcpyAsync(hrec.data(), blk.p, 64 + (size_t)kFirst * 64, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t *head = hrec.data();
     const uint32_t n_sel = (uint32_t)head[1];
     if (n_sel <= kCap) {
-      std::vector<uint64_t> hrec((size_t)n_sel * 8);
-      if (n_sel) HIP_TRY(hipMemcpy(hrec.data(), recs.p, (size_t)n_sel * 64, hipMemcpyDeviceToHost));
+      if (n_sel > kFirst) HIP_TRY(hipMemcpy(hrec.data() + 8 + (size_t)kFirst * 8, recs + (size_t)kFirst * 8, (size_t)(n_sel - kFirst) * 64, hipMemcpyDeviceToHost));
       std::vector<llkv_join_group_row> cand(n_sel);
       for (uint32_t i = 0; i < n_sel; ++i) {
-        const uint64_t *c = &hrec[(size_t)i * 8];
+        const uint64_t *c = &hrec[8 + (size_t)i * 8];
         llkv_join_group_row &g = cand[i];
         g.group_index = (uint32_t)c[0];
         g.key = (int64_t)c[1];

@@ -25,7 +25,11 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
   const uint32_t sub0 = wave * p.sub_rows;
   const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
   const uint64_t slot = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
-  uint64_t base = WRITE ? p.aux_in[slot] : 0;
+  // WRITE with aux_in == nullptr is the single-pass form (predicates that are expensive to evaluate twice): each
+  // (tile, wave) writes into its own sub_rows-sized stripe and reports its count; a compaction follows
+  const bool strided = WRITE && p.aux_in == nullptr;
+  uint64_t base = WRITE ? (strided ? slot * p.sub_rows : p.aux_in[slot]) : 0;
+  const uint64_t base0 = base;
   uint64_t count = 0;
   uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -50,9 +54,9 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
       count += __popcll(b0) + __popcll(b1);
     }
   }
-  if constexpr (!WRITE) {
+  if (!WRITE || strided) {
     const bool any_err = __ballot(perr != 0) != 0;
-    if (lane == 0) p.tile_partials[slot] = count + (any_err ? kPredErrorBit : 0);
+    if (lane == 0) p.tile_partials[slot] = (WRITE ? base - base0 : count) + (any_err ? kPredErrorBit : 0);
   }
 }
 

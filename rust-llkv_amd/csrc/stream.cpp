@@ -43,7 +43,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
 }
 
 // The selection kernels of an already lowered predicate (prepared statements keep the plan).
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set) {
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, bool single_pass) {
   int rc;
   std::string err;
   scratch_free(sel->d_ids); sel->d_ids = nullptr;
@@ -73,7 +73,17 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
     p.bm_min = key_set->kmin;
     p.bm_span = key_set->span;
   }
-  if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &p, sizeof p, stream))) return rc;
+  DeviceBuf stripe_ids, stripe_dev;
+  if (single_pass) {
+    const size_t stripe_bytes = (size_t)n_slots * p.sub_rows * 8;
+    if ((rc = stripe_ids.alloc(stripe_bytes)) || (rc = stripe_dev.alloc(stripe_bytes))) return rc;
+    p.aux_in = nullptr;
+    p.aux_out = (uint64_t *)stripe_ids.p;
+    p.aux_out2 = (uint64_t *)stripe_dev.p;
+    if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
+  } else if ((rc = jit_launch_raw(k.fn, ts->n_tiles, &p, sizeof p, stream))) {
+    return rc;
+  }
   HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, stream));
   uint64_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, stream));
@@ -84,10 +94,15 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
   sel->d_ids = (uint64_t *)scratch_alloc(total * 8);
   sel->d_dev = (uint64_t *)scratch_alloc(total * 8);
   if (!sel->d_ids || !sel->d_dev) return set_error(LLKV_INTERNAL, "device scratch allocation failed");
-  p.aux_in = (const uint64_t *)offsets.p;
-  p.aux_out = sel->d_ids;
-  p.aux_out2 = sel->d_dev;
-  if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
+  if (single_pass) {
+    HIP_TRY(hj_launch_compact_stripes2((const uint64_t *)stripe_ids.p, (const uint64_t *)stripe_dev.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p,
+                                       n_slots, p.sub_rows, sel->d_ids, sel->d_dev, stream));
+  } else {
+    p.aux_in = (const uint64_t *)offsets.p;
+    p.aux_out = sel->d_ids;
+    p.aux_out2 = sel->d_dev;
+    if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(stream));
   return LLKV_OK;
 }
