@@ -353,6 +353,34 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
   return LLKV_OK;
 }
 
+// ---- Readback ---------------------------------------------------------------------
+namespace {
+struct PinnedSlab {
+  void *p = nullptr;
+  ~PinnedSlab() { if (p) (void)hipHostFree(p); }
+};
+thread_local PinnedSlab t_readback;
+} // namespace
+
+int Readback::add(void *host_dst, const void *device_src, size_t bytes, hipStream_t s) {
+  if (!t_readback.p) HIP_TRY(hipHostMalloc(&t_readback.p, kBytes, hipHostMallocDefault));
+  const size_t off = (used + 7) & ~(size_t)7;
+  if (n == 8 || off + bytes > kBytes) return set_error(LLKV_INTERNAL, "read-back buffer exhausted");
+  HIP_TRY(hipMemcpyAsync((char *)t_readback.p + off, device_src, bytes, hipMemcpyDeviceToHost, s));
+  items[n++] = {host_dst, off, bytes};
+  used = off + bytes;
+  stream = s;
+  return LLKV_OK;
+}
+
+int Readback::wait() {
+  if (n) HIP_TRY(hipStreamSynchronize(stream));
+  for (int i = 0; i < n; ++i) std::memcpy(items[i].dst, (const char *)t_readback.p + items[i].off, items[i].bytes);
+  n = 0;
+  used = 0;
+  return LLKV_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // Query
 // ---------------------------------------------------------------------------------

@@ -296,9 +296,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   DB scan_tmp;
   if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
   uint32_t dup_keys = 0;
-  HIP_TRY(hipMemcpyAsync(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, s));
-  if (direct) HIP_TRY(hipMemcpyAsync(&dup_keys, dt.flag.p, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  Readback rb;
+  if ((rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (direct && (rc = rb.add(&dup_keys, dt.flag.p, 4, s))) || (rc = rb.wait())) return rc;
   if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
   if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
@@ -314,9 +313,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   HIP_TRY(hipMemsetAsync(multi.p, 0, 4, s));
   HIP_TRY(hj_launch_run_sums((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, (uint32_t *)multi.p, s));
   uint32_t multi_run = 0;
-  HIP_TRY(hipMemcpyAsync(&multi_run, multi.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
-  HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = rb.add(&multi_run, multi.p, 4, s)) || (rc = rb.wait())) return rc;
   if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
     std::swap(s_group.p, e_group.p); // a group's pairs are contiguous and in row order: all the later phases need
     std::swap(s_val.p, e_val.p);
@@ -353,7 +351,8 @@ int JoinAgg::straddlers() {
   DB scan_tmp;
   if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, n_pairs + 1, scan_tmp, s))) return rc;
   uint64_t n = 0;
-  HIP_TRY(hipMemcpy(&n, (uint64_t *)offs.p + n_pairs, 8, hipMemcpyDeviceToHost));
+  Readback rb;
+  if ((rc = rb.add(&n, (uint64_t *)offs.p + n_pairs, 8, s)) || (rc = rb.wait())) return rc;
   if (n == 0) return LLKV_OK;
   if (n > (64ull << 20)) return set_error(LLKV_UNSUPPORTED, "fact rows of groups that straddle ranks exceed 64 Mi: the fact table is not clustered by the join key");
   DB og, ov;
@@ -408,8 +407,8 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     HIP_TRY(hj_launch_topk_select((const double *)sums.p, (const uint64_t *)report.p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p,
                                   state, (uint32_t *)groups_d.p, recs, s));
     std::vector<uint64_t> hrec(8 + (size_t)kCap * 8); // one read-back: the head and the first records (all of them, usually)
-    HIP_TRY(hipMemcpyAsync(hrec.data(), blk.p, 64 + (size_t)kFirst * 64, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    Readback rb;
+    if ((rc = rb.add(hrec.data(), blk.p, 64 + (size_t)kFirst * 64, s)) || (rc = rb.wait())) return rc;
     const uint64_t *head = hrec.data();
     const uint32_t n_sel = (uint32_t)head[1];
     if (n_sel <= kCap) {

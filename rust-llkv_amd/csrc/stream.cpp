@@ -86,8 +86,8 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
   }
   HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, stream));
   uint64_t total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + n_slots, 8, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
+  Readback rb;
+  if ((rc = rb.add(&total, (uint64_t *)offsets.p + n_slots, 8, stream)) || (rc = rb.wait())) return rc;
   if (total >= kPredErrorBit) return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison");
   sel->n = total;
   if (total == 0) return LLKV_OK;
