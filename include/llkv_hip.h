@@ -522,7 +522,9 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
                                  const llkv_scan_options *options, llkv_on_batch on_batch,
                                  void *user);
 /* `StorageTable::filter_row_ids` (storage.rs:34-37): matching row ids, ascending.
- * `*out_row_ids` is malloc'd; release with llkv_hip_free.                    */
+ * `*out_row_ids` belongs to the library (large vectors live in recycled pinned
+ * host memory, written by the device at PCIe speed); release it with
+ * llkv_hip_free, never with free().                                          */
 llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filter *filters,
                                     uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                                     uint64_t **out_row_ids, uint64_t *out_len);

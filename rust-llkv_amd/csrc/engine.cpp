@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <unordered_map>
 
 namespace llkv {
 
@@ -256,8 +257,9 @@ struct StagerPool {
     }
     ready = false;
   }
-  // copies every piece and returns when all of them are in HBM
-  int run(const std::vector<StagePiece> &pieces) {
+  // copies every piece and returns when all of them have arrived: host → HBM, or (`to_host`) HBM → pageable
+  // host memory, where d_dst / h_src swap roles (d_dst = device source, h_src = host destination)
+  int run(const std::vector<StagePiece> &pieces, bool to_host = false) {
     std::lock_guard<std::mutex> lk(mu);
     int rc = init();
     if (rc) return rc;
@@ -281,13 +283,29 @@ struct StagerPool {
       };
       if (r) { failed = r; std::lock_guard<std::mutex> g(message_mu); message = g_last_error; return; }
       hipError_t e;
+      const StagePiece *pending[kDepth] = {}; // to_host: the segment whose bytes wait in pinned[k]
+      auto drain = [&](int k) -> bool {
+        if (!pending[k]) return true;
+        if ((e = hipEventSynchronize(l.done[k])) != hipSuccess) { fail(e); return false; }
+        std::memcpy(const_cast<void *>(pending[k]->h_src), l.pinned[k], pending[k]->bytes);
+        pending[k] = nullptr;
+        return true;
+      };
       for (size_t i; failed == LLKV_OK && (i = next.fetch_add(1)) < seg.size();) {
-        if ((e = hipEventSynchronize(l.done[l.cur])) != hipSuccess) return fail(e);
-        std::memcpy(l.pinned[l.cur], seg[i].h_src, seg[i].bytes);
-        if ((e = hipMemcpyAsync(seg[i].d_dst, l.pinned[l.cur], seg[i].bytes, hipMemcpyHostToDevice, l.stream)) != hipSuccess) return fail(e);
+        if (to_host) {
+          if (!drain(l.cur)) return;
+          if ((e = hipMemcpyAsync(l.pinned[l.cur], seg[i].d_dst, seg[i].bytes, hipMemcpyDeviceToHost, l.stream)) != hipSuccess) return fail(e);
+          pending[l.cur] = &seg[i];
+        } else {
+          if ((e = hipEventSynchronize(l.done[l.cur])) != hipSuccess) return fail(e);
+          std::memcpy(l.pinned[l.cur], seg[i].h_src, seg[i].bytes);
+          if ((e = hipMemcpyAsync(seg[i].d_dst, l.pinned[l.cur], seg[i].bytes, hipMemcpyHostToDevice, l.stream)) != hipSuccess) return fail(e);
+        }
         if ((e = hipEventRecord(l.done[l.cur], l.stream)) != hipSuccess) return fail(e);
         l.cur = (l.cur + 1) % kDepth;
       }
+      for (int k = 0; k < kDepth; ++k) // oldest first
+        if (!drain((l.cur + k) % kDepth)) return;
       if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
     };
     const int n_threads = (int)std::min<size_t>(kLanes, (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
@@ -295,13 +313,21 @@ struct StagerPool {
     for (int k = 1; k < n_threads; ++k) threads.emplace_back(work, std::ref(lanes[k]));
     work(lanes[0]);
     for (std::thread &t : threads) t.join();
-    staged_bytes += total;
-    staged_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!to_host) {
+      staged_bytes += total;
+      staged_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     if (failed != LLKV_OK) return set_error(failed, message);
     return LLKV_OK;
   }
 };
 static StagerPool g_stager;
+
+// large results (row-id vectors) leave through the same lanes: HBM → pinned ring → the caller's pageable buffer
+int fetch_to_host(void *h_dst, const void *d_src, size_t bytes) {
+  if (bytes == 0) return LLKV_OK;
+  return g_stager.run({{const_cast<void *>(d_src), h_dst, bytes}}, true);
+}
 
 // host-side preparation of a column image (dictionary coding, bitmap expansion, Decimal128 narrowing) runs chunk
 // by chunk on a few threads; fn(chunk) returns a status, the first failure wins
@@ -351,6 +377,85 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
     c.info.max_i = mm[1];
   }
   return LLKV_OK;
+}
+
+// ---- pinned host memory cache -------------------------------------------------------
+namespace {
+struct PinnedCache {
+  std::mutex mu;
+  std::vector<std::pair<void *, size_t>> free_blocks;
+  size_t cached = 0;
+  static constexpr size_t kMaxCached = 1ull << 30;
+} g_pinned;
+} // namespace
+
+void *pinned_acquire(size_t *bytes) {
+  size_t want = 4096;
+  while (want < *bytes) want <<= 1; // power-of-two classes: a block fits every later request of its class
+  *bytes = want;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    for (size_t i = 0; i < g_pinned.free_blocks.size(); ++i)
+      if (g_pinned.free_blocks[i].second == want) {
+        void *p = g_pinned.free_blocks[i].first;
+        g_pinned.free_blocks.erase(g_pinned.free_blocks.begin() + (long)i);
+        g_pinned.cached -= want;
+        return p;
+      }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void pinned_release(void *p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    if (g_pinned.cached + bytes <= PinnedCache::kMaxCached) {
+      g_pinned.free_blocks.emplace_back(p, bytes);
+      g_pinned.cached += bytes;
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+
+void pinned_release_all() {
+  std::lock_guard<std::mutex> lk(g_pinned.mu);
+  for (auto &b : g_pinned.free_blocks) (void)hipHostFree(b.first);
+  g_pinned.free_blocks.clear();
+  g_pinned.cached = 0;
+}
+
+// ---- large results handed to the caller ------------------------------------------------
+// A fresh malloc of hundreds of MB is page-faulted in while it is filled (≈ 6 GB/s); results of that size are
+// handed out in recycled pinned blocks instead, which the device writes at PCIe speed.  llkv_hip_free tells the
+// two kinds apart through this registry.
+namespace {
+std::mutex g_results_mu;
+std::unordered_map<void *, size_t> g_results;
+} // namespace
+
+void *result_acquire(size_t bytes) {
+  size_t got = bytes;
+  void *p = pinned_acquire(&got);
+  if (!p) return nullptr;
+  std::lock_guard<std::mutex> lk(g_results_mu);
+  g_results.emplace(p, got);
+  return p;
+}
+
+bool result_release(void *p) {
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_results_mu);
+    auto it = g_results.find(p);
+    if (it == g_results.end()) return false;
+    bytes = it->second;
+    g_results.erase(it);
+  }
+  pinned_release(p, bytes);
+  return true;
 }
 
 // ---- Readback ---------------------------------------------------------------------
@@ -1028,13 +1133,16 @@ void llkv_hip_shutdown(void) {
   if (!g_ctx.ready) return;
   jit_shutdown();
   scratch_release_all();
+  pinned_release_all();
   g_stager.release();
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;
 }
 
-void llkv_hip_free(void *ptr) { std::free(ptr); }
+void llkv_hip_free(void *ptr) {
+  if (!result_release(ptr)) std::free(ptr);
+}
 
 // ---- tables -------------------------------------------------------------------------
 llkv_status llkv_hip_table_create(uint16_t table_id, const uint64_t *global_chunk_rows, uint32_t n_global_chunks,

@@ -212,6 +212,20 @@ struct Scratch { // RAII temporary
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// HBM → pageable host memory through the staging lanes (pinned rings, one copier thread each); the streams used are
+// the lanes' own: the data must be complete on the device before the call.
+int fetch_to_host(void *h_dst, const void *d_src, size_t bytes);
+
+// Recycled pinned host memory (engine.cpp): *bytes is rounded up to the block actually handed out.
+void *pinned_acquire(size_t *bytes);
+void pinned_release(void *p, size_t bytes);
+void pinned_release_all();
+
+// Result buffers of llkv_hip_free-able arrays: pinned (recycled) blocks for large ones; result_release returns false
+// for a pointer it did not hand out (a plain malloc).
+void *result_acquire(size_t bytes);
+bool result_release(void *p);
+
 // Small device → host read-backs (counts, flags, a few candidate records) through a pinned buffer of the calling
 // thread: a copy into pageable memory is staged by the runtime and costs ~25 µs more per call.
 //   Readback rb; rb.add(&n, d_n, 8); rb.add(&flag, d_flag, 4); rc = rb.wait(stream);

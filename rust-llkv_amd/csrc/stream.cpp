@@ -21,10 +21,17 @@ static constexpr uint32_t kRowStreamChunk = 65536; // ROW_STREAM_CHUNK_SIZE, llk
 static constexpr uint32_t kSelectTileRows = 8192;
 
 using DeviceBuf = Scratch;
+// Pinned host buffers are recycled: pinning memory costs far more than a selective scan (hundreds of µs per
+// buffer), so freed blocks wait in a small cache for the next stream.
 struct PinnedBuf {
   void *p = nullptr;
-  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-  int alloc(size_t bytes) { HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault)); return LLKV_OK; }
+  size_t bytes = 0;
+  ~PinnedBuf() { if (p) pinned_release(p, bytes); }
+  int alloc(size_t n) {
+    bytes = n ? n : 8;
+    p = pinned_acquire(&bytes);
+    return p ? LLKV_OK : set_error(LLKV_INTERNAL, "pinned host allocation of " + std::to_string(bytes) + " bytes failed");
+  }
 };
 
 int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
@@ -202,11 +209,18 @@ llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filt
   Selection sel;
   int rc = run_selection(reinterpret_cast<const Table *>(table), filters, n_filters, ops, n_ops, &sel);
   if (rc) return (llkv_status)rc;
-  uint64_t *ids = (uint64_t *)std::malloc(sel.n ? sel.n * 8 : 8);
+  const bool large = sel.n * 8 >= (1u << 20);
+  uint64_t *ids = (uint64_t *)(large ? result_acquire(sel.n * 8) : std::malloc(sel.n ? sel.n * 8 : 8));
   if (!ids) return (llkv_status)set_error(LLKV_INTERNAL, "out of memory");
-  if (sel.n && hipMemcpy(ids, sel.d_ids, sel.n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+  // run_selection has synchronised: the ids are complete on the device
+  if (large) {
+    if (hipMemcpy(ids, sel.d_ids, sel.n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      result_release(ids);
+      return (llkv_status)set_error(LLKV_INTERNAL, "copy of row ids failed");
+    }
+  } else if ((rc = fetch_to_host(ids, sel.d_ids, sel.n * 8))) {
     std::free(ids);
-    return (llkv_status)set_error(LLKV_INTERNAL, "copy of row ids failed");
+    return (llkv_status)rc;
   }
   *out_row_ids = ids;
   *out_len = sel.n;
@@ -249,7 +263,11 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   hipStream_t stream = g_ctx.stream;
   const uint32_t n_out = (uint32_t)proj.out_dtypes.size();
   const bool with_ids = options && options->include_row_ids;
-  // two window buffers: while the host consumes window w, the device fills w + 1
+  // Two buffers of up to kSuper reference windows each: one gather launch and one copy per output fill a buffer
+  // (65 536-row launches and 512 KB copies leave the PCIe link half idle), the host then hands out its windows
+  // one by one — same batches, same order — while the device fills the other buffer.
+  constexpr uint64_t kSuper = 16;
+  const uint64_t buf_rows = std::min<uint64_t>(kSuper * kRowStreamChunk, (sel.n + kRowStreamChunk - 1) / kRowStreamChunk * kRowStreamChunk);
   struct Win {
     DeviceBuf d[kMaxOuts], d_valid[kMaxOuts];
     PinnedBuf h[kMaxOuts], h_valid[kMaxOuts], h_ids;
@@ -262,11 +280,11 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   if (hipMemsetAsync(d_err.p, 0, 4, stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "memset failed");
   for (auto &w : win) {
     for (uint32_t o = 0; o < n_out; ++o) {
-      const size_t bytes = (size_t)kRowStreamChunk * dtype_out_width(proj.out_dtypes[o]);
+      const size_t bytes = (size_t)buf_rows * dtype_out_width(proj.out_dtypes[o]);
       if ((rc = w.d[o].alloc(bytes)) || (rc = w.h[o].alloc(bytes))) return (llkv_status)rc;
-      if (proj.out_nullable[o] && ((rc = w.d_valid[o].alloc(kRowStreamChunk / 8)) || (rc = w.h_valid[o].alloc(kRowStreamChunk / 8)))) return (llkv_status)rc;
+      if (proj.out_nullable[o] && ((rc = w.d_valid[o].alloc(buf_rows / 8)) || (rc = w.h_valid[o].alloc(buf_rows / 8)))) return (llkv_status)rc;
     }
-    if (with_ids && (rc = w.h_ids.alloc((size_t)kRowStreamChunk * 8))) return (llkv_status)rc;
+    if (with_ids && (rc = w.h_ids.alloc((size_t)buf_rows * 8))) return (llkv_status)rc;
     if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "event create failed");
   }
   ProjParams pp;
@@ -277,7 +295,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   pp.error_flag = (uint32_t *)d_err.p;
 
   auto enqueue = [&](uint64_t w0, Win &w) -> int {
-    w.n = (uint32_t)std::min<uint64_t>(kRowStreamChunk, sel.n - w0);
+    w.n = (uint32_t)std::min<uint64_t>(buf_rows, sel.n - w0);
     ProjParams q = pp;
     q.dev_rows = sel.d_dev + w0;
     q.n = w.n;
@@ -302,30 +320,32 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
 
   int cur = 0;
   if ((rc = enqueue(0, win[0]))) return (llkv_status)rc;
-  for (uint64_t w0 = 0; w0 < sel.n; w0 += kRowStreamChunk) {
-    const uint64_t next = w0 + kRowStreamChunk;
+  for (uint64_t w0 = 0; w0 < sel.n; w0 += buf_rows) {
+    const uint64_t next = w0 + buf_rows;
     if (next < sel.n && (rc = enqueue(next, win[cur ^ 1]))) return (llkv_status)rc;
     Win &w = win[cur];
     if (hipEventSynchronize(w.done) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "window copy failed");
-    llkv_column_view cols[kMaxOuts];
-    for (uint32_t o = 0; o < n_out; ++o) {
-      cols[o].dtype = proj.out_dtypes[o];
-      cols[o].values = w.h[o].p;
-      cols[o].validity = proj.out_nullable[o] ? (const uint8_t *)w.h_valid[o].p : nullptr;
-      cols[o].dictionary = dicts[o].empty() ? nullptr : dicts[o].data();
-      cols[o].precision = cols[o].scale = 0;
-      if (proj.out_dtypes[o] == LLKV_DT_DECIMAL128 && proj.out_fields[o] >= 0) {
-        const ColumnInfo &ci = t->cols.at((uint32_t)proj.out_fields[o]).info;
-        cols[o].precision = ci.precision;
-        cols[o].scale = ci.scale;
+    for (uint64_t r0 = 0; r0 < w.n; r0 += kRowStreamChunk) { // the reference's windows, one callback each
+      llkv_column_view cols[kMaxOuts];
+      for (uint32_t o = 0; o < n_out; ++o) {
+        cols[o].dtype = proj.out_dtypes[o];
+        cols[o].values = (const char *)w.h[o].p + r0 * dtype_out_width(proj.out_dtypes[o]);
+        cols[o].validity = proj.out_nullable[o] ? (const uint8_t *)w.h_valid[o].p + r0 / 8 : nullptr;
+        cols[o].dictionary = dicts[o].empty() ? nullptr : dicts[o].data();
+        cols[o].precision = cols[o].scale = 0;
+        if (proj.out_dtypes[o] == LLKV_DT_DECIMAL128 && proj.out_fields[o] >= 0) {
+          const ColumnInfo &ci = t->cols.at((uint32_t)proj.out_fields[o]).info;
+          cols[o].precision = ci.precision;
+          cols[o].scale = ci.scale;
+        }
       }
+      llkv_batch_view b;
+      b.num_rows = (uint32_t)std::min<uint64_t>(kRowStreamChunk, w.n - r0);
+      b.num_columns = n_out;
+      b.columns = cols;
+      b.row_ids = with_ids ? (const uint64_t *)w.h_ids.p + r0 : nullptr;
+      on_batch(&b, user); // calling thread, ascending row-id order
     }
-    llkv_batch_view b;
-    b.num_rows = w.n;
-    b.num_columns = n_out;
-    b.columns = cols;
-    b.row_ids = with_ids ? (const uint64_t *)w.h_ids.p : nullptr;
-    on_batch(&b, user); // calling thread, ascending row-id order
     cur ^= 1;
   }
   uint32_t errflag = 0;

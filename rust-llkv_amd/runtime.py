@@ -404,19 +404,25 @@ def dense_row_runs(chunks: Sequence) -> tuple:
     return bool(dense.value), first.value
 
 
-def filter_row_ids(table: HipTable, predicate) -> np.ndarray:
-    """StorageTable::filter_row_ids (llkv-executor/src/types/storage.rs:34-37): ascending row ids."""
+def filter_row_ids(table: HipTable, predicate, count_only: bool = False):
+    """StorageTable::filter_row_ids (llkv-executor/src/types/storage.rs:34-37): ascending row ids
+    (``count_only``: just how many — the ids still reach host memory, but are not copied into numpy)."""
     p = CPlan(predicate)
     out, n = C.POINTER(C.c_uint64)(), C.c_uint64()
     check(lib().llkv_hip_filter_row_ids(table.handle, p.filters, p.n_filters, p.ops, p.n_ops, C.byref(out), C.byref(n)))
+    if count_only:
+        lib().llkv_hip_free(out)
+        return n.value
     res = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
     lib().llkv_hip_free(out)
     return res
 
 
-def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False, order=None):
+def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False, order=None, consume=None):
     """StorageTable::scan_stream: returns the list of batches [(columns, row_ids)], each column a list of
-    Python values.  ``projections``: field ids (ScanProjection::Column) or ScalarExpr (::Computed)."""
+    Python values.  ``projections``: field ids (ScanProjection::Column) or ScalarExpr (::Computed).
+    ``consume``: called with every raw ``llkv_batch_view`` instead (buffers valid during the call only); nothing
+    is converted or returned."""
     keep: list = []
     projs = (abi.CProjection * max(1, len(projections)))()
     for i, pr in enumerate(projections):
@@ -431,6 +437,9 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
 
     def on_batch(bp, _user):
         b = bp.contents
+        if consume is not None:
+            consume(b)
+            return
         n = int(b.num_rows)
         cols = []
         for ci in range(b.num_columns):
