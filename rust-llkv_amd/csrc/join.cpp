@@ -7,6 +7,8 @@
 #include "engine.hpp"
 #include "join.hpp"
 
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -32,22 +34,24 @@ struct DBuf {
     return LLKV_OK;
   }
 };
-struct HBuf {
+struct HBuf { // pinned, recycled (engine.cpp: pinned_acquire)
   void *p = nullptr;
   size_t cap = 0;
-  ~HBuf() { if (p) (void)hipHostFree(p); }
+  ~HBuf() { if (p) pinned_release(p, cap); }
   int ensure(size_t bytes) {
     if (bytes <= cap) return LLKV_OK;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
-    cap = bytes;
+    if (p) pinned_release(p, cap);
+    cap = bytes ? bytes : 8;
+    p = pinned_acquire(&cap);
+    if (!p) { cap = 0; return set_error(LLKV_INTERNAL, "pinned host allocation failed"); }
     return LLKV_OK;
   }
 };
 
 constexpr uint32_t kJoinTileRows = 8192;
-constexpr uint32_t kWindowTiles = 8; // 65 536 probe rows per window = one reference probe batch
+// probe rows per device step: 32 reference scan batches.  (One batch per step — 8 workgroups, two synchronisations,
+// three small copies — ran at 0.13 G probe rows/s.)
+constexpr uint32_t kWindowTiles = 256;
 
 bool fast_key_type(int32_t dt) { return dt == LLKV_DT_INT32 || dt == LLKV_DT_INT64 || dt == LLKV_DT_UINT32 || dt == LLKV_DT_UINT64; }
 // the types extract_key_value (hash_join.rs:405-505) turns into a KeyValue; any other key type fails there
@@ -185,6 +189,16 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   }
 
   hipStream_t s = g_ctx.stream;
+  // LLKV_HIP_TRACE=1: phase times on stderr
+  const bool trace = std::getenv("LLKV_HIP_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  double t_acc[4] = {0, 0, 0, 0}; // probe steps: count+scan, write+copy, cuts+callbacks
+  auto lap = [&]() {
+    const auto now = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - t_last).count();
+    t_last = now;
+    return ms;
+  };
   const TileSet *tr = nullptr, *tl = nullptr;
   if ((rc = get_tileset(*right, kJoinTileRows, &tr)) || (rc = get_tileset(*left, kJoinTileRows, &tl))) return rc;
 
@@ -222,19 +236,20 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     HIP_TRY(hj_launch_segments((const uint32_t *)slot_sorted.p, (uint32_t)n_build, (uint32_t *)seg_start.p, (uint32_t *)seg_count.p, s));
   }
 
+  if (trace) { (void)hipStreamSynchronize(s); std::fprintf(stderr, "[llkv join] build %9.3f ms (%llu rows)\n", lap(), (unsigned long long)n_build); }
   // ---- probe (left), window by window ----
-  const uint32_t win_pos = kWindowTiles * kJoinTileRows;
-  DBuf counts, mslot, offsets, out_l, out_r;
-  HBuf h_l, h_r, h_off;
-  if ((rc = counts.ensure((size_t)win_pos * 8)) || (rc = mslot.ensure((size_t)win_pos * 4)) || (rc = offsets.ensure((size_t)(win_pos + 1) * 8)) ||
-      (rc = h_off.ensure((size_t)(win_pos + 1) * 8)))
-    return rc;
+  const uint32_t win_pos = std::min(kWindowTiles, std::max(1u, tl->n_tiles)) * kJoinTileRows;
+  DBuf counts, mslot, offsets, out_l, out_r, scan_tmp;
+  HBuf h_l, h_r;
+  if ((rc = counts.ensure((size_t)(win_pos + 1) * 8)) || (rc = mslot.ensure((size_t)win_pos * 4)) || (rc = offsets.ensure((size_t)(win_pos + 1) * 8))) return rc;
   const bool left_only = jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI;
   // Batches.  The reference probes one scan batch (65 536 rows of the left table) at a time and flushes after the
   // probe row that brings the pending pairs to ≥ batch_size, and at the end of the scan batch (fast path,
   // hash_join.rs:1141-1213); the generic path first cuts every scan batch into slices of batch_size probe rows
-  // and applies the same rule inside each slice (:228-246,509-565).  Device windows are 8 tiles; when chunk sizes
-  // leave ragged tiles a reference batch can span two device windows, its head then waits in `pend_*`.
+  // and applies the same rule inside each slice (:228-246,509-565).  A device step covers many scan batches; the
+  // host finds the cuts in the left-row column of the pairs (ascending): a forced cut before the first pair of a
+  // row ≥ the boundary, a size cut after the last pair of the row that holds the batch_size-th pair.  Pairs after the
+  // last cut of a step wait in `pend_*` for the next one.
   constexpr uint64_t kRefWindow = 65536;
   std::vector<TileDesc> ltiles;
   {
@@ -256,17 +271,23 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     p.join_type = jt;
     p.counts = (uint64_t *)counts.p; p.match_slot = (uint32_t *)mslot.p;
     HIP_TRY(hj_launch_probe_count(p, s));
-    HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, npos, s));
+    // counts[npos] = 0, so offsets[npos] is the total (the one-workgroup scan of the selection kernels is too slow
+    // for millions of positions)
+    HIP_TRY(hipMemsetAsync((uint64_t *)counts.p + npos, 0, 8, s));
+    {
+      size_t tb = 0;
+      HIP_TRY(hj_exclusive_scan_u64(nullptr, &tb, (const uint64_t *)counts.p, (uint64_t *)offsets.p, (uint64_t)npos + 1, s));
+      if ((rc = scan_tmp.ensure(tb))) return rc;
+      HIP_TRY(hj_exclusive_scan_u64(scan_tmp.p, &tb, (const uint64_t *)counts.p, (uint64_t *)offsets.p, (uint64_t)npos + 1, s));
+    }
     uint64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, (uint64_t *)offsets.p + npos, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    Readback rb;
+    if ((rc = rb.add(&total, (uint64_t *)offsets.p + npos, 8, s)) || (rc = rb.wait())) return rc;
+    if (trace) t_acc[0] += lap();
     if (total == 0 && pend_l.empty()) continue;
     uint64_t wrows = 0;
     for (uint32_t t = 0; t < nt; ++t) wrows += ltiles[t0 + t].rows;
-    const uint64_t first_logical = ltiles[t0].logical_row;
-    const bool whole_batch = pend_l.empty() && first_logical % kRefWindow == 0 &&
-                             (wrows == kRefWindow || first_logical + wrows == left_end) && (fast || batch_size >= wrows);
-    const bool walk = !(whole_batch && total < batch_size);
+    const uint64_t L0 = ltiles[t0].logical_row, L1 = L0 + wrows; // the rows of a rank are contiguous
     if (total) {
       if ((rc = out_l.ensure(total * 8)) || (rc = out_r.ensure(total * 8)) || (rc = h_l.ensure(total * 8)) || (rc = h_r.ensure(total * 8))) return rc;
       p.offsets = (const uint64_t *)offsets.p;
@@ -274,16 +295,11 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
       HIP_TRY(hj_launch_probe_write(p, s));
       HIP_TRY(hipMemcpyAsync(h_l.p, out_l.p, total * 8, hipMemcpyDeviceToHost, s));
       if (!left_only) HIP_TRY(hipMemcpyAsync(h_r.p, out_r.p, total * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
     }
-    if (walk) HIP_TRY(hipMemcpyAsync(h_off.p, offsets.p, (size_t)(npos + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (trace) t_acc[1] += lap();
     const uint64_t *hl = (const uint64_t *)h_l.p, *hr = left_only ? nullptr : (const uint64_t *)h_r.p;
-    if (!walk) {
-      on_batch(hl, hr, total, user);
-      continue;
-    }
-    const uint64_t *off = (const uint64_t *)h_off.p;
-    uint64_t start = 0;
+    uint64_t start = 0; // pairs of this step already delivered
     auto deliver = [&](uint64_t end) {
       if (pend_l.empty()) {
         on_batch(hl + start, hr ? hr + start : nullptr, end - start, user);
@@ -296,22 +312,27 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
       }
       start = end;
     };
-    for (uint32_t t = 0; t < nt; ++t) {
-      const TileDesc &td = ltiles[t0 + t];
-      for (uint32_t r = 0; r < td.rows; ++r) {
-        const uint64_t logical = td.logical_row + r, in_win = logical % kRefWindow;
-        const uint64_t end = off[(uint64_t)t * kJoinTileRows + r + 1];
-        const uint64_t acc = pend_l.size() + (end - start);
-        if (acc == 0) continue;
-        const bool boundary = in_win + 1 == kRefWindow || logical + 1 == left_end || (!fast && (in_win + 1) % batch_size == 0);
-        if (acc >= batch_size || boundary) deliver(end);
+    for (uint64_t row = L0; row < L1;) {
+      // the next forced cut: end of the reference scan batch, of the slice (generic path), of the table
+      const uint64_t in_win = row % kRefWindow;
+      uint64_t b = row - in_win + kRefWindow;
+      if (!fast) b = std::min(b, row - in_win + (in_win / batch_size + 1) * batch_size);
+      b = std::min(b, left_end);
+      const uint64_t seg_end = (uint64_t)(std::lower_bound(hl + start, hl + total, b) - hl); // first pair of a row ≥ b
+      while (pend_l.size() + (seg_end - start) >= batch_size) {
+        const uint64_t j = start + (batch_size - pend_l.size()) - 1; // the pair that fills the batch …
+        deliver((uint64_t)(std::upper_bound(hl + j, hl + seg_end, hl[j]) - hl)); // … and the rest of its probe row
       }
+      if (b <= L1 && pend_l.size() + (seg_end - start) > 0) deliver(seg_end);
+      row = b;
     }
-    if (total > start) { // the reference batch goes on in the next device window
+    if (total > start) { // the reference batch goes on in the next step
       pend_l.insert(pend_l.end(), hl + start, hl + total);
       if (hr) pend_r.insert(pend_r.end(), hr + start, hr + total);
     }
+    if (trace) t_acc[2] += lap();
   }
+  if (trace) std::fprintf(stderr, "[llkv join] probe: count+scan %9.3f ms, write+copy %9.3f ms, cuts+callbacks %9.3f ms\n", t_acc[0], t_acc[1], t_acc[2]);
   if (!pend_l.empty()) on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
   return LLKV_OK;
 }

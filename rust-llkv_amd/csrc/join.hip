@@ -168,9 +168,12 @@ hipError_t hj_launch_cross_pairs(uint64_t l0, uint64_t ln, uint64_t r0, uint64_t
 }
 
 // JOIN types: 0 inner, 1 left, 4 semi, 5 anti (include/llkv_hip.h)
+// grid = (tiles, kProbeSplit): the workgroups of one tile interleave its rows, so a window of a few hundred tiles
+// still fills the device (a probe is a chain of dependent random loads: parallelism is all that hides it)
+constexpr uint32_t kProbeSplit = 8;
 __global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
   const TileDesc td = p.tiles[blockIdx.x];
-  for (uint32_t r = threadIdx.x; r < p.tile_rows; r += blockDim.x) {
+  for (uint32_t r = blockIdx.y * blockDim.x + threadIdx.x; r < p.tile_rows; r += blockDim.x * gridDim.y) {
     const uint64_t pos = (uint64_t)blockIdx.x * p.tile_rows + r;
     uint64_t cnt = 0;
     uint32_t mslot = 0xFFFFFFFFu;
@@ -201,13 +204,13 @@ __global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
 }
 hipError_t hj_launch_probe_count(const ProbeParams &p, hipStream_t s) {
   if (p.n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_probe_count_kernel, dim3(p.n_tiles), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(hj_probe_count_kernel, dim3(p.n_tiles, kProbeSplit), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void hj_probe_write_kernel(ProbeParams p) {
   const TileDesc td = p.tiles[blockIdx.x];
-  for (uint32_t r = threadIdx.x; r < td.rows; r += blockDim.x) {
+  for (uint32_t r = blockIdx.y * blockDim.x + threadIdx.x; r < td.rows; r += blockDim.x * gridDim.y) {
     const uint64_t pos = (uint64_t)blockIdx.x * p.tile_rows + r;
     const uint64_t cnt = p.counts[pos];
     if (cnt == 0) continue;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void hj_probe_write_kernel(ProbeParams p) {
 }
 hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s) {
   if (p.n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_probe_write_kernel, dim3(p.n_tiles), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(hj_probe_write_kernel, dim3(p.n_tiles, kProbeSplit), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

@@ -466,9 +466,10 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
     return batches
 
 
-def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN_INNER, batch_size: int = 8192):
+def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN_INNER, batch_size: int = 8192, consume=None):
     """TableJoinExt::join_stream (llkv-join/src/lib.rs:240-282): list of batches (left_rows, right_rows|None);
-    a right row of 2**64-1 is the NULL padding of a LEFT join."""
+    a right row of 2**64-1 is the NULL padding of a LEFT join.  ``consume(n_pairs)``: called per batch instead
+    (nothing is converted or returned)."""
     ck = (abi.CJoinKey * max(1, len(keys)))()
     for i, k in enumerate(keys):
         ck[i].left_field, ck[i].right_field = k[0], k[1]
@@ -477,6 +478,9 @@ def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN
     batches = []
 
     def on_batch(pl, pr, n, _u):
+        if consume is not None:
+            consume(n)
+            return
         l = np.ctypeslib.as_array(pl, shape=(n,)).tolist()
         r = np.ctypeslib.as_array(pr, shape=(n,)).tolist() if pr else None
         batches.append((l, r))
