@@ -252,8 +252,10 @@ int SortedGroupBy::run(LazyGroups *out) {
   p.out = lanes_d.as<uint64_t>();
   p.error_flag = err_d.as<uint32_t>();
   p.n_groups = n_groups;
-  const uint64_t waves_per_block = kBlock / 64;
-  if ((rc = jit_launch_raw(red_kernel.fn, (uint32_t)((n_groups + waves_per_block - 1) / waves_per_block), &p, sizeof p, s))) return rc;
+  // lanes per group: a wave, or 8 lanes when the groups average fewer than 16 rows
+  const bool narrow = n / n_groups < 16;
+  const uint64_t groups_per_block = kBlock / (narrow ? 8 : 64);
+  if ((rc = jit_launch_raw(narrow ? red_kernel.fn2 : red_kernel.fn, (uint32_t)((n_groups + groups_per_block - 1) / groups_per_block), &p, sizeof p, s))) return rc;
   HIP_TRY(hj_launch_group_keys(ks, sel.d_dev, perm, seg.as<uint64_t>(), order, n_groups, kv_d.as<int64_t>(), kvalid_d.as<uint8_t>(), s));
   mark("group reduce");
 

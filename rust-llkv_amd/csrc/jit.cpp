@@ -39,6 +39,7 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     break;
   case JitKind::Reduce:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ReduceParams p) { group_reduce_body<" + ts + ">(p); }\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_b(const ReduceParams p) { group_reduce_body<" + ts + ",8>(p); }\n";
     break;
   case JitKind::Emit:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { emit_body<" + ts + ", false>(p); }\n";
@@ -128,7 +129,7 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
   e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_a");
   if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  if (kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit) {
+  if (kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit || kind == JitKind::Reduce) {
     e = hipModuleGetFunction(&k.fn2, k.module, "llkv_jit_b");
     if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
   }

@@ -296,11 +296,13 @@ template <class CL, class AG> struct ReducePlan {
 };
 template <class P> constexpr int reduce_lane_op(int k) { return k == 0 ? OP_ADD_I64 : k == 1 ? OP_MIN_I64 : AggOps<typename P::AggT>::op(k - 2); }
 
-template <class P> __device__ __forceinline__ void group_reduce_body(const ReduceParams &rp) {
+// W lanes per group (64 = one wave; 8 when the groups are a handful of rows each: a full wave per group would
+// idle 60 of its lanes and the launch would be millions of waves).
+template <class P, int W = 64> __device__ __forceinline__ void group_reduce_body(const ReduceParams &rp) {
   constexpr int K = P::K;
-  const uint64_t g = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const uint32_t lane = threadIdx.x & 63;
-  if (g >= rp.n_groups) return;
+  const uint64_t g = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) / W;
+  const uint32_t lane = threadIdx.x & (W - 1);
+  if (g >= rp.n_groups) return; // whole W-lane groups leave together: the shuffles below stay inside a group
   ScanParams sp; // the expression types read literals through a ScanParams-shaped context
 #pragma unroll
   for (int k = 0; k < kMaxLits; ++k) { sp.lit_i[k] = rp.lit_i[k]; sp.lit_f[k] = rp.lit_f[k]; }
@@ -310,14 +312,17 @@ template <class P> __device__ __forceinline__ void group_reduce_body(const Reduc
   uint32_t err = 0;
   const uint64_t sg = rp.order ? rp.order[g] : g;
   const uint64_t b = rp.seg_start[sg], e = rp.seg_start[sg + 1];
-  for (uint64_t i = b + lane; i < e; i += 64) {
+  for (uint64_t i = b + lane; i < e; i += W) {
     const uint32_t s = rp.perm[i];
     Loaded ld;
     gather_cols<typename P::ColList>(rp.col, rp.dev_rows[s], ld);
-    Ctx c{sp, ld, 0u, rp.row_ids[s]};
+    // "row" of the aggregates that break ties by arrival (MIN / MAX over f64): the sorted position — the stable
+    // sort keeps a group's rows in row order, and only comparisons inside the group look at it; the real row id
+    // would be one more random load per row
+    Ctx c{sp, ld, 0u, i};
     uint64_t contrib[K];
     contrib[0] = 1;
-    contrib[1] = c.row;
+    contrib[1] = ~0ull; // lane 1 (first row id) is written from the head of the segment below
     AggOps<typename P::AggT>::contrib(c, 0, contrib + 2);
     err |= c.err;
 #pragma unroll
@@ -327,12 +332,12 @@ template <class P> __device__ __forceinline__ void group_reduce_body(const Reduc
   for (int k = 0; k < K; ++k) {
     uint64_t v = acc[k];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { // partner order is fixed: (l, l^1), then pairs of pairs, …
+    for (int o = 1; o < W; o <<= 1) { // partner order is fixed: (l, l^1), then pairs of pairs, …
       const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o);
       // combine(lower lane's value, upper lane's value): every lane of a pair computes the same result
       v = (lane & o) ? lane_combine(reduce_lane_op<P>(k), other, v) : lane_combine(reduce_lane_op<P>(k), v, other);
     }
-    if (lane == 0) rp.out[g * K + k] = v;
+    if (lane == 0) rp.out[g * K + k] = (k == 1 && e > b) ? rp.row_ids[rp.perm[b]] : v;
   }
   if (err) atomicOr(rp.error_flag, err);
 }
