@@ -172,6 +172,21 @@ int SortedGroupBy::run(LazyGroups *out) {
       code_rank = rank_d.as<uint8_t>();
     }
     HIP_TRY(hj_launch_gather_sort_keys(ks.k[k], base, code_rank, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
+    if (n_keys == 1 && !ks.k[k].valid) {
+      // GROUP BY the column the table is clustered by (a primary-key order): the selection already is in key order —
+      // no sort, and the reduction then streams the argument columns instead of gathering them
+      Scratch unsorted;
+      uint32_t is_unsorted = 0;
+      Readback rb;
+      if ((rc = unsorted.alloc(4))) return rc;
+      HIP_TRY(hipMemsetAsync(unsorted.p, 0, 4, s));
+      HIP_TRY(hj_launch_unsorted_flag(keys_a.as<uint64_t>(), n, unsorted.as<uint32_t>(), s));
+      if ((rc = rb.add(&is_unsorted, unsorted.p, 4, s)) || (rc = rb.wait())) return rc;
+      if (!is_unsorted && !std::getenv("LLKV_HIP_GROUP_ALWAYS_SORT")) {
+        std::swap(keys_a.p, keys_b.p); // the boundary pass reads the "sorted" images from keys_b
+        break;
+      }
+    }
     size_t tb = 0;
     HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, bits, s));
     if ((rc = tmp.alloc(tb ? tb : 8))) return rc;

@@ -467,6 +467,21 @@ hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *
   return hipGetLastError();
 }
 
+// *flag |= 1 when keys[i] < keys[i − 1] somewhere (the column is not already in key order)
+__global__ __launch_bounds__(256) void hj_unsorted_flag_kernel(const uint64_t *keys, uint64_t n, uint32_t *flag) {
+  // unsorted input sets the flag in the first waves; the others see it and leave (a million same-address atomics
+  // would serialise for 10 ms)
+  if (*(volatile uint32_t *)flag) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool bad = i > 0 && i < n && keys[i] < keys[i - 1];
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) *(volatile uint32_t *)flag = 1u;
+}
+hipError_t hj_launch_unsorted_flag(const uint64_t *keys, uint64_t n, uint32_t *flag, hipStream_t s) {
+  if (n < 2) return hipSuccess;
+  hipLaunchKernelGGL(hj_unsorted_flag_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, keys, n, flag);
+  return hipGetLastError();
+}
+
 // ---- direct-address form of the dim table (statistics-bounded key range) ------------------------------------
 __global__ __launch_bounds__(256) void hj_bitmap_build_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,
                                                                unsigned long long *bits, uint32_t *dup_flag) {

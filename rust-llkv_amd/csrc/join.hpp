@@ -131,6 +131,8 @@ hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table,
 // offsets[slot] with the hash slot translated to its group id.
 hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
                                      uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s);
+// *flag |= 1 when keys[i] < keys[i − 1] for some i (flag zeroed by the caller)
+hipError_t hj_launch_unsorted_flag(const uint64_t *keys, uint64_t n, uint32_t *flag, hipStream_t s);
 // … and of a single-pass selection (two u64 streams: row ids, device rows)
 hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
                                       uint32_t stripe, uint64_t *out_a, uint64_t *out_b, hipStream_t s);
