@@ -561,9 +561,27 @@ typedef struct llkv_join_key {
   int32_t null_equals_null;
 } llkv_join_key;
 
+/* Whose key rules a join follows.                                              */
+typedef enum llkv_join_key_rules {
+  /* llkv-join's TableJoinExt (the two paths described above)                   */
+  LLKV_JOIN_KEYS_TABLE = 0,
+  /* the executor's SQL joins — hash_join_table_batches / normalize_join_column */
+  /* / build_join_match_indices / build_left_join_match_indices,                */
+  /* llkv-executor/src/lib.rs:12218-12581: key columns are normalised first     */
+  /* (Boolean and every integer type → Int64 — a UInt64 ≥ 2^63 becomes NULL —,  */
+  /* Float32 → Float64), then compared as arrow-row bytes: equal only inside    */
+  /* one class (Int64, Float64 by bit pattern, Utf8, Date32, Decimal128 by raw   */
+  /* value); a NULL in any key part never matches; INNER and LEFT only (other   */
+  /* types: Internal, "use llkv-join"); the reference materialises ONE batch,   */
+  /* here the pairs arrive in probe order over several callbacks (batch_size is */
+  /* not looked at).                                                            */
+  LLKV_JOIN_KEYS_EXECUTOR = 1
+} llkv_join_key_rules;
+
 typedef struct llkv_join_options {
   int32_t join_type;   /* llkv_join_type                                      */
   uint64_t batch_size; /* JoinOptions.batch_size (default 8192); 0 = error    */
+  int32_t key_rules;   /* llkv_join_key_rules                                 */
 } llkv_join_options;
 
 /* Index-pair batch: right_rows[i] == UINT64_MAX marks a NULL-padded right side

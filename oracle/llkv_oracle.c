@@ -1978,7 +1978,31 @@ typedef struct jt_entry { uint64_t head, tail; int used; } jt_entry;
  * extract_key_value does not list (Date32, Boolean, Decimal128) fail the extraction → no key. */
 typedef struct jk_part { int kind; int32_t dtype; uint64_t bits; const char *str; uint32_t len; } jk_part;
 
+/* executor rules (fast == 2): normalize_join_column llkv-executor/src/lib.rs:12405-12427 then arrow-row bytes
+ * (:12458-12581): Boolean and every integer type are cast to Int64 (arrow's safe cast: a UInt64 above i64::MAX
+ * becomes NULL), Float32 to Float64; a NULL key part skips the row; keys are equal when their encodings are — same
+ * class (Int64, Float64 by bits, Utf8, Date32, Decimal128 raw value) and same value. */
+static jk_part join_key_part_executor(const orc_column *c, uint64_t row) {
+  jk_part p = {0, 0, 0, NULL, 0};
+  if (!col_valid(c, row)) return p;
+  p.kind = 1;
+  switch (c->dtype) {
+  case LLKV_DT_BOOLEAN: p.dtype = LLKV_DT_INT64; p.bits = ((const uint8_t *)c->values)[row] ? 1 : 0; return p;
+  case LLKV_DT_INT32: p.dtype = LLKV_DT_INT64; p.bits = (uint64_t)(int64_t)((const int32_t *)c->values)[row]; return p;
+  case LLKV_DT_UINT32: p.dtype = LLKV_DT_INT64; p.bits = ((const uint32_t *)c->values)[row]; return p;
+  case LLKV_DT_INT64: p.dtype = LLKV_DT_INT64; p.bits = ((const uint64_t *)c->values)[row]; return p;
+  case LLKV_DT_UINT64: p.dtype = LLKV_DT_INT64; p.bits = ((const uint64_t *)c->values)[row]; if (p.bits >> 63) p.kind = 0; return p;
+  case LLKV_DT_FLOAT32: { double d = (double)((const float *)c->values)[row]; p.dtype = LLKV_DT_FLOAT64; memcpy(&p.bits, &d, 8); return p; }
+  case LLKV_DT_FLOAT64: p.dtype = LLKV_DT_FLOAT64; p.bits = ((const uint64_t *)c->values)[row]; return p;
+  case LLKV_DT_DATE32: p.dtype = LLKV_DT_DATE32; p.bits = (uint64_t)(int64_t)((const int32_t *)c->values)[row]; return p;
+  case LLKV_DT_DECIMAL128: p.dtype = LLKV_DT_DECIMAL128; p.bits = ((const uint64_t *)c->values)[2 * row]; p.len = (uint32_t)(((const uint64_t *)c->values)[2 * row + 1] & 0xffffffffu); return p;
+  case LLKV_DT_UTF8: p.kind = 2; p.dtype = LLKV_DT_UTF8; p.str = (const char *)c->data + c->offsets[row]; p.len = (uint32_t)(c->offsets[row + 1] - c->offsets[row]); return p;
+  default: p.kind = 0; return p;
+  }
+}
+
 static jk_part join_key_part(const orc_column *c, uint64_t row, int null_eq, int fast) {
+  if (fast == 2) return join_key_part_executor(c, row);
   jk_part p = {0, c->dtype, 0, NULL, 0};
   if (!col_valid(c, row)) {
     if (!null_eq) return p;
@@ -2017,15 +2041,19 @@ static int join_rows_equal(const orc_column *const *ca, uint64_t ra, const orc_c
   for (uint32_t i = 0; i < n_keys; ++i) {
     jk_part a = join_key_part(ca[i], ra, keys[i].null_equals_null, fast), b = join_key_part(cb[i], rb, keys[i].null_equals_null, fast);
     if (a.kind != b.kind || a.dtype != b.dtype) return 0;
-    if (a.kind == 1 ? a.bits != b.bits : (a.len != b.len || memcmp(a.str, b.str, a.len) != 0)) return 0;
+    if (a.kind == 1 ? (a.bits != b.bits || a.len != b.len) : (a.len != b.len || memcmp(a.str, b.str, a.len) != 0)) return 0;
   }
   return 1;
 }
 
 int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_join_key *keys,
                       uint32_t n_keys, const llkv_join_options *options, orc_on_join_batch on_batch, void *user) {
-  uint64_t batch_size = options ? options->batch_size : 8192;
+  int executor = options && options->key_rules == LLKV_JOIN_KEYS_EXECUTOR;
+  uint64_t batch_size = executor ? UINT64_MAX : options ? options->batch_size : 8192;
   int jt = options ? options->join_type : LLKV_JOIN_INNER;
+  if (executor && jt != LLKV_JOIN_INNER && jt != LLKV_JOIN_LEFT) /* llkv-executor/src/lib.rs:12387-12391 */
+    return fail(LLKV_INTERNAL, "join type not supported in hash_join_table_batches; use llkv-join");
+  if (executor && n_keys == 0) return fail(LLKV_INVALID_ARGUMENT, "executor join rules need at least one key pair");
   if (batch_size == 0) return fail(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero"); /* llkv-join/src/lib.rs:284-310 */
   if (jt == LLKV_JOIN_RIGHT || jt == LLKV_JOIN_FULL) return fail(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented"); /* hash_join.rs:328-332 */
   if (n_keys == 0) { /* cross_product_stream hash_join.rs:1500-1599, cross_join_pair cartesian.rs:22-80 */
@@ -2061,6 +2089,7 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
    * generic typed-key path */
   int fast = n_keys == 1 && lcs[0]->dtype == rcs[0]->dtype &&
              (lcs[0]->dtype == LLKV_DT_INT32 || lcs[0]->dtype == LLKV_DT_INT64 || lcs[0]->dtype == LLKV_DT_UINT32 || lcs[0]->dtype == LLKV_DT_UINT64);
+  if (executor) fast = 2; /* the executor's key rules; one batch: all pairs in probe order */
 
   /* build: open addressing on the key (first row with that key), chained row lists in insertion order */
   uint64_t cap = 16;
@@ -2079,9 +2108,10 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
   /* probe: one scan batch of 65 536 left rows at a time (:1010-1070); the generic path cuts every scan batch
    * into slices of batch_size rows first (:228-246); inside a batch / slice the pairs are flushed after the
    * probe row that brings them to >= batch_size, and at its end (:1181-1213, :509-565) */
-  uint64_t *pl = xmalloc((batch_size + right->rows + 1) * sizeof(uint64_t));
-  uint64_t *pr = xmalloc((batch_size + right->rows + 1) * sizeof(uint64_t));
-  uint64_t np = 0;
+  uint64_t pcap = 1024, np = 0;
+  uint64_t *pl = xmalloc(pcap * sizeof(uint64_t)), *pr = xmalloc(pcap * sizeof(uint64_t));
+#define JOIN_PUSH(L_, R_) do { if (np == pcap) { pcap *= 2; pl = xrealloc(pl, pcap * sizeof(uint64_t)); pr = xrealloc(pr, pcap * sizeof(uint64_t)); } \
+                               pl[np] = (L_); pr[np] = (R_); ++np; } while (0)
   for (uint64_t l = 0; l < left->rows; ++l) {
     int matched = 0;
     uint64_t h = 0, hk;
@@ -2092,19 +2122,21 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
     }
     switch (jt) {
     case LLKV_JOIN_INNER:
-      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) { pl[np] = l; pr[np] = r; ++np; }
+      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) JOIN_PUSH(l, r);
       break;
     case LLKV_JOIN_LEFT: /* :1468-1497 unmatched left rows padded with NULLs */
-      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) { pl[np] = l; pr[np] = r; ++np; }
-      else { pl[np] = l; pr[np] = UINT64_MAX; ++np; }
+      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) JOIN_PUSH(l, r);
+      else JOIN_PUSH(l, UINT64_MAX);
       break;
-    case LLKV_JOIN_SEMI: if (matched) { pl[np] = l; pr[np] = 0; ++np; } break;
-    case LLKV_JOIN_ANTI: if (!matched) { pl[np] = l; pr[np] = 0; ++np; } break;
+    case LLKV_JOIN_SEMI: if (matched) JOIN_PUSH(l, 0); break;
+    case LLKV_JOIN_ANTI: if (!matched) JOIN_PUSH(l, 0); break;
     }
     uint64_t in_win = l % ROW_STREAM_CHUNK_SIZE;
     int boundary = in_win + 1 == ROW_STREAM_CHUNK_SIZE || l + 1 == left->rows || (!fast && (in_win + 1) % batch_size == 0);
+    if (executor) boundary = l + 1 == left->rows;
     if (np && (np >= batch_size || boundary)) { on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user); np = 0; }
   }
+#undef JOIN_PUSH
   free(pl); free(pr); free(next); free(tab);
   return LLKV_OK;
 }

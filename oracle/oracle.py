@@ -223,12 +223,12 @@ def scan_stream(table: OracleTable, projections, predicate, include_nulls=False,
     return batches
 
 
-def hash_join(left: OracleTable, right: OracleTable, keys, join_type=abi.JOIN_INNER, batch_size=8192):
+def hash_join(left: OracleTable, right: OracleTable, keys, join_type=abi.JOIN_INNER, batch_size=8192, key_rules=0):
     ck = (abi.CJoinKey * max(1, len(keys)))()
     for i, k in enumerate(keys):
         ck[i].left_field, ck[i].right_field = k[0], k[1]
         ck[i].null_equals_null = int(k[2]) if len(k) > 2 else 0
-    opts = abi.CJoinOptions(join_type, batch_size)
+    opts = abi.CJoinOptions(join_type, batch_size, key_rules)
     lt, rt = left.c(), right.c()
     batches = []
 

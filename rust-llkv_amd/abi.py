@@ -50,6 +50,7 @@ TOK_COLUMN, TOK_LITERAL, TOK_BINARY = range(1, 4)
 BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_MOD = range(1, 6)
 AGG_COUNT_STAR, AGG_COUNT, AGG_SUM, AGG_TOTAL, AGG_AVG, AGG_MIN, AGG_MAX, AGG_COUNT_NULLS = range(1, 9)
 JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL, JOIN_SEMI, JOIN_ANTI = range(6)
+JOIN_KEYS_TABLE, JOIN_KEYS_EXECUTOR = 0, 1  # llkv_join_key_rules
 
 
 # --------------------------------------------------------------------------- structs
@@ -122,7 +123,7 @@ class CJoinKey(C.Structure):
 
 
 class CJoinOptions(C.Structure):
-    _fields_ = [("join_type", C.c_int32), ("batch_size", C.c_uint64)]
+    _fields_ = [("join_type", C.c_int32), ("batch_size", C.c_uint64), ("key_rules", C.c_int32)]
 
 
 class CColumnDesc(C.Structure):

@@ -82,8 +82,14 @@ long long fast_null_sentinel(int32_t dt) { // hash_join.rs:1429-1465
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user) {
-  const uint64_t batch_size = options ? options->batch_size : 8192;
+  const bool executor = options && options->key_rules == LLKV_JOIN_KEYS_EXECUTOR;
+  if (options && options->key_rules != LLKV_JOIN_KEYS_TABLE && !executor) return set_error(LLKV_INVALID_ARGUMENT, "unknown join key rules");
+  // executor rules: no batch cuts (hash_join_table_batches materialises one batch)
+  const uint64_t batch_size = executor ? UINT64_MAX : options ? options->batch_size : 8192;
   const int jt = options ? options->join_type : LLKV_JOIN_INNER;
+  if (executor && jt != LLKV_JOIN_INNER && jt != LLKV_JOIN_LEFT)
+    return set_error(LLKV_INTERNAL, "join type not supported in hash_join_table_batches; use llkv-join"); // llkv-executor/src/lib.rs:12387-12391
+  if (executor && n_keys == 0) return set_error(LLKV_INVALID_ARGUMENT, "executor join rules need at least one key pair");
   // validate_join_options llkv-join/src/lib.rs:284-310, hash_join.rs:328-332
   if (batch_size == 0) return set_error(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero");
   if (jt == LLKV_JOIN_RIGHT || jt == LLKV_JOIN_FULL) return set_error(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented");
@@ -136,9 +142,52 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     if ((rc = key_part(left, keys[i].left_field, &lc[i], &lk.k[i])) || (rc = key_part(right, keys[i].right_field, &rc_[i], &rk.k[i]))) return rc;
   // one key of one fast integer type on both sides → the integer fast path; anything else → the generic
   // typed-key path (hash_join.rs:171-200), with its own NULL rule and its own batching
-  const bool fast = n_keys == 1 && lc[0]->info.dtype == rc_[0]->info.dtype && fast_key_type(lc[0]->info.dtype);
+  const bool fast = !executor && n_keys == 1 && lc[0]->info.dtype == rc_[0]->info.dtype && fast_key_type(lc[0]->info.dtype);
   DBuf translate;
-  if (fast) {
+  if (executor) {
+    // normalize_join_column + arrow-row bytes: equal only inside one class; NULL parts never match
+    std::vector<uint16_t> tables((size_t)n_keys * 256, 0xFFFFu);
+    bool any_table = false;
+    auto klass = [](int32_t dt) {
+      switch (dt) {
+      case LLKV_DT_BOOLEAN: case LLKV_DT_INT32: case LLKV_DT_UINT32: case LLKV_DT_INT64: case LLKV_DT_UINT64: return 1;
+      case LLKV_DT_FLOAT32: case LLKV_DT_FLOAT64: return 2;
+      case LLKV_DT_UTF8: return 3;
+      case LLKV_DT_DATE32: return 4;
+      case LLKV_DT_DECIMAL128: return 5;
+      default: return 0;
+      }
+    };
+    for (uint32_t i = 0; i < n_keys; ++i) {
+      const int32_t dts[2] = {lc[i]->info.dtype, rc_[i]->info.dtype};
+      JoinKeyPart *parts[2] = {&lk.k[i], &rk.k[i]};
+      const int kl = klass(dts[0]), kr = klass(dts[1]);
+      if (kl == 0 || kr == 0) return set_error(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(kl == 0 ? dts[0] : dts[1]));
+      for (int side = 0; side < 2; ++side) {
+        JoinKeyPart &k = *parts[side];
+        k.values_never_match = kl != kr;
+        k.is_signed = dts[side] == LLKV_DT_INT32 || dts[side] == LLKV_DT_DATE32;
+        k.f32_as_f64 = dts[side] == LLKV_DT_FLOAT32;
+        k.u64_high_is_null = dts[side] == LLKV_DT_UINT64;
+      }
+      if (kl == 3 && kr == 3) {
+        uint16_t *tab = tables.data() + (size_t)i * 256;
+        const std::vector<std::string> &ldict = lc[i]->info.dictionary, &rdict = rc_[i]->info.dictionary;
+        for (size_t c = 0; c < ldict.size() && c < 256; ++c)
+          for (size_t d = 0; d < rdict.size(); ++d)
+            if (rdict[d] == ldict[c]) tab[c] = (uint16_t)d;
+        any_table = true;
+        lk.k[i].translate = reinterpret_cast<const uint16_t *>(1); // patched below
+      }
+    }
+    if (any_table) {
+      if ((rc = translate.ensure(tables.size() * 2))) return rc;
+      HIP_TRY(hipMemcpyAsync(translate.p, tables.data(), tables.size() * 2, hipMemcpyHostToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream)); // `tables` is pageable host memory
+      for (uint32_t i = 0; i < n_keys; ++i)
+        if (lk.k[i].translate) lk.k[i].translate = (const uint16_t *)translate.p + (size_t)i * 256;
+    }
+  } else if (fast) {
     for (JoinKeyPart *k : {&lk.k[0], &rk.k[0]}) {
       k->null_equals_null = keys[0].null_equals_null != 0;
       k->null_is_value = 1;
@@ -312,6 +361,11 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
       }
       start = end;
     };
+    if (executor) { // no batch structure to reproduce: one callback per device step
+      if (total) deliver(total);
+      if (trace) t_acc[2] += lap();
+      continue;
+    }
     for (uint64_t row = L0; row < L1;) {
       // the next forced cut: end of the reference scan batch, of the slice (generic path), of the table
       const uint64_t in_win = row % kRefWindow;

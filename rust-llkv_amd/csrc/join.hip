@@ -48,10 +48,13 @@ __device__ __forceinline__ bool load_tuple(const JoinKeySet &ks, uint64_t row, K
     }
     if (k.values_never_match || k.unusable) return false;
     long long v;
-    if (k.width == 8) v = reinterpret_cast<const long long *>(k.values)[row];
-    else if (k.width == 4) {
+    if (k.width == 8) {
+      v = reinterpret_cast<const long long *>(k.values)[row];
+      if (k.u64_high_is_null && v < 0) return false;
+    } else if (k.width == 4) {
       const uint32_t w = reinterpret_cast<const uint32_t *>(k.values)[row];
-      v = k.is_signed ? (long long)(int32_t)w : (long long)w;
+      if (k.f32_as_f64) v = __double_as_longlong((double)__uint_as_float(w));
+      else v = k.is_signed ? (long long)(int32_t)w : (long long)w;
     } else {
       uint32_t code = reinterpret_cast<const uint8_t *>(k.values)[row];
       if (k.translate) {

@@ -45,6 +45,10 @@ struct JoinKeyPart {
   long long null_value;
   uint32_t values_never_match;
   uint32_t unusable;
+  // executor rules (normalize_join_column, llkv-executor/src/lib.rs:12405-12427): a Float32 cell is compared as the
+  // Float64 it casts to; a UInt64 ≥ 2^63 does not survive the cast to Int64 (NULL: no key)
+  uint32_t f32_as_f64;
+  uint32_t u64_high_is_null;
 };
 struct JoinKeySet {
   JoinKeyPart k[4];

@@ -466,7 +466,7 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
     return batches
 
 
-def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN_INNER, batch_size: int = 8192, consume=None):
+def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN_INNER, batch_size: int = 8192, consume=None, key_rules: int = 0):
     """TableJoinExt::join_stream (llkv-join/src/lib.rs:240-282): list of batches (left_rows, right_rows|None);
     a right row of 2**64-1 is the NULL padding of a LEFT join.  ``consume(n_pairs)``: called per batch instead
     (nothing is converted or returned)."""
@@ -474,7 +474,7 @@ def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN
     for i, k in enumerate(keys):
         ck[i].left_field, ck[i].right_field = k[0], k[1]
         ck[i].null_equals_null = int(k[2]) if len(k) > 2 else 0
-    opts = abi.CJoinOptions(join_type, batch_size)
+    opts = abi.CJoinOptions(join_type, batch_size, key_rules)
     batches = []
 
     def on_batch(pl, pr, n, _u):

@@ -1174,6 +1174,45 @@ def test_generic_key_types_match_oracle(rt, orc, abi):
     assert e.value.kind == "Unsupported"
 
 
+def test_executor_rule_joins_match_oracle(rt, orc, abi):
+    """llkv_join_options.key_rules = EXECUTOR: the SQL joins of the executor (normalised keys, arrow-row equality,
+    INNER / LEFT, no batch structure) — llkv-executor/src/lib.rs:12218-12581."""
+    rng = np.random.default_rng(91)
+    n_left, n_right = 150_000, 30_000
+    X = abi.JOIN_KEYS_EXECUTOR
+    cols_l = [(1, abi.DT_INT32, rng.integers(-50, 500, size=n_left).astype(np.int32), rng.random(n_left) > 0.05),
+              (2, abi.DT_UINT64, rng.choice(np.array([3, 7, 2**63, 2**64 - 1, 100], dtype=np.uint64), size=n_left), None),
+              (3, abi.DT_FLOAT32, rng.choice(np.array([0.5, 0.1, -0.0, 0.0, 7.25], dtype=np.float32), size=n_left), None),
+              (4, abi.DT_DATE32, rng.integers(0, 40, size=n_left).astype(np.int32), None),
+              (5, abi.DT_UTF8, [("x", "yy", "zzz", None)[k] for k in rng.integers(0, 4, size=n_left)], None)]
+    cols_r = [(1, abi.DT_INT64, rng.integers(-50, 500, size=n_right).astype(np.int64), rng.random(n_right) > 0.05),
+              (2, abi.DT_INT64, rng.choice(np.array([3, 7, -1, 100, -2**63], dtype=np.int64), size=n_right), None),
+              (3, abi.DT_FLOAT64, rng.choice(np.array([0.5, 0.1, float(np.float32(0.1)), 0.0, 7.25]), size=n_right), None),
+              (4, abi.DT_DATE32, rng.integers(0, 40, size=n_right).astype(np.int32), None),
+              (5, abi.DT_UTF8, [("yy", "x", "w", None)[k] for k in rng.integers(0, 4, size=n_right)], None)]
+    lt, rtab, ol, orr = _keyed_tables(rt, orc, abi, cols_l, cols_r, [70_000, 80_000], n_right)
+
+    def same(keys, jt):
+        got = rt.join_stream(lt, rtab, keys, JT[jt], 8192, key_rules=X)
+        want = orc.hash_join(ol, orr, keys, JT[jt], 8192, key_rules=X)
+        assert [x for b in got for x in b[0]] == [x for b in want for x in b[0]], (keys, jt)
+        assert [x for b in got for x in b[1]] == [x for b in want for x in b[1]], (keys, jt)
+        return sum(len(b[0]) for b in got)
+
+    assert same([(1, 1)], "inner") > 0                 # Int32 meets Int64
+    same([(1, 1)], "left")
+    assert same([(1, 1), (4, 4)], "inner") > 0         # + Date32
+    assert same([(1, 1), (5, 5)], "left") > n_left     # + Utf8 through the two dictionaries
+    assert same([(1, 1), (3, 3)], "inner") > 0         # + Float32 against Float64
+    assert same([(1, 1), (2, 2)], "inner") > 0         # + UInt64 against Int64: 2^63 and 2^64-1 are NULL after the cast
+    assert same([(4, 1)], "inner") == 0                # Date32 never meets Int64
+    for jt in ("semi", "anti"):
+        for m, args in ((rt.join_stream, (lt, rtab)), (orc.hash_join, (ol, orr))):
+            with pytest.raises(abi.LlkvError) as e:
+                m(*args, [(1, 1)], JT[jt], 8192, key_rules=X)
+            assert e.value.kind == "Internal"
+
+
 @pytest.mark.parametrize("rows,scale", [(60175, 0.01), (600_000, 0.1)])
 def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
     """TPC-H Q3 shape (BASELINE.json configs[4], single GPU): customer(segment) ⋉ orders(date) ⋈ lineitem(shipdate),

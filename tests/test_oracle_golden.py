@@ -107,6 +107,39 @@ def test_generic_join_key_rules(orc, abi):
     assert [b[0] for b in orc.hash_join(li, ri, [(1, 1)], abi.JOIN_INNER, 4)] == [[0, 2, 4, 6], [8]]  # fast path: no slices
 
 
+def test_executor_join_key_rules(orc, abi):
+    """The executor's SQL joins (hash_join_table_batches / normalize_join_column / build_join_match_indices,
+    llkv-executor/src/lib.rs:12218-12581), expectations derived by hand: integer types meet after the cast to
+    Int64 (a UInt64 ≥ 2^63 turns NULL), Float32 meets Float64, Date32 only Date32; NULL parts never match; one
+    batch; LEFT pads unmatched and NULL-key rows; other join types are refused."""
+    def pairs(batches):
+        assert len(batches) <= 1
+        return [(l, None if r == 2**64 - 1 else r) for b in batches for l, r in zip(b[0], b[1])]
+    X = abi.JOIN_KEYS_EXECUTOR
+    l32 = orc.OracleTable(4).add(1, abi.DT_INT32, np.array([7, -1, 8, 9], dtype=np.int32), [True, True, True, False])
+    r64 = orc.OracleTable(4).add(1, abi.DT_INT64, np.array([8, 7, -1, 7]))
+    assert pairs(orc.hash_join(l32, r64, [(1, 1)], abi.JOIN_INNER, key_rules=X)) == [(0, 1), (0, 3), (1, 2), (2, 0)]
+    assert pairs(orc.hash_join(l32, r64, [(1, 1)], abi.JOIN_LEFT, key_rules=X)) == [(0, 1), (0, 3), (1, 2), (2, 0), (3, None)]
+    assert pairs(orc.hash_join(l32, r64, [(1, 1)], abi.JOIN_INNER)) == []  # llkv-join: Int32 and Int64 never equal
+    ru = orc.OracleTable(3).add(1, abi.DT_UINT64, np.array([7, 2**64 - 1, 2**63], dtype=np.uint64))
+    assert pairs(orc.hash_join(l32, ru, [(1, 1)], abi.JOIN_INNER, key_rules=X)) == [(0, 0)]  # 2^64-1 is NULL after the cast, not -1
+    lf = orc.OracleTable(3).add(1, abi.DT_FLOAT32, np.array([0.5, 0.1, -0.0], dtype=np.float32))
+    rf = orc.OracleTable(4).add(1, abi.DT_FLOAT64, np.array([0.5, 0.1, float(np.float32(0.1)), 0.0]))
+    assert pairs(orc.hash_join(lf, rf, [(1, 1)], abi.JOIN_INNER, key_rules=X)) == [(0, 0), (1, 2)]
+    ld = orc.OracleTable(2).add(1, abi.DT_DATE32, np.array([10, 11], dtype=np.int32))
+    rd = orc.OracleTable(2).add(1, abi.DT_DATE32, np.array([11, 10], dtype=np.int32))
+    ri = orc.OracleTable(2).add(1, abi.DT_INT64, np.array([11, 10]))
+    assert pairs(orc.hash_join(ld, rd, [(1, 1)], abi.JOIN_INNER, key_rules=X)) == [(0, 1), (1, 0)]
+    assert pairs(orc.hash_join(ld, ri, [(1, 1)], abi.JOIN_INNER, key_rules=X)) == []
+    ls = orc.OracleTable(3).add(1, abi.DT_UTF8, ["a", None, "b"]).add(2, abi.DT_INT64, np.array([1, 2, 3]))
+    rs = orc.OracleTable(3).add(1, abi.DT_UTF8, ["b", "a", "a"]).add(2, abi.DT_INT32, np.array([3, 1, 9], dtype=np.int32))
+    assert pairs(orc.hash_join(ls, rs, [(1, 1), (2, 2)], abi.JOIN_INNER, key_rules=X)) == [(0, 1), (2, 0)]
+    for jt in (abi.JOIN_SEMI, abi.JOIN_ANTI, abi.JOIN_RIGHT):
+        with pytest.raises(abi.LlkvError) as e:
+            orc.hash_join(ls, rs, [(1, 1)], jt, key_rules=X)
+        assert e.value.kind in ("Internal", "InvalidArgumentError")
+
+
 @pytest.mark.parametrize("case", AGGS["cases"], ids=lambda c: c["name"])
 def test_aggregate_cases(case, orc, abi):
     t = oracle_table(orc, abi, case["columns"])
