@@ -131,6 +131,9 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     }
     return LLKV_OK;
   }
+  // "build side replicated, probe side sharded" (BASELINE.json configs[4]): every rank probes its own rows of the left
+  // table against the whole right table; the binding concatenates the ranks' batches in rank order
+  if (right->world != 1) return set_error(LLKV_INVALID_ARGUMENT, "the build (right) table of a join is replicated: stage it whole (world = 1) on every rank");
   if (n_keys > kMaxJoinKeys) return set_error(LLKV_UNSUPPORTED, "GPU join path takes at most " + std::to_string(kMaxJoinKeys) + " key pairs");
   if (!keys) return set_error(LLKV_INVALID_ARGUMENT, "join keys is NULL");
   JoinKeySet lk, rk;

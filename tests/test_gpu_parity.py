@@ -1174,6 +1174,47 @@ def test_generic_key_types_match_oracle(rt, orc, abi):
     assert e.value.kind == "Unsupported"
 
 
+def test_sharded_probe_side_and_scans_concatenate(rt, abi):
+    """SURVEY §8e for the selection-vector and join routes: a rank scans / probes the rows of its own chunks (row
+    ids stay global), the build side of a join is replicated; the ranks' outputs concatenated in rank order are
+    the single-GPU output."""
+    rng = np.random.default_rng(17)
+    chunks = [5000, 70_000, 300, 9000, 4096, 80_000, 123, 6000]
+    n = sum(chunks)
+    key = rng.integers(0, 3000, size=n).astype(np.int64)
+    val = rng.normal(size=n)
+    valid = rng.random(n) > 0.1
+    n_right = 2000
+    rkey = rng.integers(0, 4000, size=n_right).astype(np.int64)
+    rtab = rt.HipTable(2, [n_right]); rtab.append_column(7, abi.DT_INT64, rkey)
+    F, O = abi.Filter, abi.Operator
+    pred = [F(2, O.GreaterThan(0.25))]
+
+    def shard(rank, world):
+        t = rt.HipTable(1, chunks, rank, world)
+        lo = sum(chunks[:t.first_chunk])
+        t.append_column(1, abi.DT_INT64, key[lo:lo + t.local_rows], valid=valid[lo:lo + t.local_rows])
+        t.append_column(2, abi.DT_FLOAT64, val[lo:lo + t.local_rows])
+        return t
+
+    def outputs(t):
+        pairs = rt.join_stream(t, rtab, [(1, 7)], JT["left"], 4096)
+        ids = rt.filter_row_ids(t, pred).tolist()
+        scan = rt.scan_stream(t, [1, 2], pred, include_nulls=True, include_row_ids=True)
+        return ([x for b in pairs for x in b[0]], [x for b in pairs for x in b[1]], ids,
+                [x for b in scan for x in b[1]], [x for b in scan for x in b[0][0]])
+
+    want = outputs(shard(0, 1))
+    assert len(want[0]) > n and len(want[2]) > 1000
+    for world in (2, 4, 8):
+        parts = [outputs(shard(r, world)) for r in range(world)]
+        for k in range(5):
+            assert [x for p in parts for x in p[k]] == want[k], (world, k)
+    with pytest.raises(abi.LlkvError) as e:  # a sharded build side would join against a fraction of the table
+        rt.join_stream(shard(0, 1), shard(1, 2), [(1, 1)], JT["inner"])
+    assert e.value.kind == "InvalidArgumentError"
+
+
 def test_executor_rule_joins_match_oracle(rt, orc, abi):
     """llkv_join_options.key_rules = EXECUTOR: the SQL joins of the executor (normalised keys, arrow-row equality,
     INNER / LEFT, no batch structure) — llkv-executor/src/lib.rs:12218-12581."""
