@@ -491,25 +491,36 @@ int Readback::wait() {
 // ---------------------------------------------------------------------------------
 Query::~Query() {
   if (sorted) sorted_groupby_free(sorted);
-  if (d_tile_partials) (void)hipFree(d_tile_partials);
-  if (d_exchange && !host_mapped) (void)hipFree(d_exchange);
-  if (d_lane_ops) (void)hipFree(d_lane_ops);
-  if (d_empty_image) (void)hipFree(d_empty_image);
-  if (h_exchange) (void)hipHostFree(h_exchange);
+  // the buffers go back to the pools (hipFree / hipHostFree cost 0.2 ms per statement); executions that were
+  // launched and never collected may still be running on their streams
+  if (n_launched != n_collected) {
+    if (pending_stream) (void)hipStreamSynchronize(pending_stream);
+    for (hipStream_t st : slot_stream) if (st) (void)hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(g_ctx.stream);
+  }
+  scratch_free(d_tile_partials);
+  if (d_exchange && !host_mapped) scratch_free(d_exchange);
+  scratch_free(d_lane_ops);
+  scratch_free(d_empty_image);
+  if (h_exchange) pinned_release(h_exchange, h_exchange_bytes);
   for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto &e : copied) if (e) (void)hipEventDestroy(e);
   for (auto &e : ev_fold) if (e) (void)hipEventDestroy(e);
 }
 
-static uint32_t pick_tile_rows(const LoweredPlan &p) {
+static uint32_t pick_tile_rows(const LoweredPlan &p, uint64_t total_rows) {
   if (const char *e = std::getenv("LLKV_HIP_TILE_ROWS")) {
     long v = std::atol(e);
     if (v >= 512 && v % 512 == 0) return (uint32_t)v;
   }
   // narrow register states amortise their block reduction quickly and like many small tiles;
   // LDS-resident grouped states (2 workgroups/CU) want long tiles (sweep: profiles/r01/).
-  // Depends on the plan only, never on the GPU count (bit-reproducibility).
-  return p.acc_lds ? 65536u : 4096u;
+  // Depends on the plan and the TABLE's row count only, never on the GPU count (bit-reproducibility): long tiles
+  // leave a small table with too few workgroups for 256 CUs (Q1 at SF1: 92 tiles of 65 536 rows ran 78 µs, 366 tiles
+  // of 16 384 rows 49 µs), so they are halved until some 350 tiles exist.
+  uint32_t rows = p.acc_lds ? 65536u : 4096u;
+  while (rows > 4096u && total_rows / rows < 350) rows >>= 1;
+  return rows;
 }
 
 int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
@@ -585,7 +596,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     }
   }
   const TileSet *ts = nullptr;
-  if ((rc = get_tileset(*table, pick_tile_rows(p), &ts))) return rc;
+  if ((rc = get_tileset(*table, pick_tile_rows(p, table->total_rows), &ts))) return rc;
   q->tiles = ts;
 
   std::memset(&q->params, 0, sizeof q->params);
@@ -598,18 +609,22 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
 
   const size_t lanes = (size_t)p.lanes;
   q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles);
-  HIP_TRY(hipMalloc((void **)&q->d_tile_partials, 2 * q->partials_len * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc((void **)&q->d_lane_ops, lanes));
+  q->d_tile_partials = (uint64_t *)scratch_alloc(2 * q->partials_len * sizeof(uint64_t));
+  q->d_lane_ops = (uint8_t *)scratch_alloc(lanes);
+  if (!q->d_tile_partials || !q->d_lane_ops) return set_error(LLKV_INTERNAL, "device allocation failed");
   HIP_TRY(hipMemcpyAsync(q->d_lane_ops, p.lane_ops.data(), lanes, hipMemcpyHostToDevice, g_ctx.stream));
   for (auto &e : q->ev_fold) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : q->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
-  HIP_TRY(hipHostMalloc((void **)&q->h_exchange, ring_bytes, hipHostMallocDefault));
+  q->h_exchange_bytes = ring_bytes;
+  q->h_exchange = (uint64_t *)pinned_acquire(&q->h_exchange_bytes);
+  if (!q->h_exchange) return set_error(LLKV_INTERNAL, "pinned host allocation failed");
   std::memset(q->h_exchange, 0, ring_bytes);
   q->host_mapped = table->world == 1; // nobody else reads the image: let the kernel write it to the host directly
   if (q->host_mapped) q->d_exchange = q->h_exchange;
   else {
-    HIP_TRY(hipMalloc((void **)&q->d_exchange, ring_bytes));
+    q->d_exchange = (uint64_t *)scratch_alloc(ring_bytes);
+    if (!q->d_exchange) return set_error(LLKV_INTERNAL, "device allocation failed");
     HIP_TRY(hipMemsetAsync(q->d_exchange, 0, ring_bytes, g_ctx.stream));
   }
   { // image of an execution that launches no workgroup: identities for owned octants, zero for the others
@@ -617,7 +632,8 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     for (int o = 0; o < kOctantsHost; ++o)
       if ((table->owned_mask >> o) & 1u)
         for (size_t l = 0; l < lanes; ++l) img[o * lanes + l] = p.lane_ops[l] == 2 ? 0x7FFFFFFFFFFFFFFFull : p.lane_ops[l] == 3 ? 0x8000000000000000ull : 0ull;
-    HIP_TRY(hipMalloc((void **)&q->d_empty_image, img.size() * 8));
+    q->d_empty_image = (uint64_t *)scratch_alloc(img.size() * 8);
+    if (!q->d_empty_image) return set_error(LLKV_INTERNAL, "device allocation failed");
     HIP_TRY(hipMemcpy(q->d_empty_image, img.data(), img.size() * 8, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));

@@ -160,6 +160,7 @@ struct Query {
   bool host_mapped = false;            // single rank: the kernel writes the image straight into pinned host memory
   uint64_t *d_exchange = nullptr; // [kMaxDepth][kOctants][lanes]
   uint64_t *h_exchange = nullptr; // pinned, same shape
+  size_t h_exchange_bytes = 0;    // size class of the pinned block (pinned_acquire)
   bool order_by_keys = false;
   uint32_t n_user_aggs = 0, n_user_keys = 0;
   std::vector<GroupResult> groups;
