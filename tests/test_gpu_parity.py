@@ -1215,6 +1215,38 @@ def test_sharded_probe_side_and_scans_concatenate(rt, abi):
     assert e.value.kind == "InvalidArgumentError"
 
 
+def test_join_and_scan_edge_sizes(rt, orc, abi):
+    """Empty sides, and selections that end exactly on / just past the 16-window device buffers."""
+    X = abi.JOIN_KEYS_EXECUTOR
+    k3 = np.array([1, 2, 2], dtype=np.int64)
+    none = np.zeros(0, dtype=np.int64)
+    for lv, rv in ((none, k3), (k3, none), (none, none)):
+        lt = rt.HipTable(1, [len(lv)]); lt.append_column(1, abi.DT_INT64, lv)
+        rtab = rt.HipTable(2, [len(rv)]); rtab.append_column(7, abi.DT_INT64, rv)
+        ol, orr = orc.OracleTable(len(lv)).add(1, abi.DT_INT64, lv), orc.OracleTable(len(rv)).add(7, abi.DT_INT64, rv)
+        for jt in ("inner", "left", "semi", "anti"):
+            assert rt.join_stream(lt, rtab, [(1, 7)], JT[jt]) == orc.hash_join(ol, orr, [(1, 7)], JT[jt]), (len(lv), len(rv), jt)
+            assert rt.join_stream(lt, rtab, [(1, 7), (1, 7)], JT[jt]) == orc.hash_join(ol, orr, [(1, 7), (1, 7)], JT[jt])
+        for jt in ("inner", "left"):
+            assert rt.join_stream(lt, rtab, [(1, 7)], JT[jt], key_rules=X) == orc.hash_join(ol, orr, [(1, 7)], JT[jt], key_rules=X)
+    for n in (16 * 65536, 16 * 65536 + 1, 65536, 65537):
+        v = np.arange(n, dtype=np.int64)
+        t = rt.HipTable(1, [n]); t.append_column(1, abi.DT_INT64, v)
+        seen = []
+        rt.scan_stream(t, [1], None, include_row_ids=True, consume=lambda b: seen.append((int(b.num_rows), int(b.row_ids[0]), int(b.row_ids[int(b.num_rows) - 1]))))
+        want = [(min(65536, n - w0), w0, min(n, w0 + 65536) - 1) for w0 in range(0, n, 65536)]
+        assert seen == want, n
+        assert rt.filter_row_ids(t, [abi.Filter(1, abi.Operator.GreaterThanOrEquals(5))], count_only=True) == n - 5
+    # join → GROUP BY → top-k: no qualifying dim row, no matching fact row, LIMIT 0, LIMIT beyond the groups
+    dim = rt.HipTable(2, [4]); dim.append_column(1, abi.DT_INT64, np.array([10, 20, 30, 40])); dim.append_column(2, abi.DT_INT64, np.array([1, 2, 3, 4]))
+    fact = rt.HipTable(1, [5]); fact.append_column(7, abi.DT_INT64, np.array([20, 20, 40, 50, 20])); fact.append_column(8, abi.DT_FLOAT64, np.array([1.5, 2.5, 4.0, 9.0, 1.0]))
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    assert rt.join_groupby_topk(fact, [], 7, dim, [F(2, O.GreaterThan(100))], 1, col(8) * 1.0, payload_fields=[2], limit=3) == ([], 0)
+    assert rt.join_groupby_topk(fact, [F(8, O.GreaterThan(100.0))], 7, dim, [], 1, col(8) * 1.0, payload_fields=[2], limit=3) == ([], 0)
+    assert rt.join_groupby_topk(fact, [], 7, dim, [], 1, col(8) * 1.0, payload_fields=[2], limit=0) == ([], 2)
+    assert rt.join_groupby_topk(fact, [], 7, dim, [], 1, col(8) * 1.0, payload_fields=[2], limit=9) == ([(20, 5.0, 3, 2), (40, 4.0, 1, 4)], 2)
+
+
 def test_executor_rule_joins_match_oracle(rt, orc, abi):
     """llkv_join_options.key_rules = EXECUTOR: the SQL joins of the executor (normalised keys, arrow-row equality,
     INNER / LEFT, no batch structure) — llkv-executor/src/lib.rs:12218-12581."""
