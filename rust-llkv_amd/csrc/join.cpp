@@ -291,8 +291,7 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   if (trace) { (void)hipStreamSynchronize(s); std::fprintf(stderr, "[llkv join] build %9.3f ms (%llu rows)\n", lap(), (unsigned long long)n_build); }
   // ---- probe (left), window by window ----
   const uint32_t win_pos = std::min(kWindowTiles, std::max(1u, tl->n_tiles)) * kJoinTileRows;
-  DBuf counts, mslot, offsets, out_l, out_r, scan_tmp;
-  HBuf h_l, h_r;
+  DBuf counts, mslot, offsets, scan_tmp;
   if ((rc = counts.ensure((size_t)(win_pos + 1) * 8)) || (rc = mslot.ensure((size_t)win_pos * 4)) || (rc = offsets.ensure((size_t)(win_pos + 1) * 8))) return rc;
   const bool left_only = jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI;
   // Batches.  The reference probes one scan batch (65 536 rows of the left table) at a time and flushes after the
@@ -310,6 +309,75 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   }
   const uint64_t left_end = left->local_logical_start + left->local_rows;
   std::vector<uint64_t> pend_l, pend_r;
+  // Two pair buffers: while the pairs of step i cross PCIe on the copy stream and the host cuts step i − 1 into
+  // batches, the compute stream already counts step i + 1.
+  struct Step {
+    DBuf out_l, out_r;
+    HBuf h_l, h_r;
+    hipEvent_t written = nullptr, copied = nullptr;
+    uint64_t total = 0, L0 = 0, L1 = 0;
+    bool live = false;
+    ~Step() { // the buffers go back to their pools: nothing may still be writing them (error paths leave early)
+      if (written) { (void)hipEventSynchronize(written); (void)hipEventDestroy(written); }
+      if (copied) { (void)hipEventSynchronize(copied); (void)hipEventDestroy(copied); }
+    }
+  } steps[2];
+  for (Step &st : steps) {
+    HIP_TRY(hipEventCreateWithFlags(&st.written, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+  }
+  struct CopyStream {
+    hipStream_t s = nullptr;
+    ~CopyStream() { if (s) (void)hipStreamDestroy(s); }
+  } copy;
+  HIP_TRY(hipStreamCreateWithFlags(&copy.s, hipStreamNonBlocking));
+
+  // cuts one finished step into the reference's batches
+  auto emit = [&](Step &st) -> int {
+    if (!st.live) return LLKV_OK;
+    st.live = false;
+    HIP_TRY(hipEventSynchronize(st.copied));
+    const uint64_t total = st.total, L0 = st.L0, L1 = st.L1;
+    const uint64_t *hl = (const uint64_t *)st.h_l.p, *hr = left_only ? nullptr : (const uint64_t *)st.h_r.p;
+    uint64_t start = 0; // pairs of this step already delivered
+    auto deliver = [&](uint64_t end) {
+      if (pend_l.empty()) {
+        on_batch(hl + start, hr ? hr + start : nullptr, end - start, user);
+      } else {
+        pend_l.insert(pend_l.end(), hl + start, hl + end);
+        if (hr) pend_r.insert(pend_r.end(), hr + start, hr + end);
+        on_batch(pend_l.data(), hr ? pend_r.data() : nullptr, pend_l.size(), user);
+        pend_l.clear();
+        pend_r.clear();
+      }
+      start = end;
+    };
+    if (executor) { // no batch structure to reproduce: one callback per device step
+      if (total) deliver(total);
+      return LLKV_OK;
+    }
+    for (uint64_t row = L0; row < L1;) {
+      // the next forced cut: end of the reference scan batch, of the slice (generic path), of the table
+      const uint64_t in_win = row % kRefWindow;
+      uint64_t b = row - in_win + kRefWindow;
+      if (!fast) b = std::min(b, row - in_win + (in_win / batch_size + 1) * batch_size);
+      b = std::min(b, left_end);
+      const uint64_t seg_end = (uint64_t)(std::lower_bound(hl + start, hl + total, b) - hl); // first pair of a row ≥ b
+      while (pend_l.size() + (seg_end - start) >= batch_size) {
+        const uint64_t j = start + (batch_size - pend_l.size()) - 1; // the pair that fills the batch …
+        deliver((uint64_t)(std::upper_bound(hl + j, hl + seg_end, hl[j]) - hl)); // … and the rest of its probe row
+      }
+      if (b <= L1 && pend_l.size() + (seg_end - start) > 0) deliver(seg_end);
+      row = b;
+    }
+    if (total > start) { // the reference batch goes on in the next step
+      pend_l.insert(pend_l.end(), hl + start, hl + total);
+      if (hr) pend_r.insert(pend_r.end(), hr + start, hr + total);
+    }
+    return LLKV_OK;
+  };
+
+  int cur = 0;
   for (uint32_t t0 = 0; t0 < tl->n_tiles; t0 += kWindowTiles) {
     const uint32_t nt = std::min(kWindowTiles, tl->n_tiles - t0);
     const uint32_t npos = nt * kJoinTileRows;
@@ -336,59 +404,32 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     Readback rb;
     if ((rc = rb.add(&total, (uint64_t *)offsets.p + npos, 8, s)) || (rc = rb.wait())) return rc;
     if (trace) t_acc[0] += lap();
-    if (total == 0 && pend_l.empty()) continue;
+    Step &st = steps[cur];
+    if ((rc = emit(st))) return rc; // its buffers are about to be reused (normally already emitted below)
     uint64_t wrows = 0;
     for (uint32_t t = 0; t < nt; ++t) wrows += ltiles[t0 + t].rows;
-    const uint64_t L0 = ltiles[t0].logical_row, L1 = L0 + wrows; // the rows of a rank are contiguous
+    st.total = total;
+    st.L0 = ltiles[t0].logical_row; // the rows of a rank are contiguous
+    st.L1 = st.L0 + wrows;
+    st.live = true;
     if (total) {
-      if ((rc = out_l.ensure(total * 8)) || (rc = out_r.ensure(total * 8)) || (rc = h_l.ensure(total * 8)) || (rc = h_r.ensure(total * 8))) return rc;
+      if ((rc = st.out_l.ensure(total * 8)) || (rc = st.out_r.ensure(total * 8)) || (rc = st.h_l.ensure(total * 8)) || (rc = st.h_r.ensure(total * 8))) return rc;
       p.offsets = (const uint64_t *)offsets.p;
-      p.out_left = (uint64_t *)out_l.p; p.out_right = (uint64_t *)out_r.p;
+      p.out_left = (uint64_t *)st.out_l.p; p.out_right = (uint64_t *)st.out_r.p;
       HIP_TRY(hj_launch_probe_write(p, s));
-      HIP_TRY(hipMemcpyAsync(h_l.p, out_l.p, total * 8, hipMemcpyDeviceToHost, s));
-      if (!left_only) HIP_TRY(hipMemcpyAsync(h_r.p, out_r.p, total * 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipEventRecord(st.written, s));
+      HIP_TRY(hipStreamWaitEvent(copy.s, st.written, 0));
+      HIP_TRY(hipMemcpyAsync(st.h_l.p, st.out_l.p, total * 8, hipMemcpyDeviceToHost, copy.s));
+      if (!left_only) HIP_TRY(hipMemcpyAsync(st.h_r.p, st.out_r.p, total * 8, hipMemcpyDeviceToHost, copy.s));
     }
+    HIP_TRY(hipEventRecord(st.copied, copy.s));
     if (trace) t_acc[1] += lap();
-    const uint64_t *hl = (const uint64_t *)h_l.p, *hr = left_only ? nullptr : (const uint64_t *)h_r.p;
-    uint64_t start = 0; // pairs of this step already delivered
-    auto deliver = [&](uint64_t end) {
-      if (pend_l.empty()) {
-        on_batch(hl + start, hr ? hr + start : nullptr, end - start, user);
-      } else {
-        pend_l.insert(pend_l.end(), hl + start, hl + end);
-        if (hr) pend_r.insert(pend_r.end(), hr + start, hr + end);
-        on_batch(pend_l.data(), hr ? pend_r.data() : nullptr, pend_l.size(), user);
-        pend_l.clear();
-        pend_r.clear();
-      }
-      start = end;
-    };
-    if (executor) { // no batch structure to reproduce: one callback per device step
-      if (total) deliver(total);
-      if (trace) t_acc[2] += lap();
-      continue;
-    }
-    for (uint64_t row = L0; row < L1;) {
-      // the next forced cut: end of the reference scan batch, of the slice (generic path), of the table
-      const uint64_t in_win = row % kRefWindow;
-      uint64_t b = row - in_win + kRefWindow;
-      if (!fast) b = std::min(b, row - in_win + (in_win / batch_size + 1) * batch_size);
-      b = std::min(b, left_end);
-      const uint64_t seg_end = (uint64_t)(std::lower_bound(hl + start, hl + total, b) - hl); // first pair of a row ≥ b
-      while (pend_l.size() + (seg_end - start) >= batch_size) {
-        const uint64_t j = start + (batch_size - pend_l.size()) - 1; // the pair that fills the batch …
-        deliver((uint64_t)(std::upper_bound(hl + j, hl + seg_end, hl[j]) - hl)); // … and the rest of its probe row
-      }
-      if (b <= L1 && pend_l.size() + (seg_end - start) > 0) deliver(seg_end);
-      row = b;
-    }
-    if (total > start) { // the reference batch goes on in the next step
-      pend_l.insert(pend_l.end(), hl + start, hl + total);
-      if (hr) pend_r.insert(pend_r.end(), hr + start, hr + total);
-    }
+    if ((rc = emit(steps[cur ^ 1]))) return rc; // the previous step, while this one's pairs are on their way
     if (trace) t_acc[2] += lap();
+    cur ^= 1;
   }
+  if ((rc = emit(steps[cur])) || (rc = emit(steps[cur ^ 1]))) return rc; // oldest first
+  if (!pend_l.empty()) on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
   if (trace) std::fprintf(stderr, "[llkv join] probe: count+scan %9.3f ms, write+copy %9.3f ms, cuts+callbacks %9.3f ms\n", t_acc[0], t_acc[1], t_acc[2]);
   if (!pend_l.empty()) on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
   return LLKV_OK;
