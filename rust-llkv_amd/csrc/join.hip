@@ -21,11 +21,7 @@ __device__ __forceinline__ long long load_key(const JoinKeyColumn &k, uint64_t r
   return k.is_signed ? (long long)(int32_t)v : (long long)v;
 }
 
-__device__ __forceinline__ uint64_t hash_key(long long k) {
-  uint64_t x = (uint64_t)k;
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-  return x;
-}
+__device__ __forceinline__ uint64_t hash_key(long long k) { return mix64((uint64_t)k); }
 
 constexpr unsigned long long kEmpty = ~0ull;
 

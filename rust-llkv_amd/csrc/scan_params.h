@@ -28,6 +28,18 @@ constexpr int kMaxLits = 16;
 constexpr int kMaxKeys = 4;
 constexpr int kOctants = 8; // canonical partition of the chunk list
 
+#ifdef __HIPCC__
+#define LLKV_HOST_DEVICE __host__ __device__
+#else
+#define LLKV_HOST_DEVICE
+#endif
+// The one hash of every open-addressing table (64-bit finalizer of MurmurHash3): build kernels (join.hip) and the
+// run-time compiled probes (select.hip.h) must agree on it.
+inline LLKV_HOST_DEVICE uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
 struct TileDesc {
   uint64_t dev_row;     // first row of the tile in the device column image
   uint64_t logical_row; // row id of that row (dense ids)

@@ -75,11 +75,7 @@ __device__ __forceinline__ long long ht_load_key(const ScanParams &p, unsigned l
   const uint32_t v = reinterpret_cast<const uint32_t *>(p.ht_keys)[row];
   return p.ht_key_signed ? (long long)(int32_t)v : (long long)v;
 }
-__device__ __forceinline__ uint64_t ht_hash(long long k) {
-  uint64_t x = (uint64_t)k;
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-  return x;
-}
+__device__ __forceinline__ uint64_t ht_hash(long long k) { return mix64((uint64_t)k); }
 __device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
   uint64_t s = ht_hash(k) & p.ht_mask;
   for (;;) {
