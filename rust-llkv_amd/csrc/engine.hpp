@@ -22,6 +22,15 @@ constexpr int kOctantsHost = kOctants;
 extern thread_local std::string g_last_error;
 int set_error(int code, const std::string &msg);
 
+// HIP call → status: returns from the calling function with the error recorded
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return llkv::set_error(_e == hipErrorNoDevice || _e == hipErrorInvalidDevice ? LLKV_NO_DEVICE : LLKV_INTERNAL, \
+                             std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+  } while (0)
+
 struct Context {
   std::mutex mu;
   bool ready = false;
@@ -213,6 +222,15 @@ struct Scratch { // RAII temporary
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Staging lanes (memory.cpp): host chunks → pinned rings → HBM, every piece complete on return.
+struct StagePiece {
+  void *d_dst;
+  const void *h_src;
+  size_t bytes;
+};
+int stage_to_device(const std::vector<StagePiece> &pieces);
+void staging_totals(uint64_t *bytes, double *seconds);
+void staging_release();
 // HBM → pageable host memory through the staging lanes (pinned rings, one copier thread each); the streams used are
 // the lanes' own: the data must be complete on the device before the call.
 int fetch_to_host(void *h_dst, const void *d_src, size_t bytes);

@@ -22,12 +22,6 @@
 
 namespace llkv {
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) return set_error(LLKV_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
-
 int finalize_value(const AggOut &a, const uint64_t *g, int base, llkv_value *out, std::string *err, bool prefixes_checked);
 
 struct SortedGroupBy {

@@ -25,12 +25,6 @@
 
 namespace llkv {
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) return set_error(LLKV_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
-
 namespace {
 using DB = Scratch;
 

@@ -1,0 +1,301 @@
+// memory.cpp — device scratch pool, recycled pinned host memory, result blocks, small read-backs and the
+// staging lanes (host ↔ HBM copies through pinned rings) of the MI355X path.
+#include "engine.hpp"
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <thread>
+#include <unordered_map>
+
+namespace llkv {
+
+// ---------------------------------------------------------------------------------
+// Scratch allocator
+// ---------------------------------------------------------------------------------
+namespace {
+std::mutex g_scratch_mu;
+std::multimap<size_t, void *> g_scratch_free;   // capacity → block
+std::map<void *, size_t> g_scratch_cap;          // live + cached blocks → capacity
+size_t g_scratch_cached = 0;
+constexpr size_t kScratchCacheLimit = 16ull << 30;
+} // namespace
+
+void *scratch_alloc(size_t bytes) {
+  size_t cap = 4096;
+  while (cap < bytes) cap <<= 1; // power-of-two classes: a freed block fits every later request of its class
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto it = g_scratch_free.find(cap);
+    if (it != g_scratch_free.end()) {
+      void *p = it->second;
+      g_scratch_free.erase(it);
+      g_scratch_cached -= cap;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    scratch_release_all(); // give cached blocks back and retry once
+    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  g_scratch_cap[p] = cap;
+  return p;
+}
+
+void scratch_free(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  auto it = g_scratch_cap.find(p);
+  if (it == g_scratch_cap.end()) return;
+  if (g_scratch_cached + it->second > kScratchCacheLimit) {
+    (void)hipFree(p);
+    g_scratch_cap.erase(it);
+    return;
+  }
+  g_scratch_free.emplace(it->second, p);
+  g_scratch_cached += it->second;
+}
+
+void scratch_release_all() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  for (auto &kv : g_scratch_free) { (void)hipFree(kv.second); g_scratch_cap.erase(kv.second); }
+  g_scratch_free.clear();
+  g_scratch_cached = 0;
+}
+
+// Staging: host chunks → pinned ring → hipMemcpyAsync → HBM (north_star: "pinned and hipMemcpyAsync'd into HBM").
+// One lane = one copy stream + a small ring of pinned buffers + one host thread filling them, so the memcpy into
+// pinned memory (the slow half: one core moves ~10 GB/s) runs on several cores while the DMA engines drain the
+// other lanes.  The lanes live for the life of the device binding (pinning memory per column costs more than the
+// copy of a small column).
+struct StagerPool {
+  static constexpr int kLanes = 6, kDepth = 2;
+  static constexpr size_t kBuf = 2u << 20;
+  struct Lane {
+    hipStream_t stream = nullptr;
+    void *pinned[kDepth] = {};
+    hipEvent_t done[kDepth] = {};
+    int cur = 0;
+  };
+  std::mutex mu; // one staging call at a time
+  Lane lanes[kLanes];
+  bool ready = false;
+  uint64_t staged_bytes = 0;
+  double staged_seconds = 0;
+
+  int init() {
+    if (ready) return LLKV_OK;
+    for (Lane &l : lanes) {
+      HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+      for (int i = 0; i < kDepth; ++i) {
+        HIP_TRY(hipHostMalloc(&l.pinned[i], kBuf, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&l.done[i], hipEventDisableTiming));
+      }
+    }
+    ready = true;
+    return LLKV_OK;
+  }
+  void release() {
+    for (Lane &l : lanes) {
+      for (int i = 0; i < kDepth; ++i) {
+        if (l.pinned[i]) (void)hipHostFree(l.pinned[i]);
+        if (l.done[i]) (void)hipEventDestroy(l.done[i]);
+        l.pinned[i] = nullptr;
+        l.done[i] = nullptr;
+      }
+      if (l.stream) (void)hipStreamDestroy(l.stream);
+      l.stream = nullptr;
+    }
+    ready = false;
+  }
+  // copies every piece and returns when all of them have arrived: host → HBM, or (`to_host`) HBM → pageable
+  // host memory, where d_dst / h_src swap roles (d_dst = device source, h_src = host destination)
+  int run(const std::vector<StagePiece> &pieces, bool to_host = false) {
+    std::lock_guard<std::mutex> lk(mu);
+    int rc = init();
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<StagePiece> seg;
+    size_t total = 0;
+    for (const StagePiece &p : pieces)
+      for (size_t off = 0; off < p.bytes; off += kBuf) {
+        seg.push_back({(char *)p.d_dst + off, (const char *)p.h_src + off, std::min(kBuf, p.bytes - off)});
+        total += seg.back().bytes;
+      }
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{LLKV_OK};
+    std::string message;
+    std::mutex message_mu;
+    auto work = [&](Lane &l) {
+      int r = ensure_device();
+      auto fail = [&](hipError_t e) {
+        std::lock_guard<std::mutex> g(message_mu);
+        if (failed.exchange(LLKV_INTERNAL) == LLKV_OK) message = std::string("staging copy failed: ") + hipGetErrorString(e);
+      };
+      if (r) { failed = r; std::lock_guard<std::mutex> g(message_mu); message = g_last_error; return; }
+      hipError_t e;
+      const StagePiece *pending[kDepth] = {}; // to_host: the segment whose bytes wait in pinned[k]
+      auto drain = [&](int k) -> bool {
+        if (!pending[k]) return true;
+        if ((e = hipEventSynchronize(l.done[k])) != hipSuccess) { fail(e); return false; }
+        std::memcpy(const_cast<void *>(pending[k]->h_src), l.pinned[k], pending[k]->bytes);
+        pending[k] = nullptr;
+        return true;
+      };
+      for (size_t i; failed == LLKV_OK && (i = next.fetch_add(1)) < seg.size();) {
+        if (to_host) {
+          if (!drain(l.cur)) return;
+          if ((e = hipMemcpyAsync(l.pinned[l.cur], seg[i].d_dst, seg[i].bytes, hipMemcpyDeviceToHost, l.stream)) != hipSuccess) return fail(e);
+          pending[l.cur] = &seg[i];
+        } else {
+          if ((e = hipEventSynchronize(l.done[l.cur])) != hipSuccess) return fail(e);
+          std::memcpy(l.pinned[l.cur], seg[i].h_src, seg[i].bytes);
+          if ((e = hipMemcpyAsync(seg[i].d_dst, l.pinned[l.cur], seg[i].bytes, hipMemcpyHostToDevice, l.stream)) != hipSuccess) return fail(e);
+        }
+        if ((e = hipEventRecord(l.done[l.cur], l.stream)) != hipSuccess) return fail(e);
+        l.cur = (l.cur + 1) % kDepth;
+      }
+      for (int k = 0; k < kDepth; ++k) // oldest first
+        if (!drain((l.cur + k) % kDepth)) return;
+      if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
+    };
+    const int n_threads = (int)std::min<size_t>(kLanes, (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
+    std::vector<std::thread> threads;
+    for (int k = 1; k < n_threads; ++k) threads.emplace_back(work, std::ref(lanes[k]));
+    work(lanes[0]);
+    for (std::thread &t : threads) t.join();
+    if (!to_host) {
+      staged_bytes += total;
+      staged_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (failed != LLKV_OK) return set_error(failed, message);
+    return LLKV_OK;
+  }
+};
+static StagerPool g_stager;
+
+// large results (row-id vectors) leave through the same lanes: HBM → pinned ring → the caller's pageable buffer
+int fetch_to_host(void *h_dst, const void *d_src, size_t bytes) {
+  if (bytes == 0) return LLKV_OK;
+  return g_stager.run({{const_cast<void *>(d_src), h_dst, bytes}}, true);
+}
+
+int stage_to_device(const std::vector<StagePiece> &pieces) { return g_stager.run(pieces); }
+void staging_totals(uint64_t *bytes, double *seconds) {
+  std::lock_guard<std::mutex> lk(g_stager.mu);
+  if (bytes) *bytes = g_stager.staged_bytes;
+  if (seconds) *seconds = g_stager.staged_seconds;
+}
+void staging_release() { g_stager.release(); }
+
+// ---- pinned host memory cache -------------------------------------------------------
+namespace {
+struct PinnedCache {
+  std::mutex mu;
+  std::vector<std::pair<void *, size_t>> free_blocks;
+  size_t cached = 0;
+  static constexpr size_t kMaxCached = 1ull << 30;
+} g_pinned;
+} // namespace
+
+void *pinned_acquire(size_t *bytes) {
+  size_t want = 4096;
+  while (want < *bytes) want <<= 1; // power-of-two classes: a block fits every later request of its class
+  *bytes = want;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    for (size_t i = 0; i < g_pinned.free_blocks.size(); ++i)
+      if (g_pinned.free_blocks[i].second == want) {
+        void *p = g_pinned.free_blocks[i].first;
+        g_pinned.free_blocks.erase(g_pinned.free_blocks.begin() + (long)i);
+        g_pinned.cached -= want;
+        return p;
+      }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void pinned_release(void *p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    if (g_pinned.cached + bytes <= PinnedCache::kMaxCached) {
+      g_pinned.free_blocks.emplace_back(p, bytes);
+      g_pinned.cached += bytes;
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+
+void pinned_release_all() {
+  std::lock_guard<std::mutex> lk(g_pinned.mu);
+  for (auto &b : g_pinned.free_blocks) (void)hipHostFree(b.first);
+  g_pinned.free_blocks.clear();
+  g_pinned.cached = 0;
+}
+
+// ---- large results handed to the caller ------------------------------------------------
+// A fresh malloc of hundreds of MB is page-faulted in while it is filled (≈ 6 GB/s); results of that size are
+// handed out in recycled pinned blocks instead, which the device writes at PCIe speed.  llkv_hip_free tells the
+// two kinds apart through this registry.
+namespace {
+std::mutex g_results_mu;
+std::unordered_map<void *, size_t> g_results;
+} // namespace
+
+void *result_acquire(size_t bytes) {
+  size_t got = bytes;
+  void *p = pinned_acquire(&got);
+  if (!p) return nullptr;
+  std::lock_guard<std::mutex> lk(g_results_mu);
+  g_results.emplace(p, got);
+  return p;
+}
+
+bool result_release(void *p) {
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_results_mu);
+    auto it = g_results.find(p);
+    if (it == g_results.end()) return false;
+    bytes = it->second;
+    g_results.erase(it);
+  }
+  pinned_release(p, bytes);
+  return true;
+}
+
+// ---- Readback ---------------------------------------------------------------------
+namespace {
+struct PinnedSlab {
+  void *p = nullptr;
+  ~PinnedSlab() { if (p) (void)hipHostFree(p); }
+};
+thread_local PinnedSlab t_readback;
+} // namespace
+
+int Readback::add(void *host_dst, const void *device_src, size_t bytes, hipStream_t s) {
+  if (!t_readback.p) HIP_TRY(hipHostMalloc(&t_readback.p, kBytes, hipHostMallocDefault));
+  const size_t off = (used + 7) & ~(size_t)7;
+  if (n == 8 || off + bytes > kBytes) return set_error(LLKV_INTERNAL, "read-back buffer exhausted");
+  HIP_TRY(hipMemcpyAsync((char *)t_readback.p + off, device_src, bytes, hipMemcpyDeviceToHost, s));
+  items[n++] = {host_dst, off, bytes};
+  used = off + bytes;
+  stream = s;
+  return LLKV_OK;
+}
+
+int Readback::wait() {
+  if (n) HIP_TRY(hipStreamSynchronize(stream));
+  for (int i = 0; i < n; ++i) std::memcpy(items[i].dst, (const char *)t_readback.p + items[i].off, items[i].bytes);
+  n = 0;
+  used = 0;
+  return LLKV_OK;
+}
+
+} // namespace llkv

@@ -11,12 +11,6 @@
 
 namespace llkv {
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) return set_error(LLKV_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
-
 static constexpr uint32_t kRowStreamChunk = 65536; // ROW_STREAM_CHUNK_SIZE, llkv-scan/src/execute.rs:31
 static constexpr uint32_t kSelectTileRows = 8192;
 

@@ -1,0 +1,473 @@
+// table.cpp — HBM-resident table images behind include/llkv_hip.h: chunk → tile → octant layout, staging of
+// columns (fixed width, Utf8 dictionary coding, Decimal128 narrowing, validity masks), column statistics.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <thread>
+
+namespace llkv {
+
+static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------
+// Table image
+// ---------------------------------------------------------------------------------
+Table::~Table() {
+  for (auto &kv : cols) {
+    if (kv.second.owned && kv.second.d_values) (void)hipFree(kv.second.d_values);
+    if (kv.second.d_valid) (void)hipFree(kv.second.d_valid);
+  }
+  for (auto &kv : tilesets) if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+}
+
+// Canonical octant bounds over the global chunk list and the shard of this rank
+// (DESIGN.md "Sharding").  Pure host logic: also exercised by the CPU tests.
+void compute_layout(Table &t) {
+  const uint32_t C = (uint32_t)t.global_chunk_rows.size();
+  for (int j = 0; j <= kOctantsHost; ++j) t.octant_chunk_begin[j] = (uint32_t)((uint64_t)j * C / kOctantsHost);
+  t.owned_mask = 0;
+  for (int o = 0; o < kOctantsHost; ++o)
+    if ((uint32_t)((uint64_t)o * t.world / kOctantsHost) == t.rank) t.owned_mask |= 1u << o;
+  int first_o = -1, last_o = -1;
+  for (int o = 0; o < kOctantsHost; ++o) if ((t.owned_mask >> o) & 1u) { if (first_o < 0) first_o = o; last_o = o; }
+  t.first_chunk = first_o < 0 ? 0 : t.octant_chunk_begin[first_o];
+  t.n_local_chunks = first_o < 0 ? 0 : t.octant_chunk_begin[last_o + 1] - t.first_chunk;
+  t.total_rows = 0;
+  t.local_logical_start = 0;
+  for (uint32_t c = 0; c < C; ++c) {
+    if (c == t.first_chunk) t.local_logical_start = t.total_rows;
+    t.total_rows += t.global_chunk_rows[c];
+  }
+  t.local_rows = 0;
+  t.chunk_dev_off.assign(t.n_local_chunks + 1, 0);
+  for (uint32_t c = 0; c < t.n_local_chunks; ++c) {
+    const uint64_t rows = t.global_chunk_rows[t.first_chunk + c];
+    t.local_rows += rows;
+    // every chunk starts on a 16-row boundary of the device image so that 16-byte loads of
+    // 8-byte columns and 2-byte loads of code columns stay aligned for ragged chunks
+    t.chunk_dev_off[c + 1] = round_up(t.chunk_dev_off[c] + rows, 16);
+  }
+  t.dev_rows = t.chunk_dev_off[t.n_local_chunks];
+}
+
+uint32_t octant_of_chunk(const Table &t, uint32_t global_chunk) {
+  for (int o = 0; o < kOctantsHost; ++o)
+    if (global_chunk >= t.octant_chunk_begin[o] && global_chunk < t.octant_chunk_begin[o + 1]) return (uint32_t)o;
+  return kOctantsHost - 1;
+}
+
+void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> &tiles, uint32_t (&octant_tile_begin)[kOctantsHost + 1]) {
+  tiles.clear();
+  uint64_t logical = t.local_logical_start;
+  std::vector<uint32_t> per_octant(kOctantsHost, 0);
+  for (uint32_t c = 0; c < t.n_local_chunks; ++c) {
+    const uint64_t rows = t.global_chunk_rows[t.first_chunk + c];
+    const uint32_t o = octant_of_chunk(t, t.first_chunk + c);
+    for (uint64_t r = 0; r < rows; r += tile_rows) {
+      TileDesc d;
+      d.dev_row = t.chunk_dev_off[c] + r;
+      d.logical_row = logical + r;
+      d.rows = (uint32_t)std::min<uint64_t>(tile_rows, rows - r);
+      d.octant = o;
+      tiles.push_back(d);
+      per_octant[o]++;
+    }
+    logical += rows;
+  }
+  octant_tile_begin[0] = 0;
+  for (int o = 0; o < kOctantsHost; ++o) octant_tile_begin[o + 1] = octant_tile_begin[o] + per_octant[o];
+}
+
+int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
+  Table &t = const_cast<Table &>(tc);
+  std::lock_guard<std::mutex> lk(t.mu);
+  auto it = t.tilesets.find(tile_rows);
+  if (it != t.tilesets.end()) { *out = &it->second; return LLKV_OK; }
+  TileSet ts;
+  std::vector<TileDesc> tiles;
+  build_tiles_host(t, tile_rows, tiles, ts.octant_tile_begin);
+  ts.n_tiles = (uint32_t)tiles.size();
+  ts.tile_rows = tile_rows;
+  if (ts.n_tiles) {
+    HIP_TRY(hipMalloc((void **)&ts.d_tiles, tiles.size() * sizeof(TileDesc)));
+    HIP_TRY(hipMemcpy(ts.d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+  }
+  auto ins = t.tilesets.emplace(tile_rows, ts);
+  *out = &ins.first->second;
+  return LLKV_OK;
+}
+
+static const uint64_t kSlackRows = 8192; // readable rows past the image end (unrolled tail steps)
+
+static int alloc_column(Table &t, uint32_t width, void **d_out) {
+  const uint64_t bytes = (t.dev_rows + kSlackRows) * width;
+  HIP_TRY(hipMalloc(d_out, bytes));
+  HIP_TRY(hipMemsetAsync(*d_out, 0, bytes, g_ctx.stream));
+  return LLKV_OK;
+}
+
+// host-side preparation of a column image (dictionary coding, bitmap expansion, Decimal128 narrowing) runs chunk
+// by chunk on a few threads; fn(chunk) returns a status, the first failure wins
+template <class Fn> static int for_each_chunk_parallel(uint32_t n_chunks, Fn &&fn) {
+  const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const unsigned n_threads = std::min<unsigned>(hw, std::max(1u, n_chunks / 4));
+  std::atomic<uint32_t> next{0};
+  std::atomic<int> failed{LLKV_OK};
+  std::string message;
+  std::mutex message_mu;
+  auto work = [&] {
+    for (uint32_t i; failed == LLKV_OK && (i = next.fetch_add(1)) < n_chunks;) {
+      const int rc = fn(i);
+      if (rc) {
+        std::lock_guard<std::mutex> g(message_mu);
+        if (failed.exchange(rc) == LLKV_OK) message = g_last_error;
+      }
+    }
+  };
+  std::vector<std::thread> threads;
+  for (unsigned k = 1; k < n_threads; ++k) threads.emplace_back(work);
+  work();
+  for (std::thread &t : threads) t.join();
+  if (failed != LLKV_OK) return set_error(failed, message);
+  return LLKV_OK;
+}
+
+static int column_stats_device(Table &t, DeviceColumn &c) {
+  if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
+  if (t.dev_rows == 0) return LLKV_OK;
+  int64_t init[2] = {INT64_MAX, INT64_MIN}, *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, sizeof init));
+  HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, g_ctx.stream));
+  // padding rows between ragged chunks are zero: they can only widen the range (safe side)
+  if (c.info.dtype == LLKV_DT_INT64 || c.info.dtype == LLKV_DT_DECIMAL128) HIP_TRY(launch_minmax_i64((const int64_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
+  else HIP_TRY(launch_minmax_i32((const int32_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
+  int64_t mm[2];
+  HIP_TRY(hipMemcpyAsync(mm, d, sizeof mm, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  (void)hipFree(d);
+  c.has_local_stats = true;
+  c.local_min = mm[0];
+  c.local_max = mm[1];
+  if (t.world == 1) { // plans must not depend on the shard: sharded tables get table-wide statistics from the binding
+    c.info.has_stats = true;
+    c.info.min_i = mm[0];
+    c.info.max_i = mm[1];
+  }
+  return LLKV_OK;
+}
+
+} // namespace llkv
+
+using namespace llkv;
+
+extern "C" {
+
+// ---- tables -------------------------------------------------------------------------
+llkv_status llkv_hip_table_create(uint16_t table_id, const uint64_t *global_chunk_rows, uint32_t n_global_chunks,
+                                  uint32_t rank, uint32_t world, llkv_hip_table **out) {
+  if (!out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "out is NULL");
+  if (world == 0 || world > (uint32_t)kOctantsHost || rank >= world)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "world must be 1..8 and rank < world");
+  if (n_global_chunks && !global_chunk_rows) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk rows is NULL");
+  auto *t = new Table();
+  t->table_id = table_id;
+  t->rank = rank;
+  t->world = world;
+  t->global_chunk_rows.assign(global_chunk_rows, global_chunk_rows + n_global_chunks);
+  compute_layout(*t);
+  *out = reinterpret_cast<llkv_hip_table *>(t);
+  return LLKV_OK;
+}
+
+void llkv_hip_table_free(llkv_hip_table *table) { delete reinterpret_cast<Table *>(table); }
+
+llkv_status llkv_hip_table_local_chunks(const llkv_hip_table *table, uint32_t *first, uint32_t *count) {
+  if (!table) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto *t = reinterpret_cast<const Table *>(table);
+  if (first) *first = t->first_chunk;
+  if (count) *count = t->n_local_chunks;
+  return LLKV_OK;
+}
+uint64_t llkv_hip_table_total_rows(const llkv_hip_table *table) { return table ? reinterpret_cast<const Table *>(table)->total_rows : 0; }
+uint64_t llkv_hip_table_local_rows(const llkv_hip_table *table) { return table ? reinterpret_cast<const Table *>(table)->local_rows : 0; }
+
+static int check_new_column(Table *t, uint32_t field_id, uint32_t n_chunks) {
+  if (!t) return set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  if (t->cols.count(field_id)) return set_error(LLKV_INVALID_ARGUMENT, "field " + std::to_string(field_id) + " already staged");
+  if (n_chunks != t->n_local_chunks)
+    return set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(t->n_local_chunks) + " local chunks, got " + std::to_string(n_chunks));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,
+                                         const void *const *chunk_values, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, n_chunks);
+  if (rc) return (llkv_status)rc;
+  const uint32_t w = dtype_width(dtype);
+  if (w == 0 || dtype == LLKV_DT_UTF8) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, std::string("append_column: unsupported dtype ") + dtype_name(dtype));
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = dtype;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  if ((rc = alloc_column(*t, w, &c.d_values))) return (llkv_status)rc;
+  std::vector<StagePiece> pieces;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    if (rows && !chunk_values[i]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
+    if (rows) pieces.push_back({(char *)c.d_values + t->chunk_dev_off[i] * w, chunk_values[i], rows * w});
+  }
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed"); // the image is zeroed
+  if ((rc = stage_to_device(pieces))) return (llkv_status)rc;
+  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t field_id,
+                                              const int32_t *const *chunk_offsets, const uint8_t *const *chunk_data,
+                                              uint32_t n_chunks, const char *const *dictionary, uint32_t dict_size) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, n_chunks);
+  if (rc) return (llkv_status)rc;
+  if (!dictionary && t->world > 1)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "sharded Utf8 columns need a table-wide dictionary (ranks must agree on the codes)");
+  if (dict_size > 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = LLKV_DT_UTF8;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  // dictionary-encode on the host at staging (SURVEY.md §7 "Utf8 group keys"): 1 B/row in HBM
+  std::vector<uint8_t> codes(t->dev_rows + 16, 0);
+  std::map<std::string, uint8_t> dict;
+  const bool fixed = dictionary != nullptr;
+  for (uint32_t d = 0; d < dict_size && fixed; ++d) {
+    std::string s = dictionary[d] ? dictionary[d] : "";
+    if (!dict.emplace(s, (uint8_t)d).second) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "duplicate dictionary entry '" + s + "'");
+    c.info.dictionary.push_back(s);
+  }
+  if (!fixed) {
+    // codes follow the order of first appearance: every chunk lists its distinct values in that order (in
+    // parallel), the lists are merged in chunk order
+    std::vector<std::vector<std::string>> seen(n_chunks);
+    rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
+      const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+      const int32_t *off = chunk_offsets[i];
+      const uint8_t *data = chunk_data[i];
+      bool one_byte[256] = {};
+      std::map<std::string, int> local;
+      for (uint64_t r = 0; r < rows; ++r) {
+        const int32_t len = off[r + 1] - off[r];
+        if (len == 1) {
+          const uint8_t ch = data[off[r]];
+          if (!one_byte[ch]) { one_byte[ch] = true; seen[i].emplace_back(1, (char)ch); }
+        } else {
+          std::string s((const char *)data + off[r], (size_t)len);
+          if (local.emplace(s, 0).second) seen[i].push_back(std::move(s));
+        }
+        if (seen[i].size() > 256) return set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+      }
+      return LLKV_OK;
+    });
+    if (rc) return (llkv_status)rc;
+    for (uint32_t i = 0; i < n_chunks; ++i)
+      for (std::string &s : seen[i])
+        if (!dict.count(s)) {
+          if (dict.size() >= 256) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Utf8 column has more than 256 distinct values");
+          dict.emplace(s, (uint8_t)dict.size());
+          c.info.dictionary.push_back(s);
+        }
+  }
+  rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    const int32_t *off = chunk_offsets[i];
+    const uint8_t *data = chunk_data[i];
+    uint8_t *dst = codes.data() + t->chunk_dev_off[i];
+    int16_t lut[256]; // fast path for 1-byte strings (TPC-H flags)
+    std::fill(std::begin(lut), std::end(lut), (int16_t)-1);
+    auto code_of = [&](const std::string &s, uint8_t *out) -> int {
+      auto it = dict.find(s);
+      if (it == dict.end()) return set_error(LLKV_INVALID_ARGUMENT, "value '" + s + "' is not in the supplied dictionary");
+      *out = it->second;
+      return LLKV_OK;
+    };
+    for (uint64_t r = 0; r < rows; ++r) {
+      const int32_t len = off[r + 1] - off[r];
+      int e;
+      if (len == 1) {
+        const uint8_t ch = data[off[r]];
+        if (lut[ch] < 0) {
+          uint8_t code;
+          if ((e = code_of(std::string(1, (char)ch), &code))) return e;
+          lut[ch] = code;
+        }
+        dst[r] = (uint8_t)lut[ch];
+      } else if ((e = code_of(std::string((const char *)data + off[r], (size_t)len), &dst[r]))) {
+        return e;
+      }
+    }
+    return LLKV_OK;
+  });
+  if (rc) return (llkv_status)rc;
+  if ((rc = alloc_column(*t, 1, &c.d_values))) return (llkv_status)rc;
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if ((rc = stage_to_device({{c.d_values, codes.data(), (size_t)t->dev_rows}}))) return (llkv_status)rc;
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint32_t field_id, int32_t *has_stats,
+                                              int64_t *min_value, int64_t *max_value) {
+  const Table *t = reinterpret_cast<const Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  if (has_stats) *has_stats = it->second.has_local_stats ? 1 : 0;
+  if (min_value) *min_value = it->second.local_min;
+  if (max_value) *max_value = it->second.local_max;
+  return LLKV_OK;
+}
+
+void llkv_hip_staging_stats(uint64_t *bytes, double *seconds) {
+  staging_totals(bytes, seconds);
+}
+
+llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t field_id, int64_t min_value, int64_t max_value) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  DeviceColumn &c = it->second;
+  if (min_value > max_value) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "min exceeds max");
+  // a bound that does not cover this rank's rows would make "provably no overflow" and dense group ids wrong
+  // (the local reduction also sees the zeroed padding rows between ragged chunks, so a local bound of 0 on a
+  // padded image proves nothing)
+  const bool padded = t->dev_rows != t->local_rows;
+  const bool lo_ok = min_value <= c.local_min || (padded && c.local_min == 0), hi_ok = max_value >= c.local_max || (padded && c.local_max == 0);
+  if (c.has_local_stats && t->local_rows && !(lo_ok && hi_ok))
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "column statistics do not cover the staged values");
+  c.info.has_stats = true;
+  c.info.min_i = min_value;
+  c.info.max_i = max_value;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint32_t field_id, int32_t precision, int32_t scale,
+                                                    const void *const *chunk_values, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, n_chunks);
+  if (rc) return (llkv_status)rc;
+  if (precision < 1 || precision > 38 || scale > precision || scale < -128)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "invalid Decimal128 precision/scale");
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  // narrow the 16-byte raw values to the 8 B/row device image; a value that needs more than 64 bits keeps the
+  // column on the caller's CPU route
+  std::vector<int64_t> narrow(t->dev_rows + 16, 0);
+  rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    if (rows && !chunk_values[i]) return set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
+    const int64_t *src = static_cast<const int64_t *>(chunk_values[i]); // (lo, hi) pairs, little endian
+    int64_t *dst = narrow.data() + t->chunk_dev_off[i];
+    for (uint64_t r = 0; r < rows; ++r) {
+      const int64_t lo = src[2 * r], hi = src[2 * r + 1];
+      if (hi != (lo >> 63)) return set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id));
+      dst[r] = lo;
+    }
+    return LLKV_OK;
+  });
+  if (rc) return (llkv_status)rc;
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = LLKV_DT_DECIMAL128;
+  c.info.precision = precision;
+  c.info.scale = scale;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  if ((rc = alloc_column(*t, 8, &c.d_values))) return (llkv_status)rc;
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
+  if ((rc = stage_to_device({{c.d_values, narrow.data(), (size_t)t->dev_rows * 8}}))) return (llkv_status)rc;
+  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_set_column_validity(llkv_hip_table *table, uint32_t field_id,
+                                               const uint8_t *const *chunk_validity, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  if (n_chunks != t->n_local_chunks)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(t->n_local_chunks) + " local chunks, got " + std::to_string(n_chunks));
+  if (!chunk_validity) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk validity array is NULL");
+  int rc = ensure_device();
+  if (rc) return (llkv_status)rc;
+  DeviceColumn &c = it->second;
+  // Arrow bitmaps → 1 B/row in the device row layout (rows of padding between chunks stay 0; tiles never
+  // select them)
+  std::vector<uint8_t> mask(t->dev_rows + 16, 0);
+  std::atomic<uint64_t> nulls{0};
+  rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    uint8_t *dst = mask.data() + t->chunk_dev_off[i];
+    const uint8_t *bits = chunk_validity[i];
+    if (!bits) { std::memset(dst, 1, rows); return LLKV_OK; }
+    uint64_t n = 0;
+    for (uint64_t r = 0; r < rows; ++r) {
+      const uint8_t v = (bits[r >> 3] >> (r & 7)) & 1u;
+      dst[r] = v;
+      n += !v;
+    }
+    nulls += n;
+    return LLKV_OK;
+  });
+  if (rc) return (llkv_status)rc;
+  if (c.d_valid) { (void)hipFree(c.d_valid); c.d_valid = nullptr; }
+  c.info.nullable = false;
+  // whether a column "has NULL cells" must not depend on the shard: with world > 1 any supplied bitmap makes
+  // the column nullable on every rank (plans must agree across ranks)
+  bool any_bitmap = false;
+  for (uint32_t i = 0; i < n_chunks; ++i) any_bitmap |= chunk_validity[i] != nullptr;
+  if (nulls == 0 && !(t->world > 1 && any_bitmap)) return LLKV_OK;
+  void *d = nullptr;
+  if ((rc = alloc_column(*t, 1, &d))) return (llkv_status)rc;
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) { (void)hipFree(d); return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed"); }
+  if ((rc = stage_to_device({{d, mask.data(), (size_t)t->dev_rows}}))) { (void)hipFree(d); return (llkv_status)rc; }
+  c.d_valid = (uint8_t *)d;
+  c.info.nullable = true;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,
+                                               const void *device_values) {
+  Table *t = reinterpret_cast<Table *>(table);
+  int rc = check_new_column(t, field_id, t ? t->n_local_chunks : 0);
+  if (rc) return (llkv_status)rc;
+  if ((rc = ensure_device())) return (llkv_status)rc;
+  const uint32_t w = dtype_width(dtype);
+  if (w == 0 || dtype == LLKV_DT_UTF8) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "adopt_device_column: unsupported dtype");
+  if (t->dev_rows != t->local_rows)
+    return (llkv_status)set_error(LLKV_UNSUPPORTED, "adopting device buffers needs chunk row counts that are multiples of 16");
+  DeviceColumn c;
+  c.info.field_id = field_id;
+  c.info.dtype = dtype;
+  c.info.rows = t->total_rows;
+  c.owned = true;
+  // the adopted buffer has no slack past its end; keep an owned image with slack instead
+  if ((rc = alloc_column(*t, w, &c.d_values))) return (llkv_status)rc;
+  if (hipMemcpyAsync(c.d_values, device_values, t->dev_rows * w, hipMemcpyDeviceToDevice, g_ctx.stream) != hipSuccess ||
+      hipStreamSynchronize(g_ctx.stream) != hipSuccess)
+    return (llkv_status)set_error(LLKV_INTERNAL, "device copy failed");
+  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
+  t->cols.emplace(field_id, std::move(c));
+  return LLKV_OK;
+}
+
+} // extern "C"
