@@ -100,6 +100,12 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
 int32_t orc_aggregate_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
                                const llkv_aggregate_spec *aggs, uint32_t n_aggs,
                                llkv_value *out_values, int32_t threads);
+/* … grouped by up to two one-character Utf8 columns (TPC-H Q1's flags); groups in key-byte order:
+ * out_keys[2g], out_keys[2g+1], out_values[g][n_aggs]. */
+int32_t orc_groupby_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
+                             const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs,
+                             uint32_t n_aggs, llkv_value *out_values, uint8_t *out_keys, uint32_t *out_groups,
+                             uint32_t max_groups, int32_t threads);
 
 void orc_free(void *p);
 

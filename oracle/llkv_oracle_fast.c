@@ -8,8 +8,9 @@
  * llkv-aggregate/src/lib.rs:759-1477) but fused and chunk-parallel: each worker walks
  * whole chunks of 131 072 rows (llkv-column-map/src/store/constants.rs:22) in blocks of
  * 2 048 rows, partial states are combined in chunk order.  Restricted to what the
- * benchmark queries need: conjunction of leaf filters on non-NULL columns, ungrouped
- * SUM/COUNT/AVG/MIN/MAX over i64/f64 expressions.
+ * benchmark queries need: conjunction of leaf filters on non-NULL columns,
+ * SUM/COUNT/AVG/MIN/MAX over i64/f64 expressions, ungrouped or grouped by up to two
+ * one-character Utf8 columns (TPC-H Q1's flags: dense group ids from the byte values).
  */
 #define _GNU_SOURCE
 #include "llkv_oracle.h"
@@ -56,7 +57,11 @@ typedef struct fjob {
   const fagg *aggs;
   uint32_t n_aggs;
   uint64_t n_chunks;
-  fstate *partials; /* [n_chunks][n_aggs] */
+  /* grouped: key k of row r has the dense code code[k][key_data[k][r]]; group = code0 * card1 + code1 */
+  uint32_t n_keys, ng, card1;
+  const uint8_t *key_data[2];
+  uint8_t code[2][256];
+  fstate *partials; /* [n_chunks][ng][n_aggs] */
   uint64_t next_chunk;
   pthread_mutex_t mu;
 } fjob;
@@ -139,12 +144,13 @@ static void *worker(void *arg) {
   double (*fst)[BLOCK] = malloc(sizeof(double) * BLOCK * 8);
   int64_t (*ist)[BLOCK] = malloc(sizeof(int64_t) * BLOCK * 8);
   uint8_t *mask = malloc(BLOCK);
+  uint16_t *gid = malloc(BLOCK * sizeof(uint16_t));
   for (;;) {
     pthread_mutex_lock(&j->mu);
     uint64_t c = j->next_chunk++;
     pthread_mutex_unlock(&j->mu);
     if (c >= j->n_chunks) break;
-    fstate *st = &j->partials[c * j->n_aggs];
+    fstate *st0 = &j->partials[c * j->ng * j->n_aggs];
     uint64_t r0 = c * CHUNK_ROWS, r1 = r0 + CHUNK_ROWS < j->t->rows ? r0 + CHUNK_ROWS : j->t->rows;
     for (uint64_t b = r0; b < r1; b += BLOCK) {
       uint32_t n = (uint32_t)(r1 - b < BLOCK ? r1 - b : BLOCK);
@@ -153,14 +159,26 @@ static void *worker(void *arg) {
       uint32_t any = 0;
       for (uint32_t i = 0; i < n; ++i) any += mask[i];
       if (!any) continue;
-      for (uint32_t a = 0; a < j->n_aggs; ++a) {
+      if (j->n_keys) {
+        for (uint32_t i = 0; i < n; ++i) {
+          uint32_t g = j->code[0][j->key_data[0][b + i]];
+          if (j->n_keys > 1) g = g * j->card1 + j->code[1][j->key_data[1][b + i]];
+          gid[i] = (uint16_t)g;
+        }
+      }
+      const uint32_t na = j->n_aggs;
+      for (uint32_t a = 0; a < na; ++a) {
         const fagg *ag = &j->aggs[a];
-        fstate *s = &st[a];
-        if (ag->kind == LLKV_AGG_COUNT_STAR) { s->count += any; continue; }
+        if (ag->kind == LLKV_AGG_COUNT_STAR) {
+          if (!j->n_keys) st0[a].count += any;
+          else for (uint32_t i = 0; i < n; ++i) if (mask[i]) st0[gid[i] * na + a].count++;
+          continue;
+        }
         eval_block(j->t, ag, b, n, fst, ist);
         if (ag->is_f64) {
           const double *v = fst[0];
           for (uint32_t i = 0; i < n; ++i) if (mask[i]) {
+            fstate *s = &st0[(j->n_keys ? gid[i] : 0) * na + a];
             double x = v[i];
             s->fsum += x; s->count++;
             if (!s->has) { s->fmin = s->fmax = x; s->has = 1; } else { if (x < s->fmin) s->fmin = x; if (x > s->fmax) s->fmax = x; }
@@ -168,6 +186,7 @@ static void *worker(void *arg) {
         } else {
           const int64_t *v = ist[0];
           for (uint32_t i = 0; i < n; ++i) if (mask[i]) {
+            fstate *s = &st0[(j->n_keys ? gid[i] : 0) * na + a];
             int64_t x = v[i];
             s->isum += x; s->fsum += (double)x; s->count++;
             if (!s->has) { s->imin = s->imax = x; s->has = 1; } else { if (x < s->imin) s->imin = x; if (x > s->imax) s->imax = x; }
@@ -176,14 +195,15 @@ static void *worker(void *arg) {
       }
     }
   }
-  free(fst); free(ist); free(mask);
+  free(fst); free(ist); free(mask); free(gid);
   return NULL;
 }
 
 static __thread char g_ferr[256];
 
-int32_t orc_aggregate_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
-                               const llkv_aggregate_spec *aggs, uint32_t n_aggs, llkv_value *out_values, int32_t threads) {
+static int32_t run_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters, const uint32_t *key_fields, uint32_t n_keys,
+                            const llkv_aggregate_spec *aggs, uint32_t n_aggs, llkv_value *out_values, uint8_t *out_keys, uint32_t *out_groups,
+                            uint32_t max_groups, int32_t threads) {
   (void)g_ferr;
   fpred *preds = calloc(n_filters ? n_filters : 1, sizeof(fpred));
   fagg *fa = calloc(n_aggs ? n_aggs : 1, sizeof(fagg));
@@ -223,24 +243,51 @@ int32_t orc_aggregate_parallel(const orc_table *t, const llkv_filter *filters, u
   memset(&j, 0, sizeof j);
   j.t = t; j.preds = preds; j.n_preds = n_filters; j.aggs = fa; j.n_aggs = n_aggs;
   j.n_chunks = (t->rows + CHUNK_ROWS - 1) / CHUNK_ROWS;
-  j.partials = calloc((j.n_chunks ? j.n_chunks : 1) * (n_aggs ? n_aggs : 1), sizeof(fstate));
+  j.ng = 1;
+  uint8_t values[2][256];
+  uint32_t card[2] = {1, 1};
+  if (n_keys > 2) { free(preds); free(fa); return LLKV_UNSUPPORTED; }
+  for (uint32_t k = 0; k < n_keys; ++k) { /* one-character strings: Arrow offsets 0..n, the data bytes are the keys */
+    const orc_column *c = fcol(t, key_fields[k]);
+    if (!c || c->dtype != LLKV_DT_UTF8 || c->validity || (t->rows && (c->offsets[t->rows] != (int32_t)t->rows))) { free(preds); free(fa); return LLKV_UNSUPPORTED; }
+    uint8_t seen[256] = {0};
+    for (uint64_t r = 0; r < t->rows; ++r) seen[c->data[r]] = 1;
+    card[k] = 0;
+    for (int v = 0; v < 256; ++v) if (seen[v]) { j.code[k][v] = (uint8_t)card[k]; values[k][card[k]++] = (uint8_t)v; }
+    if (card[k] == 0) card[k] = 1;
+    j.key_data[k] = c->data;
+  }
+  j.n_keys = n_keys;
+  j.card1 = card[1];
+  j.ng = card[0] * card[1];
+  j.partials = calloc((j.n_chunks ? j.n_chunks : 1) * j.ng * (n_aggs ? n_aggs : 1), sizeof(fstate));
   pthread_mutex_init(&j.mu, NULL);
   int nt = threads > 0 ? threads : 1;
   pthread_t *th = malloc(sizeof(pthread_t) * nt);
   for (int i = 0; i < nt; ++i) pthread_create(&th[i], NULL, worker, &j);
   for (int i = 0; i < nt; ++i) pthread_join(th[i], NULL);
+  uint32_t n_out = 0;
+  for (uint32_t g = 0; g < j.ng; ++g) {
+  uint64_t group_rows = 0;
+  for (uint64_t c = 0; c < j.n_chunks && n_aggs; ++c) {
+    const fstate *p = &j.partials[(c * j.ng + g) * n_aggs];
+    for (uint32_t a = 0; a < n_aggs; ++a) group_rows += (uint64_t)p[a].count;
+  }
+  if (n_keys && group_rows == 0) continue; /* a key combination without a selected row is no group */
+  if (n_out == max_groups) break;
+  if (out_keys) { out_keys[2 * n_out] = values[0][g / j.card1]; out_keys[2 * n_out + 1] = n_keys > 1 ? values[1][g % j.card1] : 0; }
   for (uint32_t a = 0; a < n_aggs; ++a) { /* combine in chunk order */
     fstate s;
     memset(&s, 0, sizeof s);
     for (uint64_t c = 0; c < j.n_chunks; ++c) {
-      const fstate *p = &j.partials[c * n_aggs + a];
+      const fstate *p = &j.partials[(c * j.ng + g) * n_aggs + a];
       s.fsum += p->fsum; s.isum += p->isum; s.count += p->count;
       if (p->has) {
         if (!s.has) { s = (fstate){s.fsum, s.isum, s.count, p->fmin, p->fmax, p->imin, p->imax, 1}; }
         else { if (p->fmin < s.fmin) s.fmin = p->fmin; if (p->fmax > s.fmax) s.fmax = p->fmax; if (p->imin < s.imin) s.imin = p->imin; if (p->imax > s.imax) s.imax = p->imax; }
       }
     }
-    llkv_value *o = &out_values[a];
+    llkv_value *o = &out_values[(size_t)n_out * n_aggs + a];
     memset(o, 0, sizeof *o);
     int isf = fa[a].is_f64;
     switch (fa[a].kind) {
@@ -253,7 +300,24 @@ int32_t orc_aggregate_parallel(const orc_table *t, const llkv_filter *filters, u
     default: break;
     }
   }
+  ++n_out;
+  }
+  if (out_groups) *out_groups = n_out;
   pthread_mutex_destroy(&j.mu);
   free(th); free(j.partials); free(preds); free(fa);
   return LLKV_OK;
+}
+
+int32_t orc_aggregate_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,
+                               const llkv_aggregate_spec *aggs, uint32_t n_aggs, llkv_value *out_values, int32_t threads) {
+  return run_parallel(t, filters, n_filters, NULL, 0, aggs, n_aggs, out_values, NULL, NULL, 1, threads);
+}
+
+/* GROUP BY up to two one-character Utf8 columns; groups come out in key-byte order: out_keys[2g], out_keys[2g+1],
+ * out_values[g][n_aggs]; *out_groups ≤ max_groups. */
+int32_t orc_groupby_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters, const uint32_t *key_fields, uint32_t n_keys,
+                             const llkv_aggregate_spec *aggs, uint32_t n_aggs, llkv_value *out_values, uint8_t *out_keys,
+                             uint32_t *out_groups, uint32_t max_groups, int32_t threads) {
+  if (n_keys == 0 || !out_keys || !out_groups) return LLKV_INVALID_ARGUMENT;
+  return run_parallel(t, filters, n_filters, key_fields, n_keys, aggs, n_aggs, out_values, out_keys, out_groups, max_groups, threads);
 }

@@ -150,6 +150,19 @@ def aggregate_parallel(table: OracleTable, filters, aggs, threads: int) -> List[
     return [abi.Value.from_c(out[i]) for i in range(len(aggs))]
 
 
+def groupby_parallel(table: OracleTable, filters, keys: Sequence[int], aggs, threads: int, max_groups: int = 256):
+    """Chunk-parallel fused GROUP BY over up to two one-character Utf8 columns: [(key strings, [Value])] in key order."""
+    p = abi.CPlan(list(filters), aggs, keys)
+    t = table.c()
+    out = (abi.CValue * max(1, len(aggs) * max_groups))()
+    kbytes = (C.c_uint8 * (2 * max_groups))()
+    n = C.c_uint32()
+    check(lib().orc_groupby_parallel(C.byref(t), p.filters, p.n_filters, p.keys, p.n_keys, p.aggs, p.n_aggs, out, kbytes, C.byref(n),
+                                     C.c_uint32(max_groups), C.c_int32(threads)))
+    return [([chr(kbytes[2 * g + k]) for k in range(len(keys))], [abi.Value.from_c(out[g * len(aggs) + a]) for a in range(len(aggs))])
+            for g in range(n.value)]
+
+
 class GroupRow:
     def __init__(self, keys, values):
         self.keys, self.values = keys, values

@@ -225,6 +225,12 @@ def test_q6_against_numpy(orc, abi, tpch):
         assert r.values[0].value == int(d["l_quantity"][sel].sum())
         assert r.values[7].value == int(sel.sum())
         assert abs(r.values[1].value - d["l_extendedprice"][sel].sum()) <= 1e-9 * r.values[1].value
+    # the chunk-parallel fused mode (the "best-effort parallel" CPU baseline) against the reference-faithful one
+    par = orc.groupby_parallel(t, q1.predicate, q1.keys, q1.aggs, 4)
+    assert [tuple(k) for k, _ in par] == [tuple(k.value for k in r.keys) for r in rows]
+    for (_, pv), r in zip(par, rows):
+        for a, b in zip(pv, r.values):
+            assert a.value == b.value if isinstance(b.value, int) else abs(a.value - b.value) <= 1e-9 * abs(b.value)
 
 
 def test_mvcc_visibility_rules(orc, abi):
