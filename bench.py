@@ -222,12 +222,20 @@ def cpu_baseline(tpch, abi, query, sf, sample_rows):
     dt = time.perf_counter() - t0
     out = {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
            "sample": f"first {rows} lineitem rows of {query.name}_{sf}, reference-faithful sequential oracle, {dt:.2f} s"}
+    try:  # context for both figures: what the host is
+        model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
+    except OSError:
+        model = "unknown"
+    out["host"] = {"cpu_model": model, "logical_cpus": os.cpu_count(), "threads_used_parallel": host_threads(),
+                   "stream_triad_gbs": round(orc.stream_triad(50_000_000, host_threads()), 1)}
     if query.grouped:
         threads = host_threads()
         try:
-            t0 = time.perf_counter()
-            orc.groupby_parallel(t, query.predicate, query.keys, query.aggs, threads)
-            pdt = time.perf_counter() - t0
+            pdt = float("inf")
+            for _ in range(3):  # best of three: the first pass also faults the sample's pages into this process
+                t0 = time.perf_counter()
+                orc.groupby_parallel(t, query.predicate, query.keys, query.aggs, threads)
+                pdt = min(pdt, time.perf_counter() - t0)
             out["parallel"] = {"value": rows / pdt, "unit": "rows/s", "cores": threads,
                                "sample": f"{rows} rows, chunk-parallel fused oracle, {pdt:.3f} s"}
         except Exception:  # key shapes the fused mode does not take: only the faithful mode is reported
@@ -241,9 +249,11 @@ def cpu_baseline(tpch, abi, query, sf, sample_rows):
             for name in query.columns:
                 fid, dtp = tpch.LINEITEM_SCHEMA[name]
                 t.add(fid, dtp, data[name])
-        t0 = time.perf_counter()
-        orc.aggregate_parallel(t, query.predicate, query.aggs, threads)
-        pdt = time.perf_counter() - t0
+        pdt = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.aggregate_parallel(t, query.predicate, query.aggs, threads)
+            pdt = min(pdt, time.perf_counter() - t0)
         out["parallel"] = {"value": prows / pdt, "unit": "rows/s", "cores": threads,
                            "sample": f"{prows} rows, chunk-parallel fused oracle, {pdt:.3f} s"}
     return out

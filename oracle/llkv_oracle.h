@@ -106,6 +106,8 @@ int32_t orc_groupby_parallel(const orc_table *t, const llkv_filter *filters, uin
                              const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs,
                              uint32_t n_aggs, llkv_value *out_values, uint8_t *out_keys, uint32_t *out_groups,
                              uint32_t max_groups, int32_t threads);
+/* STREAM-like triad over `threads` threads, GB/s (best of `reps`): the host's memory bandwidth, for context. */
+double orc_stream_triad(uint64_t n, int32_t threads, int32_t reps);
 
 void orc_free(void *p);
 

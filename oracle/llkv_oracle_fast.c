@@ -321,3 +321,39 @@ int32_t orc_groupby_parallel(const orc_table *t, const llkv_filter *filters, uin
   if (n_keys == 0 || !out_keys || !out_groups) return LLKV_INVALID_ARGUMENT;
   return run_parallel(t, filters, n_filters, key_fields, n_keys, aggs, n_aggs, out_values, out_keys, out_groups, max_groups, threads);
 }
+
+
+/* STREAM-like triad a = b + s·c over `threads` threads (context for the CPU baseline: the host's memory bandwidth).
+ * Returns GB/s over 3 × 8 bytes per element, best of `reps`. */
+typedef struct triad_job { double *a; const double *b, *c; uint64_t lo, hi; } triad_job;
+static void *triad_worker(void *arg) {
+  triad_job *j = arg;
+  for (uint64_t i = j->lo; i < j->hi; ++i) j->a[i] = j->b[i] + 3.0 * j->c[i];
+  return NULL;
+}
+#include <time.h>
+double orc_stream_triad(uint64_t n, int32_t threads, int32_t reps) {
+  if (threads < 1) threads = 1;
+  double *a = malloc(n * 8), *b = malloc(n * 8), *c = malloc(n * 8);
+  if (!a || !b || !c) { free(a); free(b); free(c); return 0.0; }
+  for (uint64_t i = 0; i < n; ++i) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+  pthread_t *th = malloc(sizeof(pthread_t) * threads);
+  triad_job *jobs = malloc(sizeof(triad_job) * threads);
+  double best = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; ++t) {
+      jobs[t] = (triad_job){a, b, c, n * t / threads, n * (t + 1) / threads};
+      pthread_create(&th[t], NULL, triad_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double sec = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    double gbs = 24.0 * (double)n / sec / 1e9;
+    if (gbs > best) best = gbs;
+  }
+  double check = a[n / 2];
+  free(a); free(b); free(c); free(th); free(jobs);
+  return check == 7.0 ? best : 0.0;
+}

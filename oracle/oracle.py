@@ -150,6 +150,13 @@ def aggregate_parallel(table: OracleTable, filters, aggs, threads: int) -> List[
     return [abi.Value.from_c(out[i]) for i in range(len(aggs))]
 
 
+def stream_triad(n: int, threads: int, reps: int = 3) -> float:
+    """GB/s of a = b + s·c over ``threads`` host threads."""
+    f = lib().orc_stream_triad
+    f.restype = C.c_double
+    return float(f(C.c_uint64(n), C.c_int32(threads), C.c_int32(reps)))
+
+
 def groupby_parallel(table: OracleTable, filters, keys: Sequence[int], aggs, threads: int, max_groups: int = 256):
     """Chunk-parallel fused GROUP BY over up to two one-character Utf8 columns: [(key strings, [Value])] in key order."""
     p = abi.CPlan(list(filters), aggs, keys)
