@@ -287,6 +287,77 @@ def test_full_size_properties_sf10(rt, abi, tpch, name):
             assert abs(r.values[6].value - disc.sum() / g.sum()) <= REL
 
 
+def test_full_size_selection_join_and_q3_sf10(rt, abi, tpch):
+    """BASELINE.json sizes for the other routes (SF10: 59 986 052 lineitems, 14 996 513 orders, 1 500 000 customers),
+    checked through properties numpy can state: the row-id vector of Q6's predicate, the scan windows, the pair
+    sequence of lineitem ⋈ orders (every lineitem has exactly one order), and Q3's top 10 (configs[4])."""
+    n = tpch.LINEITEM_ROWS["sf10"]
+    scale = tpch.SCALE["sf10"]
+    li = tpch.gen_lineitem(n, scale, ["l_orderkey", "l_quantity", "l_shipdate", "l_extendedprice", "l_discount"])
+    lt = rt.HipTable(1, tpch.chunk_rows(n))
+    for c in li:
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
+    # ---- selection-vector route
+    q6 = tpch.q6()
+    m = (li["l_shipdate"] >= 8766) & (li["l_shipdate"] < 9131) & (li["l_discount"] >= 0.05) & (li["l_discount"] <= 0.07) & (li["l_quantity"] < 24)
+    ids = rt.filter_row_ids(lt, q6.predicate)
+    assert np.array_equal(ids, np.flatnonzero(m).astype(np.uint64))
+    import ctypes as C
+    seen = []
+
+    def consume(b):
+        k = int(b.num_rows)
+        seen.append((k, int(b.row_ids[0]), int(b.row_ids[k - 1]), float(np.ctypeslib.as_array(C.cast(b.columns[0].values, C.POINTER(C.c_double)), shape=(k,)).sum())))
+
+    rt.scan_stream(lt, [abi.col(tpch.L_EXTENDEDPRICE) * abi.col(tpch.L_DISCOUNT)], q6.predicate, include_row_ids=True, consume=consume)
+    assert [k for k, *_ in seen] == [65536] * (len(ids) // 65536) + ([len(ids) % 65536] if len(ids) % 65536 else [])
+    assert [a for _, a, _, _ in seen] == [int(ids[w]) for w in range(0, len(ids), 65536)]
+    want = float((li["l_extendedprice"][m] * li["l_discount"][m]).sum())
+    assert abs(sum(x for *_, x in seen) - want) <= REL * want
+    # ---- join_stream: lineitem ⋈ orders
+    n_ord = tpch.orders_for_lineitems(n)
+    od = tpch.gen_orders(n_ord, scale)
+    ot_ = rt.HipTable(2, tpch.chunk_rows(n_ord))
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c])
+    assert np.all(np.diff(od["o_orderkey"]) > 0)
+    order_of = np.searchsorted(od["o_orderkey"], li["l_orderkey"])
+    state = {"pairs": 0, "ok": True}
+    CB = abi.ON_JOIN_BATCH
+    def on_pairs(pl, pr, k, _u):
+        l = np.ctypeslib.as_array(pl, shape=(k,)); r = np.ctypeslib.as_array(pr, shape=(k,))
+        p0 = state["pairs"]
+        state["ok"] &= bool(l[0] == p0 and l[-1] == p0 + k - 1 and np.array_equal(r, order_of[p0:p0 + k].astype(np.uint64)))
+        state["pairs"] += k
+    ck = (abi.CJoinKey * 1)(); ck[0].left_field, ck[0].right_field, ck[0].null_equals_null = tpch.L_ORDERKEY, tpch.O_ORDERKEY, 0
+    opts = abi.CJoinOptions(abi.JOIN_INNER, 65536, 0)
+    cb = CB(on_pairs)
+    rt.check(rt.lib().llkv_hip_join_stream(lt.handle, ot_.handle, ck, C.c_uint32(1), C.byref(opts), cb, None))
+    assert state["pairs"] == n and state["ok"]
+    # ---- Q3 (configs[4], single GPU)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    ct = rt.HipTable(3, tpch.chunk_rows(n_cust))
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]])
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    D = tpch.DATE_1995_03_15
+    got, total = rt.join_groupby_topk(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY,
+                                      col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT)), payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10,
+                                      dim_fk=tpch.O_CUSTKEY, dim2=ct, dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    building = np.zeros(int(cu["c_custkey"].max()) + 1, dtype=bool)
+    building[cu["c_custkey"][cu["c_mktsegment"] == list(tpch.SEGMENTS).index("BUILDING")]] = True
+    o_ok = (od["o_orderdate"] < D) & building[od["o_custkey"]]
+    l_ok = (li["l_shipdate"] > D) & o_ok[order_of]
+    rev = np.bincount(order_of[l_ok], weights=(li["l_extendedprice"][l_ok] * (1 - li["l_discount"][l_ok])), minlength=n_ord)
+    cnt = np.bincount(order_of[l_ok], minlength=n_ord)
+    assert total == int((cnt > 0).sum())
+    top = sorted(np.flatnonzero(cnt > 0).tolist(), key=lambda i: (-rev[i], od["o_orderdate"][i]))[:10]
+    assert [r[0] for r in got] == [int(od["o_orderkey"][i]) for i in top]
+    for r, i in zip(got, top):
+        assert r[2] == int(cnt[i]) and r[3] == int(od["o_orderdate"][i]) and abs(r[1] - rev[i]) <= REL * rev[i]
+
+
 TABLE = golden("table_scan.json")
 
 
