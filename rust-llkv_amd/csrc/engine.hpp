@@ -59,6 +59,10 @@ struct TileSet {
   TileDesc *d_tiles = nullptr;
   uint32_t n_tiles = 0;
   uint32_t tile_rows = 0;
+  // every kTileSampleStride-th tile, for selectivity estimates (stream.cpp: run_selection_lowered)
+  TileDesc *d_sample = nullptr;
+  uint32_t n_sample = 0;
+  uint64_t sample_rows = 0;
   uint32_t octant_tile_begin[kOctantsHost + 1] = {0};
 };
 
@@ -275,9 +279,12 @@ struct KeySetView {
   int64_t kmin;
   uint64_t span;
 };
-// `single_pass`: evaluate the predicate once (striped output + compaction) instead of count pass + write pass —
-// pays when the predicate is expensive (table gathers) or few rows pass
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr, bool single_pass = false);
+// `single_pass`: 1 = evaluate the predicate once (striped output + compaction), 0 = count pass + write pass, −1 = decide
+// from a sample of the tiles: one pass moves 48 B per selected row beside the predicate columns, two passes read the
+// predicate columns twice and move 16 B per selected row — one pass pays when few rows pass or the predicate is wide
+// or gathers from a table
+constexpr uint32_t kTileSampleStride = 64;
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr, int single_pass = -1);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

@@ -182,7 +182,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     std::string err;
     if ((rc = lower_selection_in_set(resolve_d, dim->filters, dim->n_filters, dim_fk_field, &sel_plan, &err))) return set_error(rc, err);
     const KeySetView view{(const uint64_t *)set2_bits.bits.p, set2_bits.kmin, set2_bits.span};
-    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, true))) return rc; // the bit test gathers: evaluate it once
+    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, 1))) return rc; // the bit test gathers: evaluate it once
   } else if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) {
     return rc;
   }

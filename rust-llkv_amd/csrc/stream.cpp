@@ -44,7 +44,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
 }
 
 // The selection kernels of an already lowered predicate (prepared statements keep the plan).
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, bool single_pass) {
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, int single_pass_mode) {
   int rc;
   std::string err;
   scratch_free(sel->d_ids); sel->d_ids = nullptr;
@@ -73,6 +73,28 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
     p.bm_bits = key_set->bits;
     p.bm_min = key_set->kmin;
     p.bm_span = key_set->span;
+  }
+  bool single_pass = single_pass_mode == 1;
+  if (single_pass_mode < 0 && ts->n_sample >= 8 && !std::getenv("LLKV_HIP_SELECT_TWO_PASS")) {
+    // selectivity from every 64th tile (1.6 % of the predicate columns, one more small launch)
+    const uint32_t sample_slots = ts->n_sample * (kBlock / 64);
+    DeviceBuf sample_counts;
+    if ((rc = sample_counts.alloc((size_t)sample_slots * 8))) return rc;
+    ScanParams ps = p;
+    ps.tiles = ts->d_sample;
+    ps.n_tiles = ts->n_sample;
+    ps.tile_partials = (uint64_t *)sample_counts.p;
+    if ((rc = jit_launch_raw(k.fn, ts->n_sample, &ps, sizeof ps, stream))) return rc;
+    std::vector<uint64_t> hc(sample_slots);
+    Readback rb;
+    if (sample_slots * 8 <= Readback::kBytes) {
+      if ((rc = rb.add(hc.data(), sample_counts.p, (size_t)sample_slots * 8, stream)) || (rc = rb.wait())) return rc;
+      uint64_t hit = 0;
+      bool err_bit = false;
+      for (uint64_t c : hc) { err_bit |= c >= kPredErrorBit; hit += c; }
+      // one pass: P + 48 s bytes per row; two passes: 2 P + 16 s  →  one pass when 32 s < P
+      if (!err_bit && ts->sample_rows) single_pass = 32.0 * (double)hit / (double)ts->sample_rows < (double)plan.bytes_per_row;
+    }
   }
   DeviceBuf stripe_ids, stripe_dev;
   if (single_pass) {

@@ -20,7 +20,10 @@ Table::~Table() {
     if (kv.second.owned && kv.second.d_values) (void)hipFree(kv.second.d_values);
     if (kv.second.d_valid) (void)hipFree(kv.second.d_valid);
   }
-  for (auto &kv : tilesets) if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+  for (auto &kv : tilesets) {
+    if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+    if (kv.second.d_sample) (void)hipFree(kv.second.d_sample);
+  }
 }
 
 // Canonical octant bounds over the global chunk list and the shard of this rank
@@ -94,6 +97,13 @@ int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
   if (ts.n_tiles) {
     HIP_TRY(hipMalloc((void **)&ts.d_tiles, tiles.size() * sizeof(TileDesc)));
     HIP_TRY(hipMemcpy(ts.d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    std::vector<TileDesc> sample;
+    for (size_t i = kTileSampleStride / 2; i < tiles.size(); i += kTileSampleStride) { sample.push_back(tiles[i]); ts.sample_rows += tiles[i].rows; }
+    ts.n_sample = (uint32_t)sample.size();
+    if (ts.n_sample) {
+      HIP_TRY(hipMalloc((void **)&ts.d_sample, sample.size() * sizeof(TileDesc)));
+      HIP_TRY(hipMemcpy(ts.d_sample, sample.data(), sample.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    }
   }
   auto ins = t.tilesets.emplace(tile_rows, ts);
   *out = &ins.first->second;
