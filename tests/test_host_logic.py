@@ -29,6 +29,38 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.llkv_hip_abi_version() == 1
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: the header compiles as pedantic C99 and a C program links against the library
+    and calls through it (what a cgo / Rust FFI binding does).  Without a device the data path says so."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('''#include "llkv_hip.h"
+#include <stdio.h>
+int main(void) {
+  uint64_t rows[1] = {4};
+  llkv_hip_table *t = 0;
+  if (llkv_hip_abi_version() != LLKV_HIP_ABI_VERSION) return 1;
+  if (llkv_hip_table_create(1, rows, 1, 0, 1, &t) != LLKV_OK) return 2;   /* host-only: the chunk layout */
+  if (llkv_hip_table_total_rows(t) != 4) return 3;
+  if (llkv_hip_device_count() == 0) {
+    const long long v[4] = {1, 2, 3, 4};
+    const void *chunks[1] = {v};
+    if (llkv_hip_table_append_column(t, 1, LLKV_DT_INT64, chunks, 1) != LLKV_NO_DEVICE) return 4;
+    if (!llkv_hip_last_error()[0]) return 5;
+  }
+  llkv_hip_table_free(t);
+  puts("ok");
+  return 0;
+}
+''')
+    libdir = os.path.join(ROOT, "rust-llkv_amd")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-L", libdir, "-lllkv_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
+
+
 def test_generator_library_exports_every_declared_symbol(tpch):
     g = tpch.gen_lib()
     missing = [n for n in declared_functions("llkv_tpch_gen.h") if not hasattr(g, n)]
