@@ -193,6 +193,7 @@ void staging_release() { g_stager.release(); }
 
 // ---- pinned host memory cache -------------------------------------------------------
 namespace {
+constexpr size_t kPinnedClassLimit = 256u << 20;
 struct PinnedCache {
   std::mutex mu;
   std::vector<std::pair<void *, size_t>> free_blocks;
@@ -203,7 +204,8 @@ struct PinnedCache {
 
 void *pinned_acquire(size_t *bytes) {
   size_t want = 4096;
-  while (want < *bytes) want <<= 1; // power-of-two classes: a block fits every later request of its class
+  if (*bytes > kPinnedClassLimit) want = (*bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20); // huge: exact size, never cached
+  else while (want < *bytes) want <<= 1; // power-of-two classes: a block fits every later request of its class
   *bytes = want;
   {
     std::lock_guard<std::mutex> lk(g_pinned.mu);
@@ -223,7 +225,7 @@ void *pinned_acquire(size_t *bytes) {
 void pinned_release(void *p, size_t bytes) {
   {
     std::lock_guard<std::mutex> lk(g_pinned.mu);
-    if (g_pinned.cached + bytes <= PinnedCache::kMaxCached) {
+    if (bytes <= kPinnedClassLimit && g_pinned.cached + bytes <= PinnedCache::kMaxCached) {
       g_pinned.free_blocks.emplace_back(p, bytes);
       g_pinned.cached += bytes;
       return;

@@ -225,8 +225,12 @@ llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filt
   Selection sel;
   int rc = run_selection(reinterpret_cast<const Table *>(table), filters, n_filters, ops, n_ops, &sel);
   if (rc) return (llkv_status)rc;
-  const bool large = sel.n * 8 >= (1u << 20);
-  uint64_t *ids = (uint64_t *)(large ? result_acquire(sel.n * 8) : std::malloc(sel.n ? sel.n * 8 : 8));
+  bool large = sel.n * 8 >= (1u << 20);
+  uint64_t *ids = large ? (uint64_t *)result_acquire(sel.n * 8) : nullptr;
+  if (!ids) { // small, or no pinned memory to be had: pageable memory through the staging lanes
+    large = false;
+    ids = (uint64_t *)std::malloc(sel.n ? sel.n * 8 : 8);
+  }
   if (!ids) return (llkv_status)set_error(LLKV_INTERNAL, "out of memory");
   // run_selection has synchronised: the ids are complete on the device
   if (large) {
