@@ -372,8 +372,11 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   };
 
   int cur = 0;
-  for (uint32_t t0 = 0; t0 < tl->n_tiles; t0 += kWindowTiles) {
-    const uint32_t nt = std::min(kWindowTiles, tl->n_tiles - t0);
+  // a many-to-many key can turn one step into billions of pairs: steps shrink until their pairs fit kMaxStepPairs
+  constexpr uint64_t kMaxStepPairs = 64ull << 20; // 1 GiB of row-id pairs per buffer
+  uint32_t step_tiles = kWindowTiles;
+  for (uint32_t t0 = 0, nt = 0; t0 < tl->n_tiles; t0 += nt) {
+    nt = std::min(step_tiles, tl->n_tiles - t0);
     const uint32_t npos = nt * kJoinTileRows;
     ProbeParams p;
     std::memset(&p, 0, sizeof p);
@@ -398,6 +401,11 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     Readback rb;
     if ((rc = rb.add(&total, (uint64_t *)offsets.p + npos, 8, s)) || (rc = rb.wait())) return rc;
     if (trace) t_acc[0] += lap();
+    if (total > kMaxStepPairs && nt > 1) { // count again over fewer tiles
+      step_tiles = std::max(1u, nt / 2);
+      nt = 0;
+      continue;
+    }
     Step &st = steps[cur];
     if ((rc = emit(st))) return rc; // its buffers are about to be reused (normally already emitted below)
     uint64_t wrows = 0;

@@ -1350,6 +1350,24 @@ def test_join_and_scan_edge_sizes(rt, orc, abi):
     assert rt.join_groupby_topk(fact, [], 7, dim, [], 1, col(8) * 1.0, payload_fields=[2], limit=9) == ([(20, 5.0, 3, 2), (40, 4.0, 1, 4)], 2)
 
 
+def test_join_with_exploding_match_counts_shrinks_its_steps(rt, abi):
+    """Every probe row matches 1 000 build rows: 3 × 10⁸ pairs.  A 2 M-row device step would need 32 GB of pair
+    buffers; the steps shrink until their pairs fit 1 GiB, and the batches still follow the reference's rule
+    (≥ batch_size pairs after a probe row, and the end of every 65 536-row scan batch)."""
+    nl, nr, batch = 300_000, 1000, 65536
+    lt = rt.HipTable(1, [nl]); lt.append_column(1, abi.DT_INT64, np.ones(nl, dtype=np.int64))
+    rtab = rt.HipTable(2, [nr]); rtab.append_column(7, abi.DT_INT64, np.ones(nr, dtype=np.int64))
+    sizes = []
+    rt.join_stream(lt, rtab, [(1, 7)], JT["inner"], batch, consume=sizes.append)
+    want, acc = [], 0
+    for row in range(nl):
+        acc += nr
+        if acc >= batch or (row + 1) % 65536 == 0 or row + 1 == nl:
+            want.append(acc)
+            acc = 0
+    assert sum(sizes) == nl * nr and sizes == want
+
+
 def test_executor_rule_joins_match_oracle(rt, orc, abi):
     """llkv_join_options.key_rules = EXECUTOR: the SQL joins of the executor (normalised keys, arrow-row equality,
     INNER / LEFT, no batch structure) — llkv-executor/src/lib.rs:12218-12581."""
