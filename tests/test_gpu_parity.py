@@ -1350,6 +1350,43 @@ def test_join_and_scan_edge_sizes(rt, orc, abi):
     assert rt.join_groupby_topk(fact, [], 7, dim, [], 1, col(8) * 1.0, payload_fields=[2], limit=9) == ([(20, 5.0, 3, 2), (40, 4.0, 1, 4)], 2)
 
 
+def test_repeated_statements_do_not_leak_device_memory(rt, abi, tpch):
+    """Statement after statement (prepare → run → close, scans, joins, the Q3 pipeline, a sort-based GROUP BY): the
+    pools settle, after which the free device memory no longer moves."""
+    import torch
+    n = 200_000
+    d = tpch.gen_lineitem(n, 0.05)
+    t = rt.HipTable(1, tpch.chunk_rows(n, 65536))
+    for c, (fid, dt) in tpch.LINEITEM_SCHEMA.items():
+        t.append_utf8_column(fid, d[c]) if dt == abi.DT_UTF8 else t.append_column(fid, dt, d[c])
+    keys = rt.HipTable(2, [5000]); keys.append_column(1, abi.DT_INT64, np.unique(d["l_orderkey"])[:5000])
+    q1, q6 = tpch.q1(), tpch.q6()
+    A, col = abi.AggregateSpec, abi.col
+
+    def round_trip():
+        for q in (q1, q6):
+            pq = rt.PreparedQuery(t, q.predicate, q.aggs, q.keys, q.order_by_keys)
+            pq.run()
+            pq.close()
+        rt.filter_row_ids(t, q6.predicate)
+        rt.scan_stream(t, [tpch.L_QUANTITY], q6.predicate, consume=lambda b: None)
+        rt.join_stream(t, keys, [(tpch.L_ORDERKEY, 1)], JT["semi"], consume=lambda k: None)
+        rt.join_groupby_topk(t, [], tpch.L_ORDERKEY, keys, [], 1, col(tpch.L_EXTENDEDPRICE) * 1.0, limit=5)
+        pq = rt.PreparedQuery(t, None, [A.count_star(), A.sum(tpch.L_QUANTITY)], [tpch.L_PARTKEY], True)
+        pq.launch(0)
+        rt.check(rt.lib().llkv_hip_query_finish(pq._h, None))
+        pq.close()
+
+    for _ in range(5):
+        round_trip()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(30):
+        round_trip()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)  # nothing grows with the statement count
+
+
 def test_join_with_exploding_match_counts_shrinks_its_steps(rt, abi):
     """Every probe row matches 1 000 build rows: 3 × 10⁸ pairs.  A 2 M-row device step would need 32 GB of pair
     buffers; the steps shrink until their pairs fit 1 GiB, and the batches still follow the reference's rule
