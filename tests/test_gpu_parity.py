@@ -991,6 +991,8 @@ def test_concurrent_callers_get_sequential_answers(rt, abi, tpch):
         "row_ids": lambda: rt.filter_row_ids(ht, [F(S["l_discount"][0], O.GreaterThan(0.08))]).tolist(),
         "scan": lambda: [b[1][:50] for b in rt.scan_stream(ht, [S["l_orderkey"][0], col(S["l_extendedprice"][0]) * 2.0], [F(S["l_quantity"][0], O.Equals(7))], include_row_ids=True)],
         "join": lambda: [x for b in rt.join_stream(ht, dim, [(S["l_partkey"][0], 1)], JT["semi"], 8192) for x in b[0]][:2000],
+        "join_topk": lambda: [(r[0], np.float64(r[1]).tobytes(), r[2]) for r in rt.join_groupby_topk(ht, [F(S["l_quantity"][0], O.LessThan(30))], S["l_partkey"][0], dim, [], 1,
+                                                                                                   col(S["l_extendedprice"][0]) * (1 - col(S["l_discount"][0])), limit=7)[0]],
     }
     want = {k: f() for k, f in jobs.items()}
     errors, names = [], list(jobs)
