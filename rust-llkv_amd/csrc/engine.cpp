@@ -494,10 +494,31 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
     Scratch pos, vals_s, pos_s, flags, offs, tmp, hv, hp, hp_s;
     if ((rc = pos.alloc(n * 4)) || (rc = vals_s.alloc(n * 8)) || (rc = pos_s.alloc(n * 4)) || (rc = flags.alloc((n + 1) * 8)) || (rc = offs.alloc((n + 1) * 8))) return rc;
     HIP_TRY(hj_launch_iota(pos.as<uint32_t>(), (uint32_t)n, s));
+    // only equality matters: sort (value − min) over the bits the value range leaves (integers of a narrow range:
+    // 3 radix passes instead of 8); the minimum is added back to the distinct values afterwards
+    uint64_t vmin = 0;
+    uint32_t sort_bits = 64;
+    {
+      Scratch mm;
+      int64_t init[2] = {INT64_MAX, INT64_MIN}, got[2];
+      if ((rc = mm.alloc(16))) return rc;
+      HIP_TRY(hipMemcpyAsync(mm.p, init, 16, hipMemcpyHostToDevice, s));
+      HIP_TRY(launch_minmax_i64(vals.as<int64_t>(), n, mm.as<int64_t>(), s));
+      Readback rb;
+      if ((rc = rb.add(got, mm.p, 16, s)) || (rc = rb.wait())) return rc; // (also: `init` is on the stack)
+      const uint64_t span = (uint64_t)got[1] - (uint64_t)got[0];
+      uint32_t b = 1;
+      while (b < 64 && (span >> b) != 0) ++b;
+      if (b <= 56) { // at least one 8-bit radix pass fewer
+        vmin = (uint64_t)got[0];
+        sort_bits = b;
+        HIP_TRY(hj_launch_add_u64(vals.as<uint64_t>(), n, (uint64_t)0 - vmin, s));
+      }
+    }
     size_t tb = 0;
-    HIP_TRY(hj_sort_u64_u32(nullptr, &tb, vals.as<uint64_t>(), vals_s.as<uint64_t>(), pos.as<uint32_t>(), pos_s.as<uint32_t>(), n, s));
+    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, vals.as<uint64_t>(), vals_s.as<uint64_t>(), pos.as<uint32_t>(), pos_s.as<uint32_t>(), n, sort_bits, s));
     if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
-    HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, vals.as<uint64_t>(), vals_s.as<uint64_t>(), pos.as<uint32_t>(), pos_s.as<uint32_t>(), n, s));
+    HIP_TRY(hj_sort_u64_u32_bits(tmp.p, &tb, vals.as<uint64_t>(), vals_s.as<uint64_t>(), pos.as<uint32_t>(), pos_s.as<uint32_t>(), n, sort_bits, s));
     HIP_TRY(hipMemsetAsync(flags.p, 0, (n + 1) * 8, s));
     HIP_TRY(hj_launch_run_heads(vals_s.as<uint64_t>(), n, flags.as<uint64_t>(), s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -517,15 +538,16 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
     HIP_TRY(hipStreamSynchronize(s));
     if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
     HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, hp.as<uint32_t>(), hp_s.as<uint32_t>(), hv.as<uint64_t>(), dv.as<uint64_t>(), m, bits, s));
+    if (vmin) HIP_TRY(hj_launch_add_u64(dv.as<uint64_t>(), m, vmin, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
   auto f64_sum = [&](int as_int, double *sum) -> int {
     *sum = 0.0;
     if (m == 0) return LLKV_OK;
-    Scratch d;
+    Scratch d, partials;
     int r = d.alloc(8);
-    if (r) return r;
-    HIP_TRY(hj_launch_sum_f64_ordered(dv.as<uint64_t>(), m, as_int, d.as<double>(), s));
+    if (r || (r = partials.alloc((m / 65536 + 1) * 8))) return r;
+    HIP_TRY(hj_launch_sum_f64_ordered(dv.as<uint64_t>(), m, as_int, d.as<double>(), partials.as<double>(), s));
     HIP_TRY(hipMemcpyAsync(sum, d.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LLKV_OK;

@@ -431,6 +431,16 @@ hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table,
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void hj_add_u64_kernel(uint64_t *v, uint64_t n, uint64_t delta) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] += delta;
+}
+hipError_t hj_launch_add_u64(uint64_t *v, uint64_t n, uint64_t delta, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_add_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, n, delta);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void hj_compact_stripes_kernel(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
                                                                   uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val) {
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -798,27 +808,42 @@ hipError_t hj_launch_run_heads(const uint64_t *sorted, uint64_t n, uint64_t *fla
   hipLaunchKernelGGL(hj_run_heads_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, sorted, n, flags);
   return hipGetLastError();
 }
-__global__ __launch_bounds__(64) void hj_sum_f64_ordered_kernel(const uint64_t *vals, uint64_t n, int as_int, double *out) {
-  const uint32_t lane = threadIdx.x;
-  auto at = [&](uint64_t i) { return as_int ? (double)(long long)vals[i] : __longlong_as_double((long long)vals[i]); };
-  if (n <= 65536) { // the reference's own order: 0.0, then += in arrival order
-    if (lane == 0) {
-      double acc = 0.0;
-      for (uint64_t i = 0; i < n; ++i) acc += at(i);
-      *out = acc;
-    }
-    return;
-  }
+// Σ vals in arrival order.  Up to 65 536 values: one lane, 0.0 then += (the reference's own association).  More:
+// blocks of 65 536 consecutive values, each summed by 256 threads (strided, then a fixed butterfly and the four
+// waves in order), the block sums added in block order by one lane — a fixed association, independent of timing.
+constexpr uint64_t kOrderedSumBlock = 65536;
+__device__ __forceinline__ double ordered_sum_value(const uint64_t *vals, uint64_t i, int as_int) {
+  return as_int ? (double)(long long)vals[i] : __longlong_as_double((long long)vals[i]);
+}
+__global__ __launch_bounds__(64) void hj_sum_f64_sequential_kernel(const uint64_t *vals, uint64_t n, int as_int, double *out) {
+  if (threadIdx.x != 0) return;
   double acc = 0.0;
-  for (uint64_t i = lane; i < n; i += 64) acc += at(i);
+  for (uint64_t i = 0; i < n; ++i) acc += ordered_sum_value(vals, i, as_int);
+  *out = acc;
+}
+__global__ __launch_bounds__(256) void hj_sum_f64_blocks_kernel(const uint64_t *vals, uint64_t n, int as_int, double *partials) {
+  __shared__ double wave_sum[4];
+  const uint64_t lo = (uint64_t)blockIdx.x * kOrderedSumBlock, hi = lo + kOrderedSumBlock < n ? lo + kOrderedSumBlock : n;
+  const uint32_t lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) acc += ordered_sum_value(vals, i, as_int);
   for (int o = 1; o < 64; o <<= 1) {
     const double other = __shfl_xor(acc, o);
     acc = (lane & o) ? other + acc : acc + other;
   }
-  if (lane == 0) *out = acc;
+  if (lane == 0) wave_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
 }
-hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, hipStream_t s) {
-  hipLaunchKernelGGL(hj_sum_f64_ordered_kernel, dim3(1), dim3(64), 0, s, vals, n, as_int, out);
+// `scratch`: ⌈n / 65 536⌉ doubles of device memory (only read when n > 65 536)
+hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, double *scratch, hipStream_t s) {
+  if (n <= kOrderedSumBlock) {
+    hipLaunchKernelGGL(hj_sum_f64_sequential_kernel, dim3(1), dim3(64), 0, s, vals, n, as_int, out);
+    return hipGetLastError();
+  }
+  const uint64_t n_blocks = (n + kOrderedSumBlock - 1) / kOrderedSumBlock;
+  hipLaunchKernelGGL(hj_sum_f64_blocks_kernel, dim3((uint32_t)n_blocks), dim3(256), 0, s, vals, n, as_int, scratch);
+  hipLaunchKernelGGL(hj_sum_f64_sequential_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const uint64_t *>(scratch), n_blocks, 0, out);
   return hipGetLastError();
 }
 

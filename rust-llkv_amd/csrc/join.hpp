@@ -135,6 +135,8 @@ hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table,
 // offsets[slot] with the hash slot translated to its group id.
 hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
                                      uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s);
+// v[i] += delta (wrapping)
+hipError_t hj_launch_add_u64(uint64_t *v, uint64_t n, uint64_t delta, hipStream_t s);
 // *flag |= 1 when keys[i] < keys[i − 1] for some i (flag zeroed by the caller)
 hipError_t hj_launch_unsorted_flag(const uint64_t *keys, uint64_t n, uint32_t *flag, hipStream_t s);
 // … and of a single-pass selection (two u64 streams: row ids, device rows)
@@ -201,9 +203,9 @@ hipError_t hj_sort_u64_u32_bits(void *tmp, size_t *tmp_bytes, const uint64_t *ki
 // flags[i] = 1 when sorted value i differs from sorted value i − 1 (the head of a run of equal keys).
 hipError_t hj_launch_run_heads(const uint64_t *sorted, uint64_t n, uint64_t *flags, hipStream_t s);
 // Left-to-right f64 sum of vals[0..n) (as_int: the values are i64, added as `v as f64`; else f64 bit images):
-// strictly sequential up to 65 536 values (bit-exact with the reference's `sum += v`), beyond that one wave in
-// lane-strided order with a fixed butterfly.  *out = the sum.
-hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, hipStream_t s);
+// strictly sequential up to 65 536 values (bit-exact with the reference's `sum += v`), beyond that blocks of 65 536
+// consecutive values (256 threads, strided, fixed butterfly) whose sums are added in block order.  *out = the sum.
+hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, double *scratch /* ⌈n / 65 536⌉ doubles */, hipStream_t s);
 
 // ---- ordered scans (stream.cpp) -----------------------------------------------------------------------------
 hipError_t hj_launch_gather_u64(const uint64_t *in, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t s);
