@@ -516,6 +516,43 @@ typedef struct llkv_batch_view {
 
 typedef void (*llkv_on_batch)(const llkv_batch_view *batch, void *user);
 
+/* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html), the standard definitions.  */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char *format;
+  const char *name;
+  const char *metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema **children;
+  struct ArrowSchema *dictionary;
+  void (*release)(struct ArrowSchema *);
+  void *private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void **buffers;
+  struct ArrowArray **children;
+  struct ArrowArray *dictionary;
+  void (*release)(struct ArrowArray *);
+  void *private_data;
+};
+#endif
+
+/* One scan batch as an Arrow RecordBatch (a struct array: one child per column, then "rowid" when the view has
+ * row ids).  The reference passes batches to `on_batch` by value — Arc-backed buffers the callee may keep
+ * (llkv-executor/src/types/storage.rs:20-50) — while a view lives only during the callback: this copies the view
+ * into buffers the consumer owns and frees through the release callbacks (arrow-rs `from_ffi`, pyarrow
+ * `_import_from_c`, …).  Fields are nullable as in llkv-scan/src/execute.rs:166-181; Utf8 columns are
+ * materialised from their dictionary codes.  `column_names` may be NULL ("c0", "c1", …).  Host only.           */
+llkv_status llkv_hip_batch_export_arrow(const llkv_batch_view *batch, const char *const *column_names,
+                                        struct ArrowArray *out_array, struct ArrowSchema *out_schema);
+
 llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_projection *projections,
                                  uint32_t n_projections, const llkv_filter *filters,
                                  uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,

@@ -418,6 +418,26 @@ def filter_row_ids(table: HipTable, predicate, count_only: bool = False):
     return res
 
 
+class _ArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class _ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+def batch_to_arrow(batch_view, names: Optional[Sequence[str]] = None):
+    """A raw ``llkv_batch_view`` (inside a scan callback) as a pyarrow RecordBatch that outlives the callback:
+    llkv_hip_batch_export_arrow + the Arrow C Data Interface."""
+    import pyarrow as pa
+    arr, sch = _ArrowArray(), _ArrowSchema()
+    cn = (C.c_char_p * len(names))(*[n.encode() for n in names]) if names else None
+    check(lib().llkv_hip_batch_export_arrow(C.byref(batch_view), cn, C.byref(arr), C.byref(sch)))
+    return pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+
+
 def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False, order=None, consume=None):
     """StorageTable::scan_stream: returns the list of batches [(columns, row_ids)], each column a list of
     Python values.  ``projections``: field ids (ScanProjection::Column) or ScalarExpr (::Computed).

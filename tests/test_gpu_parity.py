@@ -1320,6 +1320,34 @@ def test_sharded_probe_side_and_scans_concatenate(rt, abi):
     assert e.value.kind == "InvalidArgumentError"
 
 
+def test_scan_batches_as_arrow_record_batches(rt, abi):
+    """scan_stream → llkv_hip_batch_export_arrow → pyarrow: the batches outlive the callback and carry the same cells
+    (values, NULLs, strings, row ids) as the raw views."""
+    pa = pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(23)
+    n = 150_000
+    i64 = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    f64 = rng.normal(size=n)
+    tags = [("x", "yy", "", "zzz")[k] for k in rng.integers(0, 4, size=n)]
+    v1 = rng.random(n) > 0.2
+    t = rt.HipTable(1, [n])
+    t.append_column(1, abi.DT_INT64, i64, valid=v1)
+    t.append_column(2, abi.DT_FLOAT64, f64)
+    t.append_utf8_column(3, tags)
+    pred = [abi.Filter(2, abi.Operator.GreaterThan(0.0))]
+    kept = []
+    rt.scan_stream(t, [1, 2, 3, abi.col(2) * 2.0], pred, include_nulls=True, include_row_ids=True, consume=lambda b: kept.append(rt.batch_to_arrow(b, ["a", "b", "s", "b2"])))
+    raw = rt.scan_stream(t, [1, 2, 3, abi.col(2) * 2.0], pred, include_nulls=True, include_row_ids=True)
+    assert [rb.num_rows for rb in kept] == [len(b[1]) for b in raw] and len(kept) >= 2
+    tab = pa.Table.from_batches(kept)
+    assert tab.column("a").to_pylist() == [x for b in raw for x in b[0][0]]
+    assert tab.column("b").to_pylist() == [x for b in raw for x in b[0][1]]
+    assert tab.column("s").to_pylist() == [x for b in raw for x in b[0][2]]
+    assert tab.column("b2").to_pylist() == [x for b in raw for x in b[0][3]]
+    assert tab.column("rowid").to_pylist() == [x for b in raw for x in b[1]]
+    assert tab.column("a").null_count == int((~v1 & (f64 > 0.0)).sum())
+
+
 def test_join_and_scan_edge_sizes(rt, orc, abi):
     """Empty sides, and selections that end exactly on / just past the 16-window device buffers."""
     X = abi.JOIN_KEYS_EXECUTOR

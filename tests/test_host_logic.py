@@ -61,6 +61,66 @@ int main(void) {
     assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
 
 
+def test_batches_export_through_the_arrow_c_data_interface(lib, abi):
+    """llkv_hip_batch_export_arrow: a scan batch view becomes an Arrow RecordBatch the consumer owns — imported here
+    by pyarrow through the C Data Interface, every storage type, NULL cells, row ids."""
+    pa = pytest.importorskip("pyarrow")
+
+    class ArrowSchema(C.Structure):
+        pass
+
+    class ArrowArray(C.Structure):
+        pass
+    ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                            ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+    ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                           ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+    n = 11
+    valid = np.array([1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 1], dtype=bool)
+    bitmap = np.packbits(valid, bitorder="little")
+    i64 = np.arange(n, dtype=np.int64) - 5
+    f64 = np.linspace(-1.0, 1.0, n)
+    i32 = (np.arange(n, dtype=np.int32) * 7)
+    u64 = np.arange(n, dtype=np.uint64) + 2**63
+    boo = (np.arange(n) % 3 == 0).astype(np.uint8)
+    dec = abi.i128_buffer([(-1) ** k * (10**20 + k) for k in range(n)])
+    codes = (np.arange(n) % 3).astype(np.uint8)
+    words = [b"alpha", b"", b"gamma-gamma"]
+    dictionary = (C.c_char_p * 3)(*words)
+    rid = np.arange(n, dtype=np.uint64) * 10
+    cols = (abi.CColumnView * 8)()
+    specs = [(abi.DT_INT64, i64, bitmap), (abi.DT_FLOAT64, f64, None), (abi.DT_INT32, i32, None), (abi.DT_DATE32, i32, bitmap), (abi.DT_UINT64, u64, None),
+             (abi.DT_BOOLEAN, boo, None), (abi.DT_DECIMAL128, dec, bitmap), (abi.DT_UTF8, codes, bitmap)]
+    for k, (dt, arr, bm) in enumerate(specs):
+        cols[k].dtype = dt
+        cols[k].values = arr.ctypes.data
+        cols[k].validity = bm.ctypes.data_as(C.POINTER(C.c_uint8)) if bm is not None else None
+        cols[k].dictionary = dictionary if dt == abi.DT_UTF8 else None
+        cols[k].precision, cols[k].scale = (38, 4) if dt == abi.DT_DECIMAL128 else (0, 0)
+    batch = abi.CBatchView(n, 8, cols, rid.ctypes.data_as(C.POINTER(C.c_uint64)))
+    names = (C.c_char_p * 8)(b"a", b"b", b"c", b"d", b"e", b"f", b"g", b"h")
+    arr, sch = ArrowArray(), ArrowSchema()
+    rc = lib.llkv_hip_batch_export_arrow(C.byref(batch), names, C.byref(arr), C.byref(sch))
+    assert rc == 0
+    rb = pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))  # takes ownership (calls release)
+    del i64, f64, u64, dec, codes  # the export owns copies
+    assert rb.num_rows == n and rb.schema.names == ["a", "b", "c", "d", "e", "f", "g", "h", "rowid"]
+    assert [str(t) for t in rb.schema.types] == ["int64", "double", "int32", "date32[day]", "uint64", "bool", "decimal128(38, 4)", "string", "uint64"]
+    mask = lambda vals: [v if ok else None for v, ok in zip(vals, valid)]
+    assert rb.column(0).to_pylist() == mask([k - 5 for k in range(n)])
+    assert rb.column(1).to_pylist() == np.linspace(-1.0, 1.0, n).tolist()
+    assert rb.column(2).to_pylist() == [7 * k for k in range(n)]
+    assert [None if v is None else (v - __import__("datetime").date(1970, 1, 1)).days for v in rb.column(3).to_pylist()] == mask([7 * k for k in range(n)])
+    assert rb.column(4).to_pylist() == [2**63 + k for k in range(n)]
+    assert rb.column(5).to_pylist() == [k % 3 == 0 for k in range(n)]
+    from decimal import Decimal
+    assert rb.column(6).to_pylist() == mask([Decimal((-1) ** k * (10**20 + k)).scaleb(-4) for k in range(n)])
+    assert rb.column(7).to_pylist() == mask([words[k % 3].decode() for k in range(n)])
+    assert rb.column(8).to_pylist() == [10 * k for k in range(n)] and rb.column(8).null_count == 0
+    assert rb.column(0).null_count == 2
+    assert lib.llkv_hip_batch_export_arrow(None, None, C.byref(arr), C.byref(sch)) != 0
+
+
 def test_generator_library_exports_every_declared_symbol(tpch):
     g = tpch.gen_lib()
     missing = [n for n in declared_functions("llkv_tpch_gen.h") if not hasattr(g, n)]
