@@ -553,6 +553,15 @@ struct ArrowArray {
 llkv_status llkv_hip_batch_export_arrow(const llkv_batch_view *batch, const char *const *column_names,
                                         struct ArrowArray *out_array, struct ArrowSchema *out_schema);
 
+/* Stage one column from Arrow arrays, one per local chunk (Int32/64, UInt32/64, Float32/64, Date32, Boolean,
+ * Decimal128, Utf8; offsets and validity bitmaps honoured) — the arrays `deserialize_array` yields for the
+ * reference's chunk blobs (llkv-column-map/src/serialization.rs:438-488).  `dictionary` as for
+ * llkv_hip_table_append_utf8_column.  The arrays are only read; they stay the caller's.                          */
+llkv_status llkv_hip_table_append_arrow_column(llkv_hip_table *table, uint32_t field_id,
+                                               const struct ArrowSchema *schema,
+                                               const struct ArrowArray *const *chunks, uint32_t n_chunks,
+                                               const char *const *dictionary, uint32_t dict_size);
+
 llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_projection *projections,
                                  uint32_t n_projections, const llkv_filter *filters,
                                  uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,

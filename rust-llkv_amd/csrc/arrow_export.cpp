@@ -8,6 +8,7 @@
 // materialised from their dictionary codes.
 #include "../../include/llkv_hip.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -187,4 +188,88 @@ extern "C" llkv_status llkv_hip_batch_export_arrow(const llkv_batch_view *batch,
     return (llkv_status)llkv::set_error(LLKV_INTERNAL, "out of memory exporting a batch");
   }
   return LLKV_OK;
+}
+
+// ---- staging from Arrow arrays --------------------------------------------------------------------------------
+// One ArrowArray per local chunk (what the reference's chunks are after `deserialize_array`,
+// llkv-column-map/src/serialization.rs:438-488): the value / offset / validity buffers are handed to the staging
+// entry points as they lie (bitmaps and Boolean bits that start at a non-zero offset are re-packed on the host).
+namespace {
+int dtype_of_format(const char *f, int32_t *precision, int32_t *scale) {
+  if (!f) return -1;
+  if (!std::strcmp(f, "l")) return LLKV_DT_INT64;
+  if (!std::strcmp(f, "L")) return LLKV_DT_UINT64;
+  if (!std::strcmp(f, "g")) return LLKV_DT_FLOAT64;
+  if (!std::strcmp(f, "f")) return LLKV_DT_FLOAT32;
+  if (!std::strcmp(f, "i")) return LLKV_DT_INT32;
+  if (!std::strcmp(f, "I")) return LLKV_DT_UINT32;
+  if (!std::strcmp(f, "tdD")) return LLKV_DT_DATE32;
+  if (!std::strcmp(f, "b")) return LLKV_DT_BOOLEAN;
+  if (!std::strcmp(f, "u")) return LLKV_DT_UTF8;
+  if (!std::strncmp(f, "d:", 2)) {
+    int p = 0, s = 0, bits = 128;
+    const int got = std::sscanf(f + 2, "%d,%d,%d", &p, &s, &bits);
+    if (got < 2 || bits != 128) return -1;
+    *precision = p;
+    *scale = s;
+    return LLKV_DT_DECIMAL128;
+  }
+  return -1;
+}
+size_t width_of(int dt) {
+  switch (dt) {
+  case LLKV_DT_INT64: case LLKV_DT_UINT64: case LLKV_DT_FLOAT64: return 8;
+  case LLKV_DT_INT32: case LLKV_DT_UINT32: case LLKV_DT_FLOAT32: case LLKV_DT_DATE32: return 4;
+  case LLKV_DT_DECIMAL128: return 16;
+  default: return 0;
+  }
+}
+bool bit_at(const uint8_t *bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) & 1u; }
+} // namespace
+
+extern "C" llkv_status llkv_hip_table_append_arrow_column(llkv_hip_table *table, uint32_t field_id, const struct ArrowSchema *schema,
+                                                          const struct ArrowArray *const *chunks, uint32_t n_chunks,
+                                                          const char *const *dictionary, uint32_t dict_size) {
+  if (!table || !schema || (n_chunks && !chunks)) return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  int32_t precision = 0, scale = 0;
+  const int dt = dtype_of_format(schema->format, &precision, &scale);
+  if (dt < 0) return (llkv_status)llkv::set_error(LLKV_UNSUPPORTED, std::string("Arrow format '") + (schema->format ? schema->format : "") + "' is not staged on the GPU path");
+  std::vector<const void *> values(n_chunks, nullptr);
+  std::vector<const int32_t *> offsets(n_chunks, nullptr);
+  std::vector<const uint8_t *> data(n_chunks, nullptr), validity(n_chunks, nullptr);
+  std::vector<std::vector<uint8_t>> repacked; // Boolean bytes, shifted bitmaps
+  repacked.reserve((size_t)n_chunks * 2);
+  bool any_nulls = false;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const ArrowArray *a = chunks[i];
+    if (!a || a->n_buffers < (dt == LLKV_DT_UTF8 ? 3 : 2)) return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow chunk without its buffers");
+    const int64_t off = a->offset, n = a->length;
+    const uint8_t *bits = static_cast<const uint8_t *>(a->buffers[0]);
+    if (bits && a->null_count != 0) {
+      any_nulls = true;
+      if (off % 8 == 0) validity[i] = bits + off / 8;
+      else {
+        repacked.emplace_back((size_t)((n + 7) / 8), 0);
+        for (int64_t r = 0; r < n; ++r) if (bit_at(bits, off + r)) repacked.back()[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+        validity[i] = repacked.back().data();
+      }
+    }
+    if (dt == LLKV_DT_UTF8) {
+      offsets[i] = static_cast<const int32_t *>(a->buffers[1]) + off;
+      data[i] = static_cast<const uint8_t *>(a->buffers[2]);
+    } else if (dt == LLKV_DT_BOOLEAN) { // bit-packed in Arrow, one byte per value in HBM
+      repacked.emplace_back((size_t)(n ? n : 1), 0);
+      const uint8_t *vb = static_cast<const uint8_t *>(a->buffers[1]);
+      for (int64_t r = 0; r < n; ++r) repacked.back()[(size_t)r] = vb && bit_at(vb, off + r) ? 1 : 0;
+      values[i] = repacked.back().data();
+    } else {
+      values[i] = static_cast<const char *>(a->buffers[1]) + (size_t)off * width_of(dt);
+    }
+  }
+  llkv_status rc;
+  if (dt == LLKV_DT_UTF8) rc = llkv_hip_table_append_utf8_column(table, field_id, offsets.data(), data.data(), n_chunks, dictionary, dict_size);
+  else if (dt == LLKV_DT_DECIMAL128) rc = llkv_hip_table_append_decimal128_column(table, field_id, precision, scale, values.data(), n_chunks);
+  else rc = llkv_hip_table_append_column(table, field_id, dt, values.data(), n_chunks);
+  if (rc != LLKV_OK || !any_nulls) return rc;
+  return llkv_hip_table_set_column_validity(table, field_id, validity.data(), n_chunks);
 }

@@ -92,6 +92,16 @@ def shutdown():
     _bound_device = None
 
 
+class _ArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class _ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+                ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 class HipTable:
     """HBM image of a table's column chunks (the `Table` the executor scans)."""
 
@@ -205,6 +215,26 @@ class HipTable:
         check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off)), dptr, C.c_uint32(dn)))
         if valid is not None:
             self.set_column_validity(field_id, valid)
+
+    def append_arrow_column(self, field_id: int, chunks, dictionary: Optional[Sequence[str]] = None):
+        """Stage a column from pyarrow arrays, one per local chunk (llkv_hip_table_append_arrow_column through the
+        Arrow C Data Interface: values, offsets and validity bitmaps are read where they lie)."""
+        import pyarrow as pa
+        arrs = [(_ArrowArray(), _ArrowSchema()) for _ in chunks]
+        for c, (a, s) in zip(chunks, arrs):
+            c._export_to_c(C.addressof(a), C.addressof(s))
+        try:
+            ptrs = (C.POINTER(_ArrowArray) * max(1, len(arrs)))(*[C.pointer(a) for a, _ in arrs])
+            if dictionary is None:
+                dptr, dn = None, 0
+            else:
+                enc = [d.encode() for d in dictionary]
+                dptr, dn = (C.c_char_p * max(1, len(enc)))(*enc), len(enc)
+            schema = C.byref(arrs[0][1]) if arrs else None
+            check(lib().llkv_hip_table_append_arrow_column(self._h, C.c_uint32(field_id), schema, ptrs, C.c_uint32(len(arrs)), dptr, C.c_uint32(dn)))
+        finally:
+            for a, s in arrs:  # hand the exported structs back: pyarrow releases them
+                pa.Array._import_from_c(C.addressof(a), C.addressof(s))
 
     def append_arr0_column(self, field_id: int, blobs: Sequence[bytes], dictionary: Optional[Sequence[str]] = None):
         """Stage a column from its llkv-column-map `ARR0` chunk blobs (one per local chunk)."""
@@ -416,16 +446,6 @@ def filter_row_ids(table: HipTable, predicate, count_only: bool = False):
     res = np.ctypeslib.as_array(out, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
     lib().llkv_hip_free(out)
     return res
-
-
-class _ArrowSchema(C.Structure):
-    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
-                ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
-
-
-class _ArrowArray(C.Structure):
-    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
-                ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
 def batch_to_arrow(batch_view, names: Optional[Sequence[str]] = None):
