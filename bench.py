@@ -143,7 +143,8 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
 
     comm = torch.cuda.Stream() if ex_tensor is not None else None
     run_steps(q, warmup, dist, stream_ptr, ex_tensor, torch, comm)
-    q.set_profiling(PROFILE_EVERY)  # HIP events around every 4th scan kernel of the timed region
+    # HIP events around every 4th scan kernel of the timed region (every one when the region is only a few steps long)
+    q.set_profiling(PROFILE_EVERY if steps >= 4 * PROFILE_EVERY else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
