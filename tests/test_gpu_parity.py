@@ -1613,6 +1613,40 @@ def test_join_groupby_topk_with_tied_sums(rt, abi, n_orders, limit):
     assert [(r[0], r[1], r[2], r[3]) for r in got] == [(int(okey[i]), float(sums[i]), int(counts[i]), int(odate[i])) for i in order]
 
 
+@pytest.mark.parametrize("switches", [("LLKV_HIP_JOIN_HASH",), ("LLKV_HIP_JOIN_SORT",), ("LLKV_HIP_TOPK_SORT",), ("LLKV_HIP_TOPK_SORT", "LLKV_HIP_TOPK_FULL"),
+                                      ("LLKV_HIP_JOIN_HASH", "LLKV_HIP_JOIN_SORT", "LLKV_HIP_TOPK_SORT"), ("LLKV_HIP_SELECT_TWO_PASS",)])
+def test_join_pipeline_fallback_forms_give_the_same_rows(rt, abi, tpch, monkeypatch, switches):
+    """The join → aggregate pipeline has a general form behind every shortcut (hash table behind bitmap + rank, pair
+    sort behind run sums, radix-sort top-k behind the threshold selection): forced through the switches of DESIGN §10
+    they return the same rows, bit for bit."""
+    rows, scale = 120_000, 0.02
+    D = tpch.DATE_1995_03_15
+    li = tpch.gen_lineitem(rows, scale)
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    lt = rt.HipTable(1, tpch.chunk_rows(rows, 32768))
+    for c in ("l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"):
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
+    ot_ = rt.HipTable(2, [n_ord])
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c])
+    ct = rt.HipTable(3, [n_cust])
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]])
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    run = lambda: rt.join_groupby_topk(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY,
+                                       col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT)), payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10,
+                                       dim_fk=tpch.O_CUSTKEY, dim2=ct, dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    bits = lambda res: ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in res[0]], res[1])
+    want = bits(run())
+    assert len(want[0]) == 10
+    for name in switches:
+        monkeypatch.setenv(name, "1")
+    assert bits(run()) == want
+
+
 def _device_i64(ptr, n):
     """int64 torch tensor aliasing a raw device pointer (what the RCCL all-reduce is given on the GPU box)."""
     import torch
