@@ -1647,6 +1647,28 @@ def test_join_pipeline_fallback_forms_give_the_same_rows(rt, abi, tpch, monkeypa
     assert bits(run()) == want
 
 
+def test_sorted_input_shortcut_of_the_sort_based_group_by(rt, abi, monkeypatch):
+    """GROUP BY a column that is in key order already (a clustered primary key) skips the sort; forcing the sort
+    (LLKV_HIP_GROUP_ALWAYS_SORT) gives the same groups and the same bits — the stable sort leaves such rows where
+    they are."""
+    rng = np.random.default_rng(31)
+    n = 200_000
+    key = np.sort(rng.integers(0, 60_000, size=n)).astype(np.int64)
+    val = rng.normal(size=n)
+    qty = rng.integers(1, 50, size=n).astype(np.int64)
+    t = rt.HipTable(1, [70_000, 130_000])
+    t.append_column(1, abi.DT_INT64, key); t.append_column(2, abi.DT_FLOAT64, val); t.append_column(3, abi.DT_INT64, qty)
+    A = abi.AggregateSpec
+    flat = lambda rows: [(r.keys[0].value, r.values[0].value, r.values[1].value, np.float64(r.values[2].value).tobytes()) for r in rows]
+    run = lambda: flat(rt.groupby(t, [abi.Filter(3, abi.Operator.GreaterThan(5))], [1], [A.count_star(), A.sum(3), A.sum(2)], True))
+    fast = run()
+    sel = qty > 5
+    uniq, counts = np.unique(key[sel], return_counts=True)
+    assert [r[0] for r in fast] == uniq.tolist() and [r[1] for r in fast] == counts.tolist()
+    monkeypatch.setenv("LLKV_HIP_GROUP_ALWAYS_SORT", "1")
+    assert run() == fast
+
+
 def _device_i64(ptr, n):
     """int64 torch tensor aliasing a raw device pointer (what the RCCL all-reduce is given on the GPU box)."""
     import torch
