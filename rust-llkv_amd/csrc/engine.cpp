@@ -74,11 +74,13 @@ static uint32_t pick_tile_rows(const LoweredPlan &p, uint64_t total_rows) {
   // narrow register states amortise their block reduction quickly and like many small tiles;
   // LDS-resident grouped states (2 workgroups/CU) want long tiles (sweep: profiles/r01/).
   // Depends on the plan and the TABLE's row count only, never on the GPU count (bit-reproducibility): long tiles
-  // leave a small table — or one rank's eighth of a larger one — with too few workgroups for 256 CUs (Q1 at SF1:
-  // 92 tiles of 65 536 rows ran 78 µs, 366 tiles of 16 384 rows 49 µs; at SF10 the two lengths are within 1 %), so
-  // they are halved, down to 16 384 rows, until the table has some 350 tiles for each of 8 ranks.
+  // leave a small table with too few workgroups for 256 CUs (Q1 at SF1: 92 tiles of 65 536 rows ran 78 µs, 366
+  // tiles of 16 384 rows 49 µs), so they are halved, down to 16 384 rows, while the table has fewer than 700 tiles.
+  // (At SF10 on one GPU 65 536-row tiles are 3 % faster than 16 384-row ones: 359 vs 369 µs; an SF10 table cut over
+  // 8 ranks would prefer the short tiles — the length cannot follow the rank count without giving up results that
+  // are bit-identical across GPU counts, and the single-GPU case decides.)
   uint32_t rows = p.acc_lds ? 65536u : 4096u;
-  while (rows > 16384u && total_rows / rows < 2800) rows >>= 1;
+  while (rows > 16384u && total_rows / rows < 700) rows >>= 1;
   return rows;
 }
 
