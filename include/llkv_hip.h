@@ -218,7 +218,7 @@ typedef enum llkv_aggregate_kind {
 
 typedef struct llkv_aggregate_spec {
   int32_t kind;     /* llkv_aggregate_kind                                   */
-  int32_t distinct; /* must be 0 on this path (DISTINCT = UNSUPPORTED)       */
+  int32_t distinct; /* DISTINCT: ungrouped COUNT / SUM / TOTAL / AVG only      */
   const llkv_expr_token *expr; /* NULL for COUNT(*)                          */
   uint32_t expr_len;
   const char *alias;

@@ -3,6 +3,7 @@ Bit-exact for counts / integer sums / min / max / group keys; f64 sums and avera
 (the reference sums strictly left to right, llkv-aggregate/src/lib.rs:881-887; its own TPC-H tolerance is
 1e-9, llkv-tpch/src/qualification.rs:39)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1667,6 +1668,19 @@ def test_sorted_input_shortcut_of_the_sort_based_group_by(rt, abi, monkeypatch):
     assert [r[0] for r in fast] == uniq.tolist() and [r[1] for r in fast] == counts.tolist()
     monkeypatch.setenv("LLKV_HIP_GROUP_ALWAYS_SORT", "1")
     assert run() == fast
+
+
+def test_c_program_runs_q6_through_the_abi(tmp_path):
+    """examples/q6.c: a C99 program (no Python, no C++) stages lineitem, prepares and runs TPC-H Q6 through
+    include/llkv_hip.h and checks the answer against its own host loop."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rust-llkv_amd")
+    exe = tmp_path / "q6"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "q6.c"), "-L", libdir, "-lllkv_hip", "-lllkv_tpch", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe), "2000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stdout, out.stderr)
 
 
 def _device_i64(ptr, n):
