@@ -443,6 +443,21 @@ llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group
                                      llkv_value *out);
 llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, uint32_t agg,
                                  llkv_value *out);
+
+/* GROUP BY of any cardinality over a SHARDED table (the sort-based route; the dense route combines through the
+ * exchange image above).  Every rank runs the query over its own chunks — launch, finish — and then holds partial
+ * groups: `key_values[n_keys][n]` (integers; Utf8 as codes of the table-wide dictionary), `key_valid[n_keys][n]`
+ * and `lanes[n][lanes_per_group]` (the accumulator lanes), valid until the next launch.  The binding all-gathers
+ * the three arrays of every rank and installs the table-wide groups with llkv_hip_query_merge_groups (rank order
+ * = row order: states of one key are combined lane by lane in that order; the groups come out in key order or in
+ * first-appearance order, as on one device); group_key / value then read the merged result.  Integer results are
+ * those of one device bit for bit, f64 sums within the 1e-9 of the contract (one more level of association).      */
+llkv_status llkv_hip_query_partial_groups(const llkv_hip_query *query, uint64_t *n_groups, uint32_t *n_keys,
+                                          uint32_t *lanes_per_group, const int64_t **key_values,
+                                          const uint8_t **key_valid, const uint64_t **lanes);
+llkv_status llkv_hip_query_merge_groups(llkv_hip_query *query, uint32_t world, const uint64_t *rank_groups,
+                                        const int64_t *const *key_values, const uint8_t *const *key_valid,
+                                        const uint64_t *const *lanes);
 /* Status a finalize step produced for one aggregate (e.g. "integer overflow"
  * is LLKV_INVALID_ARGUMENT, llkv-aggregate/src/lib.rs:816-829).              */
 

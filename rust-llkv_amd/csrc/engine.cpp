@@ -893,6 +893,27 @@ llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, ui
   return LLKV_OK;
 }
 
+llkv_status llkv_hip_query_partial_groups(const llkv_hip_query *query, uint64_t *n_groups, uint32_t *n_keys, uint32_t *lanes_per_group,
+                                          const int64_t **key_values, const uint8_t **key_valid, const uint64_t **lanes) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  if (!q || !q->sorted || !q->lazy.active) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "not a finished sort-based GROUP BY");
+  if (n_groups) *n_groups = q->lazy.n;
+  if (n_keys) *n_keys = q->lazy.n_keys;
+  if (lanes_per_group) *lanes_per_group = (uint32_t)q->lazy.k;
+  if (key_values) *key_values = q->lazy.key_vals;
+  if (key_valid) *key_valid = q->lazy.key_valid;
+  if (lanes) *lanes = q->lazy.lanes;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_query_merge_groups(llkv_hip_query *query, uint32_t world, const uint64_t *rank_groups, const int64_t *const *key_values,
+                                        const uint8_t *const *key_valid, const uint64_t *const *lanes) {
+  Query *q = reinterpret_cast<Query *>(query);
+  if (!q || !q->sorted || !q->lazy.active) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "not a finished sort-based GROUP BY");
+  if (world == 0 || !rank_groups || !key_values || !key_valid || !lanes) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  return (llkv_status)sorted_groupby_merge(q->sorted, world, rank_groups, key_values, key_valid, lanes, &q->lazy);
+}
+
 llkv_status llkv_hip_query_set_profiling(llkv_hip_query *query, int32_t enabled) {
   if (!query) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "query is NULL");
   Query *q = reinterpret_cast<Query *>(query);

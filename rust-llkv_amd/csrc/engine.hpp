@@ -143,6 +143,10 @@ int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint3
                            bool order_by_keys, SortedGroupBy **out);
 int sorted_groupby_run(SortedGroupBy *s, LazyGroups *out);
 void sorted_groupby_free(SortedGroupBy *s);
+// Sharded table: the ranks' partial groups ([n_keys][n] key cells and validity, [n][k] lanes per rank, rank order)
+// become the table-wide groups of `out` (group_sort.cpp).
+int sorted_groupby_merge(SortedGroupBy *s, uint32_t world, const uint64_t *rank_groups, const int64_t *const *key_values,
+                         const uint8_t *const *key_valid, const uint64_t *const *lanes, LazyGroups *out);
 
 struct Query {
   const Table *table = nullptr;

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <unordered_map>
 #include <vector>
 
 namespace llkv {
@@ -33,6 +34,10 @@ struct SortedGroupBy {
   // result arrays of the latest execution, pinned host memory reused across executions
   void *h_lanes = nullptr, *h_kv = nullptr, *h_kvalid = nullptr;
   size_t cap_lanes = 0, cap_kv = 0, cap_kvalid = 0;
+  // table-wide groups after sorted_groupby_merge (a sharded table: every rank ran its own rows)
+  std::vector<uint64_t> m_lanes;
+  std::vector<int64_t> m_kv;
+  std::vector<uint8_t> m_kvalid;
   int run(LazyGroups *out);
   ~SortedGroupBy() {
     if (h_lanes) (void)hipHostFree(h_lanes);
@@ -42,6 +47,112 @@ struct SortedGroupBy {
 };
 
 void sorted_groupby_free(SortedGroupBy *s) { delete s; }
+
+// ---- sharded tables: merge of the ranks' partial groups (host) -------------------------------------------------------
+// Every rank ran the query over its own chunks: its groups are partial states (the lanes of the reduce plan), keyed
+// by the raw key cells (integers; Utf8 as codes of the table-wide dictionary).  The ranks' states of one key are
+// combined lane by lane IN RANK ORDER — rank order is row order, so "first row" minima and the order of f64 partial
+// sums are those of the table — and the groups are put into the order one device would have produced: by key (NULLS
+// first, strings by dictionary order) or by first appearance.
+namespace {
+inline uint64_t combine_lane(int op, uint64_t a, uint64_t b) { // fused_scan.hip.h lane ops
+  switch (op) {
+  case 0: { double x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8); const double z = x + y; uint64_t r; std::memcpy(&r, &z, 8); return r; }
+  case 1: return a + b;
+  case 2: return (int64_t)b < (int64_t)a ? b : a;
+  case 3: return (int64_t)b > (int64_t)a ? b : a;
+  default: return b > a ? b : a;
+  }
+}
+struct KeyTupleHost {
+  int64_t v[4];
+  uint8_t valid[4];
+  bool operator==(const KeyTupleHost &o) const { return std::memcmp(v, o.v, sizeof v) == 0 && std::memcmp(valid, o.valid, sizeof valid) == 0; }
+};
+struct KeyTupleHash {
+  size_t operator()(const KeyTupleHost &k) const {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 4; ++i) { h ^= (uint64_t)k.v[i] + k.valid[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+    return (size_t)h;
+  }
+};
+} // namespace
+
+int sorted_groupby_merge(SortedGroupBy *s, uint32_t world, const uint64_t *rank_groups, const int64_t *const *key_values,
+                         const uint8_t *const *key_valid, const uint64_t *const *lanes, LazyGroups *out) {
+  const uint32_t n_keys = (uint32_t)s->key_fields.size();
+  const int K = s->red_plan.k;
+  const std::vector<uint8_t> &ops = s->red_plan.lane_ops;
+  std::unordered_map<KeyTupleHost, uint64_t, KeyTupleHash> index;
+  std::vector<KeyTupleHost> keys;
+  std::vector<uint64_t> state;
+  for (uint32_t r = 0; r < world; ++r) {
+    const uint64_t n = rank_groups[r];
+    if (n && (!key_values[r] || !key_valid[r] || !lanes[r])) return set_error(LLKV_INVALID_ARGUMENT, "partial groups of a rank are missing");
+    for (uint64_t g = 0; g < n; ++g) {
+      KeyTupleHost kt;
+      std::memset(&kt, 0, sizeof kt);
+      for (uint32_t k = 0; k < n_keys; ++k) {
+        kt.valid[k] = key_valid[r][(size_t)k * n + g] ? 1 : 0;
+        kt.v[k] = kt.valid[k] ? key_values[r][(size_t)k * n + g] : 0;
+      }
+      const uint64_t *src = lanes[r] + (size_t)g * K;
+      auto it = index.find(kt);
+      if (it == index.end()) {
+        index.emplace(kt, keys.size());
+        keys.push_back(kt);
+        state.insert(state.end(), src, src + K);
+      } else {
+        uint64_t *dst = state.data() + (size_t)it->second * K;
+        for (int l = 0; l < K; ++l) dst[l] = combine_lane(ops[(size_t)l], dst[l], src[l]);
+      }
+    }
+  }
+  const uint64_t n = keys.size();
+  std::vector<uint64_t> order(n);
+  std::iota(order.begin(), order.end(), 0ull);
+  if (s->order_by_keys) {
+    std::vector<std::vector<uint32_t>> rank_of(n_keys); // Utf8: dictionary code → position in string order
+    for (uint32_t k = 0; k < n_keys; ++k) {
+      const ColumnInfo &ci = s->table->cols.at(s->key_fields[k]).info;
+      if (ci.dtype != LLKV_DT_UTF8) continue;
+      std::vector<uint32_t> idx(ci.dictionary.size());
+      std::iota(idx.begin(), idx.end(), 0u);
+      std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ci.dictionary[a] < ci.dictionary[b]; });
+      rank_of[k].resize(idx.size());
+      for (size_t i = 0; i < idx.size(); ++i) rank_of[k][idx[i]] = (uint32_t)i;
+    }
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+      for (uint32_t k = 0; k < n_keys; ++k) {
+        const KeyTupleHost &x = keys[a], &y = keys[b];
+        if (x.valid[k] != y.valid[k]) return x.valid[k] < y.valid[k]; // NULLS FIRST
+        if (!x.valid[k]) continue;
+        int64_t xv = x.v[k], yv = y.v[k];
+        if (!rank_of[k].empty()) { xv = (uint64_t)xv < rank_of[k].size() ? rank_of[k][(size_t)xv] : xv; yv = (uint64_t)yv < rank_of[k].size() ? rank_of[k][(size_t)yv] : yv; }
+        if (xv != yv) return xv < yv;
+      }
+      return false;
+    });
+  } else { // first appearance (llkv-executor/src/lib.rs:5065-5089): lane 1 = row id of the group's first row
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return state[(size_t)a * K + 1] < state[(size_t)b * K + 1]; });
+  }
+  s->m_lanes.resize((size_t)n * K);
+  s->m_kv.resize((size_t)n * n_keys);
+  s->m_kvalid.resize((size_t)n * n_keys);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t g = order[i];
+    std::memcpy(s->m_lanes.data() + (size_t)i * K, state.data() + (size_t)g * K, (size_t)K * 8);
+    for (uint32_t k = 0; k < n_keys; ++k) {
+      s->m_kv[(size_t)k * n + i] = keys[g].v[k];
+      s->m_kvalid[(size_t)k * n + i] = keys[g].valid[k];
+    }
+  }
+  out->n = n;
+  out->lanes = s->m_lanes.data();
+  out->key_vals = s->m_kv.data();
+  out->key_valid = s->m_kvalid.data();
+  return LLKV_OK;
+}
 
 namespace {
 int pinned_reserve(void **p, size_t *cap, size_t bytes) {
@@ -59,7 +170,6 @@ int pinned_reserve(void **p, size_t *cap, size_t bytes) {
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                            const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
                            bool order_by_keys, SortedGroupBy **out) {
-  if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "sort-based GROUP BY on a sharded table");
   if (n_keys == 0 || n_keys > 4) return set_error(LLKV_UNSUPPORTED, "sort-based GROUP BY takes 1..4 keys");
   auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
     auto it = table->cols.find(fid);

@@ -100,3 +100,16 @@ def join_groupby_topk(dist, rt, join_agg, rank: int, world: int, limit: int, all
         parts = [(rows, reported)]
     merged = rt.merge_join_rows([r for p in parts for r in p[0]], join_agg.n_payload, limit)
     return merged, sum(p[1] for p in parts)
+
+
+def sorted_groupby(dist, prepared, world: int):
+    """GROUP BY of any cardinality over a sharded table (the sort-based route): this rank's shard is reduced on its
+    GPU, the partial groups of all ranks are all-gathered and merged in rank order on every rank
+    (llkv_hip_query_partial_groups / llkv_hip_query_merge_groups).  Returns the table-wide rows."""
+    prepared.launch(0)
+    prepared.finish_only()
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, prepared.partial_groups())
+        prepared.merge_groups(gathered)
+    return prepared.rows()

@@ -360,6 +360,31 @@ class PreparedQuery:
         self.launch(stream)
         return self.finish(stream)
 
+    def finish_only(self, stream: int = 0):
+        """llkv_hip_query_finish without building Python rows (the groups stay in the library's arrays)."""
+        check(lib().llkv_hip_query_finish(self._h, C.c_void_p(stream)))
+
+    def partial_groups(self):
+        """Sort-based GROUP BY over a sharded table, after launch + finish on this rank: the partial groups of its
+        rows as (key_values[n_keys][n] int64, key_valid[n_keys][n] uint8, lanes[n][k] uint64) numpy copies."""
+        n, nk, k = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        kv, kva, ln = C.POINTER(C.c_int64)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
+        check(lib().llkv_hip_query_partial_groups(self._h, C.byref(n), C.byref(nk), C.byref(k), C.byref(kv), C.byref(kva), C.byref(ln)))
+        if n.value == 0:
+            return np.zeros((nk.value, 0), np.int64), np.zeros((nk.value, 0), np.uint8), np.zeros((0, k.value), np.uint64)
+        return (np.ctypeslib.as_array(kv, shape=(nk.value, n.value)).copy(), np.ctypeslib.as_array(kva, shape=(nk.value, n.value)).copy(),
+                np.ctypeslib.as_array(ln, shape=(n.value, k.value)).copy())
+
+    def merge_groups(self, parts):
+        """Installs the table-wide groups from every rank's partial_groups() (in rank order); rows() then reads them."""
+        world = len(parts)
+        keep = [(np.ascontiguousarray(a, np.int64), np.ascontiguousarray(b, np.uint8), np.ascontiguousarray(c, np.uint64)) for a, b, c in parts]
+        counts = (C.c_uint64 * world)(*[c.shape[0] for _, _, c in keep])
+        kv = (C.c_void_p * world)(*[a.ctypes.data for a, _, _ in keep])
+        kva = (C.c_void_p * world)(*[b.ctypes.data for _, b, _ in keep])
+        ln = (C.c_void_p * world)(*[c.ctypes.data for _, _, c in keep])
+        check(lib().llkv_hip_query_merge_groups(self._h, C.c_uint32(world), counts, kv, kva, ln))
+
     def set_profiling(self, enabled):
         """False/0 off, True/1 every launch, n > 1: HIP events around every n-th scan."""
         check(lib().llkv_hip_query_set_profiling(self._h, C.c_int32(int(enabled))))

@@ -214,3 +214,52 @@ def test_two_ranks_install_identical_table_wide_statistics(tmp_path):
     mp.spawn(_stats_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     a, b = np.load(out + ".0.npy"), np.load(out + ".1.npy")
     assert a.tolist() == b.tolist() == [[1, 50], [8035, 10471], [-1, -1]]  # a column without statistics stays without
+
+
+class _FakeSortedQuery:
+    """Stands in for a PreparedQuery of the sort-based route (no GPU here): the driver under test only moves the
+    ranks' partial groups and hands them to merge_groups in rank order."""
+
+    def __init__(self, rank):
+        self.rank, self.calls, self.merged = rank, [], None
+
+    def launch(self, stream=0):
+        self.calls.append("launch")
+
+    def finish_only(self, stream=0):
+        self.calls.append("finish")
+
+    def partial_groups(self):
+        n = 3 + self.rank
+        return (np.full((2, n), self.rank, np.int64), np.ones((2, n), np.uint8), np.full((n, 4), 10 * self.rank, np.uint64))
+
+    def merge_groups(self, parts):
+        self.merged = parts
+
+    def rows(self):
+        return "rows"
+
+
+def _sorted_groupby_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q = _FakeSortedQuery(rank)
+    assert mod("dist").sorted_groupby(dist, q, world) == "rows"
+    assert q.calls == ["launch", "finish"] and len(q.merged) == world
+    np.save(out_path + f".{rank}.npy", np.array([[p[0].shape[1], int(p[0][0, 0]), int(p[2][0, 0])] for p in q.merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_partial_groups_in_rank_order(tmp_path):
+    """dist.sorted_groupby (GROUP BY of any cardinality over a sharded table): every rank receives every rank's partial
+    groups, in rank order, and merges them itself."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "parts")
+    mp.spawn(_sorted_groupby_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    assert a.tolist() == b.tolist() == [[3, 0, 0], [4, 1, 10]]
