@@ -444,6 +444,16 @@ llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group
 llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, uint32_t agg,
                                  llkv_value *out);
 
+/* DISTINCT aggregates over a SHARDED table (ungrouped COUNT / SUM / TOTAL / AVG): after launch + finish every rank
+ * exports the distinct values of its rows in order of first appearance (64-bit images: i64 values or f64 bit
+ * patterns), the binding all-gathers them, and llkv_hip_query_merge_distinct computes the aggregate over their union
+ * in rank order = the table's order of first appearance (checked i64 sums, f64 sums 0.0 then += — the accumulator's
+ * own order, so the merged f64 sums are bit-exact with the reference's).  llkv_hip_query_value then returns it.      */
+llkv_status llkv_hip_query_distinct_partial(llkv_hip_query *query, uint32_t agg, const uint64_t **values,
+                                            uint64_t *n_values);
+llkv_status llkv_hip_query_merge_distinct(llkv_hip_query *query, uint32_t agg, uint32_t world,
+                                          const uint64_t *rank_counts, const uint64_t *const *rank_values);
+
 /* GROUP BY of any cardinality over a SHARDED table (the sort-based route; the dense route combines through the
  * exchange image above).  Every rank runs the query over its own chunks — launch, finish — and then holds partial
  * groups: `key_values[n_keys][n]` (integers; Utf8 as codes of the table-wide dictionary), `key_valid[n_keys][n]`

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace llkv {
 
@@ -116,7 +117,6 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
         if (kind == LLKV_AGG_MIN || kind == LLKV_AGG_MAX || kind == LLKV_AGG_COUNT_STAR) continue;
         if (kind != LLKV_AGG_COUNT && kind != LLKV_AGG_SUM && kind != LLKV_AGG_TOTAL && kind != LLKV_AGG_AVG)
           return set_error(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind " + std::to_string(kind));
-        if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "DISTINCT aggregates on a sharded table");
         if (!aggs[a].expr || !aggs[a].expr_len) return set_error(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
         Query::DistinctAgg &da = q->distinct[a];
         if ((rc = lower_emit(resolve, filters, n_filters, ops, n_ops, aggs[a].expr, aggs[a].expr_len, &da.plan, &err, /*allow_f64=*/true, &da.is_f64)))
@@ -481,9 +481,9 @@ int Query::exact_prefix_overflow(size_t agg, bool *overflow) {
 // accumulator adds a value the first time it sees it, so the sum runs over the distinct values in order of
 // FIRST APPEARANCE.  Selected values in row order → stable sort by value → run heads (= first appearances) →
 // back into row order → exact i64 prefix scan / ordered f64 sum.
-int Query::distinct_value(size_t agg, llkv_value *out) {
+// The distinct values of this rank's selected rows, in order of first appearance (device memory).
+int Query::distinct_set(size_t agg, Scratch *dv_out, uint64_t *m_out) {
   const DistinctAgg &da = distinct[agg];
-  std::memset(out, 0, sizeof *out);
   hipStream_t s = g_ctx.stream;
   Scratch vals;
   uint64_t n = 0;
@@ -491,7 +491,7 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
   if (rc) return rc;
   if (n >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "more than 2^32 selected rows in a DISTINCT aggregate");
   uint64_t m = 0; // distinct values
-  Scratch dv;     // … in order of first appearance
+  Scratch &dv = *dv_out;
   if (n) {
     Scratch pos, vals_s, pos_s, flags, offs, tmp, hv, hp, hp_s;
     if ((rc = pos.alloc(n * 4)) || (rc = vals_s.alloc(n * 8)) || (rc = pos_s.alloc(n * 4)) || (rc = flags.alloc((n + 1) * 8)) || (rc = offs.alloc((n + 1) * 8))) return rc;
@@ -543,6 +543,18 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
     if (vmin) HIP_TRY(hj_launch_add_u64(dv.as<uint64_t>(), m, vmin, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
+  *m_out = m;
+  return LLKV_OK;
+}
+
+int Query::distinct_value(size_t agg, llkv_value *out) {
+  const DistinctAgg &da = distinct[agg];
+  std::memset(out, 0, sizeof *out);
+  hipStream_t s = g_ctx.stream;
+  Scratch dv;
+  uint64_t m = 0;
+  int rc = distinct_set(agg, &dv, &m);
+  if (rc) return rc;
   auto f64_sum = [&](int as_int, double *sum) -> int {
     *sum = 0.0;
     if (m == 0) return LLKV_OK;
@@ -580,6 +592,73 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
   }
   default: return set_error(LLKV_INTERNAL, "not a DISTINCT aggregate");
   }
+}
+
+// Sharded tables: this rank's distinct values go to the host; the binding all-gathers them.
+int Query::distinct_partial(size_t agg, const uint64_t **values, uint64_t *n) {
+  if (agg >= distinct.size() || distinct[agg].kind < 0) return set_error(LLKV_INVALID_ARGUMENT, "not a DISTINCT aggregate");
+  Scratch dv;
+  uint64_t m = 0;
+  int rc = distinct_set(agg, &dv, &m);
+  if (rc) return rc;
+  if (distinct_host.size() < distinct.size()) distinct_host.resize(distinct.size());
+  std::vector<uint64_t> &h = distinct_host[agg];
+  h.resize(m);
+  if (m && (rc = fetch_to_host(h.data(), dv.p, m * 8))) return rc;
+  *values = h.data();
+  *n = m;
+  return LLKV_OK;
+}
+
+// The ranks' distinct values in rank order = the table's order of first appearance; the aggregate over their
+// union follows the accumulator's own rules (llkv-aggregate/src/lib.rs: a value is added the first time it is
+// seen; i64 sums checked, f64 sums 0.0 then += in that order).
+int Query::merge_distinct(size_t agg, uint32_t world, const uint64_t *counts, const uint64_t *const *values) {
+  if (agg >= distinct.size() || distinct[agg].kind < 0) return set_error(LLKV_INVALID_ARGUMENT, "not a DISTINCT aggregate");
+  if (groups.empty() || agg >= groups[0].values.size()) return set_error(LLKV_INVALID_ARGUMENT, "finish the query before merging");
+  const DistinctAgg &da = distinct[agg];
+  std::unordered_set<uint64_t> seen;
+  std::vector<uint64_t> all;
+  for (uint32_t r = 0; r < world; ++r) {
+    if (counts[r] && !values[r]) return set_error(LLKV_INVALID_ARGUMENT, "distinct values of a rank are missing");
+    for (uint64_t i = 0; i < counts[r]; ++i)
+      if (seen.insert(values[r][i]).second) all.push_back(values[r][i]);
+  }
+  const uint64_t m = all.size();
+  llkv_value out;
+  std::memset(&out, 0, sizeof out);
+  auto as_f64 = [&](uint64_t bits) { double d; if (da.is_f64) std::memcpy(&d, &bits, 8); else d = (double)(int64_t)bits; return d; };
+  switch (da.kind) {
+  case LLKV_AGG_COUNT: out.dtype = LLKV_DT_INT64; out.i64 = (int64_t)m; break;
+  case LLKV_AGG_TOTAL: {
+    out.dtype = LLKV_DT_FLOAT64;
+    double acc = 0.0;
+    for (uint64_t v : all) acc += as_f64(v);
+    out.f64 = acc;
+    break;
+  }
+  case LLKV_AGG_SUM: case LLKV_AGG_AVG: {
+    const bool avg = da.kind == LLKV_AGG_AVG;
+    out.dtype = (avg || da.is_f64) ? LLKV_DT_FLOAT64 : LLKV_DT_INT64;
+    if (m == 0) { out.is_null = 1; break; }
+    if (da.is_f64) {
+      double acc = 0.0;
+      for (uint64_t v : all) acc += as_f64(v);
+      out.f64 = avg ? acc / (double)m : acc;
+      break;
+    }
+    int64_t acc = 0;
+    for (uint64_t v : all)
+      if (__builtin_add_overflow(acc, (int64_t)v, &acc))
+        return set_error(LLKV_INVALID_ARGUMENT, avg ? "AVG(DISTINCT) aggregate sum exceeds i64 range" : "integer overflow");
+    if (avg) out.f64 = (double)acc / (double)m;
+    else out.i64 = acc;
+    break;
+  }
+  default: return set_error(LLKV_INTERNAL, "not a DISTINCT aggregate");
+  }
+  groups[0].values[agg] = out;
+  return LLKV_OK;
 }
 
 int Query::finish_from_exchange(const uint64_t *exchange) {
@@ -627,7 +706,7 @@ int Query::finish_from_exchange(const uint64_t *exchange) {
     }
     if (!p.grouped)
       for (size_t a = 0; a < distinct.size() && a < gr.values.size(); ++a)
-        if (distinct[a].kind >= 0) { int rc = distinct_value(a, &gr.values[a]); if (rc) return rc; }
+        if (distinct[a].kind >= 0 && table->world == 1) { int rc = distinct_value(a, &gr.values[a]); if (rc) return rc; } // sharded: merge_distinct
     groups.push_back(std::move(gr));
   }
   if (p.grouped) {
@@ -912,6 +991,20 @@ llkv_status llkv_hip_query_merge_groups(llkv_hip_query *query, uint32_t world, c
   if (!q || !q->sorted || !q->lazy.active) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "not a finished sort-based GROUP BY");
   if (world == 0 || !rank_groups || !key_values || !key_valid || !lanes) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
   return (llkv_status)sorted_groupby_merge(q->sorted, world, rank_groups, key_values, key_valid, lanes, &q->lazy);
+}
+
+llkv_status llkv_hip_query_distinct_partial(llkv_hip_query *query, uint32_t agg, const uint64_t **values, uint64_t *n_values) {
+  Query *q = reinterpret_cast<Query *>(query);
+  if (!q || !values || !n_values) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (int rc = ensure_device()) return (llkv_status)rc;
+  return (llkv_status)q->distinct_partial(agg, values, n_values);
+}
+
+llkv_status llkv_hip_query_merge_distinct(llkv_hip_query *query, uint32_t agg, uint32_t world, const uint64_t *rank_counts,
+                                          const uint64_t *const *rank_values) {
+  Query *q = reinterpret_cast<Query *>(query);
+  if (!q || world == 0 || !rank_counts || !rank_values) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  return (llkv_status)q->merge_distinct(agg, world, rank_counts, rank_values);
 }
 
 llkv_status llkv_hip_query_set_profiling(llkv_hip_query *query, int32_t enabled) {

@@ -190,7 +190,12 @@ struct Query {
   struct DistinctAgg { int kind = -1; bool is_f64 = false; LoweredPlan plan; };
   std::vector<DistinctAgg> distinct;
   int emit_values(const LoweredPlan &ep, Scratch *vals, uint64_t *n);
+  int distinct_set(size_t agg, Scratch *dv, uint64_t *m);
   int distinct_value(size_t agg, llkv_value *out);
+  // sharded tables: this rank's distinct values on the host / the merged result (llkv_hip_query_distinct_partial, merge_distinct)
+  std::vector<std::vector<uint64_t>> distinct_host;
+  int distinct_partial(size_t agg, const uint64_t **values, uint64_t *n);
+  int merge_distinct(size_t agg, uint32_t world, const uint64_t *counts, const uint64_t *const *values);
   bool profiling = false;
   uint32_t profile_every = 1; // bracket every n-th scan with HIP events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

@@ -113,3 +113,15 @@ def sorted_groupby(dist, prepared, world: int):
         dist.all_gather_object(gathered, prepared.partial_groups())
         prepared.merge_groups(gathered)
     return prepared.rows()
+
+
+def distinct_aggregates(dist, prepared, distinct_aggs: Sequence[int], world: int):
+    """Ungrouped aggregates with DISTINCT ones among them over a sharded table: the usual exchange-image combine is
+    the caller's (launch / all-reduce / finish); this adds the per-aggregate exchange of the ranks' distinct values
+    and their merge in rank order.  Returns the rows."""
+    if world > 1:
+        for a in distinct_aggs:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, prepared.distinct_partial(a))
+            prepared.merge_distinct(a, gathered)
+    return prepared.rows()

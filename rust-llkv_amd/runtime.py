@@ -364,6 +364,20 @@ class PreparedQuery:
         """llkv_hip_query_finish without building Python rows (the groups stay in the library's arrays)."""
         check(lib().llkv_hip_query_finish(self._h, C.c_void_p(stream)))
 
+    def distinct_partial(self, agg: int) -> np.ndarray:
+        """DISTINCT aggregate ``agg`` over a sharded table: this rank's distinct values (uint64 images) in order of
+        first appearance."""
+        vals, n = C.POINTER(C.c_uint64)(), C.c_uint64()
+        check(lib().llkv_hip_query_distinct_partial(self._h, C.c_uint32(agg), C.byref(vals), C.byref(n)))
+        return np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+
+    def merge_distinct(self, agg: int, parts):
+        """Installs the table-wide value of DISTINCT aggregate ``agg`` from every rank's distinct_partial (rank order)."""
+        keep = [np.ascontiguousarray(p, np.uint64) for p in parts]
+        counts = (C.c_uint64 * len(keep))(*[len(p) for p in keep])
+        ptrs = (C.c_void_p * len(keep))(*[p.ctypes.data for p in keep])
+        check(lib().llkv_hip_query_merge_distinct(self._h, C.c_uint32(agg), C.c_uint32(len(keep)), counts, ptrs))
+
     def partial_groups(self):
         """Sort-based GROUP BY over a sharded table, after launch + finish on this rank: the partial groups of its
         rows as (key_values[n_keys][n] int64, key_valid[n_keys][n] uint8, lanes[n][k] uint64) numpy copies."""
