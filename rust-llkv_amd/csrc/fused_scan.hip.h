@@ -210,17 +210,36 @@ constexpr uint32_t kErrOverflow = 1u, kErrDivZero = 2u;
 // arrow-arith numeric::{add,sub,mul,rem}: IEEE for floats; integers checked (overflow is an error,
 // fast_numeric.rs:328-334 → Error::Internal) except `%`, which is a zero check ("Divide by zero") followed by
 // mod_wrapping; a node is evaluated only where both operands are valid.
-template <int OP, class L, class R> struct Bin {
+// The NaN an f64 operation returns, as the reference's host computes it (SSE2 scalar arithmetic): a NaN operand comes
+// back quieted WITH ITS SIGN (the first operand's when both are NaN), an invalid operation (∞ − ∞, 0 · ∞, …) gives the
+// negative "real indefinite" quiet NaN.  CDNA would hand back a NaN of the other sign in both cases (a − NaN flips the
+// operand's sign, invalid operations give +NaN), and arrow compares floats by totalOrder — where −NaN is below and
+// +NaN above everything — so the sign of a computed NaN decides `Expr::Compare` and IN-list results.
+// (Only where the bits of a NaN can be observed — template flag EXACT_NAN of Bin / Div, set by the lowering for compare /
+// IN-list sides, projected and emitted values; aggregate arguments skip it: no accumulator looks at a NaN's sign, and
+// the fix-up costs the Q1 kernel 5 %.)
+__device__ __forceinline__ double f64_result_as_sse2(double r, double a, double b) {
+  if (r == r) return r;
+  const long long quiet = 0x0008000000000000ll;
+  if (a != a) return __longlong_as_double(__double_as_longlong(a) | quiet);
+  if (b != b) return __longlong_as_double(__double_as_longlong(b) | quiet);
+  return __longlong_as_double((long long)0xFFF8000000000000ull);
+}
+
+template <int OP, class L, class R, int EXACT_NAN = 0> struct Bin {
   using Type = typename L::Type;
   static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j); }
   static __device__ __forceinline__ typename Type::T eval(Ctx &c, int j) {
     const auto a = L::eval(c, j);
     const auto b = R::eval(c, j);
     if constexpr (Type::is_float) {
-      if constexpr (OP == B_ADD) return a + b;
-      else if constexpr (OP == B_SUB) return a - b;
-      else if constexpr (OP == B_MUL) return a * b;
-      else return fmod(a, b);
+      double r;
+      if constexpr (OP == B_ADD) r = a + b;
+      else if constexpr (OP == B_SUB) r = a - b;
+      else if constexpr (OP == B_MUL) r = a * b;
+      else r = fmod(a, b);
+      if constexpr (EXACT_NAN) return f64_result_as_sse2(r, a, b);
+      else return r;
     } else if constexpr (OP == B_REM) {
       const bool ok = valid(c, j);
       const int64_t x = (int64_t)a, y = (int64_t)b;
@@ -245,13 +264,16 @@ template <class L, class R> using Mul = Bin<B_MUL, L, R>;
 // Divide on the generic (per-node typed) path, compute_binary llkv-compute/src/kernels.rs:99-177: zeros of
 // the divisor become NULLs first, then arrow `div` — truncating and checked for integers (i64::MIN / -1
 // overflows), IEEE for floats.  The operands arrive coerced to their common type.
-template <class L, class R> struct Div {
+template <class L, class R, int EXACT_NAN = 0> struct Div {
   using Type = typename L::Type;
   static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & (R::eval(c, j) != 0); }
   static __device__ __forceinline__ typename Type::T eval(Ctx &c, int j) {
     const auto a = L::eval(c, j);
     const auto b = R::eval(c, j);
-    if constexpr (Type::is_float) return a / b;
+    if constexpr (Type::is_float) {
+      if constexpr (EXACT_NAN) return f64_result_as_sse2(a / b, a, b);
+      else return a / b;
+    }
     else {
       const int64_t x = (int64_t)a, y = (int64_t)b;
       const bool ovf = (x == (int64_t)0x8000000000000000ull) & (y == -1);
@@ -514,6 +536,17 @@ template <class V> struct CountIf {
   static constexpr int N = 1;
   static constexpr int op(int) { return OP_ADD_I64; }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = V::eval(c, j) ? 1u : 0u; }
+};
+// The same over a COMPUTED argument: the reference materialises the projection for every selected row before any
+// accumulator sees it (llkv-executor/src/lib.rs:470-501), so a checked-arithmetic error in it (overflow, % by zero)
+// fails the query even though COUNT only looks at the validity — the expression is evaluated for that effect.
+template <class V, class E> struct CountIfE {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    (void)E::eval(c, j);
+    o[0] = V::eval(c, j) ? 1u : 0u;
+  }
 };
 // Any accumulator over an argument with NULL cells: a NULL row contributes every lane's identity (accumulators
 // skip NULLs), and one more lane counts the non-NULL

@@ -149,6 +149,11 @@ struct Lowering {
   LoweredPlan &p;
   std::string *err;
   bool grouped;
+  // f64 nodes that must return a computed NaN exactly as the reference's host does (sign included): set where the
+  // NaN's bits are observable — totalOrder compares, IN lists, projected / emitted values — and left off for aggregate
+  // arguments, where no accumulator looks at them (fused_scan.hip.h: f64_result_as_sse2; it costs Q1 5 %)
+  bool exact_nan = false;
+  std::string nan_flag(bool is_float) const { return exact_nan && is_float ? ",1" : ""; }
 
   int fail(int code, const std::string &m) { return set_err(err, code, m); }
 
@@ -499,6 +504,7 @@ struct Lowering {
   // (literal_type, llkv-compute/src/eval.rs:167-185), a computed side has the fast path's result type.
   enum class Side { S32, U32, S64, U64, F };
   int expr_side(const llkv_expr_token *e, uint32_t n, std::string *node, Side *cls) {
+    struct Exact { bool &f, was; explicit Exact(bool &x) : f(x), was(x) { f = true; } ~Exact() { f = was; } } exact(exact_nan); // compared by totalOrder
     for (uint32_t i = 0; i < n; ++i)
       if (e[i].kind == LLKV_TOK_LITERAL && e[i].literal.tag == LLKV_LIT_NULL) return fail(LLKV_UNSUPPORTED, "NULL literal in a comparison");
     if (n == 1 && e[0].kind == LLKV_TOK_COLUMN) {
@@ -730,7 +736,7 @@ struct Lowering {
         std::string r = st.back(); st.pop_back();
         std::string l = st.back(); st.pop_back();
         const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
-        st.push_back("Bin<" + std::to_string(op) + "," + l + "," + r + ">");
+        st.push_back("Bin<" + std::to_string(op) + "," + l + "," + r + nan_flag(any_float) + ">");
       }
     }
     if (st.size() != 1) return fail(LLKV_INTERNAL, "fast path evaluation missing result");
@@ -767,10 +773,10 @@ struct Lowering {
         V l = st.back(); st.pop_back();
         const bool f = l.f || r.f; // get_common_type: Int64 ⊕ Float64 → Float64
         const std::string a = (f && !l.f) ? "ToF64<" + l.s + ">" : l.s, b = (f && !r.f) ? "ToF64<" + r.s + ">" : r.s;
-        if (e[i].binop == LLKV_BIN_DIV) st.push_back({"Div<" + a + "," + b + ">", f});
+        if (e[i].binop == LLKV_BIN_DIV) st.push_back({"Div<" + a + "," + b + nan_flag(f) + ">", f});
         else {
           const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
-          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + ">", f});
+          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + nan_flag(f) + ">", f});
         }
       }
     }
@@ -816,7 +822,7 @@ struct Lowering {
         if (!l.f && !r.f) st.push_back({"BinViaF64<" + std::to_string(op) + "," + l.s + "," + r.s + ">", false});
         else {
           const std::string a = l.f ? l.s : "ToF64<" + l.s + ">", b = r.f ? r.s : "ToF64<" + r.s + ">";
-          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + ">", true});
+          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + nan_flag(true) + ">", true});
         }
       }
     }
@@ -873,7 +879,11 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     }
     if (s.kind == LLKV_AGG_COUNT || s.kind == LLKV_AGG_COUNT_NULLS) {
       // NULL-free argument: COUNT(x) = rows, COUNT_NULLS(x) = 0
-      if (valid.empty()) o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
+      if (!simple && !grouped) {
+        // a computed argument is evaluated for its checked-arithmetic errors even though only its validity counts
+        o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountValid : AggFinal::CountNulls;
+        o.lane = add_group("CountIfE<" + (valid.empty() ? std::string("True") : valid) + "," + node + ">", {ADD_I64});
+      } else if (valid.empty()) o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
       else {
         o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountValid : AggFinal::CountNulls;
         o.lane = add_group("CountIf<" + valid + ">", {ADD_I64});
@@ -1179,7 +1189,10 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     val = L.col_node(slot, ci->dtype);
     is_f64 = ci->dtype == LLKV_DT_FLOAT64;
   } else {
-    if ((rc = L.expr_fast(expr, expr_len, &val, &is_f64))) return rc;
+    L.exact_nan = true; // the emitted values are told apart by their bits (DISTINCT)
+    rc = L.expr_fast(expr, expr_len, &val, &is_f64);
+    L.exact_nan = false;
+    if (rc) return rc;
     if (is_f64 && !allow_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
   }
   if (is_f64_out) *is_f64_out = is_f64;
@@ -1254,7 +1267,10 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
         out->out_dtypes.push_back(ci->dtype);
         out->out_fields.push_back((int32_t)pr.expr[0].field_id);
       } else {
-        if ((rc = L.expr_fast(pr.expr, pr.expr_len, &node, &is_f64))) return rc;
+        L.exact_nan = true; // the consumer sees the bits of a projected value
+        rc = L.expr_fast(pr.expr, pr.expr_len, &node, &is_f64);
+        L.exact_nan = false;
+        if (rc) return rc;
         out->out_dtypes.push_back(is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64);
         out->out_fields.push_back(-1);
       }

@@ -36,14 +36,19 @@ def stage_both(rt, orc, abi, columns, chunk_rows):
     return ht, ot
 
 
-def assert_values(got, want, ctx=""):
+def assert_values(got, want, ctx="", abs_floor=0.0):
+    """``abs_floor``: sums whose terms cancel are compared absolutely below this (the 1e-9 of the contract is relative
+    to the magnitude of what was added, not to a result that happens to be ≈ 0)."""
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert g.dtype == w.dtype, (ctx, g, w)
         if w.value is None or isinstance(w.value, int):
             assert g.value == w.value, (ctx, g, w)
         else:
-            assert same_value(g.value, w.value, REL), (ctx, g, w)
+            ok = same_value(g.value, w.value, REL)
+            if not ok and abs_floor and isinstance(g.value, float) and isinstance(w.value, float):
+                ok = abs(g.value - w.value) <= abs_floor
+            assert ok, (ctx, g, w)
 
 
 def lineitem(tpch, abi, rows, scale, cols=None):
@@ -855,7 +860,7 @@ def _random_predicate(rng, abi, depth):
     return tree(depth)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 114, 122, 128, 141])  # the last four: computed NaNs under totalOrder compares
 def test_random_predicate_trees_match_oracle(rt, orc, abi, seed):
     """Seeded random predicate trees (leaves, compares, IN lists, IS NULL over expressions, divisions, nested
     AND / OR / NOT over columns with NULL cells): the selected row ids must equal the oracle's, which restates the
@@ -892,7 +897,7 @@ def test_random_predicate_trees_match_oracle(rt, orc, abi, seed):
     assert checked >= 10
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 120, 122, 158])  # 122, 158: COUNT over an argument whose arithmetic fails
 def test_random_aggregate_lists_match_oracle(rt, orc, abi, seed):
     """Seeded random aggregate lists over bare columns and random expressions (NULL cells, + - * / %), ungrouped
     (fast / generic projection typing) and grouped (PlanValue typing; dense and sort-based routes)."""
@@ -949,9 +954,9 @@ def test_random_aggregate_lists_match_oracle(rt, orc, abi, seed):
             if grouped:
                 assert [[x.value for x in r.keys] for r in got] == [[x.value for x in r.keys] for r in want]
                 for a, b in zip(got, want):
-                    assert_values(a.values, b.values, f"seed {seed} case {k} grouped")
+                    assert_values(a.values, b.values, f"seed {seed} case {k} grouped", abs_floor=1e-9)
             else:
-                assert_values(got, want, f"seed {seed} case {k}")
+                assert_values(got, want, f"seed {seed} case {k}", abs_floor=1e-9)
             checked += 1
     assert checked >= 8
 

@@ -245,7 +245,7 @@ def test_compare_lowering_follows_the_common_type_rules(lib, abi):
     assert "Cmp<2,ToI64<Col<0,I32>>,LitI<0>>" in ts
     # the reference's own case: UInt64 + Int32 is Float64, so the Int64 literal is compared as Float64
     ts, _, _ = rt.lower_plan(d, E.compare(col(4) + col(3), abi.CMP_GT, 220), cnt)
-    assert "Cmp<5,Bin<1,ToF64<Col<0,U64>>,ToF64<Col<1,I32>>>,ToF64<LitI<0>>>" in ts
+    assert "Cmp<5,Bin<1,ToF64<Col<0,U64>>,ToF64<Col<1,I32>>,1>,ToF64<LitI<0>>>" in ts  # ",1": a computed NaN keeps the host's sign (totalOrder)
     # signed ⋈ unsigned: 64 bits wide → Float64, 32 bits → Int64; unsigned ⋈ unsigned stays unsigned
     assert "Cmp<3,ToF64<Col<0,I64>>,ToF64<Col<1,U64>>>" in rt.lower_plan(d, E.compare(col(1), abi.CMP_LT, col(4)), cnt)[0]
     assert "Cmp<3,ToF64<ToI64<Col<0,U32>>>,ToF64<Col<1,I64>>>" in rt.lower_plan(d, E.compare(col(5), abi.CMP_LT, col(1)), cnt)[0]
