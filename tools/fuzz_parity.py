@@ -11,7 +11,7 @@ from oracle import oracle as orc
 rt.init(0)
 import test_gpu_parity as T
 bad = []
-for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 200)), ("test_random_aggregate_lists_match_oracle", range(160, 180))):
+for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 120)), ("test_random_aggregate_lists_match_oracle", range(160, 166))):
     f = getattr(T, name)
     f = getattr(f, "__wrapped__", f)
     for seed in seeds:
@@ -24,3 +24,59 @@ for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 200)
             if len(bad) > 12: break
     print(name, "done", flush=True)
 print("FAILURES:", bad)
+
+
+# ---- computed scan projections: values compared BIT FOR BIT (NaN signs included), NULLs, arithmetic errors --------
+import numpy as np
+
+
+def fuzz_projections(seeds):
+    bad = []
+    col = abi.col
+    for seed in seeds:
+        rng = np.random.default_rng(9000 + seed)
+        chunks = [4096, 3000, 77]
+        n = sum(chunks)
+        i1 = rng.integers(-6, 7, size=n).astype(np.int64)
+        i2 = rng.integers(-3, 4, size=n).astype(np.int64)
+        f3 = rng.integers(-8, 9, size=n).astype(np.float64) / 2
+        f3[rng.random(n) < 0.05] = np.nan
+        f3[rng.random(n) < 0.03] = np.inf
+        f3[rng.random(n) < 0.03] = -0.0
+        f4 = rng.integers(-4, 5, size=n).astype(np.float64)
+        v1, v3 = rng.random(n) > 0.2, rng.random(n) > 0.2
+        ht, ot = T.stage_both(rt, orc, abi, [(1, abi.DT_INT64, i1, v1), (2, abi.DT_INT64, i2), (3, abi.DT_FLOAT64, f3, v3), (4, abi.DT_FLOAT64, f4)], chunks)
+        for k in range(12):
+            e = col(int(rng.choice([1, 2, 3, 4])))
+            for _ in range(int(rng.integers(1, 4))):
+                other = col(int(rng.choice([1, 2, 3, 4]))) if rng.random() < 0.7 else (int(rng.integers(-3, 4)) if rng.random() < 0.5 else float(rng.integers(-3, 4)) / 2)
+                op = rng.choice(["+", "-", "*", "/", "%"], p=[0.25, 0.3, 0.25, 0.1, 0.1])
+                e = {"+": lambda a, b: a + b, "-": lambda a, b: a - b, "*": lambda a, b: a * b, "/": lambda a, b: a / b, "%": lambda a, b: a % b}[op](e, other)
+            pred = None if k % 2 else [abi.Filter(2, abi.Operator.GreaterThanOrEquals(0))]
+            try:
+                want = orc.scan_stream(ot, [e], pred, include_nulls=True, include_row_ids=True)
+            except abi.LlkvError as oe:
+                try:
+                    rt.scan_stream(ht, [e], pred, include_nulls=True, include_row_ids=True)
+                    bad.append((seed, k, "oracle raised, GPU did not", str(oe), e.tokens))
+                except abi.LlkvError:
+                    pass
+                continue
+            try:
+                got = rt.scan_stream(ht, [e], pred, include_nulls=True, include_row_ids=True)
+            except abi.LlkvError as ge:
+                if ge.kind != "Unsupported":
+                    bad.append((seed, k, "GPU raised", str(ge), e.tokens))
+                continue
+            bits = lambda bs: [None if x is None else (np.float64(x).tobytes() if isinstance(x, float) else x) for b in bs for x in b[0][0]]
+            if [x for b in got for x in b[1]] != [x for b in want for x in b[1]] or bits(got) != bits(want):
+                gb, wb = bits(got), bits(want)
+                first = next(i for i in range(min(len(gb), len(wb))) if gb[i] != wb[i]) if len(gb) == len(wb) else -1
+                bad.append((seed, k, "values differ", first, e.tokens))
+    return bad
+
+
+pb = fuzz_projections(range(40))
+print("PROJECTION FAILURES:", len(pb))
+for b in pb[:10]:
+    print("  ", b)
