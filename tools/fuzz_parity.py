@@ -11,7 +11,7 @@ from oracle import oracle as orc
 rt.init(0)
 import test_gpu_parity as T
 bad = []
-for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 120)), ("test_random_aggregate_lists_match_oracle", range(160, 166))):
+for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 104)), ("test_random_aggregate_lists_match_oracle", range(160, 162))):
     f = getattr(T, name)
     f = getattr(f, "__wrapped__", f)
     for seed in seeds:
@@ -76,7 +76,77 @@ def fuzz_projections(seeds):
     return bad
 
 
-pb = fuzz_projections(range(40))
+pb = fuzz_projections(range(int(os.environ.get("LLKV_FUZZ_PROJECTIONS", "8"))))
 print("PROJECTION FAILURES:", len(pb))
 for b in pb[:10]:
+    print("  ", b)
+
+
+# ---- joins: random key lists (types, NULLs, null_equals_null), join types, batch sizes, both key rule sets ---------
+def fuzz_joins(seeds):
+    bad = []
+    JT = {"inner": 0, "left": 1, "semi": 4, "anti": 5}
+    for seed in seeds:
+        rng = np.random.default_rng(7000 + seed)
+        n_left, n_right = int(rng.integers(1, 90_000)), int(rng.integers(0, 3000))
+        chunks = [n_left] if n_left < 70_000 else [n_left - 66_000, 60_000, 6_000]
+        words = ["a", "bb", "<NULL>", "", "zz"]
+
+        def column(n, kind):
+            if kind == "i64": return abi.DT_INT64, rng.integers(-5, 60, size=n).astype(np.int64)
+            if kind == "i32": return abi.DT_INT32, rng.integers(-5, 60, size=n).astype(np.int32)
+            if kind == "f64": return abi.DT_FLOAT64, rng.choice(np.array([0.0, -0.0, np.nan, 1.5, 2.0, 7.25]), size=n)
+            if kind == "d32": return abi.DT_DATE32, rng.integers(0, 30, size=n).astype(np.int32)
+            return abi.DT_UTF8, [words[k] for k in rng.integers(0, len(words), size=n)]
+
+        n_keys = int(rng.integers(1, 3))
+        kinds = [(str(rng.choice(["i64", "i32", "f64", "d32", "utf8"])), str(rng.choice(["i64", "i32", "f64", "d32", "utf8"])) if rng.random() < 0.25 else None) for _ in range(n_keys)]
+        cols_l, cols_r, keys = [], [], []
+        for k, (kl, kr) in enumerate(kinds):
+            kr = kr or kl
+            dl, vl = column(n_left, kl)
+            dr, vr = column(n_right, kr)
+            ml = None if dl == abi.DT_UTF8 or rng.random() < 0.4 else rng.random(n_left) > 0.1
+            mr = None if dr == abi.DT_UTF8 or rng.random() < 0.4 else rng.random(n_right) > 0.1
+            if dl == abi.DT_UTF8 and rng.random() < 0.5: vl = [None if rng.random() < 0.1 else x for x in vl]
+            if dr == abi.DT_UTF8 and rng.random() < 0.5: vr = [None if rng.random() < 0.1 else x for x in vr]
+            cols_l.append((k + 1, dl, vl, ml)); cols_r.append((k + 11, dr, vr, mr))
+            keys.append((k + 1, k + 11, bool(rng.random() < 0.5)))
+        try:
+            tabs = T._keyed_tables(rt, orc, abi, cols_l, cols_r, chunks, n_right)
+        except abi.LlkvError as e:
+            continue
+        lt, rtab, ol, orr = tabs
+        for _ in range(3):
+            jt = str(rng.choice(["inner", "left", "semi", "anti"]))
+            batch = int(rng.choice([7, 1000, 8192, 100_000]))
+            rules = int(rng.random() < 0.3)
+            if rules: keys_used = [(a, b) for a, b, _ in keys]
+            else: keys_used = keys
+            try:
+                want = orc.hash_join(ol, orr, keys_used, JT[jt], batch, key_rules=rules)
+            except abi.LlkvError as oe:
+                try:
+                    rt.join_stream(lt, rtab, keys_used, JT[jt], batch, key_rules=rules)
+                    bad.append((seed, "oracle raised, GPU did not", str(oe), kinds, jt, rules))
+                except abi.LlkvError:
+                    pass
+                continue
+            if sum(len(b[0]) for b in want) > 3_000_000:
+                continue
+            try:
+                got = rt.join_stream(lt, rtab, keys_used, JT[jt], batch, key_rules=rules)
+            except abi.LlkvError as ge:
+                if ge.kind != "Unsupported": bad.append((seed, "GPU raised", str(ge), kinds, jt, rules))
+                continue
+            same = [x for b in got for x in b[0]] == [x for b in want for x in b[0]] and \
+                   (jt in ("semi", "anti") or [x for b in got for x in b[1]] == [x for b in want for x in b[1]]) and \
+                   (rules == 1 or [len(b[0]) for b in got] == [len(b[0]) for b in want])
+            if not same: bad.append((seed, "pairs differ", kinds, keys_used, jt, batch, rules, n_left, n_right))
+    return bad
+
+
+jb = fuzz_joins(range(60))
+print("JOIN FAILURES:", len(jb))
+for b in jb[:10]:
     print("  ", b)
