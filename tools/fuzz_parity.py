@@ -150,3 +150,50 @@ jb = fuzz_joins(range(60))
 print("JOIN FAILURES:", len(jb))
 for b in jb[:10]:
     print("  ", b)
+
+
+# ---- DISTINCT aggregates over random expressions (NaN, ±0, NULLs) --------------------------------------------------
+def fuzz_distinct(seeds):
+    import dataclasses
+    bad = []
+    col, A = abi.col, abi.AggregateSpec
+    for seed in seeds:
+        rng = np.random.default_rng(5000 + seed)
+        n = int(rng.integers(100, 9000))
+        i1 = rng.integers(-6, 7, size=n).astype(np.int64)
+        f3 = rng.integers(-8, 9, size=n).astype(np.float64) / 2
+        f3[rng.random(n) < 0.05] = np.nan
+        f3[rng.random(n) < 0.05] = -0.0
+        v1, v3 = rng.random(n) > 0.2, rng.random(n) > 0.2
+        ht, ot = T.stage_both(rt, orc, abi, [(1, abi.DT_INT64, i1, v1), (3, abi.DT_FLOAT64, f3, v3)], [n])
+        for k in range(5):
+            e = col(int(rng.choice([1, 3])))
+            if rng.random() < 0.6:
+                other = col(int(rng.choice([1, 3]))) if rng.random() < 0.6 else float(rng.integers(-2, 3))
+                e = {"+": lambda a, b: a + b, "-": lambda a, b: a - b, "*": lambda a, b: a * b}[str(rng.choice(["+", "-", "*"]))](e, other)
+            aggs = [dataclasses.replace(getattr(A, kind)(e), distinct=True) for kind in ("count", "sum", "avg", "total")]
+            try:
+                want = orc.aggregate(ot, None, aggs)
+            except abi.LlkvError as oe:
+                try:
+                    rt.aggregate(ht, None, aggs)
+                    bad.append((seed, k, "oracle raised, GPU did not", str(oe), e.tokens))
+                except abi.LlkvError:
+                    pass
+                continue
+            try:
+                got = rt.aggregate(ht, None, aggs)
+            except abi.LlkvError as ge:
+                if ge.kind != "Unsupported": bad.append((seed, k, "GPU raised", str(ge), e.tokens))
+                continue
+            for g, w in zip(got, want):
+                gv, wv = g.value, w.value
+                ok = (gv is None and wv is None) or (isinstance(wv, float) and isinstance(gv, float) and ((gv != gv and wv != wv) or abs(gv - wv) <= 1e-9 * max(1.0, abs(wv)))) or gv == wv
+                if not ok: bad.append((seed, k, "values differ", gv, wv, e.tokens))
+    return bad
+
+
+db = fuzz_distinct(range(25))
+print("DISTINCT FAILURES:", len(db))
+for b in db[:10]:
+    print("  ", b)
