@@ -197,3 +197,33 @@ db = fuzz_distinct(range(25))
 print("DISTINCT FAILURES:", len(db))
 for b in db[:10]:
     print("  ", b)
+
+
+# ---- ordered scans: ORDER BY one column (ties, NULLs first / last, descending), with and without a predicate --------
+def fuzz_ordered(seeds):
+    bad = []
+    for seed in seeds:
+        rng = np.random.default_rng(3000 + seed)
+        chunks = [int(rng.integers(1, 5000)), int(rng.integers(1, 70_000))]
+        n = sum(chunks)
+        i64 = rng.integers(-20, 20, size=n).astype(np.int64)
+        i32 = rng.integers(-300, 300, size=n).astype(np.int32)
+        tags = [("pear", "Apple", "fig", "zebra", "apple", "")[k] for k in rng.integers(0, 6, size=n)]
+        f64 = rng.normal(size=n)
+        v1, v3 = rng.random(n) > 0.2, rng.random(n) > 0.3
+        ht, ot = T.stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64, v1), (2, abi.DT_INT32, i32), (3, abi.DT_UTF8, tags, v3), (4, abi.DT_FLOAT64, f64)], chunks)
+        for _ in range(4):
+            field, tr = [(1, abi.ORDER_IDENTITY_INT64), (2, abi.ORDER_IDENTITY_INT32), (3, abi.ORDER_IDENTITY_UTF8)][int(rng.integers(0, 3))]
+            order = (field, bool(rng.random() < 0.5), bool(rng.random() < 0.5), tr)
+            pred = None if rng.random() < 0.4 else [abi.Filter(4, abi.Operator.GreaterThan(float(rng.normal())))]
+            got = rt.scan_stream(ht, [field, 4], pred, include_nulls=True, include_row_ids=True, order=order)
+            want = orc.scan_stream(ot, [field, 4], pred, include_nulls=True, include_row_ids=True, order=order)
+            if [b[1] for b in got] != [b[1] for b in want] or [b[0][0] for b in got] != [b[0][0] for b in want]:
+                bad.append((seed, order, pred is not None, n))
+    return bad
+
+
+ob = fuzz_ordered(range(12))
+print("ORDERED SCAN FAILURES:", len(ob))
+for b in ob[:10]:
+    print("  ", b)
