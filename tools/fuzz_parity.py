@@ -15,6 +15,7 @@ for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 104)
     f = getattr(T, name)
     f = getattr(f, "__wrapped__", f)
     for seed in seeds:
+        print(name, "seed", seed, flush=True)  # progress: a silent GPU job is taken to be hung
         try:
             f(rt, orc, abi, seed)
         except BaseException:
