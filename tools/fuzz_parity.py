@@ -11,7 +11,8 @@ from oracle import oracle as orc
 rt.init(0)
 import test_gpu_parity as T
 bad = []
-for name, seeds in (("test_random_predicate_trees_match_oracle", range(100, 104)), ("test_random_aggregate_lists_match_oracle", range(160, 162))):
+_lo, _hi = (int(x) for x in os.environ.get("LLKV_FUZZ_SEEDS", "100:104").split(":"))  # e.g. LLKV_FUZZ_SEEDS=200:300
+for name, seeds in (("test_random_predicate_trees_match_oracle", range(_lo, _hi)), ("test_random_aggregate_lists_match_oracle", range(_lo, _lo + max(2, (_hi - _lo) // 5)))):
     f = getattr(T, name)
     f = getattr(f, "__wrapped__", f)
     for seed in seeds:
