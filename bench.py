@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -50,7 +52,6 @@ def parse():
 
 def stage(rt, tpch, abi, dist, query, chunks, scale, rank, world, row_begin_global=0):
     """Generate this rank's shard (its chunks of the global chunk list) on the host and stage the needed columns into HBM."""
-    dmod = importlib.import_module("rust-llkv_amd.dist")
     table = rt.HipTable(1, chunks, rank, world)
     first_row = sum(chunks[:table.first_chunk])
     data = tpch.gen_lineitem(table.local_rows, scale, query.columns, row_begin=row_begin_global + first_row)
@@ -58,16 +59,16 @@ def stage(rt, tpch, abi, dist, query, chunks, scale, rank, world, row_begin_glob
     for name in query.columns:
         fid, dt = tpch.LINEITEM_SCHEMA[name]
         if dt == abi.DT_UTF8:
-            # one rank: the library finds the dictionary itself; several: the ranks agree on one first
-            table.append_utf8_column(fid, data[name], dmod.table_wide_dictionary(dist, data[name], world) if world > 1 else None)
+            # one rank: the library finds the dictionary itself; several: the ranks agree on one first (sorted union of
+            # the shards' distinct values, all-gathered over the library's communicator)
+            table.append_utf8_column(fid, data[name], rt.comm_union_strings(sorted(chr(int(v)) for v in np.unique(data[name]))) if world > 1 else None)
         else:
             table.append_column(fid, dt, data[name])
     # host chunks → pinned ring → hipMemcpyAsync → HBM: the PCIe-bound part.  `copy` = inside the library's copy
     # loop; `wall` adds the binding's side of it (Utf8 dictionary coding, offsets, statistics, Python).
     b1, s1 = rt.staging_stats()
     table.staging = {"wall_seconds": time.perf_counter() - t0, "copy_seconds": s1 - s0, "copy_bytes": b1 - b0}
-    dmod.share_column_stats(dist, table, [tpch.LINEITEM_SCHEMA[n][0] for n in query.columns if tpch.LINEITEM_SCHEMA[n][1] != abi.DT_UTF8 and
-                                          table.local_column_stats(tpch.LINEITEM_SCHEMA[n][0]) is not None], world)
+    table.share_metadata()  # sharded: table-wide integer statistics and NULL-ability, so every rank lowers the same plan
     return table, data
 
 
@@ -75,19 +76,18 @@ PROFILE_EVERY = 4
 DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i while the GPU runs i+1..)
 
 
-def run_steps(q, steps, dist, stream_ptr, ex_tensors, torch=None, comm=None):
+def run_steps(q, steps, stream_ptr, comm_stream_ptr):
     """K complete executions; every result is folded and finalized on the host inside the timed region.
     Steady state = one kernel per execution on the compute stream (the scan of execution i folds the tile
-    partials of i-1); with several ranks the RCCL all-reduce of an execution's exchange image and its
-    copy-out run on a communication stream, one execution behind, beside the next scan."""
+    partials of i-1); with several ranks the RCCL all-reduce of an execution's exchange image (inside the library:
+    llkv_hip_query_all_reduce → ncclAllReduce, int64 sum = exact concatenation of the shard states) and its copy-out
+    run on a communication stream, one execution behind, beside the next scan."""
     rows, launched, submitted, collected = None, 0, 0, 0
 
     def exchange(slot):
-        if ex_tensors is not None:
-            q.wait_folded(comm.cuda_stream)
-            with torch.cuda.stream(comm):
-                dist.all_reduce(ex_tensors[slot])  # ncclSum over int64 lanes: exact concatenation of shard states
-            q.submit(comm.cuda_stream)
+        if comm_stream_ptr:
+            q.all_reduce(comm_stream_ptr)
+            q.submit(comm_stream_ptr)
         else:
             q.submit(0)
 
@@ -120,21 +120,17 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     torch.cuda.set_stream(stream)
     stream_ptr = stream.cuda_stream
     q.set_depth(DEPTH)
-    ex_tensor = None
-    if world > 1 or os.environ.get("LLKV_BENCH_FORCE_COLLECTIVE"):  # the env knob rehearses the collective path on one GPU
-        # zero-copy int64 views of the library's exchange ring for torch.distributed (RCCL)
-        ptr, n = q.exchange_buffer()
-        ex_tensor = [_tensor_from_ptr(torch, ptr + slot * n * 8, n) for slot in range(DEPTH)]
-
-    comm = torch.cuda.Stream() if ex_tensor is not None else None
-    run_steps(q, warmup, dist, stream_ptr, ex_tensor, torch, comm)
+    # the env knob rehearses the collective path on one GPU (a one-rank RCCL communicator)
+    comm = torch.cuda.Stream() if (world > 1 or os.environ.get("LLKV_BENCH_FORCE_COLLECTIVE")) else None
+    comm_ptr = comm.cuda_stream if comm is not None else 0
+    run_steps(q, warmup, stream_ptr, comm_ptr)
     # HIP events around every 4th scan kernel of the timed region (every one when the region is only a few steps long)
     q.set_profiling(PROFILE_EVERY if steps >= 4 * PROFILE_EVERY else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows = run_steps(q, steps, dist, stream_ptr, ex_tensor, torch, comm)
+    rows = run_steps(q, steps, stream_ptr, comm_ptr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -168,17 +164,6 @@ def pmc_traffic(workload):
         except Exception:
             continue
     return None, None
-
-
-def _tensor_from_ptr(torch, ptr, n_i64):
-    """int64 CUDA tensor aliasing a raw device pointer (exchange buffer), via __cuda_array_interface__."""
-
-    class _Raw:
-        pass
-
-    raw = _Raw()
-    raw.__cuda_array_interface__ = {"shape": (int(n_i64),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(raw, device="cuda")
 
 
 def detected_threads():
@@ -315,9 +300,8 @@ def measure_q3(rt, tpch, abi, sf):
 
 def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
     """BASELINE.json configs[4]: build side (orders, customer) replicated on every rank, lineitem sharded by chunk; per
-    step = local build + probe + per-group sums (JoinAgg) then the collectives of dist.join_groupby_topk (one int64
-    all-reduce of the per-group row counts over RCCL, all-gathers of the straddlers and of ≤ limit candidates)."""
-    dmod = importlib.import_module("rust-llkv_amd.dist")
+    step = local build + probe + per-group sums (JoinAgg) then llkv_hip_join_agg_finish_sharded (one int64 all-reduce
+    of the per-group row counts over RCCL, all-gathers of the straddlers and of ≤ limit candidates)."""
     rows, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
     D = tpch.DATE_1995_03_15
     chunks = tpch.chunk_rows(rows)
@@ -327,7 +311,7 @@ def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
     li = tpch.gen_lineitem(lt.local_rows, scale, cols, row_begin=first_row)
     for c in cols:
         lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
-    dmod.share_column_stats(dist, lt, [tpch.LINEITEM_SCHEMA[c][0] for c in cols if lt.local_column_stats(tpch.LINEITEM_SCHEMA[c][0]) is not None], world)
+    lt.share_metadata()
     n_ord = tpch.orders_for_lineitems(rows)
     od = tpch.gen_orders(n_ord, scale)
     n_cust = tpch.customers_for_scale(scale)
@@ -342,15 +326,11 @@ def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
     F, O, col = abi.Filter, abi.Operator, abi.col
     rev = col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT))
 
-    def all_reduce_counts(ptr, n):
-        dist.all_reduce(_tensor_from_ptr(torch, ptr, n))
-        torch.cuda.synchronize()
-
     def run():
         ja = rt.JoinAgg(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, rev,
                         payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
                         dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
-        return dmod.join_groupby_topk(dist, rt, ja, rank, world, 10, all_reduce_counts)
+        return ja.finish_sharded(10)  # counts all-reduce + straddler / candidate all-gathers inside the library (RCCL)
 
     run()
     ts = []
@@ -461,6 +441,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     rt.init(local_rank)
+    if dist.is_initialized():
+        # the library's own RCCL communicator (the collectives of the data path); torch.distributed only carries the
+        # ncclUniqueId, the barriers and the max-over-ranks clock of the bench contract
+        uid = [rt.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        rt.comm_init(uid[0], rank, world)
 
     main_res = measure(rt, tpch, abi, torch, dist, args.workload, rank, world, args.scaling, args.steps, args.warmup)
     rows_total = main_res["total_rows"]
@@ -540,6 +526,7 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
+        rt.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -711,7 +711,8 @@ llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_jo
  *   4. fold_straddlers    host only: exact left-to-right sums of those groups in global row order
  *   5. candidates         the top `limit` groups this rank reports (held alone, or straddlers held first)
  *   6. merge              host only: ORDER BY / LIMIT over the all-gathered candidates
- * Results are bit-identical to the single-GPU call for every rank count.                              */
+ * Results are bit-identical to the single-GPU call for every rank count.  The three tables must outlive the
+ * handle (its later phases still read their HBM images).                                                */
 typedef struct llkv_hip_join_agg llkv_hip_join_agg;
 llkv_status llkv_hip_join_agg_prepare(const llkv_join_side *fact, const llkv_join_side *dim,
                                       uint32_t dim_fk_field, const llkv_join_side *dim2 /* may be NULL */,
@@ -751,6 +752,96 @@ llkv_status llkv_hip_query_lane_ops(const llkv_hip_query *query, uint8_t *ops_ou
  * does after the copy-out).                                                    */
 llkv_status llkv_hip_fold_exchange(const uint64_t *exchange, const uint8_t *lane_ops,
                                    uint32_t lanes, uint64_t *state_out);
+
+/* ------------------------------------------------------------------------- */
+/* Collectives behind the boundary (one process per GPU).  The reference has no */
+/* counterpart (single process; its only concurrency boundary is the Rayon pool, */
+/* llkv-threading/src/lib.rs:75-82): these calls are what a multi-GPU            */
+/* `QueryExecutor` shim adds around the sharded forms of the queries above.       */
+/* Transport: RCCL over xGMI (ncclCommInitRank on the bound device), or functions */
+/* the host supplies (MPI, a socket layer, gloo in the tests) that see HOST       */
+/* memory.  One communicator per process; every rank makes the same calls in the  */
+/* same order.                                                                    */
+/* ------------------------------------------------------------------------- */
+#define LLKV_HIP_COMM_ID_BYTES 128
+/* Rank 0: a fresh ncclUniqueId (128 bytes) to hand to the other ranks over the host's own channel. */
+llkv_status llkv_hip_comm_unique_id(uint8_t id_out[LLKV_HIP_COMM_ID_BYTES]);
+/* Every rank, after llkv_hip_init: join the RCCL communicator `id` names. */
+llkv_status llkv_hip_comm_init(const uint8_t id[LLKV_HIP_COMM_ID_BYTES], uint32_t rank, uint32_t world);
+/* Host-supplied transport.  Both functions return 0 on success and are called from the thread that calls into the
+ * library: all_reduce_sum_i64 sums `n` int64 lanes over the ranks in place; all_gather concatenates every rank's
+ * `bytes_per_rank` bytes in rank order into `recv` (world · bytes_per_rank bytes).                                  */
+typedef struct llkv_comm_transport {
+  int32_t (*all_reduce_sum_i64)(int64_t *host_buf, uint64_t n, void *user);
+  int32_t (*all_gather)(const void *send, void *recv, uint64_t bytes_per_rank, void *user);
+  void *user;
+} llkv_comm_transport;
+llkv_status llkv_hip_comm_init_custom(const llkv_comm_transport *transport, uint32_t rank, uint32_t world);
+void llkv_hip_comm_destroy(void);
+uint32_t llkv_hip_comm_rank(void);
+uint32_t llkv_hip_comm_world(void); /* 0 = no communicator */
+
+/* In-place SUM of a device buffer of int64 lanes over the ranks, ordered on `hip_stream` (RCCL: ncclAllReduce,
+ * nothing blocks on the host).                                                                                   */
+llkv_status llkv_hip_comm_all_reduce_i64(void *device_buf, uint64_t n, void *hip_stream);
+/* Variable-length all-gather of host bytes: `*out` (release with llkv_hip_free) holds the ranks' contributions in
+ * rank order, `offsets_out[world + 1]` their bounds.                                                             */
+llkv_status llkv_hip_comm_all_gather_v(const void *send, uint64_t bytes, void **out, uint64_t *offsets_out);
+/* Sorted union of the ranks' string lists — the table-wide dictionary a sharded Utf8 column is staged with
+ * (llkv_hip_table_append_utf8_column).  `*out` is one block: `*n_out` pointers followed by the characters;
+ * release with llkv_hip_free.                                                                                     */
+llkv_status llkv_hip_comm_union_strings(const char *const *local, uint32_t n_local, char ***out, uint32_t *n_out);
+
+/* Table metadata plans depend on must be the same on every rank of a sharded table BEFORE queries are prepared:
+ * integer statistics (min / max over all shards, see llkv_hip_table_set_column_stats) and whether a column has NULL
+ * cells (a rank whose chunks hold none still gets an all-present mask, so that every rank lowers the same plan: same
+ * lanes, same exchange image).  All-gathers the local values of every staged column and installs the agreement.    */
+llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table);
+
+/* The one collective of a dense aggregate / GROUP BY query: make `hip_stream` wait for the exchange image of the
+ * oldest execution not yet submitted (llkv_hip_query_wait_folded), then sum it over the ranks in place on that
+ * stream.  Per execution: launch → all_reduce → submit → collect.                                                 */
+llkv_status llkv_hip_query_all_reduce(llkv_hip_query *query, void *hip_stream);
+/* finish() of any query over a sharded table, collectives included: dense plans — all_reduce + submit + collect of
+ * everything outstanding; the sort-based GROUP BY — all-gather of the ranks' partial groups and their merge
+ * (llkv_hip_query_merge_groups); DISTINCT aggregates — all-gather of the ranks' distinct values and their merge
+ * (llkv_hip_query_merge_distinct).  Every rank ends with the table-wide result.                                    */
+llkv_status llkv_hip_query_finish_sharded(llkv_hip_query *query, void *hip_stream);
+/* The join → GROUP BY → top-k pipeline over a sharded fact table in one call (steps 2–6 of the phased form below:
+ * counts all-reduce on the device, straddler and candidate all-gathers): every rank ends with the same rows.      */
+llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limit, llkv_join_group_row *out_rows,
+                                             uint32_t *out_n, uint64_t *out_total_groups);
+
+/* `configured_thread_count` of the reference's shared pool (llkv-threading/src/lib.rs:13-31): LLKV_MAX_THREADS when
+ * it parses to a positive number, else the detected parallelism.  The library's own host threads (staging lanes,
+ * per-chunk preparation of column images) are bounded by it.                                                       */
+uint32_t llkv_hip_max_threads(void);
+
+/* Route selection — `QueryExecutor::execute_select_with_filter` llkv-executor/src/lib.rs:523-563: which executor
+ * route a SELECT of this shape takes, and whether the GPU path has an entry point for it.                          */
+typedef enum llkv_route {
+  LLKV_ROUTE_COMPOUND = 1,          /* :531-533 execute_compound_select          — CPU                              */
+  LLKV_ROUTE_NO_TABLE = 2,          /* :534-536 execute_select_without_table     — CPU                              */
+  LLKV_ROUTE_GROUP_BY = 3,          /* :541-543 execute_group_by_single_table    → llkv_hip_query_prepare_groupby  */
+  LLKV_ROUTE_CROSS_PRODUCT = 4,     /* :537-539,544-546 execute_cross_product    → llkv_hip_join_groupby_topk /
+                                                                                    llkv_hip_join_stream            */
+  LLKV_ROUTE_AGGREGATES = 5,        /* :552-554 execute_aggregates               → llkv_hip_query_prepare_aggregate */
+  LLKV_ROUTE_COMPUTED_AGGREGATES = 6, /* :555-557 execute_computed_aggregates    → llkv_hip_query_prepare_aggregate */
+  LLKV_ROUTE_PROJECTION = 7         /* :558-560 execute_projection               → llkv_hip_scan_stream            */
+} llkv_route;
+/* The fields of `SelectPlan` (llkv-plan/src/plans.rs:801-829) the dispatch looks at. */
+typedef struct llkv_select_shape {
+  int32_t has_compound;                /* plan.compound.is_some()                                                   */
+  uint32_t n_tables;                   /* plan.tables.len()                                                         */
+  uint32_t n_group_by;                 /* plan.group_by.len()                                                       */
+  uint32_t n_aggregates;               /* plan.aggregates.len() (plain `agg(col)` forms)                            */
+  int32_t has_computed_aggregates;     /* Self::has_computed_aggregates(&plan): an aggregate inside a projection    */
+  uint32_t n_joins;                    /* plan.joins.len(): explicit JOIN … ON between the tables                   */
+  int32_t has_having, has_distinct, has_scalar_subqueries; /* SQL breadth the GPU path leaves to the CPU routes     */
+} llkv_select_shape;
+/* `*route_out`: the route the reference takes.  Returns LLKV_OK when the GPU path serves it, LLKV_UNSUPPORTED when
+ * the caller keeps its CPU route (message: why), LLKV_INVALID_ARGUMENT for a shape the reference rejects.          */
+llkv_status llkv_hip_select_route(const llkv_select_shape *shape, int32_t *route_out);
 
 /* ------------------------------------------------------------------------- */
 /* Plan inspection (host only, no device needed): lowers a plan exactly as the */

@@ -17,6 +17,7 @@
 
 namespace llkv {
 int set_error(int code, const std::string &msg);
+uint64_t table_chunk_rows(const llkv_hip_table *table, uint32_t global_chunk); // table.cpp
 }
 
 namespace {
@@ -240,10 +241,28 @@ extern "C" llkv_status llkv_hip_table_append_arrow_column(llkv_hip_table *table,
   std::vector<std::vector<uint8_t>> repacked; // Boolean bytes, shifted bitmaps
   repacked.reserve((size_t)n_chunks * 2);
   bool any_nulls = false;
+  // the staging entry points read `local chunk rows` elements from every buffer: the arrays must hold exactly those
+  // (the ARR0 path checks the same, arr0.cpp), their buffers must exist, and Utf8 offsets must be usable as they lie
+  uint32_t first_chunk = 0, n_local = 0;
+  if (llkv_hip_table_local_chunks(table, &first_chunk, &n_local) != LLKV_OK) return LLKV_INVALID_ARGUMENT;
+  if (n_chunks != n_local)
+    return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(n_local) + " local chunks, got " + std::to_string(n_chunks));
   for (uint32_t i = 0; i < n_chunks; ++i) {
     const ArrowArray *a = chunks[i];
-    if (!a || a->n_buffers < (dt == LLKV_DT_UTF8 ? 3 : 2)) return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow chunk without its buffers");
+    if (!a || a->n_buffers < (dt == LLKV_DT_UTF8 ? 3 : 2) || !a->buffers) return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow chunk without its buffers");
     const int64_t off = a->offset, n = a->length;
+    const uint64_t want_rows = llkv::table_chunk_rows(table, first_chunk + i);
+    if (off < 0 || n < 0 || (uint64_t)n != want_rows)
+      return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow chunk " + std::to_string(i) + " holds " + std::to_string(n) + " rows at offset " + std::to_string(off) +
+                                                                     ", the table's chunk has " + std::to_string(want_rows));
+    if (n > 0 && (!a->buffers[1] || (dt == LLKV_DT_UTF8 && !a->buffers[2] && static_cast<const int32_t *>(a->buffers[1])[off + n] != static_cast<const int32_t *>(a->buffers[1])[off])))
+      return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow chunk " + std::to_string(i) + " has a NULL values / offsets / data buffer");
+    if (dt == LLKV_DT_UTF8 && n > 0) { // offsets: non-negative and monotone, so no string has a negative length
+      const int32_t *o = static_cast<const int32_t *>(a->buffers[1]) + off;
+      if (o[0] < 0) return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow Utf8 chunk " + std::to_string(i) + " has a negative offset");
+      for (int64_t r = 0; r < n; ++r)
+        if (o[r + 1] < o[r]) return (llkv_status)llkv::set_error(LLKV_INVALID_ARGUMENT, "Arrow Utf8 chunk " + std::to_string(i) + " has descending offsets");
+    }
     const uint8_t *bits = static_cast<const uint8_t *>(a->buffers[0]);
     if (bits && a->null_count != 0) {
       any_nulls = true;

@@ -10,7 +10,8 @@ namespace llkv {
 
 template <class P> static hipError_t launch_plan(const ScanParams &p, hipStream_t stream) {
   if (p.n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL((fused_scan_kernel<P>), dim3(p.n_tiles), dim3(kBlock), 0, stream, p);
+  const uint32_t tpw = P::ACC == 1 && p.tiles_per_wg ? p.tiles_per_wg : 1u; // register plans: one tile per workgroup
+  hipLaunchKernelGGL((fused_scan_kernel<P>), dim3((p.n_tiles + tpw - 1) / tpw), dim3(kBlock), 0, stream, p);
   return hipGetLastError();
 }
 

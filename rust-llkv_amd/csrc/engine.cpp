@@ -67,22 +67,32 @@ Query::~Query() {
   for (auto &e : ev_fold) if (e) (void)hipEventDestroy(e);
 }
 
-static uint32_t pick_tile_rows(const LoweredPlan &p, uint64_t total_rows) {
+// The tile is the canonical unit of the reduction (one partial per tile — per (tile, wave) for LDS-resident states —
+// folded in order): its length depends on the plan alone, never on the table size, the shard or the GPU count, so
+// results are bit-identical across launch geometries.  Register-resident states amortise their block reduction quickly
+// and like many small tiles (4 096 rows); LDS-resident grouped states use 16 384-row tiles and let a workgroup stream
+// several of them (pick_tiles_per_wg).
+static uint32_t pick_tile_rows(const LoweredPlan &p) {
   if (const char *e = std::getenv("LLKV_HIP_TILE_ROWS")) {
     long v = std::atol(e);
     if (v >= 512 && v % 512 == 0) return (uint32_t)v;
   }
-  // narrow register states amortise their block reduction quickly and like many small tiles;
-  // LDS-resident grouped states (2 workgroups/CU) want long tiles (sweep: profiles/r01/).
-  // Depends on the plan and the TABLE's row count only, never on the GPU count (bit-reproducibility): long tiles
-  // leave a small table with too few workgroups for 256 CUs (Q1 at SF1: 92 tiles of 65 536 rows ran 78 µs, 366
-  // tiles of 16 384 rows 49 µs), so they are halved, down to 16 384 rows, while the table has fewer than 700 tiles.
-  // (At SF10 on one GPU 65 536-row tiles are 3 % faster than 16 384-row ones: 359 vs 369 µs; an SF10 table cut over
-  // 8 ranks would prefer the short tiles — the length cannot follow the rank count without giving up results that
-  // are bit-identical across GPU counts, and the single-GPU case decides.)
-  uint32_t rows = p.acc_lds ? 65536u : 4096u;
-  while (rows > 16384u && total_rows / rows < 700) rows >>= 1;
-  return rows;
+  return p.acc_lds ? 16384u : 4096u;
+}
+
+// Launch geometry of an LDS-accumulator plan, from the LOCAL tile count: a workgroup owns 1, 2, 4 or 8 consecutive
+// tiles — as many as leave ≈ 900 workgroups (256 CUs × 2 resident workgroups, a few rounds).  SF10 on one GPU:
+// 3 662 tiles → 4 per workgroup (916 workgroups of 65 536 rows, the tuned single-GPU shape); a 1/8 shard: 458 tiles
+// → one each (one round of resident workgroups), so the shard still fills the device (profiles/r02/sweep_tiles.txt).
+static uint32_t pick_tiles_per_wg(const LoweredPlan &p, uint32_t n_tiles) {
+  if (!p.acc_lds) return 1;
+  if (const char *e = std::getenv("LLKV_HIP_TILES_PER_WG")) {
+    long v = std::atol(e);
+    if (v >= 1 && v <= 64) return (uint32_t)v;
+  }
+  uint32_t tpw = 1;
+  while (tpw < 8 && n_tiles / (2 * tpw) >= 896) tpw *= 2;
+  return tpw;
 }
 
 int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
@@ -157,7 +167,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     }
   }
   const TileSet *ts = nullptr;
-  if ((rc = get_tileset(*table, pick_tile_rows(p, table->total_rows), &ts))) return rc;
+  if ((rc = get_tileset(*table, pick_tile_rows(p), &ts))) return rc;
   q->tiles = ts;
 
   std::memset(&q->params, 0, sizeof q->params);
@@ -167,9 +177,11 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   for (size_t i = 0; i < p.key_strides.size(); ++i) q->params.key_stride[i] = p.key_strides[i];
   q->params.tiles = ts->d_tiles;
   q->params.n_tiles = ts->n_tiles;
+  q->params.tiles_per_wg = pick_tiles_per_wg(p, ts->n_tiles);
 
   const size_t lanes = (size_t)p.lanes;
-  q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles);
+  const uint32_t parts_per_tile = p.acc_lds ? (uint32_t)(kBlock / 64) : 1u; // LDS-accumulator plans publish one partial per (tile, wave)
+  q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles * parts_per_tile);
   q->d_tile_partials = (uint64_t *)scratch_alloc(2 * q->partials_len * sizeof(uint64_t));
   q->d_lane_ops = (uint8_t *)scratch_alloc(lanes);
   if (!q->d_tile_partials || !q->d_lane_ops) return set_error(LLKV_INTERNAL, "device allocation failed");
@@ -207,6 +219,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->fold.n_tiles = ts->n_tiles;
   q->fold.lanes = (uint32_t)lanes;
   q->fold.owned_mask = table->owned_mask;
+  q->fold.parts_per_tile = parts_per_tile;
   *out = q.release();
   return LLKV_OK;
 }
@@ -243,7 +256,8 @@ int Query::launch(hipStream_t stream) {
   const uint32_t fold_blocks = (uint32_t)kOctantsHost * (uint32_t)((plan.lanes + kBlock / 64 - 1) / (kBlock / 64));
   bool piggy = false;
   int rc;
-  if (pending && !(run_main && tiles->n_tiles >= fold_blocks && stream == pending_stream) && (rc = flush_pending())) return rc;
+  const uint32_t grid = (tiles->n_tiles + params.tiles_per_wg - 1) / params.tiles_per_wg;
+  if (pending && !(run_main && grid >= fold_blocks && stream == pending_stream) && (rc = flush_pending())) return rc;
   if (run_main) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     // event pairs bracket every `profile_every`-th scan: each record is a packet between back-to-back kernels

@@ -206,6 +206,7 @@ struct Query {
   int launch(hipStream_t stream);
   int flush_pending();
   int wait_folded(hipStream_t stream);
+  int all_reduce(hipStream_t stream); // comm.cpp: the exchange image of the oldest unsubmitted execution, summed over the ranks
   int submit(hipStream_t stream);
   int collect();
   int finish(hipStream_t stream);
@@ -218,6 +219,11 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
                   uint32_t n_aggs, bool grouped, bool order_by_keys, Query **out);
 
 int get_tileset(const Table &t, uint32_t tile_rows, const TileSet **out);
+
+// `configured_thread_count` of the reference's shared Rayon pool (llkv-threading/src/lib.rs:13-31): LLKV_MAX_THREADS
+// when it parses to a positive number, else the detected parallelism (affinity mask ∧ cgroup quota, what
+// std::thread::available_parallelism reports).  Bounds the library's host-side worker threads (dispatch.cpp).
+uint32_t host_thread_limit();
 
 // Caching device scratch allocator (hipMalloc/hipFree cost ~100 µs each; operator pipelines allocate dozens of
 // temporaries per call).  Blocks are reused by capacity; everything is released at llkv_hip_shutdown.

@@ -628,15 +628,16 @@ template <class P> struct LaneOpTable {
 // this rank does not own are written as zero so that an integer-sum all-reduce of the image
 // concatenates the ranks' states bit-exactly; an owned octant without tiles yields the lane identity.
 // --------------------------------------------------------------------------
+// `ppt`: partials per tile (1: register plans, one per workgroup; kLdsParts: LDS-accumulator plans, one per wave).
 __device__ __forceinline__ void fold_one_lane(const uint64_t *tile_partials, uint64_t *exchange, const uint32_t *octant_tile_begin,
-                                              uint32_t owned_mask, uint32_t n_tiles, uint32_t lanes, uint32_t o, uint32_t lane, int op) {
+                                              uint32_t owned_mask, uint32_t n_tiles, uint32_t lanes, uint32_t o, uint32_t lane, int op, uint32_t ppt) {
   const uint32_t l = threadIdx.x & 63;
   if (!((owned_mask >> o) & 1u)) {
     if (l == 0) exchange[(uint64_t)o * lanes + lane] = 0;
     return;
   }
-  const uint32_t t0 = octant_tile_begin[o], t1 = octant_tile_begin[o + 1];
-  const uint64_t *src = tile_partials + (uint64_t)lane * n_tiles;
+  const uint32_t t0 = octant_tile_begin[o] * ppt, t1 = octant_tile_begin[o + 1] * ppt;
+  const uint64_t *src = tile_partials + (uint64_t)lane * n_tiles * ppt;
   uint64_t v = lane_identity(op);
   uint32_t t = t0 + l;
   for (; t + 448 < t1; t += 512) {
@@ -666,11 +667,12 @@ template <class P> __device__ __forceinline__ void piggyback_fold(const ScanPara
   const uint32_t o = blockIdx.x % kOctants;
   const uint32_t lane = (blockIdx.x / kOctants) * (kBlock / 64) + (threadIdx.x >> 6);
   if (lane < (uint32_t)P::LANES)
-    fold_one_lane(p.prev_partials, p.prev_exchange, p.octant_tile_begin, p.owned_mask, p.n_tiles, (uint32_t)P::LANES, o, lane, ops.v[lane]);
+    fold_one_lane(p.prev_partials, p.prev_exchange, p.octant_tile_begin, p.owned_mask, p.n_tiles, (uint32_t)P::LANES, o, lane, ops.v[lane],
+                  P::ACC == 1 ? (uint32_t)(kBlock / 64) : 1u);
 }
 
-__device__ __forceinline__ void publish_partial(const ScanParams &p, int lane, uint64_t v) {
-  p.tile_partials[(uint64_t)lane * p.n_tiles + blockIdx.x] = v;
+__device__ __forceinline__ void publish_partial(const ScanParams &p, int lane, uint64_t v, uint32_t part, uint32_t n_parts) {
+  p.tile_partials[(uint64_t)lane * n_parts + part] = v;
 }
 
 // --------------------------------------------------------------------------
@@ -766,7 +768,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
         // fixed operand order (lower segment first) keeps f64 adds reproducible
         v = (rq & off) ? lane_combine(op, o, v) : lane_combine(op, v, o);
       }
-      if (rq == 0) publish_partial(p, lane, v);
+      if (rq == 0) publish_partial(p, lane, v, blockIdx.x, p.n_tiles);
     }
     __syncthreads();
   }
@@ -797,26 +799,138 @@ template <class P, int K0 = 0> __device__ __forceinline__ void lds_accumulate_ro
   }
 }
 
-template <class P> __device__ __forceinline__ void fused_scan_body_lds(const ScanParams &p) {
-  constexpr int NG = P::NG, K = P::K, U = P::U, LANES = P::LANES;
-  constexpr LaneOpTable<P> ops{};
-  __shared__ uint64_t acc[LANES][kBlock]; // last row: error flags
+// Orders the LDS traffic of ONE wave: the waves of a workgroup never touch each other's columns of the accumulator
+// image, and the DS unit executes a wave's instructions in order, so all that is needed between the phases of a wave
+// (its lanes' atomics → cross-lane reads → re-initialisation) is that the COMPILER keeps them in program order.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-  const uint32_t tid = threadIdx.x;
+// A tile descriptor through the scalar cache: the tile list is never written while a scan runs, but the compiler
+// cannot know that (the kernel stores partials to global memory) and would use a vector load — whose vmcnt then
+// orders it with the column loads.  Reading through the constant address space selects s_load_dwordx4 + x2.
+__device__ __forceinline__ TileDesc load_tile_desc(const TileDesc *tiles, uint32_t i) {
+  typedef const __attribute__((address_space(4))) uint64_t *ConstU64;
+  ConstU64 q = (ConstU64)(unsigned long long)(tiles + i);
+  TileDesc d;
+  d.dev_row = q[0];
+  d.logical_row = q[1];
+  const uint64_t w = q[2];
+  d.rows = (uint32_t)w;
+  d.octant = (uint32_t)(w >> 32);
+  return d;
+}
+
+constexpr int kLdsParts = kBlock / 64; // partials an LDS-accumulator plan publishes per tile: one per wave
+
+// The positions inside a group's lane block whose combine op is OP (the same for every group): the wave reduction
+// runs class by class, so every instruction of a round combines with ONE op (a round over mixed lanes made the
+// compiler branch five ways per element).  Lane of class position idx = (idx / n)·K + v[idx % n], computed with
+// selects: a table in memory would be a VMEM load, and its s_waitcnt vmcnt(0) would wait for the column loads of the
+// next tile that are in flight during the reduction.
+template <class P, int OP> struct OpSlots {
+  int n;
+  int v[P::K];
+  constexpr OpSlots() : n(0), v{} {
+    for (int k = 0; k < P::K; ++k)
+      if (plan_lane_op<P>(k) == OP) v[n++] = k;
+  }
+};
+
+// One op class of the wave reduction: lane `idx` of a round is summed by four threads (one 16-column segment of the
+// wave's 64 columns each, starting at column li of the segment — the 16 lanes of a round then read 16 different
+// banks), then a 4-lane butterfly, lower segment first.  Fixed order: a function of (lane, wave) only.
+template <class P, int OP>
+__device__ __forceinline__ void wave_reduce_class(const ScanParams &p, const uint64_t (*acc)[kBlock], uint32_t wave, uint32_t li, uint32_t sq, uint32_t part, uint32_t n_parts) {
+  constexpr OpSlots<P, OP> cls{};
+  if constexpr (cls.n > 0) {
+    constexpr int total = P::NG * cls.n;
+#pragma unroll 1
+    for (int base = 0; base < total; base += 16) {
+      const int idx = base + (int)li;
+      if (idx < total) {
+        const int g = idx / cls.n, j = idx % cls.n;
+        int k = cls.v[0];
 #pragma unroll
-  for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
-  uint32_t err = 0;
+        for (int t = 1; t < cls.n; ++t) k = j == t ? cls.v[t] : k;
+        const int lane = g * P::K + k;
+        const uint64_t *seg = &acc[lane][wave * 64 + sq * 16];
+        uint64_t x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = seg[(li + e) & 15];
+        uint64_t v = x[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) v = lane_combine_s<OP>(v, x[e]);
+#pragma unroll
+        for (int off = 2; off >= 1; off >>= 1) {
+          const uint32_t lo = __shfl_xor((uint32_t)v, off, 4);
+          const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 4);
+          const uint64_t o = ((uint64_t)hi << 32) | lo;
+          v = (sq & off) ? lane_combine_s<OP>(o, v) : lane_combine_s<OP>(v, o);
+        }
+        if (sq == 0) publish_partial(p, lane, v, part, n_parts);
+      }
+    }
+  }
+}
 
-  const TileDesc td = p.tiles[blockIdx.x];
-  const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
+// Reduction of the wave's 64 columns of the image into the partial of (tile, wave), one op class after the other.
+template <class P>
+__device__ __forceinline__ void wave_reduce_image(const ScanParams &p, const uint64_t (*acc)[kBlock], uint32_t wave, uint32_t wl, uint32_t part, uint32_t n_parts, uint32_t err) {
+  const uint32_t li = wl >> 2, sq = wl & 3;
+  wave_lds_sync();
+  wave_reduce_class<P, OP_ADD_F64>(p, acc, wave, li, sq, part, n_parts);
+  wave_reduce_class<P, OP_ADD_I64>(p, acc, wave, li, sq, part, n_parts);
+  wave_reduce_class<P, OP_MIN_I64>(p, acc, wave, li, sq, part, n_parts);
+  wave_reduce_class<P, OP_MAX_I64>(p, acc, wave, li, sq, part, n_parts);
+  wave_reduce_class<P, OP_MAX_U64>(p, acc, wave, li, sq, part, n_parts);
+  // the error lane (codes 1 = overflow, 2 = division by zero; any non-zero code fails the query): two ballots
+  const uint32_t wave_err = (__builtin_amdgcn_ballot_w64((err & 1u) != 0) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64((err & 2u) != 0) ? 2u : 0u);
+  if (wl == 0) publish_partial(p, P::NG * P::K, wave_err, part, n_parts);
+  wave_lds_sync(); // the reads above precede the re-initialisation of the columns they read
+}
+
+template <class P> __device__ __forceinline__ void fused_scan_body_lds(const ScanParams &p) {
+  constexpr int NG = P::NG, K = P::K, U = P::U;
+  constexpr LaneOpTable<P> ops{};
+  __shared__ uint64_t acc[NG * K][kBlock]; // acc[lane][thread]: every thread owns a column
+
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, wl = tid & 63;
   piggyback_fold<P>(p);
 
-  for (uint32_t s = 0; s < nsteps; s += U) {
-    Loaded ld[U];
+  // The canonical unit of the reduction is (tile, wave): the rows of a tile that a wave's lanes own (128 consecutive
+  // rows of every 512-row step) → one partial per lane of the plan, whatever the launch geometry.  A workgroup streams
+  // `tiles_per_wg` consecutive tiles; its four waves never synchronise: each reduces its own 64 columns of the image
+  // (DS operations of one wave execute in order) and moves on.  The image of a finished tile is reduced AFTER the
+  // first loads of the next tile have been requested (same iteration: nothing loaded lives across the back-edge or a
+  // join point), so the reduction hides behind their latency; the next tile's descriptor is fetched a tile ahead.
+  const uint32_t tpw = p.tiles_per_wg ? p.tiles_per_wg : 1u;
+  uint32_t tile = blockIdx.x * tpw;
+  const uint32_t tile_end = tile + tpw < p.n_tiles ? tile + tpw : p.n_tiles;
+  if (tile >= tile_end) return;
+  const uint32_t n_parts = p.n_tiles * kLdsParts;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t row0 = (uint64_t)(s + u) * kStepRows + (uint64_t)tid * kRowsPerThread;
-      load_all<typename P::ColList>(p, td.dev_row + row0, ld[u]);
+  for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
+  uint32_t err = 0, done_err = 0, done_tile = 0;
+  bool fresh = false; // the image holds a finished tile that awaits its reduction
+
+  TileDesc td = load_tile_desc(p.tiles, tile);
+  TileDesc td_next = load_tile_desc(p.tiles, tile + 1 < tile_end ? tile + 1 : tile);
+  uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
+  uint32_t s = 0;
+  for (;;) {
+    Loaded ld[U];
+    // issue every load of the unrolled group before the first use (column buffers carry slack past the last
+    // tile, so the tail steps may read — and discard — past td.rows)
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + u) * kStepRows + (uint64_t)tid * kRowsPerThread, ld[u]);
+    if (fresh) {
+      wave_reduce_image<P>(p, acc, wave, wl, done_tile * kLdsParts + wave, n_parts, done_err);
+#pragma unroll
+      for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
+      fresh = false;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -836,31 +950,20 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
         if (pass) lds_accumulate_row<P>(&acc[gid * K][tid], contrib);
       }
     }
-  }
-  acc[NG * K][tid] = err;
-  __syncthreads(); // drains the DS queue of every wave (lgkmcnt(0)) before the cross-thread reads
-
-  // ---- block reduction straight out of the accumulator image, fixed order ----
-  const uint32_t ri = tid >> 4, rq = tid & 15;
-#pragma unroll 1
-  for (int base = 0; base < LANES; base += kRedBatch) {
-    const int lane = base + (int)ri;
-    if (lane < LANES) {
-      const int op = ops.v[lane];
-      const uint64_t *seg = &acc[lane][rq * 16];
-      uint64_t v = seg[0];
-#pragma unroll
-      for (int e = 1; e < 16; ++e) v = lane_combine(op, v, seg[e]);
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)v, off, 16);
-        const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 16);
-        const uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = (rq & off) ? lane_combine(op, o, v) : lane_combine(op, v, o);
-      }
-      if (rq == 0) publish_partial(p, lane, v);
+    s += U;
+    if (s >= nsteps) { // the tile is complete: its reduction follows the next loads (or the loop's exit)
+      done_tile = tile;
+      done_err = err;
+      err = 0;
+      fresh = true;
+      if (++tile >= tile_end) break;
+      td = td_next;
+      nsteps = (td.rows + kStepRows - 1) / kStepRows;
+      s = 0;
+      if (tile + 1 < tile_end) td_next = load_tile_desc(p.tiles, tile + 1);
     }
   }
+  wave_reduce_image<P>(p, acc, wave, wl, done_tile * kLdsParts + wave, n_parts, done_err);
 }
 
 template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {
@@ -874,7 +977,7 @@ template <class P> __global__ __launch_bounds__(kBlock) void fused_scan_kernel(c
 // grid = (kOctants, ceil(lanes / 4)).
 __global__ __launch_bounds__(kBlock) void fold_octants_kernel(const FoldParams f) {
   const uint32_t lane = blockIdx.y * (kBlock / 64) + (threadIdx.x >> 6);
-  if (lane < f.lanes) fold_one_lane(f.tile_partials, f.exchange, f.octant_tile_begin, f.owned_mask, f.n_tiles, f.lanes, blockIdx.x, lane, f.lane_ops[lane]);
+  if (lane < f.lanes) fold_one_lane(f.tile_partials, f.exchange, f.octant_tile_begin, f.owned_mask, f.n_tiles, f.lanes, blockIdx.x, lane, f.lane_ops[lane], f.parts_per_tile);
 }
 
 } // namespace llkv

@@ -59,10 +59,30 @@ uint64_t fnv1a(const std::string &s) {
   return h;
 }
 
+// Directory of cached code objects, or "" when there is no place this user alone can write to (no cache then: a
+// world-writable fallback would let another local user plant a code object this process loads onto the GPU).
 std::string cache_dir() {
   if (const char *e = std::getenv("LLKV_HIP_CACHE_DIR")) return e;
-  if (const char *h = std::getenv("HOME")) return std::string(h) + "/.cache/llkv_hip";
-  return "/tmp/llkv_hip_cache";
+  if (const char *h = std::getenv("HOME")) if (*h) return std::string(h) + "/.cache/llkv_hip";
+  return "";
+}
+
+// mkdir -p with mode 0700; the directory must end up owned by this user and closed to group / others
+bool private_dir(const std::string &dir) {
+  if (dir.empty()) return false;
+  for (size_t i = 1; i <= dir.size(); ++i)
+    if (i == dir.size() || dir[i] == '/') (void)::mkdir(dir.substr(0, i).c_str(), 0700);
+  struct stat st;
+  if (::stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  return st.st_uid == ::geteuid() && (st.st_mode & 022) == 0;
+}
+
+// What besides the source decides the code object: the compiler and its options
+std::string compile_identity() {
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  const char *extra = std::getenv("LLKV_HIP_JIT_DEFINES");
+  return "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " --offload-arch=gfx950 -O3 -std=c++17 " + (extra ? extra : "");
 }
 
 int compile_to_code(const std::string &src, std::vector<char> *code, std::string *err) {
@@ -106,32 +126,49 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) { *out = it->second; return LLKV_OK; }
 
-  const std::string src = std::string(kFusedScanSource) + wrapper_source(kind, type_string) +
-                          (std::getenv("LLKV_HIP_JIT_DEFINES") ? std::string("\n// ") + std::getenv("LLKV_HIP_JIT_DEFINES") + "\n" : std::string());
+  const std::string src = std::string(kFusedScanSource) + wrapper_source(kind, type_string);
+  // cache key: the source AND what compiles it (hiprtc version, architecture, options) — a ROCm upgrade must not
+  // resurrect code objects of the previous compiler
   char hex[32];
-  std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src));
-  const std::string dir = cache_dir(), path = dir + "/" + hex + ".hsaco";
+  std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src + "\n// " + compile_identity()));
+  const std::string dir = cache_dir();
+  const bool cacheable = private_dir(dir);
+  const std::string path = dir + "/" + hex + ".hsaco";
+  const bool two = kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit || kind == JitKind::Reduce;
+  JitKernel k;
+  auto load = [&](const std::vector<char> &code, std::string *why) -> bool {
+    k = JitKernel{};
+    hipError_t e = hipModuleLoadData(&k.module, code.data());
+    if (e != hipSuccess) { *why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return false; }
+    e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_a");
+    if (e == hipSuccess && two) e = hipModuleGetFunction(&k.fn2, k.module, "llkv_jit_b");
+    if (e != hipSuccess) {
+      *why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e);
+      (void)hipModuleUnload(k.module);
+      return false;
+    }
+    return true;
+  };
   std::vector<char> code;
-  {
+  bool loaded = false;
+  if (cacheable) {
     std::ifstream f(path, std::ios::binary);
     if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    std::string why;
+    if (!code.empty() && !(loaded = load(code, &why))) { // truncated / corrupt / stale blob: drop it and compile again
+      (void)::unlink(path.c_str());
+      code.clear();
+    }
   }
-  if (code.empty()) {
+  if (!loaded) {
     int rc = compile_to_code(src, &code, err);
     if (rc) { *err = "plan " + type_string + ": " + *err; return rc; }
-    ::mkdir(dir.c_str(), 0755);
-    const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
-    std::ofstream f(tmp, std::ios::binary);
-    if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); std::rename(tmp.c_str(), path.c_str()); }
-  }
-  JitKernel k;
-  hipError_t e = hipModuleLoadData(&k.module, code.data());
-  if (e != hipSuccess) { *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  e = hipModuleGetFunction(&k.fn, k.module, "llkv_jit_a");
-  if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
-  if (kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit || kind == JitKind::Reduce) {
-    e = hipModuleGetFunction(&k.fn2, k.module, "llkv_jit_b");
-    if (e != hipSuccess) { *err = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return LLKV_INTERNAL; }
+    if (cacheable) {
+      const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+      std::ofstream f(tmp, std::ios::binary);
+      if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); std::rename(tmp.c_str(), path.c_str()); }
+    }
+    if (!load(code, err)) return LLKV_INTERNAL;
   }
   g_jit_cache.emplace(key, k);
   *out = k;
@@ -148,7 +185,8 @@ int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t /*bytes
 
 int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream) {
   ScanParams copy = p;
-  return jit_launch_raw(k.fn, p.n_tiles, &copy, sizeof copy, stream);
+  const uint32_t tpw = p.tiles_per_wg ? p.tiles_per_wg : 1u; // the host sets it for LDS-accumulator plans only
+  return jit_launch_raw(k.fn, (p.n_tiles + tpw - 1) / tpw, &copy, sizeof copy, stream);
 }
 
 void jit_shutdown() {

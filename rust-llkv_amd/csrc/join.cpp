@@ -431,9 +431,12 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
     cur ^= 1;
   }
   if ((rc = emit(steps[cur])) || (rc = emit(steps[cur ^ 1]))) return rc; // oldest first
-  if (!pend_l.empty()) on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
+  if (!pend_l.empty()) { // pairs carried over a device step that ended inside a reference batch: the last batch
+    on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
+    pend_l.clear();
+    pend_r.clear();
+  }
   if (trace) std::fprintf(stderr, "[llkv join] probe: count+scan %9.3f ms, write+copy %9.3f ms, cuts+callbacks %9.3f ms\n", t_acc[0], t_acc[1], t_acc[2]);
-  if (!pend_l.empty()) on_batch(pend_l.data(), left_only ? nullptr : pend_r.data(), pend_l.size(), user);
   return LLKV_OK;
 }
 

@@ -14,6 +14,7 @@
 // their raw (group, value) pairs — a handful for a fact table clustered by the key, as lineitem is — and fold
 // them in rank order, i.e. global row order.  Each rank then reports the candidates of the groups it alone
 // holds plus the straddlers it holds first; the union is merged on the host.
+#include "comm.hpp"
 #include "engine.hpp"
 #include "join.hpp"
 
@@ -582,6 +583,73 @@ llkv_status llkv_hip_join_agg_merge(const llkv_join_group_row *rows, uint32_t n,
   for (uint32_t i = 0; i < m; ++i) out_rows[i] = v[i];
   *out_n = m;
   return LLKV_OK;
+}
+
+// Sharded fact table, collectives included (steps 2–6 of the phased form): the per-group row counts are all-reduced
+// where they lie (HBM, RCCL), the straddler pairs and the ranks' candidates travel as small all-gathers.  Every rank
+// returns the same rows.
+llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n,
+                                             uint64_t *out_total_groups) {
+  auto *j = reinterpret_cast<JoinAgg *>(h);
+  if (!j || !out_rows || !out_n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (!comm_ready()) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "no communicator: call llkv_hip_comm_init first");
+  const uint32_t world = comm_world(), rank = comm_rank();
+  if (j->tf->world != world || j->tf->rank != rank) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the fact table's (rank, world) is not the communicator's");
+  int rc;
+  if (j->n_dim && (rc = comm_allreduce_i64_device(static_cast<int64_t *>(j->gcnts.p), j->n_dim, g_ctx.stream))) return (llkv_status)rc;
+  if ((rc = j->straddlers())) return (llkv_status)rc; // on the same stream: ordered behind the all-reduce
+  // straddler pairs of every rank, rank order = global row order: [n][values f64 × n][groups u32 × n]
+  const uint64_t n = j->st_groups.size();
+  std::vector<uint8_t> mine(8 + n * 8 + (n * 4 + 7) / 8 * 8, 0), all;
+  std::memcpy(mine.data(), &n, 8);
+  if (n) {
+    std::memcpy(mine.data() + 8, j->st_vals.data(), n * 8);
+    std::memcpy(mine.data() + 8 + n * 8, j->st_groups.data(), n * 4);
+  }
+  std::vector<uint64_t> off;
+  if ((rc = comm_allgather_v(mine.data(), mine.size(), &all, &off))) return (llkv_status)rc;
+  std::vector<uint32_t> groups;
+  std::vector<double> values;
+  std::vector<uint64_t> rank_off(world + 1, 0);
+  for (uint32_t r = 0; r < world; ++r) {
+    uint64_t m = 0;
+    std::memcpy(&m, all.data() + off[r], 8);
+    if (off[r + 1] - off[r] != 8 + m * 8 + (m * 4 + 7) / 8 * 8) return (llkv_status)set_error(LLKV_INTERNAL, "malformed straddler block");
+    const double *v = reinterpret_cast<const double *>(all.data() + off[r] + 8);
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(all.data() + off[r] + 8 + m * 8);
+    values.insert(values.end(), v, v + m);
+    groups.insert(groups.end(), g, g + m);
+    rank_off[r + 1] = rank_off[r] + m;
+  }
+  uint64_t n_folded = std::max<uint64_t>(1, groups.size());
+  std::vector<uint32_t> fg(n_folded), ffirst(n_folded);
+  std::vector<double> fs(n_folded);
+  std::vector<uint64_t> fc(n_folded);
+  if ((rc = llkv_hip_join_agg_fold_straddlers(groups.data(), values.data(), rank_off.data(), world, fg.data(), fs.data(), fc.data(), ffirst.data(), &n_folded)))
+    return (llkv_status)rc;
+  std::vector<llkv_join_group_row> cand(std::max(1u, limit));
+  uint32_t n_cand = 0;
+  uint64_t reported = 0;
+  if ((rc = j->candidates(fg.data(), fs.data(), fc.data(), ffirst.data(), n_folded, rank, limit, cand.data(), &n_cand, &reported))) return (llkv_status)rc;
+  // candidates of every rank: [reported groups][n][rows]
+  static_assert(sizeof(llkv_join_group_row) % 8 == 0, "rows travel as 8-byte words");
+  std::vector<uint8_t> cmine(16 + (size_t)n_cand * sizeof(llkv_join_group_row)), call;
+  const uint64_t head[2] = {reported, n_cand};
+  std::memcpy(cmine.data(), head, 16);
+  if (n_cand) std::memcpy(cmine.data() + 16, cand.data(), (size_t)n_cand * sizeof(llkv_join_group_row));
+  if ((rc = comm_allgather_v(cmine.data(), cmine.size(), &call, &off))) return (llkv_status)rc;
+  std::vector<llkv_join_group_row> rows;
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    uint64_t hd[2];
+    std::memcpy(hd, call.data() + off[r], 16);
+    if (off[r + 1] - off[r] != 16 + hd[1] * sizeof(llkv_join_group_row)) return (llkv_status)set_error(LLKV_INTERNAL, "malformed candidate block");
+    total += hd[0];
+    const llkv_join_group_row *p = reinterpret_cast<const llkv_join_group_row *>(call.data() + off[r] + 16);
+    rows.insert(rows.end(), p, p + hd[1]);
+  }
+  if (out_total_groups) *out_total_groups = total;
+  return llkv_hip_join_agg_merge(rows.data(), (uint32_t)rows.size(), j->n_payload, limit, out_rows, out_n);
 }
 
 // Single-rank form: prepare → (nothing to exchange) → candidates.

@@ -162,7 +162,7 @@ struct StagerPool {
         if (!drain((l.cur + k) % kDepth)) return;
       if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
     };
-    const int n_threads = (int)std::min<size_t>(kLanes, (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
+    const int n_threads = (int)std::min<size_t>(std::min<size_t>(kLanes, host_thread_limit()), (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
     std::vector<std::thread> threads;
     for (int k = 1; k < n_threads; ++k) threads.emplace_back(work, std::ref(lanes[k]));
     work(lanes[0]);

@@ -1066,7 +1066,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   // indexed by the row's group id); ungrouped plans keep it in registers
   p.acc_lds = grouped && p.ng > 1;
   p.track_first = grouped && track_first;
-  if (p.acc_lds && (size_t)p.lanes * 2048 > 160u * 1024)
+  if (p.acc_lds && (size_t)(p.lanes - 1) * 2048 > 160u * 1024) // one 2 KiB row per group-state lane (the error lane lives in registers)
     return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
   p.unroll = (p.acc_lds || p.lanes <= 8) ? 4 : 2;
   if (const char *e = std::getenv("LLKV_HIP_UNROLL")) { // tuning knob (run-time specialised kernels only)

@@ -61,6 +61,11 @@ struct ScanParams {
   uint32_t key_stride[kMaxKeys];
   uint32_t n_tiles;
   uint32_t sub_rows;          // selection kernels: rows per wave sub-tile (tile_rows / 4)
+  // fused scan: a workgroup owns `tiles_per_wg` consecutive tiles (0 = 1) and publishes one partial per TILE, so the
+  // reduction association is a property of the canonical tile list, never of the launch geometry: a rank with few
+  // tiles launches one workgroup per tile (an SF10 shard of 1/8 still fills 256 CUs), a rank with many lets a
+  // workgroup stream several tiles back to back
+  uint32_t tiles_per_wg;
   const uint64_t *aux_in;     // selection: exclusive offsets per (tile, wave)
   uint64_t *aux_out;          // selection: logical row ids out
   uint64_t *aux_out2;         // selection: device row indices out
@@ -129,6 +134,7 @@ struct FoldParams {
   uint32_t n_tiles;
   uint32_t lanes;
   uint32_t owned_mask;
+  uint32_t parts_per_tile; // partials per tile: 1, or one per wave for LDS-accumulator plans
 };
 
 } // namespace llkv

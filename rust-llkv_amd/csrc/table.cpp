@@ -1,5 +1,6 @@
 // table.cpp — HBM-resident table images behind include/llkv_hip.h: chunk → tile → octant layout, staging of
 // columns (fixed width, Utf8 dictionary coding, Decimal128 narrowing, validity masks), column statistics.
+#include "comm.hpp"
 #include "engine.hpp"
 
 #include <algorithm>
@@ -110,6 +111,11 @@ int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
   return LLKV_OK;
 }
 
+uint64_t table_chunk_rows(const llkv_hip_table *table, uint32_t global_chunk) {
+  const Table *t = reinterpret_cast<const Table *>(table);
+  return t && global_chunk < t->global_chunk_rows.size() ? t->global_chunk_rows[global_chunk] : 0;
+}
+
 static const uint64_t kSlackRows = 8192; // readable rows past the image end (unrolled tail steps)
 
 static int alloc_column(Table &t, uint32_t width, void **d_out) {
@@ -122,7 +128,7 @@ static int alloc_column(Table &t, uint32_t width, void **d_out) {
 // host-side preparation of a column image (dictionary coding, bitmap expansion, Decimal128 narrowing) runs chunk
 // by chunk on a few threads; fn(chunk) returns a status, the first failure wins
 template <class Fn> static int for_each_chunk_parallel(uint32_t n_chunks, Fn &&fn) {
-  const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const unsigned hw = std::max(1u, std::min(8u, host_thread_limit()));
   const unsigned n_threads = std::min<unsigned>(hw, std::max(1u, n_chunks / 4));
   std::atomic<uint32_t> next{0};
   std::atomic<int> failed{LLKV_OK};
@@ -452,6 +458,64 @@ llkv_status llkv_hip_table_set_column_validity(llkv_hip_table *table, uint32_t f
   if ((rc = stage_to_device({{d, mask.data(), (size_t)t->dev_rows}}))) { (void)hipFree(d); return (llkv_status)rc; }
   c.d_valid = (uint8_t *)d;
   c.info.nullable = true;
+  return LLKV_OK;
+}
+
+// Sharded tables: what plans depend on must not depend on the shard (a rank without NULL cells lowered a
+// plan without the validity slots its neighbour had — different lanes, different exchange image).
+llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  if (t->world == 1) return LLKV_OK;
+  if (!comm_ready() || comm_world() != t->world || comm_rank() != t->rank)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the table's (rank, world) is not the communicator's");
+  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; };
+  std::vector<Rec> mine;
+  for (auto &kv : t->cols) // std::map: ascending field ids on every rank
+    mine.push_back({kv.first, kv.second.has_local_stats ? 1 : 0, kv.second.local_min, kv.second.local_max, kv.second.info.nullable ? 1 : 0, t->local_rows ? 1u : 0u});
+  std::vector<uint8_t> all;
+  std::vector<uint64_t> off;
+  int rc = comm_allgather_v(mine.data(), mine.size() * sizeof(Rec), &all, &off);
+  if (rc) return (llkv_status)rc;
+  for (uint32_t r = 0; r < t->world; ++r) {
+    if (off[r + 1] - off[r] != mine.size() * sizeof(Rec)) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the ranks staged different column sets");
+    const Rec *theirs = reinterpret_cast<const Rec *>(all.data() + off[r]);
+    for (size_t i = 0; i < mine.size(); ++i)
+      if (theirs[i].field != mine[i].field) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the ranks staged different column sets");
+  }
+  size_t i = 0;
+  for (auto &kv : t->cols) {
+    DeviceColumn &c = kv.second;
+    bool all_stats = true, any_rows = false, any_nullable = false;
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (uint32_t r = 0; r < t->world; ++r) {
+      const Rec &x = reinterpret_cast<const Rec *>(all.data() + off[r])[i];
+      any_nullable |= x.nullable != 0;
+      if (!x.local_rows_nonzero) continue; // a rank without rows constrains nothing
+      any_rows = true;
+      if (!x.has_stats) { all_stats = false; continue; }
+      lo = std::min(lo, x.lo);
+      hi = std::max(hi, x.hi);
+    }
+    if (all_stats && any_rows && lo <= hi) {
+      c.info.has_stats = true;
+      c.info.min_i = lo;
+      c.info.max_i = hi;
+    }
+    if (any_nullable && !c.info.nullable) { // no NULL cell here: an all-present mask keeps this rank's plans those of its neighbours
+      if ((rc = ensure_device())) return (llkv_status)rc;
+      void *d = nullptr;
+      const uint64_t bytes = t->dev_rows + kSlackRows;
+      if (hipMalloc(&d, bytes) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "device allocation failed");
+      if (hipMemsetAsync(d, 1, bytes, g_ctx.stream) != hipSuccess || hipStreamSynchronize(g_ctx.stream) != hipSuccess) {
+        (void)hipFree(d);
+        return (llkv_status)set_error(LLKV_INTERNAL, "validity mask could not be initialised");
+      }
+      c.d_valid = static_cast<uint8_t *>(d);
+      c.info.nullable = true;
+    }
+    ++i;
+  }
   return LLKV_OK;
 }
 

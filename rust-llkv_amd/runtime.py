@@ -92,6 +92,136 @@ def shutdown():
     _bound_device = None
 
 
+# ---------------------------------------------------------------------------------------------------
+# Collectives behind the boundary (include/llkv_hip.h "Collectives"): RCCL, or a transport the host supplies
+# ---------------------------------------------------------------------------------------------------
+COMM_ID_BYTES = 128
+_ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_int64), C.c_uint64, C.c_void_p)
+_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class _CommTransport(C.Structure):
+    _fields_ = [("all_reduce_sum_i64", _ALL_REDUCE_FN), ("all_gather", _ALL_GATHER_FN), ("user", C.c_void_p)]
+
+
+_comm_keep = None  # the ctypes callbacks of a custom transport must outlive the communicator
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: a fresh ncclUniqueId to hand to the other ranks over the host's own channel."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().llkv_hip_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init(unique_id: bytes, rank: int, world: int):
+    """Every rank, after init(): join the RCCL communicator (ncclCommInitRank on the bound device)."""
+    if len(unique_id) != COMM_ID_BYTES:
+        raise ValueError("a unique id has 128 bytes")
+    buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+    check(lib().llkv_hip_comm_init(buf, C.c_uint32(rank), C.c_uint32(world)))
+
+
+def comm_init_torch(dist, rank: int, world: int, group=None):
+    """A host-supplied transport over a torch.distributed group whose backend takes CPU tensors (gloo): the library's
+    collectives then see host memory (llkv_hip_comm_init_custom) — how the tests run the sharded drivers without RCCL,
+    and how a host with its own network layer would plug in."""
+    global _comm_keep
+    import torch
+
+    def all_reduce(buf, n, _user):
+        try:
+            t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(n),)))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception:  # nothing may unwind across the C boundary
+            return 1
+
+    def all_gather(send, recv, nbytes, _user):
+        try:
+            n = int(nbytes)
+            src = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(n,)))
+            dst = torch.from_numpy(np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(n * world,)))
+            dist.all_gather(list(dst.split(n)), src, group=group)
+            return 0
+        except Exception:
+            return 1
+
+    t = _CommTransport(_ALL_REDUCE_FN(all_reduce), _ALL_GATHER_FN(all_gather), None)
+    check(lib().llkv_hip_comm_init_custom(C.byref(t), C.c_uint32(rank), C.c_uint32(world)))
+    _comm_keep = t
+
+
+def comm_destroy():
+    global _comm_keep
+    lib().llkv_hip_comm_destroy()
+    _comm_keep = None
+
+
+def comm_world() -> int:
+    f = lib().llkv_hip_comm_world
+    f.restype = C.c_uint32
+    return int(f())
+
+
+def comm_all_reduce_i64(device_ptr: int, n: int, stream: int = 0):
+    """In-place SUM of a device buffer of int64 lanes over the ranks, ordered on ``stream``."""
+    check(lib().llkv_hip_comm_all_reduce_i64(C.c_void_p(device_ptr), C.c_uint64(n), C.c_void_p(stream)))
+
+
+def comm_all_gather_v(payload: bytes) -> List[bytes]:
+    """Variable-length all-gather of host bytes: every rank's contribution, in rank order."""
+    world = comm_world()
+    out, offs = C.c_void_p(), (C.c_uint64 * (world + 1))()
+    src = (C.c_uint8 * max(1, len(payload))).from_buffer_copy(payload or b"\0")
+    check(lib().llkv_hip_comm_all_gather_v(src, C.c_uint64(len(payload)), C.byref(out), offs))
+    try:
+        blob = C.string_at(out, offs[world]) if offs[world] else b""
+    finally:
+        lib().llkv_hip_free(out)
+    return [blob[offs[r]:offs[r + 1]] for r in range(world)]
+
+
+def comm_union_strings(local: Sequence[str]) -> List[str]:
+    """Sorted union of the ranks' string lists: the table-wide dictionary of a sharded Utf8 column."""
+    enc = [s.encode() for s in local]
+    arr = (C.c_char_p * max(1, len(enc)))(*enc)
+    out, n = C.POINTER(C.c_char_p)(), C.c_uint32()
+    check(lib().llkv_hip_comm_union_strings(arr, C.c_uint32(len(enc)), C.byref(out), C.byref(n)))
+    try:
+        return [out[i].decode() for i in range(n.value)]
+    finally:
+        lib().llkv_hip_free(out)
+
+
+def max_threads() -> int:
+    """configured_thread_count of the reference's pool (llkv-threading/src/lib.rs:22-31) as the library sees it."""
+    f = lib().llkv_hip_max_threads
+    f.restype = C.c_uint32
+    return int(f())
+
+
+class SelectShape(C.Structure):
+    """llkv_select_shape: the fields of SelectPlan the executor's dispatch looks at."""
+    _fields_ = [("has_compound", C.c_int32), ("n_tables", C.c_uint32), ("n_group_by", C.c_uint32), ("n_aggregates", C.c_uint32),
+                ("has_computed_aggregates", C.c_int32), ("n_joins", C.c_uint32), ("has_having", C.c_int32), ("has_distinct", C.c_int32),
+                ("has_scalar_subqueries", C.c_int32)]
+
+
+ROUTE_NAMES = {1: "compound", 2: "no_table", 3: "group_by", 4: "cross_product", 5: "aggregates", 6: "computed_aggregates", 7: "projection"}
+
+
+def select_route(**shape):
+    """llkv_hip_select_route: (route name, served by the GPU path?, message) for a plan shape
+    (QueryExecutor::execute_select_with_filter, llkv-executor/src/lib.rs:523-563)."""
+    s = SelectShape(**shape)
+    route = C.c_int32()
+    rc = lib().llkv_hip_select_route(C.byref(s), C.byref(route))
+    if rc not in (0, 4):
+        check(rc)
+    return ROUTE_NAMES[route.value], rc == 0, (lib().llkv_hip_last_error().decode(errors="replace") if rc else "")
+
+
 class _ArrowSchema(C.Structure):
     _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
                 ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
@@ -173,6 +303,11 @@ class HipTable:
     def set_column_stats(self, field_id: int, lo: int, hi: int):
         """Installs the table-wide (min, max) of an integer column (sharded tables; see dist.share_column_stats)."""
         check(lib().llkv_hip_table_set_column_stats(self._h, C.c_uint32(field_id), C.c_int64(lo), C.c_int64(hi)))
+
+    def share_metadata(self):
+        """Sharded tables, before any query is prepared: all ranks agree on integer statistics and on which columns
+        have NULL cells (llkv_hip_table_share_metadata over the communicator)."""
+        check(lib().llkv_hip_table_share_metadata(self._h))
 
     def set_column_validity(self, field_id: int, valid):
         """NULL cells of a staged column as one Arrow validity bitmap per local chunk (LSB first)."""
@@ -309,6 +444,16 @@ class PreparedQuery:
 
     def wait_folded(self, stream: int):
         check(lib().llkv_hip_query_wait_folded(self._h, C.c_void_p(stream)))
+
+    def all_reduce(self, stream: int = 0):
+        """The query's one collective, inside the library (RCCL): the exchange image of the oldest execution not yet
+        submitted is summed over the ranks on ``stream``."""
+        check(lib().llkv_hip_query_all_reduce(self._h, C.c_void_p(stream)))
+
+    def finish_sharded(self, stream: int = 0) -> List["GroupRow"]:
+        """finish() over a sharded table, collectives included (dense, sort-based and DISTINCT forms)."""
+        check(lib().llkv_hip_query_finish_sharded(self._h, C.c_void_p(stream)))
+        return self.rows()
 
     def submit(self, stream: int = 0):
         check(lib().llkv_hip_query_submit(self._h, C.c_void_p(stream)))
@@ -616,6 +761,7 @@ class JoinAgg:
         toks = sum_expr.to_c(keep)
         pay = (C.c_uint32 * max(1, len(payload_fields)))(*payload_fields)
         self.n_payload = len(payload_fields)
+        self._tables = (fact, dim, dim2)  # the handle reads the tables' HBM images until it is freed: keep them alive
         self._h = C.c_void_p()
         check(lib().llkv_hip_join_agg_prepare(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None, pay,
                                               C.c_uint32(len(payload_fields)), toks, C.c_uint32(len(sum_expr.tokens)), C.byref(self._h)))
@@ -624,6 +770,13 @@ class JoinAgg:
         if getattr(self, "_h", None):
             lib().llkv_hip_join_agg_free(self._h)
             self._h = None
+
+    def finish_sharded(self, limit: int):
+        """Steps 2–6 inside the library over its communicator: (rows, total_groups), identical on every rank."""
+        rows = (abi.CJoinGroupRow * max(1, limit))()
+        n, total = C.c_uint32(), C.c_uint64()
+        check(lib().llkv_hip_join_agg_finish_sharded(self._h, C.c_uint32(limit), rows, C.byref(n), C.byref(total)))
+        return [(r.key, r.sum, r.count) + tuple(r.payload[i] for i in range(self.n_payload)) for r in rows[:n.value]], total.value
 
     def counts_buffer(self):
         """(device pointer, length) of the int64 per-group row counts to all-reduce (SUM) in place."""

@@ -263,3 +263,42 @@ def test_two_ranks_exchange_partial_groups_in_rank_order(tmp_path):
     mp.spawn(_sorted_groupby_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     a, b = np.load(out + ".0.npy"), np.load(out + ".1.npy")
     assert a.tolist() == b.tolist() == [[3, 0, 0], [4, 1, 10]]
+
+
+# ---------------------------------------------------------------------------------------------------
+# The library's own collectives (include/llkv_hip.h "Collectives") over a host-supplied transport: two gloo ranks
+# behind llkv_hip_comm_init_custom.  Host-memory entry points only — the device ones need a GPU (tests/test_gpu_*).
+# ---------------------------------------------------------------------------------------------------
+def _comm_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rt = mod("runtime")
+    assert rt.comm_world() == 0
+    rt.comm_init_torch(dist, rank, world)
+    assert rt.comm_world() == world
+    # ragged contributions, one of them empty, one larger than the all-gather's padding unit
+    mine = [b"", bytes(range(256)) * 5 + b"tail"][rank]
+    parts = rt.comm_all_gather_v(mine)
+    ok = parts == [b"", bytes(range(256)) * 5 + b"tail"]
+    parts = rt.comm_all_gather_v(bytes([rank]) * (3 + 14 * rank))
+    ok = ok and parts == [bytes([0]) * 3, bytes([1]) * 17]
+    # table-wide dictionary of a sharded Utf8 column: sorted union, byte order (Rust's str::cmp)
+    union = rt.comm_union_strings([["N", "R", "éa"], ["A", "N", "", "Zz"]][rank])
+    ok = ok and union == sorted({"N", "R", "éa", "A", "", "Zz"}, key=lambda s: s.encode())
+    rt.comm_destroy()
+    assert rt.comm_world() == 0
+    with open(out_path + str(rank), "w") as f:
+        f.write("ok" if ok else "bad")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_use_the_library_collectives_over_a_host_transport(tmp_path):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "res")
+    mp.spawn(_comm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert [open(out + str(r)).read() for r in range(2)] == ["ok", "ok"]

@@ -242,6 +242,17 @@ def test_results_are_bit_reproducible_and_gpu_count_invariant(rt, abi, tpch):
     assert np.array_equal(ex1, pq.read_exchange())
     flat = lambda rows: [(tuple(k.value for k in r.keys), tuple(np.float64(v.value).tobytes() if isinstance(v.value, float) else v.value for v in r.values)) for r in rows]
     assert flat(r1) == flat(r1b)
+    # the reduction association belongs to the canonical tile list, not to the launch geometry: a workgroup may
+    # stream 1 … 8 tiles (engine.cpp: pick_tiles_per_wg follows the LOCAL tile count) and the bits do not move
+    for tpw in ("1", "2", "3", "8"):
+        os.environ["LLKV_HIP_TILES_PER_WG"] = tpw
+        try:
+            pg = rt.PreparedQuery(one, q.predicate, q.aggs, q.keys, True)
+            assert flat(pg.run()) == flat(r1), tpw
+            assert np.array_equal(pg.read_exchange(), ex1), tpw
+            pg.close()
+        finally:
+            del os.environ["LLKV_HIP_TILES_PER_WG"]
     for world in (2, 4, 8):
         total = np.zeros_like(ex1).view(np.int64)
         last = None

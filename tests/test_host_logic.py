@@ -419,3 +419,40 @@ def test_qualification_value_parsing_and_tolerance():
         q.kind_from_token("xyz")
     rows = q.parse_answer_set("l_returnflag|cnt\nA |  3\n\nN|NULL\n", ["string", "integer"])
     assert rows == [[("string", "A"), ("int", 3)], [("string", "N"), ("null", None)]]
+
+
+def test_max_threads_follows_the_reference_pool_rule(monkeypatch):
+    """configured_thread_count (llkv-threading/src/lib.rs:22-31): LLKV_MAX_THREADS trimmed and parsed as usize; zero,
+    a negative or unparsable value falls back to the detected parallelism — the reference's own test
+    (`env_override_zero_defaults`, :97-115) asserts the zero case."""
+    rt = mod("runtime")
+    monkeypatch.delenv("LLKV_MAX_THREADS", raising=False)
+    detected = rt.max_threads()
+    assert 1 <= detected <= (os.cpu_count() or 1)
+    for raw, want in [("0", detected), ("3", 3), (" 5 ", 5), ("+2", 2), ("abc", detected), ("-2", detected), ("", detected), ("2.5", detected), ("1000", 1000)]:
+        monkeypatch.setenv("LLKV_MAX_THREADS", raw)
+        assert rt.max_threads() == want, raw
+
+
+def test_route_selection_mirrors_the_executor_dispatch():
+    """llkv_hip_select_route = the if-chain of QueryExecutor::execute_select_with_filter
+    (llkv-executor/src/lib.rs:531-561), plus whether the GPU path has an entry point for the shape."""
+    route = mod("runtime").select_route
+    # compound beats everything, then "no table", then GROUP BY (single table → group-by route, several → cross product)
+    assert route(has_compound=1, n_tables=2, n_group_by=1)[:2] == ("compound", False)
+    assert route(n_tables=0, n_aggregates=1)[:2] == ("no_table", False)
+    assert route(n_tables=1, n_group_by=2, n_aggregates=3)[:2] == ("group_by", True)          # Q1
+    assert route(n_tables=3, n_group_by=3, has_computed_aggregates=1)[:2] == ("cross_product", True)  # Q3
+    assert route(n_tables=2, n_joins=1)[:2] == ("cross_product", True)                        # join_stream
+    assert route(n_tables=1, n_aggregates=1)[:2] == ("aggregates", True)                      # configs[0]
+    assert route(n_tables=1, has_computed_aggregates=1)[:2] == ("computed_aggregates", True)  # Q6
+    assert route(n_tables=1)[:2] == ("projection", True)                                      # scan_stream
+    # plain aggregates win over computed ones (:552 before :555)
+    assert route(n_tables=1, n_aggregates=1, has_computed_aggregates=1)[0] == "aggregates"
+    # SQL breadth the GPU path leaves to the CPU routes: the route is still reported
+    name, served, why = route(n_tables=1, n_group_by=1, has_having=1)
+    assert (name, served) == ("group_by", False) and "HAVING" in why
+    assert route(n_tables=1, has_distinct=1)[:2] == ("projection", False)
+    assert route(n_tables=1, n_aggregates=1, has_distinct=1)[:2] == ("aggregates", True)      # DISTINCT aggregates are on the path
+    assert route(n_tables=4, n_group_by=1)[:2] == ("cross_product", False)
+    assert route(n_tables=1, has_scalar_subqueries=1)[1] is False
