@@ -348,6 +348,13 @@ llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint3
                                               int32_t *has_stats, int64_t *min_value, int64_t *max_value);
 llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t field_id,
                                             int64_t min_value, int64_t max_value);
+/* The same for Float64 / Float32 columns: the largest and the smallest non-zero |v| over the column's finite values
+ * (0 = the column holds no non-zero value).  They bound aggregate arguments from above and below, which is what lets
+ * the shared-image GROUP BY keep its f64 sums exact and order-free (fused_scan.hip.h: SumF64X).                    */
+llkv_status llkv_hip_table_local_column_float_stats(const llkv_hip_table *table, uint32_t field_id,
+                                                    int32_t *has_stats, double *abs_max, double *abs_min_nonzero);
+llkv_status llkv_hip_table_set_column_float_stats(llkv_hip_table *table, uint32_t field_id,
+                                                  double abs_max, double abs_min_nonzero);
 
 /* Bytes moved host → HBM by the staging calls of this process so far, and the wall
  * time those copies took (pinned ring fill + DMA; the host-side preparation of a
@@ -482,6 +489,10 @@ llkv_status llkv_hip_query_kernel_time(llkv_hip_query *query, double *total_ms,
 uint64_t llkv_hip_query_algorithmic_bytes(const llkv_hip_query *query);
 /* Name of the compiled kernel variant chosen for this plan. */
 const char *llkv_hip_query_kernel_signature(const llkv_hip_query *query);
+/* Which kernel family serves the plan — register accumulators, per-thread accumulator columns in LDS (≤ 64 groups),
+ * one shared accumulator image per workgroup (hundreds … thousands of groups, order-free lanes), the sort-based
+ * route — and, when a cheaper family declined, why.                                                              */
+const char *llkv_hip_query_route_note(const llkv_hip_query *query);
 
 /* One-shot conveniences (prepare + launch + finish + copy out + free). */
 llkv_status llkv_hip_aggregate(const llkv_hip_table *table, const llkv_filter *filters,
@@ -858,10 +869,14 @@ typedef struct llkv_column_desc {
   const char *const *dictionary;
   int32_t nullable;   /* the column has NULL cells                           */
   int32_t precision, scale; /* LLKV_DT_DECIMAL128                            */
+  int32_t has_fstats; /* Float64 / Float32: the two statistics below are known */
+  double f_absmax;    /* largest |v| over the column's finite values         */
+  double f_absmin_nz; /* smallest non-zero |v| over them (0: none)           */
 } llkv_column_desc;
 
 /* `grouped`: 0 = ungrouped aggregates, 1 = GROUP BY (groups in first-appearance
- * order), 3 = GROUP BY with ORDER BY on the keys (no first-row tracking).     */
+ * order), 3 = GROUP BY with ORDER BY on the keys (no first-row tracking); + 4 =
+ * lower for the shared-image GROUP BY kernel (hundreds … thousands of groups).  */
 llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols,
                             const llkv_filter *filters, uint32_t n_filters,
                             const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields,

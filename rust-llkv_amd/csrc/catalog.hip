@@ -10,8 +10,8 @@ namespace llkv {
 
 template <class P> static hipError_t launch_plan(const ScanParams &p, hipStream_t stream) {
   if (p.n_tiles == 0) return hipSuccess;
-  const uint32_t tpw = P::ACC == 1 && p.tiles_per_wg ? p.tiles_per_wg : 1u; // register plans: one tile per workgroup
-  hipLaunchKernelGGL((fused_scan_kernel<P>), dim3((p.n_tiles + tpw - 1) / tpw), dim3(kBlock), 0, stream, p);
+  const uint32_t grid = P::ACC == 1 && p.scan_grid ? p.scan_grid : p.n_tiles; // register plans: one tile per workgroup
+  hipLaunchKernelGGL((fused_scan_kernel<P>), dim3(grid), dim3(kBlock), 0, stream, p);
   return hipGetLastError();
 }
 
@@ -58,6 +58,59 @@ template <class T> __global__ __launch_bounds__(256) void minmax_kernel(const T 
     atomicMin(&out[0], mn);
     atomicMax(&out[1], mx);
   }
+}
+
+// Float column statistics over the FINITE values (NaN / ±∞ are skipped: they travel through the sums as such):
+// out[0] = bits of the largest |v|, out[1] = bits of the smallest non-zero |v| (non-negative doubles order like their bits).
+template <class T> __global__ __launch_bounds__(256) void absrange_kernel(const T *v, uint64_t n, unsigned long long *out) {
+  double hi = 0.0, lo = __builtin_inf();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const double x = __builtin_fabs((double)v[i]);
+    const bool finite = x < __builtin_inf();
+    hi = (finite && x > hi) ? x : hi;
+    lo = (finite && x > 0.0 && x < lo) ? x : lo;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ohi = __shfl_xor(hi, off, 64), olo = __shfl_xor(lo, off, 64);
+    hi = ohi > hi ? ohi : hi;
+    lo = olo < lo ? olo : lo;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(hi));
+    atomicMin(&out[1], (unsigned long long)__double_as_longlong(lo));
+  }
+}
+hipError_t launch_absrange_f64(const double *values, uint64_t n, uint64_t *d_bits, hipStream_t stream) {
+  hipLaunchKernelGGL((absrange_kernel<double>), dim3(1024), dim3(256), 0, stream, values, n, (unsigned long long *)d_bits);
+  return hipGetLastError();
+}
+hipError_t launch_absrange_f32(const float *values, uint64_t n, uint64_t *d_bits, hipStream_t stream) {
+  hipLaunchKernelGGL((absrange_kernel<float>), dim3(1024), dim3(256), 0, stream, values, n, (unsigned long long *)d_bits);
+  return hipGetLastError();
+}
+
+// Padding rows between ragged chunks (every chunk starts on a 16-row boundary of the image) take a copy of the chunk's
+// last value: no tile ever selects them, and the column statistics (min / max, float ranges) then describe the real
+// rows only — zeros there widened a positive column's range down to 0, which cost plans their dense group ids.
+__global__ __launch_bounds__(256) void fill_padding_kernel(char *col, uint32_t width, const uint64_t *pad /* [n][3]: first row, rows, source row */, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 16) return;
+  const uint64_t *e = pad + (uint64_t)(i / 16) * 3;
+  const uint32_t r = i % 16;
+  if (r >= e[1]) return;
+  for (uint32_t b = 0; b < width; ++b) col[(e[0] + r) * width + b] = col[e[2] * width + b];
+}
+hipError_t launch_fill_padding(void *col, uint32_t width, const uint64_t *d_pad, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_padding_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, stream, (char *)col, width, d_pad, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const uint8_t *lane_ops, uint32_t n_wg, uint32_t ng, uint32_t k, uint32_t owned_mask,
+                             uint32_t passes, hipStream_t stream) {
+  ImageFoldParams f{partials, exchange, lane_ops, n_wg, ng, k, owned_mask, passes, (ng + passes - 1) / passes};
+  hipLaunchKernelGGL(image_fold_kernel, dim3((ng * k + 1 + 255) / 256), dim3(256), 0, stream, f);
+  return hipGetLastError();
 }
 
 hipError_t launch_minmax_i64(const int64_t *values, uint64_t n, int64_t *d_minmax, hipStream_t stream) {

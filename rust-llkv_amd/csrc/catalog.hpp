@@ -34,4 +34,17 @@ hipError_t launch_exclusive_scan(const uint64_t *in, uint64_t *out, uint32_t n, 
 hipError_t launch_minmax_i64(const int64_t *values, uint64_t n, int64_t *d_minmax /*[2]*/, hipStream_t stream);
 hipError_t launch_minmax_i32(const int32_t *values, uint64_t n, int64_t *d_minmax /*[2]*/, hipStream_t stream);
 
+// Float column statistics over the finite values: d_bits[0] = bits of the largest |v| (initialise to 0), d_bits[1] =
+// bits of the smallest non-zero |v| (initialise to the bits of +∞).
+hipError_t launch_absrange_f64(const double *values, uint64_t n, uint64_t *d_bits, hipStream_t stream);
+hipError_t launch_absrange_f32(const float *values, uint64_t n, uint64_t *d_bits, hipStream_t stream);
+
+// Copies a chunk's last value into the ≤ 15 padding rows behind it; d_pad = n × {first padding row, rows, source row}.
+hipError_t launch_fill_padding(void *col, uint32_t width, const uint64_t *d_pad, uint32_t n, hipStream_t stream);
+
+// Shared-image GROUP BY: workgroup images [pass][n_wg][k·ngs + 1] (lane-major, ngs = ⌈ng / passes⌉ groups per slice)
+// → exchange image [8][ng·k + 1] (group-major).
+hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const uint8_t *lane_ops, uint32_t n_wg, uint32_t ng, uint32_t k, uint32_t owned_mask,
+                             uint32_t passes, hipStream_t stream);
+
 } // namespace llkv

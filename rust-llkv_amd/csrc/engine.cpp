@@ -71,28 +71,40 @@ Query::~Query() {
 // folded in order): its length depends on the plan alone, never on the table size, the shard or the GPU count, so
 // results are bit-identical across launch geometries.  Register-resident states amortise their block reduction quickly
 // and like many small tiles (4 096 rows); LDS-resident grouped states use 16 384-row tiles and let a workgroup stream
-// several of them (pick_tiles_per_wg).
+// several of them (pick_scan_grid).
 static uint32_t pick_tile_rows(const LoweredPlan &p) {
   if (const char *e = std::getenv("LLKV_HIP_TILE_ROWS")) {
     long v = std::atol(e);
     if (v >= 512 && v % 512 == 0) return (uint32_t)v;
   }
-  return p.acc_lds ? 16384u : 4096u;
+  return p.acc_image ? 8192u : p.acc_lds ? 16384u : 4096u; // shared-image plans: tiles are only a work list (every lane is order-free)
 }
 
-// Launch geometry of an LDS-accumulator plan, from the LOCAL tile count: a workgroup owns 1, 2, 4 or 8 consecutive
-// tiles — as many as leave ≈ 900 workgroups (256 CUs × 2 resident workgroups, a few rounds).  SF10 on one GPU:
-// 3 662 tiles → 4 per workgroup (916 workgroups of 65 536 rows, the tuned single-GPU shape); a 1/8 shard: 458 tiles
-// → one each (one round of resident workgroups), so the shard still fills the device (profiles/r02/sweep_tiles.txt).
-static uint32_t pick_tiles_per_wg(const LoweredPlan &p, uint32_t n_tiles) {
-  if (!p.acc_lds) return 1;
-  if (const char *e = std::getenv("LLKV_HIP_TILES_PER_WG")) {
+// Workgroups of a shared-image scan (1024 threads each, persistent: workgroup b takes tiles b, b + g, …): as many as
+// fit the CUs at once — two per CU while two images fit the 160 KB of LDS.
+static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
+  const size_t slice_bytes = ((size_t)p.ng + p.image_passes - 1) / p.image_passes * p.k * 8;
+  uint32_t grid = slice_bytes <= 76u * 1024 ? 512u : 256u;
+  if (const char *e = std::getenv("LLKV_HIP_IMAGE_WGS")) {
     long v = std::atol(e);
-    if (v >= 1 && v <= 64) return (uint32_t)v;
+    if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 16);
   }
-  uint32_t tpw = 1;
-  while (tpw < 8 && n_tiles / (2 * tpw) >= 896) tpw *= 2;
-  return tpw;
+  return std::max(1u, std::min(grid, n_tiles));
+}
+
+// Launch geometry of an LDS-accumulator plan, from the LOCAL tile count: persistent-style, about one workgroup per
+// CU, each streaming a contiguous run of tiles (workgroup b of g: tiles [b·n/g, (b+1)·n/g)).  Fewer, longer-running
+// workgroups beat many short ones once the tile boundary is cheap (profiles/r02/sweep_tiles.txt: SF10 on one GPU,
+// 3 662 tiles: 229–458 workgroups 330–347 µs, 916 workgroups 357 µs, 3 662 workgroups 367 µs); a shard with fewer
+// tiles than CUs launches one workgroup per tile.
+static uint32_t pick_scan_grid(const LoweredPlan &p, uint32_t n_tiles) {
+  if (!p.acc_lds) return 0; // one tile per workgroup
+  uint32_t grid = 256;
+  if (const char *e = std::getenv("LLKV_HIP_SCAN_WGS")) {
+    long v = std::atol(e);
+    if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 20);
+  }
+  return std::max(1u, std::min(grid, n_tiles));
 }
 
 int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
@@ -138,10 +150,24 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     }
   }
   rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, grouped, /*track_first=*/!order_by_keys, &q->plan, &err);
+  if (rc == LLKV_UNSUPPORTED && grouped && !std::getenv("LLKV_HIP_GROUP_NO_IMAGE")) {
+    // more groups or a wider state than per-thread accumulator columns hold: ONE image per workgroup, shared by its
+    // threads (image_scan_body) — as long as the image fits the LDS and every f64 sum has a bound that makes it exact
+    std::string image_err;
+    LoweredPlan ip;
+    if (lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, true, !order_by_keys, &ip, &image_err, /*image=*/true) == LLKV_OK) {
+      q->route_note = "shared-image GROUP BY (per-thread accumulators: " + err + ")";
+      q->plan = std::move(ip);
+      rc = LLKV_OK;
+    } else {
+      err += "; shared-image route: " + image_err;
+    }
+  }
   if (rc == LLKV_UNSUPPORTED && grouped) {
-    // too many groups / too wide a state / sparse or unbounded integer keys for the dense kernel: sort-based route
+    // sparse or unbounded integer keys, too many groups, unbounded f64 sums: sort-based route
     const std::string dense_err = err;
     if (sorted_groupby_prepare(table, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, order_by_keys, &q->sorted) == LLKV_OK) {
+      q->route_note = "sort-based GROUP BY (" + dense_err + ")";
       *out = q.release();
       return LLKV_OK;
     }
@@ -160,9 +186,9 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   }
 
   if (!p.always_false) {
-    q->entry = std::getenv("LLKV_HIP_FORCE_JIT") ? nullptr : catalog_find(p.type_string.c_str());
+    q->entry = (std::getenv("LLKV_HIP_FORCE_JIT") || p.acc_image) ? nullptr : catalog_find(p.type_string.c_str());
     if (!q->entry) {
-      rc = jit_compile(JitKind::Scan, p.type_string, &q->jit, &err);
+      rc = jit_compile(p.acc_image ? JitKind::Image : JitKind::Scan, p.type_string, &q->jit, &err);
       if (rc) return set_error(rc, err);
     }
   }
@@ -177,11 +203,13 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   for (size_t i = 0; i < p.key_strides.size(); ++i) q->params.key_stride[i] = p.key_strides[i];
   q->params.tiles = ts->d_tiles;
   q->params.n_tiles = ts->n_tiles;
-  q->params.tiles_per_wg = pick_tiles_per_wg(p, ts->n_tiles);
+  q->params.scan_grid = pick_scan_grid(p, ts->n_tiles);
 
   const size_t lanes = (size_t)p.lanes;
   const uint32_t parts_per_tile = p.acc_lds ? (uint32_t)(kBlock / 64) : 1u; // LDS-accumulator plans publish one partial per (tile, wave)
-  q->partials_len = std::max<size_t>(1, lanes * ts->n_tiles * parts_per_tile);
+  q->image_grid = p.acc_image ? pick_image_grid(p, ts->n_tiles) : 0;
+  const size_t image_slice_words = p.acc_image ? ((size_t)p.ng + p.image_passes - 1) / p.image_passes * p.k + 1 : 0;
+  q->partials_len = std::max<size_t>(1, p.acc_image ? image_slice_words * q->image_grid * p.image_passes : lanes * ts->n_tiles * parts_per_tile);
   q->d_tile_partials = (uint64_t *)scratch_alloc(2 * q->partials_len * sizeof(uint64_t));
   q->d_lane_ops = (uint8_t *)scratch_alloc(lanes);
   if (!q->d_tile_partials || !q->d_lane_ops) return set_error(LLKV_INTERNAL, "device allocation failed");
@@ -193,7 +221,9 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   q->h_exchange = (uint64_t *)pinned_acquire(&q->h_exchange_bytes);
   if (!q->h_exchange) return set_error(LLKV_INTERNAL, "pinned host allocation failed");
   std::memset(q->h_exchange, 0, ring_bytes);
-  q->host_mapped = table->world == 1; // nobody else reads the image: let the kernel write it to the host directly
+  // nobody else reads the image: let the kernel write it to the host directly (not the transposing fold of a
+  // shared-image plan: thousands of scattered 8-byte stores belong in HBM, one copy brings the image over)
+  q->host_mapped = table->world == 1 && !p.acc_image;
   if (q->host_mapped) q->d_exchange = q->h_exchange;
   else {
     q->d_exchange = (uint64_t *)scratch_alloc(ring_bytes);
@@ -208,6 +238,9 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     q->d_empty_image = (uint64_t *)scratch_alloc(img.size() * 8);
     if (!q->d_empty_image) return set_error(LLKV_INTERNAL, "device allocation failed");
     HIP_TRY(hipMemcpy(q->d_empty_image, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+    if (p.acc_image) // the fold of a shared-image plan only rewrites the first owned octant of a slot: the rest is constant
+      for (uint32_t sl = 0; sl < Query::kMaxDepth; ++sl)
+        HIP_TRY(hipMemcpy(q->d_exchange + sl * q->exchange_len(), img.data(), img.size() * 8, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   q->params.tile_partials = q->d_tile_partials;
@@ -256,7 +289,40 @@ int Query::launch(hipStream_t stream) {
   const uint32_t fold_blocks = (uint32_t)kOctantsHost * (uint32_t)((plan.lanes + kBlock / 64 - 1) / (kBlock / 64));
   bool piggy = false;
   int rc;
-  const uint32_t grid = (tiles->n_tiles + params.tiles_per_wg - 1) / params.tiles_per_wg;
+  if (plan.acc_image) {
+    // shared-image GROUP BY: scan (persistent workgroups, one LDS image each) + fold of the workgroup images into the
+    // slot's exchange image, back to back on the stream; nothing is deferred to the next launch
+    if (pending && (rc = flush_pending())) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (run_main && profiling && (launches % profile_every) == 0) {
+      if (events_used == events.size()) {
+        HIP_TRY(hipEventCreate(&ev.first));
+        HIP_TRY(hipEventCreate(&ev.second));
+        events.push_back(ev);
+      }
+      ev = events[events_used++];
+      HIP_TRY(hipEventRecord(ev.first, stream));
+    }
+    if (run_main) {
+      const uint32_t ngs = (plan.ng + plan.image_passes - 1) / plan.image_passes;
+      for (int pass = 0; pass < plan.image_passes; ++pass) { // one scan per slice of the groups
+        ScanParams p = params;
+        p.group_base = (uint32_t)pass * ngs;
+        p.tile_partials = d_tile_partials + (size_t)pass * image_grid * ((size_t)ngs * plan.k + 1);
+        if ((rc = jit_launch_raw(jit.fn, image_grid, &p, sizeof p, stream, 1024))) return rc;
+      }
+      HIP_TRY(launch_image_fold(d_tile_partials, image, d_lane_ops, image_grid, plan.ng, (uint32_t)plan.k, table->owned_mask, (uint32_t)plan.image_passes, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(image, d_empty_image, exchange_len() * sizeof(uint64_t), hipMemcpyDefault, stream));
+    }
+    if (ev.second) HIP_TRY(hipEventRecord(ev.second, stream));
+    HIP_TRY(hipEventRecord(ev_fold[slot], stream));
+    slot_stream[slot] = stream;
+    launches++;
+    n_launched++;
+    return LLKV_OK;
+  }
+  const uint32_t grid = params.scan_grid ? params.scan_grid : tiles->n_tiles;
   if (pending && !(run_main && grid >= fold_blocks && stream == pending_stream) && (rc = flush_pending())) return rc;
   if (run_main) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -333,6 +399,14 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   const int64_t rows = a.count_lane >= 0 ? (int64_t)g[base + a.count_lane] : (int64_t)g[0];
   const uint64_t *l = a.lane >= 0 ? g + base + a.lane : nullptr;
   auto as_f64 = [](uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; };
+  // an f64 sum: one lane, or the exact grid-level lanes of the shared-image plans (fused_scan.hip.h: SumF64X), added
+  // smallest level first
+  auto f64_sum = [&]() {
+    if (a.exact_levels <= 1) return as_f64(l[0]);
+    double v = as_f64(l[a.exact_levels - 1]);
+    for (int j = a.exact_levels - 2; j >= 0; --j) v += as_f64(l[j]);
+    return v;
+  };
   auto exact_sum = [&](int64_t *sum, const char *overflow_msg) -> int {
     const i128 total = ((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0];
     if (total > (i128)INT64_MAX || total < (i128)INT64_MIN) { *err = overflow_msg; return LLKV_INVALID_ARGUMENT; }
@@ -386,8 +460,8 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
     if (rows == 0) { out->is_null = 1; return LLKV_OK; }
     return exact_sum(&out->i64, "integer overflow");
   }
-  case AggFinal::SumF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; out->f64 = rows ? as_f64(l[0]) : 0.0; return LLKV_OK;
-  case AggFinal::TotalF64: out->dtype = LLKV_DT_FLOAT64; out->f64 = as_f64(l[0]); return LLKV_OK;
+  case AggFinal::SumF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; out->f64 = rows ? f64_sum() : 0.0; return LLKV_OK;
+  case AggFinal::TotalF64: out->dtype = LLKV_DT_FLOAT64; out->f64 = f64_sum(); return LLKV_OK;
   case AggFinal::AvgI64Fast: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = (double)(int64_t)l[0] / (double)rows; return LLKV_OK;
   case AggFinal::AvgI64: {
     out->dtype = LLKV_DT_FLOAT64;
@@ -398,7 +472,7 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
     out->f64 = (double)s / (double)rows;
     return LLKV_OK;
   }
-  case AggFinal::AvgF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = as_f64(l[0]) / (double)rows; return LLKV_OK;
+  case AggFinal::AvgF64: out->dtype = LLKV_DT_FLOAT64; out->is_null = rows == 0; if (rows) out->f64 = f64_sum() / (double)rows; return LLKV_OK;
   case AggFinal::MinI64: case AggFinal::MaxI64: out->dtype = LLKV_DT_INT64; out->is_null = rows == 0; out->i64 = rows ? (int64_t)l[0] : 0; return LLKV_OK;
   case AggFinal::MinF64: case AggFinal::MaxF64: {
     out->dtype = LLKV_DT_FLOAT64;
@@ -1050,6 +1124,13 @@ llkv_status llkv_hip_query_kernel_time(llkv_hip_query *query, double *total_ms, 
 uint64_t llkv_hip_query_algorithmic_bytes(const llkv_hip_query *query) {
   const Query *q = reinterpret_cast<const Query *>(query);
   return q ? q->plan.bytes_per_row * q->table->local_rows : 0;
+}
+
+const char *llkv_hip_query_route_note(const llkv_hip_query *query) {
+  const Query *q = reinterpret_cast<const Query *>(query);
+  if (!q) return "";
+  if (!q->route_note.empty()) return q->route_note.c_str();
+  return q->plan.acc_lds ? "GROUP BY with per-thread accumulator columns in LDS" : q->plan.grouped ? "GROUP BY with register accumulators" : "ungrouped aggregates, register accumulators";
 }
 
 const char *llkv_hip_query_kernel_signature(const llkv_hip_query *query) {

@@ -45,6 +45,8 @@ struct DeviceColumn {
   void *d_values = nullptr;
   bool has_local_stats = false; // min / max of this rank's rows (info.has_stats / min_i / max_i are table-wide)
   int64_t local_min = 0, local_max = 0;
+  bool has_local_fstats = false; // float columns: largest finite |v| of this rank's rows (info.has_fstats / f_absmax are table-wide)
+  double local_f_absmax = 0.0, local_f_absmin_nz = 0.0;
   uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
   bool owned = false;
 };
@@ -88,7 +90,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
-enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5 };
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5, Image = 6 };
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // scan / select-count / project
@@ -96,7 +98,7 @@ struct JitKernel {
 };
 int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, std::string *err);
 int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream);
-int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t bytes, hipStream_t stream);
+int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t bytes, hipStream_t stream, uint32_t block = kBlock);
 void jit_shutdown();
 
 struct GroupKey { // GroupKeyValue: String or Int (llkv-executor/src/lib.rs:99-106)
@@ -174,6 +176,8 @@ struct Query {
   uint64_t *d_empty_image = nullptr;    // exchange image of an execution without tiles
   hipEvent_t ev_fold[kMaxDepth] = {nullptr}; // exchange image of the slot complete
   hipStream_t slot_stream[kMaxDepth] = {nullptr};
+  std::string route_note;              // which kernel family serves the plan, and why the cheaper ones declined
+  uint32_t image_grid = 0;             // shared-image plans: workgroups of the scan (= images the fold combines)
   bool host_mapped = false;            // single rank: the kernel writes the image straight into pinned host memory
   uint64_t *d_exchange = nullptr; // [kMaxDepth][kOctants][lanes]
   uint64_t *h_exchange = nullptr; // pinned, same shape

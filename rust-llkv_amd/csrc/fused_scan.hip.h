@@ -487,6 +487,25 @@ template <class E> struct SumF64 { // SumFloat64 :870-888, AvgFloat64 :1177-1199
   static constexpr int op(int) { return OP_ADD_F64; }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)__double_as_longlong((double)E::eval(c, j)); }
 };
+// The same sum, EXACT and therefore order-free: every value is cut into pieces on fixed grids — q1 = v rounded to a
+// multiple of u1, q2 = (v − q1) rounded to a multiple of u2, … — chosen by the host (plan.cpp: exact_sum_constants)
+// from a bound B ≥ |v| (column statistics through the expression) and the table's row count N so that any partial
+// sum of the pieces of one level is a multiple of its grid below 2^53 grid units: every f64 addition of a lane is
+// exact, so threads, waves, workgroups and ranks may add in ANY order and still produce the same bits.  The last grid
+// resolves the smallest non-zero |v| the statistics allow to 2^-30 of itself, so what a row drops is < 2^-31 of its
+// own magnitude.  C(j) = 1.5·2^52·u(j): (x + C) − C rounds x to the grid of C's ulp (nearest-even, branch-free).
+// ±∞ and NaN travel in the first lane.
+template <class E, class... Cs> struct SumF64X {
+  static constexpr int N = sizeof...(Cs);
+  static constexpr int op(int) { return OP_ADD_F64; }
+  template <class C0, class... Cr> static __device__ __forceinline__ void cut(Ctx &c, int j, double r, uint64_t *o) {
+    const double cj = C0::eval(c, j);
+    const double q = __dsub_rn(__dadd_rn(r, cj), cj);
+    o[0] = (uint64_t)__double_as_longlong(q);
+    if constexpr (sizeof...(Cr) > 0) cut<Cr...>(c, j, (__builtin_fabs(r) == __builtin_inf()) ? 0.0 : __dsub_rn(r, q), o + 1);
+  }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { cut<Cs...>(c, j, (double)E::eval(c, j), o); }
+};
 template <class E> struct SumI64 { // SumInt64 :801-830, AvgInt64 :1114-1144 — exact 96-bit split sum + max|v|
   static constexpr int N = 3;
   static constexpr int op(int k) { return k == 2 ? OP_MAX_U64 : OP_ADD_I64; }
@@ -572,7 +591,11 @@ template <class... As> struct Aggs {
 // ACC = 0: accumulators in registers, masked per group (ungrouped plans, NG = 1);
 // ACC = 1: accumulators in per-thread private LDS slots updated with DS atomics
 //          (ds_add_f64 / ds_add_u64 / ds_min_i64 / ...), indexed by the row's own group id.
-template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0> struct Plan {
+// ACC = 2: ONE accumulator image per workgroup in LDS, [lane][group], shared by its 1024 threads and updated with
+//          the same DS atomics (image_scan_body): hundreds to thousands of groups.  Every lane op must be order-free,
+//          so f64 sums are the exact two-level SumF64X.
+template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0, int PASSES_ = 1> struct Plan {
+  static constexpr int PASSES = PASSES_; // shared-image plans: the groups are cut into PASSES slices, one scan each
   using ColList = CL;
   using Pred = PR;
   using KeyT = KS;
@@ -901,14 +924,14 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
   piggyback_fold<P>(p);
 
   // The canonical unit of the reduction is (tile, wave): the rows of a tile that a wave's lanes own (128 consecutive
-  // rows of every 512-row step) → one partial per lane of the plan, whatever the launch geometry.  A workgroup streams
-  // `tiles_per_wg` consecutive tiles; its four waves never synchronise: each reduces its own 64 columns of the image
+  // rows of every 512-row step) → one partial per lane of the plan, whatever the launch geometry.  Workgroup b of g
+  // streams the consecutive tiles [b·n/g, (b+1)·n/g) — the host picks g (≈ one workgroup per CU, engine.cpp:
+  // pick_scan_grid); its four waves never synchronise: each reduces its own 64 columns of the image
   // (DS operations of one wave execute in order) and moves on.  The image of a finished tile is reduced AFTER the
   // first loads of the next tile have been requested (same iteration: nothing loaded lives across the back-edge or a
   // join point), so the reduction hides behind their latency; the next tile's descriptor is fetched a tile ahead.
-  const uint32_t tpw = p.tiles_per_wg ? p.tiles_per_wg : 1u;
-  uint32_t tile = blockIdx.x * tpw;
-  const uint32_t tile_end = tile + tpw < p.n_tiles ? tile + tpw : p.n_tiles;
+  uint32_t tile = (uint32_t)((uint64_t)blockIdx.x * p.n_tiles / gridDim.x);
+  const uint32_t tile_end = (uint32_t)((uint64_t)(blockIdx.x + 1) * p.n_tiles / gridDim.x);
   if (tile >= tile_end) return;
   const uint32_t n_parts = p.n_tiles * kLdsParts;
 #pragma unroll
@@ -966,8 +989,111 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
   wave_reduce_image<P>(p, acc, wave, wl, done_tile * kLdsParts + wave, n_parts, done_err);
 }
 
+// ---- grouped plans with many groups: one accumulator image per workgroup --------------------------------------
+// 65 … ~16 000 groups (GROUP BY l_shipdate: 2 526) do not fit per-thread accumulator columns; sorting the rows by key
+// and gathering the arguments through the permutation (group_sort.cpp) moves the table several times.  Here a
+// persistent workgroup of 1024 threads (16 waves: with ≥ 80 KB of image only one workgroup fits a CU, and it has to
+// hide the HBM latency on its own) keeps ONE image img[lane][group] in LDS and every row updates the K slots of its
+// group with native DS atomics.  Rows of one wave instruction that meet in a group are serialised by the LDS, in no
+// particular order — which is why every lane of such a plan is order-free: integer adds, min / max, and f64 sums as
+// exact two-level SumF64X.  The result is then independent of thread, workgroup, tile and rank geometry by
+// construction.  Each workgroup leaves its image in global memory ([workgroup][lane][group], coalesced);
+// image_fold_kernel combines them.
+constexpr int kImgBlock = 1024;
+constexpr int kImgStepRows = kImgBlock * kRowsPerThread; // 2048 rows per workgroup step
+
+template <class P, int NGS, int K0 = 0> __device__ __forceinline__ void image_accumulate_row(uint64_t *img, uint32_t gid, const uint64_t *contrib) {
+  if constexpr (K0 < P::K) {
+    lds_accumulate<plan_lane_op<P>(K0)>(img + K0 * NGS + gid, contrib[K0]);
+    image_accumulate_row<P, NGS, K0 + 1>(img, gid, contrib);
+  }
+}
+
+// When the image of all groups exceeds the LDS the groups are cut into P::PASSES slices of NG groups and the table is
+// scanned once per slice (ScanParams::group_base = first group of the launch's slice; rows of other slices are
+// skipped): P× the traffic, still far below what sorting the rows costs.
+template <class P> __device__ __forceinline__ void image_scan_body(const ScanParams &p) {
+  constexpr int K = P::K, U = P::U;
+  constexpr int NG = (P::NG + P::PASSES - 1) / P::PASSES; // groups of one slice
+  __shared__ uint64_t img[K * NG]; // [lane][group of the slice]
+  __shared__ uint32_t block_err;
+
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < (uint32_t)(K * NG); i += kImgBlock) img[i] = lane_identity(plan_lane_op<P>((int)(i / NG)));
+  if (tid == 0) block_err = 0;
+  __syncthreads();
+
+  uint32_t err = 0;
+  for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const TileDesc td = load_tile_desc(p.tiles, tile);
+    const uint32_t nsteps = (td.rows + kImgStepRows - 1) / kImgStepRows;
+    for (uint32_t s = 0; s < nsteps; s += U) {
+      Loaded ld[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + u) * kImgStepRows + (uint64_t)tid * kRowsPerThread, ld[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t row0 = (s + u) * kImgStepRows + tid * kRowsPerThread;
+#pragma unroll
+        for (int j = 0; j < kRowsPerThread; ++j) {
+          Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
+          const bool in_tile = (row0 + j) < td.rows;
+          uint32_t gid = P::KeyT::gid(c, j) - p.group_base; // groups of other slices (and the arbitrary codes of
+          const bool mine = gid < (uint32_t)NG;              // rows past the tile end) wrap past NG
+          const bool pass = in_tile & mine & P::Pred::eval(c, j);
+          gid = mine ? gid : 0u;
+          uint64_t contrib[K];
+          contrib[0] = 1;
+          if constexpr (P::first) contrib[1] = c.row;
+          AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
+          err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
+          if (pass) image_accumulate_row<P, NG>(img, gid, contrib);
+        }
+      }
+    }
+  }
+  if (err) atomicOr(&block_err, err);
+  __syncthreads();
+  uint64_t *out = p.tile_partials + (uint64_t)blockIdx.x * (uint64_t)(K * NG + 1);
+  for (uint32_t i = tid; i < (uint32_t)(K * NG); i += kImgBlock) out[i] = img[i];
+  if (tid == 0) out[K * NG] = block_err;
+}
+
+// Workgroup images [pass][n_wg][K·NGS + 1] (lane-major, NGS groups per slice) → the exchange image [kOctants][NG·K + 1] (group-major, the layout
+// of every other plan): the first octant this rank owns receives the combined image; its other octants hold the lane
+// identities and the octants of other ranks zero (both written once, when the query is prepared) — so the int64-sum
+// all-reduce and the host's octant fold work unchanged.  Every lane op is order-free here, so the order over
+// workgroups (and over ranks) is immaterial.
+struct ImageFoldParams {
+  const uint64_t *partials;
+  uint64_t *exchange;
+  const uint8_t *lane_ops; // [K]: op of lane k of a group
+  uint32_t n_wg, ng, k, owned_mask;
+  uint32_t passes, ngs; // slices of the groups, groups per slice
+};
+__global__ __launch_bounds__(256) void image_fold_kernel(const ImageFoldParams f) {
+  const uint32_t lanes = f.ng * f.k + 1, slice = f.ngs * f.k + 1; // exchange lanes; words of one workgroup image
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x; // (lane k, group g) in lane-major order, or the error lane
+  if (i >= lanes) return;
+  const uint32_t o = (uint32_t)__builtin_ctz(f.owned_mask | (1u << kOctants)); // first owned octant
+  if (o >= (uint32_t)kOctants) return;
+  if (i == lanes - 1) { // error lane: the largest code any workgroup of any pass reported
+    uint64_t e = 0;
+    for (uint32_t w = 0; w < f.passes * f.n_wg; ++w) e = lane_combine(OP_MAX_U64, e, f.partials[(uint64_t)w * slice + slice - 1]);
+    f.exchange[(uint64_t)o * lanes + i] = e;
+    return;
+  }
+  const uint32_t k = i / f.ng, g = i % f.ng, pass = g / f.ngs, gs = g % f.ngs;
+  const int op = (int)f.lane_ops[k];
+  const uint64_t *src = f.partials + (uint64_t)pass * f.n_wg * slice + (uint64_t)k * f.ngs + gs;
+  uint64_t v = lane_identity(op);
+  for (uint32_t w = 0; w < f.n_wg; ++w) v = lane_combine(op, v, src[(uint64_t)w * slice]);
+  f.exchange[(uint64_t)o * lanes + (uint64_t)g * f.k + k] = v; // → [group][lane]
+}
+
 template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {
-  if constexpr (P::ACC == 1) fused_scan_body_lds<P>(p);
+  if constexpr (P::ACC == 2) image_scan_body<P>(p);
+  else if constexpr (P::ACC == 1) fused_scan_body_lds<P>(p);
   else fused_scan_body_reg<P>(p);
 }
 

@@ -22,13 +22,16 @@ namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
 
-const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : k == JitKind::Reduce ? "reduce" : "emit"; }
+const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : k == JitKind::Reduce ? "reduce" : k == JitKind::Image ? "image" : "emit"; }
 
 std::string wrapper_source(JitKind kind, const std::string &ts) {
   std::string s = "\nusing namespace llkv;\n";
   switch (kind) {
   case JitKind::Scan:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { fused_scan_body<" + ts + ">(p); }\n";
+    break;
+  case JitKind::Image:
+    s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { image_scan_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Select:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { select_body<" + ts + ", false>(p); }\n";
@@ -175,18 +178,17 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   return LLKV_OK;
 }
 
-int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t /*bytes*/, hipStream_t stream) {
+int jit_launch_raw(hipFunction_t fn, uint32_t grid, void *params, size_t /*bytes*/, hipStream_t stream, uint32_t block) {
   if (grid == 0) return LLKV_OK;
   void *args[] = {params};
-  hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, kBlock, 1, 1, 0, stream, args, nullptr);
+  hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, stream, args, nullptr);
   if (e != hipSuccess) return set_error(LLKV_INTERNAL, std::string("hipModuleLaunchKernel: ") + hipGetErrorString(e));
   return LLKV_OK;
 }
 
 int jit_launch(const JitKernel &k, const ScanParams &p, hipStream_t stream) {
   ScanParams copy = p;
-  const uint32_t tpw = p.tiles_per_wg ? p.tiles_per_wg : 1u; // the host sets it for LDS-accumulator plans only
-  return jit_launch_raw(k.fn, (p.n_tiles + tpw - 1) / tpw, &copy, sizeof copy, stream);
+  return jit_launch_raw(k.fn, p.scan_grid ? p.scan_grid : p.n_tiles, &copy, sizeof copy, stream); // the host sets scan_grid for LDS-accumulator plans only
 }
 
 void jit_shutdown() {
@@ -205,6 +207,8 @@ extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out,
   else if (ts.rfind("ProbePlan<", 0) == 0) kind = 3;
   else if (ts.rfind("EmitPlan<", 0) == 0) kind = 4;
   else if (ts.rfind("ReducePlan<", 0) == 0) kind = 5;
+  else if (ts.rfind("Plan<", 0) == 0 && ((ts.size() > 3 && ts.compare(ts.size() - 3, 3, ",2>") == 0) ||
+                                         (ts.size() > 5 && ts.compare(ts.size() - 5, 3, ",2,") == 0))) kind = 6; // shared-image GROUP BY [, passes]
   const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
   std::vector<char> code;
   std::string err;

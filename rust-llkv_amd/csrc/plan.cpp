@@ -13,9 +13,13 @@ typedef __int128 i128;
 typedef unsigned __int128 u128;
 
 static constexpr int kMaxColsHost = 16;
-static constexpr int kMaxLitsHost = 16;
+static constexpr int kMaxLitsHost = 24; // = kMaxLits (scan_params.h)
 static constexpr int kMaxKeysHost = 4;
 static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
+// shared-image route: one image [lane][group] of 8-byte slots per workgroup; 150 KiB of the CU's 160 KiB of LDS
+static constexpr uint32_t kMaxImageGroups = 1u << 16;
+static constexpr size_t kMaxImageBytes = 150u * 1024;
+static constexpr int kMaxImagePasses = 4; // scans of the table a shared-image plan may take (the groups cut into slices)
 
 const char *dtype_name(int32_t dt) {
   switch (dt) {
@@ -154,6 +158,91 @@ struct Lowering {
   // arguments, where no accumulator looks at them (fused_scan.hip.h: f64_result_as_sse2; it costs Q1 5 %)
   bool exact_nan = false;
   std::string nan_flag(bool is_float) const { return exact_nan && is_float ? ",1" : ""; }
+  // shared-image plans: f64 sums as exact two-level pairs (SumF64X), which need a bound on |argument|
+  bool exact_f64 = false;
+  uint64_t table_rows = 0; // rows of the table the plan scans (the N of the exact sums)
+
+  // What the column statistics say about an aggregate argument: an interval [lo, hi] (integer min / max, largest
+  // finite |v| of float columns) and `nz`, a lower bound on |value| wherever the value is not zero (smallest non-zero
+  // finite |v| of float columns, 1 for integers; 0 = unknown).  Literals and + − × only: a division has no useful
+  // bound, and a sum of terms of either sign may cancel to anything (nz unknown unless the interval excludes zero).
+  bool expr_bounds(const llkv_expr_token *e, uint32_t n, double *absmax, double *nzmin) {
+    struct I { double lo, hi, nz; };
+    std::vector<I> st;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (e[i].kind == LLKV_TOK_COLUMN) {
+        const ColumnInfo *ci = resolve(e[i].field_id);
+        if (!ci) return false;
+        table_rows = std::max(table_rows, ci->rows);
+        if ((ci->dtype == LLKV_DT_FLOAT64 || ci->dtype == LLKV_DT_FLOAT32) && ci->has_fstats) st.push_back({-ci->f_absmax, ci->f_absmax, ci->f_absmin_nz});
+        else if (is_int_class(ci->dtype) && ci->has_stats) st.push_back({(double)ci->min_i, (double)ci->max_i, 1.0});
+        else return false;
+      } else if (e[i].kind == LLKV_TOK_LITERAL) {
+        const llkv_literal &lit = e[i].literal;
+        double v;
+        if (lit.tag == LLKV_LIT_FLOAT64) v = lit.f64;
+        else if (lit.tag == LLKV_LIT_INT128) v = (double)lit_i128(lit);
+        else return false;
+        if (!std::isfinite(v)) return false;
+        st.push_back({v, v, std::fabs(v)});
+      } else {
+        if (st.size() < 2) return false;
+        const I r = st.back(); st.pop_back();
+        const I l = st.back(); st.pop_back();
+        I o;
+        switch (e[i].binop) {
+        case LLKV_BIN_ADD: o = {l.lo + r.lo, l.hi + r.hi, 0.0}; break;
+        case LLKV_BIN_SUB: o = {l.lo - r.hi, l.hi - r.lo, 0.0}; break;
+        case LLKV_BIN_MUL: {
+          const double c[4] = {l.lo * r.lo, l.lo * r.hi, l.hi * r.lo, l.hi * r.hi};
+          o = {std::min(std::min(c[0], c[1]), std::min(c[2], c[3])), std::max(std::max(c[0], c[1]), std::max(c[2], c[3])), l.nz * r.nz * 0.999999};
+          break;
+        }
+        default: return false;
+        }
+        if (!std::isfinite(o.lo) || !std::isfinite(o.hi)) return false;
+        if (e[i].binop != LLKV_BIN_MUL) { // the rounded endpoints of a sum: move them outwards a little before trusting their sign
+          const double slack = 1e-12 * std::max(std::fabs(o.lo), std::fabs(o.hi));
+          if (o.lo - slack > 0.0) o.nz = o.lo - slack;
+          else if (o.hi + slack < 0.0) o.nz = -(o.hi + slack);
+        }
+        st.push_back(o);
+      }
+    }
+    if (st.size() != 1) return false;
+    *absmax = std::max(std::fabs(st[0].lo), std::fabs(st[0].hi));
+    *nzmin = st[0].nz;
+    return true;
+  }
+
+  // SumF64X constants (fused_scan.hip.h) for an argument with |v| ≤ absmax, |v| ≥ nzmin where v ≠ 0, over a table of
+  // `rows` rows: B = 2^b ≥ absmax, L = ⌈log2(rows + 1)⌉ ≥ 2, grids u1 = 2^(b+L−52), u(j+1) = u(j)·2^(L−53),
+  // C(j) = 1.5·2^52·u(j).  As many levels (2 or 3) as it takes for the last grid to resolve the smallest non-zero
+  // value to 2^-30 of itself: what a row drops is then ≤ 2^-31 of its own magnitude, so a group's sum is within
+  // 5e-10 of Σ|v| — inside the contract whatever the group holds.  0 levels: no such choice (the caller's route).
+  int exact_sum_constants(double absmax, double nzmin, uint64_t rows, double c[3]) {
+    if (!(absmax >= 0.0) || !std::isfinite(absmax)) return 0;
+    if (absmax == 0.0) { absmax = 1.0; nzmin = 1.0; } // the argument is always zero
+    if (!(nzmin > 0.0)) return 0;
+    absmax *= 1.0000001; // the kernel evaluates the argument in f64: every operation rounds, the interval endpoints did too
+    int ex;
+    const double m = std::frexp(absmax, &ex); // absmax = m·2^ex, m in [0.5, 1)
+    const int b = m == 0.5 ? ex - 1 : ex;
+    int L = 2;
+    while (L < 63 && ((uint64_t)1 << L) < rows + 1) ++L;
+    if (b < -900 || b + L > 1000 || L > 45) return 0;
+    int nz_ex;
+    (void)std::frexp(nzmin, &nz_ex); // nzmin ≥ 2^(nz_ex − 1)
+    for (int levels = 2; levels <= 3; ++levels) {
+      const int e_last = b + L - 52 + (levels - 1) * (L - 53); // log2 of the last grid
+      if (e_last < -1000) return 0;
+      if (e_last <= nz_ex - 1 - 30) {
+        for (int j = 0; j < levels; ++j) c[j] = std::ldexp(1.5, b + L + j * (L - 53));
+        return levels;
+      }
+    }
+    return 0;
+  }
 
   int fail(int code, const std::string &m) { return set_err(err, code, m); }
 
@@ -914,6 +1003,28 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       u128 m = mag(simple_ci->min_i) > mag(simple_ci->max_i) ? mag(simple_ci->min_i) : mag(simple_ci->max_i);
       fast_i64 = m * (u128)simple_ci->rows <= (u128)INT64_MAX;
     }
+    // shared-image plans: SumF64<node> → SumF64X<node, C1, C2> (exact, order-free); needs a bound on |argument|
+    bool no_bound = false;
+    auto sum_f64 = [&](const std::string &arg) -> std::pair<std::string, std::vector<uint8_t>> {
+      if (!L.exact_f64) return {"SumF64<" + arg + ">", {ADD_F64}};
+      double absmax, nzmin, c[3];
+      int levels = 0;
+      if (L.expr_bounds(s.expr, s.expr_len, &absmax, &nzmin)) levels = L.exact_sum_constants(absmax, nzmin, simple_ci ? simple_ci->rows : L.table_rows, c);
+      std::string node_x = "SumF64X<" + arg;
+      std::vector<uint8_t> lane_ops;
+      for (int j = 0; j < levels; ++j) {
+        std::string lit;
+        if (L.lit_f(c[j], &lit)) { levels = 0; break; }
+        node_x += "," + lit;
+        lane_ops.push_back(ADD_F64);
+      }
+      if (levels == 0) {
+        no_bound = true;
+        return {"SumF64<" + arg + ">", {ADD_F64}};
+      }
+      o.exact_levels = levels;
+      return {node_x + ">", lane_ops};
+    };
     // NULL argument rows contribute each lane's identity; one more lane counts the non-NULL rows
     auto add_agg = [&](const std::string &inner, std::vector<uint8_t> lane_ops) {
       if (valid.empty()) { o.lane = add_group(inner, lane_ops); return; }
@@ -942,16 +1053,18 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     }
     switch (s.kind) {
     case LLKV_AGG_SUM:
-      if (is_f64) { o.fin = AggFinal::SumF64; add_agg("SumF64<" + node + ">", {ADD_F64}); }
+      if (is_f64) { o.fin = AggFinal::SumF64; auto g = sum_f64(node); add_agg(g.first, g.second); }
       else if (fast_i64) { o.fin = AggFinal::SumI64Fast; add_agg("SumI64Fast<" + node + ">", {ADD_I64}); }
       else { o.fin = AggFinal::SumI64; add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
       break;
-    case LLKV_AGG_TOTAL:
+    case LLKV_AGG_TOTAL: {
       o.fin = AggFinal::TotalF64;
-      add_agg(is_f64 ? "SumF64<" + node + ">" : "SumF64<ToF64<" + node + ">>", {ADD_F64});
+      auto g = sum_f64(is_f64 ? node : "ToF64<" + node + ">");
+      add_agg(g.first, g.second);
       break;
+    }
     case LLKV_AGG_AVG:
-      if (is_f64) { o.fin = AggFinal::AvgF64; add_agg("SumF64<" + node + ">", {ADD_F64}); }
+      if (is_f64) { o.fin = AggFinal::AvgF64; auto g = sum_f64(node); add_agg(g.first, g.second); }
       else if (fast_i64) { o.fin = AggFinal::AvgI64Fast; add_agg("SumI64Fast<" + node + ">", {ADD_I64}); }
       else { o.fin = AggFinal::AvgI64; add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
       break;
@@ -965,6 +1078,7 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       break;
     default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
     }
+    if (no_bound) return L.fail(LLKV_UNSUPPORTED, "the column statistics do not bound an f64 sum argument from above and (where non-zero) from below: no exact, order-free sum for the shared-image GROUP BY");
     p.aggs.push_back(o);
   }
 
@@ -973,11 +1087,14 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
 
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
-               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err) {
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err, bool image) {
   *out = LoweredPlan{};
   LoweredPlan &p = *out;
   Lowering L{resolve, p, err, grouped};
   p.grouped = grouped;
+  if (image && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "the shared-image kernel serves GROUP BY plans");
+  L.exact_f64 = image;
+  const uint32_t max_groups = image ? kMaxImageGroups : kMaxDenseGroups;
   int rc;
   if (n_aggs == 0 && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate query requires at least one aggregate expression");
   if (grouped && n_keys == 0) return L.fail(LLKV_INVALID_ARGUMENT, "GROUP BY requires at least one key");
@@ -1008,9 +1125,10 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       if (int_key) {
         if (!probe->has_stats) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key without column statistics (hash path)");
         const unsigned __int128 range = (unsigned __int128)((__int128)probe->max_i - (__int128)probe->min_i) + 1;
-        if (range > 256) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key spans more than 256 values (hash path)");
+        if (range > (image ? max_groups : 256u)) return L.fail(LLKV_UNSUPPORTED, "integer GROUP BY key spans more than " + std::to_string(image ? max_groups : 256u) + " values (sort-based route)");
       }
       if ((rc = L.slot_of(key_fields[k], &ci, &slot))) return rc;
+      L.table_rows = std::max(L.table_rows, ci->rows);
       uint32_t card;
       std::string node;
       if (int_key) {
@@ -1034,8 +1152,8 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
       p.key_bases.push_back(int_key ? ci->min_i : 0);
       p.key_is_int.push_back(int_key ? 1 : 0);
       ng *= card;
+      if (ng > max_groups) return L.fail(LLKV_UNSUPPORTED, "more than " + std::to_string(max_groups) + " dense groups");
     }
-    if (ng > kMaxDenseGroups) return L.fail(LLKV_UNSUPPORTED, "more than 64 dense groups (" + std::to_string(ng) + ")");
     p.ng = (uint32_t)ng;
     p.key_strides.assign(n_keys, 1);
     for (int k = (int)n_keys - 2; k >= 0; --k) p.key_strides[k] = p.key_strides[k + 1] * p.key_cards[k + 1];
@@ -1064,11 +1182,19 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   p.lane_ops.push_back(MAX_U64);
   // accumulator placement: grouped plans keep their state in per-thread LDS slots (DS atomics
   // indexed by the row's group id); ungrouped plans keep it in registers
-  p.acc_lds = grouped && p.ng > 1;
+  p.acc_image = image;
+  p.acc_lds = grouped && p.ng > 1 && !image;
   p.track_first = grouped && track_first;
   if (p.acc_lds && (size_t)(p.lanes - 1) * 2048 > 160u * 1024) // one 2 KiB row per group-state lane (the error lane lives in registers)
     return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
-  p.unroll = (p.acc_lds || p.lanes <= 8) ? 4 : 2;
+  if (image) {
+    p.image_passes = (int)(((size_t)(p.lanes - 1) * 8 + kMaxImageBytes - 1) / kMaxImageBytes);
+    if (p.image_passes < 1) p.image_passes = 1;
+    if (p.image_passes > kMaxImagePasses)
+      return L.fail(LLKV_UNSUPPORTED, "the group image (" + std::to_string(p.ng) + " groups × " + std::to_string(p.k) + " lanes) needs more than " +
+                                           std::to_string(kMaxImagePasses) + " LDS-sized slices");
+  }
+  p.unroll = image ? 2 : (p.acc_lds || p.lanes <= 8) ? 4 : 2;
   if (const char *e = std::getenv("LLKV_HIP_UNROLL")) { // tuning knob (run-time specialised kernels only)
     const int u = std::atoi(e);
     if (u == 1 || u == 2 || u == 4 || u == 8) p.unroll = u;
@@ -1084,7 +1210,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   std::string ag = "Aggs<";
   for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
   ag += ">";
-  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_lds ? "1" : "0") + ">";
+  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_image ? "2" : p.acc_lds ? "1" : "0") + (p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
   return LLKV_OK;
 }
 

@@ -29,6 +29,9 @@ struct ColumnInfo {
   std::vector<std::string> dictionary;  // LLKV_DT_UTF8: code → string
   int32_t precision = 0, scale = 0;     // LLKV_DT_DECIMAL128 (device image: the raw values narrowed to i64)
   bool nullable = false;                // some cell is NULL (row id absent from the column): a 1 B/row validity mask is staged
+  bool has_fstats = false;              // Float64 / Float32 columns, over the finite values (staging statistics):
+  double f_absmax = 0.0;                //   largest |v|
+  double f_absmin_nz = 0.0;             //   smallest non-zero |v| (0: none / unknown)
 };
 
 using ColumnResolver = std::function<const ColumnInfo *(uint32_t field_id)>;
@@ -58,6 +61,7 @@ struct AggOut {
   bool fast_sum = false;        // decimal sums: one wrapping lane (statistics exclude i64 overflow) instead of the 96-bit split
   int32_t precision = 0, scale = 0; // Decimal128 results
   int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
+  int exact_levels = 0; // f64 sum kept as exact grid-level lanes (SumF64X, 2 or 3 of them): value = smallest level first, summed
 };
 
 struct LoweredPlan {
@@ -75,6 +79,8 @@ struct LoweredPlan {
   bool grouped = false;
   bool track_first = false; // lane [1] = first row id of the group (first-appearance order)
   bool acc_lds = false;     // accumulators in per-thread LDS slots (grouped plans)
+  bool acc_image = false;   // ONE accumulator image per workgroup in LDS, shared by its threads (hundreds … thousands of groups)
+  int image_passes = 1;     // … the groups cut into this many slices, one scan of the table each
   int k = 1;      // lanes per group
   int lanes = 2;  // ng * k + 1
   int unroll = 2;
@@ -92,10 +98,13 @@ struct LoweredPlan {
 // interpreter) instead of the computed-projection fast path; `track_first` keeps each
 // group's first row id (needed unless the output is ordered by the keys).  Returns an llkv_status;
 // on failure `err` holds the message.
+// `image`: lower for the shared-image GROUP BY kernel (image_scan_body) instead of the per-thread accumulator kernel:
+// up to kMaxImageGroups groups as long as the image fits the LDS, every lane order-free — f64 sums need a bound on
+// |argument| from the column statistics (else LLKV_UNSUPPORTED: the sort-based route takes the query).
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
                const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first,
-               LoweredPlan *out, std::string *err);
+               LoweredPlan *out, std::string *err, bool image = false);
 
 // Predicate only → "SelPlan<Cols<…>,pred>" (selection-vector kernels, select.hip.h).
 // `drop_null_fields`: GatherNullPolicy::DropNulls — rows whose listed fields are ALL NULL are not selected.

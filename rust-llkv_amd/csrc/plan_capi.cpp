@@ -29,6 +29,9 @@ llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols, const
     infos[i].nullable = cols[i].nullable != 0;
     infos[i].precision = cols[i].precision;
     infos[i].scale = cols[i].scale;
+    infos[i].has_fstats = cols[i].has_fstats != 0;
+    infos[i].f_absmax = cols[i].f_absmax;
+    infos[i].f_absmin_nz = cols[i].f_absmin_nz;
     for (uint32_t d = 0; d < cols[i].dict_size; ++d)
       infos[i].dictionary.push_back(cols[i].dictionary && cols[i].dictionary[d] ? cols[i].dictionary[d] : "");
   }
@@ -38,7 +41,7 @@ llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols, const
   };
   llkv::LoweredPlan plan;
   g_plan_err.clear();
-  int rc = llkv::lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, (grouped & 1) != 0, (grouped & 2) == 0, &plan, &g_plan_err);
+  int rc = llkv::lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, (grouped & 1) != 0, (grouped & 2) == 0, &plan, &g_plan_err, (grouped & 4) != 0);
   if (rc) return (llkv_status)rc;
   if (type_string_out && type_string_cap) {
     if (plan.type_string.size() + 1 > type_string_cap) { g_plan_err = "type string buffer too small"; return LLKV_INVALID_ARGUMENT; }

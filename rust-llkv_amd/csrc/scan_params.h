@@ -24,7 +24,7 @@ constexpr int kBlock = 256;
 constexpr int kRowsPerThread = 2;
 constexpr int kStepRows = kBlock * kRowsPerThread; // 512 rows per block step
 constexpr int kMaxCols = 16; // value slots + validity-mask slots of one plan
-constexpr int kMaxLits = 16;
+constexpr int kMaxLits = 24;
 constexpr int kMaxKeys = 4;
 constexpr int kOctants = 8; // canonical partition of the chunk list
 
@@ -61,11 +61,11 @@ struct ScanParams {
   uint32_t key_stride[kMaxKeys];
   uint32_t n_tiles;
   uint32_t sub_rows;          // selection kernels: rows per wave sub-tile (tile_rows / 4)
-  // fused scan: a workgroup owns `tiles_per_wg` consecutive tiles (0 = 1) and publishes one partial per TILE, so the
-  // reduction association is a property of the canonical tile list, never of the launch geometry: a rank with few
-  // tiles launches one workgroup per tile (an SF10 shard of 1/8 still fills 256 CUs), a rank with many lets a
-  // workgroup stream several tiles back to back
-  uint32_t tiles_per_wg;
+  // fused scan, LDS-accumulator plans: launched with `scan_grid` workgroups (0 = one per tile); workgroup b streams
+  // the consecutive tiles [b·n/g, (b+1)·n/g) and publishes one partial per (tile, wave), so the reduction association
+  // is a property of the canonical tile list, never of the launch geometry
+  uint32_t scan_grid;
+  uint32_t group_base;        // shared-image plans cut into passes: first group of this launch's slice
   const uint64_t *aux_in;     // selection: exclusive offsets per (tile, wave)
   uint64_t *aux_out;          // selection: logical row ids out
   uint64_t *aux_out2;         // selection: device row indices out

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstring>
 #include <map>
@@ -151,13 +152,52 @@ template <class Fn> static int for_each_chunk_parallel(uint32_t n_chunks, Fn &&f
   return LLKV_OK;
 }
 
+// see fill_padding_kernel (catalog.hip)
+static int fill_chunk_padding(Table &t, void *d_values, uint32_t width) {
+  std::vector<uint64_t> pad;
+  for (uint32_t i = 0; i < t.n_local_chunks; ++i) {
+    const uint64_t rows = t.global_chunk_rows[t.first_chunk + i], end = t.chunk_dev_off[i] + rows;
+    if (rows && end < t.chunk_dev_off[i + 1]) { pad.push_back(end); pad.push_back(t.chunk_dev_off[i + 1] - end); pad.push_back(end - 1); }
+  }
+  if (pad.empty()) return LLKV_OK;
+  Scratch d;
+  int rc = d.alloc(pad.size() * 8);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(d.p, pad.data(), pad.size() * 8, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(launch_fill_padding(d_values, width, d.as<uint64_t>(), (uint32_t)(pad.size() / 3), g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream)); // `pad` is pageable and dies here
+  return LLKV_OK;
+}
+
 static int column_stats_device(Table &t, DeviceColumn &c) {
+  if (t.dev_rows != t.local_rows && c.d_values) {
+    const int rc = fill_chunk_padding(t, c.d_values, dtype_width(c.info.dtype));
+    if (rc) return rc;
+  }
+  if ((c.info.dtype == LLKV_DT_FLOAT64 || c.info.dtype == LLKV_DT_FLOAT32) && t.dev_rows) {
+    // largest and smallest non-zero finite |v|: they bound aggregate arguments from above and below, which lets the
+    // shared-image GROUP BY keep f64 sums exact (padding rows between ragged chunks hold copies of real values)
+    uint64_t *d = nullptr, bits[2] = {0, 0x7FF0000000000000ull};
+    HIP_TRY(hipMalloc((void **)&d, 16));
+    HIP_TRY(hipMemcpyAsync(d, bits, 16, hipMemcpyHostToDevice, g_ctx.stream));
+    if (c.info.dtype == LLKV_DT_FLOAT64) HIP_TRY(launch_absrange_f64((const double *)c.d_values, t.dev_rows, d, g_ctx.stream));
+    else HIP_TRY(launch_absrange_f32((const float *)c.d_values, t.dev_rows, d, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(bits, d, 16, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    (void)hipFree(d);
+    c.has_local_fstats = true;
+    std::memcpy(&c.local_f_absmax, &bits[0], 8);
+    std::memcpy(&c.local_f_absmin_nz, &bits[1], 8);
+    if (!std::isfinite(c.local_f_absmin_nz)) c.local_f_absmin_nz = 0.0; // no non-zero value
+    if (t.world == 1) { c.info.has_fstats = true; c.info.f_absmax = c.local_f_absmax; c.info.f_absmin_nz = c.local_f_absmin_nz; }
+    return LLKV_OK;
+  }
   if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
   if (t.dev_rows == 0) return LLKV_OK;
   int64_t init[2] = {INT64_MAX, INT64_MIN}, *d = nullptr;
   HIP_TRY(hipMalloc((void **)&d, sizeof init));
   HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, g_ctx.stream));
-  // padding rows between ragged chunks are zero: they can only widen the range (safe side)
+  // (padding rows between ragged chunks hold a copy of a real value: fill_chunk_padding)
   if (c.info.dtype == LLKV_DT_INT64 || c.info.dtype == LLKV_DT_DECIMAL128) HIP_TRY(launch_minmax_i64((const int64_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
   else HIP_TRY(launch_minmax_i32((const int32_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
   int64_t mm[2];
@@ -363,15 +403,39 @@ llkv_status llkv_hip_table_set_column_stats(llkv_hip_table *table, uint32_t fiel
   DeviceColumn &c = it->second;
   if (min_value > max_value) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "min exceeds max");
   // a bound that does not cover this rank's rows would make "provably no overflow" and dense group ids wrong
-  // (the local reduction also sees the zeroed padding rows between ragged chunks, so a local bound of 0 on a
-  // padded image proves nothing)
-  const bool padded = t->dev_rows != t->local_rows;
-  const bool lo_ok = min_value <= c.local_min || (padded && c.local_min == 0), hi_ok = max_value >= c.local_max || (padded && c.local_max == 0);
-  if (c.has_local_stats && t->local_rows && !(lo_ok && hi_ok))
+  if (c.has_local_stats && t->local_rows && !(min_value <= c.local_min && max_value >= c.local_max))
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "column statistics do not cover the staged values");
   c.info.has_stats = true;
   c.info.min_i = min_value;
   c.info.max_i = max_value;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_local_column_float_stats(const llkv_hip_table *table, uint32_t field_id, int32_t *has_stats, double *abs_max, double *abs_min_nonzero) {
+  const Table *t = reinterpret_cast<const Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  if (has_stats) *has_stats = it->second.has_local_fstats ? 1 : 0;
+  if (abs_max) *abs_max = it->second.local_f_absmax;
+  if (abs_min_nonzero) *abs_min_nonzero = it->second.local_f_absmin_nz;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_set_column_float_stats(llkv_hip_table *table, uint32_t field_id, double abs_max, double abs_min_nonzero) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  DeviceColumn &c = it->second;
+  if (!(abs_max >= 0.0) || !(abs_min_nonzero >= 0.0) || !std::isfinite(abs_max) || abs_min_nonzero > abs_max)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "float statistics must satisfy 0 ≤ smallest non-zero |v| ≤ largest |v| < ∞");
+  // bounds that do not cover this rank's rows would break the exactness of the sums built on them
+  if (c.has_local_fstats && t->local_rows && (abs_max < c.local_f_absmax || (c.local_f_absmin_nz > 0.0 && !(abs_min_nonzero > 0.0 && abs_min_nonzero <= c.local_f_absmin_nz))))
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "column statistics do not cover the staged values");
+  c.info.has_fstats = true;
+  c.info.f_absmax = abs_max;
+  c.info.f_absmin_nz = abs_min_nonzero;
   return LLKV_OK;
 }
 
@@ -469,10 +533,11 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
   if (t->world == 1) return LLKV_OK;
   if (!comm_ready() || comm_world() != t->world || comm_rank() != t->rank)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the table's (rank, world) is not the communicator's");
-  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; };
+  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; int32_t has_fstats, pad; double f_absmax, f_absmin_nz; };
   std::vector<Rec> mine;
   for (auto &kv : t->cols) // std::map: ascending field ids on every rank
-    mine.push_back({kv.first, kv.second.has_local_stats ? 1 : 0, kv.second.local_min, kv.second.local_max, kv.second.info.nullable ? 1 : 0, t->local_rows ? 1u : 0u});
+    mine.push_back({kv.first, kv.second.has_local_stats ? 1 : 0, kv.second.local_min, kv.second.local_max, kv.second.info.nullable ? 1 : 0, t->local_rows ? 1u : 0u,
+                    kv.second.has_local_fstats ? 1 : 0, 0, kv.second.local_f_absmax, kv.second.local_f_absmin_nz});
   std::vector<uint8_t> all;
   std::vector<uint64_t> off;
   int rc = comm_allgather_v(mine.data(), mine.size() * sizeof(Rec), &all, &off);
@@ -486,16 +551,26 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
   size_t i = 0;
   for (auto &kv : t->cols) {
     DeviceColumn &c = kv.second;
-    bool all_stats = true, any_rows = false, any_nullable = false;
+    bool all_stats = true, all_fstats = true, any_rows = false, any_nullable = false;
     int64_t lo = INT64_MAX, hi = INT64_MIN;
+    double fmax = 0.0, fmin_nz = 0.0;
     for (uint32_t r = 0; r < t->world; ++r) {
       const Rec &x = reinterpret_cast<const Rec *>(all.data() + off[r])[i];
       any_nullable |= x.nullable != 0;
       if (!x.local_rows_nonzero) continue; // a rank without rows constrains nothing
       any_rows = true;
+      if (x.has_fstats) {
+        fmax = std::max(fmax, x.f_absmax);
+        if (x.f_absmin_nz > 0.0) fmin_nz = fmin_nz > 0.0 ? std::min(fmin_nz, x.f_absmin_nz) : x.f_absmin_nz;
+      } else all_fstats = false;
       if (!x.has_stats) { all_stats = false; continue; }
       lo = std::min(lo, x.lo);
       hi = std::max(hi, x.hi);
+    }
+    if (all_fstats && any_rows) {
+      c.info.has_fstats = true;
+      c.info.f_absmax = fmax;
+      c.info.f_absmin_nz = fmin_nz;
     }
     if (all_stats && any_rows && lo <= hi) {
       c.info.has_stats = true;

@@ -304,6 +304,16 @@ class HipTable:
         """Installs the table-wide (min, max) of an integer column (sharded tables; see dist.share_column_stats)."""
         check(lib().llkv_hip_table_set_column_stats(self._h, C.c_uint32(field_id), C.c_int64(lo), C.c_int64(hi)))
 
+    def local_column_float_stats(self, field_id: int):
+        """(largest |v|, smallest non-zero |v|) over the finite values of this rank's rows of a float column, or None."""
+        has, hi, lo = C.c_int32(), C.c_double(), C.c_double()
+        check(lib().llkv_hip_table_local_column_float_stats(self._h, C.c_uint32(field_id), C.byref(has), C.byref(hi), C.byref(lo)))
+        return (hi.value, lo.value) if has.value else None
+
+    def set_column_float_stats(self, field_id: int, abs_max: float, abs_min_nonzero: float):
+        """Installs the table-wide float statistics of a sharded table's column (what share_metadata agrees on)."""
+        check(lib().llkv_hip_table_set_column_float_stats(self._h, C.c_uint32(field_id), C.c_double(abs_max), C.c_double(abs_min_nonzero)))
+
     def share_metadata(self):
         """Sharded tables, before any query is prepared: all ranks agree on integer statistics and on which columns
         have NULL cells (llkv_hip_table_share_metadata over the communicator)."""
@@ -426,6 +436,12 @@ class PreparedQuery:
     @property
     def kernel_signature(self) -> str:
         return lib().llkv_hip_query_kernel_signature(self._h).decode()
+
+    @property
+    def route_note(self) -> str:
+        f = lib().llkv_hip_query_route_note
+        f.restype = C.c_char_p
+        return f(self._h).decode()
 
     @property
     def algorithmic_bytes(self) -> int:

@@ -114,6 +114,8 @@ def build_expr(abi, e):
         return abi.ScalarExpr.column(e["col"])
     if "lit" in e:
         return abi.ScalarExpr.literal(e["lit"])
+    if "lit_date32" in e:
+        return abi.ScalarExpr.literal(abi.Literal.date32(e["lit_date32"]))
     for name, op in (("add", abi.BIN_ADD), ("sub", abi.BIN_SUB), ("mul", abi.BIN_MUL), ("div", abi.BIN_DIV), ("mod", abi.BIN_MOD)):
         if name in e:
             return abi.ScalarExpr.binary(build_expr(abi, e[name][0]), op, build_expr(abi, e[name][1]))

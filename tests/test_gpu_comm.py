@@ -123,6 +123,8 @@ def _queries(abi):
         "dense": dict(predicate=[abi.Filter(1, abi.Operator.GreaterThan(10))], aggs=[A.count_star(), A.sum(3), A.sum(col(4) * 2.0), A.min(3), A.count(3)], keys=[5], order=True),
         # sort-based GROUP BY: ~12 000 groups straddling the shards
         "sorted": dict(predicate=[abi.Filter(1, abi.Operator.GreaterThan(10))], aggs=[A.count_star(), A.sum(1), A.sum(col(4) * 2.0), A.max(4)], keys=[1, 2], order=False),
+        # the same GROUP BY through the shared-image kernel (statistics bound the keys): exact, order-free lanes
+        "image": dict(predicate=[abi.Filter(1, abi.Operator.GreaterThan(10))], aggs=[A.count_star(), A.sum(1), A.sum(col(4) * 2.0)], keys=[1, 2], order=True),
         "distinct": dict(predicate=[abi.Filter(1, abi.Operator.GreaterThan(10))], aggs=[D(A.count(1)), D(A.sum(1)), D(A.sum(4)), A.count_star()], keys=[], order=False),
     }
 
@@ -166,7 +168,10 @@ def _worker(rank, world, port, out_path):
     res = {}
     t = _tables(rt, abi, rank, world)
     for name, q in _queries(abi).items():
+        if name == "sorted":
+            os.environ["LLKV_HIP_GROUP_NO_IMAGE"] = "1"  # the statistics would admit the shared-image kernel: this case is the sort route's exchange
         pq = rt.PreparedQuery(t, q["predicate"], q["aggs"], q["keys"], q["order"])
+        os.environ.pop("LLKV_HIP_GROUP_NO_IMAGE", None)
         pq.launch(0)
         res[name] = _flat(pq.finish_sharded())
         if name == "dense":  # the pipelined form: launch ×2, then all_reduce / submit / collect each
@@ -194,7 +199,13 @@ def test_two_processes_run_the_sharded_drivers_over_a_host_transport(rt, abi, tp
     assert got[0] == got[1]  # every rank ends with the table-wide answer
     whole = _tables(rt, abi, 0, 1)
     for name, q in _queries(abi).items():
-        want = _flat(rt.PreparedQuery(whole, q["predicate"], q["aggs"], q["keys"], q["order"]).run())
+        if name == "sorted":
+            os.environ["LLKV_HIP_GROUP_NO_IMAGE"] = "1"
+        pw = rt.PreparedQuery(whole, q["predicate"], q["aggs"], q["keys"], q["order"])
+        os.environ.pop("LLKV_HIP_GROUP_NO_IMAGE", None)
+        if name == "image":
+            assert ",2>" in pw.kernel_signature or ",2," in pw.kernel_signature, pw.route_note
+        want = _flat(pw.run())
         g = got[0][name]
         assert [k for k, _ in g] == [k for k, _ in want], name  # same groups, same order
         for (_, gv), (_, wv) in zip(g, want):

@@ -87,10 +87,22 @@ def test_reference_aggregate_known_answers(rt, abi, case):
         dt = DTYPES[c["dtype"]]
         if dt == abi.DT_DECIMAL128:
             ht.append_decimal128_column(c["field_id"], c["precision"], c["scale"], c["values"])
+        elif dt == abi.DT_UTF8:
+            ht.append_utf8_column(c["field_id"], c["values"])
         else:
             ht.append_column(c["field_id"], dt, np.array([fval(v) for v in c["values"]], dtype=abi.NUMPY_OF_DTYPE[dt]))
     pred = [build_filter(abi, case["filter"])] if "filter" in case else None
     aggs = build_aggs(abi, case["aggs"])
+    if "group_by" in case:
+        # literal ⊕ literal sub-expressions are folded by the reference before execution (llkv-compute/src/eval.rs:
+        # 761-791); the GPU path hands such plans back (DESIGN.md "out of scope") — or must agree
+        try:
+            rows = rt.groupby(ht, pred, case["group_by"], aggs)
+        except abi.LlkvError as e:
+            assert e.kind == "Unsupported", e
+            return
+        assert len(rows) == 1 and all(same_value(g.value, w) for g, w in zip(rows[0].values, case["expect"]))
+        return
     if "expect_error" in case:
         with pytest.raises(abi.LlkvError) as e:
             rt.aggregate(ht, pred, aggs)
@@ -242,17 +254,17 @@ def test_results_are_bit_reproducible_and_gpu_count_invariant(rt, abi, tpch):
     assert np.array_equal(ex1, pq.read_exchange())
     flat = lambda rows: [(tuple(k.value for k in r.keys), tuple(np.float64(v.value).tobytes() if isinstance(v.value, float) else v.value for v in r.values)) for r in rows]
     assert flat(r1) == flat(r1b)
-    # the reduction association belongs to the canonical tile list, not to the launch geometry: a workgroup may
-    # stream 1 … 8 tiles (engine.cpp: pick_tiles_per_wg follows the LOCAL tile count) and the bits do not move
-    for tpw in ("1", "2", "3", "8"):
-        os.environ["LLKV_HIP_TILES_PER_WG"] = tpw
+    # the reduction association belongs to the canonical tile list, not to the launch geometry: g workgroups stream
+    # the tiles [b·n/g, (b+1)·n/g) (engine.cpp: pick_scan_grid follows the LOCAL tile count) and the bits do not move
+    for wgs in ("1", "7", "33", "62", "100000"):
+        os.environ["LLKV_HIP_SCAN_WGS"] = wgs
         try:
             pg = rt.PreparedQuery(one, q.predicate, q.aggs, q.keys, True)
-            assert flat(pg.run()) == flat(r1), tpw
-            assert np.array_equal(pg.read_exchange(), ex1), tpw
+            assert flat(pg.run()) == flat(r1), wgs
+            assert np.array_equal(pg.read_exchange(), ex1), wgs
             pg.close()
         finally:
-            del os.environ["LLKV_HIP_TILES_PER_WG"]
+            del os.environ["LLKV_HIP_SCAN_WGS"]
     for world in (2, 4, 8):
         total = np.zeros_like(ex1).view(np.int64)
         last = None
@@ -410,17 +422,23 @@ def test_full_size_sort_based_group_by_sf10(rt, abi, tpch, key):
 TABLE = golden("table_scan.json")
 
 
-@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] == "base"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] != "with_nulls"], ids=lambda c: c["name"])
 def test_reference_table_scan_known_answers(rt, abi, case):
-    """The reference's filtered-scan / And / Or / Not / computed-projection tests (tests/golden/table_scan.json)
-    through llkv_hip_scan_stream.  (The include-nulls cases need NULL cells, which are not staged on the GPU.)"""
+    """The reference's filtered-scan / And / Or / Not / IN / projection / computed-projection tests
+    (tests/golden/table_scan.json: llkv-table/src/table.rs:1697-2906, llkv-executor/src/lib.rs:13880-13925) through
+    llkv_hip_scan_stream.  (The include-nulls cases run in test_reference_include_nulls_known_answers.)"""
     from conftest import build_predicate, build_expr
-    tdef = TABLE["tables"]["base"]
+    tdef = TABLE["tables"][case["table"]]
     ht = rt.HipTable(1, [tdef["rows"]])
     for c in tdef["columns"]:
         dt = DTYPES[c["dtype"]]
         ht.append_column(c["field_id"], dt, np.array(c["values"], dtype=abi.NUMPY_OF_DTYPE[dt]))
     projections = [p if isinstance(p, int) else build_expr(abi, p) for p in case["project"]]
+    if "expect_error" in case:
+        with pytest.raises(abi.LlkvError) as e:
+            rt.scan_stream(ht, projections, build_predicate(abi, case["predicate"]))
+        assert e.value.kind == case["expect_error"]
+        return
     batches = rt.scan_stream(ht, projections, build_predicate(abi, case["predicate"]))
     cols = [[] for _ in projections]
     for bcols, _ in batches:
@@ -428,6 +446,12 @@ def test_reference_table_scan_known_answers(rt, abi, case):
         for i, c in enumerate(bcols):
             cols[i].extend(c)
     assert cols == case["expect"]
+    if "expect_sum" in case:
+        assert sum(cols[0]) == case["expect_sum"]
+    if "expect_min" in case:
+        assert min(cols[0]) == case["expect_min"] and max(cols[0]) == case["expect_max"]
+    if "expect_sqrt" in case:
+        assert [float(np.sqrt(np.float64(v))) for v in cols[0]] == case["expect_sqrt"]
 
 
 @pytest.mark.parametrize("chunks", [[7], [15, 16, 17], [8192, 100, 8192, 7], [131072, 131072, 50000]])
@@ -677,11 +701,15 @@ def test_decimal128_accumulators_match_oracle(rt, orc, abi, chunks):
     assert e.value.kind == "Unsupported"
 
 
+@pytest.mark.parametrize("route", ["auto", "sort"])
 @pytest.mark.parametrize("chunks", [[13], [4096, 4097, 5], [65536, 70000, 65536]])
-def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks):
-    """GROUP BY shapes the dense LDS kernel cannot hold — thousands of groups, sparse or unbounded integer keys,
-    several keys, wide aggregate states — go through the sort-based route: same groups, same first-appearance /
-    key order, exact integer results, f64 sums within 1e-9."""
+def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeypatch):
+    """GROUP BY shapes the per-thread accumulator kernel cannot hold — thousands of groups, sparse or unbounded integer
+    keys, several keys, wide aggregate states: same groups, same first-appearance / key order, exact integer results,
+    f64 sums within 1e-9.  `auto`: the shapes with statistics-bounded keys take the shared-image kernel, the others
+    the sort-based route; `sort`: all of them take the sort-based route."""
+    if route == "sort":
+        monkeypatch.setenv("LLKV_HIP_GROUP_NO_IMAGE", "1")
     rng = np.random.default_rng(3 + len(chunks))
     n = sum(chunks)
     k_sparse = (rng.integers(0, 3000, size=n) * 1_000_003 - 10**9).astype(np.int64)   # ≤ 3000 groups, huge range
@@ -1700,10 +1728,11 @@ def test_c_program_runs_q6_through_the_abi(tmp_path):
 
 
 @pytest.mark.parametrize("order_by_keys", [True, False])
-def test_sort_based_group_by_over_a_sharded_table(rt, abi, order_by_keys):
+def test_sort_based_group_by_over_a_sharded_table(rt, abi, order_by_keys, monkeypatch):
     """SURVEY §8e for GROUP BY of any cardinality: every rank reduces its own chunks, the partial groups are merged
     in rank order (llkv_hip_query_partial_groups / merge_groups; 2 / 4 / 8 ranks emulated on one device).  Keys,
     order, counts, integer sums, MIN / MAX and NULL keys equal the single-GPU answer exactly, f64 sums within 1e-9."""
+    monkeypatch.setenv("LLKV_HIP_GROUP_NO_IMAGE", "1")  # the partial-groups exchange belongs to the sort-based route
     rng = np.random.default_rng(37)
     chunks = [6000, 9000, 300, 20_000, 4096, 17_000, 123, 8000]
     n = sum(chunks)
@@ -1945,6 +1974,40 @@ def test_q1_qualifies_against_an_oracle_answer_set(rt, orc, abi, tpch):
     assert elapsed > 0
 
 
+def test_q1_q6_q3_under_the_qualification_rule_on_real_shaped_data(rt, orc, abi, tpch):
+    """§8f-3 with the default substitution parameters (qualify.render_query) on the synthetic TPC-H-shaped data — prices in
+    cents, discounts in hundredths: nothing is dyadic, every f64 sum rounds.  What must hold at any size: strings and
+    integers exact, every number within the 1e-9 RELATIVE of the contract.  What the reference's harness asks
+    (llkv-tpch/src/qualification.rs:708-745) is stricter and size dependent — `avg` columns within an ABSOLUTE 1e-9,
+    `sum` columns equal as decimals after Decimal::from_f64 (15 significant digits): at SF0.01 the avg columns pass;
+    whether a sum column passes depends on the last bits of two different summation orders (tools/qualify_report.py
+    records it at SF1 / SF10; DESIGN.md "Qualification")."""
+    qual = __import__("importlib").import_module("rust-llkv_amd.qualify")
+    rows, scale = tpch.LINEITEM_ROWS["sf0.01"], 0.01
+    d = tpch.gen_lineitem(rows, scale)
+    ht, ot = stage_both(rt, orc, abi, [(fid, dt, d[name]) for name, (fid, dt) in tpch.LINEITEM_SCHEMA.items()], tpch.chunk_rows(rows, 8192))
+    q1 = qual.render_query(tpch, abi, 1)
+    cells = lambda rws: [[k.value for k in r.keys] + [v.value for v in r.values] for r in rws]
+    want1, got1 = cells(orc.groupby(ot, q1.predicate, q1.keys, q1.aggs, True)), cells(rt.groupby(ht, q1.predicate, q1.keys, q1.aggs, True))
+    rep = qual.compare_report(want1, got1, qual.Q1_TOKENS)
+    assert rep["rows"] == 4
+    for c in rep["columns"]:
+        assert c["max_rel_diff"] <= REL, c
+        if c["kind"] in ("string", "integer", "float"):
+            assert c["passes_reference_rule"], c  # flags, count_order; avg_qty / avg_price / avg_disc within 1e-9 absolute
+    assert rep["columns"][2]["passes_reference_rule"]  # sum_qty: an exact Int64 sum, whatever the order
+    # the harness end to end: the answer set as text, the order-insensitive diff over the columns that must agree
+    tokens = ["str", "str", "sum", "avg", "avg", "avg", "cnt"]
+    pick = lambda r: [r[0], r[1], r[2], r[6], r[7], r[8], r[9]]
+    text = qual.format_answer_set(["l_returnflag", "l_linestatus", "sum_qty", "avg_qty", "avg_price", "avg_disc", "count_order"],
+                                  [pick(r) for r in reversed(want1)], [qual.kind_from_token(t) for t in tokens])
+    diff, elapsed = qual.qualify(lambda: [pick(r) for r in got1], text, tokens)
+    assert diff.ok and elapsed >= 0
+    q6 = qual.render_query(tpch, abi, 6)
+    rep6 = qual.compare_report([[orc.aggregate(ot, q6.predicate, q6.aggs)[0].value]], [[rt.aggregate(ht, q6.predicate, q6.aggs)[0].value]], qual.Q6_TOKENS)
+    assert rep6["columns"][0]["max_rel_diff"] <= REL
+
+
 def test_integer_and_multi_key_group_by(rt, orc, abi, tpch):
     """GroupKeyValue::Int keys (every integer width and Date32 collapse to Int, llkv-executor/src/lib.rs:9362-9456)
     through dense ids from the staging statistics; up to 64 dense groups in the LDS accumulator image."""
@@ -1972,3 +2035,116 @@ def test_integer_and_multi_key_group_by(rt, orc, abi, tpch):
             assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (keys, ordered)
             for g, w in zip(got, want):
                 assert_values(g.values, w.values, str(keys))
+
+
+@pytest.mark.parametrize("case", golden("string_scans.json")["cases"], ids=lambda c: c["name"])
+def test_reference_string_scan_known_answers(rt, abi, case):
+    """llkv-table/tests/fusion_tests.rs:110-318 and table.rs:1725-1771 through llkv_hip_scan_stream: string predicates
+    (and their same-field AND) run on dictionary codes.  A column with more than 256 distinct strings is not staged."""
+    from conftest import build_string_operator
+    from test_oracle_golden import _string_scan_values
+    values = _string_scan_values(case)
+    ht = rt.HipTable(1, [len(values)])
+    if len(set(values)) > 256:
+        with pytest.raises(abi.LlkvError) as e:
+            ht.append_utf8_column(1, values)
+        assert e.value.kind == "Unsupported"
+        return
+    ht.append_utf8_column(1, values)
+    filters = [abi.Filter(1, build_string_operator(abi, op)) for op in case["ops"]]
+    got = [v for cols, _ in rt.scan_stream(ht, [1], filters) for v in cols[0]]
+    if "expect_in_order" in case:
+        assert got == case["expect_in_order"]
+    if "expect_sorted" in case:
+        assert sorted(got) == case["expect_sorted"]
+
+
+def _staged(rt, abi, columns):
+    n = len(columns[0]["values"])
+    ht = rt.HipTable(1, [n])
+    for c in columns:
+        dt = DTYPES[c["dtype"]]
+        if dt == abi.DT_UTF8:
+            ht.append_utf8_column(c["field_id"], c["values"])
+        else:
+            ht.append_column(c["field_id"], dt, np.array(c["values"], dtype=abi.NUMPY_OF_DTYPE[dt]))
+    return ht
+
+
+def test_reference_join_with_expression_filters(rt, abi):
+    """llkv-join/tests/join_tests.rs:299-561 through llkv_hip_scan_stream (Expr::Compare filters) and
+    llkv_hip_join_stream (inner join on Int32 keys): the filtered id sets, 8 joined rows, and their split over the
+    two filters are the reference's assertions."""
+    from conftest import build_predicate
+    c = golden("join_filters.json")["expression_filters"]
+    left, right = _staged(rt, abi, c["left"]["columns"]), _staged(rt, abi, c["right"]["columns"])
+    lids = [v for cols, _ in rt.scan_stream(left, [c["left_filter_project"]], build_predicate(abi, c["left_filter"])) for v in cols[0]]
+    rids = [v for cols, _ in rt.scan_stream(right, [c["right_filter_project"]], build_predicate(abi, c["right_filter"])) for v in cols[0]]
+    assert sorted(set(lids)) == c["expect_left_ids"]
+    assert len(set(rids)) == c["expect_right_id_count"] and set(c["expect_right_ids_include"]) <= set(rids)
+    pairs = [(l, r) for b in rt.join_stream(left, right, [tuple(k) for k in c["join_keys"]], abi.JOIN_INNER) for l, r in zip(b[0], b[1])]
+    assert len(pairs) == c["expect_join_rows"]
+    lk, rk = c["left"]["columns"][0]["values"], c["right"]["columns"][1]["values"]
+    counts, both = {"both": 0, "left": 0, "right": 0, "neither": 0}, set()
+    for l, r in pairs:
+        assert lk[l] == rk[r]
+        lp, rp = lk[l] in set(lids), rk[r] in set(rids)
+        counts["both" if lp and rp else "left" if lp else "right" if rp else "neither"] += 1
+        if lp and rp:
+            both.add(lk[l])
+    assert (counts["both"], counts["left"], counts["right"], counts["neither"]) == (c["expect_both"], c["expect_left_only"], c["expect_right_only"], c["expect_neither"])
+    assert sorted(both) == c["expect_both_customers"]
+
+
+@pytest.mark.parametrize("case", golden("join_filters.json")["cartesian"], ids=lambda c: c["name"])
+def test_reference_cartesian_known_answers(rt, abi, case):
+    """join_tests.rs:711-806 and llkv-executor/src/lib.rs:14065-14150 through llkv_hip_join_stream without keys."""
+    if "tables" in case:
+        cols = [[v] for v in case["tables"][0]]
+        for nxt in case["tables"][1:]:
+            lt = rt.HipTable(1, [len(cols)]); lt.append_column(1, abi.DT_INT64, np.arange(len(cols)))
+            rt_ = rt.HipTable(2, [len(nxt)]); rt_.append_column(1, abi.DT_INT64, np.array(nxt, dtype=np.int64))
+            pairs = [(l, r) for b in rt.join_stream(lt, rt_, [], abi.JOIN_INNER) for l, r in zip(b[0], b[1])]
+            cols = [cols[l] + [nxt[r]] for l, r in pairs]
+        assert len(cols) == case["expect_rows"]
+        assert [[row[i] for row in cols] for i in range(len(case["tables"]))] == case["expect_columns"]
+        return
+    left, right = _join_side(rt, abi, case["left"]), _join_side(rt, abi, case["right"])
+    pairs = [(l, r) for b in rt.join_stream(left, right, [], abi.JOIN_INNER) for l, r in zip(b[0], b[1])]
+    assert len(pairs) == case["expect_rows"]
+    if "expect_combinations" in case:
+        got = {(case["left"][l][0], case["left"][l][1], case["right"][r][0], case["right"][r][1]) for l, r in pairs}
+        assert got == {tuple(x) for x in case["expect_combinations"]}
+
+
+@pytest.mark.parametrize("dt", ["Int64", "Int32", "UInt32", "UInt64"])
+def test_sorted_range_scans_of_shuffled_integers(rt, abi, dt):
+    """The property llkv-column-map/tests/integer_scan_tests.rs:226-… asserts for every integer type — a sorted scan of
+    200 000 shuffled values, with and without a range, yields exactly the sorted (filtered) values with their row
+    ids — through llkv_hip_scan_stream with ScanStreamOptions.order (the reference's test draws random data; so does
+    this one, from a fixed seed)."""
+    n = 200_000
+    rng = np.random.default_rng(226)
+    code = DTYPES[dt]
+    npdt = np.dtype(abi.NUMPY_OF_DTYPE[code])
+    info = np.iinfo(npdt)
+    lo, hi = max(info.min, -10**12), min(info.max, 10**12)
+    vals = rng.integers(lo, hi, size=n, dtype=np.int64 if npdt.kind == "i" else np.uint64).astype(npdt)
+    ht = rt.HipTable(1, [70_000, 65_536, 64_464])
+    ht.append_column(1, code, vals)
+    transform = abi.ORDER_IDENTITY_INT64 if dt == "Int64" else abi.ORDER_IDENTITY_INT32 if dt == "Int32" else None
+    if transform is None:
+        pytest.skip("ScanOrderTransform has identity transforms for Int64 / Int32 / Utf8 only (llkv-scan/src/lib.rs:41-46)")
+    order = (1, False, False, transform)
+    got_v, got_r = [], []
+    for cols, rids in rt.scan_stream(ht, [1], None, include_row_ids=True, order=order):
+        got_v.extend(cols[0]); got_r.extend(rids)
+    idx = np.argsort(vals, kind="stable")
+    assert got_v == vals[idx].tolist() and got_r == idx.tolist()
+    a, b = int(np.percentile(vals.astype(np.float64), 25)), int(np.percentile(vals.astype(np.float64), 75))
+    F, O, B = abi.Filter, abi.Operator, abi.Bound
+    got_v, got_r = [], []
+    for cols, rids in rt.scan_stream(ht, [1], [F(1, O.Range(B.Included(a), B.Included(b)))], include_row_ids=True, order=order):
+        got_v.extend(cols[0]); got_r.extend(rids)
+    keep = idx[(vals[idx] >= a) & (vals[idx] <= b)]
+    assert got_v == vals[keep].tolist() and got_r == keep.tolist()

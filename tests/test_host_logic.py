@@ -456,3 +456,49 @@ def test_route_selection_mirrors_the_executor_dispatch():
     assert route(n_tables=1, n_aggregates=1, has_distinct=1)[:2] == ("aggregates", True)      # DISTINCT aggregates are on the path
     assert route(n_tables=4, n_group_by=1)[:2] == ("cross_product", False)
     assert route(n_tables=1, has_scalar_subqueries=1)[1] is False
+
+
+def test_query_rendering_with_default_substitution_parameters(abi, tpch):
+    """render_tpch_query / build_parameter_values (llkv-tpch/src/queries.rs:60-121,203-232): the defaults of the
+    toolkit's varsub.c (the TPC-H validation values), caller overrides by 1-based placeholder index, an unknown
+    placeholder is an error; what is rendered here is the plan, not SQL."""
+    q = mod("qualify")
+    assert q.render_parameters(1) == ["90"] and q.render_parameters(6) == ["1994-01-01", "0.06", "24"] and q.render_parameters(3) == ["BUILDING", "1995-03-15"]
+    assert q.render_parameters(6, {2: "0.05"}) == ["1994-01-01", "0.05", "24"]
+    with pytest.raises(ValueError):
+        q.render_parameters(6, {4: "x"})
+    with pytest.raises(ValueError):
+        q.render_parameters(2)
+    # the defaults reproduce the benchmark plans of tpch.py (BASELINE.json configs[1], [2], [4])
+    def lit(x):
+        return None if x is None else (x.tag, x.int_value, x.float_value, x.string)
+
+    def bound(b):
+        return None if b is None else (b.kind, lit(b.value))
+
+    def same_pred(a, b):
+        key = lambda f: (f.field_id, f.op.kind, lit(f.op.value), bound(f.op.lower), bound(f.op.upper))
+        return [key(f) for f in a] == [key(f) for f in b]
+    assert same_pred(q.render_query(tpch, abi, 1).predicate, tpch.q1().predicate)
+    assert same_pred(q.render_query(tpch, abi, 6).predicate, tpch.q6().predicate)
+    q3 = q.render_query(tpch, abi, 3)
+    assert q3["fact_filters"][0].op.value.int_value == tpch.DATE_1995_03_15 and q3["dim2_filters"][0].op.value.string == "BUILDING" and q3["limit"] == 10
+    # an override moves the rendered bounds
+    alt = q.render_query(tpch, abi, 6, {1: "1995-01-01", 3: "25"})
+    assert alt.predicate[0].op.lower.value.int_value == 9131 and alt.predicate[0].op.upper.value.int_value == 9496 and alt.predicate[2].op.value.int_value == 25
+
+
+def test_decimal_from_f64_keeps_fifteen_significant_digits():
+    """extract_decimal (qualification.rs:532-540) reads a Float64 result cell through rust_decimal's Decimal::from_f64,
+    which drops the excess binary precision: 15 significant digits.  A `sum`-kind column is then compared EXACTLY."""
+    from decimal import Decimal
+    q = mod("qualify")
+    assert q.decimal_from_f64(0.1) == Decimal("0.1")
+    assert q.decimal_from_f64(37734107.00000001) == Decimal("37734107")
+    assert q.decimal_from_f64(56586554400.730011) == Decimal("56586554400.73")
+    assert q.decimal_from_f64(-2.5e-7) == Decimal("-2.5E-7")
+    assert q.values_equal(("decimal", Decimal("56586554400.73")), q.engine_value(56586554400.73001, "decimal"), "decimal")
+    assert not q.values_equal(("decimal", Decimal("56586554400.73")), q.engine_value(56586554400.74, "decimal"), "decimal")
+    text = q.format_answer_set(["k", "s", "a", "n"], [["A", 56586554400.730011, 25.5, 7]], ["string", "decimal", "float", "integer"])
+    assert text == "k|s|a|n\nA|56586554400.73|25.5|7\n"
+    assert q.parse_answer_set(text, ["string", "decimal", "float", "integer"]) == [[("string", "A"), ("decimal", Decimal("56586554400.73")), ("float", 25.5), ("int", 7)]]

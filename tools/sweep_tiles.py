@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 2 sweep: canonical tile length × tiles per workgroup of the LDS-accumulator scan (Q1), on the whole SF10
+"""Round 2 sweep: canonical tile length × workgroup count of the LDS-accumulator scan (Q1), on the whole SF10
 table and on one 1/8 shard of it (rank 0 of 8 emulated on one device).  One subprocess per table (the knobs are read
 at prepare time, so one staged table serves every configuration)."""
 import json, os, subprocess, sys
@@ -26,22 +26,22 @@ for c in q.columns:
             t.set_column_stats(fid, int(full[c].min()), int(full[c].max()))
 for tile in sys.argv[3].split(","):
     for tpw in sys.argv[4].split(","):
-        os.environ["LLKV_HIP_TILE_ROWS"] = tile; os.environ["LLKV_HIP_TILES_PER_WG"] = tpw
-        if tpw == "auto": del os.environ["LLKV_HIP_TILES_PER_WG"]
+        os.environ["LLKV_HIP_TILE_ROWS"] = tile; os.environ["LLKV_HIP_SCAN_WGS"] = tpw
+        if tpw == "auto": del os.environ["LLKV_HIP_SCAN_WGS"]
         if tile == "auto": del os.environ["LLKV_HIP_TILE_ROWS"]
         pq = rt.PreparedQuery(t, q.predicate, q.aggs, q.keys, q.order_by_keys)
         for _ in range(5): pq.run()
         pq.set_profiling(True)
         for _ in range(steps): pq.run()
         ms, k, _ = pq.kernel_time()
-        print(json.dumps({"workload": name, "world": world, "local_rows": t.local_rows, "tile_rows": tile, "tiles_per_wg": tpw, "kernel_us": round(1e3 * ms / k, 2),
+        print(json.dumps({"workload": name, "world": world, "local_rows": t.local_rows, "tile_rows": tile, "workgroups": tpw, "kernel_us": round(1e3 * ms / k, 2),
                           "gbs": round(pq.algorithmic_bytes / (ms / k) / 1e6, 1)}), flush=True)
         pq.close()
 ''' % ROOT
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "q1_sf10"
-    tiles = sys.argv[2] if len(sys.argv) > 2 else "auto,8192,16384,32768,65536"
-    tpws = sys.argv[3] if len(sys.argv) > 3 else "auto,1,2,4,8"
+    tiles = sys.argv[2] if len(sys.argv) > 2 else "auto,8192,32768"
+    tpws = sys.argv[3] if len(sys.argv) > 3 else "auto,128,192,224,256,320,384,512,768,1024"
     for world in (1, 8):
         out = subprocess.run([sys.executable, "-c", CHILD, name, str(world), tiles, tpws], capture_output=True, text=True, timeout=900)
         print(out.stdout, end="", flush=True)
