@@ -90,7 +90,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
-enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5, Image = 6 };
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5, Image = 6, KeyBits = 7 };
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // scan / select-count / project
@@ -303,7 +303,19 @@ struct KeySetView {
 // predicate columns twice and move 16 B per selected row — one pass pays when few rows pass or the predicate is wide
 // or gathers from a table
 constexpr uint32_t kTileSampleStride = 64;
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr, int single_pass = -1);
+// `sink` (single-pass form only): the compaction of the selection also sets bit (key − kmin) of every selected row in a
+// bitmap the caller zeroed (and *dup_flag when a bit was set already) — the dim table of a join built while its rows
+// are being compacted, instead of one more pass over the row list
+struct BitmapSink {
+  const void *key_values; // key column image
+  uint32_t key_width;     // 4 or 8
+  uint32_t key_signed;
+  long long kmin;
+  unsigned long long *bits;
+  uint32_t *dup_flag;
+};
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr, int single_pass = -1,
+                          const BitmapSink *sink = nullptr);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

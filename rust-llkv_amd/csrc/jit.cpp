@@ -22,13 +22,16 @@ namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
 
-const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : k == JitKind::Reduce ? "reduce" : k == JitKind::Image ? "image" : "emit"; }
+const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : k == JitKind::Reduce ? "reduce" : k == JitKind::Image ? "image" : k == JitKind::KeyBits ? "keybits" : "emit"; }
 
 std::string wrapper_source(JitKind kind, const std::string &ts) {
   std::string s = "\nusing namespace llkv;\n";
   switch (kind) {
   case JitKind::Scan:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { fused_scan_body<" + ts + ">(p); }\n";
+    break;
+  case JitKind::KeyBits:
+    s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { keybits_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Image:
     s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { image_scan_body<" + ts + ">(p); }\n";

@@ -147,6 +147,20 @@ __global__ __launch_bounds__(256) void iota_kernel(uint32_t *out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = i;
 }
+// Fill of n 16-byte words with one 64-bit pattern (hipMemsetAsync's fill kernel reached ~130 GB/s on the 35 MB group
+// state of the join pipeline: 59 µs of a 750 µs query; this one streams at HBM speed).  `p` must be 16-byte aligned.
+__global__ __launch_bounds__(256) void hj_fill_kernel(ulonglong2 *p, uint64_t n16, unsigned long long v) {
+  const ulonglong2 w = make_ulonglong2(v, v);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) p[i] = w;
+}
+hipError_t hj_launch_fill(void *p, uint64_t bytes, uint64_t pattern, hipStream_t s) {
+  const uint64_t n16 = (bytes + 15) / 16; // scratch blocks are power-of-two sized (≥ 4 KiB): rounding up stays inside
+  if (n16 == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 2048);
+  hipLaunchKernelGGL(hj_fill_kernel, dim3(grid), dim3(256), 0, s, static_cast<ulonglong2 *>(p), n16, (unsigned long long)pattern);
+  return hipGetLastError();
+}
+
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n);
@@ -473,6 +487,64 @@ hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *
                                       uint32_t stripe, uint64_t *out_a, uint64_t *out_b, hipStream_t s) {
   if (n_slots == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_compact_stripes2_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_a, stripe_b, counts, offsets, n_slots, stripe, out_a, out_b);
+  return hipGetLastError();
+}
+
+// … and the bitmap of the selected rows' keys on the way (BitmapSink, engine.hpp): the rows of a (tile, wave) stripe are
+// consecutive table rows, so for a table clustered by the key a wave's 64 keys fall into a few bitmap words — the lanes
+// that share a word with their left neighbour let the run's first lane OR the whole run in (one atomic per word run).
+__global__ __launch_bounds__(256) void hj_compact_stripes2_bits_kernel(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets,
+                                                                        uint32_t n_slots, uint32_t stripe, uint64_t *out_a, uint64_t *out_b, const void *key_values,
+                                                                        uint32_t key_width, uint32_t key_signed, long long kmin, unsigned long long *bits, uint32_t *dup_flag) {
+  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= n_slots) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
+  for (uint64_t i0 = 0; i0 < cnt; i0 += 64) {
+    const uint64_t i = i0 + lane;
+    const bool live = i < cnt;
+    uint64_t word = ~0ull, bit = 0;
+    if (live) {
+      const uint64_t row = stripe_b[src + i];
+      out_a[dst + i] = stripe_a[src + i];
+      out_b[dst + i] = row;
+      long long k;
+      if (key_width == 8) k = reinterpret_cast<const long long *>(key_values)[row];
+      else { const uint32_t v = reinterpret_cast<const uint32_t *>(key_values)[row]; k = key_signed ? (long long)(int32_t)v : (long long)v; }
+      const uint64_t d = (uint64_t)k - (uint64_t)kmin;
+      word = d >> 6;
+      bit = 1ull << (d & 63);
+    }
+    // runs of equal words among neighbouring lanes: segmented inclusive OR-scan (a lane reaches back only as far as the
+    // head of its run), the last lane of a run issues one atomic for the run
+    const uint64_t prev_word = __shfl_up(word, 1, 64);
+    uint32_t head_idx = (lane == 0 || prev_word != word) ? lane : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(head_idx, off, 64);
+      if (lane >= (uint32_t)off) head_idx = o > head_idx ? o : head_idx;
+    }
+    uint64_t acc = bit;
+    bool dup = false;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint64_t o_acc = __shfl_up(acc, off, 64);
+      if (lane >= (uint32_t)off && lane - (uint32_t)off >= head_idx) { dup |= (acc & o_acc) != 0; acc |= o_acc; }
+    }
+    const uint64_t next_word = __shfl_down(word, 1, 64);
+    if (live && (lane == 63 || next_word != word)) {
+      const unsigned long long old = atomicOr(&bits[word], (unsigned long long)acc);
+      dup |= (old & acc) != 0;
+    }
+    if (__ballot(dup) != 0 && lane == 0) atomicOr(dup_flag, 1u);
+  }
+}
+hipError_t hj_launch_compact_stripes2_bits(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
+                                           uint32_t stripe, uint64_t *out_a, uint64_t *out_b, const void *key_values, uint32_t key_width, uint32_t key_signed,
+                                           long long kmin, unsigned long long *bits, uint32_t *dup_flag, hipStream_t s) {
+  if (n_slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_compact_stripes2_bits_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_a, stripe_b, counts, offsets, n_slots, stripe, out_a, out_b,
+                     key_values, key_width, key_signed, kmin, bits, dup_flag);
   return hipGetLastError();
 }
 

@@ -69,6 +69,8 @@ hipError_t hj_sort_by_slot(void *tmp, size_t *tmp_bytes, const uint32_t *slot_in
 // seg_start[slot] / seg_count[slot] from the sorted slot list.
 hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t *seg_start, uint32_t *seg_count, hipStream_t s);
 // identity index 0..n-1
+// Fills `bytes` (rounded up to 16; the block must be 16-byte aligned and that large) with a 64-bit pattern.
+hipError_t hj_launch_fill(void *p, uint64_t bytes, uint64_t pattern, hipStream_t s);
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
 
 // Cross product of two row windows, left-major (cross_join_pair llkv-join/src/cartesian.rs:22-80):
@@ -142,6 +144,10 @@ hipError_t hj_launch_unsorted_flag(const uint64_t *keys, uint64_t n, uint32_t *f
 // … and of a single-pass selection (two u64 streams: row ids, device rows)
 hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
                                       uint32_t stripe, uint64_t *out_a, uint64_t *out_b, hipStream_t s);
+// The same, and bit (key − kmin) of every selected row is set in `bits` (a duplicate raises *dup_flag).
+hipError_t hj_launch_compact_stripes2_bits(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
+                                           uint32_t stripe, uint64_t *out_a, uint64_t *out_b, const void *key_values, uint32_t key_width, uint32_t key_signed,
+                                           long long kmin, unsigned long long *bits, uint32_t *dup_flag, hipStream_t s);
 // Direct-address form of a dim table whose key range is bounded by the column statistics: bit (key − kmin) set for
 // every listed row (*dup_flag when a key occurs twice; dev_rows == nullptr lists rows 0..n−1), per-word popcounts →
 // exclusive scan = rank of each word's first set bit, group_of_rank[rank(key of listed row i)] = i.

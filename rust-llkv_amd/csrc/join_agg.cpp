@@ -52,8 +52,8 @@ struct HashSet {
     if (rc) return rc;
     DB flag;
     if ((rc = flag.alloc(4))) return rc;
-    HIP_TRY(hipMemsetAsync(owner.p, 0xFF, cap * 8, s));
-    HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
+    HIP_TRY(hj_launch_fill(owner.p, cap * 8, ~0ull, s));
+    HIP_TRY(hj_launch_fill(flag.p, 4, 0, s));
     HIP_TRY(hj_launch_claim_list(key, d_rows, n, (unsigned long long *)owner.p, cap - 1, (uint32_t *)flag.p, s));
     uint32_t f = 0;
     HIP_TRY(hipMemcpyAsync(&f, flag.p, 4, hipMemcpyDeviceToHost, s));
@@ -66,23 +66,33 @@ struct HashSet {
 // Direct-address form of a key set whose range the column statistics bound (join.hpp): bitmap + rank + group ids.
 constexpr uint64_t kMaxDirectSpan = 1ull << 30; // 128 MiB of bits + 64 MiB of word ranks at most
 struct DirectTable {
-  DB bits, prefix, group, flag, tmp;
+  DB bits, prefix, group, tmp;
+  uint32_t *flag_p = nullptr; // device words behind the bitmap: [0] non-zero when a key occurred twice, [1] predicate error of a key-bits scan
+  uint64_t n_words = 0;
   int64_t kmin = 0;
   uint64_t span = 0;
   static bool usable(const ColumnInfo &ci) {
     return ci.has_stats && ci.max_i >= ci.min_i && (uint64_t)ci.max_i - (uint64_t)ci.min_i < kMaxDirectSpan;
   }
-  // Launches only (no host synchronisation): `flag` (device, u32) is non-zero afterwards when a key occurred twice.
-  // `with_groups`: also the rank → list index table (the group ids of the join-aggregate pipeline).
-  int build(const ColumnInfo &ci, const JoinKeyColumn &key, const uint64_t *d_rows, uint64_t n, bool with_groups, hipStream_t s) {
+  // The zeroed bitmap (and the duplicate flag behind it): launches only.
+  int prepare_bits(const ColumnInfo &ci, hipStream_t s) {
     kmin = ci.min_i;
     span = (uint64_t)ci.max_i - (uint64_t)ci.min_i;
-    const uint64_t n_words = (span / 64 + 1 + 511) / 512 * 512; // whole pages: one fill kernel
+    n_words = (span / 64 + 1 + 511) / 512 * 512;
+    // the duplicate flag and one error word live right behind the bitmap: one allocation, one fill
+    int rc = bits.alloc(n_words * 8 + 16);
+    if (rc) return rc;
+    flag_p = reinterpret_cast<uint32_t *>(static_cast<char *>(bits.p) + n_words * 8);
+    HIP_TRY(hj_launch_fill(bits.p, n_words * 8 + 16, 0, s));
+    return LLKV_OK;
+  }
+  // Launches only (no host synchronisation): *flag_p is non-zero afterwards when a key occurred twice.
+  // `bits_done`: the bits were set already (BitmapSink of the selection's compaction).
+  // `with_groups`: also the rank → list index table (the group ids of the join-aggregate pipeline).
+  int build(const ColumnInfo &ci, const JoinKeyColumn &key, const uint64_t *d_rows, uint64_t n, bool with_groups, hipStream_t s, bool bits_done = false) {
     int rc;
-    if ((rc = bits.alloc(n_words * 8)) || (rc = flag.alloc(4))) return rc;
-    HIP_TRY(hipMemsetAsync(bits.p, 0, n_words * 8, s));
-    HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
-    HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, (uint32_t *)flag.p, s));
+    if (!bits.p && (rc = prepare_bits(ci, s))) return rc;
+    if (!bits_done) HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, flag_p, s));
     if (with_groups) {
       size_t tb = 0;
       if ((rc = prefix.alloc(n_words * 4)) || (rc = group.alloc((n ? n : 1) * 4))) return rc;
@@ -160,30 +170,81 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   DirectTable set2_bits;
   JoinKeyColumn k2{}, fk{};
   bool fused_semi = false;
+  std::string err;
+  uint32_t *key_err_flag = nullptr; // device word the key-bits scan raises on a predicate arithmetic error (lives in set2_bits)
   if (t2) {
-    Selection sel2;
-    if ((rc = run_selection(t2, dim2->filters, dim2->n_filters, nullptr, 0, &sel2))) return rc;
     if ((rc = int_key_column(t2, dim2->key_field, &k2)) || (rc = int_key_column(td, dim_fk_field, &fk))) return rc;
     const ColumnInfo &k2_info = t2->cols.find(dim2->key_field)->second.info;
-    bool dup = false;
     fused_semi = DirectTable::usable(k2_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
-    if (fused_semi) { // a set: a key that occurs twice is no error
-      if ((rc = set2_bits.build(k2_info, k2, sel2.d_dev, sel2.n, false, s))) return rc;
-      HIP_TRY(hipStreamSynchronize(s)); // sel2 is released at the end of the block
-    } else if ((rc = set2.build(k2, sel2.d_dev, sel2.n, &dup, s))) {
-      return rc;
+    bool bits_set = false;
+    if (fused_semi && k2_info.dtype == LLKV_DT_INT64 && t2->local_rows) {
+      // the key set straight from dim2's scan: rows that pass set their bit — no selection vector, no read-back
+      auto resolve_2 = [&](uint32_t fid) -> const ColumnInfo * {
+        auto it = t2->cols.find(fid);
+        return it == t2->cols.end() ? nullptr : &it->second.info;
+      };
+      llkv_expr_token key_tok;
+      std::memset(&key_tok, 0, sizeof key_tok);
+      key_tok.kind = LLKV_TOK_COLUMN;
+      key_tok.field_id = dim2->key_field;
+      LoweredPlan kp;
+      JitKernel kk;
+      const TileSet *ts2 = nullptr;
+      if (lower_emit(resolve_2, dim2->filters, dim2->n_filters, nullptr, 0, &key_tok, 1, &kp, &err) == LLKV_OK &&
+          jit_compile(JitKind::KeyBits, kp.type_string, &kk, &err) == LLKV_OK) {
+        if ((rc = set2_bits.prepare_bits(k2_info, s)) || (rc = get_tileset(*t2, 8192, &ts2))) return rc;
+        if (!kp.always_false) {
+          ScanParams p2;
+          std::memset(&p2, 0, sizeof p2);
+          for (size_t i = 0; i < kp.slot_fields.size(); ++i) p2.col[i] = slot_buffer(t2->cols, kp, i);
+          for (size_t i = 0; i < kp.lit_i.size(); ++i) p2.lit_i[i] = kp.lit_i[i];
+          for (size_t i = 0; i < kp.lit_f.size(); ++i) p2.lit_f[i] = kp.lit_f[i];
+          p2.tiles = ts2->d_tiles;
+          p2.n_tiles = ts2->n_tiles;
+          p2.aux_out = (uint64_t *)set2_bits.bits.p;
+          p2.aux_out32 = set2_bits.flag_p + 1; // predicate-error word (read with the pair count)
+          p2.bm_min = set2_bits.kmin;
+          p2.bm_span = set2_bits.span;
+          if ((rc = jit_launch_raw(kk.fn, ts2->n_tiles, &p2, sizeof p2, s))) return rc;
+        }
+        bits_set = true;
+        key_err_flag = set2_bits.flag_p + 1;
+      }
+    }
+    if (!bits_set) {
+      Selection sel2;
+      if ((rc = run_selection(t2, dim2->filters, dim2->n_filters, nullptr, 0, &sel2))) return rc;
+      bool dup = false;
+      if (fused_semi) { // a set: a key that occurs twice is no error
+        if ((rc = set2_bits.build(k2_info, k2, sel2.d_dev, sel2.n, false, s))) return rc;
+        HIP_TRY(hipStreamSynchronize(s)); // sel2 is released at the end of the block
+      } else if ((rc = set2.build(k2, sel2.d_dev, sel2.n, &dup, s))) {
+        return rc;
+      }
     }
   }
+  // dim's own table: when the statistics bound its key, the bitmap is filled while the selection is compacted
+  JoinKeyColumn kd{};
+  if ((rc = int_key_column(td, dim->key_field, &kd))) return rc;
+  const ColumnInfo &kd_info = td->cols.find(dim->key_field)->second.info;
+  const bool direct = DirectTable::usable(kd_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
+  DirectTable dt;
+  bool dt_bits_done = false;
   if (fused_semi) {
     auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
       auto it = td->cols.find(fid);
       return it == td->cols.end() ? nullptr : &it->second.info;
     };
     LoweredPlan sel_plan;
-    std::string err;
     if ((rc = lower_selection_in_set(resolve_d, dim->filters, dim->n_filters, dim_fk_field, &sel_plan, &err))) return set_error(rc, err);
     const KeySetView view{(const uint64_t *)set2_bits.bits.p, set2_bits.kmin, set2_bits.span};
-    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, 1))) return rc; // the bit test gathers: evaluate it once
+    BitmapSink sink{};
+    if (direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK")) {
+      if ((rc = dt.prepare_bits(kd_info, s))) return rc;
+      sink = BitmapSink{kd.values, kd.width, kd.is_signed, dt.kmin, (unsigned long long *)dt.bits.p, dt.flag_p};
+      dt_bits_done = true;
+    }
+    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, 1, dt_bits_done ? &sink : nullptr))) return rc; // the bit test gathers: evaluate it once
   } else if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) {
     return rc;
   }
@@ -212,25 +273,20 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   cnts.p = (char *)group_state.p + state_bytes;
   gcnts.p = (char *)group_state.p + 2 * state_bytes;
   report.p = (char *)group_state.p + 3 * state_bytes;
-  HIP_TRY(hipMemsetAsync(group_state.p, 0, 3 * state_bytes, s));
+  HIP_TRY(hj_launch_fill(group_state.p, 3 * state_bytes, 0, s));
 
   // ---- dim hash table, slot → group id -----------------------------------------------------
-  JoinKeyColumn kd{};
-  if ((rc = int_key_column(td, dim->key_field, &kd))) return rc;
   std::memset(&cc, 0, sizeof cc);
   cc.key = kd;
   cc.n_payload = n_payload;
   for (uint32_t i = 0; i < n_payload; ++i) if ((rc = int_key_column(td, payload_fields[i], &cc.payload[i]))) return rc;
   // key range bounded by the column statistics → bitmap + rank (no hashing, and a clustered fact table probes it
   // almost sequentially); otherwise the open-addressing table
-  const ColumnInfo &kd_info = td->cols.find(dim->key_field)->second.info;
-  const bool direct = DirectTable::usable(kd_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
   HashSet ht;
-  DirectTable dt;
   DB slot_group;
   bool dup = false;
   if (direct) { // launches only; the duplicate flag is read with the pair count below
-    if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, s))) return rc;
+    if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, s, dt_bits_done && d_dim_rows == seld.d_dev))) return rc;
   } else {
     if ((rc = ht.build(kd, d_dim_rows, n_dim, &dup, s))) return rc;
   }
@@ -246,7 +302,6 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     return it == tf->cols.end() ? nullptr : &it->second.info;
   };
   LoweredPlan plan;
-  std::string err;
   if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err))) return set_error(rc, err);
   if (plan.always_false || tf->local_rows == 0) { HIP_TRY(hipStreamSynchronize(s)); return LLKV_OK; }
   JitKernel k;
@@ -256,7 +311,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
   DB counts, offsets;
   if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
-  HIP_TRY(hipMemsetAsync(counts.p, 0, (size_t)(n_slots + 1) * 8, s)); // the extra trailing 0 makes offsets[n_slots] the total
+  HIP_TRY(hj_launch_fill(counts.p, (size_t)(n_slots + 1) * 8, 0, s)); // the extra trailing 0 makes offsets[n_slots] the total
   ScanParams p;
   std::memset(&p, 0, sizeof p);
   for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = slot_buffer(tf->cols, plan, i);
@@ -290,9 +345,12 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
   DB scan_tmp;
   if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
-  uint32_t dup_keys = 0;
+  uint32_t dup_keys = 0, key_err = 0;
   Readback rb;
-  if ((rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (direct && (rc = rb.add(&dup_keys, dt.flag.p, 4, s))) || (rc = rb.wait())) return rc;
+  if ((rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) ||
+      (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) || (rc = rb.wait()))
+    return rc;
+  if (key_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
   if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
@@ -304,11 +362,11 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   // The pairs are in row order.  A fact table clustered by the join key leaves every group as ONE run of them: sum
   // the runs where they lie; only when some group turns out to have a second run, sort (stable) by group first.
   DB multi;
-  if ((rc = multi.alloc(4))) return rc;
-  HIP_TRY(hipMemsetAsync(multi.p, 0, 4, s));
+  if ((rc = multi.alloc(16))) return rc;
+  HIP_TRY(hj_launch_fill(multi.p, 16, 0, s));
   HIP_TRY(hj_launch_run_sums((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, (uint32_t *)multi.p, s));
   uint32_t multi_run = 0;
-  HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
+  if (tf->world != 1) HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
   if ((rc = rb.add(&multi_run, multi.p, 4, s)) || (rc = rb.wait())) return rc;
   if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
     std::swap(s_group.p, e_group.p); // a group's pairs are contiguous and in row order: all the later phases need
@@ -319,8 +377,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     while ((1ull << bits) < n_dim) ++bits;
     DB tmp;
     size_t tb = 0;
-    HIP_TRY(hipMemsetAsync(sums.p, 0, n_dim * 8, s));
-    HIP_TRY(hipMemsetAsync(cnts.p, 0, n_dim * 8, s));
+    HIP_TRY(hj_launch_fill(group_state.p, 2 * state_bytes, 0, s)); // sums and counts again
     HIP_TRY(hj_sort_u32_u64(nullptr, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
@@ -341,7 +398,7 @@ int JoinAgg::straddlers() {
   DB flags, offs;
   int rc;
   if ((rc = flags.alloc((n_pairs + 1) * 8)) || (rc = offs.alloc((n_pairs + 1) * 8))) return rc;
-  HIP_TRY(hipMemsetAsync(flags.p, 0, (n_pairs + 1) * 8, s));
+  HIP_TRY(hj_launch_fill(flags.p, (n_pairs + 1) * 8, 0, s));
   HIP_TRY(hj_launch_straddler_flags((const uint32_t *)s_group.p, n_pairs, (const uint64_t *)cnts.p, (const int64_t *)gcnts.p, (uint64_t *)flags.p, s));
   DB scan_tmp;
   if ((rc = scan_exclusive((const uint64_t *)flags.p, (uint64_t *)offs.p, n_pairs + 1, scan_tmp, s))) return rc;
@@ -369,8 +426,10 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   if (n_dim == 0) return LLKV_OK;
   hipStream_t s = g_ctx.stream;
   int rc;
-  // groups this rank reports: the ones it alone holds …
-  HIP_TRY(hj_launch_report_counts((const uint64_t *)cnts.p, (const int64_t *)gcnts.p, n_dim, (uint64_t *)report.p, s));
+  // groups this rank reports: the ones it alone holds … (one rank holds every group alone: its counts are the report)
+  const bool alone = tf->world == 1 && n_folded == 0;
+  if (!alone) HIP_TRY(hj_launch_report_counts((const uint64_t *)cnts.p, (const int64_t *)gcnts.p, n_dim, (uint64_t *)report.p, s));
+  const uint64_t *report_p = alone ? (const uint64_t *)cnts.p : (const uint64_t *)report.p;
   // … plus the straddlers it holds first, with their exact sums and global counts
   std::vector<uint32_t> mg;
   std::vector<double> ms;
@@ -398,8 +457,8 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     DB best, blk, groups_d; // blk = {threshold, candidates, groups, pad…}[8] then the candidate records
     if ((rc = best.alloc(1024 * 8)) || (rc = blk.alloc(64 + (size_t)kCap * 64)) || (rc = groups_d.alloc(kCap * 4))) return rc;
     uint64_t *state = (uint64_t *)blk.p, *recs = state + 8;
-    HIP_TRY(hipMemsetAsync(state, 0, 64, s));
-    HIP_TRY(hj_launch_topk_select((const double *)sums.p, (const uint64_t *)report.p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p,
+    HIP_TRY(hj_launch_fill(state, 64, 0, s));
+    HIP_TRY(hj_launch_topk_select((const double *)sums.p, report_p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p,
                                   state, (uint32_t *)groups_d.p, recs, s));
     std::vector<uint64_t> hrec(8 + (size_t)kCap * 8); // one read-back: the head and the first records (all of them, usually)
     Readback rb;
@@ -431,7 +490,7 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
       (rc = n_groups_d.alloc(8)))
     return rc;
   HIP_TRY(hipMemsetAsync(n_groups_d.p, 0, 8, s));
-  HIP_TRY(hj_launch_topk_keys((const double *)sums.p, (const uint64_t *)report.p, n_dim, (uint64_t *)tk_keys.p, (uint32_t *)tk_groups.p,
+  HIP_TRY(hj_launch_topk_keys((const double *)sums.p, report_p, n_dim, (uint64_t *)tk_keys.p, (uint32_t *)tk_groups.p,
                               (unsigned long long *)n_groups_d.p, s));
   // ---- candidates → host: the first (limit + slack) groups by descending sum ------------------------------------
   // The top groups are decided by the high half of the order key almost always: sort on bits 32..63 first (half
@@ -460,7 +519,7 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
       HIP_TRY(hj_sort_u64_u32(tmp.p, &tb, (const uint64_t *)tk_keys.p, (uint64_t *)tk_keys_s.p, (const uint32_t *)tk_groups.p, (uint32_t *)tk_groups_s.p, n_dim, s));
     }
     HIP_TRY(hj_launch_gather_group_candidates(pass == 0 ? nullptr : (const uint64_t *)tk_keys_s.p, (const uint64_t *)tk_keys.p, (const uint32_t *)tk_groups_s.p, want,
-                                              d_dim_rows, (const double *)sums.p, (const uint64_t *)report.p, cc, (uint64_t *)cand_d.p, s));
+                                              d_dim_rows, (const double *)sums.p, report_p, cc, (uint64_t *)cand_d.p, s));
     HIP_TRY(hipMemcpyAsync(hc.data(), cand_d.p, (size_t)want * 64, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hg.data(), tk_groups_s.p, (size_t)want * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&n_groups, n_groups_d.p, 8, hipMemcpyDeviceToHost, s));

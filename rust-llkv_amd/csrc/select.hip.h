@@ -18,6 +18,8 @@ template <class CL, class PR> struct SelPlan {
   using Pred = PR;
 };
 
+constexpr int kSelUnroll = 4; // 128-row steps of a wave in flight
+
 // Each wave owns a contiguous quarter of the tile; a lane owns two consecutive rows per step.
 template <class P, bool WRITE> __device__ __forceinline__ void select_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
@@ -33,25 +35,32 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
   uint64_t count = 0;
   uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  for (uint32_t r = sub0; r < sub1; r += 128) {
-    Loaded ld;
-    const uint32_t row0 = r + lane * 2;
-    load_all<typename P::ColList>(p, td.dev_row + row0, ld);
-    bool f[2];
+  // kSelUnroll steps of 128 rows are requested before the first is looked at (the column images carry slack past the
+  // last tile; rows past sub1 are masked)
+  for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
+    Loaded lds[kSelUnroll];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
-      f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
-      perr |= ((row0 + j) < sub1) ? c.perr : 0u;
-    }
-    const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
-    if constexpr (WRITE) {
-      const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
-      if (f[0]) { p.aux_out[pre] = td.logical_row + row0; p.aux_out2[pre] = td.dev_row + row0; }
-      if (f[1]) { p.aux_out[pre + (f[0] ? 1 : 0)] = td.logical_row + row0 + 1; p.aux_out2[pre + (f[0] ? 1 : 0)] = td.dev_row + row0 + 1; }
-      base += __popcll(b0) + __popcll(b1);
-    } else {
-      count += __popcll(b0) + __popcll(b1);
+    for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+#pragma unroll
+    for (int u = 0; u < kSelUnroll; ++u) {
+      const Loaded &ld = lds[u];
+      const uint32_t row0 = r0 + u * 128 + lane * 2;
+      bool f[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        Ctx c{p, ld, 0u, td.logical_row + row0 + j};
+        f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+        perr |= ((row0 + j) < sub1) ? c.perr : 0u;
+      }
+      const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
+      if constexpr (WRITE) {
+        const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
+        if (f[0]) { p.aux_out[pre] = td.logical_row + row0; p.aux_out2[pre] = td.dev_row + row0; }
+        if (f[1]) { p.aux_out[pre + (f[0] ? 1 : 0)] = td.logical_row + row0 + 1; p.aux_out2[pre + (f[0] ? 1 : 0)] = td.dev_row + row0 + 1; }
+        base += __popcll(b0) + __popcll(b1);
+      } else {
+        count += __popcll(b0) + __popcll(b1);
+      }
     }
   }
   if (!WRITE || strided) {
@@ -110,31 +119,36 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
   uint64_t count = 0;
   uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  for (uint32_t r = sub0; r < sub1; r += 128) {
-    Loaded ld;
-    const uint32_t row0 = r + lane * 2;
-    load_all<typename P::ColList>(p, td.dev_row + row0, ld);
-    bool f[2];
-    uint32_t hit[2];
-    uint64_t val[2];
+  for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
+    Loaded lds[kSelUnroll];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
-      const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
-      perr |= ((row0 + j) < sub1) ? c.perr : 0u;
-      // probe only for surviving rows (the branch on the table form is uniform over the grid)
-      hit[j] = !pass ? 0xFFFFFFFFu : p.bm_bits ? bm_find(p, (long long)P::KeyE::eval(c, j)) : ht_find(p, (long long)P::KeyE::eval(c, j));
-      f[j] = hit[j] != 0xFFFFFFFFu;
-      val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
-    }
-    const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
-    if constexpr (WRITE) {
-      const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
-      if (f[0]) { p.aux_out32[pre] = hit[0]; p.aux_out[pre] = val[0]; }
-      if (f[1]) { p.aux_out32[pre + (f[0] ? 1 : 0)] = hit[1]; p.aux_out[pre + (f[0] ? 1 : 0)] = val[1]; }
-      base += __popcll(b0) + __popcll(b1);
-    } else {
-      count += __popcll(b0) + __popcll(b1);
+    for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+#pragma unroll
+    for (int u = 0; u < kSelUnroll; ++u) {
+      const Loaded &ld = lds[u];
+      const uint32_t row0 = r0 + u * 128 + lane * 2;
+      bool f[2];
+      uint32_t hit[2];
+      uint64_t val[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        Ctx c{p, ld, 0u, td.logical_row + row0 + j};
+        const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
+        perr |= ((row0 + j) < sub1) ? c.perr : 0u;
+        // probe only for surviving rows (the branch on the table form is uniform over the grid)
+        hit[j] = !pass ? 0xFFFFFFFFu : p.bm_bits ? bm_find(p, (long long)P::KeyE::eval(c, j)) : ht_find(p, (long long)P::KeyE::eval(c, j));
+        f[j] = hit[j] != 0xFFFFFFFFu;
+        val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
+      }
+      const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
+      if constexpr (WRITE) {
+        const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
+        if (f[0]) { p.aux_out32[pre] = hit[0]; p.aux_out[pre] = val[0]; }
+        if (f[1]) { p.aux_out32[pre + (f[0] ? 1 : 0)] = hit[1]; p.aux_out[pre + (f[0] ? 1 : 0)] = val[1]; }
+        base += __popcll(b0) + __popcll(b1);
+      } else {
+        count += __popcll(b0) + __popcll(b1);
+      }
     }
   }
   if (!WRITE || strided) {
@@ -190,6 +204,29 @@ template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const S
     const bool any_err = __ballot(perr != 0) != 0;
     if (lane == 0) p.tile_partials[slot_idx] = count + (any_err ? kPredErrorBit : 0);
   }
+}
+
+// ---- key bits: the rows that pass the predicate set bit (key − bm_min) of a bitmap — the key set of a semi join whose
+// key range the statistics bound (customer ⋉ in the Q3 chain), straight from the scan: no selection vector, no
+// compaction, no read-back.  aux_out = the bitmap words, aux_out32 = one error word (predicate arithmetic).
+template <class P> __device__ __forceinline__ void keybits_body(const ScanParams &p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  unsigned long long *bits = reinterpret_cast<unsigned long long *>(p.aux_out);
+  uint32_t perr = 0;
+  for (uint32_t r = threadIdx.x * 2; r < td.rows; r += kBlock * 2) {
+    Loaded ld;
+    load_all<typename P::ColList>(p, td.dev_row + r, ld);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      Ctx c{p, ld, 0u, td.logical_row + r + j};
+      const bool in_tile = (r + j) < td.rows;
+      const bool pass = in_tile & P::Pred::eval(c, j);
+      perr |= in_tile ? c.perr : 0u;
+      const uint64_t d = (uint64_t)(long long)P::ValE::eval(c, j) - (uint64_t)p.bm_min;
+      if (pass && d <= p.bm_span) atomicOr(&bits[d >> 6], 1ull << (d & 63));
+    }
+  }
+  if (perr) atomicOr(p.aux_out32, perr);
 }
 
 // Exclusive scan of the per-(tile, wave) counts; one block, fixed order.  out[n] = total.

@@ -44,7 +44,8 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
 }
 
 // The selection kernels of an already lowered predicate (prepared statements keep the plan).
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, int single_pass_mode) {
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, int single_pass_mode, const BitmapSink *sink) {
+  if (sink && single_pass_mode != 1) return set_error(LLKV_INTERNAL, "a bitmap sink belongs to the single-pass selection");
   int rc;
   std::string err;
   scratch_free(sel->d_ids); sel->d_ids = nullptr;
@@ -117,7 +118,11 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
   sel->d_ids = (uint64_t *)scratch_alloc(total * 8);
   sel->d_dev = (uint64_t *)scratch_alloc(total * 8);
   if (!sel->d_ids || !sel->d_dev) return set_error(LLKV_INTERNAL, "device scratch allocation failed");
-  if (single_pass) {
+  if (single_pass && sink) {
+    HIP_TRY(hj_launch_compact_stripes2_bits((const uint64_t *)stripe_ids.p, (const uint64_t *)stripe_dev.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p,
+                                            n_slots, p.sub_rows, sel->d_ids, sel->d_dev, sink->key_values, sink->key_width, sink->key_signed, sink->kmin, sink->bits,
+                                            sink->dup_flag, stream));
+  } else if (single_pass) {
     HIP_TRY(hj_launch_compact_stripes2((const uint64_t *)stripe_ids.p, (const uint64_t *)stripe_dev.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p,
                                        n_slots, p.sub_rows, sel->d_ids, sel->d_dev, stream));
   } else {

@@ -81,7 +81,7 @@ def test_shared_image_results_do_not_depend_on_launch_geometry_or_shards(rt, abi
     aggs = [A.count_star(), A.sum(S["l_quantity"][0]), A.sum(col(S["l_extendedprice"][0]) * (1 - col(S["l_discount"][0]))), A.max(S["l_quantity"][0])]
     cols = ["l_shipdate", "l_quantity", "l_extendedprice", "l_discount"]
 
-    many = (np.arange(n, dtype=np.int64) * 7919) % 20_000  # 20 000 groups: an image of four LDS-sized slices
+    many = (np.arange(n, dtype=np.int64) * 7919) % 10_000  # 10 000 groups × 5 lanes: an image of three LDS-sized slices
 
     def stage(rank, world):
         ht = rt.HipTable(1, chunks, rank, world)
@@ -93,7 +93,7 @@ def test_shared_image_results_do_not_depend_on_launch_geometry_or_shards(rt, abi
         return ht
 
     one = stage(0, 1)
-    # 20 000 groups × 3 lanes: the image no longer fits the LDS, the groups are cut into slices, one scan each (",2,P>")
+    # 10 000 groups × 5 lanes: the image no longer fits the LDS, the groups are cut into slices, one scan each (",2,P>")
     wide = aggs[:3]
     pw = rt.PreparedQuery(one, None, wide, [99], False)
     assert _image(pw) and not pw.kernel_signature.endswith(",2>"), (pw.route_note, pw.kernel_signature)
@@ -129,7 +129,7 @@ def test_shared_image_results_do_not_depend_on_launch_geometry_or_shards(rt, abi
         total, last = np.zeros_like(ex1).view(np.int64), None
         for rank in range(world):
             ht = stage(rank, world)
-            ht.set_column_stats(99, 0, 19_999)
+            ht.set_column_stats(99, 0, 9_999)
             for c in cols:  # the table-wide statistics, as share_metadata installs them on every rank
                 fid, dt = S[c]
                 if dt != abi.DT_FLOAT64:
