@@ -271,15 +271,24 @@ bool result_release(void *p);
 // Small device → host read-backs (counts, flags, a few candidate records) through a pinned buffer of the calling
 // thread: a copy into pageable memory is staged by the runtime and costs ~25 µs more per call.
 //   Readback rb; rb.add(&n, d_n, 8); rb.add(&flag, d_flag, 4); rc = rb.wait(stream);
+struct GatherItems; // join.hpp
 struct Readback {
   static constexpr size_t kBytes = 64 << 10;
-  struct Item { void *dst; size_t off, bytes; };
+  struct Item { void *dst; const void *src; size_t off, bytes; };
   Item items[8];
-  int n = 0;
+  int n = 0, launched = 0;
   size_t used = 0;
+  uint32_t seq = 0; // what the gathering workgroup stores behind the slab when it is done (0: nobody does)
   hipStream_t stream = nullptr;
   int add(void *host_dst, const void *device_src, size_t bytes, hipStream_t s);
-  int wait(); // synchronises the stream of the adds and delivers the values
+  // an item some kernel of the caller writes itself: *slab = where (pinned, device-visible)
+  int reserve(void *host_dst, size_t bytes, hipStream_t s, void **slab);
+  // hands the items not yet launched to a kernel of the caller (join.hip: readback_gather): *host = the slab's base
+  int take(GatherItems *g, uint32_t **host);
+  int flush(); // launches the gather of the items added so far (their device sources may be released afterwards)
+  // flush + waits for the gather (polling its done word: a stream synchronisation costs ~20 µs of wake-up; the stream
+  // may still be finishing the kernel's epilogue on return) + delivers the values
+  int wait();
 };
 
 // Selection vector of a predicate over a table image (stream.cpp): ascending logical row ids
@@ -312,10 +321,12 @@ struct BitmapSink {
   uint32_t key_signed;
   long long kmin;
   unsigned long long *bits;
-  uint32_t *dup_flag;
+  uint32_t *unsorted_flag; // raised when the selected rows are not in ascending key order (equal keys included)
 };
+// `sync` = false: the compaction is left running on the stream (the caller keeps launching behind it on the same stream
+// and synchronises before anybody else could look)
 int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set = nullptr, int single_pass = -1,
-                          const BitmapSink *sink = nullptr);
+                          const BitmapSink *sink = nullptr, bool sync = true);
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);

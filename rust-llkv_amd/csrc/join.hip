@@ -161,6 +161,44 @@ hipError_t hj_launch_fill(void *p, uint64_t bytes, uint64_t pattern, hipStream_t
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void hj_fill_zero_ranges_kernel(FillRanges r) {
+  const ulonglong2 w = make_ulonglong2(0, 0);
+  for (int k = 0; k < r.n; ++k) {
+    ulonglong2 *p = static_cast<ulonglong2 *>(r.p[k]);
+    const uint64_t n16 = (r.bytes[k] + 15) / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) p[i] = w;
+  }
+}
+hipError_t hj_launch_fill_zero_ranges(const FillRanges &r, hipStream_t s) {
+  uint64_t most = 0;
+  for (int k = 0; k < r.n; ++k) most = std::max<uint64_t>(most, (r.bytes[k] + 15) / 16);
+  if (most == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((most + 255) / 256, 2048);
+  hipLaunchKernelGGL(hj_fill_zero_ranges_kernel, dim3(grid), dim3(256), 0, s, r);
+  return hipGetLastError();
+}
+
+// (called by every thread of ONE workgroup; what the workgroup itself wrote to the slab before counts as delivered too)
+__device__ __forceinline__ void readback_gather(const GatherItems &g, uint32_t *host) {
+  for (int i = 0; i < g.n; ++i)
+    for (uint32_t w = threadIdx.x; w < g.words[i]; w += blockDim.x)
+      __hip_atomic_store(&host[g.dst_word[i] + w], __hip_atomic_load(&g.src[i][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  if (g.seq == 0) return;
+  __builtin_amdgcn_s_waitcnt(0); // this thread's stores to the host have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(&host[g.flag_word], g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(256) void hj_readback_gather_kernel(GatherItems g, uint32_t *host) { readback_gather(g, host); }
+hipError_t hj_launch_readback_gather(const GatherItems &g, uint32_t *host, hipStream_t s) {
+  if (g.n == 0 && g.seq == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_readback_gather_kernel, dim3(1), dim3(256), 0, s, g, host);
+  return hipGetLastError();
+}
+
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n);
@@ -350,6 +388,28 @@ hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64
                      (unsigned long long *)count_by_group, multi_run);
   return hipGetLastError();
 }
+// the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
+__global__ __launch_bounds__(256) void hj_run_sums_dev_kernel(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, double *sum_by_group,
+                                                               unsigned long long *count_by_group, uint32_t *multi_run) {
+  const uint64_t n = *n_dev;
+  if (n >= kPredErrorBit) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t g = group[i];
+    if (i != 0 && group[i - 1] == g) continue;
+    double acc = 0.0;
+    uint64_t j = i;
+    for (; j < n && group[j] == g; ++j) acc += __longlong_as_double((long long)val[j]);
+    if (atomicAdd(&count_by_group[g], (unsigned long long)(j - i)) != 0) atomicOr(multi_run, 1u);
+    sum_by_group[g] = acc;
+  }
+}
+hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
+                                  uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s) {
+  if (n_max == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_max + 255) / 256, 2048);
+  hipLaunchKernelGGL(hj_run_sums_dev_kernel, dim3(grid), dim3(256), 0, s, group, val, n_dev, sum_by_group, (unsigned long long *)count_by_group, multi_run);
+  return hipGetLastError();
+}
 hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
                                   uint64_t *count_by_slot, hipStream_t s) {
   if (n == 0) return hipSuccess;
@@ -459,6 +519,8 @@ __global__ __launch_bounds__(256) void hj_compact_stripes_kernel(const uint32_t 
                                                                   uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val) {
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (slot >= n_slots) return;
+  // launched before the host has seen the total: counts that carry the predicate-error mark are not offsets
+  if (offsets[n_slots] >= kPredErrorBit) return;
   const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
   for (uint64_t i = threadIdx.x & 63; i < cnt; i += 64) {
     out_group[dst + i] = slot_group ? slot_group[stripe_slot[src + i]] : stripe_slot[src + i];
@@ -490,61 +552,98 @@ hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *
   return hipGetLastError();
 }
 
+// lane i ← lane i − N of its 16-lane row (0 where the row has no such lane)
+template <int N> __device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
+}
+template <int N> __device__ __forceinline__ void segmented_or_step(uint32_t &lo, uint32_t &hi, uint32_t dist) {
+  const uint32_t in_lo = dpp_row_shr<N>(lo), in_hi = dpp_row_shr<N>(hi);
+  if (dist >= (uint32_t)N) {
+    lo |= in_lo;
+    hi |= in_hi;
+  }
+}
 // … and the bitmap of the selected rows' keys on the way (BitmapSink, engine.hpp): the rows of a (tile, wave) stripe are
 // consecutive table rows, so for a table clustered by the key a wave's 64 keys fall into a few bitmap words — the lanes
-// that share a word with their left neighbour let the run's first lane OR the whole run in (one atomic per word run).
+// that share a word with their left neighbour let the run's last lane OR the whole run in (one atomic per word run and
+// 16-lane row; an atomic per row would cost twice this whole kernel).
 __global__ __launch_bounds__(256) void hj_compact_stripes2_bits_kernel(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets,
                                                                         uint32_t n_slots, uint32_t stripe, uint64_t *out_a, uint64_t *out_b, const void *key_values,
-                                                                        uint32_t key_width, uint32_t key_signed, long long kmin, unsigned long long *bits, uint32_t *dup_flag) {
+                                                                        uint32_t key_width, uint32_t key_signed, long long kmin, unsigned long long *bits,
+                                                                        uint32_t *unsorted_flag) {
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (slot >= n_slots) return;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
-  for (uint64_t i0 = 0; i0 < cnt; i0 += 64) {
-    const uint64_t i = i0 + lane;
-    const bool live = i < cnt;
-    uint64_t word = ~0ull, bit = 0;
-    if (live) {
-      const uint64_t row = stripe_b[src + i];
-      out_a[dst + i] = stripe_a[src + i];
-      out_b[dst + i] = row;
-      long long k;
-      if (key_width == 8) k = reinterpret_cast<const long long *>(key_values)[row];
-      else { const uint32_t v = reinterpret_cast<const uint32_t *>(key_values)[row]; k = key_signed ? (long long)(int32_t)v : (long long)v; }
-      const uint64_t d = (uint64_t)k - (uint64_t)kmin;
-      word = d >> 6;
-      bit = 1ull << (d & 63);
-    }
-    // runs of equal words among neighbouring lanes: segmented inclusive OR-scan (a lane reaches back only as far as the
-    // head of its run), the last lane of a run issues one atomic for the run
-    const uint64_t prev_word = __shfl_up(word, 1, 64);
-    uint32_t head_idx = (lane == 0 || prev_word != word) ? lane : 0u;
+  auto key_of = [&](uint64_t r) -> long long {
+    if (key_width == 8) return reinterpret_cast<const long long *>(key_values)[r];
+    const uint32_t v = reinterpret_cast<const uint32_t *>(key_values)[r];
+    return key_signed ? (long long)(int32_t)v : (long long)v;
+  };
+  constexpr int kU = 4; // 64-row steps in flight: the stripe reads, then the key gathers, then the lane work
+  bool disorder = false;
+  long long first_key = 0, last_key = 0; // (uniform) first key of the stripe, last key of the step before
+  for (uint64_t i0 = 0; i0 < cnt; i0 += 64 * kU) {
+    uint64_t row[kU], a[kU];
+    long long key[kU];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_up(head_idx, off, 64);
-      if (lane >= (uint32_t)off) head_idx = o > head_idx ? o : head_idx;
+    for (int u = 0; u < kU; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * 64 + lane;
+      const bool live = i < cnt;
+      row[u] = live ? stripe_b[src + i] : 0;
+      a[u] = live ? stripe_a[src + i] : 0;
     }
-    uint64_t acc = bit;
-    bool dup = false;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint64_t o_acc = __shfl_up(acc, off, 64);
-      if (lane >= (uint32_t)off && lane - (uint32_t)off >= head_idx) { dup |= (acc & o_acc) != 0; acc |= o_acc; }
+    for (int u = 0; u < kU; ++u) key[u] = i0 + (uint64_t)u * 64 + lane < cnt ? key_of(row[u]) : 0;
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * 64 + lane;
+      if (i0 + (uint64_t)u * 64 >= cnt) break; // wave-uniform
+      const bool live = i < cnt;
+      uint32_t word = 0xFFFFFFFFu; // (a real word index stays below 2^24: the span of a direct table is bounded)
+      uint64_t bit = 0;
+      if (live) {
+        out_a[dst + i] = a[u];
+        out_b[dst + i] = row[u];
+        const uint64_t d = (uint64_t)key[u] - (uint64_t)kmin;
+        word = (uint32_t)(d >> 6);
+        bit = 1ull << (d & 63);
+      }
+      // are the selected rows in key order?  (then a key's rank among the set bits IS its list index)
+      const long long left = __shfl_up(key[u], 1);
+      const bool first_step = i0 == 0 && u == 0;
+      if (live && (lane ? key[u] <= left : (!first_step && key[u] <= last_key))) disorder = true;
+      if (first_step) first_key = __shfl(key[u], 0);
+      last_key = __shfl(key[u], 63);
+      // Runs of equal words among neighbouring lanes of a 16-lane row: the last lane of a run ORs the run's bits in with
+      // one atomic (nobody waits for its answer: a key that occurs twice shows as a bit count below the row count).
+      // Segmented inclusive OR-scan in DPP row shifts: a lane reaches back `dist` lanes, to the head of its run.
+      const bool head = (lane & 15) == 0 || dpp_row_shr<1>(word) != word;
+      const uint64_t heads = __ballot(head);
+      const uint32_t dist = lane - (63u - (uint32_t)__clzll(heads & ((2ull << lane) - 1)));
+      uint32_t lo = (uint32_t)bit, hi = (uint32_t)(bit >> 32);
+      segmented_or_step<1>(lo, hi, dist);
+      segmented_or_step<2>(lo, hi, dist);
+      segmented_or_step<4>(lo, hi, dist);
+      segmented_or_step<8>(lo, hi, dist);
+      const bool tail = (lane & 15) == 15 || (((heads >> 1) >> lane) & 1) != 0;
+      if (live && tail) (void)__hip_atomic_fetch_or(&bits[word], ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const uint64_t next_word = __shfl_down(word, 1, 64);
-    if (live && (lane == 63 || next_word != word)) {
-      const unsigned long long old = atomicOr(&bits[word], (unsigned long long)acc);
-      dup |= (old & acc) != 0;
-    }
-    if (__ballot(dup) != 0 && lane == 0) atomicOr(dup_flag, 1u);
   }
+  // … and across the stripe boundary: against the last key of the nearest stripe before this one that has rows
+  if (cnt) {
+    long long s = (long long)slot - 1;
+    while (s >= 0 && counts[s] == 0) --s;
+    if (s >= 0 && key_of(stripe_b[(uint64_t)s * stripe + counts[s] - 1]) >= first_key) disorder = true;
+  }
+  if (__ballot(disorder) != 0 && lane == 0) atomicOr(unsorted_flag, 1u);
 }
 hipError_t hj_launch_compact_stripes2_bits(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
                                            uint32_t stripe, uint64_t *out_a, uint64_t *out_b, const void *key_values, uint32_t key_width, uint32_t key_signed,
-                                           long long kmin, unsigned long long *bits, uint32_t *dup_flag, hipStream_t s) {
+                                           long long kmin, unsigned long long *bits, uint32_t *unsorted_flag, hipStream_t s) {
   if (n_slots == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_compact_stripes2_bits_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_a, stripe_b, counts, offsets, n_slots, stripe, out_a, out_b,
-                     key_values, key_width, key_signed, kmin, bits, dup_flag);
+                     key_values, key_width, key_signed, kmin, bits, unsorted_flag);
   return hipGetLastError();
 }
 
@@ -590,17 +689,37 @@ hipError_t hj_launch_popc_words(const uint64_t *bits, uint64_t n_words, uint32_t
 hipError_t hj_exclusive_scan_u32(void *tmp, size_t *tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s) {
   return rocprim::exclusive_scan(tmp, *tmp_bytes, in, out, (uint32_t)0, (size_t)n, rocprim::plus<uint32_t>(), s);
 }
+// out[w] = bits set in the words before w (the popcount is taken on the way in: no array of per-word counts)
+struct PopcWord {
+  __host__ __device__ uint32_t operator()(uint64_t w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(w);
+#else
+    return (uint32_t)__builtin_popcountll(w);
+#endif
+  }
+};
+hipError_t hj_exclusive_scan_popc(void *tmp, size_t *tmp_bytes, const uint64_t *bits, uint32_t *out, uint64_t n_words, hipStream_t s) {
+  auto in = rocprim::make_transform_iterator(bits, PopcWord());
+  return rocprim::exclusive_scan(tmp, *tmp_bytes, in, out, (uint32_t)0, (size_t)n_words, rocprim::plus<uint32_t>(), s);
+}
+// `unsorted` (optional): zero = the list is in key order, rank == list index and nothing is written.  `dup_flag`
+// (optional): raised when the bitmap holds fewer bits than the list has rows (a key occurred twice).
 __global__ __launch_bounds__(256) void hj_bitmap_groups_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,
-                                                                const uint64_t *bits, const uint32_t *prefix, uint32_t *group_of_rank) {
+                                                                const uint64_t *bits, const uint32_t *prefix, uint64_t n_words, const uint32_t *unsorted,
+                                                                uint32_t *dup_flag, uint32_t *group_of_rank) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && dup_flag && prefix[n_words - 1] + (uint32_t)__popcll(bits[n_words - 1]) != n) atomicOr(dup_flag, 1u);
+  if (unsorted && *unsorted == 0) return;
   if (i >= n) return;
   const uint64_t d = (uint64_t)load_key(key, dev_rows[i]) - (uint64_t)kmin;
   group_of_rank[prefix[d >> 6] + __popcll(bits[d >> 6] & ((1ull << (d & 63)) - 1))] = (uint32_t)i;
 }
 hipError_t hj_launch_bitmap_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, const uint64_t *bits,
-                                   const uint32_t *prefix, uint32_t *group_of_rank, hipStream_t s) {
+                                   const uint32_t *prefix, uint64_t n_words, const uint32_t *unsorted, uint32_t *dup_flag, uint32_t *group_of_rank, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_bitmap_groups_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, key, dev_rows, n, kmin, bits, prefix, group_of_rank);
+  hipLaunchKernelGGL(hj_bitmap_groups_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, key, dev_rows, n, kmin, bits, prefix, n_words, unsorted, dup_flag,
+                     group_of_rank);
   return hipGetLastError();
 }
 
@@ -669,85 +788,137 @@ __device__ __forceinline__ uint64_t desc_order_key(double v) {
   const uint64_t asc = bits < 0 ? ~(uint64_t)bits : ((uint64_t)bits | 0x8000000000000000ull);
   return ~asc;
 }
-// slice b = groups [b·per, (b+1)·per): best[b] = smallest descending key of its groups with rows (~0: none)
-__global__ __launch_bounds__(256) void hj_topk_slice_best_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t per, uint64_t *best,
-                                                                  unsigned long long *n_groups) {
-  __shared__ uint64_t wave_best[4];
-  __shared__ uint32_t wave_count[4];
+// ---- top-k by selection in two launches (join.hpp: hj_launch_topk_select2) ---------------------------------------------
+// state words: [0] bound, [1] candidate counter (u32), [2] groups with rows, [3] / [4] workgroups done with launch 1 / 2
+// What a workgroup leaves for the last one travels as agent-scope atomic stores (they go to the point all XCDs share),
+// is read back with agent-scope atomic loads, and is acknowledged before the ticket is taken: no fence — on this
+// multi-die part a device-scope release / acquire writes back / invalidates a whole L2, per wave.
+__device__ __forceinline__ bool last_workgroup(uint32_t *done) {
+  __shared__ bool last;
+  __builtin_amdgcn_s_waitcnt(0); // this thread's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  return last;
+}
+// Both launches: one 1024-thread workgroup per slice (as much in flight as 4× the workgroups, a quarter of the tickets).
+__global__ __launch_bounds__(1024) void hj_topk_bound_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t per, uint32_t want, uint64_t *best,
+                                                              uint64_t *state) {
+  __shared__ uint64_t wave_best[16];
+  __shared__ uint32_t wave_count[16];
+  __shared__ uint64_t v[kTopkSlices];
+  const uint32_t t = threadIdx.x;
   const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   uint64_t mine = ~0ull;
   uint32_t have = 0;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
-    if (counts[i] == 0) continue;
-    ++have;
-    const uint64_t k = desc_order_key(sums[i]);
-    mine = k < mine ? k : mine;
+  for (uint64_t i0 = lo + t; i0 < hi; i0 += 1024 * 4) { // four groups in flight (a sum without rows is read, never used)
+    uint64_t c[4];
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * 1024;
+      c[u] = i < hi ? counts[i] : 0;
+      x[u] = i < hi ? sums[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c[u] == 0) continue;
+      ++have;
+      const uint64_t k = desc_order_key(x[u]);
+      mine = k < mine ? k : mine;
+    }
   }
   for (int o = 32; o; o >>= 1) {
     const uint64_t other = __shfl_xor(mine, o);
     mine = other < mine ? other : mine;
     have += __shfl_xor(have, o);
   }
-  if ((threadIdx.x & 63) == 0) { wave_best[threadIdx.x >> 6] = mine; wave_count[threadIdx.x >> 6] = have; }
+  if ((t & 63) == 0) { wave_best[t >> 6] = mine; wave_count[t >> 6] = have; }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (t == 0) {
     uint64_t b = wave_best[0];
     uint32_t c = wave_count[0];
-    for (int w = 1; w < 4; ++w) { b = wave_best[w] < b ? wave_best[w] : b; c += wave_count[w]; }
-    best[blockIdx.x] = b;
-    if (c) atomicAdd(n_groups, (unsigned long long)c);
+    for (int w = 1; w < 16; ++w) { b = wave_best[w] < b ? wave_best[w] : b; c += wave_count[w]; }
+    __hip_atomic_store(&best[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&best[kTopkSlices + blockIdx.x], (uint64_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!last_workgroup(reinterpret_cast<uint32_t *>(state + 3))) return;
+  // the last workgroup (its first 256 threads hold values): the slices' best keys in ascending order (one per thread; partners
+  // within a wave trade through the lanes, the others through the LDS), the want-th is the bound
+  uint64_t a = t < gridDim.x ? __hip_atomic_load(&best[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+  uint64_t groups = t < gridDim.x ? __hip_atomic_load(&best[kTopkSlices + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  for (uint32_t k = 2; k <= kTopkSlices; k <<= 1)
+    for (uint32_t j = k >> 1; j; j >>= 1) {
+      uint64_t b = a;
+      if (j >= 64) {
+        if (t < kTopkSlices) v[t] = a;
+        __syncthreads();
+        if (t < kTopkSlices) b = v[t ^ j];
+        __syncthreads();
+      } else {
+        b = __shfl_xor(a, (int)j);
+      }
+      const bool up = (t & k) == 0, lower = (t & j) == 0;
+      const uint64_t mn = a < b ? a : b, mx = a < b ? b : a;
+      a = lower == up ? mn : mx;
+    }
+  for (int o = 32; o; o >>= 1) groups += __shfl_xor(groups, o);
+  if ((t & 63) == 0 && t < kTopkSlices) v[t >> 6] = groups;
+  __syncthreads();
+  if (t == want - 1) state[0] = a;
+  if (t == 0) {
+    state[2] = v[0] + v[1] + v[2] + v[3];
+    state[3] = 0; // ready for the next call
   }
 }
-// one workgroup: *threshold = want-th smallest of best[0..n_slices) (n_slices ≤ 1024; ~0 when fewer slices have groups)
-__global__ __launch_bounds__(1024) void hj_topk_threshold_kernel(const uint64_t *best, uint32_t n_slices, uint32_t want, uint64_t *threshold) {
-  __shared__ uint64_t v[1024];
-  const uint32_t t = threadIdx.x;
-  v[t] = t < n_slices ? best[t] : ~0ull;
-  __syncthreads();
-  for (uint32_t k = 2; k <= 1024; k <<= 1)
-    for (uint32_t j = k >> 1; j; j >>= 1) { // bitonic sort, ascending
-      const uint32_t other = t ^ j;
-      if (other > t) {
-        const bool up = (t & k) == 0;
-        const uint64_t a = v[t], b = v[other];
-        if ((a > b) == up) { v[t] = b; v[other] = a; }
-      }
-      __syncthreads();
+__global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t *state, uint32_t cap, uint32_t *groups,
+                                                                const uint64_t *dim_rows, CandidateCols cols, uint64_t *host_out, GatherItems extra, uint32_t *extra_host) {
+  const uint64_t bound = state[0];
+  uint32_t *counter = reinterpret_cast<uint32_t *>(state + 1);
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 4096 + threadIdx.x; i0 < n; i0 += (uint64_t)gridDim.x * 4096) {
+    uint64_t c[4];
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * 1024;
+      c[u] = i < n ? counts[i] : 0;
+      x[u] = i < n ? sums[i] : 0.0;
     }
-  if (t == 0) *threshold = v[want - 1 < 1023 ? want - 1 : 1023];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c[u] == 0 || desc_order_key(x[u]) > bound) continue;
+      const uint32_t at = atomicAdd(counter, 1u);
+      if (at < cap) __hip_atomic_store(&groups[at], (uint32_t)(i0 + (uint64_t)u * 1024), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (!last_workgroup(reinterpret_cast<uint32_t *>(state + 4))) return;
+  const uint32_t total = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t n_rec = total < cap ? total : cap;
+  auto to_host = [](uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+  if (threadIdx.x < 8) to_host(&host_out[threadIdx.x], threadIdx.x == 0 ? bound : threadIdx.x == 1 ? total : threadIdx.x == 2 ? state[2] : 0);
+  for (uint32_t r = threadIdx.x; r < n_rec; r += 1024) {
+    uint64_t *o = host_out + 8 + (uint64_t)r * 8;
+    const uint32_t g = __hip_atomic_load(&groups[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t owner = dim_rows[g];
+    to_host(&o[0], g);
+    to_host(&o[1], (uint64_t)load_key(cols.key, owner));
+    to_host(&o[2], (uint64_t)__double_as_longlong(sums[g]));
+    to_host(&o[3], counts[g]);
+    for (uint32_t k = 0; k < 4; ++k) to_host(&o[4 + k], k < cols.n_payload ? (uint64_t)load_key(cols.payload[k], owner) : 0);
+  }
+  readback_gather(extra, extra_host);
+  __syncthreads();
+  if (threadIdx.x == 0) { state[1] = 0; state[4] = 0; } // ready for the next call
 }
-__global__ __launch_bounds__(256) void hj_topk_collect_kernel(const double *sums, const uint64_t *counts, uint64_t n, const uint64_t *threshold, uint32_t cap,
-                                                               uint32_t *groups, uint32_t *counter) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || counts[i] == 0) return;
-  if (desc_order_key(sums[i]) > *threshold) return;
-  const uint32_t at = atomicAdd(counter, 1u);
-  if (at < cap) groups[at] = (uint32_t)i;
-}
-__global__ __launch_bounds__(128) void hj_gather_collected_kernel(const uint32_t *groups, const uint32_t *counter, uint32_t cap, const uint64_t *dim_rows,
-                                                                   const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols, uint64_t *out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cap || i >= *counter) return;
-  uint64_t *o = out + (uint64_t)i * 8;
-  const uint32_t g = groups[i];
-  const uint64_t owner = dim_rows[g];
-  o[0] = g;
-  o[1] = (uint64_t)load_key(cols.key, owner);
-  o[2] = (uint64_t)__double_as_longlong(sum_by_group[g]);
-  o[3] = count_by_group[g];
-  for (uint32_t k = 0; k < 4; ++k) o[4 + k] = k < cols.n_payload ? (uint64_t)load_key(cols.payload[k], owner) : 0;
-}
-hipError_t hj_launch_topk_select(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
-                                 uint64_t *best /*[1024]*/, uint64_t *state /*[3] zeroed: threshold, candidates (u32), groups*/,
-                                 uint32_t *groups /*[cap]*/, uint64_t *out /*[cap][8]*/, hipStream_t s) {
-  if (n == 0) return hipSuccess;
-  const uint64_t per = (n + 1023) / 1024; // as many slices as the threshold kernel sorts: the bound is tightest
+hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
+                                  uint64_t *best, uint64_t *state, uint32_t *groups, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
+                                  hipStream_t s) {
+  if (n == 0 || want == 0 || want > kTopkSlices) return hipErrorInvalidValue;
+  const uint64_t per = (n + kTopkSlices - 1) / kTopkSlices;
   const uint32_t n_slices = (uint32_t)((n + per - 1) / per);
-  if (want > 1024) want = 1024;
-  hipLaunchKernelGGL(hj_topk_slice_best_kernel, dim3(n_slices), dim3(256), 0, s, sums, counts, n, per, best, (unsigned long long *)(state + 2));
-  hipLaunchKernelGGL(hj_topk_threshold_kernel, dim3(1), dim3(1024), 0, s, best, n_slices, want, state);
-  hipLaunchKernelGGL(hj_topk_collect_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, sums, counts, n, state, cap, groups, (uint32_t *)(state + 1));
-  hipLaunchKernelGGL(hj_gather_collected_kernel, dim3((cap + 127) / 128), dim3(128), 0, s, groups, (const uint32_t *)(state + 1), cap, dim_rows, sums, counts, cols, out);
+  hipLaunchKernelGGL(hj_topk_bound_kernel, dim3(n_slices), dim3(1024), 0, s, sums, counts, n, per, want, best, state);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 4095) / 4096, 256);
+  hipLaunchKernelGGL(hj_topk_collect2_kernel, dim3(grid), dim3(1024), 0, s, sums, counts, n, state, cap, groups, dim_rows, cols, host_out, extra, extra_host);
   return hipGetLastError();
 }
 

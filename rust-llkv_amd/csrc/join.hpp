@@ -72,6 +72,26 @@ hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t 
 // Fills `bytes` (rounded up to 16; the block must be 16-byte aligned and that large) with a 64-bit pattern.
 hipError_t hj_launch_fill(void *p, uint64_t bytes, uint64_t pattern, hipStream_t s);
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
+// Up to four zero fills in one launch (same alignment rule).
+struct FillRanges {
+  void *p[4];
+  uint64_t bytes[4];
+  int n = 0;
+  void add(void *ptr, uint64_t b) { if (b) { p[n] = ptr; bytes[n] = b; ++n; } }
+};
+hipError_t hj_launch_fill_zero_ranges(const FillRanges &r, hipStream_t s);
+
+// Small device → pinned-host copies carried by one workgroup (Readback, engine.hpp): item i = words[i] 32-bit words from
+// src[i] to host word dst_word[i].
+// When seq != 0 the workgroup finally stores seq into host word flag_word: the host may poll that word instead of
+// synchronising the stream.
+struct GatherItems {
+  const uint32_t *src[8];
+  uint32_t dst_word[8], words[8];
+  int n;
+  uint32_t flag_word, seq;
+};
+hipError_t hj_launch_readback_gather(const GatherItems &g, uint32_t *host, hipStream_t s);
 
 // Cross product of two row windows, left-major (cross_join_pair llkv-join/src/cartesian.rs:22-80):
 // pair i = (l0 + i / rn, r0 + i % rn).
@@ -115,6 +135,8 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
                                   uint64_t *count_by_slot, hipStream_t s);
 // The same over unsorted pairs: runs are summed where they lie; *multi_run is set when a group has two runs
 // (count_by_group must start at zero) — the caller then sorts.
+hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
+                                  uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s);
 hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64_t n, double *sum_by_group, uint64_t *count_by_group,
                               uint32_t *multi_run, hipStream_t s);
 hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots,
@@ -147,7 +169,7 @@ hipError_t hj_launch_compact_stripes2(const uint64_t *stripe_a, const uint64_t *
 // The same, and bit (key − kmin) of every selected row is set in `bits` (a duplicate raises *dup_flag).
 hipError_t hj_launch_compact_stripes2_bits(const uint64_t *stripe_a, const uint64_t *stripe_b, const uint64_t *counts, const uint64_t *offsets, uint32_t n_slots,
                                            uint32_t stripe, uint64_t *out_a, uint64_t *out_b, const void *key_values, uint32_t key_width, uint32_t key_signed,
-                                           long long kmin, unsigned long long *bits, uint32_t *dup_flag, hipStream_t s);
+                                           long long kmin, unsigned long long *bits, uint32_t *unsorted_flag, hipStream_t s);
 // Direct-address form of a dim table whose key range is bounded by the column statistics: bit (key − kmin) set for
 // every listed row (*dup_flag when a key occurs twice; dev_rows == nullptr lists rows 0..n−1), per-word popcounts →
 // exclusive scan = rank of each word's first set bit, group_of_rank[rank(key of listed row i)] = i.
@@ -155,9 +177,11 @@ hipError_t hj_launch_compact_stripes2_bits(const uint64_t *stripe_a, const uint6
 hipError_t hj_launch_bitmap_build(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, unsigned long long *bits,
                                   uint32_t *dup_flag, hipStream_t s);
 hipError_t hj_launch_popc_words(const uint64_t *bits, uint64_t n_words, uint32_t *out, hipStream_t s);
+hipError_t hj_exclusive_scan_popc(void *tmp, size_t *tmp_bytes, const uint64_t *bits, uint32_t *out, uint64_t n_words, hipStream_t s);
 hipError_t hj_exclusive_scan_u32(void *tmp, size_t *tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s);
 hipError_t hj_launch_bitmap_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, const uint64_t *bits,
-                                   const uint32_t *prefix, uint32_t *group_of_rank, hipStream_t s);
+                                   const uint32_t *prefix, uint64_t n_words, const uint32_t *unsorted /*optional: zero = rank is the list index, nothing to write*/,
+                                   uint32_t *dup_flag /*optional: raised when the bitmap holds fewer bits than n*/, uint32_t *group_of_rank, hipStream_t s);
 // flags[i] = 1 when the group of sorted pair i has rows on another rank too (local count ≠ global count).
 hipError_t hj_launch_straddler_flags(const uint32_t *sorted_group, uint64_t n, const uint64_t *local_cnt, const int64_t *global_cnt,
                                      uint64_t *flags, hipStream_t s);
@@ -169,13 +193,18 @@ hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, co
                                   uint64_t *report, hipStream_t s);
 // gather_candidates for group ids: owner row = dim_rows[group].
 // (`sorted_keys` may be nullptr: the key of candidate i is then `keys_by_group[sorted_groups[i]]`.)
-// Top-k by selection: the groups are cut into ≤ 1024 slices, each reports its best order key; the want-th best of
-// those bounds the final top `want` from below, and the groups that reach it (in no particular order, at most `cap`
-// of them; state[1] = how many qualified) come back as candidate records {group, dim key, sum bits, count,
-// payload[4]}.  state[2] += groups that have rows.
-hipError_t hj_launch_topk_select(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
-                                 uint64_t *best /*[1024]*/, uint64_t *state /*[3] zeroed: threshold, candidates (u32), groups*/,
-                                 uint32_t *groups /*[cap]*/, uint64_t *out /*[cap][8]*/, hipStream_t s);
+// Top-k by selection: the groups are cut into slices, each reports its best order key; the want-th best of those
+// bounds the final top `want` from below, and the groups that reach it (in no particular order, at most `cap` of them)
+// come back as candidate records {group, dim key, sum bits, count, payload[4]}.
+// Two launches, nothing to zero per call and the answer written to the host by the second one: the groups
+// are cut into kTopkSlices slices; the last workgroup of the first launch orders the slices' best keys and leaves the
+// bound; the last workgroup of the second launch writes {bound, candidates, groups with rows, 0…}[8] and the candidate
+// records ([min(candidates, cap)][8]) to `host_out` (pinned, device-visible) and carries the `extra` read-back items.
+// `state`: 8 words, zero before the first use (the kernels leave it zero); `best`: 2 · kTopkSlices words.  want ≤ kTopkSlices.
+constexpr uint32_t kTopkSlices = 256;
+hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
+                                  uint64_t *best, uint64_t *state, uint32_t *groups /*[cap]*/, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
+                                  hipStream_t s);
 hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s);
 hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,

@@ -67,23 +67,27 @@ struct HashSet {
 constexpr uint64_t kMaxDirectSpan = 1ull << 30; // 128 MiB of bits + 64 MiB of word ranks at most
 struct DirectTable {
   DB bits, prefix, group, tmp;
-  uint32_t *flag_p = nullptr; // device words behind the bitmap: [0] non-zero when a key occurred twice, [1] predicate error of a key-bits scan
+  // device words behind the bitmap: [0] non-zero when a key occurred twice, [1] predicate error of a key-bits scan,
+  // [2] non-zero when the list the bitmap was filled from (BitmapSink) is not in ascending key order
+  uint32_t *flag_p = nullptr;
+  bool from_sink = false;
   uint64_t n_words = 0;
   int64_t kmin = 0;
   uint64_t span = 0;
   static bool usable(const ColumnInfo &ci) {
     return ci.has_stats && ci.max_i >= ci.min_i && (uint64_t)ci.max_i - (uint64_t)ci.min_i < kMaxDirectSpan;
   }
-  // The zeroed bitmap (and the duplicate flag behind it): launches only.
-  int prepare_bits(const ColumnInfo &ci, hipStream_t s) {
+  // The bitmap (and the duplicate flag behind it); `fill`: the caller's zero fill takes it along, else zeroed here.
+  int prepare_bits(const ColumnInfo &ci, hipStream_t s, FillRanges *fill = nullptr) {
     kmin = ci.min_i;
     span = (uint64_t)ci.max_i - (uint64_t)ci.min_i;
     n_words = (span / 64 + 1 + 511) / 512 * 512;
     // the duplicate flag and one error word live right behind the bitmap: one allocation, one fill
-    int rc = bits.alloc(n_words * 8 + 16);
+    int rc = bits.alloc(n_words * 8 + 32);
     if (rc) return rc;
     flag_p = reinterpret_cast<uint32_t *>(static_cast<char *>(bits.p) + n_words * 8);
-    HIP_TRY(hj_launch_fill(bits.p, n_words * 8 + 16, 0, s));
+    if (fill) fill->add(bits.p, n_words * 8 + 32);
+    else HIP_TRY(hj_launch_fill(bits.p, n_words * 8 + 32, 0, s));
     return LLKV_OK;
   }
   // Launches only (no host synchronisation): *flag_p is non-zero afterwards when a key occurred twice.
@@ -92,15 +96,17 @@ struct DirectTable {
   int build(const ColumnInfo &ci, const JoinKeyColumn &key, const uint64_t *d_rows, uint64_t n, bool with_groups, hipStream_t s, bool bits_done = false) {
     int rc;
     if (!bits.p && (rc = prepare_bits(ci, s))) return rc;
+    from_sink = bits_done;
     if (!bits_done) HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, flag_p, s));
     if (with_groups) {
       size_t tb = 0;
       if ((rc = prefix.alloc(n_words * 4)) || (rc = group.alloc((n ? n : 1) * 4))) return rc;
-      HIP_TRY(hj_launch_popc_words((const uint64_t *)bits.p, n_words, (uint32_t *)prefix.p, s));
-      HIP_TRY(hj_exclusive_scan_u32(nullptr, &tb, (const uint32_t *)prefix.p, (uint32_t *)prefix.p, n_words, s));
+      HIP_TRY(hj_exclusive_scan_popc(nullptr, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words, s));
       if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
-      HIP_TRY(hj_exclusive_scan_u32(tmp.p, &tb, (const uint32_t *)prefix.p, (uint32_t *)prefix.p, n_words, s));
-      HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, (uint32_t *)group.p, s));
+      HIP_TRY(hj_exclusive_scan_popc(tmp.p, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words, s));
+      // a bitmap filled by the sink: duplicates show as missing bits, and a list in key order needs no rank → index table
+      HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, n_words, from_sink ? flag_p + 2 : nullptr,
+                                      from_sink ? flag_p : nullptr, (uint32_t *)group.p, s));
     }
     return LLKV_OK;
   }
@@ -137,20 +143,33 @@ struct JoinAgg {
   DB group_state;                    // one block, one memset:
   View sums, cnts, gcnts, report;    // per group: local f64 sum, local rows, exchanged rows (int64), rows this rank reports
   DB s_group, s_val;                 // local (group, value) pairs sorted by group, row order within a group
+  DB e_group, e_val;                 // … as emitted (row order), until settle() has looked at the run flag
   uint64_t n_pairs = 0;
+  // what prepare() reads back: queued behind its launches and, when deferred, delivered together with the top-k read-back
+  Readback rb;
+  bool pending = false;
+  // … and their device sources, alive until then
+  DirectTable set2_bits, dt;
+  DB counts, offsets;
+  DB zeros;                          // one zeroed block: [0] the run flag, [8..15] the top-k selection's state words
+  uint32_t *multi_p() const { return static_cast<uint32_t *>(zeros.p); }
+  uint64_t *topk_state() const { return static_cast<uint64_t *>(zeros.p) + 8; }
+  uint32_t dup_keys = 0, key_err = 0, multi_run = 0;
+  size_t state_bytes = 0;
   std::vector<uint32_t> st_groups;   // straddler pairs of this rank (host)
   std::vector<double> st_vals;
   bool have_straddlers = false;
 
   int prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
-              const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len);
+              const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len, bool defer = false);
+  int settle(bool delivered = false);
   int straddlers();
   int candidates(const uint32_t *f_groups, const double *f_sums, const uint64_t *f_counts, const uint32_t *f_first_rank, uint64_t n_folded,
                  uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups);
 };
 
 int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
-                     const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len) {
+                     const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len, bool defer) {
   int rc = ensure_device();
   if (rc) return rc;
   if (!fact || !dim || !fact->table || !dim->table) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
@@ -167,15 +186,31 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   // dim2's key range bounded by its statistics → the semi join is one more conjunct of dim's selection (a bit
   // test); otherwise: hash set of dim2's keys, flags over dim's selection, compaction
   HashSet set2;
-  DirectTable set2_bits;
-  JoinKeyColumn k2{}, fk{};
+  JoinKeyColumn k2{}, fk{}, kd{};
   bool fused_semi = false;
   std::string err;
   uint32_t *key_err_flag = nullptr; // device word the key-bits scan raises on a predicate arithmetic error (lives in set2_bits)
+  if (t2 && ((rc = int_key_column(t2, dim2->key_field, &k2)) || (rc = int_key_column(td, dim_fk_field, &fk)))) return rc;
+  if ((rc = int_key_column(td, dim->key_field, &kd))) return rc;
+  const ColumnInfo &kd_info = td->cols.find(dim->key_field)->second.info;
+  const bool direct = DirectTable::usable(kd_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
+  if (t2) fused_semi = DirectTable::usable(t2->cols.find(dim2->key_field)->second.info) && !std::getenv("LLKV_HIP_JOIN_HASH");
+  const bool sink_bits = fused_semi && direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK"); // dim's bitmap is filled while its selection is compacted
+  // ---- everything that starts from zero, in one fill: the key bitmaps, the probe's per-stripe counts, the flags --------
+  const TileSet *ts = nullptr;
+  if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
+  const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
+  {
+    FillRanges fr;
+    if (fused_semi && (rc = set2_bits.prepare_bits(t2->cols.find(dim2->key_field)->second.info, s, &fr))) return rc;
+    if (sink_bits && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
+    if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8)) || (rc = zeros.alloc(256))) return rc;
+    fr.add(counts.p, (size_t)(n_slots + 1) * 8); // the extra trailing 0 makes offsets[n_slots] the total
+    fr.add(zeros.p, 256);
+    HIP_TRY(hj_launch_fill_zero_ranges(fr, s));
+  }
   if (t2) {
-    if ((rc = int_key_column(t2, dim2->key_field, &k2)) || (rc = int_key_column(td, dim_fk_field, &fk))) return rc;
     const ColumnInfo &k2_info = t2->cols.find(dim2->key_field)->second.info;
-    fused_semi = DirectTable::usable(k2_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
     bool bits_set = false;
     if (fused_semi && k2_info.dtype == LLKV_DT_INT64 && t2->local_rows) {
       // the key set straight from dim2's scan: rows that pass set their bit — no selection vector, no read-back
@@ -192,7 +227,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
       const TileSet *ts2 = nullptr;
       if (lower_emit(resolve_2, dim2->filters, dim2->n_filters, nullptr, 0, &key_tok, 1, &kp, &err) == LLKV_OK &&
           jit_compile(JitKind::KeyBits, kp.type_string, &kk, &err) == LLKV_OK) {
-        if ((rc = set2_bits.prepare_bits(k2_info, s)) || (rc = get_tileset(*t2, 8192, &ts2))) return rc;
+        if ((rc = get_tileset(*t2, t2->local_rows < (4u << 20) ? 2048 : 8192, &ts2))) return rc;
         if (!kp.always_false) {
           ScanParams p2;
           std::memset(&p2, 0, sizeof p2);
@@ -224,11 +259,6 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     }
   }
   // dim's own table: when the statistics bound its key, the bitmap is filled while the selection is compacted
-  JoinKeyColumn kd{};
-  if ((rc = int_key_column(td, dim->key_field, &kd))) return rc;
-  const ColumnInfo &kd_info = td->cols.find(dim->key_field)->second.info;
-  const bool direct = DirectTable::usable(kd_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
-  DirectTable dt;
   bool dt_bits_done = false;
   if (fused_semi) {
     auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
@@ -239,12 +269,11 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     if ((rc = lower_selection_in_set(resolve_d, dim->filters, dim->n_filters, dim_fk_field, &sel_plan, &err))) return set_error(rc, err);
     const KeySetView view{(const uint64_t *)set2_bits.bits.p, set2_bits.kmin, set2_bits.span};
     BitmapSink sink{};
-    if (direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK")) {
-      if ((rc = dt.prepare_bits(kd_info, s))) return rc;
-      sink = BitmapSink{kd.values, kd.width, kd.is_signed, dt.kmin, (unsigned long long *)dt.bits.p, dt.flag_p};
+    if (sink_bits) {
+      sink = BitmapSink{kd.values, kd.width, kd.is_signed, dt.kmin, (unsigned long long *)dt.bits.p, dt.flag_p + 2};
       dt_bits_done = true;
     }
-    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, 1, dt_bits_done ? &sink : nullptr))) return rc; // the bit test gathers: evaluate it once
+    if ((rc = run_selection_lowered(td, sel_plan, &seld, &view, 1, dt_bits_done ? &sink : nullptr, false))) return rc; // the bit test gathers: evaluate it once
   } else if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) {
     return rc;
   }
@@ -267,13 +296,15 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   }
   if (n_dim >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "dimension too large");
   if (n_dim == 0) return LLKV_OK;
-  const size_t state_bytes = (n_dim * 8 + 4095) / 4096 * 4096; // whole pages: the memset is one fill kernel
+  state_bytes = (n_dim * 8 + 4095) / 4096 * 4096; // whole pages: the memset is one fill kernel
   if ((rc = group_state.alloc(4 * state_bytes))) return rc;
   sums.p = group_state.p;
   cnts.p = (char *)group_state.p + state_bytes;
   gcnts.p = (char *)group_state.p + 2 * state_bytes;
   report.p = (char *)group_state.p + 3 * state_bytes;
-  HIP_TRY(hj_launch_fill(group_state.p, 3 * state_bytes, 0, s));
+  // one rank: only the row counts start from zero (a sum is read only where the count is not zero)
+  if (tf->world == 1) HIP_TRY(hj_launch_fill(cnts.p, state_bytes, 0, s));
+  else HIP_TRY(hj_launch_fill(group_state.p, 3 * state_bytes, 0, s));
 
   // ---- dim hash table, slot → group id -----------------------------------------------------
   std::memset(&cc, 0, sizeof cc);
@@ -306,12 +337,6 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   if (plan.always_false || tf->local_rows == 0) { HIP_TRY(hipStreamSynchronize(s)); return LLKV_OK; }
   JitKernel k;
   if ((rc = jit_compile(JitKind::Probe, plan.type_string, &k, &err))) return set_error(rc, err);
-  const TileSet *ts = nullptr;
-  if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
-  const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
-  DB counts, offsets;
-  if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8))) return rc;
-  HIP_TRY(hj_launch_fill(counts.p, (size_t)(n_slots + 1) * 8, 0, s)); // the extra trailing 0 makes offsets[n_slots] the total
   ScanParams p;
   std::memset(&p, 0, sizeof p);
   for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = slot_buffer(tf->cols, plan, i);
@@ -325,6 +350,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     p.bm_bits = (const uint64_t *)dt.bits.p;
     p.bm_prefix = (const uint32_t *)dt.prefix.p;
     p.bm_group = (const uint32_t *)dt.group.p;
+    p.bm_unsorted = dt.from_sink ? dt.flag_p + 2 : nullptr;
     p.bm_min = dt.kmin;
     p.bm_span = dt.span;
   } else {
@@ -344,47 +370,59 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   p.aux_out = (uint64_t *)st_val.p;
   if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
   DB scan_tmp;
-  if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
-  uint32_t dup_keys = 0, key_err = 0;
-  Readback rb;
-  if ((rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) ||
-      (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) || (rc = rb.wait()))
-    return rc;
-  if (key_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
-  if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
-  if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
-  if (n_pairs == 0) return LLKV_OK;
-  DB e_group, e_val;
-  if ((rc = e_group.alloc(n_pairs * 4)) || (rc = e_val.alloc(n_pairs * 8)) || (rc = s_group.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;
+  if (n_slots <= 64 * 1024) HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, s)); // one workgroup, rounds of 8 192
+  else if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
+  // No host round trip between the probe and the sums: the compaction and the run sums take the pair count where the
+  // scan left it (offsets[n_slots], device), the pair arrays are sized by the bound (one pair per local fact row).
+  const uint64_t max_pairs = tf->local_rows;
+  if ((rc = e_group.alloc(max_pairs * 4)) || (rc = e_val.alloc(max_pairs * 8))) return rc;
   HIP_TRY(hj_launch_compact_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p, n_slots, stripe,
                                     direct ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
   // ---- per-group sums in scan order ------------------------------------------------------------
   // The pairs are in row order.  A fact table clustered by the join key leaves every group as ONE run of them: sum
   // the runs where they lie; only when some group turns out to have a second run, sort (stable) by group first.
-  DB multi;
-  if ((rc = multi.alloc(16))) return rc;
-  HIP_TRY(hj_launch_fill(multi.p, 16, 0, s));
-  HIP_TRY(hj_launch_run_sums((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, (uint32_t *)multi.p, s));
-  uint32_t multi_run = 0;
-  if (tf->world != 1) HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
-  if ((rc = rb.add(&multi_run, multi.p, 4, s)) || (rc = rb.wait())) return rc;
+  HIP_TRY(hj_launch_run_sums_dev((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, (const uint64_t *)offsets.p + n_slots, max_pairs, (double *)sums.p,
+                                 (uint64_t *)cnts.p, multi_p(), s));
+  if ((rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) ||
+      (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) || (rc = rb.add(&multi_run, multi_p(), 4, s)))
+    return rc;
+  pending = true;
+  if (defer) return LLKV_OK; // the sources are members: the selection's last workgroup carries the items
+  return settle();
+}
+
+// The read-back of prepare(): errors, and the sort-based sums when some group's pairs were not one run.
+// `delivered`: the caller has waited on `rb` already.
+int JoinAgg::settle(bool delivered) {
+  if (!pending) return LLKV_OK;
+  int rc;
+  if (!delivered && (rc = rb.wait())) return rc;
+  pending = false;
+  hipStream_t s = g_ctx.stream;
+  if (key_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
+  if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
+  if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
+  if (n_pairs == 0) return LLKV_OK;
   if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
     std::swap(s_group.p, e_group.p); // a group's pairs are contiguous and in row order: all the later phases need
     std::swap(s_val.p, e_val.p);
+    if (tf->world != 1) HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
     return LLKV_OK;
-  } else {
-    uint32_t bits = 1;
-    while ((1ull << bits) < n_dim) ++bits;
-    DB tmp;
-    size_t tb = 0;
-    HIP_TRY(hj_launch_fill(group_state.p, 2 * state_bytes, 0, s)); // sums and counts again
-    HIP_TRY(hj_sort_u32_u64(nullptr, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
-    HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
-    HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); // tmp is released at the end of the block
   }
+  uint32_t bits = 1;
+  while ((1ull << bits) < n_dim) ++bits;
+  DB tmp;
+  size_t tb = 0;
+  if ((rc = s_group.alloc(n_pairs * 4)) || (rc = s_val.alloc(n_pairs * 8))) return rc;
+  HIP_TRY(hj_launch_fill(group_state.p, 2 * state_bytes, 0, s)); // sums and counts again
+  HIP_TRY(hj_sort_u32_u64(nullptr, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
+  if ((rc = tmp.alloc(tb))) return rc;
+  HIP_TRY(hj_sort_u32_u64(tmp.p, &tb, (const uint32_t *)e_group.p, (uint32_t *)s_group.p, (const uint64_t *)e_val.p, (uint64_t *)s_val.p, n_pairs, bits, s));
+  HIP_TRY(hj_launch_segment_sums((const uint32_t *)s_group.p, (const uint64_t *)s_val.p, n_pairs, (double *)sums.p, (uint64_t *)cnts.p, s));
+  HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s)); // tmp is released at the end of the block
+  e_group.alloc(8);
+  e_val.alloc(8);
   return LLKV_OK;
 }
 
@@ -428,6 +466,10 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   int rc;
   // groups this rank reports: the ones it alone holds … (one rank holds every group alone: its counts are the report)
   const bool alone = tf->world == 1 && n_folded == 0;
+  const bool by_selection = !std::getenv("LLKV_HIP_TOPK_SORT") && limit <= kTopkSlices;
+  // a deferred prepare(): its read-back rides with the selection's below; anything else needs it settled first
+  if (pending && !(alone && by_selection) && (rc = settle())) return rc;
+  if (!alone && tf->world == 1) HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // nobody else holds rows
   if (!alone) HIP_TRY(hj_launch_report_counts((const uint64_t *)cnts.p, (const int64_t *)gcnts.p, n_dim, (uint64_t *)report.p, s));
   const uint64_t *report_p = alone ? (const uint64_t *)cnts.p : (const uint64_t *)report.p;
   // … plus the straddlers it holds first, with their exact sums and global counts
@@ -452,24 +494,30 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   // ---- top-k by selection: the best keys of ≤ 1024 slices of the groups bound the LIMIT from below; the few groups
   // that reach the bound go to the host, which orders them exactly (sum DESC, payload[0], dim row).  More than kCap
   // of them (many equal sums) falls back to the sort below.
-  if (!std::getenv("LLKV_HIP_TOPK_SORT") && limit <= 1024) {
-    constexpr uint32_t kCap = 2048, kFirst = 256;
-    DB best, blk, groups_d; // blk = {threshold, candidates, groups, pad…}[8] then the candidate records
-    if ((rc = best.alloc(1024 * 8)) || (rc = blk.alloc(64 + (size_t)kCap * 64)) || (rc = groups_d.alloc(kCap * 4))) return rc;
-    uint64_t *state = (uint64_t *)blk.p, *recs = state + 8;
-    HIP_TRY(hj_launch_fill(state, 64, 0, s));
-    HIP_TRY(hj_launch_topk_select((const double *)sums.p, report_p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p,
-                                  state, (uint32_t *)groups_d.p, recs, s));
-    std::vector<uint64_t> hrec(8 + (size_t)kCap * 8); // one read-back: the head and the first records (all of them, usually)
-    Readback rb;
-    if ((rc = rb.add(hrec.data(), blk.p, 64 + (size_t)kFirst * 64, s)) || (rc = rb.wait())) return rc;
-    const uint64_t *head = hrec.data();
+  if (by_selection) {
+    constexpr uint32_t kCap = 960; // head + records fit the read-back slab
+    DB best, groups_d;
+    if ((rc = best.alloc(2 * kTopkSlices * 8)) || (rc = groups_d.alloc(kCap * 4))) return rc;
+    // two launches; the second one's last workgroup writes the head and the records into the read-back slab itself and
+    // carries the items a deferred prepare() left
+    void *slab = nullptr;
+    GatherItems extra;
+    uint32_t *slab_base = nullptr;
+    if ((rc = rb.reserve(nullptr, 64 + (size_t)kCap * 64, s, &slab)) || (rc = rb.take(&extra, &slab_base))) return rc;
+    HIP_TRY(hj_launch_topk_select2((const double *)sums.p, report_p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p, topk_state(),
+                                   (uint32_t *)groups_d.p, (uint64_t *)slab, extra, slab_base, s));
+    if ((rc = rb.wait())) return rc;
+    if (pending) {
+      if ((rc = settle(true))) return rc;
+      if (multi_run || std::getenv("LLKV_HIP_JOIN_SORT")) // the sums were made again: select again
+        return candidates(f_groups, f_sums, f_counts, f_first_rank, n_folded, rank, limit, out_rows, out_n, out_groups);
+    }
+    const uint64_t *head = static_cast<const uint64_t *>(slab);
     const uint32_t n_sel = (uint32_t)head[1];
     if (n_sel <= kCap) {
-      if (n_sel > kFirst) HIP_TRY(hipMemcpy(hrec.data() + 8 + (size_t)kFirst * 8, recs + (size_t)kFirst * 8, (size_t)(n_sel - kFirst) * 64, hipMemcpyDeviceToHost));
       std::vector<llkv_join_group_row> cand(n_sel);
       for (uint32_t i = 0; i < n_sel; ++i) {
-        const uint64_t *c = &hrec[8 + (size_t)i * 8];
+        const uint64_t *c = head + 8 + (size_t)i * 8;
         llkv_join_group_row &g = cand[i];
         g.group_index = (uint32_t)c[0];
         g.key = (int64_t)c[1];
@@ -720,7 +768,7 @@ llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_jo
   if (fact && fact->table && reinterpret_cast<const Table *>(fact->table)->world != 1)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "a sharded fact table needs the phased llkv_hip_join_agg_* calls (counts all-reduce, straddler exchange)");
   JoinAgg j;
-  int rc = j.prepare(fact, dim, dim_fk_field, dim2, payload_fields, n_payload, sum_expr, sum_expr_len);
+  int rc = j.prepare(fact, dim, dim_fk_field, dim2, payload_fields, n_payload, sum_expr, sum_expr_len, true);
   if (rc) return (llkv_status)rc;
   return (llkv_status)j.candidates(nullptr, nullptr, nullptr, nullptr, 0, 0, limit, out_rows, out_n, out_total_groups);
 }

@@ -1,6 +1,7 @@
 // memory.cpp — device scratch pool, recycled pinned host memory, result blocks, small read-backs and the
 // staging lanes (host ↔ HBM copies through pinned rings) of the MI355X path.
 #include "engine.hpp"
+#include "join.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -279,24 +280,87 @@ struct PinnedSlab {
   ~PinnedSlab() { if (p) (void)hipHostFree(p); }
 };
 thread_local PinnedSlab t_readback;
+thread_local uint32_t t_readback_seq = 0;
 } // namespace
 
+// One single-workgroup kernel carries every item of a read-back into the pinned (device-visible) slab: a blit copy per
+// item costs a dispatch of ~5 µs each.
 int Readback::add(void *host_dst, const void *device_src, size_t bytes, hipStream_t s) {
-  if (!t_readback.p) HIP_TRY(hipHostMalloc(&t_readback.p, kBytes, hipHostMallocDefault));
+  if (!t_readback.p) {
+    HIP_TRY(hipHostMalloc(&t_readback.p, kBytes + 64, hipHostMallocMapped | hipHostMallocCoherent)); // + the done word; fine-grained: polled while a kernel runs
+    std::memset(t_readback.p, 0, kBytes + 64);
+  }
   const size_t off = (used + 7) & ~(size_t)7;
   if (n == 8 || off + bytes > kBytes) return set_error(LLKV_INTERNAL, "read-back buffer exhausted");
-  HIP_TRY(hipMemcpyAsync((char *)t_readback.p + off, device_src, bytes, hipMemcpyDeviceToHost, s));
-  items[n++] = {host_dst, off, bytes};
+  if (stream && stream != s && launched != n) return set_error(LLKV_INTERNAL, "read-back items of two streams");
+  items[n++] = {host_dst, device_src, off, bytes};
   used = off + bytes;
   stream = s;
   return LLKV_OK;
 }
 
+int Readback::reserve(void *host_dst, size_t bytes, hipStream_t s, void **slab) {
+  int rc = add(host_dst, nullptr, bytes, s);
+  if (rc) return rc;
+  *slab = (char *)t_readback.p + items[n - 1].off;
+  return LLKV_OK;
+}
+
+int Readback::take(GatherItems *g, uint32_t **host) {
+  g->n = 0;
+  for (int i = launched; i < n; ++i) {
+    if (!items[i].src) continue; // written by a kernel of the caller
+    if ((items[i].bytes & 3) || ((uintptr_t)items[i].src & 3)) { // not made of aligned words: a copy of its own
+      HIP_TRY(hipMemcpyAsync((char *)t_readback.p + items[i].off, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, stream));
+      continue;
+    }
+    g->src[g->n] = static_cast<const uint32_t *>(items[i].src);
+    g->dst_word[g->n] = (uint32_t)(items[i].off / 4);
+    g->words[g->n] = (uint32_t)(items[i].bytes / 4);
+    ++g->n;
+  }
+  launched = n;
+  *host = static_cast<uint32_t *>(t_readback.p);
+  if (!std::getenv("LLKV_HIP_READBACK_SYNC")) {
+    if (++t_readback_seq == 0) ++t_readback_seq;
+    seq = t_readback_seq;
+  }
+  g->flag_word = (uint32_t)(kBytes / 4);
+  g->seq = seq;
+  return LLKV_OK;
+}
+
+int Readback::flush() {
+  if (launched == n) return LLKV_OK;
+  GatherItems g;
+  uint32_t *host = nullptr;
+  int rc = take(&g, &host);
+  if (rc) return rc;
+  HIP_TRY(hj_launch_readback_gather(g, host, stream));
+  return LLKV_OK;
+}
+
 int Readback::wait() {
-  if (n) HIP_TRY(hipStreamSynchronize(stream));
-  for (int i = 0; i < n; ++i) std::memcpy(items[i].dst, (const char *)t_readback.p + items[i].off, items[i].bytes);
-  n = 0;
+  int rc = flush();
+  if (rc) return rc;
+  if (n) {
+    bool seen = false;
+    if (seq) { // poll the done word for a while (a fault never delivers it: the synchronisation below reports that)
+      const volatile uint32_t *done = static_cast<const volatile uint32_t *>(t_readback.p) + kBytes / 4;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint32_t spins = 0; !(seen = *done == seq); ++spins) {
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(stream));
+  }
+  for (int i = 0; i < n; ++i)
+    if (items[i].dst) std::memcpy(items[i].dst, (const char *)t_readback.p + items[i].off, items[i].bytes); // (no dst: the caller reads the slab)
+  n = launched = 0;
   used = 0;
+  seq = 0;
   return LLKV_OK;
 }
 

@@ -90,6 +90,7 @@ struct ScanParams {
   const uint64_t *bm_bits;       // nullptr: hash table (ht_*)
   const uint32_t *bm_prefix;
   const uint32_t *bm_group;
+  const uint32_t *bm_unsorted;   // optional; *bm_unsorted == 0: the build list is in key order, the rank is the group id
   int64_t bm_min;
   uint64_t bm_span;              // max − min
 };

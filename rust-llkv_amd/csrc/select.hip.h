@@ -96,12 +96,13 @@ __device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
 }
 
 // direct addressing: group id of key k, or 0xFFFFFFFF (see ScanParams::bm_bits)
-__device__ __forceinline__ uint32_t bm_find(const ScanParams &p, long long k) {
+__device__ __forceinline__ uint32_t bm_find(const ScanParams &p, long long k, bool by_rank = false) {
   const uint64_t d = (uint64_t)k - (uint64_t)p.bm_min; // k < min wraps to a huge value
   if (d > p.bm_span) return 0xFFFFFFFFu;
   const uint64_t w = p.bm_bits[d >> 6], bit = 1ull << (d & 63);
   if (!(w & bit)) return 0xFFFFFFFFu;
-  return p.bm_group[p.bm_prefix[d >> 6] + __popcll(w & (bit - 1))];
+  const uint32_t rank = p.bm_prefix[d >> 6] + (uint32_t)__popcll(w & (bit - 1));
+  return by_rank ? rank : p.bm_group[rank];
 }
 
 template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
@@ -119,6 +120,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
   uint64_t count = 0;
   uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const bool by_rank = p.bm_unsorted && *p.bm_unsorted == 0; // (uniform) the build list is in key order: rank = group id
   for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
     Loaded lds[kSelUnroll];
 #pragma unroll
@@ -136,7 +138,7 @@ template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(c
         const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
         perr |= ((row0 + j) < sub1) ? c.perr : 0u;
         // probe only for surviving rows (the branch on the table form is uniform over the grid)
-        hit[j] = !pass ? 0xFFFFFFFFu : p.bm_bits ? bm_find(p, (long long)P::KeyE::eval(c, j)) : ht_find(p, (long long)P::KeyE::eval(c, j));
+        hit[j] = !pass ? 0xFFFFFFFFu : p.bm_bits ? bm_find(p, (long long)P::KeyE::eval(c, j), by_rank) : ht_find(p, (long long)P::KeyE::eval(c, j));
         f[j] = hit[j] != 0xFFFFFFFFu;
         val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
       }
@@ -229,25 +231,64 @@ template <class P> __device__ __forceinline__ void keybits_body(const ScanParams
   if (perr) atomicOr(p.aux_out32, perr);
 }
 
-// Exclusive scan of the per-(tile, wave) counts; one block, fixed order.  out[n] = total.
+// Exclusive scan of the per-(tile, wave) counts; one block, fixed order.  out[n] = total (+ kPredErrorBit when a count
+// carries the predicate-error mark: the offsets mean nothing then).
+// Rounds of 8 192 counts: coalesced loads (the next round's are in flight while this one is scanned) into the LDS as
+// 32-bit cells, every thread then owns 8 consecutive cells — a serial prefix in registers, ONE wave scan of the thread
+// sums, the 16 wave totals — and the prefixes go back through the LDS to coalesced stores.
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint64_t *in, uint64_t *out, uint32_t n) {
-  __shared__ uint64_t part[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t per = (n + 1023) / 1024;
-  const uint32_t b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
-  uint64_t s = 0;
-  for (uint32_t i = b; i < e; ++i) s += in[i];
-  part[t] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis–Steele inclusive scan
-    const uint64_t v = t >= off ? part[t - off] : 0;
+  constexpr uint32_t kPer = 8, kRound = 1024 * kPer;
+  __shared__ uint32_t cell[kRound];
+  __shared__ uint32_t wave_total[16];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint64_t base = 0;
+  uint32_t err = 0;
+  uint64_t next[kPer];
+#pragma unroll
+  for (uint32_t j = 0; j < kPer; ++j) next[j] = j * 1024 + t < n ? in[j * 1024 + t] : 0;
+  for (uint32_t r0 = 0; r0 < n; r0 += kRound) {
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+      err |= (next[j] >> 31) != 0 ? 1u : 0u; // real counts are rows of a stripe
+      cell[j * 1024 + t] = (uint32_t)next[j];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+      const uint64_t i = (uint64_t)r0 + kRound + j * 1024 + t;
+      next[j] = i < n ? in[i] : 0;
+    }
     __syncthreads();
-    part[t] += v;
+    uint32_t x[kPer], s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) { x[j] = cell[t * kPer + j]; s += x[j]; }
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(incl, o);
+      incl += lane >= (uint32_t)o ? u : 0;
+    }
+    if (lane == 63) wave_total[wave] = incl;
     __syncthreads();
+    uint32_t run = incl - s, round_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+      const uint32_t wt = wave_total[w];
+      run += w < wave ? wt : 0;
+      round_total += wt;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) { cell[t * kPer + j] = run; run += x[j]; }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+      const uint32_t i = r0 + j * 1024 + t;
+      if (i < n) out[i] = base + cell[j * 1024 + t];
+    }
+    base += round_total;
+    __syncthreads(); // the cells and the wave totals are reused
   }
-  uint64_t run = t ? part[t - 1] : 0;
-  for (uint32_t i = b; i < e; ++i) { out[i] = run; run += in[i]; }
-  if (t == 1023) out[n] = part[1023];
+  const int any_err = __syncthreads_or((int)err);
+  if (t == 0) out[n] = base + (any_err ? kPredErrorBit : 0);
 }
 
 // ---- window projection ---------------------------------------------------------------

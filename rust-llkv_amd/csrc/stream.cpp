@@ -44,7 +44,7 @@ int run_selection(const Table *t, const llkv_filter *filters, uint32_t n_filters
 }
 
 // The selection kernels of an already lowered predicate (prepared statements keep the plan).
-int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, int single_pass_mode, const BitmapSink *sink) {
+int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *sel, const KeySetView *key_set, int single_pass_mode, const BitmapSink *sink, bool sync) {
   if (sink && single_pass_mode != 1) return set_error(LLKV_INTERNAL, "a bitmap sink belongs to the single-pass selection");
   int rc;
   std::string err;
@@ -121,7 +121,7 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
   if (single_pass && sink) {
     HIP_TRY(hj_launch_compact_stripes2_bits((const uint64_t *)stripe_ids.p, (const uint64_t *)stripe_dev.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p,
                                             n_slots, p.sub_rows, sel->d_ids, sel->d_dev, sink->key_values, sink->key_width, sink->key_signed, sink->kmin, sink->bits,
-                                            sink->dup_flag, stream));
+                                            sink->unsorted_flag, stream));
   } else if (single_pass) {
     HIP_TRY(hj_launch_compact_stripes2((const uint64_t *)stripe_ids.p, (const uint64_t *)stripe_dev.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p,
                                        n_slots, p.sub_rows, sel->d_ids, sel->d_dev, stream));
@@ -131,7 +131,7 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
     p.aux_out2 = sel->d_dev;
     if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(stream));
+  if (sync) HIP_TRY(hipStreamSynchronize(stream)); // (the scratch blocks released on return are only handed to work on this same stream)
   return LLKV_OK;
 }
 

@@ -1692,6 +1692,56 @@ def test_join_pipeline_fallback_forms_give_the_same_rows(rt, abi, tpch, monkeypa
     assert bits(run()) == want
 
 
+def test_q3_chain_with_the_dimension_out_of_key_order_and_with_a_repeated_key(rt, abi, tpch):
+    """The orders bitmap is filled while the orders selection is compacted; a selection in key order makes a key's rank
+    among the set bits its group id (no rank → row table).  Orders in a random row order take the general form and
+    return the same rows; an order key that occurs twice among the selected rows is reported (the bitmap then holds
+    fewer bits than the selection has rows)."""
+    rows, scale = 150_000, 0.025
+    D = tpch.DATE_1995_03_15
+    li = tpch.gen_lineitem(rows, scale)
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    lt = rt.HipTable(1, tpch.chunk_rows(rows, 32768))
+    for c in ("l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"):
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
+    ct = rt.HipTable(3, [n_cust])
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]])
+    F, O, col = abi.Filter, abi.Operator, abi.col
+
+    def orders_table(cols, chunk):
+        t = rt.HipTable(2, tpch.chunk_rows(len(cols["o_orderkey"]), chunk))
+        for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+            t.append_column(fid, dt, cols[c])
+        return t
+
+    def run(ot_):
+        return rt.join_groupby_topk(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY,
+                                    col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT)), payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10,
+                                    dim_fk=tpch.O_CUSTKEY, dim2=ct, dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+
+    bits = lambda res: ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in res[0]], res[1])
+    want = bits(run(orders_table(od, 8192)))
+    assert len(want[0]) == 10
+    perm = np.random.default_rng(5).permutation(n_ord)
+    assert bits(run(orders_table({c: v[perm] for c, v in od.items()}, 8192))) == want
+    # one swap inside a stripe, one across two stripes (rows 2047 | 2048 are neighbours of different waves' stripes)
+    for a, b in ((10, 11), (2047, 2048)):
+        sw = {c: v.copy() for c, v in od.items()}
+        for v in sw.values():
+            v[[a, b]] = v[[b, a]]
+        assert bits(run(orders_table(sw, 8192))) == want
+    # a selected order twice
+    sel = np.flatnonzero((od["o_orderdate"] < D) & np.isin(od["o_custkey"], cu["c_custkey"][np.array(cu["c_mktsegment"]) == tpch.SEGMENTS.index("BUILDING")]))
+    twice = {c: np.concatenate([v, v[sel[:1]]]) for c, v in od.items()}
+    with pytest.raises(abi.LlkvError) as e:
+        run(orders_table(twice, 8192))
+    assert "not unique" in str(e.value)
+
+
 def test_sorted_input_shortcut_of_the_sort_based_group_by(rt, abi, monkeypatch):
     """GROUP BY a column that is in key order already (a clustered primary key) skips the sort; forcing the sort
     (LLKV_HIP_GROUP_ALWAYS_SORT) gives the same groups and the same bits — the stable sort leaves such rows where
