@@ -113,6 +113,28 @@ hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const
   return hipGetLastError();
 }
 
+// *flag |= 1 unless the real rows of the column (the tiles list them, in row order) are strictly ascending
+template <class T> __global__ __launch_bounds__(256) void ascending_check_kernel(const T *v, const TileDesc *tiles, uint32_t n_tiles, uint32_t *flag) {
+  const TileDesc td = tiles[blockIdx.x];
+  bool bad = false;
+  for (uint32_t r = threadIdx.x; r < td.rows; r += 256) {
+    uint64_t left = td.dev_row + r - 1;
+    if (r == 0) {
+      if (blockIdx.x == 0) continue;
+      const TileDesc before = tiles[blockIdx.x - 1]; // (no tile is empty)
+      left = before.dev_row + before.rows - 1;
+    }
+    bad |= !(v[left] < v[td.dev_row + r]);
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+hipError_t launch_ascending_check(const void *values, uint32_t width, const TileDesc *tiles, uint32_t n_tiles, uint32_t *flag, hipStream_t stream) {
+  if (n_tiles == 0) return hipSuccess;
+  if (width == 8) hipLaunchKernelGGL((ascending_check_kernel<int64_t>), dim3(n_tiles), dim3(256), 0, stream, (const int64_t *)values, tiles, n_tiles, flag);
+  else hipLaunchKernelGGL((ascending_check_kernel<int32_t>), dim3(n_tiles), dim3(256), 0, stream, (const int32_t *)values, tiles, n_tiles, flag);
+  return hipGetLastError();
+}
+
 hipError_t launch_minmax_i64(const int64_t *values, uint64_t n, int64_t *d_minmax, hipStream_t stream) {
   hipLaunchKernelGGL((minmax_kernel<int64_t>), dim3(1024), dim3(256), 0, stream, values, n, (long long *)d_minmax);
   return hipGetLastError();

@@ -52,6 +52,7 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_b(const ScanParams p) { emit_body<" + ts + ", true>(p); }\n";
     break;
   case JitKind::Probe:
+    // a = the hash-table form, b = the direct (bitmap + rank) form
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { probe_emit_body<" + ts + ", false>(p); }\n";
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_b(const ScanParams p) { probe_emit_body<" + ts + ", true>(p); }\n";
     break;

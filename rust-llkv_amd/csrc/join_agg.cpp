@@ -71,6 +71,7 @@ struct DirectTable {
   // [2] non-zero when the list the bitmap was filled from (BitmapSink) is not in ascending key order
   uint32_t *flag_p = nullptr;
   bool from_sink = false;
+  bool in_key_order = false; // known to the host (a selection from a strictly ascending column): rank = list index, no key twice
   uint64_t n_words = 0;
   int64_t kmin = 0;
   uint64_t span = 0;
@@ -100,12 +101,12 @@ struct DirectTable {
     if (!bits_done) HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, flag_p, s));
     if (with_groups) {
       size_t tb = 0;
-      if ((rc = prefix.alloc(n_words * 4)) || (rc = group.alloc((n ? n : 1) * 4))) return rc;
+      if ((rc = prefix.alloc(n_words * 4)) || (!in_key_order && (rc = group.alloc((n ? n : 1) * 4)))) return rc;
       HIP_TRY(hj_exclusive_scan_popc(nullptr, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words, s));
       if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
       HIP_TRY(hj_exclusive_scan_popc(tmp.p, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words, s));
       // a bitmap filled by the sink: duplicates show as missing bits, and a list in key order needs no rank → index table
-      HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, n_words, from_sink ? flag_p + 2 : nullptr,
+      if (!in_key_order) HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, n_words, from_sink ? flag_p + 2 : nullptr,
                                       from_sink ? flag_p : nullptr, (uint32_t *)group.p, s));
     }
     return LLKV_OK;
@@ -195,7 +196,12 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   const ColumnInfo &kd_info = td->cols.find(dim->key_field)->second.info;
   const bool direct = DirectTable::usable(kd_info) && !std::getenv("LLKV_HIP_JOIN_HASH");
   if (t2) fused_semi = DirectTable::usable(t2->cols.find(dim2->key_field)->second.info) && !std::getenv("LLKV_HIP_JOIN_HASH");
-  const bool sink_bits = fused_semi && direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK"); // dim's bitmap is filled while its selection is compacted
+  // dim's bitmap is filled while its selection is compacted (the keys of the selected rows are gathered once: that
+  // sparse gather is most of what building the table costs).  A key column in strictly ascending row order (staging
+  // statistic): the selection is in key order and has no key twice — a key's rank among the set bits is its group id;
+  // any other finds out about its order during the compaction.
+  const bool dim_sorted = direct && kd_info.ascending && !std::getenv("LLKV_HIP_JOIN_UNSORTED");
+  const bool sink_bits = fused_semi && direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK");
   // ---- everything that starts from zero, in one fill: the key bitmaps, the probe's per-stripe counts, the flags --------
   const TileSet *ts = nullptr;
   if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
@@ -204,6 +210,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     FillRanges fr;
     if (fused_semi && (rc = set2_bits.prepare_bits(t2->cols.find(dim2->key_field)->second.info, s, &fr))) return rc;
     if (sink_bits && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
+    dt.in_key_order = dim_sorted;
     if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8)) || (rc = zeros.alloc(256))) return rc;
     fr.add(counts.p, (size_t)(n_slots + 1) * 8); // the extra trailing 0 makes offsets[n_slots] the total
     fr.add(zeros.p, 256);
@@ -368,7 +375,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   p.aux_in = nullptr;
   p.aux_out32 = (uint32_t *)st_slot.p;
   p.aux_out = (uint64_t *)st_val.p;
-  if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, s))) return rc;
+  if ((rc = jit_launch_raw(direct ? k.fn2 : k.fn, ts->n_tiles, &p, sizeof p, s))) return rc;
   DB scan_tmp;
   if (n_slots <= 64 * 1024) HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, s)); // one workgroup, rounds of 8 192
   else if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;

@@ -32,6 +32,7 @@ struct ColumnInfo {
   bool has_fstats = false;              // Float64 / Float32 columns, over the finite values (staging statistics):
   double f_absmax = 0.0;                //   largest |v|
   double f_absmin_nz = 0.0;             //   smallest non-zero |v| (0: none / unknown)
+  bool ascending = false;               // integer column of an unsharded table: the rows are in strictly ascending value order
 };
 
 using ColumnResolver = std::function<const ColumnInfo *(uint32_t field_id)>;

@@ -20,6 +20,14 @@ template <class CL, class PR> struct SelPlan {
 
 constexpr int kSelUnroll = 4; // 128-row steps of a wave in flight
 
+// A predicate of the form "A, and for the rows that pass it, membership of a key in the key-set bitmap"
+template <class PR> struct GatherSplit { static constexpr bool value = false; };
+template <class A, class E> struct GatherSplit<AndThen<A, InKeySet<E>>> {
+  static constexpr bool value = true;
+  using First = A;
+  using Key = E;
+};
+
 // Each wave owns a contiguous quarter of the tile; a lane owns two consecutive rows per step.
 template <class P, bool WRITE> __device__ __forceinline__ void select_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
@@ -41,17 +49,38 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
     Loaded lds[kSelUnroll];
 #pragma unroll
     for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+    bool fe[2 * kSelUnroll];
+    if constexpr (GatherSplit<typename P::Pred>::value) {
+      // A, then a bit test in a key-set bitmap: the words of all the rows a lane holds are requested together (one
+      // round trip per step of the loop, not one per row); rows A rejects read word 0
+      using G = GatherSplit<typename P::Pred>;
+      uint64_t d[2 * kSelUnroll], w[2 * kSelUnroll];
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        const bool pass = (row < sub1) & G::First::eval(c, e & 1);
+        d[e] = (uint64_t)(long long)G::Key::eval(c, e & 1) - (uint64_t)p.bm_min; // key < min wraps to a huge value
+        perr |= row < sub1 ? c.perr : 0u;
+        fe[e] = pass && d[e] <= p.bm_span;
+      }
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) w[e] = p.bm_bits[fe[e] ? d[e] >> 6 : 0];
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) fe[e] = fe[e] && ((w[e] >> (d[e] & 63)) & 1ull) != 0;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        fe[e] = (row < sub1) & P::Pred::eval(c, e & 1);
+        perr |= row < sub1 ? c.perr : 0u;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < kSelUnroll; ++u) {
-      const Loaded &ld = lds[u];
       const uint32_t row0 = r0 + u * 128 + lane * 2;
-      bool f[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        Ctx c{p, ld, 0u, td.logical_row + row0 + j};
-        f[j] = ((row0 + j) < sub1) & P::Pred::eval(c, j);
-        perr |= ((row0 + j) < sub1) ? c.perr : 0u;
-      }
+      const bool f[2] = {fe[2 * u], fe[2 * u + 1]};
       const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
       if constexpr (WRITE) {
         const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
@@ -95,68 +124,87 @@ __device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
   }
 }
 
-// direct addressing: group id of key k, or 0xFFFFFFFF (see ScanParams::bm_bits)
-__device__ __forceinline__ uint32_t bm_find(const ScanParams &p, long long k, bool by_rank = false) {
-  const uint64_t d = (uint64_t)k - (uint64_t)p.bm_min; // k < min wraps to a huge value
-  if (d > p.bm_span) return 0xFFFFFFFFu;
-  const uint64_t w = p.bm_bits[d >> 6], bit = 1ull << (d & 63);
-  if (!(w & bit)) return 0xFFFFFFFFu;
-  const uint32_t rank = p.bm_prefix[d >> 6] + (uint32_t)__popcll(w & (bit - 1));
-  return by_rank ? rank : p.bm_group[rank];
-}
-
-template <class P, bool WRITE> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
+// Single pass: each (tile, wave) writes its (group id, value) pairs into its own sub_rows-sized stripe of the output and
+// reports its count; a compaction of the (few) emitted pairs replaces a second scan of the fact columns.
+// DIRECT (bitmap + rank): the lookups of the 2 · kSelUnroll rows a lane holds go out together — all bitmap words, then
+// all word ranks, then (a build list not in key order) all group ids: three round trips per step of the loop instead
+// of three per row.  Rows that do not probe read word 0.
+template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t sub0 = wave * p.sub_rows;
   const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
   const uint64_t slot_idx = (uint64_t)blockIdx.x * (kBlock / 64) + wave;
-  // WRITE with aux_in == nullptr is the single-pass form: each (tile, wave) writes into its own sub_rows-sized
-  // stripe of the output and reports its count as well; a compaction of the (few) emitted pairs replaces the
-  // second scan of the fact columns
-  const bool strided = WRITE && p.aux_in == nullptr;
-  uint64_t base = WRITE ? (strided ? slot_idx * p.sub_rows : p.aux_in[slot_idx]) : 0;
+  uint64_t base = slot_idx * p.sub_rows;
   const uint64_t base0 = base;
-  uint64_t count = 0;
-  uint32_t perr = 0; // predicate arithmetic error seen by this lane (count pass reports it, see kPredErrorBit)
+  uint32_t perr = 0; // predicate arithmetic error seen by this lane (reported with the count, see kPredErrorBit)
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const bool by_rank = p.bm_unsorted && *p.bm_unsorted == 0; // (uniform) the build list is in key order: rank = group id
+  // (uniform) the build list is in key order — known to the host (no table) or found out while it was compacted: rank = group id
+  const bool by_rank = DIRECT && (!p.bm_group || (p.bm_unsorted && *p.bm_unsorted == 0));
+  constexpr int kE = 2 * kSelUnroll;
   for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
     Loaded lds[kSelUnroll];
 #pragma unroll
     for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+    bool f[kE];
+    uint32_t hit[kE];
+    uint64_t val[kE];
+    if constexpr (DIRECT) {
+      uint64_t d[kE], w[kE];
 #pragma unroll
-    for (int u = 0; u < kSelUnroll; ++u) {
-      const Loaded &ld = lds[u];
-      const uint32_t row0 = r0 + u * 128 + lane * 2;
-      bool f[2];
-      uint32_t hit[2];
-      uint64_t val[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        Ctx c{p, ld, 0u, td.logical_row + row0 + j};
-        const bool pass = ((row0 + j) < sub1) & P::Pred::eval(c, j);
-        perr |= ((row0 + j) < sub1) ? c.perr : 0u;
-        // probe only for surviving rows (the branch on the table form is uniform over the grid)
-        hit[j] = !pass ? 0xFFFFFFFFu : p.bm_bits ? bm_find(p, (long long)P::KeyE::eval(c, j), by_rank) : ht_find(p, (long long)P::KeyE::eval(c, j));
-        f[j] = hit[j] != 0xFFFFFFFFu;
-        val[j] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, j));
+      for (int e = 0; e < kE; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        const bool pass = (row < sub1) & P::Pred::eval(c, e & 1);
+        perr |= row < sub1 ? c.perr : 0u;
+        d[e] = (uint64_t)(long long)P::KeyE::eval(c, e & 1) - (uint64_t)p.bm_min; // k < min wraps to a huge value
+        f[e] = pass && d[e] <= p.bm_span;
+        val[e] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, e & 1));
       }
-      const uint64_t b0 = __ballot(f[0]), b1 = __ballot(f[1]);
-      if constexpr (WRITE) {
-        const uint64_t pre = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
-        if (f[0]) { p.aux_out32[pre] = hit[0]; p.aux_out[pre] = val[0]; }
-        if (f[1]) { p.aux_out32[pre + (f[0] ? 1 : 0)] = hit[1]; p.aux_out[pre + (f[0] ? 1 : 0)] = val[1]; }
-        base += __popcll(b0) + __popcll(b1);
-      } else {
-        count += __popcll(b0) + __popcll(b1);
+#pragma unroll
+      for (int e = 0; e < kE; ++e) w[e] = p.bm_bits[f[e] ? d[e] >> 6 : 0];
+#pragma unroll
+      for (int e = 0; e < kE; ++e) {
+        const uint64_t bit = 1ull << (d[e] & 63);
+        f[e] = f[e] && (w[e] & bit) != 0;
+        hit[e] = (uint32_t)__popcll(w[e] & (bit - 1));
+      }
+      uint32_t pre[kE];
+#pragma unroll
+      for (int e = 0; e < kE; ++e) pre[e] = p.bm_prefix[f[e] ? d[e] >> 6 : 0];
+#pragma unroll
+      for (int e = 0; e < kE; ++e) hit[e] += pre[e];
+      if (!by_rank) {
+        uint32_t g[kE];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) g[e] = p.bm_group[f[e] ? hit[e] : 0];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) hit[e] = g[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < kE; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        const bool pass = (row < sub1) & P::Pred::eval(c, e & 1);
+        perr |= row < sub1 ? c.perr : 0u;
+        hit[e] = pass ? ht_find(p, (long long)P::KeyE::eval(c, e & 1)) : 0xFFFFFFFFu; // probe only for surviving rows
+        f[e] = hit[e] != 0xFFFFFFFFu;
+        val[e] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, e & 1));
       }
     }
+#pragma unroll
+    for (int u = 0; u < kSelUnroll; ++u) {
+      const bool f0 = f[2 * u], f1 = f[2 * u + 1];
+      const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
+      const uint64_t at = base + __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask);
+      if (f0) { p.aux_out32[at] = hit[2 * u]; p.aux_out[at] = val[2 * u]; }
+      if (f1) { p.aux_out32[at + (f0 ? 1 : 0)] = hit[2 * u + 1]; p.aux_out[at + (f0 ? 1 : 0)] = val[2 * u + 1]; }
+      base += __popcll(b0) + __popcll(b1);
+    }
   }
-  if (!WRITE || strided) {
-    const bool any_err = __ballot(perr != 0) != 0;
-    if (lane == 0) p.tile_partials[slot_idx] = (WRITE ? base - base0 : count) + (any_err ? kPredErrorBit : 0);
-  }
+  const bool any_err = __ballot(perr != 0) != 0;
+  if (lane == 0) p.tile_partials[slot_idx] = base - base0 + (any_err ? kPredErrorBit : 0);
 }
 
 // ---- value-emit: the argument values of the rows that pass the predicate, in row order.  Used by the

@@ -194,13 +194,22 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
   }
   if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
   if (t.dev_rows == 0) return LLKV_OK;
-  int64_t init[2] = {INT64_MAX, INT64_MIN}, *d = nullptr;
+  int64_t init[3] = {INT64_MAX, INT64_MIN, 0}, *d = nullptr;
   HIP_TRY(hipMalloc((void **)&d, sizeof init));
   HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, g_ctx.stream));
   // (padding rows between ragged chunks hold a copy of a real value: fill_chunk_padding)
   if (c.info.dtype == LLKV_DT_INT64 || c.info.dtype == LLKV_DT_DECIMAL128) HIP_TRY(launch_minmax_i64((const int64_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
   else HIP_TRY(launch_minmax_i32((const int32_t *)c.d_values, t.dev_rows, d, g_ctx.stream));
-  int64_t mm[2];
+  // … and whether the rows are in strictly ascending value order (a clustered key): a dimension selected from such a
+  // column is in key order and has no key twice (join_agg.cpp)
+  const bool ordered_type = c.info.dtype != LLKV_DT_DECIMAL128;
+  const TileSet *ts = nullptr;
+  if (ordered_type && t.world == 1) {
+    const int rc = get_tileset(t, 8192, &ts);
+    if (rc) { (void)hipFree(d); return rc; }
+    HIP_TRY(launch_ascending_check(c.d_values, c.info.dtype == LLKV_DT_INT64 ? 8 : 4, ts->d_tiles, ts->n_tiles, reinterpret_cast<uint32_t *>(d + 2), g_ctx.stream));
+  }
+  int64_t mm[3];
   HIP_TRY(hipMemcpyAsync(mm, d, sizeof mm, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   (void)hipFree(d);
@@ -211,6 +220,7 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
     c.info.has_stats = true;
     c.info.min_i = mm[0];
     c.info.max_i = mm[1];
+    c.info.ascending = ts != nullptr && mm[2] == 0;
   }
   return LLKV_OK;
 }
