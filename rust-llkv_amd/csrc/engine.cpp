@@ -237,10 +237,12 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
         for (size_t l = 0; l < lanes; ++l) img[o * lanes + l] = p.lane_ops[l] == 2 ? 0x7FFFFFFFFFFFFFFFull : p.lane_ops[l] == 3 ? 0x8000000000000000ull : 0ull;
     q->d_empty_image = (uint64_t *)scratch_alloc(img.size() * 8);
     if (!q->d_empty_image) return set_error(LLKV_INTERNAL, "device allocation failed");
-    HIP_TRY(hipMemcpy(q->d_empty_image, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+    // (on the stream of the memset above — it does not wait for the null stream — and complete before `img` goes)
+    HIP_TRY(hipMemcpyAsync(q->d_empty_image, img.data(), img.size() * 8, hipMemcpyHostToDevice, g_ctx.stream));
     if (p.acc_image) // the fold of a shared-image plan only rewrites the first owned octant of a slot: the rest is constant
       for (uint32_t sl = 0; sl < Query::kMaxDepth; ++sl)
-        HIP_TRY(hipMemcpy(q->d_exchange + sl * q->exchange_len(), img.data(), img.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(q->d_exchange + sl * q->exchange_len(), img.data(), img.size() * 8, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   q->params.tile_partials = q->d_tile_partials;

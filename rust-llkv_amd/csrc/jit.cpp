@@ -206,7 +206,8 @@ void jit_shutdown() {
 extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out, uint64_t log_cap) {
   int kind = 0;
   std::string ts = type_string;
-  if (ts.rfind("SelPlan<", 0) == 0) kind = 1;
+  if (ts.rfind("keybits:", 0) == 0) { kind = 7; ts = ts.substr(8); } // an EmitPlan compiled as the key-bits scan
+  else if (ts.rfind("SelPlan<", 0) == 0) kind = 1;
   else if (ts.rfind("ProjPlan<", 0) == 0) kind = 2;
   else if (ts.rfind("ProbePlan<", 0) == 0) kind = 3;
   else if (ts.rfind("EmitPlan<", 0) == 0) kind = 4;

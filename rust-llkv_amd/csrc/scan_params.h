@@ -103,6 +103,7 @@ struct ProjParams {
   void *out[kMaxOuts];
   uint64_t *out_valid[kMaxOuts]; // Arrow validity bitmap of a nullable output (64 rows per word), else nullptr
   uint32_t *error_flag;
+  uint32_t error_stride;         // rows per error cell (error_flag[i / error_stride]); 0: one cell for the launch
   int64_t lit_i[kMaxLits];
   double lit_f[kMaxLits];
   uint32_t n;

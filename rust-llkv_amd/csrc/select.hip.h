@@ -402,7 +402,7 @@ template <class P> __device__ __forceinline__ void project_body(const ProjParams
   gather_all<typename P::ColList>(pp, row, ld);
   Ctx c{sp, ld, 0u, row};
   StoreOuts<typename P::OutT>::run(pp, c, i);
-  if (c.err) atomicOr(pp.error_flag, c.err);
+  if (c.err) atomicOr(pp.error_flag + (pp.error_stride ? i / pp.error_stride : 0u), c.err);
 }
 
 // ---- sort-based GROUP BY: per-group reduction -------------------------------------------------------

@@ -294,16 +294,21 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   constexpr uint64_t kSuper = 16;
   const uint64_t buf_rows = std::min<uint64_t>(kSuper * kRowStreamChunk, (sel.n + kRowStreamChunk - 1) / kRowStreamChunk * kRowStreamChunk);
   struct Win {
-    DeviceBuf d[kMaxOuts], d_valid[kMaxOuts];
-    PinnedBuf h[kMaxOuts], h_valid[kMaxOuts], h_ids;
+    DeviceBuf d[kMaxOuts], d_valid[kMaxOuts], d_err; // d_err: one arithmetic-error cell per reference window of the buffer
+    PinnedBuf h[kMaxOuts], h_valid[kMaxOuts], h_ids, h_err;
     hipEvent_t done = nullptr;
     uint32_t n = 0;
     ~Win() { if (done) (void)hipEventDestroy(done); }
   } win[2];
-  DeviceBuf d_err;
-  if ((rc = d_err.alloc(4))) return (llkv_status)rc;
-  if (hipMemsetAsync(d_err.p, 0, 4, stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "memset failed");
+  // declared after the windows, so it runs before their buffers go back to the pools: on an early return the gather
+  // kernels and copies that are still in flight finish first
+  struct Drain {
+    hipStream_t s;
+    bool armed = true;
+    ~Drain() { if (armed) (void)hipStreamSynchronize(s); }
+  } drain{stream};
   for (auto &w : win) {
+    if ((rc = w.d_err.alloc(kSuper * 4)) || (rc = w.h_err.alloc(kSuper * 4))) return (llkv_status)rc;
     for (uint32_t o = 0; o < n_out; ++o) {
       const size_t bytes = (size_t)buf_rows * dtype_out_width(proj.out_dtypes[o]);
       if ((rc = w.d[o].alloc(bytes)) || (rc = w.h[o].alloc(bytes))) return (llkv_status)rc;
@@ -317,7 +322,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   for (size_t s = 0; s < proj.slot_fields.size(); ++s) pp.col[s] = slot_buffer(t->cols, proj, s);
   for (size_t i = 0; i < proj.lit_i.size(); ++i) pp.lit_i[i] = proj.lit_i[i];
   for (size_t i = 0; i < proj.lit_f.size(); ++i) pp.lit_f[i] = proj.lit_f[i];
-  pp.error_flag = (uint32_t *)d_err.p;
+  pp.error_stride = (uint32_t)kRowStreamChunk;
 
   auto enqueue = [&](uint64_t w0, Win &w) -> int {
     w.n = (uint32_t)std::min<uint64_t>(buf_rows, sel.n - w0);
@@ -325,6 +330,8 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     q.dev_rows = sel.d_dev + w0;
     q.n = w.n;
     for (uint32_t o = 0; o < n_out; ++o) { q.out[o] = w.d[o].p; q.out_valid[o] = (uint64_t *)w.d_valid[o].p; }
+    q.error_flag = (uint32_t *)w.d_err.p;
+    HIP_TRY(hipMemsetAsync(w.d_err.p, 0, kSuper * 4, stream));
     int r = jit_launch_raw(k.fn, (w.n + kBlock - 1) / kBlock, &q, sizeof q, stream);
     if (r) return r;
     for (uint32_t o = 0; o < n_out; ++o)
@@ -333,6 +340,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
       if (proj.out_nullable[o]) HIP_TRY(hipMemcpyAsync(w.h_valid[o].p, w.d_valid[o].p, (size_t)((w.n + 63) / 64) * 8, hipMemcpyDeviceToHost, stream));
     }
     if (with_ids) HIP_TRY(hipMemcpyAsync(w.h_ids.p, sel.d_ids + w0, (size_t)w.n * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(w.h_err.p, w.d_err.p, kSuper * 4, hipMemcpyDeviceToHost, stream)); // travels with the window
     HIP_TRY(hipEventRecord(w.done, stream));
     return LLKV_OK;
   };
@@ -351,6 +359,9 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     Win &w = win[cur];
     if (hipEventSynchronize(w.done) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "window copy failed");
     for (uint64_t r0 = 0; r0 < w.n; r0 += kRowStreamChunk) { // the reference's windows, one callback each
+      // a computed projection that failed in this window: the windows before it have been delivered, this one is not
+      // (the reference's arrow kernel fails the batch it is evaluating)
+      if (const uint32_t e = static_cast<const uint32_t *>(w.h_err.p)[r0 / kRowStreamChunk]) return (llkv_status)set_error(LLKV_INTERNAL, arith_error_message(e));
       llkv_column_view cols[kMaxOuts];
       for (uint32_t o = 0; o < n_out; ++o) {
         cols[o].dtype = proj.out_dtypes[o];
@@ -373,9 +384,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
     }
     cur ^= 1;
   }
-  uint32_t errflag = 0;
-  if (hipMemcpy(&errflag, d_err.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "copy failed");
-  if (errflag) return (llkv_status)set_error(LLKV_INTERNAL, arith_error_message(errflag));
+  drain.armed = false; // every window has been waited for
   return LLKV_OK;
 }
 

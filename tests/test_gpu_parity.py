@@ -751,6 +751,31 @@ def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeyp
     assert kinds[0][0] in ("InvalidArgumentError", "Unsupported")
 
 
+def test_scan_stream_fails_at_the_window_whose_projection_failed(rt, abi):
+    """A computed projection that fails (`% 0`) ends the stream at the 65 536-row window that holds the offending row:
+    the windows before it have been delivered, that one and the later ones are not (the reference's arrow kernel
+    fails the batch it is evaluating, llkv-scan/src/row_stream.rs)."""
+    n = 300_000
+    a = np.arange(n, dtype=np.int64)
+    b = np.ones(n, dtype=np.int64)
+    b[150_000] = 0  # third window
+    ht = rt.HipTable(1, [n])
+    ht.append_column(1, abi.DT_INT64, a)
+    ht.append_column(2, abi.DT_INT64, b)
+    seen = []
+    with pytest.raises(abi.LlkvError) as e:
+        rt.scan_stream(ht, [1, abi.col(1) % abi.col(2)], None, consume=lambda bv: seen.append(int(bv.num_rows)))
+    assert e.value.kind == "Internal" and "Divide by zero" in e.value.message
+    assert seen == [65536, 65536]
+    seen.clear()
+    b[150_000] = 1
+    ht2 = rt.HipTable(2, [n])
+    ht2.append_column(1, abi.DT_INT64, a)
+    ht2.append_column(2, abi.DT_INT64, b)
+    rt.scan_stream(ht2, [1, abi.col(1) % abi.col(2)], None, consume=lambda bv: seen.append(int(bv.num_rows)))
+    assert seen == [65536] * 4 + [n - 4 * 65536]
+
+
 @pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])
 def test_division_and_modulo_match_oracle(rt, orc, abi, chunks):
     """Divide leaves the fast numeric path: per-node typing, zeros of a divisor become NULLs, integer division
