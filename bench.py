@@ -160,7 +160,9 @@ def pmc_traffic(workload):
             with open(path) as f:
                 doc = json.load(f)
             if workload in doc:
-                return doc[workload]["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+                meta = doc.get("_meta", {})
+                src = os.path.relpath(path, ROOT) + (f" (collected {meta.get('date')}, commit {meta.get('commit')})" if meta else "")
+                return doc[workload]["traffic_bytes_per_launch"], src
         except Exception:
             continue
     return None, None

@@ -94,12 +94,15 @@ static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
 
 // Launch geometry of an LDS-accumulator plan, from the LOCAL tile count: persistent-style, about one workgroup per
 // CU, each streaming a contiguous run of tiles (workgroup b of g: tiles [b·n/g, (b+1)·n/g)).  Fewer, longer-running
-// workgroups beat many short ones once the tile boundary is cheap (profiles/r02/sweep_tiles.txt: SF10 on one GPU,
-// 3 662 tiles: 229–458 workgroups 330–347 µs, 916 workgroups 357 µs, 3 662 workgroups 367 µs); a shard with fewer
-// tiles than CUs launches one workgroup per tile.
+// workgroups beat many short ones once the tile boundary is cheap, and on a table of thousands of tiles 160–208
+// workgroups beat one per CU by 2–4 % on every box tried (profiles/r02/sweep_tiles_q1.txt: SF10 on one GPU, 3 662 tiles:
+// 176 workgroups 358 µs, 192: 363, 256: 372, 512: 381, 128: 408; interleaving the tiles over the workgroups instead
+// of contiguous runs changes nothing) — the scan sits at the device's multi-stream read ceiling and leaving a quarter of
+// the CUs idle seems to buy the fabric some clock; a 1/8 shard (457 tiles) wants every CU: 256 workgroups 49.8 µs, 192:
+// 56 µs.  A shard with fewer tiles than CUs launches one workgroup per tile.
 static uint32_t pick_scan_grid(const LoweredPlan &p, uint32_t n_tiles) {
   if (!p.acc_lds) return 0; // one tile per workgroup
-  uint32_t grid = 256;
+  uint32_t grid = n_tiles >= 2048 ? 192 : 256;
   if (const char *e = std::getenv("LLKV_HIP_SCAN_WGS")) {
     long v = std::atol(e);
     if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 20);

@@ -25,16 +25,18 @@ for c in q.columns:
         if world > 1 and t.local_column_stats(fid) is not None:
             t.set_column_stats(fid, int(full[c].min()), int(full[c].max()))
 for tile in sys.argv[3].split(","):
+  for unroll in os.environ.get("SWEEP_UNROLL", "auto").split(","):
     for tpw in sys.argv[4].split(","):
         os.environ["LLKV_HIP_TILE_ROWS"] = tile; os.environ["LLKV_HIP_SCAN_WGS"] = tpw
         if tpw == "auto": del os.environ["LLKV_HIP_SCAN_WGS"]
         if tile == "auto": del os.environ["LLKV_HIP_TILE_ROWS"]
+        if unroll != "auto": os.environ["LLKV_HIP_UNROLL"] = unroll; os.environ["LLKV_HIP_FORCE_JIT"] = "1"
         pq = rt.PreparedQuery(t, q.predicate, q.aggs, q.keys, q.order_by_keys)
         for _ in range(5): pq.run()
         pq.set_profiling(True)
         for _ in range(steps): pq.run()
         ms, k, _ = pq.kernel_time()
-        print(json.dumps({"workload": name, "world": world, "local_rows": t.local_rows, "tile_rows": tile, "workgroups": tpw, "kernel_us": round(1e3 * ms / k, 2),
+        print(json.dumps({"workload": name, "world": world, "local_rows": t.local_rows, "tile_rows": tile, "unroll": unroll, "workgroups": tpw, "kernel_us": round(1e3 * ms / k, 2),
                           "gbs": round(pq.algorithmic_bytes / (ms / k) / 1e6, 1)}), flush=True)
         pq.close()
 ''' % ROOT
