@@ -220,3 +220,19 @@ def test_two_processes_run_the_sharded_drivers_over_a_host_transport(rt, abi, tp
                     assert x == y, (name, a)
     jw, jtotal = rt.join_groupby_topk(limit=10, **_join_inputs(rt, abi, tpch, 0, 1))
     assert got[0]["join"] == ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in jw], jtotal)
+
+
+@pytest.mark.gpu
+def test_c_program_runs_sharded_q1_through_the_library_collectives(tmp_path):
+    """examples/q1_multi_gpu.c: one process per GPU in plain C99 — communicator id over a file, ncclCommInitRank inside
+    the library, table-wide dictionary and metadata, `finish_sharded`.  One rank here (this box has one GPU; the code
+    path is the N-rank one: a one-rank RCCL communicator still runs ncclAllReduce on the exchange image)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rust-llkv_amd")
+    exe = tmp_path / "q1mg"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "q1_multi_gpu.c"), "-L", libdir, "-lllkv_hip", "-lllkv_tpch", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe), "0", "1", str(tmp_path / "id"), "1500000", "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stdout, out.stderr)
+    assert sum(" count " in line for line in out.stdout.splitlines()) == 4  # four groups (RCCL prints its banner to stdout too)
