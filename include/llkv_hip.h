@@ -884,6 +884,10 @@ llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols,
                             int32_t grouped, char *type_string_out, uint64_t type_string_cap,
                             uint32_t *lanes_out, uint64_t *bytes_per_row_out);
 const char *llkv_plan_last_error(void);
+/* The number a Utf8 value counts as under the reference's SQLite-style coercion of aggregate inputs
+ * (`s.trim().parse::<f64>().unwrap_or(0.0)`, llkv-aggregate/src/lib.rs:426-434) — what SUM / AVG / TOTAL / MIN / MAX over
+ * a dictionary-coded Utf8 column accumulate on the GPU path.  Host only.                                            */
+double llkv_plan_parse_numeric(const char *text);
 
 #ifdef __cplusplus
 } /* extern "C" */

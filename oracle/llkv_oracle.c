@@ -13,6 +13,7 @@
 #include "llkv_oracle.h"
 
 #include <errno.h>
+#include <ctype.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1327,20 +1328,61 @@ typedef struct acc {
   int32_t distinct_rc;
 } acc;
 
+/* `str::trim` + `<f64 as FromStr>::from_str` (Rust core, published grammar): Unicode White_Space is trimmed; a float is
+ * Sign? ( "inf" | "infinity" | "nan" | Number ) in any case, Number = ( Digit+ | Digit+ "." Digit* | Digit* "." Digit+ )
+ * Exp?, Exp = ("e" | "E") Sign? Digit+ — no hexadecimal forms, nothing else around it.  Anything else → 0.0. */
+static size_t ws_len(const char *s, size_t n, size_t i, int backwards) {
+  static const char *const multi[] = {"\xC2\x85", "\xC2\xA0", "\xE1\x9A\x80", "\xE2\x80\x80", "\xE2\x80\x81", "\xE2\x80\x82", "\xE2\x80\x83",
+                                      "\xE2\x80\x84", "\xE2\x80\x85", "\xE2\x80\x86", "\xE2\x80\x87", "\xE2\x80\x88", "\xE2\x80\x89", "\xE2\x80\x8A",
+                                      "\xE2\x80\xA8", "\xE2\x80\xA9", "\xE2\x80\xAF", "\xE2\x81\x9F", "\xE3\x80\x80"};
+  const unsigned char c = (unsigned char)s[i];
+  if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+  for (size_t m = 0; m < sizeof multi / sizeof multi[0]; ++m) {
+    const size_t len = strlen(multi[m]);
+    if (!backwards) { if (i + len <= n && memcmp(s + i, multi[m], len) == 0) return len; }
+    else if (i + 1 >= len && memcmp(s + i + 1 - len, multi[m], len) == 0) return len;
+  }
+  return 0;
+}
+static int word_is(const char *s, size_t n, const char *w) {
+  if (strlen(w) != n) return 0;
+  for (size_t k = 0; k < n; ++k) if (tolower((unsigned char)s[k]) != w[k]) return 0;
+  return 1;
+}
+static double rust_parse_f64_or_zero(const char *text) {
+  size_t b = 0, e = strlen(text), len;
+  while (b < e && (len = ws_len(text, e, b, 0))) b += len;
+  while (e > b && (len = ws_len(text, e, e - 1, 1))) e -= len;
+  const char *t = text + b;
+  size_t n = e - b, i = 0;
+  int neg = 0;
+  if (i < n && (t[i] == '+' || t[i] == '-')) neg = t[i++] == '-';
+  if (word_is(t + i, n - i, "inf") || word_is(t + i, n - i, "infinity")) return neg ? -INFINITY : INFINITY;
+  if (word_is(t + i, n - i, "nan")) return neg ? -NAN : NAN;
+  size_t k = i, int_digits = 0, frac_digits = 0, exp_digits = 0;
+  while (k < n && isdigit((unsigned char)t[k])) { ++k; ++int_digits; }
+  if (k < n && t[k] == '.') { ++k; while (k < n && isdigit((unsigned char)t[k])) { ++k; ++frac_digits; } }
+  if (int_digits + frac_digits == 0) return 0.0;
+  if (k < n && (t[k] == 'e' || t[k] == 'E')) {
+    ++k;
+    if (k < n && (t[k] == '+' || t[k] == '-')) ++k;
+    while (k < n && isdigit((unsigned char)t[k])) { ++k; ++exp_digits; }
+    if (exp_digits == 0) return 0.0;
+  }
+  if (k != n) return 0.0;
+  char buf[512];
+  if (n >= sizeof buf) return 0.0; /* (a number of 500 characters: not in any fixture) */
+  memcpy(buf, t, n);
+  buf[n] = 0;
+  return strtod(buf, NULL);
+}
+
 /* array_value_to_numeric :400-449 */
 static int32_t value_to_numeric(const arr *a, uint64_t i, double *out) {
   switch (a->dtype) {
   case LLKV_DT_INT64: *out = (double)((int64_t *)a->values)[i]; return LLKV_OK;
   case LLKV_DT_FLOAT64: *out = ((double *)a->values)[i]; return LLKV_OK;
-  case LLKV_DT_UTF8: { /* SQLite behaviour: parse, non-numeric → 0.0 */
-    const char *s = a->strings[i];
-    while (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r') ++s;
-    char *end;
-    double v = strtod(s, &end);
-    while (*end == ' ' || *end == '\t' || *end == '\n' || *end == '\r') ++end;
-    *out = (end == s || *end) ? 0.0 : v;
-    return LLKV_OK;
-  }
+  case LLKV_DT_UTF8: *out = rust_parse_f64_or_zero(a->strings[i]); return LLKV_OK; /* s.trim().parse::<f64>().unwrap_or(0.0) :426-434 */
   case LLKV_DT_BOOLEAN: *out = ((uint8_t *)a->values)[i] ? 1.0 : 0.0; return LLKV_OK;
   default: return fail(LLKV_INVALID_ARGUMENT, "Numeric coercion not supported for column type %s", dtype_name(a->dtype));
   }

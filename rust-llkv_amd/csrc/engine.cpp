@@ -58,6 +58,7 @@ Query::~Query() {
     (void)hipStreamSynchronize(g_ctx.stream);
   }
   scratch_free(d_tile_partials);
+  scratch_free(d_dict_num);
   if (d_exchange && !host_mapped) scratch_free(d_exchange);
   scratch_free(d_lane_ops);
   scratch_free(d_empty_image);
@@ -201,6 +202,15 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
 
   std::memset(&q->params, 0, sizeof q->params);
   for (size_t s = 0; s < p.slot_fields.size(); ++s) q->params.col[s] = slot_buffer(table->cols, p, s);
+  if (!p.dict_num.empty()) { // numeric images of the dictionaries some aggregate reads (DictNum<slot>)
+    std::vector<double> image(p.slot_fields.size() * 256, 0.0);
+    for (auto &d : p.dict_num) std::copy(d.second.begin(), d.second.end(), image.begin() + (size_t)d.first * 256);
+    q->d_dict_num = (double *)scratch_alloc(image.size() * 8);
+    if (!q->d_dict_num) return set_error(LLKV_INTERNAL, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(q->d_dict_num, image.data(), image.size() * 8, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream)); // `image` is pageable and goes out of scope
+    q->params.dict_num = q->d_dict_num;
+  }
   for (size_t i = 0; i < p.lit_i.size(); ++i) q->params.lit_i[i] = p.lit_i[i];
   for (size_t i = 0; i < p.lit_f.size(); ++i) q->params.lit_f[i] = p.lit_f[i];
   for (size_t i = 0; i < p.key_strides.size(); ++i) q->params.key_stride[i] = p.key_strides[i];

@@ -159,6 +159,7 @@ struct Query {
   JitKernel jit;
   const TileSet *tiles = nullptr;
   ScanParams params;
+  double *d_dict_num = nullptr; // ScanParams::dict_num of plans that read dictionary codes as numbers
   // ring of exchange images so that up to `depth` executions are in flight: the host
   // finalizes execution i while the GPU already runs i+1
   static constexpr uint32_t kMaxDepth = 8;

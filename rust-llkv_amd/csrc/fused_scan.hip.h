@@ -179,6 +179,11 @@ template <int K> struct LitF {
   static __device__ __forceinline__ double eval(Ctx &c, int) { return c.p.lit_f[K]; }
   static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
 };
+template <int S> struct DictNum { // numeric value of the dictionary code in slot S (ScanParams::dict_num)
+  using Type = F64;
+  static __device__ __forceinline__ double eval(Ctx &c, int j) { return c.p.dict_num[S * 256 + (int)c.get<U8>(S, j)]; }
+  static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
+};
 template <class E> struct ToF64 { // arrow cast int → f64 / f32 → f64
   using Type = F64;
   static __device__ __forceinline__ double eval(Ctx &c, int j) { return (double)E::eval(c, j); }

@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -148,6 +149,58 @@ int cast_literal_for_column(const llkv_literal &lit, int32_t dtype, NativeLit *o
 
 namespace {
 
+} // namespace
+double parse_numeric_or_zero(const std::string &text) {
+  // str::trim(): Unicode White_Space — the ASCII ones and the multi-byte ones a UTF-8 string can start / end with
+  auto ws_at = [&](size_t i, bool backwards) -> size_t { // length of the white-space character at i (ending at i), 0 if none
+    static const char *const multi[] = {"\xC2\x85", "\xC2\xA0", "\xE1\x9A\x80", "\xE2\x80\x80", "\xE2\x80\x81", "\xE2\x80\x82", "\xE2\x80\x83",
+                                        "\xE2\x80\x84", "\xE2\x80\x85", "\xE2\x80\x86", "\xE2\x80\x87", "\xE2\x80\x88", "\xE2\x80\x89", "\xE2\x80\x8A",
+                                        "\xE2\x80\xA8", "\xE2\x80\xA9", "\xE2\x80\xAF", "\xE2\x81\x9F", "\xE3\x80\x80"};
+    const unsigned char c = (unsigned char)text[i];
+    if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+    for (const char *m : multi) {
+      const size_t n = std::strlen(m);
+      if (!backwards) { if (text.compare(i, n, m) == 0) return n; }
+      else if (i + 1 >= n && text.compare(i + 1 - n, n, m) == 0) return n;
+    }
+    return 0;
+  };
+  size_t b = 0, e = text.size();
+  for (size_t n; b < e && (n = ws_at(b, false)); b += n) {}
+  for (size_t n; e > b && (n = ws_at(e - 1, true)); e -= n) {}
+  const std::string t = text.substr(b, e - b);
+  // <f64 as FromStr>: Sign? ( 'inf' | 'infinity' | 'nan' | Number ),  Number = ( Digit+ | Digit+ '.' Digit* | Digit* '.' Digit+ ) Exp?,
+  // Exp = ('e' | 'E') Sign? Digit+
+  size_t i = 0;
+  bool neg = false;
+  if (i < t.size() && (t[i] == '+' || t[i] == '-')) neg = t[i++] == '-';
+  auto ieq = [&](const char *w) {
+    const size_t n = std::strlen(w);
+    if (t.size() - i != n) return false;
+    for (size_t k = 0; k < n; ++k) if (std::tolower((unsigned char)t[i + k]) != w[k]) return false;
+    return true;
+  };
+  if (ieq("inf") || ieq("infinity")) return neg ? -INFINITY : INFINITY;
+  if (ieq("nan")) return neg ? -std::nan("") : std::nan("");
+  size_t k = i, int_digits = 0, frac_digits = 0;
+  while (k < t.size() && std::isdigit((unsigned char)t[k])) { ++k; ++int_digits; }
+  if (k < t.size() && t[k] == '.') {
+    ++k;
+    while (k < t.size() && std::isdigit((unsigned char)t[k])) { ++k; ++frac_digits; }
+  }
+  if (int_digits + frac_digits == 0) return 0.0;
+  if (k < t.size() && (t[k] == 'e' || t[k] == 'E')) {
+    ++k;
+    if (k < t.size() && (t[k] == '+' || t[k] == '-')) ++k;
+    size_t exp_digits = 0;
+    while (k < t.size() && std::isdigit((unsigned char)t[k])) { ++k; ++exp_digits; }
+    if (exp_digits == 0) return 0.0;
+  }
+  if (k != t.size()) return 0.0;
+  return std::strtod(t.c_str(), nullptr); // a decimal literal of that grammar: both sides round it correctly
+}
+namespace {
+
 struct Lowering {
   const ColumnResolver &resolve;
   LoweredPlan &p;
@@ -161,6 +214,7 @@ struct Lowering {
   // shared-image plans: f64 sums as exact two-level pairs (SumF64X), which need a bound on |argument|
   bool exact_f64 = false;
   uint64_t table_rows = 0; // rows of the table the plan scans (the N of the exact sums)
+  bool allow_dict_num = true; // the kernels of this plan see ScanParams::dict_num (not the sort route's reduce kernel)
 
   // What the column statistics say about an aggregate argument: an interval [lo, hi] (integer min / max, largest
   // finite |v| of float columns) and `nz`, a lower bound on |value| wherever the value is not zero (smallest non-zero
@@ -175,6 +229,18 @@ struct Lowering {
         if (!ci) return false;
         table_rows = std::max(table_rows, ci->rows);
         if ((ci->dtype == LLKV_DT_FLOAT64 || ci->dtype == LLKV_DT_FLOAT32) && ci->has_fstats) st.push_back({-ci->f_absmax, ci->f_absmax, ci->f_absmin_nz});
+        else if (ci->dtype == LLKV_DT_BOOLEAN) st.push_back({0.0, 1.0, 1.0});
+        else if (ci->dtype == LLKV_DT_UTF8) { // numeric image of the dictionary
+          I b{0.0, 0.0, 0.0};
+          for (const std::string &w : ci->dictionary) {
+            const double v = parse_numeric_or_zero(w);
+            if (!std::isfinite(v)) return false;
+            b.lo = std::min(b.lo, v); b.hi = std::max(b.hi, v);
+            if (v != 0.0) b.nz = b.nz == 0.0 ? std::fabs(v) : std::min(b.nz, std::fabs(v));
+          }
+          if (b.nz == 0.0) b.nz = 1.0; // every string counts as 0
+          st.push_back(b);
+        }
         else if (is_int_class(ci->dtype) && ci->has_stats) st.push_back({(double)ci->min_i, (double)ci->max_i, 1.0});
         else return false;
       } else if (e[i].kind == LLKV_TOK_LITERAL) {
@@ -984,15 +1050,31 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     if (simple) {
       // validate_aggregate_type llkv-executor/src/lib.rs:5946-5988
       const int32_t dt = simple_ci->dtype;
-      if (dt == LLKV_DT_UTF8 || dt == LLKV_DT_BOOLEAN || dt == LLKV_DT_DATE32)
-        return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over " + dtype_name(dt) + " (SQLite-style numeric coercion) is not on the GPU path");
-      if (dt != LLKV_DT_INT64 && dt != LLKV_DT_FLOAT64 && dt != LLKV_DT_DECIMAL128)
+      // Utf8 / Boolean / Date32 inputs get Float64 accumulators fed by array_value_to_numeric (llkv-aggregate/src/lib.rs:
+      // 400-449): strings parse or count as 0, booleans are 0 / 1; Date32 has no arm there — the first non-NULL row fails
+      if (dt == LLKV_DT_DATE32)
+        return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over Date32 (the reference fails at the first non-NULL row) is not on the GPU path");
+      if (dt != LLKV_DT_INT64 && dt != LLKV_DT_FLOAT64 && dt != LLKV_DT_DECIMAL128 && dt != LLKV_DT_UTF8 && dt != LLKV_DT_BOOLEAN)
         return L.fail(LLKV_INVALID_ARGUMENT, std::string(fn) + " aggregate not supported for column type " + dtype_name(dt));
       const ColumnInfo *ci;
       int slot;
       if ((rc = L.slot_of(s.expr[0].field_id, &ci, &slot))) return rc;
-      node = L.col_node(slot, dt);
-      is_f64 = dt == LLKV_DT_FLOAT64;
+      if (dt == LLKV_DT_UTF8) {
+        if (!L.allow_dict_num) return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over a Utf8 column is not on this route");
+        node = "DictNum<" + std::to_string(slot) + ">";
+        bool have = false;
+        for (auto &d : p.dict_num) have |= d.first == slot;
+        if (!have) {
+          std::vector<double> image(256, 0.0);
+          for (size_t c = 0; c < ci->dictionary.size() && c < 256; ++c) image[c] = parse_numeric_or_zero(ci->dictionary[c]);
+          p.dict_num.emplace_back(slot, std::move(image));
+        }
+      } else if (dt == LLKV_DT_BOOLEAN) {
+        node = "ToF64<" + L.col_node(slot, dt) + ">";
+      } else {
+        node = L.col_node(slot, dt);
+      }
+      is_f64 = dt == LLKV_DT_FLOAT64 || dt == LLKV_DT_UTF8 || dt == LLKV_DT_BOOLEAN;
     } else {
       o.typed_by_first_value = grouped;
     }
@@ -1229,6 +1311,7 @@ int lower_reduce(const ColumnResolver &resolve, const llkv_aggregate_spec *aggs,
   *out = LoweredPlan{};
   LoweredPlan &p = *out;
   Lowering L{resolve, p, err, true};
+  L.allow_dict_num = false;
   p.grouped = true;
   p.track_first = true;
   std::vector<std::string> groups;

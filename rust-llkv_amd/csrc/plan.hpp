@@ -93,7 +93,14 @@ struct LoweredPlan {
   std::vector<int32_t> out_dtypes; // projection plans: storage dtype of each output
   std::vector<int32_t> out_fields; // projection plans: source field of a passthrough column, else -1
   std::vector<uint8_t> out_nullable; // projection plans: the output carries a validity bitmap
+  // slots whose dictionary codes some aggregate reads as numbers (DictNum<slot>): slot → 256 values (code → f64)
+  std::vector<std::pair<int, std::vector<double>>> dict_num;
 };
+
+// `str.trim().parse::<f64>().unwrap_or(0.0)` of the reference's numeric coercion (llkv-aggregate/src/lib.rs:426-434):
+// Rust's float grammar — sign, decimal digits with an optional point, optional exponent, or inf / infinity / nan in
+// any case; no hexadecimal forms, nothing else around the number.
+double parse_numeric_or_zero(const std::string &s);
 
 // Lowers a plan.  `grouped` selects the GROUP BY argument semantics (PlanValue
 // interpreter) instead of the computed-projection fast path; `track_first` keeps each

@@ -13,6 +13,9 @@ extern "C" {
 
 const char *llkv_plan_last_error(void) { return g_plan_err.c_str(); }
 
+// `s.trim().parse::<f64>().unwrap_or(0.0)` as the GPU path's lowering computes it for dictionary entries (plan.hpp)
+double llkv_plan_parse_numeric(const char *text) { return llkv::parse_numeric_or_zero(text ? text : ""); }
+
 llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols, const llkv_filter *filters,
                             uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                             const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs,

@@ -93,6 +93,9 @@ struct ScanParams {
   const uint32_t *bm_unsorted;   // optional; *bm_unsorted == 0: the build list is in key order, the rank is the group id
   int64_t bm_min;
   uint64_t bm_span;              // max − min
+  // numeric image of dictionary-coded Utf8 aggregate inputs (SQLite-style coercion, llkv-aggregate/src/lib.rs:400-449):
+  // dict_num[slot · 256 + code] = the string parsed as f64, 0.0 when it is not a number
+  const double *dict_num;
 };
 
 constexpr int kMaxOuts = 8;

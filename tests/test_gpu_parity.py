@@ -751,6 +751,41 @@ def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeyp
     assert kinds[0][0] in ("InvalidArgumentError", "Unsupported")
 
 
+@pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5], [65536, 30000]])
+def test_aggregates_over_utf8_and_boolean_inputs_coerce_like_the_reference(rt, orc, abi, chunks):
+    """SQLite-style coercion of aggregate inputs (validate_aggregate_type llkv-executor/src/lib.rs:5946-5988 →
+    array_value_to_numeric llkv-aggregate/src/lib.rs:400-449): SUM / AVG / TOTAL / MIN / MAX over a Utf8 column use
+    Float64 accumulators over the parsed strings (non-numbers count as 0), over a Boolean column over 0 / 1; NULL cells
+    are skipped.  On the GPU the dictionary is parsed once and the codes index its numeric image.  Ungrouped, grouped
+    by a small key (per-thread accumulators) and by a date (shared-image kernel, exact sums); Date32 inputs are left to
+    the caller (the reference fails at the first non-NULL row)."""
+    rng = np.random.default_rng(17 + len(chunks))
+    n = sum(chunks)
+    words = ["12", " 3.5 ", "abc", "", "1e2", "0x10", "-7.25", ".5", "1.", "+4", "0.125", "1000000.5"]
+    txt = [words[i] for i in rng.integers(0, len(words), size=n)]
+    boo = rng.integers(0, 2, size=n).astype(np.uint8)
+    key = np.array([ord("p"), ord("q"), ord("r")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    day = rng.integers(9000, 9700, size=n).astype(np.int32)
+    vt, vb = rng.random(n) > 0.15, rng.random(n) > 0.1
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_UTF8, txt, vt), (2, abi.DT_BOOLEAN, boo, vb), (3, abi.DT_UTF8, key), (4, abi.DT_DATE32, day),
+                                       (5, abi.DT_UTF8, txt)], chunks)
+    A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
+    aggs = [A.count_star(), A.sum(1), A.avg(1), A.total(1), A.min(1), A.max(1), A.count(1), A.sum(2), A.avg(2), A.total(2), A.min(2), A.max(2), A.sum(5), A.max(5)]
+    for pred in (None, [F(4, O.GreaterThan(9300))]):
+        assert_values(rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs), "coercion")
+        for keys in ([3], [4]):
+            pq = rt.PreparedQuery(ht, pred, aggs, keys, True)
+            assert not pq.route_note.startswith("sort"), pq.route_note
+            pq.close()
+            got, want = rt.groupby(ht, pred, keys, aggs, True), orc.groupby(ot, pred, keys, aggs, True)
+            assert [r.keys[0].value for r in got] == [r.keys[0].value for r in want]
+            for x, y in zip(got, want):
+                assert_values(x.values, y.values, f"coercion/groupby {keys}")
+    with pytest.raises(abi.LlkvError) as e:
+        rt.aggregate(ht, None, [A.sum(4)])
+    assert e.value.kind == "Unsupported"
+
+
 def test_scan_stream_fails_at_the_window_whose_projection_failed(rt, abi):
     """A computed projection that fails (`% 0`) ends the stream at the 65 536-row window that holds the offending row:
     the windows before it have been delivered, that one and the later ones are not (the reference's arrow kernel

@@ -502,3 +502,28 @@ def test_decimal_from_f64_keeps_fifteen_significant_digits():
     text = q.format_answer_set(["k", "s", "a", "n"], [["A", 56586554400.730011, 25.5, 7]], ["string", "decimal", "float", "integer"])
     assert text == "k|s|a|n\nA|56586554400.73|25.5|7\n"
     assert q.parse_answer_set(text, ["string", "decimal", "float", "integer"]) == [[("string", "A"), ("decimal", Decimal("56586554400.73")), ("float", 25.5), ("int", 7)]]
+
+
+def test_string_to_number_coercion_follows_the_rust_float_grammar(lib):
+    """SUM / AVG / TOTAL / MIN / MAX over a Utf8 column accumulate `s.trim().parse::<f64>().unwrap_or(0.0)`
+    (llkv-aggregate/src/lib.rs:426-434).  The GPU path parses every dictionary entry once on the host; the oracle parses
+    every cell.  Both follow Rust's grammar, not strtod's: no hexadecimal forms, "1." and ".5" but not ".", inf /
+    infinity / nan in any case, Unicode white space trimmed, anything else counts as 0."""
+    import math
+    from oracle import oracle as orc
+    abi = mod("abi")
+    lib.llkv_plan_parse_numeric.restype = C.c_double
+    lib.llkv_plan_parse_numeric.argtypes = [C.c_char_p]
+    cases = [("12", 12.0), (" 12 ", 12.0), ("3.5e2", 350.0), ("-7.25", -7.25), ("+4", 4.0), ("1.", 1.0), (".5", 0.5), (".", 0.0), ("", 0.0), ("abc", 0.0),
+             ("0x10", 0.0), ("1e", 0.0), ("1e+", 0.0), ("1 2", 0.0), ("12abc", 0.0), ("1E3", 1000.0), ("1e-2", 0.01), ("inf", math.inf), ("-Infinity", -math.inf),
+             ("+INF", math.inf), ("infinit", 0.0), ("\u00a07\u2003", 7.0), ("\t\n 8 \r\x0b\x0c", 8.0), ("1_000", 0.0), ("٣", 0.0), ("1e400", math.inf),
+             ("0.1", 0.1), ("123456789012345678901234567890", 1.2345678901234568e29)]
+    for text, want in cases:
+        got = lib.llkv_plan_parse_numeric(text.encode())
+        assert got == want, (text, got, want)
+        t = orc.OracleTable(1).add(1, abi.DT_UTF8, [text])
+        v = orc.aggregate(t, None, [abi.AggregateSpec.total(1)])[0].value
+        assert v == want, (text, v, want)
+    assert math.isnan(lib.llkv_plan_parse_numeric(b"NaN")) and math.isnan(lib.llkv_plan_parse_numeric(b" -nan "))
+    t = orc.OracleTable(1).add(1, abi.DT_UTF8, ["nan"])
+    assert math.isnan(orc.aggregate(t, None, [abi.AggregateSpec.total(1)])[0].value)
