@@ -138,7 +138,7 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     kern_ms, launches, kname = q.kernel_time()
     q.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = {
@@ -341,7 +341,7 @@ def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         _, groups = run()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ts.append(float(dt.item()))
     ts.sort()
@@ -437,13 +437,24 @@ def main():
     rt = importlib.import_module("rust-llkv_amd.runtime")
     tpch = importlib.import_module("rust-llkv_amd.tpch")
 
+    # LLKV_BENCH_HOST_TRANSPORT=1: rehearsal of the N-rank orchestration on ONE GPU — every rank binds device 0, the
+    # library's collectives go through a host transport over gloo (llkv_hip_comm_init_custom) instead of RCCL, which
+    # refuses two ranks on one device.  Not a measurement.
+    rehearsal = bool(os.environ.get("LLKV_BENCH_HOST_TRANSPORT"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("LLKV_BENCH_FORCE_COLLECTIVE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     rt.init(local_rank)
-    if dist.is_initialized():
+    if dist.is_initialized() and rehearsal:
+        rt.comm_init_torch(dist, rank, world)
+    elif dist.is_initialized():
         # the library's own RCCL communicator (the collectives of the data path); torch.distributed only carries the
         # ncclUniqueId, the barriers and the max-over-ranks clock of the bench contract
         uid = [rt.comm_unique_id() if rank == 0 else None]
