@@ -19,7 +19,7 @@ static constexpr int kMaxKeysHost = 4;
 static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
 // shared-image route: one image [lane][group] of 8-byte slots per workgroup; 150 KiB of the CU's 160 KiB of LDS
 static constexpr uint32_t kMaxImageGroups = 1u << 16;
-static constexpr size_t kMaxImageBytes = 150u * 1024;
+static constexpr size_t kMaxImageBytes = 158u * 1024; // of the 160 KB of a CU (the kernel keeps one more word)
 static constexpr int kMaxImagePasses = 4; // scans of the table a shared-image plan may take (the groups cut into slices)
 
 const char *dtype_name(int32_t dt) {
