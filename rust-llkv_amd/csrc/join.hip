@@ -388,6 +388,55 @@ hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64
                      (unsigned long long *)count_by_group, multi_run);
   return hipGetLastError();
 }
+// The same straight from the probe's stripes (no scan, no compaction): stripe s holds counts[s] pairs in row order and
+// the stripes follow one another in row order, so a run of equal groups may continue into the next stripes that have
+// pairs.  One wave per stripe; the first pair of a run walks it to its end, across stripes.  counts[s] carries the
+// predicate-error mark of the probe (kPredErrorBit): it is raised into flags[1]; flags[0] as `multi_run` above.
+__global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
+                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags) {
+  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (slot >= n_slots) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t raw = counts[slot];
+  if (raw >= kPredErrorBit && lane == 0) atomicOr(&flags[1], 1u);
+  const uint32_t cnt = (uint32_t)(raw & (kPredErrorBit - 1));
+  if (cnt == 0) return;
+  // the group of the pair before this stripe's first one
+  uint32_t before = 0xFFFFFFFFu;
+  for (long long s = (long long)slot - 1; s >= 0; --s) {
+    const uint32_t c = (uint32_t)(counts[s] & (kPredErrorBit - 1));
+    if (c) { before = stripe_group[(uint64_t)s * stripe + c - 1]; break; }
+  }
+  const uint32_t *grp = stripe_group + (uint64_t)slot * stripe;
+  for (uint32_t i = lane; i < cnt; i += 64) {
+    const uint32_t g = grp[i];
+    if ((i ? grp[i - 1] : before) == g) continue; // not the first pair of its run
+    double acc = 0.0;
+    unsigned long long n = 0;
+    uint32_t s = slot, j = i, c = cnt;
+    for (;;) {
+      if (j == c) { // on to the next stripe that has pairs
+        do { ++s; } while (s < n_slots && (c = (uint32_t)(counts[s] & (kPredErrorBit - 1))) == 0);
+        if (s >= n_slots) break;
+        j = 0;
+      }
+      const uint64_t at = (uint64_t)s * stripe + j;
+      if (stripe_group[at] != g) break;
+      acc += __longlong_as_double((long long)stripe_val[at]);
+      ++n;
+      ++j;
+    }
+    if (atomicAdd(&count_by_group[g], n) != 0) atomicOr(&flags[0], 1u);
+    sum_by_group[g] = acc;
+  }
+}
+hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s) {
+  if (n_slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_run_sums_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group,
+                     (unsigned long long *)count_by_group, flags);
+  return hipGetLastError();
+}
 // the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
 __global__ __launch_bounds__(256) void hj_run_sums_dev_kernel(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, double *sum_by_group,
                                                                unsigned long long *count_by_group, uint32_t *multi_run) {

@@ -135,6 +135,9 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
                                   uint64_t *count_by_slot, hipStream_t s);
 // The same over unsorted pairs: runs are summed where they lie; *multi_run is set when a group has two runs
 // (count_by_group must start at zero) — the caller then sorts.
+// run sums straight from the probe's stripes; flags[0]: some group had two runs, flags[1]: a stripe count carried the predicate-error mark
+hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s);
 hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
                                   uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s);
 hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64_t n, double *sum_by_group, uint64_t *count_by_group,

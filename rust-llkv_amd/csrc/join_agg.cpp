@@ -152,6 +152,12 @@ struct JoinAgg {
   // … and their device sources, alive until then
   DirectTable set2_bits, dt;
   DB counts, offsets;
+  DB st_slot, st_val;                // the probe's stripes: (group id | hash slot, value) pairs per (tile, wave), row order
+  uint32_t n_slots = 0, stripe = 0;
+  bool from_stripes = false;         // the sums were taken straight from the stripes: no pair count, no compacted pairs yet
+  DB slot_group;                     // hash form: slot → group id
+  bool direct_form = false;
+  uint32_t pred_err = 0;
   DB zeros;                          // one zeroed block: [0] the run flag, [8..15] the top-k selection's state words
   uint32_t *multi_p() const { return static_cast<uint32_t *>(zeros.p); }
   uint64_t *topk_state() const { return static_cast<uint64_t *>(zeros.p) + 8; }
@@ -164,6 +170,7 @@ struct JoinAgg {
   int prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
               const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len, bool defer = false);
   int settle(bool delivered = false);
+  int compact_pairs(bool run_sums);
   int straddlers();
   int candidates(const uint32_t *f_groups, const double *f_sums, const uint64_t *f_counts, const uint32_t *f_first_rank, uint64_t n_folded,
                  uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups);
@@ -205,7 +212,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   // ---- everything that starts from zero, in one fill: the key bitmaps, the probe's per-stripe counts, the flags --------
   const TileSet *ts = nullptr;
   if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
-  const uint32_t n_slots = ts->n_tiles * (kBlock / 64);
+  n_slots = ts->n_tiles * (kBlock / 64);
   {
     FillRanges fr;
     if (fused_semi && (rc = set2_bits.prepare_bits(t2->cols.find(dim2->key_field)->second.info, s, &fr))) return rc;
@@ -321,8 +328,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   // key range bounded by the column statistics → bitmap + rank (no hashing, and a clustered fact table probes it
   // almost sequentially); otherwise the open-addressing table
   HashSet ht;
-  DB slot_group;
   bool dup = false;
+  direct_form = direct;
   if (direct) { // launches only; the duplicate flag is read with the pair count below
     if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, s, dt_bits_done && d_dim_rows == seld.d_dev))) return rc;
   } else {
@@ -369,33 +376,52 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   }
   // single pass over the fact columns: every (tile, wave) writes its pairs into its own stripe and reports its
   // count; only the emitted pairs (a few percent of the rows for Q3) are touched again by the compaction
-  const uint32_t stripe = p.sub_rows;
-  DB st_slot, st_val;
+  stripe = p.sub_rows;
   if ((rc = st_slot.alloc((size_t)n_slots * stripe * 4)) || (rc = st_val.alloc((size_t)n_slots * stripe * 8))) return rc;
   p.aux_in = nullptr;
   p.aux_out32 = (uint32_t *)st_slot.p;
   p.aux_out = (uint64_t *)st_val.p;
   if ((rc = jit_launch_raw(direct ? k.fn2 : k.fn, ts->n_tiles, &p, sizeof p, s))) return rc;
-  DB scan_tmp;
-  if (n_slots <= 64 * 1024) HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, s)); // one workgroup, rounds of 8 192
-  else if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
-  // No host round trip between the probe and the sums: the compaction and the run sums take the pair count where the
-  // scan left it (offsets[n_slots], device), the pair arrays are sized by the bound (one pair per local fact row).
-  const uint64_t max_pairs = tf->local_rows;
-  if ((rc = e_group.alloc(max_pairs * 4)) || (rc = e_val.alloc(max_pairs * 8))) return rc;
-  HIP_TRY(hj_launch_compact_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p, n_slots, stripe,
-                                    direct ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
   // ---- per-group sums in scan order ------------------------------------------------------------
   // The pairs are in row order.  A fact table clustered by the join key leaves every group as ONE run of them: sum
   // the runs where they lie; only when some group turns out to have a second run, sort (stable) by group first.
-  HIP_TRY(hj_launch_run_sums_dev((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, (const uint64_t *)offsets.p + n_slots, max_pairs, (double *)sums.p,
-                                 (uint64_t *)cnts.p, multi_p(), s));
-  if ((rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) ||
-      (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) || (rc = rb.add(&multi_run, multi_p(), 4, s)))
+  // One rank, direct table: straight from the stripes (no scan, no compaction, no pair count) — whoever needs the
+  // pairs themselves later (the sort, a sharded fact table's straddlers) compacts them then.
+  from_stripes = defer && direct && tf->world == 1 && !std::getenv("LLKV_HIP_JOIN_COMPACT");
+  if (from_stripes) {
+    HIP_TRY(hj_launch_run_sums_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, n_slots, stripe, (double *)sums.p,
+                                       (uint64_t *)cnts.p, multi_p(), s));
+  } else if ((rc = compact_pairs(true))) {
+    return rc;
+  }
+  if ((!from_stripes && (rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s))) || (from_stripes && (rc = rb.add(&pred_err, multi_p() + 1, 4, s))) ||
+      (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) || (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) ||
+      (rc = rb.add(&multi_run, multi_p(), 4, s)))
     return rc;
   pending = true;
   if (defer) return LLKV_OK; // the sources are members: the selection's last workgroup carries the items
   return settle();
+}
+
+// Stripes → contiguous pairs in row order (e_group / e_val, sized by the bound of one pair per local fact row; the
+// pair count stays on the device: offsets[n_slots]), and optionally the run sums over them.  Launches only.
+int JoinAgg::compact_pairs(bool run_sums) {
+  hipStream_t s = g_ctx.stream;
+  int rc;
+  DB scan_tmp;
+  if (n_slots <= 64 * 1024) HIP_TRY(launch_exclusive_scan((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots, s)); // one workgroup, rounds of 8 192
+  else {
+    if ((rc = scan_exclusive((const uint64_t *)counts.p, (uint64_t *)offsets.p, n_slots + 1, scan_tmp, s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s)); // scan_tmp is released on return
+  }
+  const uint64_t max_pairs = tf->local_rows;
+  if ((rc = e_group.alloc(max_pairs * 4)) || (rc = e_val.alloc(max_pairs * 8))) return rc;
+  HIP_TRY(hj_launch_compact_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p, n_slots, stripe,
+                                    direct_form ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
+  if (run_sums)
+    HIP_TRY(hj_launch_run_sums_dev((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, (const uint64_t *)offsets.p + n_slots, max_pairs, (double *)sums.p,
+                                   (uint64_t *)cnts.p, multi_p(), s));
+  return LLKV_OK;
 }
 
 // The read-back of prepare(): errors, and the sort-based sums when some group's pairs were not one run.
@@ -406,8 +432,15 @@ int JoinAgg::settle(bool delivered) {
   if (!delivered && (rc = rb.wait())) return rc;
   pending = false;
   hipStream_t s = g_ctx.stream;
-  if (key_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
+  if (key_err || pred_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
+  if (from_stripes) {
+    if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) return LLKV_OK; // sums and counts are final; nobody asked for the pairs
+    // the sort needs the pairs: compact them now, and their number
+    Readback cnt;
+    if ((rc = compact_pairs(false)) || (rc = cnt.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s)) || (rc = cnt.wait())) return rc;
+    from_stripes = false;
+  }
   if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
   if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
