@@ -408,26 +408,47 @@ __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t
     if (c) { before = stripe_group[(uint64_t)s * stripe + c - 1]; break; }
   }
   const uint32_t *grp = stripe_group + (uint64_t)slot * stripe;
-  for (uint32_t i = lane; i < cnt; i += 64) {
-    const uint32_t g = grp[i];
-    if ((i ? grp[i - 1] : before) == g) continue; // not the first pair of its run
-    double acc = 0.0;
-    unsigned long long n = 0;
-    uint32_t s = slot, j = i, c = cnt;
-    for (;;) {
-      if (j == c) { // on to the next stripe that has pairs
-        do { ++s; } while (s < n_slots && (c = (uint32_t)(counts[s] & (kPredErrorBit - 1))) == 0);
-        if (s >= n_slots) break;
-        j = 0;
+  const uint64_t *val = stripe_val + (uint64_t)slot * stripe;
+  // 64 pairs at a time through the LDS (one coalesced load): the first pair of a run then walks the run there instead
+  // of through dependent global loads — left to right, the reference's order of additions
+  __shared__ uint32_t lg[4][64];
+  __shared__ uint64_t lv[4][64];
+  const uint32_t w = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const uint32_t i = base + lane;
+    const bool live = i < cnt;
+    const uint32_t g = live ? grp[i] : 0xFFFFFFFFu;
+    lg[w][lane] = g;
+    lv[w][lane] = live ? val[i] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t left = lane ? lg[w][lane - 1] : (base ? grp[base - 1] : before);
+    if (live && left != g) { // the first pair of its run
+      double acc = 0.0;
+      unsigned long long n = 0;
+      const uint32_t m = cnt - base < 64 ? cnt - base : 64; // pairs in this chunk
+      uint32_t j = lane;
+      for (; j < m && lg[w][j] == g; ++j) { acc += __longlong_as_double((long long)lv[w][j]); ++n; }
+      if (j == m) { // the run may go on behind this chunk: the rest of the stripe, then the stripes that follow
+        uint32_t s = slot, k = base + m, c = cnt;
+        for (;;) {
+          if (k >= c) { // on to the next stripe that has pairs
+            do { ++s; } while (s < n_slots && (c = (uint32_t)(counts[s] & (kPredErrorBit - 1))) == 0);
+            if (s >= n_slots) break;
+            k = 0;
+          }
+          const uint64_t at = (uint64_t)s * stripe + k;
+          if (stripe_group[at] != g) break;
+          acc += __longlong_as_double((long long)stripe_val[at]);
+          ++n;
+          ++k;
+        }
       }
-      const uint64_t at = (uint64_t)s * stripe + j;
-      if (stripe_group[at] != g) break;
-      acc += __longlong_as_double((long long)stripe_val[at]);
-      ++n;
-      ++j;
+      if (atomicAdd(&count_by_group[g], n) != 0) atomicOr(&flags[0], 1u);
+      sum_by_group[g] = acc;
     }
-    if (atomicAdd(&count_by_group[g], n) != 0) atomicOr(&flags[0], 1u);
-    sum_by_group[g] = acc;
+    __builtin_amdgcn_wave_barrier(); // the chunk is overwritten next
   }
 }
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,

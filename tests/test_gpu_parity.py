@@ -1718,6 +1718,42 @@ def test_join_groupby_topk_with_tied_sums(rt, abi, n_orders, limit):
     assert [(r[0], r[1], r[2], r[3]) for r in got] == [(int(okey[i]), float(sums[i]), int(counts[i]), int(odate[i])) for i in order]
 
 
+@pytest.mark.parametrize("rows_per_group", [1, 7, 60, 700, 5000])
+def test_join_groupby_sums_every_group_left_to_right_across_stripes(rt, abi, rows_per_group, monkeypatch):
+    """Every group of the join → GROUP BY pipeline, not only the top few: 200 groups whose fact rows are runs of
+    1 … 5 000 rows, so runs end inside a probe stripe (2 048 rows of a tile), span several stripes and whole tiles.
+    The sums are the reference's sequential f64 chain per group (SumFloat64: 0.0 then += in row order,
+    llkv-aggregate/src/lib.rs:870-888) — compared bit for bit with a sequential numpy accumulate, through the sums
+    taken straight from the stripes and through the compacted pairs."""
+    rng = np.random.default_rng(rows_per_group)
+    n_groups = 200
+    sizes = np.maximum(1, rng.integers(rows_per_group // 2, rows_per_group * 3 // 2 + 1, size=n_groups))
+    okey = np.arange(1, n_groups + 1, dtype=np.int64) * 5
+    lkey = np.repeat(okey, sizes)
+    hole = rng.random(len(lkey)) < 0.1  # fact rows that do not pass the filter: the stripes hold fewer pairs than rows
+    price = rng.normal(1000.0, 300.0, size=len(lkey))
+    flag = np.where(hole, 0, 1).astype(np.int64)
+    ot_ = rt.HipTable(2, [n_groups]); ot_.append_column(1, abi.DT_INT64, okey); ot_.append_column(2, abi.DT_DATE32, np.full(n_groups, 9000, dtype=np.int32))
+    lt = rt.HipTable(1, tpch_chunks(len(lkey))); lt.append_column(7, abi.DT_INT64, lkey); lt.append_column(8, abi.DT_FLOAT64, price); lt.append_column(9, abi.DT_INT64, flag)
+    want = {}
+    lo = 0
+    for k, sz in zip(okey, sizes):
+        v = price[lo:lo + sz][~hole[lo:lo + sz]]
+        if len(v):
+            want[int(k)] = (np.add.accumulate(np.concatenate([[0.0], v]))[-1], len(v))  # 0.0 + v0 + v1 + … left to right
+        lo += sz
+    for env in (None, "LLKV_HIP_JOIN_COMPACT"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        got, total = rt.join_groupby_topk(lt, [abi.Filter(9, abi.Operator.Equals(1))], 7, ot_, [], 1, abi.col(8) * 1.0, payload_fields=[2], limit=256)
+        assert total == len(want) == len(got)
+        assert {r[0]: (np.float64(r[1]).tobytes(), r[2]) for r in got} == {k: (np.float64(s).tobytes(), c) for k, (s, c) in want.items()}
+
+
+def tpch_chunks(n, chunk=131072):
+    return [min(chunk, n - lo) for lo in range(0, n, chunk)] or [0]
+
+
 @pytest.mark.parametrize("switches", [("LLKV_HIP_JOIN_HASH",), ("LLKV_HIP_JOIN_SORT",), ("LLKV_HIP_TOPK_SORT",), ("LLKV_HIP_TOPK_SORT", "LLKV_HIP_TOPK_FULL"),
                                       ("LLKV_HIP_JOIN_HASH", "LLKV_HIP_JOIN_SORT", "LLKV_HIP_TOPK_SORT"), ("LLKV_HIP_SELECT_TWO_PASS",),
                                       ("LLKV_HIP_JOIN_UNSORTED",), ("LLKV_HIP_JOIN_UNSORTED", "LLKV_HIP_JOIN_NO_SINK"), ("LLKV_HIP_READBACK_SYNC",),
