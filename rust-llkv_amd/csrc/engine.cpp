@@ -81,11 +81,13 @@ static uint32_t pick_tile_rows(const LoweredPlan &p) {
   return p.acc_image ? 8192u : p.acc_lds ? 16384u : 4096u; // shared-image plans: tiles are only a work list (every lane is order-free)
 }
 
-// Workgroups of a shared-image scan (1024 threads each, persistent: workgroup b takes tiles b, b + g, …): as many as
-// fit the CUs at once — two per CU while two images fit the 160 KB of LDS.
+// Workgroups of a shared-image scan (1024 threads each, persistent: workgroup b takes tiles b, b + g, …): one per CU.
+// The kernel is bound by the rate of DS atomics to scattered addresses (~60–100 cycles per 64-lane instruction: GROUP BY
+// l_shipdate with only count(*) — 4 B/row — still takes 0.15 ms), and a second workgroup on a CU adds nothing but its
+// image: 512 workgroups 0.25 ms, 1 024: 0.47 ms (profiles/r02/pmc_image.txt).
 static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
-  const size_t slice_bytes = ((size_t)p.ng + p.image_passes - 1) / p.image_passes * p.k * 8;
-  uint32_t grid = slice_bytes <= 76u * 1024 ? 512u : 256u;
+  (void)p;
+  uint32_t grid = 256u;
   if (const char *e = std::getenv("LLKV_HIP_IMAGE_WGS")) {
     long v = std::atol(e);
     if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 16);

@@ -24,9 +24,12 @@ wide = [A.count_star(), A.sum(S["l_quantity"][0]), A.avg(S["l_quantity"][0]), A.
         A.avg(S["l_extendedprice"][0]), A.min(S["l_extendedprice"][0]), A.max(S["l_extendedprice"][0]), A.sum(rev), A.avg(S["l_discount"][0]), A.total(S["l_discount"][0])]
 mid = [A.count_star(), A.sum(S["l_quantity"][0]), A.sum(rev), A.avg(S["l_discount"][0])]
 out = {}
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # "image_only": just the shared-image cases (counter runs)
 for name, keys, aggs in (("by_orderkey", [S["l_orderkey"][0]], narrow), ("by_partkey", [S["l_partkey"][0]], narrow), ("by_shipdate", [S["l_shipdate"][0]], narrow),
-                         ("by_shipdate_4aggs", [S["l_shipdate"][0]], mid), ("by_flag_status_shipdate", [S["l_returnflag"][0], S["l_linestatus"][0], S["l_shipdate"][0]], narrow[:2]),
+                         ("by_shipdate_count_only", [S["l_shipdate"][0]], narrow[:1]), ("by_shipdate_4aggs", [S["l_shipdate"][0]], mid), ("by_flag_status_shipdate", [S["l_returnflag"][0], S["l_linestatus"][0], S["l_shipdate"][0]], narrow[:2]),
                          ("q1_wide_state", [S["l_returnflag"][0], S["l_linestatus"][0]], wide)):
+    if only == "image_only" and name not in ("by_shipdate", "by_shipdate_count_only"):
+        continue
     q = rt.PreparedQuery(t, None, aggs, keys, True)
     image = q.kernel_signature.endswith(",2>")
     ts = []
