@@ -355,6 +355,10 @@ llkv_status llkv_hip_table_local_column_float_stats(const llkv_hip_table *table,
                                                     int32_t *has_stats, double *abs_max, double *abs_min_nonzero);
 llkv_status llkv_hip_table_set_column_float_stats(llkv_hip_table *table, uint32_t field_id,
                                                   double abs_max, double abs_min_nonzero);
+/* … and whether the column holds no NaN / ±∞ at all (`*all_finite` of this rank's rows; installed table-wide = every
+ * rank's rows are): then such a sum is ONE integer lane of grid steps in the kernel's image (SumF64Q).            */
+llkv_status llkv_hip_table_local_column_all_finite(const llkv_hip_table *table, uint32_t field_id, int32_t *all_finite);
+llkv_status llkv_hip_table_set_column_all_finite(llkv_hip_table *table, uint32_t field_id, int32_t all_finite);
 
 /* Bytes moved host → HBM by the staging calls of this process so far, and the wall
  * time those copies took (pinned ring fill + DMA; the host-side preparation of a
@@ -872,6 +876,7 @@ typedef struct llkv_column_desc {
   int32_t has_fstats; /* Float64 / Float32: the two statistics below are known */
   double f_absmax;    /* largest |v| over the column's finite values         */
   double f_absmin_nz; /* smallest non-zero |v| over them (0: none)           */
+  int32_t f_all_finite; /* … and the column holds no NaN / ±∞                */
 } llkv_column_desc;
 
 /* `grouped`: 0 = ungrouped aggregates, 1 = GROUP BY (groups in first-appearance

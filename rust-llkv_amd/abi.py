@@ -130,7 +130,8 @@ class CColumnDesc(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("rows", C.c_uint64), ("has_stats", C.c_int32),
                 ("min_i", C.c_int64), ("max_i", C.c_int64), ("dict_size", C.c_uint32),
                 ("dictionary", C.POINTER(C.c_char_p)), ("nullable", C.c_int32),
-                ("precision", C.c_int32), ("scale", C.c_int32), ("has_fstats", C.c_int32), ("f_absmax", C.c_double), ("f_absmin_nz", C.c_double)]
+                ("precision", C.c_int32), ("scale", C.c_int32), ("has_fstats", C.c_int32), ("f_absmax", C.c_double), ("f_absmin_nz", C.c_double),
+                ("f_all_finite", C.c_int32)]
 
 
 class CJoinSide(C.Structure):

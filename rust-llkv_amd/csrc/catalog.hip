@@ -61,12 +61,15 @@ template <class T> __global__ __launch_bounds__(256) void minmax_kernel(const T 
 }
 
 // Float column statistics over the FINITE values (NaN / ±∞ are skipped: they travel through the sums as such):
-// out[0] = bits of the largest |v|, out[1] = bits of the smallest non-zero |v| (non-negative doubles order like their bits).
+// out[0] = bits of the largest |v|, out[1] = bits of the smallest non-zero |v| (non-negative doubles order like their bits),
+// out[2] != 0 when some value is NaN or ±∞.
 template <class T> __global__ __launch_bounds__(256) void absrange_kernel(const T *v, uint64_t n, unsigned long long *out) {
   double hi = 0.0, lo = __builtin_inf();
+  bool wild = false;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const double x = __builtin_fabs((double)v[i]);
     const bool finite = x < __builtin_inf();
+    wild |= !finite;
     hi = (finite && x > hi) ? x : hi;
     lo = (finite && x > 0.0 && x < lo) ? x : lo;
   }
@@ -79,6 +82,7 @@ template <class T> __global__ __launch_bounds__(256) void absrange_kernel(const 
     atomicMax(&out[0], (unsigned long long)__double_as_longlong(hi));
     atomicMin(&out[1], (unsigned long long)__double_as_longlong(lo));
   }
+  if (__ballot(wild) != 0 && (threadIdx.x & 63) == 0) atomicOr(&out[2], 1ull);
 }
 hipError_t launch_absrange_f64(const double *values, uint64_t n, uint64_t *d_bits, hipStream_t stream) {
   hipLaunchKernelGGL((absrange_kernel<double>), dim3(1024), dim3(256), 0, stream, values, n, (unsigned long long *)d_bits);
@@ -107,9 +111,10 @@ hipError_t launch_fill_padding(void *col, uint32_t width, const uint64_t *d_pad,
 }
 
 hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const uint8_t *lane_ops, uint32_t n_wg, uint32_t ng, uint32_t k, uint32_t owned_mask,
-                             uint32_t passes, hipStream_t stream) {
-  ImageFoldParams f{partials, exchange, lane_ops, n_wg, ng, k, owned_mask, passes, (ng + passes - 1) / passes};
-  hipLaunchKernelGGL(image_fold_kernel, dim3((ng * k + 1 + 255) / 256), dim3(256), 0, stream, f);
+                             uint32_t passes, uint32_t kl, const uint8_t *lane_src, const uint8_t *lane_xf, hipStream_t stream) {
+  const uint32_t ngs = (ng + passes - 1) / passes;
+  ImageFoldParams f{partials, exchange, lane_ops, n_wg, ng, k, owned_mask, passes, ngs, kl, lane_src, lane_xf};
+  hipLaunchKernelGGL(image_fold_kernel, dim3((ng * k + 1 + kFoldCells - 1) / kFoldCells), dim3(256), 0, stream, f);
   return hipGetLastError();
 }
 

@@ -47,6 +47,6 @@ hipError_t launch_fill_padding(void *col, uint32_t width, const uint64_t *d_pad,
 // Shared-image GROUP BY: workgroup images [pass][n_wg][k·ngs + 1] (lane-major, ngs = ⌈ng / passes⌉ groups per slice)
 // → exchange image [8][ng·k + 1] (group-major).
 hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const uint8_t *lane_ops, uint32_t n_wg, uint32_t ng, uint32_t k, uint32_t owned_mask,
-                             uint32_t passes, hipStream_t stream);
+                             uint32_t passes, uint32_t kl, const uint8_t *lane_src, const uint8_t *lane_xf, hipStream_t stream);
 
 } // namespace llkv

@@ -74,11 +74,14 @@ Query::~Query() {
 // and like many small tiles (4 096 rows); LDS-resident grouped states use 16 384-row tiles and let a workgroup stream
 // several of them (pick_scan_grid).
 static uint32_t pick_tile_rows(const LoweredPlan &p) {
+  // shared-image plans: tiles are only a work list (every lane is order-free); one tile = the plan's U steps of 2 048 rows,
+  // which the kernel requests as one batch of loads (image_scan_body) — not tunable
+  if (p.acc_image) return 2048u * (uint32_t)p.unroll;
   if (const char *e = std::getenv("LLKV_HIP_TILE_ROWS")) {
     long v = std::atol(e);
     if (v >= 512 && v % 512 == 0) return (uint32_t)v;
   }
-  return p.acc_image ? 8192u : p.acc_lds ? 16384u : 4096u; // shared-image plans: tiles are only a work list (every lane is order-free)
+  return p.acc_lds ? 16384u : 4096u;
 }
 
 // Workgroups of a shared-image scan (1024 threads each, persistent: workgroup b takes tiles b, b + g, …): one per CU.
@@ -86,12 +89,12 @@ static uint32_t pick_tile_rows(const LoweredPlan &p) {
 // l_shipdate with only count(*) — 4 B/row — still takes 0.15 ms), and a second workgroup on a CU adds nothing but its
 // image: 512 workgroups 0.25 ms, 1 024: 0.47 ms (profiles/r02/pmc_image.txt).
 static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
-  (void)p;
   uint32_t grid = 256u;
   if (const char *e = std::getenv("LLKV_HIP_IMAGE_WGS")) {
     long v = std::atol(e);
     if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 16);
   }
+  grid = std::max(grid, p.image_min_grid); // fewer workgroups: an image would see more rows than its fixed-point lanes were sized for
   return std::max(1u, std::min(grid, n_tiles));
 }
 
@@ -224,12 +227,19 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   const size_t lanes = (size_t)p.lanes;
   const uint32_t parts_per_tile = p.acc_lds ? (uint32_t)(kBlock / 64) : 1u; // LDS-accumulator plans publish one partial per (tile, wave)
   q->image_grid = p.acc_image ? pick_image_grid(p, ts->n_tiles) : 0;
-  const size_t image_slice_words = p.acc_image ? ((size_t)p.ng + p.image_passes - 1) / p.image_passes * p.k + 1 : 0;
+  const size_t image_slice_words = p.acc_image ? ((size_t)p.ng + p.image_passes - 1) / p.image_passes * p.k_image + 1 : 0;
   q->partials_len = std::max<size_t>(1, p.acc_image ? image_slice_words * q->image_grid * p.image_passes : lanes * ts->n_tiles * parts_per_tile);
   q->d_tile_partials = (uint64_t *)scratch_alloc(2 * q->partials_len * sizeof(uint64_t));
-  q->d_lane_ops = (uint8_t *)scratch_alloc(lanes);
+  // lane ops, then (shared-image plans) the fold's expansion tables: [lanes] ops, [k] source kernel lane, [k] transform
+  std::vector<uint8_t> lane_tables(p.lane_ops.begin(), p.lane_ops.end());
+  lane_tables.insert(lane_tables.end(), p.image_src.begin(), p.image_src.end());
+  lane_tables.resize(lanes + p.k, 0);
+  lane_tables.insert(lane_tables.end(), p.image_xf.begin(), p.image_xf.end());
+  lane_tables.resize(lanes + 2 * (size_t)p.k, 0);
+  q->d_lane_ops = (uint8_t *)scratch_alloc(lane_tables.size());
   if (!q->d_tile_partials || !q->d_lane_ops) return set_error(LLKV_INTERNAL, "device allocation failed");
-  HIP_TRY(hipMemcpyAsync(q->d_lane_ops, p.lane_ops.data(), lanes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(q->d_lane_ops, lane_tables.data(), lane_tables.size(), hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream)); // `lane_tables` is pageable and goes out of scope
   for (auto &e : q->ev_fold) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : q->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const size_t ring_bytes = Query::kMaxDepth * kOctantsHost * lanes * sizeof(uint64_t);
@@ -326,10 +336,11 @@ int Query::launch(hipStream_t stream) {
       for (int pass = 0; pass < plan.image_passes; ++pass) { // one scan per slice of the groups
         ScanParams p = params;
         p.group_base = (uint32_t)pass * ngs;
-        p.tile_partials = d_tile_partials + (size_t)pass * image_grid * ((size_t)ngs * plan.k + 1);
+        p.tile_partials = d_tile_partials + (size_t)pass * image_grid * ((size_t)ngs * plan.k_image + 1);
         if ((rc = jit_launch_raw(jit.fn, image_grid, &p, sizeof p, stream, 1024))) return rc;
       }
-      HIP_TRY(launch_image_fold(d_tile_partials, image, d_lane_ops, image_grid, plan.ng, (uint32_t)plan.k, table->owned_mask, (uint32_t)plan.image_passes, stream));
+      HIP_TRY(launch_image_fold(d_tile_partials, image, d_lane_ops, image_grid, plan.ng, (uint32_t)plan.k, table->owned_mask, (uint32_t)plan.image_passes,
+                                (uint32_t)plan.k_image, d_lane_ops + plan.lanes, d_lane_ops + plan.lanes + plan.k, stream));
     } else {
       HIP_TRY(hipMemcpyAsync(image, d_empty_image, exchange_len() * sizeof(uint64_t), hipMemcpyDefault, stream));
     }
@@ -420,6 +431,10 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   // an f64 sum: one lane, or the exact grid-level lanes of the shared-image plans (fused_scan.hip.h: SumF64X), added
   // smallest level first
   auto f64_sum = [&]() {
+    if (a.fixed_point) { // SumF64Q: grid steps as low 32 bits + high part, both summed over workgroups, octants and ranks
+      const i128 steps = ((i128)(int64_t)l[1] << 32) + (i128)(int64_t)l[0];
+      return std::ldexp((double)steps, a.fixed_exp); // (the conversion rounds to nearest even; the scaling is exact)
+    }
     if (a.exact_levels <= 1) return as_f64(l[0]);
     double v = as_f64(l[a.exact_levels - 1]);
     for (int j = a.exact_levels - 2; j >= 0; --j) v += as_f64(l[j]);

@@ -47,6 +47,7 @@ struct DeviceColumn {
   int64_t local_min = 0, local_max = 0;
   bool has_local_fstats = false; // float columns: largest finite |v| of this rank's rows (info.has_fstats / f_absmax are table-wide)
   double local_f_absmax = 0.0, local_f_absmin_nz = 0.0;
+  bool local_f_all_finite = false; // … and none of this rank's values is NaN / ±∞
   uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
   bool owned = false;
 };

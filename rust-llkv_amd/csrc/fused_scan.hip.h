@@ -511,6 +511,16 @@ template <class E, class... Cs> struct SumF64X {
   }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { cut<Cs...>(c, j, (double)E::eval(c, j), o); }
 };
+// The same idea in ONE lane when the argument's range allows (shared-image plans, where every DS atomic to a scattered
+// address costs tens of cycles): the row's value as an integer count of grid steps, q = rint(x · 2^−e) with the grid
+// 2^e at 2^-30 of the smallest non-zero |x| — an int64 sum per workgroup image (|q| · rows of a workgroup < 2^62, the
+// lowering checks), split into low 32 bits / high part when the images are folded so that no exchange lane overflows.
+// S = LitF<2^−e>.  The argument's columns hold no NaN / ±∞ (staging statistic).
+template <class E, class S> struct SumF64Q {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)__double2ll_rn((double)E::eval(c, j) * S::eval(c, j)); }
+};
 template <class E> struct SumI64 { // SumInt64 :801-830, AvgInt64 :1114-1144 — exact 96-bit split sum + max|v|
   static constexpr int N = 3;
   static constexpr int op(int k) { return k == 2 ? OP_MAX_U64 : OP_ADD_I64; }
@@ -1028,34 +1038,49 @@ template <class P> __device__ __forceinline__ void image_scan_body(const ScanPar
   if (tid == 0) block_err = 0;
   __syncthreads();
 
+  // A tile is U steps of 2 048 rows (engine.cpp: pick_tile_rows — tiles are only a work list here), so one batch of
+  // loads covers it.  Two register buffers take turns: the loads of the tile after next are requested before a tile is
+  // accumulated — the sixteen waves of the one workgroup a CU holds run in step, and with a single buffer every batch
+  // paid its latency AND its transfer (0.37 ms for 28 B/row whatever the aggregates; 0.16 ms for 4 B/row).
   uint32_t err = 0;
-  for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    const TileDesc td = load_tile_desc(p.tiles, tile);
-    const uint32_t nsteps = (td.rows + kImgStepRows - 1) / kImgStepRows;
-    for (uint32_t s = 0; s < nsteps; s += U) {
-      Loaded ld[U];
+  auto issue = [&](const TileDesc &td, Loaded (&ld)[U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + u) * kImgStepRows + (uint64_t)tid * kRowsPerThread, ld[u]);
+    for (int u = 0; u < U; ++u) load_all<typename P::ColList>(p, td.dev_row + (uint64_t)u * kImgStepRows + (uint64_t)tid * kRowsPerThread, ld[u]);
+  };
+  auto accumulate = [&](const TileDesc &td, const Loaded (&ld)[U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t row0 = (s + u) * kImgStepRows + tid * kRowsPerThread;
+    for (int u = 0; u < U; ++u) {
+      const uint32_t row0 = u * kImgStepRows + tid * kRowsPerThread;
 #pragma unroll
-        for (int j = 0; j < kRowsPerThread; ++j) {
-          Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
-          const bool in_tile = (row0 + j) < td.rows;
-          uint32_t gid = P::KeyT::gid(c, j) - p.group_base; // groups of other slices (and the arbitrary codes of
-          const bool mine = gid < (uint32_t)NG;              // rows past the tile end) wrap past NG
-          const bool pass = in_tile & mine & P::Pred::eval(c, j);
-          gid = mine ? gid : 0u;
-          uint64_t contrib[K];
-          contrib[0] = 1;
-          if constexpr (P::first) contrib[1] = c.row;
-          AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
-          err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
-          if (pass) image_accumulate_row<P, NG>(img, gid, contrib);
-        }
+      for (int j = 0; j < kRowsPerThread; ++j) {
+        Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
+        const bool in_tile = (row0 + j) < td.rows;
+        uint32_t gid = P::KeyT::gid(c, j) - p.group_base; // groups of other slices (and the arbitrary codes of
+        const bool mine = gid < (uint32_t)NG;              // rows past the tile end) wrap past NG
+        const bool pass = in_tile & mine & P::Pred::eval(c, j);
+        gid = mine ? gid : 0u;
+        uint64_t contrib[K];
+        contrib[0] = 1;
+        if constexpr (P::first) contrib[1] = c.row;
+        AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
+        err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
+        if (pass) image_accumulate_row<P, NG>(img, gid, contrib);
       }
     }
+  };
+  const uint32_t n = p.n_tiles, g = gridDim.x;
+  uint32_t ta = blockIdx.x, tb = ta + g; // the tiles in buffers A and B (≥ n: none)
+  TileDesc da = load_tile_desc(p.tiles, ta < n ? ta : 0), db = load_tile_desc(p.tiles, tb < n ? tb : 0);
+  Loaded la[U], lb[U];
+  if (ta < n) issue(da, la);
+  while (ta < n) {
+    if (tb < n) issue(db, lb);
+    accumulate(da, la);
+    ta = tb + g;
+    if (ta < n) { da = load_tile_desc(p.tiles, ta); issue(da, la); }
+    if (tb < n) accumulate(db, lb);
+    tb = ta + g;
+    if (tb < n) db = load_tile_desc(p.tiles, tb);
   }
   if (err) atomicOr(&block_err, err);
   __syncthreads();
@@ -1075,25 +1100,49 @@ struct ImageFoldParams {
   const uint8_t *lane_ops; // [K]: op of lane k of a group
   uint32_t n_wg, ng, k, owned_mask;
   uint32_t passes, ngs; // slices of the groups, groups per slice
+  uint32_t kl;          // lanes per group of the kernel's image (≤ k: a fixed-point sum is one lane there, two here)
+  const uint8_t *lane_src, *lane_xf; // [K]: exchange lane k = xf(kernel lane src): 0 as is, 1 low 32 bits, 2 high part
 };
+// 32 cells (lane k, group g) per workgroup, 8 threads per cell: thread (cell, part) combines the workgroup images
+// part, part + 8, … — four loads in flight — and the 8 parts meet in the LDS.  (One thread per cell walking all the
+// images one dependent load at a time took 0.13 ms for 256 images: a third of the whole GROUP BY.)
+constexpr uint32_t kFoldCells = 32, kFoldParts = 8;
 __global__ __launch_bounds__(256) void image_fold_kernel(const ImageFoldParams f) {
-  const uint32_t lanes = f.ng * f.k + 1, slice = f.ngs * f.k + 1; // exchange lanes; words of one workgroup image
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x; // (lane k, group g) in lane-major order, or the error lane
-  if (i >= lanes) return;
+  __shared__ uint64_t part_v[kFoldParts][kFoldCells];
+  const uint32_t lanes = f.ng * f.k + 1, slice = f.ngs * f.kl + 1; // exchange lanes; words of one workgroup image
+  const uint32_t cell = threadIdx.x % kFoldCells, part = threadIdx.x / kFoldCells;
+  const uint32_t i = blockIdx.x * kFoldCells + cell; // (lane k, group g) in lane-major order, or the error lane
   const uint32_t o = (uint32_t)__builtin_ctz(f.owned_mask | (1u << kOctants)); // first owned octant
   if (o >= (uint32_t)kOctants) return;
-  if (i == lanes - 1) { // error lane: the largest code any workgroup of any pass reported
-    uint64_t e = 0;
-    for (uint32_t w = 0; w < f.passes * f.n_wg; ++w) e = lane_combine(OP_MAX_U64, e, f.partials[(uint64_t)w * slice + slice - 1]);
-    f.exchange[(uint64_t)o * lanes + i] = e;
-    return;
-  }
-  const uint32_t k = i / f.ng, g = i % f.ng, pass = g / f.ngs, gs = g % f.ngs;
-  const int op = (int)f.lane_ops[k];
-  const uint64_t *src = f.partials + (uint64_t)pass * f.n_wg * slice + (uint64_t)k * f.ngs + gs;
+  const bool live = i < lanes, err_lane = i == lanes - 1;
+  const uint32_t k = live && !err_lane ? i / f.ng : 0, g = live && !err_lane ? i % f.ng : 0, pass = g / f.ngs, gs = g % f.ngs;
+  const int op = err_lane ? OP_MAX_U64 : (int)f.lane_ops[k];
+  const uint32_t xf = err_lane ? 0u : f.lane_xf[k];
+  // error lane: the largest code any workgroup of any pass reported (the last word of every image)
+  const uint64_t *src = err_lane ? f.partials + slice - 1 : f.partials + (uint64_t)pass * f.n_wg * slice + (uint64_t)f.lane_src[k] * f.ngs + gs;
+  const uint32_t n_img = err_lane ? f.passes * f.n_wg : f.n_wg;
   uint64_t v = lane_identity(op);
-  for (uint32_t w = 0; w < f.n_wg; ++w) v = lane_combine(op, v, src[(uint64_t)w * slice]);
-  f.exchange[(uint64_t)o * lanes + (uint64_t)g * f.k + k] = v; // → [group][lane]
+  if (live) {
+    uint32_t w = part;
+    for (; w + 3 * kFoldParts < n_img; w += 4 * kFoldParts) {
+      uint64_t x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = src[(uint64_t)(w + u * kFoldParts) * slice];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v = lane_combine(op, v, xf == 1 ? (x[u] & 0xFFFFFFFFull) : xf == 2 ? (uint64_t)((int64_t)x[u] >> 32) : x[u]);
+    }
+    for (; w < n_img; w += kFoldParts) {
+      const uint64_t x = src[(uint64_t)w * slice];
+      v = lane_combine(op, v, xf == 1 ? (x & 0xFFFFFFFFull) : xf == 2 ? (uint64_t)((int64_t)x >> 32) : x);
+    }
+  }
+  part_v[part][cell] = v;
+  __syncthreads();
+  if (part == 0 && live) {
+#pragma unroll
+    for (uint32_t q = 1; q < kFoldParts; ++q) v = lane_combine(op, v, part_v[q][cell]);
+    f.exchange[(uint64_t)o * lanes + (err_lane ? i : (uint64_t)g * f.k + k)] = v; // → [group][lane]
+  }
 }
 
 template <class P> __device__ __forceinline__ void fused_scan_body(const ScanParams &p) {

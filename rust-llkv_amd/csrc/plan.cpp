@@ -215,6 +215,10 @@ struct Lowering {
   bool exact_f64 = false;
   uint64_t table_rows = 0; // rows of the table the plan scans (the N of the exact sums)
   bool allow_dict_num = true; // the kernels of this plan see ScanParams::dict_num (not the sort route's reduce kernel)
+  // shared-image plans: exchange lane j of a lane group = xf(kernel lane src) (LoweredPlan::image_src / image_xf); empty = as is
+  std::vector<std::vector<std::pair<uint8_t, uint8_t>>> group_expand = {};
+  std::vector<std::pair<uint8_t, uint8_t>> next_expand = {};
+  bool bounds_all_finite = true; // (expr_bounds) no column of the expression holds NaN / ±∞
 
   // What the column statistics say about an aggregate argument: an interval [lo, hi] (integer min / max, largest
   // finite |v| of float columns) and `nz`, a lower bound on |value| wherever the value is not zero (smallest non-zero
@@ -223,12 +227,16 @@ struct Lowering {
   bool expr_bounds(const llkv_expr_token *e, uint32_t n, double *absmax, double *nzmin) {
     struct I { double lo, hi, nz; };
     std::vector<I> st;
+    bounds_all_finite = true;
     for (uint32_t i = 0; i < n; ++i) {
       if (e[i].kind == LLKV_TOK_COLUMN) {
         const ColumnInfo *ci = resolve(e[i].field_id);
         if (!ci) return false;
         table_rows = std::max(table_rows, ci->rows);
-        if ((ci->dtype == LLKV_DT_FLOAT64 || ci->dtype == LLKV_DT_FLOAT32) && ci->has_fstats) st.push_back({-ci->f_absmax, ci->f_absmax, ci->f_absmin_nz});
+        if ((ci->dtype == LLKV_DT_FLOAT64 || ci->dtype == LLKV_DT_FLOAT32) && ci->has_fstats) {
+          st.push_back({-ci->f_absmax, ci->f_absmax, ci->f_absmin_nz});
+          bounds_all_finite &= ci->f_all_finite;
+        }
         else if (ci->dtype == LLKV_DT_BOOLEAN) st.push_back({0.0, 1.0, 1.0});
         else if (ci->dtype == LLKV_DT_UTF8) { // numeric image of the dictionary
           I b{0.0, 0.0, 0.0};
@@ -308,6 +316,28 @@ struct Lowering {
       }
     }
     return 0;
+  }
+
+  // SumF64Q (fused_scan.hip.h): the grid 2^e at 2^-30 of the smallest non-zero |v| (the last grid of SumF64X: the
+  // same per-row rounding), if |v| / 2^e summed over the rows ONE workgroup image can see stays below 2^62 — a shared-
+  // image scan runs at least 256 workgroups over tiles of ≤ 8 192 rows (engine.cpp: pick_image_grid honours
+  // LoweredPlan::image_min_grid), so an image sees at most rows / 128 + 16 384 rows of the table.
+  bool fixed_point_grid(double absmax, double nzmin, uint64_t rows, int *e_out) {
+    if (!(absmax >= 0.0) || !std::isfinite(absmax)) return false;
+    if (absmax == 0.0) { absmax = 1.0; nzmin = 1.0; }
+    if (!(nzmin > 0.0)) return false;
+    absmax *= 1.0000001;
+    int ex, nz_ex;
+    const double m = std::frexp(absmax, &ex);
+    const int b = m == 0.5 ? ex - 1 : ex;
+    (void)std::frexp(nzmin, &nz_ex);
+    const int e = nz_ex - 1 - 30;
+    const uint64_t image_rows = rows / 128 + 16384;
+    int lr = 1;
+    while (lr < 63 && ((uint64_t)1 << lr) < image_rows) ++lr;
+    if (b - e + lr > 61 || e < -900 || e > 900) return false;
+    *e_out = e;
+    return true;
   }
 
   int fail(int code, const std::string &m) { return set_err(err, code, m); }
@@ -997,10 +1027,14 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
   int rc;
   std::vector<int> group_lane;     // first lane (relative to base) of each lane group
   auto add_group = [&](const std::string &node, std::vector<uint8_t> lane_ops) -> int {
+    std::vector<std::pair<uint8_t, uint8_t>> expand;
+    expand.swap(L.next_expand);
     for (size_t i = 0; i < groups.size(); ++i) if (groups[i] == node) return group_lane[i];
+    if (expand.empty()) for (size_t j = 0; j < lane_ops.size(); ++j) expand.emplace_back((uint8_t)j, (uint8_t)0);
     groups.push_back(node);
     group_lane.push_back(next_lane);
     group_ops.push_back(lane_ops);
+    L.group_expand.push_back(expand);
     next_lane += (int)lane_ops.size();
     return group_lane.back();
   };
@@ -1089,9 +1123,21 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     bool no_bound = false;
     auto sum_f64 = [&](const std::string &arg) -> std::pair<std::string, std::vector<uint8_t>> {
       if (!L.exact_f64) return {"SumF64<" + arg + ">", {ADD_F64}};
-      double absmax, nzmin, c[3];
+      double absmax = 0.0, nzmin = 0.0, c[3];
       int levels = 0;
-      if (L.expr_bounds(s.expr, s.expr_len, &absmax, &nzmin)) levels = L.exact_sum_constants(absmax, nzmin, simple_ci ? simple_ci->rows : L.table_rows, c);
+      const bool bounded = L.expr_bounds(s.expr, s.expr_len, &absmax, &nzmin);
+      const uint64_t n_rows = simple_ci ? simple_ci->rows : L.table_rows;
+      int e = 0;
+      std::string scale_lit;
+      if (bounded && L.bounds_all_finite && !std::getenv("LLKV_HIP_IMAGE_NO_FIXED") && L.fixed_point_grid(absmax, nzmin, n_rows, &e) &&
+          L.lit_f(std::ldexp(1.0, -e), &scale_lit) == 0) { // one integer lane in the image, two in the exchange image
+        o.fixed_point = true;
+        o.fixed_exp = e;
+        p.image_min_grid = 256;
+        L.next_expand = {{0, 1}, {0, 2}};
+        return {"SumF64Q<" + arg + "," + scale_lit + ">", {ADD_I64, ADD_I64}};
+      }
+      if (bounded) levels = L.exact_sum_constants(absmax, nzmin, n_rows, c);
       std::string node_x = "SumF64X<" + arg;
       std::vector<uint8_t> lane_ops;
       for (int j = 0; j < levels; ++j) {
@@ -1112,6 +1158,11 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       if (valid.empty()) { o.lane = add_group(inner, lane_ops); return; }
       const int n_inner = (int)lane_ops.size();
       lane_ops.push_back(ADD_I64);
+      if (!L.next_expand.empty()) { // the count of non-NULL rows is one more kernel lane behind the inner ones
+        uint8_t kernel_lanes = 0;
+        for (auto &x : L.next_expand) kernel_lanes = std::max<uint8_t>(kernel_lanes, (uint8_t)(x.first + 1));
+        L.next_expand.emplace_back(kernel_lanes, (uint8_t)0);
+      }
       o.lane = add_group("IfValid<" + valid + "," + inner + ">", lane_ops);
       o.count_lane = o.lane + n_inner;
     };
@@ -1255,6 +1306,21 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
 
   p.k = base + next_lane;
   p.lanes = (int)p.ng * p.k + 1;
+  // the kernel's lanes per group (shared-image plans may keep a lane group in fewer lanes than the exchange image has)
+  p.image_src.clear();
+  p.image_xf.clear();
+  for (int j = 0; j < base; ++j) { p.image_src.push_back((uint8_t)j); p.image_xf.push_back(0); }
+  int kernel_lane = base;
+  for (auto &ge : L.group_expand) {
+    int used = 0;
+    for (auto &x : ge) {
+      p.image_src.push_back((uint8_t)(kernel_lane + x.first));
+      p.image_xf.push_back(x.second);
+      used = std::max(used, x.first + 1);
+    }
+    kernel_lane += used;
+  }
+  p.k_image = kernel_lane;
   p.lane_ops.clear();
   for (uint32_t g = 0; g < p.ng; ++g) {
     p.lane_ops.push_back(ADD_I64);
@@ -1270,10 +1336,10 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   if (p.acc_lds && (size_t)(p.lanes - 1) * 2048 > 160u * 1024) // one 2 KiB row per group-state lane (the error lane lives in registers)
     return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
   if (image) {
-    p.image_passes = (int)(((size_t)(p.lanes - 1) * 8 + kMaxImageBytes - 1) / kMaxImageBytes);
+    p.image_passes = (int)(((size_t)p.ng * p.k_image * 8 + kMaxImageBytes - 1) / kMaxImageBytes);
     if (p.image_passes < 1) p.image_passes = 1;
     if (p.image_passes > kMaxImagePasses)
-      return L.fail(LLKV_UNSUPPORTED, "the group image (" + std::to_string(p.ng) + " groups × " + std::to_string(p.k) + " lanes) needs more than " +
+      return L.fail(LLKV_UNSUPPORTED, "the group image (" + std::to_string(p.ng) + " groups × " + std::to_string(p.k_image) + " lanes) needs more than " +
                                            std::to_string(kMaxImagePasses) + " LDS-sized slices");
   }
   p.unroll = image ? 2 : (p.acc_lds || p.lanes <= 8) ? 4 : 2;

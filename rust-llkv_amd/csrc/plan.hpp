@@ -29,6 +29,7 @@ struct ColumnInfo {
   std::vector<std::string> dictionary;  // LLKV_DT_UTF8: code → string
   int32_t precision = 0, scale = 0;     // LLKV_DT_DECIMAL128 (device image: the raw values narrowed to i64)
   bool nullable = false;                // some cell is NULL (row id absent from the column): a 1 B/row validity mask is staged
+  bool f_all_finite = false;            // … and no NaN / ±∞ among the values (unsharded tables; agreed by share_metadata)
   bool has_fstats = false;              // Float64 / Float32 columns, over the finite values (staging statistics):
   double f_absmax = 0.0;                //   largest |v|
   double f_absmin_nz = 0.0;             //   smallest non-zero |v| (0: none / unknown)
@@ -63,6 +64,8 @@ struct AggOut {
   int32_t precision = 0, scale = 0; // Decimal128 results
   int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
   int exact_levels = 0; // f64 sum kept as exact grid-level lanes (SumF64X, 2 or 3 of them): value = smallest level first, summed
+  bool fixed_point = false; // f64 sum kept as an integer count of grid steps 2^fixed_exp (SumF64Q): lanes = low 32 bits, high part
+  int fixed_exp = 0;
 };
 
 struct LoweredPlan {
@@ -82,6 +85,11 @@ struct LoweredPlan {
   bool acc_lds = false;     // accumulators in per-thread LDS slots (grouped plans)
   bool acc_image = false;   // ONE accumulator image per workgroup in LDS, shared by its threads (hundreds … thousands of groups)
   int image_passes = 1;     // … the groups cut into this many slices, one scan of the table each
+  // shared-image plans: the kernel's image has k_image lanes per group; the fold expands them into the k lanes of the
+  // exchange image — exchange lane j of a group = xf(kernel lane image_src[j]): 0 as is, 1 low 32 bits, 2 high part (>> 32)
+  int k_image = 0;
+  std::vector<uint8_t> image_src, image_xf;
+  uint32_t image_min_grid = 0; // workgroups below which an image lane could overflow (fixed-point sums)
   int k = 1;      // lanes per group
   int lanes = 2;  // ng * k + 1
   int unroll = 2;

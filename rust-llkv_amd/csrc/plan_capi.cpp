@@ -35,6 +35,7 @@ llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols, const
     infos[i].has_fstats = cols[i].has_fstats != 0;
     infos[i].f_absmax = cols[i].f_absmax;
     infos[i].f_absmin_nz = cols[i].f_absmin_nz;
+    infos[i].f_all_finite = cols[i].f_all_finite != 0;
     for (uint32_t d = 0; d < cols[i].dict_size; ++d)
       infos[i].dictionary.push_back(cols[i].dictionary && cols[i].dictionary[d] ? cols[i].dictionary[d] : "");
   }

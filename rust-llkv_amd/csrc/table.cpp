@@ -177,19 +177,20 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
   if ((c.info.dtype == LLKV_DT_FLOAT64 || c.info.dtype == LLKV_DT_FLOAT32) && t.dev_rows) {
     // largest and smallest non-zero finite |v|: they bound aggregate arguments from above and below, which lets the
     // shared-image GROUP BY keep f64 sums exact (padding rows between ragged chunks hold copies of real values)
-    uint64_t *d = nullptr, bits[2] = {0, 0x7FF0000000000000ull};
-    HIP_TRY(hipMalloc((void **)&d, 16));
-    HIP_TRY(hipMemcpyAsync(d, bits, 16, hipMemcpyHostToDevice, g_ctx.stream));
+    uint64_t *d = nullptr, bits[3] = {0, 0x7FF0000000000000ull, 0};
+    HIP_TRY(hipMalloc((void **)&d, 24));
+    HIP_TRY(hipMemcpyAsync(d, bits, 24, hipMemcpyHostToDevice, g_ctx.stream));
     if (c.info.dtype == LLKV_DT_FLOAT64) HIP_TRY(launch_absrange_f64((const double *)c.d_values, t.dev_rows, d, g_ctx.stream));
     else HIP_TRY(launch_absrange_f32((const float *)c.d_values, t.dev_rows, d, g_ctx.stream));
-    HIP_TRY(hipMemcpyAsync(bits, d, 16, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(bits, d, 24, hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     (void)hipFree(d);
     c.has_local_fstats = true;
     std::memcpy(&c.local_f_absmax, &bits[0], 8);
     std::memcpy(&c.local_f_absmin_nz, &bits[1], 8);
     if (!std::isfinite(c.local_f_absmin_nz)) c.local_f_absmin_nz = 0.0; // no non-zero value
-    if (t.world == 1) { c.info.has_fstats = true; c.info.f_absmax = c.local_f_absmax; c.info.f_absmin_nz = c.local_f_absmin_nz; }
+    c.local_f_all_finite = bits[2] == 0;
+    if (t.world == 1) { c.info.has_fstats = true; c.info.f_absmax = c.local_f_absmax; c.info.f_absmin_nz = c.local_f_absmin_nz; c.info.f_all_finite = c.local_f_all_finite; }
     return LLKV_OK;
   }
   if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
@@ -449,6 +450,27 @@ llkv_status llkv_hip_table_set_column_float_stats(llkv_hip_table *table, uint32_
   return LLKV_OK;
 }
 
+llkv_status llkv_hip_table_local_column_all_finite(const llkv_hip_table *table, uint32_t field_id, int32_t *all_finite) {
+  const Table *t = reinterpret_cast<const Table *>(table);
+  if (!t || !all_finite) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  *all_finite = it->second.has_local_fstats && it->second.local_f_all_finite ? 1 : 0;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_set_column_all_finite(llkv_hip_table *table, uint32_t field_id, int32_t all_finite) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "table is NULL");
+  auto it = t->cols.find(field_id);
+  if (it == t->cols.end()) return (llkv_status)set_error(LLKV_NOT_FOUND, "field " + std::to_string(field_id) + " is not staged");
+  DeviceColumn &c = it->second;
+  if (all_finite && c.has_local_fstats && t->local_rows && !c.local_f_all_finite)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "this rank's rows of the column hold NaN or ±∞");
+  c.info.f_all_finite = all_finite != 0;
+  return LLKV_OK;
+}
+
 llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint32_t field_id, int32_t precision, int32_t scale,
                                                     const void *const *chunk_values, uint32_t n_chunks) {
   Table *t = reinterpret_cast<Table *>(table);
@@ -543,11 +565,11 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
   if (t->world == 1) return LLKV_OK;
   if (!comm_ready() || comm_world() != t->world || comm_rank() != t->rank)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the table's (rank, world) is not the communicator's");
-  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; int32_t has_fstats, pad; double f_absmax, f_absmin_nz; };
+  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; int32_t has_fstats, all_finite; double f_absmax, f_absmin_nz; };
   std::vector<Rec> mine;
   for (auto &kv : t->cols) // std::map: ascending field ids on every rank
     mine.push_back({kv.first, kv.second.has_local_stats ? 1 : 0, kv.second.local_min, kv.second.local_max, kv.second.info.nullable ? 1 : 0, t->local_rows ? 1u : 0u,
-                    kv.second.has_local_fstats ? 1 : 0, 0, kv.second.local_f_absmax, kv.second.local_f_absmin_nz});
+                    kv.second.has_local_fstats ? 1 : 0, kv.second.local_f_all_finite ? 1 : 0, kv.second.local_f_absmax, kv.second.local_f_absmin_nz});
   std::vector<uint8_t> all;
   std::vector<uint64_t> off;
   int rc = comm_allgather_v(mine.data(), mine.size() * sizeof(Rec), &all, &off);
@@ -561,7 +583,7 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
   size_t i = 0;
   for (auto &kv : t->cols) {
     DeviceColumn &c = kv.second;
-    bool all_stats = true, all_fstats = true, any_rows = false, any_nullable = false;
+    bool all_stats = true, all_fstats = true, any_rows = false, any_nullable = false, all_finite = true;
     int64_t lo = INT64_MAX, hi = INT64_MIN;
     double fmax = 0.0, fmin_nz = 0.0;
     for (uint32_t r = 0; r < t->world; ++r) {
@@ -569,6 +591,7 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
       any_nullable |= x.nullable != 0;
       if (!x.local_rows_nonzero) continue; // a rank without rows constrains nothing
       any_rows = true;
+      all_finite &= x.all_finite != 0;
       if (x.has_fstats) {
         fmax = std::max(fmax, x.f_absmax);
         if (x.f_absmin_nz > 0.0) fmin_nz = fmin_nz > 0.0 ? std::min(fmin_nz, x.f_absmin_nz) : x.f_absmin_nz;
@@ -581,6 +604,7 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
       c.info.has_fstats = true;
       c.info.f_absmax = fmax;
       c.info.f_absmin_nz = fmin_nz;
+      c.info.f_all_finite = all_finite;
     }
     if (all_stats && any_rows && lo <= hi) {
       c.info.has_stats = true;

@@ -314,6 +314,16 @@ class HipTable:
         """Installs the table-wide float statistics of a sharded table's column (what share_metadata agrees on)."""
         check(lib().llkv_hip_table_set_column_float_stats(self._h, C.c_uint32(field_id), C.c_double(abs_max), C.c_double(abs_min_nonzero)))
 
+    def local_column_all_finite(self, field_id: int) -> bool:
+        """No NaN / ±∞ among this rank's rows of a float column."""
+        v = C.c_int32()
+        check(lib().llkv_hip_table_local_column_all_finite(self._h, C.c_uint32(field_id), C.byref(v)))
+        return bool(v.value)
+
+    def set_column_all_finite(self, field_id: int, all_finite: bool):
+        """Installs the table-wide answer (what share_metadata agrees on)."""
+        check(lib().llkv_hip_table_set_column_all_finite(self._h, C.c_uint32(field_id), C.c_int32(1 if all_finite else 0)))
+
     def share_metadata(self):
         """Sharded tables, before any query is prepared: all ranks agree on integer statistics and on which columns
         have NULL cells (llkv_hip_table_share_metadata over the communicator)."""

@@ -96,7 +96,8 @@ def test_shared_image_results_do_not_depend_on_launch_geometry_or_shards(rt, abi
     # 10 000 groups × 5 lanes: the image no longer fits the LDS, the groups are cut into slices, one scan each (",2,P>")
     wide = aggs[:3]
     pw = rt.PreparedQuery(one, None, wide, [99], False)
-    assert _image(pw) and not pw.kernel_signature.endswith(",2>"), (pw.route_note, pw.kernel_signature)
+    tail = pw.kernel_signature[pw.kernel_signature.rindex(">,") + 2:-1].split(",")  # unroll, accumulator placement[, group slices]
+    assert _image(pw) and len(tail) == 3 and tail[1] == "2" and int(tail[2]) > 1, (pw.route_note, pw.kernel_signature)
     os.environ["LLKV_HIP_GROUP_NO_IMAGE"] = "1"
     try:
         ps = rt.PreparedQuery(one, None, wide, [99], False)
@@ -136,6 +137,7 @@ def test_shared_image_results_do_not_depend_on_launch_geometry_or_shards(rt, abi
                     ht.set_column_stats(fid, int(d[c].min()), int(d[c].max()))
                 else:
                     ht.set_column_float_stats(fid, *one.local_column_float_stats(fid))
+                    ht.set_column_all_finite(fid, one.local_column_all_finite(fid))
             pr = rt.PreparedQuery(ht, None, aggs, [S["l_shipdate"][0]], True)
             assert _image(pr), pr.route_note
             pr.launch()
