@@ -785,7 +785,9 @@ int Query::merge_distinct(size_t agg, uint32_t world, const uint64_t *counts, co
 int Query::finish_from_exchange(const uint64_t *exchange) {
   const LoweredPlan &p = plan;
   std::vector<uint64_t> state(p.lanes);
-  fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
+  if (p.acc_image && table->world == 1) // the image fold left everything in the first octant (the others hold the lane identities)
+    std::memcpy(state.data(), exchange + (size_t)__builtin_ctz(table->owned_mask | 0x100u) * p.lanes, (size_t)p.lanes * 8);
+  else fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
   groups.clear();
   if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic failed on a selected row
     return set_error(LLKV_INTERNAL, arith_error_message(state[(size_t)p.ng * p.k]));
@@ -862,8 +864,12 @@ int Query::submit(hipStream_t stream) {
     if (pending && pending_slot == slot && (rc = flush_pending())) return rc;
     if (!stream) stream = slot_stream[slot];
     else if (stream != slot_stream[slot]) HIP_TRY(hipStreamWaitEvent(stream, ev_fold[slot], 0));
-    const size_t bytes = exchange_len() * sizeof(uint64_t);
-    HIP_TRY(hipMemcpyAsync(h_exchange + slot * exchange_len(), d_exchange + slot * exchange_len(), bytes, hipMemcpyDeviceToHost, stream));
+    size_t bytes = exchange_len() * sizeof(uint64_t), first = 0;
+    if (plan.acc_image && table->world == 1) { // only the first octant carries data (finish_from_exchange)
+      first = (size_t)__builtin_ctz(table->owned_mask | 0x100u) * plan.lanes;
+      bytes = (size_t)plan.lanes * sizeof(uint64_t);
+    }
+    HIP_TRY(hipMemcpyAsync(h_exchange + slot * exchange_len() + first, d_exchange + slot * exchange_len() + first, bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(copied[slot], stream));
   }
   n_submitted++;
