@@ -109,7 +109,22 @@ static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
 static uint32_t pick_scan_grid(const LoweredPlan &p, uint32_t n_tiles) {
   if (!p.acc_lds) return 0; // one tile per workgroup
   // (a state of more than 6 lanes per row keeps every CU busy with its DS atomics: 12 lanes 0.334 ms at 256, 0.428 ms at 192)
-  uint32_t grid = n_tiles >= 2048 && p.k <= 6 ? 192 : 256;
+  // Within that range the count that leaves the least idle time wins: workgroups take whole tiles, so 3 662 tiles over
+  // 192 workgroups are 19 or 20 each (the kernel lasts 20, the average is 19.07: 352 µs), over 193 they are 18 or 19
+  // (342 µs), over 216 or 229 likewise.
+  uint32_t grid = 256;
+  if (n_tiles >= 2048) {
+    const uint32_t lo = p.k <= 6 ? 184 : 232, hi = p.k <= 6 ? 232 : 256;
+    // the smallest count that keeps the workgroups ≥ 99.5 % busy (else the busiest): on the slower boxes fewer
+    // workgroups still win among balanced counts (193: 354 µs, 204: 356, 216: 357, 229: 361; 192: 362)
+    double best = 0.0;
+    for (uint32_t g = lo; g <= hi; ++g) {
+      const uint32_t most = (n_tiles + g - 1) / g;
+      const double busy = (double)n_tiles / ((double)most * g);
+      if (busy >= 0.995) { grid = g; break; }
+      if (busy > best + 1e-9) { best = busy; grid = g; }
+    }
+  }
   if (const char *e = std::getenv("LLKV_HIP_SCAN_WGS")) {
     long v = std::atol(e);
     if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 20);
