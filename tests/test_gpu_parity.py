@@ -2305,7 +2305,7 @@ def test_randomized_parity_window_of_the_fuzz_tool():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LLKV_FUZZ_SEEDS="700:703", LLKV_FUZZ_PROJECTIONS="4")
+    env = dict(os.environ, LLKV_FUZZ_SEEDS="700:702", LLKV_FUZZ_PROJECTIONS="3")
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     verdicts = [line for line in out.stdout.splitlines() if "FAILURES:" in line]
