@@ -751,7 +751,7 @@ int Query::distinct_partial(size_t agg, const uint64_t **values, uint64_t *n) {
 // seen; i64 sums checked, f64 sums 0.0 then += in that order).
 int Query::merge_distinct(size_t agg, uint32_t world, const uint64_t *counts, const uint64_t *const *values) {
   if (agg >= distinct.size() || distinct[agg].kind < 0) return set_error(LLKV_INVALID_ARGUMENT, "not a DISTINCT aggregate");
-  if (groups.empty() || agg >= groups[0].values.size()) return set_error(LLKV_INVALID_ARGUMENT, "finish the query before merging");
+  if (groups.empty() || agg >= groups.n_values) return set_error(LLKV_INVALID_ARGUMENT, "finish the query before merging");
   const DistinctAgg &da = distinct[agg];
   std::unordered_set<uint64_t> seen;
   std::vector<uint64_t> all;
@@ -793,65 +793,105 @@ int Query::merge_distinct(size_t agg, uint32_t world, const uint64_t *counts, co
   }
   default: return set_error(LLKV_INTERNAL, "not a DISTINCT aggregate");
   }
-  groups[0].values[agg] = out;
+  groups.value(0, agg) = out;
   return LLKV_OK;
 }
 
 int Query::finish_from_exchange(const uint64_t *exchange) {
   const LoweredPlan &p = plan;
+  const bool trace = std::getenv("LLKV_HIP_TRACE") != nullptr; // phase times of the host-side finalize on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (trace) std::fprintf(stderr, "[llkv_hip] finalize %-10s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  };
   std::vector<uint64_t> state(p.lanes);
   if (p.acc_image && table->world == 1) // the image fold left everything in the first octant (the others hold the lane identities)
     std::memcpy(state.data(), exchange + (size_t)__builtin_ctz(table->owned_mask | 0x100u) * p.lanes, (size_t)p.lanes * 8);
   else fold_exchange_host(exchange, p.lane_ops.data(), (uint32_t)p.lanes, state.data());
-  groups.clear();
+  mark("fold");
+  groups.reset(0, 0, 0);
   if (state[(size_t)p.ng * p.k] != 0) // checked arithmetic failed on a selected row
     return set_error(LLKV_INTERNAL, arith_error_message(state[(size_t)p.ng * p.k]));
   const int base = p.track_first ? 2 : 1;
+  // The groups that appeared, in output order, BEFORE any per-group object exists: ORDER BY keys ASC NULLS FIRST = the order
+  // of a mixed-radix number whose digits are the ranks of the key codes (an integer key's code is its rank, a dictionary
+  // code ranks by its string, the NULL code ranks first); else first-appearance order (llkv-executor/src/lib.rs:5065-5089)
+  // by the first-row lane; else dense id order.  (Sorting 2 526 finished group objects by their key vectors cost as much
+  // as the kernel that produced them.)
+  struct Ref { uint64_t order; uint32_t g; };
+  std::vector<Ref> present;
+  present.reserve(p.ng);
+  std::vector<std::vector<uint32_t>> rank(p.key_fields.size());
+  if (p.grouped && order_by_keys)
+    for (size_t k = 0; k < p.key_fields.size(); ++k) {
+      const uint32_t card = p.key_cards[k], n_codes = p.key_nullable[k] ? card - 1 : card;
+      rank[k].assign(card, 0);
+      std::vector<uint32_t> by_value(n_codes);
+      for (uint32_t c = 0; c < n_codes; ++c) by_value[c] = c;
+      if (!p.key_is_int[k]) {
+        const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
+        auto word = [&](uint32_t c) -> const std::string & { static const std::string none; return c < dict.size() ? dict[c] : none; };
+        std::stable_sort(by_value.begin(), by_value.end(), [&](uint32_t x, uint32_t y) { return word(x) < word(y); });
+      }
+      for (uint32_t r = 0; r < n_codes; ++r) rank[k][by_value[r]] = r + 1; // 0 is the NULL group's
+    }
   for (uint32_t g = 0; g < p.ng; ++g) {
     const uint64_t *gl = &state[(size_t)g * p.k];
     if (p.grouped && gl[0] == 0) continue; // group never appeared
-    GroupResult gr;
-    gr.first_row = p.track_first ? gl[1] : 0;
+    uint64_t order = g;
+    if (p.grouped && order_by_keys) {
+      order = 0;
+      for (size_t k = 0; k < p.key_fields.size(); ++k) order = order * (p.key_cards[k] + 1) + rank[k][(g / p.key_strides[k]) % p.key_cards[k]];
+    } else if (p.track_first) {
+      order = gl[1];
+    }
+    present.push_back({order, g});
+  }
+  auto before = [](const Ref &x, const Ref &y) { return x.order < y.order; };
+  if (p.grouped && !std::is_sorted(present.begin(), present.end(), before)) std::stable_sort(present.begin(), present.end(), before); // (integer keys: already in order)
+  mark("order");
+  groups.reset(present.size(), p.grouped ? p.key_fields.size() : 0, p.aggs.size());
+  std::vector<const std::vector<std::string> *> dicts(p.key_fields.size(), nullptr);
+  for (size_t k = 0; p.grouped && k < p.key_fields.size(); ++k)
+    if (!p.key_is_int[k]) dicts[k] = &table->cols.at(p.key_fields[k]).info.dictionary;
+  std::string err;
+  for (const Ref &ref : present) {
+    const uint32_t g = ref.g;
+    const uint64_t *gl = &state[(size_t)g * p.k];
+    const size_t at = groups.n++;
     if (p.grouped)
       for (size_t k = 0; k < p.key_fields.size(); ++k) {
         const uint32_t code = (g / p.key_strides[k]) % p.key_cards[k];
-        GroupKey gk;
+        groups.keys.emplace_back();
+        GroupKey &gk = groups.keys.back();
         if (p.key_nullable[k] && code == p.key_cards[k] - 1) {
           gk.is_null = true;
           gk.is_int = p.key_is_int[k] != 0;
         } else if (p.key_is_int[k]) {
           gk.is_int = true;
           gk.i = p.key_bases[k] + (int64_t)code;
-        } else {
-          const auto &dict = table->cols.at(p.key_fields[k]).info.dictionary;
-          gk.s = code < dict.size() ? dict[code] : std::string();
+        } else if (code < dicts[k]->size()) {
+          gk.s = (*dicts[k])[code];
         }
-        gr.keys.push_back(std::move(gk));
       }
-    gr.values.resize(p.aggs.size());
     for (size_t a = 0; a < p.aggs.size(); ++a) {
-      std::string err;
-      int rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err, false);
+      llkv_value *out = &groups.value(at, a);
+      int rc = finalize_value(p.aggs[a], gl, base, out, &err, false);
       if (rc == LLKV_UNSUPPORTED && !p.grouped && a < exact_plans.size() && !exact_plans[a].type_string.empty()) {
         // the order-free state cannot tell whether a PREFIX of the reference's checked_add chain overflows:
         // decide it exactly from the selected values in row order
         bool overflow = false;
         if ((rc = exact_prefix_overflow(a, &overflow))) return rc;
         if (overflow) return set_error(LLKV_INVALID_ARGUMENT, p.aggs[a].fin == AggFinal::AvgI64 ? "AVG aggregate sum exceeds i64 range" : "integer overflow");
-        rc = finalize_value(p.aggs[a], gl, base, &gr.values[a], &err, true);
+        rc = finalize_value(p.aggs[a], gl, base, out, &err, true);
       }
       if (rc) return set_error(rc, err);
     }
     if (!p.grouped)
-      for (size_t a = 0; a < distinct.size() && a < gr.values.size(); ++a)
-        if (distinct[a].kind >= 0 && table->world == 1) { int rc = distinct_value(a, &gr.values[a]); if (rc) return rc; } // sharded: merge_distinct
-    groups.push_back(std::move(gr));
+      for (size_t a = 0; a < distinct.size() && a < p.aggs.size(); ++a)
+        if (distinct[a].kind >= 0 && table->world == 1) { int rc = distinct_value(a, &groups.value(at, a)); if (rc) return rc; } // sharded: merge_distinct
   }
-  if (p.grouped) {
-    // first-appearance order (llkv-executor/src/lib.rs:5065-5089), then ORDER BY keys ASC
-    if (p.track_first) std::sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.first_row < b.first_row; });
-    if (order_by_keys) std::stable_sort(groups.begin(), groups.end(), [](const GroupResult &a, const GroupResult &b) { return a.keys < b.keys; });
-  }
+  mark("groups");
   return LLKV_OK;
 }
 
@@ -1089,10 +1129,10 @@ llkv_status llkv_hip_query_group_key(const llkv_hip_query *query, uint32_t group
     }
     return LLKV_OK;
   }
-  if (!q || !out || group >= q->groups.size() || key >= q->groups[group].keys.size())
+  if (!q || !out || group >= q->groups.size() || key >= q->groups.n_keys)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/key index out of range");
   std::memset(out, 0, sizeof *out);
-  const GroupKey &gk = q->groups[group].keys[key];
+  const GroupKey &gk = q->groups.key(group, key);
   if (gk.is_int) { out->dtype = LLKV_DT_INT64; out->i64 = gk.i; }
   else { out->dtype = LLKV_DT_UTF8; out->str = gk.s.c_str(); }
   out->is_null = gk.is_null ? 1 : 0;
@@ -1108,9 +1148,9 @@ llkv_status llkv_hip_query_value(const llkv_hip_query *query, uint32_t group, ui
     const int rc = finalize_value(lz.plan->aggs[agg], lz.lanes + (size_t)group * lz.k, 2, out, &err, false);
     return rc ? (llkv_status)set_error(rc, err) : LLKV_OK;
   }
-  if (!q || !out || group >= q->groups.size() || agg >= q->groups[group].values.size())
+  if (!q || !out || group >= q->groups.size() || agg >= q->groups.n_values)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "group/aggregate index out of range");
-  *out = q->groups[group].values[agg];
+  *out = q->groups.value(group, agg);
   return LLKV_OK;
 }
 

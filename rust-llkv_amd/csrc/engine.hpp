@@ -111,10 +111,23 @@ struct GroupKey { // GroupKeyValue: String or Int (llkv-executor/src/lib.rs:99-1
   bool operator<(const GroupKey &o) const { return (is_null || o.is_null) ? (is_null && !o.is_null) : (is_int ? i < o.i : s < o.s); }
   bool operator==(const GroupKey &o) const { return (is_null || o.is_null) ? (is_null == o.is_null) : (is_int ? i == o.i : s == o.s); }
 };
-struct GroupResult {
-  uint64_t first_row = 0;
+// The finished groups of a dense / shared-image plan live in two flat arrays (keys: n_groups × n_keys, values: n_groups ×
+// n_aggs): a vector pair per group was two heap allocations each — as much time as the kernel for 2 526 groups.
+struct GroupStore {
+  size_t n = 0, n_keys = 0, n_values = 0;
   std::vector<GroupKey> keys;
   std::vector<llkv_value> values;
+  void reset(size_t groups, size_t keys_per_group, size_t values_per_group) {
+    n = 0; n_keys = keys_per_group; n_values = values_per_group;
+    keys.clear(); values.clear();
+    keys.reserve(groups * keys_per_group);
+    values.resize(groups * values_per_group);
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  const GroupKey &key(size_t g, size_t k) const { return keys[g * n_keys + k]; }
+  llkv_value &value(size_t g, size_t a) { return values[g * n_values + a]; }
+  const llkv_value &value(size_t g, size_t a) const { return values[g * n_values + a]; }
 };
 
 // Result of a sort-based GROUP BY, kept as the arrays the device produced (already in output order, pinned host
@@ -186,7 +199,7 @@ struct Query {
   size_t h_exchange_bytes = 0;    // size class of the pinned block (pinned_acquire)
   bool order_by_keys = false;
   uint32_t n_user_aggs = 0, n_user_keys = 0;
-  std::vector<GroupResult> groups;
+  GroupStore groups;
   // ungrouped SUM/AVG(Int64) without overflow-excluding statistics: plan that emits the argument values of
   // the selected rows in row order, for the exact prefix-overflow check (index = aggregate, empty = n/a)
   std::vector<LoweredPlan> exact_plans;
