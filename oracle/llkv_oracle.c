@@ -1935,13 +1935,14 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
         acc st;
         arr col;
         memset(&col, 0, sizeof col);
-        if (aggs[a].distinct) { rc = fail(LLKV_UNSUPPORTED, "DISTINCT aggregates are out of scope"); break; }
+        /* every group runs its own accumulator over its rows in scan order (:5222-5247): DISTINCT forms included */
+        const int is_distinct = aggs[a].distinct && aggs[a].kind != LLKV_AGG_MIN && aggs[a].kind != LLKV_AGG_MAX && aggs[a].kind != LLKV_AGG_COUNT_STAR;
         if (aggs[a].kind == LLKV_AGG_COUNT_STAR) {
           rc = acc_new(aggs[a].kind, LLKV_DT_NULL, &st);
           if (rc == LLKV_OK) rc = acc_update(&st, &col, gn);
         } else if (is_simple_column(aggs[a].expr, aggs[a].expr_len)) {
           const arr *src = find_gathered(m.cols, n_fields, aggs[a].expr[0].field_id);
-          rc = acc_new(aggs[a].kind, src->dtype, &st);
+          rc = is_distinct ? acc_new_distinct(aggs[a].kind, src->dtype, &st) : acc_new(aggs[a].kind, src->dtype, &st);
           if (rc) break;
           st.precision = src->precision; st.scale = src->scale;
           /* arrow `take` of the group's rows (:5131-5146) */
@@ -1975,13 +1976,16 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
               else ((int64_t *)col.values)[i] = pv[i].i;
             }
             if (col.dtype == LLKV_DT_NULL) { col.dtype = LLKV_DT_INT64; } /* new_null_array(Int64) */
-            if (rc == LLKV_OK) rc = acc_new(aggs[a].kind, col.dtype, &st);
+            if (rc == LLKV_OK) rc = is_distinct ? acc_new_distinct(aggs[a].kind, col.dtype, &st) : acc_new(aggs[a].kind, col.dtype, &st);
             if (rc == LLKV_OK) rc = acc_update(&st, &col, gn);
             arr_free(&col);
           }
           free(pv);
         }
-        if (rc == LLKV_OK) acc_finalize(&st, &vals[(size_t)g * n_aggs + a]);
+        if (rc == LLKV_OK) {
+          if (st.distinct) { rc = acc_finalize_distinct(&st, &vals[(size_t)g * n_aggs + a]); free(st.seen); }
+          else acc_finalize(&st, &vals[(size_t)g * n_aggs + a]);
+        }
       }
     }
     free(start); free(fill); free(order);

@@ -131,6 +131,8 @@ struct Ctx {
   uint32_t err; // sticky: checked integer arithmetic overflowed on a selected row
   uint64_t row; // logical row id of the row being evaluated
   uint32_t perr; // sticky: ... inside the predicate (Expr::Compare sides), which is evaluated on EVERY row
+  uint64_t dval; // sort-based GROUP BY with DISTINCT aggregates: the value of their column in this row …
+  uint32_t dhead; // … and 1 when the row is the first of its group with that value
 
   template <class Ty> __device__ __forceinline__ typename Ty::T get(int s, int j) const {
     if constexpr (Ty::W == 8) {
@@ -520,6 +522,29 @@ template <class E, class S> struct SumF64Q {
   static constexpr int N = 1;
   static constexpr int op(int) { return OP_ADD_I64; }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)__double2ll_rn((double)E::eval(c, j) * S::eval(c, j)); }
+};
+// DISTINCT forms inside GROUP BY (sort-based route: the argument column is the least significant sort key, so equal
+// values of a group are neighbours and group_reduce_body marks the first of each run): every group runs the reference's
+// distinct accumulators over its own rows (llkv-executor/src/lib.rs:5222-5247, llkv-aggregate/src/lib.rs:95-249).
+struct DistinctCount {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int, uint64_t *o) { o[0] = c.dhead; }
+};
+struct DistinctSumI64 { // (statistics exclude an i64 overflow of the sum)
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int, uint64_t *o) { o[0] = c.dhead ? c.dval : 0ull; }
+};
+struct DistinctTotalI64 { // TOTAL(DISTINCT int): an f64 sum of the values as f64
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_F64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int, uint64_t *o) { o[0] = (uint64_t)__double_as_longlong(c.dhead ? (double)(int64_t)c.dval : 0.0); }
+};
+struct DistinctSumF64 {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_ADD_F64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int, uint64_t *o) { o[0] = c.dhead ? c.dval : 0ull; } // +0.0 for the others
 };
 template <class E> struct SumI64 { // SumInt64 :801-830, AvgInt64 :1114-1144 — exact 96-bit split sum + max|v|
   static constexpr int N = 3;

@@ -193,6 +193,8 @@ int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint3
   int rc;
   if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, nullptr, 0, &s->sel_plan, &err))) return set_error(rc, err);
   if ((rc = lower_reduce(resolve, aggs, n_aggs, &s->red_plan, &err))) return set_error(rc, err);
+  if (s->red_plan.distinct_field >= 0 && table->world != 1)
+    return set_error(LLKV_UNSUPPORTED, "DISTINCT aggregates inside GROUP BY over a sharded table (the ranks' partial groups cannot be merged)");
   if ((rc = jit_compile(JitKind::Reduce, s->red_plan.type_string, &s->red_kernel, &err))) return set_error(rc, err);
   *out = s.release();
   return LLKV_OK;
@@ -258,6 +260,35 @@ int SortedGroupBy::run(LazyGroups *out) {
   GroupKeySet ks;
   std::memset(&ks, 0, sizeof ks);
   ks.n = n_keys;
+  // DISTINCT aggregates: their column is the least significant sort key (NULL cells first, then by value), so that
+  // inside a group equal values are neighbours
+  const bool has_distinct = red_plan.distinct_field >= 0;
+  JoinKeyColumn dcol;
+  std::memset(&dcol, 0, sizeof dcol);
+  if (has_distinct) {
+    const DeviceColumn &dc = table->cols.at((uint32_t)red_plan.distinct_field);
+    dcol.values = dc.d_values;
+    dcol.valid = dc.info.nullable ? dc.d_valid : nullptr;
+    dcol.width = 8;
+    dcol.is_signed = 0; // only equality matters: the 64-bit pattern (Float64: "by bit pattern", llkv-aggregate/src/lib.rs:252-331)
+    HIP_TRY(hj_launch_gather_sort_keys(dcol, 0, nullptr, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
+    size_t tb = 0;
+    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, 64, s));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_sort_u64_u32_bits(tmp.p, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, 64, s));
+    std::swap(perm, perm_other);
+    if (dcol.valid) {
+      if ((rc = vkeys_a.alloc(n * 4)) || (rc = vkeys_b.alloc(n * 4))) return rc;
+      HIP_TRY(hj_launch_gather_valid(dcol, sel.d_dev, perm, n, vkeys_a.as<uint32_t>(), s));
+      size_t vb = 0;
+      HIP_TRY(hj_sort_by_slot(nullptr, &vb, vkeys_a.as<uint32_t>(), vkeys_b.as<uint32_t>(), perm, perm_other, (uint32_t)n, 1, s));
+      HIP_TRY(hipStreamSynchronize(s)); // tmp is in use by the sort before
+      if ((rc = tmp.alloc(vb ? vb : 8))) return rc;
+      HIP_TRY(hj_sort_by_slot(tmp.p, &vb, vkeys_a.as<uint32_t>(), vkeys_b.as<uint32_t>(), perm, perm_other, (uint32_t)n, 1, s));
+      std::swap(perm, perm_other);
+    }
+    HIP_TRY(hipStreamSynchronize(s)); // tmp is reallocated by the next pass
+  }
   for (int k = (int)n_keys - 1; k >= 0; --k) {
     long long base;
     uint32_t bits;
@@ -276,7 +307,7 @@ int SortedGroupBy::run(LazyGroups *out) {
       code_rank = rank_d.as<uint8_t>();
     }
     HIP_TRY(hj_launch_gather_sort_keys(ks.k[k], base, code_rank, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
-    if (n_keys == 1 && !ks.k[k].valid) {
+    if (n_keys == 1 && !ks.k[k].valid && !has_distinct) {
       // GROUP BY the column the table is clustered by (a primary-key order): the selection already is in key order —
       // no sort, and the reduction then streams the argument columns instead of gathering them
       Scratch unsorted;
@@ -371,6 +402,13 @@ int SortedGroupBy::run(LazyGroups *out) {
   p.out = lanes_d.as<uint64_t>();
   p.error_flag = err_d.as<uint32_t>();
   p.n_groups = n_groups;
+  Scratch dval, dhead;
+  if (has_distinct) {
+    if ((rc = dval.alloc(n * 8)) || (rc = dhead.alloc(n))) return rc;
+    HIP_TRY(hj_launch_distinct_heads(dcol, sel.d_dev, perm, flags.as<uint64_t>(), n, dval.as<uint64_t>(), dhead.as<uint8_t>(), s));
+    p.dval = dval.as<uint64_t>();
+    p.dhead = dhead.as<uint8_t>();
+  }
   // lanes per group: a wave, or 8 lanes when the groups average fewer than 16 rows
   const bool narrow = n / n_groups < 16;
   const uint64_t groups_per_block = kBlock / (narrow ? 8 : 64);

@@ -1069,6 +1069,33 @@ hipError_t hj_launch_group_boundaries(GroupKeySet ks, const uint64_t *dev_rows, 
   hipLaunchKernelGGL(hj_group_boundaries_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, ks, dev_rows, perm, n, flags);
   return hipGetLastError();
 }
+// DISTINCT aggregates of a sort-based GROUP BY: the rows are sorted by (group keys, NULL-ness of the argument, argument),
+// so inside a group equal argument values are neighbours.  Per sorted position: the argument's 64-bit value and whether
+// the row is the first of its group with that value (a NULL cell never is).  `group_start[i]` != 0 marks a group's
+// first position.
+__global__ __launch_bounds__(256) void hj_distinct_heads_kernel(JoinKeyColumn col, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *group_start,
+                                                                 uint64_t n, uint64_t *dval, uint8_t *dhead) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t row = dev_rows[perm[i]];
+  const uint64_t v = reinterpret_cast<const uint64_t *>(col.values)[row];
+  const bool ok = !col.valid || col.valid[row] != 0;
+  bool head = ok;
+  if (ok && i && group_start[i] == 0) {
+    const uint64_t before = dev_rows[perm[i - 1]];
+    const bool ok_before = !col.valid || col.valid[before] != 0;
+    head = !(ok_before && reinterpret_cast<const uint64_t *>(col.values)[before] == v);
+  }
+  dval[i] = v;
+  dhead[i] = head ? 1 : 0;
+}
+hipError_t hj_launch_distinct_heads(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *group_start, uint64_t n, uint64_t *dval,
+                                    uint8_t *dhead, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_distinct_heads_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, dev_rows, perm, group_start, n, dval, dhead);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void hj_segment_starts_kernel(const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t n_groups, uint64_t *seg_start) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && flags[i]) seg_start[offsets[i]] = i;

@@ -215,6 +215,7 @@ struct Lowering {
   bool exact_f64 = false;
   uint64_t table_rows = 0; // rows of the table the plan scans (the N of the exact sums)
   bool allow_dict_num = true; // the kernels of this plan see ScanParams::dict_num (not the sort route's reduce kernel)
+  bool allow_sorted_distinct = false; // reduce plans: DISTINCT aggregates over ONE Int64 / Float64 column (it sorts last)
   // shared-image plans: exchange lane j of a lane group = xf(kernel lane src) (LoweredPlan::image_src / image_xf); empty = as is
   std::vector<std::vector<std::pair<uint8_t, uint8_t>>> group_expand = {};
   std::vector<std::pair<uint8_t, uint8_t>> next_expand = {};
@@ -1042,8 +1043,38 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
 
   for (uint32_t a = 0; a < n_aggs; ++a) {
     const llkv_aggregate_spec &s = aggs[a];
-    if (s.distinct) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates are not on the GPU path");
     AggOut o{AggFinal::CountRows, -1};
+    if (s.distinct && s.kind != LLKV_AGG_MIN && s.kind != LLKV_AGG_MAX && s.kind != LLKV_AGG_COUNT_STAR) {
+      // every group runs the reference's distinct accumulator over its own rows (llkv-executor/src/lib.rs:5222-5247):
+      // on the sort-based route the argument column is one more sort key and the reduction counts the first row of
+      // every run of equal values
+      if (!L.allow_sorted_distinct) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates inside GROUP BY run on the sort-based route");
+      if (s.kind != LLKV_AGG_COUNT && s.kind != LLKV_AGG_SUM && s.kind != LLKV_AGG_TOTAL && s.kind != LLKV_AGG_AVG)
+        return L.fail(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind " + std::to_string(s.kind));
+      if (!s.expr || s.expr_len != 1 || s.expr[0].kind != LLKV_TOK_COLUMN) return L.fail(LLKV_UNSUPPORTED, "DISTINCT inside GROUP BY over a computed argument");
+      const ColumnInfo *dci = resolve(s.expr[0].field_id);
+      if (!dci) return L.fail(LLKV_INVALID_ARGUMENT, "unknown column '" + std::to_string(s.expr[0].field_id) + "' in aggregate");
+      if (dci->dtype != LLKV_DT_INT64 && dci->dtype != LLKV_DT_FLOAT64) return L.fail(LLKV_UNSUPPORTED, std::string("DISTINCT aggregate over ") + dtype_name(dci->dtype));
+      if (p.distinct_field >= 0 && p.distinct_field != (int64_t)s.expr[0].field_id)
+        return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates over more than one column in a GROUP BY");
+      p.distinct_field = s.expr[0].field_id;
+      const bool f = dci->dtype == LLKV_DT_FLOAT64;
+      const int count_lane = add_group("DistinctCount", {ADD_I64});
+      if (s.kind == LLKV_AGG_COUNT) { o.fin = AggFinal::CountValid; o.lane = count_lane; p.aggs.push_back(o); continue; }
+      if (!f && s.kind != LLKV_AGG_TOTAL) { // the checked_add chain over the distinct values cannot overflow whatever their order
+        auto mag = [](int64_t v) -> u128 { return v < 0 ? (u128)(-(i128)v) : (u128)v; };
+        if (!dci->has_stats) return L.fail(LLKV_UNSUPPORTED, "SUM(DISTINCT) over an integer column without statistics (order-dependent overflow check)");
+        const u128 m = mag(dci->min_i) > mag(dci->max_i) ? mag(dci->min_i) : mag(dci->max_i);
+        if (m * (u128)dci->rows > (u128)INT64_MAX) return L.fail(LLKV_UNSUPPORTED, "possible i64 overflow in SUM(DISTINCT): order-dependent check is not on the GPU path");
+      }
+      o.count_lane = count_lane;
+      if (s.kind == LLKV_AGG_TOTAL) { o.fin = AggFinal::TotalF64; o.lane = add_group(f ? "DistinctSumF64" : "DistinctTotalI64", {ADD_F64}); }
+      else if (f) { o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumF64 : AggFinal::AvgF64; o.lane = add_group("DistinctSumF64", {ADD_F64}); }
+      else { o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumI64Fast : AggFinal::AvgI64Fast; o.lane = add_group("DistinctSumI64", {ADD_I64}); }
+      p.aggs.push_back(o);
+      continue;
+    }
+    if (s.distinct && s.kind == LLKV_AGG_COUNT_STAR) return L.fail(LLKV_UNSUPPORTED, "COUNT(DISTINCT *)");
     if (s.kind == LLKV_AGG_COUNT_STAR) { p.aggs.push_back(o); continue; }
     if (!s.expr || s.expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
     const bool simple = s.expr_len == 1 && s.expr[0].kind == LLKV_TOK_COLUMN;
@@ -1378,6 +1409,7 @@ int lower_reduce(const ColumnResolver &resolve, const llkv_aggregate_spec *aggs,
   LoweredPlan &p = *out;
   Lowering L{resolve, p, err, true};
   L.allow_dict_num = false;
+  L.allow_sorted_distinct = true;
   p.grouped = true;
   p.track_first = true;
   std::vector<std::string> groups;

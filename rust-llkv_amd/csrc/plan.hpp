@@ -90,6 +90,7 @@ struct LoweredPlan {
   int k_image = 0;
   std::vector<uint8_t> image_src, image_xf;
   uint32_t image_min_grid = 0; // workgroups below which an image lane could overflow (fixed-point sums)
+  int64_t distinct_field = -1; // reduce plans (sort-based GROUP BY): the column every DISTINCT aggregate is over (-1: none)
   int k = 1;      // lanes per group
   int lanes = 2;  // ng * k + 1
   int unroll = 2;

@@ -124,6 +124,10 @@ struct ReduceParams {
   const uint64_t *seg_start; // [n_groups + 1] segment bounds in sorted positions
   const uint32_t *order;     // output position → segment (nullptr = identity): groups leave in their final order
   uint64_t *out;             // [n_groups][K] lanes: rows, first row id, aggregate lanes
+  // DISTINCT aggregates (all over one column, which sorted last): per sorted position the column's value and whether the
+  // row is the first of its group with that value (NULL cells never are); nullptr when the plan has none
+  const uint64_t *dval;
+  const uint8_t *dhead;
   uint32_t *error_flag;
   int64_t lit_i[kMaxLits];
   double lit_f[kMaxLits];

@@ -442,6 +442,7 @@ template <class P, int W = 64> __device__ __forceinline__ void group_reduce_body
     // sort keeps a group's rows in row order, and only comparisons inside the group look at it; the real row id
     // would be one more random load per row
     Ctx c{sp, ld, 0u, i};
+    if (rp.dval) { c.dval = rp.dval[i]; c.dhead = rp.dhead[i]; }
     uint64_t contrib[K];
     contrib[0] = 1;
     contrib[1] = ~0ull; // lane 1 (first row id) is written from the head of the segment below

@@ -30,6 +30,8 @@ for name, keys, aggs in (("by_orderkey", [S["l_orderkey"][0]], narrow), ("by_par
                          ("q1_wide_state", [S["l_returnflag"][0], S["l_linestatus"][0]], wide)):
     if only == "image_only" and name not in ("by_shipdate", "by_shipdate_count_only"):
         continue
+    if only and only != "image_only" and name not in only.split(","):
+        continue
     q = rt.PreparedQuery(t, None, aggs, keys, True)
     image = q.kernel_signature.endswith(",2>")
     ts = []
