@@ -428,3 +428,16 @@ def test_golden_inventory_says_what_pins_the_oracle():
     held += len(STRINGS["cases"]) + len(STRING_SCANS["cases"]) + 1 + len(JOIN_FILTERS["cartesian"])
     print(f"golden cases held by the reference's own tests: {held}; derived from source lines: {derived}")
     assert held >= 70 and derived <= 10
+
+
+def test_oracle_runs_distinct_accumulators_per_group(orc, abi):
+    """GROUP BY hands every group's rows, in scan order, to the same accumulators an ungrouped query uses
+    (llkv-executor/src/lib.rs:5100-5247) — the DISTINCT forms included: Int64 by value, Float64 by bit pattern, NULL cells
+    skipped, f64 sums in order of first appearance.  Expectations derived by hand from those rules (not reference-held)."""
+    import dataclasses
+    t = orc.OracleTable(8).add(1, abi.DT_UTF8, ["a", "b", "a", "a", "b", "b", "a", "b"])
+    t.add(2, abi.DT_INT64, np.array([1, 1, 2, 1, 5, 5, 3, 7]), [1, 1, 1, 1, 1, 0, 1, 1]).add(3, abi.DT_FLOAT64, np.array([.5, .5, .5, 1.5, 2., 2., .5, 4.]))
+    A = abi.AggregateSpec
+    D = lambda a: dataclasses.replace(a, distinct=True)
+    res = orc.groupby(t, None, [1], [A.count_star(), D(A.count(2)), D(A.sum(2)), D(A.avg(2)), D(A.total(3)), D(A.sum(3)), D(A.max(2))], True)
+    assert [[k.value for k in r.keys] + [v.value for v in r.values] for r in res] == [["a", 4, 3, 6, 2.0, 2.0, 2.0, 3], ["b", 4, 3, 13, 13 / 3, 6.5, 6.5, 7]]
