@@ -367,9 +367,13 @@ int SortedGroupBy::run(LazyGroups *out) {
   // (llkv-executor/src/lib.rs:5065-5089): sort the segments by the row id of their first row.
   Scratch first_d, first_s, ord_in, ord_out;
   const uint32_t *order = nullptr;
+  if (has_distinct) { // the rows of a group are sorted by the argument too: its first appearance is its smallest row id
+    if ((rc = first_d.alloc(n_groups * 8))) return rc;
+    HIP_TRY(hj_launch_segment_min_rows(sel.d_ids, perm, seg.as<uint64_t>(), n_groups, first_d.as<uint64_t>(), s));
+  }
   if (!order_by_keys && n_groups > 1) {
-    if ((rc = first_d.alloc(n_groups * 8)) || (rc = first_s.alloc(n_groups * 8)) || (rc = ord_in.alloc(n_groups * 4)) || (rc = ord_out.alloc(n_groups * 4))) return rc;
-    HIP_TRY(hj_launch_first_rows(sel.d_ids, perm, seg.as<uint64_t>(), n_groups, first_d.as<uint64_t>(), s));
+    if ((!has_distinct && (rc = first_d.alloc(n_groups * 8))) || (rc = first_s.alloc(n_groups * 8)) || (rc = ord_in.alloc(n_groups * 4)) || (rc = ord_out.alloc(n_groups * 4))) return rc;
+    if (!has_distinct) HIP_TRY(hj_launch_first_rows(sel.d_ids, perm, seg.as<uint64_t>(), n_groups, first_d.as<uint64_t>(), s));
     HIP_TRY(hj_launch_iota(ord_in.as<uint32_t>(), (uint32_t)n_groups, s));
     uint32_t bits = 1;
     while (bits < 64 && (table->total_rows >> bits) != 0) ++bits;
@@ -408,6 +412,7 @@ int SortedGroupBy::run(LazyGroups *out) {
     HIP_TRY(hj_launch_distinct_heads(dcol, sel.d_dev, perm, flags.as<uint64_t>(), n, dval.as<uint64_t>(), dhead.as<uint8_t>(), s));
     p.dval = dval.as<uint64_t>();
     p.dhead = dhead.as<uint8_t>();
+    p.first_rows = first_d.as<uint64_t>();
   }
   // lanes per group: a wave, or 8 lanes when the groups average fewer than 16 rows
   const bool narrow = n / n_groups < 16;

@@ -1115,6 +1115,28 @@ hipError_t hj_launch_first_rows(const uint64_t *row_ids, const uint32_t *perm, c
   hipLaunchKernelGGL(hj_first_rows_kernel, dim3((uint32_t)((n_groups + 255) / 256)), dim3(256), 0, s, row_ids, perm, seg_start, n_groups, first_rows);
   return hipGetLastError();
 }
+// the smallest row id of every segment (8 lanes per segment): a group's first appearance when the rows inside a group
+// are NOT in row order (DISTINCT aggregates sort them by the argument as well)
+__global__ __launch_bounds__(256) void hj_segment_min_rows_kernel(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows) {
+  const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+  const uint32_t lane = threadIdx.x & 7;
+  if (g >= n_groups) return;
+  uint64_t m = ~0ull;
+  for (uint64_t i = seg_start[g] + lane; i < seg_start[g + 1]; i += 8) {
+    const uint64_t r = row_ids[perm[i]];
+    m = r < m ? r : m;
+  }
+  for (int o = 1; o < 8; o <<= 1) {
+    const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(m >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)m, o);
+    m = other < m ? other : m;
+  }
+  if (lane == 0) first_rows[g] = m;
+}
+hipError_t hj_launch_segment_min_rows(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows, hipStream_t s) {
+  if (n_groups == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_segment_min_rows_kernel, dim3((uint32_t)((n_groups * 8 + 255) / 256)), dim3(256), 0, s, row_ids, perm, seg_start, n_groups, first_rows);
+  return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void hj_group_keys_kernel(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start,
                                                              const uint32_t *order, uint64_t n_groups, int64_t *out_vals, uint8_t *out_valid) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -221,6 +221,7 @@ hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const 
 hipError_t hj_launch_gather_sort_keys(const JoinKeyColumn &col, long long base, const uint8_t *code_rank, const uint64_t *dev_rows, const uint32_t *perm,
                                       uint64_t n, uint64_t *keys, hipStream_t s);
 // first_rows[g] = logical row id of the first row of segment g (the stable sort keeps row order inside a group).
+hipError_t hj_launch_segment_min_rows(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows, hipStream_t s);
 hipError_t hj_launch_first_rows(const uint64_t *row_ids, const uint32_t *perm, const uint64_t *seg_start, uint64_t n_groups, uint64_t *first_rows, hipStream_t s);
 hipError_t hj_launch_gather_valid(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint32_t *out, hipStream_t s);
 struct GroupKeySet {

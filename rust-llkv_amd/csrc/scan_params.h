@@ -128,6 +128,7 @@ struct ReduceParams {
   // row is the first of its group with that value (NULL cells never are); nullptr when the plan has none
   const uint64_t *dval;
   const uint8_t *dhead;
+  const uint64_t *first_rows; // … and (rows inside a group are then not in row order) every segment's smallest row id
   uint32_t *error_flag;
   int64_t lit_i[kMaxLits];
   double lit_f[kMaxLits];

@@ -441,7 +441,8 @@ template <class P, int W = 64> __device__ __forceinline__ void group_reduce_body
     // "row" of the aggregates that break ties by arrival (MIN / MAX over f64): the sorted position — the stable
     // sort keeps a group's rows in row order, and only comparisons inside the group look at it; the real row id
     // would be one more random load per row
-    Ctx c{sp, ld, 0u, i};
+    // (with DISTINCT aggregates the rows of a group are sorted by their argument as well: the real row id then)
+    Ctx c{sp, ld, 0u, rp.dval ? rp.row_ids[s] : i};
     if (rp.dval) { c.dval = rp.dval[i]; c.dhead = rp.dhead[i]; }
     uint64_t contrib[K];
     contrib[0] = 1;
@@ -460,7 +461,7 @@ template <class P, int W = 64> __device__ __forceinline__ void group_reduce_body
       // combine(lower lane's value, upper lane's value): every lane of a pair computes the same result
       v = (lane & o) ? lane_combine(reduce_lane_op<P>(k), other, v) : lane_combine(reduce_lane_op<P>(k), v, other);
     }
-    if (lane == 0) rp.out[g * K + k] = (k == 1 && e > b) ? rp.row_ids[rp.perm[b]] : v;
+    if (lane == 0) rp.out[g * K + k] = (k == 1 && e > b) ? (rp.first_rows ? rp.first_rows[sg] : rp.row_ids[rp.perm[b]]) : v;
   }
   if (err) atomicOr(rp.error_flag, err);
 }

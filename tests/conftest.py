@@ -165,7 +165,7 @@ def same_value(got, want, rel=0.0):
     if isinstance(want, float) and math.isnan(want):
         return isinstance(got, float) and math.isnan(got)
     if isinstance(want, float) or isinstance(got, float):
-        if rel == 0.0:
+        if rel == 0.0 or math.isinf(float(want)) or math.isinf(float(got)):
             return float(got) == float(want)
         return abs(float(got) - float(want)) <= rel * max(abs(float(want)), 1e-300)
     return got == want
