@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void hj_compact_stripes2_bits_kernel(const uin
                                                                         uint32_t key_width, uint32_t key_signed, long long kmin, unsigned long long *bits,
                                                                         uint32_t *unsorted_flag) {
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (slot >= n_slots) return;
+  if (slot >= n_slots || offsets[n_slots] >= kPredErrorBit) return; // (a predicate error: the counts carry the mark; the host reports it)
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
   auto key_of = [&](uint64_t r) -> long long {
