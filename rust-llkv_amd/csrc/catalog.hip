@@ -118,6 +118,21 @@ hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const
   return hipGetLastError();
 }
 
+hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, uint64_t *out, const uint8_t *lane_ops,
+                              const uint8_t *lane_src, const uint8_t *lane_xf, uint32_t n_tiles, uint32_t np, uint32_t ngs, uint32_t ng, uint32_t kl, uint32_t k,
+                              hipStream_t stream) {
+  const size_t lds = (size_t)kl * ngs * 8;
+  static bool raised = false; // (the attribute belongs to the function, not to a launch)
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(part_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  PartReduceParams f{offsets, records, out, lane_ops, lane_src, lane_xf, n_tiles, ngs, ng, kl, k};
+  hipLaunchKernelGGL(part_reduce_kernel, dim3(np), dim3(1024), lds, stream, f);
+  return hipGetLastError();
+}
+
 // *flag |= 1 unless the real rows of the column (the tiles list them, in row order) are strictly ascending
 template <class T> __global__ __launch_bounds__(256) void ascending_check_kernel(const T *v, const TileDesc *tiles, uint32_t n_tiles, uint32_t *flag) {
   const TileDesc td = tiles[blockIdx.x];

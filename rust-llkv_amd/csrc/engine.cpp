@@ -192,7 +192,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
     // sparse or unbounded integer keys, too many groups, unbounded f64 sums: sort-based route
     const std::string dense_err = err;
     if (sorted_groupby_prepare(table, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, order_by_keys, &q->sorted) == LLKV_OK) {
-      q->route_note = "sort-based GROUP BY (" + dense_err + ")";
+      q->route_note = std::string(sorted_groupby_partitioned(q->sorted) ? "partitioned GROUP BY (" : "sort-based GROUP BY (") + dense_err + ")";
       *out = q.release();
       return LLKV_OK;
     }

@@ -91,7 +91,7 @@ void build_tiles_host(const Table &t, uint32_t tile_rows, std::vector<TileDesc> 
                       uint32_t (&octant_tile_begin)[kOctantsHost + 1]);
 
 // run-time compiled plan (jit.cpp)
-enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5, Image = 6, KeyBits = 7 };
+enum class JitKind : int { Scan = 0, Select = 1, Project = 2, Probe = 3, Emit = 4, Reduce = 5, Image = 6, KeyBits = 7, Part = 8 };
 struct JitKernel {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // scan / select-count / project
@@ -152,8 +152,18 @@ inline const char *arith_error_message(uint64_t code) {
   return (code & 2u) ? "Divide by zero" : "Arithmetic overflow: Overflow happened in a computed projection";
 }
 
-// Sort-based GROUP BY (group_sort.cpp): any number of groups, any state width.
+// Partitioned GROUP BY (group_part.cpp): up to 2^24 dense groups with order-free lanes, one rank.
+struct PartGroupBy;
+int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                         const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool order_by_keys, PartGroupBy **out);
+int part_groupby_run(PartGroupBy *p, LazyGroups *out);
+void part_groupby_free(PartGroupBy *p);
+const LoweredPlan *part_groupby_plan(const PartGroupBy *p);
+
+// Sort-based GROUP BY (group_sort.cpp): any number of groups, any state width.  A query the partitioned route admits is
+// handed to it instead (sorted_groupby_partitioned() says so).
 struct SortedGroupBy;
+bool sorted_groupby_partitioned(const SortedGroupBy *s);
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                            const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
                            bool order_by_keys, SortedGroupBy **out);

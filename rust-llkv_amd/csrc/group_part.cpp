@@ -1,0 +1,271 @@
+// group_part.cpp — partitioned GROUP BY: more dense groups than a few LDS-sized slices cover (tens of thousands …
+// 2^24), every lane order-free (the shared-image lowering: integer adds, min / max, f64 sums on exact grids).
+//   count pass   part_count_body     rows per (tile of 32 768 rows, partition of 2^shift consecutive group ids)
+//   scan         rocPRIM               exclusive, partition-major: where each (partition, tile) cell starts
+//   scatter pass part_scatter_body   every selected row's record (group within the partition, lane contributions) at
+//                                      its position (an LDS counter per cell hands them out: no global atomics)
+//   reduce       part_reduce_kernel    one workgroup per partition: its records → an LDS image → rows [group][lane]
+//   groups       rocPRIM select + sort the groups that have rows, in first-appearance order (lane 1 = the smallest row
+//                                      id, llkv-executor/src/lib.rs:5065-5089); their lanes and decoded key cells
+// Against the sort-based route (group_sort.cpp) for 60 M rows in 2 M groups: no radix passes over all the rows and no
+// random gathers of the argument columns — the columns are streamed twice and the records once.
+// The result is handed over like the sort-based route's (LazyGroups: cells are finalized on request).
+#include "catalog.hpp"
+#include "engine.hpp"
+#include "join.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace llkv {
+
+int finalize_value(const AggOut &a, const uint64_t *g, int base, llkv_value *out, std::string *err, bool prefixes_checked);
+
+constexpr uint32_t kPartTileRowsHost = 32768; // fused_scan.hip.h: kPartTileRows
+constexpr uint32_t kMaxPartsHost = 4096;      // fused_scan.hip.h: kMaxParts
+constexpr size_t kPartImageBytes = 128u << 10; // LDS image of one partition, at most
+
+struct PartGroupBy {
+  const Table *table = nullptr;
+  LoweredPlan plan;
+  std::vector<uint32_t> key_fields;
+  JitKernel kernel;
+  uint32_t ngs = 0, np = 0, shift = 0; // groups per partition (2^shift), partitions
+  bool order_by_keys = false;          // (integer keys without NULL cells only: ascending group ids are ascending keys)
+  double *d_dict_num = nullptr;
+  uint8_t *d_lane_tables = nullptr; // [kl] ops of the kernel lanes, [k] source lane, [k] transform
+  void *h_lanes = nullptr, *h_kv = nullptr, *h_kvalid = nullptr;
+  size_t cap_lanes = 0, cap_kv = 0, cap_kvalid = 0;
+  int run(LazyGroups *out);
+  ~PartGroupBy() {
+    scratch_free(d_dict_num);
+    scratch_free(d_lane_tables);
+    if (h_lanes) (void)hipHostFree(h_lanes);
+    if (h_kv) (void)hipHostFree(h_kv);
+    if (h_kvalid) (void)hipHostFree(h_kvalid);
+  }
+};
+
+void part_groupby_free(PartGroupBy *p) { delete p; }
+const LoweredPlan *part_groupby_plan(const PartGroupBy *p) { return &p->plan; }
+
+namespace {
+int pinned_reserve(void **p, size_t *cap, size_t bytes) {
+  if (bytes <= *cap) return LLKV_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIP_TRY(hipHostMalloc(p, bytes + bytes / 4 + 64, hipHostMallocDefault));
+  *cap = bytes + bytes / 4 + 64;
+  return LLKV_OK;
+}
+} // namespace
+
+// Admission: what the shared-image lowering takes (statistics-bounded keys, order-free lanes) with up to 2^24 dense
+// groups, on one rank; in first-appearance order, or in key order when the group ids sort like the keys.
+int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
+                         const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool order_by_keys, PartGroupBy **out) {
+  if (table->world != 1) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY runs on one rank");
+  if (table->local_rows >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 rows");
+  auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
+    auto it = table->cols.find(fid);
+    return it == table->cols.end() ? nullptr : &it->second.info;
+  };
+  std::unique_ptr<PartGroupBy> g(new PartGroupBy());
+  g->table = table;
+  g->key_fields.assign(key_fields, key_fields + n_keys);
+  std::string err;
+  int rc;
+  if ((rc = lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, /*grouped=*/true, /*track_first=*/true, &g->plan, &err,
+                       /*image=*/true, /*partitioned=*/true)))
+    return set_error(rc, err);
+  const LoweredPlan &p = g->plan;
+  const uint32_t kl = (uint32_t)p.k_image;
+  // ORDER BY the keys: the dense group id orders the groups as the keys do when every key is an integer column without
+  // NULL cells (the first key is the most significant digit; a NULL group's code would sort last, a dictionary code
+  // not as its string)
+  g->order_by_keys = order_by_keys;
+  if (order_by_keys)
+    for (uint32_t j = 0; j < n_keys; ++j)
+      if (!p.key_is_int[j] || p.key_nullable[j]) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY in key order takes integer keys without NULL cells");
+  // groups per partition: a power of two whose image fits, and small enough that the reduction has a few hundred
+  // workgroups to run
+  uint32_t shift = 0;
+  while ((size_t)(2u << shift) * kl * 8 <= kPartImageBytes) ++shift;
+  while (shift > 6 && ((uint64_t)p.ng >> shift) < 512) --shift;
+  g->shift = shift;
+  g->ngs = 1u << shift;
+  g->np = (uint32_t)(((uint64_t)p.ng + g->ngs - 1) >> shift);
+  if (g->np > kMaxPartsHost)
+    return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: " + std::to_string(p.ng) + " groups × " + std::to_string(kl) + " lanes need more than " +
+                                           std::to_string(kMaxPartsHost) + " partitions");
+  if ((rc = jit_compile(JitKind::Part, p.type_string, &g->kernel, &err))) return set_error(rc, err);
+  hipStream_t s = g_ctx.stream;
+  if (!p.dict_num.empty()) { // numeric images of the dictionaries some aggregate reads (DictNum<slot>)
+    std::vector<double> image((size_t)kMaxCols * 256, 0.0);
+    for (auto &d : p.dict_num) std::copy(d.second.begin(), d.second.end(), image.begin() + (size_t)d.first * 256);
+    g->d_dict_num = (double *)scratch_alloc(image.size() * 8);
+    if (!g->d_dict_num) return set_error(LLKV_INTERNAL, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(g->d_dict_num, image.data(), image.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // `image` is a local
+  }
+  // lane tables: ops of the kernel lanes (exchange lane j comes from kernel lane image_src[j], so that lane's op is
+  // exchange lane j's), then source and transform per exchange lane
+  const uint32_t k = (uint32_t)p.k;
+  std::vector<uint8_t> tables(kl + 2 * k, 0);
+  for (uint32_t j = 0; j < k; ++j) {
+    const uint8_t src = j < p.image_src.size() ? p.image_src[j] : (uint8_t)j;
+    tables[src] = p.lane_ops[j];
+    tables[kl + j] = src;
+    tables[kl + k + j] = j < p.image_xf.size() ? p.image_xf[j] : 0;
+  }
+  g->d_lane_tables = (uint8_t *)scratch_alloc(tables.size());
+  if (!g->d_lane_tables) return set_error(LLKV_INTERNAL, "device allocation failed");
+  HIP_TRY(hipMemcpyAsync(g->d_lane_tables, tables.data(), tables.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *out = g.release();
+  return LLKV_OK;
+}
+
+int PartGroupBy::run(LazyGroups *out) {
+  *out = LazyGroups{};
+  out->active = true;
+  out->plan = &plan;
+  out->k = plan.k;
+  out->n_keys = (uint32_t)key_fields.size();
+  for (uint32_t f : key_fields) out->key_cols.push_back(&table->cols.at(f).info);
+  if (plan.always_false || table->local_rows == 0) return LLKV_OK;
+  hipStream_t s = g_ctx.stream;
+  int rc;
+  const bool trace = std::getenv("LLKV_HIP_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[llkv group_part] %-22s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  const LoweredPlan &p = plan;
+  const uint32_t k = (uint32_t)p.k, kl = (uint32_t)p.k_image, ng = p.ng, n_keys = (uint32_t)key_fields.size();
+  const TileSet *ts = nullptr;
+  if ((rc = get_tileset(*table, kPartTileRowsHost, &ts))) return rc;
+  const uint32_t n_tiles = ts->n_tiles;
+  const uint64_t cells = (uint64_t)np * n_tiles + 1; // + the total
+  const uint64_t cap = table->local_rows;
+  Scratch hist, offs, tmp, flags, rec_val, group_rows, ids;
+  if ((rc = hist.alloc(cells * 4)) || (rc = offs.alloc(cells * 4)) || (rc = flags.alloc(16)) ||
+      (rc = rec_val.alloc((uint64_t)kl * cap * 8)) || (rc = group_rows.alloc((uint64_t)ng * k * 8)) || (rc = ids.alloc((uint64_t)ng * 4)))
+    return rc;
+  HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (cells - 1), 0, 4, s)); // (every other cell is written by the count pass)
+  HIP_TRY(hipMemsetAsync(flags.p, 0, 16, s));                         // [0] error codes, [1] number of groups
+  ScanParams sp;
+  std::memset(&sp, 0, sizeof sp);
+  for (size_t i = 0; i < p.slot_fields.size(); ++i) sp.col[i] = slot_buffer(table->cols, p, i);
+  for (size_t i = 0; i < p.lit_i.size(); ++i) sp.lit_i[i] = p.lit_i[i];
+  for (size_t i = 0; i < p.lit_f.size(); ++i) sp.lit_f[i] = p.lit_f[i];
+  for (size_t i = 0; i < p.key_strides.size(); ++i) sp.key_stride[i] = p.key_strides[i];
+  sp.dict_num = d_dict_num;
+  sp.tiles = ts->d_tiles;
+  sp.n_tiles = n_tiles;
+  sp.part_hist = hist.as<uint32_t>();
+  sp.part_offsets = offs.as<uint32_t>();
+  sp.part_val = rec_val.as<uint64_t>();
+  sp.part_shift = shift;
+  sp.part_np = np;
+  sp.part_err = flags.as<uint32_t>();
+  if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, 1024))) return rc;
+  mark("count pass");
+  {
+    size_t tb = 0;
+    HIP_TRY(hj_exclusive_scan_u32(nullptr, &tb, hist.as<uint32_t>(), offs.as<uint32_t>(), cells, s));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_exclusive_scan_u32(tmp.p, &tb, hist.as<uint32_t>(), offs.as<uint32_t>(), cells, s));
+  }
+  mark("scan");
+  if ((rc = jit_launch_raw(kernel.fn2, n_tiles, &sp, sizeof sp, s, 1024))) return rc;
+  mark("scatter pass");
+  HIP_TRY(launch_part_reduce(offs.as<uint32_t>(), rec_val.as<uint64_t>(), group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
+                             d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s));
+  mark("partition reduce");
+  // ---- the groups that have rows, in first-appearance order --------------------------------------------------------
+  Scratch tmp2;
+  {
+    size_t tb = 0;
+    HIP_TRY(hj_select_present_groups(nullptr, &tb, group_rows.as<uint64_t>(), k, ng, ids.as<uint32_t>(), flags.as<uint32_t>() + 1, s));
+    if ((rc = tmp2.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_select_present_groups(tmp2.p, &tb, group_rows.as<uint64_t>(), k, ng, ids.as<uint32_t>(), flags.as<uint32_t>() + 1, s));
+  }
+  uint32_t host_flags[2] = {0, 0};
+  {
+    Readback rb;
+    if ((rc = rb.add(host_flags, flags.p, 8, s)) || (rc = rb.wait())) return rc;
+  }
+  if (host_flags[0]) return set_error(LLKV_INTERNAL, arith_error_message(host_flags[0]));
+  const uint32_t n_groups = host_flags[1];
+  mark("present groups");
+  if (n_groups == 0) return LLKV_OK;
+  Scratch first_d, first_s, ord_in, ord_out, tmp3;
+  const uint32_t *order = nullptr;
+  if (n_groups > 1 && !order_by_keys) {
+    if ((rc = first_d.alloc((uint64_t)n_groups * 8)) || (rc = first_s.alloc((uint64_t)n_groups * 8)) || (rc = ord_in.alloc((uint64_t)n_groups * 4)) ||
+        (rc = ord_out.alloc((uint64_t)n_groups * 4)))
+      return rc;
+    HIP_TRY(hj_launch_gather_lane(group_rows.as<uint64_t>(), k, 1, ids.as<uint32_t>(), n_groups, first_d.as<uint64_t>(), s));
+    HIP_TRY(hj_launch_iota(ord_in.as<uint32_t>(), n_groups, s));
+    uint32_t bits = 1;
+    while (bits < 64 && (table->total_rows >> bits) != 0) ++bits;
+    size_t tb = 0;
+    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
+    if ((rc = tmp3.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_sort_u64_u32_bits(tmp3.p, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
+    order = ord_out.as<uint32_t>();
+  }
+  mark("output order");
+  DenseKeyLayout kl_keys;
+  std::memset(&kl_keys, 0, sizeof kl_keys);
+  kl_keys.n = n_keys;
+  for (uint32_t j = 0; j < n_keys; ++j) {
+    kl_keys.stride[j] = p.key_strides[j];
+    kl_keys.card[j] = p.key_cards[j];
+    kl_keys.nullable[j] = p.key_nullable[j];
+    kl_keys.base[j] = p.key_bases[j];
+  }
+  Scratch lanes_d, kv_d, kvalid_d;
+  if ((rc = lanes_d.alloc((uint64_t)n_groups * k * 8)) || (rc = kv_d.alloc((uint64_t)n_groups * n_keys * 8)) || (rc = kvalid_d.alloc((uint64_t)n_groups * n_keys))) return rc;
+  HIP_TRY(hj_launch_emit_dense_groups(group_rows.as<uint64_t>(), k, ids.as<uint32_t>(), order, n_groups, kl_keys, lanes_d.as<uint64_t>(), kv_d.as<int64_t>(),
+                                      kvalid_d.as<uint8_t>(), s));
+  mark("emit groups");
+  if ((rc = pinned_reserve(&h_lanes, &cap_lanes, (size_t)n_groups * k * 8)) || (rc = pinned_reserve(&h_kv, &cap_kv, (size_t)n_groups * n_keys * 8)) ||
+      (rc = pinned_reserve(&h_kvalid, &cap_kvalid, (size_t)n_groups * n_keys)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(h_lanes, lanes_d.p, (size_t)n_groups * k * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_kv, kv_d.p, (size_t)n_groups * n_keys * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_kvalid, kvalid_d.p, (size_t)n_groups * n_keys, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  mark("copy out");
+  // only the aggregates whose finalize can fail are visited now; cells are decoded on request
+  const uint64_t *lanes = static_cast<const uint64_t *>(h_lanes);
+  for (size_t a = 0; a < p.aggs.size(); ++a) {
+    if (p.aggs[a].fin != AggFinal::SumI64 && p.aggs[a].fin != AggFinal::AvgI64) continue;
+    for (uint64_t g = 0; g < n_groups; ++g) {
+      llkv_value v;
+      std::string err;
+      if ((rc = finalize_value(p.aggs[a], lanes + g * (size_t)k, 2, &v, &err, false))) return set_error(rc, err);
+    }
+  }
+  out->n = n_groups;
+  out->lanes = lanes;
+  out->key_vals = static_cast<const int64_t *>(h_kv);
+  out->key_valid = static_cast<const uint8_t *>(h_kvalid);
+  mark("host checks");
+  return LLKV_OK;
+}
+
+int part_groupby_run(PartGroupBy *p, LazyGroups *out) { return p->run(out); }
+
+} // namespace llkv

@@ -38,8 +38,10 @@ struct SortedGroupBy {
   std::vector<uint64_t> m_lanes;
   std::vector<int64_t> m_kv;
   std::vector<uint8_t> m_kvalid;
+  PartGroupBy *part = nullptr; // the partitioned route answers instead (group_part.cpp)
   int run(LazyGroups *out);
   ~SortedGroupBy() {
+    if (part) part_groupby_free(part);
     if (h_lanes) (void)hipHostFree(h_lanes);
     if (h_kv) (void)hipHostFree(h_kv);
     if (h_kvalid) (void)hipHostFree(h_kvalid);
@@ -47,6 +49,7 @@ struct SortedGroupBy {
 };
 
 void sorted_groupby_free(SortedGroupBy *s) { delete s; }
+bool sorted_groupby_partitioned(const SortedGroupBy *s) { return s && s->part; }
 
 // ---- sharded tables: merge of the ranks' partial groups (host) -------------------------------------------------------
 // Every rank ran the query over its own chunks: its groups are partial states (the lanes of the reduce plan), keyed
@@ -81,8 +84,9 @@ struct KeyTupleHash {
 int sorted_groupby_merge(SortedGroupBy *s, uint32_t world, const uint64_t *rank_groups, const int64_t *const *key_values,
                          const uint8_t *const *key_valid, const uint64_t *const *lanes, LazyGroups *out) {
   const uint32_t n_keys = (uint32_t)s->key_fields.size();
-  const int K = s->red_plan.k;
-  const std::vector<uint8_t> &ops = s->red_plan.lane_ops;
+  const LoweredPlan &lane_plan = s->part ? *part_groupby_plan(s->part) : s->red_plan; // (lane_ops: the first k entries are one group's)
+  const int K = lane_plan.k;
+  const std::vector<uint8_t> &ops = lane_plan.lane_ops;
   std::unordered_map<KeyTupleHost, uint64_t, KeyTupleHash> index;
   std::vector<KeyTupleHost> keys;
   std::vector<uint64_t> state;
@@ -191,6 +195,13 @@ int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint3
   s->key_fields.assign(key_fields, key_fields + n_keys);
   std::string err;
   int rc;
+  // statistics-bounded keys and order-free lanes (what the shared-image lowering takes), one rank: the partitioned
+  // route — no sort of the rows, no gathers
+  if (table->world == 1 && !std::getenv("LLKV_HIP_GROUP_NO_IMAGE") && !std::getenv("LLKV_HIP_GROUP_NO_PART") &&
+      part_groupby_prepare(table, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, order_by_keys, &s->part) == LLKV_OK) {
+    *out = s.release();
+    return LLKV_OK;
+  }
   if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, nullptr, 0, &s->sel_plan, &err))) return set_error(rc, err);
   if ((rc = lower_reduce(resolve, aggs, n_aggs, &s->red_plan, &err))) return set_error(rc, err);
   if (s->red_plan.distinct_field >= 0 && table->world != 1)
@@ -226,6 +237,7 @@ int key_column_of(const Table *t, uint32_t field, JoinKeyColumn *kc, long long *
 } // namespace
 
 int SortedGroupBy::run(LazyGroups *out) {
+  if (part) return part_groupby_run(part, out);
   *out = LazyGroups{};
   out->active = true;
   out->plan = &red_plan;

@@ -773,6 +773,47 @@ hipError_t hj_exclusive_scan_popc(void *tmp, size_t *tmp_bytes, const uint64_t *
   auto in = rocprim::make_transform_iterator(bits, PopcWord());
   return rocprim::exclusive_scan(tmp, *tmp_bytes, in, out, (uint32_t)0, (size_t)n_words, rocprim::plus<uint32_t>(), s);
 }
+// ---- partitioned GROUP BY (group_part.cpp): what follows the per-partition reduction ---------------------------------
+// ids of the groups that have rows (lane 0 of a group's row counts them), ascending; *count = how many
+struct GroupHasRows {
+  const uint64_t *rows;
+  uint32_t k;
+  __device__ bool operator()(uint32_t g) const { return rows[(uint64_t)g * k] != 0; }
+};
+hipError_t hj_select_present_groups(void *tmp, size_t *tmp_bytes, const uint64_t *group_rows, uint32_t k, uint32_t ng, uint32_t *ids, uint32_t *count, hipStream_t s) {
+  return rocprim::select(tmp, *tmp_bytes, rocprim::counting_iterator<uint32_t>(0), ids, count, (size_t)ng, GroupHasRows{group_rows, k}, s);
+}
+__global__ __launch_bounds__(256) void hj_gather_lane_kernel(const uint64_t *group_rows, uint32_t k, uint32_t lane, const uint32_t *ids, uint32_t n, uint64_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = group_rows[(uint64_t)ids[i] * k + lane];
+}
+hipError_t hj_launch_gather_lane(const uint64_t *group_rows, uint32_t k, uint32_t lane, const uint32_t *ids, uint32_t n, uint64_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_gather_lane_kernel, dim3((n + 255) / 256), dim3(256), 0, s, group_rows, k, lane, ids, n, out);
+  return hipGetLastError();
+}
+// Output row i = group ids[order ? order[i] : i]: its k lanes, and its key cells decoded from the dense group id
+// (digit of key j = (id / stride[j]) % card[j]; the last code of a nullable key is its NULL group).
+__global__ __launch_bounds__(256) void hj_emit_dense_groups_kernel(const uint64_t *group_rows, uint32_t k, const uint32_t *ids, const uint32_t *order, uint32_t n,
+                                                                    DenseKeyLayout keys, uint64_t *lanes_out, int64_t *key_vals, uint8_t *key_valid) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = ids[order ? order[i] : i];
+  for (uint32_t l = 0; l < k; ++l) lanes_out[(uint64_t)i * k + l] = group_rows[(uint64_t)g * k + l];
+  for (uint32_t j = 0; j < keys.n; ++j) {
+    const uint32_t code = (g / keys.stride[j]) % keys.card[j];
+    const bool is_null = keys.nullable[j] && code == keys.card[j] - 1;
+    key_vals[(uint64_t)j * n + i] = is_null ? 0 : keys.base[j] + (long long)code;
+    key_valid[(uint64_t)j * n + i] = is_null ? 0 : 1;
+  }
+}
+hipError_t hj_launch_emit_dense_groups(const uint64_t *group_rows, uint32_t k, const uint32_t *ids, const uint32_t *order, uint32_t n, const DenseKeyLayout &keys,
+                                       uint64_t *lanes_out, int64_t *key_vals, uint8_t *key_valid, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_emit_dense_groups_kernel, dim3((n + 255) / 256), dim3(256), 0, s, group_rows, k, ids, order, n, keys, lanes_out, key_vals, key_valid);
+  return hipGetLastError();
+}
+
 // `unsorted` (optional): zero = the list is in key order, rank == list index and nothing is written.  `dup_flag`
 // (optional): raised when the bitmap holds fewer bits than the list has rows (a key occurred twice).
 __global__ __launch_bounds__(256) void hj_bitmap_groups_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,

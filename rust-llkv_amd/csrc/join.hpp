@@ -258,4 +258,16 @@ hipError_t hj_launch_xor_u32(uint32_t *keys, uint64_t n, uint32_t mask, hipStrea
 // `tmp` sized by a first call with tmp == nullptr; d_prefix holds n 16-byte elements.
 hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals, uint64_t n, void *d_prefix, uint32_t *d_flag, hipStream_t s);
 
+// ---- partitioned GROUP BY (group_part.cpp) ----------------------------------------------------------------------------
+// group_rows = [ng][k] lanes, lane 0 = rows of the group: ids of the groups with rows, ascending
+hipError_t hj_select_present_groups(void *tmp, size_t *tmp_bytes, const uint64_t *group_rows, uint32_t k, uint32_t ng, uint32_t *ids, uint32_t *count, hipStream_t s);
+hipError_t hj_launch_gather_lane(const uint64_t *group_rows, uint32_t k, uint32_t lane, const uint32_t *ids, uint32_t n, uint64_t *out, hipStream_t s);
+struct DenseKeyLayout { // dense group id = Σ code_j · stride_j (plan.hpp: key_strides / key_cards / key_bases / key_nullable)
+  uint32_t n;
+  uint32_t stride[4], card[4], nullable[4];
+  long long base[4];
+};
+hipError_t hj_launch_emit_dense_groups(const uint64_t *group_rows, uint32_t k, const uint32_t *ids, const uint32_t *order, uint32_t n, const DenseKeyLayout &keys,
+                                       uint64_t *lanes_out, int64_t *key_vals, uint8_t *key_valid, hipStream_t s);
+
 } // namespace llkv

@@ -19,6 +19,7 @@ static constexpr int kMaxKeysHost = 4;
 static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
 // shared-image route: one image [lane][group] of 8-byte slots per workgroup; 150 KiB of the CU's 160 KiB of LDS
 static constexpr uint32_t kMaxImageGroups = 1u << 16;
+static constexpr uint32_t kMaxPartGroups = 1u << 24; // partitioned route: dense group ids (the result image is ng × k × 8 bytes of HBM)
 static constexpr size_t kMaxImageBytes = 158u * 1024; // of the 160 KB of a CU (the kernel keeps one more word)
 static constexpr int kMaxImagePasses = 4; // scans of the table a shared-image plan may take (the groups cut into slices)
 
@@ -213,6 +214,7 @@ struct Lowering {
   std::string nan_flag(bool is_float) const { return exact_nan && is_float ? ",1" : ""; }
   // shared-image plans: f64 sums as exact two-level pairs (SumF64X), which need a bound on |argument|
   bool exact_f64 = false;
+  bool whole_table_image = false; // partitioned route: one LDS image may receive every row of the table
   uint64_t table_rows = 0; // rows of the table the plan scans (the N of the exact sums)
   bool allow_dict_num = true; // the kernels of this plan see ScanParams::dict_num (not the sort route's reduce kernel)
   bool allow_sorted_distinct = false; // reduce plans: DISTINCT aggregates over ONE Int64 / Float64 column (it sorts last)
@@ -333,7 +335,7 @@ struct Lowering {
     const int b = m == 0.5 ? ex - 1 : ex;
     (void)std::frexp(nzmin, &nz_ex);
     const int e = nz_ex - 1 - 30;
-    const uint64_t image_rows = rows / 128 + 16384;
+    const uint64_t image_rows = whole_table_image ? rows : rows / 128 + 16384; // (a partition's image may see every row)
     int lr = 1;
     while (lr < 63 && ((uint64_t)1 << lr) < image_rows) ++lr;
     if (b - e + lr > 61 || e < -900 || e > 900) return false;
@@ -1251,14 +1253,16 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
 
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
-               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err, bool image) {
+               const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first, LoweredPlan *out, std::string *err, bool image, bool partitioned) {
   *out = LoweredPlan{};
   LoweredPlan &p = *out;
   Lowering L{resolve, p, err, grouped};
   p.grouped = grouped;
   if (image && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "the shared-image kernel serves GROUP BY plans");
+  if (partitioned && !image) return L.fail(LLKV_INVALID_ARGUMENT, "the partitioned route uses the shared-image lowering");
   L.exact_f64 = image;
-  const uint32_t max_groups = image ? kMaxImageGroups : kMaxDenseGroups;
+  L.whole_table_image = partitioned;
+  const uint32_t max_groups = partitioned ? kMaxPartGroups : image ? kMaxImageGroups : kMaxDenseGroups;
   int rc;
   if (n_aggs == 0 && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate query requires at least one aggregate expression");
   if (grouped && n_keys == 0) return L.fail(LLKV_INVALID_ARGUMENT, "GROUP BY requires at least one key");
@@ -1366,7 +1370,8 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   p.track_first = grouped && track_first;
   if (p.acc_lds && (size_t)(p.lanes - 1) * 2048 > 160u * 1024) // one 2 KiB row per group-state lane (the error lane lives in registers)
     return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
-  if (image) {
+  p.acc_part = partitioned;
+  if (image && !partitioned) {
     p.image_passes = (int)(((size_t)p.ng * p.k_image * 8 + kMaxImageBytes - 1) / kMaxImageBytes);
     if (p.image_passes < 1) p.image_passes = 1;
     if (p.image_passes > kMaxImagePasses)
@@ -1389,7 +1394,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   std::string ag = "Aggs<";
   for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
   ag += ">";
-  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_image ? "2" : p.acc_lds ? "1" : "0") + (p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
+  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_part ? "3" : p.acc_image ? "2" : p.acc_lds ? "1" : "0") + (p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
   return LLKV_OK;
 }
 

@@ -84,6 +84,7 @@ struct LoweredPlan {
   bool track_first = false; // lane [1] = first row id of the group (first-appearance order)
   bool acc_lds = false;     // accumulators in per-thread LDS slots (grouped plans)
   bool acc_image = false;   // ONE accumulator image per workgroup in LDS, shared by its threads (hundreds … thousands of groups)
+  bool acc_part = false;    // the shared-image lowering for the partitioned route (group_part.cpp): up to 2^24 dense groups, no LDS bound
   int image_passes = 1;     // … the groups cut into this many slices, one scan of the table each
   // shared-image plans: the kernel's image has k_image lanes per group; the fold expands them into the k lanes of the
   // exchange image — exchange lane j of a group = xf(kernel lane image_src[j]): 0 as is, 1 low 32 bits, 2 high part (>> 32)
@@ -121,7 +122,7 @@ double parse_numeric_or_zero(const std::string &s);
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
                const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first,
-               LoweredPlan *out, std::string *err, bool image = false);
+               LoweredPlan *out, std::string *err, bool image = false, bool partitioned = false);
 
 // Predicate only → "SelPlan<Cols<…>,pred>" (selection-vector kernels, select.hip.h).
 // `drop_null_fields`: GatherNullPolicy::DropNulls — rows whose listed fields are ALL NULL are not selected.

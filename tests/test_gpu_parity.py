@@ -751,6 +751,53 @@ def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeyp
     assert kinds[0][0] in ("InvalidArgumentError", "Unsupported")
 
 
+@pytest.mark.parametrize("route", ["partitioned", "sort"])
+@pytest.mark.parametrize("chunks", [[17], [70001, 33000, 5]])
+def test_partitioned_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeypatch):
+    """More dense groups than LDS-sized slices cover (here up to 1.2 M group ids: statistics-bounded integer keys, one or
+    two of them, one with NULL cells): the partitioned route — count pass, scan, scatter pass, one LDS image per
+    partition — returns the groups of the oracle in first-appearance order, integers exactly, f64 sums within 1e-9;
+    with LLKV_HIP_GROUP_NO_PART=1 the sort-based route answers the same."""
+    if route == "sort":
+        monkeypatch.setenv("LLKV_HIP_GROUP_NO_PART", "1")
+    rng = np.random.default_rng(41 + len(chunks))
+    n = sum(chunks)
+    k_big = rng.integers(-100_000, 200_000, size=n).astype(np.int64)      # 300 000 possible groups
+    k_mid = rng.integers(0, 2_000, size=n).astype(np.int64)
+    k_day = rng.integers(9000, 9600, size=n).astype(np.int32)              # × 2 000 = 1.2 M group ids
+    i64 = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    f64 = rng.integers(1, 400_000, size=n).astype(np.float64) / 100
+    g64 = rng.standard_normal(n) * 1e3
+    vk, va = rng.random(n) > 0.1, rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, k_big), (2, abi.DT_INT64, k_mid, vk), (3, abi.DT_DATE32, k_day), (5, abi.DT_INT64, i64, va),
+                                       (6, abi.DT_FLOAT64, f64), (7, abi.DT_FLOAT64, g64)], chunks)
+    A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+    narrow = [A.count_star(), A.sum(5), A.sum(6)]
+    wide = [A.count_star(), A.count(5), A.sum(5), A.avg(5), A.min(5), A.max(5), A.total(5), A.sum(6), A.avg(6), A.min(7), A.max(7), A.sum(col(6) * (10000 - col(6))),
+            A.sum(7)]
+    for keys, aggs in (([1], narrow), ([1], wide), ([2, 3], narrow), ([3, 2], wide)):
+        for pred in (None, [F(5, O.GreaterThan(-500))]):
+            pq = rt.PreparedQuery(ht, pred, aggs, keys, False)
+            note = pq.route_note
+            pq.close()
+            assert note.startswith(route), note
+            got, exp = rt.groupby(ht, pred, keys, aggs, False), orc.groupby(ot, pred, keys, aggs, False)
+            assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp], (keys, route)
+            for g, w in zip(got, exp):
+                assert_values(g.values, w.values, f"{route} group by {keys}")
+    assert rt.groupby(ht, [F(5, O.GreaterThan(10**6))], [1], wide, False) == []
+    # ORDER BY the keys: integer keys without NULL cells keep the route (group ids sort like the keys), a key with NULL
+    # cells (NULLS FIRST) goes to the sort-based route
+    for keys, want in (([1], route), ([2, 3], "sort")):
+        pq = rt.PreparedQuery(ht, None, narrow, keys, True)
+        assert pq.route_note.startswith(want), pq.route_note
+        pq.close()
+        got, exp = rt.groupby(ht, None, keys, narrow, True), orc.groupby(ot, None, keys, narrow, True)
+        assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp], (keys, route)
+        for g, w in zip(got, exp):
+            assert_values(g.values, w.values, f"{route} group by {keys} in key order")
+
+
 @pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5], [65536, 30000]])
 def test_aggregates_over_utf8_and_boolean_inputs_coerce_like_the_reference(rt, orc, abi, chunks):
     """SQLite-style coercion of aggregate inputs (validate_aggregate_type llkv-executor/src/lib.rs:5946-5988 →

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Sort-based GROUP BY at SF10 on one GPU: GROUP BY l_orderkey (≈15 M groups), l_partkey (2 M groups),
-l_shipdate (≈2500 groups) and the wide-state Q1 shape with every aggregate doubled — inputs resident in HBM."""
+"""GROUP BY at SF10 on one GPU beyond the per-thread accumulators: l_orderkey (≈15 M groups: sort-based route), l_partkey
+(2 M groups: partitioned route), l_shipdate (≈2500 groups: shared-image kernel) and the wide-state Q1 shape with every
+aggregate doubled — inputs resident in HBM."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
