@@ -128,7 +128,7 @@ hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, 
     if (e != hipSuccess) return e;
     raised = true;
   }
-  PartReduceParams f{offsets, records, out, lane_ops, lane_src, lane_xf, n_tiles, ngs, ng, kl, k};
+  PartReduceParams f{offsets, records, out, lane_ops, lane_src, lane_xf, n_tiles, np, ngs, ng, kl, k};
   hipLaunchKernelGGL(part_reduce_kernel, dim3(np), dim3(1024), lds, stream, f);
   return hipGetLastError();
 }

@@ -1118,53 +1118,19 @@ template <class P> __device__ __forceinline__ void image_scan_body(const ScanPar
 // The sort-based route orders all selected rows by key (radix passes) and then gathers the argument columns at random:
 // 9.5 ms for 60 M rows in 2 M groups.  Accumulating into one image in HBM is no better: device-scope atomics run at
 // 23.5 × 10⁹ / s whatever the image size (tools/micro/global_atomics.hip).  Here the rows are cut by group-id range
-// into partitions whose image fits the LDS: a count pass (rows per (tile, partition)), one scan, a scatter pass that
-// writes each selected row's (group within partition, lane contributions) at its exact position — no global atomics,
-// the positions inside a (tile, partition) cell are handed out by an LDS counter — and one workgroup per partition
-// then reduces its records in an LDS image (catalog.hip: part_reduce_kernel).  Every lane op is order-free (the
-// shared-image lowering), so the order inside a cell is immaterial.
+// into partitions whose image fits the LDS: every tile of 32 768 rows is put in partition order (part_scatter_body: a
+// count sweep, a workgroup scan, a scatter sweep that writes each selected row's (group within partition, lane
+// contributions) at its exact position — no global atomics), and one workgroup per partition then reduces its cells
+// of all the tiles in an LDS image (part_reduce_kernel).  Every lane op is order-free (the shared-image lowering), so
+// the order inside a cell is immaterial.
 constexpr int kMaxParts = 4096;
 constexpr int kPartTileRows = 32768; // rows of one (tile, partition) cell's tile: ≥ 8 rows per cell at 4 096 partitions
 constexpr int kPartStageLanes = 7;   // records of up to 7 words are sorted by partition in the LDS before they leave (152 KB of LDS)
 
-// Count pass: rows of the tile per partition.
-template <class P> __device__ __forceinline__ void part_count_body(const ScanParams &p) {
-  __shared__ uint32_t cell[kMaxParts];
-  const uint32_t tid = threadIdx.x, tile = blockIdx.x, np = p.part_np;
-  const TileDesc td = load_tile_desc(p.tiles, tile);
-  for (uint32_t i = tid; i < np; i += kImgBlock) cell[i] = 0u;
-  __syncthreads();
-  uint32_t err = 0;
-  const uint32_t nsteps = (td.rows + kImgStepRows - 1) / kImgStepRows;
-  auto rows_of = [&](uint32_t s, const Loaded &ld) {
-    const uint32_t row0 = s * kImgStepRows + tid * kRowsPerThread;
-#pragma unroll
-    for (int j = 0; j < kRowsPerThread; ++j) {
-      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
-      const bool in_tile = (row0 + j) < td.rows;
-      const uint32_t gid = P::KeyT::gid(c, j);
-      const bool pass = in_tile & (gid < (uint32_t)P::NG) & P::Pred::eval(c, j);
-      err |= in_tile ? c.perr : 0u;
-      if (pass) (void)__hip_atomic_fetch_add(&cell[gid >> p.part_shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  };
-  uint32_t s = 0;
-  for (; s + 1 < nsteps; s += 2) { // two steps of loads in flight
-    Loaded a, b;
-    load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
-    load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + 1) * kImgStepRows + (uint64_t)tid * kRowsPerThread, b);
-    rows_of(s, a);
-    rows_of(s + 1, b);
-  }
-  if (s < nsteps) {
-    Loaded a;
-    load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
-    rows_of(s, a);
-  }
-  if (err) atomicOr(p.part_err, err);
-  __syncthreads();
-  for (uint32_t i = tid; i < np; i += kImgBlock) p.part_hist[(uint64_t)i * p.n_tiles + tile] = cell[i];
-}
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load and store
+// of the wave (s_waitcnt vmcnt(0)) — with six barriers per 2 048-row step that drained the prefetched loads of the next
+// step and the record stores of this one at every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Exclusive scan of cnt[0 .. 4·1024) in place by the 1 024 threads of the workgroup (four entries each); returns the total.
 __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wave_sum /*[16]*/) {
@@ -1179,7 +1145,7 @@ __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wav
     incl += lane >= (uint32_t)off ? o : 0u;
   }
   if (lane == 63) wave_sum[wave] = incl;
-  __syncthreads();
+  lds_barrier();
   uint32_t before = 0, total = 0;
 #pragma unroll
   for (int w = 0; w < 16; ++w) {
@@ -1189,19 +1155,26 @@ __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wav
   }
   const uint32_t ex = before + incl - mine;
   *reinterpret_cast<uint4 *>(cnt + 4 * tid) = uint4{ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z};
-  __syncthreads();
+  lds_barrier();
   return total;
 }
 
-// Scatter pass.  A record = K words: [0] the group within the partition (lane 0 counts rows: nothing to carry), [l] lane l;
-// the records of a (tile, partition) cell are ONE contiguous stream (a column per lane kept K × partitions lines open
-// per workgroup: 3.6 ms for 60 M rows).  Writing each record from the thread that made it still sends the 64 lanes of
-// every store to 64 different lines (2.2 ms); so the 2 048 records of a step are first put in partition order in the
-// LDS — a counter per partition ranks them, a scan places the partitions — and leave as runs of consecutive words.
+// One workgroup per tile, two sweeps over its rows (the second finds the columns in the L2).
+//   sweep 1: rows of the tile per partition (predicate + keys) → a workgroup scan → where each partition's cell of this
+//            tile starts.  The cells of a tile are neighbours: tile t owns the records [t·32 768, (t + 1)·32 768) and
+//            lays its cells out in partition order inside — a workgroup writes into one 1.3 MB window instead of into
+//            every partition's region of the whole record array (489 cells spread over 2.4 GB: the translation misses
+//            of a wide radix fan-out made that scatter 1.74 ms for 60 M rows), and no global scan is needed.  The
+//            cell table [tile][partition] goes to global memory for the reduction.
+//   sweep 2: a record = K words: [0] the group within the partition (lane 0 counts rows: nothing to carry), [l] lane l.
+//            Writing each record from the thread that made it sends the 64 lanes of every store to 64 different lines;
+//            so the 2 048 records of a step are first put in partition order in the LDS — a counter per partition ranks
+//            them, a scan places the partitions — and leave as runs of consecutive words (records of ≤ 7 words; wider
+//            ones go straight from their thread).
 template <class P> __device__ __forceinline__ void part_scatter_body(const ScanParams &p) {
   constexpr int K = P::K;
   constexpr bool STAGED = K <= kPartStageLanes;
-  __shared__ uint32_t cell[kMaxParts];                       // next record position of each partition's cell of this tile
+  __shared__ __attribute__((aligned(16))) uint32_t cell[kMaxParts];  // next record position of each partition's cell of this tile
   __shared__ __attribute__((aligned(16))) uint32_t scnt[STAGED ? kMaxParts : 4]; // the step's records per partition → where they start in `stage`
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t dest[STAGED ? kImgStepRows : 1];       // record position of each staged slot
@@ -1209,14 +1182,53 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
   const uint32_t tid = threadIdx.x, tile = blockIdx.x, np = p.part_np;
   const TileDesc td = load_tile_desc(p.tiles, tile);
   for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += kImgBlock) {
-    cell[i] = i < np ? p.part_offsets[(uint64_t)i * p.n_tiles + tile] : 0u;
+    cell[i] = 0u;
     if constexpr (STAGED) scnt[i] = 0u;
   }
-  __syncthreads();
+  lds_barrier();
   uint32_t err = 0;
   const uint32_t mask = (1u << p.part_shift) - 1u;
   const uint32_t nsteps = (td.rows + kImgStepRows - 1) / kImgStepRows;
-  auto rows_of = [&](uint32_t s, const Loaded &ld) {
+  auto each_step = [&](auto &&rows_of) { // two steps of loads in flight
+    uint32_t s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+      Loaded a, b;
+      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
+      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + 1) * kImgStepRows + (uint64_t)tid * kRowsPerThread, b);
+      rows_of(s, a);
+      rows_of(s + 1, b);
+    }
+    if (s < nsteps) {
+      Loaded a;
+      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
+      rows_of(s, a);
+    }
+  };
+  // ---- sweep 1 ------------------------------------------------------------------------------------------------------
+  each_step([&](uint32_t s, const Loaded &ld) {
+    const uint32_t row0 = s * kImgStepRows + tid * kRowsPerThread;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      Ctx c{p, ld, 0u, td.logical_row + row0 + j};
+      const bool in_tile = (row0 + j) < td.rows;
+      const uint32_t gid = P::KeyT::gid(c, j);
+      const bool pass = in_tile & (gid < (uint32_t)P::NG) & P::Pred::eval(c, j);
+      if (pass) (void)__hip_atomic_fetch_add(&cell[gid >> p.part_shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  });
+  lds_barrier();
+  const uint32_t tile_rows = part_block_scan(cell, wave_sum);
+  const uint32_t tile_base = tile * (uint32_t)kPartTileRows;
+  uint32_t *cells_out = p.part_hist + (uint64_t)tile * (np + 1);
+  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += kImgBlock) {
+    const uint32_t at = tile_base + cell[i];
+    cell[i] = at;
+    if (i < np) cells_out[i] = at;
+  }
+  if (tid == 0) cells_out[np] = tile_base + tile_rows;
+  lds_barrier();
+  // ---- sweep 2 ------------------------------------------------------------------------------------------------------
+  each_step([&](uint32_t s, const Loaded &ld) {
     const uint32_t row0 = s * kImgStepRows + tid * kRowsPerThread;
     uint64_t contrib[kRowsPerThread][K];
     uint32_t part[kRowsPerThread], rank[kRowsPerThread];
@@ -1235,7 +1247,7 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
       rank[j] = 0;
       if (pass[j]) rank[j] = __hip_atomic_fetch_add(STAGED ? &scnt[part[j]] : &cell[part[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if constexpr (!STAGED) { // wide records: straight from the thread that made them
+    if constexpr (!STAGED) {
 #pragma unroll
       for (int j = 0; j < kRowsPerThread; ++j) {
         if (!pass[j]) continue;
@@ -1244,7 +1256,7 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
         for (int l = 0; l < K; ++l) rec[l] = contrib[j][l];
       }
     } else {
-      __syncthreads();
+      lds_barrier();
       const uint32_t total = part_block_scan(scnt, wave_sum); // scnt: records per partition → first slot of each partition
 #pragma unroll
       for (int j = 0; j < kRowsPerThread; ++j) {
@@ -1254,84 +1266,81 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
 #pragma unroll
         for (int l = 0; l < K; ++l) stage[slot * K + l] = contrib[j][l];
       }
-      __syncthreads();
+      lds_barrier();
       // the cells advance by what the step put into them; the staged words leave in order
       for (uint32_t i = tid; i < np; i += kImgBlock) cell[i] += (i + 1 < (uint32_t)kMaxParts ? scnt[i + 1] : total) - scnt[i];
       for (uint32_t w = tid; w < total * K; w += kImgBlock) {
         const uint32_t slot = w / K, l = w - slot * K;
-        p.part_val[(uint64_t)dest[slot] * K + l] = stage[w];
+        p.part_val[(uint64_t)dest[slot] * K + l] = stage[w]; // (a non-temporal store here: 2.8 ms instead of 1.8 — the L2 merges the runs into lines)
       }
-      __syncthreads();
+      lds_barrier();
       for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += kImgBlock) scnt[i] = 0u;
-      __syncthreads();
+      lds_barrier();
     }
-  };
-  uint32_t s = 0;
-  for (; s + 1 < nsteps; s += 2) { // two steps of loads in flight
-    Loaded a, b;
-    load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
-    load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + 1) * kImgStepRows + (uint64_t)tid * kRowsPerThread, b);
-    rows_of(s, a);
-    rows_of(s + 1, b);
-  }
-  if (s < nsteps) {
-    Loaded a;
-    load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
-    rows_of(s, a);
-  }
+  });
   if (err) atomicOr(p.part_err, err);
 }
 
-// One workgroup per partition: records [begin, end) → LDS image [kernel lane][group of the partition] → rows of the
+// One workgroup per partition: its cell of every tile → LDS image [kernel lane][group of the partition] → rows of the
 // group-major result [group][exchange lane] (the layout finalize_value reads; a fixed-point sum is one lane in the
 // image, low 32 bits + high part in the result: lane_src / lane_xf as in image_fold_kernel).
 struct PartReduceParams {
-  const uint32_t *offsets; // [np · n_tiles + 1]
+  const uint32_t *offsets; // [n_tiles][np + 1]: where the cell of (tile, partition) starts; [np]: where the tile's records end
   const uint64_t *val;     // records of kl words: [0] group within the partition, [l] kernel lane l
   uint64_t *out;           // [ng][k]
   const uint8_t *lane_ops; // [kl] ops of the kernel lanes
   const uint8_t *lane_src, *lane_xf; // [k]
-  uint32_t n_tiles, ngs, ng, kl, k;
+  uint32_t n_tiles, np, ngs, ng, kl, k;
 };
 __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParams f) {
   extern __shared__ uint64_t part_img[]; // [kl][ngs]
-  const uint32_t tid = threadIdx.x, part = blockIdx.x;
-  const uint32_t begin = f.offsets[(uint64_t)part * f.n_tiles], end = f.offsets[(uint64_t)(part + 1) * f.n_tiles];
+  const uint32_t tid = threadIdx.x, part = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < f.kl * f.ngs; i += 1024) part_img[i] = lane_identity((int)f.lane_ops[i / f.ngs]);
   __syncthreads();
-  // the records as a flat array of words: consecutive threads read consecutive words (a thread per record read with a
-  // stride of kl words: 1.0 ms for 60 M records of 5 words, against 0.46 ms for the same bytes read in order); the
-  // group of a word's record is word 0 of that record — the same or the neighbouring cache line
-  constexpr int kU = 4; // words per thread in flight
-  const uint64_t w_begin = (uint64_t)begin * f.kl, w_end = (uint64_t)end * f.kl;
-  const uint32_t l_step = 1024u % f.kl; // a thread's words are 1 024 apart: the lane of its next word, without a division
-  uint32_t l_next = tid % f.kl;
-  for (uint64_t w0 = w_begin; w0 < w_end; w0 += 1024 * kU) {
-    uint64_t v[kU];
-    uint32_t g[kU], l[kU];
-    bool live[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const uint64_t w = w0 + (uint64_t)u * 1024 + tid;
-      live[u] = w < w_end;
-      l[u] = l_next;
-      l_next += l_step;
-      l_next -= l_next >= f.kl ? f.kl : 0u;
-      v[u] = live[u] ? f.val[w] : 0;
-      g[u] = live[u] ? (uint32_t)f.val[w - l[u]] : 0u;
+  // a wave per (tile, partition) cell, its words read in order (a thread per record read with a stride of kl words:
+  // 1.0 ms for 60 M records of 5 words, against 0.46 ms for the same bytes read in order); the group of a word's record
+  // is word 0 of that record — the same or the neighbouring cache line.  Four cells in flight per wave.
+  auto words_of = [&](uint32_t t, uint64_t *w_begin, uint32_t *n_words) {
+    const uint32_t *cells = f.offsets + (uint64_t)t * (f.np + 1) + part;
+    const uint32_t b = cells[0], e = cells[1];
+    *w_begin = (uint64_t)b * f.kl;
+    *n_words = (e - b) * f.kl;
+  };
+  auto accumulate = [&](uint32_t l, uint32_t g, uint64_t v) {
+    uint64_t *slot = part_img + (uint64_t)l * f.ngs + g;
+    if (l == 0) { lds_accumulate<OP_ADD_I64>(slot, 1); return; }
+    switch ((int)f.lane_ops[l]) {
+    case OP_ADD_F64: lds_accumulate<OP_ADD_F64>(slot, v); break;
+    case OP_ADD_I64: lds_accumulate<OP_ADD_I64>(slot, v); break;
+    case OP_MIN_I64: lds_accumulate<OP_MIN_I64>(slot, v); break;
+    case OP_MAX_I64: lds_accumulate<OP_MAX_I64>(slot, v); break;
+    default: lds_accumulate<OP_MAX_U64>(slot, v); break;
     }
+  };
+  constexpr int kC = 4; // cells in flight per wave
+  for (uint32_t t = wave; t < f.n_tiles; t += 16 * kC) {
+    uint64_t wb[kC];
+    uint32_t nw[kC], n_max = 0;
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      if (!live[u]) continue;
-      uint64_t *slot = part_img + (uint64_t)l[u] * f.ngs + g[u];
-      if (l[u] == 0) { lds_accumulate<OP_ADD_I64>(slot, 1); continue; }
-      switch ((int)f.lane_ops[l[u]]) {
-      case OP_ADD_F64: lds_accumulate<OP_ADD_F64>(slot, v[u]); break;
-      case OP_ADD_I64: lds_accumulate<OP_ADD_I64>(slot, v[u]); break;
-      case OP_MIN_I64: lds_accumulate<OP_MIN_I64>(slot, v[u]); break;
-      case OP_MAX_I64: lds_accumulate<OP_MAX_I64>(slot, v[u]); break;
-      default: lds_accumulate<OP_MAX_U64>(slot, v[u]); break;
+    for (int c = 0; c < kC; ++c) {
+      wb[c] = 0;
+      nw[c] = 0;
+      if (t + 16 * c < f.n_tiles) words_of(t + 16 * c, &wb[c], &nw[c]);
+      n_max = nw[c] > n_max ? nw[c] : n_max;
+    }
+    for (uint32_t i = lane; i < n_max; i += 64) {
+      const uint32_t l = i % f.kl;
+      uint64_t v[kC];
+      uint32_t g[kC];
+#pragma unroll
+      for (int c = 0; c < kC; ++c) {
+        const bool live = i < nw[c];
+        v[c] = live ? f.val[wb[c] + i] : 0;
+        g[c] = live ? (uint32_t)f.val[wb[c] + i - l] : 0u;
       }
+#pragma unroll
+      for (int c = 0; c < kC; ++c)
+        if (i < nw[c]) accumulate(l, g[c], v[c]);
     }
   }
   __syncthreads();

@@ -1,14 +1,15 @@
 // group_part.cpp — partitioned GROUP BY: more dense groups than a few LDS-sized slices cover (tens of thousands …
 // 2^24), every lane order-free (the shared-image lowering: integer adds, min / max, f64 sums on exact grids).
-//   count pass   part_count_body     rows per (tile of 32 768 rows, partition of 2^shift consecutive group ids)
-//   scan         rocPRIM               exclusive, partition-major: where each (partition, tile) cell starts
-//   scatter pass part_scatter_body   every selected row's record (group within the partition, lane contributions) at
-//                                      its position (an LDS counter per cell hands them out: no global atomics)
-//   reduce       part_reduce_kernel    one workgroup per partition: its records → an LDS image → rows [group][lane]
-//   groups       rocPRIM select + sort the groups that have rows, in first-appearance order (lane 1 = the smallest row
-//                                      id, llkv-executor/src/lib.rs:5065-5089); their lanes and decoded key cells
+//   scatter  part_scatter_body   one workgroup per tile of 32 768 rows: rows per partition (2^shift consecutive group
+//                                ids) → workgroup scan → every selected row's record (group within the partition, lane
+//                                contributions) at its position inside the tile's own window of the record array, the
+//                                tile's cells in partition order; the cell table [tile][partition] for the reduction
+//   reduce   part_reduce_kernel  one workgroup per partition: its cell of every tile → an LDS image → rows [group][lane]
+//   groups   rocPRIM select + sort  the groups that have rows, in first-appearance order (lane 1 = the smallest row id,
+//                                llkv-executor/src/lib.rs:5065-5089) or key order; their lanes and decoded key cells
 // Against the sort-based route (group_sort.cpp) for 60 M rows in 2 M groups: no radix passes over all the rows and no
-// random gathers of the argument columns — the columns are streamed twice and the records once.
+// random gathers of the argument columns — the columns are streamed (the second sweep of a tile finds them in the L2)
+// and the records written and read once.  No global atomics and no global scan.
 // The result is handed over like the sort-based route's (LazyGroups: cells are finalized on request).
 #include "catalog.hpp"
 #include "engine.hpp"
@@ -155,14 +156,14 @@ int PartGroupBy::run(LazyGroups *out) {
   const TileSet *ts = nullptr;
   if ((rc = get_tileset(*table, kPartTileRowsHost, &ts))) return rc;
   const uint32_t n_tiles = ts->n_tiles;
-  const uint64_t cells = (uint64_t)np * n_tiles + 1; // + the total
-  const uint64_t cap = table->local_rows;
-  Scratch hist, offs, tmp, flags, rec_val, group_rows, ids;
-  if ((rc = hist.alloc(cells * 4)) || (rc = offs.alloc(cells * 4)) || (rc = flags.alloc(16)) ||
-      (rc = rec_val.alloc((uint64_t)kl * cap * 8)) || (rc = group_rows.alloc((uint64_t)ng * k * 8)) || (rc = ids.alloc((uint64_t)ng * 4)))
+  const uint64_t cells = (uint64_t)n_tiles * (np + 1);
+  const uint64_t cap = (uint64_t)n_tiles * kPartTileRowsHost; // tile t owns the records [t · 32 768, (t + 1) · 32 768)
+  if (cap >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 record positions");
+  Scratch cell_table, flags, rec_val, group_rows, ids;
+  if ((rc = cell_table.alloc(cells * 4)) || (rc = flags.alloc(16)) || (rc = rec_val.alloc((uint64_t)kl * cap * 8)) || (rc = group_rows.alloc((uint64_t)ng * k * 8)) ||
+      (rc = ids.alloc((uint64_t)ng * 4)))
     return rc;
-  HIP_TRY(hipMemsetAsync(hist.as<uint32_t>() + (cells - 1), 0, 4, s)); // (every other cell is written by the count pass)
-  HIP_TRY(hipMemsetAsync(flags.p, 0, 16, s));                         // [0] error codes, [1] number of groups
+  HIP_TRY(hipMemsetAsync(flags.p, 0, 16, s)); // [0] error codes, [1] number of groups
   ScanParams sp;
   std::memset(&sp, 0, sizeof sp);
   for (size_t i = 0; i < p.slot_fields.size(); ++i) sp.col[i] = slot_buffer(table->cols, p, i);
@@ -172,24 +173,14 @@ int PartGroupBy::run(LazyGroups *out) {
   sp.dict_num = d_dict_num;
   sp.tiles = ts->d_tiles;
   sp.n_tiles = n_tiles;
-  sp.part_hist = hist.as<uint32_t>();
-  sp.part_offsets = offs.as<uint32_t>();
+  sp.part_hist = cell_table.as<uint32_t>();
   sp.part_val = rec_val.as<uint64_t>();
   sp.part_shift = shift;
   sp.part_np = np;
   sp.part_err = flags.as<uint32_t>();
   if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, 1024))) return rc;
-  mark("count pass");
-  {
-    size_t tb = 0;
-    HIP_TRY(hj_exclusive_scan_u32(nullptr, &tb, hist.as<uint32_t>(), offs.as<uint32_t>(), cells, s));
-    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
-    HIP_TRY(hj_exclusive_scan_u32(tmp.p, &tb, hist.as<uint32_t>(), offs.as<uint32_t>(), cells, s));
-  }
-  mark("scan");
-  if ((rc = jit_launch_raw(kernel.fn2, n_tiles, &sp, sizeof sp, s, 1024))) return rc;
-  mark("scatter pass");
-  HIP_TRY(launch_part_reduce(offs.as<uint32_t>(), rec_val.as<uint64_t>(), group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
+  mark("scatter");
+  HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
                              d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s));
   mark("partition reduce");
   // ---- the groups that have rows, in first-appearance order --------------------------------------------------------

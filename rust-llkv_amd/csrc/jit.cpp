@@ -37,9 +37,8 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { image_scan_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Part:
-    // a = rows per (tile, partition), b = the records at their exact positions (1 024 threads)
-    s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { part_count_body<" + ts + ">(p); }\n";
-    s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_b(const ScanParams p) { part_scatter_body<" + ts + ">(p); }\n";
+    // every tile's records in partition order (1 024 threads)
+    s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { part_scatter_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Select:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { select_body<" + ts + ", false>(p); }\n";
@@ -146,7 +145,7 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   const std::string dir = cache_dir();
   const bool cacheable = private_dir(dir);
   const std::string path = dir + "/" + hex + ".hsaco";
-  const bool two = kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit || kind == JitKind::Reduce || kind == JitKind::Part;
+  const bool two = kind == JitKind::Select || kind == JitKind::Probe || kind == JitKind::Emit || kind == JitKind::Reduce;
   JitKernel k;
   auto load = [&](const std::vector<char> &code, std::string *why) -> bool {
     k = JitKernel{};
@@ -212,7 +211,7 @@ extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out,
   int kind = 0;
   std::string ts = type_string;
   if (ts.rfind("keybits:", 0) == 0) { kind = 7; ts = ts.substr(8); } // an EmitPlan compiled as the key-bits scan
-  else if (ts.rfind("part:", 0) == 0) { kind = 8; ts = ts.substr(5); } // a shared-image lowering compiled as the partitioned GROUP BY's two passes
+  else if (ts.rfind("part:", 0) == 0) { kind = 8; ts = ts.substr(5); } // a shared-image lowering compiled as the partitioned GROUP BY's scatter
   else if (ts.rfind("SelPlan<", 0) == 0) kind = 1;
   else if (ts.rfind("ProjPlan<", 0) == 0) kind = 2;
   else if (ts.rfind("ProbePlan<", 0) == 0) kind = 3;

@@ -96,11 +96,11 @@ struct ScanParams {
   // numeric image of dictionary-coded Utf8 aggregate inputs (SQLite-style coercion, llkv-aggregate/src/lib.rs:400-449):
   // dict_num[slot · 256 + code] = the string parsed as f64, 0.0 when it is not a number
   const double *dict_num;
-  // partitioned GROUP BY (group_part.cpp; fused_scan.hip.h: part_count_body / part_scatter_body): the selected rows are cut into partitions of
-  // 2^part_shift consecutive group ids — a count pass, a scan, a scatter pass — and every partition is then reduced
-  // in an LDS image of its own
-  uint32_t *part_hist;          // count pass: [partition][tile] rows
-  const uint32_t *part_offsets; // scatter pass: the exclusive scan of part_hist, same order
+  // partitioned GROUP BY (group_part.cpp; fused_scan.hip.h: part_scatter_body): every tile of 32 768 rows is put in
+  // partition order (a partition = 2^part_shift consecutive group ids), and every partition is then reduced in an LDS
+  // image of its own
+  uint32_t *part_hist;          // [tile][part_np + 1]: record position where the cell of (tile, partition) starts; [part_np]: where the tile's records end
+  const uint32_t *part_offsets; // (unused)
   uint64_t *part_val;           // record r = K words at part_val[r·K]: [0] group id within the partition (lane 0 counts rows), [l] kernel lane l
   uint32_t part_shift;
   uint32_t part_np;             // partitions (≤ kMaxParts)
