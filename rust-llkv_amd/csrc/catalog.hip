@@ -118,7 +118,7 @@ hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const
   return hipGetLastError();
 }
 
-hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, uint64_t *out, const uint8_t *lane_ops,
+hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, const TileDesc *tiles, uint64_t *out, const uint8_t *lane_ops,
                               const uint8_t *lane_src, const uint8_t *lane_xf, uint32_t n_tiles, uint32_t np, uint32_t ngs, uint32_t ng, uint32_t kl, uint32_t k,
                               hipStream_t stream) {
   const size_t lds = (size_t)kl * ngs * 8;
@@ -128,7 +128,7 @@ hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, 
     if (e != hipSuccess) return e;
     raised = true;
   }
-  PartReduceParams f{offsets, records, out, lane_ops, lane_src, lane_xf, n_tiles, np, ngs, ng, kl, k};
+  PartReduceParams f{offsets, records, tiles, out, lane_ops, lane_src, lane_xf, n_tiles, np, ngs, ng, kl, k};
   hipLaunchKernelGGL(part_reduce_kernel, dim3(np), dim3(1024), lds, stream, f);
   return hipGetLastError();
 }

@@ -1166,13 +1166,15 @@ __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wav
 //            every partition's region of the whole record array (489 cells spread over 2.4 GB: the translation misses
 //            of a wide radix fan-out made that scatter 1.74 ms for 60 M rows), and no global scan is needed.  The
 //            cell table [tile][partition] goes to global memory for the reduction.
-//   sweep 2: a record = K words: [0] the group within the partition (lane 0 counts rows: nothing to carry), [l] lane l.
+//   sweep 2: a record = K − 1 words: [0] the group within the partition and the row's position in the tile (lanes 0
+//            and 1 — rows, smallest row id — need no more), [l − 1] lane l ≥ 2.
 //            Writing each record from the thread that made it sends the 64 lanes of every store to 64 different lines;
 //            so the 2 048 records of a step are first put in partition order in the LDS — a counter per partition ranks
 //            them, a scan places the partitions — and leave as runs of consecutive words (records of ≤ 7 words; wider
 //            ones go straight from their thread).
 template <class P> __device__ __forceinline__ void part_scatter_body(const ScanParams &p) {
-  constexpr int K = P::K;
+  static_assert(P::first, "partitioned plans keep the first row of every group");
+  constexpr int K = P::K - 1; // words of a record: [0] group within the partition | row within the tile << 32, then lanes 2 …
   constexpr bool STAGED = K <= kPartStageLanes;
   __shared__ __attribute__((aligned(16))) uint32_t cell[kMaxParts];  // next record position of each partition's cell of this tile
   __shared__ __attribute__((aligned(16))) uint32_t scnt[STAGED ? kMaxParts : 4]; // the step's records per partition → where they start in `stage`
@@ -1240,9 +1242,10 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
       const uint32_t gid = P::KeyT::gid(c, j);
       pass[j] = in_tile & (gid < (uint32_t)P::NG) & P::Pred::eval(c, j);
       part[j] = pass[j] ? gid >> p.part_shift : 0u;
-      if constexpr (P::first) contrib[j][1] = c.row;
-      AggOps<typename P::AggT>::contrib(c, j, contrib[j] + P::BASE);
-      contrib[j][0] = gid & mask;
+      // lane 0 counts rows and lane 1 is the smallest row id: the row's position inside the tile (15 bits) rides with
+      // the group id, and the reduction — which knows the tile of every cell — adds the tile's first row id
+      AggOps<typename P::AggT>::contrib(c, j, contrib[j] + 1);
+      contrib[j][0] = (uint64_t)(gid & mask) | ((uint64_t)(row0 + j) << 32);
       err |= (pass[j] ? c.err : 0u) | (in_tile ? c.perr : 0u);
       rank[j] = 0;
       if (pass[j]) rank[j] = __hip_atomic_fetch_add(STAGED ? &scnt[part[j]] : &cell[part[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1286,7 +1289,8 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
 // image, low 32 bits + high part in the result: lane_src / lane_xf as in image_fold_kernel).
 struct PartReduceParams {
   const uint32_t *offsets; // [n_tiles][np + 1]: where the cell of (tile, partition) starts; [np]: where the tile's records end
-  const uint64_t *val;     // records of kl words: [0] group within the partition, [l] kernel lane l
+  const uint64_t *val;     // records of kl − 1 words: [0] group within the partition | row within the tile << 32, [l − 1] kernel lane l ≥ 2
+  const TileDesc *tiles;   // (the first row id of every tile)
   uint64_t *out;           // [ng][k]
   const uint8_t *lane_ops; // [kl] ops of the kernel lanes
   const uint8_t *lane_src, *lane_xf; // [k]
@@ -1300,15 +1304,24 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParam
   // a wave per (tile, partition) cell, its words read in order (a thread per record read with a stride of kl words:
   // 1.0 ms for 60 M records of 5 words, against 0.46 ms for the same bytes read in order); the group of a word's record
   // is word 0 of that record — the same or the neighbouring cache line.  Four cells in flight per wave.
-  auto words_of = [&](uint32_t t, uint64_t *w_begin, uint32_t *n_words) {
+  const uint32_t rw = f.kl - 1; // words of a record
+  auto words_of = [&](uint32_t t, uint64_t *w_begin, uint32_t *n_words, uint64_t *first_row) {
     const uint32_t *cells = f.offsets + (uint64_t)t * (f.np + 1) + part;
     const uint32_t b = cells[0], e = cells[1];
-    *w_begin = (uint64_t)b * f.kl;
-    *n_words = (e - b) * f.kl;
+    *w_begin = (uint64_t)b * rw;
+    *n_words = (e - b) * rw;
+    *first_row = f.tiles[t].logical_row;
   };
-  auto accumulate = [&](uint32_t l, uint32_t g, uint64_t v) {
+  // word j of a record, its head word, the tile's first row id
+  auto accumulate = [&](uint32_t j, uint64_t head, uint64_t v, uint64_t tile_row) {
+    const uint32_t g = (uint32_t)head;
+    if (j == 0) { // lanes 0 and 1: one more row; the smallest row id
+      lds_accumulate<OP_ADD_I64>(part_img + g, 1);
+      lds_accumulate<OP_MIN_I64>(part_img + f.ngs + g, tile_row + (head >> 32));
+      return;
+    }
+    const uint32_t l = j + 1;
     uint64_t *slot = part_img + (uint64_t)l * f.ngs + g;
-    if (l == 0) { lds_accumulate<OP_ADD_I64>(slot, 1); return; }
     switch ((int)f.lane_ops[l]) {
     case OP_ADD_F64: lds_accumulate<OP_ADD_F64>(slot, v); break;
     case OP_ADD_I64: lds_accumulate<OP_ADD_I64>(slot, v); break;
@@ -1319,28 +1332,28 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParam
   };
   constexpr int kC = 4; // cells in flight per wave
   for (uint32_t t = wave; t < f.n_tiles; t += 16 * kC) {
-    uint64_t wb[kC];
+    uint64_t wb[kC], row0[kC];
     uint32_t nw[kC], n_max = 0;
 #pragma unroll
     for (int c = 0; c < kC; ++c) {
       wb[c] = 0;
       nw[c] = 0;
-      if (t + 16 * c < f.n_tiles) words_of(t + 16 * c, &wb[c], &nw[c]);
+      row0[c] = 0;
+      if (t + 16 * c < f.n_tiles) words_of(t + 16 * c, &wb[c], &nw[c], &row0[c]);
       n_max = nw[c] > n_max ? nw[c] : n_max;
     }
     for (uint32_t i = lane; i < n_max; i += 64) {
-      const uint32_t l = i % f.kl;
-      uint64_t v[kC];
-      uint32_t g[kC];
+      const uint32_t j = i % rw;
+      uint64_t v[kC], head[kC];
 #pragma unroll
       for (int c = 0; c < kC; ++c) {
         const bool live = i < nw[c];
         v[c] = live ? f.val[wb[c] + i] : 0;
-        g[c] = live ? (uint32_t)f.val[wb[c] + i - l] : 0u;
+        head[c] = live ? f.val[wb[c] + i - j] : 0;
       }
 #pragma unroll
       for (int c = 0; c < kC; ++c)
-        if (i < nw[c]) accumulate(l, g[c], v[c]);
+        if (i < nw[c]) accumulate(j, head[c], v[c], row0[c]);
     }
   }
   __syncthreads();

@@ -160,7 +160,7 @@ int PartGroupBy::run(LazyGroups *out) {
   const uint64_t cap = (uint64_t)n_tiles * kPartTileRowsHost; // tile t owns the records [t · 32 768, (t + 1) · 32 768)
   if (cap >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 record positions");
   Scratch cell_table, flags, rec_val, group_rows, ids;
-  if ((rc = cell_table.alloc(cells * 4)) || (rc = flags.alloc(16)) || (rc = rec_val.alloc((uint64_t)kl * cap * 8)) || (rc = group_rows.alloc((uint64_t)ng * k * 8)) ||
+  if ((rc = cell_table.alloc(cells * 4)) || (rc = flags.alloc(16)) || (rc = rec_val.alloc((uint64_t)(kl - 1) * cap * 8)) || (rc = group_rows.alloc((uint64_t)ng * k * 8)) ||
       (rc = ids.alloc((uint64_t)ng * 4)))
     return rc;
   HIP_TRY(hipMemsetAsync(flags.p, 0, 16, s)); // [0] error codes, [1] number of groups
@@ -180,7 +180,7 @@ int PartGroupBy::run(LazyGroups *out) {
   sp.part_err = flags.as<uint32_t>();
   if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, 1024))) return rc;
   mark("scatter");
-  HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
+  HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), ts->d_tiles, group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
                              d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s));
   mark("partition reduce");
   // ---- the groups that have rows, in first-appearance order --------------------------------------------------------
