@@ -1,8 +1,8 @@
 // group_part.cpp — partitioned GROUP BY: more dense groups than a few LDS-sized slices cover (tens of thousands …
 // 2^24), every lane order-free (the shared-image lowering: integer adds, min / max, f64 sums on exact grids).
 //   scatter  part_scatter_body   one workgroup per tile of 32 768 rows: rows per partition (2^shift consecutive group
-//                                ids) → workgroup scan → every selected row's record (group within the partition, lane
-//                                contributions) at its position inside the tile's own window of the record array, the
+//                                ids) → workgroup scan → every selected row's record (group within the partition | row
+//                                within the tile, lanes 2 …) at its position inside the tile's own window of the record array, the
 //                                tile's cells in partition order; the cell table [tile][partition] for the reduction
 //   reduce   part_reduce_kernel  one workgroup per partition: its cell of every tile → an LDS image → rows [group][lane]
 //   groups   rocPRIM select + sort  the groups that have rows, in first-appearance order (lane 1 = the smallest row id,
