@@ -152,7 +152,7 @@ inline const char *arith_error_message(uint64_t code) {
   return (code & 2u) ? "Divide by zero" : "Arithmetic overflow: Overflow happened in a computed projection";
 }
 
-// Partitioned GROUP BY (group_part.cpp): up to 2^24 dense groups with order-free lanes, one rank.
+// Partitioned GROUP BY (group_part.cpp): up to 2^24 dense groups with order-free lanes.
 struct PartGroupBy;
 int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                          const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool order_by_keys, PartGroupBy **out);

@@ -195,9 +195,9 @@ int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint3
   s->key_fields.assign(key_fields, key_fields + n_keys);
   std::string err;
   int rc;
-  // statistics-bounded keys and order-free lanes (what the shared-image lowering takes), one rank: the partitioned
-  // route — no sort of the rows, no gathers
-  if (table->world == 1 && !std::getenv("LLKV_HIP_GROUP_NO_IMAGE") && !std::getenv("LLKV_HIP_GROUP_NO_PART") &&
+  // statistics-bounded keys and order-free lanes (what the shared-image lowering takes): the partitioned route — no sort
+  // of the rows, no gathers
+  if (!std::getenv("LLKV_HIP_GROUP_NO_IMAGE") && !std::getenv("LLKV_HIP_GROUP_NO_PART") &&
       part_groupby_prepare(table, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, order_by_keys, &s->part) == LLKV_OK) {
     *out = s.release();
     return LLKV_OK;

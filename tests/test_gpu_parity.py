@@ -769,13 +769,14 @@ def test_partitioned_group_by_matches_oracle(rt, orc, abi, chunks, route, monkey
     f64 = rng.integers(1, 400_000, size=n).astype(np.float64) / 100
     g64 = rng.standard_normal(n) * 1e3
     vk, va = rng.random(n) > 0.1, rng.random(n) > 0.2
-    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, k_big), (2, abi.DT_INT64, k_mid, vk), (3, abi.DT_DATE32, k_day), (5, abi.DT_INT64, i64, va),
+    k_tag = [("x", "y", "zz", "")[k] for k in rng.integers(0, 4, size=n)]     # a dictionary-coded key with NULL cells: × 300 001 ids
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, k_big), (2, abi.DT_INT64, k_mid, vk), (3, abi.DT_DATE32, k_day), (4, abi.DT_UTF8, k_tag, va), (5, abi.DT_INT64, i64, va),
                                        (6, abi.DT_FLOAT64, f64), (7, abi.DT_FLOAT64, g64)], chunks)
     A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
     narrow = [A.count_star(), A.sum(5), A.sum(6)]
     wide = [A.count_star(), A.count(5), A.sum(5), A.avg(5), A.min(5), A.max(5), A.total(5), A.sum(6), A.avg(6), A.min(7), A.max(7), A.sum(col(6) * (10000 - col(6))),
             A.sum(7)]
-    for keys, aggs in (([1], narrow), ([1], wide), ([2, 3], narrow), ([3, 2], wide), ([1], narrow[:1])):  # (the last: records of one word)
+    for keys, aggs in (([1], narrow), ([1], wide), ([2, 3], narrow), ([3, 2], wide), ([4, 1], narrow), ([1], narrow[:1])):  # (the last: records of one word)
         for pred in (None, [F(5, O.GreaterThan(-500))]):
             pq = rt.PreparedQuery(ht, pred, aggs, keys, False)
             note = pq.route_note
@@ -2014,6 +2015,54 @@ def test_sort_based_group_by_over_a_sharded_table(rt, abi, order_by_keys, monkey
         for g, w in zip(got_vals, want_vals):
             assert g[0] == w[0] and g[1] == w[1] and g[3] == w[3] and g[4] == w[4], (world, g, w)
             assert abs(g[2] - w[2]) <= REL * max(1.0, abs(w[2])) and abs(g[5] - w[5]) <= 1e-12 * max(1.0, abs(w[5]))
+
+
+@pytest.mark.parametrize("order_by_keys", [True, False])
+def test_partitioned_group_by_over_a_sharded_table(rt, abi, order_by_keys):
+    """The partitioned route over a sharded table (2 / 4 ranks emulated on one device): every rank reduces its own
+    chunks into order-free lanes, the partial groups are merged in rank order like the sort-based route's — keys,
+    order (first appearance across the shards, or key order), counts, sums, MIN / MAX / AVG equal the single-GPU answer."""
+    rng = np.random.default_rng(43)
+    chunks = [6000, 9000, 300, 20_000, 4096, 17_000, 123, 8000]
+    n = sum(chunks)
+    k1 = rng.integers(0, 150_000, size=n).astype(np.int64)
+    q = rng.integers(-100, 100, size=n).astype(np.int64)
+    A = abi.AggregateSpec
+    aggs = [A.count_star(), A.sum(3), A.min(3), A.max(3), A.avg(3)]
+    pred = [abi.Filter(3, abi.Operator.GreaterThan(-90))]
+
+    def shard(rank, world):
+        t = rt.HipTable(1, chunks, rank, world)
+        lo = sum(chunks[:t.first_chunk])
+        hi = lo + t.local_rows
+        t.append_column(1, abi.DT_INT64, k1[lo:hi])
+        t.append_column(3, abi.DT_INT64, q[lo:hi])
+        if world > 1:
+            t.set_column_stats(1, 0, 149_999)
+            t.set_column_stats(3, -100, 99)
+        return t
+
+    def cells(rows):
+        return [tuple(k.value for k in r.keys) for r in rows], [[x.value for x in r.values] for r in rows]
+
+    whole = rt.PreparedQuery(shard(0, 1), pred, aggs, [1], order_by_keys)
+    assert whole.route_note.startswith("partitioned"), whole.route_note
+    want_keys, want_vals = cells(whole.run())
+    assert len(want_keys) > 40_000
+    for world in (2, 4):
+        pqs = [rt.PreparedQuery(shard(r, world), pred, aggs, [1], order_by_keys) for r in range(world)]
+        assert all(pq.route_note.startswith("partitioned") for pq in pqs), pqs[0].route_note
+        parts = []
+        for pq in pqs:
+            pq.launch(0)
+            pq.finish_only()
+            parts.append(pq.partial_groups())
+        assert sum(p[2].shape[0] for p in parts) > len(want_keys)  # groups straddle the shards
+        last = pqs[-1]
+        last.merge_groups(parts)
+        got_keys, got_vals = cells(last.rows())
+        assert got_keys == want_keys, world
+        assert got_vals == want_vals, world
 
 
 def test_distinct_aggregates_over_a_sharded_table(rt, orc, abi):
