@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParam
     default: lds_accumulate<OP_MAX_U64>(slot, v); break;
     }
   };
-  constexpr int kC = 4; // cells in flight per wave
+  constexpr int kC = 4; // cells in flight per wave (eight: 1.04 ms instead of 0.79)
   for (uint32_t t = wave; t < f.n_tiles; t += 16 * kC) {
     uint64_t wb[kC], row0[kC];
     uint32_t nw[kC], n_max = 0;
