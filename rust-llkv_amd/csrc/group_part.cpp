@@ -36,7 +36,9 @@ struct PartGroupBy {
   std::vector<uint32_t> key_fields;
   JitKernel kernel;
   uint32_t ngs = 0, np = 0, shift = 0; // groups per partition (2^shift), partitions
-  bool order_by_keys = false;          // (integer keys without NULL cells only: ascending group ids are ascending keys)
+  bool order_by_keys = false;
+  bool ids_in_key_order = false;       // integer keys without NULL cells: ascending group ids are ascending keys
+  uint32_t *d_code_rank = nullptr;     // [key][256] dictionary code → position in string order (Utf8 keys, ORDER BY the keys)
   double *d_dict_num = nullptr;
   uint8_t *d_lane_tables = nullptr; // [kl] ops of the kernel lanes, [k] source lane, [k] transform
   void *h_lanes = nullptr, *h_kv = nullptr, *h_kvalid = nullptr;
@@ -45,6 +47,7 @@ struct PartGroupBy {
   ~PartGroupBy() {
     scratch_free(d_dict_num);
     scratch_free(d_lane_tables);
+    scratch_free(d_code_rank);
     if (h_lanes) (void)hipHostFree(h_lanes);
     if (h_kv) (void)hipHostFree(h_kv);
     if (h_kvalid) (void)hipHostFree(h_kvalid);
@@ -67,7 +70,7 @@ int pinned_reserve(void **p, size_t *cap, size_t bytes) {
 } // namespace
 
 // Admission: what the shared-image lowering takes (statistics-bounded keys, order-free lanes) with up to 2^24 dense
-// groups; in first-appearance order, or in key order when the group ids sort like the keys.  Over a sharded table every
+// groups; in first-appearance order or in key order.  Over a sharded table every
 // rank reduces its own rows and the partial groups are merged like the sort-based route's (sorted_groupby_merge: the
 // lanes are order-free, lane 1 is a table-wide row id).
 int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
@@ -88,12 +91,12 @@ int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_
   const LoweredPlan &p = g->plan;
   const uint32_t kl = (uint32_t)p.k_image;
   // ORDER BY the keys: the dense group id orders the groups as the keys do when every key is an integer column without
-  // NULL cells (the first key is the most significant digit; a NULL group's code would sort last, a dictionary code
-  // not as its string)
+  // NULL cells (the first key is the most significant digit); a NULL group's code is the key's last (NULLS FIRST wants
+  // it first) and a dictionary code does not sort as its string: those groups are sorted by the id with every digit
+  // replaced by its rank (hj_launch_dense_group_order_keys)
   g->order_by_keys = order_by_keys;
-  if (order_by_keys)
-    for (uint32_t j = 0; j < n_keys; ++j)
-      if (!p.key_is_int[j] || p.key_nullable[j]) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY in key order takes integer keys without NULL cells");
+  g->ids_in_key_order = true;
+  for (uint32_t j = 0; j < n_keys; ++j) g->ids_in_key_order &= p.key_is_int[j] && !p.key_nullable[j];
   // groups per partition: a power of two whose image fits, and small enough that the reduction has a few hundred
   // workgroups to run
   uint32_t shift = 0;
@@ -129,6 +132,21 @@ int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_
   if (!g->d_lane_tables) return set_error(LLKV_INTERNAL, "device allocation failed");
   HIP_TRY(hipMemcpyAsync(g->d_lane_tables, tables.data(), tables.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (order_by_keys && !g->ids_in_key_order) {
+    std::vector<uint32_t> ranks((size_t)n_keys * 256, 0);
+    for (uint32_t j = 0; j < n_keys; ++j) {
+      const ColumnInfo &ci = table->cols.at(key_fields[j]).info;
+      if (ci.dtype != LLKV_DT_UTF8) continue;
+      std::vector<uint32_t> idx(std::min<size_t>(ci.dictionary.size(), 256));
+      for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+      std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return ci.dictionary[a] < ci.dictionary[b]; });
+      for (size_t r = 0; r < idx.size(); ++r) ranks[(size_t)j * 256 + idx[r]] = (uint32_t)r;
+    }
+    g->d_code_rank = (uint32_t *)scratch_alloc(ranks.size() * 4);
+    if (!g->d_code_rank) return set_error(LLKV_INTERNAL, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(g->d_code_rank, ranks.data(), ranks.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   *out = g.release();
   return LLKV_OK;
 }
@@ -201,23 +219,6 @@ int PartGroupBy::run(LazyGroups *out) {
   const uint32_t n_groups = host_flags[1];
   mark("present groups");
   if (n_groups == 0) return LLKV_OK;
-  Scratch first_d, first_s, ord_in, ord_out, tmp3;
-  const uint32_t *order = nullptr;
-  if (n_groups > 1 && !order_by_keys) {
-    if ((rc = first_d.alloc((uint64_t)n_groups * 8)) || (rc = first_s.alloc((uint64_t)n_groups * 8)) || (rc = ord_in.alloc((uint64_t)n_groups * 4)) ||
-        (rc = ord_out.alloc((uint64_t)n_groups * 4)))
-      return rc;
-    HIP_TRY(hj_launch_gather_lane(group_rows.as<uint64_t>(), k, 1, ids.as<uint32_t>(), n_groups, first_d.as<uint64_t>(), s));
-    HIP_TRY(hj_launch_iota(ord_in.as<uint32_t>(), n_groups, s));
-    uint32_t bits = 1;
-    while (bits < 64 && (table->total_rows >> bits) != 0) ++bits;
-    size_t tb = 0;
-    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
-    if ((rc = tmp3.alloc(tb ? tb : 8))) return rc;
-    HIP_TRY(hj_sort_u64_u32_bits(tmp3.p, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
-    order = ord_out.as<uint32_t>();
-  }
-  mark("output order");
   DenseKeyLayout kl_keys;
   std::memset(&kl_keys, 0, sizeof kl_keys);
   kl_keys.n = n_keys;
@@ -226,7 +227,30 @@ int PartGroupBy::run(LazyGroups *out) {
     kl_keys.card[j] = p.key_cards[j];
     kl_keys.nullable[j] = p.key_nullable[j];
     kl_keys.base[j] = p.key_bases[j];
+    kl_keys.code_rank[j] = d_code_rank && !p.key_is_int[j] ? d_code_rank + (size_t)j * 256 : nullptr;
   }
+  Scratch first_d, first_s, ord_in, ord_out, tmp3;
+  const uint32_t *order = nullptr;
+  if (n_groups > 1 && !(order_by_keys && ids_in_key_order)) {
+    if ((rc = first_d.alloc((uint64_t)n_groups * 8)) || (rc = first_s.alloc((uint64_t)n_groups * 8)) || (rc = ord_in.alloc((uint64_t)n_groups * 4)) ||
+        (rc = ord_out.alloc((uint64_t)n_groups * 4)))
+      return rc;
+    uint32_t bits = 1;
+    if (order_by_keys) { // by the keys: NULLS FIRST, strings by their bytes
+      HIP_TRY(hj_launch_dense_group_order_keys(ids.as<uint32_t>(), n_groups, kl_keys, first_d.as<uint64_t>(), s));
+      while (bits < 64 && ((uint64_t)ng >> bits) != 0) ++bits;
+    } else { // first appearance: lane 1 = the smallest row id
+      HIP_TRY(hj_launch_gather_lane(group_rows.as<uint64_t>(), k, 1, ids.as<uint32_t>(), n_groups, first_d.as<uint64_t>(), s));
+      while (bits < 64 && (table->total_rows >> bits) != 0) ++bits;
+    }
+    HIP_TRY(hj_launch_iota(ord_in.as<uint32_t>(), n_groups, s));
+    size_t tb = 0;
+    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
+    if ((rc = tmp3.alloc(tb ? tb : 8))) return rc;
+    HIP_TRY(hj_sort_u64_u32_bits(tmp3.p, &tb, first_d.as<uint64_t>(), first_s.as<uint64_t>(), ord_in.as<uint32_t>(), ord_out.as<uint32_t>(), n_groups, bits, s));
+    order = ord_out.as<uint32_t>();
+  }
+  mark("output order");
   Scratch lanes_d, kv_d, kvalid_d;
   if ((rc = lanes_d.alloc((uint64_t)n_groups * k * 8)) || (rc = kv_d.alloc((uint64_t)n_groups * n_keys * 8)) || (rc = kvalid_d.alloc((uint64_t)n_groups * n_keys))) return rc;
   HIP_TRY(hj_launch_emit_dense_groups(group_rows.as<uint64_t>(), k, ids.as<uint32_t>(), order, n_groups, kl_keys, lanes_d.as<uint64_t>(), kv_d.as<int64_t>(),

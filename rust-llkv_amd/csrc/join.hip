@@ -814,6 +814,26 @@ hipError_t hj_launch_emit_dense_groups(const uint64_t *group_rows, uint32_t k, c
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void hj_dense_group_order_keys_kernel(const uint32_t *ids, uint32_t n, DenseKeyLayout keys, uint64_t *order_keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = ids[i];
+  uint64_t k = 0;
+  for (uint32_t j = 0; j < keys.n; ++j) {
+    uint32_t code = (g / keys.stride[j]) % keys.card[j];
+    const bool is_null = keys.nullable[j] && code == keys.card[j] - 1;
+    if (!is_null && keys.code_rank[j]) code = keys.code_rank[j][code];
+    const uint32_t rank = keys.nullable[j] ? (is_null ? 0u : code + 1u) : code; // NULLS FIRST
+    k += (uint64_t)rank * keys.stride[j];
+  }
+  order_keys[i] = k;
+}
+hipError_t hj_launch_dense_group_order_keys(const uint32_t *ids, uint32_t n, const DenseKeyLayout &keys, uint64_t *order_keys, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_dense_group_order_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, n, keys, order_keys);
+  return hipGetLastError();
+}
+
 // `unsorted` (optional): zero = the list is in key order, rank == list index and nothing is written.  `dup_flag`
 // (optional): raised when the bitmap holds fewer bits than the list has rows (a key occurred twice).
 __global__ __launch_bounds__(256) void hj_bitmap_groups_kernel(JoinKeyColumn key, const uint64_t *dev_rows, uint64_t n, long long kmin,

@@ -266,7 +266,11 @@ struct DenseKeyLayout { // dense group id = Σ code_j · stride_j (plan.hpp: key
   uint32_t n;
   uint32_t stride[4], card[4], nullable[4];
   long long base[4];
+  const uint32_t *code_rank[4]; // ORDER BY the keys: dictionary code → position in string order (Utf8 keys), else nullptr
 };
+// ORDER BY the keys (NULLS FIRST, strings by their bytes): the dense id of every listed group with each digit replaced by
+// its rank in that order — sorting by it orders the groups as the sort-based route does
+hipError_t hj_launch_dense_group_order_keys(const uint32_t *ids, uint32_t n, const DenseKeyLayout &keys, uint64_t *order_keys, hipStream_t s);
 hipError_t hj_launch_emit_dense_groups(const uint64_t *group_rows, uint32_t k, const uint32_t *ids, const uint32_t *order, uint32_t n, const DenseKeyLayout &keys,
                                        uint64_t *lanes_out, int64_t *key_vals, uint8_t *key_valid, hipStream_t s);
 

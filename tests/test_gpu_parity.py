@@ -787,9 +787,9 @@ def test_partitioned_group_by_matches_oracle(rt, orc, abi, chunks, route, monkey
             for g, w in zip(got, exp):
                 assert_values(g.values, w.values, f"{route} group by {keys}")
     assert rt.groupby(ht, [F(5, O.GreaterThan(10**6))], [1], wide, False) == []
-    # ORDER BY the keys: integer keys without NULL cells keep the route (group ids sort like the keys), a key with NULL
-    # cells (NULLS FIRST) goes to the sort-based route
-    for keys, want in (([1], route), ([2, 3], "sort")):
+    # ORDER BY the keys: ascending group ids are ascending keys for integer keys without NULL cells; with NULL cells
+    # (NULLS FIRST) or dictionary-coded strings the groups are sorted by their ranked id
+    for keys, want in (([1], route), ([2, 3], route), ([4, 1], route)):
         pq = rt.PreparedQuery(ht, None, narrow, keys, True)
         assert pq.route_note.startswith(want), pq.route_note
         pq.close()
