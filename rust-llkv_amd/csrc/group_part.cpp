@@ -70,9 +70,9 @@ int pinned_reserve(void **p, size_t *cap, size_t bytes) {
 } // namespace
 
 // Admission: what the shared-image lowering takes (statistics-bounded keys, order-free lanes) with up to 2^24 dense
-// groups; in first-appearance order or in key order.  Over a sharded table every
-// rank reduces its own rows and the partial groups are merged like the sort-based route's (sorted_groupby_merge: the
-// lanes are order-free, lane 1 is a table-wide row id).
+// groups; in first-appearance order or in key order.  Over a sharded table every rank reduces its own rows and the
+// partial groups are merged like the sort-based route's (sorted_groupby_merge: the lanes are order-free, lane 1 is a
+// table-wide row id).
 int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                          const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool order_by_keys, PartGroupBy **out) {
   if (table->local_rows >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 rows");
