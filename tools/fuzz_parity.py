@@ -229,3 +229,66 @@ ob = fuzz_ordered(range(12))
 print("ORDERED SCAN FAILURES:", len(ob))
 for b in ob[:10]:
     print("  ", b)
+
+
+# ---- partitioned GROUP BY: random table shapes, key ranges (tens of thousands … millions of dense ids), key lists with
+# NULL cells and dictionary-coded strings, aggregate lists, predicates, both output orders -------------------------------
+def fuzz_partitioned(seeds):
+    bad = []
+    A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+    for seed in seeds:
+        rng = np.random.default_rng(11000 + seed)
+        chunks = [int(rng.integers(1, 70_000)) for _ in range(int(rng.integers(1, 4)))]
+        n = sum(chunks)
+        span = int(rng.choice([66_000, 100_000, 300_000, 1_000_000, 4_000_000, 12_000_000]))
+        base = int(rng.integers(-10**9, 10**9))
+        k_big = (rng.integers(0, span, size=n) + base).astype(np.int64)
+        k_small = rng.integers(0, int(rng.integers(2, 40)), size=n).astype(np.int32)
+        k_tag = [("x", "y", "zz", "", "Y")[k] for k in rng.integers(0, 5, size=n)]
+        i64 = rng.integers(-1000, 1000, size=n).astype(np.int64)
+        f64 = rng.integers(1, 400_000, size=n).astype(np.float64) / 100
+        g64 = rng.standard_normal(n) * float(rng.choice([1e-3, 1.0, 1e6]))
+        vk, va = rng.random(n) > 0.1, rng.random(n) > 0.2
+        ht, ot = T.stage_both(rt, orc, abi, [(1, abi.DT_INT64, k_big, vk if rng.random() < 0.3 else None), (2, abi.DT_INT32, k_small, vk if rng.random() < 0.5 else None), (4, abi.DT_UTF8, k_tag, va),
+                                             (5, abi.DT_INT64, i64, va), (6, abi.DT_FLOAT64, f64), (7, abi.DT_FLOAT64, g64)], chunks)
+        pool = [A.count_star(), A.count(5), A.sum(5), A.avg(5), A.min(5), A.max(5), A.total(5), A.sum(6), A.avg(6), A.min(7), A.max(7), A.sum(7), A.sum(col(6) * (10000 - col(6))),
+                A.count_nulls(5), A.total(7)]
+        for k in range(4):
+            keys = [[1], [1, 2], [2, 1], [4, 1]][int(rng.integers(0, 4))]
+            if span * (40 if 2 in keys else 1) * (6 if 4 in keys else 1) > (1 << 24): keys = [1]
+            aggs = [pool[i] for i in sorted(set(int(x) for x in rng.integers(0, len(pool), size=int(rng.integers(1, 7)))))]
+            pred = [None, [F(5, O.GreaterThan(-500))], [F(6, O.LessThan(2000.0))]][int(rng.integers(0, 3))]
+            order = bool(rng.random() < 0.5)
+            pq = rt.PreparedQuery(ht, pred, aggs, keys, order)
+            note = pq.route_note.split(" (")[0]
+            pq.close()
+            try:
+                want = orc.groupby(ot, pred, keys, aggs, order)
+            except abi.LlkvError as oe:
+                try:
+                    rt.groupby(ht, pred, keys, aggs, order)
+                    bad.append((seed, k, "oracle raised, GPU did not", str(oe)))
+                except abi.LlkvError:
+                    pass
+                continue
+            try:
+                got = rt.groupby(ht, pred, keys, aggs, order)
+            except abi.LlkvError as ge:
+                if ge.kind != "Unsupported": bad.append((seed, k, "GPU raised", note, str(ge)))
+                continue
+            if [[x.value for x in r.keys] for r in got] != [[x.value for x in r.keys] for r in want]:
+                bad.append((seed, k, "keys differ", note, keys, order, len(got), len(want)))
+                continue
+            try:
+                for g, w in zip(got, want):
+                    T.assert_values(g.values, w.values, f"seed {seed} case {k}", abs_floor=1e-6)
+            except AssertionError as e:
+                bad.append((seed, k, "values differ", note, keys, str(e)[:200]))
+            print("partitioned seed", seed, "case", k, note, "groups", len(got), flush=True)
+    return bad
+
+
+gb = fuzz_partitioned(range(int(os.environ.get("LLKV_FUZZ_PARTITIONED", "10"))))
+print("PARTITIONED GROUP BY FAILURES:", len(gb))
+for b in gb[:10]:
+    print("  ", b)
