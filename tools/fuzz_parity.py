@@ -148,7 +148,7 @@ def fuzz_joins(seeds):
     return bad
 
 
-jb = fuzz_joins(range(60))
+jb = fuzz_joins(range(int(os.environ.get("LLKV_FUZZ_JOINS", "60"))))
 print("JOIN FAILURES:", len(jb))
 for b in jb[:10]:
     print("  ", b)
@@ -195,7 +195,7 @@ def fuzz_distinct(seeds):
     return bad
 
 
-db = fuzz_distinct(range(25))
+db = fuzz_distinct(range(int(os.environ.get("LLKV_FUZZ_DISTINCT", "25"))))
 print("DISTINCT FAILURES:", len(db))
 for b in db[:10]:
     print("  ", b)
@@ -225,7 +225,7 @@ def fuzz_ordered(seeds):
     return bad
 
 
-ob = fuzz_ordered(range(12))
+ob = fuzz_ordered(range(int(os.environ.get("LLKV_FUZZ_ORDERED", "12"))))
 print("ORDERED SCAN FAILURES:", len(ob))
 for b in ob[:10]:
     print("  ", b)
