@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <fstream>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -21,6 +22,7 @@ namespace llkv {
 namespace {
 std::mutex g_jit_mu;
 std::unordered_map<std::string, JitKernel> g_jit_cache;
+uint64_t g_jit_compiled = 0, g_jit_from_cache = 0, g_jit_from_seed = 0; // (under g_jit_mu) where this process's plan kernels came from
 
 const char *kind_name(JitKind k) { return k == JitKind::Scan ? "scan" : k == JitKind::Select ? "select" : k == JitKind::Project ? "project" : k == JitKind::Probe ? "probe" : k == JitKind::Reduce ? "reduce" : k == JitKind::Image ? "image" : k == JitKind::KeyBits ? "keybits" : k == JitKind::Part ? "part" : "emit"; }
 
@@ -86,6 +88,19 @@ bool private_dir(const std::string &dir) {
   struct stat st;
   if (::stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
   return st.st_uid == ::geteuid() && (st.st_mode & 022) == 0;
+}
+
+// Code objects shipped beside the library (`jit_seed/` in the directory of libllkv_hip.so): what hiprtc produced for
+// the plans of an earlier run, under the same key as the user's cache — source AND compiler identity, so an entry that
+// does not fit this build is simply never asked for.  Read-only; as trustworthy as the library next to it.  The
+// ahead-of-time catalog covers the benchmark plans; this covers the long tail a deployment (or the test suite: about a
+// thousand plans, 0.35 s of hiprtc each) sees again and again.
+std::string seed_dir() {
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<const void *>(&seed_dir), &info) || !info.dli_fname) return "";
+  const std::string lib = info.dli_fname;
+  const size_t cut = lib.rfind('/');
+  return cut == std::string::npos ? "" : lib.substr(0, cut) + "/jit_seed";
 }
 
 // What besides the source decides the code object: the compiler and its options
@@ -170,6 +185,17 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
       (void)::unlink(path.c_str());
       code.clear();
     }
+    g_jit_from_cache += loaded ? 1 : 0;
+  }
+  if (!loaded && !std::getenv("LLKV_HIP_NO_JIT_SEED")) {
+    static const std::string seeds = seed_dir();
+    if (!seeds.empty()) {
+      std::ifstream f(seeds + "/" + hex + ".hsaco", std::ios::binary);
+      if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      std::string why;
+      if (!code.empty() && !(loaded = load(code, &why))) code.clear(); // (left alone: the directory is not ours to clean)
+      g_jit_from_seed += loaded ? 1 : 0;
+    }
   }
   if (!loaded) {
     int rc = compile_to_code(src, &code, err);
@@ -180,6 +206,7 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
       if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); std::rename(tmp.c_str(), path.c_str()); }
     }
     if (!load(code, err)) return LLKV_INTERNAL;
+    ++g_jit_compiled;
   }
   g_jit_cache.emplace(key, k);
   *out = k;
@@ -203,6 +230,14 @@ void jit_shutdown() {
   std::lock_guard<std::mutex> lk(g_jit_mu);
   for (auto &kv : g_jit_cache) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
   g_jit_cache.clear();
+}
+
+// Where the plan kernels of this process came from so far: hiprtc, the user's cache directory, the seed directory.
+extern "C" void llkv_hip_jit_stats(uint64_t *compiled, uint64_t *from_cache, uint64_t *from_seed) {
+  std::lock_guard<std::mutex> lk(g_jit_mu);
+  if (compiled) *compiled = g_jit_compiled;
+  if (from_cache) *from_cache = g_jit_from_cache;
+  if (from_seed) *from_seed = g_jit_from_seed;
 }
 
 // Build check (no device needed): compiles one plan of the given kind for gfx950.

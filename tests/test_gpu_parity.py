@@ -2450,3 +2450,62 @@ def test_randomized_parity_window_of_the_fuzz_tool():
     assert verdicts[0].strip() == "FAILURES: []", verdicts
     for line in verdicts[1:]:
         assert line.strip().endswith("FAILURES: 0"), verdicts
+
+
+def test_plan_kernels_are_taken_from_the_seed_directory_when_it_holds_them(tmp_path):
+    """`jit_seed/` beside libllkv_hip.so holds code objects of earlier hiprtc compilations under the key of the user's
+    cache (source + compiler identity).  A plan compiled once (process 1: seeds off, its code object lands in cache
+    directory A) is loaded from the seed directory by a process with an empty cache (process 2) — nothing compiled, the
+    same answer."""
+    import glob
+    import json
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seeds = os.path.join(root, "rust-llkv_amd", "jit_seed")
+    script = tmp_path / "seed_probe.py"
+    script.write_text(
+        "import importlib, sys, json, ctypes as C, numpy as np\n"
+        "sys.path.insert(0, sys.argv[1])\n"
+        "abi = importlib.import_module('rust-llkv_amd.abi'); rt = importlib.import_module('rust-llkv_amd.runtime')\n"
+        "rt.init(0)\n"
+        "t = rt.HipTable(1, [1000])\n"
+        "t.append_column(1, abi.DT_INT64, np.arange(1000, dtype=np.int64))\n"
+        "t.append_column(2, abi.DT_FLOAT64, np.arange(1000, dtype=np.float64) / 8)\n"
+        "A = abi.AggregateSpec\n"
+        "vals = [v.value for v in rt.aggregate(t, [abi.Filter(1, abi.Operator.GreaterThan(17))], [A.sum(abi.col(2) * 3.25 + abi.col(1) * 7), A.max(abi.col(1) % 13), A.count_star()])]\n"
+        "x = [C.c_uint64(), C.c_uint64(), C.c_uint64()]\n"
+        "rt.lib().llkv_hip_jit_stats(*[C.byref(v) for v in x])\n"
+        "print(json.dumps({'values': vals, 'compiled': x[0].value, 'from_cache': x[1].value, 'from_seed': x[2].value}))\n")
+    a, b = tmp_path / "cache_a", tmp_path / "cache_b"
+    a.mkdir(mode=0o700)
+    b.mkdir(mode=0o700)
+
+    def run(cache, no_seed):
+        env = dict(os.environ, LLKV_HIP_CACHE_DIR=str(cache))
+        env.pop("LLKV_HIP_NO_JIT_SEED", None)
+        if no_seed:
+            env["LLKV_HIP_NO_JIT_SEED"] = "1"
+        out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    first = run(a, True)
+    assert first["compiled"] >= 1 and first["from_seed"] == 0, first
+    made = sorted(glob.glob(str(a / "*.hsaco")))
+    assert len(made) == first["compiled"], (made, first)
+    os.makedirs(seeds, exist_ok=True)
+    planted = []
+    try:
+        for f in made:
+            dst = os.path.join(seeds, os.path.basename(f))
+            if not os.path.exists(dst):
+                shutil.copy(f, dst)
+                planted.append(dst)
+        second = run(b, False)
+        assert second["compiled"] == 0 and second["from_seed"] == first["compiled"], (first, second)
+        assert second["values"] == first["values"]
+    finally:
+        for f in planted:
+            os.remove(f)
