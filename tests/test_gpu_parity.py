@@ -752,7 +752,7 @@ def test_sort_based_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeyp
 
 
 @pytest.mark.parametrize("route", ["partitioned", "sort"])
-@pytest.mark.parametrize("chunks", [[17], [34001, 8192, 5]])
+@pytest.mark.parametrize("chunks", [[17], [33001, 4096, 5]])
 def test_partitioned_group_by_matches_oracle(rt, orc, abi, chunks, route, monkeypatch):
     """More dense groups than LDS-sized slices cover (here up to 1.2 M group ids: statistics-bounded integer keys, one or
     two of them, one with NULL cells): the partitioned route — count pass, scan, scatter pass, one LDS image per
