@@ -881,7 +881,8 @@ typedef struct llkv_column_desc {
 
 /* `grouped`: 0 = ungrouped aggregates, 1 = GROUP BY (groups in first-appearance
  * order), 3 = GROUP BY with ORDER BY on the keys (no first-row tracking); + 4 =
- * lower for the shared-image GROUP BY kernel (hundreds … thousands of groups).  */
+ * lower for the shared-image GROUP BY kernel (hundreds … thousands of groups); + 8
+ * (with 4) = that lowering in the partitioned route's form (up to 2^24 dense group ids).  */
 llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols,
                             const llkv_filter *filters, uint32_t n_filters,
                             const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields,

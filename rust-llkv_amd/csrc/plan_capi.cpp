@@ -45,7 +45,7 @@ llkv_status llkv_plan_lower(const llkv_column_desc *cols, uint32_t n_cols, const
   };
   llkv::LoweredPlan plan;
   g_plan_err.clear();
-  int rc = llkv::lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, (grouped & 1) != 0, (grouped & 2) == 0, &plan, &g_plan_err, (grouped & 4) != 0);
+  int rc = llkv::lower_plan(resolve, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, (grouped & 1) != 0, (grouped & 2) == 0, &plan, &g_plan_err, (grouped & 4) != 0, (grouped & 8) != 0);
   if (rc) return (llkv_status)rc;
   if (type_string_out && type_string_cap) {
     if (plan.type_string.size() + 1 > type_string_cap) { g_plan_err = "type string buffer too small"; return LLKV_INVALID_ARGUMENT; }

@@ -865,15 +865,16 @@ def merge_join_rows(rows, n_payload: int, limit: int):
 
 
 def lower_plan(column_descs, predicate, aggs: Sequence[AggregateSpec], keys: Sequence[int] = (), grouped: bool = False,
-               plan_lib=None, order_by_keys: bool = False):
-    """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError."""
+               plan_lib=None, order_by_keys: bool = False, form: int = 0):
+    """llkv_plan_lower: returns (type_string, lanes, bytes_per_row) or raises LlkvError.
+    form: 0 = per-thread accumulators, 4 = the shared-image lowering, 12 = its partitioned form."""
     L = plan_lib or lib()
     L.llkv_plan_last_error.restype = C.c_char_p
     p = CPlan(predicate, aggs, keys)
     buf = C.create_string_buffer(16384)
     lanes, bpr = C.c_uint32(), C.c_uint64()
     rc = L.llkv_plan_lower(column_descs, C.c_uint32(len(column_descs)), p.filters, p.n_filters, p.ops, p.n_ops, p.keys, p.n_keys,
-                           p.aggs, p.n_aggs, C.c_int32(int(grouped) | (2 if (grouped and order_by_keys) else 0)), buf, C.c_uint64(len(buf)), C.byref(lanes), C.byref(bpr))
+                           p.aggs, p.n_aggs, C.c_int32(int(grouped) | (2 if (grouped and order_by_keys) else 0) | form), buf, C.c_uint64(len(buf)), C.byref(lanes), C.byref(bpr))
     if rc != 0:
         raise LlkvError(rc, L.llkv_plan_last_error().decode(errors="replace"))
     return buf.value.decode(), lanes.value, bpr.value

@@ -178,6 +178,44 @@ def _desc(abi, cols):
     return arr
 
 
+def test_group_by_lowering_forms_and_their_group_limits(lib, abi):
+    """The three GROUP BY lowerings over statistics-bounded integer keys: per-thread accumulators (key ranges ≤ 256,
+    ≤ 64 groups), the shared-image form (≤ 65 536 dense group ids, ≤ 4 LDS-sized slices, order-free lanes: an f64 sum
+    needs bounds from the statistics), and its partitioned form (≤ 2^24 dense ids, no LDS bound, first row always kept)."""
+    rt = mod("runtime")
+    A = abi.AggregateSpec
+
+    def descs(span):
+        d = (abi.CColumnDesc * 3)()
+        d[0].field_id, d[0].dtype, d[0].rows, d[0].has_stats, d[0].min_i, d[0].max_i = 1, abi.DT_INT64, 10**7, 1, 1, span
+        d[1].field_id, d[1].dtype, d[1].rows, d[1].has_stats, d[1].min_i, d[1].max_i = 2, abi.DT_INT64, 10**7, 1, 1, 50
+        d[2].field_id, d[2].dtype, d[2].rows = 3, abi.DT_FLOAT64, 10**7
+        d[2].has_fstats, d[2].f_absmax, d[2].f_absmin_nz, d[2].f_all_finite = 1, 105000.0, 900.0, 1
+        return d
+
+    aggs = [A.count_star(), A.sum(2), A.sum(3)]
+    for span, dense, image, part in ((12, True, True, True), (2526, False, True, True), (2_000_000, False, False, True), ((1 << 24) + 1, False, False, False)):
+        for form, ok, tail in ((0, dense, ",1>"), (4, image, ",2"), (12, part, ",3>")):
+            if ok:
+                ts, lanes, _ = rt.lower_plan(descs(span), None, aggs, [1], True, form=form)
+                assert f"Keys<{span},1,KeyInt<0,I64," in ts and tail in ts[-6:], (span, form, ts)
+                assert ("SumF64<" in ts) == (form == 0) and ("SumF64Q<" in ts or "SumF64X<" in ts) == (form != 0), ts  # order-free f64 sums off the dense form
+            else:
+                with pytest.raises(abi.LlkvError) as e:
+                    rt.lower_plan(descs(span), None, aggs, [1], True, form=form)
+                assert e.value.kind == "Unsupported", (span, form)
+    # a whole table's rows may meet in one partition's image: the fixed-point grid of the shared-image form (sized for the
+    # rows ONE workgroup sees) does not fit 10^7 rows of this column, the multi-level grids do
+    ts_i, _, _ = rt.lower_plan(descs(2526), None, aggs, [1], True, form=4)
+    ts_p, _, _ = rt.lower_plan(descs(2526), None, aggs, [1], True, form=12)
+    assert "SumF64Q<" in ts_i and "SumF64X<" in ts_p, (ts_i, ts_p)
+    # without bounds on the f64 argument there is no order-free sum: only the dense form (and the sort-based route) take it
+    d = descs(2526)
+    d[2].has_fstats = 0
+    with pytest.raises(abi.LlkvError):
+        rt.lower_plan(d, None, aggs, [1], True, form=12)
+
+
 def test_literal_cast_rules(lib, abi):
     """llkv-types/src/literal.rs:364-520: integer columns accept only integer (or scale-0 decimal)
     literals; Date32 filters as i32 and rejects a Date32 literal; f64 accepts ints and decimals."""
