@@ -483,7 +483,9 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
       out->is_null = rows == 0;
       v = rows ? (i128)(int64_t)l[0] : 0;
     } else {
-      const i128 sum = a.fast_sum ? (i128)(int64_t)l[0] : (((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0]);
+      // (wide values: the limb sums mod 2^128 — the lowering excluded a prefix outside i128, so the true sum is inside)
+      const i128 sum = a.wide ? (i128)((u128)l[0] + ((u128)l[1] << 32) + ((u128)l[2] << 64) + ((u128)l[3] << 96))
+                              : a.fast_sum ? (i128)(int64_t)l[0] : (((i128)(int64_t)l[1] << 32) + (i128)(u128)l[0]);
       if (a.fin == AggFinal::AvgDec) {
         if (rows > 0) { // sum / count, rounded half away from zero
           const i128 n = rows, rem = sum % n;

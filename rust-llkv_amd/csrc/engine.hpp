@@ -49,13 +49,16 @@ struct DeviceColumn {
   double local_f_absmax = 0.0, local_f_absmin_nz = 0.0;
   bool local_f_all_finite = false; // … and none of this rank's values is NaN / ±∞
   uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
+  void *d_hi = nullptr;       // Decimal128 values beyond 64 bits (info.wide128): d_values holds the low halves, this the high halves
   bool owned = false;
 };
 
-// Device buffer read by slot `s` of a lowered plan: the field's values, or its validity mask.
+// Device buffer read by slot `s` of a lowered plan: the field's values, its validity mask, or the high halves of a wide
+// Decimal128 column.
 inline const void *slot_buffer(const std::map<uint32_t, DeviceColumn> &cols, const LoweredPlan &p, size_t s) {
   const DeviceColumn &c = cols.at(p.slot_fields[s]);
-  return (s < p.slot_is_valid.size() && p.slot_is_valid[s]) ? (const void *)c.d_valid : (const void *)c.d_values;
+  const uint8_t part = s < p.slot_is_valid.size() ? p.slot_is_valid[s] : 0;
+  return part == 1 ? (const void *)c.d_valid : part == 2 ? (const void *)c.d_hi : (const void *)c.d_values;
 }
 
 struct TileSet {

@@ -558,6 +558,22 @@ template <class E> struct SumI64 { // SumInt64 :801-830, AvgInt64 :1114-1144 —
 };
 // Same sum when the column statistics gathered at staging prove rows·max|v| < 2^63
 // (no prefix of the reference's checked_add chain can overflow): one wrapping lane.
+// SUM / TOTAL / AVG over a Decimal128 column with values beyond 64 bits (llkv-aggregate/src/lib.rs:925-943: i128
+// checked_add row by row): the column is two 8 B/row buffers (slot SLO: low halves, slot SHI: high halves), the lanes
+// are the sums of the four 32-bit limbs — the top one sign-extended — so every lane stays inside 64 bits for < 2^31
+// rows and the host rebuilds Σ v mod 2^128 (the lowering admits the plan only when no prefix can leave i128).
+template <int SLO, int SHI> struct SumDecWide {
+  static constexpr int N = 4;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    const uint64_t lo = c.get<U64>(SLO, j);
+    const int64_t hi = c.get<I64>(SHI, j);
+    o[0] = lo & 0xFFFFFFFFull;
+    o[1] = lo >> 32;
+    o[2] = (uint64_t)hi & 0xFFFFFFFFull;
+    o[3] = (uint64_t)(hi >> 32); // arithmetic shift: the signed top limb
+  }
+};
 template <class E> struct SumI64Fast {
   static constexpr int N = 1;
   static constexpr int op(int) { return OP_ADD_I64; }

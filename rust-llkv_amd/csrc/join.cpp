@@ -55,6 +55,7 @@ int key_part(const Table *t, uint32_t field, const DeviceColumn **col, JoinKeyPa
   auto it = t->cols.find(field);
   if (it == t->cols.end()) return set_error(LLKV_NOT_FOUND, "join key field " + std::to_string(field) + " not found");
   const DeviceColumn &c = it->second;
+  if (c.info.wide128) return set_error(LLKV_UNSUPPORTED, "join key over Decimal128 values beyond 64 bits (field " + std::to_string(field) + ")");
   *col = &c;
   std::memset(out, 0, sizeof *out);
   out->values = c.d_values;

@@ -349,6 +349,9 @@ struct Lowering {
     const ColumnInfo *ci = resolve(field);
     if (!ci) return fail(LLKV_NOT_FOUND, "field " + std::to_string(field) + " not found");
     *ci_out = ci;
+    // every reader of a column's values comes through here: a wide Decimal128 column has no 8 B/row value image
+    if (ci->wide128)
+      return fail(LLKV_UNSUPPORTED, "Decimal128 values beyond 64 bits in field " + std::to_string(field) + ": only SUM / TOTAL / AVG / COUNT over the bare column are on the GPU path");
     for (size_t i = 0; i < p.slot_fields.size(); ++i)
       if (p.slot_fields[i] == field && !p.slot_is_valid[i]) { *slot = (int)i; return LLKV_OK; }
     if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 16 column buffers");
@@ -356,6 +359,25 @@ struct Lowering {
     p.slot_dtypes.push_back(ci->dtype);
     p.slot_is_valid.push_back(0);
     *slot = (int)p.slot_fields.size() - 1;
+    return LLKV_OK;
+  }
+  // The two buffers of a wide Decimal128 column: low halves (u64), high halves (i64).
+  int wide_slots_of(uint32_t field, int *lo, int *hi) {
+    *lo = *hi = -1;
+    for (size_t i = 0; i < p.slot_fields.size(); ++i) {
+      if (p.slot_fields[i] != field) continue;
+      if (p.slot_is_valid[i] == 0) *lo = (int)i;
+      if (p.slot_is_valid[i] == 2) *hi = (int)i;
+    }
+    for (int part = 0; part < 2; ++part) {
+      int &slot = part ? *hi : *lo;
+      if (slot >= 0) continue;
+      if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 16 column buffers");
+      p.slot_fields.push_back(field);
+      p.slot_dtypes.push_back(part ? LLKV_DT_INT64 : LLKV_DT_UINT64);
+      p.slot_is_valid.push_back(part ? 2 : 0);
+      slot = (int)p.slot_fields.size() - 1;
+    }
     return LLKV_OK;
   }
   // Validity of a field as a predicate node: "" when the column has no NULL cell, else `Valid<slot>` over the
@@ -367,7 +389,7 @@ struct Lowering {
     if (!ci->nullable) return LLKV_OK;
     int slot = -1;
     for (size_t i = 0; i < p.slot_fields.size(); ++i)
-      if (p.slot_fields[i] == field && p.slot_is_valid[i]) slot = (int)i;
+      if (p.slot_fields[i] == field && p.slot_is_valid[i] == 1) slot = (int)i;
     if (slot < 0) {
       if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 16 column buffers");
       p.slot_fields.push_back(field);
@@ -1114,7 +1136,7 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       continue;
     }
     const char *fn = s.kind == LLKV_AGG_SUM ? "SUM" : s.kind == LLKV_AGG_TOTAL ? "TOTAL" : s.kind == LLKV_AGG_AVG ? "AVG" : s.kind == LLKV_AGG_MIN ? "MIN" : "MAX";
-    if (simple) {
+    if (simple && !simple_ci->wide128) {
       // validate_aggregate_type llkv-executor/src/lib.rs:5946-5988
       const int32_t dt = simple_ci->dtype;
       // Utf8 / Boolean / Date32 inputs get Float64 accumulators fed by array_value_to_numeric (llkv-aggregate/src/lib.rs:
@@ -1199,6 +1221,27 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       o.lane = add_group("IfValid<" + valid + "," + inner + ">", lane_ops);
       o.count_lane = o.lane + n_inner;
     };
+    if (simple && simple_ci->wide128) {
+      // Decimal128 values beyond 64 bits (llkv-aggregate/src/lib.rs:925-943: `sum.checked_add(v)` in i128, row by row):
+      // four ADD_I64 lanes over the 32-bit limbs (the top one signed) — exact for < 2^31 rows, order-free.  The
+      // reference's overflow check is order dependent (a prefix may leave i128 although the total fits): the plan is
+      // taken only when rows · max|v| ≤ i128::MAX excludes that.  AVG: half away from zero (:1720-1742).
+      if (s.kind == LLKV_AGG_MIN || s.kind == LLKV_AGG_MAX)
+        return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over Decimal128 values beyond 64 bits (a 128-bit compare has no order-free lanes) is not on the GPU path");
+      if (s.kind != LLKV_AGG_SUM && s.kind != LLKV_AGG_TOTAL && s.kind != LLKV_AGG_AVG) return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
+      const u128 absmax = ((u128)simple_ci->wide_absmax_hi << 64) | simple_ci->wide_absmax_lo;
+      const u128 i128_max = ~(u128)0 >> 1;
+      if (simple_ci->rows >= (1ull << 31) || (absmax != 0 && (u128)simple_ci->rows > i128_max / absmax))
+        return L.fail(LLKV_UNSUPPORTED, "possible Decimal128 sum overflow (rows · max|v| exceeds i128): the reference's check is order dependent");
+      int lo, hi;
+      if ((rc = L.wide_slots_of(s.expr[0].field_id, &lo, &hi))) return rc;
+      o.precision = simple_ci->precision; o.scale = simple_ci->scale;
+      o.wide = true;
+      o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumDec : s.kind == LLKV_AGG_TOTAL ? AggFinal::TotalDec : AggFinal::AvgDec;
+      add_agg("SumDecWide<" + std::to_string(lo) + "," + std::to_string(hi) + ">", {ADD_I64, ADD_I64, ADD_I64, ADD_I64});
+      p.aggs.push_back(o);
+      continue;
+    }
     if (simple && simple_ci->dtype == LLKV_DT_DECIMAL128) {
       // Decimal128 accumulators (llkv-aggregate/src/lib.rs:925-967,1071-1088,1236-1259,1332-1352,1400-1420) over the
       // 64-bit image: the same exact lanes as Int64, finalized in i128 with the column's (precision, scale)

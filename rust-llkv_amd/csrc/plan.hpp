@@ -34,6 +34,10 @@ struct ColumnInfo {
   double f_absmax = 0.0;                //   largest |v|
   double f_absmin_nz = 0.0;             //   smallest non-zero |v| (0: none / unknown)
   bool ascending = false;               // integer column of an unsharded table: the rows are in strictly ascending value order
+  // LLKV_DT_DECIMAL128 with values beyond 64 bits: the device image is two 8 B/row buffers (low halves, high halves) and
+  // only SUM / TOTAL / AVG (and the counts, which read no value) take the column; largest |v| as (hi, lo)
+  bool wide128 = false;
+  uint64_t wide_absmax_hi = 0, wide_absmax_lo = 0;
 };
 
 using ColumnResolver = std::function<const ColumnInfo *(uint32_t field_id)>;
@@ -61,6 +65,7 @@ struct AggOut {
   bool typed_by_first_value = false; // GROUP BY computed argument: the group's temp column takes the type of its first
                                      // non-NULL value, Int64 when there is none (llkv-executor/src/lib.rs:298-406)
   bool fast_sum = false;        // decimal sums: one wrapping lane (statistics exclude i64 overflow) instead of the 96-bit split
+  bool wide = false;            // decimal sums over values beyond 64 bits: four lanes, the sums of the 32-bit limbs (SumDecWide)
   int32_t precision = 0, scale = 0; // Decimal128 results
   int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
   int exact_levels = 0; // f64 sum kept as exact grid-level lanes (SumF64X, 2 or 3 of them): value = smallest level first, summed
@@ -72,7 +77,7 @@ struct LoweredPlan {
   std::string type_string;            // "Plan<Cols<...>,<pred>,Keys<...>,Aggs<...>,U>"
   std::vector<uint32_t> slot_fields;  // slot → field id
   std::vector<int32_t> slot_dtypes;   // slot → llkv_dtype (UTF8 = 1-byte codes)
-  std::vector<uint8_t> slot_is_valid; // slot reads the field's validity mask (1 B/row) instead of its values
+  std::vector<uint8_t> slot_is_valid; // what of the field the slot reads: 0 its values, 1 its validity mask (1 B/row), 2 the high halves of a wide Decimal128 column
   std::vector<int64_t> lit_i;
   std::vector<double> lit_f;
   std::vector<uint32_t> key_fields, key_slots, key_strides, key_cards;

@@ -21,6 +21,7 @@ Table::~Table() {
   for (auto &kv : cols) {
     if (kv.second.owned && kv.second.d_values) (void)hipFree(kv.second.d_values);
     if (kv.second.d_valid) (void)hipFree(kv.second.d_valid);
+    if (kv.second.d_hi) (void)hipFree(kv.second.d_hi);
   }
   for (auto &kv : tilesets) {
     if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
@@ -479,19 +480,23 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
   if (precision < 1 || precision > 38 || scale > precision || scale < -128)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "invalid Decimal128 precision/scale");
   if ((rc = ensure_device())) return (llkv_status)rc;
-  // narrow the 16-byte raw values to the 8 B/row device image; a value that needs more than 64 bits keeps the
-  // column on the caller's CPU route
-  std::vector<int64_t> narrow(t->dev_rows + 16, 0);
+  // narrow the 16-byte raw values to the 8 B/row device image.  A column with a value that needs more than 64 bits is
+  // staged as two 8 B/row buffers instead (low halves, high halves): SUM / TOTAL / AVG and the counts take it, every
+  // other use keeps the caller's CPU route (plan.cpp: slot_of)
+  std::vector<int64_t> narrow(t->dev_rows + 16, 0), high;
+  std::atomic<bool> any_wide{false};
   rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
     if (rows && !chunk_values[i]) return set_error(LLKV_INVALID_ARGUMENT, "chunk values pointer is NULL");
     const int64_t *src = static_cast<const int64_t *>(chunk_values[i]); // (lo, hi) pairs, little endian
     int64_t *dst = narrow.data() + t->chunk_dev_off[i];
+    bool wide = false;
     for (uint64_t r = 0; r < rows; ++r) {
       const int64_t lo = src[2 * r], hi = src[2 * r + 1];
-      if (hi != (lo >> 63)) return set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id));
+      wide |= hi != (lo >> 63);
       dst[r] = lo;
     }
+    if (wide) any_wide = true;
     return LLKV_OK;
   });
   if (rc) return (llkv_status)rc;
@@ -502,10 +507,39 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
   c.info.scale = scale;
   c.info.rows = t->total_rows;
   c.owned = true;
-  if ((rc = alloc_column(*t, 8, &c.d_values))) return (llkv_status)rc;
+  if (any_wide) {
+    // (a sharded table would need the ranks to agree on the layout and on max|v|: not exchanged yet)
+    if (t->world != 1) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id) + " of a sharded table");
+    high.assign(t->dev_rows + 16, 0);
+    unsigned __int128 absmax = 0;
+    for (uint32_t i = 0; i < n_chunks; ++i) { // (sequential: wide columns are rare, and max|v| is one value)
+      const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+      const int64_t *src = static_cast<const int64_t *>(chunk_values[i]);
+      int64_t *dst = high.data() + t->chunk_dev_off[i];
+      for (uint64_t r = 0; r < rows; ++r) {
+        dst[r] = src[2 * r + 1];
+        const __int128 v = ((__int128)src[2 * r + 1] << 64) | (unsigned __int128)(uint64_t)src[2 * r];
+        const unsigned __int128 mag = v < 0 ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
+        absmax = mag > absmax ? mag : absmax;
+      }
+    }
+    c.info.wide128 = true;
+    c.info.wide_absmax_hi = (uint64_t)(absmax >> 64);
+    c.info.wide_absmax_lo = (uint64_t)absmax;
+  }
+  if ((rc = alloc_column(*t, 8, &c.d_values)) || (any_wide && (rc = alloc_column(*t, 8, &c.d_hi)))) {
+    if (c.d_values) (void)hipFree(c.d_values);
+    return (llkv_status)rc;
+  }
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
-  if ((rc = stage_to_device({{c.d_values, narrow.data(), (size_t)t->dev_rows * 8}}))) return (llkv_status)rc;
-  if ((rc = column_stats_device(*t, c))) return (llkv_status)rc;
+  rc = any_wide ? stage_to_device({{c.d_values, narrow.data(), (size_t)t->dev_rows * 8}, {c.d_hi, high.data(), (size_t)t->dev_rows * 8}})
+                : stage_to_device({{c.d_values, narrow.data(), (size_t)t->dev_rows * 8}});
+  if (!rc && !any_wide) rc = column_stats_device(*t, c); // (integer statistics describe the narrowed image only)
+  if (rc) {
+    (void)hipFree(c.d_values);
+    if (c.d_hi) (void)hipFree(c.d_hi);
+    return (llkv_status)rc;
+  }
   t->cols.emplace(field_id, std::move(c));
   return LLKV_OK;
 }
