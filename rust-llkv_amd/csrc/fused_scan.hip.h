@@ -196,6 +196,11 @@ template <class E> struct Widen128 { // Decimal128 column staged as i64 → arro
   static __device__ __forceinline__ __int128 eval(Ctx &c, int j) { return (__int128)(int64_t)E::eval(c, j); }
   static __device__ __forceinline__ bool valid(Ctx &c, int j) { return E::valid(c, j); }
 };
+template <int SLO, int SHI> struct Join128 { // Decimal128 column with values beyond 64 bits (staged as low / high halves) → the 16-byte raw value
+  using Type = I128;
+  static __device__ __forceinline__ __int128 eval(Ctx &c, int j) { return ((__int128)c.get<I64>(SHI, j) << 64) | (__int128)(unsigned __int128)c.get<U64>(SLO, j); }
+  static __device__ __forceinline__ bool valid(Ctx &, int) { return true; }
+};
 template <class E> struct ToI64 { // widening of the narrow integer types
   using Type = I64;
   static __device__ __forceinline__ int64_t eval(Ctx &c, int j) { return (int64_t)E::eval(c, j); }

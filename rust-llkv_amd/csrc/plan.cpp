@@ -1597,13 +1597,27 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
   for (uint32_t i = 0; i < n_projections; ++i) {
     const llkv_projection &pr = projections[i];
     std::string node;
+    // a Decimal128 column with values beyond 64 bits passes through as it was staged: low and high halves → 16 bytes
+    auto wide_column = [&](uint32_t field, std::string *n, const ColumnInfo **ci_out) -> int {
+      const ColumnInfo *ci = resolve(field);
+      if (!ci || !ci->wide128) return -1; // not one
+      int lo, hi;
+      int r = L.wide_slots_of(field, &lo, &hi);
+      if (r) return r;
+      *n = "Join128<" + std::to_string(lo) + "," + std::to_string(hi) + ">";
+      *ci_out = ci;
+      return LLKV_OK;
+    };
     if (!pr.computed) {
       const ColumnInfo *ci;
       int slot;
-      if ((rc = L.slot_of(pr.field_id, &ci, &slot))) return rc;
-      if (dtype_width(ci->dtype) == 0) return L.fail(LLKV_UNSUPPORTED, std::string("projection of ") + dtype_name(ci->dtype));
-      node = L.col_node(slot, ci->dtype);
-      if (ci->dtype == LLKV_DT_DECIMAL128) node = "Widen128<" + node + ">"; // back to arrow's 16-byte raw values
+      if ((rc = wide_column(pr.field_id, &node, &ci)) > 0) return rc;
+      if (rc < 0) {
+        if ((rc = L.slot_of(pr.field_id, &ci, &slot))) return rc;
+        if (dtype_width(ci->dtype) == 0) return L.fail(LLKV_UNSUPPORTED, std::string("projection of ") + dtype_name(ci->dtype));
+        node = L.col_node(slot, ci->dtype);
+        if (ci->dtype == LLKV_DT_DECIMAL128) node = "Widen128<" + node + ">"; // back to arrow's 16-byte raw values
+      }
       out->out_dtypes.push_back(ci->dtype);
       out->out_fields.push_back((int32_t)pr.field_id);
       std::string v;
@@ -1616,9 +1630,12 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
       if (pr.expr_len == 1 && pr.expr[0].kind == LLKV_TOK_COLUMN) { // bare column written as an expression
         const ColumnInfo *ci;
         int slot;
-        if ((rc = L.slot_of(pr.expr[0].field_id, &ci, &slot))) return rc;
-        node = L.col_node(slot, ci->dtype);
-        if (ci->dtype == LLKV_DT_DECIMAL128) node = "Widen128<" + node + ">";
+        if ((rc = wide_column(pr.expr[0].field_id, &node, &ci)) > 0) return rc;
+        if (rc < 0) {
+          if ((rc = L.slot_of(pr.expr[0].field_id, &ci, &slot))) return rc;
+          node = L.col_node(slot, ci->dtype);
+          if (ci->dtype == LLKV_DT_DECIMAL128) node = "Widen128<" + node + ">";
+        }
         out->out_dtypes.push_back(ci->dtype);
         out->out_fields.push_back((int32_t)pr.expr[0].field_id);
       } else {

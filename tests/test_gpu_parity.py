@@ -702,8 +702,8 @@ def test_wide_decimal128_sums_match_oracle(rt, orc, abi, chunks):
     """Decimal128 columns with values beyond 64 bits (staged as low and high halves): SUM / TOTAL / AVG (i128, half away
     from zero) and the counts equal the oracle's raw i128 results exactly — ungrouped, grouped by a small key (per-thread
     accumulators), by a date (shared-image kernel) and by a sparse key (sort-based route), with NULL cells and
-    predicates on other columns.  Everything else over such a column stays on the caller's route (`Unsupported`), and
-    so does a sum whose prefixes could leave i128 (the reference's check is order dependent)."""
+    predicates on other columns; a scan passes the column through as 16-byte values.  Everything else over such a column
+    stays on the caller's route (`Unsupported`), and so does a sum whose prefixes could leave i128 (the reference's check is order dependent)."""
     rng = np.random.default_rng(50 + len(chunks))
     n = sum(chunks)
     wide = [int(a) * 2**41 + int(b) for a, b in zip(rng.integers(-2**62, 2**62, size=n), rng.integers(0, 2**41, size=n))]  # |v| < 2^103
@@ -739,8 +739,13 @@ def test_wide_decimal128_sums_match_oracle(rt, orc, abi, chunks):
         with pytest.raises(abi.LlkvError) as e:
             rt.aggregate(ht, None, bad)
         assert e.value.kind == "Unsupported", bad
+    if n < 20000:  # the column itself passes through a scan as the 16-byte values it was staged from
+        for inc in (False, True):
+            got = rt.scan_stream(ht, [2, 1, 3], [F(3, O.LessThan(2))], include_nulls=inc, include_row_ids=True)
+            want = orc.scan_stream(ot, [2, 1, 3], [F(3, O.LessThan(2))], include_nulls=inc, include_row_ids=True)
+            assert got == want
     with pytest.raises(abi.LlkvError) as e:
-        rt.scan_stream(ht, [2, 3], [F(3, O.LessThan(2))])
+        rt.scan_stream(ht, [abi.col(2) + 1], None)
     assert e.value.kind == "Unsupported"
     with pytest.raises(abi.LlkvError) as e:
         rt.join_stream(ht, ht, [(2, 2, False)], 0, 4096)
