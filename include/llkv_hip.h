@@ -683,6 +683,50 @@ llkv_status llkv_hip_join_stream(const llkv_hip_table *left, const llkv_hip_tabl
                                  const llkv_join_options *options, llkv_on_join_batch on_batch,
                                  void *user);
 
+/* The same join delivering what the reference's `on_batch` receives: the joined RecordBatch, gathered on the    */
+/* device (emit_joined_batch / emit_left_joined_batch / emit_semi_batch llkv-join/src/hash_join.rs:715-772,     */
+/* cross_join_pair llkv-join/src/cartesian.rs:22-110, synthesize_left_join_nulls :1468-1497; the executor's     */
+/* hash_join_table_batches llkv-executor/src/lib.rs:12218-12392 under LLKV_JOIN_KEYS_EXECUTOR).                 */
+/* · `left_columns` / `right_columns` are the USER columns of the two tables in schema order with their names   */
+/*   (build_user_projections :782-806: every schema field that carries a field id; the row-id column never is   */
+/*   one), so the batch holds the left columns, then the right columns — SEMI / ANTI: the left columns only     */
+/*   (build_output_schema :877-943).  A right name already taken gets the suffix "_1" (:913-939; the executor   */
+/*   rules keep the names as given, :12237-12244).  `column_names` of the callback are the output names.        */
+/* · Both sides are read as `scan_stream(all user columns, ScanStreamOptions::default())` reads them            */
+/*   (:203-240,:346-375): a row that is NULL in EVERY user column is dropped by the scan's DropNulls gather      */
+/*   (llkv-column-map/src/store/projection.rs:1326-1330) — it joins nothing and is not padded by a LEFT join    */
+/*   (LLKV_JOIN_KEYS_TABLE only; the generic typed-key path over a probe side that holds such rows answers      */
+/*   LLKV_UNSUPPORTED: its slices count the rows that survive).                                                  */
+/* · A LEFT join pads the right columns of an unmatched row with NULLs; every right column of a LEFT join       */
+/*   carries a validity bitmap.  Batches are cut exactly where the reference cuts them (see above); rows keep   */
+/*   probe order × build insertion order.  `batch->row_ids` is NULL.  An empty column list on either side:      */
+/*   the reference scans nothing there (:211-221,:226) — no left columns, no batches.                           */
+/* The view and the names are valid during the callback; llkv_hip_batch_export_arrow makes an owned RecordBatch. */
+typedef struct llkv_join_column {
+  uint32_t field_id;
+  const char *name;
+} llkv_join_column;
+
+typedef struct llkv_join_output {
+  const llkv_join_column *left_columns;
+  uint32_t n_left;
+  const llkv_join_column *right_columns;
+  uint32_t n_right;
+} llkv_join_output;
+
+typedef void (*llkv_on_join_record_batch)(const llkv_batch_view *batch, const char *const *column_names,
+                                          void *user);
+
+llkv_status llkv_hip_join_stream_batches(const llkv_hip_table *left, const llkv_hip_table *right,
+                                         const llkv_join_key *keys, uint32_t n_keys,
+                                         const llkv_join_options *options, const llkv_join_output *output,
+                                         llkv_on_join_record_batch on_batch, void *user);
+
+/* build_output_schema alone (hash_join.rs:877-943): writes the n_left (+ n_right unless SEMI / ANTI) output     */
+/* names into `names` (each a malloc'ed string the caller frees with llkv_hip_free) and their count.  Host only. */
+llkv_status llkv_hip_join_output_names(const llkv_join_output *output, int32_t join_type, int32_t key_rules,
+                                       char **names, uint32_t *n_names);
+
 /* ------------------------------------------------------------------------- */
 /* Join → GROUP BY → ORDER BY … LIMIT for the TPC-H Q3 shape — the executor's   */
 /* multi-table route: try_execute_hash_join llkv-executor/src/lib.rs:3780-4052, */

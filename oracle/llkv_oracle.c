@@ -2092,16 +2092,139 @@ static int join_rows_equal(const orc_column *const *ca, uint64_t ra, const orc_c
   return 1;
 }
 
+/* The rows a side's scan delivers (scan_stream(all user columns, ScanStreamOptions::default()), hash_join.rs:203-240,
+ * :346-375) and the batches they arrive in: the surviving rows of every 65 536-row-id window (execute.rs:297-372). */
+typedef struct join_rows {
+  uint64_t *rows;        /* row ids, ascending */
+  uint64_t n;
+  uint64_t *batch_start; /* [n_batches + 1] indices into rows */
+  uint64_t n_batches;
+} join_rows;
+static void join_rows_free(join_rows *r) { free(r->rows); free(r->batch_start); memset(r, 0, sizeof *r); }
+
+/* `fields` == NULL: every row (the index-pair delivery); else GatherNullPolicy::DropNulls over the projected fields
+ * (store/projection.rs:1326-1330): a row NULL in all of them is dropped; a window left without rows is no batch. */
+static int32_t join_scan_rows(const orc_table *t, const uint32_t *fields, uint32_t n_fields, int one_batch, join_rows *out) {
+  memset(out, 0, sizeof *out);
+  out->rows = xmalloc((t->rows ? t->rows : 1) * sizeof(uint64_t));
+  out->batch_start = xmalloc((t->rows / ROW_STREAM_CHUNK_SIZE + 2) * sizeof(uint64_t));
+  for (uint64_t w0 = 0; w0 < t->rows; w0 += ROW_STREAM_CHUNK_SIZE) {
+    const uint64_t wn = t->rows - w0 < ROW_STREAM_CHUNK_SIZE ? t->rows - w0 : ROW_STREAM_CHUNK_SIZE, first = out->n;
+    for (uint64_t r = w0; r < w0 + wn; ++r) {
+      int keep = fields == NULL;
+      for (uint32_t j = 0; j < n_fields && !keep; ++j) keep = col_valid(find_col(t, fields[j]), r);
+      if (keep) out->rows[out->n++] = r;
+    }
+    if (out->n > first && (!one_batch || out->n_batches == 0)) out->batch_start[out->n_batches++] = first;
+  }
+  out->batch_start[out->n_batches] = out->n;
+  /* a table whose every row is dropped comes out of the scan as ONE synthetic batch of NULL rows
+   * (llkv-scan/src/execute.rs:385-400, llkv-compute/src/projection.rs:36-66): not restated */
+  if (fields && t->rows && out->n == 0) { join_rows_free(out); return fail(LLKV_UNSUPPORTED, "every row of a join side is NULL in all of its user columns"); }
+  return LLKV_OK;
+}
+
+typedef void (*join_pair_sink)(const uint64_t *left_rows, const uint64_t *right_rows, uint64_t n_pairs, void *user, int32_t *rc);
+
+/* hash_join_stream hash_join.rs:151-335 / the integer fast paths :955-1417 / build_join_match_indices
+ * llkv-executor/src/lib.rs:12458-12581 over the rows the two scans delivered; `fast`: 1 integer fast path, 0 generic
+ * typed-key path, 2 executor rules. */
+static int32_t hash_join_core(const orc_table *left, const orc_table *right, const llkv_join_key *keys, uint32_t n_keys, int jt, uint64_t batch_size,
+                              int fast, const join_rows *L, const join_rows *R, join_pair_sink sink, void *user) {
+  const orc_column *lcs[4], *rcs[4];
+  for (uint32_t i = 0; i < n_keys; ++i) {
+    lcs[i] = find_col(left, keys[i].left_field);
+    rcs[i] = find_col(right, keys[i].right_field);
+    if (!lcs[i] || !rcs[i]) return fail(LLKV_NOT_FOUND, "join key field not found");
+  }
+  /* build: open addressing on the key (first row with that key), chained row lists in insertion order */
+  uint64_t cap = 16;
+  while (cap < R->n * 2 + 16) cap <<= 1;
+  jt_entry *tab = xcalloc(cap, sizeof(jt_entry));
+  uint64_t *next = xmalloc((right->rows ? right->rows : 1) * sizeof(uint64_t));
+  for (uint64_t i = 0; i < R->n; ++i) {
+    const uint64_t r = R->rows[i];
+    next[r] = UINT64_MAX;
+    uint64_t hk;
+    if (!join_row_hash(rcs, keys, n_keys, fast, r, &hk)) continue;
+    uint64_t h = (hk * 0x9E3779B97F4A7C15ULL) & (cap - 1);
+    while (tab[h].used && !join_rows_equal(rcs, tab[h].head, rcs, r, keys, n_keys, fast)) h = (h + 1) & (cap - 1);
+    if (!tab[h].used) { tab[h].used = 1; tab[h].head = tab[h].tail = r; }
+    else { next[tab[h].tail] = r; tab[h].tail = r; }
+  }
+  /* probe: one scan batch at a time (:1010-1070); the generic path cuts every scan batch into slices of batch_size
+   * rows first (:228-246); inside a batch / slice the pairs are flushed after the probe row that brings them to
+   * >= batch_size, and at its end (:1181-1213, :509-565); the executor materialises one batch */
+  uint64_t pcap = 1024, np = 0;
+  uint64_t *pl = xmalloc(pcap * sizeof(uint64_t)), *pr = xmalloc(pcap * sizeof(uint64_t));
+  int32_t rc = LLKV_OK;
+#define JOIN_PUSH(L_, R_) do { if (np == pcap) { pcap *= 2; pl = xrealloc(pl, pcap * sizeof(uint64_t)); pr = xrealloc(pr, pcap * sizeof(uint64_t)); } \
+                               pl[np] = (L_); pr[np] = (R_); ++np; } while (0)
+  for (uint64_t b = 0; b < L->n_batches && rc == LLKV_OK; ++b) {
+    const uint64_t b0 = L->batch_start[b], m = L->batch_start[b + 1] - b0;
+    for (uint64_t idx = 0; idx < m && rc == LLKV_OK; ++idx) {
+      const uint64_t l = L->rows[b0 + idx];
+      int matched = 0;
+      uint64_t h = 0, hk;
+      if (join_row_hash(lcs, keys, n_keys, fast, l, &hk)) {
+        h = (hk * 0x9E3779B97F4A7C15ULL) & (cap - 1);
+        while (tab[h].used && !join_rows_equal(rcs, tab[h].head, lcs, l, keys, n_keys, fast)) h = (h + 1) & (cap - 1);
+        matched = tab[h].used;
+      }
+      switch (jt) {
+      case LLKV_JOIN_INNER:
+        if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) JOIN_PUSH(l, r);
+        break;
+      case LLKV_JOIN_LEFT: /* unmatched left rows padded with NULLs */
+        if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) JOIN_PUSH(l, r);
+        else JOIN_PUSH(l, UINT64_MAX);
+        break;
+      case LLKV_JOIN_SEMI: if (matched) JOIN_PUSH(l, 0); break;
+      case LLKV_JOIN_ANTI: if (!matched) JOIN_PUSH(l, 0); break;
+      }
+      const int boundary = idx + 1 == m || (fast == 0 && (idx + 1) % batch_size == 0);
+      if (np && (np >= batch_size || boundary)) { sink(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user, &rc); np = 0; }
+    }
+  }
+#undef JOIN_PUSH
+  free(pl); free(pr); free(next); free(tab);
+  return rc;
+}
+
+/* validate_join_options llkv-join/src/lib.rs:284-310; hash_join.rs:328-332; llkv-executor/src/lib.rs:12387-12391 */
+static int32_t join_check_options(const llkv_join_options *options, uint32_t n_keys, int *executor, uint64_t *batch_size, int *jt) {
+  *executor = options && options->key_rules == LLKV_JOIN_KEYS_EXECUTOR;
+  *batch_size = *executor ? UINT64_MAX : options ? options->batch_size : 8192;
+  *jt = options ? options->join_type : LLKV_JOIN_INNER;
+  if (*executor && *jt != LLKV_JOIN_INNER && *jt != LLKV_JOIN_LEFT)
+    return fail(LLKV_INTERNAL, "join type not supported in hash_join_table_batches; use llkv-join");
+  if (*executor && n_keys == 0) return fail(LLKV_INVALID_ARGUMENT, "executor join rules need at least one key pair");
+  if (*batch_size == 0) return fail(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero");
+  if (*jt == LLKV_JOIN_RIGHT || *jt == LLKV_JOIN_FULL) return fail(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented");
+  return LLKV_OK;
+}
+/* integer fast path: one key, identical integer key types (hash_join.rs:171-200); everything else takes the generic
+ * typed-key path; 2 = the executor's key rules */
+static int32_t join_path(const orc_table *left, const orc_table *right, const llkv_join_key *keys, uint32_t n_keys, int executor, int *fast) {
+  if (n_keys > 4) return fail(LLKV_UNSUPPORTED, "more than four join key pairs (n_keys=%u)", n_keys);
+  const orc_column *l0 = find_col(left, keys[0].left_field), *r0 = find_col(right, keys[0].right_field);
+  for (uint32_t i = 0; i < n_keys; ++i)
+    if (!find_col(left, keys[i].left_field) || !find_col(right, keys[i].right_field)) return fail(LLKV_NOT_FOUND, "join key field not found");
+  *fast = n_keys == 1 && l0->dtype == r0->dtype &&
+          (l0->dtype == LLKV_DT_INT32 || l0->dtype == LLKV_DT_INT64 || l0->dtype == LLKV_DT_UINT32 || l0->dtype == LLKV_DT_UINT64);
+  if (executor) *fast = 2;
+  return LLKV_OK;
+}
+
+typedef struct pair_fwd { orc_on_join_batch cb; void *user; } pair_fwd;
+static void pair_forward(const uint64_t *l, const uint64_t *r, uint64_t n, void *user, int32_t *rc) { (void)rc; pair_fwd *f = user; f->cb(l, r, n, f->user); }
+
 int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_join_key *keys,
                       uint32_t n_keys, const llkv_join_options *options, orc_on_join_batch on_batch, void *user) {
-  int executor = options && options->key_rules == LLKV_JOIN_KEYS_EXECUTOR;
-  uint64_t batch_size = executor ? UINT64_MAX : options ? options->batch_size : 8192;
-  int jt = options ? options->join_type : LLKV_JOIN_INNER;
-  if (executor && jt != LLKV_JOIN_INNER && jt != LLKV_JOIN_LEFT) /* llkv-executor/src/lib.rs:12387-12391 */
-    return fail(LLKV_INTERNAL, "join type not supported in hash_join_table_batches; use llkv-join");
-  if (executor && n_keys == 0) return fail(LLKV_INVALID_ARGUMENT, "executor join rules need at least one key pair");
-  if (batch_size == 0) return fail(LLKV_INVALID_ARGUMENT, "join batch_size must be greater than zero"); /* llkv-join/src/lib.rs:284-310 */
-  if (jt == LLKV_JOIN_RIGHT || jt == LLKV_JOIN_FULL) return fail(LLKV_INVALID_ARGUMENT, "Right and Full joins are not yet implemented"); /* hash_join.rs:328-332 */
+  int executor, jt, fast = 0;
+  uint64_t batch_size;
+  int32_t rc = join_check_options(options, n_keys, &executor, &batch_size, &jt);
+  if (rc) return rc;
   if (n_keys == 0) { /* cross_product_stream hash_join.rs:1500-1599, cross_join_pair cartesian.rs:22-80 */
     if (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) return fail(LLKV_INTERNAL, "cross join schema mismatch");
     if (right->rows == 0 && jt == LLKV_JOIN_INNER) return LLKV_OK;
@@ -2124,65 +2247,146 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
     }
     return LLKV_OK;
   }
-  if (n_keys > 4) return fail(LLKV_UNSUPPORTED, "more than four join key pairs (n_keys=%u)", n_keys);
-  const orc_column *lcs[4], *rcs[4];
-  for (uint32_t i = 0; i < n_keys; ++i) {
-    lcs[i] = find_col(left, keys[i].left_field);
-    rcs[i] = find_col(right, keys[i].right_field);
-    if (!lcs[i] || !rcs[i]) return fail(LLKV_NOT_FOUND, "join key field not found");
-  }
-  /* integer fast path: one key, identical integer key types (hash_join.rs:171-200); everything else takes the
-   * generic typed-key path */
-  int fast = n_keys == 1 && lcs[0]->dtype == rcs[0]->dtype &&
-             (lcs[0]->dtype == LLKV_DT_INT32 || lcs[0]->dtype == LLKV_DT_INT64 || lcs[0]->dtype == LLKV_DT_UINT32 || lcs[0]->dtype == LLKV_DT_UINT64);
-  if (executor) fast = 2; /* the executor's key rules; one batch: all pairs in probe order */
+  if ((rc = join_path(left, right, keys, n_keys, executor, &fast))) return rc;
+  join_rows L, R;
+  if ((rc = join_scan_rows(left, NULL, 0, executor, &L))) return rc;
+  if ((rc = join_scan_rows(right, NULL, 0, 0, &R))) { join_rows_free(&L); return rc; }
+  pair_fwd f = {on_batch, user};
+  rc = hash_join_core(left, right, keys, n_keys, jt, batch_size, fast, &L, &R, pair_forward, &f);
+  join_rows_free(&L); join_rows_free(&R);
+  return rc;
+}
 
-  /* build: open addressing on the key (first row with that key), chained row lists in insertion order */
-  uint64_t cap = 16;
-  while (cap < right->rows * 2 + 16) cap <<= 1;
-  jt_entry *tab = xcalloc(cap, sizeof(jt_entry));
-  uint64_t *next = xmalloc((right->rows ? right->rows : 1) * sizeof(uint64_t));
-  for (uint64_t r = 0; r < right->rows; ++r) {
-    next[r] = UINT64_MAX;
-    uint64_t hk;
-    if (!join_row_hash(rcs, keys, n_keys, fast, r, &hk)) continue;
-    uint64_t h = (hk * 0x9E3779B97F4A7C15ULL) & (cap - 1);
-    while (tab[h].used && !join_rows_equal(rcs, tab[h].head, rcs, r, keys, n_keys, fast)) h = (h + 1) & (cap - 1);
-    if (!tab[h].used) { tab[h].used = 1; tab[h].head = tab[h].tail = r; }
-    else { next[tab[h].tail] = r; tab[h].tail = r; }
+/* --- the joined RecordBatches ------------------------------------------------------------------------------------
+ * emit_joined_batch / emit_left_joined_batch / emit_semi_batch hash_join.rs:715-772: the probe batch's columns gathered
+ * at the probe rows, then the build batches' at the build rows (None → NULL, gather_optional_indices_from_batches
+ * llkv-column-map/src/gather.rs:167-260); output schema build_output_schema :877-943. */
+typedef struct batch_sink {
+  const orc_table *left, *right;
+  const llkv_join_output *out;
+  int left_only;
+  const char *const *names;
+  orc_on_join_record_batch cb;
+  void *user;
+} batch_sink;
+
+static arr gather_optional(const orc_column *c, const uint64_t *ids, uint64_t n) {
+  uint64_t *safe = xmalloc((n ? n : 1) * sizeof(uint64_t));
+  for (uint64_t i = 0; i < n; ++i) safe[i] = ids[i] == UINT64_MAX ? 0 : ids[i];
+  arr a;
+  int any_row = 0;
+  for (uint64_t i = 0; i < n; ++i) any_row |= ids[i] != UINT64_MAX;
+  if (any_row) a = gather_column(c, safe, n);
+  else { /* nothing to read (the build side may hold no row at all): NULL cells */
+    memset(&a, 0, sizeof a);
+    a.dtype = c->dtype; a.precision = c->precision; a.scale = c->scale; a.n = n;
+    a.valid = xcalloc(n ? n : 1, 1);
+    if (c->dtype == LLKV_DT_UTF8) { a.strings = xcalloc(n ? n : 1, sizeof(char *)); for (uint64_t i = 0; i < n; ++i) a.strings[i] = xcalloc(1, 1); }
+    else a.values = xcalloc(n ? n : 1, dtype_width(c->dtype));
   }
-  /* probe: one scan batch of 65 536 left rows at a time (:1010-1070); the generic path cuts every scan batch
-   * into slices of batch_size rows first (:228-246); inside a batch / slice the pairs are flushed after the
-   * probe row that brings them to >= batch_size, and at its end (:1181-1213, :509-565) */
-  uint64_t pcap = 1024, np = 0;
-  uint64_t *pl = xmalloc(pcap * sizeof(uint64_t)), *pr = xmalloc(pcap * sizeof(uint64_t));
-#define JOIN_PUSH(L_, R_) do { if (np == pcap) { pcap *= 2; pl = xrealloc(pl, pcap * sizeof(uint64_t)); pr = xrealloc(pr, pcap * sizeof(uint64_t)); } \
-                               pl[np] = (L_); pr[np] = (R_); ++np; } while (0)
-  for (uint64_t l = 0; l < left->rows; ++l) {
-    int matched = 0;
-    uint64_t h = 0, hk;
-    if (join_row_hash(lcs, keys, n_keys, fast, l, &hk)) {
-      h = (hk * 0x9E3779B97F4A7C15ULL) & (cap - 1);
-      while (tab[h].used && !join_rows_equal(rcs, tab[h].head, lcs, l, keys, n_keys, fast)) h = (h + 1) & (cap - 1);
-      matched = tab[h].used;
+  for (uint64_t i = 0; i < n; ++i)
+    if (ids[i] == UINT64_MAX) {
+      a.valid[i] = 0;
+      if (a.strings) a.strings[i][0] = 0;
+      else memset((char *)a.values + i * dtype_width(c->dtype), 0, dtype_width(c->dtype));
     }
-    switch (jt) {
-    case LLKV_JOIN_INNER:
-      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) JOIN_PUSH(l, r);
-      break;
-    case LLKV_JOIN_LEFT: /* :1468-1497 unmatched left rows padded with NULLs */
-      if (matched) for (uint64_t r = tab[h].head; r != UINT64_MAX; r = next[r]) JOIN_PUSH(l, r);
-      else JOIN_PUSH(l, UINT64_MAX);
-      break;
-    case LLKV_JOIN_SEMI: if (matched) JOIN_PUSH(l, 0); break;
-    case LLKV_JOIN_ANTI: if (!matched) JOIN_PUSH(l, 0); break;
-    }
-    uint64_t in_win = l % ROW_STREAM_CHUNK_SIZE;
-    int boundary = in_win + 1 == ROW_STREAM_CHUNK_SIZE || l + 1 == left->rows || (!fast && (in_win + 1) % batch_size == 0);
-    if (executor) boundary = l + 1 == left->rows;
-    if (np && (np >= batch_size || boundary)) { on_batch(pl, (jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI) ? NULL : pr, np, user); np = 0; }
+  free(safe);
+  return a;
+}
+
+static void batch_from_pairs(const uint64_t *l, const uint64_t *r, uint64_t n, void *user, int32_t *rc) {
+  (void)rc;
+  batch_sink *b = user;
+  const uint32_t nl = b->out->n_left, nr = b->left_only ? 0 : b->out->n_right, nc = nl + nr;
+  arr *cols = xcalloc(nc ? nc : 1, sizeof(arr));
+  orc_batch_column *bc = xcalloc(nc ? nc : 1, sizeof *bc);
+  for (uint32_t i = 0; i < nl; ++i) cols[i] = gather_column(find_col(b->left, b->out->left_columns[i].field_id), l, n);
+  for (uint32_t i = 0; i < nr; ++i) cols[nl + i] = gather_optional(find_col(b->right, b->out->right_columns[i].field_id), r, n);
+  for (uint32_t i = 0; i < nc; ++i) {
+    bc[i].dtype = cols[i].dtype; bc[i].values = cols[i].values; bc[i].valid = cols[i].valid;
+    bc[i].strings = (const char *const *)cols[i].strings; bc[i].precision = cols[i].precision; bc[i].scale = cols[i].scale;
   }
-#undef JOIN_PUSH
-  free(pl); free(pr); free(next); free(tab);
-  return LLKV_OK;
+  orc_batch ob = {n, nc, bc, NULL};
+  b->cb(&ob, b->names, b->user);
+  for (uint32_t i = 0; i < nc; ++i) arr_free(&cols[i]);
+  free(cols); free(bc);
+}
+
+int32_t orc_hash_join_batches(const orc_table *left, const orc_table *right, const llkv_join_key *keys, uint32_t n_keys,
+                              const llkv_join_options *options, const llkv_join_output *output, orc_on_join_record_batch on_batch, void *user) {
+  int executor, jt, fast = 0;
+  uint64_t batch_size;
+  int32_t rc = join_check_options(options, n_keys, &executor, &batch_size, &jt);
+  if (rc) return rc;
+  const int left_only = jt == LLKV_JOIN_SEMI || jt == LLKV_JOIN_ANTI;
+  const uint32_t nl = output->n_left, nr = output->n_right;
+  for (uint32_t i = 0; i < nl; ++i) if (!find_col(left, output->left_columns[i].field_id)) return fail(LLKV_NOT_FOUND, "join output field %u not found", output->left_columns[i].field_id);
+  for (uint32_t i = 0; i < nr; ++i) if (!find_col(right, output->right_columns[i].field_id)) return fail(LLKV_NOT_FOUND, "join output field %u not found", output->right_columns[i].field_id);
+  /* build_output_schema :877-943: left fields, then right fields, a name already taken gets "_1"; SEMI / ANTI: left only;
+   * the executor keeps the names as given (llkv-executor/src/lib.rs:12237-12244) */
+  char **names = xcalloc(nl + nr + 1, sizeof(char *));
+  uint32_t nn = 0;
+  for (uint32_t i = 0; i < nl; ++i) { const char *s = output->left_columns[i].name ? output->left_columns[i].name : ""; names[nn] = xmalloc(strlen(s) + 1); strcpy(names[nn++], s); }
+  for (uint32_t i = 0; i < nr && !left_only; ++i) {
+    const char *s = output->right_columns[i].name ? output->right_columns[i].name : "";
+    int taken = 0;
+    for (uint32_t k = 0; k < nn && !executor; ++k) taken |= strcmp(names[k], s) == 0;
+    names[nn] = xmalloc(strlen(s) + 3);
+    strcpy(names[nn], s);
+    if (taken) strcat(names[nn], "_1");
+    ++nn;
+  }
+  uint32_t *lf = xmalloc((nl ? nl : 1) * sizeof(uint32_t)), *rf = xmalloc((nr ? nr : 1) * sizeof(uint32_t));
+  for (uint32_t i = 0; i < nl; ++i) lf[i] = output->left_columns[i].field_id;
+  for (uint32_t i = 0; i < nr; ++i) rf[i] = output->right_columns[i].field_id;
+  batch_sink sink = {left, right, output, left_only, (const char *const *)names, on_batch, user};
+  join_rows L, R;
+  memset(&L, 0, sizeof L); memset(&R, 0, sizeof R);
+  /* the executor's tables come with their NULL rows (collect_table_data scans with include_nulls) */
+  if (nr && (rc = join_scan_rows(right, executor ? NULL : rf, nr, 0, &R))) goto done;
+  if (nr == 0) { R.rows = xmalloc(8); R.batch_start = xcalloc(1, 8); } /* no right projections: nothing is scanned (:211-215) */
+  if (n_keys == 0) { /* cross_product_stream :1500-1599 */
+    const int right_empty = R.n == 0;
+    if (right_empty && jt == LLKV_JOIN_INNER) goto done;
+    if (nl == 0) goto done;
+    if ((rc = join_scan_rows(left, lf, nl, 0, &L))) goto done;
+    for (uint64_t lb = 0; lb < L.n_batches && rc == LLKV_OK; ++lb) {
+      const uint64_t l0 = L.batch_start[lb], ln = L.batch_start[lb + 1] - l0;
+      if (right_empty) {
+        if (jt != LLKV_JOIN_LEFT) continue;
+        uint64_t *pr = xmalloc(ln * 8);
+        for (uint64_t i = 0; i < ln; ++i) pr[i] = UINT64_MAX; /* synthesize_left_join_nulls :1468-1497 */
+        batch_from_pairs(L.rows + l0, pr, ln, &sink, &rc);
+        free(pr);
+        continue;
+      }
+      for (uint64_t rb = 0; rb < R.n_batches && rc == LLKV_OK; ++rb) {
+        if (left_only) { rc = fail(LLKV_INTERNAL, "cross join schema mismatch: semi / anti joins deliver left columns only"); break; } /* cartesian.rs:36-44 */
+        const uint64_t r0 = R.batch_start[rb], rn = R.batch_start[rb + 1] - r0, np = ln * rn;
+        uint64_t *pl = xmalloc(np * 8), *pr = xmalloc(np * 8), k = 0;
+        for (uint64_t i = 0; i < ln; ++i) for (uint64_t j = 0; j < rn; ++j) { pl[k] = L.rows[l0 + i]; pr[k++] = R.rows[r0 + j]; }
+        batch_from_pairs(pl, pr, np, &sink, &rc);
+        free(pl); free(pr);
+      }
+    }
+    goto done;
+  }
+  if ((rc = join_path(left, right, keys, n_keys, executor, &fast))) goto done;
+  if (nl == 0) goto done; /* no left projections: nothing is probed (:226) */
+  if ((rc = join_scan_rows(left, executor ? NULL : lf, nl, executor, &L))) goto done;
+  if (fast == 0 && L.n != left->rows) { rc = fail(LLKV_UNSUPPORTED, "generic join path over a probe side with rows that are NULL in every user column"); goto done; } /* (kept in step with the GPU path's limit) */
+  /* a build side without a batch: a LEFT join's gather_optional_indices_from_batches returns no arrays and
+   * RecordBatch::try_new fails on the column count — the fast path logs and drops that error per probe batch
+   * (:1058-1060), the generic path returns it (:313-317) */
+  if (R.n_batches == 0 && jt == LLKV_JOIN_LEFT && !executor) {
+    if (fast == 1 || L.n == 0) goto done;
+    rc = fail(LLKV_INTERNAL, "Invalid argument error: number of columns(%u) must match number of fields(%u) in schema", nl, nl + nr);
+    goto done;
+  }
+  rc = hash_join_core(left, right, keys, n_keys, jt, batch_size, fast, &L, &R, batch_from_pairs, &sink);
+done:
+  join_rows_free(&L); join_rows_free(&R);
+  for (uint32_t i = 0; i < nn; ++i) free(names[i]);
+  free(names); free(lf); free(rf);
+  return rc;
 }

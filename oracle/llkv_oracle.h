@@ -95,6 +95,13 @@ int32_t orc_hash_join(const orc_table *left, const orc_table *right, const llkv_
                       uint32_t n_keys, const llkv_join_options *options,
                       orc_on_join_batch on_batch, void *user);
 
+/* … and the joined RecordBatches (emit :715-772, output schema :877-943, cross product :1500-1599, the executor's
+ * hash_join_table_batches llkv-executor/src/lib.rs:12218-12392): left user columns, right user columns. */
+typedef void (*orc_on_join_record_batch)(const orc_batch *batch, const char *const *column_names, void *user);
+int32_t orc_hash_join_batches(const orc_table *left, const orc_table *right, const llkv_join_key *keys,
+                              uint32_t n_keys, const llkv_join_options *options, const llkv_join_output *output,
+                              orc_on_join_record_batch on_batch, void *user);
+
 /* Chunk-parallel fused variants of the same arithmetic (BASELINE.md §2 mode 2,
  * "best-effort parallel"): per-chunk partial sums combined in chunk order.       */
 int32_t orc_aggregate_parallel(const orc_table *t, const llkv_filter *filters, uint32_t n_filters,

@@ -201,6 +201,19 @@ def groupby(table: OracleTable, predicate, keys: Sequence[int], aggs, order_by_k
     return rows
 
 
+def decode_orc_column(c, n: int) -> list:
+    """One ``orc_batch_column`` of n rows as a list of Python values (None = NULL cell)."""
+    valid = np.frombuffer(C.string_at(c.valid, n), dtype=np.uint8).astype(bool).tolist() if n else []
+    if c.dtype == abi.DT_DECIMAL128:
+        raw = np.frombuffer(C.string_at(c.values, n * 16), dtype=np.uint64).reshape(n, 2)
+        return [abi.i128_from_words(int(raw[i, 0]), int(np.int64(raw[i, 1]))) if valid[i] else None for i in range(n)]
+    if c.dtype == abi.DT_UTF8:
+        return [c.strings[i].decode() if valid[i] else None for i in range(n)]
+    npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
+    raw = np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt).tolist()
+    return [v if ok else None for v, ok in zip(raw, valid)]
+
+
 def scan_stream(table: OracleTable, projections, predicate, include_nulls=False, include_row_ids=False, order=None):
     """Returns the list of batches; each batch = (columns, row_ids) with columns as lists of
     Python values (None = NULL).  ``projections``: field ids or ScalarExpr."""
@@ -219,21 +232,7 @@ def scan_stream(table: OracleTable, projections, predicate, include_nulls=False,
 
     def on_batch(bp, _user):
         b = bp.contents
-        cols = []
-        for ci in range(b.num_columns):
-            c = b.columns[ci]
-            n = b.num_rows
-            valid = [bool(c.valid[i]) for i in range(n)]
-            if c.dtype == abi.DT_DECIMAL128:
-                raw = np.frombuffer(C.string_at(c.values, n * 16), dtype=np.uint64).reshape(n, 2)
-                vals = [abi.i128_from_words(int(raw[i, 0]), int(np.int64(raw[i, 1]))) if valid[i] else None for i in range(n)]
-            elif c.dtype == abi.DT_UTF8:
-                vals = [c.strings[i].decode() if valid[i] else None for i in range(n)]
-            else:
-                npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
-                raw = np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt)
-                vals = [raw[i].item() if valid[i] else None for i in range(n)]
-            cols.append(vals)
+        cols = [decode_orc_column(b.columns[ci], int(b.num_rows)) for ci in range(b.num_columns)]
         rids = [b.row_ids[i] for i in range(b.num_rows)] if b.row_ids else None
         batches.append((cols, rids))
 
@@ -259,4 +258,30 @@ def hash_join(left: OracleTable, right: OracleTable, keys, join_type=abi.JOIN_IN
 
     cb = abi.ON_JOIN_BATCH(on_batch)
     check(lib().orc_hash_join(C.byref(lt), C.byref(rt), ck, C.c_uint32(len(keys)), C.byref(opts), cb, None))
+    return batches
+
+
+ORC_ON_JOIN_RECORD_BATCH = C.CFUNCTYPE(None, C.POINTER(COrcBatch), C.POINTER(C.c_char_p), C.c_void_p)
+
+
+def hash_join_batches(left: OracleTable, right: OracleTable, keys, left_columns, right_columns, join_type=abi.JOIN_INNER, batch_size=8192,
+                      key_rules=0):
+    """orc_hash_join_batches: [(names, columns)] — the reference's joined RecordBatches."""
+    ck = (abi.CJoinKey * max(1, len(keys)))()
+    for i, k in enumerate(keys):
+        ck[i].left_field, ck[i].right_field = k[0], k[1]
+        ck[i].null_equals_null = int(k[2]) if len(k) > 2 else 0
+    opts = abi.CJoinOptions(join_type, batch_size, key_rules)
+    out, keep = abi.join_output(left_columns, right_columns)
+    lt, rt = left.c(), right.c()
+    batches = []
+
+    def on_batch(bp, names, _u):
+        b = bp.contents
+        n = int(b.num_rows)
+        batches.append(([names[i].decode() for i in range(b.num_columns)], [decode_orc_column(b.columns[ci], n) for ci in range(b.num_columns)]))
+
+    cb = ORC_ON_JOIN_RECORD_BATCH(on_batch)
+    check(lib().orc_hash_join_batches(C.byref(lt), C.byref(rt), ck, C.c_uint32(len(keys)), C.byref(opts), C.byref(out), cb, None))
+    del keep
     return batches

@@ -126,6 +126,25 @@ class CJoinOptions(C.Structure):
     _fields_ = [("join_type", C.c_int32), ("batch_size", C.c_uint64), ("key_rules", C.c_int32)]
 
 
+class CJoinColumn(C.Structure):
+    _fields_ = [("field_id", C.c_uint32), ("name", C.c_char_p)]
+
+
+class CJoinOutput(C.Structure):
+    _fields_ = [("left_columns", C.POINTER(CJoinColumn)), ("n_left", C.c_uint32),
+                ("right_columns", C.POINTER(CJoinColumn)), ("n_right", C.c_uint32)]
+
+
+def join_output(left_columns, right_columns):
+    """llkv_join_output from two lists of (field_id, name); returns (struct, keep-alive)."""
+    la = (CJoinColumn * max(1, len(left_columns)))()
+    ra = (CJoinColumn * max(1, len(right_columns)))()
+    for arr, cols in ((la, left_columns), (ra, right_columns)):
+        for i, (fid, name) in enumerate(cols):
+            arr[i].field_id, arr[i].name = fid, name.encode()
+    return CJoinOutput(la, len(left_columns), ra, len(right_columns)), (la, ra)
+
+
 class CColumnDesc(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("rows", C.c_uint64), ("has_stats", C.c_int32),
                 ("min_i", C.c_int64), ("max_i", C.c_int64), ("dict_size", C.c_uint32),
@@ -154,6 +173,7 @@ class CChunkMeta(C.Structure):
 
 ON_BATCH = C.CFUNCTYPE(None, C.POINTER(CBatchView), C.c_void_p)
 ON_JOIN_BATCH = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p)
+ON_JOIN_RECORD_BATCH = C.CFUNCTYPE(None, C.POINTER(CBatchView), C.POINTER(C.c_char_p), C.c_void_p)
 
 
 class LlkvError(Exception):

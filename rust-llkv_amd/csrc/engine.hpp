@@ -358,6 +358,9 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
 
 int run_join(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
              const llkv_join_options *options, llkv_on_join_batch on_batch, void *user);
+int run_join_batches(const Table *left, const Table *right, const llkv_join_key *keys, uint32_t n_keys,
+                     const llkv_join_options *options, const llkv_join_output *output, llkv_on_join_record_batch on_batch, void *user);
+int join_output_names_c(const llkv_join_output *output, int32_t join_type, int32_t key_rules, char **names, uint32_t *n_names);
 
 void fold_exchange_host(const uint64_t *exchange, const uint8_t *lane_ops, uint32_t lanes, uint64_t *state);
 int finalize_value(const AggOut &a, const uint64_t *group_lanes, int base, llkv_value *out, std::string *err, bool prefixes_checked);

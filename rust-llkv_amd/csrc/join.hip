@@ -32,6 +32,7 @@ struct KeyTuple {
 };
 __device__ __forceinline__ bool load_tuple(const JoinKeySet &ks, uint64_t row, KeyTuple *out) {
   out->nulls = 0;
+  if (ks.live && !ks.live[row]) return false;
 #pragma unroll
   for (uint32_t i = 0; i < kMaxJoinKeys; ++i) {
     if (i >= ks.n) break;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void hj_probe_count_kernel(ProbeParams p) {
       case 4: cnt = m ? 1 : 0; break;
       default: cnt = m ? 0 : 1; break;
       }
+      if (p.lkey.live && !p.lkey.live[td.dev_row + r]) cnt = 0; // the probe scan never delivered this row
     }
     p.counts[pos] = cnt;
     p.match_slot[pos] = mslot;
@@ -283,6 +285,111 @@ __global__ __launch_bounds__(256) void hj_probe_write_kernel(ProbeParams p) {
 hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s) {
   if (p.n_tiles == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_probe_write_kernel, dim3(p.n_tiles, kProbeSplit), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_probe_write_rows_kernel(ProbeParams p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  for (uint32_t r = blockIdx.y * blockDim.x + threadIdx.x; r < td.rows; r += blockDim.x * gridDim.y) {
+    const uint64_t pos = (uint64_t)blockIdx.x * p.tile_rows + r;
+    const uint64_t cnt = p.counts[pos];
+    if (cnt == 0) continue;
+    uint64_t o = p.offsets[pos];
+    // the batch of this probe row's pairs = cuts at or below their first index (a batch never ends inside a probe row)
+    uint32_t lo = 0, hi = p.n_cuts;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (p.cuts[mid] <= o) lo = mid + 1; else hi = mid;
+    }
+    o = (uint64_t)((int64_t)o + p.batch_shift[lo]);
+    const uint64_t lrow = td.dev_row + r;
+    const uint32_t ms = p.match_slot[pos];
+    if (p.join_type == 0 || (p.join_type == 1 && ms != 0xFFFFFFFFu)) {
+      const uint32_t st = p.seg_start[ms];
+      for (uint64_t i = 0; i < cnt; ++i) {
+        p.out_left[o + i] = lrow;
+        p.out_right[o + i] = p.build_dev[p.sorted_idx[st + i]];
+      }
+    } else {
+      p.out_left[o] = lrow;
+      if (p.out_right) p.out_right[o] = ~0ull; // LEFT: NULL-padded right side; SEMI/ANTI: no right side
+    }
+  }
+}
+hipError_t hj_launch_probe_write_rows(const ProbeParams &p, hipStream_t s) {
+  if (p.n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_probe_write_rows_kernel, dim3(p.n_tiles, kProbeSplit), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// One thread per segment walks the segment's chain of size cuts (each a binary search in the scan).  A step has a few
+// dozen segments on the integer fast path; the generic path's slices make it (positions / batch_size).
+__global__ __launch_bounds__(256) void hj_batch_cuts_kernel(CutParams p) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.n_seg) {
+    if (k == p.n_seg && !p.cuts) p.seg_cuts[k] = 0; // so that the exclusive scan's last entry is the total
+    return;
+  }
+  const uint32_t pa = p.seg_pos[k], pb = p.seg_pos[k + 1];
+  uint64_t start = p.offsets[pa];
+  const uint64_t end = p.offsets[pb];
+  uint64_t pend = k == 0 ? p.carry_in : 0; // only the first segment of a step continues a batch (every other one follows a forced cut)
+  uint64_t n = 0, *out = p.cuts ? p.cuts + p.seg_cut_base[k] : nullptr;
+  while (pend + (end - start) >= p.batch_size) {
+    const uint64_t j = start + (p.batch_size - pend) - 1; // the pair that fills the batch …
+    uint32_t lo = pa, hi = pb;                            // … belongs to the last position whose pairs start at or below j
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (p.offsets[mid] <= j) lo = mid; else hi = mid;
+    }
+    start = p.offsets[lo + 1];                            // … and the batch ends with the rest of that probe row
+    if (out) out[n] = start;
+    ++n;
+    pend = 0;
+  }
+  const bool open = p.last_open && k + 1 == p.n_seg;
+  if (!open && pend + (end - start) > 0) {
+    if (out) out[n] = end;
+    ++n;
+    start = end;
+    pend = 0;
+  }
+  if (!p.cuts) p.seg_cuts[k] = n;
+  else if (k + 1 == p.n_seg) *p.carry_out = pend + (end - start);
+}
+hipError_t hj_launch_batch_cuts(const CutParams &p, hipStream_t s) {
+  hipLaunchKernelGGL(hj_batch_cuts_kernel, dim3((p.n_seg + 1 + 255) / 256), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_live_mask_kernel(LiveMaskCols cols, const TileDesc *tiles, uint8_t *live, unsigned long long *dead) {
+  const TileDesc td = tiles[blockIdx.x];
+  uint32_t mine = 0;
+  for (uint32_t r = threadIdx.x; r < td.rows; r += blockDim.x) {
+    const uint64_t row = td.dev_row + r;
+    uint8_t any = 0;
+    for (uint32_t c = 0; c < cols.n; ++c) any |= cols.valid[c][row];
+    live[row] = any ? 1 : 0;
+    mine += any ? 0 : 1;
+  }
+  if (mine) atomicAdd(dead, (unsigned long long)mine);
+}
+hipError_t hj_launch_live_mask(const LiveMaskCols &cols, const TileDesc *tiles, uint32_t n_tiles, uint8_t *live, unsigned long long *dead, hipStream_t s) {
+  if (n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_live_mask_kernel, dim3(n_tiles), dim3(256), 0, s, cols, tiles, live, dead);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hj_cross_rows_kernel(const uint64_t *lrows, uint64_t ln, const uint64_t *rrows, uint64_t rn, uint64_t *out_left, uint64_t *out_right) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ln * rn) return;
+  out_left[i] = lrows[i / rn];
+  out_right[i] = rrows[i % rn];
+}
+hipError_t hj_launch_cross_rows(const uint64_t *lrows, uint64_t ln, const uint64_t *rrows, uint64_t rn, uint64_t *out_left, uint64_t *out_right, hipStream_t s) {
+  const uint64_t n = ln * rn;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_cross_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, lrows, ln, rrows, rn, out_left, out_right);
   return hipGetLastError();
 }
 

@@ -53,6 +53,10 @@ struct JoinKeyPart {
 struct JoinKeySet {
   JoinKeyPart k[4];
   uint32_t n;
+  // 1 B/row mask or nullptr: a row with 0 is not part of the join at all — the reference's scan of the side dropped it
+  // (NULL in every user column, GatherNullPolicy::DropNulls): it is not built, matches nothing and a LEFT / ANTI join
+  // does not emit it (join_emit.cpp)
+  const uint8_t *live;
 };
 constexpr uint32_t kMaxJoinKeys = 4;
 
@@ -111,9 +115,48 @@ struct ProbeParams {
   uint32_t *match_slot;                  // [n_tiles * tile_rows] matching slot or UINT32_MAX
   const uint64_t *offsets;               // exclusive scan of counts
   uint64_t *out_left, *out_right;        // pair output
+  // hj_launch_probe_write_rows: device row indices in the batch layout of join_emit.cpp
+  const uint64_t *build_dev;             // compact build index → device row
+  const uint64_t *cuts;                  // pair index where batch b + 1 of this step starts, ascending
+  uint32_t n_cuts;
+  const int64_t *batch_shift;            // [n_cuts + 1] position of a batch's pairs in the output − their pair index
 };
 hipError_t hj_launch_probe_count(const ProbeParams &p, hipStream_t s);
 hipError_t hj_launch_probe_write(const ProbeParams &p, hipStream_t s);
+// The write pass for device-side materialisation: out_left / out_right receive DEVICE row indices (right: ~0 = the NULL
+// padding of a LEFT join) at pair index + batch_shift[batch of the pair] — every batch of the step starts on a multiple
+// of 64 rows, so the gather kernels pack validity words that belong to one batch.
+hipError_t hj_launch_probe_write_rows(const ProbeParams &p, hipStream_t s);
+
+// Where the reference cuts the pairs of a probe step into batches, from the exclusive scan of the per-position pair
+// counts alone (hash_join.rs:1181-1213, :509-565): the step's positions are cut into segments [seg_pos[k], seg_pos[k+1])
+// — a scan batch of 65 536 probe rows, or a slice of batch_size rows of it on the generic path — inside a segment a batch
+// ends after the probe row that brings it to >= batch_size pairs, and at the segment's end (unless `last_open`: the
+// segment goes on in the next step).  `carry_in` / `carry_out`: pairs of the running batch left over by the previous step /
+// by this one.  Pass 1 (cuts == nullptr) counts the cuts of every segment into seg_cuts[k]; pass 2 writes
+// them at seg_cut_base[k] (the exclusive scan of the counts).
+struct CutParams {
+  const uint64_t *offsets;
+  const uint32_t *seg_pos; // [n_seg + 1]
+  uint32_t n_seg, last_open;
+  uint64_t batch_size;
+  uint64_t carry_in;
+  uint64_t *carry_out;     // device word
+  uint64_t *seg_cuts;      // [n_seg + 1], pass 1 (entry n_seg = 0)
+  const uint64_t *seg_cut_base;
+  uint64_t *cuts;          // pass 2
+};
+hipError_t hj_launch_batch_cuts(const CutParams &p, hipStream_t s);
+
+// live[dev row] = some column of `valid` (1 B/row masks, up to 32) holds a value in this row; *dead += rows without any
+struct LiveMaskCols {
+  const uint8_t *valid[32];
+  uint32_t n;
+};
+hipError_t hj_launch_live_mask(const LiveMaskCols &cols, const TileDesc *tiles, uint32_t n_tiles, uint8_t *live, unsigned long long *dead, hipStream_t s);
+
+// Cross product of two windows of selected rows (device row lists), left-major: pair i = (lrows[i / rn], rrows[i % rn])
+hipError_t hj_launch_cross_rows(const uint64_t *lrows, uint64_t ln, const uint64_t *rrows, uint64_t rn, uint64_t *out_left, uint64_t *out_right, hipStream_t s);
 
 // ---- join → GROUP BY → top-k pipeline pieces (join_agg.cpp) ---------------------------
 // Claim the keys of the listed build rows; *dup_flag is set when a key occurs twice.

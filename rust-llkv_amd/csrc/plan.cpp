@@ -1587,7 +1587,7 @@ int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint3
 }
 
 int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,
-                     LoweredPlan *out, std::string *err) {
+                     LoweredPlan *out, std::string *err, bool pad_rows) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, false};
   if (n_projections == 0) return L.fail(LLKV_INVALID_ARGUMENT, "scan requires at least one projection");
@@ -1622,9 +1622,11 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
       out->out_fields.push_back((int32_t)pr.field_id);
       std::string v;
       if ((rc = L.valid_of_field(pr.field_id, &v))) return rc;
+      if (pad_rows) v = v.empty() ? "RowPresent" : "And<RowPresent," + v + ">"; // NULL padding of a LEFT join (select.hip.h: ProjPlan PAD)
       if (!v.empty()) node = "OutV<" + node + "," + v + ">";
       out->out_nullable.push_back(!v.empty());
     } else {
+      if (pad_rows) return L.fail(LLKV_INVALID_ARGUMENT, "join projections cannot include computed columns yet"); // hash_join.rs:822-826
       bool is_f64 = false;
       if (!pr.expr || pr.expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "computed projection without expression");
       if (pr.expr_len == 1 && pr.expr[0].kind == LLKV_TOK_COLUMN) { // bare column written as an expression
@@ -1653,7 +1655,7 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
     }
     outs += (i ? "," : "") + node;
   }
-  out->type_string = "ProjPlan<" + cols_string(*out, &out->bytes_per_row) + "," + outs + ">>";
+  out->type_string = "ProjPlan<" + cols_string(*out, &out->bytes_per_row) + "," + outs + (pad_rows ? ">,1>" : ">>");
   return LLKV_OK;
 }
 

@@ -140,8 +140,9 @@ int lower_selection_in_set(const ColumnResolver &resolve, const llkv_filter *fil
                            LoweredPlan *out, std::string *err);
 // Scan projections (ScanProjection::{Column,Computed}, llkv-scan/src/lib.rs:59-65) →
 // "ProjPlan<Cols<…>,Outs<…>>" (window gather + computed expressions).
+// `pad_rows`: a row index of ~0 yields a NULL in every output (the build side of a LEFT join)
 int lower_projection(const ColumnResolver &resolve, const llkv_projection *projections, uint32_t n_projections,
-                     LoweredPlan *out, std::string *err);
+                     LoweredPlan *out, std::string *err, bool pad_rows = false);
 
 // Fact side of a join → aggregate pipeline → "ProbePlan<Cols<…>,pred,KeyExpr,ValExpr>" (select.hip.h).
 // The aggregate argument follows the GROUP BY (PlanValue) semantics and must be Float64.

@@ -341,9 +341,15 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint64_t *in
 
 // ---- window projection ---------------------------------------------------------------
 template <class... Es> struct Outs { static constexpr int N = sizeof...(Es); };
-template <class CL, class OT> struct ProjPlan {
+// PAD = 1 (the build side of a LEFT join, join_emit.cpp): a row index of ~0 is the NULL padding of an unmatched
+// probe row — nothing is gathered for it (row 0 stands in) and `RowPresent` clears the validity bit of every output.
+template <class CL, class OT, int PAD = 0> struct ProjPlan {
   using ColList = CL;
   using OutT = OT;
+  static constexpr int kPad = PAD;
+};
+struct RowPresent {
+  static __device__ __forceinline__ bool eval(Ctx &c, int) { return c.row != ~0ull; }
 };
 
 template <class Ty> __device__ __forceinline__ void load_one(const void *base, uint64_t row, uint32_t (&w)[4]) {
@@ -399,7 +405,7 @@ template <class P> __device__ __forceinline__ void project_body(const ProjParams
   for (int k = 0; k < kMaxLits; ++k) { sp.lit_i[k] = pp.lit_i[k]; sp.lit_f[k] = pp.lit_f[k]; }
   Loaded ld;
   const uint64_t row = pp.dev_rows[i];
-  gather_all<typename P::ColList>(pp, row, ld);
+  gather_all<typename P::ColList>(pp, P::kPad && row == ~0ull ? 0ull : row, ld);
   Ctx c{sp, ld, 0u, row};
   StoreOuts<typename P::OutT>::run(pp, c, i);
   if (c.err) atomicOr(pp.error_flag + (pp.error_stride ? i / pp.error_stride : 0u), c.err);

@@ -393,4 +393,14 @@ llkv_status llkv_hip_join_stream(const llkv_hip_table *left, const llkv_hip_tabl
   return (llkv_status)run_join(reinterpret_cast<const Table *>(left), reinterpret_cast<const Table *>(right), keys, n_keys, options, on_batch, user);
 }
 
+llkv_status llkv_hip_join_stream_batches(const llkv_hip_table *left, const llkv_hip_table *right, const llkv_join_key *keys, uint32_t n_keys,
+                                         const llkv_join_options *options, const llkv_join_output *output, llkv_on_join_record_batch on_batch,
+                                         void *user) {
+  return (llkv_status)run_join_batches(reinterpret_cast<const Table *>(left), reinterpret_cast<const Table *>(right), keys, n_keys, options, output, on_batch, user);
+}
+
+llkv_status llkv_hip_join_output_names(const llkv_join_output *output, int32_t join_type, int32_t key_rules, char **names, uint32_t *n_names) {
+  return (llkv_status)join_output_names_c(output, join_type, key_rules, names, n_names);
+}
+
 } // extern "C"

@@ -668,6 +668,26 @@ def batch_to_arrow(batch_view, names: Optional[Sequence[str]] = None):
     return pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
 
 
+def decode_view_column(c, n: int) -> list:
+    """One ``llkv_column_view`` of n rows as a list of Python values (None = NULL cell)."""
+    if c.dtype == abi.DT_DECIMAL128:
+        raw = np.frombuffer(C.string_at(c.values, n * 16), dtype=np.uint64).reshape(n, 2)
+        vals = [abi.i128_from_words(int(lo), int(np.int64(hi))) for lo, hi in raw]
+    elif c.dtype == abi.DT_UTF8:
+        codes = np.frombuffer(C.string_at(c.values, n), dtype=np.uint8)
+        vals = [c.dictionary[int(k)].decode() for k in codes] if not c.validity else None
+        if vals is None:  # a NULL cell's code may be any byte
+            bits = np.unpackbits(np.frombuffer(C.string_at(c.validity, (n + 7) // 8), dtype=np.uint8), bitorder="little")[:n]
+            return [c.dictionary[int(k)].decode() if ok else None for k, ok in zip(codes, bits)]
+    else:
+        npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
+        vals = np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt).tolist()
+    if c.validity:  # Arrow validity bitmap → None for NULL cells
+        bits = np.unpackbits(np.frombuffer(C.string_at(c.validity, (n + 7) // 8), dtype=np.uint8), bitorder="little")[:n]
+        vals = [v if ok else None for v, ok in zip(vals, bits)]
+    return vals
+
+
 def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = False, include_row_ids: bool = False, order=None, consume=None):
     """StorageTable::scan_stream: returns the list of batches [(columns, row_ids)], each column a list of
     Python values.  ``projections``: field ids (ScanProjection::Column) or ScalarExpr (::Computed).
@@ -691,22 +711,7 @@ def scan_stream(table: HipTable, projections, predicate, include_nulls: bool = F
             consume(b)
             return
         n = int(b.num_rows)
-        cols = []
-        for ci in range(b.num_columns):
-            c = b.columns[ci]
-            if c.dtype == abi.DT_DECIMAL128:
-                raw = np.frombuffer(C.string_at(c.values, n * 16), dtype=np.uint64).reshape(n, 2)
-                vals = [abi.i128_from_words(int(lo), int(np.int64(hi))) for lo, hi in raw]
-            elif c.dtype == abi.DT_UTF8:
-                codes = np.frombuffer(C.string_at(c.values, n), dtype=np.uint8)
-                vals = [c.dictionary[int(k)].decode() for k in codes]
-            else:
-                npdt = np.dtype(abi.NUMPY_OF_DTYPE[c.dtype])
-                vals = np.frombuffer(C.string_at(c.values, n * npdt.itemsize), dtype=npdt).tolist()
-            if c.validity:  # Arrow validity bitmap → None for NULL cells
-                bits = np.unpackbits(np.frombuffer(C.string_at(c.validity, (n + 7) // 8), dtype=np.uint8), bitorder="little")[:n]
-                vals = [v if ok else None for v, ok in zip(vals, bits)]
-            cols.append(vals)
+        cols = [decode_view_column(b.columns[ci], n) for ci in range(b.num_columns)]
         rids = np.frombuffer(C.string_at(b.row_ids, n * 8), dtype=np.uint64).tolist() if b.row_ids else None
         batches.append((cols, rids))
 
@@ -738,6 +743,54 @@ def join_stream(left: HipTable, right: HipTable, keys, join_type: int = abi.JOIN
     cb = abi.ON_JOIN_BATCH(on_batch)
     check(lib().llkv_hip_join_stream(left.handle, right.handle, ck, C.c_uint32(len(keys)), C.byref(opts), cb, None))
     return batches
+
+
+def _join_keys(keys):
+    ck = (abi.CJoinKey * max(1, len(keys)))()
+    for i, k in enumerate(keys):
+        ck[i].left_field, ck[i].right_field = k[0], k[1]
+        ck[i].null_equals_null = int(k[2]) if len(k) > 2 else 0
+    return ck
+
+
+def join_stream_batches(left: HipTable, right: HipTable, keys, left_columns, right_columns, join_type: int = abi.JOIN_INNER,
+                        batch_size: int = 8192, key_rules: int = 0, consume=None):
+    """TableJoinExt::join_stream delivering the joined RecordBatches (llkv_hip_join_stream_batches):
+    ``left_columns`` / ``right_columns`` = [(field_id, name)] — the user columns of the two schemas.  Returns
+    [(names, columns)], each column a list of Python values (None = NULL).  ``consume(batch_view, names)``: called
+    with every raw view instead (buffers valid during the call only)."""
+    out, keep = abi.join_output(left_columns, right_columns)
+    opts = abi.CJoinOptions(join_type, batch_size, key_rules)
+    batches = []
+
+    def on_batch(bp, names, _u):
+        b = bp.contents
+        nm = [names[i].decode() for i in range(b.num_columns)]
+        if consume is not None:
+            consume(b, nm)
+            return
+        assert not b.row_ids
+        n = int(b.num_rows)
+        batches.append((nm, [decode_view_column(b.columns[ci], n) for ci in range(b.num_columns)]))
+
+    cb = abi.ON_JOIN_RECORD_BATCH(on_batch)
+    check(lib().llkv_hip_join_stream_batches(left.handle, right.handle, _join_keys(keys), C.c_uint32(len(keys)), C.byref(opts), C.byref(out), cb, None))
+    del keep
+    return batches
+
+
+def join_output_names(left_columns, right_columns, join_type: int = abi.JOIN_INNER, key_rules: int = 0) -> List[str]:
+    """build_output_schema's names (llkv_hip_join_output_names; host only)."""
+    out, keep = abi.join_output(left_columns, right_columns)
+    names = (C.c_void_p * (len(left_columns) + len(right_columns) + 1))()
+    n = C.c_uint32()
+    check(lib().llkv_hip_join_output_names(C.byref(out), C.c_int32(join_type), C.c_int32(key_rules), names, C.byref(n)))
+    res = []
+    for i in range(n.value):
+        res.append(C.string_at(names[i]).decode())
+        lib().llkv_hip_free(C.c_void_p(names[i]))
+    del keep
+    return res
 
 
 def join_groupby_topk(fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, sum_expr,

@@ -1331,6 +1331,216 @@ def test_reference_join_known_answers(rt, abi, case):
         assert ls == case["expect_left"] and all(b[1] is None for b in batches)
 
 
+JOIN_COLS = [(1, "user_id"), (2, "name")]  # create_test_table join_tests.rs:18-53
+
+
+@pytest.mark.parametrize("case", JOINS["cases"], ids=lambda c: c["name"])
+def test_reference_join_record_batches(rt, abi, case):
+    """llkv-join/tests/join_tests.rs through llkv_hip_join_stream_batches — what the reference's `on_batch` receives:
+    `expect_columns`, the output names (left, right, `_1`) and every cell of the joined rows, gathered on the device."""
+    from test_oracle_golden import check_join_batches
+    left, right = _join_side(rt, abi, case["left"]), _join_side(rt, abi, case["right"])
+    keys = [] if case.get("cross") else [(1, 1)]
+    if "expect_error" in case:
+        with pytest.raises(abi.LlkvError) as e:
+            rt.join_stream_batches(left, right, keys, JOIN_COLS, JOIN_COLS, JT[case["type"]], case.get("batch_size", 8192))
+        assert e.value.kind == case["expect_error"]
+        return
+    check_join_batches(case, rt.join_stream_batches(left, right, keys, JOIN_COLS, JOIN_COLS, JT[case["type"]], case.get("batch_size", 8192)))
+
+
+def test_reference_join_record_batches_expression_filters(rt, abi):
+    """join_tests.rs:470-558 on the joined batches themselves (columns 0, 2, 5, 6 as the reference reads them)."""
+    from test_oracle_golden import check_expression_filter_batches
+    c = golden("join_filters.json")["expression_filters"]
+    def mk(tid, cols):
+        t = rt.HipTable(tid, [len(cols[0]["values"])])
+        for col in cols:
+            if col["dtype"] == "Utf8":
+                t.append_utf8_column(col["field_id"], col["values"])
+            else:
+                t.append_column(col["field_id"], DTYPES[col["dtype"]], np.array(col["values"], dtype=abi.NUMPY_OF_DTYPE[DTYPES[col["dtype"]]]))
+        return t
+    left, right = mk(41, c["left"]["columns"]), mk(84, c["right"]["columns"])
+    lcols = [(col["field_id"], nm) for col, nm in zip(c["left"]["columns"], ["customer_id", "segment", "annual_revenue", "loyalty_score"])]
+    rcols = [(col["field_id"], nm) for col, nm in zip(c["right"]["columns"], ["order_id", "customer_id", "avg_order_value", "trailing_spend"])]
+    check_expression_filter_batches(c, rt.join_stream_batches(left, right, [tuple(k) for k in c["join_keys"]], lcols, rcols, JT["inner"]))
+
+
+def _wide_join_tables(rt, orc, abi, n_left, n_right, keyspace, chunks_left=None, seed=0, key_dtype=None, all_nullable=False):
+    """Two tables with a key and a mix of payload types (Int64 / Float64 / Int32 / Date32 / Utf8 / Decimal128 / nullable
+    columns — seven user columns a side, so every gather runs in two launches), staged on both engines."""
+    rng = np.random.default_rng(seed + n_left + 3 * n_right)
+    key_dtype = key_dtype or abi.DT_INT64
+    npk = np.dtype(abi.NUMPY_OF_DTYPE[key_dtype])
+    words = ["ash", "birch", "cedar", "<NULL>", "elm", ""]
+    def side(tid, n, chunks, lo, hi, base):
+        ht, ot = rt.HipTable(tid, chunks or [n]), orc.OracleTable(n)
+        kv = rng.random(n) > 0.05
+        cols = [(base + 1, key_dtype, rng.integers(lo, hi, size=n).astype(npk), kv if all_nullable or tid == 1 else None),
+                (base + 2, abi.DT_FLOAT64, rng.normal(size=n), (rng.random(n) > 0.2) if all_nullable else None),
+                (base + 3, abi.DT_INT32, rng.integers(-5, 5, size=n).astype(np.int32), rng.random(n) > 0.3),
+                (base + 4, abi.DT_DATE32, rng.integers(8000, 9000, size=n).astype(np.int32), (rng.random(n) > 0.2) if all_nullable else None),
+                (base + 6, abi.DT_INT64, rng.integers(-2**62, 2**62, size=n), rng.random(n) > 0.5)]
+        for f, dt, vals, valid in cols:
+            ht.append_column(f, dt, vals, valid=valid)
+            ot.add(f, dt, vals, None if valid is None else list(valid))
+        strs = [words[i] for i in rng.integers(0, len(words), size=n)]
+        sv = rng.random(n) > 0.25
+        ht.append_utf8_column(base + 5, strs, valid=sv)
+        ot.add(base + 5, abi.DT_UTF8, [s if ok else None for s, ok in zip(strs, sv)])
+        dec = [int(v) for v in rng.integers(-10**12, 10**12, size=n)]
+        dv = rng.random(n) > 0.1
+        ht.append_decimal128_column(base + 7, 15, 2, dec, valid=dv)
+        ot.add(base + 7, abi.DT_DECIMAL128, dec, list(dv), precision=15, scale=2)
+        names = ["key", "f", "i32", "d", "big", "s", "dec"]
+        return ht, ot, [(base + 1 + i if i < 4 else base + {4: 6, 5: 5, 6: 7}[i], names[i]) for i in range(7)]
+    lt, ol, lcols = side(1, n_left, chunks_left, -keyspace, keyspace, 0)
+    rtab, orr, rcols = side(2, n_right, None, -keyspace // 2, 2 * keyspace, 10)
+    return lt, rtab, ol, orr, lcols, rcols
+
+
+def _same_batches(got, want, what=""):
+    assert len(got) == len(want), (what, len(got), len(want))
+    assert [names for names, _ in got] == [names for names, _ in want], what
+    assert [len(cols[0]) for _, cols in got] == [len(cols[0]) for _, cols in want], what  # the reference's batch cuts
+    for (_, g), (_, w) in zip(got, want):
+        for ci, (gc, wc) in enumerate(zip(g, w)):
+            if gc != wc:  # NaN-free columns: plain equality of the cells (None = NULL)
+                bad = next(i for i, (a, b) in enumerate(zip(gc, wc)) if a != b)
+                raise AssertionError(f"{what}: column {ci} row {bad}: {gc[bad]!r} != {wc[bad]!r}")
+
+
+@pytest.mark.parametrize("n_left,n_right,keyspace,batch,chunks", [(1000, 300, 50, 8192, None), (150_000, 40_000, 30_000, 8192, [65536, 70000, 14464]),
+                                                                   (70_000, 10, 3, 1000, [4096, 60000, 5904]), (5, 20_000, 1000, 7, None),
+                                                                   (9000, 700, 200, 1, [1000, 8000])])
+@pytest.mark.parametrize("jt", ["inner", "left", "semi", "anti"])
+def test_random_join_record_batches_match_oracle(rt, orc, abi, n_left, n_right, keyspace, batch, chunks, jt):
+    """Whole joined batches against an oracle that gathers the way the reference does: names, batch cuts, every cell
+    (NULL keys, NULL payload cells, NULL padding of LEFT joins, Utf8 / Decimal128 / Date32 columns, ragged chunks so that
+    device steps end inside a reference batch, many-to-many keys, batch_size 1)."""
+    lt, rtab, ol, orr, lcols, rcols = _wide_join_tables(rt, orc, abi, n_left, n_right, keyspace, chunks)
+    got = rt.join_stream_batches(lt, rtab, [(1, 11)], lcols, rcols, JT[jt], batch)
+    want = orc.hash_join_batches(ol, orr, [(1, 11)], lcols, rcols, JT[jt], batch)
+    _same_batches(got, want, jt)
+    assert len(want) > 0
+
+
+def test_join_record_batches_generic_path_and_executor_rules(rt, orc, abi):
+    """Composite / mixed keys (the generic typed-key path: slices of batch_size probe rows) and the executor's rules
+    (one batch per device step here, ONE batch in the reference: compared as the concatenation)."""
+    lt, rtab, ol, orr, lcols, rcols = _wide_join_tables(rt, orc, abi, 40_000, 9000, 300, [30_000, 10_000], seed=7)
+    small = _wide_join_tables(rt, orc, abi, 3000, 150, 300, [1000, 2000], seed=8)  # low-cardinality keys: many-to-many
+    for keys, tabs in (([(1, 11), (3, 13)], None), ([(1, 11, True), (3, 13, True)], None), ([(5, 15)], small), ([(5, 15, True)], small), ([(3, 13)], small)):
+        a, b, oa, ob, lc, rc_ = tabs or (lt, rtab, ol, orr, lcols, rcols)
+        for jt in ("inner", "left", "semi", "anti"):
+            for batch in (8192, 100):
+                _same_batches(rt.join_stream_batches(a, b, keys, lc, rc_, JT[jt], batch), orc.hash_join_batches(oa, ob, keys, lc, rc_, JT[jt], batch), (keys, jt, batch))
+    for jt in ("inner", "left"):
+        got = rt.join_stream_batches(lt, rtab, [(1, 11), (3, 13)], lcols, rcols, JT[jt], key_rules=1)
+        want = orc.hash_join_batches(ol, orr, [(1, 11), (3, 13)], lcols, rcols, JT[jt], key_rules=1)
+        assert len(want) == 1 and all(names == want[0][0] for names, _ in got)
+        assert want[0][0][7:] == [nm for _, nm in rcols]  # the executor keeps the names as given (no `_1`)
+        cat = [[v for _, cols in got for v in cols[ci]] for ci in range(len(want[0][1]))]
+        assert cat == want[0][1]
+
+
+def test_join_record_batches_drop_rows_null_in_every_column(rt, orc, abi):
+    """The reference reads both sides with scan_stream's DropNulls gather: a row that is NULL in EVERY user column never
+    reaches the join — not built, not probed, not padded by a LEFT join, not listed by an ANTI join."""
+    lt, rtab, ol, orr, lcols, rcols = _wide_join_tables(rt, orc, abi, 70_000, 3000, 500, [40_000, 30_000], seed=3, all_nullable=True)
+    # two columns a side, both nullable: a fifth of the rows is NULL in both
+    lsub, rsub = [lcols[0], lcols[2]], [rcols[0], rcols[2]]
+    for jt in ("inner", "left", "semi", "anti"):
+        got = rt.join_stream_batches(lt, rtab, [(1, 11, True)], lsub, rsub, JT[jt], 500)
+        want = orc.hash_join_batches(ol, orr, [(1, 11, True)], lsub, rsub, JT[jt], 500)
+        _same_batches(got, want, jt)
+    rows = sum(len(c[0]) for _, c in orc.hash_join_batches(ol, orr, [(1, 11)], lsub, rsub, JT["left"], 500))
+    assert rows < sum(len(b[0]) for b in orc.hash_join(ol, orr, [(1, 11)], JT["left"], 500))  # the index-pair delivery lists every row
+    # the generic path counts its slices in surviving rows: not on the GPU path (nor restated)
+    for m, a, b in ((rt, lt, rtab), (orc, ol, orr)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.join_stream_batches(a, b, [(1, 11), (3, 13)], lsub, rsub, JT["inner"]) if m is rt else m.hash_join_batches(a, b, [(1, 11), (3, 13)], lsub, rsub, JT["inner"])
+        assert e.value.kind == "Unsupported"
+
+
+def test_join_record_batches_edge_cases(rt, orc, abi):
+    """Empty sides, no columns on a side, the reference's LEFT-join-without-a-build-batch behaviour, cross products with
+    NULL padding, SEMI / ANTI cross products."""
+    lt, rtab, ol, orr, lcols, rcols = _wide_join_tables(rt, orc, abi, 3000, 500, 100, seed=11)
+    e_h = rt.HipTable(3, [0]); e_o = orc.OracleTable(0)
+    for f, dt in ((11, abi.DT_INT64), (13, abi.DT_INT32)):
+        e_h.append_column(f, dt, np.zeros(0, dtype=abi.NUMPY_OF_DTYPE[dt])); e_o.add(f, dt, np.zeros(0, dtype=abi.NUMPY_OF_DTYPE[dt]))
+    ecols = [(11, "key"), (13, "i32")]
+    def both(keys, lc, rc_, jt, right=(rtab, orr), left=(lt, ol), **kw):
+        out = []
+        for m, a, b in ((rt, left[0], right[0]), (orc, left[1], right[1])):
+            f = m.join_stream_batches if m is rt else m.hash_join_batches
+            try:
+                out.append(f(a, b, keys, lc, rc_, JT[jt], **kw))
+            except abi.LlkvError as e:
+                out.append((e.kind, e.message))
+        return out
+    # empty build side: INNER / SEMI nothing, ANTI every probe row
+    for jt in ("inner", "semi", "anti"):
+        g, w = both([(1, 11)], lcols, ecols, jt, right=(e_h, e_o))
+        _same_batches(g, w, jt)
+        assert (len(w) > 0) == (jt == "anti")
+    # LEFT join, no build batch: the fast path drops every probe batch (the failed RecordBatch::try_new is logged and
+    # swallowed), the generic path returns that error
+    g, w = both([(1, 11)], lcols, ecols, "left", right=(e_h, e_o))
+    assert g == w == []
+    g, w = both([(1, 11), (3, 13)], lcols, ecols, "left", right=(e_h, e_o))
+    assert g == w and g[0] == "Internal" and "number of columns(7) must match number of fields(9)" in g[1]
+    # no right columns: nothing is built; no left columns: nothing is probed
+    for jt in ("inner", "anti"):
+        g, w = both([(1, 11)], lcols, [], jt)
+        _same_batches(g, w, jt)
+    assert both([(1, 11)], [], rcols, "inner") == [[], []]
+    # empty probe side
+    assert both([(11, 11)], ecols, rcols, "left", left=(e_h, e_o)) == [[], []]
+    # cross products: two left windows × one right window; LEFT with an empty right side pads; SEMI / ANTI fail on the
+    # first pair of batches and deliver nothing against an empty side
+    big_h, big_o = rt.HipTable(5, [65536, 4464]), orc.OracleTable(70_000)
+    v = np.arange(70_000, dtype=np.int64); ok = (v % 3) != 0
+    big_h.append_column(1, abi.DT_INT64, v, valid=ok); big_o.add(1, abi.DT_INT64, v, list(ok))
+    small_h, small_o = rt.HipTable(6, [3]), orc.OracleTable(3)
+    small_h.append_utf8_column(7, ["x", "y", "x"]); small_o.add(7, abi.DT_UTF8, ["x", "y", "x"])
+    g, w = both([], [(1, "v")], [(7, "s")], "inner", left=(big_h, big_o), right=(small_h, small_o))
+    _same_batches(g, w, "cross")
+    assert [len(c[0]) for _, c in w] == [3 * int(ok[:65536].sum()), 3 * int(ok[65536:].sum())]  # rows NULL in every column are dropped before the product
+    g, w = both([], [(1, "v")], ecols, "left", left=(big_h, big_o), right=(e_h, e_o))
+    _same_batches(g, w, "cross left")
+    assert w[0][0] == ["v", "key", "i32"] and set(w[0][1][1]) == {None}
+    g, w = both([], [(1, "v")], [(7, "s")], "semi", left=(big_h, big_o), right=(small_h, small_o))
+    assert g == w and g[0] == "Internal"
+    assert both([], [(1, "v")], ecols, "anti", left=(big_h, big_o), right=(e_h, e_o)) == [[], []]
+    assert rt.join_output_names(lcols[:2], [(11, "key"), (12, "key_1"), (13, "f")]) == ["key", "f", "key_1", "key_1_1", "f_1"]  # hash_join.rs:913-939: the set of taken names includes the renamed ones
+    assert rt.join_output_names(lcols[:2], rcols[:2], JT["semi"]) == ["key", "f"]
+
+
+def test_join_record_batches_sharded_probe_side_concatenates(rt, orc, abi):
+    """Probe side sharded by chunk over 4 ranks (emulated on one device), build side replicated: the ranks' batches in
+    rank order are the single-device rows (batch cuts follow each rank's own scan windows, as its reference would)."""
+    n_left, n_right = 300_000, 20_000
+    rng = np.random.default_rng(9)
+    lk, lv = rng.integers(0, 30_000, size=n_left), rng.normal(size=n_left)
+    rk, rv = rng.integers(0, 40_000, size=n_right), rng.integers(0, 99, size=n_right).astype(np.int32)
+    chunks = [65536] * 4 + [n_left - 4 * 65536]
+    rtab = rt.HipTable(2, [n_right]); rtab.append_column(11, abi.DT_INT64, rk); rtab.append_column(12, abi.DT_INT32, rv)
+    orr = orc.OracleTable(n_right).add(11, abi.DT_INT64, rk).add(12, abi.DT_INT32, rv)
+    ol = orc.OracleTable(n_left).add(1, abi.DT_INT64, lk).add(2, abi.DT_FLOAT64, lv)
+    want = orc.hash_join_batches(ol, orr, [(1, 11)], [(1, "k"), (2, "v")], [(11, "k"), (12, "w")], JT["left"])
+    rows = []
+    for rank in range(4):
+        lt = rt.HipTable(1, chunks, rank=rank, world=4)
+        lt.append_column(1, abi.DT_INT64, lk); lt.append_column(2, abi.DT_FLOAT64, lv)
+        for names, cols in rt.join_stream_batches(lt, rtab, [(1, 11)], [(1, "k"), (2, "v")], [(11, "k"), (12, "w")], JT["left"]):
+            assert names == ["k", "v", "k_1", "w"]
+            rows.extend(zip(*cols))
+    assert rows == [r for _, cols in want for r in zip(*cols)]
+
+
 def test_cross_products_match_oracle(rt, orc, abi):
     """Empty join keys = Cartesian product (llkv-join/src/hash_join.rs:1500-1599): window by window, left-major;
     LEFT with an empty right side pads with NULLs; SEMI / ANTI fail the reference's schema check."""

@@ -69,6 +69,71 @@ def test_join_cases(case, orc, abi):
         assert all(b[1] is None for b in batches), "semi/anti joins deliver left columns only"
 
 
+JOIN_COLS = [(1, "user_id"), (2, "name")]  # create_test_table join_tests.rs:18-53
+
+
+@pytest.mark.parametrize("case", JOINS["cases"], ids=lambda c: c["name"])
+def test_join_record_batches(case, orc, abi):
+    """The same reference tests through the delivery the reference really has — joined RecordBatches: column count
+    (`expect_columns`), output names (left, right, `_1`), and every cell = the cell of the paired source rows."""
+    left, right = _join_tables(orc, abi, case)
+    jt = {"inner": abi.JOIN_INNER, "left": abi.JOIN_LEFT, "semi": abi.JOIN_SEMI, "anti": abi.JOIN_ANTI}[case["type"]]
+    keys = [] if case.get("cross") else [(1, 1)]
+    if "expect_error" in case:
+        with pytest.raises(abi.LlkvError) as e:
+            orc.hash_join_batches(left, right, keys, JOIN_COLS, JOIN_COLS, jt, case.get("batch_size", 8192))
+        assert e.value.kind == case["expect_error"]
+        return
+    batches = orc.hash_join_batches(left, right, keys, JOIN_COLS, JOIN_COLS, jt, case.get("batch_size", 8192))
+    check_join_batches(case, batches)
+
+
+def check_join_batches(case, batches):
+    assert sum(len(cols[0]) for _, cols in batches) == case["expect_rows"]
+    assert all(len(cols[0]) > 0 for _, cols in batches)
+    left_only = case["type"] in ("semi", "anti")
+    for names, cols in batches:
+        assert len(names) == len(cols) == (2 if left_only else 4)
+        if "expect_columns" in case:
+            assert len(cols) == case["expect_columns"]
+        assert names == (["user_id", "name"] if left_only else ["user_id", "name", "user_id_1", "name_1"])
+        if "expect_names" in case:
+            assert names == case["expect_names"]
+    rows = [list(r) for _, cols in batches for r in zip(*cols)]
+    if "expect_pairs" in case:
+        want = [case["left"][l] + (case["right"][r] if r is not None else [None, None]) for l, r in case["expect_pairs"]]
+        assert rows == want
+    if "expect_left" in case:
+        assert rows == [case["left"][l] for l in case["expect_left"]]
+
+
+def test_join_record_batches_expression_filters(orc, abi):
+    """join_tests.rs:470-558: the reference reads columns 0, 2, 5 and 6 of the joined batches — customer_id, annual_revenue
+    of the left table, customer_id, avg_order_value of the right one — and counts the rows by the two filters."""
+    c = JOIN_FILTERS["expression_filters"]
+    left, right = oracle_table(orc, abi, c["left"]["columns"]), oracle_table(orc, abi, c["right"]["columns"])
+    lcols = [(col["field_id"], nm) for col, nm in zip(c["left"]["columns"], ["customer_id", "segment", "annual_revenue", "loyalty_score"])]
+    rcols = [(col["field_id"], nm) for col, nm in zip(c["right"]["columns"], ["order_id", "customer_id", "avg_order_value", "trailing_spend"])]
+    batches = orc.hash_join_batches(left, right, [tuple(k) for k in c["join_keys"]], lcols, rcols, abi.JOIN_INNER)
+    check_expression_filter_batches(c, batches)
+
+
+def check_expression_filter_batches(c, batches):
+    assert sum(len(cols[0]) for _, cols in batches) == c["expect_join_rows"]
+    counts, both = {"both": 0, "left": 0, "right": 0, "neither": 0}, set()
+    for names, cols in batches:
+        assert names == ["customer_id", "segment", "annual_revenue", "loyalty_score", "order_id", "customer_id_1", "avg_order_value", "trailing_spend"]
+        for cid_l, rev, cid_r, avg in zip(cols[0], cols[2], cols[5], cols[6]):
+            assert cid_l == cid_r
+            lp, rp = rev >= 900, cid_r in {1002, 1003, 1005, 1010, 1011}  # customers with an order of avg value >= 120
+            counts["both" if lp and rp else "left" if lp else "right" if rp else "neither"] += 1
+            if lp and rp:
+                both.add(cid_l)
+                assert rev >= 900 and avg >= 120
+    assert (counts["both"], counts["left"], counts["right"], counts["neither"]) == (c["expect_both"], c["expect_left_only"], c["expect_right_only"], c["expect_neither"])
+    assert sorted(both) == c["expect_both_customers"]
+
+
 def test_generic_join_key_rules(orc, abi):
     """The generic typed-key path (llkv-join/src/hash_join.rs:62-148,377-505; any key list that is not one
     fast integer pair), expectations derived by hand from its rules: all parts equal; NULL equals nothing, or —
