@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""llkv_hip_join_stream at SF10 on one GPU: lineitem ⋈ orders on the order key (every lineitem
-matches one order: 59 986 052 pairs), pair batches delivered to a consumer that only counts them."""
+"""llkv_hip_join_stream / llkv_hip_join_stream_batches at SF10 on one GPU: lineitem ⋈ orders on the order
+key (every lineitem matches one order: 59 986 052 pairs) — index-pair batches, and the reference's joined RecordBatches
+with four projected columns gathered on the device (l_orderkey, l_extendedprice | o_custkey, o_orderdate: 28 bytes per
+row to the host instead of 16 bytes of row ids and a second gather on the CPU); the consumer only counts."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,10 +11,11 @@ abi = importlib.import_module("rust-llkv_amd.abi"); rt = importlib.import_module
 sf = sys.argv[1] if len(sys.argv) > 1 else "sf10"
 rt.init(0)
 rows, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
-li = tpch.gen_lineitem(rows, scale, ["l_orderkey"])
+li = tpch.gen_lineitem(rows, scale, ["l_orderkey", "l_extendedprice"])
 n_ord = tpch.orders_for_lineitems(rows); od = tpch.gen_orders(n_ord, scale)
-lt = rt.HipTable(1, tpch.chunk_rows(rows)); lt.append_column(tpch.L_ORDERKEY, abi.DT_INT64, li["l_orderkey"])
+lt = rt.HipTable(1, tpch.chunk_rows(rows)); lt.append_column(tpch.L_ORDERKEY, abi.DT_INT64, li["l_orderkey"]); lt.append_column(tpch.L_EXTENDEDPRICE, abi.DT_FLOAT64, li["l_extendedprice"])
 ot = rt.HipTable(2, tpch.chunk_rows(n_ord)); ot.append_column(tpch.O_ORDERKEY, abi.DT_INT64, od["o_orderkey"]); ot.append_column(tpch.O_CUSTKEY, abi.DT_INT64, od["o_custkey"])
+ot.append_column(tpch.O_ORDERDATE, abi.DT_DATE32, od["o_orderdate"])
 out = []
 for name, (l, r, keys, jt, bs) in {
     "lineitem x orders, inner, batch 8192": (lt, ot, [(tpch.L_ORDERKEY, tpch.O_ORDERKEY)], abi.JOIN_INNER, 8192),
@@ -29,4 +32,25 @@ for name, (l, r, keys, jt, bs) in {
         seen[0] = seen[1] = 0
         t0 = time.perf_counter(); rt.join_stream(l, r, keys, jt, bs, consume=consume); ts.append(time.perf_counter() - t0)
     out.append({"case": name, "pairs": seen[0], "batches": seen[1], "seconds": min(ts), "probe_rows_per_s": l.local_rows / min(ts), "pairs_per_s": seen[0] / min(ts)})
+# the joined RecordBatches
+LCOLS, RCOLS = [(tpch.L_ORDERKEY, "l_orderkey"), (tpch.L_EXTENDEDPRICE, "l_extendedprice")], [(tpch.O_CUSTKEY, "o_custkey"), (tpch.O_ORDERDATE, "o_orderdate")]
+for name, (jt, bs, lc, rc) in {
+    "lineitem x orders, inner, 2 + 2 columns, batch 8192": (abi.JOIN_INNER, 8192, LCOLS, RCOLS),
+    "lineitem x orders, inner, 2 + 2 columns, batch 65536": (abi.JOIN_INNER, 65536, LCOLS, RCOLS),
+    "lineitem x orders, left, 2 + 2 columns, batch 65536": (abi.JOIN_LEFT, 65536, LCOLS, RCOLS),
+    "lineitem x orders, semi, 2 columns": (abi.JOIN_SEMI, 65536, LCOLS, RCOLS),
+}.items():
+    seen = [0, 0, 0]
+    def consume(b, names):
+        seen[0] += int(b.num_rows); seen[1] += 1; seen[2] = int(b.num_columns)
+    keys = [(tpch.L_ORDERKEY, tpch.O_ORDERKEY)]
+    rt.join_stream_batches(lt, ot, keys, lc, rc, jt, bs, consume=consume)
+    ts = []
+    for _ in range(2):
+        seen[0] = seen[1] = 0
+        t0 = time.perf_counter(); rt.join_stream_batches(lt, ot, keys, lc, rc, jt, bs, consume=consume); ts.append(time.perf_counter() - t0)
+    width = sum({abi.DT_INT64: 8, abi.DT_FLOAT64: 8, abi.DT_DATE32: 4}[tpch.LINEITEM_SCHEMA[n][1] if n in tpch.LINEITEM_SCHEMA else tpch.ORDERS_SCHEMA[n][1]]
+                for _, n in (lc + (rc if jt not in (abi.JOIN_SEMI, abi.JOIN_ANTI) else [])))
+    out.append({"case": name, "rows": seen[0], "batches": seen[1], "columns": seen[2], "seconds": min(ts), "probe_rows_per_s": lt.local_rows / min(ts),
+                "host_gbs": seen[0] * width / min(ts) / 1e9})
 print(json.dumps({"workload": f"join_{sf}", "cases": out}))
