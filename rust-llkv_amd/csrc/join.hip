@@ -1039,14 +1039,71 @@ __device__ __forceinline__ bool last_workgroup(uint32_t *done) {
   __syncthreads();
   return last;
 }
+// The dimension row that owns group g: listed, or found through the rank bitmap (CandidateCols, join.hpp).  A plain binary
+// search through global memory is a chain of ~20 + ~24 dependent loads (~20 µs at the end of a 500 µs query): each of the
+// two searches starts where a straight line puts the answer — ranks grow evenly over a chunk of an evenly thinned bitmap,
+// keys evenly over a dense key column (TPC-H order keys) — and gallops outwards, so that what it touches lies within a
+// cache line or two; any other distribution costs the logarithm of how far off the guess was.
+// `le(i)`: monotone (true … true false … false) over [lo, hi) with le(lo) true; returns the last i with le(i).
+template <class F> __device__ __forceinline__ uint64_t gallop_last_true(uint64_t lo, uint64_t hi, uint64_t guess, F le) {
+  if (guess < lo) guess = lo;
+  if (guess >= hi) guess = hi - 1;
+  uint64_t a, b; // le(a) true, le(b) false (b may be hi)
+  if (le(guess)) {
+    a = guess;
+    uint64_t step = 1;
+    for (;;) {
+      const uint64_t q = a + step;
+      if (q >= hi) { b = hi; break; }
+      if (!le(q)) { b = q; break; }
+      a = q;
+      step <<= 1;
+    }
+  } else {
+    b = guess;
+    uint64_t step = 1;
+    for (;;) {
+      const uint64_t q = b - lo > step ? b - step : lo;
+      if (le(q)) { a = q; break; }
+      b = q;
+      step <<= 1;
+    }
+  }
+  while (b - a > 1) {
+    const uint64_t mid = a + ((b - a) >> 1);
+    if (le(mid)) a = mid; else b = mid;
+  }
+  return a;
+}
+__device__ __forceinline__ uint64_t group_owner_row(const uint64_t *dim_rows, const CandidateCols &cols, uint32_t g) {
+  if (!cols.rank_bits) return dim_rows[g];
+  uint32_t cl = 0, ch = cols.rank_chunks; // the chunk: base[cl] <= g < base[ch]
+  while (ch - cl > 1) {
+    const uint32_t mid = (cl + ch) >> 1;
+    if (cols.rank_base[mid] <= g) cl = mid; else ch = mid;
+  }
+  const uint32_t b0 = cols.rank_base[cl], gl = g - b0, in_chunk = cols.rank_base[cl + 1] - b0;
+  const uint64_t lo = (uint64_t)cl << cols.rank_chunk_shift, hi = lo + (1ull << cols.rank_chunk_shift) < cols.rank_words ? lo + (1ull << cols.rank_chunk_shift) : cols.rank_words;
+  const uint64_t word = gallop_last_true(lo, hi, lo + (uint64_t)((double)gl / (double)(in_chunk ? in_chunk : 1) * (double)(hi - lo)),
+                                         [&](uint64_t i) { return cols.rank_prefix[i] <= gl; }); // prefix[word] <= gl < prefix[word + 1]
+  uint64_t w = cols.rank_bits[word];
+  for (uint32_t k = gl - cols.rank_prefix[word]; k; --k) w &= w - 1; // drop the set bits before it
+  const long long key = cols.rank_kmin + (long long)(word * 64 + (uint64_t)__ffsll((unsigned long long)w) - 1);
+  // the row of the ascending key column that holds it: the last row whose key is <= key
+  const uint64_t last = cols.rank_rows - 1;
+  const long long k0 = load_key(cols.key, 0), k1 = load_key(cols.key, last);
+  const uint64_t guess = k1 > k0 ? (uint64_t)((double)(key - k0) / (double)(k1 - k0) * (double)last) : 0;
+  return gallop_last_true(0, cols.rank_rows, guess, [&](uint64_t i) { return load_key(cols.key, i) <= key; });
+}
 // Both launches: one 1024-thread workgroup per slice (as much in flight as 4× the workgroups, a quarter of the tickets).
 __global__ __launch_bounds__(1024) void hj_topk_bound_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t per, uint32_t want, uint64_t *best,
-                                                              uint64_t *state) {
+                                                              uint64_t *state, const uint32_t *n_dev) {
   __shared__ uint64_t wave_best[16];
   __shared__ uint32_t wave_count[16];
   __shared__ uint64_t v[kTopkSlices];
   const uint32_t t = threadIdx.x;
-  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  if (n_dev) { n = *n_dev; per = (n + gridDim.x - 1) / gridDim.x; }
+  const uint64_t lo = (uint64_t)blockIdx.x * per < n ? (uint64_t)blockIdx.x * per : n, hi = lo + per < n ? lo + per : n;
   uint64_t mine = ~0ull;
   uint32_t have = 0;
   for (uint64_t i0 = lo + t; i0 < hi; i0 += 1024 * 4) { // four groups in flight (a sum without rows is read, never used)
@@ -1110,7 +1167,9 @@ __global__ __launch_bounds__(1024) void hj_topk_bound_kernel(const double *sums,
   }
 }
 __global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t *state, uint32_t cap, uint32_t *groups,
-                                                                const uint64_t *dim_rows, CandidateCols cols, uint64_t *host_out, GatherItems extra, uint32_t *extra_host) {
+                                                                const uint64_t *dim_rows, CandidateCols cols, uint64_t *host_out, GatherItems extra, uint32_t *extra_host,
+                                                                const uint32_t *n_dev) {
+  if (n_dev) n = *n_dev;
   const uint64_t bound = state[0];
   uint32_t *counter = reinterpret_cast<uint32_t *>(state + 1);
   for (uint64_t i0 = (uint64_t)blockIdx.x * 4096 + threadIdx.x; i0 < n; i0 += (uint64_t)gridDim.x * 4096) {
@@ -1137,7 +1196,7 @@ __global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *su
   for (uint32_t r = threadIdx.x; r < n_rec; r += 1024) {
     uint64_t *o = host_out + 8 + (uint64_t)r * 8;
     const uint32_t g = __hip_atomic_load(&groups[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t owner = dim_rows[g];
+    const uint64_t owner = group_owner_row(dim_rows, cols, g);
     to_host(&o[0], g);
     to_host(&o[1], (uint64_t)load_key(cols.key, owner));
     to_host(&o[2], (uint64_t)__double_as_longlong(sums[g]));
@@ -1150,13 +1209,64 @@ __global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *su
 }
 hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
                                   uint64_t *best, uint64_t *state, uint32_t *groups, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
-                                  hipStream_t s) {
+                                  hipStream_t s, const uint32_t *n_dev) {
   if (n == 0 || want == 0 || want > kTopkSlices) return hipErrorInvalidValue;
   const uint64_t per = (n + kTopkSlices - 1) / kTopkSlices;
-  const uint32_t n_slices = (uint32_t)((n + per - 1) / per);
-  hipLaunchKernelGGL(hj_topk_bound_kernel, dim3(n_slices), dim3(1024), 0, s, sums, counts, n, per, want, best, state);
+  const uint32_t n_slices = n_dev ? kTopkSlices : (uint32_t)((n + per - 1) / per);
+  hipLaunchKernelGGL(hj_topk_bound_kernel, dim3(n_slices), dim3(1024), 0, s, sums, counts, n, per, want, best, state, n_dev);
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 4095) / 4096, 256);
-  hipLaunchKernelGGL(hj_topk_collect2_kernel, dim3(grid), dim3(1024), 0, s, sums, counts, n, state, cap, groups, dim_rows, cols, host_out, extra, extra_host);
+  hipLaunchKernelGGL(hj_topk_collect2_kernel, dim3(grid), dim3(1024), 0, s, sums, counts, n, state, cap, groups, dim_rows, cols, host_out, extra, extra_host, n_dev);
+  return hipGetLastError();
+}
+
+// ---- bitmap → word ranks in one launch (join.hpp: hj_launch_rank_words) ------------------------------------------------
+__global__ __launch_bounds__(1024) void hj_rank_words_kernel(const uint64_t *bits, uint64_t n_words, uint32_t chunk_shift, uint32_t *prefix, uint32_t *base, uint32_t *state) {
+  __shared__ uint32_t wave_total[16];
+  __shared__ uint32_t totals[1024];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint64_t w0 = (uint64_t)blockIdx.x << chunk_shift, w1 = w0 + (1ull << chunk_shift) < n_words ? w0 + (1ull << chunk_shift) : n_words;
+  uint32_t running = 0;
+  for (uint64_t r0 = w0; r0 < w1; r0 += 4096) { // a thread owns 4 consecutive words of the round
+    const uint64_t i = r0 + (uint64_t)t * 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = i + k < w1 ? (uint32_t)__popcll(bits[i + k]) : 0;
+    const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+    uint32_t x = mine; // inclusive scan within the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if ((int)lane >= o) x += y;
+    }
+    if (lane == 63) wave_total[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) { const uint32_t v = wave_total[w]; before += w < wave ? v : 0; all += v; }
+    uint32_t at = running + before + x - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < w1) prefix[i + k] = at;
+      at += c[k];
+    }
+    running += all;
+    __syncthreads();
+  }
+  if (t == 0) __hip_atomic_store(&base[blockIdx.x], running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the chunk's total, for now
+  if (!last_workgroup(state)) return;
+  // the last workgroup: exclusive scan of the chunk totals (gridDim.x <= 1024 of them), in place; [chunks] = all set bits
+  const uint32_t c = t < gridDim.x ? __hip_atomic_load(&base[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  totals[t] = c;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t k = 0; k < t && k < gridDim.x; ++k) before += totals[k]; // (a few hundred adds per thread, once per query)
+  __syncthreads();
+  if (t < gridDim.x) base[t] = before;
+  if (t == gridDim.x - 1) base[gridDim.x] = before + c;
+  if (t == 0) *state = 0;
+}
+hipError_t hj_launch_rank_words(const uint64_t *bits, uint64_t n_words, uint32_t chunk_shift, uint32_t *prefix, uint32_t *base, uint32_t *state, hipStream_t s) {
+  const uint64_t chunks = (n_words + (1ull << chunk_shift) - 1) >> chunk_shift;
+  if (chunks == 0 || chunks > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hj_rank_words_kernel, dim3((uint32_t)chunks), dim3(1024), 0, s, bits, n_words, chunk_shift, prefix, base, state);
   return hipGetLastError();
 }
 
@@ -1170,7 +1280,7 @@ __global__ __launch_bounds__(128) void hj_gather_group_candidates_kernel(const u
   const uint64_t key = sorted_keys ? sorted_keys[i] : keys_by_group[g];
   o[0] = key;
   if (key == ~0ull) { for (int k = 1; k < 8; ++k) o[k] = 0; return; }
-  const uint64_t owner = dim_rows[g];
+  const uint64_t owner = group_owner_row(dim_rows, cols, g);
   o[1] = (uint64_t)load_key(cols.key, owner);
   o[2] = (uint64_t)__double_as_longlong(sum_by_group[g]);
   o[3] = count_by_group[g];

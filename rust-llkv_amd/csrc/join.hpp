@@ -192,6 +192,16 @@ struct CandidateCols {
   JoinKeyColumn key;
   JoinKeyColumn payload[4];
   uint32_t n_payload;
+  // Groups identified by the RANK of their key among the set bits of a bitmap (a dimension selected straight into the
+  // bitmap from a key column in ascending row order: no list of the selected rows exists).  rank_bits != nullptr: the
+  // owner row of group g = the row of the key column (rank_rows rows, ascending) that holds the g-th set bit's key.
+  const uint64_t *rank_bits;
+  const uint32_t *rank_prefix; // set bits before each word, within its chunk of 2^rank_chunk_shift words
+  const uint32_t *rank_base;   // [chunks + 1] set bits before each chunk; the last entry = the number of groups
+  uint32_t rank_chunk_shift, rank_chunks;
+  uint64_t rank_words;
+  int64_t rank_kmin;
+  uint64_t rank_rows;
 };
 hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_slots, uint32_t n, const unsigned long long *slot_owner,
                                        const double *sum_by_slot, const uint64_t *count_by_slot, CandidateCols cols, uint64_t *out /*[n][8]*/, hipStream_t s);
@@ -224,6 +234,10 @@ hipError_t hj_launch_bitmap_build(const JoinKeyColumn &key, const uint64_t *dev_
                                   uint32_t *dup_flag, hipStream_t s);
 hipError_t hj_launch_popc_words(const uint64_t *bits, uint64_t n_words, uint32_t *out, hipStream_t s);
 hipError_t hj_exclusive_scan_popc(void *tmp, size_t *tmp_bytes, const uint64_t *bits, uint32_t *out, uint64_t n_words, hipStream_t s);
+// The same in ONE launch, as chunk-local ranks: prefix[w] = set bits before word w within its chunk of 2^chunk_shift words
+// (one workgroup per chunk), base[c] = set bits before chunk c, base[n_chunks] = all set bits — written by the last workgroup
+// to finish.  `state`: one zero word (left zero).  n_chunks <= 1024.
+hipError_t hj_launch_rank_words(const uint64_t *bits, uint64_t n_words, uint32_t chunk_shift, uint32_t *prefix, uint32_t *base, uint32_t *state, hipStream_t s);
 hipError_t hj_exclusive_scan_u32(void *tmp, size_t *tmp_bytes, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s);
 hipError_t hj_launch_bitmap_groups(const JoinKeyColumn &key, const uint64_t *dev_rows, uint64_t n, long long kmin, const uint64_t *bits,
                                    const uint32_t *prefix, uint64_t n_words, const uint32_t *unsorted /*optional: zero = rank is the list index, nothing to write*/,
@@ -248,9 +262,10 @@ hipError_t hj_launch_patch_groups(const uint32_t *groups, const double *sums, co
 // records ([min(candidates, cap)][8]) to `host_out` (pinned, device-visible) and carries the `extra` read-back items.
 // `state`: 8 words, zero before the first use (the kernels leave it zero); `best`: 2 · kTopkSlices words.  want ≤ kTopkSlices.
 constexpr uint32_t kTopkSlices = 256;
+// `n_dev` (optional): the number of groups is still on the device (then `n` only bounds it).
 hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
                                   uint64_t *best, uint64_t *state, uint32_t *groups /*[cap]*/, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
-                                  hipStream_t s);
+                                  hipStream_t s, const uint32_t *n_dev = nullptr);
 hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s);
 hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,

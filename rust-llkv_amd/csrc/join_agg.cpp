@@ -101,10 +101,12 @@ struct DirectTable {
     if (!bits_done) HIP_TRY(hj_launch_bitmap_build(key, d_rows, n, kmin, (unsigned long long *)bits.p, flag_p, s));
     if (with_groups) {
       size_t tb = 0;
-      if ((rc = prefix.alloc(n_words * 4)) || (!in_key_order && (rc = group.alloc((n ? n : 1) * 4)))) return rc;
-      HIP_TRY(hj_exclusive_scan_popc(nullptr, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words, s));
+      // one entry more than words: prefix[n_words] = the number of set bits (the word behind the bitmap holds the flags; what
+      // it counts would land in an entry that does not exist)
+      if ((rc = prefix.alloc((n_words + 1) * 4)) || (!in_key_order && (rc = group.alloc((n ? n : 1) * 4)))) return rc;
+      HIP_TRY(hj_exclusive_scan_popc(nullptr, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words + 1, s));
       if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
-      HIP_TRY(hj_exclusive_scan_popc(tmp.p, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words, s));
+      HIP_TRY(hj_exclusive_scan_popc(tmp.p, &tb, (const uint64_t *)bits.p, (uint32_t *)prefix.p, n_words + 1, s));
       // a bitmap filled by the sink: duplicates show as missing bits, and a list in key order needs no rank → index table
       if (!in_key_order) HIP_TRY(hj_launch_bitmap_groups(key, d_rows, n, kmin, (const uint64_t *)bits.p, (const uint32_t *)prefix.p, n_words, from_sink ? flag_p + 2 : nullptr,
                                       from_sink ? flag_p : nullptr, (uint32_t *)group.p, s));
@@ -157,6 +159,13 @@ struct JoinAgg {
   bool from_stripes = false;         // the sums were taken straight from the stripes: no pair count, no compacted pairs yet
   DB slot_group;                     // hash form: slot → group id
   bool direct_form = false;
+  // ranked form: the dimension selection went straight into the key bitmap (no list of its rows): group id = rank of the
+  // key among the set bits, the number of groups stays on the device (dt.prefix[dt.n_words]) until the final read-back
+  bool ranked = false;
+  uint32_t n_dim_dev = 0, dim_err = 0;
+  DB rank_base;  // ranked form: set bits before each chunk of 2^rank_shift bitmap words; [rank_chunks] = the number of groups
+  uint32_t rank_shift = 0, rank_chunks = 0;
+  const uint32_t *n_dim_ptr() const { return static_cast<const uint32_t *>(rank_base.p) + rank_chunks; }
   uint32_t pred_err = 0;
   DB zeros;                          // one zeroed block: [0] the run flag, [8..15] the top-k selection's state words
   uint32_t *multi_p() const { return static_cast<uint32_t *>(zeros.p); }
@@ -170,6 +179,14 @@ struct JoinAgg {
   int prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
               const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len, bool defer = false);
   int settle(bool delivered = false);
+  // early exits after a key-bits scan has been launched: its predicate-error word is read before the call reports success
+  int error_words(const uint32_t *a, const uint32_t *b) {
+    uint32_t ea = 0, eb = 0;
+    Readback r;
+    int rc;
+    if ((a && (rc = r.add(&ea, a, 4, g_ctx.stream))) || (b && (rc = r.add(&eb, b, 4, g_ctx.stream))) || ((a || b) && (rc = r.wait()))) return rc;
+    return ea || eb ? set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison") : LLKV_OK;
+  }
   int compact_pairs(bool run_sums);
   int straddlers();
   int candidates(const uint32_t *f_groups, const double *f_sums, const uint64_t *f_counts, const uint32_t *f_first_rank, uint64_t n_folded,
@@ -209,6 +226,10 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   // any other finds out about its order during the compaction.
   const bool dim_sorted = direct && kd_info.ascending && !std::getenv("LLKV_HIP_JOIN_UNSORTED");
   const bool sink_bits = fused_semi && direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK");
+  int64_t key_range_lo = 0, key_range_hi = -1; // (range form of a sharded fact table: the keys this rank's fact rows can hold)
+  const bool use_key_range = false;
+  ranked = direct && dim_sorted && (!t2 || fused_semi) && kd_info.dtype == LLKV_DT_INT64 && td->local_rows && !std::getenv("LLKV_HIP_JOIN_NO_SINK") &&
+           !std::getenv("LLKV_HIP_JOIN_LISTED");
   // ---- everything that starts from zero, in one fill: the key bitmaps, the probe's per-stripe counts, the flags --------
   const TileSet *ts = nullptr;
   if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
@@ -216,7 +237,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   {
     FillRanges fr;
     if (fused_semi && (rc = set2_bits.prepare_bits(t2->cols.find(dim2->key_field)->second.info, s, &fr))) return rc;
-    if (sink_bits && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
+    if ((sink_bits || ranked) && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
     dt.in_key_order = dim_sorted;
     if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8)) || (rc = zeros.alloc(256))) return rc;
     fr.add(counts.p, (size_t)(n_slots + 1) * 8); // the extra trailing 0 makes offsets[n_slots] the total
@@ -252,8 +273,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
           p2.n_tiles = ts2->n_tiles;
           p2.aux_out = (uint64_t *)set2_bits.bits.p;
           p2.aux_out32 = set2_bits.flag_p + 1; // predicate-error word (read with the pair count)
-          p2.bm_min = set2_bits.kmin;
-          p2.bm_span = set2_bits.span;
+          p2.kb_min = set2_bits.kmin;
+          p2.kb_span = set2_bits.span;
           if ((rc = jit_launch_raw(kk.fn, ts2->n_tiles, &p2, sizeof p2, s))) return rc;
         }
         bits_set = true;
@@ -272,9 +293,47 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
       }
     }
   }
-  // dim's own table: when the statistics bound its key, the bitmap is filled while the selection is compacted
+  // dim's own table: when the statistics bound its key, the bitmap is filled while the selection is compacted — or, for
+  // a key column in ascending row order, by the selection scan itself (the ranked form): rows that pass set their bit,
+  // nothing is listed, counted or read back; a key's rank among the set bits is its group id and the rank scan's total
+  // the number of groups
   bool dt_bits_done = false;
-  if (fused_semi) {
+  uint32_t *dim_err_flag = nullptr;
+  if (ranked) {
+    auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
+      auto it = td->cols.find(fid);
+      return it == td->cols.end() ? nullptr : &it->second.info;
+    };
+    llkv_expr_token key_tok;
+    std::memset(&key_tok, 0, sizeof key_tok);
+    key_tok.kind = LLKV_TOK_COLUMN;
+    key_tok.field_id = dim->key_field;
+    LoweredPlan kp;
+    JitKernel kk;
+    if ((rc = lower_emit(resolve_d, dim->filters, dim->n_filters, nullptr, 0, &key_tok, 1, &kp, &err, false, nullptr, t2 ? &dim_fk_field : nullptr))) return set_error(rc, err);
+    if ((rc = jit_compile(JitKind::KeyBits, kp.type_string, &kk, &err))) return set_error(rc, err);
+    const TileSet *tsd = nullptr;
+    if ((rc = get_tileset(*td, td->local_rows < (4u << 20) ? 2048 : 8192, &tsd))) return rc;
+    if (!kp.always_false && td->local_rows) {
+      ScanParams pd;
+      std::memset(&pd, 0, sizeof pd);
+      for (size_t i = 0; i < kp.slot_fields.size(); ++i) pd.col[i] = slot_buffer(td->cols, kp, i);
+      for (size_t i = 0; i < kp.lit_i.size(); ++i) pd.lit_i[i] = kp.lit_i[i];
+      for (size_t i = 0; i < kp.lit_f.size(); ++i) pd.lit_f[i] = kp.lit_f[i];
+      pd.tiles = tsd->d_tiles;
+      pd.n_tiles = tsd->n_tiles;
+      pd.aux_out = (uint64_t *)dt.bits.p;
+      pd.aux_out32 = dt.flag_p + 1; // predicate-error word
+      pd.kb_min = dt.kmin;
+      pd.kb_span = dt.span;
+      if (t2) { pd.bm_bits = (const uint64_t *)set2_bits.bits.p; pd.bm_min = set2_bits.kmin; pd.bm_span = set2_bits.span; }
+      if (key_range_lo <= key_range_hi && use_key_range) { pd.kb_ranged = 1; pd.kb_lo = key_range_lo; pd.kb_hi = key_range_hi; }
+      if ((rc = jit_launch_raw(kk.fn, tsd->n_tiles, &pd, sizeof pd, s))) return rc;
+    }
+    dim_err_flag = dt.flag_p + 1;
+    dt_bits_done = true;
+    n_dim = std::min<uint64_t>(td->local_rows, dt.span + 1); // an upper bound: sizes the group state (the kernels read the count on the device)
+  } else if (fused_semi) {
     auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
       auto it = td->cols.find(fid);
       return it == td->cols.end() ? nullptr : &it->second.info;
@@ -291,8 +350,10 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   } else if ((rc = run_selection(td, dim->filters, dim->n_filters, nullptr, 0, &seld))) {
     return rc;
   }
-  n_dim = seld.n;
-  d_dim_rows = seld.d_dev;
+  if (!ranked) {
+    n_dim = seld.n;
+    d_dim_rows = seld.d_dev;
+  }
   if (t2 && !fused_semi && seld.n) {
     DB flags, offs, scan_tmp;
     if ((rc = flags.alloc(seld.n * 8)) || (rc = offs.alloc((seld.n + 1) * 8))) return rc;
@@ -309,15 +370,17 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     d_dim_rows = (const uint64_t *)kept.p;
   }
   if (n_dim >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "dimension too large");
-  if (n_dim == 0) return LLKV_OK;
+  if (n_dim == 0) return error_words(key_err_flag, nullptr);
   state_bytes = (n_dim * 8 + 4095) / 4096 * 4096; // whole pages: the memset is one fill kernel
   if ((rc = group_state.alloc(4 * state_bytes))) return rc;
-  sums.p = group_state.p;
-  cnts.p = (char *)group_state.p + state_bytes;
+  // (cnts first: the ranked form zeroes the first one — or three — arrays up to the real group count inside the probe launch)
+  cnts.p = group_state.p;
+  sums.p = (char *)group_state.p + state_bytes;
   gcnts.p = (char *)group_state.p + 2 * state_bytes;
   report.p = (char *)group_state.p + 3 * state_bytes;
   // one rank: only the row counts start from zero (a sum is read only where the count is not zero)
-  if (tf->world == 1) HIP_TRY(hj_launch_fill(cnts.p, state_bytes, 0, s));
+  if (ranked) {
+  } else if (tf->world == 1) HIP_TRY(hj_launch_fill(cnts.p, state_bytes, 0, s));
   else HIP_TRY(hj_launch_fill(group_state.p, 3 * state_bytes, 0, s));
 
   // ---- dim hash table, slot → group id -----------------------------------------------------
@@ -330,7 +393,35 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   HashSet ht;
   bool dup = false;
   direct_form = direct;
-  if (direct) { // launches only; the duplicate flag is read with the pair count below
+  if (ranked) { // the word ranks, chunk by chunk, and the chunk bases (in their last entry: the number of groups) — one launch
+    rank_shift = 10;
+    while (((dt.n_words + (1ull << rank_shift) - 1) >> rank_shift) > 256) ++rank_shift; // about one workgroup per CU
+    if (std::getenv("LLKV_HIP_JOIN_RANK_SCAN")) { // one chunk: the library scan's absolute ranks (two launches)
+      rank_shift = 40;
+      rank_chunks = 1;
+      if ((rc = rank_base.alloc(8))) return rc;
+      size_t tb = 0;
+      if ((rc = dt.prefix.alloc((dt.n_words + 1) * 4))) return rc;
+      HIP_TRY(hj_exclusive_scan_popc(nullptr, &tb, (const uint64_t *)dt.bits.p, (uint32_t *)dt.prefix.p, dt.n_words + 1, s));
+      if ((rc = dt.tmp.alloc(tb ? tb : 8))) return rc;
+      HIP_TRY(hj_exclusive_scan_popc(dt.tmp.p, &tb, (const uint64_t *)dt.bits.p, (uint32_t *)dt.prefix.p, dt.n_words + 1, s));
+      HIP_TRY(hipMemsetAsync(rank_base.p, 0, 4, s));
+      HIP_TRY(hipMemcpyAsync((uint32_t *)rank_base.p + 1, (uint32_t *)dt.prefix.p + dt.n_words, 4, hipMemcpyDeviceToDevice, s));
+    } else {
+      rank_chunks = (uint32_t)((dt.n_words + (1ull << rank_shift) - 1) >> rank_shift);
+      if ((rc = dt.prefix.alloc(dt.n_words * 4)) || (rc = rank_base.alloc((size_t)(rank_chunks + 1) * 4))) return rc;
+      HIP_TRY(hj_launch_rank_words((const uint64_t *)dt.bits.p, dt.n_words, rank_shift, (uint32_t *)dt.prefix.p, (uint32_t *)rank_base.p, multi_p() + 2, s));
+    }
+    dt.from_sink = true;
+    cc.rank_bits = (const uint64_t *)dt.bits.p;
+    cc.rank_prefix = (const uint32_t *)dt.prefix.p;
+    cc.rank_base = (const uint32_t *)rank_base.p;
+    cc.rank_chunk_shift = rank_shift;
+    cc.rank_chunks = rank_chunks;
+    cc.rank_words = dt.n_words;
+    cc.rank_kmin = dt.kmin;
+    cc.rank_rows = td->local_rows;
+  } else if (direct) { // launches only; the duplicate flag is read with the pair count below
     if ((rc = dt.build(kd_info, kd, d_dim_rows, n_dim, true, s, dt_bits_done && d_dim_rows == seld.d_dev))) return rc;
   } else {
     if ((rc = ht.build(kd, d_dim_rows, n_dim, &dup, s))) return rc;
@@ -348,7 +439,15 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   };
   LoweredPlan plan;
   if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err))) return set_error(rc, err);
-  if (plan.always_false || tf->local_rows == 0) { HIP_TRY(hipStreamSynchronize(s)); return LLKV_OK; }
+  if (plan.always_false || tf->local_rows == 0) {
+    if (ranked) { // nothing probes: the group state still starts from zero, and the group count is wanted
+      HIP_TRY(hj_launch_fill(group_state.p, (tf->world == 1 ? 1 : 3) * state_bytes, 0, s));
+      if ((rc = rb.add(&n_dim_dev, n_dim_ptr(), 4, s)) || (rc = rb.wait())) return rc;
+      n_dim = n_dim_dev;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return error_words(key_err_flag, dim_err_flag);
+  }
   JitKernel k;
   if ((rc = jit_compile(JitKind::Probe, plan.type_string, &k, &err))) return set_error(rc, err);
   ScanParams p;
@@ -364,9 +463,18 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     p.bm_bits = (const uint64_t *)dt.bits.p;
     p.bm_prefix = (const uint32_t *)dt.prefix.p;
     p.bm_group = (const uint32_t *)dt.group.p;
-    p.bm_unsorted = dt.from_sink ? dt.flag_p + 2 : nullptr;
+    p.bm_unsorted = dt.from_sink && !ranked ? dt.flag_p + 2 : nullptr;
     p.bm_min = dt.kmin;
     p.bm_span = dt.span;
+    if (ranked) {
+      p.bm_group = nullptr; // the rank is the group id
+      p.bm_base = rank_chunks > 1 ? (const uint32_t *)rank_base.p : nullptr;
+      p.bm_chunk_shift = rank_shift;
+      p.zero_k = tf->world == 1 ? 1 : 3;
+      p.zero_words = (uint64_t *)group_state.p;
+      p.zero_stride = state_bytes / 8;
+      p.zero_n = n_dim_ptr();
+    }
   } else {
     p.ht_owner = (const unsigned long long *)ht.owner.p;
     p.ht_mask = ht.cap - 1;
@@ -396,6 +504,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   }
   if ((!from_stripes && (rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s))) || (from_stripes && (rc = rb.add(&pred_err, multi_p() + 1, 4, s))) ||
       (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) || (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) ||
+      (dim_err_flag && (rc = rb.add(&dim_err, dim_err_flag, 4, s))) || (ranked && (rc = rb.add(&n_dim_dev, n_dim_ptr(), 4, s))) ||
       (rc = rb.add(&multi_run, multi_p(), 4, s)))
     return rc;
   pending = true;
@@ -432,7 +541,8 @@ int JoinAgg::settle(bool delivered) {
   if (!delivered && (rc = rb.wait())) return rc;
   pending = false;
   hipStream_t s = g_ctx.stream;
-  if (key_err || pred_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
+  if (key_err || pred_err || dim_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
+  if (ranked) n_dim = n_dim_dev; // the bound that sized the group state → the number of groups
   if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }
   if (from_stripes) {
     if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) return LLKV_OK; // sums and counts are final; nobody asked for the pairs
@@ -545,7 +655,7 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     uint32_t *slab_base = nullptr;
     if ((rc = rb.reserve(nullptr, 64 + (size_t)kCap * 64, s, &slab)) || (rc = rb.take(&extra, &slab_base))) return rc;
     HIP_TRY(hj_launch_topk_select2((const double *)sums.p, report_p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p, topk_state(),
-                                   (uint32_t *)groups_d.p, (uint64_t *)slab, extra, slab_base, s));
+                                   (uint32_t *)groups_d.p, (uint64_t *)slab, extra, slab_base, s, ranked && pending ? n_dim_ptr() : nullptr));
     if ((rc = rb.wait())) return rc;
     if (pending) {
       if ((rc = settle(true))) return rc;

@@ -1528,13 +1528,25 @@ int lower_selection_in_set(const ColumnResolver &resolve, const llkv_filter *fil
 
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err,
-               bool allow_f64, bool *is_f64_out) {
+               bool allow_f64, bool *is_f64_out, const uint32_t *in_set_field) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, false};
   std::string pred, val;
   int rc = L.predicate(filters, n_filters, ops, n_ops, &pred);
   if (rc) return rc;
   out->always_false = pred == "False";
+  if (in_set_field && !out->always_false) { // … AND the key of this field is in the launch's key set (a semi join as a conjunct)
+    const ColumnInfo *ci;
+    int slot;
+    std::string key;
+    if ((rc = L.slot_of(*in_set_field, &ci, &slot))) return rc;
+    if (ci->nullable) return L.fail(LLKV_UNSUPPORTED, "NULL join keys in the join-aggregate pipeline");
+    if (ci->dtype == LLKV_DT_INT64 || ci->dtype == LLKV_DT_UINT64) key = L.col_node(slot, LLKV_DT_INT64);
+    else if (ci->dtype == LLKV_DT_INT32 || ci->dtype == LLKV_DT_DATE32 || ci->dtype == LLKV_DT_UINT32) key = "ToI64<" + L.col_node(slot, ci->dtype) + ">";
+    else return L.fail(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(ci->dtype));
+    const std::string in_set = "InKeySet<" + key + ">";
+    pred = pred == "True" ? in_set : "AndThen<" + pred + "," + in_set + ">";
+  }
   bool is_f64 = false;
   if (expr_len == 1 && expr[0].kind == LLKV_TOK_COLUMN) {
     const ColumnInfo *ci;

@@ -89,6 +89,11 @@ struct ScanParams {
   // almost sequentially.
   const uint64_t *bm_bits;       // nullptr: hash table (ht_*)
   const uint32_t *bm_prefix;
+  // bm_base != nullptr: bm_prefix[w] counts the set bits before word w inside its chunk of 2^bm_chunk_shift words only, and
+  // bm_base[w >> bm_chunk_shift] the set bits before the chunk (hj_launch_rank_words: ONE launch ranks the bitmap — chunk-
+  // local prefixes need nothing from other workgroups, the last one to finish scans the few chunk totals)
+  const uint32_t *bm_base;
+  uint32_t bm_chunk_shift;
   const uint32_t *bm_group;
   const uint32_t *bm_unsorted;   // optional; *bm_unsorted == 0: the build list is in key order, the rank is the group id
   int64_t bm_min;
@@ -105,6 +110,21 @@ struct ScanParams {
   uint32_t part_shift;
   uint32_t part_np;             // partitions (≤ kMaxParts)
   uint32_t *part_err;           // arithmetic / predicate error codes, OR-ed
+  // key-bits scans (select.hip.h: keybits_body): the OUTPUT bitmap covers keys kb_min … kb_min + kb_span (bm_* describe the
+  // set an InKeySet conjunct of the predicate tests).  kb_ranged: the emitted key column is in ascending row order and only
+  // keys in [kb_lo, kb_hi] are wanted — a tile whose first key is above or whose last key is below leaves at once (a rank
+  // of a fact table clustered by that key needs the dimension rows of its own key range only).
+  int64_t kb_min;
+  uint64_t kb_span;
+  int64_t kb_lo, kb_hi;
+  uint32_t kb_ranged;
+  // probe-emit, piggy-backed: the launch also zeroes words [0, *zero_n) of zero_k arrays that lie zero_stride words apart
+  // (the per-group state the run sums add into, sized by the number of set bits the rank scan left in *zero_n) — the
+  // kernel boundary makes them visible to the next launch, and no host round trip has to learn the group count first
+  uint32_t zero_k;
+  uint64_t *zero_words;
+  uint64_t zero_stride;
+  const uint32_t *zero_n;
 };
 
 constexpr int kMaxOuts = 8;

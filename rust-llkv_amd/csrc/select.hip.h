@@ -131,6 +131,12 @@ __device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
 // of three per row.  Rows that do not probe read word 0.
 template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
+  if (p.zero_k) { // piggy-backed: this workgroup's share of the per-group state the next launch adds into
+    const uint64_t n = *p.zero_n, per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t k = 0; k < p.zero_k; ++k)
+      for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) p.zero_words[k * p.zero_stride + i] = 0;
+  }
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t sub0 = wave * p.sub_rows;
   const uint32_t sub1 = sub0 + p.sub_rows < td.rows ? sub0 + p.sub_rows : td.rows;
@@ -174,6 +180,12 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
       for (int e = 0; e < kE; ++e) pre[e] = p.bm_prefix[f[e] ? d[e] >> 6 : 0];
 #pragma unroll
       for (int e = 0; e < kE; ++e) hit[e] += pre[e];
+      if (p.bm_base) { // (uniform) chunk-local word ranks: + the set bits before the chunk
+#pragma unroll
+        for (int e = 0; e < kE; ++e) pre[e] = p.bm_base[f[e] ? (d[e] >> 6) >> p.bm_chunk_shift : 0];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) hit[e] += pre[e];
+      }
       if (!by_rank) {
         uint32_t g[kE];
 #pragma unroll
@@ -262,18 +274,61 @@ template <class P, bool WRITE> __device__ __forceinline__ void emit_body(const S
 template <class P> __device__ __forceinline__ void keybits_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
   unsigned long long *bits = reinterpret_cast<unsigned long long *>(p.aux_out);
+  if (p.kb_ranged && td.rows) { // (uniform) ascending keys: the tile's first and last row bound every key in it
+    Loaded lf, ll;
+    load_all<typename P::ColList>(p, td.dev_row, lf);
+    load_all<typename P::ColList>(p, td.dev_row + ((td.rows - 1) & ~1u), ll);
+    Ctx cf{p, lf, 0u, td.logical_row}, cl{p, ll, 0u, td.logical_row + td.rows - 1};
+    const long long first = (long long)P::ValE::eval(cf, 0), last = (long long)P::ValE::eval(cl, (int)((td.rows - 1) & 1u));
+    if (first > p.kb_hi || last < p.kb_lo) return;
+  }
   uint32_t perr = 0;
-  for (uint32_t r = threadIdx.x * 2; r < td.rows; r += kBlock * 2) {
-    Loaded ld;
-    load_all<typename P::ColList>(p, td.dev_row + r, ld);
+  // as the selection kernels: a wave owns a contiguous quarter of the tile, kSelUnroll steps of 128 rows are requested
+  // before the first is looked at, and the key-set words of all the rows a lane holds go out together
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t quarter = (td.rows + 3) / 4 + 127 & ~127u;
+  const uint32_t sub0 = wave * quarter < td.rows ? wave * quarter : td.rows;
+  const uint32_t sub1 = sub0 + quarter < td.rows ? sub0 + quarter : td.rows;
+  for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
+    Loaded lds[kSelUnroll];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      Ctx c{p, ld, 0u, td.logical_row + r + j};
-      const bool in_tile = (r + j) < td.rows;
-      const bool pass = in_tile & P::Pred::eval(c, j);
-      perr |= in_tile ? c.perr : 0u;
-      const uint64_t d = (uint64_t)(long long)P::ValE::eval(c, j) - (uint64_t)p.bm_min;
-      if (pass && d <= p.bm_span) atomicOr(&bits[d >> 6], 1ull << (d & 63));
+    for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+    bool fe[2 * kSelUnroll];
+    long long key[2 * kSelUnroll];
+    if constexpr (GatherSplit<typename P::Pred>::value) {
+      using G = GatherSplit<typename P::Pred>;
+      uint64_t d[2 * kSelUnroll], w[2 * kSelUnroll];
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        const bool pass = (row < sub1) & G::First::eval(c, e & 1);
+        d[e] = (uint64_t)(long long)G::Key::eval(c, e & 1) - (uint64_t)p.bm_min; // key < min wraps to a huge value
+        key[e] = (long long)P::ValE::eval(c, e & 1);
+        perr |= row < sub1 ? c.perr : 0u;
+        fe[e] = pass && d[e] <= p.bm_span;
+      }
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) w[e] = p.bm_bits[fe[e] ? d[e] >> 6 : 0];
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) fe[e] = fe[e] && ((w[e] >> (d[e] & 63)) & 1ull) != 0;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2 * kSelUnroll; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        fe[e] = (row < sub1) & P::Pred::eval(c, e & 1);
+        key[e] = (long long)P::ValE::eval(c, e & 1);
+        perr |= row < sub1 ? c.perr : 0u;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2 * kSelUnroll; ++e) {
+      const uint64_t d = (uint64_t)key[e] - (uint64_t)p.kb_min;
+      const bool wanted = !p.kb_ranged || (key[e] >= p.kb_lo && key[e] <= p.kb_hi);
+      // (measured: gathering a tile's words in the LDS first and storing them whole — the keys of a tile of an ascending
+      // column fall between its first and last key — is no faster than these atomics: 92 vs 90 µs over 15 M orders)
+      if (fe[e] && wanted && d <= p.kb_span) atomicOr(&bits[d >> 6], 1ull << (d & 63));
     }
   }
   if (perr) atomicOr(p.aux_out32, perr);

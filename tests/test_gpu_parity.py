@@ -2077,7 +2077,9 @@ def tpch_chunks(n, chunk=131072):
 @pytest.mark.parametrize("switches", [("LLKV_HIP_JOIN_HASH",), ("LLKV_HIP_JOIN_SORT",), ("LLKV_HIP_TOPK_SORT",), ("LLKV_HIP_TOPK_SORT", "LLKV_HIP_TOPK_FULL"),
                                       ("LLKV_HIP_JOIN_HASH", "LLKV_HIP_JOIN_SORT", "LLKV_HIP_TOPK_SORT"), ("LLKV_HIP_SELECT_TWO_PASS",),
                                       ("LLKV_HIP_JOIN_UNSORTED",), ("LLKV_HIP_JOIN_UNSORTED", "LLKV_HIP_JOIN_NO_SINK"), ("LLKV_HIP_READBACK_SYNC",),
-                                      ("LLKV_HIP_JOIN_COMPACT",), ("LLKV_HIP_JOIN_COMPACT", "LLKV_HIP_JOIN_SORT")])
+                                      ("LLKV_HIP_JOIN_COMPACT",), ("LLKV_HIP_JOIN_COMPACT", "LLKV_HIP_JOIN_SORT"),
+                                      ("LLKV_HIP_JOIN_LISTED",), ("LLKV_HIP_JOIN_LISTED", "LLKV_HIP_JOIN_SORT"), ("LLKV_HIP_JOIN_RANK_SCAN",),
+                                      ("LLKV_HIP_JOIN_RANK_SCAN", "LLKV_HIP_TOPK_SORT"), ("LLKV_HIP_JOIN_SORT", "LLKV_HIP_JOIN_COMPACT", "LLKV_HIP_TOPK_SORT")])
 def test_join_pipeline_fallback_forms_give_the_same_rows(rt, abi, tpch, monkeypatch, switches):
     """The join → aggregate pipeline has a general form behind every shortcut (hash table behind bitmap + rank, pair
     sort behind run sums, radix-sort top-k behind the threshold selection): forced through the switches of DESIGN §10
