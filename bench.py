@@ -302,8 +302,10 @@ def measure_q3(rt, tpch, abi, sf):
 
 def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
     """BASELINE.json configs[4]: build side (orders, customer) replicated on every rank, lineitem sharded by chunk; per
-    step = local build + probe + per-group sums (JoinAgg) then llkv_hip_join_agg_finish_sharded (one int64 all-reduce
-    of the per-group row counts over RCCL, all-gathers of the straddlers and of ≤ limit candidates)."""
+    step = local build + probe + per-group sums (JoinAgg) then llkv_hip_join_agg_finish_sharded.  The range form first
+    (lineitem is clustered by the order key: every rank selects the orders of its own key range only and the ranks
+    exchange ~1 KB of boundary runs + their candidates); if a rank refuses it, the general form (one int64 all-reduce of
+    the per-group row counts over RCCL, all-gathers of the straddlers and of <= limit candidates)."""
     rows, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
     D = tpch.DATE_1995_03_15
     chunks = tpch.chunk_rows(rows)
@@ -328,11 +330,38 @@ def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
     F, O, col = abi.Filter, abi.Operator, abi.col
     rev = col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT))
 
+    state = {"ranged": True, "bytes": 0}
+
     def run():
-        ja = rt.JoinAgg(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, rev,
-                        payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
-                        dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
-        return ja.finish_sharded(10)  # counts all-reduce + straddler / candidate all-gathers inside the library (RCCL)
+        def once(ranged):
+            ja = rt.JoinAgg(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, rev,
+                            payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                            dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY, ranged=ranged)
+            out = ja.finish_sharded(10)  # the collectives run inside the library (RCCL)
+            state["bytes"] = ja.exchange_bytes()
+            return out
+        if state["ranged"]:
+            # prepare refuses a shape that does not qualify on this rank, finish_sharded a pair stream out of key order
+            # (on every rank alike): all ranks must take the same form, so they agree first
+            ok = 1
+            res = None
+            try:
+                ja_try = rt.JoinAgg(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, rev,
+                                    payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                                    dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY, ranged=True)
+            except abi.LlkvError:
+                ok, ja_try = 0, None
+            flag = torch.tensor([ok], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                try:
+                    res = ja_try.finish_sharded(10)
+                    state["bytes"] = ja_try.exchange_bytes()
+                    return res
+                except abi.LlkvError:
+                    pass
+            state["ranged"] = False
+        return once(False)
 
     run()
     ts = []
@@ -350,7 +379,8 @@ def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):
     for t in (lt, ot, ct):
         t.close()
     return {"rows_per_s": rows / med, "ms_per_step": med * 1e3, "groups": int(groups), "achieved_gbs": alg / med / 1e9,
-            "frac": alg / med / 1e9 / (HBM_PEAK_GBS * world), "scaling": "strong",
+            "frac": alg / med / 1e9 / (HBM_PEAK_GBS * world), "scaling": "strong", "form": "range" if state["ranged"] else "general",
+            "exchanged_bytes_per_query": int(state["bytes"]),
             "note": "probe side sharded by chunk, build side replicated; max over ranks, host-timed median of 7, collectives included"}
 
 

@@ -797,6 +797,36 @@ llkv_status llkv_hip_join_agg_candidates(llkv_hip_join_agg *h, const uint32_t *f
 llkv_status llkv_hip_join_agg_merge(const llkv_join_group_row *rows, uint32_t n, uint32_t n_payload,
                                     uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n);
 
+/* The RANGE form of the sharded pipeline, for a fact table clustered by the join key (lineitem by l_orderkey) and a
+ * dimension whose key column is in ascending row order with a statistics-bounded range (orders by o_orderkey).  A rank
+ * then needs the dimension rows of its own key range only: the dimension scan leaves at once every tile whose keys lie
+ * outside [min, max] of the rank's fact keys (1/world of the dimension work instead of all of it), group ids are local
+ * (rank of the key in the rank's own bitmap) and nothing is exchanged per group: a group can straddle two ranks only as
+ * the LAST group of one rank's pair stream and the FIRST of the next one's, so every rank publishes those two runs as raw
+ * values (`boundary`: a few hundred bytes), folds the shared ones in rank order = global row order, and reports its
+ * candidates as before.  Per query and rank: ~1 KB of boundary runs + `limit` candidate rows, instead of 8 B per
+ * qualifying dimension row.  Results are bit-identical to the single-GPU call.
+ *   prepare_ranged   as prepare; LLKV_UNSUPPORTED when the shape does not qualify (take prepare)
+ *   boundary         this rank's block for the all-gather (valid until the handle is freed)
+ *   finish_ranged    with every rank's block (rank order; `offsets[world + 1]`): folds the shared boundary groups and
+ *                    returns this rank's candidates and how many groups it reports; LLKV_UNSUPPORTED — identically on
+ *                    every rank — when the pair streams turn out not to be in key order across the ranks, or a boundary
+ *                    run is longer than the block holds (64 rows): free the handle and take the general form
+ *   merge            as above, over the all-gathered candidates
+ * llkv_hip_join_agg_finish_sharded runs either form's collectives; counts_buffer / straddlers / candidates refuse a
+ * ranged handle.                                                                                                    */
+llkv_status llkv_hip_join_agg_prepare_ranged(const llkv_join_side *fact, const llkv_join_side *dim,
+                                             uint32_t dim_fk_field, const llkv_join_side *dim2 /* may be NULL */,
+                                             const uint32_t *payload_fields, uint32_t n_payload,
+                                             const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
+                                             llkv_hip_join_agg **out);
+llkv_status llkv_hip_join_agg_boundary(llkv_hip_join_agg *h, const void **block, uint64_t *bytes);
+/* Measurement hook: bytes the collectives of the last llkv_hip_join_agg_finish_sharded call moved (all ranks' shares). */
+uint64_t llkv_hip_join_agg_exchange_bytes(const llkv_hip_join_agg *h);
+llkv_status llkv_hip_join_agg_finish_ranged(llkv_hip_join_agg *h, const void *blocks, const uint64_t *offsets /* [world + 1] */,
+                                            uint32_t world, uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows,
+                                            uint32_t *out_n, uint64_t *out_groups /* groups this rank reports */);
+
 /* ------------------------------------------------------------------------- */
 /* Multi-GPU combine, host pieces (no device needed).  The chunk list is cut    */
 /* into 8 canonical octants (boundaries floor(j·C/8)); rank r of `world` owns   */

@@ -303,7 +303,7 @@ struct GatherItems; // join.hpp
 struct Readback {
   static constexpr size_t kBytes = 64 << 10;
   struct Item { void *dst; const void *src; size_t off, bytes; };
-  Item items[8];
+  Item items[12];
   int n = 0, launched = 0;
   size_t used = 0;
   uint32_t seq = 0; // what the gathering workgroup stores behind the slab when it is done (0: nobody does)

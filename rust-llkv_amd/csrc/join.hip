@@ -567,12 +567,13 @@ hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64
 }
 // the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
 __global__ __launch_bounds__(256) void hj_run_sums_dev_kernel(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, double *sum_by_group,
-                                                               unsigned long long *count_by_group, uint32_t *multi_run) {
+                                                               unsigned long long *count_by_group, uint32_t *multi_run, uint32_t *descending) {
   const uint64_t n = *n_dev;
   if (n >= kPredErrorBit) return;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t g = group[i];
     if (i != 0 && group[i - 1] == g) continue;
+    if (descending && i != 0 && group[i - 1] > g) atomicOr(descending, 1u); // the pair stream is not in group (= key) order
     double acc = 0.0;
     uint64_t j = i;
     for (; j < n && group[j] == g; ++j) acc += __longlong_as_double((long long)val[j]);
@@ -581,10 +582,10 @@ __global__ __launch_bounds__(256) void hj_run_sums_dev_kernel(const uint32_t *gr
   }
 }
 hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
-                                  uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s) {
+                                  uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s, uint32_t *descending) {
   if (n_max == 0) return hipSuccess;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_max + 255) / 256, 2048);
-  hipLaunchKernelGGL(hj_run_sums_dev_kernel, dim3(grid), dim3(256), 0, s, group, val, n_dev, sum_by_group, (unsigned long long *)count_by_group, multi_run);
+  hipLaunchKernelGGL(hj_run_sums_dev_kernel, dim3(grid), dim3(256), 0, s, group, val, n_dev, sum_by_group, (unsigned long long *)count_by_group, multi_run, descending);
   return hipGetLastError();
 }
 hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *sorted_val, uint64_t n, double *sum_by_slot,
@@ -1075,8 +1076,18 @@ template <class F> __device__ __forceinline__ uint64_t gallop_last_true(uint64_t
   }
   return a;
 }
+// the position (key − rank_kmin) of the g-th set bit
+__device__ __forceinline__ uint64_t group_key_bit(const CandidateCols &cols, uint32_t g);
 __device__ __forceinline__ uint64_t group_owner_row(const uint64_t *dim_rows, const CandidateCols &cols, uint32_t g) {
   if (!cols.rank_bits) return dim_rows[g];
+  const long long key = cols.rank_kmin + (long long)group_key_bit(cols, g);
+  // the row of the ascending key column that holds it: the last row whose key is <= key
+  const uint64_t last = cols.rank_rows - 1;
+  const long long k0 = load_key(cols.key, 0), k1 = load_key(cols.key, last);
+  const uint64_t guess = k1 > k0 ? (uint64_t)((double)(key - k0) / (double)(k1 - k0) * (double)last) : 0;
+  return gallop_last_true(0, cols.rank_rows, guess, [&](uint64_t i) { return load_key(cols.key, i) <= key; });
+}
+__device__ __forceinline__ uint64_t group_key_bit(const CandidateCols &cols, uint32_t g) {
   uint32_t cl = 0, ch = cols.rank_chunks; // the chunk: base[cl] <= g < base[ch]
   while (ch - cl > 1) {
     const uint32_t mid = (cl + ch) >> 1;
@@ -1088,12 +1099,31 @@ __device__ __forceinline__ uint64_t group_owner_row(const uint64_t *dim_rows, co
                                          [&](uint64_t i) { return cols.rank_prefix[i] <= gl; }); // prefix[word] <= gl < prefix[word + 1]
   uint64_t w = cols.rank_bits[word];
   for (uint32_t k = gl - cols.rank_prefix[word]; k; --k) w &= w - 1; // drop the set bits before it
-  const long long key = cols.rank_kmin + (long long)(word * 64 + (uint64_t)__ffsll((unsigned long long)w) - 1);
-  // the row of the ascending key column that holds it: the last row whose key is <= key
-  const uint64_t last = cols.rank_rows - 1;
-  const long long k0 = load_key(cols.key, 0), k1 = load_key(cols.key, last);
-  const uint64_t guess = k1 > k0 ? (uint64_t)((double)(key - k0) / (double)(k1 - k0) * (double)last) : 0;
-  return gallop_last_true(0, cols.rank_rows, guess, [&](uint64_t i) { return load_key(cols.key, i) <= key; });
+  return word * 64 + (uint64_t)__ffsll((unsigned long long)w) - 1;
+}
+// Range form of a sharded fact table (join_agg.cpp): the first and the last run of this rank's pair stream — the only
+// groups another rank can hold rows of — as raw values.  out (u64 words): [0] first group, [1] its key bit, [2] rows of
+// its run, [3] last group, [4] its key bit, [5] rows of its run (0: it IS the first run), [8 …) ≤ cap values of the first
+// run, [8 + cap …) of the last; a run longer than cap reports cap + 1 rows.  One thread: the runs are a few rows.
+__global__ void hj_boundary_runs_kernel(const uint32_t *group, const uint64_t *val, uint64_t n, const uint64_t *n_dev, uint32_t cap, CandidateCols cols, uint64_t *out) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (uint32_t i = 0; i < 8; ++i) out[i] = 0;
+  if (n_dev) n = *n_dev; // (a count that carries the predicate-error mark: the host reports the error, nothing here is looked at)
+  if (n == 0 || n >= kPredErrorBit) return;
+  const uint32_t g0 = group[0], g1 = group[n - 1];
+  uint64_t a = 0;
+  while (a < n && a <= cap && group[a] == g0) { if (a < cap) out[8 + a] = val[a]; ++a; }
+  out[0] = g0; out[1] = group_key_bit(cols, g0); out[2] = a;
+  out[3] = g1; out[4] = group_key_bit(cols, g1);
+  if (a >= n) return; // one run is the whole stream
+  uint64_t b = 0;
+  while (b < n && b <= cap && group[n - 1 - b] == g1) ++b;
+  out[5] = b;
+  for (uint64_t i = 0; i < b && i < cap; ++i) out[8 + cap + i] = val[n - (b < cap ? b : cap) + i]; // row order
+}
+hipError_t hj_launch_boundary_runs(const uint32_t *group, const uint64_t *val, uint64_t n, const uint64_t *n_dev, uint32_t cap, CandidateCols cols, uint64_t *out, hipStream_t s) {
+  hipLaunchKernelGGL(hj_boundary_runs_kernel, dim3(1), dim3(64), 0, s, group, val, n, n_dev, cap, cols, out);
+  return hipGetLastError();
 }
 // Both launches: one 1024-thread workgroup per slice (as much in flight as 4× the workgroups, a quarter of the tickets).
 __global__ __launch_bounds__(1024) void hj_topk_bound_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t per, uint32_t want, uint64_t *best,

@@ -90,8 +90,8 @@ hipError_t hj_launch_fill_zero_ranges(const FillRanges &r, hipStream_t s);
 // When seq != 0 the workgroup finally stores seq into host word flag_word: the host may poll that word instead of
 // synchronising the stream.
 struct GatherItems {
-  const uint32_t *src[8];
-  uint32_t dst_word[8], words[8];
+  const uint32_t *src[12];
+  uint32_t dst_word[12], words[12];
   int n;
   uint32_t flag_word, seq;
 };
@@ -181,8 +181,9 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
 // run sums straight from the probe's stripes; flags[0]: some group had two runs, flags[1]: a stripe count carried the predicate-error mark
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
                                       double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s);
+// `descending` (optional): raised when a run starts below the group of the pair before it
 hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
-                                  uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s);
+                                  uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s, uint32_t *descending = nullptr);
 hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64_t n, double *sum_by_group, uint64_t *count_by_group,
                               uint32_t *multi_run, hipStream_t s);
 hipError_t hj_launch_topk_keys(const double *sum_by_slot, const uint64_t *count_by_slot, uint64_t cap, uint64_t *keys, uint32_t *slots,
@@ -267,6 +268,10 @@ hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, ui
                                   uint64_t *best, uint64_t *state, uint32_t *groups /*[cap]*/, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
                                   hipStream_t s, const uint32_t *n_dev = nullptr);
 hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s);
+// Range form of a sharded fact table: the first and the last run of a pair stream with their key bits and raw values
+// (join.hip: hj_boundary_runs_kernel; out = 8 + 2 · cap words of device memory)
+// `n_dev` (optional): the pair count is still on the device
+hipError_t hj_launch_boundary_runs(const uint32_t *group, const uint64_t *val, uint64_t n, const uint64_t *n_dev, uint32_t cap, CandidateCols cols, uint64_t *out, hipStream_t s);
 hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,
                                              uint64_t *out /*[n][8]*/, hipStream_t s);

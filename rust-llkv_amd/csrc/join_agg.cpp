@@ -163,6 +163,18 @@ struct JoinAgg {
   // key among the set bits, the number of groups stays on the device (dt.prefix[dt.n_words]) until the final read-back
   bool ranked = false;
   uint32_t n_dim_dev = 0, dim_err = 0;
+  // range form of a sharded fact table (llkv_hip.h: llkv_hip_join_agg_prepare_ranged): the dimension selection is
+  // restricted to the key range of this rank's fact rows, group ids are local, the boundary runs are exchanged
+  bool range_form = false;
+  uint32_t desc_run = 0;
+  uint64_t last_exchange_bytes = 0; // what finish_sharded moved between the ranks (all ranks' contributions)
+  DB boundary_d;                        // the boundary kernel's output; its copy travels with prepare()'s read-back
+  std::vector<uint64_t> boundary_raw;
+  std::vector<uint64_t> boundary_block; // [0] bad, [1] pairs, [2] first key bit, [3] rows, [4] last key bit, [5] rows, [6] / [7] their local groups, 64 + 64 values
+  static constexpr uint32_t kBoundaryCap = 64;
+  int boundary();
+  int finish_ranged(const uint64_t *blocks, const uint64_t *offsets, uint32_t world, uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows,
+                    uint32_t *out_n, uint64_t *out_groups);
   DB rank_base;  // ranked form: set bits before each chunk of 2^rank_shift bitmap words; [rank_chunks] = the number of groups
   uint32_t rank_shift = 0, rank_chunks = 0;
   const uint32_t *n_dim_ptr() const { return static_cast<const uint32_t *>(rank_base.p) + rank_chunks; }
@@ -227,7 +239,13 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   const bool dim_sorted = direct && kd_info.ascending && !std::getenv("LLKV_HIP_JOIN_UNSORTED");
   const bool sink_bits = fused_semi && direct && !std::getenv("LLKV_HIP_JOIN_NO_SINK");
   int64_t key_range_lo = 0, key_range_hi = -1; // (range form of a sharded fact table: the keys this rank's fact rows can hold)
-  const bool use_key_range = false;
+  const bool use_key_range = range_form;
+  if (range_form) {
+    auto fk_it = tf->cols.find(fact->key_field);
+    if (fk_it == tf->cols.end()) return set_error(LLKV_NOT_FOUND, "field " + std::to_string(fact->key_field) + " not found");
+    if (tf->local_rows && !fk_it->second.has_local_stats) return set_error(LLKV_UNSUPPORTED, "range form: no statistics of this rank's fact keys");
+    if (tf->local_rows) { key_range_lo = fk_it->second.local_min; key_range_hi = fk_it->second.local_max; }
+  }
   ranked = direct && dim_sorted && (!t2 || fused_semi) && kd_info.dtype == LLKV_DT_INT64 && td->local_rows && !std::getenv("LLKV_HIP_JOIN_NO_SINK") &&
            !std::getenv("LLKV_HIP_JOIN_LISTED");
   // ---- everything that starts from zero, in one fill: the key bitmaps, the probe's per-stripe counts, the flags --------
@@ -237,7 +255,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   {
     FillRanges fr;
     if (fused_semi && (rc = set2_bits.prepare_bits(t2->cols.find(dim2->key_field)->second.info, s, &fr))) return rc;
-    if ((sink_bits || ranked) && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
+    if (range_form && !ranked) return set_error(LLKV_UNSUPPORTED, "range form: the dimension key must be an Int64 column in ascending row order with a statistics-bounded range");
+  if ((sink_bits || ranked) && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
     dt.in_key_order = dim_sorted;
     if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8)) || (rc = zeros.alloc(256))) return rc;
     fr.add(counts.p, (size_t)(n_slots + 1) * 8); // the extra trailing 0 makes offsets[n_slots] the total
@@ -327,7 +346,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
       pd.kb_min = dt.kmin;
       pd.kb_span = dt.span;
       if (t2) { pd.bm_bits = (const uint64_t *)set2_bits.bits.p; pd.bm_min = set2_bits.kmin; pd.bm_span = set2_bits.span; }
-      if (key_range_lo <= key_range_hi && use_key_range) { pd.kb_ranged = 1; pd.kb_lo = key_range_lo; pd.kb_hi = key_range_hi; }
+      if (use_key_range) { pd.kb_ranged = 1; pd.kb_lo = key_range_lo; pd.kb_hi = key_range_hi; } // (no fact rows: the empty range — no tile stays)
       if ((rc = jit_launch_raw(kk.fn, tsd->n_tiles, &pd, sizeof pd, s))) return rc;
     }
     dim_err_flag = dt.flag_p + 1;
@@ -502,9 +521,16 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   } else if ((rc = compact_pairs(true))) {
     return rc;
   }
+  if (range_form) { // the boundary runs of the pair stream, while the pair count is still on its way to the host
+    boundary_raw.assign(8 + 2 * kBoundaryCap, 0);
+    if ((rc = boundary_d.alloc(boundary_raw.size() * 8))) return rc;
+    HIP_TRY(hj_launch_boundary_runs((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, 0, (const uint64_t *)offsets.p + n_slots, kBoundaryCap, cc, (uint64_t *)boundary_d.p, s));
+    if ((rc = rb.add(boundary_raw.data(), boundary_d.p, boundary_raw.size() * 8, s))) return rc;
+  }
   if ((!from_stripes && (rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s))) || (from_stripes && (rc = rb.add(&pred_err, multi_p() + 1, 4, s))) ||
       (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) || (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) ||
       (dim_err_flag && (rc = rb.add(&dim_err, dim_err_flag, 4, s))) || (ranked && (rc = rb.add(&n_dim_dev, n_dim_ptr(), 4, s))) ||
+      (range_form && (rc = rb.add(&desc_run, multi_p() + 3, 4, s))) ||
       (rc = rb.add(&multi_run, multi_p(), 4, s)))
     return rc;
   pending = true;
@@ -529,7 +555,7 @@ int JoinAgg::compact_pairs(bool run_sums) {
                                     direct_form ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
   if (run_sums)
     HIP_TRY(hj_launch_run_sums_dev((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, (const uint64_t *)offsets.p + n_slots, max_pairs, (double *)sums.p,
-                                   (uint64_t *)cnts.p, multi_p(), s));
+                                   (uint64_t *)cnts.p, multi_p(), s, range_form ? multi_p() + 3 : nullptr));
   return LLKV_OK;
 }
 
@@ -553,11 +579,11 @@ int JoinAgg::settle(bool delivered) {
   }
   if (n_pairs >= kPredErrorBit) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (n_pairs == 0) return LLKV_OK;
-  if (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT")) {
+  if (range_form || (!multi_run && !std::getenv("LLKV_HIP_JOIN_SORT"))) {
     std::swap(s_group.p, e_group.p); // a group's pairs are contiguous and in row order: all the later phases need
     std::swap(s_val.p, e_val.p);
-    if (tf->world != 1) HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
-    return LLKV_OK;
+    if (tf->world != 1 && !range_form) HIP_TRY(hipMemcpyAsync(gcnts.p, cnts.p, n_dim * 8, hipMemcpyDeviceToDevice, s)); // the image the ranks all-reduce
+    return LLKV_OK; // (range form with a second run of some group: finish_ranged refuses, on every rank)
   }
   uint32_t bits = 1;
   while ((1ull << bits) < n_dim) ++bits;
@@ -615,7 +641,7 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   hipStream_t s = g_ctx.stream;
   int rc;
   // groups this rank reports: the ones it alone holds … (one rank holds every group alone: its counts are the report)
-  const bool alone = tf->world == 1 && n_folded == 0;
+  const bool alone = (tf->world == 1 || range_form) && n_folded == 0;
   const bool by_selection = !std::getenv("LLKV_HIP_TOPK_SORT") && limit <= kTopkSlices;
   // a deferred prepare(): its read-back rides with the selection's below; anything else needs it settled first
   if (pending && !(alone && by_selection) && (rc = settle())) return rc;
@@ -752,9 +778,92 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
   return LLKV_OK;
 }
 
+// ---- range form: boundary runs ------------------------------------------------------------------------------------------
+int JoinAgg::boundary() {
+  if (!range_form) return set_error(LLKV_INVALID_ARGUMENT, "not a ranged handle: take counts_buffer / straddlers / candidates");
+  int rc;
+  if (pending && (rc = settle())) return rc;
+  boundary_block.assign(8 + 2 * kBoundaryCap, 0);
+  boundary_block[0] = (multi_run || desc_run) ? 1 : 0;
+  boundary_block[1] = n_pairs;
+  if (n_pairs == 0 || n_dim == 0 || boundary_block[0]) return LLKV_OK;
+  if (boundary_raw.size() != boundary_block.size()) return set_error(LLKV_INTERNAL, "boundary runs were not taken");
+  const std::vector<uint64_t> &raw = boundary_raw;
+  boundary_block[2] = raw[1]; boundary_block[3] = raw[2];
+  boundary_block[4] = raw[4]; boundary_block[5] = raw[5];
+  boundary_block[6] = raw[0]; boundary_block[7] = raw[3];
+  std::copy(raw.begin() + 8, raw.end(), boundary_block.begin() + 8);
+  return LLKV_OK;
+}
+
+int JoinAgg::finish_ranged(const uint64_t *blocks, const uint64_t *offsets, uint32_t world, uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows,
+                           uint32_t *out_n, uint64_t *out_groups) {
+  if (!range_form) return set_error(LLKV_INVALID_ARGUMENT, "not a ranged handle");
+  if (boundary_block.empty()) return set_error(LLKV_INVALID_ARGUMENT, "finish_ranged before boundary");
+  const uint64_t words = 8 + 2 * kBoundaryCap;
+  // every rank sees the same blocks and takes the same decisions
+  struct Seg { uint64_t key; uint32_t rank; bool first; const uint64_t *vals; uint64_t n; };
+  std::vector<Seg> segs;
+  bool have_prev = false;
+  uint64_t prev_last = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    if (offsets[r + 1] - offsets[r] != words * 8 || offsets[r] % 8) return set_error(LLKV_INVALID_ARGUMENT, "malformed boundary block");
+    const uint64_t *b = blocks + offsets[r] / 8;
+    if (b[0]) return set_error(LLKV_UNSUPPORTED, "range form: the pairs of rank " + std::to_string(r) + " are not in key order (the fact table is not clustered by the join key)");
+    if (b[1] == 0) continue;
+    if (b[3] > kBoundaryCap || b[5] > kBoundaryCap) return set_error(LLKV_UNSUPPORTED, "range form: a boundary group of rank " + std::to_string(r) + " has more than 64 rows");
+    if (have_prev && b[2] < prev_last) return set_error(LLKV_UNSUPPORTED, "range form: the key ranges of the ranks' pairs overlap");
+    segs.push_back({b[2], r, true, b + 8, b[3]});
+    if (b[5]) segs.push_back({b[4], r, false, b + 8 + kBoundaryCap, b[5]});
+    prev_last = b[5] ? b[4] : b[2];
+    have_prev = true;
+  }
+  // a key that more than one rank holds: its exact sum in rank order = global row order (SumFloat64: 0.0, then +=)
+  std::vector<uint32_t> pg;
+  std::vector<double> ps;
+  std::vector<uint64_t> pc;
+  for (size_t i = 0; i < segs.size();) {
+    size_t j = i + 1;
+    while (j < segs.size() && segs[j].key == segs[i].key) ++j;
+    if (j - i > 1) {
+      double sum = 0.0;
+      uint64_t cnt = 0;
+      for (size_t k = i; k < j; ++k)
+        for (uint64_t v = 0; v < segs[k].n; ++v) { double x; std::memcpy(&x, &segs[k].vals[v], 8); sum += x; ++cnt; }
+      for (size_t k = i; k < j; ++k) {
+        if (segs[k].rank != rank) continue;
+        pg.push_back((uint32_t)(segs[k].first ? boundary_block[6] : boundary_block[7]));
+        ps.push_back(sum);
+        pc.push_back(k == i ? cnt : 0); // the first rank that holds the group reports it; the others drop it
+      }
+    }
+    i = j;
+  }
+  int rc;
+  hipStream_t s = g_ctx.stream;
+  if (!pg.empty()) {
+    DB dg, dsum, dcnt;
+    if ((rc = dg.alloc(pg.size() * 4)) || (rc = dsum.alloc(pg.size() * 8)) || (rc = dcnt.alloc(pg.size() * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(dg.p, pg.data(), pg.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dsum.p, ps.data(), ps.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dcnt.p, pc.data(), pc.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hj_launch_patch_groups((const uint32_t *)dg.p, (const double *)dsum.p, (const uint64_t *)dcnt.p, pg.size(), (double *)sums.p, (uint64_t *)cnts.p, s));
+    HIP_TRY(hipStreamSynchronize(s)); // the host vectors are pageable
+  }
+  *out_n = 0;
+  if (out_groups) *out_groups = 0;
+  if (n_dim == 0 || n_pairs == 0) return LLKV_OK;
+  if ((rc = candidates(nullptr, nullptr, nullptr, nullptr, 0, rank, limit, out_rows, out_n, out_groups))) return rc;
+  for (uint32_t i = 0; i < *out_n; ++i) out_rows[i].group_index = (uint64_t)(out_rows[i].key - dt.kmin); // the tie-break every rank agrees on: key order = dim row order
+  return LLKV_OK;
+}
+
 } // namespace llkv
 
 using namespace llkv;
+
+static llkv_status finish_candidates(JoinAgg *j, const llkv_join_group_row *cand, uint32_t n_cand, uint64_t reported, uint32_t world, uint32_t limit,
+                                     llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_total_groups);
 
 extern "C" {
 
@@ -769,11 +878,43 @@ llkv_status llkv_hip_join_agg_prepare(const llkv_join_side *fact, const llkv_joi
   return LLKV_OK;
 }
 
+llkv_status llkv_hip_join_agg_prepare_ranged(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
+                                             const uint32_t *payload_fields, uint32_t n_payload, const llkv_expr_token *sum_expr, uint32_t sum_expr_len,
+                                             llkv_hip_join_agg **out) {
+  if (!out) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "out is NULL");
+  if (std::getenv("LLKV_HIP_JOIN_NO_RANGE")) return (llkv_status)set_error(LLKV_UNSUPPORTED, "range form switched off (LLKV_HIP_JOIN_NO_RANGE)");
+  auto *j = new JoinAgg();
+  j->range_form = true;
+  const int rc = j->prepare(fact, dim, dim_fk_field, dim2, payload_fields, n_payload, sum_expr, sum_expr_len);
+  if (rc) { delete j; return (llkv_status)rc; }
+  *out = reinterpret_cast<llkv_hip_join_agg *>(j);
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_join_agg_boundary(llkv_hip_join_agg *h, const void **block, uint64_t *bytes) {
+  auto *j = reinterpret_cast<JoinAgg *>(h);
+  if (!j || !block || !bytes) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  const int rc = j->boundary();
+  if (rc) return (llkv_status)rc;
+  *block = j->boundary_block.data();
+  *bytes = j->boundary_block.size() * 8;
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_join_agg_finish_ranged(llkv_hip_join_agg *h, const void *blocks, const uint64_t *offsets, uint32_t world, uint32_t rank, uint32_t limit,
+                                            llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups) {
+  auto *j = reinterpret_cast<JoinAgg *>(h);
+  if (!j || !blocks || !offsets || !out_rows || !out_n || world == 0 || rank >= world) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if ((uintptr_t)blocks % 8) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "boundary blocks must be 8-byte aligned");
+  return (llkv_status)j->finish_ranged(static_cast<const uint64_t *>(blocks), offsets, world, rank, limit, out_rows, out_n, out_groups);
+}
+
 void llkv_hip_join_agg_free(llkv_hip_join_agg *h) { delete reinterpret_cast<JoinAgg *>(h); }
 
 llkv_status llkv_hip_join_agg_counts_buffer(llkv_hip_join_agg *h, void **device_ptr, uint64_t *len_i64) {
   auto *j = reinterpret_cast<JoinAgg *>(h);
   if (!j || !device_ptr || !len_i64) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (j->range_form) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "a ranged handle exchanges boundary runs, not counts: boundary / finish_ranged");
   *device_ptr = j->gcnts.p;
   *len_i64 = j->n_dim;
   return LLKV_OK;
@@ -782,6 +923,7 @@ llkv_status llkv_hip_join_agg_counts_buffer(llkv_hip_join_agg *h, void **device_
 llkv_status llkv_hip_join_agg_straddlers(llkv_hip_join_agg *h, const uint32_t **groups, const double **values, uint64_t *n) {
   auto *j = reinterpret_cast<JoinAgg *>(h);
   if (!j || !groups || !values || !n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (j->range_form) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "a ranged handle exchanges boundary runs: boundary / finish_ranged");
   const int rc = j->straddlers();
   if (rc) return (llkv_status)rc;
   *groups = j->st_groups.data();
@@ -827,6 +969,7 @@ llkv_status llkv_hip_join_agg_candidates(llkv_hip_join_agg *h, const uint32_t *f
   auto *j = reinterpret_cast<JoinAgg *>(h);
   if (!j || !out_rows || !out_n) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
   if (n_folded && (!folded_groups || !folded_sums || !folded_counts || !folded_first_rank)) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL folded arrays");
+  if (j->range_form) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "a ranged handle reports its candidates through finish_ranged");
   return (llkv_status)j->candidates(folded_groups, folded_sums, folded_counts, folded_first_rank, n_folded, rank, limit, out_rows, out_n, out_groups);
 }
 
@@ -853,6 +996,20 @@ llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limi
   const uint32_t world = comm_world(), rank = comm_rank();
   if (j->tf->world != world || j->tf->rank != rank) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the fact table's (rank, world) is not the communicator's");
   int rc;
+  std::vector<uint64_t> off;
+  std::vector<llkv_join_group_row> cand(std::max(1u, limit));
+  uint32_t n_cand = 0;
+  uint64_t reported = 0;
+  if (j->range_form) { // one small all-gather of the boundary runs instead of the per-group counts and the straddler pairs
+    if ((rc = j->boundary())) return (llkv_status)rc;
+    std::vector<uint8_t> all;
+    if ((rc = comm_allgather_v(j->boundary_block.data(), j->boundary_block.size() * 8, &all, &off))) return (llkv_status)rc;
+    std::vector<uint64_t> aligned((all.size() + 7) / 8);
+    std::memcpy(aligned.data(), all.data(), all.size());
+    if ((rc = j->finish_ranged(aligned.data(), off.data(), world, rank, limit, cand.data(), &n_cand, &reported))) return (llkv_status)rc;
+    j->last_exchange_bytes = all.size();
+    return finish_candidates(j, cand.data(), n_cand, reported, world, limit, out_rows, out_n, out_total_groups);
+  }
   if (j->n_dim && (rc = comm_allreduce_i64_device(static_cast<int64_t *>(j->gcnts.p), j->n_dim, g_ctx.stream))) return (llkv_status)rc;
   if ((rc = j->straddlers())) return (llkv_status)rc; // on the same stream: ordered behind the all-reduce
   // straddler pairs of every rank, rank order = global row order: [n][values f64 × n][groups u32 × n]
@@ -863,8 +1020,8 @@ llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limi
     std::memcpy(mine.data() + 8, j->st_vals.data(), n * 8);
     std::memcpy(mine.data() + 8 + n * 8, j->st_groups.data(), n * 4);
   }
-  std::vector<uint64_t> off;
   if ((rc = comm_allgather_v(mine.data(), mine.size(), &all, &off))) return (llkv_status)rc;
+  j->last_exchange_bytes = j->n_dim * 8 * 2 + all.size(); // the all-reduce moves the counts out and back
   std::vector<uint32_t> groups;
   std::vector<double> values;
   std::vector<uint64_t> rank_off(world + 1, 0);
@@ -884,17 +1041,24 @@ llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limi
   std::vector<uint64_t> fc(n_folded);
   if ((rc = llkv_hip_join_agg_fold_straddlers(groups.data(), values.data(), rank_off.data(), world, fg.data(), fs.data(), fc.data(), ffirst.data(), &n_folded)))
     return (llkv_status)rc;
-  std::vector<llkv_join_group_row> cand(std::max(1u, limit));
-  uint32_t n_cand = 0;
-  uint64_t reported = 0;
   if ((rc = j->candidates(fg.data(), fs.data(), fc.data(), ffirst.data(), n_folded, rank, limit, cand.data(), &n_cand, &reported))) return (llkv_status)rc;
-  // candidates of every rank: [reported groups][n][rows]
+  return finish_candidates(j, cand.data(), n_cand, reported, world, limit, out_rows, out_n, out_total_groups);
+}
+
+} // extern "C"
+
+// candidates of every rank: [reported groups][n][rows] → all-gather → ORDER BY / LIMIT
+static llkv_status finish_candidates(JoinAgg *j, const llkv_join_group_row *cand, uint32_t n_cand, uint64_t reported, uint32_t world, uint32_t limit,
+                                     llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_total_groups) {
+  int rc;
+  std::vector<uint64_t> off;
   static_assert(sizeof(llkv_join_group_row) % 8 == 0, "rows travel as 8-byte words");
   std::vector<uint8_t> cmine(16 + (size_t)n_cand * sizeof(llkv_join_group_row)), call;
   const uint64_t head[2] = {reported, n_cand};
   std::memcpy(cmine.data(), head, 16);
-  if (n_cand) std::memcpy(cmine.data() + 16, cand.data(), (size_t)n_cand * sizeof(llkv_join_group_row));
+  if (n_cand) std::memcpy(cmine.data() + 16, cand, (size_t)n_cand * sizeof(llkv_join_group_row));
   if ((rc = comm_allgather_v(cmine.data(), cmine.size(), &call, &off))) return (llkv_status)rc;
+  j->last_exchange_bytes += call.size();
   std::vector<llkv_join_group_row> rows;
   uint64_t total = 0;
   for (uint32_t r = 0; r < world; ++r) {
@@ -908,6 +1072,11 @@ llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limi
   if (out_total_groups) *out_total_groups = total;
   return llkv_hip_join_agg_merge(rows.data(), (uint32_t)rows.size(), j->n_payload, limit, out_rows, out_n);
 }
+
+extern "C" {
+
+/* bytes the collectives of the last llkv_hip_join_agg_finish_sharded call moved (every rank's contributions; bench only) */
+uint64_t llkv_hip_join_agg_exchange_bytes(const llkv_hip_join_agg *h) { return h ? reinterpret_cast<const JoinAgg *>(h)->last_exchange_bytes : 0; }
 
 // Single-rank form: prepare → (nothing to exchange) → candidates.
 llkv_status llkv_hip_join_groupby_topk(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field,

@@ -291,7 +291,7 @@ int Readback::add(void *host_dst, const void *device_src, size_t bytes, hipStrea
     std::memset(t_readback.p, 0, kBytes + 64);
   }
   const size_t off = (used + 7) & ~(size_t)7;
-  if (n == 8 || off + bytes > kBytes) return set_error(LLKV_INTERNAL, "read-back buffer exhausted");
+  if (n == 12 || off + bytes > kBytes) return set_error(LLKV_INTERNAL, "read-back buffer exhausted");
   if (stream && stream != s && launched != n) return set_error(LLKV_INTERNAL, "read-back items of two streams");
   items[n++] = {host_dst, device_src, off, bytes};
   used = off + bytes;

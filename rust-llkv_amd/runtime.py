@@ -825,7 +825,10 @@ class JoinAgg:
     (llkv_hip_join_agg_*; dist.join_groupby_topk drives the collectives between the phases)."""
 
     def __init__(self, fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, sum_expr,
-                 payload_fields: Sequence[int] = (), dim_fk: int = 0, dim2: Optional[HipTable] = None, dim2_filters=(), dim2_key: int = 0):
+                 payload_fields: Sequence[int] = (), dim_fk: int = 0, dim2: Optional[HipTable] = None, dim2_filters=(), dim2_key: int = 0,
+                 ranged: bool = False):
+        """``ranged``: the range form (llkv_hip_join_agg_prepare_ranged) — raises LlkvError "Unsupported" when the shape
+        does not qualify."""
         keep = []
 
         def side(table, filters, key):
@@ -842,8 +845,31 @@ class JoinAgg:
         self.n_payload = len(payload_fields)
         self._tables = (fact, dim, dim2)  # the handle reads the tables' HBM images until it is freed: keep them alive
         self._h = C.c_void_p()
-        check(lib().llkv_hip_join_agg_prepare(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None, pay,
-                                              C.c_uint32(len(payload_fields)), toks, C.c_uint32(len(sum_expr.tokens)), C.byref(self._h)))
+        self.ranged = ranged
+        prepare = lib().llkv_hip_join_agg_prepare_ranged if ranged else lib().llkv_hip_join_agg_prepare
+        check(prepare(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None, pay,
+                      C.c_uint32(len(payload_fields)), toks, C.c_uint32(len(sum_expr.tokens)), C.byref(self._h)))
+
+    def boundary(self) -> bytes:
+        """Range form: this rank's block of boundary runs for the all-gather."""
+        blk, n = C.c_void_p(), C.c_uint64()
+        check(lib().llkv_hip_join_agg_boundary(self._h, C.byref(blk), C.byref(n)))
+        return C.string_at(blk, n.value)
+
+    def finish_ranged(self, blocks: Sequence[bytes], rank: int, limit: int):
+        """Range form: every rank's boundary block (rank order) → (this rank's candidate rows, groups it reports)."""
+        offs = np.zeros(len(blocks) + 1, dtype=np.uint64)
+        np.cumsum([len(b) for b in blocks], out=offs[1:])
+        buf = np.frombuffer(b"".join(blocks), dtype=np.uint64).copy()
+        rows = (abi.CJoinGroupRow * max(1, limit))()
+        n, total = C.c_uint32(), C.c_uint64()
+        check(lib().llkv_hip_join_agg_finish_ranged(self._h, buf.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(len(blocks)),
+                                                    C.c_uint32(rank), C.c_uint32(limit), rows, C.byref(n), C.byref(total)))
+        return [join_row_tuple(r) for r in rows[:n.value]], total.value
+
+    def exchange_bytes(self) -> int:
+        lib().llkv_hip_join_agg_exchange_bytes.restype = C.c_uint64
+        return int(lib().llkv_hip_join_agg_exchange_bytes(self._h))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -387,6 +387,118 @@ def test_full_size_selection_join_and_q3_sf10(rt, abi, tpch):
         assert r[2] == int(cnt[i]) and r[3] == int(od["o_orderdate"][i]) and abs(r[1] - rev[i]) <= REL * rev[i]
 
 
+def test_configs3_q1_sf10_as_eight_shards_sums_to_the_single_gpu_bits(rt, abi, tpch):
+    """BASELINE.json configs[3] at full size on ONE device: SF10 lineitem staged as 8 shards, one after another (what the
+    8 ranks hold), Q1 over each, the exchange images summed as integers — what ncclAllReduce(int64, sum) does — and
+    finished: the same bits as the single-table run, and every shard leaves the octants it does not own at zero."""
+    n = tpch.LINEITEM_ROWS["sf10"]
+    chunks = tpch.chunk_rows(n)
+    q = tpch.q1()
+    d = tpch.gen_lineitem(n, tpch.SCALE["sf10"], q.columns)
+    dicts = {c: sorted({chr(int(v)) for v in np.unique(d[c])}) for c in q.columns if tpch.LINEITEM_SCHEMA[c][1] == abi.DT_UTF8}
+    stats = {c: (int(d[c].min()), int(d[c].max())) for c in q.columns if tpch.LINEITEM_SCHEMA[c][1] in (abi.DT_INT64, abi.DT_DATE32)}
+
+    def stage(rank, world):
+        ht = rt.HipTable(1, chunks, rank, world)
+        lo = sum(chunks[:ht.first_chunk])
+        for c in q.columns:
+            fid, dt = tpch.LINEITEM_SCHEMA[c]
+            part = d[c][lo:lo + ht.local_rows]
+            if dt == abi.DT_UTF8:
+                ht.append_utf8_column(fid, part, dicts[c])
+            else:
+                ht.append_column(fid, dt, part)
+                if world > 1 and c in stats and ht.local_column_stats(fid) is not None:
+                    ht.set_column_stats(fid, *stats[c])
+        return ht
+
+    flat = lambda rows: [(tuple(k.value for k in r.keys), tuple(np.float64(v.value).tobytes() if isinstance(v.value, float) else v.value for v in r.values)) for r in rows]
+    one = stage(0, 1)
+    pq = rt.PreparedQuery(one, q.predicate, q.aggs, q.keys, True)
+    want = flat(pq.run())
+    ex1 = pq.read_exchange()
+    pq.close(); one.close()
+    total = np.zeros_like(ex1).view(np.int64)
+    last = None
+    for rank in range(8):
+        if last is not None:
+            last[0].close(); last[1].close()
+        ht = stage(rank, 8)
+        assert abs(ht.local_rows - n // 8) <= 2 * max(chunks)
+        pr = rt.PreparedQuery(ht, q.predicate, q.aggs, q.keys, True)
+        pr.launch()
+        ex = pr.read_exchange()
+        assert not ex[[o for o in range(8) if o != rank]].any()
+        total += ex.view(np.int64)
+        last = (pr, ht)
+    assert np.array_equal(total.view(np.uint64), ex1)
+    assert flat(last[0].finish_from_host(total.view(np.uint64))) == want
+
+
+def test_configs4_q3_sf10_probe_side_in_eight_shards(rt, abi, tpch):
+    """BASELINE.json configs[4] at full size on ONE device: orders and customer replicated, SF10 lineitem staged as the 8
+    shards the ranks hold; the phased pipeline's collectives done by hand (general form: counts summed as the int64
+    all-reduce does, straddler pairs, candidates; range form: boundary runs, candidates).  Keys, counts, group total and
+    the revenue BITS of the top 10 equal the single-GPU answer in both forms; a clustered fact table exchanges only the
+    orders cut by a shard boundary."""
+    import torch
+    n, scale = tpch.LINEITEM_ROWS["sf10"], tpch.SCALE["sf10"]
+    D = tpch.DATE_1995_03_15
+    cols = ["l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"]
+    li = tpch.gen_lineitem(n, scale, cols)
+    n_ord = tpch.orders_for_lineitems(n); od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale); cu = tpch.gen_customer(n_cust, scale)
+    ot_ = rt.HipTable(2, tpch.chunk_rows(n_ord))
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c])
+    ct = rt.HipTable(3, tpch.chunk_rows(n_cust))
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]])
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    chunks = tpch.chunk_rows(n)
+
+    def fact(rank, world):
+        t = rt.HipTable(1, chunks, rank, world)
+        lo = sum(chunks[:t.first_chunk])
+        for c in cols:
+            t.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c][lo:lo + t.local_rows])
+        return t
+
+    args = lambda t: dict(fact=t, fact_filters=[F(tpch.L_SHIPDATE, O.GreaterThan(D))], fact_key=tpch.L_ORDERKEY, dim=ot_,
+                          dim_filters=[F(tpch.O_ORDERDATE, O.LessThan(D))], dim_key=tpch.O_ORDERKEY, sum_expr=col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT)),
+                          payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                          dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    whole = fact(0, 1)
+    want, want_total = rt.join_groupby_topk(limit=10, **args(whole))
+    whole.close()
+    bits = lambda rws: [(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in rws]
+    assert len(want) == 10 and want_total > 100_000
+    shards = [fact(r, 8) for r in range(8)]
+    # general form
+    joins = [rt.JoinAgg(**args(t)) for t in shards]
+    bufs = [j.counts_buffer() for j in joins]
+    assert len({k for _, k in bufs}) == 1
+    tensors = [_device_i64(p, k) for p, k in bufs]
+    total = sum(t.clone() for t in tensors)
+    for t in tensors:
+        t.copy_(total)
+    torch.cuda.synchronize()
+    strad = [j.straddlers() for j in joins]
+    assert sum(len(g) for g, _ in strad) <= 8 * 7  # at most one order per shard boundary, at most 7 lines each
+    folded = rt.fold_straddlers([g for g, _ in strad], [v for _, v in strad])
+    parts = [j.candidates(folded, r, 10) for r, j in enumerate(joins)]
+    assert bits(rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)) == bits(want)
+    assert sum(k for _, k in parts) == want_total
+    del joins, tensors, total
+    # range form: every rank selects the orders of its own key range, ~1 KB of boundary runs per rank is all they exchange
+    ranged = [rt.JoinAgg(ranged=True, **args(t)) for t in shards]
+    blocks = [j.boundary() for j in ranged]
+    parts = [j.finish_ranged(blocks, r, 10) for r, j in enumerate(ranged)]
+    assert bits(rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)) == bits(want)
+    assert sum(k for _, k in parts) == want_total
+    assert sum(len(b) for b in blocks) == 8 * 1088
+
+
 @pytest.mark.parametrize("key", ["l_partkey", "l_orderkey"])
 def test_full_size_sort_based_group_by_sf10(rt, abi, tpch, key):
     """SF10, GROUP BY l_partkey (2 000 000 groups, unsorted input) / l_orderkey (14 996 513 groups, input already in
@@ -2462,6 +2574,24 @@ def test_q3_sharded_fact_table_is_rank_count_invariant(rt, abi, tpch, clustered)
         got = rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)
         assert bits(got) == bits(want), world
         assert sum(n for _, n in parts) == want_total
+        # the range form: each rank selects the orders of its own key range only, nothing is exchanged per group — the
+        # ranks publish the first and last run of their pair streams (a few hundred bytes) and fold the shared ones
+        del joins
+        ranged = [rt.JoinAgg(ranged=True, **args(t)) for t in shards]
+        blocks = [j.boundary() for j in ranged]
+        assert all(len(b) == (8 + 128) * 8 for b in blocks)
+        if not clustered:  # pairs out of key order: every rank refuses alike, the caller takes the general form above
+            for r, j in enumerate(ranged):
+                with pytest.raises(abi.LlkvError) as e:
+                    j.finish_ranged(blocks, r, 10)
+                assert e.value.kind == "Unsupported"
+            continue
+        parts = [j.finish_ranged(blocks, r, 10) for r, j in enumerate(ranged)]
+        got = rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)
+        assert bits(got) == bits(want), ("ranged", world)
+        assert sum(n for _, n in parts) == want_total
+        with pytest.raises(abi.LlkvError):
+            ranged[0].counts_buffer()
 
 
 def test_table_staged_from_arr0_chunk_blobs(rt, orc, abi, tpch):

@@ -33,5 +33,63 @@ for _ in range(5):
     t0 = time.perf_counter(); out, total = run(); ts.append(time.perf_counter() - t0)
 alg = rows * 28 + n_ord * 28 + n_cust * 9
 best = min(ts)
-print(json.dumps({"workload": f"q3_{sf}", "lineitem_rows": rows, "orders": n_ord, "customers": n_cust, "groups": total, "seconds_best": best, "seconds_all": ts,
-                  "rows_per_s": rows / best, "algorithmic_bytes": alg, "gbs": alg / best / 1e9, "top": out[:3]}))
+res = {"workload": f"q3_{sf}", "lineitem_rows": rows, "orders": n_ord, "customers": n_cust, "groups": total, "seconds_best": best, "seconds_all": ts,
+       "rows_per_s": rows / best, "algorithmic_bytes": alg, "gbs": alg / best / 1e9, "top": out[:3]}
+# ---- configs[4] sharded over `world` ranks, emulated on this one device: what ONE rank runs per query (prepare: its dimension
+# work + the probe of its 1/world of lineitem + the run sums; then its share of the exchange) in the general form (dimension
+# selection replicated, per-group counts all-reduced) and in the range form (orders of the rank's own key range only, boundary
+# runs exchanged).  Not a scaling measurement — one device runs the ranks one after another — but the per-rank time bounds it.
+if "--sharded" in sys.argv:
+    import torch
+    world = 8
+    chunks = tpch.chunk_rows(rows)
+    kw = lambda t: dict(fact=t, fact_filters=[F(tpch.L_SHIPDATE, O.GreaterThan(D))], fact_key=tpch.L_ORDERKEY, dim=ot, dim_filters=[F(tpch.O_ORDERDATE, O.LessThan(D))],
+                        dim_key=tpch.O_ORDERKEY, sum_expr=rev, payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                        dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    shards = []
+    for r in range(world):
+        t = rt.HipTable(1, chunks, r, world)
+        lo = sum(chunks[:t.first_chunk])
+        for c in li: t.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c][lo:lo + t.local_rows])
+        shards.append(t)
+    sh = {}
+    for form in ("general", "range"):
+        per_rank = []
+        for r, t in enumerate(shards):
+            best_r = 1e9
+            for _ in range(4):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                j = rt.JoinAgg(ranged=form == "range", **kw(t))
+                if form == "range": blk = j.boundary()
+                torch.cuda.synchronize(); best_r = min(best_r, time.perf_counter() - t0)
+                del j
+            per_rank.append(best_r)
+        # the exchange and the finish, once, for the result and the byte count
+        joins = [rt.JoinAgg(ranged=form == "range", **kw(t)) for t in shards]
+        t0 = time.perf_counter()
+        if form == "range":
+            blocks = [j.boundary() for j in joins]
+            parts = [j.finish_ranged(blocks, r, 10) for r, j in enumerate(joins)]
+            exchanged = sum(len(b) for b in blocks)
+        else:
+            bufs = [j.counts_buffer() for j in joins]
+            class Raw: pass
+            tens = []
+            for p, k in bufs:
+                raw = Raw(); raw.__cuda_array_interface__ = {"shape": (int(k),), "typestr": "<i8", "data": (int(p), False), "version": 2}
+                tens.append(torch.as_tensor(raw, device="cuda"))
+            tot = sum(x.clone() for x in tens)
+            for x in tens: x.copy_(tot)
+            torch.cuda.synchronize()
+            strad = [j.straddlers() for j in joins]
+            folded = rt.fold_straddlers([g for g, _ in strad], [v for _, v in strad])
+            parts = [j.candidates(folded, r, 10) for r, j in enumerate(joins)]
+            exchanged = 2 * 8 * bufs[0][1] * world + sum(12 * len(g) for g, _ in strad)  # all-reduce: every rank's counts out and back
+        merged = rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)
+        exchanged += sum(16 + 72 * len(rows_r) for rows_r, _ in parts)
+        assert [m[0] for m in merged] == [o[0] for o in out] and [m[1] for m in merged] == [o[1] for o in out], form
+        sh[form] = {"per_rank_prepare_ms": [x * 1e3 for x in per_rank], "per_rank_prepare_ms_max": max(per_rank) * 1e3, "exchanged_bytes_per_query": int(exchanged),
+                    "single_gpu_ms": best * 1e3, "ratio_to_single_gpu": max(per_rank) / best}
+        del joins
+    res["sharded_world8_emulated"] = sh
+print(json.dumps(res))
