@@ -73,7 +73,7 @@ void scratch_release_all() {
 // other lanes.  The lanes live for the life of the device binding (pinning memory per column costs more than the
 // copy of a small column).
 struct StagerPool {
-  static constexpr int kLanes = 6, kDepth = 2;
+  static constexpr int kLanes = 16, kDepth = 2;
   static constexpr size_t kBuf = 2u << 20;
   struct Lane {
     hipStream_t stream = nullptr;
@@ -114,18 +114,51 @@ struct StagerPool {
   }
   // copies every piece and returns when all of them have arrived: host → HBM, or (`to_host`) HBM → pageable
   // host memory, where d_dst / h_src swap roles (d_dst = device source, h_src = host destination)
-  int run(const std::vector<StagePiece> &pieces, bool to_host = false) {
+  // Host → HBM without the bounce copy (north_star: "column chunks … are pinned and hipMemcpyAsync'd into HBM"): the caller's
+  // buffers are page-locked where they lie (hipHostRegister; pager blobs have stable addresses), the DMA engines
+  // read them directly, and the registration is dropped when the copies have landed.  Chunks that touch in memory are
+  // registered as one span, cut into parts of kPart bytes on page boundaries so that several lanes pin and copy at once;
+  // the unaligned head and tail of a span (under a page each) and any part the driver refuses to pin go through the ring.
+  static constexpr size_t kPart = 32u << 20, kPage = 4096;
+  struct Span { char *d; const char *h; size_t bytes; };
+  static void registered_plan(const std::vector<StagePiece> &pieces, std::vector<Span> *parts, std::vector<StagePiece> *rest) {
+    std::vector<Span> spans;
+    for (const StagePiece &p : pieces) {
+      if (!p.bytes) continue;
+      if (!spans.empty() && spans.back().h + spans.back().bytes == (const char *)p.h_src && spans.back().d + spans.back().bytes == (char *)p.d_dst) spans.back().bytes += p.bytes;
+      else spans.push_back({(char *)p.d_dst, (const char *)p.h_src, p.bytes});
+    }
+    for (const Span &sp : spans) {
+      const uintptr_t b = (uintptr_t)sp.h, e = b + sp.bytes;
+      const uintptr_t ab = (b + kPage - 1) / kPage * kPage, ae = e / kPage * kPage;
+      if (ae <= ab || ae - ab < (1u << 20)) { rest->push_back({sp.d, sp.h, sp.bytes}); continue; } // small: not worth a registration
+      if (ab > b) rest->push_back({sp.d, sp.h, (size_t)(ab - b)});
+      if (e > ae) rest->push_back({sp.d + (ae - b), sp.h + (ae - b), (size_t)(e - ae)});
+      for (uintptr_t at = ab; at < ae; at += kPart) parts->push_back({sp.d + (at - b), (const char *)at, (size_t)std::min<uintptr_t>(kPart, ae - at)});
+    }
+  }
+  int run(const std::vector<StagePiece> &pieces_in, bool to_host = false) {
     std::lock_guard<std::mutex> lk(mu);
     int rc = init();
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<StagePiece> seg;
     size_t total = 0;
+    std::vector<Span> parts;
+    std::vector<StagePiece> ring_pieces;
+    const char *mode = std::getenv("LLKV_HIP_STAGE_MODE"); // "bounce": everything through the pinned rings (measurement)
+    const bool in_place = !to_host && !(mode && std::string(mode) == "bounce");
+    if (in_place) registered_plan(pieces_in, &parts, &ring_pieces);
+    const std::vector<StagePiece> &pieces = in_place ? ring_pieces : pieces_in;
     for (const StagePiece &p : pieces)
       for (size_t off = 0; off < p.bytes; off += kBuf) {
         seg.push_back({(char *)p.d_dst + off, (const char *)p.h_src + off, std::min(kBuf, p.bytes - off)});
         total += seg.back().bytes;
       }
+    for (const Span &sp : parts) total += sp.bytes;
+    std::atomic<size_t> next_part{0};
+    std::mutex refused_mu;
+    std::vector<Span> refused; // parts the driver would not pin: through the ring after all
     std::atomic<size_t> next{0};
     std::atomic<int> failed{LLKV_OK};
     std::string message;
@@ -138,6 +171,24 @@ struct StagerPool {
       };
       if (r) { failed = r; std::lock_guard<std::mutex> g(message_mu); message = g_last_error; return; }
       hipError_t e;
+      { // pinned in place: register → copy → (when the lane's copies have landed) unregister
+        std::vector<const char *> mine;
+        for (size_t i; failed == LLKV_OK && (i = next_part.fetch_add(1)) < parts.size();) {
+          const Span &sp = parts[i];
+          if (hipHostRegister(const_cast<char *>(sp.h), sp.bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> g(refused_mu);
+            refused.push_back(sp);
+            continue;
+          }
+          mine.push_back(sp.h);
+          if ((e = hipMemcpyAsync(sp.d, sp.h, sp.bytes, hipMemcpyHostToDevice, l.stream)) != hipSuccess) { fail(e); break; }
+        }
+        if (!mine.empty()) {
+          if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
+          for (const char *h : mine) (void)hipHostUnregister(const_cast<char *>(h));
+        }
+      }
       const StagePiece *pending[kDepth] = {}; // to_host: the segment whose bytes wait in pinned[k]
       auto drain = [&](int k) -> bool {
         if (!pending[k]) return true;
@@ -163,11 +214,22 @@ struct StagerPool {
         if (!drain((l.cur + k) % kDepth)) return;
       if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
     };
-    const int n_threads = (int)std::min<size_t>(std::min<size_t>(kLanes, host_thread_limit()), (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
+    size_t lane_limit = kLanes;
+    if (const char *e = std::getenv("LLKV_HIP_STAGE_LANES")) lane_limit = std::max(1, std::min<int>(kLanes, std::atoi(e)));
+    const int n_threads = (int)std::min<size_t>(std::min<size_t>(lane_limit, host_thread_limit()), (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
     std::vector<std::thread> threads;
     for (int k = 1; k < n_threads; ++k) threads.emplace_back(work, std::ref(lanes[k]));
     work(lanes[0]);
     for (std::thread &t : threads) t.join();
+    if (!refused.empty() && failed == LLKV_OK) { // (unlikely: the pages could not be locked) the ring takes them
+      seg.clear();
+      for (const Span &sp : refused)
+        for (size_t off = 0; off < sp.bytes; off += kBuf) seg.push_back({sp.d + off, sp.h + off, std::min(kBuf, sp.bytes - off)});
+      parts.clear();
+      next = 0;
+      next_part = 0;
+      work(lanes[0]);
+    }
     if (!to_host) {
       staged_bytes += total;
       staged_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -120,17 +120,21 @@ uint64_t table_chunk_rows(const llkv_hip_table *table, uint32_t global_chunk) {
 
 static const uint64_t kSlackRows = 8192; // readable rows past the image end (unrolled tail steps)
 
-static int alloc_column(Table &t, uint32_t width, void **d_out) {
+// `rows_overwritten`: every row of the image is about to be staged over (value buffers of a table without padding rows
+// between its chunks): only the slack behind the image is zeroed — the runtime's fill moves ~130 GB/s, which made zeroing
+// SF10's five 480 MB columns a fifth of their staging time
+static int alloc_column(Table &t, uint32_t width, void **d_out, bool rows_overwritten = false) {
   const uint64_t bytes = (t.dev_rows + kSlackRows) * width;
   HIP_TRY(hipMalloc(d_out, bytes));
-  HIP_TRY(hipMemsetAsync(*d_out, 0, bytes, g_ctx.stream));
+  if (rows_overwritten && t.dev_rows == t.local_rows) HIP_TRY(hipMemsetAsync((char *)*d_out + t.dev_rows * width, 0, kSlackRows * width, g_ctx.stream));
+  else HIP_TRY(hipMemsetAsync(*d_out, 0, bytes, g_ctx.stream));
   return LLKV_OK;
 }
 
 // host-side preparation of a column image (dictionary coding, bitmap expansion, Decimal128 narrowing) runs chunk
 // by chunk on a few threads; fn(chunk) returns a status, the first failure wins
 template <class Fn> static int for_each_chunk_parallel(uint32_t n_chunks, Fn &&fn) {
-  const unsigned hw = std::max(1u, std::min(8u, host_thread_limit()));
+  const unsigned hw = std::max(1u, std::min(16u, host_thread_limit()));
   const unsigned n_threads = std::min<unsigned>(hw, std::max(1u, n_chunks / 4));
   std::atomic<uint32_t> next{0};
   std::atomic<int> failed{LLKV_OK};
@@ -283,7 +287,7 @@ llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_i
   c.info.dtype = dtype;
   c.info.rows = t->total_rows;
   c.owned = true;
-  if ((rc = alloc_column(*t, w, &c.d_values))) return (llkv_status)rc;
+  if ((rc = alloc_column(*t, w, &c.d_values, true))) return (llkv_status)rc;
   std::vector<StagePiece> pieces;
   for (uint32_t i = 0; i < n_chunks; ++i) {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
@@ -313,7 +317,15 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
   c.info.rows = t->total_rows;
   c.owned = true;
   // dictionary-encode on the host at staging (SURVEY.md §7 "Utf8 group keys"): 1 B/row in HBM
-  std::vector<uint8_t> codes(t->dev_rows + 16, 0);
+  // (not value-initialised: 60 MB of zeroes written by one thread cost as much as coding the column on sixteen; the padding
+  // rows between ragged chunks are zeroed below, every other byte is written by the coding pass)
+  std::unique_ptr<uint8_t[]> codes_buf(new uint8_t[t->dev_rows + 16]);
+  struct { uint8_t *p; uint8_t *data() const { return p; } } codes{codes_buf.get()};
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t end = t->chunk_dev_off[i] + t->global_chunk_rows[t->first_chunk + i];
+    std::memset(codes.data() + end, 0, t->chunk_dev_off[i + 1] - end);
+  }
+  std::memset(codes.data() + t->dev_rows, 0, 16);
   std::map<std::string, uint8_t> dict;
   const bool fixed = dictionary != nullptr;
   for (uint32_t d = 0; d < dict_size && fixed; ++d) {
