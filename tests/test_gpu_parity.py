@@ -2635,6 +2635,19 @@ def test_mvcc_visibility_fused_into_the_scan(rt, orc, abi):
         assert_values(rt.aggregate(ht, pred, [A.count_star(), A.sum(3), A.max(3)]), orc.aggregate(ot, pred, [A.count_star(), A.sum(3), A.max(3)]), "mvcc")
 
 
+@pytest.mark.parametrize("case", golden("mvcc.json")["cases"], ids=lambda c: c["name"])
+def test_mvcc_reference_visibility_sequence(rt, abi, case):
+    """llkv-transaction/src/mvcc.rs:528-556 (test_row_visibility_simple) through the fused MVCC leaf: the reference's own
+    five is_visible_for assertions, each with the ids, snapshot and Active set the manager holds at that point."""
+    t = rt.HipTable(1, [1])
+    t.append_column(1, abi.DT_UINT64, np.array([case["created_by"]], dtype=np.uint64))
+    t.append_column(2, abi.DT_UINT64, np.array([case["deleted_by"]], dtype=np.uint64))
+    F, O = abi.Filter, abi.Operator
+    vis = F(1, O.MvccVisible(2, txn_id=case["txn_id"], snapshot_id=case["snapshot_id"], uncommitted=case["uncommitted"]))
+    assert (rt.filter_row_ids(t, [vis]).tolist() == [0]) == case["expect"]
+    assert rt.aggregate(t, [vis], [abi.AggregateSpec.count_star()])[0].value == int(case["expect"])
+
+
 def test_q1_qualifies_against_an_oracle_answer_set(rt, orc, abi, tpch):
     """§8f-3: the qualification harness (order-insensitive diff, exact ints/strings, ABSOLUTE 1e-9 on floats) run on
     the GPU path's Q1 rows against an answer set rendered from the oracle in dbgen's `|` format.  The absolute

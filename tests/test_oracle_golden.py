@@ -313,6 +313,33 @@ def test_q6_against_numpy(orc, abi, tpch):
             assert a.value == b.value if isinstance(b.value, int) else abs(a.value - b.value) <= 1e-9 * abs(b.value)
 
 
+MVCC = golden("mvcc.json")
+
+
+def mvcc_case_rows(m, abi, case):
+    """One (created_by, deleted_by) row and the snapshot of one assertion of test_row_visibility_simple."""
+    t = m.OracleTable(1) if hasattr(m, "OracleTable") else None
+    F, O = abi.Filter, abi.Operator
+    pred = [F(1, O.MvccVisible(2, txn_id=case["txn_id"], snapshot_id=case["snapshot_id"], uncommitted=case["uncommitted"]))]
+    return np.array([case["created_by"]], dtype=np.uint64), np.array([case["deleted_by"]], dtype=np.uint64), pred
+
+
+@pytest.mark.parametrize("case", MVCC["cases"], ids=lambda c: c["name"])
+def test_mvcc_reference_visibility_sequence(case, orc, abi):
+    """llkv-transaction/src/mvcc.rs:528-556 (test_row_visibility_simple): the five is_visible_for assertions with the
+    transaction ids, snapshots and Active sets the manager has at each of them."""
+    created, deleted, pred = mvcc_case_rows(orc, abi, case)
+    t = orc.OracleTable(1).add(1, abi.DT_UINT64, created).add(2, abi.DT_UINT64, deleted)
+    assert (orc.filter_row_ids(t, pred).tolist() == [0]) == case["expect"]
+
+
+def test_mvcc_reference_basic_visibility():
+    """mvcc.rs:535,540-541: RowVersion::is_visible — numeric ordering only (:276-279); held by the same reference test."""
+    NONE = 2**64 - 1
+    for c in MVCC["basic"]:
+        assert (c["created_by"] <= c["snapshot_txn_id"] and (c["deleted_by"] == NONE or c["deleted_by"] > c["snapshot_txn_id"])) == c["expect"]
+
+
 def test_mvcc_visibility_rules(orc, abi):
     """RowVersion::is_visible_for (llkv-transaction/src/mvcc.rs:283-333) case by case:
     (created_by, deleted_by) under snapshot {txn_id 7, snapshot_id 5}, txn 4 Active (not committed)."""
@@ -490,9 +517,9 @@ def test_golden_inventory_says_what_pins_the_oracle():
                 held += 1
             else:
                 derived += 1
-    held += len(STRINGS["cases"]) + len(STRING_SCANS["cases"]) + 1 + len(JOIN_FILTERS["cartesian"])
+    held += len(STRINGS["cases"]) + len(STRING_SCANS["cases"]) + 1 + len(JOIN_FILTERS["cartesian"]) + len(MVCC["cases"])
     print(f"golden cases held by the reference's own tests: {held}; derived from source lines: {derived}")
-    assert held >= 70 and derived <= 10
+    assert held >= 82 and derived <= 10
 
 
 def test_oracle_runs_distinct_accumulators_per_group(orc, abi):
