@@ -91,6 +91,8 @@ def build_filter(abi, f):
         return abi.Filter(f["field"], O.Range(bound(f.get("lower")), bound(f.get("upper"))))
     if op == "in":
         return abi.Filter(f["field"], O.In(f["values"]))
+    if op == "starts_with":
+        return abi.Filter(f["field"], O.StartsWith(f["value"], f.get("case_sensitive", True)))
     ctor = {"eq": O.Equals, "gt": O.GreaterThan, "ge": O.GreaterThanOrEquals, "lt": O.LessThan, "le": O.LessThanOrEquals}[op]
     return abi.Filter(f["field"], ctor(f["value"]))
 

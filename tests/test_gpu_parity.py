@@ -532,9 +532,10 @@ def test_full_size_sort_based_group_by_sf10(rt, abi, tpch, key):
 
 
 TABLE = golden("table_scan.json")
+NULLABLE_TABLES = {name for name, t in TABLE["tables"].items() if any(v is None for c in t["columns"] for v in c["values"])}
 
 
-@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] != "with_nulls"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] not in NULLABLE_TABLES], ids=lambda c: c["name"])
 def test_reference_table_scan_known_answers(rt, abi, case):
     """The reference's filtered-scan / And / Or / Not / IN / projection / computed-projection tests
     (tests/golden/table_scan.json: llkv-table/src/table.rs:1697-2906, llkv-executor/src/lib.rs:13880-13925) through
@@ -557,6 +558,9 @@ def test_reference_table_scan_known_answers(rt, abi, case):
         assert len(bcols[0]) > 0
         for i, c in enumerate(bcols):
             cols[i].extend(c)
+    if "expect_sorted" in case:
+        assert sorted(cols[0]) == case["expect_sorted"]
+        return
     assert cols == case["expect"]
     if "expect_sum" in case:
         assert sum(cols[0]) == case["expect_sum"]
@@ -656,12 +660,13 @@ def test_expression_compares_match_oracle(rt, orc, abi, chunks):
     assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
 
 
-@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] == "with_nulls"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in TABLE["cases"] if c["table"] in NULLABLE_TABLES], ids=lambda c: c["name"])
 def test_reference_include_nulls_known_answers(rt, abi, case):
-    """test_scan_stream_include_nulls_toggle (table.rs:2357-2486) through llkv_hip_scan_stream: a NULL cell is
-    staged as a validity bit, DropNulls drops the rows whose projected columns are all NULL."""
+    """test_scan_stream_include_nulls_toggle (table.rs:2357-2486) and the gather NULL-policy tests of llkv-column-map
+    (gather_rows_policy_tests.rs, gather_multi_tests.rs) through llkv_hip_scan_stream: a NULL cell is staged as a
+    validity bit, DropNulls drops the rows whose projected columns are all NULL."""
     from conftest import build_predicate
-    tdef = TABLE["tables"]["with_nulls"]
+    tdef = TABLE["tables"][case["table"]]
     ht = rt.HipTable(1, [tdef["rows"]])
     for c in tdef["columns"]:
         dt = DTYPES[c["dtype"]]
