@@ -9,6 +9,16 @@
  * whose behaviour it replaces.  Error behaviour follows `llkv-result/src/error.rs`:
  * every call returns a status code, the message is fetched with
  * `llkv_hip_last_error()` (thread-local), nothing unwinds across the boundary.
+ *
+ * Threads and streams.  Calls may come from any host thread (the traits the shim implements are Send + Sync,
+ * llkv-executor/src/types/storage.rs:20-50).  The multi-kernel pipelines — scan_stream, filter_row_ids, the joins,
+ * the join → GROUP BY → top-k pipeline, the sort-based and partitioned GROUP BY — run on ONE stream the library owns
+ * and recycle their device temporaries in the order of that stream: a block handed back while a kernel still reads
+ * it can only be handed to work queued behind that kernel.  Device memory that a CALLER's stream will touch (the
+ * buffers of a prepared query: llkv_hip_query_launch / _all_reduce / _submit take a stream) is allocated by the
+ * prepare call, which drains the library's stream before it returns — no such buffer aliases an in-flight temporary.
+ * Small read-backs of one host thread share one pinned slab: a thread has one of them in flight at a time (the
+ * library's own calls keep to that; a handle of the phased join pipeline must not be driven from two threads at once).
  */
 #ifndef LLKV_HIP_H
 #define LLKV_HIP_H

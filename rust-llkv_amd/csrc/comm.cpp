@@ -30,6 +30,43 @@ struct Comm {
   ncclComm_t nccl = nullptr;
   llkv_comm_transport cb{};
   hipStream_t stream = nullptr; // the communicator's own stream (all-gathers of host pieces)
+  // staging of host all-gathers, kept for the life of the communicator (grow-only): pinned host send / receive blocks and
+  // their device twins — no allocation, no pageable copy per call
+  void *h_send = nullptr, *h_recv = nullptr, *d_send = nullptr, *d_recv = nullptr;
+  size_t send_cap = 0, recv_cap = 0;
+  int reserve(size_t send_bytes, size_t recv_bytes) {
+    if (send_bytes > send_cap) {
+      if (h_send) (void)hipHostFree(h_send);
+      if (d_send) (void)hipFree(d_send);
+      h_send = d_send = nullptr;
+      send_cap = 0;
+      size_t cap = 64 << 10;
+      while (cap < send_bytes) cap <<= 1;
+      HIP_TRY(hipHostMalloc(&h_send, cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&d_send, cap));
+      send_cap = cap;
+    }
+    if (recv_bytes > recv_cap) {
+      if (h_recv) (void)hipHostFree(h_recv);
+      if (d_recv) (void)hipFree(d_recv);
+      h_recv = d_recv = nullptr;
+      recv_cap = 0;
+      size_t cap = 512 << 10;
+      while (cap < recv_bytes) cap <<= 1;
+      HIP_TRY(hipHostMalloc(&h_recv, cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&d_recv, cap));
+      recv_cap = cap;
+    }
+    return LLKV_OK;
+  }
+  void release_staging() {
+    if (h_send) (void)hipHostFree(h_send);
+    if (h_recv) (void)hipHostFree(h_recv);
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    h_send = h_recv = d_send = d_recv = nullptr;
+    send_cap = recv_cap = 0;
+  }
 };
 Comm g_comm;
 
@@ -54,13 +91,14 @@ int allgather_fixed_host(const void *send, void *recv, uint64_t bytes) {
   }
   int rc = ensure_device();
   if (rc) return rc;
-  Scratch ds, dr;
-  if ((rc = ds.alloc(bytes)) || (rc = dr.alloc(bytes * g_comm.world))) return rc;
+  if ((rc = g_comm.reserve(bytes, bytes * g_comm.world))) return rc;
   hipStream_t s = g_comm.stream;
-  HIP_TRY(hipMemcpyAsync(ds.p, send, bytes, hipMemcpyHostToDevice, s));
-  NCCL_TRY(ncclAllGather(ds.p, dr.p, bytes, ncclUint8, g_comm.nccl, s));
-  HIP_TRY(hipMemcpyAsync(recv, dr.p, bytes * g_comm.world, hipMemcpyDeviceToHost, s));
+  std::memcpy(g_comm.h_send, send, bytes);
+  HIP_TRY(hipMemcpyAsync(g_comm.d_send, g_comm.h_send, bytes, hipMemcpyHostToDevice, s));
+  NCCL_TRY(ncclAllGather(g_comm.d_send, g_comm.d_recv, bytes, ncclUint8, g_comm.nccl, s));
+  HIP_TRY(hipMemcpyAsync(g_comm.h_recv, g_comm.d_recv, bytes * g_comm.world, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  std::memcpy(recv, g_comm.h_recv, bytes * g_comm.world);
   return LLKV_OK;
 }
 } // namespace
@@ -95,16 +133,28 @@ int comm_allgather_v(const void *send, uint64_t bytes, std::vector<uint8_t> *out
   if (rc) return rc;
   std::lock_guard<std::mutex> lk(g_comm.mu);
   const uint32_t world = g_comm.world;
+  // one collective when every rank's piece is small (Q1 / Q6 results, Q3's boundary runs and candidates): each rank sends
+  // [its size | its first kInline bytes]; only when some piece is longer does the payload travel in a second one
+  constexpr uint64_t kInline = 8192;
+  std::vector<uint8_t> head(8 + kInline, 0), heads((size_t)(8 + kInline) * world);
+  std::memcpy(head.data(), &bytes, 8);
+  if (bytes) std::memcpy(head.data() + 8, send, std::min(bytes, kInline));
+  if ((rc = allgather_fixed_host(head.data(), heads.data(), 8 + kInline))) return rc;
   std::vector<uint64_t> sizes(world, 0);
-  if ((rc = allgather_fixed_host(&bytes, sizes.data(), 8))) return rc;
   offsets->assign(world + 1, 0);
   uint64_t widest = 0;
   for (uint32_t r = 0; r < world; ++r) {
+    std::memcpy(&sizes[r], heads.data() + (size_t)r * (8 + kInline), 8);
     (*offsets)[r + 1] = (*offsets)[r] + sizes[r];
     widest = std::max(widest, sizes[r]);
   }
   out->resize((*offsets)[world]);
   if (widest == 0) return LLKV_OK;
+  if (widest <= kInline) {
+    for (uint32_t r = 0; r < world; ++r)
+      if (sizes[r]) std::memcpy(out->data() + (*offsets)[r], heads.data() + (size_t)r * (8 + kInline) + 8, sizes[r]);
+    return LLKV_OK;
+  }
   const uint64_t padded = (widest + 15) / 16 * 16; // ncclAllGather moves equal pieces
   std::vector<uint8_t> mine(padded, 0), all((size_t)padded * world);
   if (bytes) std::memcpy(mine.data(), send, bytes);
@@ -248,6 +298,7 @@ void llkv_hip_comm_destroy(void) {
   if (!g_comm.custom) {
     if (g_comm.stream) { (void)hipStreamSynchronize(g_comm.stream); (void)hipStreamDestroy(g_comm.stream); }
     if (g_comm.nccl) (void)ncclCommDestroy(g_comm.nccl);
+    g_comm.release_staging();
   }
   g_comm.stream = nullptr;
   g_comm.nccl = nullptr;

@@ -89,7 +89,7 @@ static uint32_t pick_tile_rows(const LoweredPlan &p) {
 // l_shipdate with only count(*) — 4 B/row — still takes 0.15 ms), and a second workgroup on a CU adds nothing but its
 // image: 512 workgroups 0.25 ms, 1 024: 0.47 ms (profiles/r02/pmc_image.txt).
 static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
-  uint32_t grid = 256u;
+  uint32_t grid = g_ctx.cu_count;
   if (const char *e = std::getenv("LLKV_HIP_IMAGE_WGS")) {
     long v = std::atol(e);
     if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 16);
@@ -112,9 +112,11 @@ static uint32_t pick_scan_grid(const LoweredPlan &p, uint32_t n_tiles) {
   // Within that range the count that leaves the least idle time wins: workgroups take whole tiles, so 3 662 tiles over
   // 192 workgroups are 19 or 20 each (the kernel lasts 20, the average is 19.07: 352 µs), over 193 they are 18 or 19
   // (342 µs), over 216 or 229 likewise.
-  uint32_t grid = 256;
-  if (n_tiles >= 2048) {
-    const uint32_t lo = p.k <= 6 ? 184 : 232, hi = p.k <= 6 ? 232 : 256;
+  // (the counts below were swept on the 256 CUs of an MI355X; another part keeps the proportions)
+  const uint32_t cus = g_ctx.cu_count;
+  uint32_t grid = cus;
+  if (n_tiles >= 8 * cus) {
+    const uint32_t lo = (p.k <= 6 ? 184u : 232u) * cus / 256u, hi = (p.k <= 6 ? 232u : 256u) * cus / 256u;
     // the smallest count that keeps the workgroups ≥ 99.5 % busy (else the busiest): on the slower boxes fewer
     // workgroups still win among balanced counts (193: 354 µs, 204: 356, 216: 357, 229: 361; 192: 362)
     double best = 0.0;
@@ -986,6 +988,8 @@ llkv_status llkv_hip_init(int32_t device_ordinal) {
   if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return (llkv_status)set_error(LLKV_NO_DEVICE, hipGetErrorString(e));
   if ((e = hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking)) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, hipGetErrorString(e));
   g_ctx.device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) g_ctx.cu_count = (uint32_t)prop.multiProcessorCount;
   g_ctx.ready = true;
   return LLKV_OK;
 }

@@ -36,6 +36,7 @@ struct Context {
   bool ready = false;
   int device = -1;
   hipStream_t stream = nullptr;
+  uint32_t cu_count = 256; // hipDeviceProp_t::multiProcessorCount of the bound device (MI355X: 256); sizes the persistent grids
 };
 extern Context g_ctx;
 int ensure_device();

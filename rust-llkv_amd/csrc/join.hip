@@ -133,9 +133,21 @@ __global__ __launch_bounds__(256) void hj_segments_kernel(const uint32_t *sorted
   const uint32_t s = sorted_slot[i];
   if (i == 0 || sorted_slot[i - 1] != s) {
     seg_start[s] = i;
-    uint32_t j = i + 1; // segments are short (duplicates per key); the tail walk is bounded by the run
-    while (j < n && sorted_slot[j] == s) ++j;
-    seg_count[s] = j - i;
+    // the end of the run: gallop, then bisect — a key with a million duplicates costs its head ~40 loads, not a million
+    // (a serial walk of the run made ONE lane read every row of a hot key)
+    uint32_t lo = i, step = 1; // sorted_slot[lo] == s
+    uint32_t hi;
+    for (;;) {
+      hi = lo + step < n && lo + step > lo ? lo + step : n;
+      if (hi == n || sorted_slot[hi] != s) break;
+      lo = hi;
+      step <<= 1;
+    }
+    while (hi - lo > 1) { // sorted_slot[lo] == s, (hi == n or sorted_slot[hi] != s)
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (sorted_slot[mid] == s) lo = mid; else hi = mid;
+    }
+    seg_count[s] = hi - i;
   }
 }
 hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t *seg_start, uint32_t *seg_count, hipStream_t s) {

@@ -1710,6 +1710,29 @@ def test_random_joins_match_oracle(rt, orc, abi, n_left, n_right, keyspace, batc
     assert [len(b[0]) for b in got] == [len(b[0]) for b in want]  # flushes: ≥ batch_size pairs, and every 65 536 probe rows
 
 
+def test_join_build_side_with_a_hot_key(rt, orc, abi):
+    """One key holds half of the build rows (200 000 duplicates): the build's run lengths come from a gallop + bisection at
+    each run head, not from a walk of the run; pairs and batches as the reference's."""
+    n_right, n_left = 400_000, 60
+    rng = np.random.default_rng(21)
+    rk = rng.integers(1000, 2_000_000, size=n_right).astype(np.int64)
+    rk[rng.permutation(n_right)[:n_right // 2]] = 7
+    lk = rng.integers(1000, 2_000_000, size=n_left).astype(np.int64)
+    lk[[3, 41]] = 7
+    lt = rt.HipTable(1, [n_left]); lt.append_column(1, abi.DT_INT64, lk)
+    rtab = rt.HipTable(2, [131072, 131072, 137856]); rtab.append_column(7, abi.DT_INT64, rk)
+    ol, orr = orc.OracleTable(n_left).add(1, abi.DT_INT64, lk), orc.OracleTable(n_right).add(7, abi.DT_INT64, rk)
+    for jt in ("inner", "semi", "anti"):
+        got, want = rt.join_stream(lt, rtab, [(1, 7)], JT[jt], 8192), orc.hash_join(ol, orr, [(1, 7)], JT[jt], 8192)
+        assert [len(b[0]) for b in got] == [len(b[0]) for b in want], jt
+        for (gl, gr_), (wl, wr) in zip(got, want):
+            assert gl == wl and gr_ == wr, jt
+    n_pairs = sum(len(b[0]) for b in orc.hash_join(ol, orr, [(1, 7)], JT["inner"], 8192))
+    assert n_pairs >= 2 * (n_right // 2)
+    got = rt.join_stream_batches(lt, rtab, [(1, 7)], [(1, "k")], [(7, "k")], JT["inner"], 8192)
+    assert sum(len(c[0]) for _, c in got) == n_pairs and all(c[0] == c[1] for _, c in got)
+
+
 @pytest.mark.parametrize("dt", ["DT_INT64", "DT_INT32", "DT_UINT32", "DT_UINT64"])
 @pytest.mark.parametrize("null_eq", [False, True])
 def test_joins_with_null_keys_match_oracle(rt, orc, abi, dt, null_eq):
