@@ -262,6 +262,7 @@ uint32_t host_thread_limit();
 // temporaries per call).  Blocks are reused by capacity; everything is released at llkv_hip_shutdown.
 void *scratch_alloc(size_t bytes);
 void scratch_free(void *p);
+bool scratch_can_hold(size_t bytes); // whether scratch_alloc(bytes) could succeed now (admission of memory-hungry routes)
 void scratch_release_all();
 struct Scratch { // RAII temporary
   void *p = nullptr;

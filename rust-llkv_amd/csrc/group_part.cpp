@@ -147,6 +147,14 @@ int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_
     HIP_TRY(hipMemcpyAsync(g->d_code_rank, ranks.data(), ranks.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
+  { // admission by memory: every run keeps (k_image − 1) words for every record position of the table (SF10, 6 lanes: 2.4 GB,
+    // a 4 GB block of the pool) — a table too large for that is the sort-based route's (LLKV_UNSUPPORTED: the caller falls through)
+    const TileSet *ts = nullptr;
+    if ((rc = get_tileset(*table, kPartTileRowsHost, &ts))) return rc;
+    const uint64_t record_bytes = (uint64_t)(g->plan.k_image - 1) * ts->n_tiles * kPartTileRowsHost * 8;
+    if (!scratch_can_hold(record_bytes))
+      return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: " + std::to_string(record_bytes >> 20) + " MiB of records do not fit the free HBM");
+  }
   *out = g.release();
   return LLKV_OK;
 }

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <dirent.h>
 #include <dlfcn.h>
 #include <fstream>
 #include <sys/stat.h>
@@ -146,6 +147,46 @@ int compile_to_code(const std::string &src, std::vector<char> *code, std::string
 }
 } // namespace
 
+// A stored code object carries what it was compiled from behind the ELF: [identity text][its length, 8 bytes]["LLKVJIT1"].
+// The file NAME is a 64-bit hash of (source, compiler identity); the identity text — kind, plan type string, a second hash
+// of the source and the compiler identity — is compared on load, so a colliding or mis-copied file that happens to export
+// llkv_jit_a is never run in another plan's place.
+static const char kBlobMagic[8] = {'L', 'L', 'K', 'V', 'J', 'I', 'T', '1'};
+static uint64_t fnv1a_alt(const std::string &s) { // independent of fnv1a: other basis, the length mixed in
+  uint64_t h = 0x84222325cbf29ce4ull ^ (uint64_t)s.size();
+  for (unsigned char c : s) h = (h ^ c) * 0x100000001b3ull + 0x9E3779B97F4A7C15ull;
+  return h;
+}
+static std::string blob_identity(JitKind kind, const std::string &type_string, const std::string &src) {
+  char h2[32];
+  std::snprintf(h2, sizeof h2, "%016llx", (unsigned long long)fnv1a_alt(src));
+  return std::string(kind_name(kind)) + "|" + type_string + "\n" + h2 + "\n" + compile_identity();
+}
+static void blob_append_identity(std::vector<char> *file, const std::string &id) {
+  file->insert(file->end(), id.begin(), id.end());
+  const uint64_t n = id.size();
+  file->insert(file->end(), reinterpret_cast<const char *>(&n), reinterpret_cast<const char *>(&n) + 8);
+  file->insert(file->end(), kBlobMagic, kBlobMagic + 8);
+}
+// strips the trailer; false when it is missing or `expect` (if given) is not what it says; *id_out = the stored text
+static bool blob_take_identity(std::vector<char> *file, const std::string *expect, std::string *id_out = nullptr) {
+  if (file->size() < 16 || std::memcmp(file->data() + file->size() - 8, kBlobMagic, 8) != 0) return false;
+  uint64_t n = 0;
+  std::memcpy(&n, file->data() + file->size() - 16, 8);
+  if (n > file->size() - 16) return false;
+  const std::string id(file->data() + file->size() - 16 - n, (size_t)n);
+  if (expect && id != *expect) return false;
+  if (id_out) *id_out = id;
+  file->resize(file->size() - 16 - (size_t)n);
+  return true;
+}
+// the seed directory is trusted like the library beside it — if nobody but its owner (this user or root) can write to it
+static bool trusted_dir(const std::string &dir) {
+  struct stat st;
+  if (dir.empty() || ::stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  return (st.st_uid == ::geteuid() || st.st_uid == 0) && (st.st_mode & 022) == 0;
+}
+
 int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, std::string *err) {
   std::lock_guard<std::mutex> lk(g_jit_mu);
   const std::string key = std::string(kind_name(kind)) + "|" + type_string;
@@ -177,23 +218,24 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
   };
   std::vector<char> code;
   bool loaded = false;
+  const std::string identity = blob_identity(kind, type_string, src);
   if (cacheable) {
     std::ifstream f(path, std::ios::binary);
     if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
     std::string why;
-    if (!code.empty() && !(loaded = load(code, &why))) { // truncated / corrupt / stale blob: drop it and compile again
+    if (!code.empty() && !(blob_take_identity(&code, &identity) && (loaded = load(code, &why)))) { // truncated / corrupt / stale / somebody else's blob: drop it and compile again
       (void)::unlink(path.c_str());
       code.clear();
     }
     g_jit_from_cache += loaded ? 1 : 0;
   }
   if (!loaded && !std::getenv("LLKV_HIP_NO_JIT_SEED")) {
-    static const std::string seeds = seed_dir();
+    static const std::string seeds = trusted_dir(seed_dir()) ? seed_dir() : std::string();
     if (!seeds.empty()) {
       std::ifstream f(seeds + "/" + hex + ".hsaco", std::ios::binary);
       if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
       std::string why;
-      if (!code.empty() && !(loaded = load(code, &why))) code.clear(); // (left alone: the directory is not ours to clean)
+      if (!code.empty() && !(blob_take_identity(&code, &identity) && (loaded = load(code, &why)))) code.clear(); // (left alone: the directory is not ours to clean)
       g_jit_from_seed += loaded ? 1 : 0;
     }
   }
@@ -203,7 +245,9 @@ int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, st
     if (cacheable) {
       const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
       std::ofstream f(tmp, std::ios::binary);
-      if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); std::rename(tmp.c_str(), path.c_str()); }
+      std::vector<char> file = code;
+      blob_append_identity(&file, identity);
+      if (f) { f.write(file.data(), (std::streamsize)file.size()); f.close(); std::rename(tmp.c_str(), path.c_str()); }
     }
     if (!load(code, err)) return LLKV_INTERNAL;
     ++g_jit_compiled;
@@ -238,6 +282,58 @@ extern "C" void llkv_hip_jit_stats(uint64_t *compiled, uint64_t *from_cache, uin
   if (compiled) *compiled = g_jit_compiled;
   if (from_cache) *from_cache = g_jit_from_cache;
   if (from_seed) *from_seed = g_jit_from_seed;
+}
+
+// Does a directory of stored code objects (the seed directory, a cache) hold what hiprtc makes of the tracked kernel source
+// today?  Every `every`-th file (by name order) is compiled again from the identity it carries and compared byte for byte.
+// No device needed.  Returns 0 and the counts; files without an identity, of another compiler or another source count as bad.
+extern "C" int llkv_hip_jit_verify_dir(const char *dir, uint32_t every, uint64_t *checked, uint64_t *bad, char *first_bad, uint64_t first_bad_cap) {
+  if (checked) *checked = 0;
+  if (bad) *bad = 0;
+  if (first_bad && first_bad_cap) first_bad[0] = 0;
+  if (!dir) return LLKV_INVALID_ARGUMENT;
+  std::vector<std::string> names;
+  if (DIR *d = ::opendir(dir)) {
+    while (struct dirent *e = ::readdir(d)) {
+      const std::string n = e->d_name;
+      if (n.size() > 6 && n.compare(n.size() - 6, 6, ".hsaco") == 0) names.push_back(n);
+    }
+    ::closedir(d);
+  } else {
+    return LLKV_NOT_FOUND;
+  }
+  std::sort(names.begin(), names.end());
+  if (every == 0) every = 1;
+  for (size_t i = 0; i < names.size(); i += every) {
+    std::ifstream f(std::string(dir) + "/" + names[i], std::ios::binary);
+    std::vector<char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::string id;
+    bool ok = blob_take_identity(&file, nullptr, &id);
+    if (ok) {
+      const size_t bar = id.find('|'), nl = id.find('\n');
+      ok = bar != std::string::npos && nl != std::string::npos && bar < nl;
+      if (ok) {
+        const std::string kind_s = id.substr(0, bar), ts = id.substr(bar + 1, nl - bar - 1);
+        int kind = -1;
+        for (int k = 0; k <= 8; ++k) if (kind_s == kind_name((JitKind)k)) kind = k;
+        ok = kind >= 0;
+        if (ok) {
+          const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
+          char hex[32];
+          std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src + "\n// " + compile_identity()));
+          std::vector<char> code;
+          std::string err;
+          ok = names[i] == std::string(hex) + ".hsaco" && id == blob_identity((JitKind)kind, ts, src) && compile_to_code(src, &code, &err) == LLKV_OK && code == file;
+        }
+      }
+    }
+    if (checked) ++*checked;
+    if (!ok) {
+      if (bad) ++*bad;
+      if (first_bad && first_bad_cap && !first_bad[0]) std::snprintf(first_bad, (size_t)first_bad_cap, "%s", names[i].c_str());
+    }
+  }
+  return LLKV_OK;
 }
 
 // Build check (no device needed): compiles one plan of the given kind for gfx950.

@@ -46,6 +46,21 @@ void *scratch_alloc(size_t bytes) {
   return p;
 }
 
+// Could scratch_alloc(bytes) succeed now?  (a cached block of the size class, or enough free HBM once the cache is given back)
+bool scratch_can_hold(size_t bytes) {
+  size_t cap = 4096;
+  while (cap < bytes) cap <<= 1;
+  size_t cached;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_free.count(cap)) return true;
+    cached = g_scratch_cached;
+  }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true; // (cannot tell: let the allocation speak)
+  return cap + (1ull << 30) <= free_b + cached;
+}
+
 void scratch_free(void *p) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_scratch_mu);

@@ -189,3 +189,37 @@ def test_exact_sums_and_hostile_values(rt, orc, abi):
     got, exp = check([A.sum(3), A.count_star()], False, {0}, scale=1e299)  # 600 decades: the sort-based route
     assert got[12].values[0].value == exp[12].values[0].value  # a group of subnormals only
     check([A.sum(col(2) / col(2)), A.count_star()], False, {0})
+
+
+def test_order_free_f64_sums_are_bounded_error_not_exact(rt, orc, abi):
+    """The order-free f64 sums of the shared-image / partitioned routes round every row to one grid (2^-30 of the column's
+    smallest non-zero magnitude) or cut it into exactly-added levels: bit-identical over geometries, and within 1e-9 of the
+    magnitude of what was added — NOT of a result that cancels.  Wide dynamic range (1e-6 … 1e9), mixed signs, groups whose
+    large terms cancel exactly: the error against the exactly rounded sum (math.fsum) stays below 1e-9 · Σ|v| of the group,
+    and the oracle's sequential sum is no closer to it than that either."""
+    import math
+    rng = np.random.default_rng(17)
+    n = 120_000
+    key = rng.integers(0, 300, size=n).astype(np.int64)
+    mag = 10.0 ** rng.uniform(-6, 9, size=n)
+    v = mag * rng.choice([-1.0, 1.0], size=n)
+    # cancellation: in the groups 0..49 every large value gets its negative in the same group
+    big = np.flatnonzero((key < 50) & (np.abs(v) > 1e6))
+    half = len(big) // 2
+    v[big[half:2 * half]] = -v[big[:half]]
+    key[big[half:2 * half]] = key[big[:half]]
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, key), (2, abi.DT_FLOAT64, v)], [50_000, 70_000])
+    A = abi.AggregateSpec
+    pq = rt.PreparedQuery(ht, None, [A.sum(2), A.count_star()], [1], True)
+    assert _image(pq), pq.route_note
+    got, exp = pq.run(), orc.groupby(ot, None, [1], [A.sum(2), A.count_star()], True)
+    assert [r.keys[0].value for r in got] == [r.keys[0].value for r in exp]
+    worst = 0.0
+    for g, w in zip(got, exp):
+        sel = key == g.keys[0].value
+        exact, added = math.fsum(v[sel].tolist()), float(np.abs(v[sel]).sum())
+        assert g.values[1].value == w.values[1].value == int(sel.sum())
+        assert abs(g.values[0].value - exact) <= REL * added, (g.keys[0].value, g.values[0].value, exact, added)
+        assert abs(w.values[0].value - exact) <= REL * added
+        worst = max(worst, abs(g.values[0].value - exact) / added)
+    assert worst < 5e-10

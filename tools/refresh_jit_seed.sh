@@ -17,5 +17,18 @@ case "${1:-}" in
     rm -rf "$ROOT/rust-llkv_amd/jit_seed"; mkdir -p "$ROOT/rust-llkv_amd/jit_seed"
     cp "$ROOT"/gpurun_out/jit_cache/*.hsaco "$ROOT/rust-llkv_amd/jit_seed/"
     ls "$ROOT/rust-llkv_amd/jit_seed" | wc -l ;;
-  *) echo "usage: $0 collect|install" >&2; exit 2 ;;
+  verify) # every seed against a fresh hiprtc build of the tracked kernel source (no GPU needed; ~0.35 s per file)
+    cd "$ROOT" && python3 - <<'PY'
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.getcwd())
+rt = importlib.import_module("rust-llkv_amd.runtime")
+lib = rt.lib()
+checked, bad, first = C.c_uint64(), C.c_uint64(), C.create_string_buffer(256)
+every = int(os.environ.get("EVERY", "1"))
+rc = lib.llkv_hip_jit_verify_dir(os.path.join(os.getcwd(), "rust-llkv_amd", "jit_seed").encode(), C.c_uint32(every), C.byref(checked), C.byref(bad), first, C.c_uint64(256))
+print(f"rc={rc} checked={checked.value} bad={bad.value} first_bad={first.value.decode()}")
+sys.exit(1 if rc or bad.value else 0)
+PY
+    ;;
+  *) echo "usage: $0 collect|install|verify" >&2; exit 2 ;;
 esac
