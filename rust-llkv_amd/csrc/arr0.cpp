@@ -22,8 +22,10 @@ static int32_t dtype_of_prim(int32_t code) {
   case 6: return LLKV_DT_INT64;
   case 11: return LLKV_DT_FLOAT64;
   case 12: return LLKV_DT_UTF8;
+  case 15: return LLKV_DT_BOOLEAN;    // bit-packed values buffer
   case 16: return LLKV_DT_DATE32;
-  default: return -1; // Binary, narrow ints, Boolean (bit-packed), Date64, Decimal128, views: not on this path
+  case 18: return LLKV_DT_DECIMAL128; // precision / scale in header bytes 6 / 7 (serialize_primitive, serialization.rs:282-296)
+  default: return -1; // Binary, Int16 / Int8 / UInt16 / UInt8 and Date64 (no storage type of theirs on this path), views
   }
 }
 
@@ -43,7 +45,11 @@ int arr0_describe(const uint8_t *blob, uint64_t blob_len, llkv_arr0_desc *out) {
     out->values_offset = 24;
     out->values_len = extra_a;
     out->dtype = dtype_of_prim(out->type_code);
-    if (out->dtype >= 0 && out->dtype != LLKV_DT_UTF8 && dtype_width(out->dtype) * out->len != extra_a)
+    if (out->dtype == LLKV_DT_BOOLEAN) { // an arrow bit buffer: at least ⌈len / 8⌉ bytes
+      if (extra_a < (out->len + 7) / 8) return set_error(LLKV_INTERNAL, "boolean values buffer shorter than the element count");
+    } else if (out->dtype == LLKV_DT_DECIMAL128) {
+      if (16 * out->len != extra_a) return set_error(LLKV_INTERNAL, "primitive values length does not match the element count");
+    } else if (out->dtype >= 0 && out->dtype != LLKV_DT_UTF8 && dtype_width(out->dtype) * out->len != extra_a)
       return set_error(LLKV_INTERNAL, "primitive values length does not match the element count");
     if (out->dtype == LLKV_DT_UTF8) out->dtype = -1;
   } else if (out->layout == 2) { // Varlen: [offsets][values]
@@ -100,7 +106,8 @@ llkv_status llkv_hip_table_append_arr0_column(llkv_hip_table *table, uint32_t fi
   std::vector<const void *> values(n_chunks);
   std::vector<const int32_t *> offsets(n_chunks);
   std::vector<const uint8_t *> data(n_chunks);
-  int32_t dtype = -2;
+  std::vector<std::vector<uint8_t>> unpacked; // Boolean: one byte per value, as the staging entry point takes them
+  int32_t dtype = -2, precision = 0, scale = 0;
   for (uint32_t i = 0; i < n_chunks; ++i) {
     llkv_arr0_desc d;
     int rc = arr0_describe(blobs[i], blob_lens[i], &d);
@@ -114,9 +121,21 @@ llkv_status llkv_hip_table_append_arr0_column(llkv_hip_table *table, uint32_t fi
     values[i] = blobs[i] + d.values_offset;
     offsets[i] = reinterpret_cast<const int32_t *>(blobs[i] + d.payload_offset);
     data[i] = blobs[i] + d.values_offset;
+    if (d.dtype == LLKV_DT_BOOLEAN) {
+      unpacked.emplace_back((size_t)(d.len ? d.len : 1), 0);
+      const uint8_t *bits = blobs[i] + d.values_offset;
+      for (uint64_t r = 0; r < d.len; ++r) unpacked.back()[(size_t)r] = (bits[r >> 3] >> (r & 7)) & 1u;
+    } else if (d.dtype == LLKV_DT_DECIMAL128) {
+      const int32_t pr = blobs[i][6], sc = (int8_t)blobs[i][7];
+      if (i && (pr != precision || sc != scale)) return (llkv_status)set_error(LLKV_INTERNAL, "chunks of one Decimal128 column disagree on precision / scale");
+      precision = pr;
+      scale = sc;
+    }
   }
+  if (dtype == LLKV_DT_BOOLEAN) for (uint32_t i = 0; i < n_chunks; ++i) values[i] = unpacked[i].data(); // (after the loop: the vector of vectors no longer moves)
   if (n_chunks == 0) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "no chunks: the column type is unknown");
   if (dtype == LLKV_DT_UTF8) return llkv_hip_table_append_utf8_column(table, field_id, offsets.data(), data.data(), n_chunks, dictionary, dict_size);
+  if (dtype == LLKV_DT_DECIMAL128) return llkv_hip_table_append_decimal128_column(table, field_id, precision, scale, values.data(), n_chunks);
   return llkv_hip_table_append_column(table, field_id, dtype, values.data(), n_chunks);
 }
 

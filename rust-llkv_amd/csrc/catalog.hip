@@ -10,7 +10,7 @@ namespace llkv {
 
 template <class P> static hipError_t launch_plan(const ScanParams &p, hipStream_t stream) {
   if (p.n_tiles == 0) return hipSuccess;
-  const uint32_t grid = P::ACC == 1 && p.scan_grid ? p.scan_grid : p.n_tiles; // register plans: one tile per workgroup
+  const uint32_t grid = P::ACC != 2 && p.scan_grid ? p.scan_grid : p.n_tiles; // scan_grid workgroups stream runs of tiles; 0: one tile per workgroup
   hipLaunchKernelGGL((fused_scan_kernel<P>), dim3(grid), dim3(kBlock), 0, stream, p);
   return hipGetLastError();
 }

@@ -107,7 +107,15 @@ static uint32_t pick_image_grid(const LoweredPlan &p, uint32_t n_tiles) {
 // the CUs idle seems to buy the fabric some clock; a 1/8 shard (457 tiles) wants every CU: 256 workgroups 49.8 µs, 192:
 // 56 µs.  A shard with fewer tiles than CUs launches one workgroup per tile.
 static uint32_t pick_scan_grid(const LoweredPlan &p, uint32_t n_tiles) {
-  if (!p.acc_lds) return 0; // one tile per workgroup
+  if (!p.acc_lds) { // register-resident states: one tile per workgroup, unless the table is small enough for the dispatch of its
+    // workgroups to show (kRegGridTiles, swept on Q6 SF1: profiles/r03/sweep_q6_sf1.txt)
+    uint32_t grid = 0;
+    if (const char *e = std::getenv("LLKV_HIP_SCAN_WGS")) {
+      long v = std::atol(e);
+      if (v >= 1) grid = (uint32_t)std::min<long>(v, 1 << 20);
+    }
+    return grid >= n_tiles ? 0 : grid;
+  }
   // (a state of more than 6 lanes per row keeps every CU busy with its DS atomics: 12 lanes 0.334 ms at 256, 0.428 ms at 192)
   // Within that range the count that leaves the least idle time wins: workgroups take whole tiles, so 3 662 tiles over
   // 192 workgroups are 19 or 20 each (the kernel lasts 20, the average is 19.07: 352 µs), over 193 they are 18 or 19

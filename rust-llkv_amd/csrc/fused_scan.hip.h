@@ -769,18 +769,25 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
   constexpr int NG = P::NG, K = P::K, U = P::U, LANES = P::LANES;
   constexpr LaneOpTable<P> ops{};
   __shared__ uint64_t red[LANES < kRedBatch ? LANES : kRedBatch][kRedRow];
-
+  const uint32_t tid = threadIdx.x;
+  piggyback_fold<P>(p);
+  // One workgroup per tile, or (scan_grid != 0: tables of a few thousand tiles, where the dispatch of one short workgroup
+  // per tile is a visible part of the kernel) workgroup b of g streams the tiles [b·n/g, (b+1)·n/g).  Either way every tile
+  // is reduced on its own and publishes its own partial: the association — and so the bits — do not depend on the grid.
+  const uint32_t g = p.scan_grid;
+  if (g && blockIdx.x >= g) return; // (a launch wider than the grid the host announced must not walk off the tile list)
+  const uint32_t t_first = g ? (uint32_t)((uint64_t)blockIdx.x * p.n_tiles / g) : blockIdx.x;
+  const uint32_t t_last = g ? (uint32_t)((uint64_t)(blockIdx.x + 1) * p.n_tiles / g) : (blockIdx.x < p.n_tiles ? blockIdx.x + 1 : blockIdx.x);
+  for (uint32_t tile = t_first; tile < t_last; ++tile) {
   uint64_t acc[NG][K];
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
+  for (int gg = 0; gg < NG; ++gg)
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[g][k] = lane_identity(ops.v[g * K + k]);
+    for (int k = 0; k < K; ++k) acc[gg][k] = lane_identity(ops.v[gg * K + k]);
   uint32_t err = 0;
 
-  const TileDesc td = p.tiles[blockIdx.x];
-  const uint32_t tid = threadIdx.x;
+  const TileDesc td = p.tiles[tile];
   const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
-  piggyback_fold<P>(p);
 
   for (uint32_t s = 0; s < nsteps; s += U) {
     Loaded ld[U];
@@ -806,13 +813,13 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
         AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
         err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const bool sel = pass & (NG == 1 || gid == (uint32_t)g);
+        for (int gg = 0; gg < NG; ++gg) {
+          const bool sel = pass & (NG == 1 || gid == (uint32_t)gg);
 #pragma unroll
           for (int k = 0; k < K; ++k) {
-            const int op = ops.v[g * K + k];
+            const int op = ops.v[gg * K + k];
             const uint64_t x = sel ? contrib[k] : lane_identity(op);
-            acc[g][k] = lane_combine(op, acc[g][k], x);
+            acc[gg][k] = lane_combine(op, acc[gg][k], x);
           }
         }
       }
@@ -852,10 +859,11 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
         // fixed operand order (lower segment first) keeps f64 adds reproducible
         v = (rq & off) ? lane_combine(op, o, v) : lane_combine(op, v, o);
       }
-      if (rq == 0) publish_partial(p, lane, v, blockIdx.x, p.n_tiles);
+      if (rq == 0) publish_partial(p, lane, v, tile, p.n_tiles);
     }
     __syncthreads();
   }
+  } // tiles of this workgroup
 }
 
 

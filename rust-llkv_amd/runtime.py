@@ -613,10 +613,16 @@ PRIM_TYPE_CODES = {abi.DT_UINT64: 1, abi.DT_INT32: 2, abi.DT_UINT32: 3, abi.DT_F
                    abi.DT_UTF8: 12, abi.DT_DATE32: 16}
 
 
-def arr0_serialize(dtype: int, values) -> bytes:
+def arr0_serialize(dtype: int, values, precision: int = 0, scale: int = 0) -> bytes:
     """Writer of the `ARR0` chunk blob for the types on this path (layout documented in
     llkv-column-map/src/serialization.rs:41-140) — harness / test helper."""
     import struct
+    if dtype == abi.DT_BOOLEAN:  # arrow's bit-packed values buffer
+        bits = np.packbits(np.asarray(values, dtype=bool), bitorder="little").tobytes()
+        return b"ARR0" + bytes([0, 15, 0, 0]) + struct.pack("<QII", len(values), len(bits), 0) + bits
+    if dtype == abi.DT_DECIMAL128:  # 16-byte little-endian raw values; precision / scale in the two reserved header bytes
+        raw = abi.i128_buffer(values).tobytes()
+        return b"ARR0" + bytes([0, 18, precision & 0xFF, scale & 0xFF]) + struct.pack("<QII", len(values), len(raw), 0) + raw
     if dtype == abi.DT_UTF8:
         enc = [s.encode() for s in values]
         offsets = np.zeros(len(enc) + 1, dtype=np.int32)

@@ -265,6 +265,20 @@ def test_results_are_bit_reproducible_and_gpu_count_invariant(rt, abi, tpch):
             pg.close()
         finally:
             del os.environ["LLKV_HIP_SCAN_WGS"]
+    # register-resident states (ungrouped plans) too: a workgroup that streams a run of tiles still reduces and publishes
+    # every tile on its own
+    q6 = tpch.q6()
+    p6 = rt.PreparedQuery(one, q6.predicate, q6.aggs, q6.keys, False)
+    r6, e6 = flat(p6.run()), p6.read_exchange()
+    for wgs in ("1", "7", "33", "100", "245"):
+        os.environ["LLKV_HIP_SCAN_WGS"] = wgs
+        try:
+            pg = rt.PreparedQuery(one, q6.predicate, q6.aggs, q6.keys, False)
+            assert flat(pg.run()) == r6 and np.array_equal(pg.read_exchange(), e6), wgs
+            assert flat(pg.run()) == r6, wgs  # (with the fold of the previous execution riding in the launch)
+            pg.close()
+        finally:
+            del os.environ["LLKV_HIP_SCAN_WGS"]
     for world in (2, 4, 8):
         total = np.zeros_like(ex1).view(np.int64)
         last = None
@@ -1651,7 +1665,8 @@ def test_join_record_batches_sharded_probe_side_concatenates(rt, orc, abi):
     rows = []
     for rank in range(4):
         lt = rt.HipTable(1, chunks, rank=rank, world=4)
-        lt.append_column(1, abi.DT_INT64, lk); lt.append_column(2, abi.DT_FLOAT64, lv)
+        lo = sum(chunks[:lt.first_chunk])
+        lt.append_column(1, abi.DT_INT64, lk[lo:lo + lt.local_rows]); lt.append_column(2, abi.DT_FLOAT64, lv[lo:lo + lt.local_rows])
         for names, cols in rt.join_stream_batches(lt, rtab, [(1, 11)], [(1, "k"), (2, "v")], [(11, "k"), (12, "w")], JT["left"]):
             assert names == ["k", "v", "k_1", "w"]
             rows.extend(zip(*cols))
@@ -2639,10 +2654,29 @@ def test_table_staged_from_arr0_chunk_blobs(rt, orc, abi, tpch):
             blobs.append(rt.arr0_serialize(dt, [chr(int(v)) for v in part] if dt == abi.DT_UTF8 else part))
             off += r
         ht.append_arr0_column(fid, blobs)
+    # Boolean (bit-packed) and Decimal128 (precision / scale in the header) chunk blobs
+    rng = np.random.default_rng(4)
+    flags = rng.random(n) < 0.3
+    money = [int(v) for v in rng.integers(-10**11, 10**11, size=n)]
+    fb, fd = 90, 91
+    ot.add(fb, abi.DT_BOOLEAN, flags.astype(np.uint8))
+    ot.add(fd, abi.DT_DECIMAL128, money, precision=15, scale=2)
+    bb, bd, off = [], [], 0
+    for r in chunks:
+        bb.append(rt.arr0_serialize(abi.DT_BOOLEAN, flags[off:off + r]))
+        bd.append(rt.arr0_serialize(abi.DT_DECIMAL128, money[off:off + r], precision=15, scale=2))
+        off += r
+    ht.append_arr0_column(fb, bb)
+    ht.append_arr0_column(fd, bd)
     got, want = rt.groupby(ht, q.predicate, q.keys, q.aggs, True), orc.groupby(ot, q.predicate, q.keys, q.aggs, True)
     assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want]
     for g, w in zip(got, want):
         assert_values(g.values, w.values, "arr0")
+    A = abi.AggregateSpec
+    aggs = [A.count_star(), A.sum(fd), A.avg(fd), A.min(fd), A.max(fd), A.sum(fb)]
+    assert_values(rt.aggregate(ht, q.predicate, aggs), orc.aggregate(ot, q.predicate, aggs), "arr0 boolean / decimal")
+    g, w = rt.scan_stream(ht, [fb, fd], q.predicate), orc.scan_stream(ot, [fb, fd], q.predicate)
+    assert [c for b in g for c in b[0]] == [c for b in w for c in b[0]]
 
 
 def test_mvcc_visibility_fused_into_the_scan(rt, orc, abi):

@@ -419,7 +419,13 @@ def test_arr0_chunk_reader(lib, abi):
             rt.arr0_describe(bad)
         assert e.value.kind == "Internal"
     d = rt.arr0_describe(b"ARR0" + bytes([0, 18, 15, 2]) + (2).to_bytes(8, "little") + (32).to_bytes(4, "little") + bytes(4) + bytes(32))
-    assert d.dtype == -1  # Decimal128 is not on this path (it cannot even be leaf-filtered, llkv-table/src/table.rs:1160-1167)
+    assert (d.dtype, d.len, d.values_len) == (abi.DT_DECIMAL128, 2, 32)  # precision 15 / scale 2 ride in header bytes 6 / 7 (serialization.rs:282-296)
+    d = rt.arr0_describe(rt.arr0_serialize(abi.DT_BOOLEAN, [True, False, True, True, False, False, True, False, True]))
+    assert (d.type_code, d.dtype, d.len, d.values_len) == (15, abi.DT_BOOLEAN, 9, 2)  # an arrow bit buffer
+    d = rt.arr0_describe(rt.arr0_serialize(abi.DT_DECIMAL128, [10**20, -5], precision=38, scale=4))
+    assert (d.type_code, d.dtype, d.len, d.values_len) == (18, abi.DT_DECIMAL128, 2, 32)
+    for code in (7, 8, 9, 10, 17):  # Int16 / Int8 / UInt16 / UInt8 / Date64: no storage type of theirs on this path
+        assert rt.arr0_describe(b"ARR0" + bytes([0, code, 0, 0]) + (1).to_bytes(8, "little") + (8).to_bytes(4, "little") + bytes(4) + bytes(8)).dtype == -1
 
 
 def test_dense_row_runs(lib):

@@ -81,7 +81,8 @@ int main(int argc, char **argv) {
   if (run<4, false, 1>("1 stream, U=4, temporal", s, bytes, 131072, out, reps)) return 1;
   if (run<2, true, 5>("5 streams, U=2, non-temporal", s, bytes, 131072, out, reps)) return 1;
   if (run<1, true, 5>("5 streams, U=1, non-temporal", s, bytes, 131072, out, reps)) return 1;
-  if (run<4, true, 4>("4 streams, U=4 (Q6-like)", s, 1679609456ull, 131072, out, reps)) return 1;
+  if (run<4, true, 4>("4 streams, U=4 (Q6-like)", s, std::min<size_t>(bytes, 1679609456ull), 131072, out, reps)) return 1; // never past the allocation
+  if (run<4, true, 4>("4 streams, U=4, 16 KiB tiles", s, std::min<size_t>(bytes, 1679609456ull), 16384, out, reps)) return 1;
   CHECK(hipFree(src)); CHECK(hipFree(out));
   return 0;
 }
