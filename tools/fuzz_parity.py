@@ -145,6 +145,33 @@ def fuzz_joins(seeds):
                    (jt in ("semi", "anti") or [x for b in got for x in b[1]] == [x for b in want for x in b[1]]) and \
                    (rules == 1 or [len(b[0]) for b in got] == [len(b[0]) for b in want])
             if not same: bad.append((seed, "pairs differ", kinds, keys_used, jt, batch, rules, n_left, n_right))
+            # … and the joined RecordBatches (llkv_hip_join_stream_batches): the key columns of both sides as the output,
+            # names, batch cuts, every cell (a NaN cell compares by its bits)
+            lcols = [(f, f"k{f}") for f, *_ in cols_l][:int(rng.integers(0, n_keys + 1)) or None]
+            rcols = [(f, f"k{f - 10}") for f, *_ in cols_r][:int(rng.integers(0, n_keys + 1)) or None]
+            def cells(batches):
+                import struct
+                return [(names, [[struct.pack("<d", v) if isinstance(v, float) else v for v in c] for c in cols]) for names, cols in batches]
+            try:
+                wantb = orc.hash_join_batches(ol, orr, keys_used, lcols, rcols, JT[jt], batch, key_rules=rules)
+            except abi.LlkvError as oe:
+                try:
+                    rt.join_stream_batches(lt, rtab, keys_used, lcols, rcols, JT[jt], batch, key_rules=rules)
+                    bad.append((seed, "batches: oracle raised, GPU did not", str(oe), kinds, jt, rules))
+                except abi.LlkvError as ge:
+                    if ge.kind != oe.kind: bad.append((seed, "batches: different errors", str(oe), str(ge), kinds, jt, rules))
+                continue
+            try:
+                gotb = rt.join_stream_batches(lt, rtab, keys_used, lcols, rcols, JT[jt], batch, key_rules=rules)
+            except abi.LlkvError as ge:
+                bad.append((seed, "batches: GPU raised", str(ge), kinds, jt, rules))
+                continue
+            if rules == 1:  # one batch in the reference, one per device step here: compared as the concatenation
+                cat = lambda bs: [sum((c[i] for _, c in bs), []) for i in range(len(bs[0][1]))] if bs else []
+                okb = cat(cells(gotb)) == cat(cells(wantb)) and all(n == wantb[0][0] for n, _ in gotb)
+            else:
+                okb = cells(gotb) == cells(wantb)
+            if not okb: bad.append((seed, "batches differ", kinds, keys_used, jt, batch, rules, n_left, n_right, lcols, rcols))
     return bad
 
 
