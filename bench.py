@@ -297,7 +297,7 @@ def measure_q3(rt, tpch, abi, sf):
     for t in (lt, ot, ct):
         t.close()
     return {"rows_per_s": rows / med, "ms_per_step": med * 1e3, "groups": int(groups), "achieved_gbs": alg / med / 1e9, "frac": alg / med / 1e9 / HBM_PEAK_GBS,
-            "note": "whole pipeline (2 selections, semi join, hash build, probe, sort, sums, top-k), host-timed median of 7"}
+            "note": "whole pipeline (two key-set scans, bitmap ranks, probe, run sums, top-k: 8 launches), host-timed median of 7"}
 
 
 def measure_q3_sharded(rt, tpch, abi, torch, dist, sf, rank, world):

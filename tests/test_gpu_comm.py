@@ -184,6 +184,12 @@ def _worker(rank, world, port, out_path):
     ja = rt.JoinAgg(**_join_inputs(rt, abi, tpch, rank, world))
     rows, total = ja.finish_sharded(10)
     res["join"] = ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in rows], total)
+    # the range form: every rank selects the dimension rows of its own fact key range and the ranks exchange their boundary
+    # runs (one small all-gather inside finish_sharded) instead of the per-group counts
+    jr = rt.JoinAgg(ranged=True, **_join_inputs(rt, abi, tpch, rank, world))
+    rows, total = jr.finish_sharded(10)
+    res["join_ranged"] = ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in rows], total)
+    res["join_ranged_bytes"] = jr.exchange_bytes()
     with open(f"{out_path}.{rank}", "wb") as f:
         pickle.dump(res, f)
     rt.comm_destroy()
@@ -220,6 +226,7 @@ def test_two_processes_run_the_sharded_drivers_over_a_host_transport(rt, abi, tp
                     assert x == y, (name, a)
     jw, jtotal = rt.join_groupby_topk(limit=10, **_join_inputs(rt, abi, tpch, 0, 1))
     assert got[0]["join"] == ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in jw], jtotal)
+    assert got[0]["join_ranged"] == got[0]["join"] and 0 < got[0]["join_ranged_bytes"] < 8192
 
 
 @pytest.mark.gpu
