@@ -332,7 +332,11 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     if ((rc = lower_emit(resolve_d, dim->filters, dim->n_filters, nullptr, 0, &key_tok, 1, &kp, &err, false, nullptr, t2 ? &dim_fk_field : nullptr))) return set_error(rc, err);
     if ((rc = jit_compile(JitKind::KeyBits, kp.type_string, &kk, &err))) return set_error(rc, err);
     const TileSet *tsd = nullptr;
-    if ((rc = get_tileset(*td, td->local_rows < (4u << 20) ? 2048 : 8192, &tsd))) return rc;
+    // 2 048-row tiles: a wave's quarter is exactly one batch of kSelUnroll steps — every load and key-set gather of the tile
+    // goes out before the first use (SF10 orders: 81 µs; 4 096: 85, 8 192: 90, 16 384: 92; 1 024: 114 — half-empty batches)
+    uint32_t dim_tile = 2048;
+    if (const char *e = std::getenv("LLKV_HIP_KEYBITS_TILE")) { const long v = std::atol(e); if (v >= 512 && v <= 65536 && v % 512 == 0) dim_tile = (uint32_t)v; }
+    if ((rc = get_tileset(*td, dim_tile, &tsd))) return rc;
     if (!kp.always_false && td->local_rows) {
       ScanParams pd;
       std::memset(&pd, 0, sizeof pd);
