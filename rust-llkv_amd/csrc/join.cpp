@@ -611,7 +611,8 @@ struct JoinEmitter {
   std::vector<std::vector<uint8_t>> pend_vals;
   std::vector<std::vector<uint64_t>> pend_valid;
 
-  ~JoinEmitter() { if (copy_stream) (void)hipStreamDestroy(copy_stream); }
+  // (the steps' pinned buffers go back to their pool after this: no copy of an abandoned step may still be writing them)
+  ~JoinEmitter() { if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); } }
   uint32_t n_out() const { return (uint32_t)widths.size(); }
 
   int init() {
