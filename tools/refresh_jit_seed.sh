@@ -15,7 +15,9 @@ case "${1:-}" in
     ls "$ROOT/gpurun_out/jit_cache" | wc -l ;;
   install)
     rm -rf "$ROOT/rust-llkv_amd/jit_seed"; mkdir -p "$ROOT/rust-llkv_amd/jit_seed"
-    cp "$ROOT"/gpurun_out/jit_cache/*.hsaco "$ROOT/rust-llkv_amd/jit_seed/"
+    for f in "$ROOT"/gpurun_out/jit_cache/*.hsaco; do # only code objects that carry their identity (csrc/jit.cpp: kBlobMagic): leftovers of older runs stay behind
+      [ "$(tail -c 8 "$f")" = "LLKVJIT1" ] && cp "$f" "$ROOT/rust-llkv_amd/jit_seed/"
+    done
     ls "$ROOT/rust-llkv_amd/jit_seed" | wc -l ;;
   verify) # every seed against a fresh hiprtc build of the tracked kernel source (no GPU needed; ~0.35 s per file)
     cd "$ROOT" && python3 - <<'PY'
