@@ -314,8 +314,8 @@ llkv_status llkv_hip_arr0_describe(const uint8_t *blob, uint64_t blob_len, llkv_
 
 /* Row-id shadow chunk metadata (ChunkMetadata, store/descriptor.rs:19-84) and the
  * density test of `dense_row_runs` (store/scan/filter.rs:1510-1582): every chunk
- * spans exactly row_count ids and chunks follow one another.  The GPU path takes
- * dense tables only; `*is_dense == 0` means "stay on the CPU route".           */
+ * spans exactly row_count ids and chunks follow one another.  `*is_dense == 0`: hand the
+ * table its row ids (llkv_hip_table_set_row_ids below).                          */
 typedef struct llkv_chunk_meta {
   uint64_t row_count;
   uint64_t min_val_u64;
@@ -323,6 +323,16 @@ typedef struct llkv_chunk_meta {
 } llkv_chunk_meta;
 llkv_status llkv_hip_dense_row_runs(const llkv_chunk_meta *rowid_chunks, uint32_t n_chunks,
                                     int32_t *is_dense, uint64_t *first_row_id);
+
+/* Row ids that are not dense from 0: the row-id shadow column of the table (one array per local chunk, strictly
+ * ascending — llkv-column-map keeps it beside every column, store/descriptor.rs:19-84; gaps appear where rows were
+ * removed, gather over such ids: store/gather.rs:764-884).  Everything inside the library works on row POSITIONS
+ * (predicates, windows, first-appearance order, probe order: all follow the position, which orders as the ids do); the
+ * calls that report row ids — llkv_hip_filter_row_ids, llkv_hip_scan_stream with include_row_ids — translate positions to
+ * these ids on the device.  llkv_hip_join_stream (index pairs) answers LLKV_UNSUPPORTED over such a table: its batch cuts
+ * are positions and its pairs ids; llkv_hip_join_stream_batches reports no ids and takes it.  Ids that ARE the positions:
+ * nothing is kept.  Call before the table is queried; once.                                                           */
+llkv_status llkv_hip_table_set_row_ids(llkv_hip_table *table, const uint64_t *const *chunk_row_ids, uint32_t n_chunks);
 
 /* Stage one column straight from its ARR0 chunk blobs (the pager blobs the
  * reference deserializes zero-copy, serialization.rs:438-488).                 */
@@ -918,6 +928,17 @@ llkv_status llkv_hip_join_agg_finish_sharded(llkv_hip_join_agg *h, uint32_t limi
  * it parses to a positive number, else the detected parallelism.  The library's own host threads (staging lanes,
  * per-chunk preparation of column images) are bounded by it.                                                       */
 uint32_t llkv_hip_max_threads(void);
+
+/* Planning option, process wide, read when a query is prepared: every f64 SUM / AVG / TOTAL becomes the correctly rounded
+ * EXACT sum of the rows' values instead of a fixed-order tree of rounded additions.  The reference adds sequentially
+ * (llkv-aggregate/src/lib.rs:870-888): its 15th–16th digit is a property of that order, which no parallel sum shares —
+ * and which the qualification rule of llkv-tpch compares (`sum` columns as Decimal::from_f64, 15 significant digits,
+ * qualification.rs:672-706).  The exact sum is the order-free answer both approximate; it costs one more state lane per
+ * sum.  Needs column statistics that bound the argument (no NaN / ±inf, a smallest non-zero magnitude, |max| / |min
+ * non-zero| < 2^9 for the two-lane form); a plan whose argument they do not bound answers LLKV_UNSUPPORTED while the
+ * option is on.  Default off.                                                                                        */
+void llkv_hip_set_exact_f64_sums(int32_t on);
+int32_t llkv_hip_exact_f64_sums(void);
 
 /* Route selection — `QueryExecutor::execute_select_with_filter` llkv-executor/src/lib.rs:523-563: which executor
  * route a SELECT of this shape takes, and whether the GPU path has an entry point for it.                          */

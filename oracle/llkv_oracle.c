@@ -617,9 +617,70 @@ static int32_t common_type(int32_t a, int32_t b) {
   return LLKV_DT_NULL;
 }
 
-/* Result type of a postfix token program (fast_numeric.rs:249-298, PlanBuilder::visit).
+/* ScalarEvaluator::simplify llkv-compute/src/eval.rs:761-791, applied by the scan to every computed projection first
+ * (llkv-scan/src/execute.rs:91): Binary(Literal, Literal) → fold_binary_literals (:1010-1031) = compute_binary
+ * (kernels.rs:99-177) over literal_to_array of each side (:521-543: Int128 → Int64 `as i64`, Float64 → Float64, Null →
+ * Null array): common type, checked integer kernels, Divide nullifies a zero divisor first (cmp::eq against the cast 0 —
+ * totalOrder on floats, so −0.0 is not "zero"), float kernels IEEE; a NULL result → Literal::Null; a kernel error →
+ * None, the node stays unfolded (returned as UNSUPPORTED here: neither side evaluates such plans).  Postfix in,
+ * postfix out (`out` holds ≥ n tokens). */
+static int is_numeric_literal_token(const llkv_expr_token *t) {
+  return t->kind == LLKV_TOK_LITERAL && (t->literal.tag == LLKV_LIT_INT128 || t->literal.tag == LLKV_LIT_FLOAT64 || t->literal.tag == LLKV_LIT_NULL);
+}
+static int32_t simplify_tokens(const llkv_expr_token *e, uint32_t n, llkv_expr_token *out, uint32_t *n_out) {
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!(e[i].kind == LLKV_TOK_BINARY && m >= 2 && is_numeric_literal_token(&out[m - 1]) && is_numeric_literal_token(&out[m - 2]))) { out[m++] = e[i]; continue; }
+    const llkv_literal *l = &out[m - 2].literal, *r = &out[m - 1].literal;
+    llkv_literal z;
+    memset(&z, 0, sizeof z);
+    if (e[i].binop < LLKV_BIN_ADD || e[i].binop > LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "constant sub-expression under this operator");
+    if (l->tag == LLKV_LIT_NULL || r->tag == LLKV_LIT_NULL) z.tag = LLKV_LIT_NULL; /* coerced to the other side's type, NULL in → NULL out */
+    else if (l->tag == LLKV_LIT_FLOAT64 || r->tag == LLKV_LIT_FLOAT64) { /* get_common_type: Float64 */
+      double a = l->tag == LLKV_LIT_FLOAT64 ? l->f64 : (double)(int64_t)lit_i128(l);
+      double b = r->tag == LLKV_LIT_FLOAT64 ? r->f64 : (double)(int64_t)lit_i128(r);
+      z.tag = LLKV_LIT_FLOAT64;
+      switch (e[i].binop) {
+      case LLKV_BIN_ADD: z.f64 = a + b; break;
+      case LLKV_BIN_SUB: z.f64 = a - b; break;
+      case LLKV_BIN_MUL: z.f64 = a * b; break;
+      case LLKV_BIN_DIV: if (b == 0.0 && !signbit(b)) z.tag = LLKV_LIT_NULL; else z.f64 = a / b; break;
+      case LLKV_BIN_MOD: z.f64 = fmod(a, b); break;
+      }
+    } else {
+      int64_t a = (int64_t)lit_i128(l), b = (int64_t)lit_i128(r), v = 0;
+      int err = 0, null = 0;
+      switch (e[i].binop) {
+      case LLKV_BIN_ADD: err = __builtin_add_overflow(a, b, &v); break;
+      case LLKV_BIN_SUB: err = __builtin_sub_overflow(a, b, &v); break;
+      case LLKV_BIN_MUL: err = __builtin_mul_overflow(a, b, &v); break;
+      case LLKV_BIN_DIV: if (b == 0) null = 1; else if (a == INT64_MIN && b == -1) err = 1; else v = a / b; break;
+      case LLKV_BIN_MOD: if (b == 0) err = 1; else v = b == -1 ? 0 : a % b; break;
+      }
+      if (err) return fail(LLKV_UNSUPPORTED, "constant sub-expression the reference leaves unfolded (its fold errors)");
+      if (null) z.tag = LLKV_LIT_NULL;
+      else { z.tag = LLKV_LIT_INT128; z.lo = (uint64_t)v; z.hi = v < 0 ? -1 : 0; }
+    }
+    --m;
+    out[m - 1].literal = z;
+  }
+  *n_out = m;
+  return LLKV_OK;
+}
+
+static int32_t infer_simplified_type(const orc_table *t, const llkv_expr_token *e, uint32_t n, int *has_div, int32_t *rc_out);
+/* Result type of a postfix token program (fast_numeric.rs:249-298, PlanBuilder::visit), after simplify.
  * Returns LLKV_DT_NULL when the program is not numeric. */
 static int32_t infer_expr_type(const orc_table *t, const llkv_expr_token *e, uint32_t n, int *has_div, int32_t *rc_out) {
+  llkv_expr_token *s = xmalloc((n ? n : 1) * sizeof *s);
+  uint32_t m = 0;
+  *has_div = 0;
+  if ((*rc_out = simplify_tokens(e, n, s, &m))) { free(s); return LLKV_DT_NULL; }
+  int32_t dt = infer_simplified_type(t, s, m, has_div, rc_out);
+  free(s);
+  return dt;
+}
+static int32_t infer_simplified_type(const orc_table *t, const llkv_expr_token *e, uint32_t n, int *has_div, int32_t *rc_out) {
   int32_t st[64];
   uint32_t sp = 0;
   *has_div = 0;
@@ -645,7 +706,7 @@ static int32_t infer_expr_type(const orc_table *t, const llkv_expr_token *e, uin
       int32_t r = common_type(st[sp - 2], st[sp - 1]);
       if (r == LLKV_DT_NULL || r == LLKV_DT_DATE32 || r == LLKV_DT_UTF8) { *rc_out = fail(LLKV_UNSUPPORTED, "unsupported operand types %s, %s", dtype_name(st[sp - 2]), dtype_name(st[sp - 1])); return LLKV_DT_NULL; }
       /* Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference — checked i32 arithmetic and an
-       * Int32 result; literal ⊕ literal is folded in i128 first (eval.rs:761-791).  Neither is restated. */
+       * Int32 result: not restated.  (Numeric literal pairs were folded by simplify_tokens; what is left is not numeric.) */
       if (r == LLKV_DT_INT32 || r == LLKV_DT_UINT32) { *rc_out = fail(LLKV_UNSUPPORTED, "32-bit-only integer arithmetic"); return LLKV_DT_NULL; }
       if (i >= 2 && e[i - 1].kind == LLKV_TOK_LITERAL && e[i - 2].kind == LLKV_TOK_LITERAL) { *rc_out = fail(LLKV_UNSUPPORTED, "constant sub-expression"); return LLKV_DT_NULL; }
       sp -= 2;
@@ -707,7 +768,7 @@ static int32_t binary_kernel(const arr *l, const arr *r, int32_t op, arr *out) {
       case LLKV_BIN_ADD: z = x + y; break;
       case LLKV_BIN_SUB: z = x - y; break;
       case LLKV_BIN_MUL: z = x * y; break;
-      case LLKV_BIN_DIV: if (y == 0.0) a.valid[i] = 0; else z = x / y; break; /* nullif(rhs == 0) */
+      case LLKV_BIN_DIV: if (y == 0.0 && !signbit(y)) a.valid[i] = 0; else z = x / y; break; /* nullif(eq(rhs, cast(0))): arrow-ord `eq` is totalOrder on floats, −0.0 is not 0.0 */
       case LLKV_BIN_MOD: z = fmod(x, y); break;
       }
       ((double *)a.values)[i] = z;
@@ -746,10 +807,21 @@ static const arr *find_gathered(const gathered *g, uint32_t n, uint32_t field_id
   return NULL;
 }
 
+static int32_t eval_simplified(const orc_table *t, const llkv_expr_token *e, uint32_t n_tok,
+                               const gathered *g, uint32_t n_g, uint64_t len, arr *out);
 static int32_t eval_program(const orc_table *t, const llkv_expr_token *e, uint32_t n_tok,
                             const gathered *g, uint32_t n_g, uint64_t len, arr *out) {
+  llkv_expr_token *s = xmalloc((n_tok ? n_tok : 1) * sizeof *s);
+  uint32_t m = 0;
+  int32_t rc = simplify_tokens(e, n_tok, s, &m);
+  if (rc == LLKV_OK) rc = eval_simplified(t, s, m, g, n_g, len, out);
+  free(s);
+  return rc;
+}
+static int32_t eval_simplified(const orc_table *t, const llkv_expr_token *e, uint32_t n_tok,
+                               const gathered *g, uint32_t n_g, uint64_t len, arr *out) {
   int has_div, rc;
-  int32_t target = infer_expr_type(t, e, n_tok, &has_div, &rc);
+  int32_t target = infer_simplified_type(t, e, n_tok, &has_div, &rc);
   if (rc) return rc;
   if (target != LLKV_DT_FLOAT64) target = target == LLKV_DT_NULL ? LLKV_DT_NULL : LLKV_DT_INT64;
   if (target == LLKV_DT_NULL) return fail(LLKV_UNSUPPORTED, "non-numeric computed projection");

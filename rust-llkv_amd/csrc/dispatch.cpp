@@ -3,6 +3,7 @@
 //   worker threads    configured_thread_count / with_thread_pool   llkv-threading/src/lib.rs:13-31,75-82
 // No device is needed for either.
 #include "engine.hpp"
+#include "plan.hpp"
 
 #include <sched.h>
 
@@ -68,6 +69,9 @@ using namespace llkv;
 extern "C" {
 
 uint32_t llkv_hip_max_threads(void) { return host_thread_limit(); }
+
+void llkv_hip_set_exact_f64_sums(int32_t on) { plan_set_exact_f64_sums(on != 0); }
+int32_t llkv_hip_exact_f64_sums(void) { return plan_exact_f64_sums() ? 1 : 0; }
 
 // The if-chain of execute_select_with_filter, branch for branch; then: does the GPU path have an entry point for
 // that route and this shape?

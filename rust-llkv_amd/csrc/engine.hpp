@@ -85,6 +85,9 @@ struct Table {
   uint64_t dev_rows = 0;
   std::map<uint32_t, DeviceColumn> cols;
   std::map<uint32_t, TileSet> tilesets;
+  // Row ids that are not the positions 0 … n − 1 (llkv_hip_table_set_row_ids): the id of every local row, in the row layout of
+  // the column images; nullptr = dense ids.  Everything inside works on positions; the calls that REPORT row ids translate.
+  uint64_t *d_row_ids = nullptr;
   std::mutex mu;
   ~Table();
 };

@@ -278,7 +278,13 @@ template <class L, class R> using Mul = Bin<B_MUL, L, R>;
 // overflows), IEEE for floats.  The operands arrive coerced to their common type.
 template <class L, class R, int EXACT_NAN = 0> struct Div {
   using Type = typename L::Type;
-  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & (R::eval(c, j) != 0); }
+  // "zero" is what arrow's `eq` says equals the cast 0: for floats that compare is totalOrder, so +0.0 only — a −0.0
+  // divisor is divided by (∓inf, NaN for 0 / −0.0)
+  static __device__ __forceinline__ bool nonzero(typename Type::T b) {
+    if constexpr (Type::is_float) return __double_as_longlong(b) != 0;
+    else return b != 0;
+  }
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & nonzero(R::eval(c, j)); }
   static __device__ __forceinline__ typename Type::T eval(Ctx &c, int j) {
     const auto a = L::eval(c, j);
     const auto b = R::eval(c, j);
@@ -527,6 +533,19 @@ template <class E, class S> struct SumF64Q {
   static constexpr int N = 1;
   static constexpr int op(int) { return OP_ADD_I64; }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)__double2ll_rn((double)E::eval(c, j) * S::eval(c, j)); }
+};
+// The exact form for the register / per-thread-column plans (planning option llkv_hip_set_exact_f64_sums): the grid is the
+// ulp of the smallest non-zero |x| the statistics allow, so x · 2^−e IS an integer (below 2^62, the lowering checks) and
+// the two lanes — its low 32 bits, the rest — add without overflow below 2^31 rows: the finalize step rounds the exact
+// sum once.
+template <class E, class S> struct SumF64Q2 {
+  static constexpr int N = 2;
+  static constexpr int op(int) { return OP_ADD_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    const long long q = __double2ll_rn((double)E::eval(c, j) * S::eval(c, j));
+    o[0] = (uint64_t)q & 0xFFFFFFFFull;
+    o[1] = (uint64_t)(q >> 32);
+  }
 };
 // DISTINCT forms inside GROUP BY (sort-based route: the argument column is the least significant sort key, so equal
 // values of a group are neighbours and group_reduce_body marks the first of each run): every group runs the reference's
@@ -871,6 +890,9 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
 // acc[slot][tid], slot = gid * K + k.  Every thread only ever touches its own column, so the DS
 // read-modify-write instructions are uncontended, execute in program order and the result is
 // deterministic; a row updates K slots of ITS group — no per-group masking, no accumulator VGPRs.
+// (Measured against a plain ds_read_b64 + VALU op + ds_write_b64 — the slot is private, no atomicity is needed: Q1 SF10
+// 0.377 → 0.391 ms, the 12-lane state 0.333 → 0.523 ms; the compiler has to order every row's reads behind the previous
+// row's writes, the atomics carry no such dependency.  profiles/r03/lds_rmw_experiment.txt)
 template <int OP> __device__ __forceinline__ void lds_accumulate(uint64_t *slot, uint64_t x) {
   if constexpr (OP == OP_ADD_F64)
     (void)__hip_atomic_fetch_add(reinterpret_cast<double *>(slot), __longlong_as_double((long long)x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -272,6 +272,8 @@ int run_join(const Table *left, const Table *right, const llkv_join_key *keys, u
   const int jt = jp.jt;
   if ((rc = ensure_device())) return rc;
   if (!left || !right || !on_batch) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (left->d_row_ids || right->d_row_ids)
+    return set_error(LLKV_UNSUPPORTED, "index pairs over a table whose row ids are not its positions (llkv_hip_join_stream_batches takes it)");
   if (n_keys == 0) {
     // Empty join keys = Cartesian product (cross_product_stream, llkv-join/src/hash_join.rs:1500-1599): every
     // 65 536-row scan window of the left against every window of the right, left-major inside a pair of windows;

@@ -1539,6 +1539,15 @@ hipError_t hj_launch_gather_u64(const uint64_t *in, const uint32_t *perm, uint64
   hipLaunchKernelGGL(hj_gather_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, perm, n, out);
   return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void hj_gather_u64_by_row_kernel(const uint64_t *in, const uint64_t *idx, uint64_t n, uint64_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+hipError_t hj_launch_gather_u64_by_row(const uint64_t *in, const uint64_t *idx, uint64_t n, uint64_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_gather_u64_by_row_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, idx, n, out);
+  return hipGetLastError();
+}
 __global__ __launch_bounds__(256) void hj_xor_u64_kernel(uint64_t *keys, uint64_t n, uint64_t mask) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) keys[i] ^= mask;

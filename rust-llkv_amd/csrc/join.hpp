@@ -314,6 +314,8 @@ hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_in
 
 // ---- ordered scans (stream.cpp) -----------------------------------------------------------------------------
 hipError_t hj_launch_gather_u64(const uint64_t *in, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t s);
+// out[i] = in[idx[i]] (64-bit indices: device row → row id of a table whose ids are not its positions)
+hipError_t hj_launch_gather_u64_by_row(const uint64_t *in, const uint64_t *idx, uint64_t n, uint64_t *out, hipStream_t s);
 hipError_t hj_launch_xor_u64(uint64_t *keys, uint64_t n, uint64_t mask, hipStream_t s);
 hipError_t hj_launch_xor_u32(uint32_t *keys, uint64_t n, uint32_t mask, hipStream_t s);
 

@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -16,6 +17,7 @@ typedef unsigned __int128 u128;
 static constexpr int kMaxColsHost = 16;
 static constexpr int kMaxLitsHost = 24; // = kMaxLits (scan_params.h)
 static constexpr int kMaxKeysHost = 4;
+bool plan_exact_f64_sums();
 static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
 // shared-image route: one image [lane][group] of 8-byte slots per workgroup; 150 KiB of the CU's 160 KiB of LDS
 static constexpr uint32_t kMaxImageGroups = 1u << 16;
@@ -214,6 +216,11 @@ struct Lowering {
   std::string nan_flag(bool is_float) const { return exact_nan && is_float ? ",1" : ""; }
   // shared-image plans: f64 sums as exact two-level pairs (SumF64X), which need a bound on |argument|
   bool exact_f64 = false;
+  // planning option (plan_set_exact_f64_sums): every f64 SUM / AVG / TOTAL is the correctly rounded EXACT sum of its rows'
+  // values, on every route — the last grid sits at the ulp of the smallest non-zero |argument| the statistics allow, so
+  // no row drops a bit
+  bool strict_exact = false;
+  bool image_plan = false;
   bool whole_table_image = false; // partitioned route: one LDS image may receive every row of the table
   uint64_t table_rows = 0; // rows of the table the plan scans (the N of the exact sums)
   bool allow_dict_num = true; // the kernels of this plan see ScanParams::dict_num (not the sort route's reduce kernel)
@@ -297,7 +304,7 @@ struct Lowering {
   // C(j) = 1.5·2^52·u(j).  As many levels (2 or 3) as it takes for the last grid to resolve the smallest non-zero
   // value to 2^-30 of itself: what a row drops is then ≤ 2^-31 of its own magnitude, so a group's sum is within
   // 5e-10 of Σ|v| — inside the contract whatever the group holds.  0 levels: no such choice (the caller's route).
-  int exact_sum_constants(double absmax, double nzmin, uint64_t rows, double c[3]) {
+  int exact_sum_constants(double absmax, double nzmin, uint64_t rows, double c[4]) {
     if (!(absmax >= 0.0) || !std::isfinite(absmax)) return 0;
     if (absmax == 0.0) { absmax = 1.0; nzmin = 1.0; } // the argument is always zero
     if (!(nzmin > 0.0)) return 0;
@@ -310,10 +317,11 @@ struct Lowering {
     if (b < -900 || b + L > 1000 || L > 45) return 0;
     int nz_ex;
     (void)std::frexp(nzmin, &nz_ex); // nzmin ≥ 2^(nz_ex − 1)
-    for (int levels = 2; levels <= 3; ++levels) {
+    const int keep = strict_exact ? 52 : 30; // bits of the smallest non-zero value the last grid resolves (52: all of them)
+    for (int levels = 2; levels <= (strict_exact ? 4 : 3); ++levels) {
       const int e_last = b + L - 52 + (levels - 1) * (L - 53); // log2 of the last grid
       if (e_last < -1000) return 0;
-      if (e_last <= nz_ex - 1 - 30) {
+      if (e_last <= nz_ex - 1 - keep) {
         for (int j = 0; j < levels; ++j) c[j] = std::ldexp(1.5, b + L + j * (L - 53));
         return levels;
       }
@@ -334,11 +342,28 @@ struct Lowering {
     const double m = std::frexp(absmax, &ex);
     const int b = m == 0.5 ? ex - 1 : ex;
     (void)std::frexp(nzmin, &nz_ex);
-    const int e = nz_ex - 1 - 30;
+    const int e = nz_ex - 1 - (strict_exact ? 52 : 30);
     const uint64_t image_rows = whole_table_image ? rows : rows / 128 + 16384; // (a partition's image may see every row)
     int lr = 1;
     while (lr < 63 && ((uint64_t)1 << lr) < image_rows) ++lr;
     if (b - e + lr > 61 || e < -900 || e > 900) return false;
+    *e_out = e;
+    return true;
+  }
+  // SumF64Q2 (register / per-thread-column plans under the exact-sum option): the row's value as an integer count of steps
+  // 2^e, e = the ulp of the smallest non-zero |v| — exact, since every value is a multiple of it — split by the kernel
+  // into its low 32 bits and the rest: two ADD_I64 lanes that cannot overflow below 2^31 rows.  Needs |v| / 2^e < 2^62.
+  bool exact_fixed_point(double absmax, double nzmin, uint64_t rows, int *e_out) {
+    if (!(absmax >= 0.0) || !std::isfinite(absmax) || rows >= (1ull << 31)) return false;
+    if (absmax == 0.0) { absmax = 1.0; nzmin = 1.0; }
+    if (!(nzmin > 0.0)) return false;
+    absmax *= 1.0000001;
+    int ex, nz_ex;
+    const double m = std::frexp(absmax, &ex);
+    const int b = m == 0.5 ? ex - 1 : ex;
+    (void)std::frexp(nzmin, &nz_ex);
+    const int e = nz_ex - 1 - 52;
+    if (b - e > 62 || e < -900 || e > 900) return false;
     *e_out = e;
     return true;
   }
@@ -889,7 +914,65 @@ struct Lowering {
 
   // Computed projection, fast numeric path: final type first, then every column cast to
   // it and every literal broadcast in it (llkv-compute/src/fast_numeric.rs:69-121).
-  int expr_fast(const llkv_expr_token *e, uint32_t n, std::string *node, bool *is_f64) {
+  // ScalarEvaluator::simplify (llkv-compute/src/eval.rs:761-791), which the scan applies to every computed projection
+  // before anything looks at it (llkv-scan/src/execute.rs:91): literal ⊕ literal folds bottom-up through
+  // fold_binary_literals (:1010-1031) = compute_binary over two one-element arrays (Int128 literal → Int64 by `as i64`,
+  // Float64 → Float64; kernels.rs:99-177) — checked integer arithmetic, a zero divisor nullified first (so x / 0 is the
+  // NULL literal; x / −0.0 is not, the float compare is totalOrder), IEEE floats, a NULL side → NULL.  A fold that
+  // errors (integer overflow, x % 0) leaves the node as it was: such a plan is handed back.
+  int fold_constants(const llkv_expr_token *e, uint32_t n, std::vector<llkv_expr_token> *out) {
+    out->clear();
+    auto is_num = [](const llkv_expr_token &t) {
+      return t.kind == LLKV_TOK_LITERAL && (t.literal.tag == LLKV_LIT_INT128 || t.literal.tag == LLKV_LIT_FLOAT64 || t.literal.tag == LLKV_LIT_NULL);
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+      const size_t m = out->size();
+      if (!(e[i].kind == LLKV_TOK_BINARY && m >= 2 && is_num((*out)[m - 1]) && is_num((*out)[m - 2]))) { out->push_back(e[i]); continue; }
+      const llkv_literal &a = (*out)[m - 2].literal, &b = (*out)[m - 1].literal;
+      llkv_expr_token r = (*out)[m - 2];
+      r.literal = llkv_literal{};
+      const int op = e[i].binop;
+      if (op < LLKV_BIN_ADD || op > LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "constant sub-expression under this operator");
+      if (a.tag == LLKV_LIT_NULL || b.tag == LLKV_LIT_NULL) r.literal.tag = LLKV_LIT_NULL;
+      else if (a.tag == LLKV_LIT_FLOAT64 || b.tag == LLKV_LIT_FLOAT64) {
+        const double x = a.tag == LLKV_LIT_FLOAT64 ? a.f64 : (double)(int64_t)lit_i128(a), y = b.tag == LLKV_LIT_FLOAT64 ? b.f64 : (double)(int64_t)lit_i128(b);
+        r.literal.tag = LLKV_LIT_FLOAT64;
+        uint64_t ybits;
+        memcpy(&ybits, &y, 8);
+        switch (op) {
+        case LLKV_BIN_ADD: r.literal.f64 = x + y; break;
+        case LLKV_BIN_SUB: r.literal.f64 = x - y; break;
+        case LLKV_BIN_MUL: r.literal.f64 = x * y; break;
+        case LLKV_BIN_DIV: if (ybits == 0) r.literal.tag = LLKV_LIT_NULL; else r.literal.f64 = x / y; break;
+        default: r.literal.f64 = std::fmod(x, y); break;
+        }
+      } else {
+        const int64_t x = (int64_t)lit_i128(a), y = (int64_t)lit_i128(b);
+        int64_t z = 0;
+        bool bad = false, null = false;
+        switch (op) {
+        case LLKV_BIN_ADD: bad = __builtin_add_overflow(x, y, &z); break;
+        case LLKV_BIN_SUB: bad = __builtin_sub_overflow(x, y, &z); break;
+        case LLKV_BIN_MUL: bad = __builtin_mul_overflow(x, y, &z); break;
+        case LLKV_BIN_DIV: if (y == 0) null = true; else if (x == INT64_MIN && y == -1) bad = true; else z = x / y; break;
+        default: if (y == 0) bad = true; else z = y == -1 ? 0 : x % y; break;
+        }
+        if (bad) return fail(LLKV_UNSUPPORTED, "constant sub-expression the reference leaves unfolded (its fold errors)");
+        if (null) r.literal.tag = LLKV_LIT_NULL;
+        else { r.literal.tag = LLKV_LIT_INT128; r.literal.lo = (uint64_t)z; r.literal.hi = z < 0 ? -1 : 0; }
+      }
+      out->pop_back();
+      out->back() = r;
+    }
+    return LLKV_OK;
+  }
+
+  int expr_fast(const llkv_expr_token *e_in, uint32_t n_in, std::string *node, bool *is_f64) {
+    std::vector<llkv_expr_token> folded;
+    int frc = fold_constants(e_in, n_in, &folded);
+    if (frc) return frc;
+    const llkv_expr_token *e = folded.data();
+    const uint32_t n = (uint32_t)folded.size();
     bool any_float = false, any_u64 = false, any_other = false;
     for (uint32_t i = 0; i < n; ++i) {
       if (e[i].kind == LLKV_TOK_COLUMN) {
@@ -916,8 +999,7 @@ struct Lowering {
       }
       if (all_i32 || all_u32) return fail(LLKV_UNSUPPORTED, "32-bit-only integer arithmetic");
     }
-    // ScalarEvaluator::simplify folds literal ⊕ literal in i128 first (eval.rs:761-791)
-    for (uint32_t i = 2; i < n; ++i)
+    for (uint32_t i = 2; i < n; ++i) // (only non-numeric literal pairs are left unfolded)
       if (e[i].kind == LLKV_TOK_BINARY && e[i - 1].kind == LLKV_TOK_LITERAL && e[i - 2].kind == LLKV_TOK_LITERAL) return fail(LLKV_UNSUPPORTED, "constant sub-expression");
     // get_common_type (llkv-compute/src/kernels.rs:179-242): a 64-bit unsigned side with a signed side → Float64
     if (any_u64) {
@@ -1178,13 +1260,18 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     bool no_bound = false;
     auto sum_f64 = [&](const std::string &arg) -> std::pair<std::string, std::vector<uint8_t>> {
       if (!L.exact_f64) return {"SumF64<" + arg + ">", {ADD_F64}};
-      double absmax = 0.0, nzmin = 0.0, c[3];
+      double absmax = 0.0, nzmin = 0.0, c[4];
       int levels = 0;
       const bool bounded = L.expr_bounds(s.expr, s.expr_len, &absmax, &nzmin);
       const uint64_t n_rows = simple_ci ? simple_ci->rows : L.table_rows;
       int e = 0;
       std::string scale_lit;
-      if (bounded && L.bounds_all_finite && !std::getenv("LLKV_HIP_IMAGE_NO_FIXED") && L.fixed_point_grid(absmax, nzmin, n_rows, &e) &&
+      if (!L.image_plan && bounded && L.bounds_all_finite && L.exact_fixed_point(absmax, nzmin, n_rows, &e) && L.lit_f(std::ldexp(1.0, -e), &scale_lit) == 0) {
+        o.fixed_point = true;
+        o.fixed_exp = e;
+        return {"SumF64Q2<" + arg + "," + scale_lit + ">", {ADD_I64, ADD_I64}};
+      }
+      if (L.image_plan && bounded && L.bounds_all_finite && !std::getenv("LLKV_HIP_IMAGE_NO_FIXED") && L.fixed_point_grid(absmax, nzmin, n_rows, &e) &&
           L.lit_f(std::ldexp(1.0, -e), &scale_lit) == 0) { // one integer lane in the image, two in the exchange image
         o.fixed_point = true;
         o.fixed_exp = e;
@@ -1287,12 +1374,16 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       break;
     default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
     }
-    if (no_bound) return L.fail(LLKV_UNSUPPORTED, "the column statistics do not bound an f64 sum argument from above and (where non-zero) from below: no exact, order-free sum for the shared-image GROUP BY");
+    if (no_bound) return L.fail(LLKV_UNSUPPORTED, std::string("the column statistics do not bound an f64 sum argument from above and (where non-zero) from below: no exact, order-free sum for ") + (L.image_plan ? "the shared-image GROUP BY" : "the exact-sum option"));
     p.aggs.push_back(o);
   }
 
   return LLKV_OK;
 }
+
+static std::atomic<bool> g_exact_f64_sums{false};
+void plan_set_exact_f64_sums(bool on) { g_exact_f64_sums.store(on); }
+bool plan_exact_f64_sums() { return g_exact_f64_sums.load(); }
 
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
@@ -1303,7 +1394,9 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   p.grouped = grouped;
   if (image && !grouped) return L.fail(LLKV_INVALID_ARGUMENT, "the shared-image kernel serves GROUP BY plans");
   if (partitioned && !image) return L.fail(LLKV_INVALID_ARGUMENT, "the partitioned route uses the shared-image lowering");
-  L.exact_f64 = image;
+  L.strict_exact = plan_exact_f64_sums();
+  L.image_plan = image;
+  L.exact_f64 = image || L.strict_exact;
   L.whole_table_image = partitioned;
   const uint32_t max_groups = partitioned ? kMaxPartGroups : image ? kMaxImageGroups : kMaxDenseGroups;
   int rc;

@@ -124,6 +124,10 @@ double parse_numeric_or_zero(const std::string &s);
 // `image`: lower for the shared-image GROUP BY kernel (image_scan_body) instead of the per-thread accumulator kernel:
 // up to kMaxImageGroups groups as long as the image fits the LDS, every lane order-free — f64 sums need a bound on
 // |argument| from the column statistics (else LLKV_UNSUPPORTED: the sort-based route takes the query).
+// Planning option: f64 SUM / AVG / TOTAL as the correctly rounded exact sum of the rows' values (llkv_hip_set_exact_f64_sums).
+void plan_set_exact_f64_sums(bool on);
+bool plan_exact_f64_sums();
+
 int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters,
                const llkv_eval_op *ops, uint32_t n_ops, const uint32_t *key_fields, uint32_t n_keys,
                const llkv_aggregate_spec *aggs, uint32_t n_aggs, bool grouped, bool track_first,

@@ -131,6 +131,8 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
     p.aux_out2 = sel->d_dev;
     if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
   }
+  // a table whose row ids are not its positions: the ids the callers report (filter_row_ids, scan windows) are the table's
+  if (t->d_row_ids) HIP_TRY(hj_launch_gather_u64_by_row(t->d_row_ids, sel->d_dev, total, sel->d_ids, stream));
   if (sync) HIP_TRY(hipStreamSynchronize(stream)); // (the scratch blocks released on return are only handed to work on this same stream)
   return LLKV_OK;
 }

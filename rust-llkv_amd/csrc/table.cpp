@@ -23,6 +23,7 @@ Table::~Table() {
     if (kv.second.d_valid) (void)hipFree(kv.second.d_valid);
     if (kv.second.d_hi) (void)hipFree(kv.second.d_hi);
   }
+  if (d_row_ids) (void)hipFree(d_row_ids);
   for (auto &kv : tilesets) {
     if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
     if (kv.second.d_sample) (void)hipFree(kv.second.d_sample);
@@ -271,6 +272,42 @@ static int check_new_column(Table *t, uint32_t field_id, uint32_t n_chunks) {
   if (t->cols.count(field_id)) return set_error(LLKV_INVALID_ARGUMENT, "field " + std::to_string(field_id) + " already staged");
   if (n_chunks != t->n_local_chunks)
     return set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(t->n_local_chunks) + " local chunks, got " + std::to_string(n_chunks));
+  return LLKV_OK;
+}
+
+llkv_status llkv_hip_table_set_row_ids(llkv_hip_table *table, const uint64_t *const *chunk_row_ids, uint32_t n_chunks) {
+  Table *t = reinterpret_cast<Table *>(table);
+  if (!t || (n_chunks && !chunk_row_ids)) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
+  if (n_chunks != t->n_local_chunks)
+    return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "expected " + std::to_string(t->n_local_chunks) + " local chunks, got " + std::to_string(n_chunks));
+  if (t->d_row_ids) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "row ids already set");
+  int rc = ensure_device();
+  if (rc) return (llkv_status)rc;
+  // strictly ascending over the local chunks (positions and ids order alike: scans, windows, first-appearance order and
+  // the joins' probe order all follow the position); dense ids from the table's first position need no translation
+  bool dense = true, have = false;
+  uint64_t prev = 0, at = t->local_logical_start;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    if (rows && !chunk_row_ids[i]) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "chunk row-id pointer is NULL");
+    for (uint64_t r = 0; r < rows; ++r, ++at) {
+      const uint64_t id = chunk_row_ids[i][r];
+      if (have && id <= prev) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "row ids must ascend strictly (chunk " + std::to_string(i) + ", row " + std::to_string(r) + ")");
+      prev = id;
+      have = true;
+      dense &= id == at;
+    }
+  }
+  if (dense) return LLKV_OK;
+  void *d = nullptr;
+  if ((rc = alloc_column(*t, 8, &d))) return (llkv_status)rc;
+  std::vector<StagePiece> pieces;
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
+    if (rows) pieces.push_back({(char *)d + t->chunk_dev_off[i] * 8, chunk_row_ids[i], rows * 8});
+  }
+  if (hipStreamSynchronize(g_ctx.stream) != hipSuccess || (rc = stage_to_device(pieces))) { (void)hipFree(d); return (llkv_status)(rc ? rc : set_error(LLKV_INTERNAL, "staging copy failed")); }
+  t->d_row_ids = static_cast<uint64_t *>(d);
   return LLKV_OK;
 }
 

@@ -194,6 +194,13 @@ def comm_union_strings(local: Sequence[str]) -> List[str]:
         lib().llkv_hip_free(out)
 
 
+def set_exact_f64_sums(on: bool):
+    """llkv_hip_set_exact_f64_sums: queries prepared from now on keep every f64 SUM / AVG / TOTAL exactly."""
+    f = lib().llkv_hip_set_exact_f64_sums
+    f.restype = None
+    f(C.c_int32(1 if on else 0))
+
+
 def max_threads() -> int:
     """configured_thread_count of the reference's pool (llkv-threading/src/lib.rs:22-31) as the library sees it."""
     f = lib().llkv_hip_max_threads
@@ -283,6 +290,13 @@ class HipTable:
         check(lib().llkv_hip_table_append_column(self._h, C.c_uint32(field_id), C.c_int32(dtype), ptrs, C.c_uint32(len(chunks))))
         if valid is not None:
             self.set_column_validity(field_id, valid)
+
+    def set_row_ids(self, row_ids: Union[np.ndarray, Sequence[np.ndarray]]):
+        """The table's row ids where they are not 0 … n − 1 (local rows, strictly ascending); reported ids follow them."""
+        chunks = self._split(row_ids) if isinstance(row_ids, np.ndarray) else list(row_ids)
+        chunks = [np.ascontiguousarray(c, dtype=np.uint64) for c in chunks]
+        ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
+        check(lib().llkv_hip_table_set_row_ids(self._h, ptrs, C.c_uint32(len(chunks))))
 
     def append_decimal128_column(self, field_id: int, precision: int, scale: int, values, valid=None):
         """Stage a Decimal128(precision, scale) column from Python ints (raw values) or an (n, 2) uint64 buffer."""

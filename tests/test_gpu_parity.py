@@ -610,6 +610,76 @@ def test_scan_stream_and_row_ids_match_oracle(rt, orc, abi, chunks):
                     assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (x, y)
 
 
+@pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5], [65536, 70000]])
+def test_row_ids_with_gaps_are_reported_as_the_tables_ids(rt, orc, abi, chunks):
+    """A table whose row ids are not 0 … n − 1 (rows removed before it was staged; the row-id shadow column of
+    llkv-column-map/src/store/descriptor.rs, gathered over by store/gather.rs:764-884): positions order as the ids do, so
+    everything but the REPORTED ids is what a dense table gives, and the reported ids are ids[position]."""
+    rng = np.random.default_rng(sum(chunks) + 3)
+    n = sum(chunks)
+    i64, f64, i32, big, s = random_columns(rng, n)
+    ids = np.cumsum(rng.integers(1, 5, size=n)).astype(np.uint64) + np.uint64(2**40 if len(chunks) == 1 else 0)
+    cols = [(1, abi.DT_INT64, i64), (2, abi.DT_FLOAT64, f64), (3, abi.DT_INT32, i32), (5, abi.DT_UTF8, s)]
+    ht, ot = stage_both(rt, orc, abi, cols, chunks)
+    ht.set_row_ids(ids)
+    F, O, E, col, A = abi.Filter, abi.Operator, abi.Expr, abi.col, abi.AggregateSpec
+    preds = [None, [F(1, O.LessThan(0))], E.any_of([F(3, O.In([1, 2, 3])), E.not_(F(2, O.GreaterThan(-500.0)))]), [F(1, O.Equals(2**40))]]
+    for p in preds:
+        want_pos = orc.filter_row_ids(ot, p)
+        got_ids = rt.filter_row_ids(ht, p)
+        assert got_ids.dtype == np.uint64 and np.array_equal(got_ids, ids[want_pos])
+        projs = [1, 5, col(2) * 2.0 + col(1)]
+        got = rt.scan_stream(ht, projs, p, include_row_ids=True)
+        want = orc.scan_stream(ot, projs, p, include_nulls=True, include_row_ids=True)
+        assert [len(b[1]) for b in got] == [len(b[1]) for b in want]
+        for (gc, gr), (wc, wr) in zip(got, want):
+            assert np.array_equal(np.asarray(gr, dtype=np.uint64), ids[np.asarray(wr, dtype=np.int64)])
+            for a, b in zip(gc, wc):
+                assert len(a) == len(b)
+                assert all((x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)) for x, y in zip(a, b))
+        # what reports no ids is untouched
+        assert_values(rt.aggregate(ht, p, [A.count_star(), A.sum(1), A.min(1)]), orc.aggregate(ot, p, [A.count_star(), A.sum(1), A.min(1)]))
+    # dense ids from 0 keep nothing; ids that do not ascend are refused
+    hd = rt.HipTable(1, chunks)
+    hd.append_column(1, abi.DT_INT64, i64)
+    hd.set_row_ids(np.arange(n, dtype=np.uint64))
+    assert np.array_equal(rt.filter_row_ids(hd, [F(1, O.LessThan(0))]), orc.filter_row_ids(ot, [F(1, O.LessThan(0))]))
+    if n > 1:
+        bad = ids.copy()
+        bad[n // 2] = bad[n // 2 - 1]
+        hb = rt.HipTable(1, chunks)
+        hb.append_column(1, abi.DT_INT64, i64)
+        with pytest.raises(abi.LlkvError) as e:
+            hb.set_row_ids(bad)
+        assert e.value.kind == "InvalidArgumentError" and "ascend" in e.value.message
+
+
+def test_joins_over_tables_whose_row_ids_have_gaps(rt, orc, abi):
+    """The joined RecordBatches carry no row ids: identical to the dense table's.  The index-pair form reports ids and
+    cuts by position — handed back rather than mixed."""
+    rng = np.random.default_rng(77)
+    nl, nr = 30000, 9000
+    lk = rng.integers(0, 12000, size=nl).astype(np.int64)
+    rk = rng.permutation(12000)[:nr].astype(np.int64)
+    lv = rng.integers(-1000, 1000, size=nl).astype(np.int64)
+    rv = rng.normal(size=nr)
+    hl, ol = stage_both(rt, orc, abi, [(1, abi.DT_INT64, lk), (2, abi.DT_INT64, lv)], [nl])
+    hr, orr = stage_both(rt, orc, abi, [(1, abi.DT_INT64, rk), (2, abi.DT_FLOAT64, rv)], [nr])
+    hl.set_row_ids(np.cumsum(rng.integers(1, 4, size=nl)).astype(np.uint64))
+    hr.set_row_ids(np.cumsum(rng.integers(1, 4, size=nr)).astype(np.uint64))
+    lc, rc = [(1, "k"), (2, "v")], [(1, "k"), (2, "w")]
+    for jt in (abi.JOIN_INNER, abi.JOIN_LEFT):
+        got = rt.join_stream_batches(hl, hr, [(1, 1)], lc, rc, join_type=jt, batch_size=4096)
+        want = orc.hash_join_batches(ol, orr, [(1, 1)], lc, rc, join_type=jt, batch_size=4096)
+        assert len(got) == len(want)
+        for (gn, gc), (wn, wc) in zip(got, want):
+            assert gn == wn and [len(c) for c in gc] == [len(c) for c in wc]
+            assert gc == wc
+    with pytest.raises(abi.LlkvError) as e:
+        rt.join_stream(hl, hr, [(1, 1)])
+    assert e.value.kind == "Unsupported" and "row ids" in e.value.message
+
+
 @pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])
 def test_expression_compares_match_oracle(rt, orc, abi, chunks):
     """Expr::Compare fused into the scan (Cmp node): every common-type class of get_common_type, totalOrder on
@@ -1050,6 +1120,96 @@ def test_scan_stream_fails_at_the_window_whose_projection_failed(rt, abi):
     ht2.append_column(2, abi.DT_INT64, b)
     rt.scan_stream(ht2, [1, abi.col(1) % abi.col(2)], None, consume=lambda bv: seen.append(int(bv.num_rows)))
     assert seen == [65536] * 4 + [n - 4 * 65536]
+
+
+@pytest.mark.parametrize("chunks", [[1000], [65536, 65536, 30000], [300000, 300000, 300000, 123457]])
+def test_exact_f64_sums_option_gives_the_correctly_rounded_sum(rt, orc, abi, chunks):
+    """llkv_hip_set_exact_f64_sums: SUM / AVG / TOTAL over f64 arguments are the exact sum of the rows' values, rounded
+    once — math.fsum of the same per-row doubles, bit for bit, ungrouped (register plans) and grouped (per-thread LDS
+    columns), whatever the geometry; and within the contract's 1e-9 of the oracle's sequential chain."""
+    rng = np.random.default_rng(len(chunks) * 7 + 1)
+    n = sum(chunks)
+    price = np.round(rng.uniform(900.0, 105000.0, size=n), 2)          # cents: not dyadic
+    disc = rng.integers(0, 11, size=n).astype(np.float64) / 100.0
+    tax = rng.integers(0, 9, size=n).astype(np.float64) / 100.0
+    qty = rng.integers(1, 51, size=n).astype(np.int64)
+    flag = np.array([ord("A"), ord("N"), ord("R")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    valid = rng.random(n) > 0.05
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_FLOAT64, price), (2, abi.DT_FLOAT64, disc), (3, abi.DT_FLOAT64, tax), (4, abi.DT_INT64, qty),
+                                       (5, abi.DT_UTF8, flag), (6, abi.DT_FLOAT64, price, valid)], chunks)
+    A, F, O, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col
+    dp = col(1) * (1 - col(2))
+    ch = col(1) * (1 - col(2)) * (1 + col(3))
+    aggs = [A.count_star(), A.sum(1), A.sum(dp), A.sum(ch), A.avg(2), A.total(1), A.sum(6), A.avg(6), A.sum(4)]
+    v_dp, v_ch = price * (1 - disc), price * (1 - disc) * (1 + tax)
+    pred = [F(4, O.LessThan(40))]
+    keep = qty < 40
+
+    def expect(m):
+        k = int(m.sum())
+        nv = int((m & valid).sum())
+        return [k, math.fsum(price[m]), math.fsum(v_dp[m]), math.fsum(v_ch[m]), math.fsum(disc[m]) / k, math.fsum(price[m]), math.fsum(price[m & valid]),
+                math.fsum(price[m & valid]) / nv, int(qty[m].sum())]
+
+    rt.set_exact_f64_sums(True)
+    try:
+        got = rt.aggregate(ht, pred, aggs)
+        assert [g.value for g in got] == expect(keep)
+        assert_values(got, orc.aggregate(ot, pred, aggs), "exact vs chain")
+        rows = rt.groupby(ht, pred, [5], aggs, True)
+        want = orc.groupby(ot, pred, [5], aggs, True)
+        assert [r.keys[0].value for r in rows] == ["A", "N", "R"][: len(rows)]
+        for r, w, code in zip(rows, want, (ord("A"), ord("N"), ord("R"))):
+            assert [v.value for v in r.values] == expect(keep & (flag == code)), chr(code)
+            assert_values(r.values, w.values, "exact vs chain, grouped")
+        q = rt.PreparedQuery(ht, pred, aggs, [5], True)
+        assert "SumF64Q2<" in q.kernel_signature
+        q.close()
+        # an argument the statistics cannot bound away from zero has no exact grid: handed back while the option is on
+        with pytest.raises(abi.LlkvError) as e:
+            rt.aggregate(ht, None, [A.sum(col(1) - col(6))])
+        assert e.value.kind == "Unsupported"
+    finally:
+        rt.set_exact_f64_sums(False)
+    q = rt.PreparedQuery(ht, pred, aggs, [5], True)
+    assert "SumF64Q2<" not in q.kernel_signature
+    q.close()
+
+
+@pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5]])
+def test_constant_subexpressions_fold_like_the_reference(rt, orc, abi, chunks):
+    """ScalarEvaluator::simplify (llkv-compute/src/eval.rs:761-791) on the host, before the plan is typed: literal ⊕ literal
+    folds through compute_binary's rules; a fold that errors is a plan neither side takes; x / −0.0 is IEEE."""
+    rng = np.random.default_rng(5 + len(chunks))
+    n = sum(chunks)
+    a = rng.integers(-1000, 1000, size=n).astype(np.int64)
+    f = rng.integers(-40, 40, size=n).astype(np.float64) / 4
+    f[rng.random(n) < 0.05] = -0.0
+    f[rng.random(n) < 0.05] = 0.0
+    va = rng.random(n) > 0.1
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, a, va), (2, abi.DT_FLOAT64, f)], chunks)
+    L, col, A, E = abi.ScalarExpr.literal, abi.col, abi.AggregateSpec, abi.Expr
+    exprs = [col(1) * (L(2) + 3), col(1) + (L(7) / 2), col(1) * (L(1) / 4), col(2) * (L(1) / 4.0), (L(10) % 4) + col(1),
+             (L(2) * 3 + 1) * col(2) - (L(1.5) - 0.25), (L(6) / 3) / col(1), col(1) - (L(-7) % 3), (L(1) + 1) * (L(2.5) * 2) + col(1),
+             col(1) / col(2), (L(3) - 2) / col(2)]
+    for part in (exprs[:6], exprs[6:]):  # (a scan takes up to 8 projections)
+        got = rt.scan_stream(ht, [1] + part, None, include_nulls=True, include_row_ids=True)
+        want = orc.scan_stream(ot, [1] + part, None, include_nulls=True, include_row_ids=True)
+        assert [b[1] for b in got] == [b[1] for b in want]
+        for (gc, _), (wc, _) in zip(got, want):
+            for k, (x, y) in enumerate(zip(gc, wc)):
+                assert len(x) == len(y)
+                bad = [(p, q) for p, q in zip(x, y) if not ((p == q and type(p) is type(q)) or (isinstance(p, float) and isinstance(q, float) and math.isnan(p) and math.isnan(q)))]
+                assert not bad, (k, bad[:3])
+    aggs = [A.count_star()] + [A.sum(e) for e in exprs[:9]] + [A.count(exprs[9]), A.count(exprs[10]), A.min(exprs[10]), A.max(exprs[9])]
+    for pred in (None, E.compare(col(1) * (L(2) + 3), abi.CMP_GT, L(10) * 10), E.compare((L(3) - 2) / col(2), abi.CMP_LT, 0.0)):
+        assert np.array_equal(rt.filter_row_ids(ht, pred), orc.filter_row_ids(ot, pred))
+        assert_values(rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs), "folded")
+    for bad in (col(1) + (L(2**62) + 2**62), col(1) + (L(5) % 0), col(1) * (L(-2**63) / -1)):
+        for m, t in ((rt, ht), (orc, ot)):
+            with pytest.raises(abi.LlkvError) as e:
+                m.aggregate(t, None, [A.sum(bad)])
+            assert e.value.kind == "Unsupported"
 
 
 @pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])

@@ -284,6 +284,41 @@ def test_aggregate_expression_div_by_zero_is_null(orc, abi):
     assert [v.value for v in rows[0].values] == [2, 1, 9.25]
 
 
+def test_constant_subexpressions_fold_before_the_projection_is_typed(orc, abi):
+    """ScalarEvaluator::simplify (llkv-compute/src/eval.rs:761-791, applied by llkv-scan/src/execute.rs:91): literal ⊕ literal
+    is one compute_binary call over one-element arrays — integers checked and truncating, x / 0 the NULL literal, floats
+    IEEE — and only then does the projection pick its route: `col * (1 / 4)` has no Divide left (fast path, times 0).
+    Expected values derived by hand from those rules."""
+    t = orc.OracleTable(3)
+    t.add(1, abi.DT_INT64, np.array([10, -3, 7], dtype=np.int64))
+    t.add(2, abi.DT_FLOAT64, np.array([0.5, -2.0, 4.0]))
+    L, col = abi.ScalarExpr.literal, abi.col
+    projs = [col(1) * (L(2) + 3), col(1) + (L(7) / 2), col(1) * (L(1) / 4), col(2) * (L(1) / 4.0), (L(10) % 4) + col(1),
+             (L(2) * 3 + 1) * col(2) - (L(1.5) - 0.25), (L(6) / 3) / col(1), col(1) + (L(-7) / 2), col(1) - (L(-7) % 3)]
+    (cols, _), = orc.scan_stream(t, projs, None)
+    assert cols == [[50, -15, 35], [13, 0, 10], [0, 0, 0], [0.125, -0.5, 1.0], [12, -1, 9],
+                    [2.25, -15.25, 26.75], [0, 0, 0], [7, -6, 4], [11, -2, 8]]
+    assert all(isinstance(v, int) for c in (cols[0], cols[1], cols[2], cols[4], cols[6]) for v in c)
+    # a fold that errors stays unfolded in the reference (fold_binary_literals → None): neither side takes such plans
+    for bad in (col(1) + (L(2**62) + 2**62), col(1) + (L(5) % 0), col(1) * (L(-2**63) / -1)):
+        with pytest.raises(abi.LlkvError) as e:
+            orc.scan_stream(t, [bad], None)
+        assert e.value.kind == "Unsupported"
+
+
+def test_a_negative_zero_divisor_is_not_the_zero_that_becomes_null(orc, abi):
+    """compute_binary's Divide nullifies the rows where `eq(rhs, cast(0))` (llkv-compute/src/kernels.rs:121-135); arrow-ord's
+    `eq` (57.x, Cargo.lock) compares floats by totalOrder, so only +0.0 is nullified and x / −0.0 is IEEE: ∓inf, NaN for 0."""
+    t = orc.OracleTable(4)
+    t.add(1, abi.DT_FLOAT64, np.array([1.0, 1.0, -1.0, 0.0]))
+    t.add(2, abi.DT_FLOAT64, np.array([0.0, -0.0, -0.0, -0.0]))
+    (cols, _), = orc.scan_stream(t, [abi.col(1) / abi.col(2)], None, include_nulls=True)
+    assert cols[0][0] is None and cols[0][1] == float("-inf") and cols[0][2] == float("inf") and np.isnan(cols[0][3])
+    t.add(3, abi.DT_UTF8, ["g"] * 4)
+    rows = orc.groupby(t, None, [3], [abi.AggregateSpec.count(abi.col(1) / abi.col(2))])  # the PlanValue interpreter compares with ==: NULL for both zeros
+    assert [r.values[0].value for r in rows] == [0]
+
+
 def test_q6_against_numpy(orc, abi, tpch):
     """Independent cross-check of the restatement (pyarrow/numpy are NOT the reference)."""
     n = tpch.LINEITEM_ROWS["sf0.01"]
