@@ -1398,7 +1398,55 @@ typedef struct acc {
   uint64_t *seen;
   uint64_t n_seen, cap_seen;
   int32_t distinct_rc;
+  /* … and for Str / Bool / Date / Decimal keys (DistinctKey :252-331) the set itself, in order of first insertion: the key's
+   * bytes, its numeric image (what `*sum += v` adds for a new key, :904-921) or raw i128 */
+  int32_t distinct_dtype;
+  struct dkey { char *bytes; uint32_t len; double num; __int128 raw; } *keys;
+  uint64_t n_keys, cap_keys;
+  uint64_t *key_slots; /* open addressing over `keys`: index + 1, 0 = empty */
+  uint64_t n_slots;
 } acc;
+
+static void acc_free_distinct(acc *a) {
+  free(a->seen);
+  for (uint64_t i = 0; i < a->n_keys; ++i) free(a->keys[i].bytes);
+  free(a->keys);
+  free(a->key_slots);
+  a->seen = NULL; a->keys = NULL; a->key_slots = NULL; a->n_keys = a->cap_keys = a->n_slots = 0;
+}
+static uint64_t bytes_hash(const char *b, uint32_t n) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (uint32_t i = 0; i < n; ++i) h = (h ^ (unsigned char)b[i]) * 0x100000001b3ull;
+  return h;
+}
+/* seen.insert(key): 1 when the key is new (then *at = its position in insertion order) */
+static int acc_insert_key(acc *a, const char *bytes, uint32_t len, uint64_t *at) {
+  if ((a->n_keys + 1) * 2 > a->n_slots) {
+    const uint64_t ns = a->n_slots ? a->n_slots * 2 : 1024;
+    free(a->key_slots);
+    a->key_slots = xcalloc(ns, sizeof(uint64_t));
+    a->n_slots = ns;
+    for (uint64_t i = 0; i < a->n_keys; ++i) {
+      uint64_t p = bytes_hash(a->keys[i].bytes, a->keys[i].len) & (ns - 1);
+      while (a->key_slots[p]) p = (p + 1) & (ns - 1);
+      a->key_slots[p] = i + 1;
+    }
+  }
+  uint64_t p = bytes_hash(bytes, len) & (a->n_slots - 1);
+  while (a->key_slots[p]) {
+    const struct dkey *k = &a->keys[a->key_slots[p] - 1];
+    if (k->len == len && memcmp(k->bytes, bytes, len) == 0) return 0;
+    p = (p + 1) & (a->n_slots - 1);
+  }
+  if (a->n_keys == a->cap_keys) { a->cap_keys = a->cap_keys ? a->cap_keys * 2 : 256; a->keys = xrealloc(a->keys, a->cap_keys * sizeof *a->keys); }
+  struct dkey *k = &a->keys[a->n_keys];
+  k->bytes = xmalloc(len ? len : 1);
+  memcpy(k->bytes, bytes, len);
+  k->len = len; k->num = 0.0; k->raw = 0;
+  a->key_slots[p] = a->n_keys + 1;
+  *at = a->n_keys++;
+  return 1;
+}
 
 /* `str::trim` + `<f64 as FromStr>::from_str` (Rust core, published grammar): Unicode White_Space is trimmed; a float is
  * Sign? ( "inf" | "infinity" | "nan" | Number ) in any case, Number = ( Digit+ | Digit+ "." Digit* | Digit* "." Digit+ )
@@ -1492,7 +1540,11 @@ static int32_t acc_new(int32_t agg_kind, int32_t input_dtype, acc *out) {
 
 static int32_t acc_new_distinct(int32_t agg_kind, int32_t input_dtype, acc *out) {
   memset(out, 0, sizeof *out);
-  if (input_dtype != LLKV_DT_INT64 && input_dtype != LLKV_DT_FLOAT64) return fail(LLKV_UNSUPPORTED, "DISTINCT aggregate over %s", dtype_name(input_dtype));
+  /* DistinctKey::from_array :261-331: Int64, Float64, Utf8, Boolean, Date32, Decimal128 */
+  if (input_dtype != LLKV_DT_INT64 && input_dtype != LLKV_DT_FLOAT64 && input_dtype != LLKV_DT_UTF8 && input_dtype != LLKV_DT_BOOLEAN &&
+      input_dtype != LLKV_DT_DATE32 && input_dtype != LLKV_DT_DECIMAL128)
+    return fail(LLKV_INVALID_ARGUMENT, "COUNT(DISTINCT) is not supported for column type %s", dtype_name(input_dtype));
+  out->distinct_dtype = input_dtype;
   if (agg_kind != LLKV_AGG_COUNT && agg_kind != LLKV_AGG_SUM && agg_kind != LLKV_AGG_TOTAL && agg_kind != LLKV_AGG_AVG)
     return fail(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind %d", agg_kind);
   out->distinct = 1;
@@ -1516,6 +1568,30 @@ static int idx_cmp(const void *a, const void *b) {
  * :1684-1720 (avg).  Returns the error update() would have raised. */
 static int32_t acc_finalize_distinct(const acc *a, llkv_value *out) {
   memset(out, 0, sizeof *out);
+  if (a->distinct_dtype != LLKV_DT_INT64 && a->distinct_dtype != LLKV_DT_FLOAT64) {
+    const uint64_t m = a->n_keys;
+    if (a->distinct_rc) return a->distinct_rc; /* the error update() raised */
+    if (a->distinct_kind == LLKV_AGG_COUNT) { out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)m; return LLKV_OK; } /* :1502-1510 */
+    if (a->distinct_dtype == LLKV_DT_DECIMAL128) { /* :1583-1612, 1656-1672, 1762-1800 */
+      out->dtype = LLKV_DT_DECIMAL128; out->precision = a->precision; out->scale = a->scale;
+      if (m == 0) { out->is_null = a->distinct_kind != LLKV_AGG_TOTAL; return LLKV_OK; }
+      __int128 v = a->d;
+      if (a->distinct_kind == LLKV_AGG_AVG) { /* half away from zero */
+        const __int128 cnt = (__int128)m;
+        __int128 avg = v / cnt, rem = v % cnt;
+        if ((rem < 0 ? -rem : rem) * 2 >= cnt) avg += v >= 0 ? 1 : -1;
+        v = avg;
+      }
+      out->i64 = (int64_t)(uint64_t)(unsigned __int128)v;
+      out->i64_hi = (int64_t)(v >> 64);
+      return LLKV_OK;
+    }
+    out->dtype = LLKV_DT_FLOAT64; /* Sum / Total / AvgDistinctFloat64 :1544-1565, 1638-1655, 1721-1760 */
+    if (a->distinct_kind == LLKV_AGG_TOTAL) { out->f64 = a->f; return LLKV_OK; }
+    if (m == 0) { out->is_null = 1; return LLKV_OK; }
+    out->f64 = a->distinct_kind == LLKV_AGG_AVG ? a->f / (double)m : a->f;
+    return LLKV_OK;
+  }
   seen_ent *e = xmalloc((a->n_seen ? a->n_seen : 1) * sizeof *e);
   for (uint64_t i = 0; i < a->n_seen; ++i) { e[i].v = a->seen[i]; e[i].idx = i; }
   qsort(e, a->n_seen, sizeof *e, seen_cmp);
@@ -1552,6 +1628,36 @@ static int32_t acc_finalize_distinct(const acc *a, llkv_value *out) {
 
 /* update(&RecordBatch) :759-1477 — strictly sequential, arrival order. */
 static int32_t acc_update(acc *a, const arr *col, uint64_t num_rows) {
+  if (a->distinct && a->distinct_dtype != LLKV_DT_INT64 && a->distinct_dtype != LLKV_DT_FLOAT64) {
+    /* CountDistinctColumn :787-799; Sum / Total / AvgDistinctFloat64 over a non-float column :889-924 (a NEW key adds its
+     * numeric image: Str → array_value_to_numeric, Bool → 1 / 0, Date → the day number); Sum / Total / AvgDistinctDecimal128
+     * :943-967,1089-1112,1260-1284 (i128 checked_add of a new raw value) */
+    if (col->dtype == LLKV_DT_NULL || a->distinct_rc) return LLKV_OK;
+    for (uint64_t i = 0; i < col->n; ++i) {
+      if (!col->valid[i]) continue;
+      uint64_t at;
+      if (col->dtype == LLKV_DT_UTF8) {
+        if (!acc_insert_key(a, col->strings[i], (uint32_t)strlen(col->strings[i]), &at)) continue;
+        a->f += rust_parse_f64_or_zero(col->strings[i]);
+      } else if (col->dtype == LLKV_DT_BOOLEAN) {
+        if (!acc_insert_key(a, (const char *)col->values + i, 1, &at)) continue;
+        a->f += ((const uint8_t *)col->values)[i] ? 1.0 : 0.0;
+      } else if (col->dtype == LLKV_DT_DATE32) {
+        if (!acc_insert_key(a, (const char *)col->values + i * 4, 4, &at)) continue;
+        a->f += (double)((const int32_t *)col->values)[i];
+      } else if (col->dtype == LLKV_DT_DECIMAL128) {
+        if (!acc_insert_key(a, (const char *)col->values + i * 16, 16, &at)) continue;
+        __int128 v;
+        memcpy(&v, (const char *)col->values + i * 16, 16);
+        if (a->distinct_kind != LLKV_AGG_COUNT && __builtin_add_overflow(a->d, v, &a->d))
+          a->distinct_rc = fail(LLKV_INVALID_ARGUMENT, a->distinct_kind == LLKV_AGG_TOTAL ? "Decimal128 total overflow" : "Decimal128 sum overflow");
+      } else {
+        return fail(LLKV_INVALID_ARGUMENT, "COUNT(DISTINCT) is not supported for column type %s", dtype_name(col->dtype));
+      }
+      if (a->distinct_rc) return a->distinct_rc;
+    }
+    return LLKV_OK;
+  }
   if (a->distinct) {
     if (col->dtype == LLKV_DT_NULL) return LLKV_OK;
     for (uint64_t i = 0; i < col->n; ++i) {
@@ -1743,7 +1849,7 @@ int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n
     if (accs[i].distinct) rc = acc_finalize_distinct(&accs[i], &out_values[i]);
     else acc_finalize(&accs[i], &out_values[i]);
   }
-  for (uint32_t i = 0; i < n_aggs; ++i) free(accs[i].seen);
+  for (uint32_t i = 0; i < n_aggs; ++i) acc_free_distinct(&accs[i]);
   free(accs); free(proj_of); free(projs);
   return rc;
 }
@@ -2055,7 +2161,7 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
           free(pv);
         }
         if (rc == LLKV_OK) {
-          if (st.distinct) { rc = acc_finalize_distinct(&st, &vals[(size_t)g * n_aggs + a]); free(st.seen); }
+          if (st.distinct) { rc = acc_finalize_distinct(&st, &vals[(size_t)g * n_aggs + a]); acc_free_distinct(&st); }
           else acc_finalize(&st, &vals[(size_t)g * n_aggs + a]);
         }
       }

@@ -176,8 +176,15 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
           return set_error(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind " + std::to_string(kind));
         if (!aggs[a].expr || !aggs[a].expr_len) return set_error(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
         Query::DistinctAgg &da = q->distinct[a];
-        if ((rc = lower_emit(resolve, filters, n_filters, ops, n_ops, aggs[a].expr, aggs[a].expr_len, &da.plan, &err, /*allow_f64=*/true, &da.is_f64)))
+        if ((rc = lower_emit(resolve, filters, n_filters, ops, n_ops, aggs[a].expr, aggs[a].expr_len, &da.plan, &err, /*allow_f64=*/true, &da.is_f64, nullptr, &da.key_dtype)))
           return set_error(rc, err);
+        if (da.key_dtype == LLKV_DT_UTF8 || da.key_dtype == LLKV_DT_DECIMAL128) {
+          const ColumnInfo *ci = resolve(aggs[a].expr[0].field_id);
+          da.precision = ci->precision; da.scale = ci->scale;
+          if (da.key_dtype == LLKV_DT_UTF8 && kind != LLKV_AGG_COUNT) { // SUM / TOTAL / AVG over strings: Float64 accumulators fed by array_value_to_numeric (:400-449)
+            for (const std::string &w : ci->dictionary) da.key_numeric.push_back(parse_numeric_or_zero(w));
+          }
+        }
         da.kind = kind;
         subst[a].kind = LLKV_AGG_COUNT_STAR;
       }
@@ -714,8 +721,49 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
     HIP_TRY(hipStreamSynchronize(s));
     return LLKV_OK;
   };
+  if (da.kind == LLKV_AGG_COUNT) { out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)m; return LLKV_OK; }
+  if (da.key_dtype == LLKV_DT_UTF8 || da.key_dtype == LLKV_DT_BOOLEAN || da.key_dtype == LLKV_DT_DATE32) {
+    // Sum / Total / AvgDistinctFloat64 over a non-float column (:889-924,1035-1066,1200-1232): each NEW key adds its numeric
+    // image — Str through array_value_to_numeric, Bool 1 / 0, Date its day number — in order of first appearance.  The
+    // keys are few (a dictionary, two booleans, the days of a table): the chain runs on the host.
+    std::vector<uint64_t> keys(m);
+    if (m) {
+      HIP_TRY(hipMemcpyAsync(keys.data(), dv.p, m * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    double sum = 0.0;
+    for (uint64_t k : keys) {
+      if (da.key_dtype == LLKV_DT_UTF8) { if (k >= da.key_numeric.size()) return set_error(LLKV_INTERNAL, "dictionary code beyond the dictionary"); sum += da.key_numeric[k]; }
+      else if (da.key_dtype == LLKV_DT_BOOLEAN) sum += k ? 1.0 : 0.0;
+      else sum += (double)(int32_t)(int64_t)k;
+    }
+    out->dtype = LLKV_DT_FLOAT64;
+    if (da.kind == LLKV_AGG_TOTAL) { out->f64 = sum; return LLKV_OK; }
+    if (m == 0) { out->is_null = 1; return LLKV_OK; }
+    out->f64 = da.kind == LLKV_AGG_AVG ? sum / (double)m : sum;
+    return LLKV_OK;
+  }
+  if (da.key_dtype == LLKV_DT_DECIMAL128) {
+    // Sum / Total / AvgDistinctDecimal128 (:943-967,1089-1112,1260-1284; finalize :1583-1612,1656-1672,1762-1800): an i128
+    // sum of the distinct raw values (64-bit images, < 2^32 of them: no i128 overflow), AVG half away from zero
+    out->dtype = LLKV_DT_DECIMAL128;
+    out->precision = da.precision; out->scale = da.scale;
+    if (m == 0) { out->is_null = da.kind != LLKV_AGG_TOTAL; return LLKV_OK; }
+    bool overflow = false;
+    __int128 total = 0;
+    if ((rc = prefix_overflow_of(dv.as<int64_t>(), m, &overflow, &total))) return rc;
+    if (da.kind == LLKV_AGG_AVG) {
+      const __int128 cnt = (__int128)m;
+      __int128 avg = total / cnt;
+      const __int128 rem = total % cnt;
+      if ((rem < 0 ? -rem : rem) * 2 >= cnt) avg += total >= 0 ? 1 : -1;
+      total = avg;
+    }
+    out->i64 = (int64_t)(uint64_t)(unsigned __int128)total;
+    out->i64_hi = (int64_t)(total >> 64);
+    return LLKV_OK;
+  }
   switch (da.kind) {
-  case LLKV_AGG_COUNT: out->dtype = LLKV_DT_INT64; out->i64 = (int64_t)m; return LLKV_OK;
   case LLKV_AGG_TOTAL: {
     out->dtype = LLKV_DT_FLOAT64;
     return f64_sum(da.is_f64 ? 0 : 1, &out->f64);
@@ -745,6 +793,8 @@ int Query::distinct_value(size_t agg, llkv_value *out) {
 // Sharded tables: this rank's distinct values go to the host; the binding all-gathers them.
 int Query::distinct_partial(size_t agg, const uint64_t **values, uint64_t *n) {
   if (agg >= distinct.size() || distinct[agg].kind < 0) return set_error(LLKV_INVALID_ARGUMENT, "not a DISTINCT aggregate");
+  if (distinct[agg].key_dtype != LLKV_DT_INT64 && distinct[agg].key_dtype != LLKV_DT_FLOAT64)
+    return set_error(LLKV_UNSUPPORTED, std::string("DISTINCT aggregate over a ") + dtype_name(distinct[agg].key_dtype) + " column of a sharded table");
   Scratch dv;
   uint64_t m = 0;
   int rc = distinct_set(agg, &dv, &m);

@@ -223,7 +223,14 @@ struct Query {
   int exact_prefix_overflow(size_t agg, bool *overflow);
   // ungrouped DISTINCT aggregates (COUNT / SUM / TOTAL / AVG): a value-emission plan per aggregate, evaluated
   // at finish by a sort-based pipeline (index = aggregate; kind < 0 = not a DISTINCT aggregate)
-  struct DistinctAgg { int kind = -1; bool is_f64 = false; LoweredPlan plan; };
+  struct DistinctAgg {
+    int kind = -1;
+    bool is_f64 = false;
+    LoweredPlan plan;
+    int32_t key_dtype = LLKV_DT_INT64;  // what the emitted 64-bit key stands for: Int64 / Float64 values, a Utf8 dictionary code, Boolean, Date32, the 64-bit image of a Decimal128
+    int32_t precision = 0, scale = 0;   // Decimal128
+    std::vector<double> key_numeric;    // Utf8: array_value_to_numeric of each dictionary entry
+  };
   std::vector<DistinctAgg> distinct;
   int emit_values(const LoweredPlan &ep, Scratch *vals, uint64_t *n);
   int distinct_set(size_t agg, Scratch *dv, uint64_t *m);

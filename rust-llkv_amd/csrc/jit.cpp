@@ -336,6 +336,58 @@ extern "C" int llkv_hip_jit_verify_dir(const char *dir, uint32_t every, uint64_t
   return LLKV_OK;
 }
 
+// Refills a directory of code objects from the plans another one names: every file of `from` that carries an identity
+// (whatever source or compiler it came from) names a (kind, plan type string); that plan is compiled from the tracked
+// kernel source of THIS library and stored in `to` under today's key.  No device needed — after a change to the kernel
+// headers the seed directory is rebuilt where the change was made (tools/refresh_jit_seed.sh rebuild) instead of by a run
+// of the whole suite on a GPU box.  Files i with i % n_shards == shard (by name order): one process per shard.
+extern "C" int llkv_hip_jit_rebuild_dir(const char *from, const char *to, uint32_t shard, uint32_t n_shards, uint64_t *built, uint64_t *failed) {
+  if (built) *built = 0;
+  if (failed) *failed = 0;
+  if (!from || !to || n_shards == 0) return LLKV_INVALID_ARGUMENT;
+  std::vector<std::string> names;
+  if (DIR *d = ::opendir(from)) {
+    while (struct dirent *e = ::readdir(d)) {
+      const std::string n = e->d_name;
+      if (n.size() > 6 && n.compare(n.size() - 6, 6, ".hsaco") == 0) names.push_back(n);
+    }
+    ::closedir(d);
+  } else {
+    return LLKV_NOT_FOUND;
+  }
+  std::sort(names.begin(), names.end());
+  for (size_t i = shard; i < names.size(); i += n_shards) {
+    std::ifstream f(std::string(from) + "/" + names[i], std::ios::binary);
+    std::vector<char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::string id;
+    if (!blob_take_identity(&file, nullptr, &id)) continue; // not one of ours
+    const size_t bar = id.find('|'), nl = id.find('\n');
+    if (bar == std::string::npos || nl == std::string::npos || bar > nl) continue;
+    const std::string kind_s = id.substr(0, bar), ts = id.substr(bar + 1, nl - bar - 1);
+    int kind = -1;
+    for (int k = 0; k <= 8; ++k) if (kind_s == kind_name((JitKind)k)) kind = k;
+    if (kind < 0) continue;
+    const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
+    char hex[32];
+    std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src + "\n// " + compile_identity()));
+    const std::string path = std::string(to) + "/" + hex + ".hsaco";
+    struct stat st;
+    if (::stat(path.c_str(), &st) == 0) { if (built) ++*built; continue; } // (two stale files may name one plan)
+    std::vector<char> code;
+    std::string err;
+    if (compile_to_code(src, &code, &err) != LLKV_OK) { // a plan the current source no longer accepts: nothing to seed
+      if (failed) ++*failed;
+      continue;
+    }
+    blob_append_identity(&code, blob_identity((JitKind)kind, ts, src));
+    const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+    std::ofstream o(tmp, std::ios::binary);
+    if (o) { o.write(code.data(), (std::streamsize)code.size()); o.close(); std::rename(tmp.c_str(), path.c_str()); }
+    if (built) ++*built;
+  }
+  return LLKV_OK;
+}
+
 // Build check (no device needed): compiles one plan of the given kind for gfx950.
 // kind: 0 scan, 1 select, 2 project.
 extern "C" int llkv_hip_jit_compile_only(const char *type_string, char *log_out, uint64_t log_cap) {

@@ -1621,7 +1621,7 @@ int lower_selection_in_set(const ColumnResolver &resolve, const llkv_filter *fil
 
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err,
-               bool allow_f64, bool *is_f64_out, const uint32_t *in_set_field) {
+               bool allow_f64, bool *is_f64_out, const uint32_t *in_set_field, int32_t *key_dtype) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, false};
   std::string pred, val;
@@ -1645,15 +1645,22 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     const ColumnInfo *ci;
     int slot;
     if ((rc = L.slot_of(expr[0].field_id, &ci, &slot))) return rc;
-    if (ci->dtype != LLKV_DT_INT64 && !(allow_f64 && ci->dtype == LLKV_DT_FLOAT64)) return L.fail(LLKV_UNSUPPORTED, std::string("value emission over a ") + dtype_name(ci->dtype) + " column");
+    // DISTINCT keys (DistinctKey::from_array llkv-aggregate/src/lib.rs:261-331): Int by value, Float by bits — and, where the
+    // caller takes them (key_dtype), Str by its dictionary code (the staged dictionary holds every string once), Bool,
+    // Date and the 64-bit image of a Decimal by value
+    const bool keyed = key_dtype && (ci->dtype == LLKV_DT_UTF8 || ci->dtype == LLKV_DT_BOOLEAN || ci->dtype == LLKV_DT_DATE32 || (ci->dtype == LLKV_DT_DECIMAL128 && !ci->wide128));
+    if (ci->dtype != LLKV_DT_INT64 && !(allow_f64 && ci->dtype == LLKV_DT_FLOAT64) && !keyed) return L.fail(LLKV_UNSUPPORTED, std::string("value emission over a ") + dtype_name(ci->dtype) + " column");
     val = L.col_node(slot, ci->dtype);
+    if (keyed && ci->dtype != LLKV_DT_DECIMAL128) val = "ToI64<" + val + ">";
     is_f64 = ci->dtype == LLKV_DT_FLOAT64;
+    if (key_dtype) *key_dtype = ci->dtype;
   } else {
     L.exact_nan = true; // the emitted values are told apart by their bits (DISTINCT)
     rc = L.expr_fast(expr, expr_len, &val, &is_f64);
     L.exact_nan = false;
     if (rc) return rc;
     if (is_f64 && !allow_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
+    if (key_dtype) *key_dtype = is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64;
   }
   if (is_f64_out) *is_f64_out = is_f64;
   { // NULL argument rows are not part of the accumulator's chain

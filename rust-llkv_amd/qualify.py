@@ -98,6 +98,15 @@ def decimal_from_f64(x: float) -> Decimal:
     return d.quantize(q, rounding=ROUND_HALF_UP, context=Context(prec=60)).normalize()
 
 
+def decimal_15_digits(d: Decimal) -> Decimal:
+    """An exact decimal cut to the 15 significant digits Decimal::from_f64 keeps (half up): what an engine whose f64 result
+    is the correctly rounded exact value presents to the `sum`-kind compare."""
+    from decimal import ROUND_HALF_UP, Context
+    if d == 0:
+        return Decimal(0)
+    return d.quantize(Decimal(1).scaleb(d.adjusted() - 14), rounding=ROUND_HALF_UP, context=Context(prec=60)).normalize()
+
+
 def values_equal(expected, actual, kind: str) -> bool:
     """values_equal (qualification.rs:708-745)."""
     (te, ve), (ta, va) = expected, actual
@@ -278,7 +287,7 @@ def compare_report(expected_rows: Sequence[Sequence], actual_rows: Sequence[Sequ
         ok, max_abs, max_rel = True, 0.0, 0.0
         for e, a in zip(expected_rows, actual_rows):
             ok &= values_equal(engine_value(e[c], k), engine_value(a[c], k), k)
-            if isinstance(e[c], (int, float)) and isinstance(a[c], (int, float)) and not isinstance(e[c], bool):
+            if isinstance(e[c], (int, float, Decimal)) and isinstance(a[c], (int, float, Decimal)) and not isinstance(e[c], bool):
                 d = abs(float(e[c]) - float(a[c]))
                 max_abs = max(max_abs, d)
                 if e[c]:

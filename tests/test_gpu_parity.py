@@ -1565,6 +1565,42 @@ def test_distinct_aggregates_match_oracle(rt, orc, abi, chunks):
 
 
 @pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])
+def test_distinct_aggregates_over_string_boolean_date_and_decimal_keys(rt, orc, abi, chunks):
+    """DistinctKey (llkv-aggregate/src/lib.rs:252-331) beyond Int / Float: strings by value (the staged dictionary holds each
+    once: the code IS the key), booleans, dates, raw decimals; SUM / TOTAL / AVG add a new key's numeric image in order of
+    first appearance (:889-924) or run in i128 over decimals (:943-967,1762-1800)."""
+    rng = np.random.default_rng(41 + len(chunks))
+    n = sum(chunks)
+    words = ["12", " 3.5 ", "abc", "", "1e2", "12.0", "-7.25", ".5", "1.", "+4", "0.125", "1000000.5", "1", "1.0"]
+    txt = [words[i] for i in rng.integers(0, len(words), size=n)]
+    boo = rng.integers(0, 2, size=n).astype(np.uint8)
+    day = rng.integers(9000, 9040, size=n).astype(np.int32)
+    dec = [int(v) for v in rng.integers(-500, 500, size=n)]
+    sel = rng.integers(0, 5, size=n).astype(np.int64)
+    vt, vb, vd = rng.random(n) > 0.15, rng.random(n) > 0.1, rng.random(n) > 0.1
+    ht = rt.HipTable(1, chunks)
+    ht.append_utf8_column(1, txt, valid=vt)
+    ht.append_column(2, abi.DT_BOOLEAN, boo, valid=vb)
+    ht.append_column(3, abi.DT_DATE32, day)
+    ht.append_decimal128_column(4, 12, 2, dec, valid=vd)
+    ht.append_column(5, abi.DT_INT64, sel)
+    ot = orc.OracleTable(n)
+    ot.add(1, abi.DT_UTF8, [t if ok else None for t, ok in zip(txt, vt)]).add(2, abi.DT_BOOLEAN, boo, list(vb)).add(3, abi.DT_DATE32, day)
+    ot.add(4, abi.DT_DECIMAL128, dec, list(vd), precision=12, scale=2).add(5, abi.DT_INT64, sel)
+    A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
+
+    def D(kind, e):
+        s = getattr(A, kind)(e)
+        s.distinct = True
+        return s
+
+    aggs = [D(k, f) for f in (1, 2, 3, 4) for k in ("count", "sum", "total", "avg")] + [A.count_star(), A.sum(5)]
+    for pred in (None, [F(5, O.Equals(2))], [F(5, O.GreaterThan(9))]):
+        got, want = rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs)
+        assert got == want, pred  # the same keys in the same order: the same f64 chain, bit for bit; decimals as raw i128
+
+
+@pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])
 def test_ordered_scans_match_oracle(rt, orc, abi, chunks):
     """ScanStreamOptions.order (sort_row_ids_with_order, llkv-scan/src/ordering.rs:16-140): the selected rows are
     sorted by one column — Int64 / Int32 / Utf8 (string order), ascending or descending, NULLs first or last —

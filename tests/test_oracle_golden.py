@@ -319,6 +319,36 @@ def test_a_negative_zero_divisor_is_not_the_zero_that_becomes_null(orc, abi):
     assert [r.values[0].value for r in rows] == [0]
 
 
+def test_distinct_accumulators_over_string_boolean_date_and_decimal_keys(orc, abi):
+    """DistinctKey (llkv-aggregate/src/lib.rs:252-331): Str by value — "1" and "1.0" are two keys although both parse to 1.0 —,
+    Bool, Date and the raw Decimal by value; SUM / TOTAL / AVG over a non-float key add each NEW key's numeric image in order
+    of first appearance (:889-924: strings parse or count 0, booleans 1 / 0, dates their day number), over Decimal128 they
+    run in i128 and AVG rounds half away from zero (:1762-1800).  Expected values derived by hand from those rules."""
+    t = orc.OracleTable(7)
+    t.add(1, abi.DT_UTF8, ["1", "1.0", "x", "1", " 2.5 ", None, "x"])
+    t.add(2, abi.DT_BOOLEAN, np.array([1, 0, 1, 1, 0, 0, 1], dtype=np.uint8), [True, True, True, True, True, False, True])
+    t.add(3, abi.DT_DATE32, np.array([10, 10, -3, 7, 7, 7, 10], dtype=np.int32))
+    t.add(4, abi.DT_DECIMAL128, [150, 150, -25, 1, 1, 150, 2], precision=10, scale=2)
+    A = abi.AggregateSpec
+    D = lambda k, f: A(k, abi._colexpr(f), "d", True)
+    got = orc.aggregate(t, None, [D(abi.AGG_COUNT, 1), D(abi.AGG_SUM, 1), D(abi.AGG_TOTAL, 1), D(abi.AGG_AVG, 1),
+                                  D(abi.AGG_COUNT, 2), D(abi.AGG_SUM, 2), D(abi.AGG_COUNT, 3), D(abi.AGG_SUM, 3), D(abi.AGG_AVG, 3),
+                                  D(abi.AGG_COUNT, 4), D(abi.AGG_SUM, 4), D(abi.AGG_TOTAL, 4), D(abi.AGG_AVG, 4)])
+    vals = [None if g.is_null else g.value for g in got]
+    assert vals[:9] == [4, 4.5, 4.5, 4.5 / 4, 2, 1.0, 3, 14.0, 14.0 / 3]
+    assert [(g.dtype, g.precision, g.scale) for g in got[10:]] == [(abi.DT_DECIMAL128, 10, 2)] * 3
+    assert vals[9:] == [4, 128, 128, 32]  # 150 − 25 + 1 + 2 = 128 (raw, scale 2); 128 / 4 = 32 exactly
+    none = orc.aggregate(t, [abi.Filter(3, abi.Operator.GreaterThan(100))], [D(abi.AGG_COUNT, 1), D(abi.AGG_SUM, 1), D(abi.AGG_TOTAL, 1), D(abi.AGG_SUM, 4), D(abi.AGG_TOTAL, 4), D(abi.AGG_AVG, 4)])
+    assert [bool(g.is_null) for g in none] == [False, True, False, True, False, True]
+    assert none[0].value == 0 and none[2].value == 0.0 and none[4].value == 0
+    t2 = orc.OracleTable(3)
+    t2.add(1, abi.DT_DECIMAL128, [1, 2, 4], precision=5, scale=1)
+    assert orc.aggregate(t2, None, [D(abi.AGG_AVG, 1)])[0].value == 2   # 7 / 3 = 2.33 → 2
+    t3 = orc.OracleTable(2)
+    t3.add(1, abi.DT_DECIMAL128, [-1, -2], precision=5, scale=1)
+    assert orc.aggregate(t3, None, [D(abi.AGG_AVG, 1)])[0].value == -2  # −3 / 2 = −1.5 → −2 (half away from zero)
+
+
 def test_q6_against_numpy(orc, abi, tpch):
     """Independent cross-check of the restatement (pyarrow/numpy are NOT the reference)."""
     n = tpch.LINEITEM_ROWS["sf0.01"]

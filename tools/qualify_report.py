@@ -25,6 +25,29 @@ for sf in sys.argv[1:] or ["sf0.01", "sf1"]:
     q1 = qual.render_query(tpch, abi, 1)
     cells = lambda rws: [[k.value for k in r.keys] + [v.value for v in r.values] for r in rws]
     res["q1"] = qual.compare_report(cells(orc.groupby(ot, q1.predicate, q1.keys, q1.aggs, True)), cells(rt.groupby(ht, q1.predicate, q1.keys, q1.aggs, True)), qual.Q1_TOKENS)
+    # Q1 against the decimal-exact answer (prices are cents, discounts and taxes hundredths: integer arithmetic, no
+    # rounding anywhere), each `sum` cut to the 15 digits Decimal::from_f64 keeps: the sequential f64 chain of the
+    # reference (oracle), the GPU path's fixed-order tree, and the GPU path with llkv_hip_set_exact_f64_sums
+    from decimal import Decimal
+    cutoff = qual._date32("1998-12-01") - int(qual.render_parameters(1)[0])
+    keep = d["l_shipdate"] <= cutoff
+    pc = np.rint(d["l_extendedprice"] * 100).astype(np.int64); dh = np.rint(d["l_discount"] * 100).astype(np.int64); th = np.rint(d["l_tax"] * 100).astype(np.int64)
+    exact_rows = []
+    for r in orc.groupby(ot, q1.predicate, q1.keys, q1.aggs, True):
+        f, st = r.keys[0].value, r.keys[1].value
+        m = keep & (d["l_returnflag"] == ord(f)) & (d["l_linestatus"] == ord(st))
+        n, sq = int(m.sum()), int(d["l_quantity"][m].sum())
+        sp, sd = int(pc[m].sum()), int(dh[m].sum())
+        sdp, sch = int((pc[m] * (100 - dh[m])).sum()), int((pc[m] * (100 - dh[m]) * (100 + th[m])).sum())
+        exact_rows.append([f, st, sq, qual.decimal_15_digits(Decimal(sp) / 100), qual.decimal_15_digits(Decimal(sdp) / 10**4), qual.decimal_15_digits(Decimal(sch) / 10**6),
+                           sq / n, float(Decimal(sp) / 100 / n), float(Decimal(sd) / 100 / n), n])
+    res["q1_vs_decimal_exact"] = {"reference_order_chain": qual.compare_report(exact_rows, cells(orc.groupby(ot, q1.predicate, q1.keys, q1.aggs, True)), qual.Q1_TOKENS),
+                                  "gpu_default": qual.compare_report(exact_rows, cells(rt.groupby(ht, q1.predicate, q1.keys, q1.aggs, True)), qual.Q1_TOKENS)}
+    rt.set_exact_f64_sums(True)
+    try:
+        res["q1_vs_decimal_exact"]["gpu_exact_f64_sums"] = qual.compare_report(exact_rows, cells(rt.groupby(ht, q1.predicate, q1.keys, q1.aggs, True)), qual.Q1_TOKENS)
+    finally:
+        rt.set_exact_f64_sums(False)
     q6 = qual.render_query(tpch, abi, 6)
     res["q6"] = qual.compare_report([[orc.aggregate(ot, q6.predicate, q6.aggs)[0].value]], [[rt.aggregate(ht, q6.predicate, q6.aggs)[0].value]], qual.Q6_TOKENS)
     n_ord = tpch.orders_for_lineitems(rows); od = tpch.gen_orders(n_ord, scale)

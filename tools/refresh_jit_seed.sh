@@ -4,6 +4,7 @@
 # git-ignored, shipped with the tree).  Needs a GPU box: run it there (gpurun), then copy gpurun_out/jit_cache back:
 #   gpurun -- 'bash tools/refresh_jit_seed.sh collect'      # on the GPU box: the suite with an empty, capturable cache
 #   bash tools/refresh_jit_seed.sh install                   # here: gpurun_out/jit_cache/*.hsaco → rust-llkv_amd/jit_seed/
+#   bash tools/refresh_jit_seed.sh rebuild                   # here, no GPU: the plans the present seeds name, recompiled from today's source
 # Entries are keyed by the kernel source AND the compiler identity: after a change to csrc/*.hip.h or a ROCm upgrade the
 # old ones are never asked for again (delete them and refresh).
 set -euo pipefail
@@ -19,6 +20,24 @@ case "${1:-}" in
       [ "$(tail -c 8 "$f")" = "LLKVJIT1" ] && cp "$f" "$ROOT/rust-llkv_amd/jit_seed/"
     done
     ls "$ROOT/rust-llkv_amd/jit_seed" | wc -l ;;
+  rebuild) # no GPU: every plan the old seeds (and any gpurun_out/jit_cache*) name, compiled from the tracked source of today
+    cd "$ROOT" && rm -rf rust-llkv_amd/jit_seed.new && mkdir -p rust-llkv_amd/jit_seed.new && chmod 755 rust-llkv_amd/jit_seed.new
+    for src in rust-llkv_amd/jit_seed gpurun_out/jit_cache*; do
+      [ -d "$src" ] || continue
+      for shard in 0 1 2 3 4 5 6 7; do
+        python3 - "$src" "$shard" <<'PY' &
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.getcwd())
+lib = importlib.import_module("rust-llkv_amd.runtime").lib()
+built, failed = C.c_uint64(), C.c_uint64()
+rc = lib.llkv_hip_jit_rebuild_dir(sys.argv[1].encode(), b"rust-llkv_amd/jit_seed.new", C.c_uint32(int(sys.argv[2])), C.c_uint32(8), C.byref(built), C.byref(failed))
+print(f"{sys.argv[1]} shard {sys.argv[2]}: rc={rc} built={built.value} failed={failed.value}", flush=True)
+PY
+      done
+      wait
+    done
+    rm -rf rust-llkv_amd/jit_seed && mv rust-llkv_amd/jit_seed.new rust-llkv_amd/jit_seed
+    ls rust-llkv_amd/jit_seed | wc -l ;;
   verify) # every seed against a fresh hiprtc build of the tracked kernel source (no GPU needed; ~0.35 s per file)
     cd "$ROOT" && python3 - <<'PY'
 import ctypes as C, importlib, os, sys
@@ -32,5 +51,5 @@ print(f"rc={rc} checked={checked.value} bad={bad.value} first_bad={first.value.d
 sys.exit(1 if rc or bad.value else 0)
 PY
     ;;
-  *) echo "usage: $0 collect|install|verify" >&2; exit 2 ;;
+  *) echo "usage: $0 collect|install|rebuild|verify" >&2; exit 2 ;;
 esac
