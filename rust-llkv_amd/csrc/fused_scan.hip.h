@@ -124,6 +124,14 @@ template <class CL, int I = 0> __device__ __forceinline__ void load_all(const Sc
   }
 }
 
+// Columns [LO, HI) only: the plans that read some columns for the rows that pass and no others (late materialisation).
+template <class CL, int LO, int HI> __device__ __forceinline__ void load_range(const ScanParams &p, uint64_t row, Loaded &ld) {
+  if constexpr (LO < HI && LO < CL::N) {
+    load_pair<typename ColAt<LO, CL>::type>(p.col[LO], row, ld.w[LO]);
+    load_range<CL, LO + 1, HI>(p, row, ld);
+  }
+}
+
 // Per-row evaluation context.
 struct Ctx {
   const ScanParams &p;
@@ -674,7 +682,11 @@ template <class... As> struct Aggs {
 // ACC = 2: ONE accumulator image per workgroup in LDS, [lane][group], shared by its 1024 threads and updated with
 //          the same DS atomics (image_scan_body): hundreds to thousands of groups.  Every lane op must be order-free,
 //          so f64 sums are the exact two-level SumF64X.
-template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0, int PASSES_ = 1> struct Plan {
+template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0, int PASSES_ = 1, int EARLY_ = -1> struct Plan {
+  // register-state plans: the columns [0, EARLY) feed the predicate (and keys) and are streamed for every row, the ones
+  // behind them feed aggregate arguments alone and are read for the row pairs that hold a passing row (EARLY_ < 0: all
+  // columns up front)
+  static constexpr int EARLY = EARLY_ < 0 ? CL::N : EARLY_;
   static constexpr int PASSES = PASSES_; // shared-image plans: the groups are cut into PASSES slices, one scan each
   using ColList = CL;
   using Pred = PR;
@@ -808,6 +820,78 @@ template <class P> __device__ __forceinline__ void fused_scan_body_reg(const Sca
   const TileDesc td = p.tiles[tile];
   const uint32_t nsteps = (td.rows + kStepRows - 1) / kStepRows;
 
+  if constexpr (P::EARLY < P::ColList::N) {
+    // Late materialisation.  Per group of U steps: the predicate over the early columns → the argument columns of the row
+    // pairs that hold a passing row → the early columns of the NEXT group (requested behind the late loads, so waiting for
+    // the late ones does not wait for them: the counter retires loads in order) → the accumulation.  A lane whose rows both
+    // fail requests nothing; the same bits as the eager form (same rows, same order of combination).
+    Loaded ld[U], nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int c = P::EARLY; c < P::ColList::N; ++c) ld[u].w[c][0] = ld[u].w[c][1] = ld[u].w[c][2] = ld[u].w[c][3] = 0u;
+      load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + (uint64_t)u * kStepRows + (uint64_t)tid * kRowsPerThread, ld[u]);
+    }
+    for (uint32_t s = 0; s < nsteps; s += U) {
+      bool pass[U][kRowsPerThread];
+      uint32_t gidv[U][kRowsPerThread];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t row0 = (s + u) * kStepRows + tid * kRowsPerThread;
+#pragma unroll
+        for (int j = 0; j < kRowsPerThread; ++j) {
+          Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
+          const bool in_tile = (row0 + j) < td.rows;
+          pass[u][j] = in_tile & P::Pred::eval(c, j);
+          gidv[u][j] = P::KeyT::gid(c, j);
+          err |= in_tile ? c.perr : 0u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < kRowsPerThread; ++j) any |= pass[u][j];
+        if (any) load_range<typename P::ColList, P::EARLY, P::ColList::N>(p, td.dev_row + (uint64_t)(s + u) * kStepRows + (uint64_t)tid * kRowsPerThread, ld[u]);
+      }
+      const bool more = s + U < nsteps;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + (uint64_t)(s + U + u) * kStepRows + (uint64_t)tid * kRowsPerThread, nx[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t row0 = (s + u) * kStepRows + tid * kRowsPerThread;
+#pragma unroll
+        for (int j = 0; j < kRowsPerThread; ++j) {
+          Ctx c{p, ld[u], 0u, td.logical_row + row0 + j};
+          uint64_t contrib[K];
+          contrib[0] = 1;
+          if constexpr (P::first) contrib[1] = c.row;
+          AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
+          err |= pass[u][j] ? c.err : 0u;
+#pragma unroll
+          for (int gg = 0; gg < NG; ++gg) {
+            const bool sel = pass[u][j] & (NG == 1 || gidv[u][j] == (uint32_t)gg);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const int op = ops.v[gg * K + k];
+              const uint64_t x = sel ? contrib[k] : lane_identity(op);
+              acc[gg][k] = lane_combine(op, acc[gg][k], x);
+            }
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < P::EARLY; ++c)
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) ld[u].w[c][wd] = nx[u].w[c][wd];
+      }
+    }
+  } else
   for (uint32_t s = 0; s < nsteps; s += U) {
     Loaded ld[U];
     // issue every load of the unrolled group before the first use (column buffers carry

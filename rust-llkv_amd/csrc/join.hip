@@ -511,8 +511,16 @@ hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64
 // the stripes follow one another in row order, so a run of equal groups may continue into the next stripes that have
 // pairs.  One wave per stripe; the first pair of a run walks it to its end, across stripes.  counts[s] carries the
 // predicate-error mark of the probe (kPredErrorBit): it is raised into flags[1]; flags[0] as `multi_run` above.
+// key-bit position → group id (RankCols, join.hpp)
+__device__ __forceinline__ uint32_t rank_of_keybit(const RankCols &r, uint32_t d) {
+  const uint32_t word = d >> 6;
+  const uint64_t w = r.bits[word];
+  uint32_t g = (uint32_t)__popcll(w & ((1ull << (d & 63)) - 1ull)) + r.prefix[word];
+  if (r.base) g += r.base[word >> r.chunk_shift];
+  return g;
+}
 __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
-                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags) {
+                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank) {
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (slot >= n_slots) return;
   const uint32_t lane = threadIdx.x & 63;
@@ -564,17 +572,18 @@ __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t
           ++k;
         }
       }
-      if (atomicAdd(&count_by_group[g], n) != 0) atomicOr(&flags[0], 1u);
-      sum_by_group[g] = acc;
+      const uint32_t gid = rank.bits ? rank_of_keybit(rank, g) : g; // (one rank per run instead of one per probed row)
+      if (atomicAdd(&count_by_group[gid], n) != 0) atomicOr(&flags[0], 1u);
+      sum_by_group[gid] = acc;
     }
     __builtin_amdgcn_wave_barrier(); // the chunk is overwritten next
   }
 }
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
-                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s) {
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank) {
   if (n_slots == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_run_sums_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group,
-                     (unsigned long long *)count_by_group, flags);
+                     (unsigned long long *)count_by_group, flags, rank);
   return hipGetLastError();
 }
 // the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
@@ -706,21 +715,21 @@ hipError_t hj_launch_add_u64(uint64_t *v, uint64_t n, uint64_t delta, hipStream_
 }
 
 __global__ __launch_bounds__(256) void hj_compact_stripes_kernel(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
-                                                                  uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val) {
+                                                                  uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, RankCols rank) {
   const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (slot >= n_slots) return;
   // launched before the host has seen the total: counts that carry the predicate-error mark are not offsets
   if (offsets[n_slots] >= kPredErrorBit) return;
   const uint64_t cnt = counts[slot], src = (uint64_t)slot * stripe, dst = offsets[slot];
   for (uint64_t i = threadIdx.x & 63; i < cnt; i += 64) {
-    out_group[dst + i] = slot_group ? slot_group[stripe_slot[src + i]] : stripe_slot[src + i];
+    out_group[dst + i] = rank.bits ? rank_of_keybit(rank, stripe_slot[src + i]) : slot_group ? slot_group[stripe_slot[src + i]] : stripe_slot[src + i];
     out_val[dst + i] = stripe_val[src + i];
   }
 }
 hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
-                                     uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s) {
+                                     uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s, RankCols rank) {
   if (n_slots == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_compact_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_slot, stripe_val, counts, offsets, n_slots, stripe, slot_group, out_group, out_val);
+  hipLaunchKernelGGL(hj_compact_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_slot, stripe_val, counts, offsets, n_slots, stripe, slot_group, out_group, out_val, rank);
   return hipGetLastError();
 }
 

@@ -179,8 +179,16 @@ hipError_t hj_launch_segment_sums(const uint32_t *sorted_slot, const uint64_t *s
 // The same over unsorted pairs: runs are summed where they lie; *multi_run is set when a group has two runs
 // (count_by_group must start at zero) — the caller then sorts.
 // run sums straight from the probe's stripes; flags[0]: some group had two runs, flags[1]: a stripe count carried the predicate-error mark
+// The stripes of a probe that emitted key-bit positions instead of group ids (ScanParams::bm_emit_keybit): the group of a
+// position = the number of set bits before it (bits == nullptr: the stripes hold group ids already).
+struct RankCols {
+  const uint64_t *bits;
+  const uint32_t *prefix; // set bits before each word, within its chunk of 2^chunk_shift words
+  const uint32_t *base;   // set bits before each chunk (nullptr: one chunk)
+  uint32_t chunk_shift;
+};
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
-                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s);
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank = RankCols{nullptr, nullptr, nullptr, 0});
 // `descending` (optional): raised when a run starts below the group of the pair before it
 hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
                                   uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s, uint32_t *descending = nullptr);
@@ -215,7 +223,8 @@ hipError_t hj_launch_map_u32(uint32_t *inout, uint64_t n, const uint32_t *table,
 // Compaction of the single-pass probe output: stripe `slot` holds counts[slot] pairs at slot·stripe; they move to
 // offsets[slot] with the hash slot translated to its group id.
 hipError_t hj_launch_compact_stripes(const uint32_t *stripe_slot, const uint64_t *stripe_val, const uint64_t *counts, const uint64_t *offsets,
-                                     uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s);
+                                     uint32_t n_slots, uint32_t stripe, const uint32_t *slot_group, uint32_t *out_group, uint64_t *out_val, hipStream_t s,
+                                     RankCols rank = RankCols{nullptr, nullptr, nullptr, 0});
 // v[i] += delta (wrapping)
 hipError_t hj_launch_add_u64(uint64_t *v, uint64_t n, uint64_t delta, hipStream_t s);
 // *flag |= 1 when keys[i] < keys[i − 1] for some i (flag zeroed by the caller)

@@ -157,6 +157,8 @@ struct JoinAgg {
   DB st_slot, st_val;                // the probe's stripes: (group id | hash slot, value) pairs per (tile, wave), row order
   uint32_t n_slots = 0, stripe = 0;
   bool from_stripes = false;         // the sums were taken straight from the stripes: no pair count, no compacted pairs yet
+  bool keybit_stripes = false;       // … and the stripes hold key-bit positions, not group ids (ScanParams::bm_emit_keybit)
+  RankCols stripe_ranks{nullptr, nullptr, nullptr, 0};
   DB slot_group;                     // hash form: slot → group id
   bool direct_form = false;
   // ranked form: the dimension selection went straight into the key bitmap (no list of its rows): group id = rank of the
@@ -461,7 +463,10 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     return it == tf->cols.end() ? nullptr : &it->second.info;
   };
   LoweredPlan plan;
-  if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err))) return set_error(rc, err);
+  // one rank, ranked form, sums straight from the stripes: the probe emits the key's bit position and the head of every run
+  // looks the rank up
+  keybit_stripes = ranked && direct && defer && tf->world == 1 && dt.span < (1ull << 32) && !std::getenv("LLKV_HIP_JOIN_COMPACT") && !std::getenv("LLKV_HIP_JOIN_PROBE_RANKS");
+  if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err, keybit_stripes))) return set_error(rc, err);
   if (plan.always_false || tf->local_rows == 0) {
     if (ranked) { // nothing probes: the group state still starts from zero, and the group count is wanted
       HIP_TRY(hj_launch_fill(group_state.p, (tf->world == 1 ? 1 : 3) * state_bytes, 0, s));
@@ -493,6 +498,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
       p.bm_group = nullptr; // the rank is the group id
       p.bm_base = rank_chunks > 1 ? (const uint32_t *)rank_base.p : nullptr;
       p.bm_chunk_shift = rank_shift;
+      stripe_ranks = RankCols{(const uint64_t *)dt.bits.p, (const uint32_t *)dt.prefix.p, p.bm_base, rank_shift};
       p.zero_k = tf->world == 1 ? 1 : 3;
       p.zero_words = (uint64_t *)group_state.p;
       p.zero_stride = state_bytes / 8;
@@ -521,7 +527,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   from_stripes = defer && direct && tf->world == 1 && !std::getenv("LLKV_HIP_JOIN_COMPACT");
   if (from_stripes) {
     HIP_TRY(hj_launch_run_sums_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, n_slots, stripe, (double *)sums.p,
-                                       (uint64_t *)cnts.p, multi_p(), s));
+                                       (uint64_t *)cnts.p, multi_p(), s, keybit_stripes ? stripe_ranks : RankCols{nullptr, nullptr, nullptr, 0}));
   } else if ((rc = compact_pairs(true))) {
     return rc;
   }
@@ -556,7 +562,8 @@ int JoinAgg::compact_pairs(bool run_sums) {
   const uint64_t max_pairs = tf->local_rows;
   if ((rc = e_group.alloc(max_pairs * 4)) || (rc = e_val.alloc(max_pairs * 8))) return rc;
   HIP_TRY(hj_launch_compact_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, (const uint64_t *)offsets.p, n_slots, stripe,
-                                    direct_form ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s)); // slot → group id on the way
+                                    direct_form ? nullptr : (const uint32_t *)slot_group.p, (uint32_t *)e_group.p, (uint64_t *)e_val.p, s, // slot / key bit → group id on the way
+                                    keybit_stripes ? stripe_ranks : RankCols{nullptr, nullptr, nullptr, 0}));
   if (run_sums)
     HIP_TRY(hj_launch_run_sums_dev((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, (const uint64_t *)offsets.p + n_slots, max_pairs, (double *)sums.p,
                                    (uint64_t *)cnts.p, multi_p(), s, range_form ? multi_p() + 3 : nullptr));

@@ -1472,6 +1472,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   std::vector<std::string> groups; // lane-group node strings
   std::vector<std::vector<uint8_t>> group_ops;
   int next_lane = 0;
+  const size_t early_slots = p.slot_fields.size(); // what the predicate and the keys read; the slots behind feed aggregate arguments only
   if ((rc = lower_aggregates(L, resolve, aggs, n_aggs, grouped, groups, group_ops, next_lane))) return rc;
   enum { ADD_F64 = 0, ADD_I64 = 1, MIN_I64 = 2, MAX_I64 = 3, MAX_U64 = 4 };
 
@@ -1530,7 +1531,12 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   std::string ag = "Aggs<";
   for (size_t i = 0; i < groups.size(); ++i) ag += (i ? "," : "") + groups[i];
   ag += ">";
-  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_part ? "3" : p.acc_image ? "2" : p.acc_lds ? "1" : "0") + (p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
+  // register-state plans with a predicate: the argument-only columns are read for the rows that pass (fused_scan.hip.h:
+  // Plan::EARLY, late materialisation — Q6 reads 20 B of every row and the price of the 2 % that pass)
+  const bool late = !p.acc_part && !p.acc_image && !p.acc_lds && pred != "True" && pred != "False" && early_slots > 0 && early_slots < p.slot_fields.size() &&
+                    !std::getenv("LLKV_HIP_SCAN_NO_LATE");
+  p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_part ? "3" : p.acc_image ? "2" : p.acc_lds ? "1" : "0") +
+                  (late ? ",1," + std::to_string(early_slots) : p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
   return LLKV_OK;
 }
 
@@ -1673,7 +1679,7 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
 }
 
 int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
-                const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err) {
+                const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err, bool emit_keybit) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, true};
   std::string pred, key, val;
@@ -1692,9 +1698,13 @@ int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint3
   else return L.fail(LLKV_UNSUPPORTED, std::string("join key of type ") + dtype_name(ci->dtype));
   bool is_f64 = false;
   if (!expr || expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
+  const size_t early = out->slot_fields.size(); // the slots so far feed the predicate and the key; what the value adds is read late
   if ((rc = L.expr_planvalue(expr, expr_len, &val, &is_f64))) return rc;
   if (!is_f64) return L.fail(LLKV_UNSUPPORTED, "integer SUM in the join-aggregate pipeline");
-  out->type_string = "ProbePlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + "," + key + "," + val + ">";
+  const bool late = early < out->slot_fields.size() && !std::getenv("LLKV_HIP_JOIN_NO_LATE");
+  // (the direct-table probe of a plan with KEYBIT = 1 emits the key's bit position instead of its rank: join_agg.cpp)
+  const std::string tail = emit_keybit ? "," + std::to_string(late ? early : out->slot_fields.size()) + ",1" : late ? "," + std::to_string(early) : "";
+  out->type_string = "ProbePlan<" + cols_string(*out, &out->bytes_per_row) + "," + pred + "," + key + "," + val + tail + ">";
   return LLKV_OK;
 }
 

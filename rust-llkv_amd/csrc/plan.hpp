@@ -151,7 +151,7 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
 // Fact side of a join → aggregate pipeline → "ProbePlan<Cols<…>,pred,KeyExpr,ValExpr>" (select.hip.h).
 // The aggregate argument follows the GROUP BY (PlanValue) semantics and must be Float64.
 int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, uint32_t key_field,
-                const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err);
+                const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err, bool emit_keybit = false);
 
 // Selected argument values in row order → "EmitPlan<Cols<…>,pred,ValExpr>" (exact SUM(Int64) overflow check).
 // `allow_f64`: Float64 arguments are emitted as bit images (DISTINCT aggregates); *is_f64 reports the type.

@@ -18,7 +18,7 @@ template <class CL, class PR> struct SelPlan {
   using Pred = PR;
 };
 
-constexpr int kSelUnroll = 4; // 128-row steps of a wave in flight
+constexpr int kSelUnroll = 4; // 128-row steps of a wave in flight (2 … 8 measured on the Q3 probe: 175 / 171 / 188 / 171 µs — not what bounds it)
 
 // A predicate of the form "A, and for the rows that pass it, membership of a key in the key-set bitmap"
 template <class PR> struct GatherSplit { static constexpr bool value = false; };
@@ -101,11 +101,19 @@ template <class P, bool WRITE> __device__ __forceinline__ void select_body(const
 // ---- probe-emit: fact-side rows that pass the predicate AND hit the build table emit
 // (slot, value) in row order — the input of the order-preserving join → GROUP BY pipeline
 // (llkv-executor/src/lib.rs:12529-12569 probe + :1629-1646 mask + :5186-5199 per-row argument).
-template <class CL, class PR, class KE, class VE> struct ProbePlan {
+// EARLY: the columns [0, EARLY) feed the predicate and the key and are streamed for every row; the columns behind them feed
+// the value alone and are read for the rows that pass AND hit the build side — two consecutive rows per lane, so a miss
+// costs nothing and a hit one sector per late column (late materialisation: Q3's probe reads 12 B of every lineitem row
+// and the price / discount of the ~0.5 % that join).  EARLY = all columns: everything up front.
+// KEYBIT: the direct-table probe emits the key's bit position (key − bm_min) and leaves the rank to the head of each run
+// of a key's pairs (hj_run_sums_stripes): a third as many rank lookups, and none inside the probe's chain of round trips.
+template <class CL, class PR, class KE, class VE, int EARLY_ = CL::N, int KEYBIT_ = 0> struct ProbePlan {
   using ColList = CL;
   using Pred = PR;
   using KeyE = KE;
   using ValE = VE;
+  static constexpr int EARLY = EARLY_;
+  static constexpr bool KEYBIT = KEYBIT_ != 0;
 };
 
 __device__ __forceinline__ long long ht_load_key(const ScanParams &p, unsigned long long row) {
@@ -150,8 +158,15 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
   constexpr int kE = 2 * kSelUnroll;
   for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
     Loaded lds[kSelUnroll];
+    constexpr bool LATE = P::EARLY < P::ColList::N;
+    if constexpr (LATE) {
 #pragma unroll
-    for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+      for (int u = 0; u < kSelUnroll; ++u)
+#pragma unroll
+        for (int s = P::EARLY; s < P::ColList::N; ++s) lds[u].w[s][0] = lds[u].w[s][1] = lds[u].w[s][2] = lds[u].w[s][3] = 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
     bool f[kE];
     uint32_t hit[kE];
     uint64_t val[kE];
@@ -165,7 +180,7 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
         perr |= row < sub1 ? c.perr : 0u;
         d[e] = (uint64_t)(long long)P::KeyE::eval(c, e & 1) - (uint64_t)p.bm_min; // k < min wraps to a huge value
         f[e] = pass && d[e] <= p.bm_span;
-        val[e] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, e & 1));
+        if constexpr (!LATE) val[e] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, e & 1));
       }
 #pragma unroll
       for (int e = 0; e < kE; ++e) w[e] = p.bm_bits[f[e] ? d[e] >> 6 : 0];
@@ -175,18 +190,25 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
         f[e] = f[e] && (w[e] & bit) != 0;
         hit[e] = (uint32_t)__popcll(w[e] & (bit - 1));
       }
-      uint32_t pre[kE];
+      // (the word ranks and chunk bases are fetched for the rows that hit only — measured: sending all three gathers out
+      // together for every row that passed the predicate costs 25 µs more than the two round trips it saves)
+      if constexpr (P::KEYBIT) {
 #pragma unroll
-      for (int e = 0; e < kE; ++e) pre[e] = p.bm_prefix[f[e] ? d[e] >> 6 : 0];
+        for (int e = 0; e < kE; ++e) hit[e] = (uint32_t)d[e];
+      } else {
+        uint32_t pre[kE];
 #pragma unroll
-      for (int e = 0; e < kE; ++e) hit[e] += pre[e];
-      if (p.bm_base) { // (uniform) chunk-local word ranks: + the set bits before the chunk
-#pragma unroll
-        for (int e = 0; e < kE; ++e) pre[e] = p.bm_base[f[e] ? (d[e] >> 6) >> p.bm_chunk_shift : 0];
+        for (int e = 0; e < kE; ++e) pre[e] = p.bm_prefix[f[e] ? d[e] >> 6 : 0];
 #pragma unroll
         for (int e = 0; e < kE; ++e) hit[e] += pre[e];
+        if (p.bm_base) { // (uniform) chunk-local word ranks: + the set bits before the chunk
+#pragma unroll
+          for (int e = 0; e < kE; ++e) pre[e] = p.bm_base[f[e] ? (d[e] >> 6) >> p.bm_chunk_shift : 0];
+#pragma unroll
+          for (int e = 0; e < kE; ++e) hit[e] += pre[e];
+        }
       }
-      if (!by_rank) {
+      if (!P::KEYBIT && !by_rank) {
         uint32_t g[kE];
 #pragma unroll
         for (int e = 0; e < kE; ++e) g[e] = p.bm_group[f[e] ? hit[e] : 0];
@@ -202,6 +224,16 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
         perr |= row < sub1 ? c.perr : 0u;
         hit[e] = pass ? ht_find(p, (long long)P::KeyE::eval(c, e & 1)) : 0xFFFFFFFFu; // probe only for surviving rows
         f[e] = hit[e] != 0xFFFFFFFFu;
+        if constexpr (!LATE) val[e] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, e & 1));
+      }
+    }
+    if constexpr (LATE) { // the value columns of the pairs that hold a joining row, then the values
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u)
+        if (f[2 * u] | f[2 * u + 1]) load_range<typename P::ColList, P::EARLY, P::ColList::N>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+#pragma unroll
+      for (int e = 0; e < kE; ++e) {
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + r0 + (e >> 1) * 128 + lane * 2 + (e & 1)};
         val[e] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, e & 1));
       }
     }
