@@ -1113,6 +1113,9 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
   for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
   uint32_t err = 0, done_err = 0, done_tile = 0;
   bool fresh = false; // the image holds a finished tile that awaits its reduction
+  // (Measured, r03: requesting the NEXT group of U steps before this one is accumulated — a second Loaded[U], free in
+  // registers at two waves per SIMD — is slower here: Q1 0.359 → 0.370 ms, the 12-lane state 0.338 → 0.368 ms; the
+  // register-state kernel's late form does gain from it.  profiles/r03/lds_rmw_experiment.txt)
 
   TileDesc td = load_tile_desc(p.tiles, tile);
   TileDesc td_next = load_tile_desc(p.tiles, tile + 1 < tile_end ? tile + 1 : tile);

@@ -511,6 +511,7 @@ hipError_t hj_launch_run_sums(const uint32_t *group, const uint64_t *val, uint64
 // the stripes follow one another in row order, so a run of equal groups may continue into the next stripes that have
 // pairs.  One wave per stripe; the first pair of a run walks it to its end, across stripes.  counts[s] carries the
 // predicate-error mark of the probe (kPredErrorBit): it is raised into flags[1]; flags[0] as `multi_run` above.
+__device__ __forceinline__ uint64_t desc_order_key(double v); // (top-k section below)
 // key-bit position → group id (RankCols, join.hpp)
 __device__ __forceinline__ uint32_t rank_of_keybit(const RankCols &r, uint32_t d) {
   const uint32_t word = d >> 6;
@@ -519,9 +520,10 @@ __device__ __forceinline__ uint32_t rank_of_keybit(const RankCols &r, uint32_t d
   if (r.base) g += r.base[word >> r.chunk_shift];
   return g;
 }
-__global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
-                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank) {
-  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+// one wave = one stripe; my_best / my_groups: the best run this lane finished (as ~order key: 0 = none) and how many
+__device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
+                                                double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, const RankCols &rank, uint32_t slot,
+                                                unsigned long long &my_best, unsigned long long &my_groups) {
   if (slot >= n_slots) return;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t raw = counts[slot];
@@ -575,15 +577,42 @@ __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t
       const uint32_t gid = rank.bits ? rank_of_keybit(rank, g) : g; // (one rank per run instead of one per probed row)
       if (atomicAdd(&count_by_group[gid], n) != 0) atomicOr(&flags[0], 1u);
       sum_by_group[gid] = acc;
+      const unsigned long long inv = ~desc_order_key(acc);
+      my_best = inv > my_best ? inv : my_best;
+      ++my_groups;
     }
     __builtin_amdgcn_wave_barrier(); // the chunk is overwritten next
   }
 }
+__global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
+                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank,
+                                                                   unsigned long long *slice_best) {
+  unsigned long long my_best = 0, my_groups = 0;
+  run_sums_stripe(stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group, count_by_group, flags, rank, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), my_best, my_groups);
+  if (slice_best) { // the top-k selection's first pass, on the way: the best sum and the number of groups of slice (workgroup mod kTopkSlices)
+    __shared__ unsigned long long wb[4], wg[4];
+    for (int o = 32; o; o >>= 1) {
+      const unsigned long long other = __shfl_xor(my_best, o);
+      my_best = other > my_best ? other : my_best;
+      my_groups += __shfl_xor(my_groups, o);
+    }
+    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = my_best; wg[threadIdx.x >> 6] = my_groups; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long b = wb[0], g = wg[0];
+      for (int w = 1; w < 4; ++w) { b = wb[w] > b ? wb[w] : b; g += wg[w]; }
+      if (g) {
+        (void)__hip_atomic_fetch_max(&slice_best[blockIdx.x & (kTopkSlices - 1)], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(&slice_best[kTopkSlices + (blockIdx.x & (kTopkSlices - 1))], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
-                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank) {
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank, uint64_t *slice_best) {
   if (n_slots == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_run_sums_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group,
-                     (unsigned long long *)count_by_group, flags, rank);
+                     (unsigned long long *)count_by_group, flags, rank, (unsigned long long *)slice_best);
   return hipGetLastError();
 }
 // the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
@@ -1219,9 +1248,45 @@ __global__ __launch_bounds__(1024) void hj_topk_bound_kernel(const double *sums,
 }
 __global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *sums, const uint64_t *counts, uint64_t n, uint64_t *state, uint32_t cap, uint32_t *groups,
                                                                 const uint64_t *dim_rows, CandidateCols cols, uint64_t *host_out, GatherItems extra, uint32_t *extra_host,
-                                                                const uint32_t *n_dev) {
+                                                                const uint32_t *n_dev, const uint64_t *slice_best, uint32_t want_m1) {
   if (n_dev) n = *n_dev;
-  const uint64_t bound = state[0];
+  __shared__ uint64_t sv[kTopkSlices];
+  __shared__ uint64_t s_bound, s_total;
+  uint64_t bound, total_groups;
+  if (slice_best) {
+    // the first launch's work came with the run sums (hj_run_sums_stripes: slice_best[slice] = ~best key, [kTopkSlices + slice] =
+    // groups): every workgroup orders the 256 slice winners itself — the want-th is the bound — instead of waiting for a
+    // launch that does it once
+    const uint32_t t = threadIdx.x;
+    uint64_t a = t < kTopkSlices ? ~slice_best[t] : ~0ull; // (an empty slice holds 0: the key ~0, behind every real one)
+    uint64_t groups = t < kTopkSlices ? slice_best[kTopkSlices + t] : 0;
+    for (uint32_t k = 2; k <= kTopkSlices; k <<= 1)
+      for (uint32_t j = k >> 1; j; j >>= 1) {
+        uint64_t b = a;
+        if (j >= 64) {
+          if (t < kTopkSlices) sv[t] = a;
+          __syncthreads();
+          if (t < kTopkSlices) b = sv[t ^ j];
+          __syncthreads();
+        } else {
+          b = __shfl_xor(a, (int)j);
+        }
+        const bool up = (t & k) == 0, lower = (t & j) == 0;
+        const uint64_t mn = a < b ? a : b, mx = a < b ? b : a;
+        a = lower == up ? mn : mx;
+      }
+    for (int o = 32; o; o >>= 1) groups += __shfl_xor(groups, o);
+    if ((t & 63) == 0 && t < kTopkSlices) sv[t >> 6] = groups;
+    __syncthreads();
+    if (t == want_m1) s_bound = a;
+    if (t == 0) s_total = sv[0] + sv[1] + sv[2] + sv[3];
+    __syncthreads();
+    bound = s_bound;
+    total_groups = s_total;
+  } else {
+    bound = state[0];
+    total_groups = state[2];
+  }
   uint32_t *counter = reinterpret_cast<uint32_t *>(state + 1);
   for (uint64_t i0 = (uint64_t)blockIdx.x * 4096 + threadIdx.x; i0 < n; i0 += (uint64_t)gridDim.x * 4096) {
     uint64_t c[4];
@@ -1243,7 +1308,7 @@ __global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *su
   const uint32_t total = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t n_rec = total < cap ? total : cap;
   auto to_host = [](uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-  if (threadIdx.x < 8) to_host(&host_out[threadIdx.x], threadIdx.x == 0 ? bound : threadIdx.x == 1 ? total : threadIdx.x == 2 ? state[2] : 0);
+  if (threadIdx.x < 8) to_host(&host_out[threadIdx.x], threadIdx.x == 0 ? bound : threadIdx.x == 1 ? total : threadIdx.x == 2 ? total_groups : 0);
   for (uint32_t r = threadIdx.x; r < n_rec; r += 1024) {
     uint64_t *o = host_out + 8 + (uint64_t)r * 8;
     const uint32_t g = __hip_atomic_load(&groups[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1260,13 +1325,14 @@ __global__ __launch_bounds__(1024) void hj_topk_collect2_kernel(const double *su
 }
 hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
                                   uint64_t *best, uint64_t *state, uint32_t *groups, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
-                                  hipStream_t s, const uint32_t *n_dev) {
+                                  hipStream_t s, const uint32_t *n_dev, const uint64_t *slice_best) {
   if (n == 0 || want == 0 || want > kTopkSlices) return hipErrorInvalidValue;
   const uint64_t per = (n + kTopkSlices - 1) / kTopkSlices;
   const uint32_t n_slices = n_dev ? kTopkSlices : (uint32_t)((n + per - 1) / per);
-  hipLaunchKernelGGL(hj_topk_bound_kernel, dim3(n_slices), dim3(1024), 0, s, sums, counts, n, per, want, best, state, n_dev);
+  if (!slice_best) hipLaunchKernelGGL(hj_topk_bound_kernel, dim3(n_slices), dim3(1024), 0, s, sums, counts, n, per, want, best, state, n_dev);
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 4095) / 4096, 256);
-  hipLaunchKernelGGL(hj_topk_collect2_kernel, dim3(grid), dim3(1024), 0, s, sums, counts, n, state, cap, groups, dim_rows, cols, host_out, extra, extra_host, n_dev);
+  hipLaunchKernelGGL(hj_topk_collect2_kernel, dim3(grid), dim3(1024), 0, s, sums, counts, n, state, cap, groups, dim_rows, cols, host_out, extra, extra_host, n_dev, slice_best,
+                     want - 1);
   return hipGetLastError();
 }
 

@@ -188,7 +188,8 @@ struct RankCols {
   uint32_t chunk_shift;
 };
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
-                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank = RankCols{nullptr, nullptr, nullptr, 0});
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank = RankCols{nullptr, nullptr, nullptr, 0},
+                                      uint64_t *slice_best = nullptr /* [2 · kTopkSlices], zero: the top-k selection's slice winners (~best key) and group counts, on the way */);
 // `descending` (optional): raised when a run starts below the group of the pair before it
 hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
                                   uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s, uint32_t *descending = nullptr);
@@ -275,7 +276,7 @@ constexpr uint32_t kTopkSlices = 256;
 // `n_dev` (optional): the number of groups is still on the device (then `n` only bounds it).
 hipError_t hj_launch_topk_select2(const double *sums, const uint64_t *counts, uint64_t n, uint32_t want, uint32_t cap, const uint64_t *dim_rows, CandidateCols cols,
                                   uint64_t *best, uint64_t *state, uint32_t *groups /*[cap]*/, uint64_t *host_out, const GatherItems &extra, uint32_t *extra_host,
-                                  hipStream_t s, const uint32_t *n_dev = nullptr);
+                                  hipStream_t s, const uint32_t *n_dev = nullptr, const uint64_t *slice_best = nullptr /* filled by hj_launch_run_sums_stripes: no first launch */);
 hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out, hipStream_t s);
 // Range form of a sharded fact table: the first and the last run of a pair stream with their key bits and raw values
 // (join.hip: hj_boundary_runs_kernel; out = 8 + 2 · cap words of device memory)

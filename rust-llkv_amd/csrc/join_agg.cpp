@@ -184,6 +184,7 @@ struct JoinAgg {
   DB zeros;                          // one zeroed block: [0] the run flag, [8..15] the top-k selection's state words
   uint32_t *multi_p() const { return static_cast<uint32_t *>(zeros.p); }
   uint64_t *topk_state() const { return static_cast<uint64_t *>(zeros.p) + 8; }
+  uint64_t *slice_best() const { return static_cast<uint64_t *>(zeros.p) + 32; } // [2 · kTopkSlices]: ~best key and groups of every slice (hj_launch_run_sums_stripes)
   uint32_t dup_keys = 0, key_err = 0, multi_run = 0;
   size_t state_bytes = 0;
   std::vector<uint32_t> st_groups;   // straddler pairs of this rank (host)
@@ -260,9 +261,9 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     if (range_form && !ranked) return set_error(LLKV_UNSUPPORTED, "range form: the dimension key must be an Int64 column in ascending row order with a statistics-bounded range");
   if ((sink_bits || ranked) && (rc = dt.prepare_bits(kd_info, s, &fr))) return rc;
     dt.in_key_order = dim_sorted;
-    if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8)) || (rc = zeros.alloc(256))) return rc;
+    if ((rc = counts.alloc((size_t)(n_slots + 1) * 8)) || (rc = offsets.alloc((size_t)(n_slots + 1) * 8)) || (rc = zeros.alloc(256 + 2 * kTopkSlices * 8))) return rc;
     fr.add(counts.p, (size_t)(n_slots + 1) * 8); // the extra trailing 0 makes offsets[n_slots] the total
-    fr.add(zeros.p, 256);
+    fr.add(zeros.p, 256 + 2 * kTopkSlices * 8);  // (… and the top-k selection's slice winners, which the run sums fill on the way)
     HIP_TRY(hj_launch_fill_zero_ranges(fr, s));
   }
   if (t2) {
@@ -527,7 +528,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   from_stripes = defer && direct && tf->world == 1 && !std::getenv("LLKV_HIP_JOIN_COMPACT");
   if (from_stripes) {
     HIP_TRY(hj_launch_run_sums_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, n_slots, stripe, (double *)sums.p,
-                                       (uint64_t *)cnts.p, multi_p(), s, keybit_stripes ? stripe_ranks : RankCols{nullptr, nullptr, nullptr, 0}));
+                                       (uint64_t *)cnts.p, multi_p(), s, keybit_stripes ? stripe_ranks : RankCols{nullptr, nullptr, nullptr, 0}, slice_best()));
   } else if ((rc = compact_pairs(true))) {
     return rc;
   }
@@ -691,8 +692,12 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     GatherItems extra;
     uint32_t *slab_base = nullptr;
     if ((rc = rb.reserve(nullptr, 64 + (size_t)kCap * 64, s, &slab)) || (rc = rb.take(&extra, &slab_base))) return rc;
+    // (sums straight from the stripes, nothing patched in: the first launch's slice winners came with the run sums — if some
+    // group turns out to have had two runs, everything is redone below)
+    const bool winners_known = pending && from_stripes && alone && mg.empty() && !std::getenv("LLKV_HIP_TOPK_TWO_LAUNCHES");
     HIP_TRY(hj_launch_topk_select2((const double *)sums.p, report_p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p, topk_state(),
-                                   (uint32_t *)groups_d.p, (uint64_t *)slab, extra, slab_base, s, ranked && pending ? n_dim_ptr() : nullptr));
+                                   (uint32_t *)groups_d.p, (uint64_t *)slab, extra, slab_base, s, ranked && pending ? n_dim_ptr() : nullptr,
+                                   winners_known ? slice_best() : nullptr));
     if ((rc = rb.wait())) return rc;
     if (pending) {
       if ((rc = settle(true))) return rc;
