@@ -321,10 +321,15 @@ template <class P> __device__ __forceinline__ void keybits_body(const ScanParams
   const uint32_t quarter = (td.rows + 3) / 4 + 127 & ~127u;
   const uint32_t sub0 = wave * quarter < td.rows ? wave * quarter : td.rows;
   const uint32_t sub1 = sub0 + quarter < td.rows ? sub0 + quarter : td.rows;
-  for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
-    Loaded lds[kSelUnroll];
+  // the batch in hand was requested one iteration ago; the next one goes out behind this batch's key-set gather (loads
+  // retire in order: the wait for the gather does not wait for it)
+  Loaded lds[kSelUnroll], nxt[kSelUnroll];
+  if (sub0 < sub1) {
 #pragma unroll
-    for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+    for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + sub0 + u * 128 + lane * 2, lds[u]);
+  }
+  for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
+    const bool more = r0 + 128 * kSelUnroll < sub1;
     bool fe[2 * kSelUnroll];
     long long key[2 * kSelUnroll];
     if constexpr (GatherSplit<typename P::Pred>::value) {
@@ -342,9 +347,17 @@ template <class P> __device__ __forceinline__ void keybits_body(const ScanParams
       }
 #pragma unroll
       for (int e = 0; e < 2 * kSelUnroll; ++e) w[e] = p.bm_bits[fe[e] ? d[e] >> 6 : 0];
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + 128 * kSelUnroll + u * 128 + lane * 2, nxt[u]);
+      }
 #pragma unroll
       for (int e = 0; e < 2 * kSelUnroll; ++e) fe[e] = fe[e] && ((w[e] >> (d[e] & 63)) & 1ull) != 0;
     } else {
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) load_all<typename P::ColList>(p, td.dev_row + r0 + 128 * kSelUnroll + u * 128 + lane * 2, nxt[u]);
+      }
 #pragma unroll
       for (int e = 0; e < 2 * kSelUnroll; ++e) {
         const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
@@ -361,6 +374,10 @@ template <class P> __device__ __forceinline__ void keybits_body(const ScanParams
       // (measured: gathering a tile's words in the LDS first and storing them whole — the keys of a tile of an ascending
       // column fall between its first and last key — is no faster than these atomics: 92 vs 90 µs over 15 M orders)
       if (fe[e] && wanted && d <= p.kb_span) atomicOr(&bits[d >> 6], 1ull << (d & 63));
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) lds[u] = nxt[u];
     }
   }
   if (perr) atomicOr(p.aux_out32, perr);

@@ -2362,6 +2362,57 @@ def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
         assert np.float64(g[1]).tobytes() == np.float64(w[1]).tobytes(), (g, w)  # bit-exact revenue
 
 
+def test_late_materialisation_and_its_eager_forms_give_the_same_bits(rt, abi, tpch, monkeypatch):
+    """Argument-only columns read late (Plan::EARLY, ProbePlan EARLY / KEYBIT) and the top-k selection's slice winners taken from
+    the run sums are the SAME computation as their eager forms — same rows, same order of additions: every switch leaves
+    every bit of Q6, of a selective two-aggregate scan and of the Q3 pipeline where it was."""
+    rows, scale = 300_000, 0.05
+    li = tpch.gen_lineitem(rows, scale)
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    n_cust = tpch.customers_for_scale(scale)
+    cu = tpch.gen_customer(n_cust, scale)
+    lt = rt.HipTable(1, tpch.chunk_rows(rows, 65536))
+    for c in ("l_orderkey", "l_shipdate", "l_quantity", "l_extendedprice", "l_discount"):
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c])
+    ot_ = rt.HipTable(2, tpch.chunk_rows(n_ord, 65536))
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c])
+    ct = rt.HipTable(3, tpch.chunk_rows(n_cust, 65536))
+    ct.append_column(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"])
+    ct.append_utf8_column(tpch.C_MKTSEGMENT, [tpch.SEGMENTS[c] for c in cu["c_mktsegment"]])
+    A, F, O, B, col = abi.AggregateSpec, abi.Filter, abi.Operator, abi.Bound, abi.col
+    D = tpch.DATE_1995_03_15
+    price, disc, qty = tpch.L_EXTENDEDPRICE, tpch.L_DISCOUNT, tpch.L_QUANTITY
+    q6 = tpch.q6()
+    scans = [(q6.predicate, q6.aggs), ([F(qty, O.LessThan(3))], [A.sum(price), A.sum(col(price) * col(disc)), A.min(price), A.count_star()]),
+             ([F(qty, O.LessThan(60))], [A.sum(price), A.avg(disc)])]
+
+    def run_all():
+        out, sigs = [], []
+        for pred, aggs in scans:
+            q = rt.PreparedQuery(lt, pred, aggs)
+            sigs.append(q.kernel_signature)
+            out.append([(v.dtype, v.is_null, np.float64(v.value).tobytes() if isinstance(v.value, float) else v.value) for v in q.run()[0].values])
+            q.close()
+        top, total = rt.join_groupby_topk(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY,
+                                          col(price) * (1 - col(disc)), payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10, dim_fk=tpch.O_CUSTKEY, dim2=ct,
+                                          dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+        out.append([(g[0], np.float64(g[1]).tobytes(), g[2], g[3], g[4]) for g in top] + [total])
+        return out, sigs
+
+    base, sigs = run_all()
+    assert all(s.endswith(",0,1,%d>" % n) for s, n in zip(sigs, (3, 1, 1))), sigs  # the late form is what runs by default
+    assert base[3][-1] > 0 and len(base[3]) == 11
+    for switch in ("LLKV_HIP_SCAN_NO_LATE", "LLKV_HIP_JOIN_NO_LATE", "LLKV_HIP_JOIN_PROBE_RANKS", "LLKV_HIP_TOPK_TWO_LAUNCHES"):
+        monkeypatch.setenv(switch, "1")
+        got, sigs2 = run_all()
+        monkeypatch.delenv(switch)
+        assert got == base, switch
+        if switch == "LLKV_HIP_SCAN_NO_LATE":
+            assert all(s.endswith(",0>") for s in sigs2), sigs2
+
+
 @pytest.mark.parametrize("n_orders,limit", [(1500, 10), (40_000, 10), (40_000, 300)])
 def test_join_groupby_topk_with_tied_sums(rt, abi, n_orders, limit):
     """Top-k by selection (slice winners → threshold → candidates → exact host order): thousands of groups share
