@@ -81,7 +81,9 @@ static uint32_t pick_tile_rows(const LoweredPlan &p) {
     long v = std::atol(e);
     if (v >= 512 && v % 512 == 0) return (uint32_t)v;
   }
-  return p.acc_lds ? 16384u : 4096u;
+  // (the late form of a register-state plan requests the next group of U steps while it works on this one — inside a tile:
+  // 8 192 rows = four groups; Q6 SF10 226 / 212 / 219 µs and SF1 32.2 / 28.7 / 31.5 µs at 4 096 / 8 192 / 16 384)
+  return p.acc_lds ? 16384u : p.late_columns ? 8192u : 4096u;
 }
 
 // Workgroups of a shared-image scan (1024 threads each, persistent: workgroup b takes tiles b, b + g, …): one per CU.

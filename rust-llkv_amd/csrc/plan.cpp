@@ -1535,6 +1535,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   // Plan::EARLY, late materialisation — Q6 reads 20 B of every row and the price of the 2 % that pass)
   const bool late = !p.acc_part && !p.acc_image && !p.acc_lds && pred != "True" && pred != "False" && early_slots > 0 && early_slots < p.slot_fields.size() &&
                     !std::getenv("LLKV_HIP_SCAN_NO_LATE");
+  p.late_columns = late;
   p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_part ? "3" : p.acc_image ? "2" : p.acc_lds ? "1" : "0") +
                   (late ? ",1," + std::to_string(early_slots) : p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
   return LLKV_OK;

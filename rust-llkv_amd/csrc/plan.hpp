@@ -76,6 +76,7 @@ struct AggOut {
 struct LoweredPlan {
   std::string type_string;            // "Plan<Cols<...>,<pred>,Keys<...>,Aggs<...>,U>"
   std::vector<uint32_t> slot_fields;  // slot → field id
+  bool late_columns = false;          // register-state plan whose argument-only columns are read for the passing rows (Plan::EARLY)
   std::vector<int32_t> slot_dtypes;   // slot → llkv_dtype (UTF8 = 1-byte codes)
   std::vector<uint8_t> slot_is_valid; // what of the field the slot reads: 0 its values, 1 its validity mask (1 B/row), 2 the high halves of a wide Decimal128 column
   std::vector<int64_t> lit_i;

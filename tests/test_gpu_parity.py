@@ -2406,8 +2406,11 @@ def test_late_materialisation_and_its_eager_forms_give_the_same_bits(rt, abi, tp
     assert base[3][-1] > 0 and len(base[3]) == 11
     for switch in ("LLKV_HIP_SCAN_NO_LATE", "LLKV_HIP_JOIN_NO_LATE", "LLKV_HIP_JOIN_PROBE_RANKS", "LLKV_HIP_TOPK_TWO_LAUNCHES"):
         monkeypatch.setenv(switch, "1")
+        if switch == "LLKV_HIP_SCAN_NO_LATE":
+            monkeypatch.setenv("LLKV_HIP_TILE_ROWS", "8192")  # (the tile is the unit of the reduction: the late form's tile length)
         got, sigs2 = run_all()
         monkeypatch.delenv(switch)
+        monkeypatch.delenv("LLKV_HIP_TILE_ROWS", raising=False)
         assert got == base, switch
         if switch == "LLKV_HIP_SCAN_NO_LATE":
             assert all(s.endswith(",0>") for s in sigs2), sigs2
