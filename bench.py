@@ -474,6 +474,7 @@ def main():
     # library's collectives go through a host transport over gloo (llkv_hip_comm_init_custom) instead of RCCL, which
     # refuses two ranks on one device.  Not a measurement.
     rehearsal = bool(os.environ.get("LLKV_BENCH_HOST_TRANSPORT"))
+    collective_backend = "host transport over gloo (rehearsal)" if rehearsal else "RCCL"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -492,7 +493,20 @@ def main():
         # ncclUniqueId, the barriers and the max-over-ranks clock of the bench contract
         uid = [rt.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        rt.comm_init(uid[0], rank, world)
+        ok, why = 1, ""
+        try:
+            rt.comm_init(uid[0], rank, world)
+        except Exception as e:  # every rank must take the same road: agree, then fall back together
+            ok, why = 0, str(e)
+        agreed = torch.tensor([ok], device="cuda")
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            try:
+                rt.comm_destroy()
+            except Exception:
+                pass
+            rt.comm_init_torch(dist, rank, world, group=dist.new_group(backend="gloo"))
+            collective_backend = "host transport over gloo (the library's RCCL communicator could not be created" + (": " + why if why else " on another rank") + ")"
 
     main_res = measure(rt, tpch, abi, torch, dist, args.workload, rank, world, args.scaling, args.steps, args.warmup)
     rows_total = main_res["total_rows"]
@@ -515,7 +529,7 @@ def main():
         "config": {
             "workload": f"{shape}, columns resident in HBM, {main_res['query'].bytes_per_row} B/row algorithmic",
             "sharding": (f"{args.scaling}: by chunk (131072 rows) into 8 canonical octants, rank r owns octants [r·8/N, (r+1)·8/N); "
-                         "one RCCL all-reduce (int64 sum) of the partial aggregate state per execution") if world > 1 else "single GPU",
+                         f"one all-reduce (int64 sum) of the partial aggregate state per execution, {collective_backend}") if world > 1 else "single GPU",
             "kernel": main_res["signature"],
         },
         "roofline": {
