@@ -292,6 +292,7 @@ struct StagePiece {
   size_t bytes;
 };
 int stage_to_device(const std::vector<StagePiece> &pieces);
+int stage_from_pinned(void *d_dst, const void *h_pinned, size_t bytes); // (a block of pinned_acquire)
 void staging_totals(uint64_t *bytes, double *seconds);
 void staging_release();
 // HBM → pageable host memory through the staging lanes (pinned rings, one copier thread each); the streams used are

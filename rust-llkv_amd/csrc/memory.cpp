@@ -262,6 +262,19 @@ int fetch_to_host(void *h_dst, const void *d_src, size_t bytes) {
 }
 
 int stage_to_device(const std::vector<StagePiece> &pieces) { return g_stager.run(pieces); }
+// … from a block of the pinned cache (pinned_acquire): one direct DMA, nothing to register and nothing to bounce
+int stage_from_pinned(void *d_dst, const void *h_pinned, size_t bytes) {
+  if (bytes == 0) return LLKV_OK;
+  std::lock_guard<std::mutex> lk(g_stager.mu);
+  int rc = g_stager.init();
+  if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemcpyAsync(d_dst, h_pinned, bytes, hipMemcpyHostToDevice, g_stager.lanes[0].stream));
+  HIP_TRY(hipStreamSynchronize(g_stager.lanes[0].stream));
+  g_stager.staged_bytes += bytes;
+  g_stager.staged_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return LLKV_OK;
+}
 void staging_totals(uint64_t *bytes, double *seconds) {
   std::lock_guard<std::mutex> lk(g_stager.mu);
   if (bytes) *bytes = g_stager.staged_bytes;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <thread>
@@ -338,6 +339,14 @@ llkv_status llkv_hip_table_append_column(llkv_hip_table *table, uint32_t field_i
   return LLKV_OK;
 }
 
+// every string of the chunk is one byte long (then string r is the byte data[off[0] + r])
+static bool all_unit_strings(const int32_t *off, uint64_t rows) {
+  if (rows == 0 || (int64_t)off[rows] - (int64_t)off[0] != (int64_t)rows) return false;
+  uint32_t bad = 0;
+  for (uint64_t r = 0; r < rows; ++r) bad |= (uint32_t)(off[r + 1] - off[r]) ^ 1u; // (branch-free: vectorises)
+  return bad == 0;
+}
+
 llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t field_id,
                                               const int32_t *const *chunk_offsets, const uint8_t *const *chunk_data,
                                               uint32_t n_chunks, const char *const *dictionary, uint32_t dict_size) {
@@ -356,8 +365,25 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
   // dictionary-encode on the host at staging (SURVEY.md §7 "Utf8 group keys"): 1 B/row in HBM
   // (not value-initialised: 60 MB of zeroes written by one thread cost as much as coding the column on sixteen; the padding
   // rows between ragged chunks are zeroed below, every other byte is written by the coding pass)
-  std::unique_ptr<uint8_t[]> codes_buf(new uint8_t[t->dev_rows + 16]);
-  struct { uint8_t *p; uint8_t *data() const { return p; } } codes{codes_buf.get()};
+  const bool trace = std::getenv("LLKV_HIP_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[llkv utf8 staging] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  // … and not a fresh heap block either: 60 MB of new pages are faulted in while they are written, pinned for the copy and
+  // unmapped on the way out (≈ 10 ms a column at SF10) — a recycled block of the pinned cache is written and copied at once
+  size_t codes_bytes = (size_t)t->dev_rows + 16;
+  struct PinnedBlock {
+    void *p = nullptr; size_t bytes = 0;
+    ~PinnedBlock() { if (p) pinned_release(p, bytes); }
+  } codes_block;
+  codes_block.p = pinned_acquire(&codes_bytes);
+  codes_block.bytes = codes_bytes;
+  if (!codes_block.p) return (llkv_status)set_error(LLKV_INTERNAL, "no pinned host memory for the dictionary codes");
+  struct { uint8_t *p; uint8_t *data() const { return p; } } codes{static_cast<uint8_t *>(codes_block.p)};
   for (uint32_t i = 0; i < n_chunks; ++i) {
     const uint64_t end = t->chunk_dev_off[i] + t->global_chunk_rows[t->first_chunk + i];
     std::memset(codes.data() + end, 0, t->chunk_dev_off[i + 1] - end);
@@ -370,6 +396,7 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
     if (!dict.emplace(s, (uint8_t)d).second) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "duplicate dictionary entry '" + s + "'");
     c.info.dictionary.push_back(s);
   }
+  mark("buffer");
   if (!fixed) {
     // codes follow the order of first appearance: every chunk lists its distinct values in that order (in
     // parallel), the lists are merged in chunk order
@@ -380,6 +407,12 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
       const uint8_t *data = chunk_data[i];
       bool one_byte[256] = {};
       std::map<std::string, int> local;
+      if (all_unit_strings(off, rows)) { // a chunk of 1-byte strings (TPC-H flags): the byte is the string
+        const uint8_t *b = data + off[0];
+        for (uint64_t r = 0; r < rows; ++r)
+          if (!one_byte[b[r]]) { one_byte[b[r]] = true; seen[i].emplace_back(1, (char)b[r]); }
+        return LLKV_OK;
+      }
       for (uint64_t r = 0; r < rows; ++r) {
         const int32_t len = off[r + 1] - off[r];
         if (len == 1) {
@@ -402,6 +435,7 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
           c.info.dictionary.push_back(s);
         }
   }
+  mark("distinct values");
   rc = for_each_chunk_parallel(n_chunks, [&](uint32_t i) -> int {
     const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
     const int32_t *off = chunk_offsets[i];
@@ -415,6 +449,19 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
       *out = it->second;
       return LLKV_OK;
     };
+    if (all_unit_strings(off, rows)) {
+      uint8_t code_of_byte[256];
+      bool known[256] = {};
+      const uint8_t *b = data + off[0];
+      for (uint64_t r = 0; r < rows; ++r) { // (first: which bytes occur — a dictionary miss is reported before anything is written)
+        if (known[b[r]]) continue;
+        int e;
+        if ((e = code_of(std::string(1, (char)b[r]), &code_of_byte[b[r]]))) return e;
+        known[b[r]] = true;
+      }
+      for (uint64_t r = 0; r < rows; ++r) dst[r] = code_of_byte[b[r]];
+      return LLKV_OK;
+    }
     for (uint64_t r = 0; r < rows; ++r) {
       const int32_t len = off[r + 1] - off[r];
       int e;
@@ -433,9 +480,12 @@ llkv_status llkv_hip_table_append_utf8_column(llkv_hip_table *table, uint32_t fi
     return LLKV_OK;
   });
   if (rc) return (llkv_status)rc;
+  mark("codes");
   if ((rc = alloc_column(*t, 1, &c.d_values))) return (llkv_status)rc;
   if (hipStreamSynchronize(g_ctx.stream) != hipSuccess) return (llkv_status)set_error(LLKV_INTERNAL, "staging copy failed");
-  if ((rc = stage_to_device({{c.d_values, codes.data(), (size_t)t->dev_rows}}))) return (llkv_status)rc;
+  mark("device buffer");
+  if ((rc = stage_from_pinned(c.d_values, codes.data(), (size_t)t->dev_rows))) return (llkv_status)rc;
+  mark("copy");
   t->cols.emplace(field_id, std::move(c));
   return LLKV_OK;
 }
