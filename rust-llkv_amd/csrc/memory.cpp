@@ -102,9 +102,12 @@ struct StagerPool {
   uint64_t staged_bytes = 0;
   double staged_seconds = 0;
 
-  int init() {
-    if (ready) return LLKV_OK;
-    for (Lane &l : lanes) {
+  // lanes [0, n) exist (streams, rings, events); the others are made when a call first wants them — a cold first query that
+  // pins its columns in place uses two lanes, and 28 more pinned ring buffers cost it 20–30 ms for nothing
+  int init(int n = 1) {
+    for (int k = 0; k < n && k < kLanes; ++k) {
+      Lane &l = lanes[k];
+      if (l.stream) continue;
       HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
       for (int i = 0; i < kDepth; ++i) {
         HIP_TRY(hipHostMalloc(&l.pinned[i], kBuf, hipHostMallocDefault));
@@ -154,8 +157,7 @@ struct StagerPool {
   }
   int run(const std::vector<StagePiece> &pieces_in, bool to_host = false) {
     std::lock_guard<std::mutex> lk(mu);
-    int rc = init();
-    if (rc) return rc;
+    int rc;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<StagePiece> seg;
     size_t total = 0;
@@ -229,9 +231,12 @@ struct StagerPool {
         if (!drain((l.cur + k) % kDepth)) return;
       if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) fail(e);
     };
-    size_t lane_limit = kLanes;
+    // pinned in place: two lanes saturate the link (54 GB/s) and more of them only contend for the address space's lock in
+    // hipHostRegister (SF10 Q1 columns: 55–57 ms with 2, 57–96 with 4, 71–99 with 16); the bounce copy wants the memcpy threads
+    size_t lane_limit = in_place ? 2 : kLanes;
     if (const char *e = std::getenv("LLKV_HIP_STAGE_LANES")) lane_limit = std::max(1, std::min<int>(kLanes, std::atoi(e)));
     const int n_threads = (int)std::min<size_t>(std::min<size_t>(lane_limit, host_thread_limit()), (total + (4u << 20) - 1) / (4u << 20)); // small columns: one lane
+    if ((rc = init(std::max(1, n_threads)))) return rc;
     std::vector<std::thread> threads;
     for (int k = 1; k < n_threads; ++k) threads.emplace_back(work, std::ref(lanes[k]));
     work(lanes[0]);
