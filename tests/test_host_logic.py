@@ -267,6 +267,32 @@ def test_expression_typing_rules(lib, abi):
     assert e.value.kind == "InvalidArgumentError" and "not supported for column type Int32" in e.value.message
 
 
+def test_constant_folding_and_late_columns_in_the_lowering(lib, abi):
+    """ScalarEvaluator::simplify before typing (llkv-compute/src/eval.rs:761-791): literal ⊕ literal is one literal, a division
+    of constants is gone before the route is picked, a fold that errors is a plan nobody takes.  And the slot order the
+    late-materialising kernels rely on: predicate columns first, argument-only columns behind them (Plan<…,0,1,EARLY>)."""
+    rt = mod("runtime")
+    d = _desc(abi, [(1, abi.DT_INT64), (2, abi.DT_FLOAT64), (3, abi.DT_INT64)])
+    A, F, O, col, L = abi.AggregateSpec, abi.Filter, abi.Operator, abi.col, abi.ScalarExpr.literal
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * (L(2) + 3))])
+    assert "SumI64<Bin<3,Col<0,I64>,LitI<0>>>" in ts and "LitI<1>" not in ts
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * (L(1) / 4))])
+    assert "Div<" not in ts and "SumI64<Bin<3,Col<0,I64>,LitI<0>>>" in ts  # times the folded 0, on the fast path
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(2) * (L(1) / 4.0) + (L(3) - 1))])
+    assert "LitF<1>" in ts and "LitF<2>" not in ts and "Div<" not in ts  # two literals are left of the four
+    for bad in (col(1) + (L(2**62) + 2**62), col(1) + (L(5) % 0), col(1) * (L(-2**63) / -1), col(1) + (L(1) / 0)):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.lower_plan(d, None, [A.sum(bad)])
+        assert e.value.kind == "Unsupported", bad
+    # late columns: field 3 feeds the predicate (slot 0), fields 1 and 2 only the arguments
+    ts, _, _ = rt.lower_plan(d, [F(3, O.LessThan(7))], [A.sum(col(1) * 2), A.sum(2)])
+    assert ts.startswith("Plan<Cols<I64,I64,F64>,And<Range<Col<0,I64>") and ts.endswith(",0,1,1>"), ts
+    ts, _, _ = rt.lower_plan(d, [F(3, O.LessThan(7))], [A.sum(3), A.count_star()])
+    assert ts.endswith(",0>"), ts  # nothing is argument-only: the eager form
+    ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * 2)])
+    assert ts.endswith(",0>"), ts  # no predicate: every row passes
+
+
 def test_compare_lowering_follows_the_common_type_rules(lib, abi):
     """Expr::Compare (llkv-scan/src/predicate.rs:333-396): column ⋈ literal is the leaf filter; anything else
     is evaluated per side and coerced with get_common_type (llkv-compute/src/kernels.rs:179-242)."""
