@@ -1201,7 +1201,11 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     } else {
       rc = grouped ? L.expr_planvalue(s.expr, s.expr_len, &node, &is_f64) : L.expr_fast(s.expr, s.expr_len, &node, &is_f64);
       if (rc) return rc;
-      if ((rc = L.valid_of_node(s.expr, s.expr_len, node, grouped, &valid))) return rc;
+      // (what can make the value NULL is read off the expression the scan evaluates: the simplified one — a division of
+      // constants is gone from it)
+      std::vector<llkv_expr_token> folded;
+      if (!grouped && (rc = L.fold_constants(s.expr, s.expr_len, &folded))) return rc;
+      if ((rc = grouped ? L.valid_of_node(s.expr, s.expr_len, node, grouped, &valid) : L.valid_of_node(folded.data(), (uint32_t)folded.size(), node, grouped, &valid))) return rc;
     }
     if (s.kind == LLKV_AGG_COUNT || s.kind == LLKV_AGG_COUNT_NULLS) {
       // NULL-free argument: COUNT(x) = rows, COUNT_NULLS(x) = 0

@@ -279,7 +279,7 @@ def test_constant_folding_and_late_columns_in_the_lowering(lib, abi):
     ts, _, _ = rt.lower_plan(d, None, [A.sum(col(1) * (L(1) / 4))])
     assert "Div<" not in ts and "SumI64<Bin<3,Col<0,I64>,LitI<0>>>" in ts  # times the folded 0, on the fast path
     ts, _, _ = rt.lower_plan(d, None, [A.sum(col(2) * (L(1) / 4.0) + (L(3) - 1))])
-    assert "LitF<1>" in ts and "LitF<2>" not in ts and "Div<" not in ts  # two literals are left of the four
+    assert "LitF<1>" in ts and "LitF<2>" not in ts and "Div<" not in ts and "IfValid<" not in ts  # two literals are left of the four; nothing can be NULL
     for bad in (col(1) + (L(2**62) + 2**62), col(1) + (L(5) % 0), col(1) * (L(-2**63) / -1), col(1) + (L(1) / 0)):
         with pytest.raises(abi.LlkvError) as e:
             rt.lower_plan(d, None, [A.sum(bad)])
