@@ -523,13 +523,14 @@ __device__ __forceinline__ uint32_t rank_of_keybit(const RankCols &r, uint32_t d
 // one wave = one stripe; my_best / my_groups: the best run this lane finished (as ~order key: 0 = none) and how many
 __device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
                                                 double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, const RankCols &rank, uint32_t slot,
-                                                unsigned long long &my_best, unsigned long long &my_groups) {
+                                                unsigned long long &my_best, unsigned long long &my_groups, unsigned long long &my_pairs) {
   if (slot >= n_slots) return;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t raw = counts[slot];
   if (raw >= kPredErrorBit && lane == 0) atomicOr(&flags[1], 1u);
   const uint32_t cnt = (uint32_t)(raw & (kPredErrorBit - 1));
   if (cnt == 0) return;
+  if (lane == 0) my_pairs = cnt;
   // the group of the pair before this stripe's first one
   uint32_t before = 0xFFFFFFFFu;
   for (long long s = (long long)slot - 1; s >= 0; --s) {
@@ -554,6 +555,7 @@ __device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t left = lane ? lg[w][lane - 1] : (base ? grp[base - 1] : before);
     if (live && left != g) { // the first pair of its run
+      if (left != 0xFFFFFFFFu && left > g) atomicOr(&flags[3], 1u); // (key-bit positions and ranks order alike) the pair stream is not in key order
       double acc = 0.0;
       unsigned long long n = 0;
       const uint32_t m = cnt - base < 64 ? cnt - base : 64; // pairs in this chunk
@@ -586,33 +588,35 @@ __device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, co
 }
 __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
                                                                    uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank,
-                                                                   unsigned long long *slice_best) {
-  unsigned long long my_best = 0, my_groups = 0;
-  run_sums_stripe(stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group, count_by_group, flags, rank, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), my_best, my_groups);
+                                                                   unsigned long long *slice_best, unsigned long long *total_pairs) {
+  unsigned long long my_best = 0, my_groups = 0, my_pairs = 0;
+  run_sums_stripe(stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group, count_by_group, flags, rank, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), my_best, my_groups,
+                  my_pairs);
   if (slice_best) { // the top-k selection's first pass, on the way: the best sum and the number of groups of slice (workgroup mod kTopkSlices)
-    __shared__ unsigned long long wb[4], wg[4];
+    __shared__ unsigned long long wb[4], wg[4], wp[4];
     for (int o = 32; o; o >>= 1) {
       const unsigned long long other = __shfl_xor(my_best, o);
       my_best = other > my_best ? other : my_best;
       my_groups += __shfl_xor(my_groups, o);
     }
-    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = my_best; wg[threadIdx.x >> 6] = my_groups; }
+    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = my_best; wg[threadIdx.x >> 6] = my_groups; wp[threadIdx.x >> 6] = my_pairs; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsigned long long b = wb[0], g = wg[0];
-      for (int w = 1; w < 4; ++w) { b = wb[w] > b ? wb[w] : b; g += wg[w]; }
+      unsigned long long b = wb[0], g = wg[0], np = wp[0];
+      for (int w = 1; w < 4; ++w) { b = wb[w] > b ? wb[w] : b; g += wg[w]; np += wp[w]; }
       if (g) {
         (void)__hip_atomic_fetch_max(&slice_best[blockIdx.x & (kTopkSlices - 1)], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         (void)__hip_atomic_fetch_add(&slice_best[kTopkSlices + (blockIdx.x & (kTopkSlices - 1))], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (total_pairs && np) (void)__hip_atomic_fetch_add(total_pairs, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the range form's pair count)
     }
   }
 }
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
-                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank, uint64_t *slice_best) {
+                                      double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank, uint64_t *slice_best, uint64_t *total_pairs) {
   if (n_slots == 0) return hipSuccess;
   hipLaunchKernelGGL(hj_run_sums_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group,
-                     (unsigned long long *)count_by_group, flags, rank, (unsigned long long *)slice_best);
+                     (unsigned long long *)count_by_group, flags, rank, (unsigned long long *)slice_best, (unsigned long long *)total_pairs);
   return hipGetLastError();
 }
 // the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
@@ -1170,6 +1174,91 @@ __global__ void hj_boundary_runs_kernel(const uint32_t *group, const uint64_t *v
   while (b < n && b <= cap && group[n - 1 - b] == g1) ++b;
   out[5] = b;
   for (uint64_t i = 0; i < b && i < cap; ++i) out[8 + cap + i] = val[n - (b < cap ? b : cap) + i]; // row order
+}
+// The same from the probe's stripes (no compacted pair stream exists: one rank of a range form sums its runs where the probe left
+// them).  One wave: the first / last stripe that holds pairs by ballot, then one lane walks the two runs across stripes.
+// `rank.bits` != nullptr: the stripes hold key-bit positions (the group is their rank); else group ids (the key bit through cols).
+__global__ __launch_bounds__(64) void hj_boundary_runs_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
+                                                                       uint32_t stripe, uint32_t cap, CandidateCols cols, RankCols rank, uint64_t *out) {
+  const uint32_t lane = threadIdx.x;
+  if (lane < 8) out[lane] = 0;
+  auto cnt_of = [&](uint32_t s) { return (uint32_t)(counts[s] & (kPredErrorBit - 1)); };
+  uint32_t first = n_slots, last = n_slots;
+  for (uint32_t s0 = 0; s0 < n_slots && first == n_slots; s0 += 64) {
+    const uint64_t b = __ballot(s0 + lane < n_slots && cnt_of(s0 + lane) != 0);
+    if (b) first = s0 + (uint32_t)__ffsll((unsigned long long)b) - 1;
+  }
+  if (first == n_slots) return; // no pairs
+  for (uint32_t s1 = (n_slots + 63) / 64 * 64; s1 > 0 && last == n_slots; s1 -= 64) {
+    const uint32_t s0 = s1 - 64;
+    const uint64_t b = __ballot(s0 + lane < n_slots && cnt_of(s0 + lane) != 0);
+    if (b) last = s0 + 63 - (uint32_t)__clzll((unsigned long long)b);
+  }
+  if (lane) return;
+  auto gid_of = [&](uint32_t v) { return rank.bits ? rank_of_keybit(rank, v) : v; };
+  auto bit_of = [&](uint32_t v) -> uint64_t { return rank.bits ? (uint64_t)v : group_key_bit(cols, v); };
+  const uint32_t g0 = stripe_group[(uint64_t)first * stripe];
+  const uint32_t cl = cnt_of(last), g1 = stripe_group[(uint64_t)last * stripe + cl - 1];
+  // first run: forward from (first, 0)
+  uint64_t a = 0;
+  bool whole = false; // the first run is the whole stream
+  {
+    uint32_t s = first, k = 0, c = cnt_of(first);
+    for (;;) {
+      if (k >= c) {
+        do { ++s; } while (s < n_slots && (c = cnt_of(s)) == 0);
+        if (s >= n_slots) { whole = true; break; }
+        k = 0;
+      }
+      if (stripe_group[(uint64_t)s * stripe + k] != g0 || a > cap) break;
+      if (a < cap) out[8 + a] = stripe_val[(uint64_t)s * stripe + k];
+      ++a; ++k;
+    }
+  }
+  out[0] = gid_of(g0); out[1] = bit_of(g0); out[2] = a;
+  out[3] = gid_of(g1); out[4] = bit_of(g1);
+  if (whole) return;
+  // last run: backward from (last, cl − 1); its values land in row order
+  uint64_t b = 0;
+  {
+    uint32_t s = last;
+    long long k = (long long)cl - 1;
+    for (;;) {
+      if (k < 0) {
+        uint32_t c = 0;
+        while (s > 0 && (c = cnt_of(s - 1)) == 0) --s;
+        if (s == 0) break;
+        --s; k = (long long)c - 1;
+      }
+      if (stripe_group[(uint64_t)s * stripe + (uint64_t)k] != g1 || b > cap) break;
+      ++b; --k;
+    }
+  }
+  out[5] = b;
+  { // … again, forward from where the run starts (at most cap values)
+    const uint64_t want = b < cap ? b : cap;
+    uint32_t s = last;
+    long long k = (long long)cl - 1;
+    for (uint64_t back = 1; back < want; ++back) { // step back want − 1 pairs
+      --k;
+      if (k < 0) {
+        uint32_t c = 0;
+        while (s > 0 && (c = cnt_of(s - 1)) == 0) --s;
+        --s; k = (long long)c - 1;
+      }
+    }
+    uint32_t c = cnt_of(s);
+    for (uint64_t i = 0; i < want; ++i) {
+      if ((uint32_t)k >= c) { do { ++s; } while ((c = cnt_of(s)) == 0); k = 0; }
+      out[8 + cap + i] = stripe_val[(uint64_t)s * stripe + (uint64_t)k];
+      ++k;
+    }
+  }
+}
+hipError_t hj_launch_boundary_runs_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe, uint32_t cap,
+                                           CandidateCols cols, RankCols rank, uint64_t *out, hipStream_t s) {
+  hipLaunchKernelGGL(hj_boundary_runs_stripes_kernel, dim3(1), dim3(64), 0, s, stripe_group, stripe_val, counts, n_slots, stripe, cap, cols, rank, out);
+  return hipGetLastError();
 }
 hipError_t hj_launch_boundary_runs(const uint32_t *group, const uint64_t *val, uint64_t n, const uint64_t *n_dev, uint32_t cap, CandidateCols cols, uint64_t *out, hipStream_t s) {
   hipLaunchKernelGGL(hj_boundary_runs_kernel, dim3(1), dim3(64), 0, s, group, val, n, n_dev, cap, cols, out);

@@ -189,7 +189,8 @@ struct RankCols {
 };
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
                                       double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank = RankCols{nullptr, nullptr, nullptr, 0},
-                                      uint64_t *slice_best = nullptr /* [2 · kTopkSlices], zero: the top-k selection's slice winners (~best key) and group counts, on the way */);
+                                      uint64_t *slice_best = nullptr /* [2 · kTopkSlices], zero: the top-k selection's slice winners (~best key) and group counts, on the way */,
+                                      uint64_t *total_pairs = nullptr /* zero: + the number of pairs (with slice_best) */);
 // `descending` (optional): raised when a run starts below the group of the pair before it
 hipError_t hj_launch_run_sums_dev(const uint32_t *group, const uint64_t *val, const uint64_t *n_dev, uint64_t n_max, double *sum_by_group,
                                   uint64_t *count_by_group, uint32_t *multi_run, hipStream_t s, uint32_t *descending = nullptr);
@@ -282,6 +283,9 @@ hipError_t hj_launch_high_halves(const uint64_t *keys, uint64_t n, uint32_t *out
 // (join.hip: hj_boundary_runs_kernel; out = 8 + 2 · cap words of device memory)
 // `n_dev` (optional): the pair count is still on the device
 hipError_t hj_launch_boundary_runs(const uint32_t *group, const uint64_t *val, uint64_t n, const uint64_t *n_dev, uint32_t cap, CandidateCols cols, uint64_t *out, hipStream_t s);
+// … straight from the probe's stripes (rank.bits != nullptr: they hold key-bit positions)
+hipError_t hj_launch_boundary_runs_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe, uint32_t cap,
+                                           CandidateCols cols, RankCols rank, uint64_t *out, hipStream_t s);
 hipError_t hj_launch_gather_group_candidates(const uint64_t *sorted_keys, const uint64_t *keys_by_group, const uint32_t *sorted_groups, uint32_t n, const uint64_t *dim_rows,
                                              const double *sum_by_group, const uint64_t *count_by_group, CandidateCols cols,
                                              uint64_t *out /*[n][8]*/, hipStream_t s);

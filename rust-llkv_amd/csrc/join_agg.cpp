@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -157,7 +158,8 @@ struct JoinAgg {
   DB st_slot, st_val;                // the probe's stripes: (group id | hash slot, value) pairs per (tile, wave), row order
   uint32_t n_slots = 0, stripe = 0;
   bool from_stripes = false;         // the sums were taken straight from the stripes: no pair count, no compacted pairs yet
-  bool keybit_stripes = false;       // … and the stripes hold key-bit positions, not group ids (ScanParams::bm_emit_keybit)
+  bool keybit_stripes = false;       // … and the stripes hold key-bit positions, not group ids (ProbePlan KEYBIT)
+  bool sums_patched = false;         // finish_ranged has replaced boundary groups' sums / counts
   RankCols stripe_ranks{nullptr, nullptr, nullptr, 0};
   DB slot_group;                     // hash form: slot → group id
   bool direct_form = false;
@@ -184,6 +186,7 @@ struct JoinAgg {
   DB zeros;                          // one zeroed block: [0] the run flag, [8..15] the top-k selection's state words
   uint32_t *multi_p() const { return static_cast<uint32_t *>(zeros.p); }
   uint64_t *topk_state() const { return static_cast<uint64_t *>(zeros.p) + 8; }
+  uint64_t *total_pairs_p() const { return static_cast<uint64_t *>(zeros.p) + 4; } // range form, sums from the stripes: the number of pairs
   uint64_t *slice_best() const { return static_cast<uint64_t *>(zeros.p) + 32; } // [2 · kTopkSlices]: ~best key and groups of every slice (hj_launch_run_sums_stripes)
   uint32_t dup_keys = 0, key_err = 0, multi_run = 0;
   size_t state_bytes = 0;
@@ -212,6 +215,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
                      const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len, bool defer) {
   int rc = ensure_device();
   if (rc) return rc;
+  const auto t_enter = std::chrono::steady_clock::now(); // (LLKV_HIP_TRACE=1: host time up to the last launch, then the wait)
   if (!fact || !dim || !fact->table || !dim->table) return set_error(LLKV_INVALID_ARGUMENT, "NULL argument");
   if (n_payload_ > 4) return set_error(LLKV_UNSUPPORTED, "more than 4 payload columns");
   tf = reinterpret_cast<const Table *>(fact->table);
@@ -466,7 +470,9 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   LoweredPlan plan;
   // one rank, ranked form, sums straight from the stripes: the probe emits the key's bit position and the head of every run
   // looks the rank up
-  keybit_stripes = ranked && direct && defer && tf->world == 1 && dt.span < (1ull << 32) && !std::getenv("LLKV_HIP_JOIN_COMPACT") && !std::getenv("LLKV_HIP_JOIN_PROBE_RANKS");
+  // (… and one rank of a range form: its boundary runs are read off the stripes too, nothing of it needs the pairs compacted)
+  const bool stripes_ok = direct && !std::getenv("LLKV_HIP_JOIN_COMPACT") && ((tf->world == 1 && defer) || (range_form && !std::getenv("LLKV_HIP_JOIN_RANGE_COMPACT")));
+  keybit_stripes = ranked && stripes_ok && dt.span < (1ull << 32) && !std::getenv("LLKV_HIP_JOIN_PROBE_RANKS");
   if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err, keybit_stripes))) return set_error(rc, err);
   if (plan.always_false || tf->local_rows == 0) {
     if (ranked) { // nothing probes: the group state still starts from zero, and the group count is wanted
@@ -525,18 +531,24 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   // the runs where they lie; only when some group turns out to have a second run, sort (stable) by group first.
   // One rank, direct table: straight from the stripes (no scan, no compaction, no pair count) — whoever needs the
   // pairs themselves later (the sort, a sharded fact table's straddlers) compacts them then.
-  from_stripes = defer && direct && tf->world == 1 && !std::getenv("LLKV_HIP_JOIN_COMPACT");
+  from_stripes = stripes_ok;
+  const RankCols stripe_rank_cols = keybit_stripes ? stripe_ranks : RankCols{nullptr, nullptr, nullptr, 0};
   if (from_stripes) {
     HIP_TRY(hj_launch_run_sums_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, n_slots, stripe, (double *)sums.p,
-                                       (uint64_t *)cnts.p, multi_p(), s, keybit_stripes ? stripe_ranks : RankCols{nullptr, nullptr, nullptr, 0}, slice_best()));
+                                       (uint64_t *)cnts.p, multi_p(), s, stripe_rank_cols, slice_best(), range_form ? total_pairs_p() : nullptr));
   } else if ((rc = compact_pairs(true))) {
     return rc;
   }
   if (range_form) { // the boundary runs of the pair stream, while the pair count is still on its way to the host
     boundary_raw.assign(8 + 2 * kBoundaryCap, 0);
     if ((rc = boundary_d.alloc(boundary_raw.size() * 8))) return rc;
-    HIP_TRY(hj_launch_boundary_runs((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, 0, (const uint64_t *)offsets.p + n_slots, kBoundaryCap, cc, (uint64_t *)boundary_d.p, s));
+    if (from_stripes)
+      HIP_TRY(hj_launch_boundary_runs_stripes((const uint32_t *)st_slot.p, (const uint64_t *)st_val.p, (const uint64_t *)counts.p, n_slots, stripe, kBoundaryCap, cc, stripe_rank_cols,
+                                              (uint64_t *)boundary_d.p, s));
+    else
+      HIP_TRY(hj_launch_boundary_runs((const uint32_t *)e_group.p, (const uint64_t *)e_val.p, 0, (const uint64_t *)offsets.p + n_slots, kBoundaryCap, cc, (uint64_t *)boundary_d.p, s));
     if ((rc = rb.add(boundary_raw.data(), boundary_d.p, boundary_raw.size() * 8, s))) return rc;
+    if (from_stripes && (rc = rb.add(&n_pairs, total_pairs_p(), 8, s))) return rc;
   }
   if ((!from_stripes && (rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s))) || (from_stripes && (rc = rb.add(&pred_err, multi_p() + 1, 4, s))) ||
       (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) || (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) ||
@@ -546,7 +558,13 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     return rc;
   pending = true;
   if (defer) return LLKV_OK; // the sources are members: the selection's last workgroup carries the items
-  return settle();
+  const auto t_launched = std::chrono::steady_clock::now();
+  rc = settle();
+  if (std::getenv("LLKV_HIP_TRACE"))
+    std::fprintf(stderr, "[llkv join_agg] host to the last launch %7.1f us, wait for the device %7.1f us\n",
+                 std::chrono::duration<double, std::micro>(t_launched - t_enter).count(),
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_launched).count());
+  return rc;
 }
 
 // Stripes → contiguous pairs in row order (e_group / e_val, sized by the bound of one pair per local fact row; the
@@ -694,7 +712,7 @@ int JoinAgg::candidates(const uint32_t *f_groups, const double *f_sums, const ui
     if ((rc = rb.reserve(nullptr, 64 + (size_t)kCap * 64, s, &slab)) || (rc = rb.take(&extra, &slab_base))) return rc;
     // (sums straight from the stripes, nothing patched in: the first launch's slice winners came with the run sums — if some
     // group turns out to have had two runs, everything is redone below)
-    const bool winners_known = pending && from_stripes && alone && mg.empty() && !std::getenv("LLKV_HIP_TOPK_TWO_LAUNCHES");
+    const bool winners_known = from_stripes && alone && mg.empty() && !sums_patched && (pending || !multi_run) && !std::getenv("LLKV_HIP_TOPK_TWO_LAUNCHES");
     HIP_TRY(hj_launch_topk_select2((const double *)sums.p, report_p, n_dim, std::max(1u, limit), kCap, d_dim_rows, cc, (uint64_t *)best.p, topk_state(),
                                    (uint32_t *)groups_d.p, (uint64_t *)slab, extra, slab_base, s, ranked && pending ? n_dim_ptr() : nullptr,
                                    winners_known ? slice_best() : nullptr));
@@ -865,6 +883,7 @@ int JoinAgg::finish_ranged(const uint64_t *blocks, const uint64_t *offsets, uint
     HIP_TRY(hipMemcpyAsync(dcnt.p, pc.data(), pc.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hj_launch_patch_groups((const uint32_t *)dg.p, (const double *)dsum.p, (const uint64_t *)dcnt.p, pg.size(), (double *)sums.p, (uint64_t *)cnts.p, s));
     HIP_TRY(hipStreamSynchronize(s)); // the host vectors are pageable
+    sums_patched = true; // (a group another rank reports has lost its count here: the slice winners the run sums left may name it)
   }
   *out_n = 0;
   if (out_groups) *out_groups = 0;
