@@ -1160,8 +1160,9 @@ __device__ __forceinline__ uint64_t group_key_bit(const CandidateCols &cols, uin
 // its run, [3] last group, [4] its key bit, [5] rows of its run (0: it IS the first run), [8 …) ≤ cap values of the first
 // run, [8 + cap …) of the last; a run longer than cap reports cap + 1 rows.  One thread: the runs are a few rows.
 __global__ void hj_boundary_runs_kernel(const uint32_t *group, const uint64_t *val, uint64_t n, const uint64_t *n_dev, uint32_t cap, CandidateCols cols, uint64_t *out) {
-  if (threadIdx.x || blockIdx.x) return;
-  for (uint32_t i = 0; i < 8; ++i) out[i] = 0;
+  if (blockIdx.x) return;
+  for (uint32_t i = threadIdx.x; i < 8 + 2 * cap; i += blockDim.x) out[i] = 0; // (the whole block travels to the other ranks)
+  if (threadIdx.x) return;
   if (n_dev) n = *n_dev; // (a count that carries the predicate-error mark: the host reports the error, nothing here is looked at)
   if (n == 0 || n >= kPredErrorBit) return;
   const uint32_t g0 = group[0], g1 = group[n - 1];
@@ -1181,7 +1182,7 @@ __global__ void hj_boundary_runs_kernel(const uint32_t *group, const uint64_t *v
 __global__ __launch_bounds__(64) void hj_boundary_runs_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
                                                                        uint32_t stripe, uint32_t cap, CandidateCols cols, RankCols rank, uint64_t *out) {
   const uint32_t lane = threadIdx.x;
-  if (lane < 8) out[lane] = 0;
+  for (uint32_t i = lane; i < 8 + 2 * cap; i += 64) out[i] = 0; // (the whole block travels to the other ranks: no stale device memory in the unused value slots)
   auto cnt_of = [&](uint32_t s) { return (uint32_t)(counts[s] & (kPredErrorBit - 1)); };
   uint32_t first = n_slots, last = n_slots;
   for (uint32_t s0 = 0; s0 < n_slots && first == n_slots; s0 += 64) {

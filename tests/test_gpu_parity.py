@@ -2885,6 +2885,16 @@ def test_q3_sharded_fact_table_is_rank_count_invariant(rt, abi, tpch, clustered)
         assert sum(n for _, n in parts) == want_total
         with pytest.raises(abi.LlkvError):
             ranged[0].counts_buffer()
+        # … and the same blocks, bit for bit, from a rank that compacts its pairs first (the runs are read off the stripes by default)
+        del ranged
+        os.environ["LLKV_HIP_JOIN_RANGE_COMPACT"] = "1"
+        try:
+            compacting = [rt.JoinAgg(ranged=True, **args(t)) for t in shards]
+            assert [bytes(j.boundary()) for j in compacting] == [bytes(b) for b in blocks], world
+            parts = [j.finish_ranged(blocks, r, 10) for r, j in enumerate(compacting)]
+        finally:
+            del os.environ["LLKV_HIP_JOIN_RANGE_COMPACT"]
+        assert bits(rt.merge_join_rows([row for rows_r, _ in parts for row in rows_r], 2, 10)) == bits(want), ("ranged, compacted", world)
 
 
 def test_table_staged_from_arr0_chunk_blobs(rt, orc, abi, tpch):
