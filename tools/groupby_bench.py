@@ -10,6 +10,8 @@ import torch  # noqa: F401
 abi = importlib.import_module("rust-llkv_amd.abi"); rt = importlib.import_module("rust-llkv_amd.runtime"); tpch = importlib.import_module("rust-llkv_amd.tpch")
 sf = sys.argv[1] if len(sys.argv) > 1 else "sf10"
 rt.init(0)
+if os.environ.get("LLKV_BENCH_EXACT_SUMS"):  # the exact-sum planning option: f64 sums as two int64 fixed-point lanes
+    rt.set_exact_f64_sums(True)
 rows, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
 cols = ["l_orderkey", "l_partkey", "l_shipdate", "l_quantity", "l_extendedprice", "l_discount", "l_returnflag", "l_linestatus"]
 li = tpch.gen_lineitem(rows, scale, cols)
