@@ -1180,6 +1180,12 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
 constexpr int kImgBlock = 1024;
 constexpr int kImgStepRows = kImgBlock * kRowsPerThread; // 2048 rows per workgroup step
 
+// copies of an image of `cells` 64-bit cells: a power of two ≤ 32 that keeps them within 64 KB
+constexpr int image_replicas(int cells) {
+  int r = 1;
+  while (r < 32 && (long)(2 * r) * cells * 8 <= 64 * 1024) r *= 2;
+  return r;
+}
 template <class P, int NGS, int K0 = 0> __device__ __forceinline__ void image_accumulate_row(uint64_t *img, uint32_t gid, const uint64_t *contrib) {
   if constexpr (K0 < P::K) {
     lds_accumulate<plan_lane_op<P>(K0)>(img + K0 * NGS + gid, contrib[K0]);
@@ -1193,11 +1199,17 @@ template <class P, int NGS, int K0 = 0> __device__ __forceinline__ void image_ac
 template <class P> __device__ __forceinline__ void image_scan_body(const ScanParams &p) {
   constexpr int K = P::K, U = P::U;
   constexpr int NG = (P::NG + P::PASSES - 1) / P::PASSES; // groups of one slice
-  __shared__ uint64_t img[K * NG]; // [lane][group of the slice]
+  // A small image (a few groups under many lanes, or a few hundred groups) is kept R times and thread t adds into copy
+  // t mod R: the 64 rows of a wave instruction that meet in a cell are serialised by the LDS, and with four groups all of
+  // them meet (12 + 3 lanes over the 4 groups of Q1: 3.6 ms for SF10 with one copy).  Every lane is order-free, so the
+  // copies are combined in any order when the workgroup leaves its image.  R depends on the plan alone.
+  constexpr int R = image_replicas(K * NG);
+  __shared__ uint64_t img_all[R * K * NG]; // [copy][lane][group of the slice]
   __shared__ uint32_t block_err;
 
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < (uint32_t)(K * NG); i += kImgBlock) img[i] = lane_identity(plan_lane_op<P>((int)(i / NG)));
+  uint64_t *img = img_all + (tid % (uint32_t)R) * (uint32_t)(K * NG);
+  for (uint32_t i = tid; i < (uint32_t)(R * K * NG); i += kImgBlock) img_all[i] = lane_identity(plan_lane_op<P>((int)((i % (uint32_t)(K * NG)) / NG)));
   if (tid == 0) block_err = 0;
   __syncthreads();
 
@@ -1248,7 +1260,15 @@ template <class P> __device__ __forceinline__ void image_scan_body(const ScanPar
   if (err) atomicOr(&block_err, err);
   __syncthreads();
   uint64_t *out = p.tile_partials + (uint64_t)blockIdx.x * (uint64_t)(K * NG + 1);
-  for (uint32_t i = tid; i < (uint32_t)(K * NG); i += kImgBlock) out[i] = img[i];
+  for (uint32_t i = tid; i < (uint32_t)(K * NG); i += kImgBlock) {
+    uint64_t v = img_all[i];
+    if constexpr (R > 1) {
+      const int op = plan_lane_op<P>((int)(i / NG));
+#pragma unroll 1
+      for (int r = 1; r < R; ++r) v = lane_combine(op, v, img_all[(uint32_t)r * (uint32_t)(K * NG) + i]);
+    }
+    out[i] = v;
+  }
   if (tid == 0) out[K * NG] = block_err;
 }
 
