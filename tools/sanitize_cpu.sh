@@ -21,7 +21,8 @@ rt._lib = C.CDLL(sys.argv[1])  # the lowering entry point only: no llkv_hip_* sy
 import test_host_logic as T
 for name in ("test_literal_cast_rules", "test_expression_typing_rules", "test_compare_lowering_follows_the_common_type_rules",
              "test_null_cells_lower_to_validity_masks_and_domains", "test_utf8_ordering_predicates_become_code_sets",
-             "test_in_list_and_is_null_expression_lowering", "test_int_sum_uses_statistics_to_exclude_overflow"):
+             "test_in_list_and_is_null_expression_lowering", "test_int_sum_uses_statistics_to_exclude_overflow",
+             "test_constant_folding_and_late_columns_in_the_lowering"):
     f = getattr(T, name)
     f(**{p: {"lib": rt._lib, "abi": abi, "tpch": tpch}[p] for p in inspect.signature(f).parameters})
     print("ok", name)
