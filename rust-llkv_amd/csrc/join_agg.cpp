@@ -257,7 +257,9 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
            !std::getenv("LLKV_HIP_JOIN_LISTED");
   // ---- everything that starts from zero, in one fill: the key bitmaps, the probe's per-stripe counts, the flags --------
   const TileSet *ts = nullptr;
-  if ((rc = get_tileset(*tf, 8192, &ts))) return rc;
+  uint32_t probe_tile = 8192; // rows of a probe workgroup (a wave owns a quarter: its stripe)
+  if (const char *e = std::getenv("LLKV_HIP_PROBE_TILE")) { const long v = std::atol(e); if (v >= 1024 && v <= 65536 && v % 512 == 0) probe_tile = (uint32_t)v; }
+  if ((rc = get_tileset(*tf, probe_tile, &ts))) return rc;
   n_slots = ts->n_tiles * (kBlock / 64);
   {
     FillRanges fr;
@@ -492,7 +494,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   for (size_t i = 0; i < plan.lit_f.size(); ++i) p.lit_f[i] = plan.lit_f[i];
   p.tiles = ts->d_tiles;
   p.n_tiles = ts->n_tiles;
-  p.sub_rows = 8192 / (kBlock / 64);
+  p.sub_rows = probe_tile / (kBlock / 64);
   p.tile_partials = (uint64_t *)counts.p;
   if (direct) {
     p.bm_bits = (const uint64_t *)dt.bits.p;
