@@ -520,6 +520,10 @@ __device__ __forceinline__ uint32_t rank_of_keybit(const RankCols &r, uint32_t d
   if (r.base) g += r.base[word >> r.chunk_shift];
   return g;
 }
+#ifndef LLKV_RUN_SUM_SLOTS
+#define LLKV_RUN_SUM_SLOTS 4
+#endif
+constexpr uint32_t kRunSumSlots = LLKV_RUN_SUM_SLOTS;
 // one wave = one stripe; my_best / my_groups: the best run this lane finished (as ~order key: 0 = none) and how many
 __device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
                                                 double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, const RankCols &rank, uint32_t slot,
@@ -590,8 +594,14 @@ __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t
                                                                    uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank,
                                                                    unsigned long long *slice_best, unsigned long long *total_pairs) {
   unsigned long long my_best = 0, my_groups = 0, my_pairs = 0;
-  run_sums_stripe(stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group, count_by_group, flags, rank, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), my_best, my_groups,
-                  my_pairs);
+  // a wave takes kRunSumSlots consecutive stripes (most hold a handful of pairs: what a stripe costs is its wave, not its pairs)
+  const uint32_t slot0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kRunSumSlots;
+#pragma unroll 1
+  for (uint32_t k = 0; k < kRunSumSlots; ++k) {
+    unsigned long long pairs = 0;
+    run_sums_stripe(stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group, count_by_group, flags, rank, slot0 + k, my_best, my_groups, pairs);
+    my_pairs += pairs;
+  }
   if (slice_best) { // the top-k selection's first pass, on the way: the best sum and the number of groups of slice (workgroup mod kTopkSlices)
     __shared__ unsigned long long wb[4], wg[4], wp[4];
     for (int o = 32; o; o >>= 1) {
@@ -615,8 +625,8 @@ __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
                                       double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank, uint64_t *slice_best, uint64_t *total_pairs) {
   if (n_slots == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_run_sums_stripes_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, s, stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group,
-                     (unsigned long long *)count_by_group, flags, rank, (unsigned long long *)slice_best, (unsigned long long *)total_pairs);
+  hipLaunchKernelGGL(hj_run_sums_stripes_kernel, dim3((n_slots + 4 * kRunSumSlots - 1) / (4 * kRunSumSlots)), dim3(256), 0, s, stripe_group, stripe_val, counts, n_slots, stripe,
+                     sum_by_group, (unsigned long long *)count_by_group, flags, rank, (unsigned long long *)slice_best, (unsigned long long *)total_pairs);
   return hipGetLastError();
 }
 // the same with the pair count still on the device (*n_dev; nothing runs when it carries the predicate-error mark)
