@@ -2642,6 +2642,20 @@ def test_c_program_runs_q6_through_the_abi(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stdout, out.stderr)
 
 
+def test_c_example_joins_through_the_abi(tmp_path):
+    """examples/q3_join.c: a C99 program (no Python, no C++) stages lineitem / orders / customer, takes lineitem ⋈ orders as the
+    reference's joined RecordBatches (llkv_hip_join_stream_batches: names, cells and totals checked against a host join) and
+    runs the Q3 pipeline (llkv_hip_join_groupby_topk) against its own host loop, revenue bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rust-llkv_amd")
+    exe = tmp_path / "q3_join"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "q3_join.c"), "-L", libdir, "-lllkv_hip", "-lllkv_tpch", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe), "900000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stdout, out.stderr)
+
+
 @pytest.mark.parametrize("order_by_keys", [True, False])
 def test_sort_based_group_by_over_a_sharded_table(rt, abi, order_by_keys, monkeypatch):
     """SURVEY §8e for GROUP BY of any cardinality: every rank reduces its own chunks, the partial groups are merged
