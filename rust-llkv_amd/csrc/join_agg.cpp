@@ -261,6 +261,29 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   if (const char *e = std::getenv("LLKV_HIP_PROBE_TILE")) { const long v = std::atol(e); if (v >= 1024 && v <= 65536 && v % 512 == 0) probe_tile = (uint32_t)v; }
   if ((rc = get_tileset(*tf, probe_tile, &ts))) return rc;
   n_slots = ts->n_tiles * (kBlock / 64);
+  // The ranked form's dimension plan is lowered and looked up BEFORE the first launch: the fill and the dim2 key-set scan are a
+  // few µs each, and a host that lowers this plan between them leaves the device idle until the dimension scan is queued
+  // (17 µs of a 320 µs query once the customer scan took 5 µs instead of 13).
+  LoweredPlan dim_kp;
+  JitKernel dim_kk;
+  const TileSet *dim_ts = nullptr;
+  if (ranked) {
+    auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
+      auto it = td->cols.find(fid);
+      return it == td->cols.end() ? nullptr : &it->second.info;
+    };
+    llkv_expr_token key_tok;
+    std::memset(&key_tok, 0, sizeof key_tok);
+    key_tok.kind = LLKV_TOK_COLUMN;
+    key_tok.field_id = dim->key_field;
+    if ((rc = lower_emit(resolve_d, dim->filters, dim->n_filters, nullptr, 0, &key_tok, 1, &dim_kp, &err, false, nullptr, t2 ? &dim_fk_field : nullptr))) return set_error(rc, err);
+    if ((rc = jit_compile(JitKind::KeyBits, dim_kp.type_string, &dim_kk, &err))) return set_error(rc, err);
+    // 2 048-row tiles: a wave's quarter is exactly one batch of kSelUnroll steps — every load and key-set gather of the tile
+    // goes out before the first use (SF10 orders: 81 µs; 4 096: 85, 8 192: 90, 16 384: 92; 1 024: 114 — half-empty batches)
+    uint32_t dim_tile = 2048;
+    if (const char *e = std::getenv("LLKV_HIP_KEYBITS_TILE")) { const long v = std::atol(e); if (v >= 512 && v <= 65536 && v % 512 == 0) dim_tile = (uint32_t)v; }
+    if ((rc = get_tileset(*td, dim_tile, &dim_ts))) return rc;
+  }
   {
     FillRanges fr;
     if (fused_semi && (rc = set2_bits.prepare_bits(t2->cols.find(dim2->key_field)->second.info, s, &fr))) return rc;
@@ -328,24 +351,9 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   bool dt_bits_done = false;
   uint32_t *dim_err_flag = nullptr;
   if (ranked) {
-    auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
-      auto it = td->cols.find(fid);
-      return it == td->cols.end() ? nullptr : &it->second.info;
-    };
-    llkv_expr_token key_tok;
-    std::memset(&key_tok, 0, sizeof key_tok);
-    key_tok.kind = LLKV_TOK_COLUMN;
-    key_tok.field_id = dim->key_field;
-    LoweredPlan kp;
-    JitKernel kk;
-    if ((rc = lower_emit(resolve_d, dim->filters, dim->n_filters, nullptr, 0, &key_tok, 1, &kp, &err, false, nullptr, t2 ? &dim_fk_field : nullptr))) return set_error(rc, err);
-    if ((rc = jit_compile(JitKind::KeyBits, kp.type_string, &kk, &err))) return set_error(rc, err);
-    const TileSet *tsd = nullptr;
-    // 2 048-row tiles: a wave's quarter is exactly one batch of kSelUnroll steps — every load and key-set gather of the tile
-    // goes out before the first use (SF10 orders: 81 µs; 4 096: 85, 8 192: 90, 16 384: 92; 1 024: 114 — half-empty batches)
-    uint32_t dim_tile = 2048;
-    if (const char *e = std::getenv("LLKV_HIP_KEYBITS_TILE")) { const long v = std::atol(e); if (v >= 512 && v <= 65536 && v % 512 == 0) dim_tile = (uint32_t)v; }
-    if ((rc = get_tileset(*td, dim_tile, &tsd))) return rc;
+    const LoweredPlan &kp = dim_kp;
+    const JitKernel &kk = dim_kk;
+    const TileSet *tsd = dim_ts;
     if (!kp.always_false && td->local_rows) {
       ScanParams pd;
       std::memset(&pd, 0, sizeof pd);

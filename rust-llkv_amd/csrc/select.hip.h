@@ -315,6 +315,7 @@ template <class P> __device__ __forceinline__ void keybits_body(const ScanParams
     if (first > p.kb_hi || last < p.kb_lo) return;
   }
   uint32_t perr = 0;
+  __shared__ unsigned long long kb_words[kBlock / 64][64]; // per wave: the words its batch's hits fall into
   // as the selection kernels: a wave owns a contiguous quarter of the tile, kSelUnroll steps of 128 rows are requested
   // before the first is looked at, and the key-set words of all the rows a lane holds go out together
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -367,13 +368,46 @@ template <class P> __device__ __forceinline__ void keybits_body(const ScanParams
         perr |= row < sub1 ? c.perr : 0u;
       }
     }
+    // The hits of a batch mostly share a few words (dense keys: 512 customers = 8 words, a fifth of them hit): when they all
+    // fall within 64 words they are OR-ed in the LDS first and one lane per word issues the device-scope atomic — a dozen
+    // instead of a hundred for the customer set (13 → 5 µs), about as many as before for the sparser order keys.
+    uint64_t dd[2 * kSelUnroll];
+    uint64_t wmin = ~0ull, wmax = 0;
 #pragma unroll
     for (int e = 0; e < 2 * kSelUnroll; ++e) {
-      const uint64_t d = (uint64_t)key[e] - (uint64_t)p.kb_min;
+      dd[e] = (uint64_t)key[e] - (uint64_t)p.kb_min;
       const bool wanted = !p.kb_ranged || (key[e] >= p.kb_lo && key[e] <= p.kb_hi);
-      // (measured: gathering a tile's words in the LDS first and storing them whole — the keys of a tile of an ascending
-      // column fall between its first and last key — is no faster than these atomics: 92 vs 90 µs over 15 M orders)
-      if (fe[e] && wanted && d <= p.kb_span) atomicOr(&bits[d >> 6], 1ull << (d & 63));
+      fe[e] = fe[e] && wanted && dd[e] <= p.kb_span;
+      const uint64_t w = dd[e] >> 6;
+      wmin = fe[e] && w < wmin ? w : wmin;
+      wmax = fe[e] && w > wmax ? w : wmax;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+      const uint64_t a = ((uint64_t)__shfl_xor((uint32_t)(wmin >> 32), o) << 32) | __shfl_xor((uint32_t)wmin, o);
+      const uint64_t b = ((uint64_t)__shfl_xor((uint32_t)(wmax >> 32), o) << 32) | __shfl_xor((uint32_t)wmax, o);
+      wmin = a < wmin ? a : wmin;
+      wmax = b > wmax ? b : wmax;
+    }
+    if (wmin != ~0ull) { // (uniform) some row of the batch hit
+      if (wmax - wmin < 64) {
+        kb_words[wave][lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 2 * kSelUnroll; ++e)
+          if (fe[e]) (void)__hip_atomic_fetch_or(&kb_words[wave][(dd[e] >> 6) - wmin], 1ull << (dd[e] & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long mine = kb_words[wave][lane];
+        if (mine) atomicOr(&bits[wmin + lane], mine);
+        __builtin_amdgcn_wave_barrier(); // the words are zeroed again by the next batch
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2 * kSelUnroll; ++e)
+          if (fe[e]) atomicOr(&bits[dd[e] >> 6], 1ull << (dd[e] & 63));
+      }
     }
     if (more) {
 #pragma unroll
