@@ -682,7 +682,10 @@ template <class... As> struct Aggs {
 // ACC = 2: ONE accumulator image per workgroup in LDS, [lane][group], shared by its 1024 threads and updated with
 //          the same DS atomics (image_scan_body): hundreds to thousands of groups.  Every lane op must be order-free,
 //          so f64 sums are the exact two-level SumF64X.
-template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0, int PASSES_ = 1, int EARLY_ = -1> struct Plan {
+template <class CL, class PR, class KS, class AG, int U_ = 2, int ACC_ = 0, int PASSES_ = 1, int EARLY_ = -1, int CELL32_ = 0> struct Plan {
+  // shared-image plans whose every lane is a count or an integer sum that the statistics keep below 2^31 per workgroup image
+  // (and a first-row lane over fewer than 2^32 rows): 4-byte cells — twice the groups per LDS-sized slice, 32-bit DS atomics
+  static constexpr bool CELL32 = CELL32_ != 0;
   // register-state plans: the columns [0, EARLY) feed the predicate (and keys) and are streamed for every row, the ones
   // behind them feed aggregate arguments alone and are read for the row pairs that hold a passing row (EARLY_ < 0: all
   // columns up front)
@@ -1180,13 +1183,22 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
 constexpr int kImgBlock = 1024;
 constexpr int kImgStepRows = kImgBlock * kRowsPerThread; // 2048 rows per workgroup step
 
-// copies of an image of `cells` 64-bit cells: a power of two ≤ 32 that keeps them within 64 KB
-constexpr int image_replicas(int cells) {
+// copies of an image of `cells` cells of `cell_bytes`: a power of two ≤ 32 that keeps them within 64 KB
+constexpr int image_replicas(int cells, int cell_bytes = 8) {
   int r = 1;
-  while (r < 32 && (long)(2 * r) * cells * 8 <= 64 * 1024) r *= 2;
+  while (r < 32 && (long)(2 * r) * cells * cell_bytes <= 64 * 1024) r *= 2;
   return r;
 }
-template <class P, int NGS, int K0 = 0> __device__ __forceinline__ void image_accumulate_row(uint64_t *img, uint32_t gid, const uint64_t *contrib) {
+template <bool NARROW> struct ImageCell { using T = uint64_t; };
+template <> struct ImageCell<true> { using T = uint32_t; };
+// 4-byte cells (Plan::CELL32): integer adds wrap in 32 bits (the lowering has bounded the image's total), the first-row lane is
+// an unsigned minimum of row ids below 2^32
+template <int OP> __device__ __forceinline__ void lds_accumulate(uint32_t *slot, uint64_t x) {
+  static_assert(OP == OP_ADD_I64 || OP == OP_MIN_I64, "4-byte image cells hold counts, bounded integer sums and first rows");
+  if constexpr (OP == OP_ADD_I64) (void)__hip_atomic_fetch_add(slot, (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else (void)__hip_atomic_fetch_min(slot, (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class P, int NGS, int K0 = 0, class Cell> __device__ __forceinline__ void image_accumulate_row(Cell *img, uint32_t gid, const uint64_t *contrib) {
   if constexpr (K0 < P::K) {
     lds_accumulate<plan_lane_op<P>(K0)>(img + K0 * NGS + gid, contrib[K0]);
     image_accumulate_row<P, NGS, K0 + 1>(img, gid, contrib);
@@ -1203,13 +1215,18 @@ template <class P> __device__ __forceinline__ void image_scan_body(const ScanPar
   // t mod R: the 64 rows of a wave instruction that meet in a cell are serialised by the LDS, and with four groups all of
   // them meet (12 + 3 lanes over the 4 groups of Q1: 3.6 ms for SF10 with one copy).  Every lane is order-free, so the
   // copies are combined in any order when the workgroup leaves its image.  R depends on the plan alone.
-  constexpr int R = image_replicas(K * NG);
-  __shared__ uint64_t img_all[R * K * NG]; // [copy][lane][group of the slice]
+  using Cell = typename ImageCell<P::CELL32>::T;
+  constexpr int R = image_replicas(K * NG, (int)sizeof(Cell));
+  __shared__ Cell img_all[R * K * NG]; // [copy][lane][group of the slice]
   __shared__ uint32_t block_err;
 
   const uint32_t tid = threadIdx.x;
-  uint64_t *img = img_all + (tid % (uint32_t)R) * (uint32_t)(K * NG);
-  for (uint32_t i = tid; i < (uint32_t)(R * K * NG); i += kImgBlock) img_all[i] = lane_identity(plan_lane_op<P>((int)((i % (uint32_t)(K * NG)) / NG)));
+  Cell *img = img_all + (tid % (uint32_t)R) * (uint32_t)(K * NG);
+  for (uint32_t i = tid; i < (uint32_t)(R * K * NG); i += kImgBlock) {
+    const int op = plan_lane_op<P>((int)((i % (uint32_t)(K * NG)) / NG));
+    if constexpr (P::CELL32) img_all[i] = op == OP_MIN_I64 ? 0xFFFFFFFFu : 0u;
+    else img_all[i] = lane_identity(op);
+  }
   if (tid == 0) block_err = 0;
   __syncthreads();
 
@@ -1261,13 +1278,23 @@ template <class P> __device__ __forceinline__ void image_scan_body(const ScanPar
   __syncthreads();
   uint64_t *out = p.tile_partials + (uint64_t)blockIdx.x * (uint64_t)(K * NG + 1);
   for (uint32_t i = tid; i < (uint32_t)(K * NG); i += kImgBlock) {
-    uint64_t v = img_all[i];
-    if constexpr (R > 1) {
-      const int op = plan_lane_op<P>((int)(i / NG));
+    const int op = plan_lane_op<P>((int)(i / NG));
+    if constexpr (P::CELL32) { // the image leaves as 64-bit lanes (the fold and everything behind it are the same)
+      uint32_t v = img_all[i];
 #pragma unroll 1
-      for (int r = 1; r < R; ++r) v = lane_combine(op, v, img_all[(uint32_t)r * (uint32_t)(K * NG) + i]);
+      for (int r = 1; r < R; ++r) {
+        const uint32_t o = img_all[(uint32_t)r * (uint32_t)(K * NG) + i];
+        v = op == OP_MIN_I64 ? (o < v ? o : v) : v + o;
+      }
+      out[i] = op == OP_MIN_I64 ? (v == 0xFFFFFFFFu ? lane_identity(OP_MIN_I64) : (uint64_t)v) : (uint64_t)(int64_t)(int32_t)v;
+    } else {
+      uint64_t v = img_all[i];
+      if constexpr (R > 1) {
+#pragma unroll 1
+        for (int r = 1; r < R; ++r) v = lane_combine(op, v, img_all[(uint32_t)r * (uint32_t)(K * NG) + i]);
+      }
+      out[i] = v;
     }
-    out[i] = v;
   }
   if (tid == 0) out[K * NG] = block_err;
 }

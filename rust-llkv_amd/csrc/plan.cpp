@@ -229,6 +229,10 @@ struct Lowering {
   std::vector<std::vector<std::pair<uint8_t, uint8_t>>> group_expand = {};
   std::vector<std::pair<uint8_t, uint8_t>> next_expand = {};
   bool bounds_all_finite = true; // (expr_bounds) no column of the expression holds NaN / ±∞
+  // shared-image plans: the largest |contribution| a row makes to any lane of a lane group (counts: 1; SumI64Fast: max |v| of
+  // its column) when every lane of the group is a plain integer add; −1: the group needs 8-byte cells.  Set before add_group.
+  double next_narrow = -1.0;
+  std::vector<double> group_narrow = {};
 
   // What the column statistics say about an aggregate argument: an interval [lo, hi] (integer min / max, largest
   // finite |v| of float columns) and `nz`, a lower bound on |value| wherever the value is not zero (smallest non-zero
@@ -1136,7 +1140,10 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
   auto add_group = [&](const std::string &node, std::vector<uint8_t> lane_ops) -> int {
     std::vector<std::pair<uint8_t, uint8_t>> expand;
     expand.swap(L.next_expand);
+    const double narrow = L.next_narrow;
+    L.next_narrow = -1.0;
     for (size_t i = 0; i < groups.size(); ++i) if (groups[i] == node) return group_lane[i];
+    L.group_narrow.push_back(narrow);
     if (expand.empty()) for (size_t j = 0; j < lane_ops.size(); ++j) expand.emplace_back((uint8_t)j, (uint8_t)0);
     groups.push_back(node);
     group_lane.push_back(next_lane);
@@ -1216,6 +1223,7 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       } else if (valid.empty()) o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountRows : AggFinal::CountNullsZero;
       else {
         o.fin = s.kind == LLKV_AGG_COUNT ? AggFinal::CountValid : AggFinal::CountNulls;
+        L.next_narrow = 1.0;
         o.lane = add_group("CountIf<" + valid + ">", {ADD_I64});
       }
       p.aggs.push_back(o);
@@ -1300,7 +1308,11 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       return {node_x + ">", lane_ops};
     };
     // NULL argument rows contribute each lane's identity; one more lane counts the non-NULL rows
+    double narrow_bound = -1.0; // (SumI64Fast over a plain integer column: max |v|)
+    if (!is_f64 && simple && fast_i64 && simple_ci->dtype == LLKV_DT_INT64)
+      narrow_bound = std::max(std::fabs((double)simple_ci->min_i), std::fabs((double)simple_ci->max_i));
     auto add_agg = [&](const std::string &inner, std::vector<uint8_t> lane_ops) {
+      if (inner.rfind("SumI64Fast<", 0) == 0 && narrow_bound >= 0.0) L.next_narrow = std::max(1.0, narrow_bound); // (with IfValid: + a count lane)
       if (valid.empty()) { o.lane = add_group(inner, lane_ops); return; }
       const int n_inner = (int)lane_ops.size();
       lane_ops.push_back(ADD_I64);
@@ -1512,8 +1524,21 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
   if (p.acc_lds && (size_t)(p.lanes - 1) * 2048 > 160u * 1024) // one 2 KiB row per group-state lane (the error lane lives in registers)
     return L.fail(LLKV_UNSUPPORTED, "dense group state does not fit the LDS (" + std::to_string(p.lanes) + " lanes)");
   p.acc_part = partitioned;
+  // 4-byte cells: every lane a count or a bounded integer sum (and the first-row lane over fewer than 2^32 rows), and what ONE
+  // workgroup image can add up — it sees at most rows / 128 + 16 384 rows (fixed_point_grid) — stays below 2^31
+  bool narrow = false;
+  if (image && !partitioned && !std::getenv("LLKV_HIP_IMAGE_WIDE_CELLS")) {
+    uint64_t rows = 0;
+    for (uint32_t k = 0; k < n_keys; ++k) if (const ColumnInfo *ci = resolve(key_fields[k])) rows = std::max(rows, ci->rows);
+    double bound = 1.0;
+    narrow = rows > 0 && rows < (1ull << 32) && L.group_narrow.size() == groups.size();
+    for (double b : L.group_narrow) { narrow = narrow && b >= 0.0; bound = std::max(bound, b); }
+    narrow = narrow && bound * ((double)(rows / 128 + 16384)) < 2147483648.0;
+    if (narrow) p.image_min_grid = 256;
+  }
+  p.image_cell32 = narrow;
   if (image && !partitioned) {
-    p.image_passes = (int)(((size_t)p.ng * p.k_image * 8 + kMaxImageBytes - 1) / kMaxImageBytes);
+    p.image_passes = (int)(((size_t)p.ng * p.k_image * (narrow ? 4 : 8) + kMaxImageBytes - 1) / kMaxImageBytes);
     if (p.image_passes < 1) p.image_passes = 1;
     if (p.image_passes > kMaxImagePasses)
       return L.fail(LLKV_UNSUPPORTED, "the group image (" + std::to_string(p.ng) + " groups × " + std::to_string(p.k_image) + " lanes) needs more than " +
@@ -1541,7 +1566,7 @@ int lower_plan(const ColumnResolver &resolve, const llkv_filter *filters, uint32
                     !std::getenv("LLKV_HIP_SCAN_NO_LATE");
   p.late_columns = late;
   p.type_string = "Plan<" + cols + "," + pred + "," + keys + "," + ag + "," + std::to_string(p.unroll) + "," + (p.acc_part ? "3" : p.acc_image ? "2" : p.acc_lds ? "1" : "0") +
-                  (late ? ",1," + std::to_string(early_slots) : p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
+                  (late ? ",1," + std::to_string(early_slots) : p.image_cell32 ? "," + std::to_string(p.image_passes) + ",-1,1" : p.image_passes > 1 ? "," + std::to_string(p.image_passes) : std::string()) + ">";
   return LLKV_OK;
 }
 

@@ -92,6 +92,7 @@ struct LoweredPlan {
   bool acc_image = false;   // ONE accumulator image per workgroup in LDS, shared by its threads (hundreds … thousands of groups)
   bool acc_part = false;    // the shared-image lowering for the partitioned route (group_part.cpp): up to 2^24 dense groups, no LDS bound
   int image_passes = 1;     // … the groups cut into this many slices, one scan of the table each
+  bool image_cell32 = false; // … with 4-byte cells (counts and bounded integer sums only: Plan::CELL32)
   // shared-image plans: the kernel's image has k_image lanes per group; the fold expands them into the k lanes of the
   // exchange image — exchange lane j of a group = xf(kernel lane image_src[j]): 0 as is, 1 low 32 bits, 2 high part (>> 32)
   int k_image = 0;

@@ -22,7 +22,7 @@ def _flat(rows):
 
 def _image(pq):
     import re
-    return re.search(r",2(,\d+)?>$", pq.kernel_signature) is not None
+    return re.search(r",2(,\d+(,-1,1)?)?>$", pq.kernel_signature) is not None
 
 
 @pytest.mark.parametrize("chunks", [[7], [4096, 4097, 5], [65536, 70000, 30011]])
@@ -68,6 +68,53 @@ def test_shared_image_group_by_matches_oracle(rt, orc, abi, chunks):
     assert _image(pq)
     got, exp = pq.run(), orc.groupby(ot, None, [1], [A.min(8), A.max(8), A.count_star()], True)
     assert _flat(got) == _flat(exp)
+
+
+@pytest.mark.parametrize("chunks", [[4096, 4097, 5], [65536, 70000, 30011]])
+def test_counts_and_bounded_integer_sums_take_four_byte_image_cells(rt, orc, abi, chunks, monkeypatch):
+    """Plan::CELL32: every lane a count or an integer sum the statistics bound below 2^31 per workgroup image (and the
+    first-row lane): 4-byte cells — 15 156 groups × 3 lanes in ONE slice instead of three — with the same answers as the
+    8-byte cells and the oracle; a column whose values could overflow 32 bits per image keeps the wide cells."""
+    rng = np.random.default_rng(23 + len(chunks))
+    n = sum(chunks)
+    k_day = rng.integers(8000, 10526, size=n).astype(np.int32)
+    k_tag = [("N", "R", "A", "O", "F", "")[k] for k in rng.integers(0, 6, size=n)]
+    small = rng.integers(-50, 51, size=n).astype(np.int64)
+    huge = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+    f64 = rng.normal(size=n)
+    va = rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_DATE32, k_day), (2, abi.DT_UTF8, k_tag), (3, abi.DT_INT64, small, va), (4, abi.DT_INT64, huge), (5, abi.DT_FLOAT64, f64),
+                                       (6, abi.DT_INT64, small)], chunks)
+    A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
+    narrow_aggs = [A.count_star(), A.sum(6), A.count(3), A.sum(3), A.avg(3), A.count_nulls(3)]
+    for keys in ([2, 1], [1]):
+        for order in (True, False):
+            for pred in (None, [F(6, O.GreaterThan(-10))]):
+                pq = rt.PreparedQuery(ht, pred, narrow_aggs, keys, order)
+                assert pq.kernel_signature.endswith(",-1,1>"), pq.kernel_signature
+                got = pq.run()
+                pq.close()
+                want = orc.groupby(ot, pred, keys, narrow_aggs, order)
+                assert _flat(got) == _flat(want), (keys, order)
+                monkeypatch.setenv("LLKV_HIP_IMAGE_WIDE_CELLS", "1")
+                pq = rt.PreparedQuery(ht, pred, narrow_aggs, keys, order)
+                assert not pq.kernel_signature.endswith(",-1,1>")
+                assert _flat(pq.run()) == _flat(got)
+                pq.close()
+                monkeypatch.delenv("LLKV_HIP_IMAGE_WIDE_CELLS")
+    # the slices: (tag, day) = 6 × 2 526 groups × 5 lanes are two slices of 4-byte cells, four of 8-byte ones
+    pq = rt.PreparedQuery(ht, None, narrow_aggs, [2, 1], True)
+    assert pq.kernel_signature.endswith(",2,2,-1,1>"), pq.kernel_signature
+    pq.close()
+    monkeypatch.setenv("LLKV_HIP_IMAGE_WIDE_CELLS", "1")
+    pq = rt.PreparedQuery(ht, None, narrow_aggs, [2, 1], True)
+    assert pq.kernel_signature.endswith(",2,4>"), pq.kernel_signature
+    pq.close()
+    monkeypatch.delenv("LLKV_HIP_IMAGE_WIDE_CELLS")
+    for wide in ([A.count_star(), A.sum(4)], [A.count_star(), A.sum(5)], [A.count_star(), A.min(6)]):
+        pq = rt.PreparedQuery(ht, None, wide, [1], True)
+        assert _image(pq) and not pq.kernel_signature.endswith(",-1,1>"), pq.kernel_signature
+        pq.close()
 
 
 def test_shared_image_results_do_not_depend_on_launch_geometry_or_shards(rt, abi, tpch):
