@@ -1051,6 +1051,7 @@ llkv_status llkv_hip_init(int32_t device_ordinal) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) g_ctx.cu_count = (uint32_t)prop.multiProcessorCount;
   g_ctx.ready = true;
+  if (!std::getenv("LLKV_HIP_NO_STAGING_PRIME")) staging_prime();
   return LLKV_OK;
 }
 

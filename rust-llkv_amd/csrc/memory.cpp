@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <thread>
@@ -286,6 +287,28 @@ void staging_totals(uint64_t *bytes, double *seconds) {
   if (seconds) *seconds = g_stager.staged_seconds;
 }
 void staging_release() { g_stager.release(); }
+// The device binding makes the two copy lanes of the pinned-in-place path and sends one page-locked block through each: the
+// first hipHostRegister + DMA of a process costs 23 ms whatever it copies (profiles/r03/staging_cold.txt: the first 240 MB
+// column of a process 27.6 ms, the same column of a second table 4.4 ms) — paid here, once, not by the first table.
+// Best effort: a refusal leaves the lanes to be made by the first staging call, as before.
+void staging_prime() {
+  std::lock_guard<std::mutex> lk(g_stager.mu);
+  if (g_stager.init(2) != LLKV_OK) return;
+  constexpr size_t kBytes = 8u << 20;
+  void *host = std::aligned_alloc(4096, kBytes);
+  void *dev = scratch_alloc(kBytes);
+  if (host && dev) {
+    std::memset(host, 0, kBytes);
+    if (hipHostRegister(host, kBytes, hipHostRegisterDefault) == hipSuccess) {
+      for (int k = 0; k < 2; ++k) (void)hipMemcpyAsync(dev, host, kBytes, hipMemcpyHostToDevice, g_stager.lanes[k].stream);
+      for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(g_stager.lanes[k].stream);
+      (void)hipHostUnregister(host);
+    }
+    (void)hipGetLastError();
+  }
+  scratch_free(dev);
+  std::free(host);
+}
 
 // ---- pinned host memory cache -------------------------------------------------------
 namespace {
