@@ -295,6 +295,7 @@ int stage_to_device(const std::vector<StagePiece> &pieces);
 int stage_from_pinned(void *d_dst, const void *h_pinned, size_t bytes); // (a block of pinned_acquire)
 void staging_totals(uint64_t *bytes, double *seconds);
 void staging_release();
+uint32_t part_block_threads(); // threads of the partitioned GROUP BY's scatter workgroups (group_part.cpp)
 void staging_prime(); // llkv_hip_init: the copy lanes and the first registration of the process
 // HBM → pageable host memory through the staging lanes (pinned rings, one copier thread each); the streams used are
 // the lanes' own: the data must be complete on the device before the call.

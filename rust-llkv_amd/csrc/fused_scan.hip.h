@@ -1317,12 +1317,19 @@ constexpr int kPartStageLanes = 7;   // records of up to 7 words are sorted by p
 // step and the record stores of this one at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Exclusive scan of cnt[0 .. 4·1024) in place by the 1 024 threads of the workgroup (four entries each); returns the total.
-__device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wave_sum /*[16]*/) {
-  static_assert(kMaxParts == 4 * kImgBlock, "four entries per thread");
+// Exclusive scan of cnt[0 .. kMaxParts) in place by the B threads of the workgroup (kMaxParts / B entries each); returns the total.
+template <int B> __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wave_sum /*[B / 64]*/) {
+  constexpr int E = kMaxParts / B; // entries per thread
+  static_assert(E * B == kMaxParts && E % 4 == 0, "whole uint4s per thread");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint4 c = *reinterpret_cast<const uint4 *>(cnt + 4 * tid);
-  const uint32_t mine = c.x + c.y + c.z + c.w;
+  uint32_t c[E];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < E / 4; ++q) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(cnt + E * tid + 4 * q);
+    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+    mine += v.x + v.y + v.z + v.w;
+  }
   uint32_t incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -1333,13 +1340,21 @@ __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wav
   lds_barrier();
   uint32_t before = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < B / 64; ++w) {
     const uint32_t x = wave_sum[w];
     before += (uint32_t)w < wave ? x : 0u;
     total += x;
   }
-  const uint32_t ex = before + incl - mine;
-  *reinterpret_cast<uint4 *>(cnt + 4 * tid) = uint4{ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z};
+  uint32_t ex = before + incl - mine;
+#pragma unroll
+  for (int q = 0; q < E / 4; ++q) {
+    uint4 v;
+    v.x = ex; ex += c[4 * q];
+    v.y = ex; ex += c[4 * q + 1];
+    v.z = ex; ex += c[4 * q + 2];
+    v.w = ex; ex += c[4 * q + 3];
+    *reinterpret_cast<uint4 *>(cnt + E * tid + 4 * q) = v;
+  }
   lds_barrier();
   return total;
 }
@@ -1357,43 +1372,44 @@ __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wav
 //            so the 2 048 records of a step are first put in partition order in the LDS — a counter per partition ranks
 //            them, a scan places the partitions — and leave as runs of consecutive words (records of ≤ 7 words; wider
 //            ones go straight from their thread).
-template <class P> __device__ __forceinline__ void part_scatter_body(const ScanParams &p) {
+template <class P, int B = 1024> __device__ __forceinline__ void part_scatter_body(const ScanParams &p) {
+  constexpr int kStep = B * kRowsPerThread; // rows of one workgroup step
   static_assert(P::first, "partitioned plans keep the first row of every group");
   constexpr int K = P::K - 1; // words of a record: [0] group within the partition | row within the tile << 32, then lanes 2 …
   constexpr bool STAGED = K <= kPartStageLanes;
   __shared__ __attribute__((aligned(16))) uint32_t cell[kMaxParts];  // next record position of each partition's cell of this tile
   __shared__ __attribute__((aligned(16))) uint32_t scnt[STAGED ? kMaxParts : 4]; // the step's records per partition → where they start in `stage`
-  __shared__ uint32_t wave_sum[16];
-  __shared__ uint32_t dest[STAGED ? kImgStepRows : 1];       // record position of each staged slot
-  __shared__ uint64_t stage[STAGED ? kImgStepRows * K : 1];
+  __shared__ uint32_t wave_sum[B / 64];
+  __shared__ uint32_t dest[STAGED ? kStep : 1];       // record position of each staged slot
+  __shared__ uint64_t stage[STAGED ? kStep * K : 1];
   const uint32_t tid = threadIdx.x, tile = blockIdx.x, np = p.part_np;
   const TileDesc td = load_tile_desc(p.tiles, tile);
-  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += kImgBlock) {
+  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += B) {
     cell[i] = 0u;
     if constexpr (STAGED) scnt[i] = 0u;
   }
   lds_barrier();
   uint32_t err = 0;
   const uint32_t mask = (1u << p.part_shift) - 1u;
-  const uint32_t nsteps = (td.rows + kImgStepRows - 1) / kImgStepRows;
+  const uint32_t nsteps = (td.rows + kStep - 1) / kStep;
   auto each_step = [&](auto &&rows_of) { // two steps of loads in flight
     uint32_t s = 0;
     for (; s + 1 < nsteps; s += 2) {
       Loaded a, b;
-      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
-      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + 1) * kImgStepRows + (uint64_t)tid * kRowsPerThread, b);
+      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kStep + (uint64_t)tid * kRowsPerThread, a);
+      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)(s + 1) * kStep + (uint64_t)tid * kRowsPerThread, b);
       rows_of(s, a);
       rows_of(s + 1, b);
     }
     if (s < nsteps) {
       Loaded a;
-      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kImgStepRows + (uint64_t)tid * kRowsPerThread, a);
+      load_all<typename P::ColList>(p, td.dev_row + (uint64_t)s * kStep + (uint64_t)tid * kRowsPerThread, a);
       rows_of(s, a);
     }
   };
   // ---- sweep 1 ------------------------------------------------------------------------------------------------------
   each_step([&](uint32_t s, const Loaded &ld) {
-    const uint32_t row0 = s * kImgStepRows + tid * kRowsPerThread;
+    const uint32_t row0 = s * kStep + tid * kRowsPerThread;
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
       Ctx c{p, ld, 0u, td.logical_row + row0 + j};
@@ -1404,10 +1420,10 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
     }
   });
   lds_barrier();
-  const uint32_t tile_rows = part_block_scan(cell, wave_sum);
+  const uint32_t tile_rows = part_block_scan<B>(cell, wave_sum);
   const uint32_t tile_base = tile * (uint32_t)kPartTileRows;
   uint32_t *cells_out = p.part_hist + (uint64_t)tile * (np + 1);
-  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += kImgBlock) {
+  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += B) {
     const uint32_t at = tile_base + cell[i];
     cell[i] = at;
     if (i < np) cells_out[i] = at;
@@ -1416,7 +1432,7 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
   lds_barrier();
   // ---- sweep 2 ------------------------------------------------------------------------------------------------------
   each_step([&](uint32_t s, const Loaded &ld) {
-    const uint32_t row0 = s * kImgStepRows + tid * kRowsPerThread;
+    const uint32_t row0 = s * kStep + tid * kRowsPerThread;
     uint64_t contrib[kRowsPerThread][K];
     uint32_t part[kRowsPerThread], rank[kRowsPerThread];
     bool pass[kRowsPerThread];
@@ -1445,7 +1461,7 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
       }
     } else {
       lds_barrier();
-      const uint32_t total = part_block_scan(scnt, wave_sum); // scnt: records per partition → first slot of each partition
+      const uint32_t total = part_block_scan<B>(scnt, wave_sum); // scnt: records per partition → first slot of each partition
 #pragma unroll
       for (int j = 0; j < kRowsPerThread; ++j) {
         if (!pass[j]) continue;
@@ -1456,13 +1472,13 @@ template <class P> __device__ __forceinline__ void part_scatter_body(const ScanP
       }
       lds_barrier();
       // the cells advance by what the step put into them; the staged words leave in order
-      for (uint32_t i = tid; i < np; i += kImgBlock) cell[i] += (i + 1 < (uint32_t)kMaxParts ? scnt[i + 1] : total) - scnt[i];
-      for (uint32_t w = tid; w < total * K; w += kImgBlock) {
+      for (uint32_t i = tid; i < np; i += B) cell[i] += (i + 1 < (uint32_t)kMaxParts ? scnt[i + 1] : total) - scnt[i];
+      for (uint32_t w = tid; w < total * K; w += B) {
         const uint32_t slot = w / K, l = w - slot * K;
         p.part_val[(uint64_t)dest[slot] * K + l] = stage[w]; // (a non-temporal store here: 2.8 ms instead of 1.8 — the L2 merges the runs into lines)
       }
       lds_barrier();
-      for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += kImgBlock) scnt[i] = 0u;
+      for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += B) scnt[i] = 0u;
       lds_barrier();
     }
   });

@@ -54,6 +54,17 @@ struct PartGroupBy {
   }
 };
 
+// Threads of one scatter workgroup.  The scatter is a chain of LDS phases between barriers with the record stores at its
+// end: smaller workgroups leave room for several on a CU, and one's stores drain while another ranks its rows.
+uint32_t part_block_threads() {
+  static const uint32_t b = [] {
+    const char *e = std::getenv("LLKV_HIP_PART_BLOCK");
+    const int v = e ? std::atoi(e) : 0;
+    return v == 256 || v == 512 || v == 1024 ? (uint32_t)v : 1024u;
+  }();
+  return b;
+}
+
 void part_groupby_free(PartGroupBy *p) { delete p; }
 const LoweredPlan *part_groupby_plan(const PartGroupBy *p) { return &p->plan; }
 
@@ -205,7 +216,7 @@ int PartGroupBy::run(LazyGroups *out) {
   sp.part_shift = shift;
   sp.part_np = np;
   sp.part_err = flags.as<uint32_t>();
-  if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, 1024))) return rc;
+  if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, part_block_threads()))) return rc;
   mark("scatter");
   HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), ts->d_tiles, group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
                              d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s));

@@ -40,8 +40,9 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { image_scan_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Part:
-    // every tile's records in partition order (1 024 threads)
-    s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { part_scatter_body<" + ts + ">(p); }\n";
+    // every tile's records in partition order (part_block_threads() threads per workgroup)
+    s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(part_block_threads()) + ") void llkv_jit_a(const ScanParams p) { part_scatter_body<" + ts + ", " +
+         std::to_string(part_block_threads()) + ">(p); }\n";
     break;
   case JitKind::Select:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { select_body<" + ts + ", false>(p); }\n";
