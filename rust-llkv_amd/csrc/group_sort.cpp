@@ -277,17 +277,23 @@ int SortedGroupBy::run(LazyGroups *out) {
   const bool has_distinct = red_plan.distinct_field >= 0;
   JoinKeyColumn dcol;
   std::memset(&dcol, 0, sizeof dcol);
+  Scratch ddict; // numeric image of the dictionary a DISTINCT aggregate is over
   if (has_distinct) {
     const DeviceColumn &dc = table->cols.at((uint32_t)red_plan.distinct_field);
     dcol.values = dc.d_values;
     dcol.valid = dc.info.nullable ? dc.d_valid : nullptr;
-    dcol.width = 8;
-    dcol.is_signed = 0; // only equality matters: the 64-bit pattern (Float64: "by bit pattern", llkv-aggregate/src/lib.rs:252-331)
+    dcol.width = dc.info.dtype == LLKV_DT_DATE32 ? 4 : (dc.info.dtype == LLKV_DT_INT64 || dc.info.dtype == LLKV_DT_FLOAT64) ? 8 : 1; // (dictionary codes and Booleans: a byte)
+    dcol.is_signed = dc.info.dtype == LLKV_DT_DATE32; // otherwise only equality matters: the cell's pattern (Float64: "by bit pattern", llkv-aggregate/src/lib.rs:252-331)
+    if (red_plan.distinct_numeric == 1) {
+      if ((rc = ddict.alloc(256 * 8))) return rc;
+      HIP_TRY(hipMemcpyAsync(ddict.p, red_plan.distinct_dict_num.data(), 256 * 8, hipMemcpyHostToDevice, s)); // (the plan outlives the run)
+    }
     HIP_TRY(hj_launch_gather_sort_keys(dcol, 0, nullptr, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
     size_t tb = 0;
-    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, 64, s));
+    const uint32_t dbits = dcol.width == 1 ? 8 : 64;
+    HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, dbits, s));
     if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
-    HIP_TRY(hj_sort_u64_u32_bits(tmp.p, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, 64, s));
+    HIP_TRY(hj_sort_u64_u32_bits(tmp.p, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, dbits, s));
     std::swap(perm, perm_other);
     if (dcol.valid) {
       if ((rc = vkeys_a.alloc(n * 4)) || (rc = vkeys_b.alloc(n * 4))) return rc;
@@ -421,7 +427,7 @@ int SortedGroupBy::run(LazyGroups *out) {
   Scratch dval, dhead;
   if (has_distinct) {
     if ((rc = dval.alloc(n * 8)) || (rc = dhead.alloc(n))) return rc;
-    HIP_TRY(hj_launch_distinct_heads(dcol, sel.d_dev, perm, flags.as<uint64_t>(), n, dval.as<uint64_t>(), dhead.as<uint8_t>(), s));
+    HIP_TRY(hj_launch_distinct_heads(dcol, red_plan.distinct_numeric, ddict.as<double>(), sel.d_dev, perm, flags.as<uint64_t>(), n, dval.as<uint64_t>(), dhead.as<uint8_t>(), s));
     p.dval = dval.as<uint64_t>();
     p.dhead = dhead.as<uint8_t>();
     p.first_rows = first_d.as<uint64_t>();

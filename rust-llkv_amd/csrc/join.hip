@@ -1568,26 +1568,33 @@ hipError_t hj_launch_group_boundaries(GroupKeySet ks, const uint64_t *dev_rows, 
 // so inside a group equal argument values are neighbours.  Per sorted position: the argument's 64-bit value and whether
 // the row is the first of its group with that value (a NULL cell never is).  `group_start[i]` != 0 marks a group's
 // first position.
-__global__ __launch_bounds__(256) void hj_distinct_heads_kernel(JoinKeyColumn col, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *group_start,
-                                                                 uint64_t n, uint64_t *dval, uint8_t *dhead) {
+// `numeric`: what a DISTINCT lane adds for a key that is not its own number — 0 the 64-bit cell as it is (Int64 by value, Float64
+// by bit pattern), 1 the numeric image of a dictionary code (`dict_num[code]`: array_value_to_numeric over the string), 2 a
+// Boolean's 1.0 / 0.0, 3 a Date32's day number as f64 (llkv-aggregate/src/lib.rs:400-449; the keys themselves are compared
+// as cells: DistinctKey::from_array :261-331).
+__global__ __launch_bounds__(256) void hj_distinct_heads_kernel(JoinKeyColumn col, uint32_t numeric, const double *dict_num, const uint64_t *dev_rows, const uint32_t *perm,
+                                                                 const uint64_t *group_start, uint64_t n, uint64_t *dval, uint8_t *dhead) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t row = dev_rows[perm[i]];
-  const uint64_t v = reinterpret_cast<const uint64_t *>(col.values)[row];
-  const bool ok = !col.valid || col.valid[row] != 0;
+  long long v;
+  const bool ok = key_cell(col, dev_rows[perm[i]], &v);
   bool head = ok;
   if (ok && i && group_start[i] == 0) {
-    const uint64_t before = dev_rows[perm[i - 1]];
-    const bool ok_before = !col.valid || col.valid[before] != 0;
-    head = !(ok_before && reinterpret_cast<const uint64_t *>(col.values)[before] == v);
+    long long before;
+    const bool ok_before = key_cell(col, dev_rows[perm[i - 1]], &before);
+    head = !(ok_before && before == v);
   }
-  dval[i] = v;
+  uint64_t image = (uint64_t)v;
+  if (numeric == 1) image = (uint64_t)__double_as_longlong(dict_num[(uint8_t)v]);
+  else if (numeric == 2) image = (uint64_t)__double_as_longlong(v ? 1.0 : 0.0);
+  else if (numeric == 3) image = (uint64_t)__double_as_longlong((double)v);
+  dval[i] = image;
   dhead[i] = head ? 1 : 0;
 }
-hipError_t hj_launch_distinct_heads(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *group_start, uint64_t n, uint64_t *dval,
-                                    uint8_t *dhead, hipStream_t s) {
+hipError_t hj_launch_distinct_heads(const JoinKeyColumn &col, uint32_t numeric, const double *dict_num, const uint64_t *dev_rows, const uint32_t *perm,
+                                    const uint64_t *group_start, uint64_t n, uint64_t *dval, uint8_t *dhead, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(hj_distinct_heads_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, dev_rows, perm, group_start, n, dval, dhead);
+  hipLaunchKernelGGL(hj_distinct_heads_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, col, numeric, dict_num, dev_rows, perm, group_start, n, dval, dhead);
   return hipGetLastError();
 }
 

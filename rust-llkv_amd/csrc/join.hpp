@@ -308,9 +308,10 @@ struct GroupKeySet {
 // flags[i] = 1 when sorted position i starts a new group (i == 0 or some key differs from position i − 1).
 hipError_t hj_launch_group_boundaries(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, uint64_t n, uint64_t *flags, hipStream_t s);
 // seg_start[offsets[i]] = i for every flagged i; seg_start[n_groups] = n.
-// per sorted position: the 64-bit value of `col` (an Int64 / Float64 column) and "first of its group with this value"
-hipError_t hj_launch_distinct_heads(const JoinKeyColumn &col, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *group_start, uint64_t n, uint64_t *dval,
-                                    uint8_t *dhead, hipStream_t s);
+// per sorted position: what a DISTINCT lane adds for the cell of `col` (numeric 0: the 64-bit cell of an Int64 / Float64 column;
+// 1: dict_num[code] of a Utf8 column; 2: a Boolean's 1.0 / 0.0; 3: a Date32's day number as f64) and "first of its group with this cell"
+hipError_t hj_launch_distinct_heads(const JoinKeyColumn &col, uint32_t numeric, const double *dict_num, const uint64_t *dev_rows, const uint32_t *perm,
+                                    const uint64_t *group_start, uint64_t n, uint64_t *dval, uint8_t *dhead, hipStream_t s);
 hipError_t hj_launch_segment_starts(const uint64_t *flags, const uint64_t *offsets, uint64_t n, uint64_t n_groups, uint64_t *seg_start, hipStream_t s);
 // Raw key cells of each group's first sorted row: out_vals[k][g] (sign-extended to i64), out_valid[k][g].
 hipError_t hj_launch_group_keys(GroupKeySet ks, const uint64_t *dev_rows, const uint32_t *perm, const uint64_t *seg_start, const uint32_t *order, uint64_t n_groups,

@@ -1167,11 +1167,20 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       if (!s.expr || s.expr_len != 1 || s.expr[0].kind != LLKV_TOK_COLUMN) return L.fail(LLKV_UNSUPPORTED, "DISTINCT inside GROUP BY over a computed argument");
       const ColumnInfo *dci = resolve(s.expr[0].field_id);
       if (!dci) return L.fail(LLKV_INVALID_ARGUMENT, "unknown column '" + std::to_string(s.expr[0].field_id) + "' in aggregate");
-      if (dci->dtype != LLKV_DT_INT64 && dci->dtype != LLKV_DT_FLOAT64) return L.fail(LLKV_UNSUPPORTED, std::string("DISTINCT aggregate over ") + dtype_name(dci->dtype));
+      // DistinctKey::from_array (llkv-aggregate/src/lib.rs:261-331): Int by value, Float by bits, Str by its string (here: its
+      // dictionary code — the staged dictionary holds every string once), Bool, Date by its day number; what SUM / TOTAL / AVG
+      // add for the last three is their numeric image in the Float64 accumulators (:400-449,889-924,1035-1066,1200-1232)
+      const bool keyed = dci->dtype == LLKV_DT_UTF8 || dci->dtype == LLKV_DT_BOOLEAN || dci->dtype == LLKV_DT_DATE32;
+      if (dci->dtype != LLKV_DT_INT64 && dci->dtype != LLKV_DT_FLOAT64 && !keyed) return L.fail(LLKV_UNSUPPORTED, std::string("DISTINCT aggregate over ") + dtype_name(dci->dtype));
       if (p.distinct_field >= 0 && p.distinct_field != (int64_t)s.expr[0].field_id)
         return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates over more than one column in a GROUP BY");
       p.distinct_field = s.expr[0].field_id;
-      const bool f = dci->dtype == LLKV_DT_FLOAT64;
+      p.distinct_numeric = dci->dtype == LLKV_DT_UTF8 ? 1u : dci->dtype == LLKV_DT_BOOLEAN ? 2u : dci->dtype == LLKV_DT_DATE32 ? 3u : 0u;
+      if (dci->dtype == LLKV_DT_UTF8 && p.distinct_dict_num.empty()) {
+        p.distinct_dict_num.assign(256, 0.0);
+        for (size_t c = 0; c < dci->dictionary.size() && c < 256; ++c) p.distinct_dict_num[c] = parse_numeric_or_zero(dci->dictionary[c]);
+      }
+      const bool f = dci->dtype == LLKV_DT_FLOAT64 || keyed;
       const int count_lane = add_group("DistinctCount", {ADD_I64});
       if (s.kind == LLKV_AGG_COUNT) { o.fin = AggFinal::CountValid; o.lane = count_lane; p.aggs.push_back(o); continue; }
       if (!f && s.kind != LLKV_AGG_TOTAL) { // the checked_add chain over the distinct values cannot overflow whatever their order

@@ -99,6 +99,8 @@ struct LoweredPlan {
   std::vector<uint8_t> image_src, image_xf;
   uint32_t image_min_grid = 0; // workgroups below which an image lane could overflow (fixed-point sums)
   int64_t distinct_field = -1; // reduce plans (sort-based GROUP BY): the column every DISTINCT aggregate is over (-1: none)
+  uint32_t distinct_numeric = 0; // what its lanes add: 0 the Int64 / Float64 cell, 1 the numeric image of a Utf8 code, 2 a Boolean's 1.0 / 0.0, 3 a Date32's day number (join.hpp: hj_launch_distinct_heads)
+  std::vector<double> distinct_dict_num; // (1) array_value_to_numeric over the dictionary
   int k = 1;      // lanes per group
   int lanes = 2;  // ng * k + 1
   int unroll = 2;

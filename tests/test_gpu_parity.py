@@ -2607,6 +2607,51 @@ def test_distinct_aggregates_inside_group_by_match_oracle(rt, orc, abi, chunks):
         assert e.value.kind == "Unsupported"
 
 
+@pytest.mark.parametrize("chunks", [[700], [4096, 4097, 5]])
+def test_distinct_aggregates_inside_group_by_over_string_boolean_and_date_keys(rt, orc, abi, chunks):
+    """COUNT / SUM / TOTAL / AVG (DISTINCT x) per group over a Utf8, Boolean or Date32 column: the key is the cell (a string's
+    dictionary code, DistinctKey::from_array llkv-aggregate/src/lib.rs:261-331), what the Float64 accumulators add is its numeric
+    image (array_value_to_numeric :400-449).  On the sort-based route the cell is the least significant sort key and the head of
+    every run of equal cells adds `dict_num[code]` / 1.0 or 0.0 / the day number.  Counts exact, f64 sums within 1e-9 (the oracle
+    adds the images in order of first appearance)."""
+    rng = np.random.default_rng(57 + len(chunks))
+    n = sum(chunks)
+    words = ["12", " 3.5 ", "abc", "", "1e2", "12.0", "-7.25", ".5", "1.", "+4", "0.125", "1000000.5", "1", "1.0"]
+    txt = [words[i] for i in rng.integers(0, len(words), size=n)]
+    boo = rng.integers(0, 2, size=n).astype(np.uint8)
+    day = rng.integers(-20, 20, size=n).astype(np.int32) * 365
+    g_int = rng.integers(0, 23, size=n).astype(np.int64)
+    g_tag = [("a", "b", "", "dd")[k] for k in rng.integers(0, 4, size=n)]
+    val = rng.integers(-9, 9, size=n).astype(np.int64)
+    vt, vb, vd, vg = rng.random(n) > 0.15, rng.random(n) > 0.1, rng.random(n) > 0.1, rng.random(n) > 0.1
+    ht = rt.HipTable(1, chunks)
+    ht.append_utf8_column(1, txt, valid=vt)
+    ht.append_column(2, abi.DT_BOOLEAN, boo, valid=vb)
+    ht.append_column(3, abi.DT_DATE32, day, valid=vd)
+    ht.append_column(4, abi.DT_INT64, g_int)
+    ht.append_utf8_column(5, g_tag, valid=vg)
+    ht.append_column(6, abi.DT_INT64, val)
+    ot = orc.OracleTable(n)
+    ot.add(1, abi.DT_UTF8, [t if ok else None for t, ok in zip(txt, vt)]).add(2, abi.DT_BOOLEAN, boo, list(vb)).add(3, abi.DT_DATE32, day, list(vd))
+    ot.add(4, abi.DT_INT64, g_int).add(5, abi.DT_UTF8, [t if ok else None for t, ok in zip(g_tag, vg)]).add(6, abi.DT_INT64, val)
+    A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
+
+    def D(kind, e):
+        s = getattr(A, kind)(e)
+        s.distinct = True
+        return s
+
+    for field in (1, 2, 3):
+        aggs = [A.count_star()] + [D(k, field) for k in ("count", "sum", "total", "avg")] + [A.sum(6), A.count(field)]
+        for keys in ([4], [5], [5, 4]):
+            for pred in (None, [F(6, O.GreaterThan(-3))]):
+                for order in (True, False):
+                    got, want = rt.groupby(ht, pred, keys, aggs, order), orc.groupby(ot, pred, keys, aggs, order)
+                    assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (field, keys, order)
+                    for x, y in zip(got, want):
+                        assert_values(x.values, y.values, f"distinct/groupby over field {field} by {keys}")
+
+
 def test_sorted_input_shortcut_of_the_sort_based_group_by(rt, abi, monkeypatch):
     """GROUP BY a column that is in key order already (a clustered primary key) skips the sort; forcing the sort
     (LLKV_HIP_GROUP_ALWAYS_SORT) gives the same groups and the same bits — the stable sort leaves such rows where
