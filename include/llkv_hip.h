@@ -353,9 +353,10 @@ llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t f
  * narrowed to 8 B/row at staging — half the traffic, and a sum of < 2^63 rows can
  * no longer leave i128, so the order-dependent overflow check disappears.  A column
  * with a wider value is staged as low and high halves (16 B/row): SUM / TOTAL / AVG
- * (exact, when rows · max|v| ≤ i128::MAX excludes an overflowing prefix), the counts and
- * plain scan projections take it, every other use of it — and such a column in a
- * sharded table — returns LLKV_UNSUPPORTED.                                                             */
+ * (exact, when rows · max|v| ≤ i128::MAX excludes an overflowing prefix), MIN / MAX (when
+ * the column's values span less than 2^64), the counts and plain scan projections take
+ * it, every other use of it — and such a column in a sharded table — returns
+ * LLKV_UNSUPPORTED.                                                                                     */
 llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint32_t field_id,
                                                     int32_t precision, int32_t scale,
                                                     const void *const *chunk_values,

@@ -500,7 +500,10 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
     i128 v = 0;
     if (a.fin == AggFinal::MinDec || a.fin == AggFinal::MaxDec) {
       out->is_null = rows == 0;
-      v = rows ? (i128)(int64_t)l[0] : 0;
+      if (a.wide_delta) { // values beyond 64 bits: the lane is the largest v − min(column) (MAX) or max(column) − v (MIN)
+        const i128 base = (i128)(((u128)a.wide_base_hi << 64) | a.wide_base_lo);
+        v = !rows ? 0 : a.wide_delta == 1 ? base + (i128)(u128)l[0] : base - (i128)(u128)l[0];
+      } else v = rows ? (i128)(int64_t)l[0] : 0;
     } else {
       // (wide values: the limb sums mod 2^128 — the lowering excluded a prefix outside i128, so the true sum is inside)
       const i128 sum = a.wide ? (i128)((u128)l[0] + ((u128)l[1] << 32) + ((u128)l[2] << 64) + ((u128)l[3] << 96))

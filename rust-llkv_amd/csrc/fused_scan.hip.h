@@ -606,6 +606,16 @@ template <int SLO, int SHI> struct SumDecWide {
     o[3] = (uint64_t)(hi >> 32); // arithmetic shift: the signed top limb
   }
 };
+// MIN / MAX over such a column whose values span less than 2^64 (llkv-aggregate/src/lib.rs:1332-1352,1400-1420): v − min(column)
+// — or max(column) − v — fits 64 bits and is the wrapping difference of the low halves; the host adds the base back in i128.
+template <int SLO, class Base, int NEG> struct MaxWideDelta {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_MAX_U64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    const uint64_t lo = c.get<U64>(SLO, j), base = Base::eval(c, j);
+    o[0] = NEG ? base - lo : lo - base;
+  }
+};
 template <class E> struct SumI64Fast {
   static constexpr int N = 1;
   static constexpr int op(int) { return OP_ADD_I64; }

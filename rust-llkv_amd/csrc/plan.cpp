@@ -391,14 +391,14 @@ struct Lowering {
     return LLKV_OK;
   }
   // The two buffers of a wide Decimal128 column: low halves (u64), high halves (i64).
-  int wide_slots_of(uint32_t field, int *lo, int *hi) {
+  int wide_slots_of(uint32_t field, int *lo, int *hi, bool want_hi = true) {
     *lo = *hi = -1;
     for (size_t i = 0; i < p.slot_fields.size(); ++i) {
       if (p.slot_fields[i] != field) continue;
       if (p.slot_is_valid[i] == 0) *lo = (int)i;
       if (p.slot_is_valid[i] == 2) *hi = (int)i;
     }
-    for (int part = 0; part < 2; ++part) {
+    for (int part = 0; part < (want_hi ? 2 : 1); ++part) {
       int &slot = part ? *hi : *lo;
       if (slot >= 0) continue;
       if ((int)p.slot_fields.size() >= kMaxColsHost) return fail(LLKV_UNSUPPORTED, "plan touches more than 16 column buffers");
@@ -1338,8 +1338,29 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       // four ADD_I64 lanes over the 32-bit limbs (the top one signed) — exact for < 2^31 rows, order-free.  The
       // reference's overflow check is order dependent (a prefix may leave i128 although the total fits): the plan is
       // taken only when rows · max|v| ≤ i128::MAX excludes that.  AVG: half away from zero (:1720-1742).
-      if (s.kind == LLKV_AGG_MIN || s.kind == LLKV_AGG_MAX)
-        return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over Decimal128 values beyond 64 bits (a 128-bit compare has no order-free lanes) is not on the GPU path");
+      if (s.kind == LLKV_AGG_MIN || s.kind == LLKV_AGG_MAX) {
+        // MinDecimal128 / MaxDecimal128 (llkv-aggregate/src/lib.rs:1332-1352,1400-1420: i128 min / max over the non-NULL rows).  A
+        // 128-bit compare has no order-free lanes, but a column whose values span less than 2^64 — known from staging — needs
+        // none: v − min(column) fits 64 bits and is the low halves' wrapping difference, so MAX is one MAX_U64 lane over
+        // lo − min_lo and MIN one over max_lo − lo; the host adds the column's min / max back in i128.
+        const i128 vmin = (i128)(((u128)simple_ci->wide_min_hi << 64) | simple_ci->wide_min_lo), vmax = (i128)(((u128)simple_ci->wide_max_hi << 64) | simple_ci->wide_max_lo);
+        if (vmax < vmin || (u128)(vmax - vmin) >> 64)
+          return L.fail(LLKV_UNSUPPORTED, std::string(fn) + " over Decimal128 values beyond 64 bits that span 2^64 or more (a 128-bit compare has no order-free lanes) is not on the GPU path");
+        int lo, hi;
+        if ((rc = L.wide_slots_of(s.expr[0].field_id, &lo, &hi, /*want_hi=*/false))) return rc;
+        const bool is_min = s.kind == LLKV_AGG_MIN;
+        std::string base;
+        if ((rc = L.lit_i((int64_t)(is_min ? simple_ci->wide_max_lo : simple_ci->wide_min_lo), &base, "LitU"))) return rc;
+        o.precision = simple_ci->precision; o.scale = simple_ci->scale;
+        o.wide = true;
+        o.wide_delta = is_min ? 2 : 1;
+        o.wide_base_hi = is_min ? simple_ci->wide_max_hi : simple_ci->wide_min_hi;
+        o.wide_base_lo = is_min ? simple_ci->wide_max_lo : simple_ci->wide_min_lo;
+        o.fin = is_min ? AggFinal::MinDec : AggFinal::MaxDec;
+        add_agg("MaxWideDelta<" + std::to_string(lo) + "," + base + "," + (is_min ? "1" : "0") + ">", {MAX_U64});
+        p.aggs.push_back(o);
+        continue;
+      }
       if (s.kind != LLKV_AGG_SUM && s.kind != LLKV_AGG_TOTAL && s.kind != LLKV_AGG_AVG) return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
       const u128 absmax = ((u128)simple_ci->wide_absmax_hi << 64) | simple_ci->wide_absmax_lo;
       const u128 i128_max = ~(u128)0 >> 1;

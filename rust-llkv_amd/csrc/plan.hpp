@@ -38,6 +38,7 @@ struct ColumnInfo {
   // only SUM / TOTAL / AVG (and the counts, which read no value) take the column; largest |v| as (hi, lo)
   bool wide128 = false;
   uint64_t wide_absmax_hi = 0, wide_absmax_lo = 0;
+  uint64_t wide_min_hi = 0, wide_min_lo = 0, wide_max_hi = 0, wide_max_lo = 0; // i128 smallest / largest value of a wide128 column (every cell, NULL ones too)
 };
 
 using ColumnResolver = std::function<const ColumnInfo *(uint32_t field_id)>;
@@ -66,6 +67,8 @@ struct AggOut {
                                      // non-NULL value, Int64 when there is none (llkv-executor/src/lib.rs:298-406)
   bool fast_sum = false;        // decimal sums: one wrapping lane (statistics exclude i64 overflow) instead of the 96-bit split
   bool wide = false;            // decimal sums over values beyond 64 bits: four lanes, the sums of the 32-bit limbs (SumDecWide)
+  int wide_delta = 0;           // MIN / MAX over such values: one MAX_U64 lane of (v − column min) [1] or (column max − v) [2] (MaxWideDelta)
+  uint64_t wide_base_hi = 0, wide_base_lo = 0; // … and that column min / max
   int32_t precision = 0, scale = 0; // Decimal128 results
   int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
   int exact_levels = 0; // f64 sum kept as exact grid-level lanes (SumF64X, 2 or 3 of them): value = smallest level first, summed

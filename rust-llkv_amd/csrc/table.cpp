@@ -611,6 +611,7 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
     if (t->world != 1) return (llkv_status)set_error(LLKV_UNSUPPORTED, "Decimal128 value beyond 64 bits in field " + std::to_string(field_id) + " of a sharded table");
     high.assign(t->dev_rows + 16, 0);
     unsigned __int128 absmax = 0;
+    __int128 vmin = (__int128)(~(unsigned __int128)0 >> 1), vmax = -vmin - 1; // smallest / largest value (MIN / MAX run over v − min, plan.cpp)
     for (uint32_t i = 0; i < n_chunks; ++i) { // (sequential: wide columns are rare, and max|v| is one value)
       const uint64_t rows = t->global_chunk_rows[t->first_chunk + i];
       const int64_t *src = static_cast<const int64_t *>(chunk_values[i]);
@@ -620,11 +621,15 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
         const __int128 v = ((__int128)src[2 * r + 1] << 64) | (unsigned __int128)(uint64_t)src[2 * r];
         const unsigned __int128 mag = v < 0 ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
         absmax = mag > absmax ? mag : absmax;
+        vmin = v < vmin ? v : vmin;
+        vmax = v > vmax ? v : vmax;
       }
     }
     c.info.wide128 = true;
     c.info.wide_absmax_hi = (uint64_t)(absmax >> 64);
     c.info.wide_absmax_lo = (uint64_t)absmax;
+    c.info.wide_min_hi = (uint64_t)(vmin >> 64); c.info.wide_min_lo = (uint64_t)vmin;
+    c.info.wide_max_hi = (uint64_t)(vmax >> 64); c.info.wide_max_lo = (uint64_t)vmax;
   }
   if ((rc = alloc_column(*t, 8, &c.d_values)) || (any_wide && (rc = alloc_column(*t, 8, &c.d_hi)))) {
     if (c.d_values) (void)hipFree(c.d_values);

@@ -899,6 +899,54 @@ def test_decimal128_accumulators_match_oracle(rt, orc, abi, chunks):
 
 
 @pytest.mark.parametrize("chunks", [[7], [4096, 4097, 3], [65536, 9000]])
+def test_wide_decimal128_min_max_over_a_span_below_64_bits(rt, orc, abi, chunks):
+    """MIN / MAX over Decimal128 values beyond 64 bits (llkv-aggregate/src/lib.rs:1332-1352,1400-1420: i128 min / max of the
+    non-NULL rows): when the column's values span less than 2^64 — a staging statistic — one MAX_U64 lane over v − min(column)
+    (MAX) or max(column) − v (MIN) carries them (`MaxWideDelta`) and the host adds the base back in i128.  Ungrouped and on every
+    GROUP BY route, with NULL cells and predicates, beside the limb sums of the same column; raw i128 equality with the oracle.
+    A column that spans more stays `Unsupported`."""
+    rng = np.random.default_rng(77 + len(chunks))
+    n = sum(chunks)
+    up = [10**30 + int(d) for d in rng.integers(-2**62, 2**62, size=n)]
+    down = [-(10**33) - int(d) for d in rng.integers(0, 2**63, size=n)]
+    up[n // 3], down[n // 4] = 10**30 + 2**62 + 5, -(10**33) - 2**63 - 11  # the extremes sit in known rows (still a span below 2^64)
+    valid = rng.random(n) > 0.25
+    flag = rng.integers(0, 4, size=n).astype(np.int64)
+    keys = np.array([ord("a"), ord("b"), ord("c")], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    day = rng.integers(9000, 9400, size=n).astype(np.int32)
+    sparse = (rng.integers(0, 300, size=n) * 1_000_003).astype(np.int64)
+    ht = rt.HipTable(1, chunks)
+    ht.append_decimal128_column(1, 38, 4, up, valid=valid)
+    ht.append_decimal128_column(2, 38, 0, down)
+    ht.append_column(3, abi.DT_INT64, flag)
+    ht.append_utf8_column(4, keys)
+    ht.append_column(5, abi.DT_DATE32, day)
+    ht.append_column(6, abi.DT_INT64, sparse)
+    ot = orc.OracleTable(n)
+    ot.add(1, abi.DT_DECIMAL128, up, list(valid), precision=38, scale=4)
+    ot.add(2, abi.DT_DECIMAL128, down, precision=38, scale=0)
+    ot.add(3, abi.DT_INT64, flag).add(4, abi.DT_UTF8, keys).add(5, abi.DT_DATE32, day).add(6, abi.DT_INT64, sparse)
+    A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
+    aggs = [A.min(1), A.max(1), A.min(2), A.max(2), A.count(1), A.sum(1), A.avg(2), A.count_star()]
+    for pred in (None, [F(3, O.Equals(1))], [F(3, O.GreaterThan(7))]):
+        got, want = rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs)
+        assert got == want, pred
+        for key_fields, order in (([4], True), ([5], False), ([6], True), ([4, 5], False)):
+            g, w = rt.groupby(ht, pred, key_fields, aggs, order), orc.groupby(ot, pred, key_fields, aggs, order)
+            assert [[k.value for k in r.keys] for r in g] == [[k.value for k in r.keys] for r in w], (pred, key_fields)
+            for a, b in zip(g, w):
+                assert a.values == b.values, (pred, key_fields, [k.value for k in a.keys])
+    got = rt.aggregate(ht, None, [A.max(1), A.min(2)])
+    assert got[0].value == max(v for v, ok in zip(up, valid) if ok) and got[1].value == min(down)
+    far = rt.HipTable(2, [3])
+    far.append_decimal128_column(1, 38, 0, [10**30, 10**30 + 2**64, 7])
+    for bad in ([A.min(1)], [A.max(1)]):
+        with pytest.raises(abi.LlkvError) as e:
+            rt.aggregate(far, None, bad)
+        assert e.value.kind == "Unsupported", bad
+
+
+@pytest.mark.parametrize("chunks", [[7], [4096, 4097, 3], [65536, 9000]])
 def test_wide_decimal128_sums_match_oracle(rt, orc, abi, chunks):
     """Decimal128 columns with values beyond 64 bits (staged as low and high halves): SUM / TOTAL / AVG (i128, half away
     from zero) and the counts equal the oracle's raw i128 results exactly — ungrouped, grouped by a small key (per-thread
