@@ -514,7 +514,8 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
           v = sum / n;
           if ((rem < 0 ? -rem : rem) * 2 >= n) v += sum > 0 ? 1 : -1;
         } else out->is_null = 1;
-      } else v = sum; // SUM / TOTAL: `vec![sum]` — 0, not NULL, without rows
+      } else if (a.null_without_values && rows == 0) out->is_null = 1; // SUM(DISTINCT) over no value
+      else v = sum; // SUM / TOTAL: `vec![sum]` — 0, not NULL, without rows
     }
     out->i64 = (int64_t)(uint64_t)v;
     out->i64_hi = (int64_t)(v >> 64);

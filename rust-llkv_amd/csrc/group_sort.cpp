@@ -282,7 +282,7 @@ int SortedGroupBy::run(LazyGroups *out) {
     const DeviceColumn &dc = table->cols.at((uint32_t)red_plan.distinct_field);
     dcol.values = dc.d_values;
     dcol.valid = dc.info.nullable ? dc.d_valid : nullptr;
-    dcol.width = dc.info.dtype == LLKV_DT_DATE32 ? 4 : (dc.info.dtype == LLKV_DT_INT64 || dc.info.dtype == LLKV_DT_FLOAT64) ? 8 : 1; // (dictionary codes and Booleans: a byte)
+    dcol.width = dc.info.dtype == LLKV_DT_DATE32 ? 4 : (dc.info.dtype == LLKV_DT_INT64 || dc.info.dtype == LLKV_DT_FLOAT64 || dc.info.dtype == LLKV_DT_DECIMAL128) ? 8 : 1; // (the 64-bit image of a decimal; dictionary codes and Booleans: a byte)
     dcol.is_signed = dc.info.dtype == LLKV_DT_DATE32; // otherwise only equality matters: the cell's pattern (Float64: "by bit pattern", llkv-aggregate/src/lib.rs:252-331)
     if (red_plan.distinct_numeric == 1) {
       if ((rc = ddict.alloc(256 * 8))) return rc;

@@ -1171,7 +1171,9 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       // dictionary code — the staged dictionary holds every string once), Bool, Date by its day number; what SUM / TOTAL / AVG
       // add for the last three is their numeric image in the Float64 accumulators (:400-449,889-924,1035-1066,1200-1232)
       const bool keyed = dci->dtype == LLKV_DT_UTF8 || dci->dtype == LLKV_DT_BOOLEAN || dci->dtype == LLKV_DT_DATE32;
-      if (dci->dtype != LLKV_DT_INT64 && dci->dtype != LLKV_DT_FLOAT64 && !keyed) return L.fail(LLKV_UNSUPPORTED, std::string("DISTINCT aggregate over ") + dtype_name(dci->dtype));
+      // … and Decimal by its raw value (the 64-bit image; Sum / Total / AvgDistinctDecimal128 :943-967,1089-1112,1260-1284)
+      const bool dec = dci->dtype == LLKV_DT_DECIMAL128 && !dci->wide128;
+      if (dci->dtype != LLKV_DT_INT64 && dci->dtype != LLKV_DT_FLOAT64 && !keyed && !dec) return L.fail(LLKV_UNSUPPORTED, std::string("DISTINCT aggregate over ") + dtype_name(dci->dtype));
       if (p.distinct_field >= 0 && p.distinct_field != (int64_t)s.expr[0].field_id)
         return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates over more than one column in a GROUP BY");
       p.distinct_field = s.expr[0].field_id;
@@ -1183,13 +1185,22 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       const bool f = dci->dtype == LLKV_DT_FLOAT64 || keyed;
       const int count_lane = add_group("DistinctCount", {ADD_I64});
       if (s.kind == LLKV_AGG_COUNT) { o.fin = AggFinal::CountValid; o.lane = count_lane; p.aggs.push_back(o); continue; }
-      if (!f && s.kind != LLKV_AGG_TOTAL) { // the checked_add chain over the distinct values cannot overflow whatever their order
+      if (!f && (s.kind != LLKV_AGG_TOTAL || dec)) { // the checked_add chain over the distinct values cannot overflow whatever their order (decimals: the i64 lane holds their i128 sum)
         auto mag = [](int64_t v) -> u128 { return v < 0 ? (u128)(-(i128)v) : (u128)v; };
         if (!dci->has_stats) return L.fail(LLKV_UNSUPPORTED, "SUM(DISTINCT) over an integer column without statistics (order-dependent overflow check)");
         const u128 m = mag(dci->min_i) > mag(dci->max_i) ? mag(dci->min_i) : mag(dci->max_i);
         if (m * (u128)dci->rows > (u128)INT64_MAX) return L.fail(LLKV_UNSUPPORTED, "possible i64 overflow in SUM(DISTINCT): order-dependent check is not on the GPU path");
       }
       o.count_lane = count_lane;
+      if (dec) { // finalize :1583-1612,1656-1672,1762-1800: i128 sum with the column's (precision, scale); SUM / AVG are NULL without a value
+        o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumDec : s.kind == LLKV_AGG_TOTAL ? AggFinal::TotalDec : AggFinal::AvgDec;
+        o.precision = dci->precision; o.scale = dci->scale;
+        o.fast_sum = true;
+        o.null_without_values = s.kind != LLKV_AGG_TOTAL;
+        o.lane = add_group("DistinctSumI64", {ADD_I64});
+        p.aggs.push_back(o);
+        continue;
+      }
       if (s.kind == LLKV_AGG_TOTAL) { o.fin = AggFinal::TotalF64; o.lane = add_group(f ? "DistinctSumF64" : "DistinctTotalI64", {ADD_F64}); }
       else if (f) { o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumF64 : AggFinal::AvgF64; o.lane = add_group("DistinctSumF64", {ADD_F64}); }
       else { o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumI64Fast : AggFinal::AvgI64Fast; o.lane = add_group("DistinctSumI64", {ADD_I64}); }

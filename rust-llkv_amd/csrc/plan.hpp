@@ -67,6 +67,7 @@ struct AggOut {
                                      // non-NULL value, Int64 when there is none (llkv-executor/src/lib.rs:298-406)
   bool fast_sum = false;        // decimal sums: one wrapping lane (statistics exclude i64 overflow) instead of the 96-bit split
   bool wide = false;            // decimal sums over values beyond 64 bits: four lanes, the sums of the 32-bit limbs (SumDecWide)
+  bool null_without_values = false; // SumDec over DISTINCT values: NULL (not 0) when the group has none (SumDistinctDecimal128 finalize)
   int wide_delta = 0;           // MIN / MAX over such values: one MAX_U64 lane of (v − column min) [1] or (column max − v) [2] (MaxWideDelta)
   uint64_t wide_base_hi = 0, wide_base_lo = 0; // … and that column min / max
   int32_t precision = 0, scale = 0; // Decimal128 results

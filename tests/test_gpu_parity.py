@@ -2656,12 +2656,13 @@ def test_distinct_aggregates_inside_group_by_match_oracle(rt, orc, abi, chunks):
 
 
 @pytest.mark.parametrize("chunks", [[700], [4096, 4097, 5]])
-def test_distinct_aggregates_inside_group_by_over_string_boolean_and_date_keys(rt, orc, abi, chunks):
-    """COUNT / SUM / TOTAL / AVG (DISTINCT x) per group over a Utf8, Boolean or Date32 column: the key is the cell (a string's
+def test_distinct_aggregates_inside_group_by_over_string_boolean_date_and_decimal_keys(rt, orc, abi, chunks):
+    """COUNT / SUM / TOTAL / AVG (DISTINCT x) per group over a Utf8, Boolean, Date32 or Decimal128 column: the key is the cell (a string's
     dictionary code, DistinctKey::from_array llkv-aggregate/src/lib.rs:261-331), what the Float64 accumulators add is its numeric
     image (array_value_to_numeric :400-449).  On the sort-based route the cell is the least significant sort key and the head of
-    every run of equal cells adds `dict_num[code]` / 1.0 or 0.0 / the day number.  Counts exact, f64 sums within 1e-9 (the oracle
-    adds the images in order of first appearance)."""
+    every run of equal cells adds `dict_num[code]` / 1.0 or 0.0 / the day number — a decimal its raw value, summed in i128 and finalized
+    with the column's (precision, scale), AVG half away from zero, SUM / AVG NULL for a group without a value.  Counts and decimals
+    exact, f64 sums within 1e-9 (the oracle adds the images in order of first appearance)."""
     rng = np.random.default_rng(57 + len(chunks))
     n = sum(chunks)
     words = ["12", " 3.5 ", "abc", "", "1e2", "12.0", "-7.25", ".5", "1.", "+4", "0.125", "1000000.5", "1", "1.0"]
@@ -2671,7 +2672,8 @@ def test_distinct_aggregates_inside_group_by_over_string_boolean_and_date_keys(r
     g_int = rng.integers(0, 23, size=n).astype(np.int64)
     g_tag = [("a", "b", "", "dd")[k] for k in rng.integers(0, 4, size=n)]
     val = rng.integers(-9, 9, size=n).astype(np.int64)
-    vt, vb, vd, vg = rng.random(n) > 0.15, rng.random(n) > 0.1, rng.random(n) > 0.1, rng.random(n) > 0.1
+    dec = [int(v) for v in rng.integers(-40, 40, size=n)]
+    vt, vb, vd, vg, vc = rng.random(n) > 0.15, rng.random(n) > 0.1, rng.random(n) > 0.1, rng.random(n) > 0.1, rng.random(n) > 0.5
     ht = rt.HipTable(1, chunks)
     ht.append_utf8_column(1, txt, valid=vt)
     ht.append_column(2, abi.DT_BOOLEAN, boo, valid=vb)
@@ -2679,9 +2681,11 @@ def test_distinct_aggregates_inside_group_by_over_string_boolean_and_date_keys(r
     ht.append_column(4, abi.DT_INT64, g_int)
     ht.append_utf8_column(5, g_tag, valid=vg)
     ht.append_column(6, abi.DT_INT64, val)
+    ht.append_decimal128_column(7, 12, 2, dec, valid=vc)
     ot = orc.OracleTable(n)
     ot.add(1, abi.DT_UTF8, [t if ok else None for t, ok in zip(txt, vt)]).add(2, abi.DT_BOOLEAN, boo, list(vb)).add(3, abi.DT_DATE32, day, list(vd))
     ot.add(4, abi.DT_INT64, g_int).add(5, abi.DT_UTF8, [t if ok else None for t, ok in zip(g_tag, vg)]).add(6, abi.DT_INT64, val)
+    ot.add(7, abi.DT_DECIMAL128, dec, list(vc), precision=12, scale=2)
     A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
 
     def D(kind, e):
@@ -2689,7 +2693,7 @@ def test_distinct_aggregates_inside_group_by_over_string_boolean_and_date_keys(r
         s.distinct = True
         return s
 
-    for field in (1, 2, 3):
+    for field in (1, 2, 3, 7):
         aggs = [A.count_star()] + [D(k, field) for k in ("count", "sum", "total", "avg")] + [A.sum(6), A.count(field)]
         for keys in ([4], [5], [5, 4]):
             for pred in (None, [F(6, O.GreaterThan(-3))]):
