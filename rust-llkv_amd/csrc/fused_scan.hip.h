@@ -1327,18 +1327,23 @@ constexpr int kPartStageLanes = 7;   // records of up to 7 words are sorted by p
 // step and the record stores of this one at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Exclusive scan of cnt[0 .. kMaxParts) in place by the B threads of the workgroup (kMaxParts / B entries each); returns the total.
-template <int B> __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wave_sum /*[B / 64]*/) {
-  constexpr int E = kMaxParts / B; // entries per thread
-  static_assert(E * B == kMaxParts && E % 4 == 0, "whole uint4s per thread");
+// Exclusive scan of cnt[0 .. MP) in place by the B threads of the workgroup (MP / B entries each); returns the total.
+template <int B, int MP = kMaxParts> __device__ __forceinline__ uint32_t part_block_scan(uint32_t *cnt, uint32_t *wave_sum /*[B / 64]*/) {
+  constexpr int E = MP / B; // entries per thread
+  static_assert(E * B == MP && (E == 1 || E % 4 == 0), "one entry or whole uint4s per thread");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t c[E];
   uint32_t mine = 0;
+  if constexpr (E == 1) {
+    c[0] = cnt[tid];
+    mine = c[0];
+  } else {
 #pragma unroll
-  for (int q = 0; q < E / 4; ++q) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(cnt + E * tid + 4 * q);
-    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
-    mine += v.x + v.y + v.z + v.w;
+    for (int q = 0; q < E / 4; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(cnt + E * tid + 4 * q);
+      c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+      mine += v.x + v.y + v.z + v.w;
+    }
   }
   uint32_t incl = mine;
 #pragma unroll
@@ -1356,14 +1361,18 @@ template <int B> __device__ __forceinline__ uint32_t part_block_scan(uint32_t *c
     total += x;
   }
   uint32_t ex = before + incl - mine;
+  if constexpr (E == 1) {
+    cnt[tid] = ex;
+  } else {
 #pragma unroll
-  for (int q = 0; q < E / 4; ++q) {
-    uint4 v;
-    v.x = ex; ex += c[4 * q];
-    v.y = ex; ex += c[4 * q + 1];
-    v.z = ex; ex += c[4 * q + 2];
-    v.w = ex; ex += c[4 * q + 3];
-    *reinterpret_cast<uint4 *>(cnt + E * tid + 4 * q) = v;
+    for (int q = 0; q < E / 4; ++q) {
+      uint4 v;
+      v.x = ex; ex += c[4 * q];
+      v.y = ex; ex += c[4 * q + 1];
+      v.z = ex; ex += c[4 * q + 2];
+      v.w = ex; ex += c[4 * q + 3];
+      *reinterpret_cast<uint4 *>(cnt + E * tid + 4 * q) = v;
+    }
   }
   lds_barrier();
   return total;
@@ -1382,22 +1391,46 @@ template <int B> __device__ __forceinline__ uint32_t part_block_scan(uint32_t *c
 //            so the 2 048 records of a step are first put in partition order in the LDS — a counter per partition ranks
 //            them, a scan places the partitions — and leave as runs of consecutive words (records of ≤ 7 words; wider
 //            ones go straight from their thread).
-template <class P, int B = 1024> __device__ __forceinline__ void part_scatter_body(const ScanParams &p) {
+//   LINES    (records of ≤ 4 words, ≤ 512 partitions, 1 024 threads): whole 128-byte lines only.  The runs a step leaves are a few
+//            records long and start anywhere; here the words of a partition's cell behind its last complete line wait in the LDS —
+//            a ring of 16 words per partition, indexed by the word's position in its line — and leave when their line is complete
+//            (or the tile ends): per step the words of the ring whose line completes (phase A) and the new words below the
+//            partition's last line boundary (phase B) go out, the rest of the new words enter the ring.
+//            Measured (profiles/r03/part_lines.txt, part_store_exp.txt): 1.355 ms against 1.403 — the record stores cost 0.7 ms
+//            whether they leave as whole lines or as runs of a few records, and 0.06 ms when they land in a window the L2 holds:
+//            what bounds them is the DRAM's rate for lines scattered over a megabyte per workgroup, not partial lines.
+template <class P, int B = 1024, bool LINES = false> __device__ __forceinline__ void part_scatter_body(const ScanParams &p) {
   constexpr int kStep = B * kRowsPerThread; // rows of one workgroup step
+  constexpr int MP = LINES ? 1024 : kMaxParts; // partition counters in the LDS
+  constexpr int kLineParts = 512;              // LINES: partitions at most (the host admits the form by np)
   static_assert(P::first, "partitioned plans keep the first row of every group");
+  static_assert(kPartTileRows == 1 << 15, "part_reduce_kernel packs (tile << 15 | row within the tile)");
   constexpr int K = P::K - 1; // words of a record: [0] group within the partition | row within the tile << 32, then lanes 2 …
   constexpr bool STAGED = K <= kPartStageLanes;
-  __shared__ __attribute__((aligned(16))) uint32_t cell[kMaxParts];  // next record position of each partition's cell of this tile
-  __shared__ __attribute__((aligned(16))) uint32_t scnt[STAGED ? kMaxParts : 4]; // the step's records per partition → where they start in `stage`
+  static_assert(!LINES || (B == 1024 && STAGED && K <= 4), "the line form: short records, one partition counter per thread");
+  __shared__ __attribute__((aligned(16))) uint32_t cell[MP];  // next record position of each partition's cell of this tile
+  __shared__ __attribute__((aligned(16))) uint32_t scnt[STAGED ? MP : 4]; // the step's records per partition → where they start in `stage`
   __shared__ uint32_t wave_sum[B / 64];
   __shared__ uint32_t dest[STAGED ? kStep : 1];       // record position of each staged slot
   __shared__ uint64_t stage[STAGED ? kStep * K : 1];
+  // LINES: word positions are relative to the tile's window (tile_base · K is a multiple of 16: a line of the record array)
+  __shared__ uint16_t slot_part[LINES ? kStep : 1];           // partition of each staged slot
+  __shared__ uint64_t ring[LINES ? kLineParts * 16 : 1];      // [partition][word position & 15]: words waiting for their line
+  __shared__ uint32_t carried[LINES ? kLineParts : 1];        // words of the partition in the ring (< 16)
+  __shared__ uint32_t lim[LINES ? kLineParts : 1];            // this step: words below leave, the others enter the ring
+  __shared__ uint32_t old_from[LINES ? kLineParts : 1];       // this step: the ring's words [old_from, old_from + old_n) leave
+  __shared__ uint32_t old_n[LINES ? kLineParts : 1];
+  if constexpr (LINES) {
+    if (p.part_np > (uint32_t)kLineParts) return; // (the host admits the form by np: no fault if it ever did not)
+  }
   const uint32_t tid = threadIdx.x, tile = blockIdx.x, np = p.part_np;
   const TileDesc td = load_tile_desc(p.tiles, tile);
-  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += B) {
+  for (uint32_t i = tid; i < (uint32_t)MP; i += B) {
     cell[i] = 0u;
     if constexpr (STAGED) scnt[i] = 0u;
   }
+  if constexpr (LINES)
+    for (uint32_t i = tid; i < (uint32_t)kLineParts; i += B) carried[i] = 0u;
   lds_barrier();
   uint32_t err = 0;
   const uint32_t mask = (1u << p.part_shift) - 1u;
@@ -1430,10 +1463,10 @@ template <class P, int B = 1024> __device__ __forceinline__ void part_scatter_bo
     }
   });
   lds_barrier();
-  const uint32_t tile_rows = part_block_scan<B>(cell, wave_sum);
+  const uint32_t tile_rows = part_block_scan<B, MP>(cell, wave_sum);
   const uint32_t tile_base = tile * (uint32_t)kPartTileRows;
   uint32_t *cells_out = p.part_hist + (uint64_t)tile * (np + 1);
-  for (uint32_t i = tid; i < (uint32_t)kMaxParts; i += B) {
+  for (uint32_t i = tid; i < (uint32_t)MP; i += B) {
     const uint32_t at = tile_base + cell[i];
     cell[i] = at;
     if (i < np) cells_out[i] = at;
@@ -1471,16 +1504,53 @@ template <class P, int B = 1024> __device__ __forceinline__ void part_scatter_bo
       }
     } else {
       lds_barrier();
-      const uint32_t total = part_block_scan<B>(scnt, wave_sum); // scnt: records per partition → first slot of each partition
+      const uint32_t total = part_block_scan<B, MP>(scnt, wave_sum); // scnt: records per partition → first slot of each partition
 #pragma unroll
       for (int j = 0; j < kRowsPerThread; ++j) {
         if (!pass[j]) continue;
         const uint32_t slot = scnt[part[j]] + rank[j];
         dest[slot] = cell[part[j]] + rank[j];
+        if constexpr (LINES) slot_part[slot] = (uint16_t)part[j];
 #pragma unroll
         for (int l = 0; l < K; ++l) stage[slot * K + l] = contrib[j][l];
       }
       lds_barrier();
+      if constexpr (LINES) {
+        // per partition: where its words stand after this step, and up to which word they leave (a line boundary; the end of
+        // the cell on the tile's last step)
+        if (tid < np) {
+          const uint32_t n = (tid + 1 < (uint32_t)MP ? scnt[tid + 1] : total) - scnt[tid];
+          const uint32_t w0 = (cell[tid] - tile_base) * K, end = w0 + n * K, from = w0 - carried[tid];
+          const uint32_t boundary = s + 1 == nsteps ? end : (end & ~15u);
+          const bool leaves = boundary > from;
+          lim[tid] = leaves ? boundary : from;
+          old_from[tid] = from;
+          old_n[tid] = leaves ? carried[tid] : 0u;
+          carried[tid] = leaves ? end - boundary : end - from;
+          cell[tid] += n;
+        }
+        lds_barrier();
+        uint64_t *win = p.part_val + (uint64_t)tile_base * K; // the tile's window of the record array
+        for (uint32_t q = tid; q < np * 16u; q += B) { // phase A: the ring's words whose line is complete now
+          const uint32_t i = q >> 4, j = q & 15u;
+          if (j < old_n[i]) {
+            const uint32_t at = old_from[i] + j;
+            win[at] = ring[i * 16u + (at & 15u)];
+          }
+        }
+        lds_barrier();
+        for (uint32_t w = tid; w < total * K; w += B) { // phase B: this step's words
+          const uint32_t slot = w / K, l = w - slot * K, i = slot_part[slot];
+          const uint32_t at = (dest[slot] - tile_base) * K + l;
+          const uint64_t v = stage[w];
+          if (at < lim[i]) win[at] = v;
+          else ring[i * 16u + (at & 15u)] = v;
+        }
+        lds_barrier();
+        for (uint32_t i = tid; i < (uint32_t)MP; i += B) scnt[i] = 0u;
+        lds_barrier();
+        return;
+      }
       // the cells advance by what the step put into them; the staged words leave in order
       for (uint32_t i = tid; i < np; i += B) cell[i] += (i + 1 < (uint32_t)kMaxParts ? scnt[i + 1] : total) - scnt[i];
       for (uint32_t w = tid; w < total * K; w += B) {
@@ -1498,6 +1568,7 @@ template <class P, int B = 1024> __device__ __forceinline__ void part_scatter_bo
 // One workgroup per partition: its cell of every tile → LDS image [kernel lane][group of the partition] → rows of the
 // group-major result [group][exchange lane] (the layout finalize_value reads; a fixed-point sum is one lane in the
 // image, low 32 bits + high part in the result: lane_src / lane_xf as in image_fold_kernel).
+template <int V> struct IntC { static constexpr int value = V; };
 struct PartReduceParams {
   const uint32_t *offsets; // [n_tiles][np + 1]: where the cell of (tile, partition) starts; [np]: where the tile's records end
   const uint64_t *val;     // records of kl − 1 words: [0] group within the partition | row within the tile << 32, [l − 1] kernel lane l ≥ 2
@@ -1506,33 +1577,39 @@ struct PartReduceParams {
   const uint8_t *lane_ops; // [kl] ops of the kernel lanes
   const uint8_t *lane_src, *lane_xf; // [k]
   uint32_t n_tiles, np, ngs, ng, kl, k;
+  uint32_t deep; // eight cells in flight per wave instead of four (an image beyond 64 KB leaves a CU one workgroup: 16 waves)
 };
 __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParams f) {
-  extern __shared__ uint64_t part_img[]; // [kl][ngs]
+  // [kl − 1][ngs]: lanes 0 and 1 share the first cell of a group — its rows in the low 32 bits, the smallest (tile << 15 | row
+  // within the tile) in the high 32 (a table has < 2^32 record positions; both are 32-bit DS atomics) — then kernel lanes 2 …:
+  // one 8-byte cell fewer per group is what lets 4 096 groups of a five-lane state share 128 KB (half the partitions, runs of
+  // twice the length in the scatter)
+  extern __shared__ uint64_t part_img[];
   const uint32_t tid = threadIdx.x, part = blockIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (uint32_t i = tid; i < f.kl * f.ngs; i += 1024) part_img[i] = lane_identity((int)f.lane_ops[i / f.ngs]);
+  for (uint32_t i = tid; i < (f.kl - 1) * f.ngs; i += 1024) part_img[i] = i < f.ngs ? 0xFFFFFFFF00000000ull : lane_identity((int)f.lane_ops[i / f.ngs + 1]);
   __syncthreads();
   // a wave per (tile, partition) cell, its words read in order (a thread per record read with a stride of kl words:
   // 1.0 ms for 60 M records of 5 words, against 0.46 ms for the same bytes read in order); the group of a word's record
   // is word 0 of that record — the same or the neighbouring cache line.  Four cells in flight per wave.
   const uint32_t rw = f.kl - 1; // words of a record
-  auto words_of = [&](uint32_t t, uint64_t *w_begin, uint32_t *n_words, uint64_t *first_row) {
+  auto words_of = [&](uint32_t t, uint64_t *w_begin, uint32_t *n_words, uint64_t *tile) {
     const uint32_t *cells = f.offsets + (uint64_t)t * (f.np + 1) + part;
     const uint32_t b = cells[0], e = cells[1];
     *w_begin = (uint64_t)b * rw;
     *n_words = (e - b) * rw;
-    *first_row = f.tiles[t].logical_row;
+    *tile = t;
   };
-  // word j of a record, its head word, the tile's first row id
-  auto accumulate = [&](uint32_t j, uint64_t head, uint64_t v, uint64_t tile_row) {
+  // word j of a record, its head word, the tile of its cell
+  auto accumulate = [&](uint32_t j, uint64_t head, uint64_t v, uint64_t tile) {
     const uint32_t g = (uint32_t)head;
-    if (j == 0) { // lanes 0 and 1: one more row; the smallest row id
-      lds_accumulate<OP_ADD_I64>(part_img + g, 1);
-      lds_accumulate<OP_MIN_I64>(part_img + f.ngs + g, tile_row + (head >> 32));
+    if (j == 0) { // lanes 0 and 1: one more row; the smallest position
+      uint32_t *cell = reinterpret_cast<uint32_t *>(part_img + g);
+      (void)__hip_atomic_fetch_add(cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_min(cell + 1, ((uint32_t)tile << 15) | (uint32_t)(head >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       return;
     }
     const uint32_t l = j + 1;
-    uint64_t *slot = part_img + (uint64_t)l * f.ngs + g;
+    uint64_t *slot = part_img + (uint64_t)(l - 1) * f.ngs + g;
     switch ((int)f.lane_ops[l]) {
     case OP_ADD_F64: lds_accumulate<OP_ADD_F64>(slot, v); break;
     case OP_ADD_I64: lds_accumulate<OP_ADD_I64>(slot, v); break;
@@ -1541,38 +1618,49 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParam
     default: lds_accumulate<OP_MAX_U64>(slot, v); break;
     }
   };
-  constexpr int kC = 4; // cells in flight per wave (eight: 1.04 ms instead of 0.79)
-  for (uint32_t t = wave; t < f.n_tiles; t += 16 * kC) {
-    uint64_t wb[kC], row0[kC];
-    uint32_t nw[kC], n_max = 0;
-#pragma unroll
-    for (int c = 0; c < kC; ++c) {
-      wb[c] = 0;
-      nw[c] = 0;
-      row0[c] = 0;
-      if (t + 16 * c < f.n_tiles) words_of(t + 16 * c, &wb[c], &nw[c], &row0[c]);
-      n_max = nw[c] > n_max ? nw[c] : n_max;
-    }
-    for (uint32_t i = lane; i < n_max; i += 64) {
-      const uint32_t j = i % rw;
-      uint64_t v[kC], head[kC];
+  // cells in flight per wave: four when two workgroups share a CU (eight: 1.04 ms instead of 0.79), eight when the image leaves room for one
+  auto walk = [&](auto cells) {
+    constexpr int kC = decltype(cells)::value;
+    for (uint32_t t = wave; t < f.n_tiles; t += 16 * (uint32_t)kC) {
+      uint64_t wb[kC], cell_tile[kC];
+      uint32_t nw[kC], n_max = 0;
 #pragma unroll
       for (int c = 0; c < kC; ++c) {
-        const bool live = i < nw[c];
-        v[c] = live ? f.val[wb[c] + i] : 0;
-        head[c] = live ? f.val[wb[c] + i - j] : 0;
+        wb[c] = 0;
+        nw[c] = 0;
+        cell_tile[c] = 0;
+        if (t + 16 * c < f.n_tiles) words_of(t + 16 * c, &wb[c], &nw[c], &cell_tile[c]);
+        n_max = nw[c] > n_max ? nw[c] : n_max;
       }
+      for (uint32_t i = lane; i < n_max; i += 64) {
+        const uint32_t j = i % rw;
+        uint64_t v[kC], head[kC];
 #pragma unroll
-      for (int c = 0; c < kC; ++c)
-        if (i < nw[c]) accumulate(j, head[c], v[c], row0[c]);
+        for (int c = 0; c < kC; ++c) {
+          const bool live = i < nw[c];
+          v[c] = live ? f.val[wb[c] + i] : 0;
+          head[c] = live ? f.val[wb[c] + i - j] : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < kC; ++c)
+          if (i < nw[c]) accumulate(j, head[c], v[c], cell_tile[c]);
+      }
     }
-  }
+  };
+  if (f.deep) walk(IntC<8>{});
+  else walk(IntC<4>{});
   __syncthreads();
   const uint64_t g0 = (uint64_t)part * f.ngs;
   for (uint32_t i = tid; i < f.ngs * f.k; i += 1024) {
     const uint32_t g = i / f.k, kk = i % f.k;
     if (g0 + g >= f.ng) break;
-    const uint64_t x = part_img[(uint64_t)f.lane_src[kk] * f.ngs + g];
+    const uint32_t src = f.lane_src[kk];
+    uint64_t x;
+    if (src == 0) x = (uint32_t)part_img[g]; // rows
+    else if (src == 1) { // the smallest row id: the tile's first row id + the row's position in the tile
+      const uint32_t at = (uint32_t)(part_img[g] >> 32);
+      x = at == 0xFFFFFFFFu ? 0x7FFFFFFFFFFFFFFFull : f.tiles[at >> 15].logical_row + (at & 0x7FFFu);
+    } else x = part_img[(uint64_t)(src - 1) * f.ngs + g];
     const uint32_t xf = f.lane_xf[kk];
     f.out[(g0 + g) * f.k + kk] = xf == 1 ? (x & 0xFFFFFFFFull) : xf == 2 ? (uint64_t)((int64_t)x >> 32) : x;
   }

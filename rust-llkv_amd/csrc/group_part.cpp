@@ -37,6 +37,7 @@ struct PartGroupBy {
   JitKernel kernel;
   uint32_t ngs = 0, np = 0, shift = 0; // groups per partition (2^shift), partitions
   bool order_by_keys = false;
+  bool lines = false;                  // the scatter writes whole 128-byte lines
   bool ids_in_key_order = false;       // integer keys without NULL cells: ascending group ids are ascending keys
   uint32_t *d_code_rank = nullptr;     // [key][256] dictionary code → position in string order (Utf8 keys, ORDER BY the keys)
   double *d_dict_num = nullptr;
@@ -111,15 +112,17 @@ int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_
   // groups per partition: a power of two whose image fits, and small enough that the reduction has a few hundred
   // workgroups to run
   uint32_t shift = 0;
-  while ((size_t)(2u << shift) * kl * 8 <= kPartImageBytes) ++shift;
-  while (shift > 6 && ((uint64_t)p.ng >> shift) < 512) --shift;
+  while ((size_t)(2u << shift) * (kl - 1) * 8 <= kPartImageBytes) ++shift; // (kl − 1 cells per group: rows and first row share one)
+  while (shift > 6 && ((uint64_t)p.ng >> shift) < 256) --shift; // (a workgroup per CU at least)
   g->shift = shift;
   g->ngs = 1u << shift;
   g->np = (uint32_t)(((uint64_t)p.ng + g->ngs - 1) >> shift);
   if (g->np > kMaxPartsHost)
     return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: " + std::to_string(p.ng) + " groups × " + std::to_string(kl) + " lanes need more than " +
                                            std::to_string(kMaxPartsHost) + " partitions");
-  if ((rc = jit_compile(JitKind::Part, p.type_string, &g->kernel, &err))) return set_error(rc, err);
+  // records of ≤ 4 words over ≤ 512 partitions leave as whole 128-byte lines (fused_scan.hip.h: part_scatter_body<…, LINES>)
+  g->lines = kl - 1 <= 4 && g->np <= 512 && part_block_threads() == 1024 && !std::getenv("LLKV_HIP_PART_NO_LINES");
+  if ((rc = jit_compile(JitKind::Part, g->lines ? p.type_string + ";lines" : p.type_string, &g->kernel, &err))) return set_error(rc, err);
   hipStream_t s = g_ctx.stream;
   if (!p.dict_num.empty()) { // numeric images of the dictionaries some aggregate reads (DictNum<slot>)
     std::vector<double> image((size_t)kMaxCols * 256, 0.0);
@@ -216,7 +219,7 @@ int PartGroupBy::run(LazyGroups *out) {
   sp.part_shift = shift;
   sp.part_np = np;
   sp.part_err = flags.as<uint32_t>();
-  if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, part_block_threads()))) return rc;
+  if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, lines ? 1024u : part_block_threads()))) return rc;
   mark("scatter");
   HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), ts->d_tiles, group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
                              d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s));

@@ -40,9 +40,13 @@ std::string wrapper_source(JitKind kind, const std::string &ts) {
     s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { image_scan_body<" + ts + ">(p); }\n";
     break;
   case JitKind::Part:
-    // every tile's records in partition order (part_block_threads() threads per workgroup)
-    s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(part_block_threads()) + ") void llkv_jit_a(const ScanParams p) { part_scatter_body<" + ts + ", " +
-         std::to_string(part_block_threads()) + ">(p); }\n";
+    // every tile's records in partition order (part_block_threads() threads per workgroup); "<plan>;lines": the form that writes
+    // whole 128-byte lines (group_part.cpp admits it: short records, ≤ 512 partitions, 1 024 threads)
+    if (ts.size() > 6 && ts.compare(ts.size() - 6, 6, ";lines") == 0)
+      s += "extern \"C\" __global__ __launch_bounds__(1024) void llkv_jit_a(const ScanParams p) { part_scatter_body<" + ts.substr(0, ts.size() - 6) + ", 1024, true>(p); }\n";
+    else
+      s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(part_block_threads()) + ") void llkv_jit_a(const ScanParams p) { part_scatter_body<" + ts + ", " +
+           std::to_string(part_block_threads()) + ">(p); }\n";
     break;
   case JitKind::Select:
     s += "extern \"C\" __global__ __launch_bounds__(256) void llkv_jit_a(const ScanParams p) { select_body<" + ts + ", false>(p); }\n";

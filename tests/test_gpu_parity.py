@@ -1087,7 +1087,8 @@ def test_partitioned_group_by_matches_oracle(rt, orc, abi, chunks, route, monkey
     narrow = [A.count_star(), A.sum(5), A.sum(6)]
     wide = [A.count_star(), A.count(5), A.sum(5), A.avg(5), A.min(5), A.max(5), A.total(5), A.sum(6), A.avg(6), A.min(7), A.max(7), A.sum(col(6) * (10000 - col(6))),
             A.sum(7)]
-    for keys, aggs in (([1], narrow), ([1], wide), ([2, 3], narrow), ([3, 2], wide), ([4, 1], narrow), ([1], narrow[:1])):  # (the last: records of one word)
+    short = [A.count_star(), A.sum(1), A.sum(6)]  # records of ≤ 4 words over ≤ 512 partitions: the scatter writes whole lines (LLKV_HIP_PART_NO_LINES=1: runs)
+    for keys, aggs in (([1], narrow), ([1], wide), ([2, 3], narrow), ([3, 2], wide), ([4, 1], narrow), ([1], narrow[:1]), ([1], short), ([1], short[:2]), ([2, 3], short)):  # (narrow[:1]: records of one word)
         for pred in (None, [F(5, O.GreaterThan(-500))]):
             pq = rt.PreparedQuery(ht, pred, aggs, keys, False)
             note = pq.route_note
@@ -1097,6 +1098,11 @@ def test_partitioned_group_by_matches_oracle(rt, orc, abi, chunks, route, monkey
             assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in exp], (keys, route)
             for g, w in zip(got, exp):
                 assert_values(g.values, w.values, f"{route} group by {keys}")
+            if route == "partitioned" and len(aggs) <= 3:  # both forms of the scatter: the same records, so the same bits
+                monkeypatch.setenv("LLKV_HIP_PART_NO_LINES", "1")
+                runs = rt.groupby(ht, pred, keys, aggs, False)
+                monkeypatch.delenv("LLKV_HIP_PART_NO_LINES")
+                assert [(r.keys, r.values) for r in runs] == [(r.keys, r.values) for r in got], (keys, "line form vs runs")
     assert rt.groupby(ht, [F(5, O.GreaterThan(10**6))], [1], wide, False) == []
     # ORDER BY the keys: ascending group ids are ascending keys for integer keys without NULL cells; with NULL cells
     # (NULLS FIRST) or dictionary-coded strings the groups are sorted by their ranked id
