@@ -249,7 +249,9 @@ typedef struct llkv_value {
 /* ------------------------------------------------------------------------- */
 /* Device / context                                                           */
 /* ------------------------------------------------------------------------- */
-/* Bind the calling process to one GPU (one process per GPU). */
+/* Bind the calling process to one GPU (one process per GPU).  Also makes the two copy lanes of the staging path and sends one
+ * page-locked block through each: the first registration + DMA of a process costs ~23 ms whatever it copies, and the first table
+ * staged should not pay it (LLKV_HIP_NO_STAGING_PRIME=1 leaves it to the first staging call). */
 llkv_status llkv_hip_init(int32_t device_ordinal);
 void llkv_hip_shutdown(void);
 int32_t llkv_hip_device_count(void);
