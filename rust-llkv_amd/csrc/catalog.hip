@@ -121,7 +121,7 @@ hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const
 
 hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, const TileDesc *tiles, uint64_t *out, const uint8_t *lane_ops,
                               const uint8_t *lane_src, const uint8_t *lane_xf, uint32_t n_tiles, uint32_t np, uint32_t ngs, uint32_t ng, uint32_t kl, uint32_t k,
-                              hipStream_t stream) {
+                              hipStream_t stream, uint32_t part0, uint32_t n_parts) {
   const size_t lds = (size_t)(kl - 1) * ngs * 8; // lanes 0 and 1 share a cell (part_reduce_kernel)
   static bool raised = false; // (the attribute belongs to the function, not to a launch)
   if (!raised) {
@@ -131,8 +131,9 @@ hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, 
   }
   const char *cells = std::getenv("LLKV_HIP_PART_REDUCE_CELLS"); // 4 | 8 (measurement)
   const uint32_t deep = cells ? (std::atoi(cells) == 8 ? 1u : 0u) : (lds > (64u << 10) ? 1u : 0u);
-  PartReduceParams f{offsets, records, tiles, out, lane_ops, lane_src, lane_xf, n_tiles, np, ngs, ng, kl, k, deep};
-  hipLaunchKernelGGL(part_reduce_kernel, dim3(np), dim3(1024), lds, stream, f);
+  if (n_parts == 0) return hipSuccess;
+  PartReduceParams f{offsets, records, tiles, out, lane_ops, lane_src, lane_xf, n_tiles, np, ngs, ng, kl, k, deep, part0};
+  hipLaunchKernelGGL(part_reduce_kernel, dim3(n_parts), dim3(1024), lds, stream, f);
   return hipGetLastError();
 }
 

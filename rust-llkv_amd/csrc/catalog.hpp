@@ -50,9 +50,9 @@ hipError_t launch_image_fold(const uint64_t *partials, uint64_t *exchange, const
                              uint32_t passes, uint32_t kl, const uint8_t *lane_src, const uint8_t *lane_xf, hipStream_t stream);
 
 // Partitioned GROUP BY: one workgroup per partition reduces its records (fused_scan.hip.h: part_scatter_body wrote them) in an LDS
-// image of kl × ngs cells and writes the rows [group][k] of its groups.
+// image of (kl − 1) × ngs cells and writes the rows [group][k] of its groups; partitions [part0, part0 + n_parts) of the np.
 hipError_t launch_part_reduce(const uint32_t *offsets, const uint64_t *records, const TileDesc *tiles, uint64_t *out, const uint8_t *lane_ops,
                               const uint8_t *lane_src, const uint8_t *lane_xf, uint32_t n_tiles, uint32_t np, uint32_t ngs, uint32_t ng, uint32_t kl, uint32_t k,
-                              hipStream_t stream);
+                              hipStream_t stream, uint32_t part0, uint32_t n_parts);
 
 } // namespace llkv

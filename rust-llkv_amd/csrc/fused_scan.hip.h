@@ -1578,6 +1578,7 @@ struct PartReduceParams {
   const uint8_t *lane_src, *lane_xf; // [k]
   uint32_t n_tiles, np, ngs, ng, kl, k;
   uint32_t deep; // eight cells in flight per wave instead of four (an image beyond 64 KB leaves a CU one workgroup: 16 waves)
+  uint32_t part0; // first partition of this launch (the copy-out of a range of partitions may run beside the reduction of the next)
 };
 __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParams f) {
   // [kl − 1][ngs]: lanes 0 and 1 share the first cell of a group — its rows in the low 32 bits, the smallest (tile << 15 | row
@@ -1585,7 +1586,7 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const PartReduceParam
   // one 8-byte cell fewer per group is what lets 4 096 groups of a five-lane state share 128 KB (half the partitions, runs of
   // twice the length in the scatter)
   extern __shared__ uint64_t part_img[];
-  const uint32_t tid = threadIdx.x, part = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, part = blockIdx.x + f.part0, lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < (f.kl - 1) * f.ngs; i += 1024) part_img[i] = i < f.ngs ? 0xFFFFFFFF00000000ull : lane_identity((int)f.lane_ops[i / f.ngs + 1]);
   __syncthreads();
   // a wave per (tile, partition) cell, its words read in order (a thread per record read with a stride of kl words:

@@ -44,6 +44,12 @@ struct PartGroupBy {
   uint8_t *d_lane_tables = nullptr; // [kl] ops of the kernel lanes, [k] source lane, [k] transform
   void *h_lanes = nullptr, *h_kv = nullptr, *h_kvalid = nullptr;
   size_t cap_lanes = 0, cap_kv = 0, cap_kvalid = 0;
+  // key order over one integer key: the groups of a range of partitions are final when its reduction is — their copy-out runs
+  // on a second stream beside the reduction of the next range
+  static constexpr uint32_t kRanges = 8;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t range_done[kRanges] = {};
+  uint32_t *h_counts = nullptr; // pinned: groups with rows per range, then the scatter's error word
   int run(LazyGroups *out);
   ~PartGroupBy() {
     scratch_free(d_dict_num);
@@ -52,6 +58,9 @@ struct PartGroupBy {
     if (h_lanes) (void)hipHostFree(h_lanes);
     if (h_kv) (void)hipHostFree(h_kv);
     if (h_kvalid) (void)hipHostFree(h_kvalid);
+    if (h_counts) (void)hipHostFree(h_counts);
+    for (hipEvent_t e : range_done) if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
   }
 };
 
@@ -221,8 +230,84 @@ int PartGroupBy::run(LazyGroups *out) {
   sp.part_err = flags.as<uint32_t>();
   if ((rc = jit_launch_raw(kernel.fn, n_tiles, &sp, sizeof sp, s, lines ? 1024u : part_block_threads()))) return rc;
   mark("scatter");
+  DenseKeyLayout kl_keys;
+  std::memset(&kl_keys, 0, sizeof kl_keys);
+  kl_keys.n = n_keys;
+  for (uint32_t j = 0; j < n_keys; ++j) {
+    kl_keys.stride[j] = p.key_strides[j];
+    kl_keys.card[j] = p.key_cards[j];
+    kl_keys.nullable[j] = p.key_nullable[j];
+    kl_keys.base[j] = p.key_bases[j];
+    kl_keys.code_rank[j] = d_code_rank && !p.key_is_int[j] ? d_code_rank + (size_t)j * 256 : nullptr;
+  }
+  uint32_t n_groups = 0;
+  Scratch lanes_d, kv_d, kvalid_d;
+  // (a range is one workgroup per CU: smaller launches leave CUs idle — four ranges of 122 partitions: 2.46 ms for reduce + copy-out,
+  // eight of 61: 3.72, against 2.77 one after the other)
+  const uint32_t per_range = std::max<uint32_t>(g_ctx.cu_count, (np + kRanges - 1) / kRanges);
+  const uint32_t n_ranges = (np + per_range - 1) / per_range;
+  const bool ranges = order_by_keys && ids_in_key_order && n_keys == 1 && n_ranges >= 2 && (uint64_t)ng * (k * 8 + 9) <= (256ull << 20) &&
+                      !std::getenv("LLKV_HIP_PART_NO_OVERLAP");
+  if (ranges) {
+    // ---- key order, one integer key: ascending group ids are the output order, so the groups of partitions [p0, p1) can leave
+    // as soon as those partitions are reduced — select, emit and copy-out of a range run on `copy_stream` while the main
+    // stream reduces the next range (the copy-out, 114 MB for 2 M groups, is the longest phase)
+    if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : range_done) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!h_counts) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_counts), 64, hipHostMallocDefault));
+    Scratch counts_d, tmp2;
+    if ((rc = counts_d.alloc(64)) || (rc = lanes_d.alloc((uint64_t)ng * k * 8)) || (rc = kv_d.alloc((uint64_t)ng * 8)) || (rc = kvalid_d.alloc(ng))) return rc;
+    if ((rc = pinned_reserve(&h_lanes, &cap_lanes, (size_t)ng * k * 8)) || (rc = pinned_reserve(&h_kv, &cap_kv, (size_t)ng * 8)) || (rc = pinned_reserve(&h_kvalid, &cap_kvalid, ng)))
+      return rc;
+    HIP_TRY(hipMemsetAsync(counts_d.p, 0, 64, s));
+    uint32_t part_at[kRanges + 1], group_at[kRanges + 1];
+    for (uint32_t c = 0; c <= n_ranges; ++c) {
+      part_at[c] = std::min<uint32_t>(np, c * per_range);
+      group_at[c] = (uint32_t)std::min<uint64_t>((uint64_t)part_at[c] * ngs, ng);
+    }
+    group_at[n_ranges] = ng;
+    size_t tb_max = 8;
+    for (uint32_t c = 0; c < n_ranges; ++c) {
+      size_t tb = 0;
+      HIP_TRY(hj_select_present_groups(nullptr, &tb, group_rows.as<uint64_t>() + (uint64_t)group_at[c] * k, k, group_at[c + 1] - group_at[c], ids.as<uint32_t>() + group_at[c],
+                                       counts_d.as<uint32_t>() + c, s));
+      tb_max = std::max(tb_max, tb);
+    }
+    if ((rc = tmp2.alloc(tb_max))) return rc;
+    for (uint32_t c = 0; c < n_ranges; ++c) {
+      HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), ts->d_tiles, group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
+                                 d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s, part_at[c], part_at[c + 1] - part_at[c]));
+      if (group_at[c + 1] > group_at[c]) { // ids relative to the range's first group
+        size_t tb = tb_max;
+        HIP_TRY(hj_select_present_groups(tmp2.p, &tb, group_rows.as<uint64_t>() + (uint64_t)group_at[c] * k, k, group_at[c + 1] - group_at[c], ids.as<uint32_t>() + group_at[c],
+                                         counts_d.as<uint32_t>() + c, s));
+      }
+      HIP_TRY(hipMemcpyAsync(h_counts + c, counts_d.as<uint32_t>() + c, 4, hipMemcpyDeviceToHost, s));
+      if (c + 1 == n_ranges) HIP_TRY(hipMemcpyAsync(h_counts + kRanges, flags.p, 4, hipMemcpyDeviceToHost, s)); // the scatter's error word
+      HIP_TRY(hipEventRecord(range_done[c], s));
+    }
+    uint64_t at = 0;
+    for (uint32_t c = 0; c < n_ranges; ++c) {
+      HIP_TRY(hipEventSynchronize(range_done[c]));
+      const uint32_t n_c = h_counts[c];
+      if (n_c == 0) continue;
+      DenseKeyLayout range_keys = kl_keys; // the ids of the range start at 0: its first group's key is the base
+      range_keys.base[0] += (long long)group_at[c];
+      HIP_TRY(hj_launch_emit_dense_groups(group_rows.as<uint64_t>() + (uint64_t)group_at[c] * k, k, ids.as<uint32_t>() + group_at[c], nullptr, n_c, range_keys,
+                                          lanes_d.as<uint64_t>() + at * k, kv_d.as<int64_t>() + at, kvalid_d.as<uint8_t>() + at, copy_stream));
+      HIP_TRY(hipMemcpyAsync(static_cast<char *>(h_lanes) + at * k * 8, lanes_d.as<uint64_t>() + at * k, (size_t)n_c * k * 8, hipMemcpyDeviceToHost, copy_stream));
+      HIP_TRY(hipMemcpyAsync(static_cast<char *>(h_kv) + at * 8, kv_d.as<int64_t>() + at, (size_t)n_c * 8, hipMemcpyDeviceToHost, copy_stream));
+      HIP_TRY(hipMemcpyAsync(static_cast<char *>(h_kvalid) + at, kvalid_d.as<uint8_t>() + at, n_c, hipMemcpyDeviceToHost, copy_stream));
+      at += n_c;
+    }
+    HIP_TRY(hipStreamSynchronize(copy_stream));
+    if (h_counts[kRanges]) return set_error(LLKV_INTERNAL, arith_error_message(h_counts[kRanges]));
+    n_groups = (uint32_t)at;
+    mark("reduce + copy out");
+    if (n_groups == 0) return LLKV_OK;
+  } else {
   HIP_TRY(launch_part_reduce(cell_table.as<uint32_t>(), rec_val.as<uint64_t>(), ts->d_tiles, group_rows.as<uint64_t>(), d_lane_tables, d_lane_tables + kl,
-                             d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s));
+                             d_lane_tables + kl + k, n_tiles, np, ngs, ng, kl, k, s, 0, np));
   mark("partition reduce");
   // ---- the groups that have rows, in first-appearance order --------------------------------------------------------
   Scratch tmp2;
@@ -238,19 +323,9 @@ int PartGroupBy::run(LazyGroups *out) {
     if ((rc = rb.add(host_flags, flags.p, 8, s)) || (rc = rb.wait())) return rc;
   }
   if (host_flags[0]) return set_error(LLKV_INTERNAL, arith_error_message(host_flags[0]));
-  const uint32_t n_groups = host_flags[1];
+  n_groups = host_flags[1];
   mark("present groups");
   if (n_groups == 0) return LLKV_OK;
-  DenseKeyLayout kl_keys;
-  std::memset(&kl_keys, 0, sizeof kl_keys);
-  kl_keys.n = n_keys;
-  for (uint32_t j = 0; j < n_keys; ++j) {
-    kl_keys.stride[j] = p.key_strides[j];
-    kl_keys.card[j] = p.key_cards[j];
-    kl_keys.nullable[j] = p.key_nullable[j];
-    kl_keys.base[j] = p.key_bases[j];
-    kl_keys.code_rank[j] = d_code_rank && !p.key_is_int[j] ? d_code_rank + (size_t)j * 256 : nullptr;
-  }
   Scratch first_d, first_s, ord_in, ord_out, tmp3;
   const uint32_t *order = nullptr;
   if (n_groups > 1 && !(order_by_keys && ids_in_key_order)) {
@@ -273,7 +348,6 @@ int PartGroupBy::run(LazyGroups *out) {
     order = ord_out.as<uint32_t>();
   }
   mark("output order");
-  Scratch lanes_d, kv_d, kvalid_d;
   if ((rc = lanes_d.alloc((uint64_t)n_groups * k * 8)) || (rc = kv_d.alloc((uint64_t)n_groups * n_keys * 8)) || (rc = kvalid_d.alloc((uint64_t)n_groups * n_keys))) return rc;
   HIP_TRY(hj_launch_emit_dense_groups(group_rows.as<uint64_t>(), k, ids.as<uint32_t>(), order, n_groups, kl_keys, lanes_d.as<uint64_t>(), kv_d.as<int64_t>(),
                                       kvalid_d.as<uint8_t>(), s));
@@ -286,6 +360,7 @@ int PartGroupBy::run(LazyGroups *out) {
   HIP_TRY(hipMemcpyAsync(h_kvalid, kvalid_d.p, (size_t)n_groups * n_keys, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   mark("copy out");
+  }
   // only the aggregates whose finalize can fail are visited now; cells are decoded on request
   const uint64_t *lanes = static_cast<const uint64_t *>(h_lanes);
   for (size_t a = 0; a < p.aggs.size(); ++a) {
