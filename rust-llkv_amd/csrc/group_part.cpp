@@ -7,6 +7,9 @@
 //   reduce   part_reduce_kernel  one workgroup per partition: its cell of every tile → an LDS image → rows [group][lane]
 //   groups   rocPRIM select + sort  the groups that have rows, in first-appearance order (lane 1 = the smallest row id,
 //                                llkv-executor/src/lib.rs:5065-5089) or key order; their lanes and decoded key cells
+//   In key order over one integer key the groups of a range of partitions (one workgroup per CU) are final when that range is
+//   reduced: select, emit and copy-out of the range run on a second stream beside the reduction of the next (PartGroupBy::run).
+//   Records of ≤ 4 words over ≤ 512 partitions leave the scatter as whole 128-byte lines (part_scatter_body<…, LINES>).
 // Against the sort-based route (group_sort.cpp) for 60 M rows in 2 M groups: no radix passes over all the rows and no
 // random gathers of the argument columns — the columns are streamed (the second sweep of a tile finds them in the L2)
 // and the records written and read once.  No global atomics and no global scan.
