@@ -125,7 +125,10 @@ int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_
   // workgroups to run
   uint32_t shift = 0;
   while ((size_t)(2u << shift) * (kl - 1) * 8 <= kPartImageBytes) ++shift; // (kl − 1 cells per group: rows and first row share one)
-  while (shift > 6 && ((uint64_t)p.ng >> shift) < 256) --shift; // (a workgroup per CU at least)
+  // (records of ≤ 4 words can leave as whole lines when the partitions number ≤ 512: 489 of them 1.16 + 0.89 ms for scatter + reduce;
+  // wider records gain less from the longer runs than the reduction loses to its larger image — 977: 1.35 + 0.76, 489: 1.29 + 0.89)
+  const bool line_form = kl - 1 <= 4 && part_block_threads() == 1024 && !std::getenv("LLKV_HIP_PART_NO_LINES");
+  while (shift > 6 && ((uint64_t)p.ng >> shift) < (line_form ? 256u : 512u)) --shift;
   g->shift = shift;
   g->ngs = 1u << shift;
   g->np = (uint32_t)(((uint64_t)p.ng + g->ngs - 1) >> shift);
@@ -133,7 +136,7 @@ int part_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_
     return set_error(LLKV_UNSUPPORTED, "partitioned GROUP BY: " + std::to_string(p.ng) + " groups × " + std::to_string(kl) + " lanes need more than " +
                                            std::to_string(kMaxPartsHost) + " partitions");
   // records of ≤ 4 words over ≤ 512 partitions leave as whole 128-byte lines (fused_scan.hip.h: part_scatter_body<…, LINES>)
-  g->lines = kl - 1 <= 4 && g->np <= 512 && part_block_threads() == 1024 && !std::getenv("LLKV_HIP_PART_NO_LINES");
+  g->lines = line_form && g->np <= 512;
   if ((rc = jit_compile(JitKind::Part, g->lines ? p.type_string + ";lines" : p.type_string, &g->kernel, &err))) return set_error(rc, err);
   hipStream_t s = g_ctx.stream;
   if (!p.dict_num.empty()) { // numeric images of the dictionaries some aggregate reads (DictNum<slot>)
