@@ -1856,11 +1856,136 @@ int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n
 
 /* ------------------------------------------------------------- GROUP BY */
 /* PlanValue (llkv-plan/src/plans.rs:1038-1061) restricted to this path. */
-enum { PV_NULL, PV_INT, PV_FLOAT, PV_STR };
-typedef struct pval { int tag; int64_t i; double f; const char *s; } pval;
+enum { PV_NULL, PV_INT, PV_FLOAT, PV_STR, PV_DEC };
+typedef struct pval { int tag; int64_t i; double f; const char *s; i128 d; int32_t scale; /* PV_DEC: DecimalValue{value, scale} */ } pval;
+
+/* ---- DecimalValue and its exact arithmetic: llkv-types/src/decimal.rs:58-110,218-262 and
+ * llkv-compute/src/scalar/decimal.rs:1-234.  The reference computes in arrow_buffer::i256 and narrows with to_i128;
+ * restated here over a sign + 256-bit magnitude (four 64-bit limbs, least significant first). */
+#define DEC_MAX_PRECISION 38 /* DECIMAL128_MAX_PRECISION */
+typedef struct u256 { uint64_t w[4]; } u256;
+
+static u256 u256_from_u128(u128 v) { u256 r = {{(uint64_t)v, (uint64_t)(v >> 64), 0, 0}}; return r; }
+static int u256_is_zero(const u256 *a) { return !(a->w[0] | a->w[1] | a->w[2] | a->w[3]); }
+static int u256_cmp(const u256 *a, const u256 *b) {
+  for (int k = 3; k >= 0; --k) if (a->w[k] != b->w[k]) return a->w[k] < b->w[k] ? -1 : 1;
+  return 0;
+}
+/* a * 10, 0 when the product leaves the i256 magnitude range (≥ 2^255): checked_mul → DecimalError::Overflow */
+static int u256_mul10(u256 *a) {
+  u128 carry = 0;
+  for (int k = 0; k < 4; ++k) { u128 t = (u128)a->w[k] * 10u + carry; a->w[k] = (uint64_t)t; carry = t >> 64; }
+  return carry == 0 && !(a->w[3] >> 63);
+}
+static void u256_shl1(u256 *a) { for (int k = 3; k > 0; --k) a->w[k] = (a->w[k] << 1) | (a->w[k - 1] >> 63); a->w[0] <<= 1; }
+static void u256_sub(u256 *a, const u256 *b) {
+  unsigned borrow = 0;
+  for (int k = 0; k < 4; ++k) { u128 t = (u128)a->w[k] - b->w[k] - borrow; a->w[k] = (uint64_t)t; borrow = (unsigned)((t >> 64) & 1); }
+}
+/* magnitudes: q = n / d, r = n % d (d != 0): shift-subtract, one bit at a time */
+static void u256_divmod(const u256 *n, const u256 *d, u256 *q, u256 *r) {
+  u256 rem = {{0, 0, 0, 0}}, quo = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; --bit) {
+    u256_shl1(&rem);
+    rem.w[0] |= (n->w[bit >> 6] >> (bit & 63)) & 1u;
+    u256_shl1(&quo);
+    if (u256_cmp(&rem, d) >= 0) { u256_sub(&rem, d); quo.w[0] |= 1u; }
+  }
+  *q = quo; *r = rem;
+}
+static u128 i128_mag(i128 v) { return v < 0 ? (u128)0 - (u128)v : (u128)v; }
+/* digit_count_i256 llkv-types/src/decimal.rs:218-231: 1 for zero */
+static int dec_digits(i128 v) {
+  u128 m = i128_mag(v);
+  int n = 0;
+  do { m /= 10; ++n; } while (m);
+  return n;
+}
+static int dec_scale_ok(int s) { return s >= -DEC_MAX_PRECISION && s <= DEC_MAX_PRECISION; } /* scale_within_bounds :258-261 */
+/* DecimalValue::new :66-76: scale bounds, then at most 38 digits */
+static int32_t dec_new(i128 value, int scale, const char *what, pval *out) {
+  if (!dec_scale_ok(scale)) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal scale %d outside supported range", what, scale);
+  if (dec_digits(value) > DEC_MAX_PRECISION) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal value with scale %d exceeds maximum precision", what, scale);
+  memset(out, 0, sizeof *out);
+  out->tag = PV_DEC; out->d = value; out->scale = scale;
+  return LLKV_OK;
+}
+/* rescale :29-64 towards a LARGER scale (add / sub align to the maximum): value · 10^diff in i256 (checked), to_i128,
+ * DecimalValue::new.  A product beyond i128 is Overflow at the latest in to_i128, so i128 steps decide the same. */
+static int32_t dec_rescale_up(pval v, int target, const char *what, pval *out) {
+  if (!dec_scale_ok(target)) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal scale %d outside supported range", what, target);
+  i128 x = v.d;
+  for (int k = v.scale; k < target; ++k)
+    if (__builtin_mul_overflow(x, (i128)10, &x)) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal arithmetic overflow", what);
+  return dec_new(x, target, what, out);
+}
+/* add / sub :128-151, mul :153-166, div :168-234 (target scale = the left operand's, llkv-executor/src/lib.rs:7303-7316) */
+static int32_t dec_binary(pval l, pval r, int32_t op, const char *what, pval *out) {
+  if (op == LLKV_BIN_ADD || op == LLKV_BIN_SUB) {
+    const int target = l.scale > r.scale ? l.scale : r.scale;
+    pval a, b;
+    int32_t rc;
+    if ((rc = dec_rescale_up(l, target, what, &a)) || (rc = dec_rescale_up(r, target, what, &b))) return rc;
+    i128 z;
+    if (op == LLKV_BIN_ADD ? __builtin_add_overflow(a.d, b.d, &z) : __builtin_sub_overflow(a.d, b.d, &z))
+      return fail(LLKV_INVALID_ARGUMENT, "%s: decimal arithmetic overflow", what); /* the i256 sum does not fit i128 */
+    return dec_new(z, target, what, out);
+  }
+  if (op == LLKV_BIN_MUL) {
+    const int scale = l.scale + r.scale;
+    if (!dec_scale_ok(scale)) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal scale %d outside supported range", what, scale);
+    i128 z;
+    if (__builtin_mul_overflow(l.d, r.d, &z)) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal arithmetic overflow", what);
+    return dec_new(z, scale, what, out);
+  }
+  /* div: numerator · 10^(target + rhs.scale − lhs.scale) = 10^rhs.scale here, exact division by a negative power,
+   * truncating quotient, then "half away from zero" as the reference writes it: half = denominator / 2 truncated, so an
+   * odd denominator rounds up from (|d| − 1) / 2, and the direction follows the signs of the TRUNCATED quotient and the
+   * denominator (a quotient of 0 counts as positive) */
+  const int target = l.scale;
+  const int adj = target + r.scale - l.scale;
+  u256 num = u256_from_u128(i128_mag(l.d));
+  const int num_neg = l.d < 0, den_neg = r.d < 0;
+  if (adj > 0) {
+    if (adj > 2 * DEC_MAX_PRECISION) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal scale %d outside supported range", what, adj);
+    for (int k = 0; k < adj; ++k) if (!u256_mul10(&num)) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal arithmetic overflow", what);
+  } else if (adj < 0) {
+    u256 f = u256_from_u128(1), q, rem;
+    for (int k = 0; k < -adj; ++k) u256_mul10(&f);
+    u256_divmod(&num, &f, &q, &rem);
+    if (!u256_is_zero(&rem)) return fail(LLKV_INVALID_ARGUMENT, "%s: cannot rescale decimal from scale %d to %d without losing precision", what, l.scale, l.scale + adj);
+    num = q;
+  }
+  const u256 den = u256_from_u128(i128_mag(r.d));
+  u256 q, rem;
+  u256_divmod(&num, &den, &q, &rem);
+  int q_neg = (num_neg != den_neg) && !u256_is_zero(&q);
+  if (!u256_is_zero(&rem)) {
+    const u256 half = u256_from_u128(i128_mag(r.d) / 2);
+    if (u256_cmp(&rem, &half) >= 0) {
+      const int up = (!q_neg) == (!den_neg); /* (quotient >= 0) == (denominator >= 0) → + 1, else − 1 */
+      /* signed q ± 1 on the magnitude */
+      if (up == !q_neg) { /* moving away from zero (or from 0 upwards) */
+        unsigned carry = 1;
+        for (int k = 0; k < 4 && carry; ++k) { q.w[k] += 1; carry = q.w[k] == 0; }
+      } else if (u256_is_zero(&q)) { /* 0 − 1 */
+        q.w[0] = 1; q_neg = 1;
+      } else { /* towards zero */
+        const u256 one = u256_from_u128(1);
+        u256_sub(&q, &one);
+        if (u256_is_zero(&q)) q_neg = 0;
+      }
+    }
+  }
+  /* to_i128 */
+  if (q.w[2] | q.w[3]) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal arithmetic overflow", what);
+  const u128 mag = ((u128)q.w[1] << 64) | q.w[0];
+  if (mag > ((u128)1 << 127) || (!q_neg && mag == ((u128)1 << 127))) return fail(LLKV_INVALID_ARGUMENT, "%s: decimal arithmetic overflow", what);
+  return dec_new(q_neg ? (i128)((u128)0 - mag) : (i128)mag, target, what, out);
+}
 
 static pval pv_from_arr(const arr *a, uint64_t i) {
-  pval v = {PV_NULL, 0, 0, NULL};
+  pval v = {PV_NULL, 0, 0, NULL, 0, 0};
   if (!a->valid[i]) return v;
   switch (a->dtype) {
   case LLKV_DT_INT64: v.tag = PV_INT; v.i = ((int64_t *)a->values)[i]; break;
@@ -1870,6 +1995,8 @@ static pval pv_from_arr(const arr *a, uint64_t i) {
   case LLKV_DT_FLOAT64: v.tag = PV_FLOAT; v.f = ((double *)a->values)[i]; break;
   case LLKV_DT_FLOAT32: v.tag = PV_FLOAT; v.f = ((float *)a->values)[i]; break;
   case LLKV_DT_UTF8: v.tag = PV_STR; v.s = a->strings[i]; break;
+  case LLKV_DT_DECIMAL128: /* plan_value_from_array llkv-plan/src/plans.rs:1160-1174: DecimalValue::new(raw, scale) — checked by pv_eval */
+    v.tag = PV_DEC; memcpy(&v.d, (const char *)a->values + i * 16, 16); v.scale = a->scale; break;
   default: break;
   }
   return v;
@@ -1888,14 +2015,34 @@ static int64_t f64_as_i64(double x) {
  * back to i64 (:7338-7389); Int/Int truncates, i64::MIN / -1 → Float (:7213-7227);
  * x/0, x%0 → NULL; NULL propagates. */
 static int32_t pv_binary(pval l, pval r, int32_t op, pval *out) {
-  pval z = {PV_NULL, 0, 0, NULL};
+  pval z = {PV_NULL, 0, 0, NULL, 0, 0};
   if (l.tag == PV_NULL || r.tag == PV_NULL) { *out = z; return LLKV_OK; }
-  if (l.tag == PV_STR || r.tag == PV_STR) return fail(LLKV_INVALID_ARGUMENT, "Non-numeric value in binary operation");
   if (op == LLKV_BIN_DIV && l.tag == PV_INT && r.tag == PV_INT) {
     if (r.i == 0) { *out = z; return LLKV_OK; }
     if (l.i == INT64_MIN && r.i == -1) { z.tag = PV_FLOAT; z.f = (double)l.i / (double)r.i; *out = z; return LLKV_OK; }
     z.tag = PV_INT; z.i = l.i / r.i; *out = z; return LLKV_OK;
   }
+  /* a Decimal operand: exact decimal arithmetic, the other side converted (:7229-7330) — Integer through
+   * DecimalValue::from_i64 (scale 0), Float is an error, Modulo is an error, a zero divisor gives NULL */
+  if (l.tag == PV_DEC || r.tag == PV_DEC) {
+    pval side[2] = {l, r};
+    for (int k = 0; k < 2; ++k) {
+      if (side[k].tag == PV_INT) { side[k].tag = PV_DEC; side[k].d = side[k].i; side[k].scale = 0; }
+      else if (side[k].tag == PV_FLOAT) return fail(LLKV_INVALID_ARGUMENT, "Cannot perform exact decimal arithmetic with Float operands");
+      else if (side[k].tag != PV_DEC) return fail(LLKV_INVALID_ARGUMENT, "Non-numeric value in binary operation");
+    }
+    switch (op) {
+    case LLKV_BIN_ADD: return dec_binary(side[0], side[1], op, "Decimal addition overflow", out);
+    case LLKV_BIN_SUB: return dec_binary(side[0], side[1], op, "Decimal subtraction overflow", out);
+    case LLKV_BIN_MUL: return dec_binary(side[0], side[1], op, "Decimal multiplication overflow", out);
+    case LLKV_BIN_DIV:
+      if (side[1].d == 0) { *out = z; return LLKV_OK; }
+      return dec_binary(side[0], side[1], op, "Decimal division error", out);
+    case LLKV_BIN_MOD: return fail(LLKV_INVALID_ARGUMENT, "Modulo not supported for Decimal types");
+    default: return fail(LLKV_INTERNAL, "bad binary op");
+    }
+  }
+  if (l.tag == PV_STR || r.tag == PV_STR) return fail(LLKV_INVALID_ARGUMENT, "Non-numeric value in binary operation");
   int lf = l.tag == PV_FLOAT, rf = r.tag == PV_FLOAT;
   double a = lf ? l.f : (double)l.i, b = rf ? r.f : (double)r.i, res = 0;
   switch (op) {
@@ -1920,14 +2067,20 @@ static int32_t pv_eval(const llkv_expr_token *e, uint32_t n, const gathered *g, 
     case LLKV_TOK_COLUMN: {
       const arr *a = find_gathered(g, n_g, e[i].field_id);
       if (!a) return fail(LLKV_INVALID_ARGUMENT, "column not found for aggregate");
-      st[sp++] = pv_from_arr(a, row);
+      pval cv = pv_from_arr(a, row);
+      if (cv.tag == PV_DEC) { /* DecimalValue::new over the cell: more than 38 digits fail the conversion */
+        int32_t rc = dec_new(cv.d, cv.scale, "failed to convert Decimal128 value", &cv);
+        if (rc) return rc;
+      }
+      st[sp++] = cv;
       break;
     }
     case LLKV_TOK_LITERAL: {
-      pval v = {PV_NULL, 0, 0, NULL};
+      pval v = {PV_NULL, 0, 0, NULL, 0, 0};
       const llkv_literal *l = &e[i].literal;
-      if (l->tag == LLKV_LIT_INT128) { v.tag = PV_INT; v.i = (int64_t)lit_i128(l); }
+      if (l->tag == LLKV_LIT_INT128) { v.tag = PV_INT; v.i = (int64_t)lit_i128(l); } /* `*v as i64` llkv-executor/src/lib.rs:7019 */
       else if (l->tag == LLKV_LIT_FLOAT64) { v.tag = PV_FLOAT; v.f = l->f64; }
+      else if (l->tag == LLKV_LIT_DECIMAL128) { v.tag = PV_DEC; v.d = lit_i128(l); v.scale = l->scale; } /* Literal::Decimal128(DecimalValue) :7021 */
       else if (l->tag != LLKV_LIT_NULL) return fail(LLKV_UNSUPPORTED, "literal kind in aggregate expression");
       st[sp++] = v;
       break;
@@ -2140,29 +2293,51 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
            * first non-NULL value (plan_values_to_arrow_array :298-406) */
           pval *pv = xmalloc((gn ? gn : 1) * sizeof(pval));
           int first = PV_NULL;
+          uint64_t first_at = 0;
           for (uint64_t i = 0; i < gn && rc == LLKV_OK; ++i) {
             rc = pv_eval(aggs[a].expr, aggs[a].expr_len, m.cols, n_fields, rows[i], &pv[i]);
-            if (first == PV_NULL && rc == LLKV_OK) first = pv[i].tag;
+            if (first == PV_NULL && rc == LLKV_OK) { first = pv[i].tag; first_at = i; }
           }
           if (rc == LLKV_OK) {
-            col.n = gn; col.valid = xmalloc(gn ? gn : 1); col.values = xmalloc((gn ? gn : 1) * 8);
-            col.dtype = first == PV_FLOAT ? LLKV_DT_FLOAT64 : first == PV_INT ? LLKV_DT_INT64 : LLKV_DT_NULL;
+            col.n = gn; col.valid = xmalloc(gn ? gn : 1); col.values = xmalloc((gn ? gn : 1) * 16);
+            col.dtype = first == PV_FLOAT ? LLKV_DT_FLOAT64 : first == PV_INT ? LLKV_DT_INT64 : first == PV_DEC ? LLKV_DT_DECIMAL128 : LLKV_DT_NULL;
+            if (first == PV_DEC) {
+              /* Decimal128Array::builder(..).with_precision_and_scale(d.precision(), d.scale()) of the FIRST non-NULL value
+               * (:314-324): its digit count is the column's precision, and arrow-rs 57.1 validate_decimal_precision_and_scale
+               * refuses a positive scale above the precision — a first value below 10^(scale−1) in magnitude fails the query */
+              col.precision = dec_digits(pv[first_at].d); col.scale = pv[first_at].scale;
+              if (col.scale > 0 && col.scale > col.precision)
+                rc = fail(LLKV_INVALID_ARGUMENT, "invalid Decimal128 precision/scale: scale %d is greater than precision %d", col.scale, col.precision);
+            }
             for (uint64_t i = 0; i < gn && rc == LLKV_OK; ++i) {
               col.valid[i] = pv[i].tag != PV_NULL;
-              if (col.dtype == LLKV_DT_FLOAT64) ((double *)col.values)[i] = pv[i].tag == PV_FLOAT ? pv[i].f : (double)pv[i].i;
+              if (col.dtype == LLKV_DT_DECIMAL128) { /* append_value(raw) — the later values are not checked against the precision */
+                if (pv[i].tag != PV_DEC && pv[i].tag != PV_NULL) rc = fail(LLKV_INVALID_ARGUMENT, "expected DECIMAL plan value");
+                else { const i128 raw = pv[i].tag == PV_DEC ? pv[i].d : 0; memcpy((char *)col.values + i * 16, &raw, 16); }
+              }
+              else if (pv[i].tag == PV_DEC) rc = fail(LLKV_INVALID_ARGUMENT, "expected %s plan value, found Decimal", col.dtype == LLKV_DT_FLOAT64 ? "FLOAT" : "INTEGER");
+              else if (col.dtype == LLKV_DT_FLOAT64) ((double *)col.values)[i] = pv[i].tag == PV_FLOAT ? pv[i].f : (double)pv[i].i;
               else if (pv[i].tag == PV_FLOAT) rc = fail(LLKV_INVALID_ARGUMENT, "expected INTEGER plan value, found Float");
               else ((int64_t *)col.values)[i] = pv[i].i;
             }
             if (col.dtype == LLKV_DT_NULL) { col.dtype = LLKV_DT_INT64; } /* new_null_array(Int64) */
             if (rc == LLKV_OK) rc = is_distinct ? acc_new_distinct(aggs[a].kind, col.dtype, &st) : acc_new(aggs[a].kind, col.dtype, &st);
+            if (rc == LLKV_OK) { st.precision = col.precision; st.scale = col.scale; }
             if (rc == LLKV_OK) rc = acc_update(&st, &col, gn);
             arr_free(&col);
           }
           free(pv);
         }
         if (rc == LLKV_OK) {
-          if (st.distinct) { rc = acc_finalize_distinct(&st, &vals[(size_t)g * n_aggs + a]); acc_free_distinct(&st); }
-          else acc_finalize(&st, &vals[(size_t)g * n_aggs + a]);
+          llkv_value *fv = &vals[(size_t)g * n_aggs + a];
+          if (st.distinct) { rc = acc_finalize_distinct(&st, fv); acc_free_distinct(&st); }
+          else acc_finalize(&st, fv);
+          /* the finalized array goes back through plan_value_from_array (:5241): a Decimal128 cell of more than 38 digits
+           * fails DecimalValue::new (llkv-plan/src/plans.rs:1160-1174) */
+          if (rc == LLKV_OK && fv->dtype == LLKV_DT_DECIMAL128 && !fv->is_null) {
+            const i128 raw = (i128)(((u128)(uint64_t)fv->i64_hi << 64) | (u128)(uint64_t)fv->i64);
+            if (dec_digits(raw) > DEC_MAX_PRECISION) rc = fail(LLKV_INVALID_ARGUMENT, "failed to convert Decimal128 value: exceeds maximum precision");
+          }
         }
       }
     }

@@ -601,3 +601,85 @@ def test_oracle_runs_distinct_accumulators_per_group(orc, abi):
     D = lambda a: dataclasses.replace(a, distinct=True)
     res = orc.groupby(t, None, [1], [A.count_star(), D(A.count(2)), D(A.sum(2)), D(A.avg(2)), D(A.total(3)), D(A.sum(3)), D(A.max(2))], True)
     assert [[k.value for k in r.keys] + [v.value for v in r.values] for r in res] == [["a", 4, 3, 6, 2.0, 2.0, 2.0, 3], ["b", 4, 3, 13, 13 / 3, 6.5, 6.5, 7]]
+
+
+def test_decimal_arithmetic_in_group_by_arguments_follows_the_planvalue_rules(orc, abi):
+    """GROUP BY aggregate arguments with a Decimal operand: exact decimal arithmetic (llkv-executor/src/lib.rs:7229-7330 over
+    llkv-compute/src/scalar/decimal.rs:128-234).  Hand-derived from those lines (held_by_reference: false — the reference has no
+    test of this arm): the known quirks by value, then 300 random shapes against the Python-integer model of tests/decimal_model.py."""
+    import random
+    import decimal_model as dm
+    A, S = abi.AggregateSpec, abi.ScalarExpr
+    ops = {"+": abi.BIN_ADD, "-": abi.BIN_SUB, "*": abi.BIN_MUL, "/": abi.BIN_DIV}
+
+    def run(c1, s1, c2, s2, ints, expr):
+        n = len(c1)
+        t = orc.OracleTable(n)
+        t.add(1, abi.DT_DECIMAL128, c1, precision=38, scale=s1).add(2, abi.DT_DECIMAL128, c2, precision=38, scale=s2)
+        t.add(3, abi.DT_INT64, np.array(ints, dtype=np.int64)).add(4, abi.DT_INT64, np.zeros(n, dtype=np.int64))
+        return orc.groupby(t, None, [4], [A.sum(expr), A.min(expr), A.max(expr), A.avg(expr), A.count(expr)], True)[0].values
+
+    # Q1's arguments under DECIMAL(15,2): price * (1 - discount) at scale 4, * (1 + tax) at scale 6; precision = digits of the first value
+    v = run([10000, 20050], 2, [5, 10], 2, [0, 0], abi.col(1) * (1 - abi.col(2)))
+    assert (v[0].value, v[0].precision, v[0].scale) == (10000 * 95 + 20050 * 90, 6, 4) and v[4].value == 2
+    # 1.00 / 3 = 0.34 (half of an odd denominator is truncated), -0.01 / 3 = +0.01 (a truncated quotient of 0 counts as positive)
+    v = run([100, -1], 2, [0, 0], 0, [3, 3], abi.col(1) / abi.col(3))
+    assert (v[1].value, v[2].value, v[0].scale) == (1, 34, 2)
+    # x / 0 is NULL, and a group whose every value is NULL has an Int64 temp column (SUM comes back as an Int64 NULL)
+    v = run([100, 7], 2, [0, 0], 1, [0, 0], abi.col(1) / abi.col(2))
+    assert v[0].is_null and v[0].dtype == abi.DT_INT64 and v[4].value == 0
+    # a first value with fewer digits than its scale: arrow refuses Decimal128(1, 4)
+    with pytest.raises(abi.LlkvError) as e:
+        run([10000, 20000], 2, [0, 5], 2, [0, 0], abi.col(1) * abi.col(2))
+    assert e.value.kind == "InvalidArgumentError" and "precision" in e.value.message
+    # Decimal with a Float operand, Decimal % x: errors
+    for expr in (abi.col(1) * 0.5, abi.col(1) % abi.col(3)):
+        with pytest.raises(abi.LlkvError) as e:
+            run([100], 2, [1], 0, [3], expr)
+        assert e.value.kind == "InvalidArgumentError"
+
+    random.seed(20240607)
+    seen = set()
+    for _ in range(300):
+        n = random.randint(1, 12)
+        s1, s2 = random.randint(0, 6), random.randint(0, 6)
+        mag = random.choice([10, 10**6, 10**15, 10**19, 10**30, 10**37])
+        c1 = [random.randint(-mag, mag) for _ in range(n)]
+        c2 = [random.randint(-mag // 10**random.randint(0, 6) - 1, mag) for _ in range(n)]
+        if random.random() < 0.3:
+            c2[random.randrange(n)] = 0
+        ints = [random.randint(-50, 50) for _ in range(n)]
+        op = random.choice("+-*/")
+        shape = random.choice(["dd", "di", "id", "dl", "dld"])
+        lit = random.randint(-5, 5)
+        left = {"dd": lambda i: (c1[i], s1), "di": lambda i: (c1[i], s1), "id": lambda i: (ints[i], 0), "dl": lambda i: (c1[i], s1), "dld": lambda i: (c1[i], s1)}[shape]
+        right = {"dd": lambda i: (c2[i], s2), "di": lambda i: (ints[i], 0), "id": lambda i: (c2[i], s2), "dl": lambda i: (lit, 0), "dld": lambda i: (12345, 3)}[shape]
+        le = {"dd": abi.col(1), "di": abi.col(1), "id": abi.col(3), "dl": abi.col(1), "dld": abi.col(1)}[shape]
+        re_ = {"dd": abi.col(2), "di": abi.col(3), "id": abi.col(2), "dl": S.literal(lit), "dld": S.literal(abi.Literal.decimal(12345, 3))}[shape]
+        try:
+            vals = [dm.binary(left(i), right(i), op) for i in range(n)]
+            typ = dm.temp_column(vals)
+            if typ is None:
+                want = ("all NULL",)
+            else:
+                tot = 0
+                for x in vals:
+                    if x is not None:
+                        tot += x[0]
+                        if not -(1 << 127) <= tot < (1 << 127):
+                            raise dm.DecimalError("sum")
+                if dm.digits(tot) > 38:
+                    raise dm.DecimalError("final")
+                nn = [x[0] for x in vals if x is not None]
+                want = (tot, min(nn), max(nn), len(nn), typ[0], typ[1])
+        except dm.DecimalError:
+            want = ("error",)
+        try:
+            v = run(c1, s1, c2, s2, ints, S.binary(le, ops[op], re_))
+            got = ("all NULL",) if v[0].is_null and v[0].dtype == abi.DT_INT64 else (v[0].value, v[1].value, v[2].value, v[4].value, v[0].precision, v[0].scale)
+        except abi.LlkvError as ex:
+            assert ex.kind == "InvalidArgumentError"
+            got = ("error",)
+        assert got == want, (shape, op, s1, s2, c1, c2, ints)
+        seen.add((op, want[0] if isinstance(want[0], str) else "value"))
+    assert {("*", "error"), ("/", "value"), ("/", "all NULL"), ("+", "value")} <= seen
