@@ -47,19 +47,25 @@ def parse():
     ap.add_argument("--dry-run-layout", action="store_true", help="no GPU: gloo rendezvous, shard layout per rank, exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the workload timed on the CPU oracle (0 = auto)")
-    ap.add_argument("--also", default="q6_sf10,q6_sf1,q3_sf10", help="extra workloads reported under 'also' (N>1: q1 weak, q6_sf10 and q3_sf10 sharded)")
+    ap.add_argument("--also", default="q6_sf10,q6_sf1,q3_sf10,q1_sf10_decimal", help="extra workloads reported under 'also' (N>1: q1 weak, q6_sf10 and q3_sf10 sharded)")
     return ap.parse_args()
 
 
-def stage(rt, tpch, abi, dist, query, chunks, scale, rank, world, row_begin_global=0, twice=False):
-    """Generate this rank's shard (its chunks of the global chunk list) on the host and stage the needed columns into HBM."""
+def stage(rt, tpch, abi, dist, query, chunks, scale, rank, world, row_begin_global=0, twice=False, decimal=False):
+    """Generate this rank's shard (its chunks of the global chunk list) on the host and stage the needed columns into HBM.
+    `decimal`: quantity / price / discount / tax as DECIMAL(15,2) — the reference's own TPC-H DDL — handed over as arrow's
+    16-byte Decimal128 raw values."""
     table = rt.HipTable(1, chunks, rank, world)
     first_row = sum(chunks[:table.first_chunk])
     data = tpch.gen_lineitem(table.local_rows, scale, query.columns, row_begin=row_begin_global + first_row)
+    if decimal:
+        data = tpch.lineitem_as_decimal(data)
     t0, (b0, s0) = time.perf_counter(), rt.staging_stats()
     for name in query.columns:
-        fid, dt = tpch.LINEITEM_SCHEMA[name]
-        if dt == abi.DT_UTF8:
+        fid, dt = tpch.LINEITEM_SCHEMA[name][0], tpch.lineitem_dtype(name, decimal)
+        if dt == abi.DT_DECIMAL128:
+            table.append_decimal128_column(fid, tpch.DECIMAL_PRECISION, tpch.DECIMAL_SCALE, data[name])
+        elif dt == abi.DT_UTF8:
             # one rank: the library finds the dictionary itself; several: the ranks agree on one first (sorted union of
             # the shards' distinct values, all-gathered over the library's communicator)
             table.append_utf8_column(fid, data[name], rt.comm_union_strings(sorted(chr(int(v)) for v in np.unique(data[name]))) if world > 1 else None)
@@ -75,8 +81,11 @@ def stage(rt, tpch, abi, dist, query, chunks, scale, rank, world, row_begin_glob
         t0, (b0, s0) = time.perf_counter(), rt.staging_stats()
         again = rt.HipTable(2, chunks, rank, world)
         for name in query.columns:
-            fid, dt = tpch.LINEITEM_SCHEMA[name]
-            again.append_utf8_column(fid, data[name]) if dt == abi.DT_UTF8 else again.append_column(fid, dt, data[name])
+            fid, dt = tpch.LINEITEM_SCHEMA[name][0], tpch.lineitem_dtype(name, decimal)
+            if dt == abi.DT_DECIMAL128:
+                again.append_decimal128_column(fid, tpch.DECIMAL_PRECISION, tpch.DECIMAL_SCALE, data[name])
+            else:
+                again.append_utf8_column(fid, data[name]) if dt == abi.DT_UTF8 else again.append_column(fid, dt, data[name])
         b1, s1 = rt.staging_stats()
         table.staging["second_table"] = {"wall_seconds": time.perf_counter() - t0, "copy_seconds": s1 - s0, "copy_bytes": b1 - b0,
                                          "host_to_hbm_gbs": (b1 - b0) / max(s1 - s0, 1e-9) / 1e9}
@@ -119,11 +128,17 @@ def run_steps(q, steps, stream_ptr, comm_stream_ptr):
     return rows
 
 
+def split_workload(name):
+    """'q1_sf10' → ('q1', 'sf10', False); 'q1_sf10_decimal' → ('q1', 'sf10', True): the same rows with DECIMAL(15,2) money columns."""
+    parts = name.split("_")
+    return parts[0], parts[1], len(parts) > 2 and parts[2] == "decimal"
+
+
 def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmup, stage_twice=False):
-    qname, sf = name.split("_")
+    qname, sf, decimal = split_workload(name)
     query = tpch.QUERIES[qname]()
     chunks, total_rows, gen_scale = workload_chunks(tpch, name, scaling, world)
-    table, data = stage(rt, tpch, abi, dist, query, chunks, gen_scale, rank, world, twice=stage_twice)
+    table, data = stage(rt, tpch, abi, dist, query, chunks, gen_scale, rank, world, twice=stage_twice, decimal=decimal)
     del data
 
     q = rt.PreparedQuery(table, query.predicate, query.aggs, query.keys, query.order_by_keys)
@@ -219,7 +234,7 @@ def host_threads():
     return detected_threads()
 
 
-def cpu_baseline(tpch, abi, query, sf, sample_rows):
+def cpu_baseline(tpch, abi, query, sf, sample_rows, decimal=False):
     """The oracle ("port") timed on this box's host cores.  Faithful leg (the reference's pass structure, one core for
     Q1/Q6 exactly like the reference): a bounded prefix of the workload; parallel leg (chunk-parallel fused mode over
     LLKV_MAX_THREADS / all usable cores): the FULL workload."""
@@ -227,17 +242,21 @@ def cpu_baseline(tpch, abi, query, sf, sample_rows):
 
     full = tpch.LINEITEM_ROWS[sf]
     data = tpch.gen_lineitem(full, tpch.SCALE[sf], query.columns)
-    whole = orc.OracleTable(full)
-    for name in query.columns:
-        fid, dt = tpch.LINEITEM_SCHEMA[name]
-        whole.add(fid, dt, data[name])
-    rows = min(sample_rows, full)
-    t = whole
-    if rows != full:
-        t = orc.OracleTable(rows)
+    if decimal:
+        data = tpch.lineitem_as_decimal(data)
+
+    def table_of(n):
+        t = orc.OracleTable(n)
         for name in query.columns:
-            fid, dt = tpch.LINEITEM_SCHEMA[name]
-            t.add(fid, dt, data[name][:rows])
+            fid, dt = tpch.LINEITEM_SCHEMA[name][0], tpch.lineitem_dtype(name, decimal)
+            if dt == abi.DT_DECIMAL128:
+                t.add(fid, dt, data[name][:n], precision=tpch.DECIMAL_PRECISION, scale=tpch.DECIMAL_SCALE)
+            else:
+                t.add(fid, dt, data[name][:n])
+        return t
+    whole = table_of(full)
+    rows = min(sample_rows, full)
+    t = whole if rows == full else table_of(rows)
     t0 = time.perf_counter()
     if query.grouped:
         orc.groupby(t, query.predicate, query.keys, query.aggs, query.order_by_keys)
@@ -418,7 +437,7 @@ def spawn_ranks(args):
 
 def workload_chunks(tpch, name, scaling, world):
     """(global chunk list, table rows, generator scale) of a lineitem workload under a scaling mode."""
-    qname, sf = name.split("_")
+    qname, sf, _ = split_workload(name)
     rows_sf, scale = tpch.LINEITEM_ROWS[sf], tpch.SCALE[sf]
     if scaling == "weak" and world > 1:
         chunks = []
@@ -525,7 +544,7 @@ def main():
     value = rows_total * args.steps / main_res["seconds"]
     kern_s = main_res["kernel_ms_avg"] / 1e3
     achieved = main_res["alg_bytes_local"] / kern_s / 1e9 if kern_s > 0 else 0.0
-    qname, sf = args.workload.split("_")
+    qname, sf, main_decimal = split_workload(args.workload)
     traffic, traffic_src = pmc_traffic(args.workload) if world == 1 else (None, None)
     if world == 1:
         shape = f"TPC-H {qname.upper()} {sf.upper()} lineitem on one GPU ({rows_total} rows)"
@@ -537,7 +556,7 @@ def main():
         "metric": "rows/sec + HBM GB/s, TPC-H Q1/Q6 SF10 at 1/2/4/8 MI355X",
         "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_res["seconds"] / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "i64 (exact decimal)" if main_decimal else "f64", "data": "synthetic",
         "config": {
             "workload": f"{shape}, columns resident in HBM, {main_res['query'].bytes_per_row} B/row algorithmic",
             "sharding": (f"{args.scaling}: by chunk (131072 rows) into 8 canonical octants, rank r owns octants [r·8/N, (r+1)·8/N); "
@@ -573,6 +592,12 @@ def main():
                 continue
             r = measure(rt, tpch, abi, torch, dist, name, 0, 1, "strong", args.steps, args.warmup)
             also[name] = also_entry(r, args.steps)
+            if split_workload(name)[2]:
+                also[name]["bytes_per_row"] = r["query"].bytes_per_row
+                also[name]["dtype"] = "i64 (exact decimal)"
+                also[name]["note"] = ("quantity / price / discount / tax as DECIMAL(15,2) (the reference's own TPC-H DDL), staged from arrow's 16-byte "
+                                      "Decimal128 values narrowed to 8 B/row: the computed sums are exact integer lanes (PlanValue Decimal arm), "
+                                      "every cell bit-equal to the reference's Decimal128(p, s)")
             if tpch.LINEITEM_ROWS[name.split("_")[1]] * r["query"].bytes_per_row < 256 << 20:
                 also[name]["note"] = ("the columns fit the 256 MB Infinity Cache and are re-scanned every step: not an HBM figure; "
                                       f"launch-bound: {also[name]['ms_per_step'] * 1e3 - also[name]['kernel_ms'] * 1e3:.1f} µs per step outside the kernel")
@@ -586,7 +611,7 @@ def main():
         r = measure(rt, tpch, abi, torch, dist, args.workload, rank, world, other, args.steps, args.warmup)
         also[f"{args.workload}_{other}"] = dict(also_entry(r, args.steps), scaling=other, total_rows=r["total_rows"])
         r["prepared"].close(); r["table"].close()
-        for name in [w for w in names if w != args.workload and w.endswith("_" + sf)]:
+        for name in [w for w in names if w != args.workload and split_workload(w)[1] == sf]:
             if name.startswith("q3_"):
                 also[name] = measure_q3_sharded(rt, tpch, abi, torch, dist, name.split("_")[1], rank, world)
             else:
@@ -596,7 +621,7 @@ def main():
     out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample = args.cpu_sample_rows or (40_000_000 if main_res["query"].grouped else 60_000_000)  # ≈10–20 s of CPU work
-        out["cpu_baseline"] = cpu_baseline(tpch, abi, main_res["query"], sf, sample)
+        out["cpu_baseline"] = cpu_baseline(tpch, abi, main_res["query"], sf, sample, main_decimal)
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():

@@ -85,8 +85,9 @@ class OracleTable:
     def add(self, field_id: int, dtype: int, values, valid: Optional[Sequence[bool]] = None, precision: int = 0, scale: int = 0):
         c = COrcColumn()
         c.field_id, c.dtype = field_id, dtype
-        if dtype == abi.DT_DECIMAL128:  # Python ints → 16-byte little-endian raw values
-            arr = abi.i128_buffer(values)
+        if dtype == abi.DT_DECIMAL128:  # Python ints (or an int64 array of raw values) → 16-byte little-endian raw values
+            arr = values if isinstance(values, np.ndarray) and values.ndim == 2 else \
+                abi.i128_buffer_from_i64(values) if isinstance(values, np.ndarray) and values.dtype == np.int64 else abi.i128_buffer(values)
             assert len(arr) == self.rows
             self._keep.append(arr)
             c.values, c.precision, c.scale = arr.ctypes.data, precision, scale

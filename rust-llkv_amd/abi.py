@@ -36,6 +36,16 @@ def i128_buffer(values) -> "np.ndarray":
     return out
 
 
+def i128_buffer_from_i64(values) -> "np.ndarray":
+    """int64 raw values → arrow Decimal128 raw buffer (n, 2) uint64: sign-extended, vectorised (DECIMAL(15,2) money columns)."""
+    import numpy as np
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out = np.empty((len(v), 2), dtype=np.uint64)
+    out[:, 0] = v.view(np.uint64)
+    out[:, 1] = (v >> 63).view(np.uint64)
+    return out
+
+
 def i128_from_words(lo: int, hi: int) -> int:
     """(low u64 bits, high i64) → Python int."""
     return (int(hi) << 64) | (int(lo) & 0xFFFFFFFFFFFFFFFF)

@@ -486,16 +486,33 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
     *sum = (int64_t)total;
     return LLKV_OK;
   };
-  if (a.typed_by_first_value && rows == 0 && (a.fin == AggFinal::SumF64 || a.fin == AggFinal::MinF64 || a.fin == AggFinal::MaxF64)) {
+  if (a.typed_by_first_value && rows == 0 && (a.fin == AggFinal::SumF64 || a.fin == AggFinal::MinF64 || a.fin == AggFinal::MaxF64 ||
+                                              a.fin == AggFinal::SumDec || a.fin == AggFinal::MinDec || a.fin == AggFinal::MaxDec)) {
     out->dtype = LLKV_DT_INT64; // an all-NULL temp column is an Int64 column: SUM / MIN / MAX come back as Int64 NULLs
     out->is_null = 1;
     return LLKV_OK;
+  }
+  int32_t dec_precision = a.precision;
+  if (a.digits_lane >= 0) {
+    // a computed DECIMAL argument of a GROUP BY: the group's temp column is Decimal128(digits of its first non-NULL value, scale)
+    // (plan_values_to_arrow_array llkv-executor/src/lib.rs:298-330) — arrow-rs refuses a positive scale above the precision,
+    // whatever the aggregate; without a non-NULL value the column is Int64 (AVG → Float64 NULL, TOTAL → 0.0)
+    if (rows == 0) {
+      if (a.fin == AggFinal::AvgDec) { out->dtype = LLKV_DT_FLOAT64; out->is_null = 1; return LLKV_OK; }
+      if (a.fin == AggFinal::TotalDec) { out->dtype = LLKV_DT_FLOAT64; out->f64 = 0.0; return LLKV_OK; }
+    } else {
+      dec_precision = (int32_t)((g[base + a.digits_lane] >> a.digits_shift) & 63u);
+      if (a.scale > 0 && a.scale > dec_precision) {
+        *err = "invalid Decimal128 precision/scale: scale " + std::to_string(a.scale) + " is greater than precision " + std::to_string(dec_precision);
+        return LLKV_INVALID_ARGUMENT;
+      }
+    }
   }
   if (a.fin == AggFinal::SumDec || a.fin == AggFinal::TotalDec || a.fin == AggFinal::AvgDec || a.fin == AggFinal::MinDec || a.fin == AggFinal::MaxDec) {
     // Decimal128 finalize (llkv-aggregate/src/lib.rs:1567-1582,1640-1655,1720-1760): the 64-bit values cannot
     // carry a sum of < 2^63 rows out of i128, so "Decimal128 sum overflow" is unreachable on this path
     out->dtype = LLKV_DT_DECIMAL128;
-    out->precision = a.precision;
+    out->precision = dec_precision;
     out->scale = a.scale;
     i128 v = 0;
     if (a.fin == AggFinal::MinDec || a.fin == AggFinal::MaxDec) {

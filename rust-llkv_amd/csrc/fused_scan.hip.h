@@ -335,6 +335,69 @@ template <int IS_MOD, class L, class R> struct DivPV {
     else return a / b;
   }
 };
+// Exact decimal arithmetic of the PlanValue interpreter (llkv-executor/src/lib.rs:7229-7330 over llkv-compute/src/scalar/
+// decimal.rs:128-234: add / sub at the larger scale, mul at the sum of the scales, every step checked in i256 and against 38
+// digits).  The operands are the 64-bit images of Decimal128 cells, Int64 cells (DecimalValue::from_i64) and literals; the host
+// lowering (plan.cpp: expr_planvalue) carries the scales, writes a rescale as a multiplication by the literal 10^k and admits
+// the plan only when interval arithmetic over the column statistics keeps EVERY intermediate inside 64 bits — so none of the
+// reference's checks can fire and plain wrapping integer arithmetic is exact.
+template <int OP, class L, class R> struct DecBin {
+  using Type = I64;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j); }
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int j) {
+    const uint64_t a = (uint64_t)(int64_t)L::eval(c, j), b = (uint64_t)(int64_t)R::eval(c, j);
+    if constexpr (OP == B_ADD) return (int64_t)(a + b);
+    else if constexpr (OP == B_SUB) return (int64_t)(a - b);
+    else return (int64_t)(a * b);
+  }
+};
+// Division to the LEFT operand's scale (:7296-7316, decimal.rs:168-234): numerator · 10^(divisor's scale) (P10, the host's
+// literal), truncating quotient, then the reference's rounding as written — half = denominator / 2 TRUNCATED, |remainder| ≥
+// |half| rounds, and the direction follows the signs of the truncated quotient and the denominator (a quotient of 0 counts as
+// positive): 1.00 / 3 = 0.34, −0.01 / 3 = +0.01.  A zero divisor is NULL.
+template <class L, class R, class P10> struct DecDiv {
+  using Type = I64;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & ((int64_t)R::eval(c, j) != 0); }
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int j) {
+    const int64_t num = (int64_t)((uint64_t)(int64_t)L::eval(c, j) * (uint64_t)(int64_t)P10::eval(c, j));
+    const int64_t den = (int64_t)R::eval(c, j);
+    if (den == 0) return 0;
+    const uint64_t an = num < 0 ? 0ull - (uint64_t)num : (uint64_t)num, ad = den < 0 ? 0ull - (uint64_t)den : (uint64_t)den;
+    const uint64_t qm = an / ad, rm = an - qm * ad;
+    int64_t q = ((num < 0) != (den < 0)) ? -(int64_t)qm : (int64_t)qm;
+    if ((rm != 0) & (rm >= ad / 2)) q += ((q >= 0) == (den >= 0)) ? 1 : -1;
+    return q;
+  }
+};
+constexpr uint64_t dec_pow10(int k) { uint64_t v = 1; for (int i = 0; i < k; ++i) v *= 10ull; return v; }
+// Decimal digits of |E| (digit_count_i256 llkv-types/src/decimal.rs:218-231: 1 for zero), known by the lowering's interval
+// arithmetic to lie in [LO, HI]: HI − LO compares against literals.
+template <class E, int LO, int HI> struct DecDigits {
+  static __device__ __forceinline__ uint64_t digits(Ctx &c, int j) {
+    const int64_t v = (int64_t)E::eval(c, j);
+    const uint64_t m = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
+    uint64_t d = LO;
+#pragma unroll
+    for (int k = LO; k < HI; ++k) d += m >= dec_pow10(k) ? 1u : 0u;
+    return d;
+  }
+};
+// The temp column a group's computed decimal argument becomes is typed by the group's FIRST non-NULL value
+// (plan_values_to_arrow_array llkv-executor/src/lib.rs:298-330): Decimal128(its digit count, its scale) — the precision the
+// finalized cell carries, and a query error when the scale exceeds it.  One MIN lane over (row << 6·n | digits of up to n = 4
+// arguments that are NULL in the same rows — V): the smallest key is the first row's.
+template <class V, class... Ds> struct FirstDigits {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return OP_MIN_I64; }
+  template <class D0, class... Dr> static __device__ __forceinline__ uint64_t pack(Ctx &c, int j) {
+    const uint64_t d = D0::digits(c, j);
+    if constexpr (sizeof...(Dr) > 0) return (d << (6 * sizeof...(Dr))) | pack<Dr...>(c, j);
+    else return d;
+  }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
+    o[0] = V::eval(c, j) ? ((c.row << (6 * sizeof...(Ds))) | pack<Ds...>(c, j)) : 0x7FFFFFFFFFFFFFFFull;
+  }
+};
 // Predicate form of an expression's validity.
 template <class E> struct VE {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return E::valid(c, j); }

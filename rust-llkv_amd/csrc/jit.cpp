@@ -186,10 +186,15 @@ static bool blob_take_identity(std::vector<char> *file, const std::string *expec
   return true;
 }
 // the seed directory is trusted like the library beside it — if nobody but its owner (this user or root) can write to it
+// (mode 755 or tighter: a checkout under umask 002 makes it 775 and every plan cold-compiles; LLKV_HIP_TRACE=1 says so once)
 static bool trusted_dir(const std::string &dir) {
   struct stat st;
   if (dir.empty() || ::stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
-  return (st.st_uid == ::geteuid() || st.st_uid == 0) && (st.st_mode & 022) == 0;
+  const bool ok = (st.st_uid == ::geteuid() || st.st_uid == 0) && (st.st_mode & 022) == 0;
+  if (!ok && std::getenv("LLKV_HIP_TRACE"))
+    std::fprintf(stderr, "[llkv_hip] jit: seed directory %s is ignored (owner %u, mode %o: it must belong to this user or root and be writable by its owner only — chmod 755)\n",
+                 dir.c_str(), (unsigned)st.st_uid, (unsigned)(st.st_mode & 07777));
+  return ok;
 }
 
 int jit_compile(JitKind kind, const std::string &type_string, JitKernel *out, std::string *err) {

@@ -108,27 +108,36 @@ struct StagerPool {
   int init(int n = 1) {
     for (int k = 0; k < n && k < kLanes; ++k) {
       Lane &l = lanes[k];
-      if (l.stream) continue;
-      HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-      for (int i = 0; i < kDepth; ++i) {
-        HIP_TRY(hipHostMalloc(&l.pinned[i], kBuf, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&l.done[i], hipEventDisableTiming));
+      if (l.stream && l.pinned[kDepth - 1] && l.done[kDepth - 1]) continue; // complete: stream, every ring buffer, every event
+      // a lane is whole or absent: one that an earlier call left half made (pinned memory ran out after its stream existed) is
+      // taken down and made again, and a failure here leaves nothing of it behind for the ring path to trip over
+      drop_lane(l);
+      hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+      for (int i = 0; i < kDepth && e == hipSuccess; ++i) {
+        e = hipHostMalloc(&l.pinned[i], kBuf, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l.done[i], hipEventDisableTiming);
+      }
+      if (e != hipSuccess) {
+        drop_lane(l);
+        return set_error(LLKV_INTERNAL, std::string("staging lane: ") + hipGetErrorString(e));
       }
     }
     ready = true;
     return LLKV_OK;
   }
-  void release() {
-    for (Lane &l : lanes) {
-      for (int i = 0; i < kDepth; ++i) {
-        if (l.pinned[i]) (void)hipHostFree(l.pinned[i]);
-        if (l.done[i]) (void)hipEventDestroy(l.done[i]);
-        l.pinned[i] = nullptr;
-        l.done[i] = nullptr;
-      }
-      if (l.stream) (void)hipStreamDestroy(l.stream);
-      l.stream = nullptr;
+  static void drop_lane(Lane &l) {
+    for (int i = 0; i < kDepth; ++i) {
+      if (l.pinned[i]) (void)hipHostFree(l.pinned[i]);
+      if (l.done[i]) (void)hipEventDestroy(l.done[i]);
+      l.pinned[i] = nullptr;
+      l.done[i] = nullptr;
     }
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+    l.stream = nullptr;
+    l.cur = 0;
+  }
+  void release() {
+    for (Lane &l : lanes) drop_lane(l);
     ready = false;
   }
   // copies every piece and returns when all of them have arrived: host → HBM, or (`to_host`) HBM → pageable

@@ -204,6 +204,8 @@ double parse_numeric_or_zero(const std::string &text) {
 }
 namespace {
 
+struct PlanValueInfo { bool is_decimal = false; int scale = 0; i128 lo = 0, hi = 0; };
+
 struct Lowering {
   const ColumnResolver &resolve;
   LoweredPlan &p;
@@ -477,16 +479,26 @@ struct Lowering {
     return LLKV_OK;
   }
 
+  // A literal takes a slot of the plan's bank; a value the bank already holds shares its slot (so the same expression under
+  // two aggregates lowers to the same node, and the lane groups — deduplicated by node — are shared too)
   int lit_i(int64_t v, std::string *node, const char *kind = "LitI") {
-    if ((int)p.lit_i.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many integer literals");
-    p.lit_i.push_back(v);
-    *node = std::string(kind) + "<" + std::to_string(p.lit_i.size() - 1) + ">";
+    size_t at = 0;
+    while (at < p.lit_i.size() && p.lit_i[at] != v) ++at;
+    if (at == p.lit_i.size()) {
+      if ((int)p.lit_i.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many integer literals");
+      p.lit_i.push_back(v);
+    }
+    *node = std::string(kind) + "<" + std::to_string(at) + ">";
     return LLKV_OK;
   }
   int lit_f(double v, std::string *node) {
-    if ((int)p.lit_f.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many float literals");
-    p.lit_f.push_back(v);
-    *node = "LitF<" + std::to_string(p.lit_f.size() - 1) + ">";
+    size_t at = 0;
+    while (at < p.lit_f.size() && std::memcmp(&p.lit_f[at], &v, 8) != 0) ++at; // by bit pattern: −0.0 and NaNs keep their own slots
+    if (at == p.lit_f.size()) {
+      if ((int)p.lit_f.size() >= kMaxLitsHost) return fail(LLKV_UNSUPPORTED, "too many float literals");
+      p.lit_f.push_back(v);
+    }
+    *node = "LitF<" + std::to_string(at) + ">";
     return LLKV_OK;
   }
 
@@ -1082,49 +1094,175 @@ struct Lowering {
     return LLKV_OK;
   }
 
+  // What a GROUP BY aggregate argument evaluates to (PlanValue::{Integer, Float, Decimal}); for the integer and decimal
+  // classes the interval [lo, hi] the column statistics and literals leave its 64-bit image in.
+  struct PV {
+    std::string s;
+    bool f = false;     // Float
+    bool dec = false;   // Decimal(scale): the value is raw / 10^scale
+    int scale = 0;
+    bool bounded = false;
+    i128 lo = 0, hi = 0;
+    bool lit = false;   // an integer / decimal literal (lo == hi)
+  };
+  PlanValueInfo last_planvalue = {}; // (expr_planvalue) class, scale and bounds of the expression just lowered
+
+  static bool fits_i64(i128 v) { return v >= (i128)INT64_MIN && v <= (i128)INT64_MAX; }
+  static i128 pow10_i128(int k) { i128 v = 1; for (int i = 0; i < k; ++i) v *= 10; return v; }
+
   // GROUP BY aggregate argument, PlanValue semantics (llkv-executor/src/lib.rs:7193-7389).
   int expr_planvalue(const llkv_expr_token *e, uint32_t n, std::string *node, bool *is_f64) {
-    struct V { std::string s; bool f; };
-    std::vector<V> st;
+    std::vector<PV> st;
     int rc;
+    last_planvalue = PlanValueInfo{};
     for (uint32_t i = 0; i < n; ++i) {
       if (e[i].kind == LLKV_TOK_COLUMN) {
         const ColumnInfo *ci;
         std::string c;
         if ((rc = expr_col_node(e[i].field_id, &ci, &c))) return rc;
-        if (ci->dtype == LLKV_DT_FLOAT64) st.push_back({c, true});
-        else if (ci->dtype == LLKV_DT_FLOAT32) st.push_back({"ToF64<" + c + ">", true});
-        else if (ci->dtype == LLKV_DT_INT64) st.push_back({c, false});
-        else if (is_int_class(ci->dtype)) st.push_back({"ToI64<" + c + ">", false});
+        PV v;
+        if (ci->dtype == LLKV_DT_FLOAT64) { v.s = c; v.f = true; }
+        else if (ci->dtype == LLKV_DT_FLOAT32) { v.s = "ToF64<" + c + ">"; v.f = true; }
+        else if (ci->dtype == LLKV_DT_INT64) v.s = c;
+        else if (is_int_class(ci->dtype)) v.s = "ToI64<" + c + ">";
+        else if (ci->dtype == LLKV_DT_DECIMAL128) {
+          // plan_value_from_array (llkv-plan/src/plans.rs:1160-1174): DecimalValue::new(raw, scale) — a 64-bit image has at
+          // most 19 digits, so the 38-digit check cannot fail; the scale must lie within ±38
+          if (ci->scale < -38 || ci->scale > 38) return fail(LLKV_UNSUPPORTED, "Decimal128 scale outside ±38 in an aggregate expression (the reference fails the conversion)");
+          v.s = c; v.dec = true; v.scale = ci->scale;
+        }
         else return fail(LLKV_UNSUPPORTED, std::string("aggregate expression over ") + dtype_name(ci->dtype));
+        if (!v.f) {
+          v.bounded = true;
+          if (ci->has_stats) { v.lo = ci->min_i; v.hi = ci->max_i; }
+          else if (ci->dtype == LLKV_DT_INT32 || ci->dtype == LLKV_DT_DATE32) { v.lo = INT32_MIN; v.hi = INT32_MAX; }
+          else if (ci->dtype == LLKV_DT_UINT32) { v.lo = 0; v.hi = UINT32_MAX; }
+          else { v.lo = INT64_MIN; v.hi = INT64_MAX; }
+        }
+        st.push_back(v);
       } else if (e[i].kind == LLKV_TOK_LITERAL) {
         std::string l;
         const llkv_literal &lit = e[i].literal;
-        if (lit.tag == LLKV_LIT_FLOAT64) { if ((rc = lit_f(lit.f64, &l))) return rc; st.push_back({l, true}); }
-        else if (lit.tag == LLKV_LIT_INT128) { if ((rc = lit_i((int64_t)lit_i128(lit), &l))) return rc; st.push_back({l, false}); }
+        PV v;
+        if (lit.tag == LLKV_LIT_FLOAT64) { if ((rc = lit_f(lit.f64, &l))) return rc; v.f = true; }
+        else if (lit.tag == LLKV_LIT_INT128) { // `*v as i64` (:7019)
+          const int64_t x = (int64_t)lit_i128(lit);
+          if ((rc = lit_i(x, &l))) return rc;
+          v.bounded = true; v.lo = v.hi = x; v.lit = true;
+        }
+        else if (lit.tag == LLKV_LIT_DECIMAL128) { // Literal::Decimal128(DecimalValue) (:7021)
+          const i128 raw = lit_i128(lit);
+          if (!fits_i64(raw) || lit.scale < -38 || lit.scale > 38) return fail(LLKV_UNSUPPORTED, "decimal literal beyond 64 bits in an aggregate expression");
+          if ((rc = lit_i((int64_t)raw, &l))) return rc;
+          v.dec = true; v.scale = lit.scale; v.bounded = true; v.lo = v.hi = raw; v.lit = true;
+        }
         else return fail(LLKV_UNSUPPORTED, "literal kind in aggregate expression");
+        v.s = l;
+        st.push_back(v);
       } else {
         if (st.size() < 2) return fail(LLKV_INTERNAL, "expression stack underflow");
-        V r = st.back(); st.pop_back();
-        V l = st.back(); st.pop_back();
+        PV r = st.back(); st.pop_back();
+        PV l = st.back(); st.pop_back();
+        if (l.dec || r.dec) {
+          // a Decimal operand: exact decimal arithmetic (:7229-7330).  Int / Int was decided before this arm; a Float operand
+          // and Modulo are errors the reference raises on the first row whose operands are both non-NULL — not decidable here
+          if (l.f || r.f) return fail(LLKV_UNSUPPORTED, "decimal arithmetic with a Float operand (the reference raises an error on the first non-NULL row)");
+          if (e[i].binop == LLKV_BIN_MOD) return fail(LLKV_UNSUPPORTED, "Modulo over Decimal operands (an error in the reference)");
+          PV o;
+          o.dec = true;
+          o.bounded = true;
+          // rescale: value · 10^diff (decimal.rs:29-49), admitted when the statistics keep the product inside 64 bits
+          auto rescaled = [&](const PV &x, int target, PV *out) -> int {
+            *out = x;
+            out->scale = target;
+            const int diff = target - x.scale;
+            if (diff == 0) return LLKV_OK;
+            if (diff > 18) return fail(LLKV_UNSUPPORTED, "decimal rescale beyond 64 bits in an aggregate expression");
+            const i128 f = pow10_i128(diff);
+            out->lo = x.lo * f; out->hi = x.hi * f;
+            if (!fits_i64(out->lo) || !fits_i64(out->hi)) return fail(LLKV_UNSUPPORTED, "decimal intermediate beyond 64 bits in an aggregate expression");
+            if (x.lit) return lit_i((int64_t)out->lo, &out->s); // a literal is rescaled here
+            std::string k;
+            int rc2 = lit_i((int64_t)f, &k);
+            if (rc2) return rc2;
+            out->s = "DecBin<3," + x.s + "," + k + ">";
+            return LLKV_OK;
+          };
+          if (e[i].binop == LLKV_BIN_ADD || e[i].binop == LLKV_BIN_SUB) {
+            const int target = std::max(l.scale, r.scale);
+            PV a, b;
+            if ((rc = rescaled(l, target, &a)) || (rc = rescaled(r, target, &b))) return rc;
+            o.scale = target;
+            if (e[i].binop == LLKV_BIN_ADD) { o.lo = a.lo + b.lo; o.hi = a.hi + b.hi; }
+            else { o.lo = a.lo - b.hi; o.hi = a.hi - b.lo; }
+            o.s = std::string("DecBin<") + (e[i].binop == LLKV_BIN_ADD ? "1," : "2,") + a.s + "," + b.s + ">";
+          } else if (e[i].binop == LLKV_BIN_MUL) {
+            o.scale = l.scale + r.scale;
+            if (o.scale < -38 || o.scale > 38) return fail(LLKV_UNSUPPORTED, "decimal product scale outside ±38 (an error in the reference)");
+            const i128 c4[4] = {l.lo * r.lo, l.lo * r.hi, l.hi * r.lo, l.hi * r.hi};
+            o.lo = std::min(std::min(c4[0], c4[1]), std::min(c4[2], c4[3]));
+            o.hi = std::max(std::max(c4[0], c4[1]), std::max(c4[2], c4[3]));
+            o.s = "DecBin<3," + l.s + "," + r.s + ">";
+          } else { // Divide: to the left operand's scale; numerator · 10^(divisor's scale)
+            o.scale = l.scale;
+            if (r.scale < 0 || r.scale > 18) return fail(LLKV_UNSUPPORTED, "decimal division by an operand of this scale is not on the GPU path");
+            const i128 f = pow10_i128(r.scale);
+            const i128 nlo = l.lo * f, nhi = l.hi * f;
+            if (!fits_i64(nlo) || !fits_i64(nhi)) return fail(LLKV_UNSUPPORTED, "decimal intermediate beyond 64 bits in an aggregate expression");
+            const i128 m = std::max(nlo < 0 ? -nlo : nlo, nhi < 0 ? -nhi : nhi) + 1; // |quotient| ≤ |numerator|, + 1 for the rounding
+            o.lo = -m; o.hi = m;
+            std::string k;
+            if ((rc = lit_i((int64_t)f, &k))) return rc;
+            o.s = "DecDiv<" + l.s + "," + r.s + "," + k + ">";
+          }
+          if (!fits_i64(o.lo) || !fits_i64(o.hi)) return fail(LLKV_UNSUPPORTED, "decimal intermediate beyond 64 bits in an aggregate expression");
+          st.push_back(o);
+          continue;
+        }
         if (e[i].binop == LLKV_BIN_DIV || (e[i].binop == LLKV_BIN_MOD && (l.f || r.f))) {
           // Int / Int truncates but turns Float for i64::MIN / -1 (:7213-7227): the type of the group's temp column
           // would depend on the data
           if (!l.f && !r.f) return fail(LLKV_UNSUPPORTED, "integer division in GROUP BY aggregate arguments");
-          st.push_back({std::string("DivPV<") + (e[i].binop == LLKV_BIN_MOD ? "1" : "0") + "," + l.s + "," + r.s + ">", true});
+          PV o;
+          o.s = std::string("DivPV<") + (e[i].binop == LLKV_BIN_MOD ? "1" : "0") + "," + l.s + "," + r.s + ">";
+          o.f = true;
+          st.push_back(o);
           continue;
         }
         const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
-        if (!l.f && !r.f) st.push_back({"BinViaF64<" + std::to_string(op) + "," + l.s + "," + r.s + ">", false});
-        else {
+        PV o;
+        if (!l.f && !r.f) {
+          o.s = "BinViaF64<" + std::to_string(op) + "," + l.s + "," + r.s + ">";
+          // (computed in f64 and cast back: exact only below 2^53 — beyond that the interval is everything an i64 holds)
+          o.bounded = true;
+          o.lo = INT64_MIN; o.hi = INT64_MAX;
+          const i128 lim = (i128)1 << 53;
+          if (op != 4 && l.bounded && r.bounded) {
+            i128 a, b;
+            if (op == 1) { a = l.lo + r.lo; b = l.hi + r.hi; }
+            else if (op == 2) { a = l.lo - r.hi; b = l.hi - r.lo; }
+            else {
+              const i128 c4[4] = {l.lo * r.lo, l.lo * r.hi, l.hi * r.lo, l.hi * r.hi};
+              a = std::min(std::min(c4[0], c4[1]), std::min(c4[2], c4[3]));
+              b = std::max(std::max(c4[0], c4[1]), std::max(c4[2], c4[3]));
+            }
+            if (a > -lim && b < lim && l.lo > -lim && l.hi < lim && r.lo > -lim && r.hi < lim) { o.lo = a; o.hi = b; }
+          }
+        } else {
           const std::string a = l.f ? l.s : "ToF64<" + l.s + ">", b = r.f ? r.s : "ToF64<" + r.s + ">";
-          st.push_back({"Bin<" + std::to_string(op) + "," + a + "," + b + nan_flag(true) + ">", true});
+          o.s = "Bin<" + std::to_string(op) + "," + a + "," + b + nan_flag(true) + ">";
+          o.f = true;
         }
+        st.push_back(o);
       }
     }
     if (st.size() != 1) return fail(LLKV_INTERNAL, "expression evaluation missing result");
     *node = st[0].s;
     *is_f64 = st[0].f;
+    last_planvalue.is_decimal = st[0].dec;
+    last_planvalue.scale = st[0].scale;
+    last_planvalue.lo = st[0].lo;
+    last_planvalue.hi = st[0].hi;
     return LLKV_OK;
   }
 };
@@ -1153,6 +1291,11 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     return group_lane.back();
   };
   enum { ADD_F64 = 0, ADD_I64 = 1, MIN_I64 = 2, MAX_I64 = 3, MAX_U64 = 4 };
+  // computed decimal arguments of a GROUP BY: the digit count of each group's first non-NULL value types its temp column
+  // (FirstDigits, fused_scan.hip.h) — arguments that are NULL in the same rows share a lane, packed after the loop
+  struct PendingDigits { size_t agg; std::string valid, node; int dlo, dhi, scale; uint64_t rows; };
+  std::vector<PendingDigits> pending_digits;
+  auto digits_of = [](i128 v) { int d = 0; u128 m = v < 0 ? (u128)(-v) : (u128)v; do { m /= 10; ++d; } while (m); return d; };
 
   for (uint32_t a = 0; a < n_aggs; ++a) {
     const llkv_aggregate_spec &s = aggs[a];
@@ -1233,6 +1376,22 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       std::vector<llkv_expr_token> folded;
       if (!grouped && (rc = L.fold_constants(s.expr, s.expr_len, &folded))) return rc;
       if ((rc = grouped ? L.valid_of_node(s.expr, s.expr_len, node, grouped, &valid) : L.valid_of_node(folded.data(), (uint32_t)folded.size(), node, grouped, &valid))) return rc;
+    }
+    const PlanValueInfo pvi = (grouped && !simple) ? L.last_planvalue : PlanValueInfo{};
+    if (pvi.is_decimal) {
+      // every aggregate kind — COUNT too — goes through the group's temp column (llkv-executor/src/lib.rs:5186-5199)
+      PendingDigits pd;
+      pd.agg = p.aggs.size();
+      pd.valid = valid.empty() ? "True" : valid;
+      pd.node = node;
+      const i128 alo = pvi.lo < 0 ? -pvi.lo : pvi.lo, ahi = pvi.hi < 0 ? -pvi.hi : pvi.hi;
+      pd.dlo = (pvi.lo <= 0 && pvi.hi >= 0) ? 1 : digits_of(std::min(alo, ahi));
+      pd.dhi = digits_of(std::max(alo, ahi));
+      pd.rows = 0;
+      pd.scale = pvi.scale;
+      for (uint32_t k = 0; k < s.expr_len; ++k)
+        if (s.expr[k].kind == LLKV_TOK_COLUMN) { const ColumnInfo *ci = resolve(s.expr[k].field_id); if (ci) pd.rows = std::max(pd.rows, ci->rows); }
+      pending_digits.push_back(pd);
     }
     if (s.kind == LLKV_AGG_COUNT || s.kind == LLKV_AGG_COUNT_NULLS) {
       // NULL-free argument: COUNT(x) = rows, COUNT_NULLS(x) = 0
@@ -1404,6 +1563,26 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       p.aggs.push_back(o);
       continue;
     }
+    if (pvi.is_decimal) {
+      // Decimal128 accumulators over the computed argument's 64-bit image; precision = digits of the group's first non-NULL
+      // value (filled in at finalize from the FirstDigits lane), scale = the expression's
+      o.precision = 0; o.scale = pvi.scale;
+      const u128 m = (u128)std::max(pvi.lo < 0 ? -pvi.lo : pvi.lo, pvi.hi < 0 ? -pvi.hi : pvi.hi);
+      const uint64_t rows = pending_digits.back().rows;
+      o.fast_sum = rows != 0 && m * (u128)rows <= (u128)INT64_MAX;
+      switch (s.kind) {
+      case LLKV_AGG_SUM: case LLKV_AGG_TOTAL: case LLKV_AGG_AVG:
+        o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumDec : s.kind == LLKV_AGG_TOTAL ? AggFinal::TotalDec : AggFinal::AvgDec;
+        if (o.fast_sum) add_agg("SumI64Fast<" + node + ">", {ADD_I64});
+        else add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64});
+        break;
+      case LLKV_AGG_MIN: o.fin = AggFinal::MinDec; add_agg("MinI64<" + node + ">", {MIN_I64}); break;
+      case LLKV_AGG_MAX: o.fin = AggFinal::MaxDec; add_agg("MaxI64<" + node + ">", {MAX_I64}); break;
+      default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));
+      }
+      p.aggs.push_back(o);
+      continue;
+    }
     switch (s.kind) {
     case LLKV_AGG_SUM:
       if (is_f64) { o.fin = AggFinal::SumF64; auto g = sum_f64(node); add_agg(g.first, g.second); }
@@ -1435,6 +1614,36 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     p.aggs.push_back(o);
   }
 
+  // FirstDigits lanes: per validity, the distinct argument nodes in packs of up to four 6-bit digit fields under the row id
+  // (the key must stay below 2^63: four fields leave 39 bits for the row id, one field 57)
+  std::vector<bool> placed(pending_digits.size(), false);
+  for (size_t i = 0; i < pending_digits.size(); ++i) {
+    if (placed[i]) continue;
+    std::vector<size_t> nodes; // indices of the first pending entry of every distinct node in this pack
+    uint64_t rows = 0;
+    for (size_t j = i; j < pending_digits.size(); ++j) rows = std::max(rows, pending_digits[j].rows);
+    const size_t per_pack = rows < (1ull << 38) ? 4 : 1;
+    for (size_t j = i; j < pending_digits.size(); ++j) {
+      if (placed[j] || pending_digits[j].valid != pending_digits[i].valid) continue;
+      bool known = false;
+      for (size_t k : nodes) known |= pending_digits[k].node == pending_digits[j].node;
+      if (!known) { if (nodes.size() == per_pack) continue; nodes.push_back(j); }
+      placed[j] = true;
+    }
+    std::string g = "FirstDigits<" + pending_digits[i].valid;
+    for (size_t k : nodes) g += ",DecDigits<" + pending_digits[k].node + "," + std::to_string(pending_digits[k].dlo) + "," + std::to_string(pending_digits[k].dhi) + ">";
+    g += ">";
+    const int lane = add_group(g, {MIN_I64});
+    for (size_t j = i; j < pending_digits.size(); ++j) {
+      if (!placed[j] || pending_digits[j].valid != pending_digits[i].valid || p.aggs[pending_digits[j].agg].digits_lane >= 0) continue;
+      for (size_t at = 0; at < nodes.size(); ++at)
+        if (pending_digits[nodes[at]].node == pending_digits[j].node) {
+          p.aggs[pending_digits[j].agg].digits_lane = lane;
+          p.aggs[pending_digits[j].agg].digits_shift = 6 * (int)(nodes.size() - 1 - at);
+          p.aggs[pending_digits[j].agg].scale = pending_digits[j].scale;
+        }
+    }
+  }
   return LLKV_OK;
 }
 

@@ -71,6 +71,10 @@ struct AggOut {
   int wide_delta = 0;           // MIN / MAX over such values: one MAX_U64 lane of (v − column min) [1] or (column max − v) [2] (MaxWideDelta)
   uint64_t wide_base_hi = 0, wide_base_lo = 0; // … and that column min / max
   int32_t precision = 0, scale = 0; // Decimal128 results
+  // GROUP BY computed DECIMAL argument: lane (relative to the group's lane block) whose MIN is (first non-NULL row << 6·n |
+  // digit fields), and this argument's field — the digit count of the group's first non-NULL value is the precision of the
+  // temp column the reference builds (plan_values_to_arrow_array llkv-executor/src/lib.rs:298-330); a scale above it is an error
+  int digits_lane = -1, digits_shift = 0;
   int count_lane = -1; // nullable argument: lane holding the number of non-NULL argument rows (else the group's row lane)
   int exact_levels = 0; // f64 sum kept as exact grid-level lanes (SumF64X, 2 or 3 of them): value = smallest level first, summed
   bool fixed_point = false; // f64 sum kept as an integer count of grid steps 2^fixed_exp (SumF64Q): lanes = low 32 bits, high part

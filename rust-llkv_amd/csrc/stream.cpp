@@ -131,9 +131,18 @@ int run_selection_lowered(const Table *t, const LoweredPlan &plan, Selection *se
     p.aux_out2 = sel->d_dev;
     if ((rc = jit_launch_raw(k.fn2, ts->n_tiles, &p, sizeof p, stream))) return rc;
   }
-  // a table whose row ids are not its positions: the ids the callers report (filter_row_ids, scan windows) are the table's
-  if (t->d_row_ids) HIP_TRY(hj_launch_gather_u64_by_row(t->d_row_ids, sel->d_dev, total, sel->d_ids, stream));
+  // (d_ids are POSITIONS — what every consumer inside the library works on: window cuts, first-appearance order, sort bits;
+  // a table with its own row ids has them translated where ids are reported: selection_report_ids)
   if (sync) HIP_TRY(hipStreamSynchronize(stream)); // (the scratch blocks released on return are only handed to work on this same stream)
+  return LLKV_OK;
+}
+
+// A table whose row ids are not its positions (llkv_hip_table_set_row_ids): the ids the callers REPORT — filter_row_ids, the row-id
+// column of scan windows — are the table's; translated in place from the device row indices, after any sort of the selection.
+static int selection_report_ids(const Table *t, Selection *sel) {
+  if (!t->d_row_ids || sel->n == 0) return LLKV_OK;
+  HIP_TRY(hj_launch_gather_u64_by_row(t->d_row_ids, sel->d_dev, sel->n, sel->d_ids, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return LLKV_OK;
 }
 
@@ -232,6 +241,7 @@ llkv_status llkv_hip_filter_row_ids(const llkv_hip_table *table, const llkv_filt
   Selection sel;
   int rc = run_selection(reinterpret_cast<const Table *>(table), filters, n_filters, ops, n_ops, &sel);
   if (rc) return (llkv_status)rc;
+  if ((rc = selection_report_ids(reinterpret_cast<const Table *>(table), &sel))) return (llkv_status)rc;
   bool large = sel.n * 8 >= (1u << 20);
   uint64_t *ids = large ? (uint64_t *)result_acquire(sel.n * 8) : nullptr;
   if (!ids) { // small, or no pinned memory to be had: pageable memory through the staging lanes
@@ -284,6 +294,7 @@ llkv_status llkv_hip_scan_stream(const llkv_hip_table *table, const llkv_project
   if ((rc = run_selection(t, filters, n_filters, ops, n_ops, &sel, gathered.data(), (uint32_t)gathered.size()))) return (llkv_status)rc;
   if (sel.n == 0) return LLKV_OK; // a filter that matches nothing yields no batch
   if (options && options->order_enabled && (rc = sort_selection(t, options, &sel))) return (llkv_status)rc;
+  if (options && options->include_row_ids && (rc = selection_report_ids(t, &sel))) return (llkv_status)rc;
   JitKernel k;
   if ((rc = jit_compile(JitKind::Project, proj.type_string, &k, &err))) return (llkv_status)set_error(rc, err);
 

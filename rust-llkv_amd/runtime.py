@@ -299,8 +299,9 @@ class HipTable:
         check(lib().llkv_hip_table_set_row_ids(self._h, ptrs, C.c_uint32(len(chunks))))
 
     def append_decimal128_column(self, field_id: int, precision: int, scale: int, values, valid=None):
-        """Stage a Decimal128(precision, scale) column from Python ints (raw values) or an (n, 2) uint64 buffer."""
-        buf = values if isinstance(values, np.ndarray) and values.ndim == 2 else abi.i128_buffer(values)
+        """Stage a Decimal128(precision, scale) column from Python ints (raw values), an int64 array of raw values or an (n, 2) uint64 buffer."""
+        buf = values if isinstance(values, np.ndarray) and values.ndim == 2 else \
+            abi.i128_buffer_from_i64(values) if isinstance(values, np.ndarray) and values.dtype == np.int64 else abi.i128_buffer(values)
         chunks = [np.ascontiguousarray(c) for c in self._split(buf)]
         ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
         check(lib().llkv_hip_table_append_decimal128_column(self._h, C.c_uint32(field_id), C.c_int32(precision), C.c_int32(scale),

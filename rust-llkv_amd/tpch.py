@@ -83,6 +83,27 @@ def gen_lineitem(rows: int, scale: float, columns: Optional[Sequence[str]] = Non
     return out
 
 
+# The reference's own TPC-H DDL declares the money columns DECIMAL(15,2) (the dss.ddl its harness installs, llkv-tpch/src/
+# lib.rs:154,1027-1091: values parsed into PlanValue::Decimal at the column's scale): the same synthetic rows with those four
+# columns as Decimal128(15, 2) raw values — quantity · 100, prices in cents, discount and tax in hundredths.
+DECIMAL_MONEY = ("l_quantity", "l_extendedprice", "l_discount", "l_tax")
+DECIMAL_PRECISION, DECIMAL_SCALE = 15, 2
+
+
+def lineitem_as_decimal(data: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """`gen_lineitem` output with the DECIMAL_MONEY columns replaced by their int64 raw values at scale 2 (exact: the generator
+    makes every float as cents / 100.0)."""
+    out = dict(data)
+    for name in DECIMAL_MONEY:
+        if name in out:
+            out[name] = np.rint(out[name] * 100.0).astype(np.int64) if out[name].dtype != np.int64 else out[name] * 100
+    return out
+
+
+def lineitem_dtype(name: str, decimal: bool = False) -> int:
+    return abi.DT_DECIMAL128 if decimal and name in DECIMAL_MONEY else LINEITEM_SCHEMA[name][1]
+
+
 def gen_orders(rows: int, scale: float, row_begin: int = 0, seed: int = SEED, threads: int = 0) -> Dict[str, np.ndarray]:
     out = {n: np.empty(rows, dtype=_NP[ORDERS_SCHEMA[n][1]]) for n in ORDERS_SCHEMA}
     gen_lib().llkv_tpch_gen_orders(seed, scale, row_begin, rows, _ptr(out["o_orderkey"]), _ptr(out["o_custkey"]),
@@ -163,10 +184,11 @@ def q1() -> QueryPlan:
 QUERIES = {"c1": c1, "q6": q6, "q1": q1}
 
 
-def lineitem_column_descs(rows: int, keep: list):
+def lineitem_column_descs(rows: int, keep: list, decimal: bool = False):
     """llkv_column_desc[] for plan lowering without data: statistics and dictionaries as
     staging discovers them on the synthetic data (quantity 1..50; flags in first-appearance
-    order N/R/A and O/F)."""
+    order N/R/A and O/F).  `decimal`: the DECIMAL(15,2) form of the money columns with the
+    statistics of their SF10 raw values."""
     descs = (abi.CColumnDesc * len(LINEITEM_SCHEMA))()
     dicts = {"l_returnflag": [b"N", b"R", b"A"], "l_linestatus": [b"O", b"F"]}
     stats = {"l_quantity": (1, 50), "l_linenumber": (1, 7), "l_shipdate": (8036, 10561)}
@@ -175,6 +197,10 @@ def lineitem_column_descs(rows: int, keep: list):
         d.field_id, d.dtype, d.rows = fid, dt, rows
         if name in stats:
             d.has_stats, d.min_i, d.max_i = 1, stats[name][0], stats[name][1]
+        if decimal and name in DECIMAL_MONEY:
+            dstats = {"l_quantity": (100, 5000), "l_extendedprice": (90091, 10494950), "l_discount": (0, 10), "l_tax": (0, 8)}
+            d.dtype, d.precision, d.scale = abi.DT_DECIMAL128, DECIMAL_PRECISION, DECIMAL_SCALE
+            d.has_stats, d.min_i, d.max_i = 1, dstats[name][0], dstats[name][1]
         if name in dicts:
             arr = (C.c_char_p * len(dicts[name]))(*dicts[name])
             keep.append(arr)

@@ -639,6 +639,20 @@ def test_row_ids_with_gaps_are_reported_as_the_tables_ids(rt, orc, abi, chunks):
                 assert all((x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)) for x, y in zip(a, b))
         # what reports no ids is untouched
         assert_values(rt.aggregate(ht, p, [A.count_star(), A.sum(1), A.min(1)]), orc.aggregate(ot, p, [A.count_star(), A.sum(1), A.min(1)]))
+    # GROUP BY on the sort-based route (sparse keys) orders its groups by the first POSITION of each — not by the table's ids,
+    # which here exceed the row count the sort's key bits are sized from: first-appearance and key order, as over a dense table
+    sparse = (rng.integers(0, 40, size=n) * 1_000_003).astype(np.int64)
+    hs, os_ = stage_both(rt, orc, abi, [(1, abi.DT_INT64, i64), (2, abi.DT_FLOAT64, f64), (6, abi.DT_INT64, sparse)], chunks)
+    hs.set_row_ids(ids)
+    for ordered in (False, True):
+        pq = rt.PreparedQuery(hs, None, [A.count_star(), A.sum(1), A.min(2)], [6], ordered)
+        note = pq.route_note
+        pq.close()
+        assert note.startswith("sort-based"), note
+        g, w = rt.groupby(hs, None, [6], [A.count_star(), A.sum(1), A.min(2)], ordered), orc.groupby(os_, None, [6], [A.count_star(), A.sum(1), A.min(2)], ordered)
+        assert [[k.value for k in r.keys] for r in g] == [[k.value for k in r.keys] for r in w], ordered
+        for a, b in zip(g, w):
+            assert_values(a.values, b.values, "sort-based GROUP BY over row ids with gaps")
     # dense ids from 0 keep nothing; ids that do not ascend are refused
     hd = rt.HipTable(1, chunks)
     hd.append_column(1, abi.DT_INT64, i64)
@@ -678,6 +692,17 @@ def test_joins_over_tables_whose_row_ids_have_gaps(rt, orc, abi):
     with pytest.raises(abi.LlkvError) as e:
         rt.join_stream(hl, hr, [(1, 1)])
     assert e.value.kind == "Unsupported" and "row ids" in e.value.message
+    # the Cartesian product cuts both scans into 65 536-entry windows of the row-id LIST (llkv-scan/src/execute.rs via stream_row_ids:
+    # by position, not by id value): 70 000 × 3 rows with ids far apart give the dense table's batches, in its order
+    nl2, nr2 = 70000, 3
+    a, b = rng.integers(0, 100, size=nl2).astype(np.int64), np.arange(nr2, dtype=np.int64)
+    hl2, ol2 = stage_both(rt, orc, abi, [(1, abi.DT_INT64, a)], [nl2])
+    hr2, or2 = stage_both(rt, orc, abi, [(1, abi.DT_INT64, b)], [nr2])
+    hl2.set_row_ids((np.arange(nl2, dtype=np.uint64) * np.uint64(7)) + np.uint64(2**33))
+    hr2.set_row_ids(np.array([5, 70000, 2**35], dtype=np.uint64))
+    got = rt.join_stream_batches(hl2, hr2, [], [(1, "a")], [(1, "b")], join_type=abi.JOIN_INNER)
+    want = orc.hash_join_batches(ol2, or2, [], [(1, "a")], [(1, "b")], join_type=abi.JOIN_INNER)
+    assert [gn for gn, _ in got] == [wn for wn, _ in want] and [gc for _, gc in got] == [wc for _, wc in want]
 
 
 @pytest.mark.parametrize("chunks", [[9], [4096, 4097, 5], [65536, 70000]])

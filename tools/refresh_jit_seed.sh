@@ -15,7 +15,7 @@ case "${1:-}" in
     cd "$ROOT" && LLKV_HIP_NO_JIT_SEED=1 LLKV_HIP_CACHE_DIR="$ROOT/gpurun_out/jit_cache" python3 -m pytest tests -m gpu -q -x
     ls "$ROOT/gpurun_out/jit_cache" | wc -l ;;
   install)
-    rm -rf "$ROOT/rust-llkv_amd/jit_seed"; mkdir -p "$ROOT/rust-llkv_amd/jit_seed"
+    rm -rf "$ROOT/rust-llkv_amd/jit_seed"; mkdir -p "$ROOT/rust-llkv_amd/jit_seed"; chmod 755 "$ROOT/rust-llkv_amd/jit_seed" # (csrc/jit.cpp: trusted_dir)
     for f in "$ROOT"/gpurun_out/jit_cache/*.hsaco; do # only code objects that carry their identity (csrc/jit.cpp: kBlobMagic): leftovers of older runs stay behind
       [ "$(tail -c 8 "$f")" = "LLKVJIT1" ] && cp "$f" "$ROOT/rust-llkv_amd/jit_seed/"
     done
