@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: strong = one SF table sharded over the ranks (BASELINE configs[3]); weak = one SF shard per rank")
     ap.add_argument("--dry-run-layout", action="store_true", help="no GPU: gloo rendezvous, shard layout per rank, exit")
+    ap.add_argument("--dry-run-comm-failure", type=int, default=-1, help="with --dry-run-layout: this rank pretends it could not join the communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the workload timed on the CPU oracle (0 = auto)")
     ap.add_argument("--also", default="q6_sf10,q6_sf1,q3_sf10,q1_sf10_decimal", help="extra workloads reported under 'also' (N>1: q1 weak, q6_sf10 and q3_sf10 sharded)")
@@ -98,7 +99,7 @@ PROFILE_EVERY = 4
 DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i while the GPU runs i+1..)
 
 
-def run_steps(q, steps, stream_ptr, comm_stream_ptr):
+def run_steps(q, steps, stream_ptr, comm_stream_ptr, comm_stream=None, allreduce_events=None):
     """K complete executions; every result is folded and finalized on the host inside the timed region.
     Steady state = one kernel per execution on the compute stream (the scan of execution i folds the tile
     partials of i-1); with several ranks the RCCL all-reduce of an execution's exchange image (inside the library:
@@ -108,7 +109,16 @@ def run_steps(q, steps, stream_ptr, comm_stream_ptr):
 
     def exchange(slot):
         if comm_stream_ptr:
+            # every 4th all-reduce of a timed region is bracketed by events on the communication stream (`collective.allreduce_us`)
+            timed = allreduce_events is not None and comm_stream is not None and (submitted % PROFILE_EVERY) == 0
+            if timed:
+                import torch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(comm_stream)
             q.all_reduce(comm_stream_ptr)
+            if timed:
+                e1.record(comm_stream)
+                allreduce_events.append((e0, e1))
             q.submit(comm_stream_ptr)
         else:
             q.submit(0)
@@ -152,19 +162,33 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     comm = torch.cuda.Stream() if (world > 1 or os.environ.get("LLKV_BENCH_FORCE_COLLECTIVE")) else None
     comm_ptr = comm.cuda_stream if comm is not None else 0
     run_steps(q, warmup, stream_ptr, comm_ptr)
+    ar_events = [] if comm is not None else None
     # HIP events around every 4th scan kernel of the timed region (every one when the region is only a few steps long)
     q.set_profiling(PROFILE_EVERY if steps >= 4 * PROFILE_EVERY else 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows = run_steps(q, steps, stream_ptr, comm_ptr)
+    rows = run_steps(q, steps, stream_ptr, comm_ptr, comm, ar_events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern_ms, launches, kname = q.kernel_time()
     q.set_profiling(False)
+    collective = None
+    if comm is not None:
+        backend, ranks = rt.comm_describe()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in ar_events)
+        collective = {"backend": backend, "ranks": ranks, "bytes_per_step": int(q.exchange_buffer()[1]) * 8,
+                      "allreduce_us": us[len(us) // 2] if us else None, "allreduce_samples": len(us),
+                      "what": "one all-reduce (int64 sum) of the exchange image [8 octants][lanes] per execution, on the communication stream, "
+                              "one execution behind the scan; median of event-bracketed samples on rank 0"}
+    kernel_ms_by_rank = [kern_ms / max(1, launches)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, kernel_ms_by_rank[0])
+        kernel_ms_by_rank = gathered
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,6 +198,7 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
         "seconds": dt, "total_rows": total_rows, "local_rows": table.local_rows,
         "kernel_ms_avg": kern_ms / max(1, launches), "kernel_launches": launches, "kernel_name": kname,
         "alg_bytes_local": q.algorithmic_bytes, "signature": q.kernel_signature,
+        "collective": collective, "kernel_ms_by_rank": kernel_ms_by_rank,
     }
     return res
 
@@ -435,6 +460,19 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def require_all_ranks(torch, dist, ok, why, rank, device):
+    """A measurement has no fallback transport: every rank learns whether ALL of them joined the library's RCCL communicator, and
+    all of them leave with exit code 3 otherwise (LLKV_BENCH_HOST_TRANSPORT=1 is the rehearsal on one device, and says so in its
+    line).  `device`: where the agreement tensor lives ("cuda" over nccl; "cpu" in the gloo rehearsal of this very path)."""
+    agreed = torch.tensor([1 if ok else 0], device=device)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+    if int(agreed.item()) == 0:
+        sys.stderr.write(f"bench.py rank {rank}: the library's RCCL communicator could not be created"
+                         + (f" ({why})" if why else " on another rank") + " — no measurement without it\n")
+        dist.destroy_process_group()
+        raise SystemExit(3)
+
+
 def workload_chunks(tpch, name, scaling, world):
     """(global chunk list, table rows, generator scale) of a lineitem workload under a scaling mode."""
     qname, sf, _ = split_workload(name)
@@ -458,6 +496,11 @@ def dry_run_layout(args, rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.dry_run_comm_failure >= 0 and world > 1:
+        # rehearsal of the measurement's "no fallback" rule over gloo: the named rank pretends its ncclCommInitRank failed
+        import torch
+        failed = rank == args.dry_run_comm_failure
+        require_all_ranks(torch, dist, not failed, "rehearsed failure" if failed else "", rank, "cpu")
     chunks, total_rows, _ = workload_chunks(tpch, args.workload, args.scaling, world)
     table = rt.HipTable(1, chunks, rank, world)
     begin, owner = dmod.shard_layout(rt.lib(), len(chunks), world)
@@ -527,17 +570,12 @@ def main():
         ok, why = 1, ""
         try:
             rt.comm_init(uid[0], rank, world)
-        except Exception as e:  # every rank must take the same road: agree, then fall back together
+            backend, ranks = rt.comm_describe()
+            if backend != "rccl" or ranks != world:
+                ok, why = 0, f"the communicator reports backend {backend} with {ranks} ranks, {world} were launched"
+        except Exception as e:
             ok, why = 0, str(e)
-        agreed = torch.tensor([ok], device="cuda")
-        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) == 0:
-            try:
-                rt.comm_destroy()
-            except Exception:
-                pass
-            rt.comm_init_torch(dist, rank, world, group=dist.new_group(backend="gloo"))
-            collective_backend = "host transport over gloo (the library's RCCL communicator could not be created" + (": " + why if why else " on another rank") + ")"
+        require_all_ranks(torch, dist, ok, why, rank, "cuda")
 
     main_res = measure(rt, tpch, abi, torch, dist, args.workload, rank, world, args.scaling, args.steps, args.warmup, stage_twice=True)
     rows_total = main_res["total_rows"]
@@ -573,6 +611,10 @@ def main():
         },
         "hbm_gbs_end_to_end": main_res["query"].bytes_per_row * value / 1e9,
     }
+    if main_res.get("collective"):
+        out["collective"] = main_res["collective"]
+    if world > 1:
+        out["kernel_ms_by_rank"] = main_res["kernel_ms_by_rank"]
     if main_res.get("staging"):
         # never part of `value`: what one cold execution costs when the columns still have to cross PCIe
         st = dict(main_res["staging"])

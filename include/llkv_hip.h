@@ -392,6 +392,10 @@ llkv_status llkv_hip_table_set_column_all_finite(llkv_hip_table *table, uint32_t
  * column image — dictionary coding, bitmap expansion — is not in it).  Purely
  * informational: staging happens once per resident column, outside every query.   */
 void llkv_hip_staging_stats(uint64_t *bytes, double *seconds);
+/* Page-locked host memory of the library: bytes resting in its cache of recycled blocks (windows of scan_stream, large id vectors,
+ * exchange images; bounded by LLKV_HIP_PINNED_CACHE_MB, default 2048) and bytes handed out and not yet given back (results the
+ * caller still holds — llkv_hip_free returns them).                                                                        */
+void llkv_hip_pinned_stats(uint64_t *cached_bytes, uint64_t *outstanding_bytes);
 
 /* NULL cells of an already staged column.  In the reference a NULL cell is a row
  * id that is absent from the column's row-id shadow chunks (llkv-table/src/
@@ -896,6 +900,9 @@ llkv_status llkv_hip_comm_init_custom(const llkv_comm_transport *transport, uint
 void llkv_hip_comm_destroy(void);
 uint32_t llkv_hip_comm_rank(void);
 uint32_t llkv_hip_comm_world(void); /* 0 = no communicator */
+/* What the communicator is: backend 0 = none, 1 = RCCL, 2 = host transport; `ranks` = what the communicator itself reports
+ * (RCCL: ncclCommCount) — a benchmark line quotes these instead of what it asked for. */
+llkv_status llkv_hip_comm_describe(int32_t *backend, uint32_t *ranks);
 
 /* In-place SUM of a device buffer of int64 lanes over the ranks, ordered on `hip_stream` (RCCL: ncclAllReduce,
  * nothing blocks on the host).                                                                                   */

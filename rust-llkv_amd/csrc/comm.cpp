@@ -292,6 +292,21 @@ llkv_status llkv_hip_comm_init_custom(const llkv_comm_transport *t, uint32_t ran
   return LLKV_OK;
 }
 
+/* What the process's communicator is, for a measurement to verify itself: backend 0 none / 1 RCCL / 2 host transport, and the
+ * number of ranks the communicator itself reports (RCCL: ncclCommCount — not what the caller passed in). */
+llkv_status llkv_hip_comm_describe(int32_t *backend, uint32_t *ranks) {
+  std::lock_guard<std::mutex> lk(g_comm.mu);
+  if (backend) *backend = !g_comm.ready ? 0 : g_comm.custom ? 2 : 1;
+  if (ranks) *ranks = 0;
+  if (!g_comm.ready) return LLKV_OK;
+  if (g_comm.custom) { if (ranks) *ranks = g_comm.world; return LLKV_OK; }
+  int n = 0;
+  ncclResult_t r = ncclCommCount(g_comm.nccl, &n);
+  if (r != ncclSuccess) return (llkv_status)nccl_fail(r, "ncclCommCount");
+  if (ranks) *ranks = (uint32_t)n;
+  return LLKV_OK;
+}
+
 void llkv_hip_comm_destroy(void) {
   std::lock_guard<std::mutex> lk(g_comm.mu);
   if (!g_comm.ready) return;

@@ -305,6 +305,7 @@ int fetch_to_host(void *h_dst, const void *d_src, size_t bytes);
 void *pinned_acquire(size_t *bytes);
 void pinned_release(void *p, size_t bytes);
 void pinned_release_all();
+void pinned_stats(uint64_t *cached, uint64_t *outstanding); // bytes in the cache / handed out and not yet released
 
 // Result buffers of llkv_hip_free-able arrays: pinned (recycled) blocks for large ones; result_release returns false
 // for a pointer it did not hand out (a plain malloc).

@@ -397,6 +397,7 @@ template <class V, class... Ds> struct FirstDigits {
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
     o[0] = V::eval(c, j) ? ((c.row << (6 * sizeof...(Ds))) | pack<Ds...>(c, j)) : 0x7FFFFFFFFFFFFFFFull;
   }
+  static constexpr bool first_only(int) { return true; } // the key grows with the row id: a thread's first contribution to a group is its smallest
 };
 // Predicate form of an expression's validity.
 template <class E> struct VE {
@@ -707,6 +708,7 @@ template <class E, bool IS_MAX> struct ExtF64 {
     o[1] = (v == 0.0) ? ((c.row << 1) | (uint64_t)((uint64_t)__double_as_longlong(v) >> 63)) : 0x7FFFFFFFFFFFFFFFull;
     o[2] = (c.row << 1) | (nan ? 1u : 0u);
   }
+  static constexpr bool first_only(int k) { return k >= 1; } // lanes 1 and 2 are minima of keys that grow with the row id
 };
 template <class E> using MinF64 = ExtF64<E, false>;
 template <class E> using MaxF64 = ExtF64<E, true>;
@@ -731,9 +733,16 @@ template <class V, class E> struct CountIfE {
 // Any accumulator over an argument with NULL cells: a NULL row contributes every lane's identity (accumulators
 // skip NULLs), and one more lane counts the non-NULL
 // rows — the AVG denominator and the "no rows → NULL" test of finalize.
+// MIN lanes whose key is (row id << n | …): within one thread the keys of a group only grow, so the thread's FIRST contribution
+// to a group that is not the lane's identity is its smallest — the per-thread-column kernel skips the DS operation of every later
+// one (agg_first_only; same minimum, fewer LDS instructions per row).
+template <class A, class = void> struct AggFirstOnly { static constexpr bool at(int) { return false; } };
+template <class A> struct AggFirstOnly<A, decltype((void)A::first_only(0))> { static constexpr bool at(int k) { return A::first_only(k); } };
+
 template <class V, class A> struct IfValid {
   static constexpr int N = A::N + 1;
   static constexpr int op(int k) { return k < A::N ? A::op(k) : OP_ADD_I64; }
+  static constexpr bool first_only(int k) { return k < A::N && AggFirstOnly<A>::at(k); }
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
     A::contrib(c, j, o);
     const bool v = V::eval(c, j);
@@ -796,7 +805,29 @@ template <class... As> struct AggOps<Aggs<As...>> {
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
     if constexpr (sizeof...(As) > 0) contrib_all<As...>(c, j, o);
   }
+  template <class A0, class... Ar> static constexpr bool first_only_at(int k) {
+    if (k < A0::N) return AggFirstOnly<A0>::at(k);
+    if constexpr (sizeof...(Ar) > 0) return first_only_at<Ar...>(k - A0::N);
+    else return false;
+  }
+  static constexpr bool first_only(int k) {
+    if constexpr (sizeof...(As) == 0) return false;
+    else return first_only_at<As...>(k);
+  }
 };
+
+// Lane k of a group's block (0 ≤ k < K): a MIN over keys that grow with the row id (the first-row lane, FirstDigits, the
+// first-row / first-zero lanes of the f64 MIN / MAX)?
+template <class P> constexpr bool plan_lane_first_only(int k) {
+  if (k == 0) return false;
+  if (P::first && k == 1) return true;
+  return AggOps<typename P::AggT>::first_only(k - P::BASE);
+}
+template <class P> constexpr int plan_first_only_index(int k) { // how many such lanes sit before lane k
+  int n = 0;
+  for (int i = 0; i < k; ++i) n += plan_lane_first_only<P>(i) ? 1 : 0;
+  return n;
+}
 
 template <class P> constexpr int plan_lane_op(int lane) {
   if (lane == P::NG * P::K) return OP_MAX_U64; // error lane
@@ -1066,10 +1097,20 @@ template <int OP> __device__ __forceinline__ void lds_accumulate(uint64_t *slot,
     (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned long long *>(slot), (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <class P, int K0 = 0> __device__ __forceinline__ void lds_accumulate_row(uint64_t *group_base, const uint64_t *contrib) {
+// `seen[i]`: bit g set = this thread has already given first-only lane i of group g a value in this tile
+template <class P, int K0 = 0> __device__ __forceinline__ void lds_accumulate_row(uint64_t *group_base, const uint64_t *contrib, uint32_t gid, uint64_t *seen) {
   if constexpr (K0 < P::K) {
-    lds_accumulate<plan_lane_op<P>(K0)>(group_base + K0 * kBlock, contrib[K0]);
-    lds_accumulate_row<P, K0 + 1>(group_base, contrib);
+    if constexpr (plan_lane_first_only<P>(K0)) {
+      constexpr int i = plan_first_only_index<P>(K0);
+      const uint64_t bit = 1ull << gid;
+      if (!(seen[i] & bit) && contrib[K0] != lane_identity_s<plan_lane_op<P>(K0)>()) {
+        lds_accumulate<plan_lane_op<P>(K0)>(group_base + K0 * kBlock, contrib[K0]);
+        seen[i] |= bit;
+      }
+    } else {
+      lds_accumulate<plan_lane_op<P>(K0)>(group_base + K0 * kBlock, contrib[K0]);
+    }
+    lds_accumulate_row<P, K0 + 1>(group_base, contrib, gid, seen);
   }
 }
 
@@ -1188,6 +1229,9 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
 #pragma unroll
   for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
   uint32_t err = 0, done_err = 0, done_tile = 0;
+  constexpr int n_first_only = plan_first_only_index<P>(K);
+  static_assert(n_first_only == 0 || NG <= 64, "the first-only masks hold one bit per group");
+  uint64_t seen[n_first_only > 0 ? n_first_only : 1] = {};
   bool fresh = false; // the image holds a finished tile that awaits its reduction
   // (Measured, r03: requesting the NEXT group of U steps before this one is accumulated — a second Loaded[U], free in
   // registers at two waves per SIMD — is slower here: Q1 0.359 → 0.370 ms, the 12-lane state 0.338 → 0.368 ms; the
@@ -1207,6 +1251,8 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
       wave_reduce_image<P>(p, acc, wave, wl, done_tile * kLdsParts + wave, n_parts, done_err);
 #pragma unroll
       for (int l = 0; l < NG * K; ++l) acc[l][tid] = lane_identity(ops.v[l]);
+#pragma unroll
+      for (int i = 0; i < (n_first_only > 0 ? n_first_only : 1); ++i) seen[i] = 0;
       fresh = false;
     }
 #pragma unroll
@@ -1224,7 +1270,7 @@ template <class P> __device__ __forceinline__ void fused_scan_body_lds(const Sca
         if constexpr (P::first) contrib[1] = c.row;
         AggOps<typename P::AggT>::contrib(c, j, contrib + P::BASE);
         err |= (pass ? c.err : 0u) | (in_tile ? c.perr : 0u);
-        if (pass) lds_accumulate_row<P>(&acc[gid * K][tid], contrib);
+        if (pass) lds_accumulate_row<P>(&acc[gid * K][tid], contrib, gid, seen);
       }
     }
     s += U;

@@ -320,46 +320,80 @@ void staging_prime() {
 }
 
 // ---- pinned host memory cache -------------------------------------------------------
+// Blocks up to 256 MB come in power-of-two classes; larger ones (the 480 MB id vector of an unselective filter_row_ids at SF10)
+// are sized to 2 MB multiples and recycled too, best fit within a quarter of the request — hipHostMalloc + hipHostFree of such a
+// block cost ~35 ms, four times the copy that fills it (profiles/r03/scan_bench.json: 44.6 ms for 480 MB) — all under one byte
+// budget (LLKV_HIP_PINNED_CACHE_MB, default 2048).
 namespace {
 constexpr size_t kPinnedClassLimit = 256u << 20;
 struct PinnedCache {
   std::mutex mu;
   std::vector<std::pair<void *, size_t>> free_blocks;
   size_t cached = 0;
-  static constexpr size_t kMaxCached = 1ull << 30;
+  size_t outstanding = 0; // bytes handed out and not yet released
+  size_t budget() {
+    static const size_t b = [] {
+      const char *e = std::getenv("LLKV_HIP_PINNED_CACHE_MB");
+      const long mb = e ? std::atol(e) : 2048;
+      return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return b;
+  }
 } g_pinned;
 } // namespace
 
 void *pinned_acquire(size_t *bytes) {
   size_t want = 4096;
-  if (*bytes > kPinnedClassLimit) want = (*bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20); // huge: exact size, never cached
+  const bool huge = *bytes > kPinnedClassLimit;
+  if (huge) want = (*bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);
   else while (want < *bytes) want <<= 1; // power-of-two classes: a block fits every later request of its class
-  *bytes = want;
   {
     std::lock_guard<std::mutex> lk(g_pinned.mu);
-    for (size_t i = 0; i < g_pinned.free_blocks.size(); ++i)
-      if (g_pinned.free_blocks[i].second == want) {
-        void *p = g_pinned.free_blocks[i].first;
-        g_pinned.free_blocks.erase(g_pinned.free_blocks.begin() + (long)i);
-        g_pinned.cached -= want;
-        return p;
+    size_t best = g_pinned.free_blocks.size();
+    for (size_t i = 0; i < g_pinned.free_blocks.size(); ++i) {
+      const size_t have = g_pinned.free_blocks[i].second;
+      if (huge ? (have >= want && have <= want + want / 4 && (best == g_pinned.free_blocks.size() || have < g_pinned.free_blocks[best].second)) : have == want) {
+        best = i;
+        if (!huge) break;
       }
+    }
+    if (best != g_pinned.free_blocks.size()) {
+      void *p = g_pinned.free_blocks[best].first;
+      *bytes = g_pinned.free_blocks[best].second;
+      g_pinned.free_blocks.erase(g_pinned.free_blocks.begin() + (long)best);
+      g_pinned.cached -= *bytes;
+      g_pinned.outstanding += *bytes;
+      return p;
+    }
   }
+  *bytes = want;
   void *p = nullptr;
-  if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+    pinned_release_all(); // the cache may be what stands in the way: give it back and try once more
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_pinned.mu);
+  g_pinned.outstanding += want;
   return p;
 }
 
 void pinned_release(void *p, size_t bytes) {
   {
     std::lock_guard<std::mutex> lk(g_pinned.mu);
-    if (bytes <= kPinnedClassLimit && g_pinned.cached + bytes <= PinnedCache::kMaxCached) {
+    g_pinned.outstanding -= std::min(bytes, g_pinned.outstanding);
+    if (g_pinned.cached + bytes <= g_pinned.budget()) {
       g_pinned.free_blocks.emplace_back(p, bytes);
       g_pinned.cached += bytes;
       return;
     }
   }
   (void)hipHostFree(p);
+}
+
+void pinned_stats(uint64_t *cached, uint64_t *outstanding) {
+  std::lock_guard<std::mutex> lk(g_pinned.mu);
+  if (cached) *cached = g_pinned.cached;
+  if (outstanding) *outstanding = g_pinned.outstanding;
 }
 
 void pinned_release_all() {

@@ -502,6 +502,8 @@ llkv_status llkv_hip_table_local_column_stats(const llkv_hip_table *table, uint3
   return LLKV_OK;
 }
 
+void llkv_hip_pinned_stats(uint64_t *cached_bytes, uint64_t *outstanding_bytes) { pinned_stats(cached_bytes, outstanding_bytes); }
+
 void llkv_hip_staging_stats(uint64_t *bytes, double *seconds) {
   staging_totals(bytes, seconds);
 }

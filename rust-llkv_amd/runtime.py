@@ -86,6 +86,13 @@ def staging_stats():
     return b.value, t.value
 
 
+def pinned_stats():
+    """(cached, outstanding) bytes of the library's page-locked host memory: resting in its block cache / held by results."""
+    c, o = C.c_uint64(), C.c_uint64()
+    lib().llkv_hip_pinned_stats(C.byref(c), C.byref(o))
+    return c.value, o.value
+
+
 def shutdown():
     global _bound_device
     lib().llkv_hip_shutdown()
@@ -162,6 +169,13 @@ def comm_world() -> int:
     f = lib().llkv_hip_comm_world
     f.restype = C.c_uint32
     return int(f())
+
+
+def comm_describe():
+    """(backend, ranks): 'none' / 'rccl' / 'host transport', and the rank count the communicator itself reports (ncclCommCount)."""
+    b, r = C.c_int32(), C.c_uint32()
+    check(lib().llkv_hip_comm_describe(C.byref(b), C.byref(r)))
+    return {0: "none", 1: "rccl", 2: "host transport"}[b.value], r.value
 
 
 def comm_all_reduce_i64(device_ptr: int, n: int, stream: int = 0):

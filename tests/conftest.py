@@ -138,12 +138,28 @@ def build_aggs(abi, specs):
     return out
 
 
+def column_values(c):
+    """The cells of a fixture column: `values` as written, or `values_blocks` expanded — {range: n} = 0 … n−1, {value: v} = v
+    (None = a NULL cell), {blocks: […]} nested — each repeated `times` times, in order (the SLT tables of hundreds of thousands
+    of rows, transcribed as the statements that built them)."""
+    if "values" in c:
+        return c["values"]
+
+    def expand(blocks):
+        out = []
+        for b in blocks:
+            one = list(range(b["range"])) if "range" in b else expand(b["blocks"]) if "blocks" in b else [b["value"]]
+            out += one * b.get("times", 1)
+        return out
+    return expand(c["values_blocks"])
+
+
 def oracle_table(orc, abi, columns, rows=None):
-    rows = len(columns[0]["values"]) if rows is None else rows
+    rows = len(column_values(columns[0])) if rows is None else rows
     t = orc.OracleTable(rows)
     for c in columns:
         dt = DTYPES[c["dtype"]]
-        vals = [fval(v) for v in c["values"]]
+        vals = [fval(v) for v in column_values(c)]
         valid = None
         if any(v is None for v in vals):
             valid = [v is not None for v in vals]

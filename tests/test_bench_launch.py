@@ -47,3 +47,15 @@ def test_weak_scaling_gives_every_rank_an_sf10_shard():
 def test_one_rank_needs_no_launcher():
     doc = _dry_run()
     assert doc["n_gpus"] == 1 and doc["ranks"][0]["local_rows"] == 59986052 and doc["ranks"][0]["octants"] == list(range(8))
+
+
+def test_a_rank_without_the_communicator_ends_every_rank_with_a_nonzero_code():
+    """No fallback transport in a measurement: if ncclCommInitRank fails on ANY rank, all ranks agree (an all-reduce of the
+    outcome) and leave with exit code 3 — rehearsed over gloo with rank 1 pretending; nothing is printed as a result."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-layout", "--gpus", "2", "--dry-run-comm-failure", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "rank 0: the library's RCCL communicator could not be created on another rank" in p.stderr
+    assert "rank 1: the library's RCCL communicator could not be created (rehearsed failure)" in p.stderr
