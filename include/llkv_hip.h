@@ -856,6 +856,58 @@ llkv_status llkv_hip_join_agg_finish_ranged(llkv_hip_join_agg *h, const void *bl
                                             uint32_t *out_n, uint64_t *out_groups /* groups this rank reports */);
 
 /* ------------------------------------------------------------------------- */
+/* Join → GROUP BY with ANY aggregate list — the general form of the star shape    */
+/* above (execute_group_by_from_batches llkv-executor/src/lib.rs:4544-4755 over     */
+/* the batches of try_execute_hash_join :3780-4052; ORDER BY :13762-13868,          */
+/* LIMIT :10925-10955):                                                             */
+/*   fact ⋈ dim [⋉ dim2]   GROUP BY dim.key [, payload …]                           */
+/*   COUNT(*) / COUNT / SUM / TOTAL / AVG / MIN / MAX over fact-side expressions,   */
+/*   several of them; ORDER BY any of the aggregates, the payload columns and the   */
+/*   key, ASC / DESC, NULLS FIRST / LAST; LIMIT or none.                            */
+/* `prepare` builds the key set of the qualifying dimension rows (dim.key must be   */
+/* unique among them: LLKV_UNSUPPORTED otherwise, and for key columns without a     */
+/* statistics-bounded range) and returns a prepared GROUP BY of the fact key over   */
+/* the fact rows that pass `filters AND key IN (key set)`: it runs like any other   */
+/* prepared query — llkv_hip_query_launch + llkv_hip_query_finish, or               */
+/* llkv_hip_query_finish_sharded for a fact table sharded over ranks (dimension     */
+/* tables replicated; the ranks' partial groups are merged lane by lane in rank     */
+/* order) — and its groups can be read through llkv_hip_query_group_key / _value.   */
+/* Aggregate arguments follow the GROUP BY (PlanValue) semantics, decimals          */
+/* included.  `rows` looks every group's dimension row up (payload cells: integer / */
+/* Date32 columns of dim), applies ORDER BY — ties broken by the dimension row's    */
+/* position, so every rank count gives the same rows — and LIMIT (UINT64_MAX: all). */
+/* llkv_hip_join_groupby_topk stays the hand-tuned form of the single-SUM shape.    */
+/* ------------------------------------------------------------------------- */
+typedef enum llkv_join_order_kind {
+  LLKV_JOIN_ORDER_AGGREGATE = 0, /* index = position in the aggregate list */
+  LLKV_JOIN_ORDER_PAYLOAD = 1,   /* index = position in the payload list   */
+  LLKV_JOIN_ORDER_KEY = 2        /* the group key (dim.key)                */
+} llkv_join_order_kind;
+
+typedef struct llkv_join_order_key {
+  int32_t kind;  /* llkv_join_order_kind */
+  uint32_t index;
+  int32_t descending;
+  int32_t nulls_first;
+} llkv_join_order_key;
+
+typedef struct llkv_hip_join_rows llkv_hip_join_rows;
+
+llkv_status llkv_hip_join_groupby_prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field,
+                                          const llkv_join_side *dim2 /* may be NULL */, const llkv_aggregate_spec *aggs,
+                                          uint32_t n_aggs, llkv_hip_query **out);
+llkv_status llkv_hip_join_groupby_rows(llkv_hip_query *query, const uint32_t *payload_fields, uint32_t n_payload,
+                                       const llkv_join_order_key *order, uint32_t n_order, uint64_t limit,
+                                       llkv_hip_join_rows **out);
+uint64_t llkv_hip_join_rows_len(const llkv_hip_join_rows *rows);
+uint64_t llkv_hip_join_rows_total_groups(const llkv_hip_join_rows *rows); /* groups before LIMIT */
+/* Row i: the group key, payload[n_payload] (+ payload_is_null), the dimension row's position among the qualifying rows, and a
+ * pointer to its n_aggs finalized cells (owned by `rows`).  Any output pointer may be NULL.                                */
+llkv_status llkv_hip_join_rows_get(const llkv_hip_join_rows *rows, uint64_t i, int64_t *key, int64_t *payload,
+                                   uint8_t *payload_is_null, uint64_t *group_index, const llkv_value **values);
+void llkv_hip_join_rows_free(llkv_hip_join_rows *rows);
+
+/* ------------------------------------------------------------------------- */
 /* Multi-GPU combine, host pieces (no device needed).  The chunk list is cut    */
 /* into 8 canonical octants (boundaries floor(j·C/8)); rank r of `world` owns   */
 /* octants [r·8/world, (r+1)·8/world).  Partial aggregate state is exchanged    */

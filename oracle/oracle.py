@@ -81,10 +81,12 @@ class OracleTable:
         self.rows = rows
         self._cols: List[COrcColumn] = []
         self._keep: list = []
+        self._added: dict = {}  # field id → the arguments of add(): join_groupby gathers a joined table from them
 
     def add(self, field_id: int, dtype: int, values, valid: Optional[Sequence[bool]] = None, precision: int = 0, scale: int = 0):
         c = COrcColumn()
         c.field_id, c.dtype = field_id, dtype
+        self._added[field_id] = (dtype, values, valid, precision, scale)
         if dtype == abi.DT_DECIMAL128:  # Python ints (or an int64 array of raw values) → 16-byte little-endian raw values
             arr = values if isinstance(values, np.ndarray) and values.ndim == 2 else \
                 abi.i128_buffer_from_i64(values) if isinstance(values, np.ndarray) and values.dtype == np.int64 else abi.i128_buffer(values)
@@ -286,3 +288,95 @@ def hash_join_batches(left: OracleTable, right: OracleTable, keys, left_columns,
     check(lib().orc_hash_join_batches(C.byref(lt), C.byref(rt), ck, C.c_uint32(len(keys)), C.byref(opts), C.byref(out), cb, None))
     del keep
     return batches
+
+
+def _gathered(table: OracleTable, rows: np.ndarray) -> OracleTable:
+    """The rows ``rows`` of every column of ``table`` (the joined batches' fact side, in row order)."""
+    out = OracleTable(len(rows))
+    idx = rows.astype(np.int64)
+    for fid, (dtype, values, valid, precision, scale) in table._added.items():
+        if dtype == abi.DT_UTF8 and not (isinstance(values, np.ndarray) and values.dtype == np.uint8):
+            vals = [values[i] for i in idx]
+        else:
+            vals = np.asarray(values, dtype=object if dtype == abi.DT_DECIMAL128 and not isinstance(values, np.ndarray) else None)[idx]
+            if dtype == abi.DT_DECIMAL128 and vals.dtype == object:
+                vals = [int(v) for v in vals]
+        out.add(fid, dtype, vals, None if valid is None else [bool(valid[i]) for i in idx], precision, scale)
+    return out
+
+
+def _cells(table: OracleTable, field_id: int):
+    """(values, valid) of an integer column as Python lists (None-free values; valid = None when the column has no NULL cell)."""
+    dtype, values, valid, _, _ = table._added[field_id]
+    return np.asarray(values), (None if valid is None else np.asarray(valid, dtype=bool))
+
+
+def join_groupby(fact: OracleTable, fact_filters, fact_key: int, dim: OracleTable, dim_filters, dim_key: int, aggs, payload_fields=(), order=(),
+                 limit=None, dim_fk: int = 0, dim2: Optional[OracleTable] = None, dim2_filters=(), dim2_key: int = 0):
+    """fact ⋈ dim [⋉ dim2] GROUP BY dim key [, payload …] — the executor's multi-table route restated over this oracle's pieces:
+    the inner joins keep the fact rows that pass their filters and whose key is the key of a dimension row that passes its own
+    (and, with dim2, whose foreign key is among dim2's qualifying keys: NULL keys match nothing, llkv-executor/src/lib.rs:
+    12491-12494,12554-12556); execute_group_by_from_batches (:4544-4755) then groups the joined rows — a group's rows arrive in
+    fact scan order whichever side was the build side — and runs the reference's accumulators over them (orc_groupby: the
+    PlanValue argument semantics and accumulators of the single-table GROUP BY, which that function shares); non-key output
+    columns take the group's (only) dimension row; ORDER BY = arrow lexsort with the keys' descending / nulls_first flags
+    (:13762-13868: floats by totalOrder), LIMIT (:10925-10955).  Ties the sort leaves open are listed in dimension row order (the
+    reference leaves them unspecified).  Returns ([(key, payload list, [Value], dim position)], total_groups)."""
+    import functools
+    import math
+    dkeys, dvalid = _cells(dim, dim_key)
+    drows = filter_row_ids(dim, list(dim_filters or []))
+    if dvalid is not None:
+        drows = drows[dvalid[drows.astype(np.int64)]]
+    if dim2 is not None:
+        k2, v2 = _cells(dim2, dim2_key)
+        r2 = filter_row_ids(dim2, list(dim2_filters or [])).astype(np.int64)
+        if v2 is not None:
+            r2 = r2[v2[r2]]
+        set2 = set(int(v) for v in k2[r2])
+        fk, fkv = _cells(dim, dim_fk)
+        di = drows.astype(np.int64)
+        keep = np.array([(fkv is None or fkv[i]) and int(fk[i]) in set2 for i in di], dtype=bool)
+        drows = drows[keep] if len(drows) else drows
+    pos_of_key = {}
+    for pos, r in enumerate(drows.astype(np.int64)):
+        k = int(dkeys[r])
+        if k in pos_of_key:
+            raise abi.LlkvError(4, "the dimension key is not unique among the qualifying rows")
+        pos_of_key[k] = (pos, int(r))
+    fkeys, fvalid = _cells(fact, fact_key)
+    frows = filter_row_ids(fact, list(fact_filters or [])).astype(np.int64)
+    joins = np.array([(fvalid is None or fvalid[i]) and int(fkeys[i]) in pos_of_key for i in frows], dtype=bool)
+    frows = frows[joins] if len(frows) else frows
+    groups = groupby(_gathered(fact, frows), None, [fact_key], aggs, True) if len(frows) else []
+    pay_cols = [_cells(dim, f) for f in payload_fields]
+    rows = []
+    for g in groups:
+        key = g.keys[0].value
+        pos, r = pos_of_key[key]
+        payload = [None if (pv is not None and not pv[r]) else int(pc[r]) for pc, pv in pay_cols]
+        rows.append((key, payload, g.values, pos))
+
+    def cell(row, o):
+        kind, index = o[0], o[1]
+        if kind == abi.JOIN_ORDER_KEY:
+            return row[0]
+        if kind == abi.JOIN_ORDER_PAYLOAD:
+            return row[1][index]
+        return row[2][index].value
+
+    def cmp(a, b):
+        for o in order:
+            desc, nulls_first = (bool(o[2]) if len(o) > 2 else False), (bool(o[3]) if len(o) > 3 else False)
+            x, y = cell(a, o), cell(b, o)
+            if x is None or y is None:
+                if (x is None) != (y is None):
+                    return -1 if ((x is None) == nulls_first) else 1
+                continue
+            xn, yn = isinstance(x, float) and math.isnan(x), isinstance(y, float) and math.isnan(y)
+            c = (0 if xn == yn else (1 if xn else -1)) if (xn or yn) else (-1 if x < y else 1 if x > y else 0)
+            if c:
+                return -c if desc else c
+        return -1 if a[3] < b[3] else 1 if a[3] > b[3] else 0
+    rows.sort(key=functools.cmp_to_key(cmp))
+    return (rows if limit is None else rows[:limit]), len(rows)

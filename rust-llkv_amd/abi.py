@@ -155,6 +155,13 @@ def join_output(left_columns, right_columns):
     return CJoinOutput(la, len(left_columns), ra, len(right_columns)), (la, ra)
 
 
+class CJoinOrderKey(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_uint32), ("descending", C.c_int32), ("nulls_first", C.c_int32)]
+
+
+JOIN_ORDER_AGGREGATE, JOIN_ORDER_PAYLOAD, JOIN_ORDER_KEY = 0, 1, 2
+
+
 class CColumnDesc(C.Structure):
     _fields_ = [("field_id", C.c_uint32), ("dtype", C.c_int32), ("rows", C.c_uint64), ("has_stats", C.c_int32),
                 ("min_i", C.c_int64), ("max_i", C.c_int64), ("dict_size", C.c_uint32),

@@ -50,6 +50,7 @@ int ensure_device() {
 // ---------------------------------------------------------------------------------
 Query::~Query() {
   if (sorted) sorted_groupby_free(sorted);
+  if (join_state) join_group_state_free(join_state); // (behind the GROUP BY that tests its bitmap)
   // the buffers go back to the pools (hipFree / hipHostFree cost 0.2 ms per statement); executions that were
   // launched and never collected may still be running on their streams
   if (n_launched != n_collected) {

@@ -171,9 +171,13 @@ const LoweredPlan *part_groupby_plan(const PartGroupBy *p);
 // handed to it instead (sorted_groupby_partitioned() says so).
 struct SortedGroupBy;
 bool sorted_groupby_partitioned(const SortedGroupBy *s);
+void join_group_state_free(struct JoinGroupState *s); // join_group.cpp
+struct KeySetView;
+// `key_set` / `key_set_field`: one more conjunct of the selection — the integer column must be in the key set (join → GROUP BY,
+// join_group.cpp: the keys of the qualifying dimension rows; the bitmap belongs to the caller and outlives the object)
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                            const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
-                           bool order_by_keys, SortedGroupBy **out);
+                           bool order_by_keys, SortedGroupBy **out, const KeySetView *key_set = nullptr, uint32_t key_set_field = 0);
 int sorted_groupby_run(SortedGroupBy *s, LazyGroups *out);
 void sorted_groupby_free(SortedGroupBy *s);
 // Sharded table: the ranks' partial groups ([n_keys][n] key cells and validity, [n][k] lanes per rank, rank order)
@@ -185,6 +189,7 @@ struct Query {
   const Table *table = nullptr;
   LazyGroups lazy;
   SortedGroupBy *sorted = nullptr; // set when the dense GROUP BY kernel cannot hold the groups: executions run synchronously in launch()
+  struct JoinGroupState *join_state = nullptr; // join → GROUP BY (join_group.cpp): the dimension side's key set and sorted rows
   LoweredPlan plan;
   const CatalogEntry *entry = nullptr;
   JitKernel jit;

@@ -39,6 +39,10 @@ struct SortedGroupBy {
   std::vector<int64_t> m_kv;
   std::vector<uint8_t> m_kvalid;
   PartGroupBy *part = nullptr; // the partitioned route answers instead (group_part.cpp)
+  // join → GROUP BY (join_group.cpp): one more conjunct of the selection — the integer column `key_set_field` must be in the
+  // key set of the dimension rows that qualify (a bitmap the caller owns, alive as long as this object)
+  bool has_key_set = false;
+  KeySetView key_set{nullptr, 0, 0};
   int run(LazyGroups *out);
   ~SortedGroupBy() {
     if (part) part_groupby_free(part);
@@ -173,7 +177,7 @@ int pinned_reserve(void **p, size_t *cap, size_t bytes) {
 // Admission: GROUP BY shapes the dense kernel turned down for capacity reasons only.
 int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops, uint32_t n_ops,
                            const uint32_t *key_fields, uint32_t n_keys, const llkv_aggregate_spec *aggs, uint32_t n_aggs,
-                           bool order_by_keys, SortedGroupBy **out) {
+                           bool order_by_keys, SortedGroupBy **out, const KeySetView *key_set, uint32_t key_set_field) {
   if (n_keys == 0 || n_keys > 4) return set_error(LLKV_UNSUPPORTED, "sort-based GROUP BY takes 1..4 keys");
   auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
     auto it = table->cols.find(fid);
@@ -197,12 +201,17 @@ int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint3
   int rc;
   // statistics-bounded keys and order-free lanes (what the shared-image lowering takes): the partitioned route — no sort
   // of the rows, no gathers
-  if (!std::getenv("LLKV_HIP_GROUP_NO_IMAGE") && !std::getenv("LLKV_HIP_GROUP_NO_PART") &&
+  if (!key_set && !std::getenv("LLKV_HIP_GROUP_NO_IMAGE") && !std::getenv("LLKV_HIP_GROUP_NO_PART") &&
       part_groupby_prepare(table, filters, n_filters, ops, n_ops, key_fields, n_keys, aggs, n_aggs, order_by_keys, &s->part) == LLKV_OK) {
     *out = s.release();
     return LLKV_OK;
   }
-  if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, nullptr, 0, &s->sel_plan, &err))) return set_error(rc, err);
+  if (key_set) {
+    if (n_ops) return set_error(LLKV_UNSUPPORTED, "a key-set conjunct beside a predicate program");
+    s->has_key_set = true;
+    s->key_set = *key_set;
+    if ((rc = lower_selection_in_set(resolve, filters, n_filters, key_set_field, &s->sel_plan, &err))) return set_error(rc, err);
+  } else if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, nullptr, 0, &s->sel_plan, &err))) return set_error(rc, err);
   if ((rc = lower_reduce(resolve, aggs, n_aggs, &s->red_plan, &err))) return set_error(rc, err);
   if (s->red_plan.distinct_field >= 0 && table->world != 1)
     return set_error(LLKV_UNSUPPORTED, "DISTINCT aggregates inside GROUP BY over a sharded table (the ranks' partial groups cannot be merged)");
@@ -257,7 +266,7 @@ int SortedGroupBy::run(LazyGroups *out) {
     t_last = now;
   };
   Selection sel;
-  if ((rc = run_selection_lowered(table, sel_plan, &sel))) return rc;
+  if ((rc = run_selection_lowered(table, sel_plan, &sel, has_key_set ? &key_set : nullptr))) return rc;
   const uint64_t n = sel.n;
   mark("selection");
   if (n == 0) return LLKV_OK;

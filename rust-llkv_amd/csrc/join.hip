@@ -1784,4 +1784,36 @@ hipError_t hj_prefix_overflow(void *tmp, size_t *tmp_bytes, const int64_t *vals,
   return hipGetLastError();
 }
 
+// ---- join → GROUP BY with an aggregate list (join_group.cpp): the dimension row of every result group ------------------------
+// The qualifying dimension rows sorted by key image (value − base): a group's key is found by bisection, its dimension row gives
+// the payload cells and the row's position among the qualifying rows (row order) — the last tie-break of ORDER BY.
+__global__ __launch_bounds__(256) void hj_lookup_payload_kernel(const uint64_t *sorted_keys, const uint64_t *sorted_rows, const uint32_t *sorted_pos, uint64_t n_dim,
+                                                                const int64_t *probe_keys, long long base, uint64_t m, JoinPayloadCols cols,
+                                                                int64_t *out_payload, uint8_t *out_valid, uint32_t *out_pos) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint64_t want = (uint64_t)probe_keys[i] - (uint64_t)base;
+  uint64_t lo = 0, hi = n_dim;
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (sorted_keys[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  const bool found = lo < n_dim && sorted_keys[lo] == want;
+  out_pos[i] = found ? sorted_pos[lo] : 0xFFFFFFFFu;
+  const uint64_t row = found ? sorted_rows[lo] : 0;
+  for (uint32_t c = 0; c < cols.n; ++c) {
+    long long v = 0;
+    const bool ok = found && key_cell(cols.col[c], row, &v);
+    out_payload[(uint64_t)c * m + i] = ok ? v : 0;
+    out_valid[(uint64_t)c * m + i] = ok ? 1 : 0;
+  }
+}
+hipError_t hj_launch_lookup_payload(const uint64_t *sorted_keys, const uint64_t *sorted_rows, const uint32_t *sorted_pos, uint64_t n_dim, const int64_t *probe_keys,
+                                    long long base, uint64_t m, const JoinPayloadCols &cols, int64_t *out_payload, uint8_t *out_valid, uint32_t *out_pos, hipStream_t s) {
+  if (m == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_lookup_payload_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, s, sorted_keys, sorted_rows, sorted_pos, n_dim, probe_keys, base, m, cols,
+                     out_payload, out_valid, out_pos);
+  return hipGetLastError();
+}
+
 } // namespace llkv

@@ -327,6 +327,17 @@ hipError_t hj_launch_run_heads(const uint64_t *sorted, uint64_t n, uint64_t *fla
 // consecutive values (256 threads, strided, fixed butterfly) whose sums are added in block order.  *out = the sum.
 hipError_t hj_launch_sum_f64_ordered(const uint64_t *vals, uint64_t n, int as_int, double *out, double *scratch /* ⌈n / 65 536⌉ doubles */, hipStream_t s);
 
+// ---- join → GROUP BY with an aggregate list (join_group.cpp) --------------------------------------------------------------------
+// For m group keys: bisection in the qualifying dimension rows sorted by key image (value − base) → the row's payload cells
+// (out_payload[c][i], sign-extended; out_valid[c][i] = 0 for a NULL cell) and its position among the qualifying rows in row order
+// (out_pos[i]; ~0u when the key is not there).
+struct JoinPayloadCols {
+  JoinKeyColumn col[4];
+  uint32_t n;
+};
+hipError_t hj_launch_lookup_payload(const uint64_t *sorted_keys, const uint64_t *sorted_rows, const uint32_t *sorted_pos, uint64_t n_dim, const int64_t *probe_keys,
+                                    long long base, uint64_t m, const JoinPayloadCols &cols, int64_t *out_payload, uint8_t *out_valid, uint32_t *out_pos, hipStream_t s);
+
 // ---- ordered scans (stream.cpp) -----------------------------------------------------------------------------
 hipError_t hj_launch_gather_u64(const uint64_t *in, const uint32_t *perm, uint64_t n, uint64_t *out, hipStream_t s);
 // out[i] = in[idx[i]] (64-bit indices: device row → row id of a table whose ids are not its positions)

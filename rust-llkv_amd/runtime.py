@@ -855,6 +855,73 @@ def join_groupby_topk(fact: HipTable, fact_filters, fact_key: int, dim: HipTable
     return out, total.value
 
 
+class JoinRow:
+    """One result row of a join → GROUP BY: the group key (dim.key), the payload cells (None = NULL), the aggregates' finalized
+    cells and the dimension row's position among the qualifying rows (the last tie-break of the order)."""
+
+    def __init__(self, key: int, payload: list, values: List[Value], group_index: int):
+        self.key, self.payload, self.values, self.group_index = key, payload, values, group_index
+
+    def __repr__(self):
+        return f"JoinRow(key={self.key}, payload={self.payload}, values={[v.value for v in self.values]})"
+
+
+class JoinGroupBy(PreparedQuery):
+    """fact ⋈ dim [⋉ dim2] GROUP BY dim key [, payload …] with ANY aggregate list over fact-side expressions
+    (llkv_hip_join_groupby_prepare): a prepared GROUP BY of the fact key over `filters AND key IN (qualifying dimension keys)` —
+    launch / finish (or finish_sharded for a fact table sharded over ranks) like any other prepared query, then ``result``."""
+
+    def __init__(self, fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, aggs: Sequence[AggregateSpec],
+                 dim_fk: int = 0, dim2: Optional[HipTable] = None, dim2_filters=(), dim2_key: int = 0):
+        keep = []
+
+        def side(table, filters, key):
+            p = CPlan(list(filters or []))
+            keep.append(p)
+            s = abi.CJoinSide()
+            s.table, s.filters, s.n_filters, s.key_field = table.handle, p.filters, p.n_filters, key
+            return s
+
+        f, d = side(fact, fact_filters, fact_key), side(dim, dim_filters, dim_key)
+        d2 = side(dim2, dim2_filters, dim2_key) if dim2 is not None else None
+        self._plan = CPlan(None, aggs, [])
+        self._keep = keep
+        self._h = C.c_void_p()
+        self.table = fact
+        self.n_aggs = len(aggs)
+        check(lib().llkv_hip_join_groupby_prepare(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None,
+                                                  self._plan.aggs, self._plan.n_aggs, C.byref(self._h)))
+
+    def result(self, payload_fields: Sequence[int] = (), order=(), limit: Optional[int] = None):
+        """ORDER BY … LIMIT over the finished groups.  ``order``: [(kind, index, descending, nulls_first)] with kind one of
+        abi.JOIN_ORDER_AGGREGATE / _PAYLOAD / _KEY.  Returns (rows, total_groups)."""
+        L = lib()
+        pay = (C.c_uint32 * max(1, len(payload_fields)))(*payload_fields)
+        ok = (abi.CJoinOrderKey * max(1, len(order)))()
+        for i, o in enumerate(order):
+            ok[i].kind, ok[i].index, ok[i].descending, ok[i].nulls_first = o[0], o[1], int(o[2]) if len(o) > 2 else 0, int(o[3]) if len(o) > 3 else 0
+        h = C.c_void_p()
+        check(L.llkv_hip_join_groupby_rows(self._h, pay, C.c_uint32(len(payload_fields)), ok, C.c_uint32(len(order)),
+                                           C.c_uint64(2**64 - 1 if limit is None else limit), C.byref(h)))
+        try:
+            L.llkv_hip_join_rows_len.restype = C.c_uint64
+            L.llkv_hip_join_rows_total_groups.restype = C.c_uint64
+            L.llkv_hip_join_rows_len.argtypes = [C.c_void_p]
+            L.llkv_hip_join_rows_total_groups.argtypes = [C.c_void_p]
+            n, total = int(L.llkv_hip_join_rows_len(h)), int(L.llkv_hip_join_rows_total_groups(h))
+            rows = []
+            key, gi = C.c_int64(), C.c_uint64()
+            pv, pn = (C.c_int64 * 4)(), (C.c_uint8 * 4)()
+            vals = C.POINTER(abi.CValue)()
+            for i in range(n):
+                check(L.llkv_hip_join_rows_get(h, C.c_uint64(i), C.byref(key), pv, pn, C.byref(gi), C.byref(vals)))
+                rows.append(JoinRow(key.value, [None if pn[c] else pv[c] for c in range(len(payload_fields))],
+                                    [Value.from_c(vals[a]) for a in range(self.n_aggs)], gi.value))
+            return rows, total
+        finally:
+            L.llkv_hip_join_rows_free(h)
+
+
 class JoinAgg:
     """The join → GROUP BY → top-k pipeline in phases, for a fact table sharded over ranks
     (llkv_hip_join_agg_*; dist.join_groupby_topk drives the collectives between the phases)."""

@@ -194,7 +194,7 @@ def test_first_value_of_a_group_types_its_decimal_temp_column(rt, orc, abi):
     positive scale above the precision: a group whose first product is below 10^(scale−1) fails the query, COUNT included; a
     group without any non-NULL value has an Int64 temp column."""
     price = np.array([10000, 20050, 99, 5, 123456, 777], dtype=np.int64)          # DECIMAL(15,2)
-    disc = np.array([5, 10, 100, 1, 0, 2], dtype=np.int64)                         # DECIMAL(15,2)
+    disc = np.array([5, 10, 50, 1, 0, 2], dtype=np.int64)                          # DECIMAL(15,2)
     key = np.array([0, 0, 1, 1, 2, 2], dtype=np.int64)
     valid = np.array([1, 1, 1, 1, 0, 0], dtype=bool)
     ht, ot = rt.HipTable(1, [6]), orc.OracleTable(6)
