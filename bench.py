@@ -95,7 +95,7 @@ def stage(rt, tpch, abi, dist, query, chunks, scale, rank, world, row_begin_glob
     return table, data
 
 
-PROFILE_EVERY = 4
+PROFILE_EVERY = 8  # HIP events bracket every 8th scan of the timed region: each record is a ~4 µs packet between back-to-back kernels
 DEPTH = 4  # executions of the prepared query kept in flight (host finalizes i while the GPU runs i+1..)
 
 
@@ -123,19 +123,22 @@ def run_steps(q, steps, stream_ptr, comm_stream_ptr, comm_stream=None, allreduce
         else:
             q.submit(0)
 
+    # collect_only: the library waits, folds the octants and finalizes every group of the execution (that IS the result); the
+    # binding's Python row objects are built once, from the last execution — 40 ctypes calls per execution are the binding's
+    # cost, not the path's, and behind the last launch nothing hides them
     for i in range(steps):
         if launched - collected == DEPTH:
             if submitted == collected:
                 exchange(submitted % DEPTH); submitted += 1
-            rows = q.collect(); collected += 1
+            q.collect_only(); collected += 1
         q.launch(stream_ptr); launched += 1
         if launched - submitted >= 2:  # the image of the previous execution completed with this launch
             exchange(submitted % DEPTH); submitted += 1
     while collected < launched:
         if submitted == collected:
             exchange(submitted % DEPTH); submitted += 1
-        rows = q.collect(); collected += 1
-    return rows
+        q.collect_only(); collected += 1
+    return q.rows() if launched else None
 
 
 def split_workload(name):
@@ -163,8 +166,8 @@ def measure(rt, tpch, abi, torch, dist, name, rank, world, scaling, steps, warmu
     comm_ptr = comm.cuda_stream if comm is not None else 0
     run_steps(q, warmup, stream_ptr, comm_ptr)
     ar_events = [] if comm is not None else None
-    # HIP events around every 4th scan kernel of the timed region (every one when the region is only a few steps long)
-    q.set_profiling(PROFILE_EVERY if steps >= 4 * PROFILE_EVERY else 1)
+    # HIP events around every 8th scan kernel of the timed region (every 4th / every one when the region is only a few steps long)
+    q.set_profiling(PROFILE_EVERY if steps >= 2 * PROFILE_EVERY else (4 if steps >= 8 else 1))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -517,6 +517,11 @@ class PreparedQuery:
         check(lib().llkv_hip_query_collect(self._h))
         return self.rows()
 
+    def collect_only(self):
+        """llkv_hip_query_collect — the library waits for the execution, folds and FINALIZES its groups — without building Python
+        rows from them (rows() reads the latest collected execution on request)."""
+        check(lib().llkv_hip_query_collect(self._h))
+
     def finish(self, stream: int = 0) -> List[GroupRow]:
         check(lib().llkv_hip_query_finish(self._h, C.c_void_p(stream)))
         return self.rows()

@@ -157,6 +157,21 @@ def _join_inputs(rt, abi, tpch, rank, world):
                 dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
 
 
+def _join_group(rt, abi, tpch, rank, world, sharded):
+    ji = _join_inputs(rt, abi, tpch, rank, world)
+    A, col = abi.AggregateSpec, abi.col
+    aggs = [A.sum(ji["sum_expr"]), A.count_star(), A.min(tpch.L_EXTENDEDPRICE), A.avg(tpch.L_EXTENDEDPRICE)]
+    jq = rt.JoinGroupBy(ji["fact"], ji["fact_filters"], ji["fact_key"], ji["dim"], ji["dim_filters"], ji["dim_key"], aggs, dim_fk=ji["dim_fk"], dim2=ji["dim2"],
+                        dim2_filters=ji["dim2_filters"], dim2_key=ji["dim2_key"])
+    jq.launch(0)
+    if sharded:
+        rt.check(rt.lib().llkv_hip_query_finish_sharded(jq._h, None))
+    else:
+        jq.finish_only()
+    rows, total = jq.result(ji["payload_fields"], [(abi.JOIN_ORDER_AGGREGATE, 1, True), (abi.JOIN_ORDER_AGGREGATE, 2, False), (abi.JOIN_ORDER_KEY, 0, False)], 25)
+    return [(r.key, tuple(r.payload), r.group_index, r.values[1].value, r.values[2].value, r.values[0].value, r.values[3].value) for r in rows], total
+
+
 def _worker(rank, world, port, out_path):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -190,6 +205,9 @@ def _worker(rank, world, port, out_path):
     rows, total = jr.finish_sharded(10)
     res["join_ranged"] = ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in rows], total)
     res["join_ranged_bytes"] = jr.exchange_bytes()
+    # join → GROUP BY with an aggregate list (llkv_hip_join_groupby_prepare): the prepared GROUP BY of the fact key runs over this
+    # rank's shard, finish_sharded all-gathers the partial groups and merges them lane by lane in rank order
+    res["join_group"] = _join_group(rt, abi, tpch, rank, world, sharded=True)
     with open(f"{out_path}.{rank}", "wb") as f:
         pickle.dump(res, f)
     rt.comm_destroy()
@@ -227,6 +245,10 @@ def test_two_processes_run_the_sharded_drivers_over_a_host_transport(rt, abi, tp
     jw, jtotal = rt.join_groupby_topk(limit=10, **_join_inputs(rt, abi, tpch, 0, 1))
     assert got[0]["join"] == ([(r[0], np.float64(r[1]).tobytes(), r[2], r[3], r[4]) for r in jw], jtotal)
     assert got[0]["join_ranged"] == got[0]["join"] and 0 < got[0]["join_ranged_bytes"] < 8192
+    (jg, jg_total), (wg, wg_total) = got[0]["join_group"], _join_group(rt, abi, tpch, 0, 1, sharded=False)
+    assert jg_total == wg_total == jtotal and [r[:5] for r in jg] == [r[:5] for r in wg]  # keys, payload, positions, counts, minima: exact
+    for g, w in zip(jg, wg):
+        assert abs(g[5] - w[5]) <= REL * abs(w[5]) and abs(g[6] - w[6]) <= REL * abs(w[6])  # f64 sums: one more level of association
 
 
 @pytest.mark.gpu

@@ -35,6 +35,28 @@ alg = rows * 28 + n_ord * 28 + n_cust * 9
 best = min(ts)
 res = {"workload": f"q3_{sf}", "lineitem_rows": rows, "orders": n_ord, "customers": n_cust, "groups": total, "seconds_best": best, "seconds_all": ts,
        "rows_per_s": rows / best, "algorithmic_bytes": alg, "gbs": alg / best / 1e9, "top": out[:3]}
+# ---- the general join → GROUP BY route over the same star (llkv_hip_join_groupby_prepare: any aggregate list, any ORDER BY): Q3's own
+# aggregate (so the answers can be compared), then a list the hand-tuned pipeline does not take
+if "--general" in sys.argv:
+    A = abi.AggregateSpec
+    lists = {"q3_sum_only": [A.sum(rev)], "two_sums_avg_min_count": [A.sum(rev), A.sum(tpch.L_EXTENDEDPRICE), A.avg(tpch.L_DISCOUNT), A.min(tpch.L_EXTENDEDPRICE), A.count_star()]}
+    res["general"] = {}
+    for name, aggs in lists.items():
+        def once(prepared=None):
+            jq = prepared or rt.JoinGroupBy(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, aggs,
+                                            dim_fk=tpch.O_CUSTKEY, dim2=ct, dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+            jq.launch(); jq.finish_only()
+            rows_, total_ = jq.result([tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], [(abi.JOIN_ORDER_AGGREGATE, 0, True), (abi.JOIN_ORDER_PAYLOAD, 0, False)], 10)
+            return jq, rows_, total_
+        jq, rows_, total_ = once()
+        cold, warm = [], []
+        for _ in range(3):
+            t0 = time.perf_counter(); j2, rows_, total_ = once(); cold.append(time.perf_counter() - t0); j2.close()
+        for _ in range(3):  # the prepared form: the dimension key set is kept, an execution is the fact-side GROUP BY + ORDER BY / LIMIT
+            t0 = time.perf_counter(); once(jq); warm.append(time.perf_counter() - t0)
+        res["general"][name] = {"groups": total_, "seconds_prepare_and_run_best": min(cold), "seconds_prepared_run_best": min(warm),
+                                "top_keys": [r.key for r in rows_[:3]], "same_top_keys_as_the_q3_pipeline": [r.key for r in rows_] == [o[0] for o in out]}
+        jq.close()
 # ---- configs[4] sharded over `world` ranks, emulated on this one device: what ONE rank runs per query (prepare: its dimension
 # work + the probe of its 1/world of lineitem + the run sums; then its share of the exchange) in the general form (dimension
 # selection replicated, per-group counts all-reduced) and in the range form (orders of the rank's own key range only, boundary
