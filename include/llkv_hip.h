@@ -107,7 +107,7 @@ typedef enum llkv_operator_kind {
    * llkv-transaction/src/mvcc.rs:283-333).  field_id = the `created_by` column (UInt64),
    * value.lo = field id of the `deleted_by` column, lower.lo = snapshot.txn_id,
    * upper.lo = snapshot.snapshot_id, in_list = txn ids whose status is NOT Committed
-   * (Active / Aborted; ≤ 4 on the GPU path).                                              */
+   * (Active / Aborted; ≤ 32 on the GPU path).                                             */
   LLKV_OP_MVCC_VISIBLE = 10,
   /* Expr::Compare { left, op, right } over scalar expressions (the expr-vs-expr route,
    * evaluate_compare_rows llkv-scan/src/predicate.rs:562-663 → compute_compare
@@ -364,6 +364,28 @@ llkv_status llkv_hip_table_append_decimal128_column(llkv_hip_table *table, uint3
                                                     int32_t precision, int32_t scale,
                                                     const void *const *chunk_values,
                                                     uint32_t n_chunks);
+
+/* Incremental growth — ColumnStore::append (llkv-column-map/src/store/core.rs:787): `n_new_chunks` chunks of `chunk_rows[]` rows
+ * follow the table's last chunk, with the new chunks of EVERY staged column (`columns[n_columns]`: fixed-width value buffers,
+ * arrow's 16-byte Decimal128 values, or Utf8 offsets + data; optional Arrow validity bitmaps) and, for a table with its own row
+ * ids (llkv_hip_table_set_row_ids) or when the new ids are not the dense continuation, `chunk_row_ids` (else NULL).  Only the new
+ * chunks cross the host → HBM link; a column image without room moves once on the device into a buffer with headroom.
+ * Dictionaries grow by the new strings (beyond 256: LLKV_UNSUPPORTED — re-stage), statistics, validity and row ids follow.
+ * Whatever the data can refuse is checked before anything is touched: a refused append leaves the table as it was.
+ * Every successful append starts a new GENERATION of the image: a query prepared before it answers LLKV_INVALID_ARGUMENT at
+ * launch (buffers may have moved, statistics decide lowerings) — prepare it again (lowering + a kernel-cache lookup, no staging).
+ * No execution may be in flight during the call.  Unsharded tables only (world = 1).                                        */
+typedef struct llkv_column_chunks {
+  uint32_t field_id;
+  const void *const *values;      /* [n_new_chunks] fixed width: value buffers; Decimal128: 16-byte raw values; Utf8: NULL   */
+  const int32_t *const *offsets;  /* [n_new_chunks] Utf8: rows + 1 offsets per chunk                                         */
+  const uint8_t *const *data;     /* [n_new_chunks] Utf8: string bytes                                                       */
+  const uint8_t *const *validity; /* NULL, or [n_new_chunks] Arrow bitmaps (a NULL entry: every cell of the chunk present)   */
+} llkv_column_chunks;
+llkv_status llkv_hip_table_append_chunks(llkv_hip_table *table, const uint64_t *chunk_rows, uint32_t n_new_chunks,
+                                         const llkv_column_chunks *columns, uint32_t n_columns,
+                                         const uint64_t *const *chunk_row_ids);
+uint64_t llkv_hip_table_generation(const llkv_hip_table *table); /* number of appends so far */
 
 /* Integer column statistics (the analogue of ChunkMetadata.min/max_val_u64, llkv-column-map/src/store/
  * descriptor.rs:19-84).  Plans use them (exact SUM without overflow tracking, dense integer GROUP BY), so every

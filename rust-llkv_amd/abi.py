@@ -155,6 +155,11 @@ def join_output(left_columns, right_columns):
     return CJoinOutput(la, len(left_columns), ra, len(right_columns)), (la, ra)
 
 
+class CColumnChunks(C.Structure):
+    _fields_ = [("field_id", C.c_uint32), ("values", C.POINTER(C.c_void_p)), ("offsets", C.POINTER(C.c_void_p)), ("data", C.POINTER(C.c_void_p)),
+                ("validity", C.POINTER(C.c_void_p))]
+
+
 class CJoinOrderKey(C.Structure):
     _fields_ = [("kind", C.c_int32), ("index", C.c_uint32), ("descending", C.c_int32), ("nulls_first", C.c_int32)]
 

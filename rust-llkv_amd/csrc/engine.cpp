@@ -157,6 +157,7 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
   };
   std::unique_ptr<Query> q(new Query());
   q->table = table;
+  q->table_generation = table->generation;
   q->order_by_keys = order_by_keys;
   q->n_user_aggs = n_aggs;
   q->n_user_keys = grouped ? n_keys : 0;
@@ -335,6 +336,8 @@ int Query::flush_pending() {
 }
 
 int Query::launch(hipStream_t stream) {
+  if (table && table->generation != table_generation)
+    return set_error(LLKV_INVALID_ARGUMENT, "the table was appended to after this query was prepared (its buffers, statistics and tile lists have changed): prepare it again");
   if (sorted) { // the sort-based route runs to completion here; submit / collect only hand the result over
     if (n_launched != n_collected) return set_error(LLKV_INVALID_ARGUMENT, "a sort-based GROUP BY keeps one execution in flight");
     const int rc = sorted_groupby_run(sorted, &lazy);

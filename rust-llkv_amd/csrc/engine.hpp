@@ -52,6 +52,9 @@ struct DeviceColumn {
   uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
   void *d_hi = nullptr;       // Decimal128 values beyond 64 bits (info.wide128): d_values holds the low halves, this the high halves
   bool owned = false;
+  // rows the buffers above can hold (slack included); 0 = exactly the table's image + slack as allocated at staging.  An append
+  // (llkv_hip_table_append_chunks) that outgrows it moves the column into a larger buffer with headroom.
+  uint64_t cap_rows = 0, valid_cap_rows = 0;
 };
 
 // Device buffer read by slot `s` of a lowered plan: the field's values, its validity mask, or the high halves of a wide
@@ -88,6 +91,12 @@ struct Table {
   // Row ids that are not the positions 0 … n − 1 (llkv_hip_table_set_row_ids): the id of every local row, in the row layout of
   // the column images; nullptr = dense ids.  Everything inside works on positions; the calls that REPORT row ids translate.
   uint64_t *d_row_ids = nullptr;
+  uint64_t row_ids_cap = 0;   // rows d_row_ids can hold
+  uint64_t last_row_id = 0;   // the id of the table's last row (ids ascend strictly; appended chunks must continue above it)
+  // llkv_hip_table_append_chunks: every append is a new generation of the image — buffers may have moved, statistics and tile
+  // lists have changed — and a query prepared over an older one refuses to launch (prepare it again: lowering + a cache lookup)
+  uint64_t generation = 0;
+  std::vector<void *> retired; // tile lists of older generations (freed with the table: a stale handle may still name them)
   std::mutex mu;
   ~Table();
 };
@@ -187,6 +196,7 @@ int sorted_groupby_merge(SortedGroupBy *s, uint32_t world, const uint64_t *rank_
 
 struct Query {
   const Table *table = nullptr;
+  uint64_t table_generation = 0; // the table's generation this query was lowered over (Table::generation)
   LazyGroups lazy;
   SortedGroupBy *sorted = nullptr; // set when the dense GROUP BY kernel cannot hold the groups: executions run synchronously in launch()
   struct JoinGroupState *join_state = nullptr; // join → GROUP BY (join_group.cpp): the dimension side's key set and sorted rows

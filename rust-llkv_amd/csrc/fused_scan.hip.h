@@ -399,6 +399,17 @@ template <class V, class... Ds> struct FirstDigits {
   }
   static constexpr bool first_only(int) { return true; } // the key grows with the row id: a thread's first contribution to a group is its smallest
 };
+// PlanValue Int / Int (llkv-executor/src/lib.rs:7213-7227): truncating integer division, NULL for a zero divisor.  The one pair
+// that turns Float there — i64::MIN / −1 — is excluded by the host (column statistics or a literal divisor), so the group's temp
+// column stays Int64 whatever the data.
+template <class L, class R> struct DivIntPV {
+  using Type = I64;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return L::valid(c, j) & R::valid(c, j) & ((int64_t)R::eval(c, j) != 0); }
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int j) {
+    const int64_t a = (int64_t)L::eval(c, j), b = (int64_t)R::eval(c, j);
+    return b == 0 ? 0 : b == -1 ? (int64_t)(0ull - (uint64_t)a) : a / b;
+  }
+};
 // Predicate form of an expression's validity.
 template <class E> struct VE {
   static __device__ __forceinline__ bool eval(Ctx &c, int j) { return E::valid(c, j); }

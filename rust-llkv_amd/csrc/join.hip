@@ -218,6 +218,16 @@ hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void iota_u64_kernel(uint64_t *out, uint64_t n, uint64_t first) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = first + i;
+}
+hipError_t hj_launch_iota_u64(uint64_t *out, uint64_t n, uint64_t first, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(iota_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, out, n, first);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void hj_cross_pairs_kernel(uint64_t l0, uint64_t ln, uint64_t r0, uint64_t rn, uint64_t *out_left, uint64_t *out_right) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ln * rn) return;

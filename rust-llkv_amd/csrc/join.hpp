@@ -76,6 +76,7 @@ hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t 
 // Fills `bytes` (rounded up to 16; the block must be 16-byte aligned and that large) with a 64-bit pattern.
 hipError_t hj_launch_fill(void *p, uint64_t bytes, uint64_t pattern, hipStream_t s);
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
+hipError_t hj_launch_iota_u64(uint64_t *out, uint64_t n, uint64_t first, hipStream_t s); // out[i] = first + i
 // Up to four zero fills in one launch (same alignment rule).
 struct FillRanges {
   void *p[4];

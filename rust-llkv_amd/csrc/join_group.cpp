@@ -171,6 +171,7 @@ static int join_groupby_prepare(const llkv_join_side *fact, const llkv_join_side
   if ((rc = key_col_of(tf, fact->key_field, &kf, nullptr, false))) return rc;
   std::unique_ptr<Query> q(new Query());
   q->table = tf;
+  q->table_generation = tf->generation;
   q->order_by_keys = true; // ascending keys: the same order on every rank count (the caller's ORDER BY is applied by _rows)
   q->n_user_aggs = n_aggs;
   q->n_user_keys = 1;

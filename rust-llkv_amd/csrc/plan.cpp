@@ -15,7 +15,7 @@ typedef __int128 i128;
 typedef unsigned __int128 u128;
 
 static constexpr int kMaxColsHost = 16;
-static constexpr int kMaxLitsHost = 24; // = kMaxLits (scan_params.h)
+static constexpr int kMaxLitsHost = 48; // = kMaxLits (scan_params.h)
 static constexpr int kMaxKeysHost = 4;
 bool plan_exact_f64_sums();
 static constexpr uint32_t kMaxDenseGroups = 64; // bounded further by the LDS image (lanes · 2 KiB ≤ 160 KiB)
@@ -538,7 +538,9 @@ struct Lowering {
       const ColumnInfo *cd = resolve((uint32_t)f.value.lo);
       if (!cd) return fail(LLKV_NOT_FOUND, "deleted_by field " + std::to_string((uint32_t)f.value.lo) + " not found");
       if (ci->dtype != LLKV_DT_UINT64 || cd->dtype != LLKV_DT_UINT64) return fail(LLKV_INVALID_ARGUMENT, "MVCC columns must be UInt64");
-      if (f.in_len > 4) return fail(LLKV_UNSUPPORTED, "more than 4 non-committed transactions in the snapshot");
+      // every non-committed id is one literal slot and two compares per row (created_by, deleted_by) against a scalar register;
+      // beyond 32 of them a sorted array and a bisection per row would be the form (not built)
+      if (f.in_len > 32) return fail(LLKV_UNSUPPORTED, "more than 32 non-committed transactions in the snapshot");
       int sc, sd, rc2;
       const ColumnInfo *tmp;
       if ((rc2 = slot_of(f.field_id, &tmp, &sc)) || (rc2 = slot_of((uint32_t)f.value.lo, &tmp, &sd))) return rc2;
@@ -1221,8 +1223,21 @@ struct Lowering {
         }
         if (e[i].binop == LLKV_BIN_DIV || (e[i].binop == LLKV_BIN_MOD && (l.f || r.f))) {
           // Int / Int truncates but turns Float for i64::MIN / -1 (:7213-7227): the type of the group's temp column
-          // would depend on the data
-          if (!l.f && !r.f) return fail(LLKV_UNSUPPORTED, "integer division in GROUP BY aggregate arguments");
+          // would depend on the data — unless the statistics (or a literal divisor) exclude that pair
+          if (!l.f && !r.f) {
+            const bool never_min = l.bounded && l.lo > (i128)INT64_MIN, never_minus_one = r.bounded && (r.lo > -1 || r.hi < -1);
+            if (!never_min && !never_minus_one)
+              return fail(LLKV_UNSUPPORTED, "integer division in GROUP BY aggregate arguments whose operands may be i64::MIN / −1 (it turns Float in the reference: the temp column's type would depend on the data)");
+            PV o;
+            o.s = "DivIntPV<" + l.s + "," + r.s + ">";
+            o.bounded = true;
+            const i128 m = std::max(l.lo < 0 ? -l.lo : l.lo, l.hi < 0 ? -l.hi : l.hi);
+            o.lo = -m; o.hi = m;
+            if (!fits_i64(o.lo)) o.lo = INT64_MIN;
+            if (!fits_i64(o.hi)) o.hi = INT64_MAX;
+            st.push_back(o);
+            continue;
+          }
           PV o;
           o.s = std::string("DivPV<") + (e[i].binop == LLKV_BIN_MOD ? "1" : "0") + "," + l.s + "," + r.s + ">";
           o.f = true;

@@ -24,7 +24,7 @@ constexpr int kBlock = 256;
 constexpr int kRowsPerThread = 2;
 constexpr int kStepRows = kBlock * kRowsPerThread; // 512 rows per block step
 constexpr int kMaxCols = 16; // value slots + validity-mask slots of one plan
-constexpr int kMaxLits = 24;
+constexpr int kMaxLits = 48; // literal slots per bank (the MVCC leaf keeps the snapshot's non-committed transaction ids here)
 constexpr int kMaxKeys = 4;
 constexpr int kOctants = 8; // canonical partition of the chunk list
 

@@ -267,6 +267,8 @@ class HipTable:
         self.first_chunk, self.n_local_chunks = first.value, count.value
         self.rank, self.world = rank, world
         self._keep: list = []
+        self._utf8_fields: set = set()     # what append_chunks needs to know about the staged columns
+        self._decimal_fields: set = set()
 
     @property
     def handle(self):
@@ -320,6 +322,7 @@ class HipTable:
         ptrs = (C.c_void_p * max(1, len(chunks)))(*[c.ctypes.data for c in chunks])
         check(lib().llkv_hip_table_append_decimal128_column(self._h, C.c_uint32(field_id), C.c_int32(precision), C.c_int32(scale),
                                                             ptrs, C.c_uint32(len(chunks))))
+        self._decimal_fields.add(field_id)
         if valid is not None:
             self.set_column_validity(field_id, valid)
 
@@ -397,8 +400,79 @@ class HipTable:
             enc = [d.encode() for d in dictionary]
             dptr, dn = (C.c_char_p * max(1, len(enc)))(*enc), len(enc)
         check(lib().llkv_hip_table_append_utf8_column(self._h, C.c_uint32(field_id), poff, pdat, C.c_uint32(len(chunks_off)), dptr, C.c_uint32(dn)))
+        self._utf8_fields.add(field_id)
         if valid is not None:
             self.set_column_validity(field_id, valid)
+
+    @property
+    def generation(self) -> int:
+        f = lib().llkv_hip_table_generation
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p]
+        return int(f(self._h))
+
+    def append_chunks(self, chunk_rows: Sequence[int], columns: Dict[int, object], valid: Optional[Dict[int, object]] = None, row_ids=None):
+        """llkv_hip_table_append_chunks: ``chunk_rows`` new chunks behind the table's last one.  ``columns``: field id → the NEW rows of
+        that column (numpy array of the staged dtype; int64 raw values / Python ints / (n, 2) uint64 for Decimal128; a uint8 array of
+        1-byte strings or a sequence of str / None for Utf8) — every staged column must be there.  ``valid``: field id → boolean array
+        (False = NULL cell).  ``row_ids``: uint64 ids of the new rows (a table with its own ids needs them).  Queries prepared before
+        the call must be prepared again."""
+        chunk_rows = [int(r) for r in chunk_rows]
+        n_new, total = len(chunk_rows), sum(chunk_rows)
+        keep = []
+
+        def split(a):
+            out, off = [], 0
+            for r in chunk_rows:
+                out.append(a[off:off + r])
+                off += r
+            if off != len(a):
+                raise ValueError(f"{len(a)} new rows given, the new chunks hold {off}")
+            return out
+
+        def ptrs(arrs):
+            arrs = [np.ascontiguousarray(a) for a in arrs]
+            keep.append(arrs)
+            p = (C.c_void_p * max(1, len(arrs)))(*[a.ctypes.data if a.size else None for a in arrs])
+            keep.append(p)
+            return C.cast(p, C.POINTER(C.c_void_p))
+        valid = dict(valid or {})
+        cc = (abi.CColumnChunks * max(1, len(columns)))()
+        for i, (fid, vals) in enumerate(columns.items()):
+            cc[i].field_id = fid
+            if fid in self._utf8_fields:
+                if isinstance(vals, np.ndarray) and vals.dtype == np.uint8:
+                    offs = [np.arange(r + 1, dtype=np.int32) for r in chunk_rows]
+                    dats = [np.ascontiguousarray(c) if len(c) else np.zeros(1, np.uint8) for c in split(vals)]
+                else:
+                    vals = list(vals)
+                    if fid not in valid and any(x is None for x in vals):
+                        valid[fid] = [x is not None for x in vals]
+                    offs, dats = [], []
+                    for c in split(["" if x is None else x for x in vals]):
+                        enc = [x.encode() for x in c]
+                        o = np.zeros(len(enc) + 1, dtype=np.int32)
+                        np.cumsum([len(e) for e in enc], out=o[1:])
+                        offs.append(o)
+                        dats.append(np.frombuffer(b"".join(enc) or b"\0", dtype=np.uint8).copy())
+                cc[i].offsets, cc[i].data = ptrs(offs), ptrs(dats)
+            elif fid in self._decimal_fields:
+                buf = vals if isinstance(vals, np.ndarray) and vals.ndim == 2 else \
+                    abi.i128_buffer_from_i64(vals) if isinstance(vals, np.ndarray) and vals.dtype == np.int64 else abi.i128_buffer(vals)
+                cc[i].values = ptrs(split(buf))
+            else:
+                cc[i].values = ptrs(split(np.asarray(vals)))
+            if fid in valid:
+                v = np.asarray(valid[fid], dtype=bool)
+                cc[i].validity = ptrs([np.packbits(c, bitorder="little") if len(c) else np.zeros(1, np.uint8) for c in split(v)])
+        rows_arr = (C.c_uint64 * max(1, n_new))(*chunk_rows)
+        idp = None
+        if row_ids is not None:
+            idp = ptrs(split(np.ascontiguousarray(row_ids, dtype=np.uint64)))
+        check(lib().llkv_hip_table_append_chunks(self._h, rows_arr, C.c_uint32(n_new), cc, C.c_uint32(len(columns)), idp))
+        self.chunk_rows += chunk_rows
+        self.n_local_chunks += n_new
+        del total
 
     def append_arrow_column(self, field_id: int, chunks, dictionary: Optional[Sequence[str]] = None):
         """Stage a column from pyarrow arrays, one per local chunk (llkv_hip_table_append_arrow_column through the

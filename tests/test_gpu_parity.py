@@ -1337,9 +1337,13 @@ def test_division_and_modulo_match_oracle(rt, orc, abi, chunks):
         with pytest.raises(abi.LlkvError) as e:
             m.aggregate(t, None, [A.sum(col(3) % col(2))])
         assert e.value.kind == "Internal" and "Divide by zero" in e.value.message
-    with pytest.raises(abi.LlkvError) as e:  # Int / Int in a GROUP BY argument can turn Float (i64::MIN / -1): handed back
-        rt.groupby(ht, None, [6], [A.sum(col(1) / col(3))], True)
-    assert e.value.kind == "Unsupported"
+    # Int / Int in a GROUP BY argument (PlanValue: truncating, x / 0 → NULL) — taken when the statistics exclude the one pair that
+    # turns Float in the reference, i64::MIN / −1 (handed back otherwise: the table below)
+    gi = [A.sum(col(1) / col(3)), A.count(col(1) / col(3)), A.min(col(1) / col(3)), A.sum(col(1) / 7), A.sum(col(3) / 0)]
+    g, w = rt.groupby(ht, None, [6], gi, True), orc.groupby(ot, None, [6], gi, True)
+    assert [[k.value for k in r.keys] for r in g] == [[k.value for k in r.keys] for r in w]
+    for a, b in zip(g, w):
+        assert_values(a.values, b.values, "Int / Int in GROUP BY arguments")
     mn = np.array([-2**63, 5, 7] + [1] * (n - 3), dtype=np.int64)
     m1 = np.array([-1, 0, 2] + [1] * (n - 3), dtype=np.int64)
     other = np.zeros(n, dtype=np.int64)
@@ -1355,6 +1359,9 @@ def test_division_and_modulo_match_oracle(rt, orc, abi, chunks):
         assert e.value.kind == "Internal" and "overflow" in e.value.message.lower()
         r = m.aggregate(t, [F(2, O.GreaterThanOrEquals(0))], [A.sum(col(1) / col(2)), A.count(col(1) / col(2)), A.sum(col(1) % col(2) if False else col(1) / col(2) + col(3))])
         assert [x.value for x in r] == [3 + (n - 3), n - 2, 3 + (n - 3)]
+    with pytest.raises(abi.LlkvError) as e:  # i64::MIN over a column that holds −1: the group's temp column could turn Float
+        rt.groupby(ht2, None, [3], [A.sum(col(1) / col(2))], True)
+    assert e.value.kind == "Unsupported"
 
 
 @pytest.mark.parametrize("chunks", [[10], [4096, 4097, 5], [65536, 70000]])
@@ -3125,6 +3132,30 @@ def test_mvcc_visibility_fused_into_the_scan(rt, orc, abi):
         assert np.array_equal(rt.filter_row_ids(ht, [vis]), orc.filter_row_ids(ot, [vis]))
         pred = E.all_of([F(3, O.LessThan(500)), vis])
         assert_values(rt.aggregate(ht, pred, [A.count_star(), A.sum(3), A.max(3)]), orc.aggregate(ot, pred, [A.count_star(), A.sum(3), A.max(3)]), "mvcc")
+
+
+@pytest.mark.parametrize("n_uncommitted", [5, 20, 32])
+def test_mvcc_leaf_with_many_non_committed_transactions(rt, orc, abi, n_uncommitted):
+    """A busy engine: the snapshot's non-committed set holds up to 32 transaction ids (one literal slot each in the fused leaf; the
+    round-3 limit was 4).  Row versions created / deleted by committed, non-committed and the asking transaction, against the
+    oracle's RowVersion::is_visible_for; one id more than 32 is handed back."""
+    rng = np.random.default_rng(n_uncommitted)
+    n = 40_000
+    NONE = np.uint64(2**64 - 1)
+    created = rng.integers(1, 80, size=n).astype(np.uint64)
+    deleted = np.where(rng.random(n) < 0.5, NONE, rng.integers(1, 80, size=n).astype(np.uint64))
+    val = rng.integers(0, 1000, size=n).astype(np.int64)
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_UINT64, created), (2, abi.DT_UINT64, deleted), (3, abi.DT_INT64, val)], [16384, 16384, n - 32768])
+    uncommitted = [int(v) for v in rng.choice(np.arange(2, 80), size=n_uncommitted, replace=False)]
+    F, O, A = abi.Filter, abi.Operator, abi.AggregateSpec
+    for txn, snap in ((uncommitted[0], 50), (1, 70), (79, 79)):
+        vis = F(1, O.MvccVisible(2, txn_id=txn, snapshot_id=snap, uncommitted=uncommitted))
+        want = orc.filter_row_ids(ot, [vis, F(3, O.LessThan(600))])
+        assert np.array_equal(rt.filter_row_ids(ht, [vis, F(3, O.LessThan(600))]), want) and 0 < len(want) < n
+        assert_values(rt.aggregate(ht, [vis], [A.count_star(), A.sum(3)]), orc.aggregate(ot, [vis], [A.count_star(), A.sum(3)]))
+    with pytest.raises(abi.LlkvError) as e:
+        rt.aggregate(ht, [F(1, O.MvccVisible(2, txn_id=5, snapshot_id=9, uncommitted=list(range(100, 133))))], [A.count_star()])
+    assert e.value.kind == "Unsupported"
 
 
 @pytest.mark.parametrize("case", golden("mvcc.json")["cases"], ids=lambda c: c["name"])
