@@ -181,6 +181,47 @@ int main(int argc, char **argv) {
     ok = top[i].key == hg[i].key && memcmp(&top[i].sum, &hg[i].sum, 8) == 0 && top[i].payload[0] == hg[i].date;
   }
 
+  /* ---- the same star with an aggregate LIST — sum(revenue), count(*), min(l_extendedprice) — ordered by count desc, key asc:
+   *      llkv_hip_join_groupby_prepare → launch → finish → llkv_hip_join_groupby_rows (the general route; the call above is the
+   *      hand-tuned single-SUM shape).  Counts, minima, keys and payload are exact; the f64 sum is a tree per group (1e-9). */
+  llkv_expr_token price[1];
+  memset(price, 0, sizeof price);
+  price[0].kind = LLKV_TOK_COLUMN; price[0].field_id = L_EXTENDEDPRICE;
+  llkv_aggregate_spec aggs[3];
+  memset(aggs, 0, sizeof aggs);
+  aggs[0].kind = LLKV_AGG_SUM; aggs[0].expr = e; aggs[0].expr_len = 5;
+  aggs[1].kind = LLKV_AGG_COUNT_STAR;
+  aggs[2].kind = LLKV_AGG_MIN; aggs[2].expr = price; aggs[2].expr_len = 1;
+  llkv_hip_query *jq = NULL;
+  CHECK(llkv_hip_join_groupby_prepare(&fact, &dim, O_CUSTKEY, &dim2, aggs, 3, &jq));
+  CHECK(llkv_hip_query_launch(jq, NULL));
+  CHECK(llkv_hip_query_finish(jq, NULL));
+  llkv_join_order_key order[2];
+  memset(order, 0, sizeof order);
+  order[0].kind = LLKV_JOIN_ORDER_AGGREGATE; order[0].index = 1; order[0].descending = 1;
+  order[1].kind = LLKV_JOIN_ORDER_KEY;
+  llkv_hip_join_rows *jr = NULL;
+  CHECK(llkv_hip_join_groupby_rows(jq, payload, 2, order, 2, 5, &jr));
+  ok = ok && llkv_hip_join_rows_total_groups(jr) == n_hg && llkv_hip_join_rows_len(jr) == (n_hg < 5 ? n_hg : 5);
+  for (uint64_t i = 0; i < llkv_hip_join_rows_len(jr) && ok; ++i) {
+    int64_t key, pay[4];
+    uint8_t pay_null[4];
+    uint64_t pos;
+    const llkv_value *v;
+    CHECK(llkv_hip_join_rows_get(jr, i, &key, pay, pay_null, &pos, &v));
+    /* the host's figures for this order: count, minimum price, sum of the revenue */
+    uint64_t cnt = 0, h = 0;
+    double mn = 0.0, sum = 0.0;
+    while (h < n_hg && hg[h].key != key) ++h;
+    for (uint64_t r = 0; r < n_li; ++r)
+      if (l_key[r] == key && l_ship[r] > DATE_1995_03_15) { mn = cnt == 0 || l_price[r] < mn ? l_price[r] : mn; sum += l_price[r] * (1 - l_disc[r]); ++cnt; }
+    printf("  general: %10lld  count %llu  min %.2f  sum %.4f  date %d\n", (long long)key, (unsigned long long)v[1].i64, v[2].f64, v[0].f64, (int)pay[0]);
+    ok = h < n_hg && (uint64_t)v[1].i64 == cnt && v[2].f64 == mn && !pay_null[0] && pay[0] == hg[h].date &&
+         (v[0].f64 - sum <= 1e-9 * sum && sum - v[0].f64 <= 1e-9 * sum);
+  }
+  llkv_hip_join_rows_free(jr);
+  llkv_hip_query_free(jq);
+
   llkv_hip_table_free(lt); llkv_hip_table_free(ot); llkv_hip_table_free(ct);
   llkv_hip_shutdown();
   puts(ok ? "ok" : "MISMATCH");

@@ -2368,6 +2368,7 @@ int32_t orc_groupby(const orc_table *t, const llkv_filter *filters, uint32_t n_f
  * left in scan order (:1141-1214); NULL keys never match unless null_equals_null,
  * which uses the sentinel i64::MIN (:1116-1123,1429,1441); batches of ≥ batch_size
  * pairs are flushed after finishing a probe row (:1181-1193). */
+#define ORC_MAX_JOIN_KEYS 8
 typedef struct jt_entry { uint64_t head, tail; int used; } jt_entry;
 
 /* One part of a join key.  kind 0: no key (the row matches nothing); 1: a value of type `dtype` with the bit
@@ -2484,7 +2485,7 @@ typedef void (*join_pair_sink)(const uint64_t *left_rows, const uint64_t *right_
  * typed-key path, 2 executor rules. */
 static int32_t hash_join_core(const orc_table *left, const orc_table *right, const llkv_join_key *keys, uint32_t n_keys, int jt, uint64_t batch_size,
                               int fast, const join_rows *L, const join_rows *R, join_pair_sink sink, void *user) {
-  const orc_column *lcs[4], *rcs[4];
+  const orc_column *lcs[ORC_MAX_JOIN_KEYS], *rcs[ORC_MAX_JOIN_KEYS];
   for (uint32_t i = 0; i < n_keys; ++i) {
     lcs[i] = find_col(left, keys[i].left_field);
     rcs[i] = find_col(right, keys[i].right_field);
@@ -2559,7 +2560,7 @@ static int32_t join_check_options(const llkv_join_options *options, uint32_t n_k
 /* integer fast path: one key, identical integer key types (hash_join.rs:171-200); everything else takes the generic
  * typed-key path; 2 = the executor's key rules */
 static int32_t join_path(const orc_table *left, const orc_table *right, const llkv_join_key *keys, uint32_t n_keys, int executor, int *fast) {
-  if (n_keys > 4) return fail(LLKV_UNSUPPORTED, "more than four join key pairs (n_keys=%u)", n_keys);
+  if (n_keys > ORC_MAX_JOIN_KEYS) return fail(LLKV_UNSUPPORTED, "more than %d join key pairs (n_keys=%u)", ORC_MAX_JOIN_KEYS, n_keys); /* (the reference has no limit, hash_join.rs:200-335: a fixed array here) */
   const orc_column *l0 = find_col(left, keys[0].left_field), *r0 = find_col(right, keys[0].right_field);
   for (uint32_t i = 0; i < n_keys; ++i)
     if (!find_col(left, keys[i].left_field) || !find_col(right, keys[i].right_field)) return fail(LLKV_NOT_FOUND, "join key field not found");

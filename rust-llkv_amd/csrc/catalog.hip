@@ -63,14 +63,16 @@ template <class T> __global__ __launch_bounds__(256) void minmax_kernel(const T 
 
 // Float column statistics over the FINITE values (NaN / ±∞ are skipped: they travel through the sums as such):
 // out[0] = bits of the largest |v|, out[1] = bits of the smallest non-zero |v| (non-negative doubles order like their bits),
-// out[2] != 0 when some value is NaN or ±∞.
+// out[2]: bit 0 when some value is NaN or ±∞, bit 1 when some value is −0.0.
 template <class T> __global__ __launch_bounds__(256) void absrange_kernel(const T *v, uint64_t n, unsigned long long *out) {
   double hi = 0.0, lo = __builtin_inf();
-  bool wild = false;
+  bool wild = false, negz = false;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const double x = __builtin_fabs((double)v[i]);
+    const double raw = (double)v[i];
+    const double x = __builtin_fabs(raw);
     const bool finite = x < __builtin_inf();
     wild |= !finite;
+    negz |= (unsigned long long)__double_as_longlong(raw) == 0x8000000000000000ull; // −0.0: the f64 MIN / MAX keep ±0 ties in row order
     hi = (finite && x > hi) ? x : hi;
     lo = (finite && x > 0.0 && x < lo) ? x : lo;
   }
@@ -83,7 +85,8 @@ template <class T> __global__ __launch_bounds__(256) void absrange_kernel(const 
     atomicMax(&out[0], (unsigned long long)__double_as_longlong(hi));
     atomicMin(&out[1], (unsigned long long)__double_as_longlong(lo));
   }
-  if (__ballot(wild) != 0 && (threadIdx.x & 63) == 0) atomicOr(&out[2], 1ull);
+  const unsigned long long flags = (__ballot(wild) != 0 ? 1ull : 0ull) | (__ballot(negz) != 0 ? 2ull : 0ull);
+  if (flags && (threadIdx.x & 63) == 0) atomicOr(&out[2], flags);
 }
 hipError_t launch_absrange_f64(const double *values, uint64_t n, uint64_t *d_bits, hipStream_t stream) {
   hipLaunchKernelGGL((absrange_kernel<double>), dim3(1024), dim3(256), 0, stream, values, n, (unsigned long long *)d_bits);

@@ -571,6 +571,7 @@ int finalize_value(const AggOut &a, const uint64_t *g /*group lanes*/, int base,
   case AggFinal::MinF64: case AggFinal::MaxF64: {
     out->dtype = LLKV_DT_FLOAT64;
     if (rows == 0) { out->is_null = 1; return LLKV_OK; }
+    if (a.plain_minmax) { out->f64 = key_to_f64((int64_t)l[0]); return LLKV_OK; } // (no NaN, no −0.0 in the column: the order key is the answer)
     if (l[2] & 1u) { out->f64 = std::nan(""); return LLKV_OK; } // a leading NaN sticks (:1319-1330)
     const uint64_t none = a.fin == AggFinal::MinF64 ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull;
     if (l[0] == none) { out->f64 = std::nan(""); return LLKV_OK; } // unreachable: first row is not NaN

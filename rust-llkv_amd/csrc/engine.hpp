@@ -49,6 +49,7 @@ struct DeviceColumn {
   bool has_local_fstats = false; // float columns: largest finite |v| of this rank's rows (info.has_fstats / f_absmax are table-wide)
   double local_f_absmax = 0.0, local_f_absmin_nz = 0.0;
   bool local_f_all_finite = false; // … and none of this rank's values is NaN / ±∞
+  bool local_f_no_neg_zero = false; // … nor −0.0
   uint8_t *d_valid = nullptr; // 1 B/row validity mask (info.nullable), same row layout as d_values
   void *d_hi = nullptr;       // Decimal128 values beyond 64 bits (info.wide128): d_values holds the low halves, this the high halves
   bool owned = false;

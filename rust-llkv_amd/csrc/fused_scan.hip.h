@@ -223,6 +223,15 @@ __device__ __forceinline__ int64_t f64_as_i64_sat(double x) {
   return (int64_t)x;
 }
 
+// Which MIN lanes whose key grows with the row id skip the DS instruction after a thread's first contribution to a group
+// (plan_lane_first_only): 0 none (default), 1 the FirstDigits lane of computed decimal arguments, 2 also the first-row lane and the
+// first-row / first-zero lanes of the f64 MIN / MAX.  Built in r04 and measured on one box (profiles/r04/first_only_lanes.txt,
+// tools/first_only_ab.sh): the skip is an exec-masked region per lane and row, and it does NOT pay — Q1 over DECIMAL(15,2) 365.1 /
+// 364.9 / 363.5 µs under modes 0 / 1 / 2, the Float64 Q1 in first-appearance order 368.3 / 369.6 / 365.1 µs, the 12-aggregate wide
+// state 337 / 339 / 421 µs (four such lanes beside nine others: +25 %).  Kept behind the switch as the record of the experiment.
+#ifndef LLKV_FIRST_ONLY_MODE
+#define LLKV_FIRST_ONLY_MODE 0
+#endif
 enum BinKind : int { B_ADD = 1, B_SUB = 2, B_MUL = 3, B_REM = 4 };
 // sticky error codes of Ctx::err / the error lane (combined with max): 1 = arithmetic overflow, 2 = division by zero
 constexpr uint32_t kErrOverflow = 1u, kErrDivZero = 2u;
@@ -397,7 +406,7 @@ template <class V, class... Ds> struct FirstDigits {
   static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) {
     o[0] = V::eval(c, j) ? ((c.row << (6 * sizeof...(Ds))) | pack<Ds...>(c, j)) : 0x7FFFFFFFFFFFFFFFull;
   }
-  static constexpr bool first_only(int) { return true; } // the key grows with the row id: a thread's first contribution to a group is its smallest
+  static constexpr bool first_only(int) { return LLKV_FIRST_ONLY_MODE >= 1; } // the key grows with the row id: a thread's first contribution to a group is its smallest
 };
 // PlanValue Int / Int (llkv-executor/src/lib.rs:7213-7227): truncating integer division, NULL for a zero divisor.  The one pair
 // that turns Float there — i64::MIN / −1 — is excluded by the host (column statistics or a literal divisor), so the group's temp
@@ -719,8 +728,17 @@ template <class E, bool IS_MAX> struct ExtF64 {
     o[1] = (v == 0.0) ? ((c.row << 1) | (uint64_t)((uint64_t)__double_as_longlong(v) >> 63)) : 0x7FFFFFFFFFFFFFFFull;
     o[2] = (c.row << 1) | (nan ? 1u : 0u);
   }
-  static constexpr bool first_only(int k) { return k >= 1; } // lanes 1 and 2 are minima of keys that grow with the row id
+  static constexpr bool first_only(int k) { return LLKV_FIRST_ONLY_MODE >= 2 && k >= 1; } // lanes 1 and 2 are minima of keys that grow with the row id
 };
+// The same over a column that holds neither NaN nor −0.0 (staging statistics): nothing sticks, no tie depends on the row order —
+// the order key alone.
+template <class E, bool IS_MAX> struct ExtF64P {
+  static constexpr int N = 1;
+  static constexpr int op(int) { return IS_MAX ? OP_MAX_I64 : OP_MIN_I64; }
+  static __device__ __forceinline__ void contrib(Ctx &c, int j, uint64_t *o) { o[0] = (uint64_t)f64_order_key((double)E::eval(c, j)); }
+};
+template <class E> using MinF64P = ExtF64P<E, false>;
+template <class E> using MaxF64P = ExtF64P<E, true>;
 template <class E> using MinF64 = ExtF64<E, false>;
 template <class E> using MaxF64 = ExtF64<E, true>;
 
@@ -831,7 +849,7 @@ template <class... As> struct AggOps<Aggs<As...>> {
 // first-row / first-zero lanes of the f64 MIN / MAX)?
 template <class P> constexpr bool plan_lane_first_only(int k) {
   if (k == 0) return false;
-  if (P::first && k == 1) return true;
+  if (P::first && k == 1) return LLKV_FIRST_ONLY_MODE >= 2;
   return AggOps<typename P::AggT>::first_only(k - P::BASE);
 }
 template <class P> constexpr int plan_first_only_index(int k) { // how many such lanes sit before lane k

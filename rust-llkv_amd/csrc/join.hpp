@@ -50,15 +50,15 @@ struct JoinKeyPart {
   uint32_t f32_as_f64;
   uint32_t u64_high_is_null;
 };
+constexpr uint32_t kMaxJoinKeys = 8; // key pairs of one join (the reference has no limit, hash_join.rs:200-335: kernel arguments have)
 struct JoinKeySet {
-  JoinKeyPart k[4];
+  JoinKeyPart k[kMaxJoinKeys];
   uint32_t n;
   // 1 B/row mask or nullptr: a row with 0 is not part of the join at all — the reference's scan of the side dropped it
   // (NULL in every user column, GatherNullPolicy::DropNulls): it is not built, matches nothing and a LEFT / ANTI join
   // does not emit it (join_emit.cpp)
   const uint8_t *live;
 };
-constexpr uint32_t kMaxJoinKeys = 4;
 
 // Build side: distinct keys claim slots of an open-addressing table (slot_owner = row that owns the slot,
 // UINT64_MAX = empty); every build row records its slot.  All arrays are device memory.

@@ -1453,7 +1453,7 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       }
       is_f64 = dt == LLKV_DT_FLOAT64 || dt == LLKV_DT_UTF8 || dt == LLKV_DT_BOOLEAN;
     } else {
-      o.typed_by_first_value = grouped;
+      o.typed_by_first_value = grouped && !simple; // (a bare column keeps its own type: only a computed argument becomes a temp column)
     }
     // statistics that exclude i64 overflow of any prefix sum: rows · max|v| ≤ i64::MAX
     bool fast_i64 = false;
@@ -1598,6 +1598,11 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       p.aggs.push_back(o);
       continue;
     }
+    // MinFloat64 / MaxFloat64 (llkv-aggregate/src/lib.rs:1309-1331,1377-1399) fold sequentially by partial_cmp: a leading NaN sticks,
+    // ±0 ties keep the earlier row — which costs two row-order lanes beside the order key.  A bare Float64 column whose staging
+    // statistics say "no NaN / ±∞, no −0.0" has neither case: one order-key lane (a third of the DS instructions)
+    const bool plain_f64 = simple && simple_ci->dtype == LLKV_DT_FLOAT64 && simple_ci->has_fstats && simple_ci->f_all_finite && simple_ci->f_no_neg_zero &&
+                           !std::getenv("LLKV_HIP_MINMAX_ROW_ORDER");
     switch (s.kind) {
     case LLKV_AGG_SUM:
       if (is_f64) { o.fin = AggFinal::SumF64; auto g = sum_f64(node); add_agg(g.first, g.second); }
@@ -1616,11 +1621,13 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       else { o.fin = AggFinal::AvgI64; add_agg("SumI64<" + node + ">", {ADD_I64, ADD_I64, MAX_U64}); }
       break;
     case LLKV_AGG_MIN:
-      if (is_f64) { o.fin = AggFinal::MinF64; add_agg("MinF64<" + node + ">", {MIN_I64, MIN_I64, MIN_I64}); }
+      if (is_f64 && plain_f64) { o.fin = AggFinal::MinF64; o.plain_minmax = true; add_agg("MinF64P<" + node + ">", {MIN_I64}); }
+      else if (is_f64) { o.fin = AggFinal::MinF64; add_agg("MinF64<" + node + ">", {MIN_I64, MIN_I64, MIN_I64}); }
       else { o.fin = AggFinal::MinI64; add_agg("MinI64<" + node + ">", {MIN_I64}); }
       break;
     case LLKV_AGG_MAX:
-      if (is_f64) { o.fin = AggFinal::MaxF64; add_agg("MaxF64<" + node + ">", {MAX_I64, MIN_I64, MIN_I64}); }
+      if (is_f64 && plain_f64) { o.fin = AggFinal::MaxF64; o.plain_minmax = true; add_agg("MaxF64P<" + node + ">", {MAX_I64}); }
+      else if (is_f64) { o.fin = AggFinal::MaxF64; add_agg("MaxF64<" + node + ">", {MAX_I64, MIN_I64, MIN_I64}); }
       else { o.fin = AggFinal::MaxI64; add_agg("MaxI64<" + node + ">", {MAX_I64}); }
       break;
     default: return L.fail(LLKV_UNSUPPORTED, "aggregate kind " + std::to_string(s.kind));

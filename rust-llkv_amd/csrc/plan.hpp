@@ -30,6 +30,7 @@ struct ColumnInfo {
   int32_t precision = 0, scale = 0;     // LLKV_DT_DECIMAL128 (device image: the raw values narrowed to i64)
   bool nullable = false;                // some cell is NULL (row id absent from the column): a 1 B/row validity mask is staged
   bool f_all_finite = false;            // … and no NaN / ±∞ among the values (unsharded tables; agreed by share_metadata)
+  bool f_no_neg_zero = false;           // … and no −0.0: with both, MIN / MAX over the bare column need no row-order lanes (one order-key lane)
   bool has_fstats = false;              // Float64 / Float32 columns, over the finite values (staging statistics):
   double f_absmax = 0.0;                //   largest |v|
   double f_absmin_nz = 0.0;             //   smallest non-zero |v| (0: none / unknown)
@@ -67,6 +68,7 @@ struct AggOut {
                                      // non-NULL value, Int64 when there is none (llkv-executor/src/lib.rs:298-406)
   bool fast_sum = false;        // decimal sums: one wrapping lane (statistics exclude i64 overflow) instead of the 96-bit split
   bool wide = false;            // decimal sums over values beyond 64 bits: four lanes, the sums of the 32-bit limbs (SumDecWide)
+  bool plain_minmax = false;    // f64 MIN / MAX as ONE order-key lane (the column holds no NaN and no −0.0: no leading NaN to stick, no ±0 tie to break)
   bool null_without_values = false; // SumDec over DISTINCT values: NULL (not 0) when the group has none (SumDistinctDecimal128 finalize)
   int wide_delta = 0;           // MIN / MAX over such values: one MAX_U64 lane of (v − column min) [1] or (column max − v) [2] (MaxWideDelta)
   uint64_t wide_base_hi = 0, wide_base_lo = 0; // … and that column min / max

@@ -198,8 +198,9 @@ static int column_stats_device(Table &t, DeviceColumn &c) {
     std::memcpy(&c.local_f_absmax, &bits[0], 8);
     std::memcpy(&c.local_f_absmin_nz, &bits[1], 8);
     if (!std::isfinite(c.local_f_absmin_nz)) c.local_f_absmin_nz = 0.0; // no non-zero value
-    c.local_f_all_finite = bits[2] == 0;
-    if (t.world == 1) { c.info.has_fstats = true; c.info.f_absmax = c.local_f_absmax; c.info.f_absmin_nz = c.local_f_absmin_nz; c.info.f_all_finite = c.local_f_all_finite; }
+    c.local_f_all_finite = (bits[2] & 1u) == 0;
+    c.local_f_no_neg_zero = (bits[2] & 2u) == 0;
+    if (t.world == 1) { c.info.has_fstats = true; c.info.f_absmax = c.local_f_absmax; c.info.f_absmin_nz = c.local_f_absmin_nz; c.info.f_all_finite = c.local_f_all_finite; c.info.f_no_neg_zero = c.local_f_no_neg_zero; }
     return LLKV_OK;
   }
   if (c.info.dtype != LLKV_DT_INT64 && c.info.dtype != LLKV_DT_INT32 && c.info.dtype != LLKV_DT_DATE32 && c.info.dtype != LLKV_DT_DECIMAL128) return LLKV_OK;
@@ -709,11 +710,12 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
   if (t->world == 1) return LLKV_OK;
   if (!comm_ready() || comm_world() != t->world || comm_rank() != t->rank)
     return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "the table's (rank, world) is not the communicator's");
-  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; int32_t has_fstats, all_finite; double f_absmax, f_absmin_nz; };
+  struct Rec { uint32_t field; int32_t has_stats; int64_t lo, hi; int32_t nullable; uint32_t local_rows_nonzero; int32_t has_fstats, all_finite; double f_absmax, f_absmin_nz; int32_t no_neg_zero, pad_; };
   std::vector<Rec> mine;
   for (auto &kv : t->cols) // std::map: ascending field ids on every rank
     mine.push_back({kv.first, kv.second.has_local_stats ? 1 : 0, kv.second.local_min, kv.second.local_max, kv.second.info.nullable ? 1 : 0, t->local_rows ? 1u : 0u,
-                    kv.second.has_local_fstats ? 1 : 0, kv.second.local_f_all_finite ? 1 : 0, kv.second.local_f_absmax, kv.second.local_f_absmin_nz});
+                    kv.second.has_local_fstats ? 1 : 0, kv.second.local_f_all_finite ? 1 : 0, kv.second.local_f_absmax, kv.second.local_f_absmin_nz,
+                    kv.second.local_f_no_neg_zero ? 1 : 0, 0});
   std::vector<uint8_t> all;
   std::vector<uint64_t> off;
   int rc = comm_allgather_v(mine.data(), mine.size() * sizeof(Rec), &all, &off);
@@ -727,7 +729,7 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
   size_t i = 0;
   for (auto &kv : t->cols) {
     DeviceColumn &c = kv.second;
-    bool all_stats = true, all_fstats = true, any_rows = false, any_nullable = false, all_finite = true;
+    bool all_stats = true, all_fstats = true, any_rows = false, any_nullable = false, all_finite = true, no_neg_zero = true;
     int64_t lo = INT64_MAX, hi = INT64_MIN;
     double fmax = 0.0, fmin_nz = 0.0;
     for (uint32_t r = 0; r < t->world; ++r) {
@@ -736,6 +738,7 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
       if (!x.local_rows_nonzero) continue; // a rank without rows constrains nothing
       any_rows = true;
       all_finite &= x.all_finite != 0;
+      no_neg_zero &= x.no_neg_zero != 0;
       if (x.has_fstats) {
         fmax = std::max(fmax, x.f_absmax);
         if (x.f_absmin_nz > 0.0) fmin_nz = fmin_nz > 0.0 ? std::min(fmin_nz, x.f_absmin_nz) : x.f_absmin_nz;
@@ -749,6 +752,7 @@ llkv_status llkv_hip_table_share_metadata(llkv_hip_table *table) {
       c.info.f_absmax = fmax;
       c.info.f_absmin_nz = fmin_nz;
       c.info.f_all_finite = all_finite;
+      c.info.f_no_neg_zero = no_neg_zero;
     }
     if (all_stats && any_rows && lo <= hi) {
       c.info.has_stats = true;

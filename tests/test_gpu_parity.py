@@ -2112,6 +2112,68 @@ def test_composite_key_joins_match_oracle(rt, orc, abi, null_eq):
     _same_join(rt, orc, tabs, [(1, 7, null_eq[0])], 5000, jts=("inner", "semi"))
 
 
+@pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5], [65536, 40000]])
+def test_float_min_max_over_columns_without_nan_or_negative_zero(rt, orc, abi, chunks, monkeypatch):
+    """MinFloat64 / MaxFloat64 fold by partial_cmp in row order (a leading NaN sticks, ±0 ties keep the earlier row:
+    llkv-aggregate/src/lib.rs:1309-1331,1377-1399).  A bare column whose staging statistics show neither NaN / ±∞ nor −0.0 has no such
+    case and takes ONE order-key lane (`MinF64P` / `MaxF64P`); a column with a −0.0 or a NaN keeps the three row-order lanes.  Both
+    against the oracle — ungrouped, per-thread columns, shared image, sort-based — with NULL cells and +0.0 values."""
+    rng = np.random.default_rng(3 + len(chunks))
+    n = sum(chunks)
+    clean = rng.integers(-50, 50, size=n).astype(np.float64) / 4      # plenty of +0.0, no −0.0, no NaN
+    dirty = clean.copy()
+    dirty[rng.random(n) < 0.05] = -0.0
+    dirty[rng.random(n) < 0.02] = np.nan
+    valid = rng.random(n) > 0.2
+    small = rng.integers(0, 4, size=n).astype(np.int64)
+    day = rng.integers(9000, 9700, size=n).astype(np.int32)
+    sparse = (rng.integers(0, 90, size=n) * 1_000_003).astype(np.int64)
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_FLOAT64, clean, valid), (2, abi.DT_FLOAT64, dirty), (3, abi.DT_INT64, small), (4, abi.DT_DATE32, day), (5, abi.DT_INT64, sparse),
+                                       (6, abi.DT_FLOAT64, clean)], chunks)
+    A, F, O = abi.AggregateSpec, abi.Filter, abi.Operator
+    aggs = [A.min(1), A.max(1), A.min(6), A.max(6), A.min(2), A.max(2), A.count(1)]
+    pq = rt.PreparedQuery(ht, None, aggs, [3], True)
+    sig = pq.kernel_signature
+    pq.close()
+    assert "MinF64P<" in sig and "MaxF64P<" in sig and "MinF64<Col<" in sig  # clean columns: one lane; the dirty one: three
+    for order_env in (None, "1"):
+        if order_env:
+            monkeypatch.setenv("LLKV_HIP_MINMAX_ROW_ORDER", order_env)  # the row-order lanes everywhere: the same answers
+        for pred in (None, [F(3, O.GreaterThan(0))], [F(6, O.GreaterThan(1000.0))]):
+            assert_values(rt.aggregate(ht, pred, aggs), orc.aggregate(ot, pred, aggs), "ungrouped")
+            for keys in ([3], [4], [5]):
+                g, w = rt.groupby(ht, pred, keys, aggs, True), orc.groupby(ot, pred, keys, aggs, True)
+                assert [[k.value for k in r.keys] for r in g] == [[k.value for k in r.keys] for r in w]
+                for a, b in zip(g, w):
+                    for x, y in zip(a.values, b.values):
+                        assert x.is_null == y.is_null and (x.is_null or same_value(x.value, y.value) or (x.value == 0.0 and y.value == 0.0 and math.copysign(1, x.value) == math.copysign(1, y.value))), (keys, x, y)
+                        if not x.is_null and isinstance(y.value, float) and y.value == 0.0:
+                            assert math.copysign(1, x.value) == math.copysign(1, y.value), (keys, x, y)  # the sign of a zero result too
+
+
+def test_join_key_lists_of_up_to_eight_pairs(rt, orc, abi):
+    """The reference's generic path takes any number of key pairs (hash_join.rs:200-335); the kernels' key tuple holds eight (r03: four):
+    six and eight pairs of mixed types, some with NULL cells, against the oracle; a ninth pair is handed back."""
+    rng = np.random.default_rng(5)
+    chunks, n_right = [20_000, 10_001], 9_000
+    n_left = sum(chunks)
+    def cols(n, first_fid):
+        out = []
+        for k in range(8):
+            dt = (abi.DT_INT64, abi.DT_INT32, abi.DT_UINT32, abi.DT_INT64)[k % 4]
+            vals = rng.integers(0, 3, size=n).astype({abi.DT_INT64: np.int64, abi.DT_INT32: np.int32, abi.DT_UINT32: np.uint32}[dt])
+            out.append((first_fid + k, dt, vals, (rng.random(n) > 0.03) if k % 3 == 0 else None))
+        return out
+    tabs = _keyed_tables(rt, orc, abi, cols(n_left, 1), cols(n_right, 11), chunks, n_right)
+    for n_pairs in (6, 8):
+        keys = [(1 + k, 11 + k, k % 2 == 0) for k in range(n_pairs)]
+        got = _same_join(rt, orc, tabs, keys, 4096, jts=("inner", "left", "semi", "anti"))
+        assert sum(len(b[0]) for b in got) > 0
+    with pytest.raises(abi.LlkvError) as e:
+        rt.join_stream(tabs[0], tabs[1], [(1 + k % 8, 11 + k % 8, False) for k in range(9)], abi.JOIN_INNER, 4096)
+    assert e.value.kind == "Unsupported"
+
+
 def test_generic_key_types_match_oracle(rt, orc, abi):
     """Float64 keys by bit pattern, Utf8 keys through the two tables' dictionaries (with the "<NULL>" marker
     string), mismatched types (never equal), Date32 (key extraction fails: the row matches nothing)."""

@@ -8,7 +8,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/pmc"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for w in q1_sf10 q6_sf10; do
+for w in q1_sf10 q6_sf10 q1_sf10_decimal; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc "$c" --kernel-trace --output-format csv -d "$OUT/${w}_$c" -o pmc -- \
       python3 "$ROOT/bench.py" --workload "$w" --steps 10 --warmup 2 --also "" --no-cpu-baseline > "$OUT/${w}_$c.log" 2>&1
@@ -17,9 +17,9 @@ done
 python3 - "$ROOT" "$ROUND" "$OUT" <<'PY'
 import csv, glob, json, os, sys
 root, rnd, out = sys.argv[1:4]
-alg = {"q1_sf10": 59986052 * 38, "q6_sf10": 59986052 * 28}
+alg = {"q1_sf10": 59986052 * 38, "q6_sf10": 59986052 * 28, "q1_sf10_decimal": 59986052 * 38}
 doc = {}
-for w in ("q1_sf10", "q6_sf10"):
+for w in ("q1_sf10", "q6_sf10", "q1_sf10_decimal"):
     avg = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         path = glob.glob(os.path.join(out, f"{w}_{c}", "**", "*counter_collection.csv"), recursive=True)[0]
