@@ -319,3 +319,75 @@ gb = fuzz_partitioned(range(int(os.environ.get("LLKV_FUZZ_PARTITIONED", "10"))))
 print("PARTITIONED GROUP BY FAILURES:", len(gb))
 for b in gb[:10]:
     print("  ", b)
+
+
+# ---- decimal arithmetic in GROUP BY aggregate arguments (r04): random expression trees over Decimal128 / Int64 columns and integer /
+# decimal literals, random aggregate kinds, every GROUP BY route — each cell (dtype, NULL-ness, raw i128, precision, scale) against the
+# oracle; an error on one side must be the same error class on the other; LLKV_UNSUPPORTED (intermediates the statistics cannot keep in
+# 64 bits, Float operands) keeps the caller's route and is only counted
+def fuzz_decimals(seeds):
+    bad, stats = [], {"values": 0, "errors": 0, "unsupported": 0}
+    S, A, col = abi.ScalarExpr, abi.AggregateSpec, abi.col
+    ops = [abi.BIN_ADD, abi.BIN_SUB, abi.BIN_MUL, abi.BIN_DIV]
+    for seed in seeds:
+        rng = np.random.default_rng(31000 + seed)
+        n = int(rng.choice([17, 5000, 70000]))
+        chunks = [n] if n < 100 else [n // 2, n - n // 2]
+        scales = [int(rng.integers(0, 5)) for _ in range(3)]
+        mags = [int(rng.choice([10**3, 10**6, 10**9])) for _ in range(3)]
+        cols = [rng.integers(-m, m, size=n).astype(np.int64) for m in mags]
+        if rng.random() < 0.5: cols[1] = np.abs(cols[1]) + 10**int(rng.integers(0, 4))  # a column that is never zero / always positive
+        ints = rng.integers(-9, 10, size=n).astype(np.int64)
+        valid = rng.random(n) > 0.1
+        keyspace = int(rng.choice([4, 700, 90000]))
+        key = rng.integers(0, keyspace, size=n).astype(np.int64) * int(rng.choice([1, 1_000_003]))
+        ht, ot = rt.HipTable(1, chunks), orc.OracleTable(n)
+        for f, (v, sc) in enumerate(zip(cols, scales), start=1):
+            vm = valid if f == 1 else None
+            ht.append_decimal128_column(f, 18, sc, v, valid=vm)
+            ot.add(f, abi.DT_DECIMAL128, v, None if vm is None else list(vm), precision=18, scale=sc)
+        ht.append_column(4, abi.DT_INT64, ints); ot.add(4, abi.DT_INT64, ints)
+        ht.append_column(5, abi.DT_INT64, key); ot.add(5, abi.DT_INT64, key)
+
+        def leaf():
+            r = rng.random()
+            if r < 0.55: return col(int(rng.integers(1, 4)))
+            if r < 0.7: return col(4)
+            if r < 0.85: return S.literal(int(rng.integers(-3, 12)))
+            return S.literal(abi.Literal.decimal(int(rng.integers(1, 5000)), int(rng.integers(0, 4))))
+
+        def tree(depth):
+            if depth == 0 or rng.random() < 0.25: return leaf()
+            return S.binary(tree(depth - 1), int(rng.choice(ops, p=[0.3, 0.25, 0.3, 0.15])), tree(depth - 1))
+        for case in range(4):
+            e = tree(int(rng.integers(1, 4)))
+            kinds = [A.sum, A.avg, A.min, A.max, A.count, A.total]
+            aggs = [A.count_star()] + [kinds[int(i)](e) for i in rng.choice(len(kinds), size=int(rng.integers(1, 4)), replace=False)]
+            ordered = bool(rng.integers(0, 2))
+            def run(m, t):
+                try:
+                    return m.groupby(t, None, [5], aggs, ordered)
+                except abi.LlkvError as ex:
+                    return ("error", ex.kind)
+            want, got = run(orc, ot), run(rt, ht)
+            if isinstance(got, tuple) and got[1] == "Unsupported":
+                stats["unsupported"] += 1
+                continue
+            if isinstance(want, tuple) or isinstance(got, tuple):
+                if want != got: bad.append((seed, case, "outcome differs", got if isinstance(got, tuple) else "values", want if isinstance(want, tuple) else "values"))
+                else: stats["errors"] += 1
+                continue
+            if [[k.value for k in r.keys] for r in got] != [[k.value for k in r.keys] for r in want]:
+                bad.append((seed, case, "keys differ")); continue
+            diff = [(a.keys[0].value, i) for a, b in zip(got, want) for i, (x, y) in enumerate(zip(a.values, b.values))
+                    if not (x == y or (isinstance(y.value, float) and x.dtype == y.dtype and conftest.same_value(x.value, y.value, 1e-9)))]
+            if diff: bad.append((seed, case, "cells differ", diff[:3]))
+            else: stats["values"] += 1
+        print("decimals seed", seed, stats, flush=True)
+    return bad
+
+
+xb = fuzz_decimals(range(int(os.environ.get("LLKV_FUZZ_DECIMALS", "12"))))
+print("DECIMAL ARGUMENT FAILURES:", len(xb))
+for b in xb[:10]:
+    print("  ", b)

@@ -24,9 +24,11 @@ if [[ "$PART" == *a* ]]; then
     c="$(find "$f" -name '*counter_collection.csv' | head -1)"; [ -n "$c" ] && cp "$c" "$OUT/pmc_$(basename "$f")_counter_collection.csv"
   done
   echo "[pmc] done"
+  ROUND="$ROUND" bash "$ROOT/tools/bench_timeline.sh" "$ROUND" > "$OUT/bench_timeline.log" 2>&1 && cp "$ROOT/gpurun_out/$ROUND/bench_timeline.txt" "$OUT/bench_timeline.txt"; echo "[timeline] rc=$?"
+  bash "$ROOT/tools/steps_overhead.sh" > "$OUT/steps_overhead.txt" 2>&1; echo "[steps] rc=$?"
 fi
 if [[ "$PART" == *b* ]]; then
-  python3 "$ROOT/tools/q3_bench.py" sf10 > "$OUT/q3_bench.json" 2>/dev/null; echo "[q3] rc=$?"
+  python3 "$ROOT/tools/q3_bench.py" sf10 --general > "$OUT/q3_bench.json" 2>/dev/null; echo "[q3] rc=$?"
   stats q3 python3 "$ROOT/tools/q3_bench.py" sf10
   # one iteration of the pipeline kernel by kernel (start offset, duration): the busy time against the host's time
   rm -rf /tmp/prof_q3db; rocprofv3 --kernel-trace -d /tmp/prof_q3db -o q3 -- python3 "$ROOT/tools/q3_bench.py" sf10 > "$OUT/q3_timeline_rocprof.log" 2>&1
