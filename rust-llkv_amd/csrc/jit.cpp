@@ -7,6 +7,7 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <dirent.h>
@@ -389,6 +390,77 @@ extern "C" int llkv_hip_jit_rebuild_dir(const char *from, const char *to, uint32
       if (failed) ++*failed;
       continue;
     }
+    blob_append_identity(&code, blob_identity((JitKind)kind, ts, src));
+    const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+    std::ofstream o(tmp, std::ios::binary);
+    if (o) { o.write(code.data(), (std::streamsize)code.size()); o.close(); std::rename(tmp.c_str(), path.c_str()); }
+    if (built) ++*built;
+  }
+  return LLKV_OK;
+}
+
+// The plans a directory of code objects names, one "kind|type string" per line, sorted and unique → `list_path` (a text file that
+// can be TRACKED: the seed directory itself is a build artefact, and a clean checkout rebuilds it from this list —
+// llkv_hip_jit_build_list, __graft_entry__.build(), tools/refresh_jit_seed.sh list / from-list).
+extern "C" int llkv_hip_jit_list_dir(const char *from, const char *list_path, uint64_t *n_plans) {
+  if (n_plans) *n_plans = 0;
+  if (!from || !list_path) return LLKV_INVALID_ARGUMENT;
+  std::vector<std::string> ids;
+  if (DIR *d = ::opendir(from)) {
+    while (struct dirent *e = ::readdir(d)) {
+      const std::string n = e->d_name;
+      if (n.size() <= 6 || n.compare(n.size() - 6, 6, ".hsaco") != 0) continue;
+      std::ifstream f(std::string(from) + "/" + n, std::ios::binary);
+      std::vector<char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+      std::string id;
+      if (!blob_take_identity(&file, nullptr, &id)) continue;
+      const size_t nl = id.find('\n');
+      if (nl != std::string::npos && id.find('|') < nl) ids.push_back(id.substr(0, nl));
+    }
+    ::closedir(d);
+  } else {
+    return LLKV_NOT_FOUND;
+  }
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  std::ofstream o(list_path);
+  if (!o) return LLKV_INTERNAL;
+  for (const std::string &id : ids) o << id << "\n";
+  if (n_plans) *n_plans = ids.size();
+  return LLKV_OK;
+}
+
+// Compiles the plans of such a list (lines i with i % n_shards == shard; one process per shard) from the tracked kernel source of
+// THIS library into `to`, under today's keys.  No device needed.  `max_seconds` > 0: stop taking new plans after that long (what
+// is left compiles at run time, as any unseeded plan does).
+extern "C" int llkv_hip_jit_build_list(const char *list_path, const char *to, uint32_t shard, uint32_t n_shards, double max_seconds, uint64_t *built, uint64_t *failed,
+                                       uint64_t *skipped) {
+  if (built) *built = 0;
+  if (failed) *failed = 0;
+  if (skipped) *skipped = 0;
+  if (!list_path || !to || n_shards == 0) return LLKV_INVALID_ARGUMENT;
+  std::ifstream in(list_path);
+  if (!in) return LLKV_NOT_FOUND;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::string line;
+  for (size_t i = 0; std::getline(in, line); ++i) {
+    if (i % n_shards != shard || line.empty()) continue;
+    if (max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds) { if (skipped) ++*skipped; continue; }
+    const size_t bar = line.find('|');
+    if (bar == std::string::npos) continue;
+    const std::string kind_s = line.substr(0, bar), ts = line.substr(bar + 1);
+    int kind = -1;
+    for (int k = 0; k <= 8; ++k) if (kind_s == kind_name((JitKind)k)) kind = k;
+    if (kind < 0) continue;
+    const std::string src = std::string(kFusedScanSource) + wrapper_source((JitKind)kind, ts);
+    char hex[32];
+    std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(src + "\n// " + compile_identity()));
+    const std::string path = std::string(to) + "/" + hex + ".hsaco";
+    struct stat st;
+    if (::stat(path.c_str(), &st) == 0) { if (built) ++*built; continue; }
+    std::vector<char> code;
+    std::string err;
+    if (compile_to_code(src, &code, &err) != LLKV_OK) { if (failed) ++*failed; continue; } // a plan the current source no longer accepts
     blob_append_identity(&code, blob_identity((JitKind)kind, ts, src));
     const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
     std::ofstream o(tmp, std::ios::binary);
