@@ -386,6 +386,10 @@ llkv_status llkv_hip_table_append_chunks(llkv_hip_table *table, const uint64_t *
                                          const llkv_column_chunks *columns, uint32_t n_columns,
                                          const uint64_t *const *chunk_row_ids);
 uint64_t llkv_hip_table_generation(const llkv_hip_table *table); /* number of appends so far */
+/* Key images: the 4-byte copies of Int64 key columns whose statistics fit 32 bits that the join → GROUP BY pipeline builds on first
+ * use and streams in place of the 8-byte column.  Device memory the table holds beside its columns: 4 B per row
+ * and image; an append drops them.  `LLKV_HIP_JOIN_NO_KEY_IMAGE=1` turns them off.                                               */
+llkv_status llkv_hip_table_key_images(const llkv_hip_table *table, uint32_t *n_images, uint64_t *device_bytes);
 
 /* Integer column statistics (the analogue of ChunkMetadata.min/max_val_u64, llkv-column-map/src/store/
  * descriptor.rs:19-84).  Plans use them (exact SUM without overflow tracking, dense integer GROUP BY), so every

@@ -1,5 +1,6 @@
 // catalog.hip — AOT instantiations of the fused scan kernel for gfx950 plus the small
 // fixed-function kernels (octant fold, column statistics).
+#include <algorithm>
 #include <cstdlib>
 #include "catalog.hpp"
 #include "fused_scan.hip.h"
@@ -159,6 +160,22 @@ hipError_t launch_ascending_check(const void *values, uint32_t width, const Tile
   if (n_tiles == 0) return hipSuccess;
   if (width == 8) hipLaunchKernelGGL((ascending_check_kernel<int64_t>), dim3(n_tiles), dim3(256), 0, stream, (const int64_t *)values, tiles, n_tiles, flag);
   else hipLaunchKernelGGL((ascending_check_kernel<int32_t>), dim3(n_tiles), dim3(256), 0, stream, (const int32_t *)values, tiles, n_tiles, flag);
+  return hipGetLastError();
+}
+
+// Int64 → the 4-byte key image (engine.hpp: KeyImage); the caller has checked the statistics.  Two rows per thread: 16 B in, 8 B out.
+__global__ __launch_bounds__(256) void narrow_i64_kernel(const int64_t *values, uint64_t n, int32_t *out) {
+  const uint64_t pairs = n / 2, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+    const longlong2 v = reinterpret_cast<const longlong2 *>(values)[i];
+    reinterpret_cast<int2 *>(out)[i] = make_int2((int)v.x, (int)v.y);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = (int32_t)values[n - 1];
+}
+hipError_t launch_narrow_i64(const int64_t *values, uint64_t n, int32_t *out, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n / 2 + 255) / 256 + 1, 256 * 16);
+  hipLaunchKernelGGL(narrow_i64_kernel, dim3(grid), dim3(256), 0, stream, values, n, out);
   return hipGetLastError();
 }
 

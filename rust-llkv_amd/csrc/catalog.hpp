@@ -33,6 +33,7 @@ hipError_t launch_exclusive_scan(const uint64_t *in, uint64_t *out, uint32_t n, 
 
 // Column statistics (min/max of an integer column already resident in HBM).
 hipError_t launch_ascending_check(const void *values, uint32_t width /*4 or 8, signed*/, const TileDesc *tiles, uint32_t n_tiles, uint32_t *flag, hipStream_t stream);
+hipError_t launch_narrow_i64(const int64_t *values, uint64_t n, int32_t *out, hipStream_t stream); // Int64 → the 4-byte key image
 hipError_t launch_minmax_i64(const int64_t *values, uint64_t n, int64_t *d_minmax /*[2]*/, hipStream_t stream);
 hipError_t launch_minmax_i32(const int32_t *values, uint64_t n, int64_t *d_minmax /*[2]*/, hipStream_t stream);
 

@@ -77,6 +77,15 @@ struct TileSet {
   uint32_t octant_tile_begin[kOctantsHost + 1] = {0};
 };
 
+// A 4-byte image of an Int64 column whose statistics fit 32 bits (table.cpp: get_key_image): what the streaming scans of the join
+// pipeline read in place of the 8-byte column — the order-key column is a third of the bytes the Q3 probe streams, two thirds of the
+// order-bits scan's.  Built on first use (one pass: 8 B in, 4 B out per row), kept with the table, same row layout; an append
+// (a new generation) drops it.  Sparse lookups (an owner's key, a payload) stay on the column itself.
+struct KeyImage {
+  void *d = nullptr;
+  ColumnInfo info; // the column's, with dtype = Int32
+};
+
 struct Table {
   uint16_t table_id = 0;
   uint32_t rank = 0, world = 1;
@@ -89,6 +98,7 @@ struct Table {
   uint64_t dev_rows = 0;
   std::map<uint32_t, DeviceColumn> cols;
   std::map<uint32_t, TileSet> tilesets;
+  std::map<uint32_t, KeyImage> key_images;
   // Row ids that are not the positions 0 … n − 1 (llkv_hip_table_set_row_ids): the id of every local row, in the row layout of
   // the column images; nullptr = dense ids.  Everything inside works on positions; the calls that REPORT row ids translate.
   uint64_t *d_row_ids = nullptr;
@@ -278,6 +288,8 @@ int prepare_query(const Table *table, const llkv_filter *filters, uint32_t n_fil
                   uint32_t n_aggs, bool grouped, bool order_by_keys, Query **out);
 
 int get_tileset(const Table &t, uint32_t tile_rows, const TileSet **out);
+// *out = nullptr when the column does not qualify (not Int64, no statistics, a value outside 32 bits, fewer than `min_rows` rows)
+int get_key_image(const Table &t, uint32_t field, uint64_t min_rows, const KeyImage **out);
 
 // `configured_thread_count` of the reference's shared Rayon pool (llkv-threading/src/lib.rs:13-31): LLKV_MAX_THREADS
 // when it parses to a positive number, else the detected parallelism (affinity mask ∧ cgroup quota, what

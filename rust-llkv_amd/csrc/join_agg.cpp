@@ -182,7 +182,7 @@ struct JoinAgg {
   DB rank_base;  // ranked form: set bits before each chunk of 2^rank_shift bitmap words; [rank_chunks] = the number of groups
   uint32_t rank_shift = 0, rank_chunks = 0;
   const uint32_t *n_dim_ptr() const { return static_cast<const uint32_t *>(rank_base.p) + rank_chunks; }
-  uint32_t pred_err = 0;
+  uint32_t pred_err = 0, zero_err = 0;
   DB zeros;                          // one zeroed block: [0] the run flag, [8..15] the top-k selection's state words
   uint32_t *multi_p() const { return static_cast<uint32_t *>(zeros.p); }
   uint64_t *topk_state() const { return static_cast<uint64_t *>(zeros.p) + 8; }
@@ -210,6 +210,49 @@ struct JoinAgg {
   int candidates(const uint32_t *f_groups, const double *f_sums, const uint64_t *f_counts, const uint32_t *f_first_rank, uint64_t n_folded,
                  uint32_t rank, uint32_t limit, llkv_join_group_row *out_rows, uint32_t *out_n, uint64_t *out_groups);
 };
+
+// ---- key images (engine.hpp: KeyImage) ------------------------------------------------------------------------------------
+// The scans of the ranked form stream their key columns for every row.  An Int64 key whose statistics fit 32 bits is read from its
+// 4-byte image instead: the plan is lowered over a resolver that presents the field as Int32, and the slot is bound to the image.
+// Only a field that the filters and the summed expression do not name (there the column keeps its own type and buffer).
+namespace {
+bool tokens_name(const llkv_expr_token *t, uint32_t n, uint32_t field) {
+  for (uint32_t i = 0; t && i < n; ++i) if (t[i].kind == LLKV_TOK_COLUMN && t[i].field_id == field) return true;
+  return false;
+}
+bool filters_name(const llkv_filter *f, uint32_t n, uint32_t field) {
+  for (uint32_t i = 0; f && i < n; ++i) {
+    if (f[i].field_id == field) return true; // (an expression filter leaves it 0: field 0 then reads as named — the column is used as it is)
+    if (tokens_name(f[i].cmp_left, f[i].cmp_left_len, field) || tokens_name(f[i].cmp_right, f[i].cmp_right_len, field)) return true;
+    for (uint32_t k = 0; f[i].list_exprs && k < f[i].list_len; ++k) if (tokens_name(f[i].list_exprs[k], f[i].list_expr_lens[k], field)) return true;
+  }
+  return false;
+}
+struct ImageBinds {
+  const Table *t = nullptr;
+  std::vector<std::pair<uint32_t, const KeyImage *>> of;
+  const ColumnInfo *resolve(uint32_t fid) const {
+    for (const auto &b : of) if (b.first == fid) return &b.second->info;
+    auto it = t->cols.find(fid);
+    return it == t->cols.end() ? nullptr : &it->second.info;
+  }
+  const void *buffer(const LoweredPlan &lp, size_t slot) const {
+    const uint8_t part = slot < lp.slot_is_valid.size() ? lp.slot_is_valid[slot] : 0;
+    if (part == 0) for (const auto &b : of) if (b.first == lp.slot_fields[slot]) return b.second->d;
+    return slot_buffer(t->cols, lp, slot);
+  }
+  int add(uint32_t field, const llkv_filter *f, uint32_t nf, const llkv_expr_token *e = nullptr, uint32_t ne = 0) {
+    if (std::getenv("LLKV_HIP_JOIN_NO_KEY_IMAGE") || filters_name(f, nf, field) || tokens_name(e, ne, field)) return LLKV_OK;
+    for (const auto &b : of) if (b.first == field) return LLKV_OK;
+    const KeyImage *img = nullptr;
+    uint64_t min_rows = 1u << 20; // below that the scans are a few µs whatever they read
+    if (const char *e = std::getenv("LLKV_HIP_KEY_IMAGE_MIN_ROWS")) min_rows = (uint64_t)std::atoll(e);
+    const int rc = get_key_image(*t, field, min_rows, &img);
+    if (!rc && img) of.emplace_back(field, img);
+    return rc;
+  }
+};
+} // namespace
 
 int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint32_t dim_fk_field, const llkv_join_side *dim2,
                      const uint32_t *payload_fields, uint32_t n_payload_, const llkv_expr_token *sum_expr, uint32_t sum_expr_len, bool defer) {
@@ -267,22 +310,45 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   LoweredPlan dim_kp;
   JitKernel dim_kk;
   const TileSet *dim_ts = nullptr;
+  ImageBinds img_d, img_f;
+  img_d.t = td;
+  img_f.t = tf;
   if (ranked) {
-    auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * {
-      auto it = td->cols.find(fid);
-      return it == td->cols.end() ? nullptr : &it->second.info;
-    };
+    // (the dimension's key and its foreign key into dim2 from their 4-byte images when the statistics allow: 20 → 12 B per order)
+    if ((rc = img_d.add(dim->key_field, dim->filters, dim->n_filters)) || (t2 && (rc = img_d.add(dim_fk_field, dim->filters, dim->n_filters)))) return rc;
+    auto resolve_d = [&](uint32_t fid) -> const ColumnInfo * { return img_d.resolve(fid); };
     llkv_expr_token key_tok;
     std::memset(&key_tok, 0, sizeof key_tok);
     key_tok.kind = LLKV_TOK_COLUMN;
     key_tok.field_id = dim->key_field;
-    if ((rc = lower_emit(resolve_d, dim->filters, dim->n_filters, nullptr, 0, &key_tok, 1, &dim_kp, &err, false, nullptr, t2 ? &dim_fk_field : nullptr))) return set_error(rc, err);
+    if ((rc = lower_emit(resolve_d, dim->filters, dim->n_filters, nullptr, 0, &key_tok, 1, &dim_kp, &err, false, nullptr, t2 ? &dim_fk_field : nullptr, nullptr, true))) return set_error(rc, err);
     if ((rc = jit_compile(JitKind::KeyBits, dim_kp.type_string, &dim_kk, &err))) return set_error(rc, err);
     // 2 048-row tiles: a wave's quarter is exactly one batch of kSelUnroll steps — every load and key-set gather of the tile
     // goes out before the first use (SF10 orders: 81 µs; 4 096: 85, 8 192: 90, 16 384: 92; 1 024: 114 — half-empty batches)
     uint32_t dim_tile = 2048;
     if (const char *e = std::getenv("LLKV_HIP_KEYBITS_TILE")) { const long v = std::atol(e); if (v >= 512 && v <= 65536 && v % 512 == 0) dim_tile = (uint32_t)v; }
     if ((rc = get_tileset(*td, dim_tile, &dim_ts))) return rc;
+  }
+  // … and dim2's key-set scan with it (the fill below is 4 µs: whatever the host does between the two launches, the device waits for)
+  LoweredPlan kp2;
+  JitKernel kk2;
+  const TileSet *ts2 = nullptr;
+  bool have_kp2 = false;
+  if (t2 && fused_semi && t2->cols.find(dim2->key_field)->second.info.dtype == LLKV_DT_INT64 && t2->local_rows) {
+    auto resolve_2 = [&](uint32_t fid) -> const ColumnInfo * {
+      auto it = t2->cols.find(fid);
+      return it == t2->cols.end() ? nullptr : &it->second.info;
+    };
+    llkv_expr_token key_tok;
+    std::memset(&key_tok, 0, sizeof key_tok);
+    key_tok.kind = LLKV_TOK_COLUMN;
+    key_tok.field_id = dim2->key_field;
+    std::string ignore;
+    if (lower_emit(resolve_2, dim2->filters, dim2->n_filters, nullptr, 0, &key_tok, 1, &kp2, &ignore) == LLKV_OK &&
+        jit_compile(JitKind::KeyBits, kp2.type_string, &kk2, &ignore) == LLKV_OK) {
+      if ((rc = get_tileset(*t2, t2->local_rows < (4u << 20) ? 2048 : 8192, &ts2))) return rc;
+      have_kp2 = true;
+    }
   }
   {
     FillRanges fr;
@@ -298,39 +364,24 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   if (t2) {
     const ColumnInfo &k2_info = t2->cols.find(dim2->key_field)->second.info;
     bool bits_set = false;
-    if (fused_semi && k2_info.dtype == LLKV_DT_INT64 && t2->local_rows) {
+    if (have_kp2) {
       // the key set straight from dim2's scan: rows that pass set their bit — no selection vector, no read-back
-      auto resolve_2 = [&](uint32_t fid) -> const ColumnInfo * {
-        auto it = t2->cols.find(fid);
-        return it == t2->cols.end() ? nullptr : &it->second.info;
-      };
-      llkv_expr_token key_tok;
-      std::memset(&key_tok, 0, sizeof key_tok);
-      key_tok.kind = LLKV_TOK_COLUMN;
-      key_tok.field_id = dim2->key_field;
-      LoweredPlan kp;
-      JitKernel kk;
-      const TileSet *ts2 = nullptr;
-      if (lower_emit(resolve_2, dim2->filters, dim2->n_filters, nullptr, 0, &key_tok, 1, &kp, &err) == LLKV_OK &&
-          jit_compile(JitKind::KeyBits, kp.type_string, &kk, &err) == LLKV_OK) {
-        if ((rc = get_tileset(*t2, t2->local_rows < (4u << 20) ? 2048 : 8192, &ts2))) return rc;
-        if (!kp.always_false) {
-          ScanParams p2;
-          std::memset(&p2, 0, sizeof p2);
-          for (size_t i = 0; i < kp.slot_fields.size(); ++i) p2.col[i] = slot_buffer(t2->cols, kp, i);
-          for (size_t i = 0; i < kp.lit_i.size(); ++i) p2.lit_i[i] = kp.lit_i[i];
-          for (size_t i = 0; i < kp.lit_f.size(); ++i) p2.lit_f[i] = kp.lit_f[i];
-          p2.tiles = ts2->d_tiles;
-          p2.n_tiles = ts2->n_tiles;
-          p2.aux_out = (uint64_t *)set2_bits.bits.p;
-          p2.aux_out32 = set2_bits.flag_p + 1; // predicate-error word (read with the pair count)
-          p2.kb_min = set2_bits.kmin;
-          p2.kb_span = set2_bits.span;
-          if ((rc = jit_launch_raw(kk.fn, ts2->n_tiles, &p2, sizeof p2, s))) return rc;
-        }
-        bits_set = true;
-        key_err_flag = set2_bits.flag_p + 1;
+      if (!kp2.always_false) {
+        ScanParams p2;
+        std::memset(&p2, 0, sizeof p2);
+        for (size_t i = 0; i < kp2.slot_fields.size(); ++i) p2.col[i] = slot_buffer(t2->cols, kp2, i);
+        for (size_t i = 0; i < kp2.lit_i.size(); ++i) p2.lit_i[i] = kp2.lit_i[i];
+        for (size_t i = 0; i < kp2.lit_f.size(); ++i) p2.lit_f[i] = kp2.lit_f[i];
+        p2.tiles = ts2->d_tiles;
+        p2.n_tiles = ts2->n_tiles;
+        p2.aux_out = (uint64_t *)set2_bits.bits.p;
+        p2.aux_out32 = set2_bits.flag_p + 1; // predicate-error word (read with the pair count)
+        p2.kb_min = set2_bits.kmin;
+        p2.kb_span = set2_bits.span;
+        if ((rc = jit_launch_raw(kk2.fn, ts2->n_tiles, &p2, sizeof p2, s))) return rc;
       }
+      bits_set = true;
+      key_err_flag = set2_bits.flag_p + 1;
     }
     if (!bits_set) {
       Selection sel2;
@@ -357,7 +408,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     if (!kp.always_false && td->local_rows) {
       ScanParams pd;
       std::memset(&pd, 0, sizeof pd);
-      for (size_t i = 0; i < kp.slot_fields.size(); ++i) pd.col[i] = slot_buffer(td->cols, kp, i);
+      for (size_t i = 0; i < kp.slot_fields.size(); ++i) pd.col[i] = img_d.buffer(kp, i);
       for (size_t i = 0; i < kp.lit_i.size(); ++i) pd.lit_i[i] = kp.lit_i[i];
       for (size_t i = 0; i < kp.lit_f.size(); ++i) pd.lit_f[i] = kp.lit_f[i];
       pd.tiles = tsd->d_tiles;
@@ -433,6 +484,12 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   HashSet ht;
   bool dup = false;
   direct_form = direct;
+  // one rank, ranked form, sums straight from the stripes: the probe emits the key's bit position and the head of every run
+  // looks the rank up
+  // (… and one rank of a range form: its boundary runs are read off the stripes too, nothing of it needs the pairs compacted)
+  const bool stripes_ok = direct && !std::getenv("LLKV_HIP_JOIN_COMPACT") && ((tf->world == 1 && defer) || (range_form && !std::getenv("LLKV_HIP_JOIN_RANGE_COMPACT")));
+  keybit_stripes = ranked && stripes_ok && dt.span < (1ull << 32) && !std::getenv("LLKV_HIP_JOIN_PROBE_RANKS");
+  bool rank_in_probe = false; // such a probe needs no rank itself: its first workgroups rank the bitmap on the way (select.hip.h: probe_rank_chunk)
   if (ranked) { // the word ranks, chunk by chunk, and the chunk bases (in their last entry: the number of groups) — one launch
     rank_shift = 10;
     while (((dt.n_words + (1ull << rank_shift) - 1) >> rank_shift) > 256) ++rank_shift; // about one workgroup per CU
@@ -450,7 +507,8 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     } else {
       rank_chunks = (uint32_t)((dt.n_words + (1ull << rank_shift) - 1) >> rank_shift);
       if ((rc = dt.prefix.alloc(dt.n_words * 4)) || (rc = rank_base.alloc((size_t)(rank_chunks + 1) * 4))) return rc;
-      HIP_TRY(hj_launch_rank_words((const uint64_t *)dt.bits.p, dt.n_words, rank_shift, (uint32_t *)dt.prefix.p, (uint32_t *)rank_base.p, multi_p() + 2, s));
+      rank_in_probe = keybit_stripes && rank_chunks <= kBlock && ts->n_tiles >= rank_chunks && tf->local_rows && !std::getenv("LLKV_HIP_JOIN_RANK_LAUNCH");
+      if (!rank_in_probe) HIP_TRY(hj_launch_rank_words((const uint64_t *)dt.bits.p, dt.n_words, rank_shift, (uint32_t *)dt.prefix.p, (uint32_t *)rank_base.p, multi_p() + 2, s));
     }
     dt.from_sink = true;
     cc.rank_bits = (const uint64_t *)dt.bits.p;
@@ -473,19 +531,14 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   }
 
   // ---- fact probe-emit -------------------------------------------------------------------
-  auto resolve = [&](uint32_t fid) -> const ColumnInfo * {
-    auto it = tf->cols.find(fid);
-    return it == tf->cols.end() ? nullptr : &it->second.info;
-  };
+  // (the fact key from its 4-byte image when the statistics allow: the Q3 probe streams 8 B of every lineitem row instead of 12)
+  if (ranked && (rc = img_f.add(fact->key_field, fact->filters, fact->n_filters, sum_expr, sum_expr_len))) return rc;
+  auto resolve = [&](uint32_t fid) -> const ColumnInfo * { return img_f.resolve(fid); };
   LoweredPlan plan;
-  // one rank, ranked form, sums straight from the stripes: the probe emits the key's bit position and the head of every run
-  // looks the rank up
-  // (… and one rank of a range form: its boundary runs are read off the stripes too, nothing of it needs the pairs compacted)
-  const bool stripes_ok = direct && !std::getenv("LLKV_HIP_JOIN_COMPACT") && ((tf->world == 1 && defer) || (range_form && !std::getenv("LLKV_HIP_JOIN_RANGE_COMPACT")));
-  keybit_stripes = ranked && stripes_ok && dt.span < (1ull << 32) && !std::getenv("LLKV_HIP_JOIN_PROBE_RANKS");
   if ((rc = lower_probe(resolve, fact->filters, fact->n_filters, fact->key_field, sum_expr, sum_expr_len, &plan, &err, keybit_stripes))) return set_error(rc, err);
   if (plan.always_false || tf->local_rows == 0) {
     if (ranked) { // nothing probes: the group state still starts from zero, and the group count is wanted
+      if (rank_in_probe) HIP_TRY(hj_launch_rank_words((const uint64_t *)dt.bits.p, dt.n_words, rank_shift, (uint32_t *)dt.prefix.p, (uint32_t *)rank_base.p, multi_p() + 2, s));
       HIP_TRY(hj_launch_fill(group_state.p, (tf->world == 1 ? 1 : 3) * state_bytes, 0, s));
       if ((rc = rb.add(&n_dim_dev, n_dim_ptr(), 4, s)) || (rc = rb.wait())) return rc;
       n_dim = n_dim_dev;
@@ -495,9 +548,16 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   }
   JitKernel k;
   if ((rc = jit_compile(JitKind::Probe, plan.type_string, &k, &err))) return set_error(rc, err);
+  if (rank_in_probe) { // a helper may wait for the ranking workgroups: all of them and the helpers must fit on the device together
+    int per_cu = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn2, (int)kBlock, 0) != hipSuccess || (uint64_t)per_cu * g_ctx.cu_count < (uint64_t)rank_chunks + 64) {
+      rank_in_probe = false;
+      HIP_TRY(hj_launch_rank_words((const uint64_t *)dt.bits.p, dt.n_words, rank_shift, (uint32_t *)dt.prefix.p, (uint32_t *)rank_base.p, multi_p() + 2, s));
+    }
+  }
   ScanParams p;
   std::memset(&p, 0, sizeof p);
-  for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = slot_buffer(tf->cols, plan, i);
+  for (size_t i = 0; i < plan.slot_fields.size(); ++i) p.col[i] = img_f.buffer(plan, i);
   for (size_t i = 0; i < plan.lit_i.size(); ++i) p.lit_i[i] = plan.lit_i[i];
   for (size_t i = 0; i < plan.lit_f.size(); ++i) p.lit_f[i] = plan.lit_f[i];
   p.tiles = ts->d_tiles;
@@ -520,6 +580,18 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
       p.zero_words = (uint64_t *)group_state.p;
       p.zero_stride = state_bytes / 8;
       p.zero_n = n_dim_ptr();
+      if (rank_in_probe) {
+        p.rk_bits = (const uint64_t *)dt.bits.p;
+        p.rk_words = dt.n_words;
+        p.rk_shift = rank_shift;
+        p.rk_chunks = rank_chunks;
+        p.rk_prefix = (uint32_t *)dt.prefix.p;
+        p.rk_base = (uint32_t *)rank_base.p;
+        p.rk_state = multi_p() + 40; // four of the zeroed block's free words
+        // the helpers that zero the group state: workgroups of the second round of dispatch
+        p.rk_helpers = std::min<uint32_t>(64, ts->n_tiles);
+        p.rk_help_first = std::min<uint32_t>(5 * g_ctx.cu_count, ts->n_tiles - p.rk_helpers);
+      }
     }
   } else {
     p.ht_owner = (const unsigned long long *)ht.owner.p;
@@ -560,7 +632,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
     if ((rc = rb.add(boundary_raw.data(), boundary_d.p, boundary_raw.size() * 8, s))) return rc;
     if (from_stripes && (rc = rb.add(&n_pairs, total_pairs_p(), 8, s))) return rc;
   }
-  if ((!from_stripes && (rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s))) || (from_stripes && (rc = rb.add(&pred_err, multi_p() + 1, 4, s))) ||
+  if ((!from_stripes && (rc = rb.add(&n_pairs, (uint64_t *)offsets.p + n_slots, 8, s))) || (from_stripes && (rc = rb.add(&pred_err, multi_p() + 1, 4, s))) || (rank_in_probe && (rc = rb.add(&zero_err, multi_p() + 43, 4, s))) ||
       (direct && (rc = rb.add(&dup_keys, dt.flag_p, 4, s))) || (key_err_flag && (rc = rb.add(&key_err, key_err_flag, 4, s))) ||
       (dim_err_flag && (rc = rb.add(&dim_err, dim_err_flag, 4, s))) || (ranked && (rc = rb.add(&n_dim_dev, n_dim_ptr(), 4, s))) ||
       (range_form && (rc = rb.add(&desc_run, multi_p() + 3, 4, s))) ||
@@ -607,6 +679,7 @@ int JoinAgg::settle(bool delivered) {
   if (!delivered && (rc = rb.wait())) return rc;
   pending = false;
   hipStream_t s = g_ctx.stream;
+  if (zero_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "join pipeline: the group state was not zeroed (a probe workgroup gave up waiting for the group count)"); }
   if (key_err || pred_err || dim_err) { n_pairs = 0; return set_error(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened in a comparison"); }
   if (ranked) n_dim = n_dim_dev; // the bound that sized the group state → the number of groups
   if (dup_keys) { n_pairs = 0; return set_error(LLKV_UNSUPPORTED, "dimension key is not unique: groups are not identified by the dim row"); }

@@ -1929,7 +1929,7 @@ int lower_selection_in_set(const ColumnResolver &resolve, const llkv_filter *fil
 
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err,
-               bool allow_f64, bool *is_f64_out, const uint32_t *in_set_field, int32_t *key_dtype) {
+               bool allow_f64, bool *is_f64_out, const uint32_t *in_set_field, int32_t *key_dtype, bool int32_value) {
   *out = LoweredPlan{};
   Lowering L{resolve, *out, err, false};
   std::string pred, val;
@@ -1957,9 +1957,10 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     // caller takes them (key_dtype), Str by its dictionary code (the staged dictionary holds every string once), Bool,
     // Date and the 64-bit image of a Decimal by value
     const bool keyed = key_dtype && (ci->dtype == LLKV_DT_UTF8 || ci->dtype == LLKV_DT_BOOLEAN || ci->dtype == LLKV_DT_DATE32 || (ci->dtype == LLKV_DT_DECIMAL128 && !ci->wide128));
-    if (ci->dtype != LLKV_DT_INT64 && !(allow_f64 && ci->dtype == LLKV_DT_FLOAT64) && !keyed) return L.fail(LLKV_UNSUPPORTED, std::string("value emission over a ") + dtype_name(ci->dtype) + " column");
+    const bool narrow = int32_value && ci->dtype == LLKV_DT_INT32;
+    if (ci->dtype != LLKV_DT_INT64 && !(allow_f64 && ci->dtype == LLKV_DT_FLOAT64) && !keyed && !narrow) return L.fail(LLKV_UNSUPPORTED, std::string("value emission over a ") + dtype_name(ci->dtype) + " column");
     val = L.col_node(slot, ci->dtype);
-    if (keyed && ci->dtype != LLKV_DT_DECIMAL128) val = "ToI64<" + val + ">";
+    if ((keyed && ci->dtype != LLKV_DT_DECIMAL128) || narrow) val = "ToI64<" + val + ">";
     is_f64 = ci->dtype == LLKV_DT_FLOAT64;
     if (key_dtype) *key_dtype = ci->dtype;
   } else {

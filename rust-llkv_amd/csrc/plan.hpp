@@ -171,7 +171,8 @@ int lower_probe(const ColumnResolver &resolve, const llkv_filter *filters, uint3
 // `allow_f64`: Float64 arguments are emitted as bit images (DISTINCT aggregates); *is_f64 reports the type.
 int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32_t n_filters, const llkv_eval_op *ops,
                uint32_t n_ops, const llkv_expr_token *expr, uint32_t expr_len, LoweredPlan *out, std::string *err,
-               bool allow_f64 = false, bool *is_f64 = nullptr, const uint32_t *in_set_field = nullptr, int32_t *key_dtype = nullptr);
+               bool allow_f64 = false, bool *is_f64 = nullptr, const uint32_t *in_set_field = nullptr, int32_t *key_dtype = nullptr,
+               bool int32_value = false); // (int32_value: a bare Int32 column is emitted sign-extended — the key-bits scan over a key image)
 
 // Aggregates of a sort-based GROUP BY (any number of groups, any state width): "ReducePlan<Cols<…>,Aggs<…>>",
 // one wave per group over the group's rows (select.hip.h: group_reduce_body).  Lane layout per group:

@@ -125,6 +125,16 @@ struct ScanParams {
   uint64_t *zero_words;
   uint64_t zero_stride;
   const uint32_t *zero_n;
+  // … and, when the probe emits key-bit positions (it needs no rank itself), the word ranks of the dimension bitmap: the first
+  // rk_chunks (≤ kBlock) workgroups rank one chunk of 2^rk_shift words each before they turn to their tile, the last of them to
+  // finish scans the chunk totals (rk_base[rk_chunks] = the number of groups) and publishes count + 1 in rk_state[1].  The group
+  // state is then zeroed in slices by the rk_helpers workgroups from rk_help_first on, at their END (select.hip.h: probe_zero_slices)
+  // — instead of by share at the start.  rk_state: 4 zeroed words ([3]: a helper gave up waiting for the count).
+  const uint64_t *rk_bits;
+  uint64_t rk_words;
+  uint32_t rk_shift, rk_chunks;
+  uint32_t *rk_prefix, *rk_base, *rk_state;
+  uint32_t rk_help_first, rk_helpers;
 };
 
 constexpr int kMaxOuts = 8;

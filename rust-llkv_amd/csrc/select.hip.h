@@ -137,9 +137,99 @@ __device__ __forceinline__ uint32_t ht_find(const ScanParams &p, long long k) {
 // DIRECT (bitmap + rank): the lookups of the 2 · kSelUnroll rows a lane holds go out together — all bitmap words, then
 // all word ranks, then (a build list not in key order) all group ids: three round trips per step of the loop instead
 // of three per row.  Rows that do not probe read word 0.
+// Word ranks of one chunk of the dimension bitmap, by the probe workgroup of the same index (ScanParams::rk_*; the stand-alone
+// form is hj_rank_words_kernel, join.hip).  Rounds of 4 · kBlock words, a thread owns four consecutive ones.
+#ifndef LLKV_RK_EXPERIMENT
+#define LLKV_RK_EXPERIMENT 0 // (measurement only, wrong answers: 1 = no zeroing at the end)
+#endif
+__device__ __forceinline__ void probe_rank_chunk(const ScanParams &p) {
+  __shared__ uint32_t rk_wave_total[kBlock / 64];
+  __shared__ uint32_t rk_totals[kBlock];
+  __shared__ bool rk_last;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint64_t w0 = (uint64_t)blockIdx.x << p.rk_shift, w1 = w0 + (1ull << p.rk_shift) < p.rk_words ? w0 + (1ull << p.rk_shift) : p.rk_words;
+  uint32_t running = 0;
+  for (uint64_t r0 = w0; r0 < w1; r0 += 4 * kBlock) {
+    const uint64_t i = r0 + (uint64_t)t * 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = i + k < w1 ? (uint32_t)__popcll(p.rk_bits[i + k]) : 0;
+    const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+    uint32_t x = mine; // inclusive scan within the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if ((int)lane >= o) x += y;
+    }
+    if (lane == 63) rk_wave_total[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < kBlock / 64; ++w) { const uint32_t v = rk_wave_total[w]; before += w < wave ? v : 0; all += v; }
+    uint32_t at = running + before + x - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < w1) p.rk_prefix[i + k] = at;
+      at += c[k];
+    }
+    running += all;
+    __syncthreads();
+  }
+  if (t == 0) __hip_atomic_store(&p.rk_base[blockIdx.x], running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the chunk's total, for now
+  __builtin_amdgcn_s_waitcnt(0); // acknowledged before the ticket is taken (no fence: join.hip, last_workgroup)
+  __syncthreads();
+  if (t == 0) rk_last = __hip_atomic_fetch_add(&p.rk_state[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.rk_chunks - 1;
+  __syncthreads();
+  if (!rk_last) return;
+  // the last of the ranking workgroups: exclusive scan of the chunk totals in place; [rk_chunks] = all set bits = the number of groups
+  const uint32_t c = t < p.rk_chunks ? __hip_atomic_load(&p.rk_base[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  rk_totals[t] = c;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t k = 0; k < t && k < p.rk_chunks; ++k) before += rk_totals[k];
+  if (t < p.rk_chunks) p.rk_base[t] = before;
+  if (t == p.rk_chunks - 1) {
+    p.rk_base[p.rk_chunks] = before + c;
+    __hip_atomic_store(&p.rk_state[1], before + c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The group state is zeroed at the END of rk_helpers workgroups that start in the launch's second round of dispatch (they end
+// well after the count is out and long before the launch does): helper h takes the slices h, h + rk_helpers, … of 4 096 words.
+// A helper that ends before the count is out waits for it: the ranking workgroups have the lowest indices, so all of them were
+// running before any helper started, and the host launches this form only when rankers and helpers fit on the device together.
+// What this device taught on the way (profiles/r04/q3_rank_in_probe.txt): a read-modify-write of one word costs ~65 ns and they
+// queue — 7 324 workgroups taking a ticket each from one counter made the launch 480 µs longer; two dependent read-modify-writes
+// at the end of the LAST workgroups (tickets handed to whoever ends) cost 17 µs of tail: the memory system is saturated then.
+__device__ __forceinline__ void probe_zero_slices(const ScanParams &p) {
+  __shared__ uint32_t zs_n1;
+  constexpr uint32_t kSlice = 4096;
+  if (LLKV_RK_EXPERIMENT == 1) return;
+  if (blockIdx.x < p.rk_help_first || blockIdx.x >= p.rk_help_first + p.rk_helpers) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t n1 = 0;
+    for (uint32_t spin = 0; spin < (1u << 20); ++spin) { // (asked with a read-modify-write: performed where all XCDs meet, never served by this XCD's L2)
+      n1 = __hip_atomic_fetch_or(&p.rk_state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n1) break;
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (!n1) __hip_atomic_store(&p.rk_state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // gave up (seconds): the host reports it
+    zs_n1 = n1;
+  }
+  __syncthreads();
+  if (zs_n1 == 0) return;
+  const uint64_t n = zs_n1 - 1;
+  for (uint64_t lo = (uint64_t)(blockIdx.x - p.rk_help_first) * kSlice; lo < n; lo += (uint64_t)p.rk_helpers * kSlice) {
+    const uint64_t hi = lo + kSlice < n ? lo + kSlice : n;
+    for (uint32_t k = 0; k < p.zero_k; ++k)
+      for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) p.zero_words[k * p.zero_stride + i] = 0;
+  }
+}
+
 template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
-  if (p.zero_k) { // piggy-backed: this workgroup's share of the per-group state the next launch adds into
+  if (p.rk_chunks) { // (uniform) piggy-backed: the word ranks of the dimension bitmap, chunk by chunk
+    if (blockIdx.x < p.rk_chunks) probe_rank_chunk(p);
+  } else if (p.zero_k) { // piggy-backed: this workgroup's share of the per-group state the next launch adds into
     const uint64_t n = *p.zero_n, per = (n + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     for (uint32_t k = 0; k < p.zero_k; ++k)
@@ -249,6 +339,7 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
   }
   const bool any_err = __ballot(perr != 0) != 0;
   if (lane == 0) p.tile_partials[slot_idx] = base - base0 + (any_err ? kPredErrorBit : 0);
+  if (p.rk_chunks && p.zero_k) probe_zero_slices(p);
 }
 
 // ---- value-emit: the argument values of the rows that pass the predicate, in row order.  Used by the

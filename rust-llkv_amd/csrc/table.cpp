@@ -27,6 +27,7 @@ Table::~Table() {
   }
   if (d_row_ids) (void)hipFree(d_row_ids);
   for (void *p : retired) (void)hipFree(p);
+  for (auto &kv : key_images) if (kv.second.d) (void)hipFree(kv.second.d);
   for (auto &kv : tilesets) {
     if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
     if (kv.second.d_sample) (void)hipFree(kv.second.d_sample);
@@ -117,12 +118,38 @@ int get_tileset(const Table &tc, uint32_t tile_rows, const TileSet **out) {
   return LLKV_OK;
 }
 
+static const uint64_t kSlackRows = 8192; // readable rows past the image end (unrolled tail steps)
+
+int get_key_image(const Table &tc, uint32_t field, uint64_t min_rows, const KeyImage **out) {
+  *out = nullptr;
+  Table &t = const_cast<Table &>(tc);
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (t.local_rows < min_rows) return LLKV_OK;
+  auto have = t.key_images.find(field);
+  if (have != t.key_images.end()) { *out = &have->second; return LLKV_OK; }
+  auto it = t.cols.find(field);
+  if (it == t.cols.end()) return LLKV_OK;
+  const DeviceColumn &c = it->second;
+  if (c.info.dtype != LLKV_DT_INT64 || !c.info.has_stats || c.info.wide128 || !c.d_values) return LLKV_OK;
+  if (c.info.min_i < INT32_MIN || c.info.max_i > INT32_MAX) return LLKV_OK;
+  KeyImage img;
+  img.info = c.info;
+  img.info.dtype = LLKV_DT_INT32;
+  // (padding rows between chunks and the slack behind the image hold what the column holds there — zeros or copies of real rows,
+  // truncated like any other: no tile names them)
+  const uint64_t rows = t.dev_rows + kSlackRows;
+  HIP_TRY(hipMalloc(&img.d, rows * 4));
+  HIP_TRY(launch_narrow_i64((const int64_t *)c.d_values, rows, (int32_t *)img.d, g_ctx.stream));
+  auto ins = t.key_images.emplace(field, img);
+  *out = &ins.first->second;
+  return LLKV_OK;
+}
+
 uint64_t table_chunk_rows(const llkv_hip_table *table, uint32_t global_chunk) {
   const Table *t = reinterpret_cast<const Table *>(table);
   return t && global_chunk < t->global_chunk_rows.size() ? t->global_chunk_rows[global_chunk] : 0;
 }
 
-static const uint64_t kSlackRows = 8192; // readable rows past the image end (unrolled tail steps)
 
 // `rows_overwritten`: every row of the image is about to be staged over (value buffers of a table without padding rows
 // between its chunks): only the slack behind the image is zeroed — the runtime's fill moves ~130 GB/s, which made zeroing
@@ -998,6 +1025,8 @@ static int append_chunks_impl(Table *t, const uint64_t *chunk_rows, uint32_t n_n
     std::lock_guard<std::mutex> lk(t->mu);
     for (auto &kv : t->tilesets) { if (kv.second.d_tiles) t->retired.push_back(kv.second.d_tiles); if (kv.second.d_sample) t->retired.push_back(kv.second.d_sample); }
     t->tilesets.clear();
+    for (auto &kv : t->key_images) if (kv.second.d) t->retired.push_back(kv.second.d);
+    t->key_images.clear();
   }
   for (auto &kv : t->cols) {
     kv.second.info.rows = t->total_rows;
@@ -1012,6 +1041,14 @@ llkv_status llkv_hip_table_append_chunks(llkv_hip_table *table, const uint64_t *
   return (llkv_status)append_chunks_impl(reinterpret_cast<Table *>(table), chunk_rows, n_new, columns, n_columns, chunk_row_ids);
 }
 
+llkv_status llkv_hip_table_key_images(const llkv_hip_table *table, uint32_t *n_images, uint64_t *device_bytes) {
+  if (!table) return (llkv_status)set_error(LLKV_INVALID_ARGUMENT, "NULL table");
+  Table *t = const_cast<Table *>(reinterpret_cast<const Table *>(table));
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (n_images) *n_images = (uint32_t)t->key_images.size();
+  if (device_bytes) *device_bytes = t->key_images.size() * (t->dev_rows + kSlackRows) * 4;
+  return LLKV_OK;
+}
 uint64_t llkv_hip_table_generation(const llkv_hip_table *table) { return table ? reinterpret_cast<const Table *>(table)->generation : 0; }
 
 llkv_status llkv_hip_table_adopt_device_column(llkv_hip_table *table, uint32_t field_id, int32_t dtype,

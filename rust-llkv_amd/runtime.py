@@ -411,6 +411,14 @@ class HipTable:
         f.argtypes = [C.c_void_p]
         return int(f(self._h))
 
+    def key_images(self):
+        """llkv_hip_table_key_images: (images held, their device bytes)."""
+        n, b = C.c_uint32(), C.c_uint64()
+        f = lib().llkv_hip_table_key_images
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        check(f(self._h, C.byref(n), C.byref(b)))
+        return int(n.value), int(b.value)
+
     def append_chunks(self, chunk_rows: Sequence[int], columns: Dict[int, object], valid: Optional[Dict[int, object]] = None, row_ids=None):
         """llkv_hip_table_append_chunks: ``chunk_rows`` new chunks behind the table's last one.  ``columns``: field id → the NEW rows of
         that column (numpy array of the staged dtype; int64 raw values / Python ints / (n, 2) uint64 for Decimal128; a uint8 array of

@@ -2124,6 +2124,7 @@ def test_float_min_max_over_columns_without_nan_or_negative_zero(rt, orc, abi, c
     dirty = clean.copy()
     dirty[rng.random(n) < 0.05] = -0.0
     dirty[rng.random(n) < 0.02] = np.nan
+    dirty[3], dirty[7] = -0.0, np.nan  # (eleven rows may draw neither)
     valid = rng.random(n) > 0.2
     small = rng.integers(0, 4, size=n).astype(np.int64)
     day = rng.integers(9000, 9700, size=n).astype(np.int32)
@@ -2476,12 +2477,15 @@ def test_executor_rule_joins_match_oracle(rt, orc, abi):
             assert e.value.kind == "Internal"
 
 
+@pytest.mark.parametrize("key_images", [False, True])
 @pytest.mark.parametrize("rows,scale", [(60175, 0.01), (600_000, 0.1)])
-def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
+def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale, key_images, monkeypatch):
     """TPC-H Q3 shape (BASELINE.json configs[4], single GPU): customer(segment) ⋉ orders(date) ⋈ lineitem(shipdate),
     GROUP BY l_orderkey, o_orderdate, o_shippriority, SUM(price*(1-disc)), ORDER BY revenue DESC, o_orderdate LIMIT 10.
     The oracle side composes the restated operators in the executor's order (join → mask → group-by → sort → limit);
     sums add an order's lineitems in scan order on both sides, so revenue is compared bit for bit."""
+    if key_images:  # the scans read 4-byte images of the Int64 key columns (KeyImage, csrc/engine.hpp): at SF10 they do by themselves
+        monkeypatch.setenv("LLKV_HIP_KEY_IMAGE_MIN_ROWS", "1")
     D = tpch.DATE_1995_03_15
     li = tpch.gen_lineitem(rows, scale)
     n_ord = tpch.orders_for_lineitems(rows)
@@ -2507,6 +2511,7 @@ def test_q3_join_groupby_topk_matches_oracle(rt, orc, abi, tpch, rows, scale):
         ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, revenue,
         payload_fields=[tpch.O_ORDERDATE, tpch.O_SHIPPRIORITY], limit=10,
         dim_fk=tpch.O_CUSTKEY, dim2=ct, dim2_filters=[F(tpch.C_MKTSEGMENT, O.Equals("BUILDING"))], dim2_key=tpch.C_CUSTKEY)
+    assert (lt.key_images()[0], ot_.key_images()[0]) == ((1, 2) if key_images else (0, 0))
 
     # ---- oracle composition
     cust_t = orc.OracleTable(n_cust).add(tpch.C_CUSTKEY, abi.DT_INT64, cu["c_custkey"]).add(tpch.C_MKTSEGMENT, abi.DT_UTF8, seg)
@@ -2580,7 +2585,8 @@ def test_late_materialisation_and_its_eager_forms_give_the_same_bits(rt, abi, tp
     base, sigs = run_all()
     assert all(s.endswith(",0,1,%d>" % n) for s, n in zip(sigs, (3, 1, 1))), sigs  # the late form is what runs by default
     assert base[3][-1] > 0 and len(base[3]) == 11
-    for switch in ("LLKV_HIP_SCAN_NO_LATE", "LLKV_HIP_JOIN_NO_LATE", "LLKV_HIP_JOIN_PROBE_RANKS", "LLKV_HIP_TOPK_TWO_LAUNCHES"):
+    assert lt.key_images()[0] == ot_.key_images()[0] == 0  # (tables of this size read their key columns as they are)
+    for switch in ("LLKV_HIP_SCAN_NO_LATE", "LLKV_HIP_JOIN_NO_LATE", "LLKV_HIP_JOIN_PROBE_RANKS", "LLKV_HIP_TOPK_TWO_LAUNCHES", "LLKV_HIP_KEY_IMAGE_MIN_ROWS"):
         monkeypatch.setenv(switch, "1")
         if switch == "LLKV_HIP_SCAN_NO_LATE":
             monkeypatch.setenv("LLKV_HIP_TILE_ROWS", "8192")  # (the tile is the unit of the reduction: the late form's tile length)
@@ -2590,6 +2596,8 @@ def test_late_materialisation_and_its_eager_forms_give_the_same_bits(rt, abi, tp
         assert got == base, switch
         if switch == "LLKV_HIP_SCAN_NO_LATE":
             assert all(s.endswith(",0>") for s in sigs2), sigs2
+        if switch == "LLKV_HIP_KEY_IMAGE_MIN_ROWS":  # the 4-byte key images: l_orderkey; o_orderkey and o_custkey
+            assert lt.key_images()[0] == 1 and lt.key_images()[1] >= rows * 4 and ot_.key_images()[0] == 2
 
 
 @pytest.mark.parametrize("n_orders,limit", [(1500, 10), (40_000, 10), (40_000, 300)])
