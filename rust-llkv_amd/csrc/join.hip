@@ -533,33 +533,41 @@ __device__ __forceinline__ uint32_t rank_of_keybit(const RankCols &r, uint32_t d
 #ifndef LLKV_RUN_SUM_SLOTS
 #define LLKV_RUN_SUM_SLOTS 4
 #endif
-constexpr uint32_t kRunSumSlots = LLKV_RUN_SUM_SLOTS;
-// one wave = one stripe; my_best / my_groups: the best run this lane finished (as ~order key: 0 = none) and how many
-__device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
-                                                double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, const RankCols &rank, uint32_t slot,
-                                                unsigned long long &my_best, unsigned long long &my_groups, unsigned long long &my_pairs) {
-  if (slot >= n_slots) return;
-  const uint32_t lane = threadIdx.x & 63;
-  const uint64_t raw = counts[slot];
-  if (raw >= kPredErrorBit && lane == 0) atomicOr(&flags[1], 1u);
-  const uint32_t cnt = (uint32_t)(raw & (kPredErrorBit - 1));
-  if (cnt == 0) return;
-  if (lane == 0) my_pairs = cnt;
-  // the group of the pair before this stripe's first one
-  uint32_t before = 0xFFFFFFFFu;
-  for (long long s = (long long)slot - 1; s >= 0; --s) {
-    const uint32_t c = (uint32_t)(counts[s] & (kPredErrorBit - 1));
-    if (c) { before = stripe_group[(uint64_t)s * stripe + c - 1]; break; }
-  }
-  const uint32_t *grp = stripe_group + (uint64_t)slot * stripe;
-  const uint64_t *val = stripe_val + (uint64_t)slot * stripe;
-  // 64 pairs at a time through the LDS (one coalesced load): the first pair of a run then walks the run there instead
-  // of through dependent global loads — left to right, the reference's order of additions
+constexpr uint32_t kRunSumSlots = LLKV_RUN_SUM_SLOTS; // stripes of a wave, side by side: 64 / kRunSumSlots lanes each
+// A wave takes kRunSumSlots consecutive stripes (most hold a handful of pairs: what a stripe costs is its chain of dependent loads —
+// its count, the count and the last pair of the stripe before it, its pairs, the rank of every run's head, the counter of the group
+// — not its pairs), one per group of kL = 64 / kRunSumSlots lanes, SIDE BY SIDE: taken one after the other the four chains were
+// the launch (23 µs for Q3's 29 296 stripes; one stripe per wave: 26 µs — four times the waves).
+// my_best / my_groups: the best run this lane finished (as ~order key: 0 = none) and how many
+__global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
+                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank,
+                                                                   unsigned long long *slice_best, unsigned long long *total_pairs) {
+  constexpr uint32_t kL = 64 / kRunSumSlots;
+  unsigned long long my_best = 0, my_groups = 0, my_pairs = 0;
   __shared__ uint32_t lg[4][64];
   __shared__ uint64_t lv[4][64];
-  const uint32_t w = threadIdx.x >> 6;
-  for (uint32_t base = 0; base < cnt; base += 64) {
-    const uint32_t i = base + lane;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, sl = lane & (kL - 1), l0 = lane - sl;
+  const uint32_t slot = (blockIdx.x * (blockDim.x >> 6) + w) * kRunSumSlots + lane / kL;
+  uint32_t cnt = 0;
+  if (slot < n_slots) {
+    const uint64_t raw = counts[slot];
+    if (raw >= kPredErrorBit && sl == 0) atomicOr(&flags[1], 1u);
+    cnt = (uint32_t)(raw & (kPredErrorBit - 1));
+  }
+  if (sl == 0) my_pairs = cnt;
+  // the group of the pair before this stripe's first one
+  uint32_t before = 0xFFFFFFFFu;
+  if (cnt)
+    for (long long s = (long long)slot - 1; s >= 0; --s) {
+      const uint32_t c = (uint32_t)(counts[s] & (kPredErrorBit - 1));
+      if (c) { before = stripe_group[(uint64_t)s * stripe + c - 1]; break; }
+    }
+  const uint32_t *grp = stripe_group + (uint64_t)slot * stripe;
+  const uint64_t *val = stripe_val + (uint64_t)slot * stripe;
+  // kL pairs of every stripe at a time through the LDS (one coalesced load per stripe): the first pair of a run then walks the run
+  // there instead of through dependent global loads — left to right, the reference's order of additions
+  for (uint32_t base = 0; __any(base < cnt); base += kL) {
+    const uint32_t i = base + sl;
     const bool live = i < cnt;
     const uint32_t g = live ? grp[i] : 0xFFFFFFFFu;
     lg[w][lane] = g;
@@ -567,14 +575,14 @@ __device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t left = lane ? lg[w][lane - 1] : (base ? grp[base - 1] : before);
+    const uint32_t left = sl ? lg[w][lane - 1] : (base && live ? grp[base - 1] : before);
     if (live && left != g) { // the first pair of its run
       if (left != 0xFFFFFFFFu && left > g) atomicOr(&flags[3], 1u); // (key-bit positions and ranks order alike) the pair stream is not in key order
       double acc = 0.0;
       unsigned long long n = 0;
-      const uint32_t m = cnt - base < 64 ? cnt - base : 64; // pairs in this chunk
-      uint32_t j = lane;
-      for (; j < m && lg[w][j] == g; ++j) { acc += __longlong_as_double((long long)lv[w][j]); ++n; }
+      const uint32_t m = cnt - base < kL ? cnt - base : kL; // pairs of this stripe in the chunk
+      uint32_t j = sl;
+      for (; j < m && lg[w][l0 + j] == g; ++j) { acc += __longlong_as_double((long long)lv[w][l0 + j]); ++n; }
       if (j == m) { // the run may go on behind this chunk: the rest of the stripe, then the stripes that follow
         uint32_t s = slot, k = base + m, c = cnt;
         for (;;) {
@@ -593,24 +601,12 @@ __device__ __forceinline__ void run_sums_stripe(const uint32_t *stripe_group, co
       const uint32_t gid = rank.bits ? rank_of_keybit(rank, g) : g; // (one rank per run instead of one per probed row)
       if (atomicAdd(&count_by_group[gid], n) != 0) atomicOr(&flags[0], 1u);
       sum_by_group[gid] = acc;
+      if (rank.pos_out) rank.pos_out[gid] = g;
       const unsigned long long inv = ~desc_order_key(acc);
       my_best = inv > my_best ? inv : my_best;
       ++my_groups;
     }
     __builtin_amdgcn_wave_barrier(); // the chunk is overwritten next
-  }
-}
-__global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots,
-                                                                   uint32_t stripe, double *sum_by_group, unsigned long long *count_by_group, uint32_t *flags, RankCols rank,
-                                                                   unsigned long long *slice_best, unsigned long long *total_pairs) {
-  unsigned long long my_best = 0, my_groups = 0, my_pairs = 0;
-  // a wave takes kRunSumSlots consecutive stripes (most hold a handful of pairs: what a stripe costs is its wave, not its pairs)
-  const uint32_t slot0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kRunSumSlots;
-#pragma unroll 1
-  for (uint32_t k = 0; k < kRunSumSlots; ++k) {
-    unsigned long long pairs = 0;
-    run_sums_stripe(stripe_group, stripe_val, counts, n_slots, stripe, sum_by_group, count_by_group, flags, rank, slot0 + k, my_best, my_groups, pairs);
-    my_pairs += pairs;
   }
   if (slice_best) { // the top-k selection's first pass, on the way: the best sum and the number of groups of slice (workgroup mod kTopkSlices)
     __shared__ unsigned long long wb[4], wg[4], wp[4];
@@ -618,12 +614,13 @@ __global__ __launch_bounds__(256) void hj_run_sums_stripes_kernel(const uint32_t
       const unsigned long long other = __shfl_xor(my_best, o);
       my_best = other > my_best ? other : my_best;
       my_groups += __shfl_xor(my_groups, o);
+      my_pairs += __shfl_xor(my_pairs, o);
     }
     if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = my_best; wg[threadIdx.x >> 6] = my_groups; wp[threadIdx.x >> 6] = my_pairs; }
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned long long b = wb[0], g = wg[0], np = wp[0];
-      for (int w = 1; w < 4; ++w) { b = wb[w] > b ? wb[w] : b; g += wg[w]; np += wp[w]; }
+      for (int w2 = 1; w2 < 4; ++w2) { b = wb[w2] > b ? wb[w2] : b; g += wg[w2]; np += wp[w2]; }
       if (g) {
         (void)__hip_atomic_fetch_max(&slice_best[blockIdx.x & (kTopkSlices - 1)], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         (void)__hip_atomic_fetch_add(&slice_best[kTopkSlices + (blockIdx.x & (kTopkSlices - 1))], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1154,7 +1151,7 @@ template <class F> __device__ __forceinline__ uint64_t gallop_last_true(uint64_t
 __device__ __forceinline__ uint64_t group_key_bit(const CandidateCols &cols, uint32_t g);
 __device__ __forceinline__ uint64_t group_owner_row(const uint64_t *dim_rows, const CandidateCols &cols, uint32_t g) {
   if (!cols.rank_bits) return dim_rows[g];
-  const long long key = cols.rank_kmin + (long long)group_key_bit(cols, g);
+  const long long key = cols.rank_kmin + (long long)(cols.pos_by_group ? (uint64_t)cols.pos_by_group[g] : group_key_bit(cols, g));
   // the row of the ascending key column that holds it: the last row whose key is <= key
   const uint64_t last = cols.rank_rows - 1;
   const long long k0 = load_key(cols.key, 0), k1 = load_key(cols.key, last);

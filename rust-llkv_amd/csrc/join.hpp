@@ -187,6 +187,9 @@ struct RankCols {
   const uint32_t *prefix; // set bits before each word, within its chunk of 2^chunk_shift words
   const uint32_t *base;   // set bits before each chunk (nullptr: one chunk)
   uint32_t chunk_shift;
+  // optional (run sums): the head of every run leaves its key-bit position at pos_out[group] — the top-k candidates' keys are then
+  // one load away (CandidateCols::pos_by_group) instead of a search of the rank structure for the g-th set bit
+  uint32_t *pos_out = nullptr;
 };
 hipError_t hj_launch_run_sums_stripes(const uint32_t *stripe_group, const uint64_t *stripe_val, const uint64_t *counts, uint32_t n_slots, uint32_t stripe,
                                       double *sum_by_group, uint64_t *count_by_group, uint32_t *flags, hipStream_t s, RankCols rank = RankCols{nullptr, nullptr, nullptr, 0},
@@ -214,6 +217,7 @@ struct CandidateCols {
   uint64_t rank_words;
   int64_t rank_kmin;
   uint64_t rank_rows;
+  const uint32_t *pos_by_group; // optional: the key-bit position of every group that has rows (RankCols::pos_out)
 };
 hipError_t hj_launch_gather_candidates(const uint64_t *sorted_keys, const uint32_t *sorted_slots, uint32_t n, const unsigned long long *slot_owner,
                                        const double *sum_by_slot, const uint64_t *count_by_slot, CandidateCols cols, uint64_t *out /*[n][8]*/, hipStream_t s);

@@ -463,7 +463,7 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
   if (n_dim >= (1ull << 32)) return set_error(LLKV_UNSUPPORTED, "dimension too large");
   if (n_dim == 0) return error_words(key_err_flag, nullptr);
   state_bytes = (n_dim * 8 + 4095) / 4096 * 4096; // whole pages: the memset is one fill kernel
-  if ((rc = group_state.alloc(4 * state_bytes))) return rc;
+  if ((rc = group_state.alloc(5 * state_bytes))) return rc; // (the fifth: key-bit positions by group, half used — RankCols::pos_out)
   // (cnts first: the ranked form zeroes the first one — or three — arrays up to the real group count inside the probe launch)
   cnts.p = group_state.p;
   sums.p = (char *)group_state.p + state_bytes;
@@ -576,6 +576,10 @@ int JoinAgg::prepare(const llkv_join_side *fact, const llkv_join_side *dim, uint
       p.bm_base = rank_chunks > 1 ? (const uint32_t *)rank_base.p : nullptr;
       p.bm_chunk_shift = rank_shift;
       stripe_ranks = RankCols{(const uint64_t *)dt.bits.p, (const uint32_t *)dt.prefix.p, p.bm_base, rank_shift};
+      if (keybit_stripes && tf->world == 1 && !std::getenv("LLKV_HIP_JOIN_NO_GROUP_POS")) { // one rank: the candidates are read off this run's own sums
+        stripe_ranks.pos_out = (uint32_t *)((char *)group_state.p + 4 * state_bytes);
+        cc.pos_by_group = stripe_ranks.pos_out;
+      }
       p.zero_k = tf->world == 1 ? 1 : 3;
       p.zero_words = (uint64_t *)group_state.p;
       p.zero_stride = state_bytes / 8;

@@ -915,31 +915,46 @@ def join_output_names(left_columns, right_columns, join_type: int = abi.JOIN_INN
     return res
 
 
+class JoinTopk:
+    """The arguments of llkv_hip_join_groupby_topk, marshalled once (what a C caller holds anyway): ``run()`` is the call itself —
+    building the filter / token structures from Python objects costs about as much host time as the device spends on a tenth of Q3."""
+
+    def __init__(self, fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, sum_expr,
+                 payload_fields: Sequence[int] = (), limit: int = 10, dim_fk: int = 0, dim2: Optional[HipTable] = None,
+                 dim2_filters=(), dim2_key: int = 0):
+        keep = [fact, dim, dim2]
+
+        def side(table, filters, key):
+            p = CPlan(list(filters or []))
+            keep.append(p)
+            s = abi.CJoinSide()
+            s.table, s.filters, s.n_filters, s.key_field = table.handle, p.filters, p.n_filters, key
+            return s
+
+        self._f, self._d = side(fact, fact_filters, fact_key), side(dim, dim_filters, dim_key)
+        self._d2 = side(dim2, dim2_filters, dim2_key) if dim2 is not None else None
+        self._toks, self._n_toks = sum_expr.to_c(keep), len(sum_expr.tokens)
+        self._n_payload = len(payload_fields)
+        self._pay = (C.c_uint32 * max(1, self._n_payload))(*payload_fields)
+        self._limit, self._dim_fk = limit, dim_fk
+        self._rows = (abi.CJoinGroupRow * max(1, limit))()
+        self._keep = keep
+        self._fn = lib().llkv_hip_join_groupby_topk
+
+    def run(self):
+        n, total = C.c_uint32(), C.c_uint64()
+        check(self._fn(C.byref(self._f), C.byref(self._d), C.c_uint32(self._dim_fk), C.byref(self._d2) if self._d2 is not None else None, self._pay,
+                       C.c_uint32(self._n_payload), self._toks, C.c_uint32(self._n_toks), C.c_uint32(self._limit), self._rows, C.byref(n), C.byref(total)))
+        out = [(r.key, r.sum, r.count) + tuple(r.payload[i] for i in range(self._n_payload)) for r in self._rows[:n.value]]
+        return out, total.value
+
+
 def join_groupby_topk(fact: HipTable, fact_filters, fact_key: int, dim: HipTable, dim_filters, dim_key: int, sum_expr,
                       payload_fields: Sequence[int] = (), limit: int = 10, dim_fk: int = 0, dim2: Optional[HipTable] = None,
                       dim2_filters=(), dim2_key: int = 0):
     """fact ⋈ dim [⋉ dim2] GROUP BY dim key (+payload) SUM(expr) ORDER BY sum DESC, payload[0] LIMIT k
     (TPC-H Q3 shape; llkv_hip_join_groupby_topk).  Returns (rows, total_groups); rows = (key, sum, count, payload...)."""
-    keep = []
-
-    def side(table, filters, key):
-        p = CPlan(list(filters or []))
-        keep.append(p)
-        s = abi.CJoinSide()
-        s.table, s.filters, s.n_filters, s.key_field = table.handle, p.filters, p.n_filters, key
-        return s
-
-    f, d = side(fact, fact_filters, fact_key), side(dim, dim_filters, dim_key)
-    d2 = side(dim2, dim2_filters, dim2_key) if dim2 is not None else None
-    toks = sum_expr.to_c(keep)
-    pay = (C.c_uint32 * max(1, len(payload_fields)))(*payload_fields)
-    rows = (abi.CJoinGroupRow * max(1, limit))()
-    n, total = C.c_uint32(), C.c_uint64()
-    check(lib().llkv_hip_join_groupby_topk(C.byref(f), C.byref(d), C.c_uint32(dim_fk), C.byref(d2) if d2 is not None else None, pay,
-                                           C.c_uint32(len(payload_fields)), toks, C.c_uint32(len(sum_expr.tokens)), C.c_uint32(limit),
-                                           rows, C.byref(n), C.byref(total)))
-    out = [(r.key, r.sum, r.count) + tuple(r.payload[i] for i in range(len(payload_fields))) for r in rows[:n.value]]
-    return out, total.value
+    return JoinTopk(fact, fact_filters, fact_key, dim, dim_filters, dim_key, sum_expr, payload_fields, limit, dim_fk, dim2, dim2_filters, dim2_key).run()
 
 
 class JoinRow:
