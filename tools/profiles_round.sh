@@ -33,6 +33,7 @@ if [[ "$PART" == *b* ]]; then
   # one iteration of the pipeline kernel by kernel (start offset, duration): the busy time against the host's time
   rm -rf /tmp/prof_q3db; rocprofv3 --kernel-trace -d /tmp/prof_q3db -o q3 -- python3 "$ROOT/tools/q3_bench.py" sf10 > "$OUT/q3_timeline_rocprof.log" 2>&1
   db="$(find /tmp/prof_q3db -name '*_results.db' | head -1)"; [ -n "$db" ] && python3 "$ROOT/tools/rocprof_timeline.py" "$db" hj_fill_zero_ranges_kernel > "$OUT/q3_timeline.txt"
+  bash "$ROOT/tools/pmc_q3.sh" > "$OUT/pmc_q3.log" 2>&1 && cp "$ROOT/gpurun_out/pmc_q3.json" "$OUT/pmc_q3.json"; echo "[pmc q3] rc=$?"
   python3 "$ROOT/tools/groupby_bench.py" sf10 > "$OUT/groupby_bench.txt" 2>/dev/null; echo "[groupby] rc=$?"
   stats groupby python3 "$ROOT/tools/groupby_bench.py" sf10
   python3 "$ROOT/tools/scan_bench.py" > "$OUT/scan_bench.json" 2>/dev/null; echo "[scan] rc=$?"
