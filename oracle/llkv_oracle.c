@@ -705,9 +705,8 @@ static int32_t infer_simplified_type(const orc_table *t, const llkv_expr_token *
       if (e[i].binop == LLKV_BIN_DIV) *has_div = 1;
       int32_t r = common_type(st[sp - 2], st[sp - 1]);
       if (r == LLKV_DT_NULL || r == LLKV_DT_DATE32 || r == LLKV_DT_UTF8) { *rc_out = fail(LLKV_UNSUPPORTED, "unsupported operand types %s, %s", dtype_name(st[sp - 2]), dtype_name(st[sp - 1])); return LLKV_DT_NULL; }
-      /* Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference — checked i32 arithmetic and an
-       * Int32 result: not restated.  (Numeric literal pairs were folded by simplify_tokens; what is left is not numeric.) */
-      if (r == LLKV_DT_INT32 || r == LLKV_DT_UINT32) { *rc_out = fail(LLKV_UNSUPPORTED, "32-bit-only integer arithmetic"); return LLKV_DT_NULL; }
+      /* Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide — what the ROOT type is decides the fast path's kernels (eval_simplified).
+       * (Numeric literal pairs were folded by simplify_tokens; what is left is not numeric.) */
       if (i >= 2 && e[i - 1].kind == LLKV_TOK_LITERAL && e[i - 2].kind == LLKV_TOK_LITERAL) { *rc_out = fail(LLKV_UNSUPPORTED, "constant sub-expression"); return LLKV_DT_NULL; }
       sp -= 2;
       st[sp++] = r;
@@ -751,6 +750,10 @@ static arr cast_to(const arr *src, int32_t target) {
  * and a slot is only evaluated where both operands are valid.  Divide is never on the fast path (:273-275);
  * on the generic path zeros of the divisor become NULLs first (kernels.rs:121-135), then arrow `div`
  * (truncating, i64::MIN / -1 overflows). */
+/* Fast path whose target type is Int32 / UInt32 (fast_numeric.rs:333-355: binary_prim!(Int32Type) — arrow's checked 32-bit kernels).
+ * The temporaries here are 64 bits wide; the operands are within 32 bits, so + − * are exact in 64 and the reference's overflow is
+ * "the result does not fit" (1: Int32, 2: UInt32; 0: the 64-bit kernels).  Set around the fast path's loop by eval_simplified. */
+static int g_fit32 = 0;
 static int32_t binary_kernel(const arr *l, const arr *r, int32_t op, arr *out) {
   arr a;
   memset(&a, 0, sizeof a);
@@ -785,6 +788,8 @@ static int32_t binary_kernel(const arr *l, const arr *r, int32_t op, arr *out) {
         z = y == -1 ? 0 : x % y; /* mod_wrapping: i64::MIN % -1 = 0 */
         break;
       }
+      if (g_fit32 == 1 && (z < INT32_MIN || z > INT32_MAX)) ovf = 1;
+      if (g_fit32 == 2 && (z < 0 || z > (int64_t)UINT32_MAX)) ovf = 1;
       if (ovf) { arr_free(&a); return fail(LLKV_INTERNAL, "Arithmetic overflow: Overflow happened on: %lld %s %lld", (long long)x, op == LLKV_BIN_ADD ? "+" : op == LLKV_BIN_SUB ? "-" : op == LLKV_BIN_MUL ? "*" : op == LLKV_BIN_DIV ? "/" : "%", (long long)y); }
       ((int64_t *)a.values)[i] = z;
     }
@@ -823,8 +828,11 @@ static int32_t eval_simplified(const orc_table *t, const llkv_expr_token *e, uin
   int has_div, rc;
   int32_t target = infer_simplified_type(t, e, n_tok, &has_div, &rc);
   if (rc) return rc;
+  const int32_t root = target;
   if (target != LLKV_DT_FLOAT64) target = target == LLKV_DT_NULL ? LLKV_DT_NULL : LLKV_DT_INT64;
   if (target == LLKV_DT_NULL) return fail(LLKV_UNSUPPORTED, "non-numeric computed projection");
+  /* a root type of 32 bits (every leaf a column of that type) on the fast path: 32-bit checked kernels, a 32-bit result array */
+  const int fit32 = (!has_div && n_tok > 1 && root == LLKV_DT_INT32) ? 1 : (!has_div && n_tok > 1 && root == LLKV_DT_UINT32) ? 2 : 0;
   arr st[64];
   uint32_t sp = 0;
   rc = LLKV_OK;
@@ -872,6 +880,7 @@ static int32_t eval_simplified(const orc_table *t, const llkv_expr_token *e, uin
     *out = st[0];
     return LLKV_OK;
   }
+  g_fit32 = fit32;
   for (uint32_t i = 0; i < n_tok && rc == LLKV_OK; ++i) {
     switch (e[i].kind) {
     case LLKV_TOK_COLUMN: {
@@ -903,7 +912,17 @@ static int32_t eval_simplified(const orc_table *t, const llkv_expr_token *e, uin
     }
     }
   }
+  g_fit32 = 0;
   if (rc != LLKV_OK) { for (uint32_t i = 0; i < sp; ++i) arr_free(&st[i]); return rc; }
+  if (fit32) { /* the result array in its own width */
+    arr z = st[0];
+    int32_t *narrow = xmalloc((z.n ? z.n : 1) * 4);
+    for (uint64_t k = 0; k < z.n; ++k) narrow[k] = (int32_t)((int64_t *)z.values)[k]; /* (UInt32: the same low 32 bits) */
+    free(z.values);
+    z.values = narrow;
+    z.dtype = root;
+    st[0] = z;
+  }
   *out = st[0];
   return LLKV_OK;
 }
@@ -1818,6 +1837,10 @@ int32_t orc_aggregate(const orc_table *t, const llkv_filter *filters, uint32_t n
     int has_div;
     int32_t dt = infer_expr_type(t, aggs[i].expr, aggs[i].expr_len, &has_div, &rc);
     if (rc) break;
+    if (!is_simple_column(aggs[i].expr, aggs[i].expr_len) && !has_div && (dt == LLKV_DT_INT32 || dt == LLKV_DT_UINT32)) {
+      rc = fail(LLKV_UNSUPPORTED, "aggregate over a 32-bit-only integer expression (the reference has no Int32 accumulator)"); /* (its array would be Int32: not restated) */
+      break;
+    }
     if (!is_simple_column(aggs[i].expr, aggs[i].expr_len) && dt != LLKV_DT_FLOAT64) dt = LLKV_DT_INT64;
     const int is_distinct = aggs[i].distinct && aggs[i].kind != LLKV_AGG_MIN && aggs[i].kind != LLKV_AGG_MAX; /* MIN / MAX have no DISTINCT form */
     rc = is_distinct ? acc_new_distinct(aggs[i].kind, dt, &accs[i]) : acc_new(aggs[i].kind, dt, &accs[i]);
@@ -2472,9 +2495,16 @@ static int32_t join_scan_rows(const orc_table *t, const uint32_t *fields, uint32
     if (out->n > first && (!one_batch || out->n_batches == 0)) out->batch_start[out->n_batches++] = first;
   }
   out->batch_start[out->n_batches] = out->n;
-  /* a table whose every row is dropped comes out of the scan as ONE synthetic batch of NULL rows
-   * (llkv-scan/src/execute.rs:385-400, llkv-compute/src/projection.rs:36-66): not restated */
-  if (fields && t->rows && out->n == 0) { join_rows_free(out); return fail(LLKV_UNSUPPORTED, "every row of a join side is NULL in all of its user columns"); }
+  /* a table whose every row is dropped comes out of the scan as ONE synthetic batch of total_rows NULL rows
+   * (llkv-scan/src/execute.rs:355-372 `if !emitted_rows`, llkv-compute/src/projection.rs:36-66): the rows are back, every cell
+   * NULL as it was, in one batch instead of one per window */
+  if (fields && t->rows && out->n == 0) {
+    for (uint64_t r = 0; r < t->rows; ++r) out->rows[r] = r;
+    out->n = t->rows;
+    out->n_batches = 1;
+    out->batch_start[0] = 0;
+    out->batch_start[1] = out->n;
+  }
   return LLKV_OK;
 }
 

@@ -286,6 +286,24 @@ template <int OP, class L, class R, int EXACT_NAN = 0> struct Bin {
     }
   }
 };
+// A fast-path expression whose root type is Int32 / UInt32 (every leaf a column of that type, no literal: a literal is Int64) runs on
+// arrow's checked 32-bit kernels (llkv-compute/src/fast_numeric.rs:312-356).  The operands are within 32 bits, so the 64-bit result of
+// + − * is exact and the reference's overflow is "does not fit 32 bits"; rem as Bin's.  Carried in 64 bits; Narrow32 is the output column.
+template <class E, int SIGNED> struct Fit32 {
+  using Type = I64;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return E::valid(c, j); }
+  static __device__ __forceinline__ int64_t eval(Ctx &c, int j) {
+    const int64_t z = (int64_t)E::eval(c, j);
+    const bool fits = SIGNED ? (z >= -2147483648ll && z <= 2147483647ll) : (z >= 0 && z <= 4294967295ll);
+    c.err = max(c.err, (!fits & E::valid(c, j)) ? kErrOverflow : 0u);
+    return z;
+  }
+};
+template <class E, class T32> struct Narrow32 {
+  using Type = T32;
+  static __device__ __forceinline__ bool valid(Ctx &c, int j) { return E::valid(c, j); }
+  static __device__ __forceinline__ typename T32::T eval(Ctx &c, int j) { return (typename T32::T)E::eval(c, j); }
+};
 template <class L, class R> using Add = Bin<B_ADD, L, R>;
 template <class L, class R> using Sub = Bin<B_SUB, L, R>;
 template <class L, class R> using Mul = Bin<B_MUL, L, R>;

@@ -213,7 +213,7 @@ int sorted_groupby_prepare(const Table *table, const llkv_filter *filters, uint3
     if ((rc = lower_selection_in_set(resolve, filters, n_filters, key_set_field, &s->sel_plan, &err))) return set_error(rc, err);
   } else if ((rc = lower_selection(resolve, filters, n_filters, ops, n_ops, nullptr, 0, &s->sel_plan, &err))) return set_error(rc, err);
   if ((rc = lower_reduce(resolve, aggs, n_aggs, &s->red_plan, &err))) return set_error(rc, err);
-  if (s->red_plan.distinct_field >= 0 && table->world != 1)
+  if (s->red_plan.has_distinct() && table->world != 1)
     return set_error(LLKV_UNSUPPORTED, "DISTINCT aggregates inside GROUP BY over a sharded table (the ranks' partial groups cannot be merged)");
   if ((rc = jit_compile(JitKind::Reduce, s->red_plan.type_string, &s->red_kernel, &err))) return set_error(rc, err);
   *out = s.release();
@@ -283,21 +283,58 @@ int SortedGroupBy::run(LazyGroups *out) {
   ks.n = n_keys;
   // DISTINCT aggregates: their column is the least significant sort key (NULL cells first, then by value), so that
   // inside a group equal values are neighbours
-  const bool has_distinct = red_plan.distinct_field >= 0;
+  const bool has_distinct = red_plan.has_distinct();
   JoinKeyColumn dcol;
   std::memset(&dcol, 0, sizeof dcol);
   Scratch ddict; // numeric image of the dictionary a DISTINCT aggregate is over
-  if (has_distinct) {
+  // where the DISTINCT argument's cell of selection entry j lies: its device row in the column — or j itself in the values a computed
+  // argument was evaluated to (one Int64 / Float64 per selected row, PlanValue semantics: the group's temp column)
+  const uint64_t *drows = sel.d_dev;
+  Scratch dvalues, dvalid_bits, dvalid_bytes, diota, derr;
+  if (has_distinct && red_plan.distinct_proj) {
+    const LoweredPlan &proj = *red_plan.distinct_proj;
+    JitKernel pk;
+    std::string perr;
+    if ((rc = jit_compile(JitKind::Project, proj.type_string, &pk, &perr))) return set_error(rc, perr);
+    const bool nullable = !proj.out_nullable.empty() && proj.out_nullable[0];
+    if ((rc = dvalues.alloc(n * 8)) || (rc = diota.alloc(n * 8)) || (rc = derr.alloc(4)) || (nullable && ((rc = dvalid_bits.alloc((n + 63) / 64 * 8 + 8)) || (rc = dvalid_bytes.alloc(n))))) return rc;
+    ProjParams q;
+    std::memset(&q, 0, sizeof q);
+    for (size_t sl = 0; sl < proj.slot_fields.size(); ++sl) q.col[sl] = slot_buffer(table->cols, proj, sl);
+    for (size_t i = 0; i < proj.lit_i.size(); ++i) q.lit_i[i] = proj.lit_i[i];
+    for (size_t i = 0; i < proj.lit_f.size(); ++i) q.lit_f[i] = proj.lit_f[i];
+    q.dev_rows = sel.d_dev;
+    q.n = (uint32_t)n;
+    q.out[0] = dvalues.p;
+    q.out_valid[0] = nullable ? dvalid_bits.as<uint64_t>() : nullptr;
+    q.error_flag = derr.as<uint32_t>();
+    q.error_stride = 0;
+    HIP_TRY(hipMemsetAsync(derr.p, 0, 4, s));
+    if ((rc = jit_launch_raw(pk.fn, (uint32_t)((n + kBlock - 1) / kBlock), &q, sizeof q, s))) return rc;
+    if (nullable) HIP_TRY(hj_launch_bits_to_bytes(dvalid_bits.as<uint64_t>(), n, dvalid_bytes.as<uint8_t>(), s));
+    HIP_TRY(hj_launch_iota_u64(diota.as<uint64_t>(), n, 0, s));
+    uint32_t perr_bits = 0;
+    Readback rb;
+    if ((rc = rb.add(&perr_bits, derr.p, 4, s)) || (rc = rb.wait())) return rc;
+    if (perr_bits) return set_error(LLKV_INTERNAL, "Arithmetic overflow in a DISTINCT aggregate's argument");
+    dcol.values = dvalues.p;
+    dcol.valid = nullable ? dvalid_bytes.as<uint8_t>() : nullptr;
+    dcol.width = 8;
+    dcol.is_signed = 0;
+    drows = diota.as<uint64_t>();
+  } else if (has_distinct) {
     const DeviceColumn &dc = table->cols.at((uint32_t)red_plan.distinct_field);
     dcol.values = dc.d_values;
     dcol.valid = dc.info.nullable ? dc.d_valid : nullptr;
     dcol.width = dc.info.dtype == LLKV_DT_DATE32 ? 4 : (dc.info.dtype == LLKV_DT_INT64 || dc.info.dtype == LLKV_DT_FLOAT64 || dc.info.dtype == LLKV_DT_DECIMAL128) ? 8 : 1; // (the 64-bit image of a decimal; dictionary codes and Booleans: a byte)
     dcol.is_signed = dc.info.dtype == LLKV_DT_DATE32; // otherwise only equality matters: the cell's pattern (Float64: "by bit pattern", llkv-aggregate/src/lib.rs:252-331)
+  }
+  if (has_distinct) {
     if (red_plan.distinct_numeric == 1) {
       if ((rc = ddict.alloc(256 * 8))) return rc;
       HIP_TRY(hipMemcpyAsync(ddict.p, red_plan.distinct_dict_num.data(), 256 * 8, hipMemcpyHostToDevice, s)); // (the plan outlives the run)
     }
-    HIP_TRY(hj_launch_gather_sort_keys(dcol, 0, nullptr, sel.d_dev, perm, n, keys_a.as<uint64_t>(), s));
+    HIP_TRY(hj_launch_gather_sort_keys(dcol, 0, nullptr, drows, perm, n, keys_a.as<uint64_t>(), s));
     size_t tb = 0;
     const uint32_t dbits = dcol.width == 1 ? 8 : 64;
     HIP_TRY(hj_sort_u64_u32_bits(nullptr, &tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_other, n, dbits, s));
@@ -306,7 +343,7 @@ int SortedGroupBy::run(LazyGroups *out) {
     std::swap(perm, perm_other);
     if (dcol.valid) {
       if ((rc = vkeys_a.alloc(n * 4)) || (rc = vkeys_b.alloc(n * 4))) return rc;
-      HIP_TRY(hj_launch_gather_valid(dcol, sel.d_dev, perm, n, vkeys_a.as<uint32_t>(), s));
+      HIP_TRY(hj_launch_gather_valid(dcol, drows, perm, n, vkeys_a.as<uint32_t>(), s));
       size_t vb = 0;
       HIP_TRY(hj_sort_by_slot(nullptr, &vb, vkeys_a.as<uint32_t>(), vkeys_b.as<uint32_t>(), perm, perm_other, (uint32_t)n, 1, s));
       HIP_TRY(hipStreamSynchronize(s)); // tmp is in use by the sort before
@@ -436,7 +473,7 @@ int SortedGroupBy::run(LazyGroups *out) {
   Scratch dval, dhead;
   if (has_distinct) {
     if ((rc = dval.alloc(n * 8)) || (rc = dhead.alloc(n))) return rc;
-    HIP_TRY(hj_launch_distinct_heads(dcol, red_plan.distinct_numeric, ddict.as<double>(), sel.d_dev, perm, flags.as<uint64_t>(), n, dval.as<uint64_t>(), dhead.as<uint8_t>(), s));
+    HIP_TRY(hj_launch_distinct_heads(dcol, red_plan.distinct_numeric, ddict.as<double>(), drows, perm, flags.as<uint64_t>(), n, dval.as<uint64_t>(), dhead.as<uint8_t>(), s));
     p.dval = dval.as<uint64_t>();
     p.dhead = dhead.as<uint8_t>();
     p.first_rows = first_d.as<uint64_t>();

@@ -558,8 +558,9 @@ struct SideOut {
 };
 
 // live[dev row] of a side whose user columns all have NULL cells (else no row can be dropped: *live stays empty)
-int side_live_mask(const SideOut &so, DBuf *live, uint64_t *dead, hipStream_t s) {
+int side_live_mask(const SideOut &so, DBuf *live, uint64_t *dead, hipStream_t s, bool *synthetic) {
   *dead = 0;
+  *synthetic = false;
   if (!so.all_nullable || so.n() == 0 || so.t->local_rows == 0) return LLKV_OK;
   if (so.n() > 32) return set_error(LLKV_UNSUPPORTED, "more than 32 output columns that all have NULL cells");
   const TileSet *ts = nullptr;
@@ -574,9 +575,14 @@ int side_live_mask(const SideOut &so, DBuf *live, uint64_t *dead, hipStream_t s)
   HIP_TRY(hj_launch_live_mask(lc, ts->d_tiles, ts->n_tiles, (uint8_t *)live->p, (unsigned long long *)d_dead.p, s));
   Readback rb;
   if ((rc = rb.add(dead, d_dead.p, 8, s)) || (rc = rb.wait())) return rc;
-  // a table whose every row is dropped comes out of the reference's scan as ONE synthetic batch of NULL rows
-  // (llkv-scan/src/execute.rs:385-400): not restated
-  if (*dead == so.t->local_rows) return set_error(LLKV_UNSUPPORTED, "every row of a join side is NULL in all of its user columns");
+  // a table whose every row is dropped comes out of the reference's scan as ONE synthetic batch of total_rows NULL rows
+  // (llkv-scan/src/execute.rs:355-372, llkv-compute/src/projection.rs:36-66): the rows are back — every cell NULL, as it was —
+  // in one batch instead of one per 65 536-row window
+  if (*dead == so.t->local_rows) {
+    if (so.t->world != 1) return set_error(LLKV_UNSUPPORTED, "a sharded join side whose every row is NULL in all of its user columns");
+    *dead = 0;
+    *synthetic = true;
+  }
   return LLKV_OK;
 }
 
@@ -816,13 +822,21 @@ int run_join_batches(const Table *left, const Table *right, const llkv_join_key 
     if (left->world != 1 || right->world != 1) return set_error(LLKV_UNSUPPORTED, "cross product over sharded tables");
     // the two scans: all user columns, DropNulls; batches = the surviving rows of every 65 536-row-id window
     Selection rsel, lsel;
+    // (a side whose every row is NULL in all of its user columns: ONE synthetic batch of all its rows, llkv-scan/src/execute.rs:355-372)
+    bool l_one = false, r_one = false;
     if (em.R.n() && (rc = run_selection(right, nullptr, 0, nullptr, 0, &rsel, em.R.fields.data(), em.R.n()))) return rc;
-    if (em.R.n() && right->local_rows && rsel.n == 0) return set_error(LLKV_UNSUPPORTED, "every row of a join side is NULL in all of its user columns");
+    if (em.R.n() && right->local_rows && rsel.n == 0) {
+      if ((rc = run_selection(right, nullptr, 0, nullptr, 0, &rsel))) return rc;
+      r_one = true;
+    }
     const bool right_empty = rsel.n == 0;
     if (right_empty && jt == LLKV_JOIN_INNER) return LLKV_OK;
     if (em.L.n() == 0) return LLKV_OK;
     if ((rc = run_selection(left, nullptr, 0, nullptr, 0, &lsel, em.L.fields.data(), em.L.n()))) return rc;
-    if (left->local_rows && lsel.n == 0) return set_error(LLKV_UNSUPPORTED, "every row of a join side is NULL in all of its user columns");
+    if (left->local_rows && lsel.n == 0) {
+      if ((rc = run_selection(left, nullptr, 0, nullptr, 0, &lsel))) return rc;
+      l_one = true;
+    }
     auto windows = [&](const Selection &sel, std::vector<uint64_t> *start) -> int { // index of every window's first surviving row (+ end)
       std::vector<uint64_t> ids(sel.n);
       if (sel.n) { int r = fetch_to_host(ids.data(), sel.d_ids, sel.n * 8); if (r) return r; }
@@ -834,6 +848,8 @@ int run_join_batches(const Table *left, const Table *right, const llkv_join_key 
     };
     std::vector<uint64_t> lw, rw;
     if ((rc = windows(lsel, &lw)) || (rc = windows(rsel, &rw))) return rc;
+    if (l_one) lw = {0, lsel.n};
+    if (r_one) rw = {0, rsel.n};
     DBuf d_l, d_r;
     int cur = 0;
     for (size_t li = 0; li + 1 < lw.size(); ++li) {
@@ -873,7 +889,8 @@ int run_join_batches(const Table *left, const Table *right, const llkv_join_key 
   // rows the two scans drop (NULL in every user column); the executor's join reads its tables with their NULL rows
   DBuf l_live, r_live;
   uint64_t l_dead = 0, r_dead = 0;
-  if (!jp.executor && ((rc = side_live_mask(em.L, &l_live, &l_dead, s)) || (rc = side_live_mask(em.R, &r_live, &r_dead, s)))) return rc;
+  bool l_synthetic = false, r_synthetic = false; // (the build side's batches do not show in a hash join's output)
+  if (!jp.executor && ((rc = side_live_mask(em.L, &l_live, &l_dead, s, &l_synthetic)) || (rc = side_live_mask(em.R, &r_live, &r_dead, s, &r_synthetic)))) return rc;
   if (l_dead) jp.lk.live = (const uint8_t *)l_live.p;
   if (r_dead) jp.rk.live = (const uint8_t *)r_live.p;
   if (l_dead && !jp.fast && !jp.executor)
@@ -947,8 +964,8 @@ int run_join_batches(const Table *left, const Table *right, const llkv_join_key 
       };
       seg_pos.push_back(0);
       for (uint64_t row = L0; row < L1;) {
-        const uint64_t in_win = row % kRefWindow;
-        uint64_t b = row - in_win + kRefWindow;
+        const uint64_t in_win = l_synthetic ? row : row % kRefWindow; // (the synthetic batch of an all-NULL side: one window)
+        uint64_t b = l_synthetic ? left_end : row - in_win + kRefWindow;
         if (!jp.fast) b = std::min(b, row - in_win + (in_win / batch_size + 1) * batch_size);
         b = std::min(b, left_end);
         if (b > L1) { last_open = true; b = L1; }

@@ -222,6 +222,16 @@ __global__ __launch_bounds__(256) void iota_u64_kernel(uint64_t *out, uint64_t n
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = first + i;
 }
+// Arrow validity bits (bit k of word w = row 64·w + k) → the 1 B/row mask the key-cell readers take
+__global__ __launch_bounds__(256) void hj_bits_to_bytes_kernel(const uint64_t *bits, uint64_t n, uint8_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)((bits[i >> 6] >> (i & 63)) & 1ull);
+}
+hipError_t hj_launch_bits_to_bytes(const uint64_t *bits, uint64_t n, uint8_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hj_bits_to_bytes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, bits, n, out);
+  return hipGetLastError();
+}
 hipError_t hj_launch_iota_u64(uint64_t *out, uint64_t n, uint64_t first, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(iota_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, out, n, first);

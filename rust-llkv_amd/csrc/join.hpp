@@ -77,6 +77,7 @@ hipError_t hj_launch_segments(const uint32_t *sorted_slot, uint32_t n, uint32_t 
 hipError_t hj_launch_fill(void *p, uint64_t bytes, uint64_t pattern, hipStream_t s);
 hipError_t hj_launch_iota(uint32_t *out, uint32_t n, hipStream_t s);
 hipError_t hj_launch_iota_u64(uint64_t *out, uint64_t n, uint64_t first, hipStream_t s); // out[i] = first + i
+hipError_t hj_launch_bits_to_bytes(const uint64_t *bits, uint64_t n, uint8_t *out, hipStream_t s); // Arrow validity bits → 1 B/row
 // Up to four zero fills in one launch (same alignment rule).
 struct FillRanges {
   void *p[4];

@@ -202,9 +202,10 @@ double parse_numeric_or_zero(const std::string &text) {
   if (k != t.size()) return 0.0;
   return std::strtod(t.c_str(), nullptr); // a decimal literal of that grammar: both sides round it correctly
 }
+static std::string cols_string(const LoweredPlan &p, uint64_t *bytes);
 namespace {
 
-struct PlanValueInfo { bool is_decimal = false; int scale = 0; i128 lo = 0, hi = 0; };
+struct PlanValueInfo { bool is_decimal = false; int scale = 0; i128 lo = 0, hi = 0; bool bounded = false; };
 
 struct Lowering {
   const ColumnResolver &resolve;
@@ -215,6 +216,7 @@ struct Lowering {
   // NaN's bits are observable — totalOrder compares, IN lists, projected / emitted values — and left off for aggregate
   // arguments, where no accumulator looks at them (fused_scan.hip.h: f64_result_as_sse2; it costs Q1 5 %)
   bool exact_nan = false;
+  int last_fast_32 = 0; // expr_fast: the expression's root type is Int32 (1) / UInt32 (2): the nodes are wrapped in Fit32
   std::string nan_flag(bool is_float) const { return exact_nan && is_float ? ",1" : ""; }
   // shared-image plans: f64 sums as exact two-level pairs (SumF64X), which need a bound on |argument|
   bool exact_f64 = false;
@@ -787,7 +789,7 @@ struct Lowering {
     }
     bool is_f64 = false;
     const int rc = expr_fast(e, n, node, &is_f64);
-    *cls = is_f64 ? Side::F : Side::S64;
+    *cls = is_f64 ? Side::F : last_fast_32 == 1 ? Side::S32 : last_fast_32 == 2 ? Side::U32 : Side::S64;
     return rc;
   }
 
@@ -986,6 +988,7 @@ struct Lowering {
   }
 
   int expr_fast(const llkv_expr_token *e_in, uint32_t n_in, std::string *node, bool *is_f64) {
+    last_fast_32 = 0;
     std::vector<llkv_expr_token> folded;
     int frc = fold_constants(e_in, n_in, &folded);
     if (frc) return frc;
@@ -1008,15 +1011,18 @@ struct Lowering {
         if (e[i].binop == LLKV_BIN_DIV) return expr_generic(e, n, node, is_f64); // Divide leaves the fast path (fast_numeric.rs:273-275)
       }
     }
-    // Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference (checked i32 arithmetic, Int32 result)
+    // Int32 ⊕ Int32 (UInt32 ⊕ UInt32) stays 32 bits wide in the reference (checked i32 arithmetic, Int32 result): what decides is the
+    // ROOT type — columns are cast to it before the first kernel — and that is 32 bits wide only when every leaf is such a column
+    int fit32 = 0;
     if (n > 1 && !any_float && !any_u64) {
       bool all_i32 = true, all_u32 = true;
       for (uint32_t i = 0; i < n; ++i) {
         if (e[i].kind == LLKV_TOK_LITERAL) all_i32 = all_u32 = false;
         else if (e[i].kind == LLKV_TOK_COLUMN) { const int32_t dt = resolve(e[i].field_id)->dtype; all_i32 &= dt == LLKV_DT_INT32; all_u32 &= dt == LLKV_DT_UINT32; }
       }
-      if (all_i32 || all_u32) return fail(LLKV_UNSUPPORTED, "32-bit-only integer arithmetic");
+      if (all_i32 || all_u32) fit32 = all_i32 ? 1 : 2; // every node's result must fit 32 bits (Fit32, fused_scan.hip.h)
     }
+    last_fast_32 = fit32;
     for (uint32_t i = 2; i < n; ++i) // (only non-numeric literal pairs are left unfolded)
       if (e[i].kind == LLKV_TOK_BINARY && e[i - 1].kind == LLKV_TOK_LITERAL && e[i - 2].kind == LLKV_TOK_LITERAL) return fail(LLKV_UNSUPPORTED, "constant sub-expression");
     // get_common_type (llkv-compute/src/kernels.rs:179-242): a 64-bit unsigned side with a signed side → Float64
@@ -1046,7 +1052,9 @@ struct Lowering {
         std::string r = st.back(); st.pop_back();
         std::string l = st.back(); st.pop_back();
         const int op = e[i].binop == LLKV_BIN_ADD ? 1 : e[i].binop == LLKV_BIN_SUB ? 2 : e[i].binop == LLKV_BIN_MUL ? 3 : 4;
-        st.push_back("Bin<" + std::to_string(op) + "," + l + "," + r + nan_flag(any_float) + ">");
+        std::string b = "Bin<" + std::to_string(op) + "," + l + "," + r + nan_flag(any_float) + ">";
+        if (fit32) b = "Fit32<" + b + "," + (fit32 == 1 ? "1" : "0") + ">";
+        st.push_back(b);
       }
     }
     if (st.size() != 1) return fail(LLKV_INTERNAL, "fast path evaluation missing result");
@@ -1262,6 +1270,12 @@ struct Lowering {
               b = std::max(std::max(c4[0], c4[1]), std::max(c4[2], c4[3]));
             }
             if (a > -lim && b < lim && l.lo > -lim && l.hi < lim && r.lo > -lim && r.hi < lim) { o.lo = a; o.hi = b; }
+          } else if (op == 4 && l.bounded && r.bounded && l.lo > -lim && l.hi < lim && r.lo > -lim && r.hi < lim) {
+            // fmod keeps the dividend's sign and stays below the divisor in magnitude
+            const i128 ml = std::max(l.lo < 0 ? -l.lo : l.lo, l.hi < 0 ? -l.hi : l.hi), mr = std::max(r.lo < 0 ? -r.lo : r.lo, r.hi < 0 ? -r.hi : r.hi);
+            const i128 m = std::min(ml, mr > 0 ? mr - 1 : (i128)0);
+            o.lo = l.lo < 0 ? -m : 0;
+            o.hi = l.hi > 0 ? m : 0;
           }
         } else {
           const std::string a = l.f ? l.s : "ToF64<" + l.s + ">", b = r.f ? r.s : "ToF64<" + r.s + ">";
@@ -1278,6 +1292,7 @@ struct Lowering {
     last_planvalue.scale = st[0].scale;
     last_planvalue.lo = st[0].lo;
     last_planvalue.hi = st[0].hi;
+    last_planvalue.bounded = st[0].bounded && !st[0].f;
     return LLKV_OK;
   }
 };
@@ -1322,7 +1337,64 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
       if (!L.allow_sorted_distinct) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates inside GROUP BY run on the sort-based route");
       if (s.kind != LLKV_AGG_COUNT && s.kind != LLKV_AGG_SUM && s.kind != LLKV_AGG_TOTAL && s.kind != LLKV_AGG_AVG)
         return L.fail(LLKV_UNSUPPORTED, "DISTINCT form of aggregate kind " + std::to_string(s.kind));
-      if (!s.expr || s.expr_len != 1 || s.expr[0].kind != LLKV_TOK_COLUMN) return L.fail(LLKV_UNSUPPORTED, "DISTINCT inside GROUP BY over a computed argument");
+      if (!s.expr || s.expr_len == 0) return L.fail(LLKV_INVALID_ARGUMENT, "aggregate requires an argument");
+      if (s.expr_len != 1 || s.expr[0].kind != LLKV_TOK_COLUMN) {
+        // a computed argument: the group's temp column holds the PlanValue of every row (llkv-executor/src/lib.rs:5186-5199) and the
+        // distinct accumulator runs over it — Int by value, Float by bits.  The values are computed once for the selected rows by a
+        // projection plan of their own and sort as a column's cells would.
+        if (p.distinct_field >= 0) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates over more than one argument in a GROUP BY");
+        auto dp = std::make_shared<LoweredPlan>();
+        Lowering LP{resolve, *dp, L.err, true};
+        LP.exact_nan = true; // the values are told apart by their bits
+        std::string dnode, dvalid;
+        bool df = false;
+        if ((rc = LP.expr_planvalue(s.expr, s.expr_len, &dnode, &df))) return rc;
+        const PlanValueInfo dpv = LP.last_planvalue;
+        if (dpv.is_decimal) return L.fail(LLKV_UNSUPPORTED, "DISTINCT inside GROUP BY over a computed decimal argument");
+        if ((rc = LP.valid_of_node(s.expr, s.expr_len, dnode, true, &dvalid))) return rc;
+        auto same_tokens = [&]() {
+          if (p.distinct_tokens.size() != s.expr_len) return false;
+          for (uint32_t k = 0; k < s.expr_len; ++k) {
+            const llkv_expr_token &x = p.distinct_tokens[k], &y = s.expr[k];
+            if (x.kind != y.kind) return false;
+            if (x.kind == LLKV_TOK_COLUMN && x.field_id != y.field_id) return false;
+            if (x.kind == LLKV_TOK_BINARY && x.binop != y.binop) return false;
+            if (x.kind == LLKV_TOK_LITERAL && (x.literal.tag != y.literal.tag || x.literal.scale != y.literal.scale || x.literal.lo != y.literal.lo || x.literal.hi != y.literal.hi ||
+                                               std::memcmp(&x.literal.f64, &y.literal.f64, 8) != 0)) return false;
+          }
+          return true;
+        };
+        if (p.distinct_proj && !same_tokens()) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates over more than one argument in a GROUP BY");
+        if (!p.distinct_proj) {
+          p.distinct_tokens.assign(s.expr, s.expr + s.expr_len);
+          for (auto &tk : p.distinct_tokens) tk.literal.str = nullptr; // (numeric literals only: expr_planvalue took nothing else)
+          dp->out_dtypes = {df ? LLKV_DT_FLOAT64 : LLKV_DT_INT64};
+          dp->out_fields = {-1};
+          dp->out_nullable = {!dvalid.empty()};
+          dp->type_string = "ProjPlan<" + cols_string(*dp, &dp->bytes_per_row) + ",Outs<" + (dvalid.empty() ? dnode : "OutV<" + dnode + "," + dvalid + ">") + ">>";
+          p.distinct_proj = dp;
+          p.distinct_node = dnode;
+          p.distinct_numeric = 0;
+        }
+        const int count_lane = add_group("DistinctCount", {ADD_I64});
+        if (s.kind == LLKV_AGG_COUNT) { o.fin = AggFinal::CountValid; o.lane = count_lane; p.aggs.push_back(o); continue; }
+        if (!df && s.kind != LLKV_AGG_TOTAL) { // the checked_add chain over the distinct values cannot overflow whatever their order
+          auto mag = [](i128 v) -> u128 { return v < 0 ? (u128)(-v) : (u128)v; };
+          uint64_t rows = 0;
+          for (uint32_t k = 0; k < s.expr_len; ++k)
+            if (s.expr[k].kind == LLKV_TOK_COLUMN) { const ColumnInfo *ci = resolve(s.expr[k].field_id); if (ci) rows = std::max(rows, ci->rows); }
+          const u128 m = std::max(mag(dpv.lo), mag(dpv.hi));
+          if (!dpv.bounded || m * (u128)rows > (u128)INT64_MAX) return L.fail(LLKV_UNSUPPORTED, "possible i64 overflow in SUM(DISTINCT) over a computed argument: order-dependent check is not on the GPU path");
+        }
+        o.count_lane = count_lane;
+        o.typed_by_first_value = true; // (a group without a non-NULL value: the temp column is an Int64 column — SUM comes back as an Int64 NULL)
+        if (s.kind == LLKV_AGG_TOTAL) { o.fin = AggFinal::TotalF64; o.lane = add_group(df ? "DistinctSumF64" : "DistinctTotalI64", {ADD_F64}); }
+        else if (df) { o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumF64 : AggFinal::AvgF64; o.lane = add_group("DistinctSumF64", {ADD_F64}); }
+        else { o.fin = s.kind == LLKV_AGG_SUM ? AggFinal::SumI64Fast : AggFinal::AvgI64Fast; o.lane = add_group("DistinctSumI64", {ADD_I64}); }
+        p.aggs.push_back(o);
+        continue;
+      }
+      if (p.distinct_proj) return L.fail(LLKV_UNSUPPORTED, "DISTINCT aggregates over more than one argument in a GROUP BY");
       const ColumnInfo *dci = resolve(s.expr[0].field_id);
       if (!dci) return L.fail(LLKV_INVALID_ARGUMENT, "unknown column '" + std::to_string(s.expr[0].field_id) + "' in aggregate");
       // DistinctKey::from_array (llkv-aggregate/src/lib.rs:261-331): Int by value, Float by bits, Str by its string (here: its
@@ -1386,6 +1458,7 @@ static int lower_aggregates(Lowering &L, const ColumnResolver &resolve, const ll
     } else {
       rc = grouped ? L.expr_planvalue(s.expr, s.expr_len, &node, &is_f64) : L.expr_fast(s.expr, s.expr_len, &node, &is_f64);
       if (rc) return rc;
+      if (!grouped && L.last_fast_32) return L.fail(LLKV_UNSUPPORTED, "aggregate over a 32-bit-only integer expression (the reference has no Int32 accumulator)");
       // (what can make the value NULL is read off the expression the scan evaluates: the simplified one — a division of
       // constants is gone from it)
       std::vector<llkv_expr_token> folded;
@@ -1968,6 +2041,7 @@ int lower_emit(const ColumnResolver &resolve, const llkv_filter *filters, uint32
     rc = L.expr_fast(expr, expr_len, &val, &is_f64);
     L.exact_nan = false;
     if (rc) return rc;
+    if (L.last_fast_32) return L.fail(LLKV_UNSUPPORTED, "aggregate over a 32-bit-only integer expression (the reference has no Int32 accumulator)");
     if (is_f64 && !allow_f64) return L.fail(LLKV_INTERNAL, "exact sum check over a float expression");
     if (key_dtype) *key_dtype = is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64;
   }
@@ -2070,7 +2144,8 @@ int lower_projection(const ColumnResolver &resolve, const llkv_projection *proje
         rc = L.expr_fast(pr.expr, pr.expr_len, &node, &is_f64);
         L.exact_nan = false;
         if (rc) return rc;
-        out->out_dtypes.push_back(is_f64 ? LLKV_DT_FLOAT64 : LLKV_DT_INT64);
+        if (L.last_fast_32) node = std::string("Narrow32<") + node + (L.last_fast_32 == 1 ? ",I32>" : ",U32>");
+        out->out_dtypes.push_back(is_f64 ? LLKV_DT_FLOAT64 : L.last_fast_32 == 1 ? LLKV_DT_INT32 : L.last_fast_32 == 2 ? LLKV_DT_UINT32 : LLKV_DT_INT64);
         out->out_fields.push_back(-1);
       }
       std::string v;

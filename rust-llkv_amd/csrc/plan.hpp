@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -111,6 +112,13 @@ struct LoweredPlan {
   int64_t distinct_field = -1; // reduce plans (sort-based GROUP BY): the column every DISTINCT aggregate is over (-1: none)
   uint32_t distinct_numeric = 0; // what its lanes add: 0 the Int64 / Float64 cell, 1 the numeric image of a Utf8 code, 2 a Boolean's 1.0 / 0.0, 3 a Date32's day number (join.hpp: hj_launch_distinct_heads)
   std::vector<double> distinct_dict_num; // (1) array_value_to_numeric over the dictionary
+  // … or a COMPUTED argument (distinct_field stays −1): the projection plan that evaluates it — PlanValue semantics — for the selected
+  // rows ("ProjPlan<Cols<…>,Outs<E>>", one Int64 / Float64 output, its validity when some row can be NULL); the values are one more
+  // sort key exactly as a column's cells are
+  std::shared_ptr<LoweredPlan> distinct_proj;
+  std::string distinct_node;
+  std::vector<llkv_expr_token> distinct_tokens; // (the argument itself: two DISTINCT aggregates share the sort key only over the same expression)
+  bool has_distinct() const { return distinct_field >= 0 || distinct_proj != nullptr; }
   int k = 1;      // lanes per group
   int lanes = 2;  // ng * k + 1
   int unroll = 2;

@@ -607,6 +607,52 @@ def test_scan_stream_and_row_ids_match_oracle(rt, orc, abi, chunks):
                     assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (x, y)
 
 
+@pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5]])
+def test_int32_only_arithmetic_runs_on_the_checked_32_bit_kernels(rt, orc, abi, chunks):
+    """An expression whose every leaf is an Int32 (UInt32) column has that ROOT type (get_common_type, llkv-compute/src/kernels.rs:
+    179-242: same ⊕ same → same) and the fast path runs arrow's checked 32-bit kernels over it (fast_numeric.rs:333-355): an Int32 /
+    UInt32 result column, an error where an intermediate leaves 32 bits.  One Int64 leaf or literal makes the root Int64: the
+    columns are cast up before the first kernel and `(a + b) * w` cannot overflow at 32 bits.  Aggregates over such an expression
+    are refused on both sides (the reference has no Int32 accumulator)."""
+    rng = np.random.default_rng(7 + len(chunks))
+    n = sum(chunks)
+    a = rng.integers(-40_000, 40_000, size=n).astype(np.int32)
+    b = rng.integers(-40_000, 40_000, size=n).astype(np.int32)
+    u = rng.integers(0, 60_000, size=n).astype(np.uint32)
+    v = rng.integers(0, 60_000, size=n).astype(np.uint32)
+    w = rng.integers(-2**40, 2**40, size=n).astype(np.int64)
+    vb = rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT32, a), (2, abi.DT_INT32, b, vb), (3, abi.DT_UINT32, u), (4, abi.DT_UINT32, v), (5, abi.DT_INT64, w)], chunks)
+    E, col, A = abi.Expr, abi.col, abi.AggregateSpec
+    projs = [col(1) + col(2), col(1) * col(2) - col(1), col(1) - col(2), (col(1) + col(2)) * col(5), col(3) + col(4), col(3) * col(4), col(1) + col(3)]
+    preds = [None, E.compare(col(1) + col(2), abi.CMP_GT, col(1) * col(2)), E.compare(col(3) * col(4), abi.CMP_LT_EQ, col(5)), E.compare(col(1) - col(2), abi.CMP_LT, col(3) + col(4))]
+    for p in preds:
+        assert np.array_equal(rt.filter_row_ids(ht, p), orc.filter_row_ids(ot, p))
+        got = rt.scan_stream(ht, projs, p, include_row_ids=True)
+        want = orc.scan_stream(ot, projs, p, include_nulls=True, include_row_ids=True)
+        assert [b_[1] for b_ in got] == [b_[1] for b_ in want] and [b_[0] for b_ in got] == [b_[0] for b_ in want]
+    # the products stay below 2^31 in magnitude only because the operands are small: 40 000² = 1.6e9 < 2^31; widen one operand and both sides fail
+    a2 = a.copy()
+    a2[n // 2] = 2**31 - 1
+    u2 = u.copy()
+    u2[n // 3] = 0
+    h2, o2 = stage_both(rt, orc, abi, [(1, abi.DT_INT32, a2), (2, abi.DT_INT32, np.ones(n, dtype=np.int32)), (3, abi.DT_UINT32, u2), (4, abi.DT_UINT32, np.ones(n, dtype=np.uint32)), (5, abi.DT_INT64, w)], chunks)
+    for expr in (col(1) + col(2), col(3) - col(4)):  # i32::MAX + 1; 0 − 1 in UInt32
+        for m, t in ((rt, h2), (orc, o2)):
+            with pytest.raises(abi.LlkvError) as e:
+                m.scan_stream(t, [expr], None)
+            assert e.value.kind == "Internal" and "overflow" in e.value.message.lower(), (m, expr)
+            with pytest.raises(abi.LlkvError) as e:
+                m.filter_row_ids(t, E.compare(expr, abi.CMP_GT, col(5)))
+            assert e.value.kind == "Internal" and "overflow" in e.value.message.lower(), (m, expr)
+    # … while an Int64 leaf widens the whole expression: no error, the same values
+    assert rt.scan_stream(h2, [(col(1) + col(2)) + col(5)], None) == orc.scan_stream(o2, [(col(1) + col(2)) + col(5)], None, include_nulls=True)
+    for m, t in ((rt, ht), (orc, ot)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.aggregate(t, None, [A.sum(col(1) + col(2))])
+        assert e.value.kind == "Unsupported", m
+
+
 @pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5], [65536, 70000]])
 def test_row_ids_with_gaps_are_reported_as_the_tables_ids(rt, orc, abi, chunks):
     """A table whose row ids are not 0 … n − 1 (rows removed before it was staged; the row-id shadow column of
@@ -1879,6 +1925,47 @@ def test_join_record_batches_drop_rows_null_in_every_column(rt, orc, abi):
         assert e.value.kind == "Unsupported"
 
 
+def test_a_join_side_whose_every_row_is_null_arrives_as_one_synthetic_batch(rt, orc, abi):
+    """A table none of whose rows survives the DropNulls gather of its user columns comes out of the reference's scan as ONE batch
+    of total_rows NULL rows (llkv-scan/src/execute.rs:355-372, llkv-compute/src/projection.rs:36-66) instead of no batch at all:
+    as a probe side it is one window of 70 000 rows (a LEFT join pads every one of them, cut by the batch size alone), as a build
+    side its NULL keys meet only NULL keys that are allowed to (null_equals_null), in a cross product it is one window."""
+    n = 70_000  # two scan windows of a side that has rows
+    rng = np.random.default_rng(5)
+    none = np.zeros(n, dtype=bool)
+    nulls_h, nulls_o = rt.HipTable(1, [65536, n - 65536]), orc.OracleTable(n)
+    for f, dt, v in ((1, abi.DT_INT64, rng.integers(0, 50, size=n)), (2, abi.DT_FLOAT64, rng.normal(size=n))):
+        nulls_h.append_column(f, dt, v.astype(abi.NUMPY_OF_DTYPE[dt]), valid=none); nulls_o.add(f, dt, v.astype(abi.NUMPY_OF_DTYPE[dt]), list(none))
+    m = 3000
+    rk, rvalid = rng.integers(0, 50, size=m).astype(np.int64), rng.random(m) > 0.3
+    w12 = rng.normal(size=m)
+    live_h = rt.HipTable(2, [m])
+    live_h.append_column(11, abi.DT_INT64, rk, valid=rvalid); live_h.append_column(12, abi.DT_FLOAT64, w12)
+    live_o = orc.OracleTable(m).add(11, abi.DT_INT64, rk, list(rvalid)).add(12, abi.DT_FLOAT64, w12)
+    lcols, rcols = [(1, "k"), (2, "v")], [(11, "rk"), (12, "w")]
+    # probe side all NULL
+    for jt, keys in (("inner", [(1, 11)]), ("left", [(1, 11)]), ("anti", [(1, 11)]), ("semi", [(1, 11, True)]), ("left", [(1, 11, True)])):
+        got = rt.join_stream_batches(nulls_h, live_h, keys, lcols, rcols, JT[jt], 5000)  # (5 000 does not divide a 65 536-row window)
+        want = orc.hash_join_batches(nulls_o, live_o, keys, lcols, rcols, JT[jt], 5000)
+        _same_batches(got, want, jt)
+    assert [len(c[0]) for _, c in orc.hash_join_batches(nulls_o, live_o, [(1, 11)], lcols, rcols, JT["left"], 5000)] == [5000] * 14
+    # build side all NULL
+    for jt, keys in (("inner", [(11, 1)]), ("left", [(11, 1)]), ("inner", [(11, 1, True)]), ("anti", [(11, 1)])):
+        got = rt.join_stream_batches(live_h, nulls_h, keys, rcols, lcols, JT[jt], 512)
+        want = orc.hash_join_batches(live_o, nulls_o, keys, rcols, lcols, JT[jt], 512)
+        _same_batches(got, want, jt)
+    # cross products: the all-NULL side is ONE window whichever side it is on
+    small_h, small_o = rt.HipTable(6, [3]), orc.OracleTable(3)
+    small_h.append_utf8_column(7, ["x", "y", "x"]); small_o.add(7, abi.DT_UTF8, ["x", "y", "x"])
+    got = rt.join_stream_batches(nulls_h, small_h, [], [(1, "k")], [(7, "s")], JT["inner"])
+    want = orc.hash_join_batches(nulls_o, small_o, [], [(1, "k")], [(7, "s")], JT["inner"])
+    _same_batches(got, want, "cross, left side all NULL")
+    assert [len(c[0]) for _, c in want] == [3 * n]
+    got = rt.join_stream_batches(small_h, nulls_h, [], [(7, "s")], [(2, "v")], JT["inner"])
+    want = orc.hash_join_batches(small_o, nulls_o, [], [(7, "s")], [(2, "v")], JT["inner"])
+    _same_batches(got, want, "cross, right side all NULL")
+
+
 def test_join_record_batches_edge_cases(rt, orc, abi):
     """Empty sides, no columns on a side, the reference's LEFT-join-without-a-build-batch behaviour, cross products with
     NULL padding, SEMI / ANTI cross products."""
@@ -2202,7 +2289,7 @@ def test_generic_key_types_match_oracle(rt, orc, abi):
         _same_join(rt, orc, tabs, [(3, 1, null_eq)], 8192, jts=("semi", "anti"))           # Int32 against Utf8
         _same_join(rt, orc, tabs, [(5, 5), (1, 1, null_eq)], 20_000, jts=("semi", "left"))  # Int64 + Utf8 composite
     with pytest.raises(abi.LlkvError) as e:
-        rt.join_stream(tabs[0], tabs[1], [(5, 5)] * 5, JT["inner"])
+        rt.join_stream(tabs[0], tabs[1], [(5, 5)] * 9, JT["inner"])  # (up to eight pairs run since r04)
     assert e.value.kind == "Unsupported"
 
 
@@ -2785,7 +2872,24 @@ def test_distinct_aggregates_inside_group_by_match_oracle(rt, orc, abi, chunks):
                     assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (keys, order)
                     for x, y in zip(got, want):
                         assert_values(x.values, y.values, f"distinct/groupby {keys}")
-    for bad in ([D(A.count(3)), D(A.count(4))], [D(A.sum(abi.col(3) * 2))]):  # two distinct columns; a computed argument
+    # a computed argument (r04): the group's temp column holds the PlanValue of every row (llkv-executor/src/lib.rs:5186-5199) —
+    # Int ∘ Int through f64, a NULL operand or x % 0 makes the cell NULL — and the distinct accumulator runs over it; on the GPU
+    # a projection plan evaluates it once for the selected rows and the values sort as a column's cells would
+    col = abi.col
+    computed = [[A.count_star(), D(A.count(col(3) * 2)), D(A.sum(col(3) * 2)), D(A.avg(col(3) * 2)), D(A.total(col(3) * 2)), A.sum(3)],
+                [D(A.count(col(3) % 7)), D(A.sum(col(3) % 7)), A.count(3)],
+                [D(A.count(col(4) * 2.0)), D(A.total(col(4) * 2.0)), A.count(4)],
+                [D(A.sum(col(5) + col(3))), D(A.avg(col(5) + col(3))), D(A.count(col(5) + col(3)))],
+                [D(A.count(col(3) / col(3))), D(A.sum(col(3) / col(3)))]]  # x / 0 is NULL
+    for keys in ([1], [2, 1]):
+        for aggs in computed:
+            for pred in (None, [F(3, O.GreaterThan(-10))]):
+                for order in (True, False):
+                    got, want = rt.groupby(ht, pred, keys, aggs, order), orc.groupby(ot, pred, keys, aggs, order)
+                    assert [[k.value for k in r.keys] for r in got] == [[k.value for k in r.keys] for r in want], (keys, order)
+                    for x, y in zip(got, want):
+                        assert_values(x.values, y.values, f"distinct over a computed argument / groupby {keys}")
+    for bad in ([D(A.count(3)), D(A.count(4))], [D(A.sum(col(3) * 2)), D(A.count(col(3) * 3))], [D(A.count(3)), D(A.count(col(3) * 2))]):  # two distinct arguments
         with pytest.raises(abi.LlkvError) as e:
             rt.groupby(ht, None, [1], bad, True)
         assert e.value.kind == "Unsupported"

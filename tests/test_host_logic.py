@@ -316,8 +316,10 @@ def test_compare_lowering_follows_the_common_type_rules(lib, abi):
     assert "Cmp<3,ToI64<Col<0,I32>>,ToI64<Col<1,U32>>>" in rt.lower_plan(d, E.compare(col(3), abi.CMP_LT, col(5)), cnt)[0]
     assert "Cmp<6,Col<0,U64>,ToI64<Col<1,U32>>>" in rt.lower_plan(d, E.compare(col(4), abi.CMP_GT_EQ, col(5)), cnt)[0]
     assert "Cmp<1,Bin<3,Col<0,I64>,LitI<0>>,ToI64<Col<1,I32>>>" in rt.lower_plan(d, E.compare(col(1) * 3, abi.CMP_EQ, col(3)), cnt)[0]
+    # Int32-only arithmetic stays Int32: every node checked against 32 bits, the side compares as an Int32 does
+    assert "Cmp<3,Fit32<Bin<1,ToI64<Col<0,I32>>,ToI64<Col<0,I32>>>,1>,Col<1,I64>>" in rt.lower_plan(d, E.compare(col(3) + col(3), abi.CMP_LT, col(1)), cnt)[0]
+    assert "Cmp<3,ToF64<Fit32<Bin<3,ToI64<Col<0,U32>>,ToI64<Col<0,U32>>>,0>>,ToF64<Col<1,I64>>>" in rt.lower_plan(d, E.compare(col(5) * col(5), abi.CMP_LT, col(1)), cnt)[0]
     for bad in (E.compare(abi.ScalarExpr.literal(1) + 2, abi.CMP_LT, 4),  # constant compare
-                E.compare(col(3) + col(3), abi.CMP_LT, col(1)),             # Int32-only arithmetic stays Int32
                 E.compare(col(1), abi.CMP_NOT_EQ, abi.ScalarExpr.literal(abi.Literal.of(None)))):
         with pytest.raises(abi.LlkvError) as e:
             rt.lower_plan(d, bad, cnt)
