@@ -225,6 +225,12 @@ __device__ __forceinline__ void probe_zero_slices(const ScanParams &p) {
   }
 }
 
+#ifndef LLKV_PROBE_WINDOW
+#define LLKV_PROBE_WINDOW 1 // (0: the lean probe gathers every batch's bitmap words — A/B)
+#endif
+#ifndef LLKV_PROBE_LEAN
+#define LLKV_PROBE_LEAN 1 // (0: the general loop for every probe form; 2: the lean form + the next batch requested behind the gather — A/B, profiles/r04/q3_probe_lean.txt)
+#endif
 template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
   if (p.rk_chunks) { // (uniform) piggy-backed: the word ranks of the dimension bitmap, chunk by chunk
@@ -246,9 +252,130 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
   // (uniform) the build list is in key order — known to the host (no table) or found out while it was compacted: rank = group id
   const bool by_rank = DIRECT && (!p.bm_group || (p.bm_unsorted && *p.bm_unsorted == 0));
   constexpr int kE = 2 * kSelUnroll;
+  constexpr bool LATE = P::EARLY < P::ColList::N;
+  if constexpr (DIRECT && P::KEYBIT && LATE && LLKV_PROBE_LEAN) {
+    // The form Q3 takes — direct table, key-bit stripes, late value columns.  The loop below costs a batch of 512 rows three round
+    // trips — the streamed columns, the bitmap gather, and (a batch holds a joining row 92 times in 100 although only 0.5 % of the
+    // rows join) the value columns of its hits — but what bounds it is the texture addresser (profiles/r04/q3_sq_counters.txt:
+    // TA busy 71 % of the kernel's cycles; more waves in flight or fewer round trips alone changed nothing).  Here:
+    // * a hit leaves its key-bit position in the stripe at once and (position in the stripe, row) in a queue of the wave in the
+    //   LDS; the queue is worked off — one lane per hit: all columns of its row, the value, the store — when 64 − 8 entries are
+    //   waiting and when the stripe ends (~10 hits per stripe: once);
+    // * the bit positions are 32 bits wide (the host emits key bits only when the span is below 2^32) and the bitmap is read in
+    //   32-bit halves: 76 – 82 VGPRs instead of 98;
+    // * a batch whose bit positions lie within 64 bitmap dwords (a fact table clustered by the key) reads them with ONE coalesced
+    //   load and a lane permute per row instead of eight gathers (below).
+    // LLKV_PROBE_LEAN = 2 also requests the next batch's columns behind this batch's lookup — measured slower (114 VGPRs).
+    // Same pairs, same order, same values (profiles/r04/q3_probe_lean.txt).
+    constexpr uint32_t kQueue = 64;
+    __shared__ uint32_t pq_at[kBlock / 64][kQueue], pq_row[kBlock / 64][kQueue];
+    uint32_t queued = 0;
+    auto work_off = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < queued) {
+        const uint32_t at = pq_at[wave][lane], row = pq_row[wave][lane]; // row: within the tile
+        Loaded lv;
+        load_range<typename P::ColList, 0, P::ColList::N>(p, td.dev_row + (row & ~1u), lv);
+        Ctx c{p, lv, 0u, td.logical_row + row};
+        p.aux_out[base0 + at] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, (int)(row & 1u)));
+      }
+      __builtin_amdgcn_wave_barrier(); // the queue is refilled next
+      queued = 0;
+    };
+    const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(p.bm_bits);
+    Loaded lds[kSelUnroll], nxt[kSelUnroll];
+    if (LLKV_PROBE_LEAN == 2 && sub0 < sub1) {
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + sub0 + u * 128 + lane * 2, lds[u]);
+    }
+    for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
+      if (LLKV_PROBE_LEAN != 2) {
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+      }
+      const bool more = LLKV_PROBE_LEAN == 2 && r0 + 128 * kSelUnroll < sub1;
+      bool f[kE];
+      uint32_t d32[kE], w32[kE];
+#pragma unroll
+      for (int e = 0; e < kE; ++e) {
+        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
+        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
+        const bool pass = (row < sub1) & P::Pred::eval(c, e & 1);
+        perr |= row < sub1 ? c.perr : 0u;
+        const uint64_t d = (uint64_t)(long long)P::KeyE::eval(c, e & 1) - (uint64_t)p.bm_min; // k < min wraps to a huge value
+        f[e] = pass && d <= p.bm_span;
+        d32[e] = (uint32_t)d;
+      }
+      // The bitmap words of a batch.  Eight gathers a lane are eight instructions whose 64 addresses the texture addresser takes
+      // apart one by one (TA_BUSY 71 % of this kernel's cycles, profiles/r04/q3_sq_counters.txt: what bounds it is neither the
+      // HBM nor the round trips but the address pipeline).  A fact table clustered by the key keeps the keys of 512 consecutive
+      // rows close together: when the batch's bit positions span fewer than 64 bitmap dwords, ONE coalesced load brings a dword
+      // to every lane and the rows fetch theirs with a lane permute; any other batch gathers as before.
+      uint32_t dlo = ~0u, dhi = 0u;
+#pragma unroll
+      for (int e = 0; e < kE; ++e) { dlo = f[e] && d32[e] < dlo ? d32[e] : dlo; dhi = f[e] && d32[e] > dhi ? d32[e] : dhi; }
+      if (LLKV_PROBE_WINDOW) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+          const uint32_t a = __shfl_xor(dlo, o), b = __shfl_xor(dhi, o);
+          dlo = a < dlo ? a : dlo;
+          dhi = b > dhi ? b : dhi;
+        }
+      }
+      const uint32_t w0 = dlo >> 5;
+      const bool windowed = LLKV_PROBE_WINDOW && dlo != ~0u && (dhi >> 5) - w0 < 64u; // (uniform)
+      if (dlo == ~0u && LLKV_PROBE_WINDOW) { // (uniform) no row of the batch passed: nothing to look up
+#pragma unroll
+        for (int e = 0; e < kE; ++e) w32[e] = 0u;
+      } else if (windowed) {
+        const uint32_t last = (uint32_t)(p.bm_span >> 5) | 1u; // the bitmap's last dword
+        const uint32_t mine = bm32[w0 + lane < last ? w0 + lane : last];
+#pragma unroll
+        for (int e = 0; e < kE; ++e) w32[e] = __shfl(mine, (int)(((d32[e] >> 5) - w0) & 63u));
+      } else {
+#pragma unroll
+        for (int e = 0; e < kE; ++e) w32[e] = bm32[f[e] ? d32[e] >> 5 : 0];
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + 128 * kSelUnroll + u * 128 + lane * 2, nxt[u]);
+      }
+#pragma unroll
+      for (int e = 0; e < kE; ++e) f[e] = f[e] && ((w32[e] >> (d32[e] & 31u)) & 1u) != 0;
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) {
+        const bool f0 = f[2 * u], f1 = f[2 * u + 1];
+        const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
+        if (b0 | b1) { // (uniform) some row of the step joins
+          const uint32_t n_hits = (uint32_t)(__popcll(b0) + __popcll(b1));
+          if (queued + n_hits > kQueue) work_off(); // (a step holds at most 128)
+          const uint32_t before = (uint32_t)(__popcll(b0 & lt_mask) + __popcll(b1 & lt_mask));
+          const uint32_t at = (uint32_t)(base - base0) + before, row = r0 + u * 128 + lane * 2;
+          if (n_hits > kQueue) { // more hits in one step than the queue holds (a dense join): each lane finishes its own
+            Loaded lv;
+            if (f0 | f1) load_range<typename P::ColList, 0, P::ColList::N>(p, td.dev_row + row, lv);
+            if (f0) { Ctx c{p, lv, 0u, td.logical_row + row}; p.aux_out32[base0 + at] = d32[2 * u]; p.aux_out[base0 + at] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, 0)); }
+            if (f1) { Ctx c{p, lv, 0u, td.logical_row + row + 1}; p.aux_out32[base0 + at + (f0 ? 1 : 0)] = d32[2 * u + 1]; p.aux_out[base0 + at + (f0 ? 1 : 0)] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, 1)); }
+          } else {
+            if (f0) { p.aux_out32[base0 + at] = d32[2 * u]; pq_at[wave][queued + before] = at; pq_row[wave][queued + before] = row; }
+            if (f1) { p.aux_out32[base0 + at + (f0 ? 1 : 0)] = d32[2 * u + 1]; pq_at[wave][queued + before + (f0 ? 1 : 0)] = at + (f0 ? 1 : 0); pq_row[wave][queued + before + (f0 ? 1 : 0)] = row + 1; }
+            queued += n_hits;
+          }
+          base += n_hits;
+        }
+      }
+      if (queued > kQueue - 8) work_off();
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kSelUnroll; ++u) lds[u] = nxt[u];
+      }
+    }
+    if (queued) work_off();
+  } else
   for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
     Loaded lds[kSelUnroll];
-    constexpr bool LATE = P::EARLY < P::ColList::N;
     if constexpr (LATE) {
 #pragma unroll
       for (int u = 0; u < kSelUnroll; ++u)
