@@ -15,6 +15,7 @@ if [ -n "${PMC_MEM:-}" ]; then
   SETS=("TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
         "TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_32B_sum" "GRBM_GUI_ACTIVE TCC_EA0_RDREQ_LEVEL_sum TCC_BUSY_avr TCP_READ_TAGCONFLICT_STALL_CYCLES_sum")
 fi
+if [ -n "${PMC_SETS:-}" ]; then IFS=';' read -r -a SETS <<< "$PMC_SETS"; fi # e.g. PMC_SETS="TA_BUSY_avr GRBM_GUI_ACTIVE;SQ_WAIT_ANY SQ_WAVE_CYCLES"
 for set in "${SETS[@]}"; do
   tag="$(echo "$set" | tr ' ' '_')"
   echo "[pmc] $set"
