@@ -2,6 +2,7 @@
 # Where the waves of the Q3 pipeline's kernels spend their cycles: SQ counters per kernel (rocprofv3 --pmc, its own run).
 # WAIT_ANY (parked on s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ≈ WAVE_CYCLES (MI355X_MICROARCH.md).
 # usage (GPU box): bash tools/pmc_sq.sh [extra env assignments…]   → gpurun_out/pmc_sq.txt
+#   PMC_MEM=1: the memory pipeline's counters; PMC_SETS="A B;C D": these sets; PMC_CMD="script.py args" PMC_BY_NAME=1: another workload, per kernel name
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/pmc_sq"
@@ -19,7 +20,7 @@ if [ -n "${PMC_SETS:-}" ]; then IFS=';' read -r -a SETS <<< "$PMC_SETS"; fi # e.
 for set in "${SETS[@]}"; do
   tag="$(echo "$set" | tr ' ' '_')"
   echo "[pmc] $set"
-  timeout -k 5 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/$tag" -o pmc -- python3 "$ROOT/tools/q3_bench.py" sf10 > "$OUT/$tag.log" 2>&1 || echo "pass $tag failed"
+  timeout -k 5 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/$tag" -o pmc -- python3 ${PMC_CMD:-"$ROOT/tools/q3_bench.py" sf10} > "$OUT/$tag.log" 2>&1 || echo "pass $tag failed"
 done
 python3 - "$OUT" <<'PY' | tee "$ROOT/gpurun_out/pmc_sq.txt"
 import csv, glob, os, sys, collections
@@ -36,6 +37,13 @@ for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recurs
         n = rs[0]["Kernel_Name"].split("(")[0].replace("llkv::", "")
         if n.startswith("hj_fill_zero_ranges"): cur = []; pipes.append(cur)
         if cur is not None: cur.append((n, {r["Counter_Name"]: float(r["Counter_Value"]) for r in rs}))
+    if os.environ.get("PMC_BY_NAME"):  # any command: average per kernel name (the first dispatch of a name is dropped: cold)
+        seen = set()
+        for d, rs in by_dispatch.items():
+            n = rs[0]["Kernel_Name"].split("(")[0].replace("llkv::", "")[:60]
+            if n not in seen: seen.add(n); continue
+            for r in rs: acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        continue
     if not pipes: continue
     pipes = [p for p in pipes if len(p) == len(pipes[-1])][1:]
     for p in pipes:
