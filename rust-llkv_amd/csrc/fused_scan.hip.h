@@ -117,6 +117,30 @@ template <class Ty> __device__ __forceinline__ void load_pair(const void *base, 
   }
 }
 
+// FOUR consecutive rows of a column no wider than 4 bytes (one 16-byte / 4-byte load: half the vector-memory instructions of two
+// pairs — the scans of narrow columns are bound by the address pipeline, profiles/r04/q3_sq_counters.txt); Ctx::get reads rows
+// 0 … 3 of such a column as it reads rows 0 and 1.
+template <class Ty> __device__ __forceinline__ void load_quad(const void *base, uint64_t row, uint32_t (&w)[4]) {
+  static_assert(Ty::W <= 4, "four rows of an 8-byte column do not fit a column's registers");
+  if constexpr (Ty::W == 4) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = stream_load(reinterpret_cast<const v4u *>(static_cast<const char *>(base) + row * 4));
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  } else {
+    w[0] = stream_load(reinterpret_cast<const uint32_t *>(static_cast<const char *>(base) + row));
+  }
+}
+template <class CL, int LO, int HI> __device__ __forceinline__ void load_quad_range(const ScanParams &p, uint64_t row, Loaded &ld) {
+  if constexpr (LO < HI && LO < CL::N) {
+    load_quad<typename ColAt<LO, CL>::type>(p.col[LO], row, ld.w[LO]);
+    load_quad_range<CL, LO + 1, HI>(p, row, ld);
+  }
+}
+template <class CL, int LO, int HI> constexpr bool cols_narrow() {
+  if constexpr (LO < HI && LO < CL::N) return ColAt<LO, CL>::type::W <= 4 && ColAt<LO, CL>::type::W != 2 && cols_narrow<CL, LO + 1, HI>();
+  else return true;
+}
+
 template <class CL, int I = 0> __device__ __forceinline__ void load_all(const ScanParams &p, uint64_t row, Loaded &ld) {
   if constexpr (I < CL::N) {
     load_pair<typename ColAt<I, CL>::type>(p.col[I], row, ld.w[I]);

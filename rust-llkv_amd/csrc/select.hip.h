@@ -225,11 +225,14 @@ __device__ __forceinline__ void probe_zero_slices(const ScanParams &p) {
   }
 }
 
+#ifndef LLKV_PROBE_QUAD
+#define LLKV_PROBE_QUAD 1 // (0: the lean probe takes two rows of a step per lane whatever the columns' width — A/B)
+#endif
 #ifndef LLKV_PROBE_WINDOW
 #define LLKV_PROBE_WINDOW 1 // (0: the lean probe gathers every batch's bitmap words — A/B)
 #endif
 #ifndef LLKV_PROBE_LEAN
-#define LLKV_PROBE_LEAN 1 // (0: the general loop for every probe form; 2: the lean form + the next batch requested behind the gather — A/B, profiles/r04/q3_probe_lean.txt)
+#define LLKV_PROBE_LEAN 1 // (0: the general loop for every probe form — A/B, profiles/r04/q3_probe_lean.txt)
 #endif
 template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(const ScanParams &p) {
   const TileDesc td = p.tiles[blockIdx.x];
@@ -265,7 +268,7 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
     //   32-bit halves: 76 – 82 VGPRs instead of 98;
     // * a batch whose bit positions lie within 64 bitmap dwords (a fact table clustered by the key) reads them with ONE coalesced
     //   load and a lane permute per row instead of eight gathers (below).
-    // LLKV_PROBE_LEAN = 2 also requests the next batch's columns behind this batch's lookup — measured slower (114 VGPRs).
+    // (Requesting the next batch's columns behind this batch's lookup on top of that was measured slower — 114 VGPRs — and is gone.)
     // Same pairs, same order, same values (profiles/r04/q3_probe_lean.txt).
     constexpr uint32_t kQueue = 64;
     __shared__ uint32_t pq_at[kBlock / 64][kQueue], pq_row[kBlock / 64][kQueue];
@@ -284,27 +287,28 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
       __builtin_amdgcn_wave_barrier(); // the queue is refilled next
       queued = 0;
     };
+    // * when every streamed column is at most 4 bytes wide (the key images make Q3's so) a lane takes FOUR consecutive rows of a
+    //   step with one 16-byte load per column instead of two rows with an 8-byte one: half the stream instructions.
+    constexpr bool kQuad = LLKV_PROBE_QUAD && cols_narrow<typename P::ColList, 0, P::EARLY>();
+    constexpr int R = kQuad ? 4 : 2, kSteps = kE / R; // rows of a lane per step; steps of a batch (512 rows either way)
+    constexpr uint32_t kStepRows = 64 * R;
     const uint32_t *bm32 = reinterpret_cast<const uint32_t *>(p.bm_bits);
-    Loaded lds[kSelUnroll], nxt[kSelUnroll];
-    if (LLKV_PROBE_LEAN == 2 && sub0 < sub1) {
+    for (uint32_t r0 = sub0; r0 < sub1; r0 += kStepRows * kSteps) {
+      Loaded lds[kSteps];
 #pragma unroll
-      for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + sub0 + u * 128 + lane * 2, lds[u]);
-    }
-    for (uint32_t r0 = sub0; r0 < sub1; r0 += 128 * kSelUnroll) {
-      if (LLKV_PROBE_LEAN != 2) {
-#pragma unroll
-        for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + u * 128 + lane * 2, lds[u]);
+      for (int u = 0; u < kSteps; ++u) {
+        if constexpr (kQuad) load_quad_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + u * kStepRows + lane * R, lds[u]);
+        else load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + u * kStepRows + lane * R, lds[u]);
       }
-      const bool more = LLKV_PROBE_LEAN == 2 && r0 + 128 * kSelUnroll < sub1;
       bool f[kE];
       uint32_t d32[kE], w32[kE];
 #pragma unroll
       for (int e = 0; e < kE; ++e) {
-        const uint32_t row = r0 + (e >> 1) * 128 + lane * 2 + (e & 1);
-        Ctx c{p, lds[e >> 1], 0u, td.logical_row + row};
-        const bool pass = (row < sub1) & P::Pred::eval(c, e & 1);
+        const uint32_t row = r0 + (e / R) * kStepRows + lane * R + (e % R);
+        Ctx c{p, lds[e / R], 0u, td.logical_row + row};
+        const bool pass = (row < sub1) & P::Pred::eval(c, e % R);
         perr |= row < sub1 ? c.perr : 0u;
-        const uint64_t d = (uint64_t)(long long)P::KeyE::eval(c, e & 1) - (uint64_t)p.bm_min; // k < min wraps to a huge value
+        const uint64_t d = (uint64_t)(long long)P::KeyE::eval(c, e % R) - (uint64_t)p.bm_min; // k < min wraps to a huge value
         f[e] = pass && d <= p.bm_span;
         d32[e] = (uint32_t)d;
       }
@@ -338,39 +342,49 @@ template <class P, bool DIRECT> __device__ __forceinline__ void probe_emit_body(
 #pragma unroll
         for (int e = 0; e < kE; ++e) w32[e] = bm32[f[e] ? d32[e] >> 5 : 0];
       }
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < kSelUnroll; ++u) load_range<typename P::ColList, 0, P::EARLY>(p, td.dev_row + r0 + 128 * kSelUnroll + u * 128 + lane * 2, nxt[u]);
-      }
 #pragma unroll
       for (int e = 0; e < kE; ++e) f[e] = f[e] && ((w32[e] >> (d32[e] & 31u)) & 1u) != 0;
 #pragma unroll
-      for (int u = 0; u < kSelUnroll; ++u) {
-        const bool f0 = f[2 * u], f1 = f[2 * u + 1];
-        const uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
-        if (b0 | b1) { // (uniform) some row of the step joins
-          const uint32_t n_hits = (uint32_t)(__popcll(b0) + __popcll(b1));
-          if (queued + n_hits > kQueue) work_off(); // (a step holds at most 128)
-          const uint32_t before = (uint32_t)(__popcll(b0 & lt_mask) + __popcll(b1 & lt_mask));
-          const uint32_t at = (uint32_t)(base - base0) + before, row = r0 + u * 128 + lane * 2;
+      for (int u = 0; u < kSteps; ++u) {
+        uint64_t any = 0;
+        uint32_t n_hits = 0, before = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const uint64_t bj = __ballot(f[u * R + j]);
+          any |= bj;
+          n_hits += (uint32_t)__popcll(bj);
+          before += (uint32_t)__popcll(bj & lt_mask);
+        }
+        if (any) { // (uniform) some row of the step joins
+          if (queued + n_hits > kQueue) work_off(); // (a step holds at most 64 · R)
+          const uint32_t at = (uint32_t)(base - base0) + before, row = r0 + u * kStepRows + lane * R;
+          uint32_t off = 0;
           if (n_hits > kQueue) { // more hits in one step than the queue holds (a dense join): each lane finishes its own
-            Loaded lv;
-            if (f0 | f1) load_range<typename P::ColList, 0, P::ColList::N>(p, td.dev_row + row, lv);
-            if (f0) { Ctx c{p, lv, 0u, td.logical_row + row}; p.aux_out32[base0 + at] = d32[2 * u]; p.aux_out[base0 + at] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, 0)); }
-            if (f1) { Ctx c{p, lv, 0u, td.logical_row + row + 1}; p.aux_out32[base0 + at + (f0 ? 1 : 0)] = d32[2 * u + 1]; p.aux_out[base0 + at + (f0 ? 1 : 0)] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, 1)); }
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+              if (f[u * R + j]) {
+                Loaded lv;
+                load_range<typename P::ColList, 0, P::ColList::N>(p, td.dev_row + ((row + j) & ~1u), lv);
+                Ctx c{p, lv, 0u, td.logical_row + row + j};
+                p.aux_out32[base0 + at + off] = d32[u * R + j];
+                p.aux_out[base0 + at + off] = (uint64_t)__double_as_longlong((double)P::ValE::eval(c, (int)((row + j) & 1u)));
+                ++off;
+              }
           } else {
-            if (f0) { p.aux_out32[base0 + at] = d32[2 * u]; pq_at[wave][queued + before] = at; pq_row[wave][queued + before] = row; }
-            if (f1) { p.aux_out32[base0 + at + (f0 ? 1 : 0)] = d32[2 * u + 1]; pq_at[wave][queued + before + (f0 ? 1 : 0)] = at + (f0 ? 1 : 0); pq_row[wave][queued + before + (f0 ? 1 : 0)] = row + 1; }
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+              if (f[u * R + j]) {
+                p.aux_out32[base0 + at + off] = d32[u * R + j];
+                pq_at[wave][queued + before + off] = at + off;
+                pq_row[wave][queued + before + off] = row + j;
+                ++off;
+              }
             queued += n_hits;
           }
           base += n_hits;
         }
       }
       if (queued > kQueue - 8) work_off();
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < kSelUnroll; ++u) lds[u] = nxt[u];
-      }
     }
     if (queued) work_off();
   } else
