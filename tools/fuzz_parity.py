@@ -219,6 +219,32 @@ def fuzz_distinct(seeds):
                 gv, wv = g.value, w.value
                 ok = (gv is None and wv is None) or (isinstance(wv, float) and isinstance(gv, float) and ((gv != gv and wv != wv) or abs(gv - wv) <= 1e-9 * max(1.0, abs(wv)))) or gv == wv
                 if not ok: bad.append((seed, k, "values differ", gv, wv, e.tokens))
+            # … and the same argument inside a GROUP BY (r04: computed arguments — PlanValue semantics, the group's temp column — on the
+            # sort-based route): a sparse integer key, so that no dense route takes the query
+            gk = (rng.integers(0, 9, size=n) * 1_000_003).astype(np.int64)
+            hg, og = T.stage_both(rt, orc, abi, [(1, abi.DT_INT64, i1, v1), (3, abi.DT_FLOAT64, f3, v3), (7, abi.DT_INT64, gk)], [n])
+            try:
+                wantg = orc.groupby(og, None, [7], aggs, True)
+            except abi.LlkvError as oe:
+                try:
+                    rt.groupby(hg, None, [7], aggs, True)
+                    bad.append((seed, k, "grouped: oracle raised, GPU did not", str(oe), e.tokens))
+                except abi.LlkvError:
+                    pass
+                continue
+            try:
+                gotg = rt.groupby(hg, None, [7], aggs, True)
+            except abi.LlkvError as ge:
+                if ge.kind != "Unsupported": bad.append((seed, k, "grouped: GPU raised", str(ge), e.tokens))
+                continue
+            if [[x.value for x in r.keys] for r in gotg] != [[x.value for x in r.keys] for r in wantg]:
+                bad.append((seed, k, "grouped: keys differ", e.tokens))
+                continue
+            for rg, rw in zip(gotg, wantg):
+                for g, w in zip(rg.values, rw.values):
+                    gv, wv = g.value, w.value
+                    ok = g.dtype == w.dtype and ((gv is None and wv is None) or (isinstance(wv, float) and isinstance(gv, float) and ((gv != gv and wv != wv) or abs(gv - wv) <= 1e-9 * max(1.0, abs(wv)))) or gv == wv)
+                    if not ok: bad.append((seed, k, "grouped: values differ", (g.dtype, gv), (w.dtype, wv), e.tokens))
     return bad
 
 
