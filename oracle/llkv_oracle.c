@@ -1034,7 +1034,32 @@ static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *row
       if (j == n_fields) { if (n_fields == 64) return fail(LLKV_INTERNAL, "too many fields"); fields[n_fields++] = e[i].field_id; }
     }
   }
-  if (n_fields == 0) return fail(LLKV_UNSUPPORTED, "constant comparison");
+  if (n_fields == 0) {
+    /* no field at all (:354-360; domain :791-796): evaluate_constant_compare :887-907 — both sides evaluated once (evaluate_value over
+     * an empty array map: a literal is literal_to_array, literal arithmetic compute_binary, i.e. what simplify folds), compared by
+     * compute_compare in their common type.  Some(true) → every row of the table; Some(false) → none; both determined everywhere;
+     * None (a NULL side) → nothing matched, nothing determined.  Restated for sides that fold to one numeric or NULL literal. */
+    llkv_expr_token fl[64], fr[64];
+    uint32_t nl = 0, nr = 0;
+    if (f->cmp_left_len > 64 || f->cmp_right_len > 64) return fail(LLKV_INTERNAL, "expression too long");
+    int32_t frc = simplify_tokens(l, f->cmp_left_len, fl, &nl);
+    if (frc == LLKV_OK) frc = simplify_tokens(r, f->cmp_right_len, fr, &nr);
+    if (frc) return frc;
+    if (nl != 1 || nr != 1 || !is_numeric_literal_token(&fl[0]) || !is_numeric_literal_token(&fr[0]))
+      return fail(LLKV_UNSUPPORTED, "constant comparison over sides that do not fold to a numeric literal");
+    const llkv_literal *a = &fl[0].literal, *b = &fr[0].literal;
+    idvec hit = {0}, all = {0};
+    if (a->tag == LLKV_LIT_NULL || b->tag == LLKV_LIT_NULL) { *rows = hit; *dom = all; return LLKV_OK; } /* (both empty) */
+    int m;
+    if (a->tag == LLKV_LIT_FLOAT64 || b->tag == LLKV_LIT_FLOAT64) {
+      const double x = a->tag == LLKV_LIT_FLOAT64 ? a->f64 : (double)(int64_t)lit_i128(a), y = b->tag == LLKV_LIT_FLOAT64 ? b->f64 : (double)(int64_t)lit_i128(b);
+      m = rel_i(f->cmp_op, total_order_key(x), total_order_key(y));
+    } else m = rel_i(f->cmp_op, (int64_t)lit_i128(a), (int64_t)lit_i128(b));
+    for (uint64_t i = 0; i < t->rows; ++i) { idv_push(&all, i); if (m) idv_push(&hit, i); }
+    *rows = hit; /* (every row when the compare holds) */
+    *dom = all;
+    return LLKV_OK;
+  }
   idvec d = {0};
   for (uint32_t j = 0; j < n_fields; ++j) {
     idvec nn;
@@ -1045,6 +1070,9 @@ static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *row
   }
   idvec matched = {0}, determined = {0};
   int32_t rc = LLKV_OK;
+  /* a side that IS the NULL literal: literal_to_array gives a NullArray, coerce_types casts it to the other side's type — all NULL:
+   * the compare is NULL on every row (nothing matched, nothing determined), the other side is still evaluated (its errors count) */
+  const int l_null = l_lit && l[0].literal.tag == LLKV_LIT_NULL, r_null = r_lit && r[0].literal.tag == LLKV_LIT_NULL;
   /* 4096-row chunks of the domain (CHUNK_SIZE), each gathered and evaluated on its own */
   for (uint64_t c0 = 0; c0 < d.n && rc == LLKV_OK; c0 += 4096) {
     const uint64_t n = d.n - c0 < 4096 ? d.n - c0 : 4096;
@@ -1052,6 +1080,13 @@ static int32_t compare_rows(const orc_table *t, const llkv_filter *f, idvec *row
     for (uint32_t j = 0; j < n_fields; ++j) { g[j].field_id = fields[j]; g[j].a = gather_column(find_col(t, fields[j]), d.v + c0, n); }
     arr la, ra;
     memset(&la, 0, sizeof la); memset(&ra, 0, sizeof ra);
+    if (l_null || r_null) {
+      if (!l_null) rc = compare_side(t, l, f->cmp_left_len, g, n_fields, d.v + c0, n, &la);
+      if (!r_null) rc = compare_side(t, r, f->cmp_right_len, g, n_fields, d.v + c0, n, &ra);
+      arr_free(&la); arr_free(&ra);
+      for (uint32_t j = 0; j < n_fields; ++j) arr_free(&g[j].a);
+      continue;
+    }
     rc = compare_side(t, l, f->cmp_left_len, g, n_fields, d.v + c0, n, &la);
     if (rc == LLKV_OK) rc = compare_side(t, r, f->cmp_right_len, g, n_fields, d.v + c0, n, &ra);
     if (rc == LLKV_OK) {

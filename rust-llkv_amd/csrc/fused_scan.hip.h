@@ -545,6 +545,19 @@ template <int OP, class L, class R, class V = AlwaysValid> struct Cmp {
     return v & m;
   }
 };
+// A compare whose other side is the NULL literal matches nothing and determines nothing, but the side that is there is still
+// evaluated over the rows where its fields are present (evaluate_compare_rows, llkv-scan/src/predicate.rs:562-663): its checked
+// arithmetic can fail the scan.
+template <class E, class V = AlwaysValid> struct ErrOnly {
+  static __device__ __forceinline__ bool eval(Ctx &c, int j) {
+    const uint32_t outer = c.err;
+    c.err = 0;
+    (void)E::eval(c, j);
+    c.perr |= V::eval(c, j) ? c.err : 0u;
+    c.err = outer;
+    return false;
+  }
+};
 // MVCC visibility of a row version (llkv-transaction/src/mvcc.rs:283-333), fused into the scan instead of
 // the reference's per-row gather of `_created_by` / `_deleted_by` (helpers.rs:205-244).  UN… = txn ids whose
 // status is not Committed; TXN_ID_NONE = u64::MAX has status None; TXN_ID_AUTO_COMMIT = 1 is never "current".

@@ -744,7 +744,10 @@ struct Lowering {
       }
       case LLKV_EVAL_NOT:
         if (st.empty()) return fail(LLKV_INTERNAL, "predicate stack underflow");
-        st.back().rows = st.back().dom == "True" ? "Not<" + st.back().rows + ">" : "And<" + st.back().dom + ",Not<" + st.back().rows + ">>";
+        if (st.back().dom == "False") st.back().rows = "False"; // (determined nowhere: NOT of it holds nowhere)
+        else if (st.back().rows == "False") st.back().rows = st.back().dom; // NOT FALSE = where it is determined
+        else if (st.back().rows == "True" && st.back().dom == "True") st.back().rows = "False";
+        else st.back().rows = st.back().dom == "True" ? "Not<" + st.back().rows + ">" : "And<" + st.back().dom + ",Not<" + st.back().rows + ">>";
         break;
       default: return fail(LLKV_INTERNAL, "unknown predicate opcode");
       }
@@ -902,10 +905,53 @@ struct Lowering {
     bool any_col = false;
     for (uint32_t i = 0; i < f.cmp_left_len; ++i) any_col |= l[i].kind == LLKV_TOK_COLUMN;
     for (uint32_t i = 0; i < f.cmp_right_len; ++i) any_col |= r[i].kind == LLKV_TOK_COLUMN;
-    if (!any_col) return fail(LLKV_UNSUPPORTED, "constant comparison");
+    int rc;
+    if (!any_col) {
+      // no field at all (predicate.rs:354-360, :791-796): evaluate_constant_compare — both sides are evaluated once, compared in their
+      // common type; TRUE selects every row of the table, FALSE none (both are "determined" everywhere), NULL selects and determines
+      // nothing.  Restated for sides that fold to one numeric or NULL literal (what `simplify` leaves of literal arithmetic).
+      std::vector<llkv_expr_token> fl, fr;
+      if ((rc = fold_constants(l, f.cmp_left_len, &fl)) || (rc = fold_constants(r, f.cmp_right_len, &fr))) return rc;
+      auto one_lit = [](const std::vector<llkv_expr_token> &v) {
+        return v.size() == 1 && v[0].kind == LLKV_TOK_LITERAL && (v[0].literal.tag == LLKV_LIT_INT128 || v[0].literal.tag == LLKV_LIT_FLOAT64 || v[0].literal.tag == LLKV_LIT_NULL);
+      };
+      if (!one_lit(fl) || !one_lit(fr)) return fail(LLKV_UNSUPPORTED, "constant comparison over sides that do not fold to a numeric literal");
+      const llkv_literal &a = fl[0].literal, &b = fr[0].literal;
+      if (a.tag == LLKV_LIT_NULL || b.tag == LLKV_LIT_NULL) { *out = "False"; *dom = "False"; return LLKV_OK; }
+      bool m;
+      auto rel = [&](auto x, auto y) { return f.cmp_op == LLKV_CMP_EQ ? x == y : f.cmp_op == LLKV_CMP_NOT_EQ ? x != y : f.cmp_op == LLKV_CMP_LT ? x < y : f.cmp_op == LLKV_CMP_LT_EQ ? x <= y : f.cmp_op == LLKV_CMP_GT ? x > y : x >= y; };
+      if (a.tag == LLKV_LIT_FLOAT64 || b.tag == LLKV_LIT_FLOAT64) { // Float64 by totalOrder
+        auto key = [](double v) { int64_t k; std::memcpy(&k, &v, 8); return k ^ (int64_t)((uint64_t)(k >> 63) >> 1); };
+        const double x = a.tag == LLKV_LIT_FLOAT64 ? a.f64 : (double)(int64_t)lit_i128(a), y = b.tag == LLKV_LIT_FLOAT64 ? b.f64 : (double)(int64_t)lit_i128(b);
+        m = rel(key(x), key(y));
+      } else m = rel((int64_t)lit_i128(a), (int64_t)lit_i128(b)); // (literal_to_array: `*v as i64`)
+      *out = m ? "True" : "False";
+      *dom = "True";
+      return LLKV_OK;
+    }
+    {
+      // one side is the NULL literal itself: the compare is NULL on every row — nothing matches, nothing is determined — but the other
+      // side is evaluated over the rows where its fields are present, and its checked arithmetic can fail the scan
+      const bool l_null = f.cmp_left_len == 1 && l[0].kind == LLKV_TOK_LITERAL && l[0].literal.tag == LLKV_LIT_NULL;
+      const bool r_null = f.cmp_right_len == 1 && r[0].kind == LLKV_TOK_LITERAL && r[0].literal.tag == LLKV_LIT_NULL;
+      if (l_null || r_null) {
+        const llkv_expr_token *e = l_null ? r : l;
+        const uint32_t en = l_null ? f.cmp_right_len : f.cmp_left_len;
+        *dom = "False";
+        if (en == 1) { *out = "False"; return LLKV_OK; } // (a bare column: nothing to evaluate)
+        std::string node;
+        Side cls;
+        if ((rc = expr_side(e, en, &node, &cls))) return rc;
+        std::vector<std::string> vs;
+        if ((rc = valid_of_expr(e, en, &vs))) return rc;
+        if (has_division(e, en)) vs.push_back("VE<" + node + ">");
+        const std::string v = all_of(vs);
+        *out = "ErrOnly<" + node + (v.empty() ? "" : "," + v) + ">";
+        return LLKV_OK;
+      }
+    }
     std::string ln, rn;
     Side lc, rc_;
-    int rc;
     if ((rc = expr_side(l, f.cmp_left_len, &ln, &lc)) || (rc = expr_side(r, f.cmp_right_len, &rn, &rc_))) return rc;
     // get_common_type (llkv-compute/src/kernels.rs:179-242) of the two sides
     const auto is_unsigned = [](Side s) { return s == Side::U32 || s == Side::U64; };

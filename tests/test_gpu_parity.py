@@ -608,6 +608,49 @@ def test_scan_stream_and_row_ids_match_oracle(rt, orc, abi, chunks):
 
 
 @pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5]])
+def test_compares_with_the_null_literal_and_without_a_column(rt, orc, abi, chunks):
+    """Expr::Compare where one side IS the NULL literal (`x = NULL`: literal_to_array gives a NullArray, coerce_types casts it to the
+    other side's type — the compare is NULL on every row: nothing matches, nothing is determined, NOT of it holds nowhere either; the
+    other side is still evaluated and its checked arithmetic can fail the scan) and where no side names a field
+    (evaluate_constant_compare, llkv-scan/src/predicate.rs:887-907: TRUE keeps every row of the table, FALSE none, a NULL side
+    determines nothing) — alone, negated, and inside AND / OR trees with ordinary leaves."""
+    rng = np.random.default_rng(41 + len(chunks))
+    n = sum(chunks)
+    a = rng.integers(-50, 50, size=n).astype(np.int64)
+    b = rng.normal(size=n)
+    va = rng.random(n) > 0.2
+    ht, ot = stage_both(rt, orc, abi, [(1, abi.DT_INT64, a, va), (2, abi.DT_FLOAT64, b)], chunks)
+    E, F, O, col, A = abi.Expr, abi.Filter, abi.Operator, abi.col, abi.AggregateSpec
+    L = abi.ScalarExpr.literal
+    NULL = L(abi.Literal.of(None))
+    leaf = E.pred(F(1, O.GreaterThan(0)))
+    atoms = [E.compare(col(1), abi.CMP_EQ, NULL), E.compare(NULL, abi.CMP_LT, col(2)), E.compare(col(1) * 3 + 1, abi.CMP_NOT_EQ, NULL),
+             E.compare(L(1) + 2, abi.CMP_LT, 4), E.compare(L(5), abi.CMP_LT, 4.5), E.compare(L(2.5) * 2, abi.CMP_EQ, 5), E.compare(NULL, abi.CMP_EQ, 1),
+             E.compare(L(1) - 1, abi.CMP_GT_EQ, L(0) * 7)]
+    preds = []
+    for x in atoms:
+        preds += [x, E.not_(x), E.all_of([leaf, x]), E.any_of([leaf, E.not_(x)]), E.not_(E.any_of([x, leaf]))]
+    for p in preds:
+        assert np.array_equal(rt.filter_row_ids(ht, p), orc.filter_row_ids(ot, p))
+        assert_values(rt.aggregate(ht, p, [A.count_star(), A.sum(1), A.min(2)]), orc.aggregate(ot, p, [A.count_star(), A.sum(1), A.min(2)]))
+    assert len(orc.filter_row_ids(ot, atoms[3])) == n and len(orc.filter_row_ids(ot, atoms[0])) == 0
+    # the side beside the NULL literal is evaluated: its overflow fails the scan on both sides
+    big = a.copy()
+    big[n // 2] = 2**62
+    hb, ob = stage_both(rt, orc, abi, [(1, abi.DT_INT64, big)], chunks)
+    for m, t in ((rt, hb), (orc, ob)):
+        with pytest.raises(abi.LlkvError) as e:
+            m.filter_row_ids(t, E.compare(col(1) * 4, abi.CMP_GT, NULL))
+        assert e.value.kind == "Internal" and "overflow" in e.value.message.lower(), m
+    # what stays refused: a NULL literal inside a side's arithmetic; constant sides that do not fold to a literal
+    for bad in (E.compare(col(1) + NULL, abi.CMP_LT, 4), E.compare(L(1) % 0, abi.CMP_LT, 4)):
+        for m, t in ((rt, ht), (orc, ot)):
+            with pytest.raises(abi.LlkvError) as e:
+                m.filter_row_ids(t, bad)
+            assert e.value.kind == "Unsupported", (m, bad)
+
+
+@pytest.mark.parametrize("chunks", [[11], [4096, 4097, 5]])
 def test_int32_only_arithmetic_runs_on_the_checked_32_bit_kernels(rt, orc, abi, chunks):
     """An expression whose every leaf is an Int32 (UInt32) column has that ROOT type (get_common_type, llkv-compute/src/kernels.rs:
     179-242: same ⊕ same → same) and the fast path runs arrow's checked 32-bit kernels over it (fast_numeric.rs:333-355): an Int32 /

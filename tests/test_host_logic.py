@@ -319,8 +319,15 @@ def test_compare_lowering_follows_the_common_type_rules(lib, abi):
     # Int32-only arithmetic stays Int32: every node checked against 32 bits, the side compares as an Int32 does
     assert "Cmp<3,Fit32<Bin<1,ToI64<Col<0,I32>>,ToI64<Col<0,I32>>>,1>,Col<1,I64>>" in rt.lower_plan(d, E.compare(col(3) + col(3), abi.CMP_LT, col(1)), cnt)[0]
     assert "Cmp<3,ToF64<Fit32<Bin<3,ToI64<Col<0,U32>>,ToI64<Col<0,U32>>>,0>>,ToF64<Col<1,I64>>>" in rt.lower_plan(d, E.compare(col(5) * col(5), abi.CMP_LT, col(1)), cnt)[0]
-    for bad in (E.compare(abi.ScalarExpr.literal(1) + 2, abi.CMP_LT, 4),  # constant compare
-                E.compare(col(1), abi.CMP_NOT_EQ, abi.ScalarExpr.literal(abi.Literal.of(None)))):
+    # no field at all: evaluate_constant_compare — TRUE keeps every row, FALSE / NULL none (r04)
+    L, NULL = abi.ScalarExpr.literal, abi.ScalarExpr.literal(abi.Literal.of(None))
+    assert ",True," in rt.lower_plan(d, E.compare(L(1) + 2, abi.CMP_LT, 4), cnt)[0]
+    assert ",False," in rt.lower_plan(d, E.compare(L(1) + 2, abi.CMP_GT, 4.5), cnt)[0]
+    assert ",False," in rt.lower_plan(d, E.not_(E.compare(NULL, abi.CMP_EQ, 1)), cnt)[0]
+    # a side that IS the NULL literal: nothing matches, nothing is determined — but the other side's arithmetic is still evaluated
+    assert ",False," in rt.lower_plan(d, E.compare(col(1), abi.CMP_NOT_EQ, NULL), cnt)[0]
+    assert "ErrOnly<Bin<3,Col<0,I64>,LitI<0>>>" in rt.lower_plan(d, E.compare(col(1) * 3, abi.CMP_GT, NULL), cnt)[0]
+    for bad in (E.compare(col(1) + NULL, abi.CMP_LT, 4),):  # a NULL literal inside a side's arithmetic
         with pytest.raises(abi.LlkvError) as e:
             rt.lower_plan(d, bad, cnt)
         assert e.value.kind == "Unsupported"
