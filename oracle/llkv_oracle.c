@@ -1138,12 +1138,47 @@ static int dtype_mode(int32_t a, int32_t b) { /* 0 = Float64, 1 = signed, 2 = un
 /* evaluate_in_list_over_rows llkv-scan/src/predicate.rs:443-560: rows where every referenced field is present;
  * the target is re-coerced with every item (`target_array = new_target`), `eq` per item (floats by totalOrder),
  * or_kleene over the items, `not` when negated; a NULL result is neither matched nor determined. */
+/* A side without a field, as evaluate_value leaves it: one numeric or NULL literal (what simplify folds literal arithmetic to). */
+static int32_t constant_side(const llkv_expr_token *e, uint32_t n, llkv_literal *out) {
+  llkv_expr_token fl[64];
+  uint32_t m = 0;
+  if (n > 64) return fail(LLKV_INTERNAL, "expression too long");
+  int32_t rc = simplify_tokens(e, n, fl, &m);
+  if (rc) return rc;
+  if (m != 1 || !is_numeric_literal_token(&fl[0])) return fail(LLKV_UNSUPPORTED, "constant predicate over a side that does not fold to a numeric literal");
+  *out = fl[0].literal;
+  return LLKV_OK;
+}
+static void all_rows_of(const orc_table *t, idvec *v) { for (uint64_t i = 0; i < t->rows; ++i) idv_push(v, i); }
+
 static int32_t in_list_rows(const orc_table *t, const llkv_filter *f, idvec *rows, idvec *dom) {
   if (!f->cmp_left || !f->cmp_left_len) return fail(LLKV_INVALID_ARGUMENT, "IN list needs a target expression");
   uint32_t fields[64], n_fields = 0;
   collect_expr_fields(f->cmp_left, f->cmp_left_len, fields, &n_fields);
   for (uint32_t k = 0; k < f->list_len; ++k) collect_expr_fields(f->list_exprs[k], f->list_expr_lens[k], fields, &n_fields);
-  if (n_fields == 0) return fail(LLKV_UNSUPPORTED, "constant IN list");
+  if (n_fields == 0) {
+    /* evaluate_constant_in_list :909-963 (rows) and collect_in_list_domain_rows :832-836 (its second result): a NULL target matches and
+     * determines nothing; the first item equal to the target decides (Some(!negated)); else a NULL item leaves it None; else Some(negated) */
+    llkv_literal tgt, item;
+    idvec hit = {0}, all = {0};
+    int32_t crc = constant_side(f->cmp_left, f->cmp_left_len, &tgt);
+    if (crc) return crc;
+    if (tgt.tag == LLKV_LIT_NULL) { *rows = hit; *dom = all; return LLKV_OK; }
+    int matched = 0, saw_null = 0;
+    for (uint32_t k = 0; k < f->list_len && !matched; ++k) {
+      if ((crc = constant_side(f->list_exprs[k], f->list_expr_lens[k], &item))) return crc;
+      if (item.tag == LLKV_LIT_NULL) { saw_null = 1; continue; }
+      if (tgt.tag == LLKV_LIT_FLOAT64 || item.tag == LLKV_LIT_FLOAT64) {
+        const double x = tgt.tag == LLKV_LIT_FLOAT64 ? tgt.f64 : (double)(int64_t)lit_i128(&tgt), y = item.tag == LLKV_LIT_FLOAT64 ? item.f64 : (double)(int64_t)lit_i128(&item);
+        matched = total_order_key(x) == total_order_key(y);
+      } else matched = (int64_t)lit_i128(&tgt) == (int64_t)lit_i128(&item);
+    }
+    if (!matched && saw_null) { *rows = hit; *dom = all; return LLKV_OK; }
+    all_rows_of(t, &all);
+    if (matched ? !f->negated : f->negated) all_rows_of(t, &hit);
+    *rows = hit; *dom = all;
+    return LLKV_OK;
+  }
   idvec d = {0};
   for (uint32_t j = 0; j < n_fields; ++j) {
     idvec nn;
@@ -1218,7 +1253,16 @@ static int32_t is_null_expr_rows(const orc_table *t, const llkv_filter *f, idvec
   }
   uint32_t fields[64], n_fields = 0;
   collect_expr_fields(f->cmp_left, f->cmp_left_len, fields, &n_fields);
-  if (n_fields == 0) return fail(LLKV_UNSUPPORTED, "constant IS NULL");
+  if (n_fields == 0) { /* :276-284: the constant is NULL or not — every row of the table or none; determined everywhere (:746-749) */
+    llkv_literal v;
+    int32_t crc = constant_side(f->cmp_left, f->cmp_left_len, &v);
+    if (crc) return crc;
+    idvec hit = {0}, all = {0};
+    all_rows_of(t, &all);
+    if ((v.tag == LLKV_LIT_NULL) != (f->negated != 0)) all_rows_of(t, &hit);
+    *rows = hit; *dom = all;
+    return LLKV_OK;
+  }
   idvec uni = {0}, inter = {0};
   for (uint32_t j = 0; j < n_fields; ++j) {
     idvec nn;

@@ -744,7 +744,7 @@ struct Lowering {
       }
       case LLKV_EVAL_NOT:
         if (st.empty()) return fail(LLKV_INTERNAL, "predicate stack underflow");
-        if (st.back().dom == "False") st.back().rows = "False"; // (determined nowhere: NOT of it holds nowhere)
+        if (st.back().dom == "False") { if (st.back().rows == "True") st.back().rows = "False"; } // determined nowhere: NOT of it holds nowhere — and neither does it (matched ⊆ determined), so it stays as it is: what it evaluates (ErrOnly) still counts
         else if (st.back().rows == "False") st.back().rows = st.back().dom; // NOT FALSE = where it is determined
         else if (st.back().rows == "True" && st.back().dom == "True") st.back().rows = "False";
         else st.back().rows = st.back().dom == "True" ? "Not<" + st.back().rows + ">" : "And<" + st.back().dom + ",Not<" + st.back().rows + ">>";
@@ -809,6 +809,24 @@ struct Lowering {
   // arrow `cast` of a side node to the common type (the integer classes share an i64 / u64 image already)
   static std::string cast_side(const std::string &node, Side from, Side to) { return (to == Side::F && from != Side::F) ? "ToF64<" + node + ">" : node; }
 
+  // A side without a column, as evaluate_value leaves it: one numeric or NULL literal (what `simplify` folds literal arithmetic to)
+  int constant_side(const llkv_expr_token *e, uint32_t n, llkv_literal *out) {
+    std::vector<llkv_expr_token> fl;
+    int rc = fold_constants(e, n, &fl);
+    if (rc) return rc;
+    if (fl.size() != 1 || fl[0].kind != LLKV_TOK_LITERAL || (fl[0].literal.tag != LLKV_LIT_INT128 && fl[0].literal.tag != LLKV_LIT_FLOAT64 && fl[0].literal.tag != LLKV_LIT_NULL))
+      return fail(LLKV_UNSUPPORTED, "constant predicate over a side that does not fold to a numeric literal");
+    *out = fl[0].literal;
+    return LLKV_OK;
+  }
+  static bool constants_equal(const llkv_literal &a, const llkv_literal &b) { // arrow `eq` in the common type (floats by totalOrder)
+    if (a.tag == LLKV_LIT_FLOAT64 || b.tag == LLKV_LIT_FLOAT64) {
+      const double x = a.tag == LLKV_LIT_FLOAT64 ? a.f64 : (double)(int64_t)lit_i128(a), y = b.tag == LLKV_LIT_FLOAT64 ? b.f64 : (double)(int64_t)lit_i128(b);
+      return std::memcmp(&x, &y, 8) == 0;
+    }
+    return (int64_t)lit_i128(a) == (int64_t)lit_i128(b);
+  }
+
   // Expr::InList (evaluate_in_list_over_rows, llkv-scan/src/predicate.rs:443-560): the target is coerced item by
   // item — its type can only widen along the list — and compared with `eq`; over rows where all fields are present
   // nothing is NULL, so or_kleene / not are plain OR / NOT.
@@ -821,7 +839,24 @@ struct Lowering {
       div |= has_division(f.list_exprs[k], f.list_expr_lens[k]);
       for (uint32_t i = 0; i < f.list_expr_lens[k]; ++i) any_col |= f.list_exprs[k][i].kind == LLKV_TOK_COLUMN;
     }
-    if (!any_col) return fail(LLKV_UNSUPPORTED, "constant IN list");
+    if (!any_col) {
+      // evaluate_constant_in_list (:909-963): a NULL target matches and determines nothing; a matching item decides (→ !negated);
+      // else a NULL item leaves it NULL; else `negated`.  TRUE keeps every row, FALSE none, both determined everywhere.
+      llkv_literal tgt, item;
+      int rc;
+      if ((rc = constant_side(f.cmp_left, f.cmp_left_len, &tgt))) return rc;
+      if (tgt.tag == LLKV_LIT_NULL) { *out = "False"; *dom = "False"; return LLKV_OK; }
+      bool matched = false, saw_null = false;
+      for (uint32_t k = 0; k < f.list_len && !matched; ++k) {
+        if ((rc = constant_side(f.list_exprs[k], f.list_expr_lens[k], &item))) return rc;
+        if (item.tag == LLKV_LIT_NULL) { saw_null = true; continue; }
+        matched = constants_equal(tgt, item);
+      }
+      if (!matched && saw_null) { *out = "False"; *dom = "False"; return LLKV_OK; }
+      *out = (matched ? !f.negated : (bool)f.negated) ? "True" : "False";
+      *dom = "True";
+      return LLKV_OK;
+    }
     if (div) return fail(LLKV_UNSUPPORTED, "division inside an IN list (three-valued OR over NULL items)");
     std::string tn;
     Side tc;
@@ -867,7 +902,13 @@ struct Lowering {
       if (v.empty()) some_never_null = true;
       else if (std::find(vs.begin(), vs.end(), v) == vs.end()) vs.push_back(v);
     }
-    if (!any_col) return fail(LLKV_UNSUPPORTED, "constant IS NULL");
+    if (!any_col) { // (:276-284) the value is NULL or it is not; every row of the table or none, determined everywhere (:746-749)
+      llkv_literal v;
+      if ((rc = constant_side(f.cmp_left, f.cmp_left_len, &v))) return rc;
+      *out = ((v.tag == LLKV_LIT_NULL) != (bool)f.negated) ? "True" : "False";
+      *dom = "True";
+      return LLKV_OK;
+    }
     std::string node;
     bool is_f64 = false;
     if ((rc = expr_fast(f.cmp_left, f.cmp_left_len, &node, &is_f64))) return rc;

@@ -400,7 +400,11 @@ def test_in_list_and_is_null_expression_lowering(lib, abi):
     assert ",Not<VE<Bin<1,ColN<1,I64,0>,Col<2,I64>>>>,Keys" in ts
     ts = rt.lower_plan(d, E.is_null(col(3) / col(3), negated=True), cnt)[0]
     assert ",VE<Div<Col<0,I64>,Col<0,I64>>>,Keys" in ts
-    for bad in (E.in_list(abi.ScalarExpr.literal(3), [1, 2]), E.in_list(col(3), [col(3) / 2]), E.is_null(abi.ScalarExpr.literal(1) + 2)):
+    # without a column (r04): decided on the host — every row of the table or none
+    Lit = abi.ScalarExpr.literal
+    assert ",False," in rt.lower_plan(d, E.in_list(Lit(3), [1, 2]), cnt)[0] and ",True," in rt.lower_plan(d, E.in_list(Lit(3), [1, Lit(1) + 2]), cnt)[0]
+    assert ",False," in rt.lower_plan(d, E.is_null(Lit(1) + 2), cnt)[0] and ",True," in rt.lower_plan(d, E.is_null(Lit(1) + 2, negated=True), cnt)[0]
+    for bad in (E.in_list(col(3), [col(3) / 2]),):
         with pytest.raises(abi.LlkvError) as e:
             rt.lower_plan(d, bad, cnt)
         assert e.value.kind == "Unsupported"
