@@ -229,7 +229,8 @@ typedef enum llkv_aggregate_kind {
 typedef struct llkv_aggregate_spec {
   int32_t kind;     /* llkv_aggregate_kind                                   */
   int32_t distinct; /* DISTINCT forms of COUNT / SUM / TOTAL / AVG (MIN / MAX ignore it): ungrouped, and inside GROUP BY over ONE
-                     * bare column (sort-based route); LLKV_UNSUPPORTED otherwise */
+                     * argument — a bare column or a computed Int64 / Float64 expression — on the sort-based route of an unsharded
+                     * table; LLKV_UNSUPPORTED otherwise */
   const llkv_expr_token *expr; /* NULL for COUNT(*)                          */
   uint32_t expr_len;
   const char *alias;
