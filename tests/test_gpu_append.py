@@ -118,3 +118,63 @@ def test_append_grows_dictionaries_validity_decimals_and_row_ids(rt, orc, abi):
     got = rt.scan_stream(t, [4, 2, 5], [F(1, O.Equals(3))], include_nulls=True)
     want = orc.scan_stream(ot, [4, 2, 5], [F(1, O.Equals(3))], include_nulls=True)
     assert got == want
+
+
+def test_key_images_are_dropped_by_an_append_and_built_again(rt, abi, tpch, monkeypatch):
+    """The join pipeline's 4-byte key images (KeyImage, csrc/engine.hpp) belong to a generation of the table: an append drops them
+    (the column may have moved, its statistics have changed — a new key may no longer fit 32 bits) and the next join builds them over
+    the grown image.  Q3's star over tables staged without their last chunks, then grown: the top ten before and after equal what
+    numpy computes from the same rows; an order key beyond 32 bits arriving with an append turns the image off for that column."""
+    monkeypatch.setenv("LLKV_HIP_KEY_IMAGE_MIN_ROWS", "1")
+    rows, scale = 120_000, 0.02
+    li = tpch.gen_lineitem(rows, scale, ["l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"])
+    n_ord = tpch.orders_for_lineitems(rows)
+    od = tpch.gen_orders(n_ord, scale)
+    D = tpch.DATE_1995_03_15
+    F, O, col = abi.Filter, abi.Operator, abi.col
+    rev = col(tpch.L_EXTENDEDPRICE) * (1 - col(tpch.L_DISCOUNT))
+
+    def expected(n_li, n_or, okeys=None):
+        okey = od["o_orderkey"][:n_or] if okeys is None else okeys
+        ok = od["o_orderdate"][:n_or] < D
+        sums, counts = {}, {}
+        keep = dict(zip(okey[ok].tolist(), np.flatnonzero(ok).tolist()))
+        lk, ls = li["l_orderkey"][:n_li], li["l_shipdate"][:n_li]
+        val = li["l_extendedprice"][:n_li] * (1 - li["l_discount"][:n_li])
+        for i in np.flatnonzero(ls > D).tolist():
+            k = int(lk[i])
+            if k in keep:
+                sums[k] = sums.get(k, 0.0) + float(val[i])  # row order: the pipeline adds an order's rows left to right
+                counts[k] = counts.get(k, 0) + 1
+        order = sorted(sums, key=lambda k: (-sums[k], int(od["o_orderdate"][keep[k]]), keep[k]))[:10]
+        return [(k, sums[k], counts[k], int(od["o_orderdate"][keep[k]])) for k in order], len(sums)
+
+    def run(lt, ot_):
+        got, total = rt.join_groupby_topk(lt, [F(tpch.L_SHIPDATE, O.GreaterThan(D))], tpch.L_ORDERKEY, ot_, [F(tpch.O_ORDERDATE, O.LessThan(D))], tpch.O_ORDERKEY, rev,
+                                          payload_fields=[tpch.O_ORDERDATE], limit=10)
+        return [(g[0], g[1], g[2], g[3]) for g in got], total
+
+    li_chunks, or_chunks = tpch.chunk_rows(rows, 16384), tpch.chunk_rows(n_ord, 8192)
+    li_head, or_head = sum(li_chunks[:-2]), sum(or_chunks[:-1])
+    lt = rt.HipTable(1, li_chunks[:-2])
+    for c in li:
+        lt.append_column(tpch.LINEITEM_SCHEMA[c][0], tpch.LINEITEM_SCHEMA[c][1], li[c][:li_head])
+    ot_ = rt.HipTable(2, or_chunks[:-1])
+    for c, (fid, dt) in tpch.ORDERS_SCHEMA.items():
+        ot_.append_column(fid, dt, od[c][:or_head])
+    assert run(lt, ot_) == expected(li_head, or_head)
+    assert lt.key_images()[0] == 1 and ot_.key_images()[0] == 1
+    lt.append_chunks(li_chunks[-2:], {tpch.LINEITEM_SCHEMA[c][0]: li[c][li_head:] for c in li})
+    ot_.append_chunks(or_chunks[-1:], {fid: od[c][or_head:] for c, (fid, dt) in tpch.ORDERS_SCHEMA.items()})
+    assert lt.key_images() == (0, 0) and ot_.key_images() == (0, 0)  # a new generation: the images went with the old one
+    assert run(lt, ot_) == expected(rows, n_ord)
+    assert lt.key_images()[0] == 1 and ot_.key_images()[0] == 1
+    # an order whose key does not fit 32 bits arrives: the orders' key column is read as it is from now on (the lineitem image stays)
+    big = {fid: od[c][-3:].copy() for c, (fid, dt) in tpch.ORDERS_SCHEMA.items()}
+    big[tpch.O_ORDERKEY] = np.array([2**33 + 1, 2**33 + 5, 2**33 + 9], dtype=np.int64)
+    ot_.append_chunks([3], big)
+    keys = np.concatenate([od["o_orderkey"], big[tpch.O_ORDERKEY]])
+    got = run(lt, ot_)
+    assert ot_.key_images()[0] == 0 and lt.key_images()[0] == 1
+    want = expected(rows, n_ord)  # (no lineitem names the three new orders)
+    assert got == want and len(keys) == n_ord + 3
